@@ -1,0 +1,576 @@
+// raymarching.hip — occupancy-grid ray marching, morton codes, bit packing and volume
+// compositing for gfx950.  Replaces raymarching/src/raymarching.cu of the reference behind the
+// C ABI of include/seal3d_hip.h (per-function citations there).
+//
+// MI355X notes
+//  * One ray per lane, ONE WAVE PER WORKGROUP for the marching kernels: a 4,096-ray training
+//    batch is only 64 waves, so the kernels are latency-bound on the per-step bitfield probe;
+//    64-thread workgroups spread those waves over 64 CUs instead of 16.
+//  * Ray compaction: spans are reserved with a wave64 prefix sum (no per-ray atomics).  The
+//    count kernel leaves (local offset, count) per ray and one total per wave; the write
+//    kernel turns wave totals into the wave's base with a strided wave reduction.  The packing
+//    is therefore the RAY-ORDERED one — deterministic, bit-identical to the oracle.
+//  * Integer results (cell coordinates, morton rows, sample counts, span offsets) follow the
+//    oracle expression by expression: explicit fmaf, -ffp-contract=off, IEEE division.
+#include "s3d_common.hpp"
+
+namespace s3d {
+namespace {
+
+constexpr float kSqrt3 = 1.7320508075688772f;
+constexpr float kRPi = 0.3183098861837907f;
+
+__device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton3d(uint32_t x, uint32_t y, uint32_t z) {
+    return expand_bits(x) | (expand_bits(y) << 1) | (expand_bits(z) << 2);
+}
+__device__ __forceinline__ uint32_t morton3d_invert(uint32_t x) {
+    x = x & 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+// ---------------------------------------------------------------- small utilities
+__global__ void k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                           const float* __restrict__ aabb, uint32_t N, float min_near,
+                           float* __restrict__ nears, float* __restrict__ fars) {
+    const float a0 = aabb[0], a1 = aabb[1], a2 = aabb[2], a3 = aabb[3], a4 = aabb[4], a5 = aabb[5];
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+        const float rdx = 1 / rays_d[n * 3], rdy = 1 / rays_d[n * 3 + 1], rdz = 1 / rays_d[n * 3 + 2];
+        float near = (a0 - ox) * rdx, far = (a3 - ox) * rdx;
+        if (near > far) { float t = near; near = far; far = t; }
+        float near_y = (a1 - oy) * rdy, far_y = (a4 - oy) * rdy;
+        if (near_y > far_y) { float t = near_y; near_y = far_y; far_y = t; }
+        bool miss = (near > far_y || near_y > far);
+        if (!miss) {
+            if (near_y > near) near = near_y;
+            if (far_y < far) far = far_y;
+            float near_z = (a2 - oz) * rdz, far_z = (a5 - oz) * rdz;
+            if (near_z > far_z) { float t = near_z; near_z = far_z; far_z = t; }
+            miss = (near > far_z || near_z > far);
+            if (!miss) {
+                if (near_z > near) near = near_z;
+                if (far_z < far) far = far_z;
+                if (near < min_near) near = min_near;
+            }
+        }
+        nears[n] = miss ? 3.402823466e+38f : near;
+        fars[n] = miss ? 3.402823466e+38f : far;
+    }
+}
+
+__global__ void k_sph_from_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                               float radius, uint32_t N, float* __restrict__ coords) {
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+        const float dx = rays_d[n * 3], dy = rays_d[n * 3 + 1], dz = rays_d[n * 3 + 2];
+        const float A = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        const float B = __builtin_fmaf(oz, dz, __builtin_fmaf(oy, dy, ox * dx));
+        const float Cc = __builtin_fmaf(-radius, radius, __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox)));
+        const float t = (-B + sqrtf(__builtin_fmaf(B, B, -(A * Cc)))) / A;
+        const float x = __builtin_fmaf(t, dx, ox), y = __builtin_fmaf(t, dy, oy), z = __builtin_fmaf(t, dz, oz);
+        const float theta = atan2f(sqrtf(__builtin_fmaf(z, z, x * x)), y);
+        const float phi = atan2f(z, x);
+        coords[n * 2] = __builtin_fmaf(2 * theta, kRPi, -1.0f);
+        coords[n * 2 + 1] = phi * kRPi;
+    }
+}
+
+__global__ void k_morton3d(const int32_t* __restrict__ coords, uint32_t N, int32_t* __restrict__ indices) {
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x)
+        indices[n] = (int32_t)morton3d((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1], (uint32_t)coords[n * 3 + 2]);
+}
+
+__global__ void k_morton3d_invert(const int32_t* __restrict__ indices, uint32_t N, int32_t* __restrict__ coords) {
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const int32_t ind = indices[n];
+        coords[n * 3] = (int32_t)morton3d_invert((uint32_t)(ind >> 0));
+        coords[n * 3 + 1] = (int32_t)morton3d_invert((uint32_t)(ind >> 1));
+        coords[n * 3 + 2] = (int32_t)morton3d_invert((uint32_t)(ind >> 2));
+    }
+}
+
+// one lane = one output byte = 8 cells = two float4 loads (32 B/lane, 2 KiB contiguous per wave)
+__global__ void k_packbits(const float* __restrict__ grid, uint32_t N, float thresh, uint8_t* __restrict__ bitfield) {
+    const float4* g4 = reinterpret_cast<const float4*>(grid);
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        const float4 a = g4[n * 2], b = g4[n * 2 + 1];
+        uint32_t bits = 0;
+        bits |= (a.x > thresh) ? 1u : 0u;   bits |= (a.y > thresh) ? 2u : 0u;
+        bits |= (a.z > thresh) ? 4u : 0u;   bits |= (a.w > thresh) ? 8u : 0u;
+        bits |= (b.x > thresh) ? 16u : 0u;  bits |= (b.y > thresh) ? 32u : 0u;
+        bits |= (b.z > thresh) ? 64u : 0u;  bits |= (b.w > thresh) ? 128u : 0u;
+        bitfield[n] = (uint8_t)bits;
+    }
+}
+
+// ---------------------------------------------------------------- DDA core
+struct Ray {
+    float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
+};
+struct MarchParams {
+    float bound, dt_gamma, dt_min, dt_max, rH, H3, Cf, Hf, Hm1;
+    double Hd;
+    const uint8_t* grid;
+};
+
+__device__ __forceinline__ MarchParams make_params(float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                                                   uint32_t H, const uint8_t* grid) {
+    MarchParams p;
+    p.bound = bound; p.dt_gamma = dt_gamma;
+    p.dt_min = 2 * kSqrt3 / (float)max_steps;
+    p.dt_max = 2 * kSqrt3 * (float)(1 << (C - 1)) / (float)H;
+    p.rH = 1 / (float)H;
+    p.H3 = (float)(H * H * H);
+    p.Cf = (float)C; p.Hf = (float)H; p.Hm1 = (float)(H - 1); p.Hd = (double)H;
+    p.grid = grid;
+    return p;
+}
+
+__device__ __forceinline__ Ray load_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d, uint32_t n) {
+    Ray r;
+    r.ox = rays_o[n * 3]; r.oy = rays_o[n * 3 + 1]; r.oz = rays_o[n * 3 + 2];
+    r.dx = rays_d[n * 3]; r.dy = rays_d[n * 3 + 1]; r.dz = rays_d[n * 3 + 2];
+    r.rdx = 1 / r.dx; r.rdy = 1 / r.dy; r.rdz = 1 / r.dz;
+    return r;
+}
+
+__device__ __forceinline__ int mip_level(float x, float y, float z, float dt, const MarchParams& p) {
+    int e1, e2;
+    (void)frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e1);
+    const int la = (int)fminf(p.Cf - 1, fmaxf(0.0f, (float)e1));
+    (void)frexpf((float)((double)(dt * p.Hf) * 0.5), &e2);
+    const int lb = (int)fminf(p.Cf - 1, fmaxf(0.0f, (float)e2));
+    return la > lb ? la : lb;
+}
+
+// Probe the grid at parameter t.  Returns occupancy; x,y,z,dt always valid; t_skip valid when !occ.
+__device__ __forceinline__ bool probe(const Ray& r, const MarchParams& p, float t, float& x, float& y, float& z,
+                                      float& dt, float& t_skip) {
+    x = clampf(__builtin_fmaf(t, r.dx, r.ox), -p.bound, p.bound);
+    y = clampf(__builtin_fmaf(t, r.dy, r.oy), -p.bound, p.bound);
+    z = clampf(__builtin_fmaf(t, r.dz, r.oz), -p.bound, p.bound);
+    dt = clampf(t * p.dt_gamma, p.dt_min, p.dt_max);
+    const int level = mip_level(x, y, z, dt, p);
+    const float mip_bound = fminf(ldexpf(1.0f, level), p.bound);
+    const float mip_rbound = 1 / mip_bound;
+    const int nx = (int)clampf((float)(0.5 * (double)__builtin_fmaf(x, mip_rbound, 1.0f) * p.Hd), 0.0f, p.Hm1);
+    const int ny = (int)clampf((float)(0.5 * (double)__builtin_fmaf(y, mip_rbound, 1.0f) * p.Hd), 0.0f, p.Hm1);
+    const int nz = (int)clampf((float)(0.5 * (double)__builtin_fmaf(z, mip_rbound, 1.0f) * p.Hd), 0.0f, p.Hm1);
+    const uint32_t index = (uint32_t)((float)level * p.H3 + (float)morton3d((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+    const bool occ = (p.grid[index >> 3] & (1u << (index & 7u))) != 0;
+    if (!occ) {
+        const float sx = copysignf(1.0f, r.dx), sy = copysignf(1.0f, r.dy), sz = copysignf(1.0f, r.dz);
+        const float tx = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.5f, sx, (float)nx + 0.5f) * p.rH, 2.0f, -1.0f), mip_bound, -x) * r.rdx;
+        const float ty = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.5f, sy, (float)ny + 0.5f) * p.rH, 2.0f, -1.0f), mip_bound, -y) * r.rdy;
+        const float tz = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.5f, sz, (float)nz + 0.5f) * p.rH, 2.0f, -1.0f), mip_bound, -z) * r.rdz;
+        t_skip = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    }
+    return occ;
+}
+
+__device__ __forceinline__ float skip_to(const MarchParams& p, float t, float tt) {
+    do { t += clampf(t * p.dt_gamma, p.dt_min, p.dt_max); } while (t < tt);
+    return t;
+}
+
+// ---------------------------------------------------------------- march_rays_train
+// workspace: u32 base | u32 pad[3] | u32 wave_total[nw]
+constexpr uint32_t kWsHeader = 4;
+
+// pass 1: count + wave-local exclusive scan.  grid = ceil(N/64) workgroups of one wave.
+__global__ void __launch_bounds__(64) k_march_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                    const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                                    const float* __restrict__ nears, const float* __restrict__ fars,
+                                                    const float* __restrict__ noises, int32_t* __restrict__ rays,
+                                                    const int32_t* __restrict__ counter, uint32_t* __restrict__ ws) {
+    const uint32_t n = blockIdx.x * 64 + threadIdx.x;
+    uint32_t num_steps = 0;
+    if (n < N) {
+        const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
+        const Ray r = load_ray(rays_o, rays_d, n);
+        const float far = fars[n];
+        float t = nears[n];
+        t = __builtin_fmaf(clampf(t * dt_gamma, p.dt_min, p.dt_max), noises[n], t);
+        while (t < far && num_steps < max_steps) {
+            float x, y, z, dt, tt;
+            if (probe(r, p, t, x, y, z, dt, tt)) { num_steps++; t += dt; }
+            else t = skip_to(p, t, tt);
+        }
+    }
+    const uint32_t incl = wave_incl_scan(num_steps);
+    if (n < N) {
+        rays[n * 3] = (int32_t)n;
+        rays[n * 3 + 1] = (int32_t)(incl - num_steps);  // wave-local offset, rebased by pass 2
+        rays[n * 3 + 2] = (int32_t)num_steps;
+    }
+    if (threadIdx.x == 63) ws[kWsHeader + blockIdx.x] = incl;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ws[0] = (uint32_t)counter[0];
+}
+
+// pass 2: rebase spans, write samples.
+__global__ void __launch_bounds__(64) k_march_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                    const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                    const float* __restrict__ nears, const float* __restrict__ fars,
+                                                    const float* __restrict__ noises, float* __restrict__ xyzs,
+                                                    float* __restrict__ dirs, float* __restrict__ deltas,
+                                                    int32_t* __restrict__ rays, int32_t* __restrict__ counter,
+                                                    const uint32_t* __restrict__ ws) {
+    // wave base = counter value at entry + totals of all earlier waves (strided wave reduction)
+    uint32_t part = 0;
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 64) part += ws[kWsHeader + i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    const uint32_t base = ws[0] + part;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        counter[0] = (int32_t)(base + ws[kWsHeader + blockIdx.x]);
+        counter[1] = counter[1] + (int32_t)N;
+    }
+    const uint32_t n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t num_steps = (uint32_t)rays[n * 3 + 2];
+    const uint32_t off = base + (uint32_t)rays[n * 3 + 1];
+    rays[n * 3 + 1] = (int32_t)off;
+    if (num_steps == 0 || off + num_steps > M) return;
+
+    const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
+    const Ray r = load_ray(rays_o, rays_d, n);
+    const float far = fars[n];
+    float t = nears[n];
+    t = __builtin_fmaf(clampf(t * dt_gamma, p.dt_min, p.dt_max), noises[n], t);
+    float last_t = t;
+    float* px = xyzs + (size_t)off * 3;
+    float* pd = dirs + (size_t)off * 3;
+    float* pl = deltas + (size_t)off * 2;
+    uint32_t step = 0;
+    while (t < far && step < num_steps) {
+        float x, y, z, dt, tt;
+        if (probe(r, p, t, x, y, z, dt, tt)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            t += dt;
+            pl[0] = dt; pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2; step++;
+        } else t = skip_to(p, t, tt);
+    }
+}
+
+// ---------------------------------------------------------------- composite (training)
+__global__ void __launch_bounds__(64) k_composite_train_fwd(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                            const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+                                                            uint32_t M, uint32_t N, float T_thresh,
+                                                            float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                            float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    float r = 0, g = 0, b = 0, ws = 0, d = 0;
+    if (num_steps != 0 && offset + num_steps <= M) {
+        const float* s = sigmas + offset;
+        const float* c = rgbs + (size_t)offset * 3;
+        const float2* dl = reinterpret_cast<const float2*>(deltas) + offset;
+        float T = 1.0f, t = 0;
+        for (uint32_t step = 0; step < num_steps; step++) {
+            const float2 dd = dl[step];
+            const float alpha = 1.0f - __expf(-s[step] * dd.x);
+            const float weight = alpha * T;
+            r = __builtin_fmaf(weight, c[step * 3], r);
+            g = __builtin_fmaf(weight, c[step * 3 + 1], g);
+            b = __builtin_fmaf(weight, c[step * 3 + 2], b);
+            t += dd.y;
+            d = __builtin_fmaf(weight, t, d);
+            ws += weight;
+            T *= 1.0f - alpha;
+            if (T < T_thresh) break;
+        }
+    }
+    weights_sum[index] = ws; depth[index] = d;
+    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+}
+
+__global__ void __launch_bounds__(64) k_composite_train_bwd(const float* __restrict__ grad_weights_sum,
+                                                            const float* __restrict__ grad_image,
+                                                            const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                            const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+                                                            const float* __restrict__ weights_sum,
+                                                            const float* __restrict__ image, uint32_t M, uint32_t N,
+                                                            float T_thresh, float* __restrict__ grad_sigmas,
+                                                            float* __restrict__ grad_rgbs) {
+    const uint32_t n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps > M) return;
+    const float gws = grad_weights_sum[index];
+    const float gi0 = grad_image[index * 3], gi1 = grad_image[index * 3 + 1], gi2 = grad_image[index * 3 + 2];
+    const float r_final = image[index * 3], g_final = image[index * 3 + 1], b_final = image[index * 3 + 2];
+    const float ws_final = weights_sum[index];
+    const float* s = sigmas + offset;
+    const float* c = rgbs + (size_t)offset * 3;
+    const float2* dl = reinterpret_cast<const float2*>(deltas) + offset;
+    float* gs = grad_sigmas + offset;
+    float* gc = grad_rgbs + (size_t)offset * 3;
+    float T = 1.0f, r = 0, g = 0, b = 0, ws = 0;
+    for (uint32_t step = 0; step < num_steps; step++) {
+        const float2 dd = dl[step];
+        const float c0 = c[step * 3], c1 = c[step * 3 + 1], c2 = c[step * 3 + 2];
+        const float alpha = 1.0f - __expf(-s[step] * dd.x);
+        const float weight = alpha * T;
+        r = __builtin_fmaf(weight, c0, r); g = __builtin_fmaf(weight, c1, g); b = __builtin_fmaf(weight, c2, b);
+        ws += weight;
+        T *= 1.0f - alpha;
+        gc[step * 3] = gi0 * weight; gc[step * 3 + 1] = gi1 * weight; gc[step * 3 + 2] = gi2 * weight;
+        float acc = gi0 * __builtin_fmaf(T, c0, -(r_final - r));
+        acc = __builtin_fmaf(gi1, __builtin_fmaf(T, c1, -(g_final - g)), acc);
+        acc = __builtin_fmaf(gi2, __builtin_fmaf(T, c2, -(b_final - b)), acc);
+        acc = __builtin_fmaf(gws, 1 - ws_final, acc);
+        gs[step] = dd.x * acc;
+        if (T < T_thresh) break;
+    }
+}
+
+// ---------------------------------------------------------------- inference
+__global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive,
+                                                   const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                                                   const float* __restrict__ rays_d, float bound, float dt_gamma,
+                                                   uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                                                   const float* __restrict__ fars, float* __restrict__ xyzs,
+                                                   float* __restrict__ dirs, float* __restrict__ deltas,
+                                                   const float* __restrict__ noises) {
+    const uint32_t n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= n_alive) return;
+    const uint32_t index = (uint32_t)rays_alive[n];
+    const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
+    const Ray r = load_ray(rays_o, rays_d, index);
+    float* px = xyzs + (size_t)n * n_step * 3;
+    float* pd = dirs + (size_t)n * n_step * 3;
+    float* pl = deltas + (size_t)n * n_step * 2;
+    float t = rays_t[index];
+    const float far = fars[index];
+    t = __builtin_fmaf(clampf(t * dt_gamma, p.dt_min, p.dt_max), noises[n], t);
+    float last_t = t;
+    uint32_t step = 0;
+    while (t < far && step < n_step) {
+        float x, y, z, dt, tt;
+        if (probe(r, p, t, x, y, z, dt, tt)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
+            t += dt;
+            pl[0] = dt; pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2; step++;
+        } else t = skip_to(p, t, tt);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
+                                                       int32_t* __restrict__ rays_alive, float* __restrict__ rays_t,
+                                                       const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                       const float* __restrict__ deltas, float* __restrict__ weights_sum,
+                                                       float* __restrict__ depth, float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * 64 + threadIdx.x;
+    if (n >= n_alive) return;
+    const uint32_t index = (uint32_t)rays_alive[n];
+    const float* s = sigmas + (size_t)n * n_step;
+    const float* c = rgbs + (size_t)n * n_step * 3;
+    const float2* dl = reinterpret_cast<const float2*>(deltas) + (size_t)n * n_step;
+    float t = rays_t[index];
+    float weight_sum = weights_sum[index], d = depth[index];
+    float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        const float2 dd = dl[step];
+        if (dd.x == 0) break;
+        const float alpha = 1.0f - __expf(-s[step] * dd.x);
+        const float T = 1 - weight_sum;
+        const float weight = alpha * T;
+        weight_sum += weight;
+        t += dd.y;
+        d = __builtin_fmaf(weight, t, d);
+        r = __builtin_fmaf(weight, c[step * 3], r);
+        g = __builtin_fmaf(weight, c[step * 3 + 1], g);
+        b = __builtin_fmaf(weight, c[step * 3 + 2], b);
+        if (T < T_thresh) break;
+        step++;
+    }
+    if (step < n_step) rays_alive[n] = -1; else rays_t[index] = t;
+    weights_sum[index] = weight_sum; depth[index] = d;
+    image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+}
+
+// ---------------------------------------------------------------- alive-ray compaction
+// Stable compaction with wave ballots.  Pass 1: per-wave survivor counts.  Pass 2: wave base by
+// strided reduction over earlier waves (same scheme as march_write), rank by mbcnt of the ballot.
+__global__ void __launch_bounds__(64) k_compact_count(const int32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ ws) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    const bool keep = i < n && in[i] >= 0;
+    const unsigned long long m = __ballot(keep);
+    if (threadIdx.x == 0) ws[blockIdx.x] = (uint32_t)__popcll(m);
+}
+__global__ void __launch_bounds__(64) k_compact_write(const int32_t* __restrict__ in, uint32_t n, int32_t* __restrict__ out,
+                                                      int32_t* __restrict__ n_out, const uint32_t* __restrict__ ws) {
+    uint32_t part = 0;
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 64) part += ws[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    const int32_t v = i < n ? in[i] : -1;
+    const bool keep = v >= 0;
+    const unsigned long long m = __ballot(keep);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (keep) out[part + rank] = v;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_out = (int32_t)(part + (uint32_t)__popcll(m));
+}
+
+}  // namespace
+}  // namespace s3d
+
+using namespace s3d;
+
+S3D_EXPORT int s3d_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N,
+                                      float min_near, float* nears, float* fars, s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(rays_o && rays_d && aabb && nears && fars, "near_far_from_aabb: null pointer");
+    hipLaunchKernelGGL(k_near_far, dim3(stream_grid(N, 256)), dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, N,
+                       min_near, nears, fars);
+    return check_launch("near_far_from_aabb");
+}
+
+S3D_EXPORT int s3d_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
+                                s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(rays_o && rays_d && coords, "sph_from_ray: null pointer");
+    hipLaunchKernelGGL(k_sph_from_ray, dim3(stream_grid(N, 256)), dim3(256), 0, as_stream(stream), rays_o, rays_d,
+                       radius, N, coords);
+    return check_launch("sph_from_ray");
+}
+
+S3D_EXPORT int s3d_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(coords && indices, "morton3D: null pointer");
+    hipLaunchKernelGGL(k_morton3d, dim3(stream_grid(N, 256)), dim3(256), 0, as_stream(stream), coords, N, indices);
+    return check_launch("morton3D");
+}
+
+S3D_EXPORT int s3d_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(coords && indices, "morton3D_invert: null pointer");
+    hipLaunchKernelGGL(k_morton3d_invert, dim3(stream_grid(N, 256)), dim3(256), 0, as_stream(stream), indices, N, coords);
+    return check_launch("morton3D_invert");
+}
+
+S3D_EXPORT int s3d_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield,
+                            s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(grid && bitfield, "packbits: null pointer");
+    S3D_REQUIRE(((uintptr_t)grid & 15) == 0, "packbits: grid must be 16-byte aligned");
+    hipLaunchKernelGGL(k_packbits, dim3(stream_grid(N, 256)), dim3(256), 0, as_stream(stream), grid, N, density_thresh,
+                       bitfield);
+    return check_launch("packbits");
+}
+
+S3D_EXPORT size_t s3d_march_rays_train_workspace_size(uint32_t N) {
+    return sizeof(uint32_t) * (kWsHeader + (size_t)div_up<uint32_t>(N ? N : 1, 64));
+}
+
+S3D_EXPORT int s3d_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                                    float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                    const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                                    int32_t* rays, int32_t* counter, const float* noises, void* workspace,
+                                    size_t workspace_bytes, s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises, "march_rays_train: null pointer");
+    S3D_REQUIRE(M == 0 || (xyzs && dirs && deltas), "march_rays_train: null output");
+    S3D_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024, "march_rays_train: unsupported cascade/grid size C=%u H=%u", C, H);
+    S3D_REQUIRE(workspace && workspace_bytes >= s3d_march_rays_train_workspace_size(N),
+                "march_rays_train: workspace too small (%zu < %zu)", workspace_bytes,
+                s3d_march_rays_train_workspace_size(N));
+    const uint32_t nw = div_up<uint32_t>(N, 64);
+    uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
+    hipLaunchKernelGGL(k_march_count, dim3(nw), dim3(64), 0, as_stream(stream), rays_o, rays_d, grid, bound, dt_gamma,
+                       max_steps, N, C, H, nears, fars, noises, rays, (const int32_t*)counter, ws);
+    hipLaunchKernelGGL(k_march_write, dim3(nw), dim3(64), 0, as_stream(stream), rays_o, rays_d, grid, bound, dt_gamma,
+                       max_steps, N, C, H, M, nears, fars, noises, xyzs, dirs, deltas, rays, counter,
+                       (const uint32_t*)ws);
+    return check_launch("march_rays_train");
+}
+
+S3D_EXPORT int s3d_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
+                                                const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
+                                                float* weights_sum, float* depth, float* image, s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(rays && weights_sum && depth && image, "composite_rays_train_forward: null pointer");
+    S3D_REQUIRE(M == 0 || (sigmas && rgbs && deltas), "composite_rays_train_forward: null input");
+    hipLaunchKernelGGL(k_composite_train_fwd, dim3(div_up<uint32_t>(N, 64)), dim3(64), 0, as_stream(stream), sigmas, rgbs,
+                       deltas, rays, M, N, T_thresh, weights_sum, depth, image);
+    return check_launch("composite_rays_train_forward");
+}
+
+S3D_EXPORT int s3d_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image,
+                                                 const float* sigmas, const float* rgbs, const float* deltas,
+                                                 const int32_t* rays, const float* weights_sum, const float* image,
+                                                 uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas,
+                                                 float* grad_rgbs, s3d_stream_t stream) {
+    if (N == 0 || M == 0) return S3D_OK;
+    S3D_REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image &&
+                    grad_sigmas && grad_rgbs, "composite_rays_train_backward: null pointer");
+    hipLaunchKernelGGL(k_composite_train_bwd, dim3(div_up<uint32_t>(N, 64)), dim3(64), 0, as_stream(stream),
+                       grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh,
+                       grad_sigmas, grad_rgbs);
+    return check_launch("composite_rays_train_backward");
+}
+
+S3D_EXPORT int s3d_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                              const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                              uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                              float* xyzs, float* dirs, float* deltas, const float* noises, s3d_stream_t stream) {
+    (void)nears;
+    if (n_alive == 0 || n_step == 0) return S3D_OK;
+    S3D_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && noises,
+                "march_rays: null pointer");
+    S3D_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024, "march_rays: unsupported cascade/grid size C=%u H=%u", C, H);
+    hipLaunchKernelGGL(k_march_rays, dim3(div_up<uint32_t>(n_alive, 64)), dim3(64), 0, as_stream(stream), n_alive, n_step,
+                       rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs,
+                       deltas, noises);
+    return check_launch("march_rays");
+}
+
+S3D_EXPORT int s3d_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive,
+                                  float* rays_t, const float* sigmas, const float* rgbs, const float* deltas,
+                                  float* weights_sum, float* depth, float* image, s3d_stream_t stream) {
+    if (n_alive == 0) return S3D_OK;
+    S3D_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image,
+                "composite_rays: null pointer");
+    hipLaunchKernelGGL(k_composite_rays, dim3(div_up<uint32_t>(n_alive, 64)), dim3(64), 0, as_stream(stream), n_alive,
+                       n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    return check_launch("composite_rays");
+}
+
+S3D_EXPORT size_t s3d_compact_alive_workspace_size(uint32_t n) {
+    return sizeof(uint32_t) * (size_t)div_up<uint32_t>(n ? n : 1, 64);
+}
+
+S3D_EXPORT int s3d_compact_alive(const int32_t* in, uint32_t n, int32_t* out, int32_t* n_out, void* workspace,
+                                 size_t workspace_bytes, s3d_stream_t stream) {
+    S3D_REQUIRE(n_out, "compact_alive: null n_out");
+    if (n == 0) { S3D_HIP(hipMemsetAsync(n_out, 0, sizeof(int32_t), as_stream(stream))); return S3D_OK; }
+    S3D_REQUIRE(in && out && workspace && workspace_bytes >= s3d_compact_alive_workspace_size(n),
+                "compact_alive: bad arguments");
+    const uint32_t nw = div_up<uint32_t>(n, 64);
+    hipLaunchKernelGGL(k_compact_count, dim3(nw), dim3(64), 0, as_stream(stream), in, n, (uint32_t*)workspace);
+    hipLaunchKernelGGL(k_compact_write, dim3(nw), dim3(64), 0, as_stream(stream), in, n, out, n_out,
+                       (const uint32_t*)workspace);
+    return check_launch("compact_alive");
+}

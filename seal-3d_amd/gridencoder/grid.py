@@ -1,0 +1,139 @@
+"""gridencoder — drop-in for the reference's `gridencoder` package on MI355X.
+
+Same `GridEncoder` constructor / attributes / forward and `grid_encode`
+Function surface as gridencoder/grid.py of the reference; native work goes to
+libseal3d_hip (s3d_hip.GridBackend).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+import s3d_hip
+
+_backend = s3d_hip.GridBackend
+
+_GRIDTYPE = {"hash": 0, "tiled": 1}
+_INTERP = {"linear": 0, "smoothstep": 1}
+
+
+class _GridEncode(Function):
+    """grid.py:24-89.  Autocast is handled by hand: inputs stay fp32, the table is cast to half when C is even."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False,
+                gridtype=0, align_corners=False, interpolation=0):
+        inputs = inputs.contiguous()
+        B, D = inputs.shape
+        L = offsets.shape[0] - 1
+        C = embeddings.shape[1]
+        S = float(np.log2(per_level_scale))
+        H = base_resolution
+
+        if torch.is_autocast_enabled("cuda") and C % 2 == 0:
+            embeddings = embeddings.to(torch.half)
+        embeddings = embeddings.contiguous()
+
+        outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)  # level-major
+        dy_dx = (torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype)
+                 if calc_grad_inputs else None)
+        _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype,
+                                     align_corners, interpolation)
+        outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
+
+        ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
+        ctx.meta = (B, D, C, L, S, H, gridtype, interpolation, align_corners)
+        return outputs
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad):
+        inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype, interpolation, align_corners = ctx.meta
+        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()  # [L, B, C]
+        grad_embeddings = torch.zeros_like(embeddings)
+        grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
+        _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
+                                      grad_inputs, gridtype, align_corners, interpolation)
+        if grad_inputs is not None:
+            grad_inputs = grad_inputs.to(inputs.dtype)
+        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
+
+
+grid_encode = _GridEncode.apply
+
+
+class GridEncoder(nn.Module):
+    """grid.py:96-185"""
+
+    def __init__(self, input_dim=3, num_levels=16, level_dim=2, per_level_scale=2, base_resolution=16,
+                 log2_hashmap_size=19, desired_resolution=None, gridtype="hash", align_corners=False,
+                 interpolation="linear"):
+        super().__init__()
+        if desired_resolution is not None:
+            # geometric growth that lands on `desired_resolution` at the last level (grid.py:101-102)
+            per_level_scale = np.exp2(np.log2(desired_resolution / base_resolution) / (num_levels - 1))
+
+        self.input_dim = input_dim
+        self.num_levels = num_levels
+        self.level_dim = level_dim
+        self.per_level_scale = per_level_scale
+        self.log2_hashmap_size = log2_hashmap_size
+        self.base_resolution = base_resolution
+        self.output_dim = num_levels * level_dim
+        self.gridtype = gridtype
+        self.gridtype_id = _GRIDTYPE[gridtype]
+        self.interpolation = interpolation
+        self.interp_id = _INTERP[interpolation]
+        self.align_corners = align_corners
+        self.max_params = 2 ** log2_hashmap_size
+
+        # per-level row counts: dense while (res+1)^D fits, capped at 2^log2_hashmap_size, padded to x8
+        sizes = []
+        for lvl in range(num_levels):
+            res = int(np.ceil(base_resolution * per_level_scale ** lvl))
+            rows = min(self.max_params, (res if align_corners else res + 1) ** input_dim)
+            sizes.append(int(np.ceil(rows / 8) * 8))
+        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        self.register_buffer("offsets", torch.from_numpy(offsets))
+        total = int(offsets[-1])
+        self.n_params = self.offsets[-1] * level_dim
+        self.embeddings = nn.Parameter(torch.empty(total, level_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.embeddings.data.uniform_(-1e-4, 1e-4)
+
+    def __repr__(self):
+        top = int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))
+        return (f"GridEncoder: input_dim={self.input_dim} num_levels={self.num_levels} level_dim={self.level_dim} "
+                f"resolution={self.base_resolution} -> {top} per_level_scale={self.per_level_scale:.4f} "
+                f"params={tuple(self.embeddings.shape)} gridtype={self.gridtype} align_corners={self.align_corners} "
+                f"interpolation={self.interpolation}")
+
+    def forward(self, inputs, bound=1):
+        inputs = (inputs + bound) / (2 * bound)  # [-bound, bound] -> [0, 1]
+        lead = list(inputs.shape[:-1])
+        inputs = inputs.view(-1, self.input_dim)
+        out = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
+                          inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id)
+        return out.view(lead + [self.output_dim])
+
+    @torch.autocast("cuda", enabled=False)
+    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
+        """grid.py:162-185: adds the TV gradient into `embeddings.grad` (call between backward() and step())."""
+        D, C, L = self.input_dim, self.embeddings.shape[1], self.offsets.shape[0] - 1
+        S, H = float(np.log2(self.per_level_scale)), self.base_resolution
+        if inputs is None:
+            inputs = torch.rand(B, self.input_dim, device=self.embeddings.device)
+        else:
+            inputs = ((inputs + bound) / (2 * bound)).view(-1, self.input_dim)
+            B = inputs.shape[0]
+        if self.embeddings.grad is None:
+            raise ValueError("grad is None, should be called after loss.backward() and before optimizer.step()!")
+        _backend.grad_total_variation(inputs.contiguous(), self.embeddings, self.embeddings.grad, self.offsets, weight,
+                                      B, D, C, L, S, H, self.gridtype_id, self.align_corners)

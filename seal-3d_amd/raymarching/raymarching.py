@@ -1,0 +1,236 @@
+"""raymarching — drop-in for the reference's `raymarching` package on MI355X.
+
+Same module-level callables, argument meaning, defaults, return values and
+AMP behaviour as raymarching/raymarching.py of the reference (cited per op);
+the native work goes to libseal3d_hip through `_backend`
+(s3d_hip.RaymarchingBackend).  Tests may swap `_backend` for the CPU oracle;
+the product path never does.
+"""
+import torch
+from torch.autograd import Function
+from torch.amp import custom_bwd, custom_fwd
+
+import s3d_hip
+
+_backend = s3d_hip.RaymarchingBackend
+
+__all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
+           "composite_rays_train", "march_rays", "composite_rays", "compact_rays_alive"]
+
+
+def _on_device(t):
+    """The reference wrappers move host tensors to the GPU (`if not x.is_cuda: x = x.cuda()`,
+    raymarching.py:34-35).  Same here whenever the active backend is the GPU one."""
+    if getattr(_backend, "device_type", "cuda") == "cuda" and not t.is_cuda:
+        return t.cuda()
+    return t
+
+
+def _rays(rays_o, rays_d):
+    rays_o = _on_device(rays_o).contiguous().view(-1, 3)
+    rays_d = _on_device(rays_d).contiguous().view(-1, 3)
+    return rays_o, rays_d
+
+
+def _align_up(m, align):
+    # raymarching.py:200 — `m += align - m % align` (adds a full `align` when already aligned)
+    return m + align - m % align if align > 0 else m
+
+
+class _NearFarFromAABB(Function):
+    """raymarching.py:19-49"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, rays_o, rays_d, aabb, min_near=0.2):
+        rays_o, rays_d = _rays(rays_o, rays_d)
+        N = rays_o.shape[0]
+        nears = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
+        fars = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
+        _backend.near_far_from_aabb(rays_o, rays_d, aabb.contiguous(), N, min_near, nears, fars)
+        return nears, fars
+
+
+near_far_from_aabb = _NearFarFromAABB.apply
+
+
+class _SphFromRay(Function):
+    """raymarching.py:52-80"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, rays_o, rays_d, radius):
+        rays_o, rays_d = _rays(rays_o, rays_d)
+        N = rays_o.shape[0]
+        coords = torch.empty(N, 2, dtype=rays_o.dtype, device=rays_o.device)
+        _backend.sph_from_ray(rays_o, rays_d, radius, N, coords)
+        return coords
+
+
+sph_from_ray = _SphFromRay.apply
+
+
+class _Morton3D(Function):
+    """raymarching.py:83-103"""
+
+    @staticmethod
+    def forward(ctx, coords):
+        coords = _on_device(coords)
+        N = coords.shape[0]
+        indices = torch.empty(N, dtype=torch.int32, device=coords.device)
+        _backend.morton3D(coords.int().contiguous(), N, indices)
+        return indices
+
+
+morton3D = _Morton3D.apply
+
+
+class _Morton3DInvert(Function):
+    """raymarching.py:105-126"""
+
+    @staticmethod
+    def forward(ctx, indices):
+        indices = _on_device(indices)
+        N = indices.shape[0]
+        coords = torch.empty(N, 3, dtype=torch.int32, device=indices.device)
+        _backend.morton3D_invert(indices.int().contiguous(), N, coords)
+        return coords
+
+
+morton3D_invert = _Morton3DInvert.apply
+
+
+class _Packbits(Function):
+    """raymarching.py:129-155"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, grid, thresh, bitfield=None):
+        grid = _on_device(grid).contiguous()
+        C, H3 = grid.shape[0], grid.shape[1]
+        N = C * H3 // 8
+        if bitfield is None:
+            bitfield = torch.empty(N, dtype=torch.uint8, device=grid.device)
+        _backend.packbits(grid, N, thresh, bitfield)
+        return bitfield
+
+
+packbits = _Packbits.apply
+
+
+class _MarchRaysTrain(Function):
+    """raymarching.py:161-235.  Sample spans are packed in ray order (deterministic)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
+                perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
+        rays_o, rays_d = _rays(rays_o, rays_d)
+        density_bitfield = _on_device(density_bitfield).contiguous()
+        dev, dt = rays_o.device, rays_o.dtype
+        N = rays_o.shape[0]
+
+        # sample budget: all rays x max_steps until a running mean exists (raymarching.py:193-203)
+        M = N * max_steps
+        budgeted = (not force_all_rays) and mean_count > 0
+        if budgeted:
+            M = _align_up(mean_count, align)
+
+        xyzs = torch.zeros(M, 3, dtype=dt, device=dev)
+        dirs = torch.zeros(M, 3, dtype=dt, device=dev)
+        deltas = torch.zeros(M, 2, dtype=dt, device=dev)
+        rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+        if step_counter is None:
+            step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        noises = torch.rand(N, dtype=dt, device=dev) if perturb else torch.zeros(N, dtype=dt, device=dev)
+
+        _backend.march_rays_train(rays_o, rays_d, density_bitfield, bound, dt_gamma, max_steps, N, C, H, M,
+                                  nears.contiguous(), fars.contiguous(), xyzs, dirs, deltas, rays, step_counter, noises)
+
+        if not budgeted:
+            # first iterations only: one D2H read to trim the over-allocation (raymarching.py:223-231)
+            m = _align_up(int(step_counter[0].item()), align)
+            xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+        return xyzs, dirs, deltas, rays
+
+
+march_rays_train = _MarchRaysTrain.apply
+
+
+class _CompositeRaysTrain(Function):
+    """raymarching.py:238-291 — differentiable w.r.t. sigmas and rgbs (grad_depth is not propagated)."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, sigmas, rgbs, deltas, rays, T_thresh=1e-4):
+        sigmas, rgbs = sigmas.contiguous(), rgbs.contiguous()
+        M, N = sigmas.shape[0], rays.shape[0]
+        weights_sum = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
+        depth = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
+        image = torch.empty(N, 3, dtype=sigmas.dtype, device=sigmas.device)
+        _backend.composite_rays_train_forward(sigmas, rgbs, deltas.contiguous(), rays, M, N, T_thresh, weights_sum,
+                                              depth, image)
+        ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
+        ctx.dims = (M, N, T_thresh)
+        return weights_sum, depth, image
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, grad_weights_sum, grad_depth, grad_image):
+        sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
+        M, N, T_thresh = ctx.dims
+        grad_sigmas = torch.zeros_like(sigmas)
+        grad_rgbs = torch.zeros_like(rgbs)
+        _backend.composite_rays_train_backward(grad_weights_sum.contiguous(), grad_image.contiguous(), sigmas, rgbs,
+                                               deltas.contiguous(), rays, weights_sum, image, M, N, T_thresh,
+                                               grad_sigmas, grad_rgbs)
+        return grad_sigmas, grad_rgbs, None, None, None
+
+
+composite_rays_train = _CompositeRaysTrain.apply
+
+
+class _MarchRays(Function):
+    """raymarching.py:297-348"""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far,
+                align=-1, perturb=False, dt_gamma=0, max_steps=1024):
+        rays_o, rays_d = _rays(rays_o, rays_d)
+        dev, dt = rays_o.device, rays_o.dtype
+        M = _align_up(n_alive * n_step, align)
+        xyzs = torch.zeros(M, 3, dtype=dt, device=dev)
+        dirs = torch.zeros(M, 3, dtype=dt, device=dev)
+        deltas = torch.zeros(M, 2, dtype=dt, device=dev)
+        noises = torch.rand(n_alive, dtype=dt, device=dev) if perturb else torch.zeros(n_alive, dtype=dt, device=dev)
+        _backend.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
+                            density_bitfield, near, far, xyzs, dirs, deltas, noises)
+        return xyzs, dirs, deltas
+
+
+march_rays = _MarchRays.apply
+
+
+class _CompositeRays(Function):
+    """raymarching.py:351-373 — accumulates into weights_sum/depth/image IN PLACE, marks dead rays with -1."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
+                T_thresh=1e-2):
+        _backend.composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas.contiguous(), rgbs.contiguous(),
+                                deltas.contiguous(), weights_sum, depth, image)
+        return tuple()
+
+
+composite_rays = _CompositeRays.apply
+
+
+def compact_rays_alive(rays_alive, n_alive):
+    """Device-side equivalent of `rays_alive[rays_alive >= 0]` (nerf/renderer.py:363): stable wave-ballot
+    compaction.  Returns (compacted buffer, device int32 count); the caller decides when to read the count."""
+    out = torch.empty_like(rays_alive)
+    n_out = torch.empty(1, dtype=torch.int32, device=rays_alive.device)
+    _backend.compact_alive(rays_alive, n_alive, out, n_out)
+    return out, n_out

@@ -1,0 +1,333 @@
+"""s3d_hip — ctypes binding of libseal3d_hip.so (the MI355X product path).
+
+This is the only module that touches the native library.  It exposes five
+backend objects whose methods have the names and argument order of the
+reference's pybind ``_backend`` modules (raymarching/src/bindings.cpp:6-17,
+gridencoder/src/bindings.cpp:6-8, shencoder/src/bindings.cpp:6-7,
+freqencoder/src/bindings.cpp:6-7, ffmlp/src/bindings.cpp:6-10), taking torch
+tensors that live on the GPU, launching on torch's *current* HIP stream, and
+raising ``RuntimeError`` on any non-zero return code.
+
+There is NO CPU fallback: if the library is missing or a tensor is not on the
+GPU the call fails loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libseal3d_hip.so")
+CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+
+F32, F16 = 0, 1
+
+# every symbol include/seal3d_hip.h declares
+EXPORTS = [
+    "s3d_last_error", "s3d_version",
+    "s3d_near_far_from_aabb", "s3d_sph_from_ray", "s3d_morton3D", "s3d_morton3D_invert", "s3d_packbits",
+    "s3d_march_rays_train_workspace_size", "s3d_march_rays_train",
+    "s3d_composite_rays_train_forward", "s3d_composite_rays_train_backward",
+    "s3d_march_rays", "s3d_composite_rays", "s3d_compact_alive_workspace_size", "s3d_compact_alive",
+    "s3d_grid_level_scales", "s3d_grid_encode_forward", "s3d_grid_corner_indices", "s3d_grid_encode_backward",
+    "s3d_grad_total_variation",
+    "s3d_sh_encode_forward", "s3d_sh_encode_backward", "s3d_freq_encode_forward", "s3d_freq_encode_backward",
+    "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
+    "s3d_ffmlp_allocate_splitk", "s3d_ffmlp_free_splitk",
+]
+
+
+def build(force=False, jobs=8):
+    """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-s", f"-j{jobs}"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"seal3d HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (needs hipcc). There is no CPU fallback for the product path.")
+        l = C.CDLL(LIB_PATH)
+        l.s3d_last_error.restype = C.c_char_p
+        l.s3d_version.restype = C.c_char_p
+        for name in ("s3d_march_rays_train_workspace_size", "s3d_compact_alive_workspace_size",
+                     "s3d_ffmlp_backward_workspace_size"):
+            getattr(l, name).restype = C.c_size_t
+        l.s3d_grid_level_scales.restype = None
+        _lib = l
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = lib().s3d_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError("seal3d HIP backend needs GPU tensors (no CPU fallback in the product path)")
+    if not t.is_contiguous():
+        raise RuntimeError("seal3d HIP backend needs contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def _u(x):
+    return C.c_uint32(int(x))
+
+
+def _f(x):
+    return C.c_float(float(x))
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float16:
+        return F16
+    raise RuntimeError(f"seal3d HIP backend: unsupported dtype {t.dtype} (float32/float16 only)")
+
+
+def _need(t, dtype, name):
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+class _Workspace:
+    """Per-device scratch owned by the binding (grown on demand, reused)."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes, device):
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+            self.buf[key] = b
+        return b
+
+
+_ws = _Workspace()
+
+
+def level_scales(L, S, H):
+    out = (C.c_float * int(L))()
+    lib().s3d_grid_level_scales(_u(L), _f(S), _u(H), out)
+    return list(out)
+
+
+class RaymarchingBackend:
+    """raymarching/src/raymarching.h:7-18"""
+
+    @staticmethod
+    def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
+        _need(rays_o, torch.float32, "rays_o")
+        _check(lib().s3d_near_far_from_aabb(_p(rays_o), _p(rays_d), _p(aabb), _u(N), _f(min_near), _p(nears),
+                                            _p(fars), _stream()), "near_far_from_aabb")
+
+    @staticmethod
+    def sph_from_ray(rays_o, rays_d, radius, N, coords):
+        _need(rays_o, torch.float32, "rays_o")
+        _check(lib().s3d_sph_from_ray(_p(rays_o), _p(rays_d), _f(radius), _u(N), _p(coords), _stream()),
+               "sph_from_ray")
+
+    @staticmethod
+    def morton3D(coords, N, indices):
+        _need(coords, torch.int32, "coords")
+        _check(lib().s3d_morton3D(_p(coords), _u(N), _p(indices), _stream()), "morton3D")
+
+    @staticmethod
+    def morton3D_invert(indices, N, coords):
+        _need(indices, torch.int32, "indices")
+        _check(lib().s3d_morton3D_invert(_p(indices), _u(N), _p(coords), _stream()), "morton3D_invert")
+
+    @staticmethod
+    def packbits(grid, N, density_thresh, bitfield):
+        _need(grid, torch.float32, "grid")
+        _check(lib().s3d_packbits(_p(grid), _u(N), _f(density_thresh), _p(bitfield), _stream()), "packbits")
+
+    @staticmethod
+    def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, Cc, H, M, nears, fars, xyzs, dirs,
+                         deltas, rays, counter, noises):
+        _need(rays_o, torch.float32, "rays_o")
+        nbytes = lib().s3d_march_rays_train_workspace_size(_u(N))
+        ws = _ws.get(nbytes, rays_o.device)
+        _check(lib().s3d_march_rays_train(_p(rays_o), _p(rays_d), _p(grid), _f(bound), _f(dt_gamma), _u(max_steps),
+                                          _u(N), _u(Cc), _u(H), _u(M), _p(nears), _p(fars), _p(xyzs), _p(dirs),
+                                          _p(deltas), _p(rays), _p(counter), _p(noises), _p(ws),
+                                          C.c_size_t(ws.numel()), _stream()), "march_rays_train")
+
+    @staticmethod
+    def composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image):
+        _need(sigmas, torch.float32, "sigmas")
+        _check(lib().s3d_composite_rays_train_forward(_p(sigmas), _p(rgbs), _p(deltas), _p(rays), _u(M), _u(N),
+                                                      _f(T_thresh), _p(weights_sum), _p(depth), _p(image),
+                                                      _stream()), "composite_rays_train_forward")
+
+    @staticmethod
+    def composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image,
+                                      M, N, T_thresh, grad_sigmas, grad_rgbs):
+        _need(grad_image, torch.float32, "grad_image")
+        _check(lib().s3d_composite_rays_train_backward(_p(grad_weights_sum), _p(grad_image), _p(sigmas), _p(rgbs),
+                                                       _p(deltas), _p(rays), _p(weights_sum), _p(image), _u(M),
+                                                       _u(N), _f(T_thresh), _p(grad_sigmas), _p(grad_rgbs),
+                                                       _stream()), "composite_rays_train_backward")
+
+    @staticmethod
+    def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, Cc, H, grid,
+                   nears, fars, xyzs, dirs, deltas, noises):
+        _need(rays_o, torch.float32, "rays_o")
+        _check(lib().s3d_march_rays(_u(n_alive), _u(n_step), _p(rays_alive), _p(rays_t), _p(rays_o), _p(rays_d),
+                                    _f(bound), _f(dt_gamma), _u(max_steps), _u(Cc), _u(H), _p(grid), _p(nears),
+                                    _p(fars), _p(xyzs), _p(dirs), _p(deltas), _p(noises), _stream()), "march_rays")
+
+    @staticmethod
+    def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth,
+                       image):
+        _need(image, torch.float32, "image")
+        _check(lib().s3d_composite_rays(_u(n_alive), _u(n_step), _f(T_thresh), _p(rays_alive), _p(rays_t),
+                                        _p(sigmas), _p(rgbs), _p(deltas), _p(weights_sum), _p(depth), _p(image),
+                                        _stream()), "composite_rays")
+
+    # --- build extension (not in the reference's native surface) ---
+    @staticmethod
+    def compact_alive(rays_alive, n, out, n_out):
+        nbytes = lib().s3d_compact_alive_workspace_size(_u(n))
+        ws = _ws.get(nbytes, rays_alive.device)
+        _check(lib().s3d_compact_alive(_p(rays_alive), _u(n), _p(out), _p(n_out), _p(ws), C.c_size_t(ws.numel()),
+                                       _stream()), "compact_alive")
+
+
+class GridBackend:
+    """gridencoder/src/gridencoder.h:12-15"""
+
+    @staticmethod
+    def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, Cc, L, S, H, dy_dx, gridtype, align_corners,
+                            interp):
+        _need(inputs, torch.float32, "inputs")
+        _need(offsets, torch.int32, "offsets")
+        if outputs.dtype != embeddings.dtype:
+            raise RuntimeError("outputs must have the dtype of embeddings")
+        _check(lib().s3d_grid_encode_forward(_p(inputs), _p(embeddings), _p(offsets), _p(outputs), _u(B), _u(D),
+                                             _u(Cc), _u(L), _f(S), _u(H), _p(dy_dx), _u(gridtype),
+                                             C.c_int(int(align_corners)), _u(interp), C.c_int(_dt(embeddings)),
+                                             _stream()), "grid_encode_forward")
+
+    @staticmethod
+    def grid_corner_indices(inputs, offsets, corner_idx, B, D, Cc, L, S, H, gridtype, align_corners):
+        _check(lib().s3d_grid_corner_indices(_p(inputs), _p(offsets), _p(corner_idx), _u(B), _u(D), _u(Cc), _u(L),
+                                             _f(S), _u(H), _u(gridtype), C.c_int(int(align_corners)), _stream()),
+               "grid_corner_indices")
+
+    @staticmethod
+    def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, Cc, L, S, H, dy_dx,
+                             grad_inputs, gridtype, align_corners, interp):
+        _need(inputs, torch.float32, "inputs")
+        if grad_embeddings.dtype != grad.dtype:
+            raise RuntimeError("grad_embeddings must have the dtype of grad")
+        _check(lib().s3d_grid_encode_backward(_p(grad), _p(inputs), _p(embeddings), _p(offsets),
+                                              _p(grad_embeddings), _u(B), _u(D), _u(Cc), _u(L), _f(S), _u(H),
+                                              _p(dy_dx), _p(grad_inputs), _u(gridtype),
+                                              C.c_int(int(align_corners)), _u(interp), C.c_int(_dt(grad)),
+                                              _stream()), "grid_encode_backward")
+
+    @staticmethod
+    def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, Cc, L, S, H, gridtype, align_corners):
+        _need(embeddings, torch.float32, "embeddings")
+        _need(inputs, torch.float32, "inputs")
+        _check(lib().s3d_grad_total_variation(_p(inputs), _p(embeddings), _p(grad), _p(offsets), _f(weight), _u(B),
+                                              _u(D), _u(Cc), _u(L), _f(S), _u(H), _u(gridtype),
+                                              C.c_int(int(align_corners)), _stream()), "grad_total_variation")
+
+
+class SHBackend:
+    """shencoder/src/shencoder.h:9-10"""
+
+    @staticmethod
+    def sh_encode_forward(inputs, outputs, B, D, Cc, dy_dx):
+        _need(inputs, torch.float32, "inputs")
+        _check(lib().s3d_sh_encode_forward(_p(inputs), _p(outputs), _u(B), _u(D), _u(Cc), _p(dy_dx), _stream()),
+               "sh_encode_forward")
+
+    @staticmethod
+    def sh_encode_backward(grad, inputs, B, D, Cc, dy_dx, grad_inputs):
+        _need(grad, torch.float32, "grad")
+        _check(lib().s3d_sh_encode_backward(_p(grad), _p(inputs), _u(B), _u(D), _u(Cc), _p(dy_dx), _p(grad_inputs),
+                                            _stream()), "sh_encode_backward")
+
+
+class FreqBackend:
+    """freqencoder/src/freqencoder.h:7,10"""
+
+    @staticmethod
+    def freq_encode_forward(inputs, B, D, deg, Cc, outputs):
+        _need(inputs, torch.float32, "inputs")
+        _check(lib().s3d_freq_encode_forward(_p(inputs), _u(B), _u(D), _u(deg), _u(Cc), _p(outputs), _stream()),
+               "freq_encode_forward")
+
+    @staticmethod
+    def freq_encode_backward(grad, outputs, B, D, deg, Cc, grad_inputs):
+        _need(grad, torch.float32, "grad")
+        _check(lib().s3d_freq_encode_backward(_p(grad), _p(outputs), _u(B), _u(D), _u(deg), _u(Cc), _p(grad_inputs),
+                                              _stream()), "freq_encode_backward")
+
+
+class FFMLPBackend:
+    """ffmlp/src/ffmlp.h:8-14"""
+
+    @staticmethod
+    def allocate_splitk(n):
+        _check(lib().s3d_ffmlp_allocate_splitk(C.c_size_t(int(n))), "allocate_splitk")
+
+    @staticmethod
+    def free_splitk():
+        _check(lib().s3d_ffmlp_free_splitk(), "free_splitk")
+
+    @staticmethod
+    def ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                      output_activation, forward_buffer, outputs):
+        _need(inputs, torch.float16, "inputs")
+        _need(weights, torch.float16, "weights")
+        _check(lib().s3d_ffmlp_forward(_p(inputs), _p(weights), _u(B), _u(input_dim), _u(output_dim), _u(hidden_dim),
+                                       _u(num_layers), _u(activation), _u(output_activation), _p(forward_buffer),
+                                       _p(outputs), _stream()), "ffmlp_forward")
+
+    @staticmethod
+    def ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                        output_activation, inference_buffer, outputs):
+        _need(inputs, torch.float16, "inputs")
+        _need(weights, torch.float16, "weights")
+        _check(lib().s3d_ffmlp_inference(_p(inputs), _p(weights), _u(B), _u(input_dim), _u(output_dim),
+                                         _u(hidden_dim), _u(num_layers), _u(activation), _u(output_activation),
+                                         _p(inference_buffer), _p(outputs), _stream()), "ffmlp_inference")
+
+    @staticmethod
+    def ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers,
+                       activation, output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights):
+        _need(grad, torch.float16, "grad")
+        nbytes = lib().s3d_ffmlp_backward_workspace_size(_u(input_dim), _u(output_dim), _u(hidden_dim),
+                                                        _u(num_layers))
+        ws = _ws.get(nbytes, grad.device)
+        _check(lib().s3d_ffmlp_backward(_p(grad), _p(inputs), _p(weights), _p(forward_buffer), _u(B), _u(input_dim),
+                                        _u(output_dim), _u(hidden_dim), _u(num_layers), _u(activation),
+                                        _u(output_activation), C.c_int(int(bool(calc_grad_inputs))),
+                                        _p(backward_buffer), _p(grad_inputs if calc_grad_inputs else None),
+                                        _p(grad_weights), _p(ws), C.c_size_t(ws.numel()), _stream()),
+               "ffmlp_backward")
