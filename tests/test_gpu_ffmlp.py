@@ -1,0 +1,94 @@
+"""GPU parity: MFMA fused MLP vs the CPU oracle (dense math, fp16 storage / fp32 accumulate) and vs the
+bias-free torch MLP twin the reference's own test uses (testing/test_ffmlp.py:11-43).
+fp16 tolerance: one half ulp per layer boundary can flip => rtol 2e-2 / atol 2e-2 on O(1) activations."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NETS = [  # in, W, n_layers, out(real), activation
+    (32, 64, 2, 16, 0),   # sigma net of nerf/network_ff.py
+    (32, 64, 3, 3, 0),    # colour net
+    (16, 64, 2, 16, 0),   # testing/test_ffmlp.py shape
+    (64, 64, 2, 8, 0),    # in == W
+    (32, 32, 4, 16, 0),   # W = 32, deeper
+    (48, 64, 2, 16, 3),   # sigmoid, in = 48
+]
+
+
+def _weights(in_dim, W, n, seed=42):
+    torch.manual_seed(seed)
+    num = W * (in_dim + W * (n - 1) + 16)
+    std = math.sqrt(3 / W)
+    return torch.empty(num).uniform_(-std, std)
+
+
+def _split(w, in_dim, W, n):
+    mats, off = [], 0
+    for k, o in [(in_dim, W)] + [(W, W)] * (n - 1) + [(W, 16)]:
+        mats.append(w[off:off + o * k].view(o, k))
+        off += o * k
+    return mats
+
+
+@pytest.mark.parametrize("in_dim,W,n,out,act", NETS)
+@pytest.mark.parametrize("B", [128, 128 * 37])
+def test_ffmlp_forward_backward(oracle, hip, in_dim, W, n, out, act, B):
+    g = torch.Generator().manual_seed(B + in_dim)
+    w = _weights(in_dim, W, n)
+    mats = _split(w, in_dim, W, n)
+    for m in mats[-1:]:
+        m[out:] = 0  # padded output rows
+    w16 = w.half()
+    x = (torch.randn(B, in_dim, generator=g) * 0.5).half()
+    # ---- oracle
+    fb_c = torch.empty(n, B, W, dtype=torch.half)
+    out_c = torch.empty(B, 16, dtype=torch.half)
+    oracle.FFMLPBackend.ffmlp_forward(x, w16, B, in_dim, 16, W, n, act, 6, fb_c, out_c)
+    # ---- hip
+    xg, wg = x.cuda(), w16.cuda()
+    fb_g = torch.empty(n, B, W, dtype=torch.half, device="cuda")
+    out_g = torch.empty(B, 16, dtype=torch.half, device="cuda")
+    hip.FFMLPBackend.ffmlp_forward(xg, wg, B, in_dim, 16, W, n, act, 6, fb_g, out_g)
+    out_i = torch.empty(B, 16, dtype=torch.half, device="cuda")
+    hip.FFMLPBackend.ffmlp_inference(xg, wg, B, in_dim, 16, W, n, act, 6, torch.empty(B, W, dtype=torch.half, device="cuda"), out_i)
+    torch.cuda.synchronize()
+    assert torch.equal(out_g, out_i), "training and inference kernels must agree exactly"
+    torch.testing.assert_close(out_g.cpu().float(), out_c.float(), rtol=2e-2, atol=2e-2)
+    # ---- torch twin (fp32 math on the fp16-rounded weights)
+    h = x.float()
+    for i, m in enumerate(_split(w16.float(), in_dim, W, n)):
+        h = h @ m.t()
+        if i != n:
+            h = torch.relu(h) if act == 0 else torch.sigmoid(h)
+    torch.testing.assert_close(out_g.cpu().float(), h, rtol=3e-2, atol=3e-2)
+
+    # ---- backward
+    grad = (torch.randn(B, 16, generator=g) * 0.1).half()
+    grad[:, out:] = 0
+    bb_c = torch.zeros(n, B, W, dtype=torch.half)
+    gi_c = torch.zeros(B, in_dim, dtype=torch.half)
+    gw_c = torch.zeros_like(w16)
+    gw32 = oracle.FFMLPBackend.ffmlp_backward(grad, x, w16, fb_c, B, in_dim, 16, W, n, act, 6, True, bb_c, gi_c, gw_c)
+    bb_g = torch.zeros(n, B, W, dtype=torch.half, device="cuda")
+    gi_g = torch.zeros(B, in_dim, dtype=torch.half, device="cuda")
+    gw_g = torch.zeros_like(wg)
+    hip.FFMLPBackend.ffmlp_backward(grad.cuda(), xg, wg, fb_g, B, in_dim, 16, W, n, act, 6, True, bb_g, gi_g, gw_g)
+    torch.cuda.synchronize()
+    # ReLU gates of near-zero pre-activations may flip between accumulation orders: L2 comparison
+    assert (gi_g.cpu().float() - gi_c.float()).norm() / gi_c.float().norm().clamp(min=1e-6) < 2e-2
+    scale = gw32.abs().max().clamp(min=1e-3)
+    err = (gw_g.cpu().float() - gw32).abs().max() / scale
+    assert err < 2e-2, f"weight-gradient relative error {err}"
+
+
+def test_ffmlp_rejects_bad_shapes(hip):
+    x = torch.zeros(100, 32, dtype=torch.half, device="cuda")
+    w = torch.zeros(64 * (32 + 64 + 16), dtype=torch.half, device="cuda")
+    with pytest.raises(RuntimeError, match="multiple of 128"):
+        hip.FFMLPBackend.ffmlp_forward(x, w, 100, 32, 16, 64, 2, 0, 6, None, torch.empty(100, 16, dtype=torch.half, device="cuda"))
+    x = torch.zeros(128, 32, dtype=torch.half, device="cuda")
+    with pytest.raises(RuntimeError, match="not supported"):
+        hip.FFMLPBackend.ffmlp_forward(x, w, 128, 32, 16, 128, 2, 0, 6, None, torch.empty(128, 16, dtype=torch.half, device="cuda"))

@@ -1,0 +1,149 @@
+"""GPU parity: grid encoder forward/backward/TV vs the CPU oracle through the C ABI.
+Corner rows (hash / dense indexing) are integer work: BIT-EXACT.  Forward outputs follow the oracle's
+operation order and are compared bit-exactly too; scatter-adds are order-dependent: tolerance."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _enc_meta(D=3, L=16, C=2, base=16, log2T=19, desired=2048, align_corners=False):
+    pls = np.exp2(np.log2(desired / base) / (L - 1)) if L > 1 else 2.0
+    offs, off = [], 0
+    for i in range(L):
+        res = int(np.ceil(base * pls ** i))
+        n = min(2 ** log2T, (res if align_corners else res + 1) ** D)
+        n = int(np.ceil(n / 8) * 8)
+        offs.append(off)
+        off += n
+    offs.append(off)
+    return torch.tensor(offs, dtype=torch.int32), float(np.log2(pls)), off
+
+
+def _inputs(B, D, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, D, generator=g)
+    x[0] = 0.0
+    x[1] = 1.0
+    x[2, 0] = -0.01     # out of range -> zero output
+    x[3, D - 1] = 1.001
+    x[4] = 0.5
+    return x.contiguous()
+
+
+CASES = [
+    # D, L, C, base, log2T, desired, gridtype, align, interp, dtype
+    (3, 16, 2, 16, 19, 2048, 0, False, 0, torch.float32),   # Lego config, fp32
+    (3, 16, 2, 16, 19, 2048, 0, False, 0, torch.float16),   # Lego config under -O
+    (3, 4, 2, 4, 8, 32, 0, False, 0, torch.float32),        # reference test_hashgrid_grad.py config
+    (2, 4, 4, 16, 12, 512, 0, False, 1, torch.float32),     # 2-D, smoothstep
+    (3, 8, 1, 16, 15, 512, 1, True, 0, torch.float32),      # tiled, align_corners, C=1
+    (3, 8, 8, 16, 14, 256, 0, False, 0, torch.float16),     # C=8 half
+    (4, 4, 2, 8, 14, 64, 0, False, 0, torch.float32),       # 4-D
+    (5, 2, 2, 4, 12, 8, 0, False, 0, torch.float32),        # 5-D
+]
+
+
+@pytest.mark.parametrize("D,L,C,base,log2T,desired,gridtype,align,interp,dtype", CASES)
+def test_grid_forward_backward(oracle, hip, D, L, C, base, log2T, desired, gridtype, align, interp, dtype):
+    offsets, S, total = _enc_meta(D, L, C, base, log2T, desired, align)
+    B = 4096 + 37
+    x = _inputs(B, D, seed=D * 100 + L)
+    g = torch.Generator().manual_seed(1)
+    emb = ((torch.rand(total, C, generator=g) * 2 - 1) * (1.0 if dtype == torch.float32 else 0.5)).to(dtype)
+    want_jac = (dtype == torch.float32)
+    out_c = torch.empty(L, B, C, dtype=dtype)
+    jac_c = torch.empty(B, L * D * C, dtype=dtype) if want_jac else None
+    cidx_c = torch.empty(B, L, 2 ** D, dtype=torch.int32)
+    oracle.GridBackend.grid_encode_forward(x, emb, offsets, out_c, B, D, C, L, S, base, jac_c, gridtype, align, interp,
+                                           corner_idx=cidx_c)
+    xg, eg, og = x.cuda(), emb.cuda(), offsets.cuda()
+    out_g = torch.empty(L, B, C, dtype=dtype, device="cuda")
+    jac_g = torch.empty(B, L * D * C, dtype=dtype, device="cuda") if want_jac else None
+    hip.GridBackend.grid_encode_forward(xg, eg, og, out_g, B, D, C, L, S, base, jac_g, gridtype, align, interp)
+    cidx_g = torch.empty(B, L, 2 ** D, dtype=torch.int32, device="cuda")
+    hip.GridBackend.grid_corner_indices(xg, og, cidx_g, B, D, C, L, S, base, gridtype, align)
+    torch.cuda.synchronize()
+    # 1. integer parity: every corner row of every (point, level)
+    assert torch.equal(cidx_c, cidx_g.cpu()), "hash/dense indexing differs"
+    # 2. outputs: same operation order as the oracle -> bit-exact
+    a = out_c.view(torch.int16 if dtype == torch.float16 else torch.int32)
+    b = out_g.cpu().view(torch.int16 if dtype == torch.float16 else torch.int32)
+    assert torch.equal(a, b), f"max abs diff {(out_c.float() - out_g.cpu().float()).abs().max()}"
+    assert (out_c[:, 2] == 0).all() and (out_c[:, 3] == 0).all()
+    if want_jac:
+        torch.testing.assert_close(jac_g.cpu(), jac_c, rtol=1e-6, atol=1e-7)
+
+    # backward
+    grad = torch.randn(L, B, C, generator=g).to(dtype)
+    ge_c = torch.zeros(total, C, dtype=dtype)
+    gi_c = torch.zeros(B, D, dtype=dtype) if want_jac else None
+    oracle.GridBackend.grid_encode_backward(grad, x, emb, offsets, ge_c, B, D, C, L, S, base, jac_c, gi_c, gridtype, align, interp)
+    if dtype == torch.float16 and C == 1:
+        return
+    ge_g = torch.zeros(total, C, dtype=dtype, device="cuda")
+    gi_g = torch.zeros(B, D, dtype=dtype, device="cuda") if want_jac else None
+    hip.GridBackend.grid_encode_backward(grad.cuda(), xg, eg, og, ge_g, B, D, C, L, S, base, jac_g, gi_g, gridtype, align, interp)
+    torch.cuda.synchronize()
+    if dtype == torch.float32:
+        torch.testing.assert_close(ge_g.cpu(), ge_c, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(gi_g.cpu(), gi_c, rtol=1e-5, atol=1e-5)
+    else:
+        # half2 atomics: the sum order is arbitrary in the reference too; compare in fp32 against an fp32 oracle run
+        ge_ref = torch.zeros(total, C, dtype=torch.float32)
+        oracle.GridBackend.grid_encode_backward(grad.float(), x, emb.float(), offsets, ge_ref, B, D, C, L, S, base, None, None,
+                                                gridtype, align, interp)
+        err = (ge_g.cpu().float() - ge_ref).abs()
+        tol = 2e-3 * ge_ref.abs().clamp(min=1.0) * np.sqrt(8.0)
+        # coarse levels accumulate thousands of half adds per slot; allow the half-precision random walk
+        big = ge_ref.abs() > 50
+        assert (err[~big] <= tol[~big] * 8).all()
+        assert (err[big] / ge_ref.abs()[big]).max() < 0.05 if big.any() else True
+    # size-independent property: the table gradient sums to sum(grad) per level/channel (weights sum to 1)
+    if dtype == torch.float32:
+        valid = ((x >= 0) & (x <= 1)).all(-1)
+        for l in (0, L - 1):
+            want = grad[l][valid].double().sum(0)
+            got = ge_g.cpu()[int(offsets[l]):int(offsets[l + 1])].double().sum(0)
+            torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-3)
+
+
+def test_grid_tv(oracle, hip):
+    offsets, S, total = _enc_meta(3, 8, 2, 16, 15, 512)
+    g = torch.Generator().manual_seed(2)
+    emb = torch.rand(total, 2, generator=g)
+    x = _inputs(5000, 3, seed=9)
+    gr_c = torch.zeros(total, 2)
+    oracle.GridBackend.grad_total_variation(x, emb, gr_c, offsets, 1e-3, 5000, 3, 2, 8, S, 16, 0, False)
+    gr_g = torch.zeros(total, 2, device="cuda")
+    hip.GridBackend.grad_total_variation(x.cuda(), emb.cuda(), gr_g, offsets.cuda(), 1e-3, 5000, 3, 2, 8, S, 16, 0, False)
+    torch.testing.assert_close(gr_g.cpu(), gr_c, rtol=1e-4, atol=1e-8)
+
+
+def test_grid_full_size_properties(hip):
+    """B = 2^21 points on the Lego table: linearity in the table and partition of unity."""
+    offsets, S, total = _enc_meta()
+    B = 1 << 21
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(B, 3, generator=g).cuda()
+    og = offsets.cuda()
+    run = lambda e: (lambda o: (hip.GridBackend.grid_encode_forward(x, e, og, o, B, 3, 2, 16, S, 16, None, 0, False, 0), o)[1])(
+        torch.empty(16, B, 2, device="cuda"))
+    ones = torch.ones(total, 2, device="cuda")
+    o1 = run(ones)
+    torch.testing.assert_close(o1, torch.ones_like(o1), rtol=0, atol=2e-6)  # weights sum to one
+    e1 = torch.randn(total, 2, generator=g).cuda()
+    e2 = torch.randn(total, 2, generator=g).cuda()
+    torch.testing.assert_close(run(e1 + 2 * e2), run(e1) + 2 * run(e2), rtol=1e-4, atol=1e-5)
+
+
+def test_grid_errors_raise(hip):
+    x = torch.rand(8, 3).cuda()
+    offs = torch.tensor([0, 8], dtype=torch.int32).cuda()
+    emb = torch.rand(8, 3).cuda()
+    with pytest.raises(RuntimeError, match="C must be 1, 2, 4, or 8"):
+        hip.GridBackend.grid_encode_forward(x, emb, offs, torch.empty(1, 8, 3, device="cuda"), 8, 3, 3, 1, 1.0, 16, None, 0, False, 0)
+    with pytest.raises(RuntimeError, match="D must be 2, 3, 4, or 5"):
+        hip.GridBackend.grid_encode_forward(torch.rand(8, 6).cuda(), torch.rand(8, 2).cuda(), offs,
+                                            torch.empty(1, 8, 2, device="cuda"), 8, 6, 2, 1, 1.0, 16, None, 0, False, 0)

@@ -1,0 +1,262 @@
+"""GPU parity: libseal3d_hip raymarching entry points vs the CPU oracle on the same seeded inputs.
+Integer / index / compaction results must be BIT-EXACT; compositing is FP (rtol 1e-4, north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from nerf import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(seed=0, cascade=1, bound=1.0):
+    grid, bits = syn.lego_like_density_grid(seed=seed, cascade=cascade, bound=bound)
+    return torch.from_numpy(grid), torch.from_numpy(bits)
+
+
+def _rays(n, seed=0, H=800, W=800):
+    poses = syn.orbit_poses(4, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    r = syn.get_rays(poses[seed % 4:seed % 4 + 1], syn.lego_intrinsics(H, W), H, W, N=n, generator=g)
+    return r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous()
+
+
+def _both(oracle, hip, name, cpu_args, n_out_tensors):
+    """run backend fn `name` on the oracle (CPU tensors) and on HIP (cuda copies); return both arg lists"""
+    gpu_args = [a.cuda() if torch.is_tensor(a) else a for a in cpu_args]
+    getattr(oracle.RaymarchingBackend, name)(*cpu_args)
+    getattr(hip.RaymarchingBackend, name)(*gpu_args)
+    torch.cuda.synchronize()
+    return cpu_args, gpu_args
+
+
+def test_morton_roundtrip_full_grid(oracle, hip):
+    idx = torch.arange(128)
+    c = torch.stack(torch.meshgrid(idx, idx, idx, indexing="ij"), -1).reshape(-1, 3).int().contiguous()
+    N = c.shape[0]
+    out_c = torch.empty(N, dtype=torch.int32)
+    cpu, gpu = _both(oracle, hip, "morton3D", [c, N, out_c], 1)
+    assert torch.equal(cpu[2], gpu[2].cpu())
+    # size-independent property: invert(morton(c)) == c, indices are a permutation of [0, 128^3)
+    back = torch.empty(N, 3, dtype=torch.int32, device="cuda")
+    hip.RaymarchingBackend.morton3D_invert(gpu[2], N, back)
+    assert torch.equal(back.cpu(), c)
+    assert torch.equal(torch.sort(gpu[2].cpu().long()).values, torch.arange(N))
+
+
+def test_morton_invert_random_incl_out_of_range(oracle, hip):
+    g = torch.Generator().manual_seed(3)
+    ind = torch.randint(0, 2 ** 30, (10000,), generator=g, dtype=torch.int64).int()
+    out = torch.empty(10000, 3, dtype=torch.int32)
+    cpu, gpu = _both(oracle, hip, "morton3D_invert", [ind, 10000, out], 1)
+    assert torch.equal(cpu[2], gpu[2].cpu())
+
+
+def test_packbits(oracle, hip):
+    g = torch.Generator().manual_seed(5)
+    grid = torch.rand(2, 128 ** 3, generator=g) * 2 - 0.5
+    grid[0, :64] = -1.0
+    N = grid.numel() // 8
+    bf = torch.empty(N, dtype=torch.uint8)
+    cpu, gpu = _both(oracle, hip, "packbits", [grid, N, 0.37, bf], 1)
+    assert torch.equal(cpu[3], gpu[3].cpu())
+    # known answer: numpy packbits little-endian
+    ref = np.packbits((grid.numpy().reshape(-1) > np.float32(0.37)).astype(np.uint8), bitorder="little")
+    assert np.array_equal(ref, gpu[3].cpu().numpy())
+
+
+def test_near_far_incl_misses_and_axis_parallel(oracle, hip):
+    ro, rd = _rays(4096, seed=1)
+    ro, rd = ro.clone(), rd.clone()
+    rd[:8] = torch.tensor([0.0, 0.0, 1.0])        # axis-parallel: 1/0 = inf in two slabs
+    ro[8:16] = torch.tensor([5.0, 5.0, 5.0])      # misses
+    rd[8:16] = torch.tensor([0.0, 1.0, 0.0])
+    ro[16:24] = torch.tensor([0.0, 0.0, 0.0])     # origin inside the box: near clamps to min_near
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1])
+    N = ro.shape[0]
+    nears, fars = torch.empty(N), torch.empty(N)
+    cpu, gpu = _both(oracle, hip, "near_far_from_aabb", [ro, rd, aabb, N, 0.2, nears, fars], 2)
+    a, b = cpu[5].numpy(), gpu[5].cpu().numpy()
+    # bit-exact incl. NaN patterns from inf*0
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(cpu[6].numpy().view(np.uint32), gpu[6].cpu().numpy().view(np.uint32))
+    assert (cpu[5][16:24] == 0.2).all()
+
+
+def test_sph_from_ray(oracle, hip):
+    ro, rd = _rays(2048, seed=2)
+    N = ro.shape[0]
+    co = torch.empty(N, 2)
+    cpu, gpu = _both(oracle, hip, "sph_from_ray", [ro * 0.1, rd, 4.0, N, co], 1)
+    torch.testing.assert_close(gpu[4].cpu(), cpu[4], rtol=1e-5, atol=1e-5)  # atan2f: FP tolerance
+
+
+def _march_train_args(ro, rd, bits, C, bound, M, perturb, dt_gamma=0.0, max_steps=1024, min_near=0.2, seed=0):
+    from oracle import oracle_backend as ob
+    N = ro.shape[0]
+    aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32)
+    nears, fars = torch.empty(N), torch.empty(N)
+    ob.RaymarchingBackend.near_far_from_aabb(ro, rd, aabb, N, min_near, nears, fars)
+    g = torch.Generator().manual_seed(seed)
+    noises = torch.rand(N, generator=g) if perturb else torch.zeros(N)
+    xyzs, dirs, deltas = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
+    rays = torch.empty(N, 3, dtype=torch.int32)
+    counter = torch.zeros(2, dtype=torch.int32)
+    return [ro, rd, bits, bound, dt_gamma, max_steps, N, C, 128, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises]
+
+
+@pytest.mark.parametrize("perturb", [False, True])
+@pytest.mark.parametrize("cascade,bound,dt_gamma", [(1, 1.0, 0.0), (2, 2.0, 1.0 / 128)])
+def test_march_rays_train_bit_exact(oracle, hip, perturb, cascade, bound, dt_gamma):
+    _, bits = _scene(seed=0, cascade=cascade, bound=bound)
+    ro, rd = _rays(4096, seed=3)
+    args = _march_train_args(ro, rd, bits, cascade, bound, 4096 * 256, perturb, dt_gamma=dt_gamma)
+    cpu, gpu = _both(oracle, hip, "march_rays_train", args, 5)
+    # compaction: per-ray (id, offset, count) and the two counters, bit-exact
+    assert torch.equal(cpu[15], gpu[15].cpu())
+    assert torch.equal(cpu[16], gpu[16].cpu())
+    m = int(cpu[16][0])
+    assert m > 4096 * 3, "scene should produce samples"
+    for k in (12, 13, 14):  # xyzs, dirs, deltas bit-exact, including the untouched zero tail
+        assert np.array_equal(cpu[k].numpy().view(np.uint32), gpu[k].cpu().numpy().view(np.uint32))
+
+
+def test_march_rays_train_capped_budget_and_empty(oracle, hip):
+    _, bits = _scene(seed=0)
+    ro, rd = _rays(4096, seed=4)
+    # budget smaller than the demand: rays whose span does not fit are dropped, nothing is written past M
+    args = _march_train_args(ro, rd, bits, 1, 1.0, 20000, True)
+    cpu, gpu = _both(oracle, hip, "march_rays_train", args, 5)
+    assert torch.equal(cpu[15], gpu[15].cpu()) and torch.equal(cpu[16], gpu[16].cpu())
+    assert int(cpu[16][0]) > 20000
+    for k in (12, 13, 14):
+        assert np.array_equal(cpu[k].numpy().view(np.uint32), gpu[k].cpu().numpy().view(np.uint32))
+    # empty bitfield: every ray has zero samples
+    args = _march_train_args(ro[:100].contiguous(), rd[:100].contiguous(), torch.zeros_like(bits), 1, 1.0, 1024, False)
+    cpu, gpu = _both(oracle, hip, "march_rays_train", args, 5)
+    assert torch.equal(cpu[15], gpu[15].cpu()) and int(gpu[16][0]) == 0 and int(gpu[16][1]) == 100
+    # ragged N (not a multiple of 64) and N = 1
+    for n in (1, 63, 65, 1000):
+        args = _march_train_args(ro[:n].contiguous(), rd[:n].contiguous(), bits, 1, 1.0, n * 256, True)
+        cpu, gpu = _both(oracle, hip, "march_rays_train", args, 5)
+        assert torch.equal(cpu[15], gpu[15].cpu()) and torch.equal(cpu[16], gpu[16].cpu())
+
+
+def _composite_inputs(oracle, seed=0, n_rays=4096):
+    _, bits = _scene(seed=0)
+    ro, rd = _rays(n_rays, seed=seed)
+    args = _march_train_args(ro, rd, bits, 1, 1.0, n_rays * 256, True)
+    oracle.RaymarchingBackend.march_rays_train(*args)
+    m = int(args[16][0])
+    g = torch.Generator().manual_seed(seed + 10)
+    # mix of dense (early-terminating) and thin samples
+    sigmas = torch.exp(torch.randn(m, generator=g) * 2 + 1).contiguous()
+    rgbs = torch.rand(m, 3, generator=g)
+    return sigmas, rgbs, args[14][:m].contiguous(), args[15], m, n_rays
+
+
+def test_composite_rays_train_forward_backward(oracle, hip):
+    sigmas, rgbs, deltas, rays, M, N = _composite_inputs(oracle)
+    ws, dp, im = torch.empty(N), torch.empty(N), torch.empty(N, 3)
+    cpu, gpu = _both(oracle, hip, "composite_rays_train_forward", [sigmas, rgbs, deltas, rays, M, N, 1e-4, ws, dp, im], 3)
+    for k in (7, 8, 9):
+        torch.testing.assert_close(gpu[k].cpu(), cpu[k], rtol=1e-4, atol=1e-6)
+    assert (cpu[7] == 0).any(), "expect some empty rays"
+    g = torch.Generator().manual_seed(7)
+    gws, gim = torch.randn(N, generator=g), torch.randn(N, 3, generator=g)
+    gs, gc = torch.zeros(M), torch.zeros(M, 3)
+    cpu2, gpu2 = _both(oracle, hip, "composite_rays_train_backward",
+                       [gws, gim, sigmas, rgbs, deltas, rays, cpu[7], cpu[9], M, N, 1e-4, gs, gc], 2)
+    torch.testing.assert_close(gpu2[12].cpu(), cpu2[12], rtol=1e-4, atol=1e-6)
+    # grad_sigmas has cancellation; compare against the per-ray scale
+    err = (gpu2[11].cpu() - cpu2[11]).abs().max() / cpu2[11].abs().max()
+    assert err < 1e-4
+    # early termination: samples after the cut keep the caller's zeros on both sides.  The cut is decided by
+    # `T < T_thresh` on an exp() that differs in the last bits (__expf vs expf), so a ray may stop one sample
+    # earlier or later: allow a 1e-3 fraction of samples to differ in written/unwritten state.
+    mism = ((gpu2[11].cpu() == 0) != (cpu2[11] == 0)).float().mean()
+    assert mism < 1e-3
+
+
+def test_march_and_composite_inference_trace(oracle, hip):
+    """three iterations of the run_cuda eval loop (nerf/renderer.py:341-367), incl. the kill pattern"""
+    _, bits = _scene(seed=0)
+    N = 8192
+    ro, rd = _rays(N, seed=6)
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1])
+    nears, fars = torch.empty(N), torch.empty(N)
+    oracle.RaymarchingBackend.near_far_from_aabb(ro, rd, aabb, N, 0.2, nears, fars)
+    st = {}
+    for dev in ("cpu", "cuda"):
+        be = oracle.RaymarchingBackend if dev == "cpu" else hip.RaymarchingBackend
+        t = lambda x: x.to(dev)
+        alive = torch.arange(N, dtype=torch.int32, device=dev)
+        rays_t = t(nears).clone()
+        ws, dp, im = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(N, 3, device=dev)
+        trace = []
+        for it in range(3):
+            n_alive = alive.shape[0]
+            n_step = max(min(N // n_alive, 8), 1)
+            M = n_alive * n_step
+            M += 128 - M % 128
+            xyzs, dirs, deltas = (torch.zeros(M, 3, device=dev), torch.zeros(M, 3, device=dev), torch.zeros(M, 2, device=dev))
+            noises = torch.zeros(n_alive, device=dev)
+            be.march_rays(n_alive, n_step, alive, rays_t, t(ro), t(rd), 1.0, 0.0, 1024, 1, 128, t(bits), t(nears), t(fars),
+                          xyzs, dirs, deltas, noises)
+            # deterministic pseudo-network: density from the analytic box scene, colour from position
+            lo, hi = syn.lego_like_boxes(0)
+            sig = syn.box_density(xyzs.cpu(), lo, hi).to(dev) * 4
+            rgb = (xyzs * 0.5 + 0.5).clamp(0, 1)
+            be.composite_rays(n_alive, n_step, 1e-2, alive, rays_t, sig, rgb, deltas, ws, dp, im)
+            trace.append((xyzs.cpu(), deltas.cpu(), alive.cpu().clone()))
+            if dev == "cuda":
+                # device-side compaction (wave ballot) must equal the host boolean-mask compaction
+                comp, cnt = torch.empty_like(alive), torch.empty(1, dtype=torch.int32, device=dev)
+                be.compact_alive(alive, n_alive, comp, cnt)
+                ref = alive[alive >= 0]
+                assert int(cnt) == ref.shape[0] and torch.equal(comp[:int(cnt)], ref)
+            alive = alive[alive >= 0]
+        st[dev] = (trace, ws.cpu(), dp.cpu(), im.cpu(), rays_t.cpu())
+    for (xa, da, aa), (xb, db, ab) in zip(st["cpu"][0], st["cuda"][0]):
+        assert np.array_equal(xa.numpy().view(np.uint32), xb.numpy().view(np.uint32))
+        assert np.array_equal(da.numpy().view(np.uint32), db.numpy().view(np.uint32))
+        assert torch.equal(aa, ab), "kill pattern differs"
+    for k in (1, 2, 3, 4):
+        torch.testing.assert_close(st["cuda"][k], st["cpu"][k], rtol=1e-4, atol=1e-6)
+    assert (st["cpu"][0][2][2] == -1).any()
+
+
+def test_full_size_properties(hip):
+    """BASELINE size (800x800 rays): size-independent properties instead of an oracle run."""
+    _, bits = _scene(seed=0)
+    N = 800 * 800
+    poses = syn.orbit_poses(1, seed=9)
+    r = syn.get_rays(poses, syn.lego_intrinsics(), 800, 800)
+    ro, rd = r["rays_o"][0].contiguous().cuda(), r["rays_d"][0].contiguous().cuda()
+    be = hip.RaymarchingBackend
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1]).cuda()
+    nears, fars = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+    be.near_far_from_aabb(ro, rd, aabb, N, 0.2, nears, fars)
+    M = 40_000_000
+    xyzs, dirs, deltas = torch.zeros(M, 3, device="cuda"), torch.zeros(M, 3, device="cuda"), torch.zeros(M, 2, device="cuda")
+    rays = torch.empty(N, 3, dtype=torch.int32, device="cuda")
+    counter = torch.zeros(2, dtype=torch.int32, device="cuda")
+    be.march_rays_train(ro, rd, bits.cuda(), 1.0, 0.0, 1024, N, 1, 128, M, nears, fars, xyzs, dirs, deltas, rays, counter,
+                        torch.zeros(N, device="cuda"))
+    rays_c = rays.cpu().long()
+    total = int(counter[0])
+    assert int(counter[1]) == N and total <= M
+    # spans are the exclusive prefix sum of the counts, in ray order
+    assert torch.equal(rays_c[:, 0], torch.arange(N))
+    assert torch.equal(rays_c[:, 1], torch.cumsum(rays_c[:, 2], 0) - rays_c[:, 2])
+    assert int(rays_c[:, 2].sum()) == total
+    # every written sample lies in an occupied cell; nothing written past `total`
+    pts = xyzs[:total]
+    cell = ((pts * 0.5 + 0.5) * 128).clamp(0, 127).int()
+    idx = torch.empty(total, dtype=torch.int32, device="cuda")
+    be.morton3D(cell.contiguous(), total, idx)
+    b = bits.cuda()[(idx.long() >> 3)]
+    assert bool(((b >> (idx & 7).to(torch.uint8)) & 1).all())
+    assert float(xyzs[total:].abs().sum()) == 0.0
+    # deltas: dt == dt_min everywhere (dt_gamma = 0)
+    assert bool((deltas[:total, 0] == deltas[0, 0]).all())

@@ -1,0 +1,122 @@
+"""GPU: the drop-in Python packages (autograd Functions / nn.Modules) on the product backend, compared with
+the same wrappers driven by the CPU oracle — exercises the boundary exactly as the reference's callers do."""
+import numpy as np
+import pytest
+import torch
+
+from nerf import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def test_grid_encoder_module_autocast_and_grads(oracle, hip):
+    import gridencoder.grid as gg
+    torch.manual_seed(0)
+    enc = gg.GridEncoder(desired_resolution=2048).cuda()
+    enc.embeddings.data.uniform_(-1, 1)
+    x = (torch.rand(5000, 3, device="cuda") * 2 - 1)
+    y = enc(x)
+    assert y.shape == (5000, 32) and y.dtype == torch.float32
+    (y * torch.linspace(0, 1, 32, device="cuda")).sum().backward()
+    g32 = enc.embeddings.grad.clone()
+    with torch.autocast("cuda", dtype=torch.float16):
+        y16 = enc(x)
+    assert y16.dtype == torch.float16
+    torch.testing.assert_close(y16.float(), y, rtol=2e-2, atol=4e-3)
+    # oracle-driven wrapper on the same weights
+    ref = gg.GridEncoder(desired_resolution=2048)
+    ref.embeddings.data.copy_(enc.embeddings.data.cpu())
+    saved = gg._backend
+    try:
+        gg._backend = oracle.GridBackend
+        yr = ref(x.cpu())
+        (yr * torch.linspace(0, 1, 32)).sum().backward()
+    finally:
+        gg._backend = saved
+    assert torch.equal(yr, y.detach().cpu()), "fp32 forward must be bit-exact vs the oracle"
+    torch.testing.assert_close(g32.cpu(), ref.embeddings.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_raymarching_functions_end_to_end(oracle, hip):
+    import raymarching.raymarching as rm
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    poses = syn.orbit_poses(1, seed=1)
+    r = syn.get_rays(poses, syn.lego_intrinsics(), 800, 800, N=4096, generator=torch.Generator().manual_seed(0))
+    ro, rd = r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous()
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1])
+    res = {}
+    for dev in ("cpu", "cuda"):
+        saved = rm._backend
+        if dev == "cpu":
+            rm._backend = oracle.RaymarchingBackend
+        try:
+            t = lambda v: v.to(dev)
+            nears, fars = rm.near_far_from_aabb(t(ro), t(rd), t(aabb), 0.2)
+            counter = torch.zeros(2, dtype=torch.int32, device=dev)
+            xyzs, dirs, deltas, rays = rm.march_rays_train(t(ro), t(rd), 1.0, t(torch.from_numpy(bits)), 1, 128, nears, fars,
+                                                          counter, -1, False, 128, False, 0, 1024)
+            lo, hi = syn.lego_like_boxes(0)
+            sig = (syn.box_density(xyzs.cpu(), lo, hi).to(dev) * 0.5).requires_grad_(True)
+            rgb = (xyzs * 0.5 + 0.5).clamp(0, 1).detach().requires_grad_(True)
+            ws, depth, image = rm.composite_rays_train(sig, rgb, deltas, rays, 1e-4)
+            loss = (image * torch.tensor([1.0, 2.0, 3.0], device=dev)).sum() + ws.sum()
+            loss.backward()
+            res[dev] = [v.detach().cpu() for v in (xyzs, deltas, rays, counter, ws, depth, image, sig.grad, rgb.grad)]
+            # packbits on the density grid reproduces the scene bitfield
+            bf = rm.packbits(t(torch.from_numpy(grid)), 0.01)
+            assert np.array_equal(bf.cpu().numpy(), bits)
+        finally:
+            rm._backend = saved
+    a, b = res["cpu"], res["cuda"]
+    assert a[0].shape == b[0].shape and a[0].shape[0] % 128 == 0
+    for k in (0, 1, 2, 3):
+        assert torch.equal(a[k], b[k])
+    for k in (4, 5, 6, 8):
+        torch.testing.assert_close(b[k], a[k], rtol=1e-4, atol=1e-6)
+    assert ((b[7] - a[7]).abs().max() / a[7].abs().max()) < 1e-4
+
+
+def test_sh_and_freq_modules(hip):
+    from shencoder import SHEncoder
+    from freqencoder import FreqEncoder
+    d = torch.randn(1000, 3, device="cuda")
+    d = d / d.norm(dim=-1, keepdim=True)
+    sh = SHEncoder(degree=4)
+    with torch.autocast("cuda", dtype=torch.float16):
+        o = sh(d.half())
+    assert o.dtype == torch.float32 and o.shape == (1000, 16)
+    assert torch.allclose(o[:, 0], torch.full((1000,), 0.28209479177387814, device="cuda"))
+    dd = d.clone().requires_grad_(True)
+    sh(dd).sum().backward()
+    assert dd.grad is not None and dd.grad.abs().sum() > 0
+    fe = FreqEncoder(input_dim=3, degree=4)
+    xx = (torch.rand(100, 3, device="cuda") - 0.5).requires_grad_(True)
+    y = fe(xx)
+    assert y.shape == (100, 27)
+    y.sum().backward()
+    ref = torch.ones_like(xx)
+    for f in range(4):
+        ref = ref + 2 ** f * (torch.cos(2 ** f * xx.detach()) - torch.sin(2 ** f * xx.detach()))
+    torch.testing.assert_close(xx.grad, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_ffmlp_module(hip):
+    from ffmlp import FFMLP
+    net = FFMLP(32, 16, 64, 2).cuda()
+    x = torch.randn(1000, 32, device="cuda") * 0.5
+    net.train()
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = net(x)
+    assert y.shape == (1000, 16) and y.dtype == torch.float16
+    y.float().pow(2).sum().backward()
+    assert net.weights.grad is not None and net.weights.grad.shape == net.weights.shape
+    # torch twin
+    w = net.weights.detach().half().float()
+    m0, m1, m2 = w[:2048].view(64, 32), w[2048:2048 + 4096].view(64, 64), w[6144:].view(16, 64)
+    xr = x.half().float()
+    ref = torch.relu(torch.relu(xr @ m0.t()) @ m1.t()) @ m2.t()
+    torch.testing.assert_close(y.float(), ref, rtol=3e-2, atol=3e-2)
+    net.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        y2 = net(x)
+    assert torch.equal(y2, y)
