@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""bench.py — hot-path benchmark for the MI355X build (contract: see the task statement / DESIGN.md §Measurement).
+
+A "step" is one NGP training step of BASELINE.json configs[1] on synthetic Lego-shaped input:
+  4,096 rays of an 800x800 Blender-Lego camera -> near/far -> march_rays_train (occupancy bitfield) ->
+  hash-grid encode (L=16, F=2, T=2^19) -> fused MLPs (ffmlp 32-64-64?-16 / 32-64-64-3, fp16 MFMA) + SH-4 ->
+  composite_rays_train -> MSE -> backward (composite bwd, ffmlp bwd, grid scatter) -> Adam (fp16 autocast +
+  GradScaler), `update_extra_state` every 16 steps.  Ray batches and targets are resident in HBM before timing.
+`value` = real marched samples (sum of step_counter[:,0] over the timed steps and over ranks) / wall time.
+
+Multi-GPU (`python -m torch.distributed.run ... bench.py --gpus N`): weak scaling, every rank trains on its own
+4,096-ray batches; one flat-bucket gradient all-reduce (RCCL) per step.
+
+Extra objects on the JSON line:
+  roofline      dominant hot kernel of the timed region, timed with HIP events on the launch stream
+  cpu_baseline  the same step on the host cores through the CPU oracle ("port"), bounded sample, rank 0, N=1 only
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "seal-3d_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--num_rays", type=int, default=4096)
+    ap.add_argument("--pretrain", type=int, default=384, help="untimed setup steps that converge the occupancy grid")
+    ap.add_argument("--net", choices=["ff", "seal"], default="ff", help="ff: nerf/network_ff (configs[1]); seal: two-encoder nn.Linear net")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_render", action="store_true")
+    ap.add_argument("--cpu_steps", type=int, default=2)
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------- synthetic data
+def analytic_targets(rays_o, rays_d, scene_bits, boxes, R):
+    """ground-truth colours of the box scene for a ray batch, composited with the build's own kernels"""
+    from nerf import synthetic as syn
+    N = rays_o.shape[0]
+    dev = rays_o.device
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1], device=dev)
+    nears, fars = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    R.near_far_from_aabb(rays_o, rays_d, aabb, N, 0.2, nears, fars)
+    M = N * 256
+    xyzs, dirs, deltas = (torch.zeros(M, 3, device=dev), torch.zeros(M, 3, device=dev), torch.zeros(M, 2, device=dev))
+    rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    R.march_rays_train(rays_o, rays_d, scene_bits, 1.0, 0.0, 1024, N, 1, 128, M, nears, fars, xyzs, dirs, deltas, rays, counter,
+                       torch.zeros(N, device=dev))
+    lo, hi = boxes
+    sig = syn.box_density(xyzs, lo, hi, sigma=60.0)
+    rgb = (0.5 + 0.5 * torch.sin(xyzs * 9.0 + torch.tensor([0.0, 2.0, 4.0], device=dev))).contiguous()
+    ws, dp, im = torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty(N, 3, device=dev)
+    R.composite_rays_train_forward(sig.contiguous(), rgb, deltas, rays, M, N, 1e-4, ws, dp, im)
+    return im + (1 - ws).unsqueeze(-1)  # white background
+
+
+def make_batches(n_batches, num_rays, seed, dev, R, scene_bits, boxes):
+    from nerf import synthetic as syn
+    poses = syn.orbit_poses(100, seed=0)  # shared camera set (torch.manual_seed(0) convention of SURVEY §8d)
+    g = torch.Generator().manual_seed(1000 + seed)
+    out = []
+    for b in range(n_batches):
+        k = int(torch.randint(0, poses.shape[0], (1,), generator=g))
+        r = syn.get_rays(poses[k:k + 1], syn.lego_intrinsics(), 800, 800, N=num_rays, generator=g)
+        ro, rd = r["rays_o"][0].contiguous().to(dev), r["rays_d"][0].contiguous().to(dev)
+        out.append((ro, rd, analytic_targets(ro, rd, scene_bits, boxes, R)))
+    return out, poses
+
+
+# ----------------------------------------------------------------------------- kernel timing hooks
+class KernelTimers:
+    """HIP-event timing of individual native calls on the launch stream (torch's current stream)."""
+
+    def __init__(self, backend_cls, names):
+        self.cls, self.names, self.orig, self.events = backend_cls, names, {}, {n: [] for n in names}
+        self.meta = {n: [] for n in names}
+
+    def install(self, meta_fn):
+        for n in self.names:
+            f = getattr(self.cls, n)
+            self.orig[n] = f
+
+            def wrapped(*a, __f=f, __n=n, **kw):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = __f(*a, **kw)
+                e.record()
+                self.events[__n].append((s, e))
+                self.meta[__n].append(meta_fn(__n, a))
+                return r
+            setattr(self.cls, n, staticmethod(wrapped))
+
+    def remove(self):
+        for n, f in self.orig.items():
+            setattr(self.cls, n, staticmethod(f))
+
+    def reset(self):
+        for n in self.names:
+            self.events[n].clear()
+            self.meta[n].clear()
+
+    def summary(self):
+        out = {}
+        for n in self.names:
+            if not self.events[n]:
+                continue
+            ms = [s.elapsed_time(e) for s, e in self.events[n]]
+            out[n] = dict(calls=len(ms), total_ms=float(sum(ms)), avg_us=float(np.mean(ms) * 1e3),
+                          units=float(np.mean(self.meta[n])))
+        return out
+
+
+def grid_meta(name, args):
+    # grid_encode_forward(inputs, embeddings, offsets, outputs, B, ...) / backward(grad, inputs, embeddings, offsets, ge, B, ...)
+    return args[4] if name == "grid_encode_forward" else args[5]
+
+
+# ----------------------------------------------------------------------------- CPU baseline (oracle port)
+def cpu_baseline(args, num_rays):
+    """the same training step (two-pass marching, hash encode, nn.Linear MLPs = the reference's `--ff`-off network,
+    composite, backward) on the host cores, native ops by the CPU oracle (OpenMP).  Bounded sample."""
+    from oracle import oracle_backend as ob
+    import raymarching.raymarching as rm
+    import gridencoder.grid as gg
+    import shencoder.sphere_harmonics as sh
+    from nerf import network, synthetic as syn
+    from nerf.trainer import Trainer
+    ob.build()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ob.set_threads(cores)
+    saved = (rm._backend, gg._backend, sh._backend)
+    rm._backend, gg._backend, sh._backend = ob.RaymarchingBackend, ob.GridBackend, ob.SHBackend
+    try:
+        torch.manual_seed(0)
+        net = network.NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10)
+        grid, bits = syn.lego_like_density_grid(seed=0)
+        net.density_grid.copy_(torch.from_numpy(grid))
+        net.density_bitfield.copy_(torch.from_numpy(bits))
+        net.iter_density = 100  # skip the full-sweep grid update: the sample is the steady-state step
+        tr = Trainer(net, fp16=False, update_extra_interval=10 ** 9)
+        tr.global_step = 1
+        boxes = syn.lego_like_boxes(0)
+        batches, _ = make_batches(2, num_rays, 0, "cpu", ob.RaymarchingBackend, torch.from_numpy(bits), boxes)
+        ro, rd, gt = batches[0]
+        tr.train_step(ro, rd, gt)  # warm-up
+        t0 = time.perf_counter()
+        samples = 0
+        for i in range(args.cpu_steps):
+            ro, rd, gt = batches[i % 2]
+            tr.train_step(ro, rd, gt)
+            samples += int(net.step_counter[(net.local_step - 1) % 16, 0])
+        dt = time.perf_counter() - t0
+    finally:
+        rm._backend, gg._backend, sh._backend = saved
+    return {"value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_steps} training steps x {num_rays} rays ({samples} samples, {dt:.1f} s) of the same synthetic "
+                      "scene, fp32, two-encoder nn.Linear network (the reference's --ff-off path), native ops = CPU oracle + OpenMP"}
+
+
+# ----------------------------------------------------------------------------- main
+def main():
+    args = parse()
+    from parallel import RayShardedDP, init_from_env
+    rank, world, local = init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import s3d_hip
+    s3d_hip.lib()
+    from nerf import network, network_ff, synthetic as syn
+    from nerf.trainer import Trainer, psnr
+    import torch.distributed as dist
+
+    torch.manual_seed(args.seed)
+    Net = network_ff.NeRFNetwork if args.net == "ff" else network.NeRFNetwork
+    model = Net(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).to(dev)
+    dp = RayShardedDP() if world > 1 else None
+    trainer = Trainer(model, lr=1e-2, fp16=True, update_extra_interval=16, dist=dp)
+
+    R = s3d_hip.RaymarchingBackend
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    scene_bits = torch.from_numpy(bits).to(dev)
+    boxes = syn.lego_like_boxes(0)
+    n_pool = 32
+    batches, poses = make_batches(n_pool, args.num_rays, args.seed + rank, dev, R, scene_bits, boxes)
+
+    def step(i):
+        ro, rd, gt = batches[i % n_pool]
+        if dp is not None and model.cuda_ray and trainer.global_step % 16 == 0:
+            loss = trainer.train_step(ro, rd, gt)
+            dp.sync_extra_state(model)
+            return loss
+        return trainer.train_step(ro, rd, gt)
+
+    # --- setup: converge the occupancy grid (untimed, not part of warm-up)
+    for i in range(args.pretrain):
+        step(i)
+    # --- warm-up
+    for i in range(args.warmup):
+        step(i)
+
+    timers = KernelTimers(s3d_hip.GridBackend, ["grid_encode_forward", "grid_encode_backward"])
+    timers.install(grid_meta)
+    rt = KernelTimers(s3d_hip.RaymarchingBackend, ["march_rays_train", "composite_rays_train_forward", "composite_rays_train_backward"])
+    rt.install(lambda n, a: 0)
+    ft = KernelTimers(s3d_hip.FFMLPBackend, ["ffmlp_forward", "ffmlp_backward"])
+    ft.install(lambda n, a: a[2] if n == "ffmlp_forward" else a[4])
+
+    samples_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+        samples_dev += model.step_counter[(model.local_step - 1) % 16, 0].long()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    for t in (timers, rt, ft):
+        t.remove()
+
+    samples = float(samples_dev.item())
+    if world > 1:
+        tt = torch.tensor([elapsed, samples], dtype=torch.float64, device=dev)
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        elapsed, samples = float(mx[0]), float(tt[1])
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # --- roofline of the dominant hot kernel
+    ksum = {}
+    for t in (timers, rt, ft):
+        ksum.update(t.summary())
+    s = 2  # fp16 tables under -O
+    bytes_pt = 12 + 16 * 8 * 2 * s + 16 * 2 * s  # 588 B / point / encoder
+    dom = max(("grid_encode_forward", "grid_encode_backward"), key=lambda n: ksum.get(n, {}).get("total_ms", 0))
+    kd = ksum[dom]
+    achieved = kd["units"] * bytes_pt / (kd["avg_us"] * 1e-6) / 1e9
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_us": kd["avg_us"], "points_per_launch": kd["units"],
+                "algorithmic_bytes_per_point": bytes_pt,
+                "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in ksum.items()}}
+
+    extra = {}
+    if not args.no_render:
+        # full 800x800 frame renders (inference loop) + PSNR against the analytic scene
+        r = syn.get_rays(poses[:1].to(dev), syn.lego_intrinsics(), 800, 800)
+        ro, rd = r["rays_o"].contiguous(), r["rays_d"].contiguous()
+        out = trainer.render_image(ro, rd)
+        torch.cuda.synchronize()
+        tr0 = time.perf_counter()
+        nfr = 3
+        for _ in range(nfr):
+            out = trainer.render_image(ro, rd)
+        torch.cuda.synchronize()
+        dtr = (time.perf_counter() - tr0) / nfr
+        gt = torch.cat([analytic_targets(ro[0, i:i + 160000].contiguous(), rd[0, i:i + 160000].contiguous(), scene_bits, boxes, R)
+                        for i in range(0, 640000, 160000)])
+        extra = {"render_mrays_per_s": 0.64 / dtr, "render_ms_per_frame": dtr * 1e3, "psnr_vs_analytic_scene": psnr(out["image"][0], gt)}
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, args.num_rays)
+
+    line = {
+        "metric": "train samples/s (NGP -O step on synthetic Lego 800x800 rays)", "value": samples / elapsed, "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": "configs[1]: nerf_synthetic/lego-shaped NGP -O (hashgrid L16 F2 T2^19 + ffmlp 64x2/64x3 + raymarching), "
+                               "800x800 cameras, 4096 rays/step/GPU" if args.net == "ff" else
+                               "Seal NGP net (two hash encoders + nn.Linear MLPs), 800x800 cameras, 4096 rays/step/GPU",
+                   "num_rays_per_gpu": args.num_rays, "samples_per_step": samples / args.steps / world,
+                   "parallelism": f"ray-sharded dp{world}", "pretrain_steps": args.pretrain},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    line.update(extra)
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,8 +35,10 @@ class _FFMLPForward(Function):
     def forward(ctx, inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
                 inference=False, calc_grad_inputs=False):
         B = inputs.shape[0]
-        inputs = inputs.contiguous()
-        weights = weights.contiguous()
+        # outside autocast `custom_fwd` does not cast: the kernels are fp16-only, so cast here (the autograd
+        # engine converts the returned fp16 gradients back to the parameter dtype)
+        inputs = inputs.to(torch.half).contiguous()
+        weights = weights.to(torch.half).contiguous()
         outputs = torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
         if inference:
             scratch = torch.empty(B, hidden_dim, device=inputs.device, dtype=inputs.dtype)

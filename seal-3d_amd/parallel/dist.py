@@ -1,0 +1,99 @@
+"""Ray/point-sharded data parallelism for the distillation / training step.
+
+The reference has no live multi-GPU path (dead DDP hooks only, nerf/utils.py:330-333).  The path shards
+naturally: every rank holds a full replica (tables 49 MB fp16, MLPs, bitfield), marches and shades its own
+slice of the rays (or pretraining points), and the only exchange is ONE sum all-reduce per step over a flat
+fp32 gradient bucket (hash-table + MLP grads, 98 MB for the Seal NGP net) — RCCL over xGMI on the GPU box
+(backend "nccl"), gloo in the CPU tests.  Parameter `.grad`s are views into the bucket, so backward writes
+straight into it and no gather/scatter copies are needed.  GradScaler consistency: gradients are reduced
+BEFORE `unscale_`, so an overflow on any rank makes the reduced gradient non-finite on every rank and all
+replicas skip the step together.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's environment; returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_slice(n, rank, world):
+    """contiguous shard [lo, hi) of n units for `rank` (remainder spread over the first ranks)"""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class RayShardedDP:
+    def __init__(self, group=None, average=True):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.average = average
+        self.flat = None
+        self.params = []
+
+    def register(self, model):
+        """broadcast rank 0's replica and re-home every parameter gradient inside one flat bucket"""
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if self.world > 1:
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, src=0, group=self.group)
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+        return self
+
+    def allreduce_grads(self, scaler=None):
+        if self.world == 1:
+            return
+        # safety: a grad that autograd re-allocated is copied back into its bucket slot
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            slot = self.flat[off:off + n]
+            if p.grad is None:
+                slot.zero_()
+                p.grad = slot.view_as(p)
+            elif p.grad.data_ptr() != slot.data_ptr():
+                slot.copy_(p.grad.reshape(-1))
+                p.grad = slot.view_as(p)
+            off += n
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.average:
+            self.flat.div_(self.world)
+
+    def sync_extra_state(self, model):
+        """keep the occupancy state identical on all replicas after `update_extra_state` (RNG differs per rank)"""
+        if self.world == 1 or not getattr(model, "cuda_ray", False):
+            return
+        dist.broadcast(model.density_grid, src=0, group=self.group)
+        dist.broadcast(model.density_bitfield, src=0, group=self.group)
+        t = torch.tensor([float(model.mean_count), float(model.mean_density)], device=model.density_grid.device)
+        dist.broadcast(t, src=0, group=self.group)
+        model.mean_count, model.mean_density = int(t[0].item()), float(t[1].item())
+
+    def all_reduce_scalar(self, value, op="sum"):
+        if self.world == 1:
+            return value
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.flat.device if self.flat is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=self.group)
+        return float(t.item())

@@ -1,0 +1,178 @@
+"""CPU: host logic of the build's wrappers / renderer / network / data-parallel layer, driven by the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+
+def test_grid_encoder_lego_layout(oracle_wrappers):
+    """offset table and parameter count of the Lego config (grid.py:117-131)"""
+    enc = oracle_wrappers.gg.GridEncoder(desired_resolution=2048)
+    assert enc.offsets.tolist()[:7] == [0, 4920, 18744, 51512, 136696, 352696, 876984]
+    assert int(enc.offsets[-1]) == 6119864 and enc.embeddings.shape == (6119864, 2)
+    assert abs(enc.per_level_scale - 1.381912879967776) < 1e-12
+    assert enc.output_dim == 32 and float(enc.embeddings.abs().max()) <= 1e-4
+
+
+def test_march_wrapper_contracts(oracle_wrappers):
+    """padding rule `m += align - m % align`, zero tails, budgeted M, counter semantics (raymarching.py:161-235)"""
+    from nerf import synthetic as syn
+    rm = oracle_wrappers.rm
+    _, bits = syn.lego_like_density_grid(seed=0)
+    bits = torch.from_numpy(bits)
+    poses = syn.orbit_poses(1, seed=0)
+    r = syn.get_rays(poses, syn.lego_intrinsics(), 800, 800, N=1024, generator=torch.Generator().manual_seed(0))
+    ro, rd = r["rays_o"][0], r["rays_d"][0]
+    nears, fars = rm.near_far_from_aabb(ro, rd, torch.tensor([-1.0, -1, -1, 1, 1, 1]), 0.2)
+    counter = torch.zeros(2, dtype=torch.int32)
+    xyzs, dirs, deltas, rays = rm.march_rays_train(ro, rd, 1.0, bits, 1, 128, nears, fars, counter, -1, False, 128, False, 0, 1024)
+    m = int(counter[0])
+    assert xyzs.shape[0] == m + 128 - m % 128 and (xyzs[m:] == 0).all() and int(counter[1]) == 1024
+    # budgeted call: M = aligned mean_count, overflowing rays dropped but still counted
+    counter2 = torch.zeros(2, dtype=torch.int32)
+    budget = m // 2
+    x2, _, _, rays2 = rm.march_rays_train(ro, rd, 1.0, bits, 1, 128, nears, fars, counter2, budget, False, 128, False, 0, 1024)
+    assert x2.shape[0] == budget + 128 - budget % 128 and int(counter2[0]) == m
+    assert torch.equal(rays2, rays)
+    fits = (rays2[:, 1] + rays2[:, 2]) <= x2.shape[0]
+    k = int(torch.nonzero(~fits)[0])
+    assert (x2[int(rays2[k - 1, 1] + rays2[k - 1, 2]):] == 0).all()
+    # composite through autograd
+    sig = torch.rand(xyzs.shape[0], requires_grad=True)
+    rgb = torch.rand(xyzs.shape[0], 3, requires_grad=True)
+    ws, depth, img = rm.composite_rays_train(sig, rgb, deltas, rays, 1e-4)
+    (img.sum() + ws.sum()).backward()
+    assert sig.grad.shape == sig.shape and (sig.grad[m:] == 0).all()
+
+
+def _tiny_net(oracle_wrappers, ff=False):
+    from nerf import network, network_ff
+    torch.manual_seed(0)
+    mod = network_ff if ff else network
+    net = mod.NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10)
+    return net
+
+
+def test_network_forward_and_param_count(oracle_wrappers):
+    net = _tiny_net(oracle_wrappers)
+    n = sum(p.numel() for p in net.parameters())
+    assert n == 24490848  # 2 x 12,239,728 + 3,072 + 8,320
+    keys = set(net.state_dict().keys())
+    for k in ("encoder.embeddings", "encoder.offsets", "encoder_color.embeddings", "sigma_net.0.weight", "sigma_net.1.weight",
+              "color_net.0.weight", "color_net.2.weight", "density_grid", "density_bitfield", "step_counter"):
+        assert k in keys
+    x = torch.rand(300, 3) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(300, 3), dim=-1)
+    sigma, rgb = net(x, d)
+    assert sigma.shape == (300,) and rgb.shape == (300, 3) and (sigma > 0).all() and ((rgb > 0) & (rgb < 1)).all()
+    assert torch.equal(net.density(x)["sigma"], sigma)
+
+
+def test_renderer_train_eval_and_density_update(oracle_wrappers):
+    """run_cuda training branch, inference loop (host compaction) and update_extra_state on the oracle backend"""
+    from nerf import synthetic as syn
+    net = _tiny_net(oracle_wrappers)
+    # fake a converged occupancy grid from the synthetic scene
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    net.density_grid.copy_(torch.from_numpy(grid))
+    net.density_bitfield.copy_(torch.from_numpy(bits))
+    poses = syn.orbit_poses(1, seed=0)
+    r = syn.get_rays(poses, syn.lego_intrinsics(64, 64), 64, 64)
+    ro, rd = r["rays_o"], r["rays_d"]
+    net.train()
+    out = net.render(ro, rd, bg_color=1, perturb=True, max_steps=1024)
+    assert out["image"].shape == (1, 4096, 3) and int(net.step_counter[0, 0]) > 0 and net.local_step == 1
+    out["image"].sum().backward()
+    assert net.encoder.embeddings.grad is not None and net.encoder_color.embeddings.grad.abs().sum() > 0
+    net.eval()
+    with torch.no_grad():
+        ev = net.render(ro, rd, bg_color=1, perturb=False, max_steps=1024)
+    assert ev["image"].shape == (1, 4096, 3) and torch.isfinite(ev["image"]).all()
+    # untouched background rays composite to the background colour
+    miss = out["weights_sum"].detach() == 0
+    assert miss.any() and torch.allclose(ev["image"][0][miss], torch.ones(3))
+    # density update: first call = full sweep over 128^3 cells
+    net.train()
+    torch.manual_seed(0)
+    net.reset_extra_state()
+    net.local_step = 3
+    net.step_counter[:3, 0] = torch.tensor([100, 200, 300], dtype=torch.int32)
+    net.update_extra_state()
+    assert net.iter_density == 1 and net.mean_count == 200 and net.local_step == 0
+    assert net.density_bitfield.shape == (128 ** 3 // 8,) and net.mean_density > 0
+    ref_bits = np.packbits((net.density_grid.numpy().reshape(-1) > np.float32(min(net.mean_density, net.density_thresh))).astype(np.uint8),
+                           bitorder="little")
+    assert np.array_equal(ref_bits, net.density_bitfield.numpy())
+
+
+def test_ffmlp_module_padding(oracle_wrappers):
+    ff = oracle_wrappers.ff
+    net = ff.FFMLP(32, 3, 64, 3)
+    assert net.num_parameters == 64 * (32 + 64 * 2 + 16) and net.padded_output_dim == 16
+    torch.manual_seed(42)
+    ref = torch.empty(net.num_parameters).uniform_(-np.sqrt(3 / 64), np.sqrt(3 / 64))
+    assert torch.equal(net.weights.data, ref)
+    x = torch.randn(200, 32)
+    net.train()
+    y = net(x.half())
+    assert y.shape == (200, 3)
+    net.eval()
+    assert torch.equal(net(x.half()), y)
+
+
+def test_shard_slice_partition():
+    from parallel import shard_slice
+    for n in (0, 1, 7, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            parts = [shard_slice(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(parts[:-1], parts[1:]))
+            assert max(p[1] - p[0] for p in parts) - min(p[1] - p[0] for p in parts) <= 1
+
+
+_DP_SCRIPT = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["S3D_REPO"]); sys.path.insert(0, os.path.join(os.environ["S3D_REPO"], "seal-3d_amd"))
+from parallel import RayShardedDP, init_from_env, shard_slice
+rank, world, _ = init_from_env("gloo")
+torch.manual_seed(100 + rank)            # replicas start DIFFERENT; register() must broadcast rank 0's
+model = torch.nn.Sequential(torch.nn.Linear(8, 16, bias=False), torch.nn.ReLU(), torch.nn.Linear(16, 3, bias=False))
+dp = RayShardedDP().register(model)
+g = torch.Generator().manual_seed(7)
+x, y = torch.randn(64, 8, generator=g), torch.randn(64, 3, generator=g)
+lo, hi = shard_slice(64, rank, world)
+loss = torch.nn.functional.mse_loss(model(x[lo:hi]), y[lo:hi], reduction="sum") / (64 * 3) * world
+loss.backward()
+dp.allreduce_grads()
+flat = dp.flat.clone()
+# single-process reference on the full batch with rank 0's weights
+ref = torch.nn.Sequential(torch.nn.Linear(8, 16, bias=False), torch.nn.ReLU(), torch.nn.Linear(16, 3, bias=False))
+ref.load_state_dict(model.state_dict())
+torch.nn.functional.mse_loss(ref(x), y).backward()
+ref_flat = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+ok = torch.allclose(flat, ref_flat, rtol=1e-5, atol=1e-6)
+w = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(w, torch.cat([p.data.reshape(-1) for p in model.parameters()]))
+same = all(torch.equal(w[0], t) for t in w)
+views = all(p.grad.data_ptr() >= dp.flat.data_ptr() for p in model.parameters())
+print(f"RANK{rank} ok={ok} same={same} views={views}")
+dist.destroy_process_group()
+'''
+
+
+def test_ray_sharded_dp_gloo_world2(tmp_path):
+    """world_size-2 gloo run: sharded-batch gradient after the flat-bucket all-reduce == full-batch gradient"""
+    script = tmp_path / "dp.py"
+    script.write_text(_DP_SCRIPT)
+    env = dict(os.environ, S3D_REPO=REPO, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stderr[-2000:]
+    for r in (0, 1):
+        assert f"RANK{r} ok=True same=True views=True" in res.stdout, res.stdout + res.stderr[-1500:]
