@@ -15,8 +15,17 @@
 //    half accumulators with one rounding per op like the reference's at::Half registers), so
 //    corner rows are bit-exact and outputs match the oracle to the last bit.
 //  * The per-level scale table is computed once on the host (glibc exp2f) and passed by value.
+//  * Backward.  Measured on MI355X: global fp atomics retire at a flat ~21 G/s chip-wide (memory-side,
+//    independent of table size or XCD locality) and LDS *float* atomics at ~0.2 T/s, while LDS *integer*
+//    atomics run at ~2.3 T/s (tools/ubench).  The table gradient is therefore accumulated in LDS as 64-bit
+//    fixed point: the table is cut into 160 KiB slices, one workgroup owns one (level, slice), scans all
+//    points, adds the contributions that land in its slice with ds_add_u64, and writes the slice back with
+//    coalesced stores.  Integer adds commute, so the result is bit-reproducible run to run (the reference's
+//    atomics are not) and carries ~40 bits below the largest |grad| of the level — more accurate than fp32
+//    atomics.  Small batches keep the direct-atomic kernel (fixed cost of the slice sweep ~25 us).
 #include "s3d_common.hpp"
 #include <math.h>
+#include <type_traits>
 
 namespace s3d {
 namespace {
@@ -279,6 +288,12 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_backward(const T* __restrict
         locate<D>(x, scale, align_corners, interp, pos, pd, pos_grid);
         T g[C];
         load_feat<T, C>(grad + ((size_t)level * B + b) * C, g);
+        // samples past a ray's early termination (and padding rows) carry exactly-zero gradients: adding zero is a
+        // no-op, and atomics are the bottleneck (~21 G/s chip-wide), so skip them
+        bool nonzero = false;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) nonzero |= (Acc<T>::to_f(g[c]) != 0.0f);
+        if (!nonzero) continue;
 #pragma unroll
         for (uint32_t idx = 0; idx < (1u << D); idx++) {
             float w = 1;
@@ -302,6 +317,261 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_backward(const T* __restrict
 #pragma unroll
                 for (uint32_t c = 0; c < C; c++) atomic_add_feat(reinterpret_cast<float*>(dst) + c, w * g[c]);
             }
+        }
+    }
+}
+
+
+// ---- LDS fixed-point backward -----------------------------------------------------------------------
+// v * 2^k as a 64-bit integer: v = m * 2^(ex-24) with a 24-bit integer mantissa m, so the product is a shift
+// (round-half-up when bits fall off the bottom).  Callers guarantee |v| * 2^k < 2^62.
+__device__ __forceinline__ long long to_fixed64(float v, int k) {
+    int ex;
+    const float f = frexpf(v, &ex);
+    const long long m = (long long)(int)ldexpf(f, 24);
+    const int sh = k + ex - 24;
+    if (sh >= 0) return m << sh;
+    if (sh > -26) return (m + (1ll << (-sh - 1))) >> (-sh);
+    return 0;
+}
+constexpr uint32_t kLdsBytes = 160 * 1024;
+constexpr uint32_t kBwdThreads = 1024;
+constexpr uint32_t kQueueLen = 192;                                   // per-wave hit queue entries (<64 pending + <=128 appended)
+constexpr uint32_t kQueueBytes = (kBwdThreads / 64) * kQueueLen * 4;  // 8 KiB at the top of the LDS allocation
+constexpr uint32_t kAccBytes = kLdsBytes - kQueueBytes;
+// Every workgroup scans all points, so its cost is (scan) + (hits); hits per workgroup = B * 2^D / slices(level).
+// Coarse levels have few rows: cutting them by LDS capacity alone would leave ONE workgroup with every hit of the
+// level (measured: the level-0 workgroup set the kernel time).  Each level is therefore cut into at least
+// kMinSlices slices — the slice count LDS capacity forces on a 2^19-row hashed level.
+__host__ __device__ constexpr uint32_t bwd_min_slices(uint32_t C) { return div_up<uint32_t>(1u << 19, kAccBytes / (8 * C)); }
+__host__ __device__ inline uint32_t bwd_slice_rows(uint32_t rows, uint32_t C) {
+    const uint32_t cap = kAccBytes / (8 * C);
+    uint32_t r = div_up<uint32_t>(div_up<uint32_t>(rows, bwd_min_slices(C)), 8u) * 8u;
+    return r < cap ? (r ? r : 8u) : cap;
+}
+
+// per-level max |grad| (bit pattern of a non-negative float is monotone as uint32)
+template <typename T>
+__global__ void __launch_bounds__(256) k_grad_absmax(const T* __restrict__ grad, uint32_t per_level, uint32_t* __restrict__ out) {
+    const T* g = grad + (size_t)blockIdx.y * per_level;
+    float m = 0.0f;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < per_level; i += gridDim.x * 256) {
+        const float v = fabsf(Acc<T>::to_f(g[i]));
+        m = (v > m || v != v) ? v : m;  // NaN propagates so that a poisoned gradient stays visible
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const float o = __shfl_xor(m, d, 64); m = (o > m || o != o) ? o : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out + blockIdx.y, __float_as_uint(m));
+}
+
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(kBwdThreads) k_grid_backward_lds(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                                  const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
+                                                                  uint32_t B, uint32_t L, LevelScales scales,
+                                                                  const uint32_t* __restrict__ absmax, uint32_t gridtype,
+                                                                  bool align_corners, uint32_t interp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);
+    // (level, slice) of this workgroup from the device offset table; the host launches an upper bound
+    // ceil(total_rows / slice) + L workgroups, the surplus exits here
+    uint32_t level = 0, first = 0, slice_rows = 0;
+    for (;; level++) {
+        if (level == L) return;
+        const uint32_t rows = (uint32_t)(offsets[level + 1] - offsets[level]);
+        slice_rows = bwd_slice_rows(rows, C);
+        const uint32_t ns = div_up<uint32_t>(rows, slice_rows);
+        if (blockIdx.x < first + ns) break;
+        first += ns;
+    }
+    const uint32_t slice = blockIdx.x - first;
+    const uint32_t off = (uint32_t)offsets[level];
+    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
+    const uint32_t row0 = slice * slice_rows;
+    const uint32_t nrows = min(slice_rows, hashmap_size - row0);
+
+    const float amax = __uint_as_float(absmax[level]);
+    if (!(amax > 0.0f)) {
+        if (amax != amax || amax == INFINITY) {  // non-finite gradient: poison the slice like a float sum would
+            for (uint32_t i = threadIdx.x; i < nrows * C; i += kBwdThreads)
+                grad_grid[((size_t)off + row0) * C + i] = Acc<T>::from_f(NAN);
+        }
+        return;  // all-zero gradient: nothing to add
+    }
+    if (amax == INFINITY) {
+        for (uint32_t i = threadIdx.x; i < nrows * C; i += kBwdThreads) grad_grid[((size_t)off + row0) * C + i] = Acc<T>::from_f(NAN);
+        return;
+    }
+    // |sum| <= B * 2^D * amax < 2^62 : pick the power-of-two scale accordingly
+    int e;
+    (void)frexpf(amax, &e);  // amax < 2^e
+    const int kexp = 62 - e - (int)(32 - __clz(B)) - (int)D;
+    const double inv_scale = ldexp(1.0, -kexp);
+
+    for (uint32_t i = threadIdx.x; i < nrows * C; i += kBwdThreads) acc[i] = 0ull;
+    __syncthreads();
+
+    const float lscale = scales.v[level];
+    const uint32_t resolution = (uint32_t)ceilf(lscale) + 1;
+    const T* glevel = grad + (size_t)level * B * C;
+
+    // Level-uniform index plan, hoisted out of the point loop (get_grid_index, gridencoder.cu:66-84):
+    // which dimensions enter the dense index (the stride loop stops once stride > hashmap_size), their strides,
+    // and whether the level is hashed.  `row % hashmap_size` becomes a mask when the size is a power of two and a
+    // no-op test for dense levels (index < rows by construction).
+    uint32_t stride[D];
+    uint32_t st = 1;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        if (st <= hashmap_size) { stride[d] = st; st *= align_corners ? resolution : (resolution + 1); }
+        else stride[d] = 0;  // dimension dropped from the dense index
+    }
+    const bool hashed = (gridtype == 0 && st > hashmap_size);
+    const bool pow2 = (hashmap_size & (hashmap_size - 1)) == 0;
+    const uint32_t mask = hashmap_size - 1;
+
+    // Hits are sparse (~2^D/slices per point) and scattered over lanes: executing the accumulate body under
+    // divergence costs a wave-iteration per hit-bearing lane (measured 3x the scan itself).  Instead every wave
+    // appends its hits (point, corner) to a small LDS queue (wave prefix sum of per-lane hit counts) and drains the
+    // queue 64 entries at a time with all lanes busy.
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* queue = reinterpret_cast<uint32_t*>(smem_raw + kLdsBytes - kQueueBytes) + wave * kQueueLen;
+
+    // The scan loop is specialised on the (workgroup-uniform) index mode so its body carries no selects:
+    //   MODE 0: hashed level, power-of-two rows (row = xor-hash & mask)      — the eleven 2^19-row levels
+    //   MODE 1: dense level (row = sum of strides; `% rows` only if index >= rows)
+    //   MODE 2: anything else (generic get_grid_index semantics)
+    auto row_of = [&](auto mode, const uint32_t (&lo)[D], const uint32_t (&hi)[D], uint32_t idx) -> uint32_t {
+        constexpr int MODE = decltype(mode)::value;
+        uint32_t index = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            const uint32_t t = ((idx >> d) & 1u) ? hi[d] : lo[d];
+            if (MODE == 0) index ^= t;
+            else if (MODE == 1) index += t;
+            else index = hashed ? (index ^ t) : (index + t);
+        }
+        if (MODE == 0) return index & mask;
+        if (MODE == 1) return (index < hashmap_size) ? index : index % hashmap_size;
+        return pow2 ? (index & mask) : ((index < hashmap_size) ? index : index % hashmap_size);
+    };
+    auto corner_terms = [&](auto mode, const uint32_t (&pos_grid)[D], uint32_t (&lo)[D], uint32_t (&hi)[D]) {
+        constexpr int MODE = decltype(mode)::value;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            const bool h = (MODE == 0) || (MODE == 2 && hashed);
+            if (h) { lo[d] = pos_grid[d] * kPrimes[d]; hi[d] = lo[d] + kPrimes[d]; }
+            else { lo[d] = pos_grid[d] * stride[d]; hi[d] = lo[d] + stride[d]; }
+        }
+    };
+
+    auto run = [&](auto mode) {
+        uint32_t qlen = 0;  // wave-uniform
+        auto drain = [&](uint32_t first, uint32_t count) {  // lanes [0,count) take entries first..first+count-1
+            if (lane < count) {
+                const uint32_t ent = queue[first + lane];
+                const uint32_t b = ent >> D, idx = ent & ((1u << D) - 1);
+                float x[D], pos[D], pd[D];
+                uint32_t pos_grid[D], lo[D], hi[D];
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
+                locate<D>(x, lscale, align_corners, interp, pos, pd, pos_grid);
+                corner_terms(mode, pos_grid, lo, hi);
+                const uint32_t local = row_of(mode, lo, hi, idx) - row0;
+                float w = 1;
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) w *= ((idx >> d) & 1u) ? pos[d] : 1 - pos[d];
+                T g[C];
+                load_feat<T, C>(glevel + (size_t)b * C, g);
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) {
+                    // same product the reference forms (float w * grad), then exact scaling to 64-bit fixed point
+                    float prod;
+                    if constexpr (sizeof(T) == 2) prod = __half2float(__float2half(w * __half2float(g[c])));
+                    else prod = w * g[c];
+                    atomicAdd(&acc[local * C + c], (unsigned long long)to_fixed64(prod, kexp));
+                }
+            }
+        };
+        auto scan = [&](uint32_t b, const float (&x)[D]) {
+            bool oob = false;
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) oob |= (x[d] < 0 || x[d] > 1);
+            float pos[D], pd[D];
+            uint32_t pos_grid[D], lo[D], hi[D];
+            locate<D>(x, lscale, align_corners, interp, pos, pd, pos_grid);
+            corner_terms(mode, pos_grid, lo, hi);
+            uint32_t hits = 0;
+#pragma unroll
+            for (uint32_t idx = 0; idx < (1u << D); idx++)
+                hits |= ((row_of(mode, lo, hi, idx) - row0) < nrows ? 1u : 0u) << idx;
+            if (oob) hits = 0;
+            if (__ballot(hits != 0) == 0) return;
+            // wave prefix sum of per-lane hit counts -> queue slots
+            // exclusive prefix sum of the per-lane hit counts (<= 2^D, i.e. D+1 bits) from ballots of the count bits:
+            // pure VALU/SALU, no cross-lane LDS traffic (a shuffle ladder costs ~6 dependent ds_bpermute round trips)
+            const uint32_t cnt = __popc(hits);
+            uint32_t excl = 0, total = 0;
+#pragma unroll
+            for (uint32_t k = 0; k <= D; k++) {
+                const unsigned long long mk = __ballot((cnt >> k) & 1u);
+                excl += __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u)) << k;
+                total += (uint32_t)__popcll(mk) << k;
+            }
+            uint32_t slot = qlen + excl;
+            if (total <= kQueueLen - 64) {
+                while (hits) {
+                    const uint32_t idx = __builtin_ctz(hits);
+                    hits &= hits - 1;
+                    queue[slot++] = (b << D) | idx;
+                }
+                qlen += total;
+                while (qlen >= 64) { qlen -= 64; drain(qlen, 64); }
+            } else {  // pathological density (e.g. many identical points): one corner at a time
+#pragma unroll 1
+                for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                    const bool hit = (hits >> idx) & 1u;
+                    const unsigned long long m = __ballot(hit);
+                    if (hit) queue[qlen + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (b << D) | idx;
+                    qlen += (uint32_t)__popcll(m);
+                    if (qlen >= 64) { qlen -= 64; drain(qlen, 64); }
+                }
+            }
+        };
+        // Point loop.  Each workgroup starts at its own offset: all workgroups read the SAME point array, and
+        // starting in phase makes every CU hit the same L2 lines at the same time.
+        constexpr uint32_t kUnroll = 4;
+        const uint32_t per_round = kBwdThreads * kUnroll;
+        const uint32_t rounds = div_up<uint32_t>(B, per_round);
+        const uint32_t start_round = (uint32_t)(((uint64_t)blockIdx.x * 2654435761ull) % rounds);
+        for (uint32_t r = 0; r < rounds; r++) {
+            uint32_t rr = start_round + r;
+            if (rr >= rounds) rr -= rounds;
+            const uint32_t b0 = rr * per_round + threadIdx.x;
+            float xs[kUnroll][D];
+#pragma unroll
+            for (uint32_t u = 0; u < kUnroll; u++) {
+                const uint32_t b = b0 + u * kBwdThreads;
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) xs[u][d] = (b < B) ? inputs[(size_t)b * D + d] : -1.0f;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < kUnroll; u++) scan(b0 + u * kBwdThreads, xs[u]);
+        }
+        drain(0, qlen);
+    };
+    bool all_dims = true;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) all_dims &= (stride[d] != 0);
+    if (hashed && pow2) run(std::integral_constant<int, 0>{});
+    else if (!hashed && all_dims) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
+    __syncthreads();
+    T* dst = grad_grid + ((size_t)off + row0) * C;
+    for (uint32_t i = threadIdx.x; i < nrows * C; i += kBwdThreads) {
+        const long long q = (long long)acc[i];
+        if (q != 0) {
+            const float add = (float)((double)q * inv_scale);
+            dst[i] = Acc<T>::from_f(Acc<T>::to_f(dst[i]) + add);
         }
     }
 }
@@ -410,12 +680,33 @@ int launch_forward(const float* inputs, const T* emb, const int32_t* offsets, T*
     return check_launch("grid_encode_forward");
 }
 
+constexpr uint32_t kLdsBackwardMinPoints = 8192;  // below this the direct-atomic kernel wins (fixed sweep cost)
+
 template <typename T, uint32_t D, uint32_t C>
-int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets, T* grad_emb, uint32_t B, uint32_t L,
-                      const LevelScales& sc, const T* dy_dx, T* grad_inputs, uint32_t gridtype, bool ac, uint32_t interp,
-                      hipStream_t st) {
-    hipLaunchKernelGGL((k_grid_backward<T, D, C>), dim3(xcd_grid(B)), dim3(kFwdBlock), 0, st, grad, inputs, offsets,
-                       grad_emb, B, L, sc, gridtype, ac, interp);
+int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets, uint32_t table_rows, T* grad_emb,
+                      uint32_t B, uint32_t L, const LevelScales& sc, const T* dy_dx, T* grad_inputs, uint32_t gridtype, bool ac,
+                      uint32_t interp, uint32_t* ws, int force_path, hipStream_t st) {
+    const bool use_lds = force_path == 2 || (force_path == 0 && B >= kLdsBackwardMinPoints && table_rows && ws);
+    if (use_lds) {
+        // upper bound on the number of (level, slice) workgroups: capacity slices + per-level minimum + remainders
+        const uint32_t nb = div_up<uint32_t>(table_rows, kAccBytes / (8 * C)) + L * (bwd_min_slices(C) + 1);
+        S3D_HIP(hipMemsetAsync(ws, 0, sizeof(uint32_t) * kMaxLevels, st));
+        const uint32_t per_level = B * C;
+        uint32_t gx = div_up<uint32_t>(per_level, 256 * 8);
+        if (gx > 256) gx = 256;
+        hipLaunchKernelGGL((k_grad_absmax<T>), dim3(gx, L), dim3(256), 0, st, grad, per_level, ws);
+        static bool attr_set = false;
+        if (!attr_set) {
+            S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_backward_lds<T, D, C>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((k_grid_backward_lds<T, D, C>), dim3(nb), dim3(kBwdThreads), kLdsBytes, st, grad, inputs, offsets,
+                           grad_emb, B, L, sc, (const uint32_t*)ws, gridtype, ac, interp);
+    } else {
+        hipLaunchKernelGGL((k_grid_backward<T, D, C>), dim3(xcd_grid(B)), dim3(kFwdBlock), 0, st, grad, inputs, offsets,
+                           grad_emb, B, L, sc, gridtype, ac, interp);
+    }
     if (dy_dx && grad_inputs)
         hipLaunchKernelGGL((k_grid_input_backward<T, D, C>), dim3(div_up<uint32_t>(B * D, 256)), dim3(256), 0, st, grad,
                            dy_dx, grad_inputs, B, L);
@@ -423,18 +714,18 @@ int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets
 }
 
 template <typename T, uint32_t D>
-int launch_backward(const T* grad, const float* inputs, const int32_t* offsets, T* grad_emb, uint32_t B, uint32_t C,
-                    uint32_t L, const LevelScales& sc, const T* dy_dx, T* grad_inputs, uint32_t gridtype, bool ac,
-                    uint32_t interp, hipStream_t st) {
+int launch_backward(const T* grad, const float* inputs, const int32_t* offsets, uint32_t table_rows, T* grad_emb,
+                    uint32_t B, uint32_t C, uint32_t L, const LevelScales& sc, const T* dy_dx, T* grad_inputs, uint32_t gridtype,
+                    bool ac, uint32_t interp, uint32_t* ws, int force_path, hipStream_t st) {
     switch (C) {
         case 1:
             if constexpr (sizeof(T) == 2) {
                 set_error("GridEncoding: fp16 tables need an even C (the reference forces fp32 when C is odd, grid.py:42)");
                 return S3D_ERR_UNSUPPORTED;
-            } else return launch_backward_c<T, D, 1>(grad, inputs, offsets, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, st);
-        case 2: return launch_backward_c<T, D, 2>(grad, inputs, offsets, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, st);
-        case 4: return launch_backward_c<T, D, 4>(grad, inputs, offsets, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, st);
-        case 8: return launch_backward_c<T, D, 8>(grad, inputs, offsets, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, st);
+            } else return launch_backward_c<T, D, 1>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, force_path, st);
+        case 2: return launch_backward_c<T, D, 2>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, force_path, st);
+        case 4: return launch_backward_c<T, D, 4>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, force_path, st);
+        case 8: return launch_backward_c<T, D, 8>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, force_path, st);
         default: set_error("GridEncoding: C must be 1, 2, 4, or 8."); return S3D_ERR_UNSUPPORTED;
     }
 }
@@ -526,34 +817,45 @@ S3D_EXPORT int s3d_grid_corner_indices(const float* inputs, const int32_t* offse
                    (launch_corner_rows<5>(inputs, offsets, corner_idx, B, L, sc, gridtype, ac, st)))
 }
 
+S3D_EXPORT size_t s3d_grid_encode_backward_workspace_size(void) { return sizeof(uint32_t) * kMaxLevels; }
+
+// process-wide override for experiments/tests: 0 = auto, 1 = direct atomics, 2 = LDS fixed-point sweep
+static int g_backward_path = 0;
+S3D_EXPORT void s3d_grid_backward_set_path(int path) { g_backward_path = path; }
+
 S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
-                                        const int32_t* offsets, void* grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
-                                        uint32_t L, float S, uint32_t H, const void* dy_dx, void* grad_inputs,
-                                        uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                        const int32_t* offsets, void* grad_embeddings, uint32_t table_rows,
+                                        uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                        const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                                        uint32_t interp, int dtype, void* workspace, size_t workspace_bytes,
                                         s3d_stream_t stream) {
     (void)embeddings;
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null pointer");
     S3D_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_backward: L must be in [1, %u]", kMaxLevels);
     S3D_REQUIRE(dtype == S3D_F32 || dtype == S3D_F16, "grid_encode_backward: dtype must be f32 or f16");
+    S3D_REQUIRE(!workspace || workspace_bytes >= s3d_grid_encode_backward_workspace_size(), "grid_encode_backward: workspace too small");
+    S3D_REQUIRE(g_backward_path != 2 || (workspace && table_rows), "grid_encode_backward: LDS path needs table_rows and a workspace");
     LevelScales sc;
     host_scales(L, S, H, sc);
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
+    uint32_t* ws = (uint32_t*)workspace;
+    const int fp = g_backward_path;
     if (dtype == S3D_F32) {
         const float* g = (const float*)grad; float* ge = (float*)grad_embeddings;
         const float* j = (const float*)dy_dx; float* gi = (float*)grad_inputs;
-        S3D_DISPATCH_D(D, (launch_backward<float, 2>(g, inputs, offsets, ge, B, C, L, sc, j, gi, gridtype, ac, interp, st)),
-                       (launch_backward<float, 3>(g, inputs, offsets, ge, B, C, L, sc, j, gi, gridtype, ac, interp, st)),
-                       (launch_backward<float, 4>(g, inputs, offsets, ge, B, C, L, sc, j, gi, gridtype, ac, interp, st)),
-                       (launch_backward<float, 5>(g, inputs, offsets, ge, B, C, L, sc, j, gi, gridtype, ac, interp, st)))
+        S3D_DISPATCH_D(D, (launch_backward<float, 2>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)),
+                       (launch_backward<float, 3>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)),
+                       (launch_backward<float, 4>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)),
+                       (launch_backward<float, 5>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)))
     } else {
         const __half* g = (const __half*)grad; __half* ge = (__half*)grad_embeddings;
         const __half* j = (const __half*)dy_dx; __half* gi = (__half*)grad_inputs;
-        S3D_DISPATCH_D(D, (launch_backward<__half, 2>(g, inputs, offsets, ge, B, C, L, sc, j, gi, gridtype, ac, interp, st)),
-                       (launch_backward<__half, 3>(g, inputs, offsets, ge, B, C, L, sc, j, gi, gridtype, ac, interp, st)),
-                       (launch_backward<__half, 4>(g, inputs, offsets, ge, B, C, L, sc, j, gi, gridtype, ac, interp, st)),
-                       (launch_backward<__half, 5>(g, inputs, offsets, ge, B, C, L, sc, j, gi, gridtype, ac, interp, st)))
+        S3D_DISPATCH_D(D, (launch_backward<__half, 2>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)),
+                       (launch_backward<__half, 3>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)),
+                       (launch_backward<__half, 4>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)),
+                       (launch_backward<__half, 5>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)))
     }
 }
 

@@ -31,6 +31,7 @@ EXPORTS = [
     "s3d_composite_rays_train_forward", "s3d_composite_rays_train_backward",
     "s3d_march_rays", "s3d_composite_rays", "s3d_compact_alive_workspace_size", "s3d_compact_alive",
     "s3d_grid_level_scales", "s3d_grid_encode_forward", "s3d_grid_corner_indices", "s3d_grid_encode_backward",
+    "s3d_grid_encode_backward_workspace_size", "s3d_grid_backward_set_path",
     "s3d_grad_total_variation",
     "s3d_sh_encode_forward", "s3d_sh_encode_backward", "s3d_freq_encode_forward", "s3d_freq_encode_backward",
     "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
@@ -61,7 +62,7 @@ def lib():
         l.s3d_last_error.restype = C.c_char_p
         l.s3d_version.restype = C.c_char_p
         for name in ("s3d_march_rays_train_workspace_size", "s3d_compact_alive_workspace_size",
-                     "s3d_ffmlp_backward_workspace_size"):
+                     "s3d_ffmlp_backward_workspace_size", "s3d_grid_encode_backward_workspace_size"):
             getattr(l, name).restype = C.c_size_t
         l.s3d_grid_level_scales.restype = None
         _lib = l
@@ -242,11 +243,17 @@ class GridBackend:
         _need(inputs, torch.float32, "inputs")
         if grad_embeddings.dtype != grad.dtype:
             raise RuntimeError("grad_embeddings must have the dtype of grad")
+        ws = _ws.get(lib().s3d_grid_encode_backward_workspace_size(), grad.device)
         _check(lib().s3d_grid_encode_backward(_p(grad), _p(inputs), _p(embeddings), _p(offsets),
-                                              _p(grad_embeddings), _u(B), _u(D), _u(Cc), _u(L), _f(S), _u(H),
-                                              _p(dy_dx), _p(grad_inputs), _u(gridtype),
-                                              C.c_int(int(align_corners)), _u(interp), C.c_int(_dt(grad)),
-                                              _stream()), "grid_encode_backward")
+                                              _p(grad_embeddings), _u(grad_embeddings.shape[0]), _u(B), _u(D),
+                                              _u(Cc), _u(L), _f(S), _u(H), _p(dy_dx), _p(grad_inputs), _u(gridtype),
+                                              C.c_int(int(align_corners)), _u(interp), C.c_int(_dt(grad)), _p(ws),
+                                              C.c_size_t(ws.numel()), _stream()), "grid_encode_backward")
+
+    @staticmethod
+    def set_backward_path(path):
+        """0 = auto, 1 = direct global atomics, 2 = LDS fixed-point sweep (tests / experiments)"""
+        lib().s3d_grid_backward_set_path(C.c_int(int(path)))
 
     @staticmethod
     def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, Cc, L, S, H, gridtype, align_corners):

@@ -47,7 +47,7 @@ def main():
     for dtype in (torch.float16, torch.float32):
         s = 2 if dtype == torch.float16 else 4
         emb = (torch.rand(total, 2, device=dev) * 2e-4 - 1e-4).to(dtype)
-        for B in (1 << 18, 1 << 21, 1 << 22):
+        for B in (1 << 15, 1 << 17, 1 << 18, 1 << 21):
             x = torch.rand(B, 3, device=dev)
             out = torch.empty(16, B, 2, device=dev, dtype=dtype)
             t = timeit(lambda: G.grid_encode_forward(x, emb, offs, out, B, 3, 2, 16, S, 16, None, 0, False, 0))
@@ -55,8 +55,13 @@ def main():
             print(f"grid_fwd {dtype} B={B}: {t*1e6:9.1f} us  {B/t/1e9:7.3f} Gpts/s  {B*bytes_pt/t/1e9:8.1f} GB/s algorithmic ({B*bytes_pt/t/8e12*100:.1f}% of 8 TB/s)")
             grad = torch.randn(16, B, 2, device=dev).to(dtype)
             ge = torch.zeros(total, 2, device=dev, dtype=dtype)
-            t = timeit(lambda: G.grid_encode_backward(grad, x, emb, offs, ge, B, 3, 2, 16, S, 16, None, None, 0, False, 0))
-            print(f"grid_bwd {dtype} B={B}: {t*1e6:9.1f} us  {B/t/1e9:7.3f} Gpts/s  {B*bytes_pt/t/1e9:8.1f} GB/s algorithmic")
+            for path in (1, 2):
+                if path == 1 and B > (1 << 18):
+                    continue
+                G.set_backward_path(path)
+                t = timeit(lambda: G.grid_encode_backward(grad, x, emb, offs, ge, B, 3, 2, 16, S, 16, None, None, 0, False, 0), iters=5)
+                print(f"grid_bwd[{'atomics' if path == 1 else 'lds-fixp'}] {dtype} B={B}: {t*1e6:9.1f} us  {B/t/1e9:7.3f} Gpts/s  {B*bytes_pt/t/1e9:8.1f} GB/s algorithmic")
+            G.set_backward_path(0)
     # coherent points (samples along rays) as in training
     grid, bits = syn.lego_like_density_grid(seed=0)
     bits = torch.from_numpy(bits).to(dev)
