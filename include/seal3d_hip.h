@@ -132,7 +132,7 @@ int s3d_grid_corner_indices(const float* inputs, const int32_t* offsets, uint32_
  * table_rows = rows of the embedding table (offsets[L], known to the host from the tensor shape).
  * workspace (s3d_grid_encode_backward_workspace_size bytes) enables the LDS fixed-point sweep used for
  * B >= 8192: deterministic, no global atomics; without it (NULL) direct atomics are used. */
-size_t s3d_grid_encode_backward_workspace_size(void);
+size_t s3d_grid_encode_backward_workspace_size(uint32_t B);
 int s3d_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
                              const int32_t* offsets, void* grad_embeddings, uint32_t table_rows, uint32_t B,
                              uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void* dy_dx,

@@ -350,6 +350,23 @@ __host__ __device__ inline uint32_t bwd_slice_rows(uint32_t rows, uint32_t C) {
     return r < cap ? (r ? r : 8u) : cap;
 }
 
+// Points are re-packed to one 16-byte record each before the sweep: measured on MI355X a wave-level vector load
+// costs ~20 cycles of address-unit time per instruction regardless of width, and a 12-byte-stride [B,3] read is
+// three of them per point (0.34 ns/point/CU) against 0.15 for one aligned float4 — and the sweep reads every point
+// once per (level, slice) workgroup.  Out-of-range points are encoded as NaN.x so the sweep needs no range test.
+template <uint32_t D>
+__global__ void __launch_bounds__(256) k_pack_points(const float* __restrict__ inputs, uint32_t B, float4* __restrict__ packed) {
+    static_assert(D <= 4, "packed record holds up to 4 coordinates");
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    float x[4] = {0, 0, 0, 0};
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) { x[d] = inputs[(size_t)b * D + d]; oob |= (x[d] < 0 || x[d] > 1); }
+    if (oob) x[0] = NAN;
+    packed[b] = make_float4(x[0], x[1], x[2], x[3]);
+}
+
 // per-level max |grad| (bit pattern of a non-negative float is monotone as uint32)
 template <typename T>
 __global__ void __launch_bounds__(256) k_grad_absmax(const T* __restrict__ grad, uint32_t per_level, uint32_t* __restrict__ out) {
@@ -366,6 +383,7 @@ __global__ void __launch_bounds__(256) k_grad_absmax(const T* __restrict__ grad,
 
 template <typename T, uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(kBwdThreads) k_grid_backward_lds(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                                  const float4* __restrict__ packed,
                                                                   const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
                                                                   uint32_t B, uint32_t L, LevelScales scales,
                                                                   const uint32_t* __restrict__ absmax, uint32_t gridtype,
@@ -495,7 +513,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_grid_backward_lds(const T* __re
         auto scan = [&](uint32_t b, const float (&x)[D]) {
             bool oob = false;
 #pragma unroll
-            for (uint32_t d = 0; d < D; d++) oob |= (x[d] < 0 || x[d] > 1);
+            for (uint32_t d = 0; d < D; d++) oob |= !(x[d] >= 0 && x[d] <= 1);  // also true for the NaN marker
             float pos[D], pd[D];
             uint32_t pos_grid[D], lo[D], hi[D];
             locate<D>(x, lscale, align_corners, interp, pos, pd, pos_grid);
@@ -539,23 +557,42 @@ __global__ void __launch_bounds__(kBwdThreads) k_grid_backward_lds(const T* __re
         };
         // Point loop.  Each workgroup starts at its own offset: all workgroups read the SAME point array, and
         // starting in phase makes every CU hit the same L2 lines at the same time.
-        constexpr uint32_t kUnroll = 4;
+        constexpr uint32_t kUnroll = 2;
         const uint32_t per_round = kBwdThreads * kUnroll;
         const uint32_t rounds = div_up<uint32_t>(B, per_round);
         const uint32_t start_round = (uint32_t)(((uint64_t)blockIdx.x * 2654435761ull) % rounds);
-        for (uint32_t r = 0; r < rounds; r++) {
+        auto fetch = [&](uint32_t r, float (&xs)[kUnroll][D]) {
             uint32_t rr = start_round + r;
             if (rr >= rounds) rr -= rounds;
             const uint32_t b0 = rr * per_round + threadIdx.x;
-            float xs[kUnroll][D];
 #pragma unroll
             for (uint32_t u = 0; u < kUnroll; u++) {
                 const uint32_t b = b0 + u * kBwdThreads;
+                if constexpr (D <= 4) {
+                    const float4 p = (b < B) ? packed[b] : make_float4(-1.0f, 0, 0, 0);
+                    const float v[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
-                for (uint32_t d = 0; d < D; d++) xs[u][d] = (b < B) ? inputs[(size_t)b * D + d] : -1.0f;
+                    for (uint32_t d = 0; d < D; d++) xs[u][d] = v[d];
+                } else {
+#pragma unroll
+                    for (uint32_t d = 0; d < D; d++) xs[u][d] = (b < B) ? inputs[(size_t)b * D + d] : -1.0f;
+                }
             }
+            return b0;
+        };
+        // software pipeline: the loads of round r+1 are in flight while round r is scanned (PMC: 48 % of the wave
+        // cycles were s_waitcnt stalls with the loads issued at the top of the same round)
+        float cur[kUnroll][D], nxt[kUnroll][D];
+        uint32_t b_cur = fetch(0, cur), b_nxt = 0;
+        for (uint32_t r = 0; r < rounds; r++) {
+            if (r + 1 < rounds) b_nxt = fetch(r + 1, nxt);
 #pragma unroll
-            for (uint32_t u = 0; u < kUnroll; u++) scan(b0 + u * kBwdThreads, xs[u]);
+            for (uint32_t u = 0; u < kUnroll; u++) scan(b_cur + u * kBwdThreads, cur[u]);
+#pragma unroll
+            for (uint32_t u = 0; u < kUnroll; u++)
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) cur[u][d] = nxt[u][d];
+            b_cur = b_nxt;
         }
         drain(0, qlen);
     };
@@ -685,12 +722,16 @@ constexpr uint32_t kLdsBackwardMinPoints = 8192;  // below this the direct-atomi
 template <typename T, uint32_t D, uint32_t C>
 int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets, uint32_t table_rows, T* grad_emb,
                       uint32_t B, uint32_t L, const LevelScales& sc, const T* dy_dx, T* grad_inputs, uint32_t gridtype, bool ac,
-                      uint32_t interp, uint32_t* ws, int force_path, hipStream_t st) {
-    const bool use_lds = force_path == 2 || (force_path == 0 && B >= kLdsBackwardMinPoints && table_rows && ws);
+                      uint32_t interp, uint32_t* ws, size_t ws_bytes, int force_path, hipStream_t st) {
+    const bool ws_ok = ws && ws_bytes >= 256 + (size_t)B * 16;
+    const bool use_lds = (force_path == 2 && ws_ok && table_rows) || (force_path == 0 && B >= kLdsBackwardMinPoints && table_rows && ws_ok);
     if (use_lds) {
         // upper bound on the number of (level, slice) workgroups: capacity slices + per-level minimum + remainders
         const uint32_t nb = div_up<uint32_t>(table_rows, kAccBytes / (8 * C)) + L * (bwd_min_slices(C) + 1);
         S3D_HIP(hipMemsetAsync(ws, 0, sizeof(uint32_t) * kMaxLevels, st));
+        float4* packed = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(ws) + 256);
+        if constexpr (D <= 4)
+            hipLaunchKernelGGL((k_pack_points<D>), dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, st, inputs, B, packed);
         const uint32_t per_level = B * C;
         uint32_t gx = div_up<uint32_t>(per_level, 256 * 8);
         if (gx > 256) gx = 256;
@@ -701,8 +742,8 @@ int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_grid_backward_lds<T, D, C>), dim3(nb), dim3(kBwdThreads), kLdsBytes, st, grad, inputs, offsets,
-                           grad_emb, B, L, sc, (const uint32_t*)ws, gridtype, ac, interp);
+        hipLaunchKernelGGL((k_grid_backward_lds<T, D, C>), dim3(nb), dim3(kBwdThreads), kLdsBytes, st, grad, inputs,
+                           (const float4*)packed, offsets, grad_emb, B, L, sc, (const uint32_t*)ws, gridtype, ac, interp);
     } else {
         hipLaunchKernelGGL((k_grid_backward<T, D, C>), dim3(xcd_grid(B)), dim3(kFwdBlock), 0, st, grad, inputs, offsets,
                            grad_emb, B, L, sc, gridtype, ac, interp);
@@ -716,16 +757,16 @@ int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets
 template <typename T, uint32_t D>
 int launch_backward(const T* grad, const float* inputs, const int32_t* offsets, uint32_t table_rows, T* grad_emb,
                     uint32_t B, uint32_t C, uint32_t L, const LevelScales& sc, const T* dy_dx, T* grad_inputs, uint32_t gridtype,
-                    bool ac, uint32_t interp, uint32_t* ws, int force_path, hipStream_t st) {
+                    bool ac, uint32_t interp, uint32_t* ws, size_t ws_bytes, int force_path, hipStream_t st) {
     switch (C) {
         case 1:
             if constexpr (sizeof(T) == 2) {
                 set_error("GridEncoding: fp16 tables need an even C (the reference forces fp32 when C is odd, grid.py:42)");
                 return S3D_ERR_UNSUPPORTED;
-            } else return launch_backward_c<T, D, 1>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, force_path, st);
-        case 2: return launch_backward_c<T, D, 2>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, force_path, st);
-        case 4: return launch_backward_c<T, D, 4>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, force_path, st);
-        case 8: return launch_backward_c<T, D, 8>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, force_path, st);
+            } else return launch_backward_c<T, D, 1>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
+        case 2: return launch_backward_c<T, D, 2>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
+        case 4: return launch_backward_c<T, D, 4>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
+        case 8: return launch_backward_c<T, D, 8>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
         default: set_error("GridEncoding: C must be 1, 2, 4, or 8."); return S3D_ERR_UNSUPPORTED;
     }
 }
@@ -817,7 +858,7 @@ S3D_EXPORT int s3d_grid_corner_indices(const float* inputs, const int32_t* offse
                    (launch_corner_rows<5>(inputs, offsets, corner_idx, B, L, sc, gridtype, ac, st)))
 }
 
-S3D_EXPORT size_t s3d_grid_encode_backward_workspace_size(void) { return sizeof(uint32_t) * kMaxLevels; }
+S3D_EXPORT size_t s3d_grid_encode_backward_workspace_size(uint32_t B) { return 256 + (size_t)B * 16; }
 
 // process-wide override for experiments/tests: 0 = auto, 1 = direct atomics, 2 = LDS fixed-point sweep
 static int g_backward_path = 0;
@@ -834,8 +875,8 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
     S3D_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null pointer");
     S3D_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_backward: L must be in [1, %u]", kMaxLevels);
     S3D_REQUIRE(dtype == S3D_F32 || dtype == S3D_F16, "grid_encode_backward: dtype must be f32 or f16");
-    S3D_REQUIRE(!workspace || workspace_bytes >= s3d_grid_encode_backward_workspace_size(), "grid_encode_backward: workspace too small");
-    S3D_REQUIRE(g_backward_path != 2 || (workspace && table_rows), "grid_encode_backward: LDS path needs table_rows and a workspace");
+    S3D_REQUIRE(g_backward_path != 2 || (workspace && table_rows && workspace_bytes >= s3d_grid_encode_backward_workspace_size(B)),
+                "grid_encode_backward: LDS path needs table_rows and a workspace of s3d_grid_encode_backward_workspace_size(B) bytes");
     LevelScales sc;
     host_scales(L, S, H, sc);
     hipStream_t st = as_stream(stream);
@@ -845,17 +886,17 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
     if (dtype == S3D_F32) {
         const float* g = (const float*)grad; float* ge = (float*)grad_embeddings;
         const float* j = (const float*)dy_dx; float* gi = (float*)grad_inputs;
-        S3D_DISPATCH_D(D, (launch_backward<float, 2>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)),
-                       (launch_backward<float, 3>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)),
-                       (launch_backward<float, 4>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)),
-                       (launch_backward<float, 5>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)))
+        S3D_DISPATCH_D(D, (launch_backward<float, 2>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
+                       (launch_backward<float, 3>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
+                       (launch_backward<float, 4>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
+                       (launch_backward<float, 5>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)))
     } else {
         const __half* g = (const __half*)grad; __half* ge = (__half*)grad_embeddings;
         const __half* j = (const __half*)dy_dx; __half* gi = (__half*)grad_inputs;
-        S3D_DISPATCH_D(D, (launch_backward<__half, 2>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)),
-                       (launch_backward<__half, 3>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)),
-                       (launch_backward<__half, 4>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)),
-                       (launch_backward<__half, 5>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, fp, st)))
+        S3D_DISPATCH_D(D, (launch_backward<__half, 2>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
+                       (launch_backward<__half, 3>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
+                       (launch_backward<__half, 4>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
+                       (launch_backward<__half, 5>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)))
     }
 }
 

@@ -243,7 +243,7 @@ class GridBackend:
         _need(inputs, torch.float32, "inputs")
         if grad_embeddings.dtype != grad.dtype:
             raise RuntimeError("grad_embeddings must have the dtype of grad")
-        ws = _ws.get(lib().s3d_grid_encode_backward_workspace_size(), grad.device)
+        ws = _ws.get(lib().s3d_grid_encode_backward_workspace_size(_u(B)), grad.device)
         _check(lib().s3d_grid_encode_backward(_p(grad), _p(inputs), _p(embeddings), _p(offsets),
                                               _p(grad_embeddings), _u(grad_embeddings.shape[0]), _u(B), _u(D),
                                               _u(Cc), _u(L), _f(S), _u(H), _p(dy_dx), _p(grad_inputs), _u(gridtype),

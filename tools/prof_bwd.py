@@ -12,10 +12,8 @@ for dtype in (torch.float16,):
     grad = torch.randn(16, B, 2, device="cuda").to(dtype)
     ge = torch.zeros(total, 2, device="cuda", dtype=dtype)
     out = torch.empty(16, B, 2, device="cuda", dtype=dtype)
-    for path in (2, 1):
+    for path in (2,):
         G.set_backward_path(path)
         for _ in range(3):
             G.grid_encode_backward(grad, x, emb, offs, ge, B, 3, 2, 16, S, 16, None, None, 0, False, 0)
-    for _ in range(3):
-        G.grid_encode_forward(x, emb, offs, out, B, 3, 2, 16, S, 16, None, 0, False, 0)
 torch.cuda.synchronize()
