@@ -62,7 +62,9 @@ int s3d_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* b
  *                                        nears, fars, xyzs, dirs, deltas, rays, counter, noises)
  * Spans are packed in RAY ORDER (deterministic; one valid outcome of the reference's atomic
  * reservation, raymarching.cu:405-406).  counter[0] += total samples, counter[1] += N. */
-size_t s3d_march_rays_train_workspace_size(uint32_t N);
+size_t s3d_march_rays_train_workspace_size(uint32_t N, uint32_t max_steps);
+/* experiments/tests: 0 = auto (wave-per-ray up to 16,384 rays), 1 = lane-per-ray, 2 = wave-per-ray */
+void s3d_march_set_path(int path);
 int s3d_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                          float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                          uint32_t M, const float* nears, const float* fars, float* xyzs, float* dirs,

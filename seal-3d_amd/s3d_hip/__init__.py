@@ -27,7 +27,7 @@ F32, F16 = 0, 1
 EXPORTS = [
     "s3d_last_error", "s3d_version",
     "s3d_near_far_from_aabb", "s3d_sph_from_ray", "s3d_morton3D", "s3d_morton3D_invert", "s3d_packbits",
-    "s3d_march_rays_train_workspace_size", "s3d_march_rays_train",
+    "s3d_march_rays_train_workspace_size", "s3d_march_set_path", "s3d_march_rays_train",
     "s3d_composite_rays_train_forward", "s3d_composite_rays_train_backward",
     "s3d_march_rays", "s3d_composite_rays", "s3d_compact_alive_workspace_size", "s3d_compact_alive",
     "s3d_grid_level_scales", "s3d_grid_encode_forward", "s3d_grid_corner_indices", "s3d_grid_encode_backward",
@@ -168,7 +168,7 @@ class RaymarchingBackend:
     def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, Cc, H, M, nears, fars, xyzs, dirs,
                          deltas, rays, counter, noises):
         _need(rays_o, torch.float32, "rays_o")
-        nbytes = lib().s3d_march_rays_train_workspace_size(_u(N))
+        nbytes = lib().s3d_march_rays_train_workspace_size(_u(N), _u(max_steps))
         ws = _ws.get(nbytes, rays_o.device)
         _check(lib().s3d_march_rays_train(_p(rays_o), _p(rays_d), _p(grid), _f(bound), _f(dt_gamma), _u(max_steps),
                                           _u(N), _u(Cc), _u(H), _u(M), _p(nears), _p(fars), _p(xyzs), _p(dirs),
@@ -206,6 +206,11 @@ class RaymarchingBackend:
         _check(lib().s3d_composite_rays(_u(n_alive), _u(n_step), _f(T_thresh), _p(rays_alive), _p(rays_t),
                                         _p(sigmas), _p(rgbs), _p(deltas), _p(weights_sum), _p(depth), _p(image),
                                         _stream()), "composite_rays")
+
+    @staticmethod
+    def set_march_path(path):
+        """0 = auto, 1 = lane-per-ray kernels, 2 = wave-per-ray kernels (tests / experiments)"""
+        lib().s3d_march_set_path(C.c_int(int(path)))
 
     # --- build extension (not in the reference's native surface) ---
     @staticmethod

@@ -105,23 +105,33 @@ def _march_train_args(ro, rd, bits, C, bound, M, perturb, dt_gamma=0.0, max_step
     return [ro, rd, bits, bound, dt_gamma, max_steps, N, C, 128, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises]
 
 
+@pytest.fixture(params=[1, 2], ids=["lane-per-ray", "wave-per-ray"])
+def march_path(request, hip):
+    hip.RaymarchingBackend.set_march_path(request.param)
+    yield request.param
+    hip.RaymarchingBackend.set_march_path(0)
+
+
 @pytest.mark.parametrize("perturb", [False, True])
-@pytest.mark.parametrize("cascade,bound,dt_gamma", [(1, 1.0, 0.0), (2, 2.0, 1.0 / 128)])
-def test_march_rays_train_bit_exact(oracle, hip, perturb, cascade, bound, dt_gamma):
+@pytest.mark.parametrize("cascade,bound,dt_gamma,max_steps", [(1, 1.0, 0.0, 1024), (2, 2.0, 1.0 / 128, 1024), (3, 4.0, 0.0, 4096),
+                                                              (1, 1.0, 0.0, 20)])
+def test_march_rays_train_bit_exact(oracle, hip, march_path, perturb, cascade, bound, dt_gamma, max_steps):
     _, bits = _scene(seed=0, cascade=cascade, bound=bound)
     ro, rd = _rays(4096, seed=3)
-    args = _march_train_args(ro, rd, bits, cascade, bound, 4096 * 256, perturb, dt_gamma=dt_gamma)
+    args = _march_train_args(ro, rd, bits, cascade, bound, 4096 * 256, perturb, dt_gamma=dt_gamma, max_steps=max_steps)
     cpu, gpu = _both(oracle, hip, "march_rays_train", args, 5)
     # compaction: per-ray (id, offset, count) and the two counters, bit-exact
     assert torch.equal(cpu[15], gpu[15].cpu())
     assert torch.equal(cpu[16], gpu[16].cpu())
     m = int(cpu[16][0])
-    assert m > 4096 * 3, "scene should produce samples"
+    assert m > (4096 * 3 if max_steps > 20 else 4096), "scene should produce samples"
+    if max_steps == 20:
+        assert int(cpu[15][:, 2].max()) == 20, "the per-ray max_steps cap must bind"
     for k in (12, 13, 14):  # xyzs, dirs, deltas bit-exact, including the untouched zero tail
         assert np.array_equal(cpu[k].numpy().view(np.uint32), gpu[k].cpu().numpy().view(np.uint32))
 
 
-def test_march_rays_train_capped_budget_and_empty(oracle, hip):
+def test_march_rays_train_capped_budget_and_empty(oracle, hip, march_path):
     _, bits = _scene(seed=0)
     ro, rd = _rays(4096, seed=4)
     # budget smaller than the demand: rays whose span does not fit are dropped, nothing is written past M

@@ -65,7 +65,7 @@ def main():
     # coherent points (samples along rays) as in training
     grid, bits = syn.lego_like_density_grid(seed=0)
     bits = torch.from_numpy(bits).to(dev)
-    for N in (4096, 65536, 640000):
+    for N in (4096, 16384, 640000):
         poses = syn.orbit_poses(1, seed=0)
         r = syn.get_rays(poses, syn.lego_intrinsics(), 800, 800, N=N if N < 640000 else -1, generator=torch.Generator().manual_seed(0))
         ro, rd = r["rays_o"][0].contiguous().to(dev), r["rays_d"][0].contiguous().to(dev)
@@ -83,9 +83,14 @@ def main():
         def march():
             counter.zero_()
             R.march_rays_train(ro, rd, bits, 1.0, 0.0, 1024, N, 1, 128, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises)
-        t = timeit(march)
-        m = int(counter[0])
-        print(f"march_rays_train N={N}: {t*1e6:.1f} us  samples={m} ({m/N:.1f}/ray)  {m/t/1e9:.3f} Gsamples/s")
+        for path in (1, 2):
+            if path == 2 and N > 16384:
+                continue
+            R.set_march_path(path)
+            t = timeit(march)
+            m = int(counter[0])
+            print(f"march_rays_train[{'lane' if path == 1 else 'wave'}] N={N}: {t*1e6:.1f} us  samples={m} ({m/N:.1f}/ray)  {m/t/1e9:.3f} Gsamples/s")
+        R.set_march_path(0)
         sig = torch.rand(m, device=dev) * 20
         rgb = torch.rand(m, 3, device=dev)
         ws, dp, im = torch.empty(N, device=dev), torch.empty(N, device=dev), torch.empty(N, 3, device=dev)
