@@ -71,6 +71,9 @@ int s3d_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t
                          float* deltas, int32_t* rays, int32_t* counter, const float* noises,
                          void* workspace, size_t workspace_bytes, s3d_stream_t stream);
 
+/* experiments/tests: 0 = wave-per-ray compositing (default), 1 = lane-per-ray (serial chain) */
+void s3d_composite_set_path(int path);
+
 /* raymarching.h:14 void composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh,
  *                                                    weights_sum, depth, image) */
 int s3d_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,

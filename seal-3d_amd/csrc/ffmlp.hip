@@ -393,12 +393,20 @@ __global__ void k_ffmlp_wgrad_reduce(WgradPlan plan, uint32_t nblk, const float*
     if (e >= L.Fo * L.Fi) return;
     const uint32_t o = e / L.Fi, i = e - o * L.Fi;
     const float* p = partial + (size_t)blockIdx.y * nblk * kWgradPad * kWgradPad + o * kWgradPad + i;
-    float s = 0.0f;
-    for (uint32_t b = 0; b < nblk; b++) s += p[(size_t)b * kWgradPad * kWgradPad];
-    grad_weights[L.w_off + e] = (_Float16)s;
+    // independent partial sums keep several loads in flight (a single dependent chain was latency-bound: 38 us)
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    uint32_t b = 0;
+    for (; b + 4 <= nblk; b += 4) {
+        s0 += p[(size_t)(b + 0) * kWgradPad * kWgradPad];
+        s1 += p[(size_t)(b + 1) * kWgradPad * kWgradPad];
+        s2 += p[(size_t)(b + 2) * kWgradPad * kWgradPad];
+        s3 += p[(size_t)(b + 3) * kWgradPad * kWgradPad];
+    }
+    for (; b < nblk; b++) s0 += p[(size_t)b * kWgradPad * kWgradPad];
+    grad_weights[L.w_off + e] = (_Float16)((s0 + s1) + (s2 + s3));
 }
 
-constexpr uint32_t kWgradBlocks = 128;
+constexpr uint32_t kWgradBlocks = 64;
 
 int check_shape(uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t W, uint32_t n_layers) {
     S3D_REQUIRE(W == 32 || W == 64, "ffmlp: hidden_dim %u not supported by the MFMA path (32 or 64)", W);

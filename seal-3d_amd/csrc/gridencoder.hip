@@ -370,15 +370,30 @@ __global__ void __launch_bounds__(256) k_pack_points(const float* __restrict__ i
 // per-level max |grad| (bit pattern of a non-negative float is monotone as uint32)
 template <typename T>
 __global__ void __launch_bounds__(256) k_grad_absmax(const T* __restrict__ grad, uint32_t per_level, uint32_t* __restrict__ out) {
+    // 16-byte loads, block-level reduction, ONE atomic per workgroup (all workgroups of a level hit the same word)
+    constexpr uint32_t V = 16 / sizeof(T);
     const T* g = grad + (size_t)blockIdx.y * per_level;
     float m = 0.0f;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < per_level; i += gridDim.x * 256) {
-        const float v = fabsf(Acc<T>::to_f(g[i]));
-        m = (v > m || v != v) ? v : m;  // NaN propagates so that a poisoned gradient stays visible
+    auto upd = [&](float v) { v = fabsf(v); m = (v > m || v != v) ? v : m; };  // NaN propagates
+    const uint32_t nvec = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? per_level / V : 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
+        const uint4 raw = reinterpret_cast<const uint4*>(g)[i];
+        T v[V];
+        __builtin_memcpy(v, &raw, 16);
+#pragma unroll
+        for (uint32_t k = 0; k < V; k++) upd(Acc<T>::to_f(v[k]));
     }
+    for (uint32_t i = nvec * V + blockIdx.x * 256 + threadIdx.x; i < per_level; i += gridDim.x * 256) upd(Acc<T>::to_f(g[i]));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const float o = __shfl_xor(m, d, 64); m = (o > m || o != o) ? o : m; }
-    if ((threadIdx.x & 63) == 0) atomicMax(out + blockIdx.y, __float_as_uint(m));
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; w++) { const float o = part[w]; m = (o > m || o != o) ? o : m; }
+        atomicMax(out + blockIdx.y, __float_as_uint(m));
+    }
 }
 
 template <typename T, uint32_t D, uint32_t C>
@@ -733,8 +748,8 @@ int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets
         if constexpr (D <= 4)
             hipLaunchKernelGGL((k_pack_points<D>), dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, st, inputs, B, packed);
         const uint32_t per_level = B * C;
-        uint32_t gx = div_up<uint32_t>(per_level, 256 * 8);
-        if (gx > 256) gx = 256;
+        uint32_t gx = div_up<uint32_t>(per_level, 256 * 32);
+        if (gx > 64) gx = 64;
         hipLaunchKernelGGL((k_grad_absmax<T>), dim3(gx, L), dim3(256), 0, st, grad, per_level, ws);
         static bool attr_set = false;
         if (!attr_set) {

@@ -476,6 +476,116 @@ __global__ void __launch_bounds__(64) k_composite_train_bwd(const float* __restr
     }
 }
 
+
+// ---------------------------------------------------------------- composite (training), one WAVE per ray
+// The lane-per-ray kernels above walk each span serially with uncoalesced loads (4,096 rays = 64 waves, ~125 us).
+// Here a wave owns one ray: 64 consecutive samples are loaded coalesced, transmittance is a wave prefix PRODUCT,
+// depth a wave prefix SUM, early termination a prefix property (sample i is used iff the transmittance in front of
+// it is still >= T_thresh), and the pixel is a wave reduction.  Same formulas as raymarching.cu:540-567 / 643-681;
+// the products/sums are re-associated (tree instead of chain), covered by the FP tolerance of the parity tests.
+__device__ __forceinline__ float wave_scan_mul(float v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(v, d, 64); if (lane >= (uint32_t)d) v *= o; }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(v, d, 64); if (lane >= (uint32_t)d) v += o; }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_composite_train_fwd_wave(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                 const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+                                                                 uint32_t M, uint32_t N, float T_thresh,
+                                                                 float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                                 float* __restrict__ image) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    float r = 0, g = 0, b = 0, ws = 0, dsum = 0;
+    if (num_steps != 0 && offset + num_steps <= M) {
+        float T_carry = 1.0f, t_carry = 0.0f;
+        for (uint32_t base = 0; base < num_steps; base += 64) {
+            const uint32_t i = base + lane;
+            const bool valid = i < num_steps;
+            const size_t o = (size_t)offset + i;
+            const float sg = valid ? sigmas[o] : 0.0f;
+            const float2 dd = valid ? reinterpret_cast<const float2*>(deltas)[o] : make_float2(0.0f, 0.0f);
+            const float c0 = valid ? rgbs[o * 3] : 0.0f, c1 = valid ? rgbs[o * 3 + 1] : 0.0f, c2 = valid ? rgbs[o * 3 + 2] : 0.0f;
+            const float alpha = 1.0f - __expf(-sg * dd.x);
+            const float P = wave_scan_mul(1.0f - alpha, lane);
+            float Pex = __shfl_up(P, 1, 64);
+            if (lane == 0) Pex = 1.0f;
+            const float T = T_carry * Pex;                       // transmittance in front of sample i
+            const float tc = t_carry + wave_scan_add(dd.y, lane);  // ray parameter after sample i
+            const bool used = valid && (i == 0 || !(T < T_thresh));
+            const float w = used ? alpha * T : 0.0f;
+            r += w * c0; g += w * c1; b += w * c2; ws += w; dsum += w * tc;
+            T_carry *= __shfl(P, 63, 64);
+            t_carry = __shfl(tc, 63, 64);
+            if (T_carry < T_thresh) break;
+        }
+        r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); ws = wave_sum(ws); dsum = wave_sum(dsum);
+    }
+    if (lane == 0) {
+        weights_sum[index] = ws; depth[index] = dsum;
+        image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_composite_train_bwd_wave(const float* __restrict__ grad_weights_sum,
+                                                                 const float* __restrict__ grad_image,
+                                                                 const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                 const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+                                                                 const float* __restrict__ weights_sum,
+                                                                 const float* __restrict__ image, uint32_t M, uint32_t N,
+                                                                 float T_thresh, float* __restrict__ grad_sigmas,
+                                                                 float* __restrict__ grad_rgbs) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (num_steps == 0 || offset + num_steps > M) return;
+    const float gws = grad_weights_sum[index];
+    const float gi0 = grad_image[index * 3], gi1 = grad_image[index * 3 + 1], gi2 = grad_image[index * 3 + 2];
+    const float rf = image[index * 3], gf = image[index * 3 + 1], bf = image[index * 3 + 2], wsf = weights_sum[index];
+    float T_carry = 1.0f, rc = 0, gc = 0, bc = 0;  // running composites up to the previous chunk
+    for (uint32_t base = 0; base < num_steps; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < num_steps;
+        const size_t o = (size_t)offset + i;
+        const float sg = valid ? sigmas[o] : 0.0f;
+        const float d0 = valid ? deltas[o * 2] : 0.0f;
+        const float c0 = valid ? rgbs[o * 3] : 0.0f, c1 = valid ? rgbs[o * 3 + 1] : 0.0f, c2 = valid ? rgbs[o * 3 + 2] : 0.0f;
+        const float alpha = 1.0f - __expf(-sg * d0);
+        const float P = wave_scan_mul(1.0f - alpha, lane);
+        float Pex = __shfl_up(P, 1, 64);
+        if (lane == 0) Pex = 1.0f;
+        const float T = T_carry * Pex;   // in front of sample i
+        const float Tn = T_carry * P;    // behind sample i
+        const bool used = valid && (i == 0 || !(T < T_thresh));
+        const float w = used ? alpha * T : 0.0f;
+        const float rr = rc + wave_scan_add(w * c0, lane), gg = gc + wave_scan_add(w * c1, lane), bb = bc + wave_scan_add(w * c2, lane);
+        if (used) {
+            grad_rgbs[o * 3] = gi0 * w; grad_rgbs[o * 3 + 1] = gi1 * w; grad_rgbs[o * 3 + 2] = gi2 * w;
+            float acc = gi0 * (Tn * c0 - (rf - rr));
+            acc += gi1 * (Tn * c1 - (gf - gg));
+            acc += gi2 * (Tn * c2 - (bf - bb));
+            acc += gws * (1 - wsf);
+            grad_sigmas[o] = d0 * acc;
+        }
+        T_carry *= __shfl(P, 63, 64);
+        rc = __shfl(rr, 63, 64); gc = __shfl(gg, 63, 64); bc = __shfl(bb, 63, 64);
+        if (T_carry < T_thresh) break;
+    }
+}
+
 // ---------------------------------------------------------------- inference
 __global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive,
                                                    const float* __restrict__ rays_t, const float* __restrict__ rays_o,
@@ -658,14 +768,22 @@ S3D_EXPORT int s3d_march_rays_train(const float* rays_o, const float* rays_d, co
     return check_launch("march_rays_train");
 }
 
+// experiments/tests: 0/2 = wave-per-ray (default), 1 = lane-per-ray (serial chain, the oracle's summation order)
+static int g_composite_path = 0;
+S3D_EXPORT void s3d_composite_set_path(int path) { g_composite_path = path; }
+
 S3D_EXPORT int s3d_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
                                                 const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
                                                 float* weights_sum, float* depth, float* image, s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(rays && weights_sum && depth && image, "composite_rays_train_forward: null pointer");
     S3D_REQUIRE(M == 0 || (sigmas && rgbs && deltas), "composite_rays_train_forward: null input");
-    hipLaunchKernelGGL(k_composite_train_fwd, dim3(div_up<uint32_t>(N, 64)), dim3(64), 0, as_stream(stream), sigmas, rgbs,
-                       deltas, rays, M, N, T_thresh, weights_sum, depth, image);
+    if (g_composite_path == 1)
+        hipLaunchKernelGGL(k_composite_train_fwd, dim3(div_up<uint32_t>(N, 64)), dim3(64), 0, as_stream(stream), sigmas, rgbs,
+                           deltas, rays, M, N, T_thresh, weights_sum, depth, image);
+    else
+        hipLaunchKernelGGL(k_composite_train_fwd_wave, dim3(div_up<uint32_t>(N, 4)), dim3(256), 0, as_stream(stream), sigmas,
+                           rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image);
     return check_launch("composite_rays_train_forward");
 }
 
@@ -677,9 +795,14 @@ S3D_EXPORT int s3d_composite_rays_train_backward(const float* grad_weights_sum, 
     if (N == 0 || M == 0) return S3D_OK;
     S3D_REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image &&
                     grad_sigmas && grad_rgbs, "composite_rays_train_backward: null pointer");
-    hipLaunchKernelGGL(k_composite_train_bwd, dim3(div_up<uint32_t>(N, 64)), dim3(64), 0, as_stream(stream),
-                       grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh,
-                       grad_sigmas, grad_rgbs);
+    if (g_composite_path == 1)
+        hipLaunchKernelGGL(k_composite_train_bwd, dim3(div_up<uint32_t>(N, 64)), dim3(64), 0, as_stream(stream),
+                           grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh,
+                           grad_sigmas, grad_rgbs);
+    else
+        hipLaunchKernelGGL(k_composite_train_bwd_wave, dim3(div_up<uint32_t>(N, 4)), dim3(256), 0, as_stream(stream),
+                           grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh,
+                           grad_sigmas, grad_rgbs);
     return check_launch("composite_rays_train_backward");
 }
 

@@ -59,10 +59,12 @@ class _FFMLPForward(Function):
         grad = grad.contiguous()
         inputs, weights, outputs, forward_buffer = ctx.saved_tensors
         input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs = ctx.meta
-        grad_inputs = (torch.zeros_like(inputs) if calc_grad_inputs
+        # the reference zero-fills these three (ffmlp.py:67-73); the HIP kernels overwrite every element, so the
+        # build allocates them uninitialised (saves two B x hidden x num_layers memsets per MLP per step)
+        grad_inputs = (torch.empty_like(inputs) if calc_grad_inputs
                        else torch.zeros(1, device=grad.device, dtype=grad.dtype))
         grad_weights = torch.zeros_like(weights)
-        backward_buffer = torch.zeros(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
+        backward_buffer = torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
         _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim,
                                 num_layers, activation, output_activation, calc_grad_inputs, backward_buffer,
                                 grad_inputs, grad_weights)

@@ -28,7 +28,7 @@ EXPORTS = [
     "s3d_last_error", "s3d_version",
     "s3d_near_far_from_aabb", "s3d_sph_from_ray", "s3d_morton3D", "s3d_morton3D_invert", "s3d_packbits",
     "s3d_march_rays_train_workspace_size", "s3d_march_set_path", "s3d_march_rays_train",
-    "s3d_composite_rays_train_forward", "s3d_composite_rays_train_backward",
+    "s3d_composite_set_path", "s3d_composite_rays_train_forward", "s3d_composite_rays_train_backward",
     "s3d_march_rays", "s3d_composite_rays", "s3d_compact_alive_workspace_size", "s3d_compact_alive",
     "s3d_grid_level_scales", "s3d_grid_encode_forward", "s3d_grid_corner_indices", "s3d_grid_encode_backward",
     "s3d_grid_encode_backward_workspace_size", "s3d_grid_backward_set_path",
@@ -206,6 +206,11 @@ class RaymarchingBackend:
         _check(lib().s3d_composite_rays(_u(n_alive), _u(n_step), _f(T_thresh), _p(rays_alive), _p(rays_t),
                                         _p(sigmas), _p(rgbs), _p(deltas), _p(weights_sum), _p(depth), _p(image),
                                         _stream()), "composite_rays")
+
+    @staticmethod
+    def set_composite_path(path):
+        """0 = wave-per-ray compositing, 1 = lane-per-ray (tests / experiments)"""
+        lib().s3d_composite_set_path(C.c_int(int(path)))
 
     @staticmethod
     def set_march_path(path):

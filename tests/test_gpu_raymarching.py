@@ -165,7 +165,9 @@ def _composite_inputs(oracle, seed=0, n_rays=4096):
     return sigmas, rgbs, args[14][:m].contiguous(), args[15], m, n_rays
 
 
-def test_composite_rays_train_forward_backward(oracle, hip):
+@pytest.mark.parametrize("cpath", [0, 1], ids=["wave-per-ray", "lane-per-ray"])
+def test_composite_rays_train_forward_backward(oracle, hip, cpath):
+    hip.RaymarchingBackend.set_composite_path(cpath)
     sigmas, rgbs, deltas, rays, M, N = _composite_inputs(oracle)
     ws, dp, im = torch.empty(N), torch.empty(N), torch.empty(N, 3)
     cpu, gpu = _both(oracle, hip, "composite_rays_train_forward", [sigmas, rgbs, deltas, rays, M, N, 1e-4, ws, dp, im], 3)
@@ -185,6 +187,7 @@ def test_composite_rays_train_forward_backward(oracle, hip):
     # `T < T_thresh` on an exp() that differs in the last bits (__expf vs expf), so a ray may stop one sample
     # earlier or later: allow a 1e-3 fraction of samples to differ in written/unwritten state.
     mism = ((gpu2[11].cpu() == 0) != (cpu2[11] == 0)).float().mean()
+    hip.RaymarchingBackend.set_composite_path(0)
     assert mism < 1e-3
 
 
