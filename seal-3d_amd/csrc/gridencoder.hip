@@ -354,17 +354,39 @@ __host__ __device__ inline uint32_t bwd_slice_rows(uint32_t rows, uint32_t C) {
 // costs ~20 cycles of address-unit time per instruction regardless of width, and a 12-byte-stride [B,3] read is
 // three of them per point (0.34 ns/point/CU) against 0.15 for one aligned float4 — and the sweep reads every point
 // once per (level, slice) workgroup.  Out-of-range points are encoded as NaN.x so the sweep needs no range test.
-template <uint32_t D>
-__global__ void __launch_bounds__(256) k_pack_points(const float* __restrict__ inputs, uint32_t B, float4* __restrict__ packed) {
-    static_assert(D <= 4, "packed record holds up to 4 coordinates");
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(256) k_pack_points(const float* __restrict__ inputs, const T* __restrict__ grad, uint32_t B,
+                                                     uint32_t L, float4* __restrict__ packed, uint32_t* __restrict__ count) {
+    // Record = (x, y, z, original point index as bits).  Points that cannot contribute are DROPPED here, once,
+    // instead of being re-scanned by every (level, slice) workgroup: out-of-range points, and points whose
+    // gradient is exactly zero on every level (samples behind a ray's early termination, padding rows).
+    // Integer accumulation is order-independent, so compaction does not affect the (bit-reproducible) result.
+    static_assert(D <= 3, "packed record holds up to 3 coordinates + the point index");
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= B) return;
-    float x[4] = {0, 0, 0, 0};
-    bool oob = false;
+    float x[3] = {0, 0, 0};
+    bool keep = b < B;
+    if (keep) {
 #pragma unroll
-    for (uint32_t d = 0; d < D; d++) { x[d] = inputs[(size_t)b * D + d]; oob |= (x[d] < 0 || x[d] > 1); }
-    if (oob) x[0] = NAN;
-    packed[b] = make_float4(x[0], x[1], x[2], x[3]);
+        for (uint32_t d = 0; d < D; d++) { x[d] = inputs[(size_t)b * D + d]; keep &= (x[d] >= 0 && x[d] <= 1); }
+    }
+    if (keep) {
+        bool nz = false;
+        for (uint32_t l = 0; l < L && !nz; l++) {
+            T g[C];
+            load_feat<T, C>(grad + ((size_t)l * B + b) * C, g);
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) nz |= (Acc<T>::to_f(g[c]) != 0.0f);
+        }
+        keep = nz;
+    }
+    const unsigned long long m = __ballot(keep);
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, 0, 64);
+    if (keep) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        packed[base + rank] = make_float4(x[0], x[1], x[2], __uint_as_float(b));
+    }
 }
 
 // per-level max |grad| (bit pattern of a non-negative float is monotone as uint32)
@@ -422,6 +444,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_grid_backward_lds(const T* __re
     const uint32_t row0 = slice * slice_rows;
     const uint32_t nrows = min(slice_rows, hashmap_size - row0);
 
+    const uint32_t n_points = (D <= 3) ? absmax[kMaxLevels] : B;  // compacted point count (written by k_pack_points)
     const float amax = __uint_as_float(absmax[level]);
     if (!(amax > 0.0f)) {
         if (amax != amax || amax == INFINITY) {  // non-finite gradient: poison the slice like a float sum would
@@ -502,11 +525,20 @@ __global__ void __launch_bounds__(kBwdThreads) k_grid_backward_lds(const T* __re
         auto drain = [&](uint32_t first, uint32_t count) {  // lanes [0,count) take entries first..first+count-1
             if (lane < count) {
                 const uint32_t ent = queue[first + lane];
-                const uint32_t b = ent >> D, idx = ent & ((1u << D) - 1);
+                uint32_t b = ent >> D;  // slot in the packed array (D <= 3) or point index
+                const uint32_t idx = ent & ((1u << D) - 1);
                 float x[D], pos[D], pd[D];
                 uint32_t pos_grid[D], lo[D], hi[D];
+                if constexpr (D <= 3) {
+                    const float4 p = packed[b];
+                    const float v[3] = {p.x, p.y, p.z};
 #pragma unroll
-                for (uint32_t d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
+                    for (uint32_t d = 0; d < D; d++) x[d] = v[d];
+                    b = __float_as_uint(p.w);  // original point index, for the gradient row
+                } else {
+#pragma unroll
+                    for (uint32_t d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
+                }
                 locate<D>(x, lscale, align_corners, interp, pos, pd, pos_grid);
                 corner_terms(mode, pos_grid, lo, hi);
                 const uint32_t local = row_of(mode, lo, hi, idx) - row0;
@@ -570,27 +602,26 @@ __global__ void __launch_bounds__(kBwdThreads) k_grid_backward_lds(const T* __re
                 }
             }
         };
-        // Point loop.  Each workgroup starts at its own offset: all workgroups read the SAME point array, and
-        // starting in phase makes every CU hit the same L2 lines at the same time.
         constexpr uint32_t kUnroll = 2;
         const uint32_t per_round = kBwdThreads * kUnroll;
-        const uint32_t rounds = div_up<uint32_t>(B, per_round);
-        const uint32_t start_round = (uint32_t)(((uint64_t)blockIdx.x * 2654435761ull) % rounds);
+        const uint32_t rounds = div_up<uint32_t>(n_points, per_round);
+        // All co-resident workgroups sweep the point array in the SAME order: the 32 CUs of an XCD then touch the
+        // same window at about the same time and share it through their L2.  (PMC, profiles/r01: with per-workgroup
+        // start offsets FETCH_SIZE was 2.8 GB per launch — 70 % of the 930 x 4.2 MB point re-reads missed the 4 MiB
+        // L2 and the sweep ran at the fabric's ~2.4 TB/s.)
         auto fetch = [&](uint32_t r, float (&xs)[kUnroll][D]) {
-            uint32_t rr = start_round + r;
-            if (rr >= rounds) rr -= rounds;
-            const uint32_t b0 = rr * per_round + threadIdx.x;
+            const uint32_t b0 = r * per_round + threadIdx.x;
 #pragma unroll
             for (uint32_t u = 0; u < kUnroll; u++) {
                 const uint32_t b = b0 + u * kBwdThreads;
-                if constexpr (D <= 4) {
-                    const float4 p = (b < B) ? packed[b] : make_float4(-1.0f, 0, 0, 0);
-                    const float v[4] = {p.x, p.y, p.z, p.w};
+                if constexpr (D <= 3) {
+                    const float4 p = (b < n_points) ? packed[b] : make_float4(-1.0f, 0, 0, 0);
+                    const float v[3] = {p.x, p.y, p.z};
 #pragma unroll
                     for (uint32_t d = 0; d < D; d++) xs[u][d] = v[d];
                 } else {
 #pragma unroll
-                    for (uint32_t d = 0; d < D; d++) xs[u][d] = (b < B) ? inputs[(size_t)b * D + d] : -1.0f;
+                    for (uint32_t d = 0; d < D; d++) xs[u][d] = (b < n_points) ? inputs[(size_t)b * D + d] : -1.0f;
                 }
             }
             return b0;
@@ -743,10 +774,11 @@ int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets
     if (use_lds) {
         // upper bound on the number of (level, slice) workgroups: capacity slices + per-level minimum + remainders
         const uint32_t nb = div_up<uint32_t>(table_rows, kAccBytes / (8 * C)) + L * (bwd_min_slices(C) + 1);
-        S3D_HIP(hipMemsetAsync(ws, 0, sizeof(uint32_t) * kMaxLevels, st));
+        S3D_HIP(hipMemsetAsync(ws, 0, sizeof(uint32_t) * (kMaxLevels + 1), st));
         float4* packed = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(ws) + 256);
-        if constexpr (D <= 4)
-            hipLaunchKernelGGL((k_pack_points<D>), dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, st, inputs, B, packed);
+        if constexpr (D <= 3)
+            hipLaunchKernelGGL((k_pack_points<T, D, C>), dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, st, inputs, grad, B, L,
+                               packed, ws + kMaxLevels);
         const uint32_t per_level = B * C;
         uint32_t gx = div_up<uint32_t>(per_level, 256 * 32);
         if (gx > 64) gx = 64;

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into the committed summaries under profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+
+
+def short(n):
+    n = n.replace("void ", "").replace("s3d::(anonymous namespace)::", "").replace("at::native::", "")
+    return n.split("(")[0][:80]
+
+
+stats = glob.glob(f"{src}/trace/*/*kernel_stats.csv")[0]
+rows = list(csv.DictReader(open(stats)))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "pct"])
+    for r in rows:
+        w.writerow([short(r["Name"]), r["Calls"], f"{float(r['TotalDurationNs'])/1e6:.3f}", f"{float(r['AverageNs'])/1e3:.2f}",
+                    f"{float(r['MinNs'])/1e3:.2f}", f"{float(r['MaxNs'])/1e3:.2f}", r["Percentage"]])
+
+# timed region = the last 32 training steps: one k_march_count_wave per step
+trace = glob.glob(f"{src}/trace/*/*kernel_trace.csv")[0]
+ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(trace)))
+march = [i for i, k in enumerate(ks) if "k_march_count" in k[2]]
+sel = ks[march[-32]:]
+agg, cnt = collections.Counter(), collections.Counter()
+for s, e, n in sel:
+    agg[short(n)] += e - s
+    cnt[short(n)] += 1
+window = sel[-1][1] - sel[0][0]
+busy = sum(agg.values())
+
+
+def pmc(kind, counter):
+    fs = glob.glob(f"{src}/{kind}/*/*counter_collection.csv")
+    if not fs:
+        return {}
+    acc, num = collections.Counter(), collections.Counter()
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] == counter:
+            acc[short(r["Kernel_Name"])] += float(r["Counter_Value"])
+            num[short(r["Kernel_Name"])] += 1
+    return {k: acc[k] / num[k] for k in acc}
+
+
+fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
+sq = {c: pmc("sq", c) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY",
+                                 "SQ_WAIT_ANY", "SQ_INSTS_VMEM_RD")}
+with open(f"profiles/{tag}_timed_region.md", "w") as f:
+    f.write(f"# rocprofv3 summary `{tag}` — `python bench.py --steps 32 --warmup 8 --no_cpu_baseline --no_render`\n\n")
+    f.write(f"Timed region (last 32 steps, profiler attached): {window/1e6/32:.3f} ms/step wall, GPU busy {busy/1e6/32:.3f} ms/step "
+            f"({100*busy/window:.0f} %), {len(sel)/32:.0f} kernel launches/step.\n\n")
+    f.write("FETCH_SIZE / WRITE_SIZE are per-dispatch averages over the WHOLE run (KiB, raw counter values; on gfx950 FETCH_SIZE "
+            "under-reports wide coalesced reads by 2x — MI355X_MICROARCH.md §HBM — the `x2` column applies that correction).\n\n")
+    f.write("| kernel | launches/step | us/launch | us/step | FETCH KiB | FETCH x2 KiB | WRITE KiB | VALU insts/wave | wait_any % |\n|---|---|---|---|---|---|---|---|---|\n")
+    for n, v in agg.most_common(24):
+        wv = sq["SQ_WAVES"].get(n)
+        valu = sq["SQ_INSTS_VALU"].get(n)
+        wc, wa = sq["SQ_WAVE_CYCLES"].get(n), sq["SQ_WAIT_ANY"].get(n)
+        f.write(f"| `{n}` | {cnt[n]/32:.1f} | {v/cnt[n]/1e3:.1f} | {v/32/1e3:.1f} | {fetch.get(n, float('nan')):.0f} | "
+                f"{2*fetch.get(n, float('nan')):.0f} | {write.get(n, float('nan')):.0f} | "
+                f"{(valu/wv if wv and valu else float('nan')):.0f} | {(100*wa/wc if wc and wa else float('nan')):.0f} |\n")
+print(open(f"profiles/{tag}_timed_region.md").read())
