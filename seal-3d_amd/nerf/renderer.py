@@ -50,6 +50,13 @@ class NeRFRenderer(nn.Module):
             self.mean_count = 0
             self.local_step = 0
 
+    # ---- per-sample hooks (identity here; the Seal teacher overrides them, SealNeRF/renderer.py:291-316, 381-399)
+    def map_samples(self, xyzs, dirs):
+        return xyzs, dirs, None
+
+    def map_colors(self, xyzs, dirs, rgbs, mask):
+        return rgbs
+
     # ---- to be provided by the network subclass
     def forward(self, x, d):
         raise NotImplementedError()
@@ -96,8 +103,10 @@ class NeRFRenderer(nn.Module):
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, counter,
                 self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
-            sigmas, rgbs = self(xyzs, dirs)
+            mxyzs, mdirs, mmask = self.map_samples(xyzs, dirs)
+            sigmas, rgbs = self(mxyzs, mdirs)
             sigmas = self.density_scale * sigmas
+            rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)
             weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
             results["weights_sum"] = weights_sum
@@ -116,8 +125,10 @@ class NeRFRenderer(nn.Module):
                 xyzs, dirs, deltas = raymarching.march_rays(
                     n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
                     self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma, max_steps)
-                sigmas, rgbs = self(xyzs, dirs)
+                mxyzs, mdirs, mmask = self.map_samples(xyzs, dirs)
+                sigmas, rgbs = self(mxyzs, mdirs)
                 sigmas = self.density_scale * sigmas
+                rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)
                 raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth,
                                            image, T_thresh)
                 if use_dev_compaction:

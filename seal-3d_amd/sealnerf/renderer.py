@@ -1,0 +1,76 @@
+"""Seal teacher/student renderers (SealNeRF/renderer.py).
+
+The teacher is a pretrained network viewed through the proxy function: every marched sample is mapped back to source
+space before the network query (`map_samples`, SealNeRF/renderer.py:291-316 / 381-399), and the cells inside the edit
+bound are forced "occupied" in the bitfield so that the (empty, in the source scene) target region is sampled at all
+(`hack_bitfield`, :50-66).  The student is a plain network whose bitfield is force-filled the same way."""
+import torch
+
+import raymarching
+
+
+class SealTeacherMixin:
+    seal_mapper = None
+    density_bitfield_origin = None
+    density_bitfield_hacked = False
+    proxy_enabled = True
+
+    def init_mapper(self, mapper):
+        """SealNeRF/renderer.py:22-47: cells of the force-fill bounds -> bitfield byte indices"""
+        self.seal_mapper = mapper
+        dev = self.density_bitfield.device
+        bounds = mapper.map_data["force_fill_bound"].clone().to(dev)
+        if bounds.ndim == 2:
+            bounds = bounds[None]
+        bounds[:, 0, :] = torch.max(bounds[:, 0, :], self.aabb_infer[:3])
+        bounds[:, 1, :] = torch.min(bounds[:, 1, :], self.aabb_infer[-3:])
+        idx = []
+        for i in range(bounds.shape[0]):
+            cmin, cmax = torch.floor(((bounds[i] + self.bound) / self.bound / 2) * self.grid_size)
+            X, Y, Z = torch.meshgrid(torch.arange(cmin[0], cmax[0], device=dev), torch.arange(cmin[1], cmax[1], device=dev),
+                                     torch.arange(cmin[2], cmax[2], device=dev), indexing="ij")
+            coords = torch.stack([X, Y, Z], dim=-1).reshape(-1, 3)
+            idx.append(raymarching.morton3D(coords.int()).long())
+        self.force_fill_grid_indices = torch.cat(idx)
+        self.force_fill_bitfield_indices = self.force_fill_grid_indices // 8
+
+    @torch.no_grad()
+    def hack_bitfield(self):
+        if self.density_bitfield_origin is None:
+            self.density_bitfield_origin = self.density_bitfield[self.force_fill_bitfield_indices]
+        self.density_bitfield[self.force_fill_bitfield_indices] = 255
+        self.density_bitfield_hacked = True
+
+    @torch.no_grad()
+    def restore_bitfield(self):
+        self.density_bitfield[self.force_fill_bitfield_indices] = self.density_bitfield_origin
+        self.density_bitfield_hacked = False
+
+    def update_extra_state(self, decay=0.95, S=128):
+        super().update_extra_state(decay, S)
+        if self.seal_mapper is not None:
+            self.hack_bitfield()
+
+    # teacher only: proxy the samples
+    def map_samples(self, xyzs, dirs):
+        if self.seal_mapper is None or not self.proxy_enabled:
+            return xyzs, dirs, None
+        return self.seal_mapper.map_to_origin(xyzs.view(-1, 3), dirs.view(-1, 3))
+
+    def map_colors(self, xyzs, dirs, rgbs, mask):
+        if mask is None or self.seal_mapper is None:
+            return rgbs
+        return self.seal_mapper.map_color(xyzs, dirs, rgbs)
+
+
+def _mix(net_cls, name, proxy):
+    return type(name, (SealTeacherMixin, net_cls), {"proxy_enabled": proxy})
+
+
+def make_teacher(net_cls, *args, **kwargs):
+    """teacher = backbone network + proxy mapping (SealNeRF/network.py:7-46 builds these classes dynamically)"""
+    return _mix(net_cls, "SealTeacher" + net_cls.__name__, True)(*args, **kwargs)
+
+
+def make_student(net_cls, *args, **kwargs):
+    return _mix(net_cls, "SealStudent" + net_cls.__name__, False)(*args, **kwargs)

@@ -1,0 +1,140 @@
+"""Seal proxy functions (SealNeRF/seal_utils.py): map edited-space points back to the source space.
+
+Only the bounding-box tool of BASELINE configs 3/4 is implemented (`SealBBoxMapper`, seal_utils.py:155-279):
+config keys `type: bbox`, `raw` (points spanning the source box), `transform` (4x4 source->target), `scale` (3),
+`boundType` ('to' | 'from' | 'both'), optional `mapSource`.  No trimesh / pytorch3d: the box meshes are built
+directly (12 triangles per box) and the inside test is the reference's two-ray Moller-Trumbore parity test
+(seal_utils.py:630-685) in plain torch.  Colour remapping (hsv/rgb/image) is outside the configs and not implemented.
+"""
+import json
+
+import numpy as np
+import torch
+
+_BOX_FACES = np.array([[0, 1, 3], [0, 3, 2], [4, 6, 7], [4, 7, 5], [0, 4, 5], [0, 5, 1],
+                       [2, 3, 7], [2, 7, 6], [0, 2, 6], [0, 6, 4], [1, 5, 7], [1, 7, 3]])
+# fixed test direction of the reference's inside test (seal_utils.py:676-678)
+_TEST_DIR = (0.4395064455, 0.617598629942, 0.652231566745)
+
+
+def _box_vertices(lo, hi):
+    return np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])], dtype=np.float64)
+
+
+def moller_trumbore_any(ray_o, ray_d, tris, eps=1e-8):
+    """does ray i hit any triangle?  (n_rays, 3), (n_rays, 3), (n_faces, 3, 3)  — seal_utils.py:630-665"""
+    E1 = tris[:, 1] - tris[:, 0]
+    E2 = tris[:, 2] - tris[:, 0]
+    N = torch.cross(E1, E2, dim=-1)
+    invdet = 1.0 / -(torch.einsum("md,nd->mn", ray_d, N) + eps)
+    A0 = ray_o[:, None] - tris[None, :, 0]
+    DA0 = torch.cross(A0, ray_d[:, None].expand(*A0.shape), dim=-1)
+    u = torch.einsum("mnd,nd->mn", DA0, E2) * invdet
+    v = -torch.einsum("mnd,nd->mn", DA0, E1) * invdet
+    t = torch.einsum("mnd,nd->mn", A0, N) * invdet
+    return ((t >= 0.0) & (u >= 0.0) & (v >= 0.0) & ((u + v) <= 1.0)).any(1)
+
+
+def points_in_mesh(points, triangles):
+    """a point is inside iff rays in BOTH directions of the test axis hit the mesh (seal_utils.py:668-685)"""
+    d = torch.tensor([_TEST_DIR], device=points.device, dtype=points.dtype).repeat(points.shape[0], 1)
+    hit = moller_trumbore_any(torch.cat([points, points]), torch.cat([d, -d]), triangles)
+    return hit[:points.shape[0]] & hit[points.shape[0]:]
+
+
+class SealBBoxMapper:
+    def __init__(self, seal_config):
+        self.config = seal_config
+        T = np.array(seal_config["transform"], dtype=np.float64)
+        scale = np.array(seal_config["scale"], dtype=np.float64)
+        raw = np.array(seal_config["raw"], dtype=np.float64)
+        lo, hi = raw.min(0), raw.max(0)  # axis-aligned source box (`bounding_box_oriented` of 8 box corners)
+        from_v = _box_vertices(lo, hi)
+        center = from_v.mean(0)
+        to_v = (from_v - center) * scale + center
+        to_v = to_v @ T[:3, :3].T + T[:3, 3]
+        to_center = to_v.mean(0)
+        from_b = np.stack([from_v.min(0), from_v.max(0)])
+        to_b = np.stack([to_v.min(0), to_v.max(0)])
+        fill = np.stack([to_b, from_b])  # [2 boxes, (min,max), 3]  == force_fill_bound
+        kind = seal_config.get("boundType", "to")
+        if kind == "to":
+            bounds, verts = to_b, [to_v]
+        elif kind == "from":
+            bounds, verts = from_b, [from_v]
+        elif kind == "both":
+            bounds, verts = fill, [to_v, from_v]
+        else:
+            raise ValueError(f"unknown boundType {kind}")
+        tris = np.concatenate([v[_BOX_FACES] for v in verts])
+        self.map_data = {
+            "force_fill_bound": torch.tensor(fill, dtype=torch.float32),
+            "map_bound": torch.tensor(bounds, dtype=torch.float32),
+            "pose_center": torch.tensor((center + to_center) / 2, dtype=torch.float32),
+            "pose_radius": float(np.linalg.norm(center - to_center) * 10),
+            "transform": torch.tensor(np.linalg.inv(T), dtype=torch.float32),
+            "rotation": torch.tensor(np.linalg.inv(T[:3, :3]), dtype=torch.float32),
+            "scale": torch.tensor(1.0 / scale, dtype=torch.float32),
+            "center": torch.tensor(center, dtype=torch.float32),
+        }
+        if seal_config.get("mapSource"):
+            self.map_data["empty_bound"] = torch.tensor(from_b, dtype=torch.float32)
+            self.map_data["map_source"] = torch.tensor(seal_config["mapSource"], dtype=torch.float32)
+        self.map_triangles = torch.tensor(tris, dtype=torch.float32)
+        self.device = torch.device("cpu")
+
+    def to(self, device):
+        if device != self.device:
+            self.map_data = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in self.map_data.items()}
+            self.map_triangles = self.map_triangles.to(device)
+            self.device = device
+        return self
+
+    def map_mask(self, points):
+        """AABB pre-test (incl. the reference's `points.all(1)` term) then the mesh inside test — seal_utils.py:132-153"""
+        bounds = self.map_data["map_bound"]
+        if bounds.ndim == 2:
+            bounds = bounds[None]
+        mask = None
+        for i in range(bounds.shape[0]):
+            cur = points.all(1) & ((bounds[i][1] > points) & (points > bounds[i][0])).all(1)
+            mask = cur if mask is None else (mask | cur)
+        if not mask.any():
+            return mask
+        inside = points_in_mesh(points[mask], self.map_triangles)
+        mask[mask.clone()] = inside
+        return mask
+
+    @torch.autocast("cuda", enabled=False)
+    def map_to_origin(self, points, dirs=None):
+        """seal_utils.py:237-279"""
+        self.to(points.device)
+        mask = self.map_mask(points)
+        if not mask.any():
+            return points, dirs, mask
+        inner = points[mask]
+        hom = torch.vstack([inner.T, torch.ones([1, inner.shape[0]], device=inner.device)])
+        moved = torch.matmul(self.map_data["transform"], hom).T[:, :3]
+        origin = (moved - self.map_data["center"]) * self.map_data["scale"] + self.map_data["center"]
+        out_p = points.clone()
+        out_d = dirs.clone() if dirs is not None else None
+        if "map_source" in self.map_data:
+            sb = self.map_data["empty_bound"]
+            out_p[((sb[1] > points) & (points > sb[0])).all(1)] = self.map_data["map_source"]
+        out_p[mask] = origin
+        if dirs is not None:
+            out_d[mask] = torch.matmul(self.map_data["rotation"], dirs[mask].T).T
+        return out_p, out_d, mask
+
+    def map_color(self, points, dirs, colors):
+        return colors  # hsv / rgb / image remaps are outside the BASELINE configs
+
+
+def get_seal_mapper(config_dict=None, config_file=None):
+    """seal_utils.py:573-584 (plain JSON instead of json5)"""
+    if config_dict is None:
+        with open(config_file) as f:
+            config_dict = json.load(f)
+    if config_dict["type"] == "bbox":
+        return SealBBoxMapper(config_dict)
+    raise NotImplementedError(f"seal tool `{config_dict['type']}` is outside the BASELINE configs (bbox only)")
