@@ -1,0 +1,101 @@
+"""TensoRF (vector-matrix) backbone of BASELINE config 5 — counterpart of tensoRF/network.py:13-199.
+
+Density rank 16x3, colour rank 48x3 plane/line factors sampled with stock `F.grid_sample` (the reference has no custom
+kernel here either, tensoRF/network.py:125-126), `basis_mat` 144 -> 27, colour MLP on
+FreqEncoder(27, deg 2) + FreqEncoder(3, deg 2) = 150 -> 128 -> 128 -> 3.  The hot-path pieces it exercises are the
+HIP `freqencoder` and `raymarching` packages.  Parameter names follow the reference (sigma_mat/sigma_vec/color_mat/
+color_vec/basis_mat/color_net) so checkpoints keep their keys."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from activation import trunc_exp
+from encoding import get_encoder
+from nerf.renderer import NeRFRenderer
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, resolution=(128, 128, 128), sigma_rank=(16, 16, 16), color_rank=(48, 48, 48), color_feat_dim=27,
+                 num_layers=3, hidden_dim=128, bound=1, **kwargs):
+        super().__init__(bound, **kwargs)
+        self.resolution = list(resolution)
+        self.sigma_rank, self.color_rank, self.color_feat_dim = list(sigma_rank), list(color_rank), color_feat_dim
+        self.mat_ids = [[0, 1], [0, 2], [1, 2]]
+        self.vec_ids = [2, 1, 0]
+        self.sigma_mat, self.sigma_vec = self.init_one_svd(self.sigma_rank, self.resolution)
+        self.color_mat, self.color_vec = self.init_one_svd(self.color_rank, self.resolution)
+        self.basis_mat = nn.Linear(sum(self.color_rank), color_feat_dim, bias=False)
+        self.num_layers, self.hidden_dim = num_layers, hidden_dim
+        self.encoder, enc_dim = get_encoder("frequency", input_dim=color_feat_dim, multires=2)
+        self.encoder_dir, enc_dim_dir = get_encoder("frequency", input_dim=3, multires=2)
+        self.in_dim = enc_dim + enc_dim_dir
+        dims = [self.in_dim] + [hidden_dim] * (num_layers - 1) + [3]
+        self.color_net = nn.ModuleList([nn.Linear(i, o, bias=False) for i, o in zip(dims[:-1], dims[1:])])
+        if self.bg_radius > 0:
+            raise NotImplementedError("background model is outside the BASELINE configs")
+
+    def init_one_svd(self, n_component, resolution, scale=0.1):
+        mat, vec = [], []
+        for i, vec_id in enumerate(self.vec_ids):
+            m0, m1 = self.mat_ids[i]
+            mat.append(nn.Parameter(scale * torch.randn((1, n_component[i], resolution[m1], resolution[m0]))))
+            vec.append(nn.Parameter(scale * torch.randn((1, n_component[i], resolution[vec_id], 1))))
+        return nn.ParameterList(mat), nn.ParameterList(vec)
+
+    def _coords(self, x):
+        mat = torch.stack([x[..., ids] for ids in self.mat_ids]).view(3, -1, 1, 2)
+        vec = torch.stack([x[..., i] for i in self.vec_ids])
+        vec = torch.stack((torch.zeros_like(vec), vec), dim=-1).view(3, -1, 1, 2)
+        return mat, vec
+
+    def _factors(self, mats, vecs, x):
+        N = x.shape[0]
+        mat_coord, vec_coord = self._coords(x)
+        mf = [F.grid_sample(mats[i], mat_coord[[i]], align_corners=True).view(-1, N) for i in range(3)]
+        vf = [F.grid_sample(vecs[i], vec_coord[[i]], align_corners=True).view(-1, N) for i in range(3)]
+        return mf, vf
+
+    def get_sigma_feat(self, x):
+        mf, vf = self._factors(self.sigma_mat, self.sigma_vec, x)
+        out = torch.zeros([x.shape[0]], device=x.device)
+        for m, v in zip(mf, vf):
+            out = out + torch.sum(m * v, dim=0)
+        return out
+
+    def get_color_feat(self, x):
+        mf, vf = self._factors(self.color_mat, self.color_vec, x)
+        return self.basis_mat((torch.cat(mf, dim=0) * torch.cat(vf, dim=0)).T)
+
+    def _normalize(self, x):
+        return 2 * (x - self.aabb_train[:3]) / (self.aabb_train[3:] - self.aabb_train[:3]) - 1
+
+    def forward(self, x, d):
+        x = self._normalize(x)
+        sigma = trunc_exp(self.get_sigma_feat(x))
+        h = torch.cat([self.encoder(self.get_color_feat(x)), self.encoder_dir(d)], dim=-1)
+        for k, layer in enumerate(self.color_net):
+            h = layer(h)
+            if k != self.num_layers - 1:
+                h = F.relu(h, inplace=True)
+        return sigma, torch.sigmoid(h)
+
+    def density(self, x):
+        return {"sigma": trunc_exp(self.get_sigma_feat(self._normalize(x)))}
+
+    def get_params(self, lr1, lr2=None):
+        lr2 = lr1 if lr2 is None else lr2
+        return [{"params": self.sigma_mat, "lr": lr1}, {"params": self.sigma_vec, "lr": lr1},
+                {"params": self.color_mat, "lr": lr1}, {"params": self.color_vec, "lr": lr1},
+                {"params": self.basis_mat.parameters(), "lr": lr2}, {"params": self.color_net.parameters(), "lr": lr2}]
+
+    @torch.no_grad()
+    def upsample_model(self, resolution):
+        """bilinear re-sampling of all factors to a new resolution (tensoRF/network.py:266-318)"""
+        def up(mats, vecs):
+            for i, vec_id in enumerate(self.vec_ids):
+                m0, m1 = self.mat_ids[i]
+                mats[i] = nn.Parameter(F.interpolate(mats[i].data, size=(resolution[m1], resolution[m0]), mode="bilinear", align_corners=True))
+                vecs[i] = nn.Parameter(F.interpolate(vecs[i].data, size=(resolution[vec_id], 1), mode="bilinear", align_corners=True))
+        up(self.sigma_mat, self.sigma_vec)
+        up(self.color_mat, self.color_vec)
+        self.resolution = list(resolution)

@@ -1,0 +1,76 @@
+"""GPU smoke/parity of the remaining BASELINE configurations on the product path:
+config 3 (Seal bbox distillation, teacher+student NGP) and config 5 (TensoRF VM backbone with the HIP freq encoder)."""
+import pytest
+import torch
+
+from nerf import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+BBOX = {"type": "bbox",
+        "raw": [[x, y, z] for x in (-0.2, 0.2) for y in (0.0, 0.3) for z in (-0.2, 0.2)],
+        "transform": [[1, 0, 0, 0.3], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], "scale": [1, 1, 1], "boundType": "both"}
+
+
+def test_seal_bbox_distillation_on_gpu(hip):
+    from nerf import network
+    from sealnerf import SealBBoxMapper, SealTrainer, make_student, make_teacher
+    torch.manual_seed(0)
+    kw = dict(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10)
+    teacher = make_teacher(network.NeRFNetwork, **kw).cuda()
+    student = make_student(network.NeRFNetwork, **kw).cuda()
+    # a "pretrained" teacher: occupancy of the synthetic scene + some structure in the weights
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    teacher.density_grid.copy_(torch.from_numpy(grid))
+    teacher.density_bitfield.copy_(torch.from_numpy(bits))
+    for p in teacher.parameters():
+        p.data.uniform_(-0.2, 0.2)
+    student.load_state_dict(teacher.state_dict())
+    mapper = SealBBoxMapper(BBOX)
+    teacher.init_mapper(mapper)
+    student.init_mapper(mapper)
+    tr = SealTrainer(student, teacher, lr=1e-2, fp16=True)
+    n = tr.init_pretraining(batch_size=1 << 20, lr=0.05, local_point_step=0.01)
+    assert n > 50000
+    losses = [float(tr.pretrain_one_epoch()) for _ in range(6)]
+    assert losses[-1] < losses[0], losses
+    assert torch.equal(student.sigma_net[0].weight, teacher.sigma_net[0].weight)  # MLPs frozen
+    # global fine-tuning steps against teacher-rendered targets
+    poses = syn.orbit_poses(2, seed=1).cuda()
+    g = torch.Generator().manual_seed(0)
+    student.mean_count = 0
+    for i in range(3):
+        r = syn.get_rays(poses[i % 2:i % 2 + 1], syn.lego_intrinsics(), 800, 800, N=4096, generator=g)
+        loss = tr.train_step(r["rays_o"].contiguous(), r["rays_d"].contiguous())
+        assert torch.isfinite(loss)
+    # edited-view render: the teacher shows source content at the target location
+    r = syn.get_rays(poses[:1], syn.lego_intrinsics(100, 100), 100, 100)
+    img, depth = tr.proxy_truth(r["rays_o"].contiguous(), r["rays_d"].contiguous())
+    assert img.shape == (1, 10000, 3) and torch.isfinite(img).all()
+
+
+def test_tensorf_vm48_step_on_gpu(hip):
+    from tensoRF import network as trf
+    from nerf.trainer import Trainer
+    torch.manual_seed(0)
+    net = trf.NeRFNetwork(resolution=[128] * 3, bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).cuda()
+    assert net.in_dim == 150 and net.color_net[0].weight.shape == (128, 150)
+    nparams = sum(p.numel() for p in net.parameters())
+    assert nparams == 3 * 16 * (128 * 128 + 128) + 3 * 48 * (128 * 128 + 128) + 144 * 27 + 150 * 128 + 128 * 128 + 128 * 3
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    net.density_grid.copy_(torch.from_numpy(grid))
+    net.density_bitfield.copy_(torch.from_numpy(bits))
+    net.iter_density = 100
+    tr = Trainer(net, lr=2e-2, fp16=True, update_extra_interval=10 ** 9)
+    tr.global_step = 1
+    poses = syn.orbit_poses(1, seed=0).cuda()
+    r = syn.get_rays(poses, syn.lego_intrinsics(), 800, 800, N=4096, generator=torch.Generator().manual_seed(0))
+    ro, rd = r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous()
+    gt = torch.rand(4096, 3, device="cuda")
+    l0 = float(tr.train_step(ro, rd, gt))
+    for _ in range(10):
+        l1 = float(tr.train_step(ro, rd, gt))
+    assert l1 < l0
+    net.upsample_model([160] * 3)
+    out = tr.render_image(ro[None, :1000], rd[None, :1000])
+    assert out["image"].shape == (1, 1000, 3) and torch.isfinite(out["image"]).all()
