@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--num_rays", type=int, default=4096)
     ap.add_argument("--pretrain", type=int, default=384, help="untimed setup steps that converge the occupancy grid")
     ap.add_argument("--net", choices=["ff", "seal"], default="ff", help="ff: nerf/network_ff (configs[1]); seal: two-encoder nn.Linear net")
+    ap.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_render", action="store_true")
     ap.add_argument("--cpu_steps", type=int, default=2)
@@ -186,14 +187,18 @@ def main():
     import s3d_hip
     s3d_hip.lib()
     from nerf import network, network_ff, synthetic as syn
-    from nerf.trainer import Trainer, psnr
+    from nerf.trainer import GraphedTrainer, Trainer, psnr
     import torch.distributed as dist
 
     torch.manual_seed(args.seed)
     Net = network_ff.NeRFNetwork if args.net == "ff" else network.NeRFNetwork
     model = Net(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).to(dev)
     dp = RayShardedDP() if world > 1 else None
-    trainer = Trainer(model, lr=1e-2, fp16=True, update_extra_interval=16, dist=dp)
+    if args.no_graph or world > 1:  # the RCCL all-reduce stays outside graph capture (untested on this pool)
+        args.no_graph = True
+        trainer = Trainer(model, lr=1e-2, fp16=True, update_extra_interval=16, dist=dp)
+    else:
+        trainer = GraphedTrainer(model, args.num_rays, lr=1e-2, fp16=True, update_extra_interval=16, dist=dp)
 
     R = s3d_hip.RaymarchingBackend
     grid, bits = syn.lego_like_density_grid(seed=0)
@@ -218,11 +223,16 @@ def main():
         step(i)
 
     timers = KernelTimers(s3d_hip.GridBackend, ["grid_encode_forward", "grid_encode_backward"])
-    timers.install(grid_meta)
     rt = KernelTimers(s3d_hip.RaymarchingBackend, ["march_rays_train", "composite_rays_train_forward", "composite_rays_train_backward"])
-    rt.install(lambda n, a: 0)
     ft = KernelTimers(s3d_hip.FFMLPBackend, ["ffmlp_forward", "ffmlp_backward"])
-    ft.install(lambda n, a: a[2] if n == "ffmlp_forward" else a[4])
+    graphed = not args.no_graph
+
+    def install_timers():
+        timers.install(grid_meta)
+        rt.install(lambda n, a: 0)
+        ft.install(lambda n, a: a[2] if n == "ffmlp_forward" else a[4])
+    if not graphed:
+        install_timers()
 
     samples_dev = torch.zeros(1, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
@@ -238,6 +248,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    timer_steps = args.steps
+    if graphed:
+        # HIP events cannot be recorded inside a graph replay: time the individual kernels in an eager pass of the
+        # SAME step on the same state, immediately after the timed region (not part of `value`)
+        eager = Trainer(model, lr=1e-2, fp16=True, update_extra_interval=10 ** 9, dist=None)
+        eager.optimizer, eager.scaler, eager.global_step = trainer.optimizer, trainer.scaler, 1
+        install_timers()
+        timer_steps = 8
+        for i in range(timer_steps):
+            ro, rd, gt = batches[i % n_pool]
+            eager.train_step(ro, rd, gt)
+        torch.cuda.synchronize()
     for t in (timers, rt, ft):
         t.remove()
 
@@ -266,7 +288,10 @@ def main():
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_us": kd["avg_us"], "points_per_launch": kd["units"],
                 "algorithmic_bytes_per_point": bytes_pt,
-                "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in ksum.items()}}
+                "kernels_ms_per_step": {k: v["total_ms"] / timer_steps for k, v in ksum.items()},
+                "timing": "HIP events around each native call on the launch stream; " +
+                          ("eager pass of 8 identical steps right after the graph-replayed timed region" if graphed
+                           else "inside the timed region")}
 
     extra = {}
     if not args.no_render:
@@ -297,7 +322,8 @@ def main():
                                "800x800 cameras, 4096 rays/step/GPU" if args.net == "ff" else
                                "Seal NGP net (two hash encoders + nn.Linear MLPs), 800x800 cameras, 4096 rays/step/GPU",
                    "num_rays_per_gpu": args.num_rays, "samples_per_step": samples / args.steps / world,
-                   "parallelism": f"ray-sharded dp{world}", "pretrain_steps": args.pretrain},
+                   "parallelism": f"ray-sharded dp{world}", "pretrain_steps": args.pretrain,
+                   "launch": "hip-graph replay" if graphed else "eager"},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     line.update(extra)
