@@ -406,7 +406,7 @@ __global__ void k_ffmlp_wgrad_reduce(WgradPlan plan, uint32_t nblk, const float*
     grad_weights[L.w_off + e] = (_Float16)((s0 + s1) + (s2 + s3));
 }
 
-constexpr uint32_t kWgradBlocks = 64;
+constexpr uint32_t kWgradBlocks = 256;
 
 int check_shape(uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t W, uint32_t n_layers) {
     S3D_REQUIRE(W == 32 || W == 64, "ffmlp: hidden_dim %u not supported by the MFMA path (32 or 64)", W);

@@ -522,93 +522,115 @@ __global__ void __launch_bounds__(kBwdThreads) k_grid_backward_lds(const T* __re
 
     auto run = [&](auto mode) {
         uint32_t qlen = 0;  // wave-uniform
-        auto drain = [&](uint32_t first, uint32_t count) {  // lanes [0,count) take entries first..first+count-1
-            if (lane < count) {
-                const uint32_t ent = queue[first + lane];
-                uint32_t b = ent >> D;  // slot in the packed array (D <= 3) or point index
-                const uint32_t idx = ent & ((1u << D) - 1);
-                float x[D], pos[D], pd[D];
+        // Drain, software-pipelined by one stage: a drain ISSUES the loads of its 64 entries (packed point + gradient
+        // row) and PROCESSES the entries whose loads the previous drain issued, so the ~1-2 us round trip overlaps
+        // the scan in between instead of stalling the wave (PMC: 51 % of wave cycles were s_waitcnt stalls).
+        bool pend = false;           // this lane holds a loaded, unprocessed entry
+        uint32_t pend_idx = 0, pend_b = 0;
+        float pend_x[D];
+        T pend_g[C];
+        auto process = [&]() {
+            if (pend) {
+                float pos[D], pd[D];
                 uint32_t pos_grid[D], lo[D], hi[D];
-                if constexpr (D <= 3) {
-                    const float4 p = packed[b];
-                    const float v[3] = {p.x, p.y, p.z};
-#pragma unroll
-                    for (uint32_t d = 0; d < D; d++) x[d] = v[d];
-                    b = __float_as_uint(p.w);  // original point index, for the gradient row
-                } else {
-#pragma unroll
-                    for (uint32_t d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
-                }
-                locate<D>(x, lscale, align_corners, interp, pos, pd, pos_grid);
+                locate<D>(pend_x, lscale, align_corners, interp, pos, pd, pos_grid);
                 corner_terms(mode, pos_grid, lo, hi);
-                const uint32_t local = row_of(mode, lo, hi, idx) - row0;
+                const uint32_t local = row_of(mode, lo, hi, pend_idx) - row0;
                 float w = 1;
 #pragma unroll
-                for (uint32_t d = 0; d < D; d++) w *= ((idx >> d) & 1u) ? pos[d] : 1 - pos[d];
-                T g[C];
-                load_feat<T, C>(glevel + (size_t)b * C, g);
+                for (uint32_t d = 0; d < D; d++) w *= ((pend_idx >> d) & 1u) ? pos[d] : 1 - pos[d];
 #pragma unroll
                 for (uint32_t c = 0; c < C; c++) {
                     // same product the reference forms (float w * grad), then exact scaling to 64-bit fixed point
                     float prod;
-                    if constexpr (sizeof(T) == 2) prod = __half2float(__float2half(w * __half2float(g[c])));
-                    else prod = w * g[c];
+                    if constexpr (sizeof(T) == 2) prod = __half2float(__float2half(w * __half2float(pend_g[c])));
+                    else prod = w * pend_g[c];
                     atomicAdd(&acc[local * C + c], (unsigned long long)to_fixed64(prod, kexp));
                 }
+                pend = false;
             }
         };
-        auto scan = [&](uint32_t b, const float (&x)[D]) {
-            bool oob = false;
+        auto drain = [&](uint32_t first, uint32_t count) {  // lanes [0,count) take entries first..first+count-1
+            process();
+            if (lane < count) {
+                const uint32_t ent = queue[first + lane];
+                uint32_t b = ent >> D;  // slot in the packed array (D <= 3) or point index
+                pend_idx = ent & ((1u << D) - 1);
+                if constexpr (D <= 3) {
+                    const float4 p = packed[b];
+                    const float v[3] = {p.x, p.y, p.z};
 #pragma unroll
-            for (uint32_t d = 0; d < D; d++) oob |= !(x[d] >= 0 && x[d] <= 1);  // also true for the NaN marker
-            float pos[D], pd[D];
-            uint32_t pos_grid[D], lo[D], hi[D];
-            locate<D>(x, lscale, align_corners, interp, pos, pd, pos_grid);
-            corner_terms(mode, pos_grid, lo, hi);
-            uint32_t hits = 0;
+                    for (uint32_t d = 0; d < D; d++) pend_x[d] = v[d];
+                    b = __float_as_uint(p.w);  // original point index, for the gradient row
+                } else {
 #pragma unroll
-            for (uint32_t idx = 0; idx < (1u << D); idx++)
-                hits |= ((row_of(mode, lo, hi, idx) - row0) < nrows ? 1u : 0u) << idx;
-            if (oob) hits = 0;
+                    for (uint32_t d = 0; d < D; d++) pend_x[d] = inputs[(size_t)b * D + d];
+                }
+                pend_b = b;
+                load_feat<T, C>(glevel + (size_t)b * C, pend_g);
+                pend = true;
+            }
+        };
+        // Scan kUnroll points per lane, then append ALL their hits with one wave prefix sum: the hit test is pure
+        // VALU, and the VALU->SGPR->branch round trips of the queue bookkeeping (ballots, popcounts, drain test) are
+        // paid once per kUnroll points instead of once per point.
+        constexpr uint32_t kCorners = 1u << D;
+        constexpr uint32_t kUnroll = kCorners <= 8 ? 4 : (kCorners <= 16 ? 2 : 1);
+        static_assert(kUnroll * kCorners <= 32, "per-lane hit mask must fit 32 bits");
+        auto scan = [&](uint32_t b0, const float (&xs)[kUnroll][D]) {
+            uint32_t hits = 0;  // bit (u * 2^D + corner)
+#pragma unroll
+            for (uint32_t u = 0; u < kUnroll; u++) {
+                bool oob = false;
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) oob |= !(xs[u][d] >= 0 && xs[u][d] <= 1);  // also true for the padding marker
+                float pos[D], pd[D];
+                uint32_t pos_grid[D], lo[D], hi[D];
+                locate<D>(xs[u], lscale, align_corners, interp, pos, pd, pos_grid);
+                corner_terms(mode, pos_grid, lo, hi);
+                uint32_t h = 0;
+#pragma unroll
+                for (uint32_t idx = 0; idx < kCorners; idx++)
+                    h |= ((row_of(mode, lo, hi, idx) - row0) < nrows ? 1u : 0u) << idx;
+                hits |= (oob ? 0u : h) << (u * kCorners);
+            }
             if (__ballot(hits != 0) == 0) return;
-            // wave prefix sum of per-lane hit counts -> queue slots
-            // exclusive prefix sum of the per-lane hit counts (<= 2^D, i.e. D+1 bits) from ballots of the count bits:
-            // pure VALU/SALU, no cross-lane LDS traffic (a shuffle ladder costs ~6 dependent ds_bpermute round trips)
+            // exclusive prefix sum of the per-lane hit counts from ballots of the count bits (no LDS round trips)
             const uint32_t cnt = __popc(hits);
             uint32_t excl = 0, total = 0;
 #pragma unroll
-            for (uint32_t k = 0; k <= D; k++) {
+            for (uint32_t k = 0; k < 6; k++) {
                 const unsigned long long mk = __ballot((cnt >> k) & 1u);
                 excl += __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u)) << k;
                 total += (uint32_t)__popcll(mk) << k;
             }
-            uint32_t slot = qlen + excl;
             if (total <= kQueueLen - 64) {
+                uint32_t slot = qlen + excl;
                 while (hits) {
-                    const uint32_t idx = __builtin_ctz(hits);
+                    const uint32_t j = __builtin_ctz(hits);
                     hits &= hits - 1;
-                    queue[slot++] = (b << D) | idx;
+                    queue[slot++] = ((b0 + (j / kCorners) * kBwdThreads) << D) | (j % kCorners);
                 }
                 qlen += total;
                 while (qlen >= 64) { qlen -= 64; drain(qlen, 64); }
-            } else {  // pathological density (e.g. many identical points): one corner at a time
+            } else {  // pathological density (e.g. many identical points): one (point, corner) at a time
 #pragma unroll 1
-                for (uint32_t idx = 0; idx < (1u << D); idx++) {
-                    const bool hit = (hits >> idx) & 1u;
+                for (uint32_t j = 0; j < kUnroll * kCorners; j++) {
+                    const bool hit = (hits >> j) & 1u;
                     const unsigned long long m = __ballot(hit);
-                    if (hit) queue[qlen + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (b << D) | idx;
+                    if (hit) queue[qlen + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                        ((b0 + (j / kCorners) * kBwdThreads) << D) | (j % kCorners);
                     qlen += (uint32_t)__popcll(m);
                     if (qlen >= 64) { qlen -= 64; drain(qlen, 64); }
                 }
             }
         };
-        constexpr uint32_t kUnroll = 2;
-        const uint32_t per_round = kBwdThreads * kUnroll;
-        const uint32_t rounds = div_up<uint32_t>(n_points, per_round);
         // All co-resident workgroups sweep the point array in the SAME order: the 32 CUs of an XCD then touch the
         // same window at about the same time and share it through their L2.  (PMC, profiles/r01: with per-workgroup
         // start offsets FETCH_SIZE was 2.8 GB per launch — 70 % of the 930 x 4.2 MB point re-reads missed the 4 MiB
         // L2 and the sweep ran at the fabric's ~2.4 TB/s.)
+        const uint32_t per_round = kBwdThreads * kUnroll;
+        const uint32_t rounds = div_up<uint32_t>(n_points, per_round);
         auto fetch = [&](uint32_t r, float (&xs)[kUnroll][D]) {
             const uint32_t b0 = r * per_round + threadIdx.x;
 #pragma unroll
@@ -632,8 +654,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_grid_backward_lds(const T* __re
         uint32_t b_cur = fetch(0, cur), b_nxt = 0;
         for (uint32_t r = 0; r < rounds; r++) {
             if (r + 1 < rounds) b_nxt = fetch(r + 1, nxt);
-#pragma unroll
-            for (uint32_t u = 0; u < kUnroll; u++) scan(b_cur + u * kBwdThreads, cur[u]);
+            scan(b_cur, cur);
 #pragma unroll
             for (uint32_t u = 0; u < kUnroll; u++)
 #pragma unroll
@@ -641,6 +662,7 @@ __global__ void __launch_bounds__(kBwdThreads) k_grid_backward_lds(const T* __re
             b_cur = b_nxt;
         }
         drain(0, qlen);
+        process();
     };
     bool all_dims = true;
 #pragma unroll
