@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_render", action="store_true")
+    ap.add_argument("--infer_batch_scale", type=int, default=4, help="inference samples/ray/iteration multiplier (1 = reference heuristic)")
     ap.add_argument("--cpu_steps", type=int, default=2)
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
@@ -296,6 +297,7 @@ def main():
     extra = {}
     if not args.no_render:
         # full 800x800 frame renders (inference loop) + PSNR against the analytic scene
+        model.infer_batch_scale = args.infer_batch_scale
         r = syn.get_rays(poses[:1].to(dev), syn.lego_intrinsics(), 800, 800)
         ro, rd = r["rays_o"].contiguous(), r["rays_d"].contiguous()
         out = trainer.render_image(ro, rd)
@@ -308,7 +310,7 @@ def main():
         dtr = (time.perf_counter() - tr0) / nfr
         gt = torch.cat([analytic_targets(ro[0, i:i + 160000].contiguous(), rd[0, i:i + 160000].contiguous(), scene_bits, boxes, R)
                         for i in range(0, 640000, 160000)])
-        extra = {"render_mrays_per_s": 0.64 / dtr, "render_ms_per_frame": dtr * 1e3, "psnr_vs_analytic_scene": psnr(out["image"][0], gt)}
+        extra = {"render_infer_batch_scale": args.infer_batch_scale, "render_mrays_per_s": 0.64 / dtr, "render_ms_per_frame": dtr * 1e3, "psnr_vs_analytic_scene": psnr(out["image"][0], gt)}
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:

@@ -25,7 +25,7 @@ def _meshgrid(*args):
 
 class NeRFRenderer(nn.Module):
     def __init__(self, bound=1, cuda_ray=False, density_scale=1, min_near=0.2, density_thresh=0.01, bg_radius=-1,
-                 device_compaction=True):
+                 device_compaction=True, infer_batch_scale=1):
         super().__init__()
         self.bound = bound
         self.cascade = 1 + math.ceil(math.log2(bound))
@@ -35,6 +35,10 @@ class NeRFRenderer(nn.Module):
         self.density_thresh = density_thresh
         self.bg_radius = bg_radius
         self.device_compaction = device_compaction
+        # inference: samples marched per alive ray and iteration = min(scale*N // n_alive, 8*scale).  1 = the reference's
+        # heuristic (keeps ~N samples per iteration, nerf/renderer.py:352); larger values trade a few wasted samples of
+        # rays that terminate mid-chunk for fewer, fuller iterations.  The composited result does not depend on it.
+        self.infer_batch_scale = infer_batch_scale
 
         aabb = torch.FloatTensor([-bound, -bound, -bound, bound, bound, bound])
         self.register_buffer("aabb_train", aabb)
@@ -121,7 +125,7 @@ class NeRFRenderer(nn.Module):
             use_dev_compaction = self.device_compaction and device.type == "cuda"
             step = 0
             while step < max_steps and n_alive > 0:
-                n_step = max(min(N // n_alive, 8), 1)
+                n_step = max(min(self.infer_batch_scale * N // n_alive, 8 * self.infer_batch_scale), 1)
                 xyzs, dirs, deltas = raymarching.march_rays(
                     n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
                     self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma, max_steps)
