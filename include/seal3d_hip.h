@@ -134,16 +134,20 @@ int s3d_grid_corner_indices(const float* inputs, const int32_t* offsets, uint32_
 /* gridencoder.h:13 void grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C,
  *                        L, S, H, dy_dx, grad_inputs, gridtype, align_corners, interp)
  * grad [L,B,C]; grad_embeddings [table_rows,C] zero-initialised by the caller, accumulated into.
- * table_rows = rows of the embedding table (offsets[L], known to the host from the tensor shape).
- * workspace (s3d_grid_encode_backward_workspace_size bytes) enables the LDS fixed-point sweep used for
- * B >= 8192: deterministic, no global atomics; without it (NULL) direct atomics are used. */
-size_t s3d_grid_encode_backward_workspace_size(uint32_t B);
+ * max_level_rows = max over levels of offsets[l+1]-offsets[l] (the module builds `offsets` on the host,
+ * grid.py:104-112, so it knows it; 0 = unknown).
+ * workspace (s3d_grid_encode_backward_workspace_size bytes; 0 = configuration not supported) enables the
+ * binned path used for B >= 8192: contributions are partitioned by table slice and summed in LDS as 64-bit
+ * fixed point — deterministic, no global atomics.  Without it (NULL) direct atomics are used. */
+size_t s3d_grid_encode_backward_workspace_size(uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                               uint32_t max_level_rows, int dtype);
 int s3d_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
-                             const int32_t* offsets, void* grad_embeddings, uint32_t table_rows, uint32_t B,
-                             uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H, const void* dy_dx,
-                             void* grad_inputs, uint32_t gridtype, int align_corners, uint32_t interp,
-                             int dtype, void* workspace, size_t workspace_bytes, s3d_stream_t stream);
-/* experiments/tests: 0 = auto, 1 = direct atomics, 2 = LDS fixed-point sweep */
+                             const int32_t* offsets, void* grad_embeddings, uint32_t max_level_rows,
+                             uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                             const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
+                             uint32_t interp, int dtype, void* workspace, size_t workspace_bytes,
+                             s3d_stream_t stream);
+/* experiments/tests: 0 = auto, 1 = direct atomics, 2 = binned (partition + LDS accumulate) */
 void s3d_grid_backward_set_path(int path);
 
 /* gridencoder.h:15 void grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H,

@@ -15,14 +15,8 @@
 //    half accumulators with one rounding per op like the reference's at::Half registers), so
 //    corner rows are bit-exact and outputs match the oracle to the last bit.
 //  * The per-level scale table is computed once on the host (glibc exp2f) and passed by value.
-//  * Backward.  Measured on MI355X: global fp atomics retire at a flat ~21 G/s chip-wide (memory-side,
-//    independent of table size or XCD locality) and LDS *float* atomics at ~0.2 T/s, while LDS *integer*
-//    atomics run at ~2.3 T/s (tools/ubench).  The table gradient is therefore accumulated in LDS as 64-bit
-//    fixed point: the table is cut into 160 KiB slices, one workgroup owns one (level, slice), scans all
-//    points, adds the contributions that land in its slice with ds_add_u64, and writes the slice back with
-//    coalesced stores.  Integer adds commute, so the result is bit-reproducible run to run (the reference's
-//    atomics are not) and carries ~40 bits below the largest |grad| of the level — more accurate than fp32
-//    atomics.  Small batches keep the direct-atomic kernel (fixed cost of the slice sweep ~25 us).
+//  * Backward: direct atomics for small batches; for training-size batches the contributions are partitioned by
+//    table slice and summed in LDS as 64-bit fixed point (see "binned backward" below): deterministic, no global atomics.
 #include "s3d_common.hpp"
 #include <math.h>
 #include <type_traits>
@@ -322,361 +316,386 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_backward(const T* __restrict
 }
 
 
-// ---- LDS fixed-point backward -----------------------------------------------------------------------
-// v * 2^k as a 64-bit integer: v = m * 2^(ex-24) with a 24-bit integer mantissa m, so the product is a shift
-// (round-half-up when bits fall off the bottom).  Callers guarantee |v| * 2^k < 2^62.
-__device__ __forceinline__ long long to_fixed64(float v, int k) {
-    int ex;
-    const float f = frexpf(v, &ex);
-    const long long m = (long long)(int)ldexpf(f, 24);
-    const int sh = k + ex - 24;
-    if (sh >= 0) return m << sh;
-    if (sh > -26) return (m + (1ll << (-sh - 1))) >> (-sh);
-    return 0;
-}
-constexpr uint32_t kLdsBytes = 160 * 1024;
-constexpr uint32_t kBwdThreads = 1024;
-constexpr uint32_t kQueueLen = 192;                                   // per-wave hit queue entries (<64 pending + <=128 appended)
-constexpr uint32_t kQueueBytes = (kBwdThreads / 64) * kQueueLen * 4;  // 8 KiB at the top of the LDS allocation
-constexpr uint32_t kAccBytes = kLdsBytes - kQueueBytes;
-// Every workgroup scans all points, so its cost is (scan) + (hits); hits per workgroup = B * 2^D / slices(level).
-// Coarse levels have few rows: cutting them by LDS capacity alone would leave ONE workgroup with every hit of the
-// level (measured: the level-0 workgroup set the kernel time).  Each level is therefore cut into at least
-// kMinSlices slices — the slice count LDS capacity forces on a 2^19-row hashed level.
-__host__ __device__ constexpr uint32_t bwd_min_slices(uint32_t C) { return div_up<uint32_t>(1u << 19, kAccBytes / (8 * C)); }
-__host__ __device__ inline uint32_t bwd_slice_rows(uint32_t rows, uint32_t C) {
-    const uint32_t cap = kAccBytes / (8 * C);
-    uint32_t r = div_up<uint32_t>(div_up<uint32_t>(rows, bwd_min_slices(C)), 8u) * 8u;
-    return r < cap ? (r ? r : 8u) : cap;
-}
+// ---- binned backward: partition the contributions by table slice, accumulate each slice in LDS --------------
+// v * 2^k rounded to the nearest integer (ties to even).  A float has 24 significant bits and callers keep
+// |v| * 2^k < 2^62, so the scaled double is exact and only the final conversion rounds.
+// [An all-integer version (frexp mantissa shifted with variable 64-bit shifts inside divergent branches) returned wrong
+//  values for a few lanes per million when inlined next to ds_add_u64 on gfx950 / ROCm 7.2 — the same source is exact
+//  in a plain store kernel.  tools/ubench/fix64_lds.hip reproduces it and verifies this form bit for bit.]
+__device__ __forceinline__ long long to_fixed64(float v, int k) { return __double2ll_rn(ldexp((double)v, k)); }
 
-// Points are re-packed to one 16-byte record each before the sweep: measured on MI355X a wave-level vector load
-// costs ~20 cycles of address-unit time per instruction regardless of width, and a 12-byte-stride [B,3] read is
-// three of them per point (0.34 ns/point/CU) against 0.15 for one aligned float4 — and the sweep reads every point
-// once per (level, slice) workgroup.  Out-of-range points are encoded as NaN.x so the sweep needs no range test.
+// Measured on MI355X (tools/ubench): global fp atomics retire at a flat ~21 G/s chip-wide whatever the locality, LDS
+// float atomics at ~0.2 T/s, LDS *integer* atomics at ~2.3 T/s.  So the table gradient is accumulated in LDS as
+// 64-bit fixed point, one workgroup per (level, table slice), and the (point, level, corner) contributions are first
+// PARTITIONED by slice so that each workgroup streams exactly its own records:
+//   k_bin_count    per-level |grad| max (fixes the fixed-point scale) + records per (level, slice)
+//   k_bin_scatter  one workgroup = one chunk of points at one level: forms the 2^D records of each point
+//                  {row-in-slice, w * grad rounded to T — the product the reference adds}, counting-sorts them by
+//                  slice in an LDS staging buffer, reserves a run in every slice's bucket (one atomic per slice) and
+//                  copies the sorted chunk out as contiguous runs
+//   k_bin_accumulate  one workgroup = one (level, slice): streams its bucket, ds_add_u64 into the slice, adds the
+//                  slice into the table with coalesced stores.
+// Each contribution is computed once and costs one HBM write + one read of an 8-byte record (fp16, C = 2); integer
+// adds commute, so the result is bit-reproducible run to run (the reference's float atomics are not) and carries
+// ~40 bits below the largest |grad| of the level.  Small batches keep the direct-atomic kernel.
+// [An earlier version skipped the partition: every (level, slice) workgroup scanned ALL points and kept the hits.
+//  That is ~55x redundant index arithmetic; the partitioned form measured 2.3-3.5x faster at every size.]
+//
+// Slices are INTERLEAVED in groups of kBinGroup rows (slice = (row / 32) % S): a dense level's rows follow the
+// scene's geometry, and contiguous slices would leave the slabs that cover the object with most of the records.
+#ifndef S3D_BIN_ACC_KB  // tuning knobs of k_bin_accumulate (tools/tune_bin.sh builds variants)
+#define S3D_BIN_ACC_KB 128
+#define S3D_BIN_ACC_THREADS 1024
+#define S3D_BIN_ACC_UNROLL 4
+#endif
+constexpr uint32_t kBinGroup = 32;
+constexpr uint32_t kBinAccBytes = S3D_BIN_ACC_KB * 1024;
+constexpr uint32_t kBinAccThreads = S3D_BIN_ACC_THREADS;
+constexpr uint32_t kBinAccUnroll = S3D_BIN_ACC_UNROLL;
+constexpr uint32_t kBinMinSlices = 64;
+constexpr uint32_t kBinMaxSlices = 512;
+constexpr uint32_t kBinStageBytes = 64 * 1024;
+constexpr uint32_t kBinCtlWords = 3 * kBinMaxSlices;  // cnt / base / gbase
+
+// slices of a level: a power of two (slice / local-row arithmetic is shifts and masks), >= kBinMinSlices for balance
+__host__ __device__ inline uint32_t bin_slices(uint32_t rows, uint32_t C) {
+    const uint32_t cap = kBinAccBytes / (8 * C);  // rows per slice; a multiple of kBinGroup
+    const uint32_t need = div_up<uint32_t>(div_up<uint32_t>(rows, kBinGroup) * kBinGroup, cap);
+    uint32_t s = kBinMinSlices;
+    while (s < need) s <<= 1;
+    return s;
+}
+__host__ __device__ inline uint32_t bin_local_rows(uint32_t rows, uint32_t S) {
+    return div_up<uint32_t>(div_up<uint32_t>(rows, kBinGroup), S) * kBinGroup;
+}
 template <typename T, uint32_t D, uint32_t C>
-__global__ void __launch_bounds__(256) k_pack_points(const float* __restrict__ inputs, const T* __restrict__ grad, uint32_t B,
-                                                     uint32_t L, float4* __restrict__ packed, uint32_t* __restrict__ count) {
-    // Record = (x, y, z, original point index as bits).  Points that cannot contribute are DROPPED here, once,
-    // instead of being re-scanned by every (level, slice) workgroup: out-of-range points, and points whose
-    // gradient is exactly zero on every level (samples behind a ray's early termination, padding rows).
-    // Integer accumulation is order-independent, so compaction does not affect the (bit-reproducible) result.
-    static_assert(D <= 3, "packed record holds up to 3 coordinates + the point index");
-    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    float x[3] = {0, 0, 0};
-    bool keep = b < B;
-    if (keep) {
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++) { x[d] = inputs[(size_t)b * D + d]; keep &= (x[d] >= 0 && x[d] <= 1); }
-    }
-    if (keep) {
-        bool nz = false;
-        for (uint32_t l = 0; l < L && !nz; l++) {
-            T g[C];
-            load_feat<T, C>(grad + ((size_t)l * B + b) * C, g);
-#pragma unroll
-            for (uint32_t c = 0; c < C; c++) nz |= (Acc<T>::to_f(g[c]) != 0.0f);
-        }
-        keep = nz;
-    }
-    const unsigned long long m = __ballot(keep);
-    uint32_t base = 0;
-    if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(count, (uint32_t)__popcll(m));
-    base = __shfl(base, 0, 64);
-    if (keep) {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        packed[base + rank] = make_float4(x[0], x[1], x[2], __uint_as_float(b));
-    }
+__host__ __device__ constexpr uint32_t bin_chunk_points() {
+    const uint32_t rec = 4 + sizeof(T) * C;
+    const uint32_t p = (kBinStageBytes / (rec << D)) / 64 * 64;
+    return p > 1024 ? 1024 : p;
 }
 
-// per-level max |grad| (bit pattern of a non-negative float is monotone as uint32)
-template <typename T>
-__global__ void __launch_bounds__(256) k_grad_absmax(const T* __restrict__ grad, uint32_t per_level, uint32_t* __restrict__ out) {
-    // 16-byte loads, block-level reduction, ONE atomic per workgroup (all workgroups of a level hit the same word)
-    constexpr uint32_t V = 16 / sizeof(T);
-    const T* g = grad + (size_t)blockIdx.y * per_level;
-    float m = 0.0f;
-    auto upd = [&](float v) { v = fabsf(v); m = (v > m || v != v) ? v : m; };  // NaN propagates
-    const uint32_t nvec = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? per_level / V : 0;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
-        const uint4 raw = reinterpret_cast<const uint4*>(g)[i];
-        T v[V];
-        __builtin_memcpy(v, &raw, 16);
+// Level-uniform index plan (get_grid_index, gridencoder.cu:66-84): which dimensions enter the dense index (the
+// stride loop stops once stride > hashmap_size), their strides, whether the level is hashed; `% hashmap_size` is a
+// mask for power-of-two sizes and a no-op for dense rows below the size.  Same rows as grid_row, fewer divisions.
+template <uint32_t D>
+struct LevelIndex {
+    uint32_t mul[D];  // per-dimension multiplier: prime (hashed) or stride (dense; 0 = dimension dropped)
+    uint32_t size, mask;
+    bool hashed, pow2;
+    __device__ __forceinline__ void init(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution) {
+        uint32_t st = 1;
 #pragma unroll
-        for (uint32_t k = 0; k < V; k++) upd(Acc<T>::to_f(v[k]));
-    }
-    for (uint32_t i = nvec * V + blockIdx.x * 256 + threadIdx.x; i < per_level; i += gridDim.x * 256) upd(Acc<T>::to_f(g[i]));
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const float o = __shfl_xor(m, d, 64); m = (o > m || o != o) ? o : m; }
-    __shared__ float part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int w = 1; w < 4; w++) { const float o = part[w]; m = (o > m || o != o) ? o : m; }
-        atomicMax(out + blockIdx.y, __float_as_uint(m));
-    }
-}
-
-template <typename T, uint32_t D, uint32_t C>
-__global__ void __launch_bounds__(kBwdThreads) k_grid_backward_lds(const T* __restrict__ grad, const float* __restrict__ inputs,
-                                                                  const float4* __restrict__ packed,
-                                                                  const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
-                                                                  uint32_t B, uint32_t L, LevelScales scales,
-                                                                  const uint32_t* __restrict__ absmax, uint32_t gridtype,
-                                                                  bool align_corners, uint32_t interp) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);
-    // (level, slice) of this workgroup from the device offset table; the host launches an upper bound
-    // ceil(total_rows / slice) + L workgroups, the surplus exits here
-    uint32_t level = 0, first = 0, slice_rows = 0;
-    for (;; level++) {
-        if (level == L) return;
-        const uint32_t rows = (uint32_t)(offsets[level + 1] - offsets[level]);
-        slice_rows = bwd_slice_rows(rows, C);
-        const uint32_t ns = div_up<uint32_t>(rows, slice_rows);
-        if (blockIdx.x < first + ns) break;
-        first += ns;
-    }
-    const uint32_t slice = blockIdx.x - first;
-    const uint32_t off = (uint32_t)offsets[level];
-    const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
-    const uint32_t row0 = slice * slice_rows;
-    const uint32_t nrows = min(slice_rows, hashmap_size - row0);
-
-    const uint32_t n_points = (D <= 3) ? absmax[kMaxLevels] : B;  // compacted point count (written by k_pack_points)
-    const float amax = __uint_as_float(absmax[level]);
-    if (!(amax > 0.0f)) {
-        if (amax != amax || amax == INFINITY) {  // non-finite gradient: poison the slice like a float sum would
-            for (uint32_t i = threadIdx.x; i < nrows * C; i += kBwdThreads)
-                grad_grid[((size_t)off + row0) * C + i] = Acc<T>::from_f(NAN);
+        for (uint32_t d = 0; d < D; d++) {
+            if (st <= hashmap_size) { mul[d] = st; st *= align_corners ? resolution : (resolution + 1); }
+            else mul[d] = 0;
         }
-        return;  // all-zero gradient: nothing to add
-    }
-    if (amax == INFINITY) {
-        for (uint32_t i = threadIdx.x; i < nrows * C; i += kBwdThreads) grad_grid[((size_t)off + row0) * C + i] = Acc<T>::from_f(NAN);
-        return;
-    }
-    // |sum| <= B * 2^D * amax < 2^62 : pick the power-of-two scale accordingly
-    int e;
-    (void)frexpf(amax, &e);  // amax < 2^e
-    const int kexp = 62 - e - (int)(32 - __clz(B)) - (int)D;
-    const double inv_scale = ldexp(1.0, -kexp);
-
-    for (uint32_t i = threadIdx.x; i < nrows * C; i += kBwdThreads) acc[i] = 0ull;
-    __syncthreads();
-
-    const float lscale = scales.v[level];
-    const uint32_t resolution = (uint32_t)ceilf(lscale) + 1;
-    const T* glevel = grad + (size_t)level * B * C;
-
-    // Level-uniform index plan, hoisted out of the point loop (get_grid_index, gridencoder.cu:66-84):
-    // which dimensions enter the dense index (the stride loop stops once stride > hashmap_size), their strides,
-    // and whether the level is hashed.  `row % hashmap_size` becomes a mask when the size is a power of two and a
-    // no-op test for dense levels (index < rows by construction).
-    uint32_t stride[D];
-    uint32_t st = 1;
+        hashed = (gridtype == 0 && st > hashmap_size);
+        if (hashed) {
 #pragma unroll
-    for (uint32_t d = 0; d < D; d++) {
-        if (st <= hashmap_size) { stride[d] = st; st *= align_corners ? resolution : (resolution + 1); }
-        else stride[d] = 0;  // dimension dropped from the dense index
+            for (uint32_t d = 0; d < D; d++) mul[d] = kPrimes[d];
+        }
+        size = hashmap_size;
+        mask = hashmap_size - 1;
+        pow2 = (hashmap_size & mask) == 0;
     }
-    const bool hashed = (gridtype == 0 && st > hashmap_size);
-    const bool pow2 = (hashmap_size & (hashmap_size - 1)) == 0;
-    const uint32_t mask = hashmap_size - 1;
-
-    // Hits are sparse (~2^D/slices per point) and scattered over lanes: executing the accumulate body under
-    // divergence costs a wave-iteration per hit-bearing lane (measured 3x the scan itself).  Instead every wave
-    // appends its hits (point, corner) to a small LDS queue (wave prefix sum of per-lane hit counts) and drains the
-    // queue 64 entries at a time with all lanes busy.
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t* queue = reinterpret_cast<uint32_t*>(smem_raw + kLdsBytes - kQueueBytes) + wave * kQueueLen;
-
-    // The scan loop is specialised on the (workgroup-uniform) index mode so its body carries no selects:
-    //   MODE 0: hashed level, power-of-two rows (row = xor-hash & mask)      — the eleven 2^19-row levels
-    //   MODE 1: dense level (row = sum of strides; `% rows` only if index >= rows)
-    //   MODE 2: anything else (generic get_grid_index semantics)
-    auto row_of = [&](auto mode, const uint32_t (&lo)[D], const uint32_t (&hi)[D], uint32_t idx) -> uint32_t {
-        constexpr int MODE = decltype(mode)::value;
+    __device__ __forceinline__ uint32_t row(const uint32_t (&lo)[D], uint32_t idx) const {  // lo[d] = pos_grid[d] * mul[d]
         uint32_t index = 0;
 #pragma unroll
         for (uint32_t d = 0; d < D; d++) {
-            const uint32_t t = ((idx >> d) & 1u) ? hi[d] : lo[d];
-            if (MODE == 0) index ^= t;
-            else if (MODE == 1) index += t;
-            else index = hashed ? (index ^ t) : (index + t);
+            const uint32_t t = ((idx >> d) & 1u) ? lo[d] + mul[d] : lo[d];
+            index = hashed ? (index ^ t) : (index + t);
         }
-        if (MODE == 0) return index & mask;
-        if (MODE == 1) return (index < hashmap_size) ? index : index % hashmap_size;
-        return pow2 ? (index & mask) : ((index < hashmap_size) ? index : index % hashmap_size);
-    };
-    auto corner_terms = [&](auto mode, const uint32_t (&pos_grid)[D], uint32_t (&lo)[D], uint32_t (&hi)[D]) {
-        constexpr int MODE = decltype(mode)::value;
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++) {
-            const bool h = (MODE == 0) || (MODE == 2 && hashed);
-            if (h) { lo[d] = pos_grid[d] * kPrimes[d]; hi[d] = lo[d] + kPrimes[d]; }
-            else { lo[d] = pos_grid[d] * stride[d]; hi[d] = lo[d] + stride[d]; }
-        }
-    };
+        if (pow2) return index & mask;
+        return index < size ? index : index % size;
+    }
+};
 
-    auto run = [&](auto mode) {
-        uint32_t qlen = 0;  // wave-uniform
-        // Drain, software-pipelined by one stage: a drain ISSUES the loads of its 64 entries (packed point + gradient
-        // row) and PROCESSES the entries whose loads the previous drain issued, so the ~1-2 us round trip overlaps
-        // the scan in between instead of stalling the wave (PMC: 51 % of wave cycles were s_waitcnt stalls).
-        bool pend = false;           // this lane holds a loaded, unprocessed entry
-        uint32_t pend_idx = 0, pend_b = 0;
-        float pend_x[D];
-        T pend_g[C];
-        auto process = [&]() {
-            if (pend) {
-                float pos[D], pd[D];
-                uint32_t pos_grid[D], lo[D], hi[D];
-                locate<D>(pend_x, lscale, align_corners, interp, pos, pd, pos_grid);
-                corner_terms(mode, pos_grid, lo, hi);
-                const uint32_t local = row_of(mode, lo, hi, pend_idx) - row0;
+template <typename T, uint32_t C>
+__device__ __forceinline__ float absmax_feat(const T (&g)[C], bool& nonzero) {
+    float m = 0.0f;
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) {
+        const float v = fabsf(Acc<T>::to_f(g[c]));
+        nonzero |= (v != 0.0f);
+        m = (v > m || v != v) ? v : m;  // NaN propagates
+    }
+    return m;
+}
+
+// hdr[level] = max |grad| over in-range points (bit pattern of a non-negative float is monotone as uint32; NaN
+// patterns sort above +inf); tot[level * smax + slice] = records of the slice.
+// Few, fat workgroups: every workgroup ends each level with one global atomic per slice on the SAME smax words, and
+// same-address device atomics serialise (measured: one workgroup per 256 points spent 190 us in them at B = 2^18).
+constexpr uint32_t kBinCountThreads = 1024;
+constexpr uint32_t kBinCountChunks = 64;  // workgroups per level
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(kBinCountThreads) k_bin_count(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                                const int32_t* __restrict__ offsets, uint32_t B,
+                                                                uint32_t points_per_block, LevelScales scales,
+                                                                uint32_t* __restrict__ hdr, uint32_t* __restrict__ tot,
+                                                                uint32_t smax, uint32_t gridtype, bool align_corners,
+                                                                uint32_t interp) {
+    constexpr uint32_t K = 1u << D;
+    constexpr uint32_t U = 4;  // points per lane in flight
+    __shared__ uint32_t cnt[kBinMaxSlices];
+    __shared__ float wmax[kBinCountThreads / 64];
+    const uint32_t b_begin = blockIdx.x * points_per_block;
+    const uint32_t b_end = min(B, b_begin + points_per_block);
+    const uint32_t level = blockIdx.y;
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t S = bin_slices(hashmap_size, C);
+    const float lscale = scales.v[level];
+    LevelIndex<D> li;
+    li.init(gridtype, align_corners, hashmap_size, (uint32_t)ceilf(lscale) + 1);
+    for (uint32_t s = threadIdx.x; s < S; s += kBinCountThreads) cnt[s] = 0;
+    __syncthreads();
+    float m = 0.0f;
+    for (uint32_t b0 = b_begin + threadIdx.x; b0 < b_end; b0 += U * kBinCountThreads) {
+        float x[U][D];
+        T g[U][C];
+        bool in[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t b = b0 + u * kBinCountThreads;
+            in[u] = b < b_end;
+            if (in[u]) {
+                in[u] = !load_point<D>(inputs, b, x[u]);
+                load_feat<T, C>(grad + ((size_t)level * B + b) * C, g[u]);
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            if (!in[u]) continue;
+            bool nz = false;
+            const float a = absmax_feat<T, C>(g[u], nz);
+            m = (a > m || a != a) ? a : m;
+            if (!nz) continue;
+            float pos[D], pd[D];
+            uint32_t pos_grid[D], lo[D];
+            locate<D>(x[u], lscale, align_corners, interp, pos, pd, pos_grid);
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) lo[d] = pos_grid[d] * li.mul[d];
+#pragma unroll
+            for (uint32_t idx = 0; idx < K; idx++) atomicAdd(&cnt[(li.row(lo, idx) / kBinGroup) & (S - 1)], 1u);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const float o = __shfl_xor(m, d, 64); m = (o > m || o != o) ? o : m; }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < kBinCountThreads / 64; w++) { const float o = wmax[w]; m = (o > m || o != o) ? o : m; }
+        if (m != 0.0f) atomicMax(hdr + level, __float_as_uint(m));
+    }
+    for (uint32_t s = threadIdx.x; s < S; s += kBinCountThreads)
+        if (cnt[s]) atomicAdd(&tot[level * smax + s], cnt[s]);
+}
+
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(1024) k_bin_scatter(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                     const int32_t* __restrict__ offsets, uint32_t B, uint32_t level0,
+                                                     LevelScales scales, const uint32_t* __restrict__ hdr,
+                                                     const uint32_t* __restrict__ tot, uint32_t* __restrict__ cursor,
+                                                     uint32_t smax, uint32_t* __restrict__ gkeys,
+                                                     typename FeatVec<T, C>::type* __restrict__ gvals, uint32_t gridtype,
+                                                     bool align_corners, uint32_t interp) {
+    using V = typename FeatVec<T, C>::type;
+    constexpr uint32_t K = 1u << D;
+    constexpr uint32_t P = bin_chunk_points<T, D, C>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);
+    uint32_t* base = cnt + kBinMaxSlices;
+    uint32_t* gbase = base + kBinMaxSlices;
+    uint32_t* skeys = gbase + kBinMaxSlices;
+    V* svals = reinterpret_cast<V*>(skeys + P * K);
+
+    const uint32_t level = level0 + blockIdx.y;
+    const float amax = __uint_as_float(hdr[level]);
+    if (!(amax > 0.0f) || amax == INFINITY) return;  // zero / non-finite levels carry no records (uniform exit)
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t S = bin_slices(hashmap_size, C);
+    const uint32_t sshift = 31 - __clz(S);
+    const float lscale = scales.v[level];
+    LevelIndex<D> li;
+    li.init(gridtype, align_corners, hashmap_size, (uint32_t)ceilf(lscale) + 1);
+
+    for (uint32_t s = threadIdx.x; s < S; s += P) cnt[s] = 0;
+    __syncthreads();
+
+    uint32_t key[K], rank[K];
+    V val[K];
+    bool active = false;
+    const uint32_t b = blockIdx.x * P + threadIdx.x;
+    float x[D];
+    if (b < B && !load_point<D>(inputs, b, x)) {
+        T g[C];
+        load_feat<T, C>(grad + ((size_t)level * B + b) * C, g);
+        (void)absmax_feat<T, C>(g, active);
+        if (active) {
+            float pos[D], pd[D];
+            uint32_t pos_grid[D], lo[D];
+            locate<D>(x, lscale, align_corners, interp, pos, pd, pos_grid);
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) lo[d] = pos_grid[d] * li.mul[d];
+#pragma unroll
+            for (uint32_t idx = 0; idx < K; idx++) {
                 float w = 1;
 #pragma unroll
-                for (uint32_t d = 0; d < D; d++) w *= ((pend_idx >> d) & 1u) ? pos[d] : 1 - pos[d];
+                for (uint32_t d = 0; d < D; d++) w *= ((idx >> d) & 1u) ? pos[d] : 1 - pos[d];
+                const uint32_t row = li.row(lo, idx);
+                const uint32_t grp = row / kBinGroup;
+                const uint32_t s = grp & (S - 1);
+                key[idx] = (s << 20) | ((grp >> sshift) * kBinGroup + row % kBinGroup);
+                rank[idx] = atomicAdd(&cnt[s], 1u);
+                T pr[C];
 #pragma unroll
-                for (uint32_t c = 0; c < C; c++) {
-                    // same product the reference forms (float w * grad), then exact scaling to 64-bit fixed point
-                    float prod;
-                    if constexpr (sizeof(T) == 2) prod = __half2float(__float2half(w * __half2float(pend_g[c])));
-                    else prod = w * pend_g[c];
-                    atomicAdd(&acc[local * C + c], (unsigned long long)to_fixed64(prod, kexp));
-                }
-                pend = false;
+                for (uint32_t c = 0; c < C; c++) pr[c] = Acc<T>::from_f(w * Acc<T>::to_f(g[c]));  // the reference's product
+                __builtin_memcpy(&val[idx], pr, sizeof(V));
             }
-        };
-        auto drain = [&](uint32_t first, uint32_t count) {  // lanes [0,count) take entries first..first+count-1
-            process();
-            if (lane < count) {
-                const uint32_t ent = queue[first + lane];
-                uint32_t b = ent >> D;  // slot in the packed array (D <= 3) or point index
-                pend_idx = ent & ((1u << D) - 1);
-                if constexpr (D <= 3) {
-                    const float4 p = packed[b];
-                    const float v[3] = {p.x, p.y, p.z};
-#pragma unroll
-                    for (uint32_t d = 0; d < D; d++) pend_x[d] = v[d];
-                    b = __float_as_uint(p.w);  // original point index, for the gradient row
-                } else {
-#pragma unroll
-                    for (uint32_t d = 0; d < D; d++) pend_x[d] = inputs[(size_t)b * D + d];
-                }
-                pend_b = b;
-                load_feat<T, C>(glevel + (size_t)b * C, pend_g);
-                pend = true;
-            }
-        };
-        // Scan kUnroll points per lane, then append ALL their hits with one wave prefix sum: the hit test is pure
-        // VALU, and the VALU->SGPR->branch round trips of the queue bookkeeping (ballots, popcounts, drain test) are
-        // paid once per kUnroll points instead of once per point.
-        constexpr uint32_t kCorners = 1u << D;
-        constexpr uint32_t kUnroll = kCorners <= 8 ? 4 : (kCorners <= 16 ? 2 : 1);
-        static_assert(kUnroll * kCorners <= 32, "per-lane hit mask must fit 32 bits");
-        auto scan = [&](uint32_t b0, const float (&xs)[kUnroll][D]) {
-            uint32_t hits = 0;  // bit (u * 2^D + corner)
-#pragma unroll
-            for (uint32_t u = 0; u < kUnroll; u++) {
-                bool oob = false;
-#pragma unroll
-                for (uint32_t d = 0; d < D; d++) oob |= !(xs[u][d] >= 0 && xs[u][d] <= 1);  // also true for the padding marker
-                float pos[D], pd[D];
-                uint32_t pos_grid[D], lo[D], hi[D];
-                locate<D>(xs[u], lscale, align_corners, interp, pos, pd, pos_grid);
-                corner_terms(mode, pos_grid, lo, hi);
-                uint32_t h = 0;
-#pragma unroll
-                for (uint32_t idx = 0; idx < kCorners; idx++)
-                    h |= ((row_of(mode, lo, hi, idx) - row0) < nrows ? 1u : 0u) << idx;
-                hits |= (oob ? 0u : h) << (u * kCorners);
-            }
-            if (__ballot(hits != 0) == 0) return;
-            // exclusive prefix sum of the per-lane hit counts from ballots of the count bits (no LDS round trips)
-            const uint32_t cnt = __popc(hits);
-            uint32_t excl = 0, total = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 6; k++) {
-                const unsigned long long mk = __ballot((cnt >> k) & 1u);
-                excl += __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u)) << k;
-                total += (uint32_t)__popcll(mk) << k;
-            }
-            if (total <= kQueueLen - 64) {
-                uint32_t slot = qlen + excl;
-                while (hits) {
-                    const uint32_t j = __builtin_ctz(hits);
-                    hits &= hits - 1;
-                    queue[slot++] = ((b0 + (j / kCorners) * kBwdThreads) << D) | (j % kCorners);
-                }
-                qlen += total;
-                while (qlen >= 64) { qlen -= 64; drain(qlen, 64); }
-            } else {  // pathological density (e.g. many identical points): one (point, corner) at a time
-#pragma unroll 1
-                for (uint32_t j = 0; j < kUnroll * kCorners; j++) {
-                    const bool hit = (hits >> j) & 1u;
-                    const unsigned long long m = __ballot(hit);
-                    if (hit) queue[qlen + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
-                        ((b0 + (j / kCorners) * kBwdThreads) << D) | (j % kCorners);
-                    qlen += (uint32_t)__popcll(m);
-                    if (qlen >= 64) { qlen -= 64; drain(qlen, 64); }
-                }
-            }
-        };
-        // All co-resident workgroups sweep the point array in the SAME order: the 32 CUs of an XCD then touch the
-        // same window at about the same time and share it through their L2.  (PMC, profiles/r01: with per-workgroup
-        // start offsets FETCH_SIZE was 2.8 GB per launch — 70 % of the 930 x 4.2 MB point re-reads missed the 4 MiB
-        // L2 and the sweep ran at the fabric's ~2.4 TB/s.)
-        const uint32_t per_round = kBwdThreads * kUnroll;
-        const uint32_t rounds = div_up<uint32_t>(n_points, per_round);
-        auto fetch = [&](uint32_t r, float (&xs)[kUnroll][D]) {
-            const uint32_t b0 = r * per_round + threadIdx.x;
-#pragma unroll
-            for (uint32_t u = 0; u < kUnroll; u++) {
-                const uint32_t b = b0 + u * kBwdThreads;
-                if constexpr (D <= 3) {
-                    const float4 p = (b < n_points) ? packed[b] : make_float4(-1.0f, 0, 0, 0);
-                    const float v[3] = {p.x, p.y, p.z};
-#pragma unroll
-                    for (uint32_t d = 0; d < D; d++) xs[u][d] = v[d];
-                } else {
-#pragma unroll
-                    for (uint32_t d = 0; d < D; d++) xs[u][d] = (b < n_points) ? inputs[(size_t)b * D + d] : -1.0f;
-                }
-            }
-            return b0;
-        };
-        // software pipeline: the loads of round r+1 are in flight while round r is scanned (PMC: 48 % of the wave
-        // cycles were s_waitcnt stalls with the loads issued at the top of the same round)
-        float cur[kUnroll][D], nxt[kUnroll][D];
-        uint32_t b_cur = fetch(0, cur), b_nxt = 0;
-        for (uint32_t r = 0; r < rounds; r++) {
-            if (r + 1 < rounds) b_nxt = fetch(r + 1, nxt);
-            scan(b_cur, cur);
-#pragma unroll
-            for (uint32_t u = 0; u < kUnroll; u++)
-#pragma unroll
-                for (uint32_t d = 0; d < D; d++) cur[u][d] = nxt[u][d];
-            b_cur = b_nxt;
         }
-        drain(0, qlen);
-        process();
-    };
-    bool all_dims = true;
-#pragma unroll
-    for (uint32_t d = 0; d < D; d++) all_dims &= (stride[d] != 0);
-    if (hashed && pow2) run(std::integral_constant<int, 0>{});
-    else if (!hashed && all_dims) run(std::integral_constant<int, 1>{});
-    else run(std::integral_constant<int, 2>{});
+    }
     __syncthreads();
-    T* dst = grad_grid + ((size_t)off + row0) * C;
-    for (uint32_t i = threadIdx.x; i < nrows * C; i += kBwdThreads) {
-        const long long q = (long long)acc[i];
-        if (q != 0) {
-            const float add = (float)((double)q * inv_scale);
-            dst[i] = Acc<T>::from_f(Acc<T>::to_f(dst[i]) + add);
+    // first wave: exclusive scan of this chunk's slice counts (offsets into the staging buffer)
+    const uint32_t per = S / 64;  // S is a power of two >= 64
+    if (threadIdx.x < 64) {
+        uint32_t sum = 0;
+        for (uint32_t j = 0; j < per; j++) sum += cnt[threadIdx.x * per + j];
+        uint32_t run = wave_incl_scan(sum) - sum;
+        for (uint32_t j = 0; j < per; j++) { base[threadIdx.x * per + j] = run; run += cnt[threadIdx.x * per + j]; }
+    }
+    __syncthreads();
+    // ... then, while the other waves stage their records, the first wave reserves the chunk's run in every slice's
+    // bucket: bucket start (exclusive scan of the level's slice totals) + one returning atomic per non-empty slice
+    if (threadIdx.x < 64) {
+        uint32_t gsum = 0;
+        for (uint32_t j = 0; j < per; j++) gsum += tot[level * smax + threadIdx.x * per + j];
+        uint32_t grun = wave_incl_scan(gsum) - gsum;
+        for (uint32_t j = 0; j < per; j++) {
+            const uint32_t s = threadIdx.x * per + j, c = cnt[s];
+            gbase[s] = c ? grun + atomicAdd(&cursor[level * smax + s], c) : 0u;
+            grun += tot[level * smax + s];
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (uint32_t idx = 0; idx < K; idx++) {
+            const uint32_t at = base[key[idx] >> 20] + rank[idx];
+            skeys[at] = key[idx];
+            svals[at] = val[idx];
+        }
+    }
+    __syncthreads();
+    const uint32_t total = base[S - 1] + cnt[S - 1];
+    const size_t region = (size_t)blockIdx.y * K * B;  // this level's record region inside the pass
+    for (uint32_t i = threadIdx.x; i < total; i += P) {
+        const uint32_t k = skeys[i];
+        const uint32_t s = k >> 20;
+        const size_t at = region + gbase[s] + (i - base[s]);
+        gkeys[at] = k & 0xfffffu;
+        gvals[at] = svals[i];
+    }
+}
+
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate(const uint32_t* __restrict__ gkeys,
+                                                                  const typename FeatVec<T, C>::type* __restrict__ gvals,
+                                                                  const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
+                                                                  uint32_t B, uint32_t level0, const uint32_t* __restrict__ hdr,
+                                                                  const uint32_t* __restrict__ tot, uint32_t smax) {
+    using V = typename FeatVec<T, C>::type;
+    constexpr uint32_t K = 1u << D;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);
+    __shared__ uint32_t wsum[kBinAccThreads / 64];
+    const uint32_t level = level0 + blockIdx.y, slice = blockIdx.x;
+    const uint32_t off = (uint32_t)offsets[level];
+    const uint32_t rows = (uint32_t)offsets[level + 1] - off;
+    const uint32_t S = bin_slices(rows, C);
+    if (slice >= S) return;
+    const uint32_t local_rows = bin_local_rows(rows, S);
+    auto row_of_local = [&](uint32_t local) { return ((local / kBinGroup) * S + slice) * kBinGroup + local % kBinGroup; };
+    T* table = grad_grid + (size_t)off * C;
+    const float amax = __uint_as_float(hdr[level]);
+    if (!(amax > 0.0f) || amax == INFINITY) {
+        if (amax != amax || amax == INFINITY) {  // non-finite gradient: poison the level like a float sum would
+            for (uint32_t i = threadIdx.x; i < local_rows * C; i += kBinAccThreads) {
+                const uint32_t row = row_of_local(i / C);
+                if (row < rows) table[(size_t)row * C + i % C] = Acc<T>::from_f(NAN);
+            }
+        }
+        return;
+    }
+    const uint32_t count = tot[level * smax + slice];
+    if (count == 0) return;
+    // bucket start = records of the slices before this one (loads issued first, consumed after the LDS clear)
+    uint32_t part = 0;
+    for (uint32_t s = threadIdx.x; s < slice; s += kBinAccThreads) part += tot[level * smax + s];
+    for (uint32_t i = threadIdx.x; i < local_rows * C; i += kBinAccThreads) acc[i] = 0ull;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+    __syncthreads();
+    uint32_t start = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < kBinAccThreads / 64; w++) start += wsum[w];
+    const uint32_t end = start + count;
+    int e;
+    (void)frexpf(amax, &e);  // amax < 2^e ; |sum| <= B * 2^D * amax < 2^62
+    const int kexp = 62 - e - (int)(32 - __clz(B)) - (int)D;
+    const double inv_scale = ldexp(1.0, -kexp);
+    const size_t region = (size_t)blockIdx.y * K * B;
+    const uint32_t* keys = gkeys + region;
+    const V* vals = gvals + region;
+    // stream the bucket: U independent record loads per lane in flight, then the adds
+    constexpr uint32_t U = kBinAccUnroll;
+    for (uint32_t i0 = start + threadIdx.x; i0 < end; i0 += U * kBinAccThreads) {
+        uint32_t k[U];
+        V v[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t i = i0 + u * kBinAccThreads;
+            if (i < end) { k[u] = keys[i]; v[u] = vals[i]; }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            if (i0 + u * kBinAccThreads < end) {
+                T pr[C];
+                __builtin_memcpy(pr, &v[u], sizeof(V));
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++)
+                    atomicAdd(&acc[k[u] * C + c], (unsigned long long)to_fixed64(Acc<T>::to_f(pr[c]), kexp));
+            }
+        }
+    }
+    __syncthreads();
+    // add the slice into the table: one vector load + store per touched row, W rows per lane in flight
+    constexpr uint32_t W = C <= 2 ? 8 : (C == 4 ? 4 : 2);
+    for (uint32_t r0 = threadIdx.x; r0 < local_rows; r0 += W * kBinAccThreads) {
+        long long q[W][C];
+        V old[W];
+        bool nz[W];
+#pragma unroll
+        for (uint32_t w = 0; w < W; w++) {
+            const uint32_t r = r0 + w * kBinAccThreads;
+            nz[w] = false;
+            if (r < local_rows) {
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) { q[w][c] = (long long)acc[r * C + c]; nz[w] |= (q[w][c] != 0); }
+            }
+        }
+#pragma unroll
+        for (uint32_t w = 0; w < W; w++)
+            if (nz[w]) old[w] = *reinterpret_cast<const V*>(table + (size_t)row_of_local(r0 + w * kBinAccThreads) * C);
+#pragma unroll
+        for (uint32_t w = 0; w < W; w++) {
+            if (nz[w]) {
+                T o[C];
+                __builtin_memcpy(o, &old[w], sizeof(V));
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) o[c] = Acc<T>::from_f(Acc<T>::to_f(o[c]) + (float)((double)q[w][c] * inv_scale));
+                store_feat<T, C>(table + (size_t)row_of_local(r0 + w * kBinAccThreads) * C, o);
+            }
         }
     }
 }
@@ -785,34 +804,76 @@ int launch_forward(const float* inputs, const T* emb, const int32_t* offsets, T*
     return check_launch("grid_encode_forward");
 }
 
-constexpr uint32_t kLdsBackwardMinPoints = 8192;  // below this the direct-atomic kernel wins (fixed sweep cost)
+constexpr uint32_t kBinnedMinPoints = 8192;   // below this the direct-atomic kernel wins (fixed cost of the sorted path)
+constexpr size_t kBinPassBytes = 1ull << 30;  // record storage per pass; levels are processed in groups that fit
+
+// Workspace layout of the binned path (offsets 256-byte aligned):
+//   hdr: |grad| max per level [kMaxLevels] | tot[L][smax] | cursor[L][smax] | keys | vals      (hdr..cursor are memset)
+struct BinLayout {
+    uint32_t levels_per_pass, chunks, chunk_points, smax;
+    size_t tot, cursor, keys, vals, total;
+    bool ok;
+};
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline BinLayout bin_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level_rows, uint32_t elem) {
+    BinLayout o{};
+    if (!(C == 1 || C == 2 || C == 4 || C == 8) || D < 2 || D > 5 || !max_level_rows || !L || L > kMaxLevels || !B) return o;
+    const uint32_t rec = 4 + elem * C;
+    o.smax = bin_slices(max_level_rows, C);  // bin_slices is monotone in rows: no level has more slices
+    const uint32_t p = (kBinStageBytes / (rec << D)) / 64 * 64;
+    o.ok = o.smax <= kBinMaxSlices && p >= 64 && ((uint64_t)B << D) < (1ull << 31);
+    if (!o.ok) return o;
+    o.chunk_points = p > 1024 ? 1024 : p;
+    o.chunks = div_up<uint32_t>(B, o.chunk_points);
+    const size_t per_level = ((size_t)B << D) * rec;
+    const size_t lp = kBinPassBytes / per_level;
+    o.levels_per_pass = (uint32_t)(lp < 1 ? 1 : (lp > L ? L : lp));
+    o.tot = 256;
+    o.cursor = o.tot + (size_t)L * o.smax * 4;
+    o.keys = align256(o.cursor + (size_t)L * o.smax * 4);
+    o.vals = align256(o.keys + (size_t)o.levels_per_pass * ((size_t)B << D) * 4);
+    o.total = align256(o.vals + (size_t)o.levels_per_pass * ((size_t)B << D) * elem * C);
+    return o;
+}
 
 template <typename T, uint32_t D, uint32_t C>
-int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets, uint32_t table_rows, T* grad_emb,
+int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets, uint32_t max_level_rows, T* grad_emb,
                       uint32_t B, uint32_t L, const LevelScales& sc, const T* dy_dx, T* grad_inputs, uint32_t gridtype, bool ac,
-                      uint32_t interp, uint32_t* ws, size_t ws_bytes, int force_path, hipStream_t st) {
-    const bool ws_ok = ws && ws_bytes >= 256 + (size_t)B * 16;
-    const bool use_lds = (force_path == 2 && ws_ok && table_rows) || (force_path == 0 && B >= kLdsBackwardMinPoints && table_rows && ws_ok);
-    if (use_lds) {
-        // upper bound on the number of (level, slice) workgroups: capacity slices + per-level minimum + remainders
-        const uint32_t nb = div_up<uint32_t>(table_rows, kAccBytes / (8 * C)) + L * (bwd_min_slices(C) + 1);
-        S3D_HIP(hipMemsetAsync(ws, 0, sizeof(uint32_t) * (kMaxLevels + 1), st));
-        float4* packed = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(ws) + 256);
-        if constexpr (D <= 3)
-            hipLaunchKernelGGL((k_pack_points<T, D, C>), dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, st, inputs, grad, B, L,
-                               packed, ws + kMaxLevels);
-        const uint32_t per_level = B * C;
-        uint32_t gx = div_up<uint32_t>(per_level, 256 * 32);
-        if (gx > 64) gx = 64;
-        hipLaunchKernelGGL((k_grad_absmax<T>), dim3(gx, L), dim3(256), 0, st, grad, per_level, ws);
+                      uint32_t interp, unsigned char* ws, size_t ws_bytes, int force_path, hipStream_t st) {
+    const BinLayout lay = bin_layout(B, D, C, L, max_level_rows, sizeof(T));
+    const bool bin_ok = lay.ok && ws && ws_bytes >= lay.total;
+    // 0 auto: binned for large batches; 1 direct atomics; 2 binned
+    const bool binned = bin_ok && (force_path == 2 || (force_path == 0 && B >= kBinnedMinPoints));
+    if (binned) {
+        using V = typename FeatVec<T, C>::type;
+        constexpr uint32_t P = bin_chunk_points<T, D, C>();
+        constexpr uint32_t K = 1u << D;
+        constexpr uint32_t stage = kBinCtlWords * 4 + P * K * (4 + (uint32_t)sizeof(V));
         static bool attr_set = false;
         if (!attr_set) {
-            S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_backward_lds<T, D, C>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes));
+            S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_scatter<T, D, C>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage));
+            S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_accumulate<T, D, C>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinAccBytes));
             attr_set = true;
         }
-        hipLaunchKernelGGL((k_grid_backward_lds<T, D, C>), dim3(nb), dim3(kBwdThreads), kLdsBytes, st, grad, inputs,
-                           (const float4*)packed, offsets, grad_emb, B, L, sc, (const uint32_t*)ws, gridtype, ac, interp);
+        uint32_t* hdr = reinterpret_cast<uint32_t*>(ws);
+        uint32_t* tot = reinterpret_cast<uint32_t*>(ws + lay.tot);
+        uint32_t* cursor = reinterpret_cast<uint32_t*>(ws + lay.cursor);
+        uint32_t* keys = reinterpret_cast<uint32_t*>(ws + lay.keys);
+        V* vals = reinterpret_cast<V*>(ws + lay.vals);
+        S3D_HIP(hipMemsetAsync(ws, 0, lay.cursor + (size_t)L * lay.smax * 4, st));
+        const uint32_t ppb = div_up<uint32_t>(div_up<uint32_t>(B, kBinCountChunks), kBinCountThreads) * kBinCountThreads;
+        hipLaunchKernelGGL((k_bin_count<T, D, C>), dim3(div_up<uint32_t>(B, ppb), L), dim3(kBinCountThreads), 0, st, grad, inputs,
+                           offsets, B, ppb, sc, hdr, tot, lay.smax, gridtype, ac, interp);
+        for (uint32_t l0 = 0; l0 < L; l0 += lay.levels_per_pass) {
+            const uint32_t nl = (L - l0 < lay.levels_per_pass) ? L - l0 : lay.levels_per_pass;
+            hipLaunchKernelGGL((k_bin_scatter<T, D, C>), dim3(lay.chunks, nl), dim3(P), stage, st, grad, inputs, offsets, B, l0, sc,
+                               (const uint32_t*)hdr, (const uint32_t*)tot, cursor, lay.smax, keys, vals, gridtype, ac, interp);
+            hipLaunchKernelGGL((k_bin_accumulate<T, D, C>), dim3(lay.smax, nl), dim3(kBinAccThreads), kBinAccBytes, st,
+                               (const uint32_t*)keys, (const V*)vals, offsets, grad_emb, B, l0, (const uint32_t*)hdr,
+                               (const uint32_t*)tot, lay.smax);
+        }
     } else {
         hipLaunchKernelGGL((k_grid_backward<T, D, C>), dim3(xcd_grid(B)), dim3(kFwdBlock), 0, st, grad, inputs, offsets,
                            grad_emb, B, L, sc, gridtype, ac, interp);
@@ -824,18 +885,18 @@ int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets
 }
 
 template <typename T, uint32_t D>
-int launch_backward(const T* grad, const float* inputs, const int32_t* offsets, uint32_t table_rows, T* grad_emb,
-                    uint32_t B, uint32_t C, uint32_t L, const LevelScales& sc, const T* dy_dx, T* grad_inputs, uint32_t gridtype,
-                    bool ac, uint32_t interp, uint32_t* ws, size_t ws_bytes, int force_path, hipStream_t st) {
+int launch_backward(const T* grad, const float* inputs, const int32_t* offsets, uint32_t max_level_rows,
+                    T* grad_emb, uint32_t B, uint32_t C, uint32_t L, const LevelScales& sc, const T* dy_dx, T* grad_inputs, uint32_t gridtype,
+                    bool ac, uint32_t interp, unsigned char* ws, size_t ws_bytes, int force_path, hipStream_t st) {
     switch (C) {
         case 1:
             if constexpr (sizeof(T) == 2) {
                 set_error("GridEncoding: fp16 tables need an even C (the reference forces fp32 when C is odd, grid.py:42)");
                 return S3D_ERR_UNSUPPORTED;
-            } else return launch_backward_c<T, D, 1>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
-        case 2: return launch_backward_c<T, D, 2>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
-        case 4: return launch_backward_c<T, D, 4>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
-        case 8: return launch_backward_c<T, D, 8>(grad, inputs, offsets, table_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
+            } else return launch_backward_c<T, D, 1>(grad, inputs, offsets, max_level_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
+        case 2: return launch_backward_c<T, D, 2>(grad, inputs, offsets, max_level_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
+        case 4: return launch_backward_c<T, D, 4>(grad, inputs, offsets, max_level_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
+        case 8: return launch_backward_c<T, D, 8>(grad, inputs, offsets, max_level_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
         default: set_error("GridEncoding: C must be 1, 2, 4, or 8."); return S3D_ERR_UNSUPPORTED;
     }
 }
@@ -927,15 +988,19 @@ S3D_EXPORT int s3d_grid_corner_indices(const float* inputs, const int32_t* offse
                    (launch_corner_rows<5>(inputs, offsets, corner_idx, B, L, sc, gridtype, ac, st)))
 }
 
-S3D_EXPORT size_t s3d_grid_encode_backward_workspace_size(uint32_t B) { return 256 + (size_t)B * 16; }
+S3D_EXPORT size_t s3d_grid_encode_backward_workspace_size(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level_rows,
+                                                          int dtype) {
+    const BinLayout lay = bin_layout(B, D, C, L, max_level_rows, dtype == S3D_F16 ? 2u : 4u);
+    return lay.ok ? lay.total : 0;
+}
 
-// process-wide override for experiments/tests: 0 = auto, 1 = direct atomics, 2 = LDS fixed-point sweep
+// process-wide override for experiments/tests: 0 = auto, 1 = direct atomics, 2 = binned (partition + LDS accumulate)
 static int g_backward_path = 0;
 S3D_EXPORT void s3d_grid_backward_set_path(int path) { g_backward_path = path; }
 
 S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
-                                        const int32_t* offsets, void* grad_embeddings, uint32_t table_rows,
-                                        uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
+                                        const int32_t* offsets, void* grad_embeddings,
+                                        uint32_t max_level_rows, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                         const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                                         uint32_t interp, int dtype, void* workspace, size_t workspace_bytes,
                                         s3d_stream_t stream) {
@@ -944,28 +1009,32 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
     S3D_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null pointer");
     S3D_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_backward: L must be in [1, %u]", kMaxLevels);
     S3D_REQUIRE(dtype == S3D_F32 || dtype == S3D_F16, "grid_encode_backward: dtype must be f32 or f16");
-    S3D_REQUIRE(g_backward_path != 2 || (workspace && table_rows && workspace_bytes >= s3d_grid_encode_backward_workspace_size(B)),
-                "grid_encode_backward: LDS path needs table_rows and a workspace of s3d_grid_encode_backward_workspace_size(B) bytes");
+    if (g_backward_path == 2) {
+        const BinLayout lay = bin_layout(B, D, C, L, max_level_rows, dtype == S3D_F16 ? 2u : 4u);
+        S3D_REQUIRE(lay.ok && workspace && workspace_bytes >= lay.total,
+                    "grid_encode_backward: the binned path needs max_level_rows and a workspace of "
+                    "s3d_grid_encode_backward_workspace_size() bytes");
+    }
     LevelScales sc;
     host_scales(L, S, H, sc);
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
-    uint32_t* ws = (uint32_t*)workspace;
+    unsigned char* ws = (unsigned char*)workspace;
     const int fp = g_backward_path;
     if (dtype == S3D_F32) {
         const float* g = (const float*)grad; float* ge = (float*)grad_embeddings;
         const float* j = (const float*)dy_dx; float* gi = (float*)grad_inputs;
-        S3D_DISPATCH_D(D, (launch_backward<float, 2>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
-                       (launch_backward<float, 3>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
-                       (launch_backward<float, 4>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
-                       (launch_backward<float, 5>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)))
+        S3D_DISPATCH_D(D, (launch_backward<float, 2>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
+                       (launch_backward<float, 3>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
+                       (launch_backward<float, 4>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
+                       (launch_backward<float, 5>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)))
     } else {
         const __half* g = (const __half*)grad; __half* ge = (__half*)grad_embeddings;
         const __half* j = (const __half*)dy_dx; __half* gi = (__half*)grad_inputs;
-        S3D_DISPATCH_D(D, (launch_backward<__half, 2>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
-                       (launch_backward<__half, 3>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
-                       (launch_backward<__half, 4>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
-                       (launch_backward<__half, 5>(g, inputs, offsets, table_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)))
+        S3D_DISPATCH_D(D, (launch_backward<__half, 2>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
+                       (launch_backward<__half, 3>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
+                       (launch_backward<__half, 4>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
+                       (launch_backward<__half, 5>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)))
     }
 }
 

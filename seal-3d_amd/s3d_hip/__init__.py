@@ -14,11 +14,12 @@ GPU the call fails loudly.
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libseal3d_hip.so")
+LIB_PATH = os.environ.get("S3D_HIP_LIB") or os.path.join(_HERE, "libseal3d_hip.so")  # override: kernel-tuning experiments
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 
 F32, F16 = 0, 1
@@ -226,6 +227,26 @@ class RaymarchingBackend:
                                        _stream()), "compact_alive")
 
 
+_level_rows_cache = {}  # id(tensor) -> (weakref, version, rows)
+
+
+def _max_level_rows(offsets):
+    """max rows of one level.  `offsets` is the module's registered buffer (built on the host, grid.py:104-112); the
+    one-time read-back happens on the first backward, before any graph capture, and is cached per tensor object."""
+    hit = _level_rows_cache.get(id(offsets))
+    if hit is not None and hit[0]() is offsets and hit[1] == offsets._version:
+        return hit[2]
+    if torch.cuda.is_current_stream_capturing():
+        return 0  # unknown: the library falls back to direct atomics
+    o = offsets.detach().cpu()
+    v = int((o[1:] - o[:-1]).max().item()) if o.numel() > 1 else 0
+    if len(_level_rows_cache) > 256:
+        for k in [k for k, h in _level_rows_cache.items() if h[0]() is None]:
+            del _level_rows_cache[k]
+    _level_rows_cache[id(offsets)] = (weakref.ref(offsets), offsets._version, v)
+    return v
+
+
 class GridBackend:
     """gridencoder/src/gridencoder.h:12-15"""
 
@@ -253,16 +274,18 @@ class GridBackend:
         _need(inputs, torch.float32, "inputs")
         if grad_embeddings.dtype != grad.dtype:
             raise RuntimeError("grad_embeddings must have the dtype of grad")
-        ws = _ws.get(lib().s3d_grid_encode_backward_workspace_size(_u(B)), grad.device)
+        mlr = _max_level_rows(offsets)
+        ws = _ws.get(lib().s3d_grid_encode_backward_workspace_size(_u(B), _u(D), _u(Cc), _u(L), _u(mlr),
+                                                                   C.c_int(_dt(grad))), grad.device)
         _check(lib().s3d_grid_encode_backward(_p(grad), _p(inputs), _p(embeddings), _p(offsets),
-                                              _p(grad_embeddings), _u(grad_embeddings.shape[0]), _u(B), _u(D),
+                                              _p(grad_embeddings), _u(mlr), _u(B), _u(D),
                                               _u(Cc), _u(L), _f(S), _u(H), _p(dy_dx), _p(grad_inputs), _u(gridtype),
                                               C.c_int(int(align_corners)), _u(interp), C.c_int(_dt(grad)), _p(ws),
                                               C.c_size_t(ws.numel()), _stream()), "grid_encode_backward")
 
     @staticmethod
     def set_backward_path(path):
-        """0 = auto, 1 = direct global atomics, 2 = LDS fixed-point sweep (tests / experiments)"""
+        """0 = auto, 1 = direct global atomics, 2 = binned: partition + LDS accumulate (tests / experiments)"""
         lib().s3d_grid_backward_set_path(C.c_int(int(path)))
 
     @staticmethod

@@ -103,18 +103,21 @@ def test_grid_forward_backward(oracle, hip, D, L, C, base, log2T, desired, gridt
         big = ge_ref.abs() > 50
         assert (err[~big] <= 2e-3 * ge_ref.abs().clamp(min=1.0)[~big] * np.sqrt(8.0) * 8).all()
         assert (err[big] / ge_ref.abs()[big]).max() < 0.05 if big.any() else True
-    # ---- path 2: LDS 64-bit fixed-point sweep: exact integer accumulation, deterministic
-    hip.GridBackend.set_backward_path(2)
+    # ---- path 2: binned — contributions partitioned by table slice, 64-bit fixed-point accumulation in LDS: exact
+    # integer sums of the reference's products, deterministic
+    runs = []
     try:
-        runs = []
-        for _ in range(2):
+        for path in (2, 2):
+            hip.GridBackend.set_backward_path(path)
             ge2 = torch.zeros(total, C, dtype=dtype, device="cuda")
             hip.GridBackend.grid_encode_backward(grad.cuda(), xg, eg, og, ge2, B, D, C, L, S, base, None, None, gridtype, align, interp)
             runs.append(ge2.cpu())
         torch.cuda.synchronize()
     finally:
         hip.GridBackend.set_backward_path(0)
-    assert torch.equal(runs[0], runs[1]), "LDS backward must be bit-reproducible"
+    for r in runs[1:]:
+        assert torch.equal(runs[0].view(torch.int16 if dtype == torch.float16 else torch.int32),
+                           r.view(torch.int16 if dtype == torch.float16 else torch.int32)), "binned backward must be bit-reproducible"
     if dtype == torch.float32:
         torch.testing.assert_close(runs[0], ge_c, rtol=2e-5, atol=1e-5)  # the sequential fp32 oracle sum carries the rounding, not the exact integer sum
     else:
@@ -128,6 +131,72 @@ def test_grid_forward_backward(oracle, hip, D, L, C, base, log2T, desired, gridt
             want = grad[l][valid].double().sum(0)
             got = ge_g.cpu()[int(offsets[l]):int(offsets[l + 1])].double().sum(0)
             torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("D,L,C,base,log2T,desired,gridtype,interp,dtype,B", [
+    (3, 16, 2, 16, 19, 2048, 0, 0, torch.float16, 70001),   # Lego config under -O, many chunks
+    (3, 16, 2, 16, 19, 2048, 0, 0, torch.float32, 33000),
+    (3, 6, 4, 16, 17, 512, 0, 1, torch.float16, 20000),
+    (3, 4, 8, 16, 16, 128, 1, 0, torch.float32, 9000),      # tiled, C=8 (192-point chunks)
+    (2, 8, 1, 16, 14, 1024, 0, 0, torch.float32, 50000),
+    (4, 3, 2, 8, 15, 48, 0, 0, torch.float32, 12000),       # 4-D: 16 records per point and level
+])
+def test_grid_backward_binned_large(hip, D, L, C, base, log2T, desired, gridtype, interp, dtype, B):
+    """Training-size batches take the binned path (count -> scatter -> LDS accumulate).  Checked with samples clustered
+    in a few cells (heavy same-row traffic), zero-gradient tails and out-of-range points: reproducible bit for bit, the
+    automatic choice IS the binned path, the fp32 result agrees with the direct-atomic kernel, and per level the
+    table gradient sums to the sum of the in-range gradients (interpolation weights sum to one)."""
+    offsets, S, total = _enc_meta(D, L, C, base, log2T, desired, False)
+    g = torch.Generator().manual_seed(B)
+    x = torch.rand(B, D, generator=g)
+    x[: B // 4] = x[: B // 4] * 0.02 + 0.4            # a dense cluster: many identical rows
+    x[B // 4: B // 4 + 100] = -0.5                    # out of range
+    grad = (torch.randn(L, B, C, generator=g) * 1e-3).to(dtype)
+    grad[:, B // 2: B // 2 + B // 8] = 0              # zero-gradient points
+    grad[L - 1, : B // 3] = 0                         # zero on one level only
+    xg, og, gg = x.cuda(), offsets.cuda(), grad.cuda()
+    emb = torch.zeros(total, C, dtype=dtype, device="cuda")
+    out = {}
+    try:
+        for tag, path in (("binned", 2), ("again", 2), ("auto", 0), ("atomics", 1)):
+            hip.GridBackend.set_backward_path(path)
+            ge = torch.zeros(total, C, dtype=dtype, device="cuda")
+            hip.GridBackend.grid_encode_backward(gg, xg, emb, og, ge, B, D, C, L, S, base, None, None, gridtype, False, interp)
+            out[tag] = ge.cpu()
+    finally:
+        hip.GridBackend.set_backward_path(0)
+    it = torch.int16 if dtype == torch.float16 else torch.int32
+    assert torch.equal(out["binned"].view(it), out["again"].view(it))
+    assert torch.equal(out["binned"].view(it), out["auto"].view(it))
+    assert out["binned"].float().abs().sum() > 0
+    if dtype == torch.float32:
+        torch.testing.assert_close(out["binned"], out["atomics"], rtol=1e-4, atol=1e-6)
+    else:  # half atomics lose low bits on every add; the binned sum is exact and rounded once
+        torch.testing.assert_close(out["binned"].float(), out["atomics"].float(), rtol=5e-2, atol=5e-3)
+    valid = ((x >= 0) & (x <= 1)).all(-1)
+    for l in (0, L - 1):
+        want = grad[l][valid].double().sum(0)
+        got = out["binned"][int(offsets[l]):int(offsets[l + 1])].double().sum(0)
+        torch.testing.assert_close(got, want, rtol=2e-2 if dtype == torch.float16 else 1e-4, atol=2e-3)
+
+
+def test_grid_backward_nonfinite_poisons_level(hip):
+    offsets, S, total = _enc_meta(3, 4, 2, 16, 14, 64)
+    B = 9000
+    x = torch.rand(B, 3, generator=torch.Generator().manual_seed(5)).cuda()
+    grad = torch.ones(4, B, 2, device="cuda")
+    grad[2, 17, 1] = float("inf")
+    emb = torch.zeros(total, 2, device="cuda")
+    try:
+        for path in (2,):
+            hip.GridBackend.set_backward_path(path)
+            ge = torch.zeros(total, 2, device="cuda")
+            hip.GridBackend.grid_encode_backward(grad, x, emb, offsets.cuda(), ge, B, 3, 2, 4, S, 16, None, None, 0, False, 0)
+            lv = ge[int(offsets[2]):int(offsets[3])]
+            assert torch.isnan(lv).all(), f"path {path}: non-finite gradient must poison its level"
+            assert torch.isfinite(ge[: int(offsets[2])]).all() and torch.isfinite(ge[int(offsets[3]):]).all()
+    finally:
+        hip.GridBackend.set_backward_path(0)
 
 
 def test_grid_tv(oracle, hip):

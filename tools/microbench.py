@@ -60,7 +60,7 @@ def main():
                     continue
                 G.set_backward_path(path)
                 t = timeit(lambda: G.grid_encode_backward(grad, x, emb, offs, ge, B, 3, 2, 16, S, 16, None, None, 0, False, 0), iters=5)
-                print(f"grid_bwd[{'atomics' if path == 1 else 'lds-fixp'}] {dtype} B={B}: {t*1e6:9.1f} us  {B/t/1e9:7.3f} Gpts/s  {B*bytes_pt/t/1e9:8.1f} GB/s algorithmic")
+                print(f"grid_bwd[{('', 'atomics', 'binned')[path]}] {dtype} B={B}: {t*1e6:9.1f} us  {B/t/1e9:7.3f} Gpts/s  {B*bytes_pt/t/1e9:8.1f} GB/s algorithmic")
             G.set_backward_path(0)
     # coherent points (samples along rays) as in training
     grid, bits = syn.lego_like_density_grid(seed=0)
