@@ -317,12 +317,21 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_backward(const T* __restrict
 
 
 // ---- binned backward: partition the contributions by table slice, accumulate each slice in LDS --------------
-// v * 2^k rounded to the nearest integer (ties to even).  A float has 24 significant bits and callers keep
-// |v| * 2^k < 2^62, so the scaled double is exact and only the final conversion rounds.
-// [An all-integer version (frexp mantissa shifted with variable 64-bit shifts inside divergent branches) returned wrong
-//  values for a few lanes per million when inlined next to ds_add_u64 on gfx950 / ROCm 7.2 — the same source is exact
-//  in a plain store kernel.  tools/ubench/fix64_lds.hip reproduces it and verifies this form bit for bit.]
-__device__ __forceinline__ long long to_fixed64(float v, int k) { return __double2ll_rn(ldexp((double)v, k)); }
+// v * 2^k rounded to the nearest integer (ties to even), |v| * 2^k < 2^62, in fp32 and 32-bit integer ops only:
+// t = |v| * 2^(k-32) is exact, floor(t) is the high word, the (exact) remainder scaled by 2^32 and rounded is the low word.
+// [Two other forms were tried.  (a) frexp mantissa moved with variable 64-bit shifts inside divergent branches: wrong
+//  values for a few lanes per million when inlined next to ds_add_u64 on gfx950 / ROCm 7.2, although the same source is
+//  exact in a plain store kernel.  (b) __double2ll_rn(ldexp((double)v, k)): exact, but ~12 half-rate fp64 instructions
+//  per value were ~half of the accumulate kernel's time.  tools/ubench/fix64_lds.hip reproduces (a) and verifies this
+//  form bit for bit against llrint(ldexp((double)v, k)) for several k.]
+__device__ __forceinline__ long long to_fixed64(float v, int k) {
+    const float t = ldexpf(fabsf(v), k - 32);
+    const float hf = floorf(t);
+    const uint32_t hi = (uint32_t)(int)hf;
+    const uint32_t lo = (uint32_t)rintf(ldexpf(t - hf, 32));
+    const long long q = (long long)(((unsigned long long)hi << 32) | lo);
+    return v < 0 ? -q : q;
+}
 
 // Measured on MI355X (tools/ubench): global fp atomics retire at a flat ~21 G/s chip-wide whatever the locality, LDS
 // float atomics at ~0.2 T/s, LDS *integer* atomics at ~2.3 T/s.  So the table gradient is accumulated in LDS as
@@ -423,6 +432,11 @@ __device__ __forceinline__ float absmax_feat(const T (&g)[C], bool& nonzero) {
     return m;
 }
 
+__global__ void __launch_bounds__(1024) k_zero_words(uint32_t* __restrict__ p, uint32_t n) {
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
 // hdr[level] = max |grad| over in-range points (bit pattern of a non-negative float is monotone as uint32; NaN
 // patterns sort above +inf); tot[level * smax + slice] = records of the slice.
 // Few, fat workgroups: every workgroup ends each level with one global atomic per slice on the SAME smax words, and
@@ -509,11 +523,32 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const T* __restrict__ grad
     uint32_t* gbase = base + kBinMaxSlices;
     uint32_t* skeys = gbase + kBinMaxSlices;
     V* svals = reinterpret_cast<V*>(skeys + P * K);
+    // 4-byte values (fp16 C=2, fp32 C=1) travel as ONE 8-byte {key, value} record: half the store / load instructions
+    constexpr bool kPacked = sizeof(V) == 4;
+    uint2* srecs = reinterpret_cast<uint2*>(skeys);
 
+    // all global loads of the prologue are issued before the first test (see k_bin_accumulate)
     const uint32_t level = level0 + blockIdx.y;
     const float amax = __uint_as_float(hdr[level]);
-    if (!(amax > 0.0f) || amax == INFINITY) return;  // zero / non-finite levels carry no records (uniform exit)
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t b = blockIdx.x * P + threadIdx.x;
+    float x[D];
+    T g[C];
+    bool inside = b < B;
+    if (inside) {
+        inside = !load_point<D>(inputs, b, x);
+        load_feat<T, C>(grad + ((size_t)level * B + b) * C, g);
+    }
+    constexpr uint32_t kPer = kBinMaxSlices / 64;
+    uint32_t my_tot[kPer];  // first wave: the level's slice totals, lane t holds slices t, t + 64, t + 128, ...
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) {
+            const uint32_t sl = j * 64 + threadIdx.x;
+            my_tot[j] = sl < smax ? tot[level * smax + sl] : 0u;
+        }
+    }
+    if (!(amax > 0.0f) || amax == INFINITY) return;  // zero / non-finite levels carry no records (uniform exit)
     const uint32_t S = bin_slices(hashmap_size, C);
     const uint32_t sshift = 31 - __clz(S);
     const float lscale = scales.v[level];
@@ -526,11 +561,7 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const T* __restrict__ grad
     uint32_t key[K], rank[K];
     V val[K];
     bool active = false;
-    const uint32_t b = blockIdx.x * P + threadIdx.x;
-    float x[D];
-    if (b < B && !load_point<D>(inputs, b, x)) {
-        T g[C];
-        load_feat<T, C>(grad + ((size_t)level * B + b) * C, g);
+    if (inside) {
         (void)absmax_feat<T, C>(g, active);
         if (active) {
             float pos[D], pd[D];
@@ -556,44 +587,61 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const T* __restrict__ grad
         }
     }
     __syncthreads();
-    // first wave: exclusive scan of this chunk's slice counts (offsets into the staging buffer)
+    // first wave: exclusive scan of this chunk's slice counts (offsets into the staging buffer), 64 slices per step
     const uint32_t per = S / 64;  // S is a power of two >= 64
     if (threadIdx.x < 64) {
-        uint32_t sum = 0;
-        for (uint32_t j = 0; j < per; j++) sum += cnt[threadIdx.x * per + j];
-        uint32_t run = wave_incl_scan(sum) - sum;
-        for (uint32_t j = 0; j < per; j++) { base[threadIdx.x * per + j] = run; run += cnt[threadIdx.x * per + j]; }
+        uint32_t carry = 0;
+        for (uint32_t j = 0; j < per; j++) {
+            const uint32_t c = cnt[j * 64 + threadIdx.x];
+            const uint32_t incl = wave_incl_scan(c);
+            base[j * 64 + threadIdx.x] = carry + incl - c;
+            carry += __shfl(incl, 63, 64);
+        }
     }
     __syncthreads();
     // ... then, while the other waves stage their records, the first wave reserves the chunk's run in every slice's
     // bucket: bucket start (exclusive scan of the level's slice totals) + one returning atomic per non-empty slice
     if (threadIdx.x < 64) {
-        uint32_t gsum = 0;
-        for (uint32_t j = 0; j < per; j++) gsum += tot[level * smax + threadIdx.x * per + j];
-        uint32_t grun = wave_incl_scan(gsum) - gsum;
-        for (uint32_t j = 0; j < per; j++) {
-            const uint32_t s = threadIdx.x * per + j, c = cnt[s];
-            gbase[s] = c ? grun + atomicAdd(&cursor[level * smax + s], c) : 0u;
-            grun += tot[level * smax + s];
+        uint32_t carry = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) {
+            if (j < per) {
+                const uint32_t sl = j * 64 + threadIdx.x, c = cnt[sl];
+                const uint32_t incl = wave_incl_scan(my_tot[j]);
+                gbase[sl] = c ? carry + incl - my_tot[j] + atomicAdd(&cursor[level * smax + sl], c) : 0u;
+                carry += __shfl(incl, 63, 64);
+            }
         }
     }
     if (active) {
 #pragma unroll
         for (uint32_t idx = 0; idx < K; idx++) {
             const uint32_t at = base[key[idx] >> 20] + rank[idx];
-            skeys[at] = key[idx];
-            svals[at] = val[idx];
+            if constexpr (kPacked) {
+                uint32_t bits;
+                __builtin_memcpy(&bits, &val[idx], 4);
+                srecs[at] = make_uint2(key[idx], bits);
+            } else {
+                skeys[at] = key[idx];
+                svals[at] = val[idx];
+            }
         }
     }
     __syncthreads();
     const uint32_t total = base[S - 1] + cnt[S - 1];
     const size_t region = (size_t)blockIdx.y * K * B;  // this level's record region inside the pass
     for (uint32_t i = threadIdx.x; i < total; i += P) {
-        const uint32_t k = skeys[i];
-        const uint32_t s = k >> 20;
-        const size_t at = region + gbase[s] + (i - base[s]);
-        gkeys[at] = k & 0xfffffu;
-        gvals[at] = svals[i];
+        if constexpr (kPacked) {
+            const uint2 r = srecs[i];
+            const uint32_t s = r.x >> 20;
+            reinterpret_cast<uint2*>(gkeys)[region + gbase[s] + (i - base[s])] = make_uint2(r.x & 0xfffffu, r.y);
+        } else {
+            const uint32_t k = skeys[i];
+            const uint32_t s = k >> 20;
+            const size_t at = region + gbase[s] + (i - base[s]);
+            gkeys[at] = k & 0xfffffu;
+            gvals[at] = svals[i];
+        }
     }
 }
 
@@ -606,17 +654,23 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate(const uint32_
     using V = typename FeatVec<T, C>::type;
     constexpr uint32_t K = 1u << D;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);  // [C][local_rows]: a wave's adds of one channel spread over all banks
     __shared__ uint32_t wsum[kBinAccThreads / 64];
-    const uint32_t level = level0 + blockIdx.y, slice = blockIdx.x;
+    const uint32_t level = level0 + blockIdx.y, slice = blockIdx.x;  // slice < smax (grid), so every load below is in range
+    // Every global value the prologue needs is loaded up front, before any of them is tested: a dependent round trip
+    // costs ~2 us here (the words were just written by the previous kernel on another XCD), and this workgroup's
+    // whole useful life is ~10 us.
     const uint32_t off = (uint32_t)offsets[level];
     const uint32_t rows = (uint32_t)offsets[level + 1] - off;
+    const float amax = __uint_as_float(hdr[level]);
+    const uint32_t count = tot[level * smax + slice];
+    uint32_t part = 0;  // bucket start = records of the slices before this one
+    for (uint32_t s = threadIdx.x; s < slice; s += kBinAccThreads) part += tot[level * smax + s];
     const uint32_t S = bin_slices(rows, C);
     if (slice >= S) return;
     const uint32_t local_rows = bin_local_rows(rows, S);
     auto row_of_local = [&](uint32_t local) { return ((local / kBinGroup) * S + slice) * kBinGroup + local % kBinGroup; };
     T* table = grad_grid + (size_t)off * C;
-    const float amax = __uint_as_float(hdr[level]);
     if (!(amax > 0.0f) || amax == INFINITY) {
         if (amax != amax || amax == INFINITY) {  // non-finite gradient: poison the level like a float sum would
             for (uint32_t i = threadIdx.x; i < local_rows * C; i += kBinAccThreads) {
@@ -626,11 +680,7 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate(const uint32_
         }
         return;
     }
-    const uint32_t count = tot[level * smax + slice];
     if (count == 0) return;
-    // bucket start = records of the slices before this one (loads issued first, consumed after the LDS clear)
-    uint32_t part = 0;
-    for (uint32_t s = threadIdx.x; s < slice; s += kBinAccThreads) part += tot[level * smax + s];
     for (uint32_t i = threadIdx.x; i < local_rows * C; i += kBinAccThreads) acc[i] = 0ull;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
@@ -655,7 +705,13 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate(const uint32_
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
             const uint32_t i = i0 + u * kBinAccThreads;
-            if (i < end) { k[u] = keys[i]; v[u] = vals[i]; }
+            if (i < end) {
+                if constexpr (sizeof(V) == 4) {
+                    const uint2 r = reinterpret_cast<const uint2*>(gkeys)[region + i];
+                    k[u] = r.x;
+                    __builtin_memcpy(&v[u], &r.y, 4);
+                } else { k[u] = keys[i]; v[u] = vals[i]; }
+            }
         }
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
@@ -664,7 +720,7 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate(const uint32_
                 __builtin_memcpy(pr, &v[u], sizeof(V));
 #pragma unroll
                 for (uint32_t c = 0; c < C; c++)
-                    atomicAdd(&acc[k[u] * C + c], (unsigned long long)to_fixed64(Acc<T>::to_f(pr[c]), kexp));
+                    atomicAdd(&acc[c * local_rows + k[u]], (unsigned long long)to_fixed64(Acc<T>::to_f(pr[c]), kexp));
             }
         }
     }
@@ -681,7 +737,7 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate(const uint32_
             nz[w] = false;
             if (r < local_rows) {
 #pragma unroll
-                for (uint32_t c = 0; c < C; c++) { q[w][c] = (long long)acc[r * C + c]; nz[w] |= (q[w][c] != 0); }
+                for (uint32_t c = 0; c < C; c++) { q[w][c] = (long long)acc[c * local_rows + r]; nz[w] |= (q[w][c] != 0); }
             }
         }
 #pragma unroll
@@ -862,7 +918,10 @@ int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets
         uint32_t* cursor = reinterpret_cast<uint32_t*>(ws + lay.cursor);
         uint32_t* keys = reinterpret_cast<uint32_t*>(ws + lay.keys);
         V* vals = reinterpret_cast<V*>(ws + lay.vals);
-        S3D_HIP(hipMemsetAsync(ws, 0, lay.cursor + (size_t)L * lay.smax * 4, st));
+        // (a kernel, not hipMemsetAsync: captured as a hipGraph memset node the clear did not take effect from the second
+        //  replay on — stale cursors, out-of-range record writes — on ROCm 7.2)
+        const uint32_t clear_words = (uint32_t)((lay.cursor + (size_t)L * lay.smax * 4) / 4);
+        hipLaunchKernelGGL(k_zero_words, dim3(div_up<uint32_t>(clear_words, 1024)), dim3(1024), 0, st, hdr, clear_words);
         const uint32_t ppb = div_up<uint32_t>(div_up<uint32_t>(B, kBinCountChunks), kBinCountThreads) * kBinCountThreads;
         hipLaunchKernelGGL((k_bin_count<T, D, C>), dim3(div_up<uint32_t>(B, ppb), L), dim3(kBinCountThreads), 0, st, grad, inputs,
                            offsets, B, ppb, sc, hdr, tot, lay.smax, gridtype, ac, interp);

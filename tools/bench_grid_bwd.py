@@ -45,6 +45,8 @@ def main():
     cases = [("uniform", torch.rand(1 << 15, 3, device="cuda")), ("uniform", torch.rand(1 << 18, 3, device="cuda")),
              ("uniform", torch.rand(1 << 20, 3, device="cuda")), ("rays4096", coherent_points(4096)),
              ("rays16384", coherent_points(16384))]
+    r = coherent_points(4096)
+    cases.append(("rays4096s", r[torch.randperm(r.shape[0], device="cuda")].contiguous()))  # same points, order shuffled
     cases = [(n, x) for n, x in cases if not only or only == (n + (str(x.shape[0]) if n == 'uniform' else ''))]
     for dtype in dts:
         emb = torch.zeros(total, 2, device="cuda", dtype=dtype)

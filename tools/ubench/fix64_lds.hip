@@ -28,7 +28,17 @@ __device__ __forceinline__ long long to_fixed64_nobranch(float v, int k) {
     const long long half = (1ll << r) >> 1;
     return ((m << l) + half) >> r;
 }
+__device__ __forceinline__ long long to_fixed64_split(float v, int k) {  // fp32 + 32-bit ops only, round-half-even
+    const float a = fabsf(v);
+    const float t = ldexpf(a, k - 32);
+    const float hf = floorf(t);
+    const uint32_t hi = (uint32_t)(int)hf;
+    const uint32_t lo = (uint32_t)rintf(ldexpf(t - hf, 32));
+    const long long q = (long long)(((unsigned long long)hi << 32) | lo);
+    return v < 0 ? -q : q;
+}
 template <int VAR> __device__ __forceinline__ long long cvt(float v, int k) {
+    if (VAR == 4) return to_fixed64_split(v, k);
     if (VAR == 0) return to_fixed64(v, k);
     if (VAR == 1) return to_fixed64_dbl(v, k);
     if (VAR == 2) return to_fixed64_nobranch(v, k);
@@ -119,5 +129,15 @@ int main() {
     run(k_acc<1>, "double", true);
     run(k_acc<2>, "nobranch", false);
     run(k_acc<3>, "branchy+nop", false);
+    run(k_acc<4>, "fp32split", true);
+    for (int kk : {50, 40, 61, 33, 20}) {   // other scales: values are ~1e-3 * w, so |v| * 2^kk stays below 2^62
+        std::vector<long long> w2(rows * 2, 0);
+        for (int i = 0; i < n; i++) { w2[keys[i] * 2] += (long long)llrint(ldexp((double)v[i].x, kk)); w2[keys[i] * 2 + 1] += (long long)llrint(ldexp((double)v[i].y, kk)); }
+        hipLaunchKernelGGL(k_acc<4>, dim3(1), dim3(1024), rows * 16, 0, dk, dv, n, kk, dacc, rows);
+        hipMemcpy(got.data(), dacc, rows * 16, hipMemcpyDeviceToHost);
+        int bad2 = 0;
+        for (int j = 0; j < rows * 2; j++) bad2 += got[j] != w2[j];
+        printf("fp32split k=%d: mismatches %d\n", kk, bad2);
+    }
     return 0;
 }
