@@ -9,7 +9,8 @@ A "step" is one NGP training step of BASELINE.json configs[1] on synthetic Lego-
 `value` = real marched samples (sum of step_counter[:,0] over the timed steps and over ranks) / wall time.
 
 Multi-GPU (`python -m torch.distributed.run ... bench.py --gpus N`): weak scaling, every rank trains on its own
-4,096-ray batches; one flat-bucket gradient all-reduce (RCCL) per step.
+4,096-ray batches; one flat-bucket gradient all-reduce (RCCL) per step, issued eagerly between the two graph
+replays of the step (forward+backward | optimizer) — the collective itself is never captured.
 
 Extra objects on the JSON line:
   roofline      dominant hot kernel of the timed region, timed with HIP events on the launch stream
@@ -42,6 +43,7 @@ def parse():
     ap.add_argument("--pretrain", type=int, default=384, help="untimed setup steps that converge the occupancy grid")
     ap.add_argument("--net", choices=["ff", "seal"], default="ff", help="ff: nerf/network_ff (configs[1]); seal: two-encoder nn.Linear net")
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--force_dp", action="store_true", help="run the data-parallel path (flat-bucket all-reduce, split graphs) on 1 GPU")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_render", action="store_true")
     ap.add_argument("--infer_batch_scale", type=int, default=4, help="inference samples/ray/iteration multiplier (1 = reference heuristic)")
@@ -194,9 +196,12 @@ def main():
     torch.manual_seed(args.seed)
     Net = network_ff.NeRFNetwork if args.net == "ff" else network.NeRFNetwork
     model = Net(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).to(dev)
-    dp = RayShardedDP() if world > 1 else None
-    if args.no_graph or world > 1:  # the RCCL all-reduce stays outside graph capture (untested on this pool)
-        args.no_graph = True
+    if args.force_dp and world == 1:  # single-GPU exercise of the data-parallel code path (1-rank RCCL group)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    dp = RayShardedDP(force_collective=args.force_dp) if (world > 1 or args.force_dp) else None
+    if args.no_graph:
         trainer = Trainer(model, lr=1e-2, fp16=True, update_extra_interval=16, dist=dp)
     else:
         trainer = GraphedTrainer(model, args.num_rays, lr=1e-2, fp16=True, update_extra_interval=16, dist=dp)
@@ -210,11 +215,7 @@ def main():
 
     def step(i):
         ro, rd, gt = batches[i % n_pool]
-        if dp is not None and model.cuda_ray and trainer.global_step % 16 == 0:
-            loss = trainer.train_step(ro, rd, gt)
-            dp.sync_extra_state(model)
-            return loss
-        return trainer.train_step(ro, rd, gt)
+        return trainer.train_step(ro, rd, gt)  # (with dp: occupancy state is synchronised inside, after each grid update)
 
     # --- setup: converge the occupancy grid (untimed, not part of warm-up)
     for i in range(args.pretrain):
@@ -235,6 +236,19 @@ def main():
     if not graphed:
         install_timers()
 
+    # density-grid maintenance (every 16 steps, inside the timed region like in the reference's train loop): event pair per call
+    ues_events = []
+    ues_inner = model.update_extra_state
+
+    def timed_update_extra_state(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = ues_inner(*a, **k)
+        e1.record()
+        ues_events.append((e0, e1))
+        return r
+    model.update_extra_state = timed_update_extra_state
+
     samples_dev = torch.zeros(1, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
     if world > 1:
@@ -249,6 +263,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    model.update_extra_state = ues_inner
+    ues_ms = [a.elapsed_time(b) for a, b in ues_events]
     timer_steps = args.steps
     if graphed:
         # HIP events cannot be recorded inside a graph replay: time the individual kernels in an eager pass of the
@@ -295,6 +311,9 @@ def main():
                            else "inside the timed region")}
 
     extra = {}
+    if ues_ms:
+        extra["update_extra_state"] = {"calls_in_timed_region": len(ues_ms), "ms_per_call": sum(ues_ms) / len(ues_ms),
+                                       "ms_per_step_amortised": sum(ues_ms) / args.steps}
     if not args.no_render:
         # full 800x800 frame renders (inference loop) + PSNR against the analytic scene
         model.infer_batch_scale = args.infer_batch_scale
@@ -325,13 +344,21 @@ def main():
                                "Seal NGP net (two hash encoders + nn.Linear MLPs), 800x800 cameras, 4096 rays/step/GPU",
                    "num_rays_per_gpu": args.num_rays, "samples_per_step": samples / args.steps / world,
                    "parallelism": f"ray-sharded dp{world}", "pretrain_steps": args.pretrain,
-                   "launch": "hip-graph replay" if graphed else "eager"},
+                   "launch": ("hip-graph replay" + (" (fwd+bwd | all-reduce | optimizer)" if dp is not None else "")) if graphed else "eager"},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     line.update(extra)
-    print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+    # RCCL writes a version banner to C stdout, which is flushed at exit — after Python's buffer.  Flush it now so the
+    # JSON line is the LAST line of stdout.
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -113,7 +113,10 @@ class FFMLP(nn.Module):
 
     def forward(self, inputs):
         B, C = inputs.shape
-        pad = 128 - (B % 128)  # always >= 1 block of padding when B % 128 == 0 (ffmlp.py:156), kept for parity
+        # The reference always appends 128 - B % 128 zero rows (a full extra block when B is already aligned,
+        # ffmlp.py:156-159) and slices them off again: results do not depend on it, and the copy is a full pass over the
+        # activations, so rows are only added when the batch is ragged (the MFMA tiles are 32 points).
+        pad = (-B) % 128
         if pad > 0:
             inputs = torch.cat([inputs, torch.zeros(pad, C, dtype=inputs.dtype, device=inputs.device)], dim=0)
         out = ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim,

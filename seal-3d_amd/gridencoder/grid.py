@@ -6,6 +6,8 @@ libseal3d_hip (s3d_hip.GridBackend).
 """
 import math
 
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -20,13 +22,38 @@ _GRIDTYPE = {"hash": 0, "tiled": 1}
 _INTERP = {"linear": 0, "smoothstep": 1}
 
 
+_half_cache = {}  # id(parameter) -> (weakref, version, epoch, half copy)
+_weights_epoch = 0
+
+
+def bump_weights_epoch():
+    """Called by trainers that update parameters WITHOUT Python-side in-place ops (HIP-graph replays do not bump
+    `Tensor._version`), so that cached fp16 tables are refreshed."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def _half_table(embeddings, cache):
+    """fp16 copy of the table for autocast (grid.py:41-44 casts on every call).  In eval mode (the inference loop calls
+    the encoder ~50 times per frame on unchanged weights) the copy is cached per parameter version: one 73 MB cast per
+    weight update instead of one per call."""
+    if not cache or torch.cuda.is_current_stream_capturing():
+        return embeddings.to(torch.half)
+    hit = _half_cache.get(id(embeddings))
+    if hit is not None and hit[0]() is embeddings and hit[1] == embeddings._version and hit[2] == _weights_epoch:
+        return hit[3]
+    h = embeddings.detach().to(torch.half)
+    _half_cache[id(embeddings)] = (weakref.ref(embeddings), embeddings._version, _weights_epoch, h)
+    return h
+
+
 class _GridEncode(Function):
     """grid.py:24-89.  Autocast is handled by hand: inputs stay fp32, the table is cast to half when C is even."""
 
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False,
-                gridtype=0, align_corners=False, interpolation=0):
+                gridtype=0, align_corners=False, interpolation=0, cache_half=False):
         inputs = inputs.contiguous()
         B, D = inputs.shape
         L = offsets.shape[0] - 1
@@ -35,7 +62,7 @@ class _GridEncode(Function):
         H = base_resolution
 
         if torch.is_autocast_enabled("cuda") and C % 2 == 0:
-            embeddings = embeddings.to(torch.half)
+            embeddings = _half_table(embeddings, cache_half)
         embeddings = embeddings.contiguous()
 
         outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)  # level-major
@@ -61,7 +88,7 @@ class _GridEncode(Function):
                                       grad_inputs, gridtype, align_corners, interpolation)
         if grad_inputs is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
-        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None
+        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None
 
 
 grid_encode = _GridEncode.apply
@@ -120,7 +147,8 @@ class GridEncoder(nn.Module):
         lead = list(inputs.shape[:-1])
         inputs = inputs.view(-1, self.input_dim)
         out = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
-                          inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id)
+                          inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id,
+                          not self.training)
         return out.view(lead + [self.output_dim])
 
     @torch.autocast("cuda", enabled=False)

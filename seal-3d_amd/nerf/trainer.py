@@ -7,6 +7,8 @@ import math
 import torch
 import torch.nn.functional as F
 
+from gridencoder.grid import bump_weights_epoch
+
 
 def psnr(pred, target):
     return -10 * math.log10(float(torch.mean((pred.float() - target.float()) ** 2)) + 1e-20)
@@ -33,6 +35,10 @@ class Trainer:
         if model.cuda_ray and self.global_step % self.update_extra_interval == 0:
             with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
                 model.update_extra_state()
+            if self.dist is not None:
+                # replicas draw different random cells: adopt rank 0's grid / bitfield / mean_count so that every rank
+                # marches the same occupancy and takes the same (re-)capture decisions below
+                self.dist.sync_extra_state(model)
             return True
         return False
 
@@ -81,24 +87,29 @@ class GraphedTrainer(Trainer):
         self.s_gt = torch.zeros(num_rays, 3, device=dev)
         self.budget_factor = budget_factor
         self.graph = None
+        self.graph_opt = None
         self.budget = 0
         self.s_loss = None
         self.s_counter = torch.zeros(2, dtype=torch.int32, device=dev)
 
-    def _body(self):
+    def _body_fb(self):
+        """zero grads -> render -> loss -> scaled backward"""
         model = self.model
         self.optimizer.zero_grad(set_to_none=False)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             out = model.render(self.s_ro, self.s_rd, bg_color=1, perturb=True, force_all_rays=False, **self.render_kwargs)
             loss = F.mse_loss(out["image"], self.s_gt)
         self.scaler.scale(loss).backward()
-        if self.dist is not None:
-            self.dist.allreduce_grads(self.scaler)
-        self.scaler.step(self.optimizer)
-        self.scaler.update()
         return loss.detach()
 
+    def _body_opt(self):
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+
     def _capture(self):
+        """One graph for the whole step on a single GPU.  With data parallelism the step is captured as TWO graphs
+        (forward+backward | unscale+Adam+scaler update) and the gradient all-reduce is issued eagerly between the two
+        replays: the collective stays outside graph capture, the ~120 kernel launches stay inside."""
         model = self.model
         model.train()
         self.budget = int(max(model.mean_count, 1) * self.budget_factor)
@@ -111,16 +122,34 @@ class GraphedTrainer(Trainer):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(2):
+            for _ in range(2):  # real steps on the current batch (every rank runs the same number of all-reduces)
                 model.local_step = 0
-                self._body()
+                self._body_fb()
+                if self.dist is not None:
+                    self.dist.allreduce_grads(self.scaler)
+                self._body_opt()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         model.local_step = 0
-        with torch.cuda.graph(self.graph):
-            self.s_loss = self._body()
+        if self.dist is None:
+            with torch.cuda.graph(self.graph):
+                self.s_loss = self._body_fb()
+                self._body_opt()
+            self.graph_opt = None
+        else:
+            with torch.cuda.graph(self.graph):
+                self.s_loss = self._body_fb()
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+                self._body_opt()
         model.step_counter = ring
         model.mean_count, model.local_step = saved
+
+    def _replay(self):
+        self.graph.replay()
+        if self.graph_opt is not None:
+            self.dist.allreduce_grads(self.scaler)
+            self.graph_opt.replay()
 
     def train_step(self, rays_o, rays_d, gt_rgb, bg_color=1):
         model = self.model
@@ -137,7 +166,8 @@ class GraphedTrainer(Trainer):
         self.s_gt.copy_(gt_rgb.reshape(-1, 3))
         if self.graph is None:
             self._capture()  # warm-up + capture run the step on the current batch
-        self.graph.replay()
+        self._replay()
+        bump_weights_epoch()  # replays update the parameters without touching Tensor._version
         model.step_counter[model.local_step % 16].copy_(self.s_counter)
         model.local_step += 1
         return self.s_loss

@@ -38,8 +38,9 @@ def shard_slice(n, rank, world):
 
 
 class RayShardedDP:
-    def __init__(self, group=None, average=True):
+    def __init__(self, group=None, average=True, force_collective=False):
         self.group = group
+        self.force_collective = force_collective  # issue the collectives even for world == 1 (single-GPU test of the path)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.average = average
@@ -63,7 +64,7 @@ class RayShardedDP:
         return self
 
     def allreduce_grads(self, scaler=None):
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return
         # safety: a grad that autograd re-allocated is copied back into its bucket slot
         off = 0
@@ -83,12 +84,14 @@ class RayShardedDP:
 
     def sync_extra_state(self, model):
         """keep the occupancy state identical on all replicas after `update_extra_state` (RNG differs per rank)"""
-        if self.world == 1 or not getattr(model, "cuda_ray", False):
+        if (self.world == 1 and not self.force_collective) or not getattr(model, "cuda_ray", False):
             return
         dist.broadcast(model.density_grid, src=0, group=self.group)
         dist.broadcast(model.density_bitfield, src=0, group=self.group)
-        t = torch.tensor([float(model.mean_count), float(model.mean_density)], device=model.density_grid.device)
-        dist.broadcast(t, src=0, group=self.group)
+        # sample budget: the largest running mean over the ranks (each rank marches its own rays), density: rank 0's
+        t = torch.tensor([float(model.mean_count), float(model.mean_density) if self.rank == 0 else float("-inf")],
+                         device=model.density_grid.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         model.mean_count, model.mean_density = int(t[0].item()), float(t[1].item())
 
     def all_reduce_scalar(self, value, op="sum"):
