@@ -186,7 +186,13 @@ int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_
                         uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,
                         s3d_stream_t stream);
 /* ffmlp.h:11; grad_weights fp16 [same layout as weights], zero-initialised by the caller.
- * workspace: fp32 accumulation of the weight gradient (s3d_ffmlp_backward_workspace_size). */
+ * workspace: fp32 accumulation of the weight gradient (s3d_ffmlp_backward_workspace_size).
+ * forward_buffer == backward_buffer == NULL selects the fused backward: the activations are re-computed from
+ * `inputs` inside one kernel that also forms the data and weight gradients, so a training forward may skip
+ * forward_buffer altogether (call s3d_ffmlp_forward with forward_buffer = NULL).  Shapes it covers:
+ * s3d_ffmlp_fused_backward_supported() != 0 (hidden 32/64, <= 3 hidden matrices, no sine). */
+int s3d_ffmlp_fused_backward_supported(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
+                                       uint32_t num_layers, uint32_t activation);
 size_t s3d_ffmlp_backward_workspace_size(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                                          uint32_t num_layers);
 int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights,

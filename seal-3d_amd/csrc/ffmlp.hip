@@ -54,6 +54,18 @@ __device__ __forceinline__ float act_bwd(uint32_t a, float g, float fwd) {
     }
 }
 
+// Activation selected at COMPILE time when ACT >= 0 (the ReLU instantiations), at run time otherwise.  The kernels apply it
+// inside fully unrolled 32-element loops: with a run-time switch every element carried all seven branches (expf, sinf, logf
+// inlined) and the kernels grew to ~30k instructions — far beyond the instruction cache.
+template <int ACT> __device__ __forceinline__ float act_fwd_t(uint32_t a, float x) {
+    if constexpr (ACT >= 0) return act_fwd((uint32_t)ACT, x);
+    else return act_fwd(a, x);
+}
+template <int ACT> __device__ __forceinline__ float act_bwd_t(uint32_t a, float g, float fwd) {
+    if constexpr (ACT >= 0) return act_bwd((uint32_t)ACT, g, fwd);
+    else return act_bwd(a, g, fwd);
+}
+
 // K-permutation of one 16-wide k-step: element j of lane-half h
 __device__ __forceinline__ uint32_t kperm(uint32_t h, uint32_t j) { return (j & 3u) + 8u * (j >> 2) + 4u * h; }
 
@@ -89,7 +101,7 @@ __device__ __forceinline__ uint32_t native_off(uint32_t mblk, uint32_t q, uint32
 
 // ------------------------------------------------------------------------------------ forward
 // LDS fragment directory: layer 0: MB*KS0 frags | hidden k: MB*KS frags each | last: KS frags
-template <int W, bool TRAIN>
+template <int W, bool TRAIN, int ACT, int OACT>
 __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restrict__ X, const _Float16* __restrict__ Wt,
                                                        uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
                                                        uint32_t act, uint32_t out_act, _Float16* __restrict__ fwd,
@@ -148,7 +160,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
 #pragma unroll
                 for (uint32_t r = 0; r < 16; r++) {
                     const float pre = (float)(_Float16)acc[m][r];
-                    bf[2 * m + (r >> 3)][r & 7] = (_Float16)act_fwd(act, pre);
+                    bf[2 * m + (r >> 3)][r & 7] = (_Float16)act_fwd_t<ACT>(act, pre);
                 }
             if (TRAIN) {
                 _Float16* dst = fwd + (size_t)layer * B * W + (size_t)tile * 32 * W;
@@ -181,7 +193,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
         for (uint32_t q = 0; q < 2; q++) {
             half4 v;
 #pragma unroll
-            for (uint32_t e = 0; e < 4; e++) v[e] = (_Float16)act_fwd(out_act, (float)(_Float16)o[4 * q + e]);
+            for (uint32_t e = 0; e < 4; e++) v[e] = (_Float16)act_fwd_t<OACT>(out_act, (float)(_Float16)o[4 * q + e]);
             st4(orow + 8 * q + 4 * h, v);
         }
     }
@@ -189,7 +201,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
 
 // ------------------------------------------------------------------------------------ backward: dgrad
 // LDS directory: last^T: MB frags (one k-step, K = 16 outputs) | hidden^T k: MB*KS each | first^T: IMB*KS
-template <int W>
+template <int W, int ACT>
 __global__ void __launch_bounds__(256) k_ffmlp_dgrad(const _Float16* __restrict__ grad, const _Float16* __restrict__ Wt,
                                                      const _Float16* __restrict__ fwd, uint32_t B, uint32_t in_dim,
                                                      uint32_t out_dim, uint32_t n_layers, uint32_t act,
@@ -255,7 +267,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_dgrad(const _Float16* __restrict_
 #pragma unroll
                     for (uint32_t e = 0; e < 4; e++) {
                         const float g = (float)(_Float16)acc[m][4 * q + e];
-                        v[e] = (_Float16)act_bwd(act, g, (float)fv[e]);
+                        v[e] = (_Float16)act_bwd_t<ACT>(act, g, (float)fv[e]);
                         bf[2 * m + (q >> 1)][(q & 1) * 4 + e] = v[e];
                     }
                     st4(dst + native_off(m, q, n, h), v);
@@ -293,6 +305,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_dgrad(const _Float16* __restrict_
 // ------------------------------------------------------------------------------------ backward: wgrad
 // dW[o][i] = sum_b G[b][o] * X[b][i]; batch is the MFMA K dimension.  One (G, X) pair per layer.
 constexpr uint32_t kMaxMlpLayers = 8;
+constexpr uint32_t kWgradPad = 64;  // partial weight-gradient matrices are stored [64][64] fp32 regardless of W
 struct WgradLayer {
     const _Float16* G;  // gradient w.r.t. the layer's pre-activation output
     const _Float16* X;  // the layer's input
@@ -310,7 +323,6 @@ __device__ __forceinline__ uint32_t tile_elem(uint32_t native, uint32_t F, uint3
     return b * F + f;
 }
 
-constexpr uint32_t kWgradPad = 64;  // partial matrices are stored [64][64] fp32 regardless of W
 
 template <int W>
 __global__ void __launch_bounds__(256) k_ffmlp_wgrad(WgradPlan plan, uint32_t B, float* __restrict__ partial) {
@@ -386,24 +398,316 @@ __global__ void __launch_bounds__(256) k_ffmlp_wgrad(WgradPlan plan, uint32_t B,
     for (uint32_t i = threadIdx.x; i < kWgradPad * kWgradPad; i += 256) dst[i] = red[i];
 }
 
+// Eight lanes per matrix element: each sums every 8th workgroup partial with independent accumulators (a single chain over
+// 256 partials was latency-bound: ~20 us), then a fixed xor-shuffle tree combines the eight.  Deterministic.
+constexpr uint32_t kReduceSplit = 8;
 __global__ void k_ffmlp_wgrad_reduce(WgradPlan plan, uint32_t nblk, const float* __restrict__ partial,
                                      _Float16* __restrict__ grad_weights) {
     const WgradLayer L = plan.layer[blockIdx.y];
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= L.Fo * L.Fi) return;
-    const uint32_t o = e / L.Fi, i = e - o * L.Fi;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t e = t / kReduceSplit, part = t % kReduceSplit;
+    const bool live = e < L.Fo * L.Fi;
+    const uint32_t o = live ? e / L.Fi : 0, i = live ? e - o * L.Fi : 0;
     const float* p = partial + (size_t)blockIdx.y * nblk * kWgradPad * kWgradPad + o * kWgradPad + i;
-    // independent partial sums keep several loads in flight (a single dependent chain was latency-bound: 38 us)
+    constexpr size_t kPlane = (size_t)kWgradPad * kWgradPad;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    uint32_t b = 0;
-    for (; b + 4 <= nblk; b += 4) {
-        s0 += p[(size_t)(b + 0) * kWgradPad * kWgradPad];
-        s1 += p[(size_t)(b + 1) * kWgradPad * kWgradPad];
-        s2 += p[(size_t)(b + 2) * kWgradPad * kWgradPad];
-        s3 += p[(size_t)(b + 3) * kWgradPad * kWgradPad];
+    if (live) {
+        uint32_t b = part;
+        for (; b + 3 * kReduceSplit < nblk; b += 4 * kReduceSplit) {
+            s0 += p[(size_t)(b + 0 * kReduceSplit) * kPlane];
+            s1 += p[(size_t)(b + 1 * kReduceSplit) * kPlane];
+            s2 += p[(size_t)(b + 2 * kReduceSplit) * kPlane];
+            s3 += p[(size_t)(b + 3 * kReduceSplit) * kPlane];
+        }
+        for (; b < nblk; b += kReduceSplit) s0 += p[(size_t)b * kPlane];
     }
-    for (; b < nblk; b++) s0 += p[(size_t)b * kWgradPad * kWgradPad];
-    grad_weights[L.w_off + e] = (_Float16)((s0 + s1) + (s2 + s3));
+    float v = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int d = 1; d < (int)kReduceSplit; d <<= 1) v += __shfl_xor(v, d, 64);
+    if (live && part == 0) grad_weights[L.w_off + e] = (_Float16)v;
+}
+
+// ------------------------------------------------------------------------------------ backward: fused
+// One kernel for the whole backward pass, nothing but the network input, the output gradient and the weights read
+// from HBM: per 32-point tile a wave (1) RE-COMPUTES the forward activations from the input (36 kFLOP per point is
+// nothing next to the 256-384 B per point the stored forward_buffer costs to write and read back), (2) walks the
+// transposed network for the data gradient exactly like k_ffmlp_dgrad, and (3) accumulates every layer's weight
+// gradient dW[o][i] += sum_p G[p][o] X[p][i] on the spot.  For (3) the batch is the MFMA K dimension, so both
+// operands are transposed through a per-wave LDS tile: lanes scatter their (point, feature) values into
+// T[feature][point] (rows padded to 40 halfs: the two lane halves hit disjoint banks) and read their fragment back
+// as ONE 16-byte row segment (8 consecutive points of one feature).  Weight-gradient accumulators stay in registers
+// (MFMA accumulation VGPRs) for all tiles of the wave; at the end the four waves are summed through LDS in a fixed
+// order and one fp32 partial per workgroup goes to the same reduce kernel as the two-kernel path.  Deterministic.
+// HBM traffic per point: in*2 + 32 B read (+ in*2 B grad_inputs) instead of ~1.2 KB.
+constexpr uint32_t kTRow = 40;  // halfs per row of a transposed tile (32 points + 8 pad)
+
+constexpr uint32_t kTRows = 64;  // features per transposed tile (hidden width and input width are both <= 64)
+template <int NS>
+__device__ __forceinline__ void transpose_store(_Float16* __restrict__ T, const half8 (&bf)[NS], uint32_t ksteps,
+                                                uint32_t n, uint32_t h) {
+#pragma unroll
+    for (uint32_t s = 0; s < (uint32_t)NS; s++)
+        if (s < ksteps) {
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) T[(16 * s + kperm(h, j)) * kTRow + n] = bf[s][j];
+        }
+}
+// fragment (A or B operand of the weight-gradient MFMA) for feature block `blk`, k-step (16 points) s
+__device__ __forceinline__ half8 transpose_load(const _Float16* __restrict__ T, uint32_t blk, uint32_t s, uint32_t fl,
+                                                uint32_t h, uint32_t nfeat) {
+    half8 v = *reinterpret_cast<const half8*>(T + (blk * 32 + fl) * kTRow + 16 * s + 8 * h);
+    if (blk * 32 + fl >= nfeat) {
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) v[j] = (_Float16)0.0f;
+    }
+    return v;
+}
+
+// Sum one weight-gradient matrix over the four waves of the workgroup and write the workgroup's fp32 partial.
+// Each wave stores its accumulator blocks to its OWN [64][64] LDS plane (independent stores, no read-modify-write
+// chains), then all 256 threads add the four planes in a fixed order.
+template <uint32_t MBLK, uint32_t NBLK, typename Get>
+__device__ __forceinline__ void flush_matrix(float* __restrict__ red, float* __restrict__ partial, uint32_t matrix, uint32_t wave,
+                                             uint32_t n, uint32_t h, Get&& get) {
+    constexpr uint32_t kPlane = kWgradPad * kWgradPad;
+    __syncthreads();
+    float* mine = red + (size_t)wave * kPlane;
+#pragma unroll
+    for (uint32_t mo = 0; mo < MBLK; mo++)
+#pragma unroll
+        for (uint32_t ni = 0; ni < NBLK; ni++) {
+            const float16v v = get(mo, ni);
+#pragma unroll
+            for (uint32_t r = 0; r < 16; r++) mine[(mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * kWgradPad + ni * 32 + n] = v[r];
+        }
+    __syncthreads();
+    float* dst = partial + ((size_t)matrix * gridDim.x + blockIdx.x) * kPlane;
+    for (uint32_t i = threadIdx.x; i < kPlane; i += 256) {
+        const uint32_t o = i / kWgradPad, c = i % kWgradPad;
+        float v = 0.0f;
+        if (o < MBLK * 32 && c < NBLK * 32) v = ((red[i] + red[kPlane + i]) + red[2 * kPlane + i]) + red[3 * kPlane + i];
+        dst[i] = v;
+    }
+}
+
+template <int W, int NH, int IMB, int ACT>
+__global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __restrict__ grad, const _Float16* __restrict__ X,
+                                                             const _Float16* __restrict__ Wt, uint32_t B, uint32_t in_dim,
+                                                             uint32_t out_dim, uint32_t act, _Float16* __restrict__ grad_inputs,
+                                                             float* __restrict__ partial) {
+    constexpr uint32_t MB = W / 32, KS = W / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n = lane & 31, h = lane >> 5;
+    const uint32_t KS0 = in_dim / 16;
+    // LDS: forward A frags [layer0: MB*KS0 | hidden: NH*MB*KS] | transposed A frags [last^T: MB | hidden^T: NH*MB*KS |
+    //      first^T: IMB*KS (only with grad_inputs)] | per-wave transpose tiles TG, TX | (aliased at the end) red[64*64]
+    const uint32_t nf_f0 = MB * KS0, nf_fh = NH * MB * KS;
+    const uint32_t nf_bl = MB, nf_bh = NH * MB * KS, nf_b0 = grad_inputs ? IMB * KS : 0;
+    const uint32_t nfrag = nf_f0 + nf_fh + nf_bl + nf_bh + nf_b0;
+    half8* frags = reinterpret_cast<half8*>(smem_raw);
+    half8* ff0 = frags;
+    half8* ffh = ff0 + (size_t)nf_f0 * 64;
+    half8* fbl = ffh + (size_t)nf_fh * 64;
+    half8* fbh = fbl + (size_t)nf_bl * 64;
+    half8* fb0 = fbh + (size_t)nf_bh * 64;
+    _Float16* tiles = reinterpret_cast<_Float16*>(frags + (size_t)nfrag * 64);
+    _Float16* TG = tiles + (size_t)wave * 2 * kTRows * kTRow;
+    _Float16* TX = TG + (size_t)kTRows * kTRow;
+    const _Float16* w_hid = Wt + (size_t)W * in_dim;
+    const _Float16* w_last = w_hid + (size_t)NH * W * W;
+
+    for (uint32_t f = wave; f < nfrag; f += 4) {
+        half8 v;
+        if (f < nf_f0) {  // forward, layer 0: A[row = hidden feature][k = input]
+            const uint32_t mblk = f / KS0, s = f % KS0;
+            const _Float16* r = Wt + (size_t)(mblk * 32 + n) * in_dim + 16 * s;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) v[j] = r[kperm(h, j)];
+        } else if (f < nf_f0 + nf_fh) {  // forward, hidden k
+            const uint32_t g = f - nf_f0, k = g / (MB * KS), mblk = (g / KS) % MB, s = g % KS;
+            const _Float16* r = w_hid + (size_t)k * W * W + (size_t)(mblk * 32 + n) * W + 16 * s;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) v[j] = r[kperm(h, j)];
+        } else if (f < nf_f0 + nf_fh + nf_bl) {  // last^T: A[i = hidden feature][k = output] = W_last[k][i]
+            const uint32_t i = (f - nf_f0 - nf_fh) * 32 + n;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const uint32_t k = kperm(h, j);
+                v[j] = (k < out_dim) ? w_last[(size_t)k * W + i] : (_Float16)0.0f;
+            }
+        } else if (f < nf_f0 + nf_fh + nf_bl + nf_bh) {  // hidden^T: A[i = in feature][k = out feature] = W_k[k][i]
+            const uint32_t g = f - nf_f0 - nf_fh - nf_bl, k = g / (MB * KS), mblk = (g / KS) % MB, s = g % KS;
+            const _Float16* wk = w_hid + (size_t)k * W * W;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) v[j] = wk[(size_t)(16 * s + kperm(h, j)) * W + mblk * 32 + n];
+        } else {  // first^T: A[i = network input][k = first hidden feature] = W_0[k][i]
+            const uint32_t g = f - nf_f0 - nf_fh - nf_bl - nf_bh, mblk = g / KS, s = g % KS;
+            const uint32_t i = mblk * 32 + n;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++)
+                v[j] = (i < in_dim) ? Wt[(size_t)(16 * s + kperm(h, j)) * in_dim + i] : (_Float16)0.0f;
+        }
+        frags[f * 64 + lane] = v;
+    }
+    __syncthreads();
+
+    // weight-gradient accumulators: layer 0 [W x in], hidden [W x W] x NH, last [16 (one block) x W]
+    float16v dw0[MB][IMB], dwh[NH > 0 ? NH : 1][MB][MB], dwl[MB];
+#pragma unroll
+    for (uint32_t a = 0; a < MB; a++) {
+#pragma unroll
+        for (uint32_t b = 0; b < (uint32_t)IMB; b++) dw0[a][b] = zero16();
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)NH; k++)
+#pragma unroll
+            for (uint32_t b = 0; b < MB; b++) dwh[k][a][b] = zero16();
+        dwl[a] = zero16();
+    }
+
+    const uint32_t ntiles = B / 32;
+    for (uint32_t tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const size_t row = (size_t)tile * 32 + n;
+        // ---- inputs of the tile: network input (B fragments) and output gradient (one k-step)
+        half8 xf[4];  // in_dim <= 64
+        const _Float16* xrow = X + row * in_dim;
+#pragma unroll
+        for (uint32_t s = 0; s < 4; s++)
+            if (s < KS0) xf[s] = load_bfrag_rowmajor(xrow, s, h);
+        const half8 gf = load_bfrag_rowmajor(grad + row * 16, 0, h);
+
+        // ---- forward re-computation (same operations and roundings as k_ffmlp_forward)
+        half8 a[NH + 1][KS];
+        {
+            float16v acc[MB];
+#pragma unroll
+            for (uint32_t m = 0; m < MB; m++) acc[m] = zero16();
+#pragma unroll
+            for (uint32_t s = 0; s < 4; s++)
+                if (s < KS0) {
+#pragma unroll
+                    for (uint32_t m = 0; m < MB; m++) acc[m] = mfma(ff0[(m * KS0 + s) * 64 + lane], xf[s], acc[m]);
+                }
+#pragma unroll
+            for (uint32_t layer = 0; layer <= (uint32_t)NH; layer++) {
+#pragma unroll
+                for (uint32_t m = 0; m < MB; m++)
+#pragma unroll
+                    for (uint32_t r = 0; r < 16; r++) {
+                        const float pre = (float)(_Float16)acc[m][r];
+                        a[layer][2 * m + (r >> 3)][r & 7] = (_Float16)act_fwd_t<ACT>(act, pre);
+                    }
+                if (layer < (uint32_t)NH) {
+                    const half8* wf = ffh + (size_t)(layer * MB * KS) * 64;
+#pragma unroll
+                    for (uint32_t m = 0; m < MB; m++) {
+                        acc[m] = zero16();
+#pragma unroll
+                        for (uint32_t s = 0; s < KS; s++) acc[m] = mfma(wf[(m * KS + s) * 64 + lane], a[layer][s], acc[m]);
+                    }
+                }
+            }
+        }
+
+        // ---- last layer: dW_last += g^T a_NH ; dA_NH = W_last^T g
+        {
+            const half8 gtmp[1] = {gf};
+            transpose_store<1>(TG, gtmp, 1, n, h);
+            transpose_store<(int)KS>(TX, a[NH], KS, n, h);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (uint32_t s = 0; s < 2; s++) {
+                const half8 af = transpose_load(TG, 0, s, n, h, 16);
+#pragma unroll
+                for (uint32_t ni = 0; ni < MB; ni++) dwl[ni] = mfma(af, transpose_load(TX, ni, s, n, h, W), dwl[ni]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        float16v acc[MB];
+#pragma unroll
+        for (uint32_t m = 0; m < MB; m++) acc[m] = mfma(fbl[m * 64 + lane], gf, zero16());
+
+        // ---- hidden layers, top down
+        half8 G[KS];
+#pragma unroll
+        for (int k = NH; k >= 0; k--) {
+            // gradient w.r.t. the pre-activation of hidden layer k (activation transfer with the re-computed output)
+#pragma unroll
+            for (uint32_t m = 0; m < MB; m++)
+#pragma unroll
+                for (uint32_t r = 0; r < 16; r++) {
+                    const float g = (float)(_Float16)acc[m][r];
+                    G[2 * m + (r >> 3)][r & 7] = (_Float16)act_bwd_t<ACT>(act, g, (float)a[k][2 * m + (r >> 3)][r & 7]);
+                }
+            transpose_store<(int)KS>(TG, G, KS, n, h);
+            if (k > 0) {
+                transpose_store<(int)KS>(TX, a[k - 1], KS, n, h);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (uint32_t s = 0; s < 2; s++) {
+                    half8 bfr[MB];
+#pragma unroll
+                    for (uint32_t ni = 0; ni < MB; ni++) bfr[ni] = transpose_load(TX, ni, s, n, h, W);
+#pragma unroll
+                    for (uint32_t mo = 0; mo < MB; mo++) {
+                        const half8 af = transpose_load(TG, mo, s, n, h, W);
+#pragma unroll
+                        for (uint32_t ni = 0; ni < MB; ni++) dwh[k - 1][mo][ni] = mfma(af, bfr[ni], dwh[k - 1][mo][ni]);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const half8* wf = fbh + (size_t)((k - 1) * MB * KS) * 64;
+#pragma unroll
+                for (uint32_t m = 0; m < MB; m++) {
+                    acc[m] = zero16();
+#pragma unroll
+                    for (uint32_t s = 0; s < KS; s++) acc[m] = mfma(wf[(m * KS + s) * 64 + lane], G[s], acc[m]);
+                }
+            } else {
+                transpose_store<4>(TX, xf, KS0, n, h);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (uint32_t s = 0; s < 2; s++) {
+                    half8 bfr[IMB];
+#pragma unroll
+                    for (uint32_t ni = 0; ni < (uint32_t)IMB; ni++) bfr[ni] = transpose_load(TX, ni, s, n, h, in_dim);
+#pragma unroll
+                    for (uint32_t mo = 0; mo < MB; mo++) {
+                        const half8 af = transpose_load(TG, mo, s, n, h, W);
+#pragma unroll
+                        for (uint32_t ni = 0; ni < (uint32_t)IMB; ni++) dw0[mo][ni] = mfma(af, bfr[ni], dw0[mo][ni]);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (grad_inputs) {
+#pragma unroll
+            for (uint32_t m = 0; m < (uint32_t)IMB; m++) {
+                float16v gi = zero16();
+#pragma unroll
+                for (uint32_t s = 0; s < KS; s++) gi = mfma(fb0[(m * KS + s) * 64 + lane], G[s], gi);
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    const uint32_t feat = m * 32 + 8 * q + 4 * h;
+                    if (feat < in_dim) {
+                        half4 v;
+#pragma unroll
+                        for (uint32_t e = 0; e < 4; e++) v[e] = (_Float16)gi[4 * q + e];
+                        st4(grad_inputs + row * in_dim + feat, v);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- sum the four waves in a fixed order through LDS, one [64][64] fp32 partial per (matrix, workgroup)
+    float* red = reinterpret_cast<float*>(smem_raw);  // 4 planes x 16 KiB over the (no longer needed) fragments and tiles
+    flush_matrix<MB, IMB>(red, partial, 0, wave, n, h, [&](auto mo, auto ni) { return dw0[mo][ni]; });
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)NH; k++)
+        flush_matrix<MB, MB>(red, partial, 1 + k, wave, n, h, [&](auto mo, auto ni) { return dwh[k][mo][ni]; });
+    flush_matrix<1, MB>(red, partial, NH + 1, wave, n, h, [&](auto mo, auto ni) { (void)mo; return dwl[ni]; });
 }
 
 constexpr uint32_t kWgradBlocks = 256;
@@ -426,8 +730,11 @@ int launch_forward(const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t i
     const uint32_t ntiles = B / 32;
     uint32_t grid = div_up<uint32_t>(ntiles, 4);
     if (grid > 1024) grid = 1024;
-    if (fwd) hipLaunchKernelGGL((k_ffmlp_forward<W, true>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out);
-    else hipLaunchKernelGGL((k_ffmlp_forward<W, false>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out);
+#define S3D_FWD(TRAIN, A, O) hipLaunchKernelGGL((k_ffmlp_forward<W, TRAIN, A, O>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out)
+    const bool fast = act == ACT_RELU && out_act == ACT_NONE;  // the networks of the hot path; anything else: run-time switch
+    if (fwd) { if (fast) S3D_FWD(true, ACT_RELU, ACT_NONE); else S3D_FWD(true, -1, -1); }
+    else { if (fast) S3D_FWD(false, ACT_RELU, ACT_NONE); else S3D_FWD(false, -1, -1); }
+#undef S3D_FWD
     return check_launch("ffmlp_forward");
 }
 
@@ -442,8 +749,12 @@ int launch_backward(const _Float16* grad, const _Float16* X, const _Float16* Wt,
     const uint32_t ntiles = B / 32;
     uint32_t grid = div_up<uint32_t>(ntiles, 4);
     if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL((k_ffmlp_dgrad<W>), dim3(grid), dim3(256), smem, st, grad, Wt, fwd, B, in_dim, out_dim, n_layers,
-                       act, bwd, grad_inputs);
+    if (act == ACT_RELU)
+        hipLaunchKernelGGL((k_ffmlp_dgrad<W, ACT_RELU>), dim3(grid), dim3(256), smem, st, grad, Wt, fwd, B, in_dim, out_dim, n_layers,
+                           act, bwd, grad_inputs);
+    else
+        hipLaunchKernelGGL((k_ffmlp_dgrad<W, -1>), dim3(grid), dim3(256), smem, st, grad, Wt, fwd, B, in_dim, out_dim, n_layers,
+                           act, bwd, grad_inputs);
 
     // weight gradients, all layers in one launch
     WgradPlan plan;
@@ -461,9 +772,71 @@ int launch_backward(const _Float16* grad, const _Float16* X, const _Float16* Wt,
     uint32_t nblk = div_up<uint32_t>(ntiles, 4);
     if (nblk > kWgradBlocks) nblk = kWgradBlocks;
     hipLaunchKernelGGL((k_ffmlp_wgrad<W>), dim3(nblk, plan.n), dim3(256), 0, st, plan, B, partial);
-    hipLaunchKernelGGL(k_ffmlp_wgrad_reduce, dim3(div_up<uint32_t>(W * W, 256), plan.n), dim3(256), 0, st, plan, nblk,
+    hipLaunchKernelGGL(k_ffmlp_wgrad_reduce, dim3(div_up<uint32_t>(W * W * kReduceSplit, 256), plan.n), dim3(256), 0, st, plan, nblk,
                        (const float*)partial, grad_weights);
     return check_launch("ffmlp_backward");
+}
+
+// hidden [W x W] matrices the fused kernel keeps weight-gradient accumulators for (512 VGPRs per lane: W = 64 with three
+// of them spills ~130 registers; two spill ~20, accepted)
+inline uint32_t fused_max_hidden(uint32_t W) { return W == 64 ? 2u : 3u; }
+
+inline bool fused_backward_supported(uint32_t in_dim, uint32_t out_dim, uint32_t W, uint32_t n_layers, uint32_t act) {
+    return (W == 32 || W == 64) && in_dim % 16 == 0 && in_dim >= 16 && in_dim <= 64 && out_dim >= 1 && out_dim <= 16 &&
+           n_layers >= 2 && n_layers - 1 <= fused_max_hidden(W) && act != ACT_SINE;
+}
+
+template <int W, int NH, int IMB, int ACT>
+int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t in_dim,
+                            uint32_t out_dim, uint32_t act, _Float16* grad_inputs, _Float16* grad_weights, float* partial,
+                            hipStream_t st) {
+    constexpr uint32_t MB = W / 32, KS = W / 16;
+    const uint32_t nfrag = MB * (in_dim / 16) + NH * MB * KS + MB + NH * MB * KS + (grad_inputs ? IMB * KS : 0);
+    size_t smem = (size_t)nfrag * 64 * sizeof(half8) + (size_t)4 * 2 * kTRows * kTRow * sizeof(_Float16);
+    if (smem < 4 * kWgradPad * kWgradPad * sizeof(float)) smem = 4 * kWgradPad * kWgradPad * sizeof(float);  // epilogue planes
+    static bool attr_set = false;
+    if (!attr_set) {
+        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_backward_fused<W, NH, IMB, ACT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const uint32_t ntiles = B / 32;
+    uint32_t nblk = div_up<uint32_t>(ntiles, 4);
+    if (nblk > kWgradBlocks) nblk = kWgradBlocks;
+    hipLaunchKernelGGL((k_ffmlp_backward_fused<W, NH, IMB, ACT>), dim3(nblk), dim3(256), smem, st, grad, X, Wt, B, in_dim, out_dim,
+                       act, grad_inputs, partial);
+    WgradPlan plan;
+    memset(&plan, 0, sizeof(plan));
+    plan.n = NH + 2;
+    plan.layer[0] = WgradLayer{nullptr, nullptr, 0u, 0u, (uint32_t)W, in_dim, 0u};
+    for (uint32_t m = 0; m < (uint32_t)NH; m++)
+        plan.layer[1 + m] = WgradLayer{nullptr, nullptr, 0u, 0u, (uint32_t)W, (uint32_t)W, (uint32_t)(W * in_dim + m * W * W)};
+    plan.layer[NH + 1] = WgradLayer{nullptr, nullptr, 0u, 0u, 16u, (uint32_t)W, (uint32_t)(W * in_dim + NH * W * W)};
+    hipLaunchKernelGGL(k_ffmlp_wgrad_reduce, dim3(div_up<uint32_t>(W * W * kReduceSplit, 256), plan.n), dim3(256), 0, st, plan, nblk,
+                       (const float*)partial, grad_weights);
+    return check_launch("ffmlp_backward (fused)");
+}
+
+template <int W>
+int launch_backward_fused(const _Float16* grad, const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t in_dim,
+                          uint32_t out_dim, uint32_t n_layers, uint32_t act, _Float16* gi, _Float16* gw, float* partial,
+                          hipStream_t st) {
+    const uint32_t NH = n_layers - 1, IMB = (in_dim + 31) / 32;
+#define S3D_FUSED(NHV, IMBV)                                                                                              \
+    (act == ACT_RELU ? launch_backward_fused_k<W, NHV, IMBV, ACT_RELU>(grad, X, Wt, B, in_dim, out_dim, act, gi, gw, partial, st) \
+                     : launch_backward_fused_k<W, NHV, IMBV, -1>(grad, X, Wt, B, in_dim, out_dim, act, gi, gw, partial, st))
+    if (IMB == 1) {
+        if (NH == 1) return S3D_FUSED(1, 1);
+        if (NH == 2) return S3D_FUSED(2, 1);
+        if constexpr (W == 32) return S3D_FUSED(3, 1);
+    } else {
+        if (NH == 1) return S3D_FUSED(1, 2);
+        if (NH == 2) return S3D_FUSED(2, 2);
+        if constexpr (W == 32) return S3D_FUSED(3, 2);
+    }
+    set_error("ffmlp_backward: fused kernel does not cover %u hidden matrices at width %d", NH, W);
+    return S3D_ERR_UNSUPPORTED;
+#undef S3D_FUSED
 }
 
 }  // namespace
@@ -508,8 +881,9 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
                                   s3d_stream_t stream) {
     (void)output_activation;
     if (B == 0) return S3D_OK;
-    S3D_REQUIRE(grad && inputs && weights && forward_buffer && backward_buffer && grad_weights,
-                "ffmlp_backward: null pointer");
+    S3D_REQUIRE(grad && inputs && weights && grad_weights, "ffmlp_backward: null pointer");
+    S3D_REQUIRE((forward_buffer == nullptr) == (backward_buffer == nullptr),
+                "ffmlp_backward: pass both forward_buffer and backward_buffer, or neither (fused re-computing backward)");
     if (int rc = check_shape(B, input_dim, output_dim, hidden_dim, num_layers)) return rc;
     S3D_REQUIRE(output_dim == 16, "ffmlp_backward: the output must be padded to 16 columns (ffmlp.py:117)");
     S3D_REQUIRE(activation != ACT_SINE, "ffmlp_backward: sine needs pre-activations, unsupported (utils.h:546-550)");
@@ -517,6 +891,17 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
     S3D_REQUIRE(workspace && workspace_bytes >= s3d_ffmlp_backward_workspace_size(input_dim, output_dim, hidden_dim, num_layers),
                 "ffmlp_backward: workspace too small");
     _Float16* gi = calc_grad_inputs ? (_Float16*)grad_inputs : nullptr;
+    if (!forward_buffer) {
+        S3D_REQUIRE(fused_backward_supported(input_dim, 16, hidden_dim, num_layers, activation),
+                    "ffmlp_backward: this network shape needs forward_buffer/backward_buffer (s3d_ffmlp_fused_backward_supported)");
+        if (hidden_dim == 64)
+            return launch_backward_fused<64>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights, B, input_dim,
+                                             output_dim, num_layers, activation, gi, (_Float16*)grad_weights, (float*)workspace,
+                                             as_stream(stream));
+        return launch_backward_fused<32>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights, B, input_dim,
+                                         output_dim, num_layers, activation, gi, (_Float16*)grad_weights, (float*)workspace,
+                                         as_stream(stream));
+    }
     if (hidden_dim == 64)
         return launch_backward<64>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights,
                                    (const _Float16*)forward_buffer, B, input_dim, output_dim, num_layers, activation,
@@ -524,6 +909,11 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
     return launch_backward<32>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights,
                                (const _Float16*)forward_buffer, B, input_dim, output_dim, num_layers, activation,
                                (_Float16*)backward_buffer, gi, (_Float16*)grad_weights, (float*)workspace, as_stream(stream));
+}
+
+S3D_EXPORT int s3d_ffmlp_fused_backward_supported(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
+                                                  uint32_t num_layers, uint32_t activation) {
+    return fused_backward_supported(input_dim, output_dim, hidden_dim, num_layers, activation) ? 1 : 0;
 }
 
 S3D_EXPORT int s3d_ffmlp_allocate_splitk(size_t n) { (void)n; return S3D_OK; }

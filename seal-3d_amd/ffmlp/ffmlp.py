@@ -9,6 +9,7 @@ library (MFMA fragment order), exactly as they are private scratch in the
 reference.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -18,6 +19,8 @@ from torch.amp import custom_bwd, custom_fwd
 import s3d_hip
 
 _backend = s3d_hip.FFMLPBackend
+
+_FUSED_BACKWARD = os.environ.get("S3D_FFMLP_FUSED", "1") != "0"  # A/B switch: 0 = store activations, two-kernel backward
 
 _ACTIVATIONS = {"relu": 0, "exponential": 1, "sine": 2, "sigmoid": 3, "squareplus": 4, "softplus": 5}
 
@@ -45,11 +48,19 @@ class _FFMLPForward(Function):
             _backend.ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
                                      output_activation, scratch, outputs)
             return outputs
-        forward_buffer = torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
+        # The reference stores every layer's activations for the backward pass (forward_buffer [n, B, W]).  Where the
+        # fused backward kernel covers the shape, nothing is stored: it re-computes the activations from `inputs` on chip
+        # (256-384 B per sample less HBM traffic in each direction).
+        fused = _FUSED_BACKWARD and getattr(_backend, "fused_backward_supported", None) is not None and \
+            _backend.fused_backward_supported(input_dim, output_dim, hidden_dim, num_layers, activation)
+        forward_buffer = None if fused else torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
         _backend.ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
                                output_activation, forward_buffer, outputs)
-        ctx.save_for_backward(inputs, weights, outputs, forward_buffer)
-        ctx.meta = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs)
+        if fused:
+            ctx.save_for_backward(inputs, weights)
+        else:
+            ctx.save_for_backward(inputs, weights, forward_buffer)
+        ctx.meta = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs, fused)
         return outputs
 
     @staticmethod
@@ -57,14 +68,17 @@ class _FFMLPForward(Function):
     def backward(ctx, grad):
         B = grad.shape[0]
         grad = grad.contiguous()
-        inputs, weights, outputs, forward_buffer = ctx.saved_tensors
-        input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs = ctx.meta
+        input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs, fused = ctx.meta
+        if fused:
+            (inputs, weights), forward_buffer = ctx.saved_tensors, None
+        else:
+            inputs, weights, forward_buffer = ctx.saved_tensors
         # the reference zero-fills these three (ffmlp.py:67-73); the HIP kernels overwrite every element, so the
         # build allocates them uninitialised (saves two B x hidden x num_layers memsets per MLP per step)
         grad_inputs = (torch.empty_like(inputs) if calc_grad_inputs
                        else torch.zeros(1, device=grad.device, dtype=grad.dtype))
         grad_weights = torch.zeros_like(weights)
-        backward_buffer = torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
+        backward_buffer = None if fused else torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
         _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim,
                                 num_layers, activation, output_activation, calc_grad_inputs, backward_buffer,
                                 grad_inputs, grad_weights)

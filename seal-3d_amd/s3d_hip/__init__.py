@@ -36,6 +36,7 @@ EXPORTS = [
     "s3d_grad_total_variation",
     "s3d_sh_encode_forward", "s3d_sh_encode_backward", "s3d_freq_encode_forward", "s3d_freq_encode_backward",
     "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
+    "s3d_ffmlp_fused_backward_supported",
     "s3d_ffmlp_allocate_splitk", "s3d_ffmlp_free_splitk",
 ]
 
@@ -357,6 +358,12 @@ class FFMLPBackend:
         _check(lib().s3d_ffmlp_inference(_p(inputs), _p(weights), _u(B), _u(input_dim), _u(output_dim),
                                          _u(hidden_dim), _u(num_layers), _u(activation), _u(output_activation),
                                          _p(inference_buffer), _p(outputs), _stream()), "ffmlp_inference")
+
+    @staticmethod
+    def fused_backward_supported(input_dim, output_dim, hidden_dim, num_layers, activation):
+        """True when ffmlp_backward can run without forward_buffer / backward_buffer (re-computing fused kernel)"""
+        return bool(lib().s3d_ffmlp_fused_backward_supported(_u(input_dim), _u(output_dim), _u(hidden_dim),
+                                                             _u(num_layers), _u(activation)))
 
     @staticmethod
     def ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers,

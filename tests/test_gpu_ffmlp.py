@@ -34,8 +34,10 @@ def _split(w, in_dim, W, n):
 
 
 @pytest.mark.parametrize("in_dim,W,n,out,act", NETS)
-@pytest.mark.parametrize("B", [128, 128 * 37])
+@pytest.mark.parametrize("B", [128, 128 * 37, 128 * 2100])  # the last: training size, several tiles per wave / workgroup
 def test_ffmlp_forward_backward(oracle, hip, in_dim, W, n, out, act, B):
+    if B > 128 * 37 and (in_dim, W, n) not in ((32, 64, 2), (32, 64, 3)):
+        pytest.skip("training-size batch only for the two networks of nerf/network_ff.py")
     g = torch.Generator().manual_seed(B + in_dim)
     w = _weights(in_dim, W, n)
     mats = _split(w, in_dim, W, n)
@@ -82,6 +84,27 @@ def test_ffmlp_forward_backward(oracle, hip, in_dim, W, n, out, act, B):
     scale = gw32.abs().max().clamp(min=1e-3)
     err = (gw_g.cpu().float() - gw32).abs().max() / scale
     assert err < 2e-2, f"weight-gradient relative error {err}"
+
+    # ---- fused backward (no forward_buffer / backward_buffer: activations re-computed in the kernel).  Same MFMA
+    # operations on the same values for the data gradient => bit-identical grad_inputs; the weight gradient sums the
+    # same products in a different (fixed) order => fp32 rounding only, and run-to-run reproducible.
+    if hip.FFMLPBackend.fused_backward_supported(in_dim, 16, W, n, act):
+        runs = []
+        for _ in range(2):
+            gi_f = torch.zeros(B, in_dim, dtype=torch.half, device="cuda")
+            gw_f = torch.zeros_like(wg)
+            hip.FFMLPBackend.ffmlp_backward(grad.cuda(), xg, wg, None, B, in_dim, 16, W, n, act, 6, True, None, gi_f, gw_f)
+            runs.append((gi_f.cpu(), gw_f.cpu()))
+        assert torch.equal(runs[0][0].view(torch.int16), gi_g.cpu().view(torch.int16)), "fused dgrad differs from the two-kernel path"
+        assert torch.equal(runs[0][1].view(torch.int16), runs[1][1].view(torch.int16)), "fused wgrad must be reproducible"
+        errf = (runs[0][1].float() - gw32).abs().max() / scale
+        assert errf < 2e-2, f"fused weight-gradient relative error {errf}"
+        assert (runs[0][1].float() - gw_g.cpu().float()).abs().max() / scale < 4e-3
+        gw_n = torch.zeros_like(wg)  # weights only (no grad_inputs): the first-layer transposed fragments are skipped
+        hip.FFMLPBackend.ffmlp_backward(grad.cuda(), xg, wg, None, B, in_dim, 16, W, n, act, 6, False, None, None, gw_n)
+        assert torch.equal(gw_n.cpu().view(torch.int16), runs[0][1].view(torch.int16))
+    else:
+        assert W == 64 and n - 1 > 2 or act == 2
 
 
 def test_ffmlp_rejects_bad_shapes(hip):

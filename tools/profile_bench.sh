@@ -4,6 +4,7 @@
 #   2. --pmc FETCH_SIZE                  -> HBM-side read KiB per dispatch   (own pass: TCC slots)
 #   3. --pmc WRITE_SIZE                  -> HBM-side write KiB per dispatch  (own pass)
 #   4. --pmc SQ_* (issue / wait mix)     -> where the dominant kernel's cycles go
+# `profile_bench.sh <tag> trace` runs pass 1 only.
 # PMC passes use --kernel-trace only (never sys/hip/hsa trace domains together with --pmc).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -12,10 +13,12 @@ ARGS="--steps 32 --warmup 8 --no_cpu_baseline --no_render"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python "$ROOT/bench.py" $ARGS > "$OUT/trace.log" 2>&1
+if [ "${2:-full}" != "trace" ]; then
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python "$ROOT/bench.py" $ARGS > "$OUT/fetch.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python "$ROOT/bench.py" $ARGS > "$OUT/write.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD --output-format csv -d "$OUT/sq" -- python "$ROOT/bench.py" $ARGS > "$OUT/sq.log" 2>&1
-for f in trace fetch write sq; do tail -1 "$OUT/$f.log" | cut -c1-400; done
+fi
+for f in trace fetch write sq; do [ -f "$OUT/$f.log" ] && tail -1 "$OUT/$f.log" | cut -c1-400; done
 # summarise on the box; only the summaries travel back (raw counter CSVs are hundreds of MB)
 cd "$ROOT" && python tools/summarize_prof.py "${1:-r01}" > "$OUT/summary.log" 2>&1; tail -40 "$OUT/summary.log"
 mkdir -p "$ROOT/gpurun_out/profiles_out" && cp "$ROOT"/profiles/${1:-r01}_* "$ROOT/gpurun_out/profiles_out/" 2>/dev/null

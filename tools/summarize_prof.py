@@ -13,7 +13,7 @@ os.makedirs("profiles", exist_ok=True)
 
 
 def short(n):
-    n = n.replace("void ", "").replace("s3d::(anonymous namespace)::", "").replace("at::native::", "")
+    n = n.replace("void ", "").replace("s3d::(anonymous namespace)::", "").replace("at::native::", "").replace("(anonymous namespace)::", "")
     return n.split("(")[0][:80]
 
 
