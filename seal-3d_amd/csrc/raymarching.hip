@@ -275,46 +275,118 @@ __global__ void __launch_bounds__(64) k_march_write(const float* __restrict__ ra
 // a single bit of the result: the sequence of ray parameters t_{k+1} = t_k + clamp(t_k*dt_gamma, dt_min, dt_max)
 // does NOT depend on occupancy (the reference advances t by the same increment whether it samples or skips,
 // raymarching.cu:386,397); occupancy only decides which t_k are PROBED.  So per ray (one wave):
-//   A. one lane generates the t sequence of a 1,024-entry window into LDS (sequential fp32 adds, exact);
+//   A. one lane generates the t sequence of a 1,024-entry window into LDS (sequential fp32 adds, exact; eight per
+//      loop trip, and with dt_gamma == 0 the increment is the constant dt_min — one dependent add per step);
 //   B. all 64 lanes probe the occupancy of every t_k in parallel and, for empty probes, find the index the
-//      reference's skip loop would land on (first t_m >= t_skip, m > k);
-//   C. one lane walks the resulting linked list from the window start: occupied probe -> emit sample, go to k+1;
-//      empty probe -> jump.  This is the reference's state machine with all arithmetic already done.
+//      reference's skip loop would land on (first t_m >= t_skip, m > k): next[k] = k+1 (occupied) or m (empty);
+//   C. the reference's walk "occupied -> emit, go to k+1; empty -> jump" visits exactly the nodes of the list
+//      start -> next[start] -> ...; they are marked by pointer doubling (round i marks next^(2^i) of every marked node,
+//      then squares the jump table: ceil(log2(window)) rounds of 64-wide LDS gathers instead of a ~200-step dependent
+//      chain on one lane), and the occupied marked nodes are emitted in order with a ballot prefix.
 // Emitted t values go to a scratch row; after the ray-ordered prefix sum a second kernel expands them into
 // xyz / dirs / deltas with one lane per sample (coalesced).  ~5x more probes than the serial walk, but 64-wide.
 constexpr uint32_t kWin = 1024;
 constexpr uint16_t kOcc = 0xFFFF;
 // workspace (wave path): u32 base | u32 pad[3] | u32 counts[N] | float tsamples[N * max_steps]
 
+template <bool CONST_DT>
 __global__ void __launch_bounds__(64) k_march_count_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                          const uint8_t* __restrict__ grid, float bound, float dt_gamma,
                                                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                                          const float* __restrict__ nears, const float* __restrict__ fars,
                                                          const float* __restrict__ noises, int32_t* __restrict__ rays,
                                                          const int32_t* __restrict__ counter, uint32_t* __restrict__ ws) {
-    __shared__ float T[kWin + 1];
-    __shared__ uint16_t nxt[kWin];
+    __shared__ float T[kWin + 8];
+    __shared__ uint16_t nxt[kWin];          // kOcc = occupied, else the skip target index
+    __shared__ uint16_t J[2][kWin + 2];     // jump tables of the pointer-doubling rounds
+    __shared__ uint32_t mk[64];             // visited bits: entry k = lane + 64 i is bit i of mk[lane] (kWin / 64 + 1 <= 32 bits)
     __shared__ uint32_t s_wn;
     const uint32_t n = blockIdx.x, lane = threadIdx.x;
     const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
     const Ray r = load_ray(rays_o, rays_d, n);
     const float far = fars[n];
+    const float dt0 = clampf(0.0f, p.dt_min, p.dt_max);  // the step when dt_gamma == 0 (dt_max if max_steps is tiny)
+    auto dtf = [&](float t) { return CONST_DT ? dt0 : clampf(t * dt_gamma, p.dt_min, p.dt_max); };
     float t_carry = nears[n];
     t_carry = __builtin_fmaf(clampf(t_carry * dt_gamma, p.dt_min, p.dt_max), noises[n], t_carry);
     float* tout = reinterpret_cast<float*>(ws + kWsHeader + N) + (size_t)n * max_steps;
 
-    uint32_t num_steps = 0;
-    float pending_tt = -INFINITY;
+    uint32_t num_steps = 0;       // wave-uniform
+    float pending_tt = -INFINITY;  // wave-uniform: skip target carried over from the previous window
+#ifdef S3D_MARCH_PROFILE
+    long long tp[5] = {0, 0, 0, 0, 0};
+    long long c0 = wall_clock64();
+#define S3D_TICK(i) { const long long c1 = wall_clock64(); tp[i] += c1 - c0; c0 = c1; }
+#else
+#define S3D_TICK(i)
+#endif
     for (;;) {
         // ---- A: t sequence of this window (T[wn] is the first value past the window or past `far`)
-        if (lane == 0) {
+        if constexpr (CONST_DT) {
+            // t_{k+1} = fl(t_k + dt0) with a CONSTANT dt0.  Inside one binade every t_k is a multiple of the binade's ulp,
+            // so from the second step on the rounded increment is the same number of ulps every time (the only
+            // position-dependent case, a tie, resolves to "even" and then stays even): t_k advances by a constant integer
+            // step in its IEEE bit pattern.  Two real fp32 adds establish that step; the rest of the binade is filled
+            // 64-wide from the bit pattern — the same values the sequential loop produces, without its ~30 ns per step.
+            // All lanes run the (uniform) control flow; binade crossings and anything unusual take single real steps.
             float t = t_carry;
             uint32_t k = 0;
-            while (k < kWin && t < far) { T[k] = t; t += clampf(t * dt_gamma, p.dt_min, p.dt_max); k++; }
+            const uint32_t bfar = __float_as_uint(far);
+            while (k < kWin && t < far) {
+                const float t1 = t + dt0, t2 = t1 + dt0;
+                const uint32_t b0 = __float_as_uint(t), b1 = __float_as_uint(t1), b2 = __float_as_uint(t2);
+                const uint32_t inc = b2 - b1;
+                if (!(t > 0.0f) || (b0 >> 23) != (b2 >> 23) || (b0 >> 23) == 0 || inc == 0 || !(far > 0.0f) || bfar >= 0x7f800000u) {
+                    if (lane == 0) T[k] = t;  // one real step
+                    k++;
+                    t = t1;
+                    continue;
+                }
+                const uint32_t hi = ((b1 >> 23) + 1) << 23;             // first pattern of the next binade
+                const uint32_t cnt = (hi - b1) / inc + 1;                // v_j = pattern b1 + j*inc, j < cnt, all <= hi
+                const uint32_t nfill = min(cnt, kWin - k);               // positions k+1 .. k+nfill (<= kWin)
+                const uint32_t n_lt = bfar <= b1 ? 0u : min(cnt, (bfar - b1 + inc - 1) / inc);  // how many v_j < far
+                if (lane == 0) T[k] = t;
+                for (uint32_t j = lane; j < nfill; j += 64) T[k + 1 + j] = __uint_as_float(b1 + j * inc);
+                if (n_lt < nfill) {  // the ray ends inside this run: T[wn] = v_{n_lt} >= far is already in place
+                    k = k + 1 + n_lt;
+                    t = __uint_as_float(b1 + n_lt * inc);
+                    break;
+                }
+                // all filled values are below far: the last one starts the next run (or is the carry of a full window)
+                k += nfill;
+                t = __uint_as_float(b1 + (nfill - 1) * inc);
+            }
+            if (lane == 0) { T[k] = t; s_wn = k; }
+        } else if (lane == 0) {
+            float t = t_carry;
+            uint32_t k = 0;
+            while (k < kWin && t < far) {
+                float v[8];
+                v[0] = t;
+#pragma unroll
+                for (uint32_t i = 1; i < 8; i++) v[i] = v[i - 1] + dtf(v[i - 1]);
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) T[k + i] = v[i];
+                uint32_t c = 1;  // v is increasing: the entries below `far` are a prefix
+#pragma unroll
+                for (uint32_t i = 1; i < 8; i++) c += (v[i] < far) ? 1u : 0u;
+                if (c < 8) {
+                    float tn = v[1];
+#pragma unroll
+                    for (uint32_t i = 2; i < 8; i++) tn = (c == i) ? v[i] : tn;
+                    k += c;
+                    t = tn;
+                    break;
+                }
+                k += 8;
+                t = v[7] + dtf(v[7]);
+            }
             T[k] = t;
             s_wn = k;
         }
         __syncthreads();
+        S3D_TICK(0)
         const uint32_t wn = s_wn;
         // ---- B: probe every t_k
         for (uint32_t k = lane; k < wn; k += 64) {
@@ -326,34 +398,83 @@ __global__ void __launch_bounds__(64) k_march_count_wave(const float* __restrict
                 e = (uint16_t)m;  // == wn: leaves the window (carry) or the ray (T[wn] >= far)
             }
             nxt[k] = e;
+            J[0][k] = (e == kOcc) ? (uint16_t)(k + 1) : e;
         }
+        S3D_TICK(1)
+        if (lane == 0) J[0][wn] = (uint16_t)wn;
+        mk[lane] = 0;
+        // start of the walk: the first t_k at or past the skip target carried over from the previous window
+        uint32_t start = wn;
+        for (uint32_t k = lane; k < wn; k += 64)
+            if (!(T[k] < pending_tt)) { start = k; break; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) start = min(start, (uint32_t)__shfl_xor((int)start, d, 64));
+        pending_tt = -INFINITY;
         __syncthreads();
-        // ---- C: walk
-        bool more = false;
-        if (lane == 0) {
-            uint32_t k = 0;
-            while (k < wn && T[k] < pending_tt) k++;  // skip carried over from the previous window
-            pending_tt = -INFINITY;
-            while (k < wn && num_steps < max_steps) {
-                const uint16_t e = nxt[k];
-                if (e == kOcc) { tout[num_steps++] = T[k]; k++; }
-                else {
-                    if (e == wn && wn == kWin) {  // the skip target lies beyond this window: recompute it for the carry
-                        float x, y, z, dt, tt;
-                        (void)probe(r, p, T[k], x, y, z, dt, tt);
-                        pending_tt = tt;
-                    }
-                    k = e;
+        if (lane == 0 && start < wn) mk[start & 63] = 1u << (start >> 6);
+        __syncthreads();
+        // ---- C: mark the visited nodes by pointer doubling
+        uint32_t cur = 0;
+        constexpr uint32_t kPer = kWin / 64 + 1;    // entries per lane (k = lane + 64 i)
+        const uint32_t iters = wn / 64 + 1;          // ... of which this window uses the first `iters` (covers k <= wn)
+        for (uint32_t span = 1; span < wn; span <<= 1) {
+            const uint16_t* Jc = J[cur];
+            uint16_t* Jn = J[cur ^ 1];
+            uint32_t j1[kPer], j2[kPer];
+            const uint32_t mw = mk[lane];
+#pragma unroll
+            for (uint32_t i = 0; i < kPer; i++)
+                if (i < iters) { const uint32_t k = lane + 64 * i; j1[i] = k <= wn ? Jc[k] : wn; }
+#pragma unroll
+            for (uint32_t i = 0; i < kPer; i++)
+                if (i < iters) j2[i] = Jc[j1[i]];
+#pragma unroll
+            for (uint32_t i = 0; i < kPer; i++)
+                if (i < iters) {
+                    const uint32_t k = lane + 64 * i;
+                    if (((mw >> i) & 1u) && j1[i] < wn) atomicOr(&mk[j1[i] & 63], 1u << (j1[i] >> 6));
+                    if (k <= wn) Jn[k] = (uint16_t)j2[i];
                 }
-            }
-            more = (wn == kWin) && (num_steps < max_steps);
-            s_wn = more ? 1u : 0u;
+            cur ^= 1;
+            __syncthreads();
+            // the doubled jump from the start already leaves the window: every node of the walk is marked
+            if (start >= wn || J[cur][start] >= wn) break;
+        }
+        S3D_TICK(2)
+        // ---- emit the occupied visited samples in order; remember the last visited empty probe
+        uint32_t last_empty = kWin;  // per lane, then wave max
+        bool any_empty = false;
+        for (uint32_t k0 = 0; k0 < wn && num_steps < max_steps; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const bool vis = k < wn && ((mk[lane] >> (k0 >> 6)) & 1u);
+            const bool emit = vis && nxt[k] == kOcc;
+            if (vis && !emit) { last_empty = k; any_empty = true; }
+            const unsigned long long m = __ballot(emit);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (emit && num_steps + rank < max_steps) tout[num_steps + rank] = T[k];
+            num_steps = min(max_steps, num_steps + (uint32_t)__popcll(m));
+        }
+        // a visited empty probe whose skip target lies beyond a FULL window: recompute the target for the carry
+        uint32_t le = any_empty ? last_empty : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) le = max(le, (uint32_t)__shfl_xor((int)le, d, 64));
+        const bool had_empty = __ballot(any_empty) != 0;
+        const bool more = (wn == kWin) && (num_steps < max_steps);
+        if (more && had_empty && nxt[le] == (uint16_t)wn) {
+            float x, y, z, dt, tt;
+            (void)probe(r, p, T[le], x, y, z, dt, tt);
+            pending_tt = tt;
         }
         t_carry = T[kWin];  // only meaningful when the window was full
         __syncthreads();
-        if (s_wn == 0) break;
-        __syncthreads();
+        S3D_TICK(3)
+        if (!more) break;
     }
+#ifdef S3D_MARCH_PROFILE
+    if (lane == 0 && max_steps >= 256) {  // phase times (100 MHz ticks) in the unused tail of the scratch row
+        for (int i = 0; i < 4; i++) tout[max_steps - 8 + i] = (float)tp[i];
+    }
+#endif
     if (lane == 0) {
         rays[n * 3] = (int32_t)n;
         rays[n * 3 + 2] = (int32_t)num_steps;
@@ -754,8 +875,12 @@ S3D_EXPORT int s3d_march_rays_train(const float* rays_o, const float* rays_d, co
     const bool wave_ok = workspace_bytes >= march_wave_ws(N, max_steps) && max_steps >= 1;
     const bool use_wave = (g_march_path == 2 && wave_ok) || (g_march_path == 0 && wave_ok && N <= kWaveMarchMaxRays);
     if (use_wave) {
-        hipLaunchKernelGGL(k_march_count_wave, dim3(N), dim3(64), 0, as_stream(stream), rays_o, rays_d, grid, bound, dt_gamma,
-                           max_steps, N, C, H, nears, fars, noises, rays, (const int32_t*)counter, ws);
+        if (dt_gamma == 0.0f)
+            hipLaunchKernelGGL(k_march_count_wave<true>, dim3(N), dim3(64), 0, as_stream(stream), rays_o, rays_d, grid, bound,
+                               dt_gamma, max_steps, N, C, H, nears, fars, noises, rays, (const int32_t*)counter, ws);
+        else
+            hipLaunchKernelGGL(k_march_count_wave<false>, dim3(N), dim3(64), 0, as_stream(stream), rays_o, rays_d, grid, bound,
+                               dt_gamma, max_steps, N, C, H, nears, fars, noises, rays, (const int32_t*)counter, ws);
         hipLaunchKernelGGL(k_march_write_wave, dim3(N), dim3(64), 0, as_stream(stream), rays_o, rays_d, bound, dt_gamma,
                            max_steps, N, C, H, M, nears, noises, xyzs, dirs, deltas, rays, counter, (const uint32_t*)ws);
         return check_launch("march_rays_train");

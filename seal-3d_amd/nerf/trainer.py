@@ -44,7 +44,9 @@ class Trainer:
 
     def _eager_step(self, rays_o, rays_d, gt_rgb, bg_color=1):
         model = self.model
-        self.optimizer.zero_grad(set_to_none=False)
+        # without data parallelism the gradients are simply replaced each step (no 49 MB zero fill + 147 MB accumulate);
+        # with it they live in the flat all-reduce bucket and are cleared in place
+        self.optimizer.zero_grad(set_to_none=self.dist is None)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             out = model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False, **self.render_kwargs)
             loss = F.mse_loss(out["image"], gt_rgb)
@@ -95,7 +97,9 @@ class GraphedTrainer(Trainer):
     def _body_fb(self):
         """zero grads -> render -> loss -> scaled backward"""
         model = self.model
-        self.optimizer.zero_grad(set_to_none=False)
+        # without data parallelism the gradients are simply replaced each step (no 49 MB zero fill + 147 MB accumulate);
+        # with it they live in the flat all-reduce bucket and are cleared in place
+        self.optimizer.zero_grad(set_to_none=self.dist is None)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             out = model.render(self.s_ro, self.s_rd, bg_color=1, perturb=True, force_all_rays=False, **self.render_kwargs)
             loss = F.mse_loss(out["image"], self.s_gt)
