@@ -269,8 +269,9 @@ def main():
     if graphed:
         # HIP events cannot be recorded inside a graph replay: time the individual kernels in an eager pass of the
         # SAME step on the same state, immediately after the timed region (not part of `value`)
-        eager = Trainer(model, lr=1e-2, fp16=True, update_extra_interval=10 ** 9, dist=None)
-        eager.optimizer, eager.scaler, eager.global_step = trainer.optimizer, trainer.scaler, 1
+        eager = Trainer(model, lr=1e-2, fp16=True, update_extra_interval=10 ** 9, dist=None, optimizer=trainer.optimizer,
+                        scaler=trainer.scaler)
+        eager.global_step = 1
         install_timers()
         timer_steps = 8
         for i in range(timer_steps):

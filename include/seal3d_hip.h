@@ -207,6 +207,21 @@ int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
 int s3d_ffmlp_allocate_splitk(size_t n);
 int s3d_ffmlp_free_splitk(void);
 
+/* ------------------------------------------------------------------ parameter update
+ * The reference's update is torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15) under torch.cuda.amp.GradScaler
+ * (nerf/utils.py:356-361, 495-537; main_SealNeRF.py:283-288).  These three calls are that update taken directly
+ * from the gradient the backward kernels produced (fp16 for the hash tables), see csrc/optim.hip.
+ * found_inf / grad_scale / step are single device floats (GradScaler's found_inf and scale, Adam's step count).
+ * s3d_grads_nonfinite sets *found_inf = 1 if any element is inf/NaN (never clears it).
+ * s3d_adam_step updates param / exp_avg / exp_avg_sq (fp32) with grad / *grad_scale as step number *step + 1, and
+ * does nothing when *found_inf != 0; param_half (optional) receives the fp16 copy of the updated parameters.
+ * s3d_adam_advance increments *step unless *found_inf != 0 (call once per optimizer step, after the tensors). */
+int s3d_grads_nonfinite(const void* grad, size_t n, int dtype, float* found_inf, s3d_stream_t stream);
+int s3d_adam_step(float* param, const void* grad, int grad_dtype, float* exp_avg, float* exp_avg_sq,
+                  uint16_t* param_half, size_t n, float lr, float beta1, float beta2, float eps,
+                  const float* step, const float* grad_scale, const float* found_inf, s3d_stream_t stream);
+int s3d_adam_advance(float* step, const float* found_inf, s3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,8 +61,13 @@ class _GridEncode(Function):
         S = float(np.log2(per_level_scale))
         H = base_resolution
 
+        param = embeddings
         if torch.is_autocast_enabled("cuda") and C % 2 == 0:
-            embeddings = _half_table(embeddings, cache_half)
+            half = getattr(param, "_s3d_half", None)  # fp16 copy maintained by nerf.optim.NativeAdam
+            if half is not None and param._s3d_half_version == param._version:
+                embeddings = half
+            else:
+                embeddings = _half_table(embeddings, cache_half)
         embeddings = embeddings.contiguous()
 
         outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)  # level-major
@@ -74,6 +79,7 @@ class _GridEncode(Function):
 
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.meta = (B, D, C, L, S, H, gridtype, interpolation, align_corners)
+        ctx.param = param
         return outputs
 
     @staticmethod
@@ -82,13 +88,21 @@ class _GridEncode(Function):
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
         B, D, C, L, S, H, gridtype, interpolation, align_corners = ctx.meta
         grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()  # [L, B, C]
-        grad_embeddings = torch.zeros_like(embeddings)
+        # fp16 hand-over (nerf.optim.NativeAdam): the table gradient is ACCUMULATED into the optimizer's fp16 buffer and
+        # not returned to autograd, which would cast it to fp32 and add it into `.grad` (220 MB of traffic per step)
+        stash = getattr(ctx.param, "_s3d_grad", None)
+        if stash is not None and stash.dtype == embeddings.dtype and stash.shape == embeddings.shape:
+            grad_embeddings = stash
+            ctx.param._s3d_grad_touched = True
+        else:
+            stash = None
+            grad_embeddings = torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
         _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
                                       grad_inputs, gridtype, align_corners, interpolation)
         if grad_inputs is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
-        return grad_inputs, grad_embeddings, None, None, None, None, None, None, None, None
+        return grad_inputs, (None if stash is not None else grad_embeddings), None, None, None, None, None, None, None, None
 
 
 grid_encode = _GridEncode.apply
@@ -130,6 +144,7 @@ class GridEncoder(nn.Module):
         total = int(offsets[-1])
         self.n_params = self.offsets[-1] * level_dim
         self.embeddings = nn.Parameter(torch.empty(total, level_dim))
+        self.embeddings._s3d_stash_ok = True  # a native optimizer may take this table's gradient as the fp16 buffer
         self.reset_parameters()
 
     def reset_parameters(self):

@@ -1,0 +1,111 @@
+"""Parameter update of the training step, taken straight from the gradients the HIP backward kernels produce.
+
+The reference's step is `torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15)` under `torch.cuda.amp.GradScaler`
+(nerf/utils.py:356-361, 495-537; main_SealNeRF.py:283-288).  `NativeAdam` / `NativeGradScaler` are the same update
+rule and the same loss-scale schedule, re-plumbed for a 12.2 M-row hash table whose gradient is fp16:
+
+* a `GridEncoder` whose parameter has been adopted by `NativeAdam` hands its table gradient over as the fp16 buffer
+  the backward kernel wrote (`param._s3d_grad`), instead of returning it to autograd (which would cast it to fp32,
+  73 MB, and accumulate it into `.grad`, 147 MB);
+* `NativeGradScaler.step` = one read of every gradient for the non-finite check, then `s3d_adam_step` per tensor —
+  unscale, Adam and the fp16 copy of the updated table for the next autocast forward (`param._s3d_half`) in one pass;
+  all of it skipped when a gradient is non-finite, exactly like `GradScaler.step`;
+* everything stays on the device (step count, scale, found_inf), so the step is HIP-graph capturable.
+
+Both classes exist only for GPU training with libseal3d_hip; the torch optimizer + GradScaler path of the trainers is
+unchanged and remains the reference behaviour (CPU tests, A/B runs).
+"""
+import torch
+
+import s3d_hip
+
+_backend = s3d_hip.OptimBackend
+
+
+class NativeAdam(torch.optim.Optimizer):
+    """Adam (no amsgrad, no weight decay) with device-side step count.  `adopt_half_grads=True` switches every
+    GridEncoder-style parameter that carries `_s3d_stash_ok` to the fp16 hand-over described in the module docstring."""
+
+    def __init__(self, params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, adopt_half_grads=True):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.step_count = None
+        for group in self.param_groups:
+            for p in group["params"]:
+                if not p.is_cuda or p.dtype != torch.float32:
+                    raise RuntimeError("NativeAdam updates fp32 parameters on the GPU")
+                st = self.state[p]
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                if self.step_count is None:
+                    self.step_count = torch.zeros(1, dtype=torch.float32, device=p.device)
+                if adopt_half_grads and getattr(p, "_s3d_stash_ok", False):
+                    p._s3d_grad = torch.zeros(p.shape, dtype=torch.float16, device=p.device)
+                    p._s3d_half = p.detach().to(torch.float16)
+                    p._s3d_half_version = p._version
+
+    def grads(self):
+        """(param, gradient tensor) for every parameter that has one: the fp16 hand-over buffer or `.grad`"""
+        for group in self.param_groups:
+            for p in group["params"]:
+                g = getattr(p, "_s3d_grad", None)
+                if g is None or not getattr(p, "_s3d_grad_touched", False):
+                    g = p.grad  # (a table no backward pass touched this step has no gradient, like `.grad is None`)
+                if g is not None:
+                    yield group, p, g
+
+    def zero_grad(self, set_to_none=True):
+        for group in self.param_groups:
+            for p in group["params"]:
+                g = getattr(p, "_s3d_grad", None)
+                if g is not None:
+                    g.zero_()  # the table backward accumulates into it (several encoder calls per step are summed)
+                    p._s3d_grad_touched = False
+                if p.grad is not None:
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, grad_scale=None, found_inf=None):
+        for group, p, g in self.grads():
+            st = self.state[p]
+            half = getattr(p, "_s3d_half", None)
+            if half is not None and p._s3d_half_version != p._version:
+                half = None  # somebody wrote the parameter through torch: the fp16 copy is re-made below
+            b1, b2 = group["betas"]
+            _backend.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], half, group["lr"], b1, b2, group["eps"],
+                               self.step_count, grad_scale, found_inf)
+            if half is None and hasattr(p, "_s3d_half"):
+                p._s3d_half.copy_(p.detach())
+                p._s3d_half_version = p._version
+        _backend.adam_advance(self.step_count, found_inf)
+
+
+class NativeGradScaler:
+    """torch.amp.GradScaler's schedule (init 2^16, x2 after 2000 clean steps, x0.5 on overflow) driven by the flag the
+    gradient check raises; `step()` does check + unscale + Adam, `update()` the schedule (aten::_amp_update_scale_)."""
+
+    def __init__(self, device, enabled=True, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.enabled = enabled
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self._scale = torch.full((1,), init_scale if enabled else 1.0, dtype=torch.float32, device=device)
+        self._growth_tracker = torch.zeros(1, dtype=torch.int32, device=device)
+        self._found_inf = torch.zeros(1, dtype=torch.float32, device=device)
+
+    def scale(self, loss):
+        return loss * self._scale.to(loss.dtype) if self.enabled else loss
+
+    def get_scale(self):
+        return float(self._scale.item())
+
+    def step(self, optimizer):
+        self._found_inf.zero_()
+        for _, _, g in optimizer.grads():
+            _backend.grads_nonfinite(g, self._found_inf)
+        optimizer.step(grad_scale=self._scale if self.enabled else None, found_inf=self._found_inf)
+
+    def update(self):
+        if self.enabled:
+            torch._amp_update_scale_(self._scale, self._growth_tracker, self._found_inf, self.growth_factor,
+                                     self.backoff_factor, self.growth_interval)

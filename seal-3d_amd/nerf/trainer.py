@@ -16,16 +16,26 @@ def psnr(pred, target):
 
 class Trainer:
     def __init__(self, model, lr=1e-2, fp16=True, update_extra_interval=16, dist=None, max_steps=1024, dt_gamma=0,
-                 T_thresh=1e-4, capturable=False):
+                 T_thresh=1e-4, capturable=False, native_optim=None, optimizer=None, scaler=None):
         self.model = model
         self.fp16 = fp16
         self.update_extra_interval = update_extra_interval
         self.dist = dist
         self.render_kwargs = dict(max_steps=max_steps, dt_gamma=dt_gamma, T_thresh=T_thresh)
         on_gpu = next(model.parameters()).is_cuda
-        self.optimizer = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15, fused=on_gpu,
-                                          capturable=capturable and on_gpu)
-        self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
+        # GPU default: Adam + loss scaling straight from the (fp16) gradients of the HIP kernels (nerf/optim.py);
+        # native_optim=False keeps the reference's torch.optim.Adam + GradScaler (the only choice on CPU)
+        self.native_optim = on_gpu if native_optim is None else (native_optim and on_gpu)
+        if optimizer is not None:  # share an existing optimizer / scaler (e.g. an eager twin of a graphed trainer)
+            self.optimizer, self.scaler = optimizer, scaler
+        elif self.native_optim:
+            from .optim import NativeAdam, NativeGradScaler
+            self.optimizer = NativeAdam(model.get_params(lr), lr=lr, betas=(0.9, 0.99), eps=1e-15)
+            self.scaler = NativeGradScaler(next(model.parameters()).device, enabled=fp16)
+        else:
+            self.optimizer = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15, fused=on_gpu,
+                                              capturable=capturable and on_gpu)
+            self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
         self.global_step = 0
         if dist is not None:
             dist.register(model)

@@ -46,10 +46,14 @@ class RayShardedDP:
         self.average = average
         self.flat = None
         self.params = []
+        self.half_grads = []
 
     def register(self, model):
         """broadcast rank 0's replica and re-home every parameter gradient inside one flat bucket"""
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        # tables whose gradient is handed over as an fp16 buffer (nerf/optim.py) are reduced in that buffer — half the
+        # bytes on the wire; everything else is re-homed inside the flat fp32 bucket
+        self.half_grads = [p._s3d_grad for p in model.parameters() if p.requires_grad and getattr(p, "_s3d_grad", None) is not None]
+        self.params = [p for p in model.parameters() if p.requires_grad and getattr(p, "_s3d_grad", None) is None]
         if self.world > 1:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0, group=self.group)
@@ -78,6 +82,10 @@ class RayShardedDP:
                 slot.copy_(p.grad.reshape(-1))
                 p.grad = slot.view_as(p)
             off += n
+        for h in self.half_grads:
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average and self.world > 1:
+                h.div_(self.world)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         if self.average:
             self.flat.div_(self.world)

@@ -38,6 +38,7 @@ EXPORTS = [
     "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
     "s3d_ffmlp_fused_backward_supported",
     "s3d_ffmlp_allocate_splitk", "s3d_ffmlp_free_splitk",
+    "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_advance",
 ]
 
 
@@ -378,3 +379,30 @@ class FFMLPBackend:
                                         _p(backward_buffer), _p(grad_inputs if calc_grad_inputs else None),
                                         _p(grad_weights), _p(ws), C.c_size_t(ws.numel()), _stream()),
                "ffmlp_backward")
+
+
+class OptimBackend:
+    """csrc/optim.hip — Adam + GradScaler bookkeeping straight from the (fp16) gradients"""
+
+    @staticmethod
+    def grads_nonfinite(grad, found_inf):
+        _need(found_inf, torch.float32, "found_inf")
+        _check(lib().s3d_grads_nonfinite(_p(grad), C.c_size_t(grad.numel()), C.c_int(_dt(grad)), _p(found_inf), _stream()),
+               "grads_nonfinite")
+
+    @staticmethod
+    def adam_step(param, grad, exp_avg, exp_avg_sq, param_half, lr, beta1, beta2, eps, step, grad_scale, found_inf):
+        _need(param, torch.float32, "param")
+        _need(exp_avg, torch.float32, "exp_avg")
+        _need(exp_avg_sq, torch.float32, "exp_avg_sq")
+        if grad.numel() != param.numel() or not grad.is_contiguous() or not param.is_contiguous():
+            raise RuntimeError("adam_step: param and grad must be contiguous and of equal size")
+        if param_half is not None:
+            _need(param_half, torch.float16, "param_half")
+        _check(lib().s3d_adam_step(_p(param), _p(grad), C.c_int(_dt(grad)), _p(exp_avg), _p(exp_avg_sq), _p(param_half),
+                                   C.c_size_t(param.numel()), _f(lr), _f(beta1), _f(beta2), _f(eps), _p(step),
+                                   _p(grad_scale), _p(found_inf), _stream()), "adam_step")
+
+    @staticmethod
+    def adam_advance(step, found_inf):
+        _check(lib().s3d_adam_advance(_p(step), _p(found_inf), _stream()), "adam_advance")

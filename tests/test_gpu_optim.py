@@ -1,0 +1,99 @@
+"""GPU: nerf.optim.NativeAdam / NativeGradScaler against torch.optim.Adam + torch.amp.GradScaler (the reference's
+update, nerf/utils.py:356-361), including the fp16 gradient hand-over of GridEncoder and the skipped step on overflow."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g)
+
+
+def test_native_adam_matches_torch_adam(hip):
+    from nerf.optim import NativeAdam
+    p0 = [_mk((1000, 2), 1), _mk((4097,), 2)]
+    pa = [torch.nn.Parameter(t.clone().cuda()) for t in p0]
+    pb = [torch.nn.Parameter(t.clone().cuda()) for t in p0]
+    oa = NativeAdam([{"params": pa}], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    ob = torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    scale = torch.full((1,), 128.0, device="cuda")
+    flag = torch.zeros(1, device="cuda")
+    for step in range(6):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            g = _mk(a.shape, 10 * step + i).cuda() * (10.0 ** (i - 1))
+            g[::7] = 0  # exact zeros keep m/v decaying only
+            a.grad = g * 128.0  # scaled gradient, as GradScaler hands it over
+            b.grad = g.clone()
+        flag.fill_(1.0 if step == 3 else 0.0)  # step 3 is an overflow step: must be skipped entirely
+        oa.step(grad_scale=scale, found_inf=flag)
+        if step != 3:
+            ob.step()
+    assert float(oa.step_count) == 5.0
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-6, atol=1e-7)
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+
+
+def test_grid_encoder_half_grad_handover_matches_reference_update(hip):
+    """Same data through (a) autograd fp32 grads + torch Adam + GradScaler and (b) fp16 hand-over + NativeAdam +
+    NativeGradScaler: the tables must follow the same trajectory (the fp16 gradient values are identical, only their
+    route to the optimizer differs), and the fp16 copy used by the next forward must equal the cast of the table."""
+    from gridencoder import GridEncoder
+    from nerf.optim import NativeAdam, NativeGradScaler
+    torch.manual_seed(0)
+    ea = GridEncoder(num_levels=4, base_resolution=4, log2_hashmap_size=10, desired_resolution=32).cuda()
+    eb = GridEncoder(num_levels=4, base_resolution=4, log2_hashmap_size=10, desired_resolution=32).cuda()
+    eb.load_state_dict(ea.state_dict())
+    w = _mk((8, 1), 3).cuda()
+    oa = NativeAdam([{"params": ea.parameters()}], lr=1e-2)
+    sa = NativeGradScaler("cuda", init_scale=1024.0)
+    ob = torch.optim.Adam(eb.parameters(), lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    sb = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    assert ea.embeddings._s3d_grad.dtype == torch.float16
+    for step in range(4):
+        x = (torch.rand(9000, 3, generator=torch.Generator().manual_seed(step)) * 2 - 1).cuda()
+        for enc, opt, sc in ((ea, oa, sa), (eb, ob, sb)):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.float16):
+                y = enc(x, bound=1)
+                loss = ((y.float() @ w) ** 2).mean() * (1e8 if step == 2 else 1.0)  # step 2 overflows fp16 -> skipped
+            sc.scale(loss).backward()
+            sc.step(opt)
+            sc.update()
+        assert ea.embeddings.grad is None, "the table gradient must not go through autograd"
+        # step 0 agrees to an fp32 ulp; afterwards an ulp of difference in the table can flip a bit of its fp16 copy,
+        # and Adam with eps = 1e-15 turns gradient noise of rarely-hit rows (v ~ 1e-18) into percent-level changes of
+        # their 1e-2-sized updates: trajectories are compared at 1e-3 of an update
+        torch.testing.assert_close(ea.embeddings.detach(), eb.embeddings.detach(), rtol=1e-3, atol=(1e-8 if step == 0 else 2e-5))
+        assert torch.equal(ea.embeddings._s3d_half, ea.embeddings.detach().half())
+        assert sa.get_scale() == sb.get_scale()
+    assert sa.get_scale() == 512.0  # one overflow halved the scale
+    # writing the parameter through torch invalidates the fp16 copy; the next forward must see the new values
+    with torch.no_grad():
+        ea.embeddings.mul_(2.0)
+    x = (torch.rand(8192, 3) * 2 - 1).cuda()
+    with torch.autocast("cuda", dtype=torch.float16):
+        y2 = ea(x, bound=1)
+        eb.embeddings.data.copy_(ea.embeddings.data)
+        y_ref = eb(x, bound=1)
+    assert torch.equal(y2, y_ref)
+
+
+def test_native_scaler_growth(hip):
+    from nerf.optim import NativeAdam, NativeGradScaler
+    p = torch.nn.Parameter(torch.ones(64, device="cuda"))
+    opt = NativeAdam([{"params": [p]}], lr=1e-3)
+    sc = NativeGradScaler("cuda", init_scale=4.0, growth_interval=2)
+    for i in range(4):
+        p.grad = torch.ones_like(p)
+        sc.step(opt)
+        sc.update()
+    assert sc.get_scale() == 16.0 and float(opt.step_count) == 4.0
+    p.grad = torch.full_like(p, float("nan"))
+    before = p.detach().clone()
+    sc.step(opt)
+    sc.update()
+    assert sc.get_scale() == 8.0 and float(opt.step_count) == 4.0 and torch.equal(before, p.detach())
