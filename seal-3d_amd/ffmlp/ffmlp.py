@@ -30,13 +30,21 @@ def convert_activation(act):
     return _ACTIVATIONS.get(act, 6)
 
 
+class _ParamRef:
+    """Carries the fp32 Parameter through `custom_fwd(cast_inputs=...)` (which only touches tensors) to backward()."""
+    __slots__ = ("param",)
+
+    def __init__(self, param):
+        self.param = param
+
+
 class _FFMLPForward(Function):
     """ffmlp.py:15-83"""
 
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.half)
     def forward(ctx, inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
-                inference=False, calc_grad_inputs=False):
+                inference=False, calc_grad_inputs=False, param_ref=None, hook=None):
         B = inputs.shape[0]
         # outside autocast `custom_fwd` does not cast: the kernels are fp16-only, so cast here (the autograd
         # engine converts the returned fp16 gradients back to the parameter dtype)
@@ -61,6 +69,7 @@ class _FFMLPForward(Function):
         else:
             ctx.save_for_backward(inputs, weights, forward_buffer)
         ctx.meta = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs, fused)
+        ctx.param_ref = param_ref
         return outputs
 
     @staticmethod
@@ -82,7 +91,14 @@ class _FFMLPForward(Function):
         _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim,
                                 num_layers, activation, output_activation, calc_grad_inputs, backward_buffer,
                                 grad_inputs, grad_weights)
-        return ((grad_inputs if calc_grad_inputs else None), grad_weights) + (None,) * 8
+        # fp16 hand-over (nerf.optim.NativeAdam): the weight gradient is added to the optimizer's fp16 buffer instead of
+        # being returned to autograd (fp32 cast + accumulate)
+        stash = getattr(ctx.param_ref.param, "_s3d_grad", None) if ctx.param_ref is not None else None
+        if stash is not None:
+            stash.add_(grad_weights.view(stash.shape))
+            ctx.param_ref.param._s3d_grad_touched = True
+            grad_weights = None
+        return ((grad_inputs if calc_grad_inputs else None), grad_weights) + (None,) * 10
 
 
 ffmlp_forward = _FFMLPForward.apply
@@ -110,6 +126,8 @@ class FFMLP(nn.Module):
         self.padded_output_dim = int(math.ceil(output_dim / 16)) * 16
         self.num_parameters = hidden_dim * (input_dim + hidden_dim * (num_layers - 1) + self.padded_output_dim)
         self.weights = nn.Parameter(torch.zeros(self.num_parameters))
+        self.weights._s3d_stash_ok = True  # a native optimizer may take this gradient as an fp16 buffer (nerf/optim.py)
+        self._autograd_hook = torch.zeros((), requires_grad=True)
         self.reset_parameters()
         _backend.allocate_splitk(self.num_layers + 1)
 
@@ -133,9 +151,18 @@ class FFMLP(nn.Module):
         pad = (-B) % 128
         if pad > 0:
             inputs = torch.cat([inputs, torch.zeros(pad, C, dtype=inputs.dtype, device=inputs.device)], dim=0)
-        out = ffmlp_forward(inputs, self.weights, self.input_dim, self.padded_output_dim, self.hidden_dim,
+        w, ref, hook = self.weights, None, None
+        if getattr(w, "_s3d_grad", None) is not None and getattr(w, "_s3d_half_version", None) == w._version:
+            # a native optimizer maintains the fp16 copy of the weights and takes their gradient as an fp16 buffer
+            if torch.is_grad_enabled() and w.requires_grad:
+                ref = _ParamRef(w)
+                # the fp16 copy carries no autograd history: a 0-dim CPU leaf (never cast, never read) keeps the node
+                # in the graph when the inputs do not require a gradient either
+                hook = self._autograd_hook
+            w = w._s3d_half
+        out = ffmlp_forward(inputs, w, self.input_dim, self.padded_output_dim, self.hidden_dim,
                             self.num_layers, self.activation, self.output_activation, not self.training,
-                            inputs.requires_grad)
+                            inputs.requires_grad, ref, hook)
         if B != out.shape[0] or self.padded_output_dim != self.output_dim:
             out = out[:B, :self.output_dim]
         return out

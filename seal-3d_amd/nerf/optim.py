@@ -29,6 +29,8 @@ class NativeAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, adopt_half_grads=True):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.step_count = None
+        self.flat_half = None  # ONE fp16 buffer behind every handed-over gradient: one clear, one check, one all-reduce
+        adopted = []
         for group in self.param_groups:
             for p in group["params"]:
                 if not p.is_cuda or p.dtype != torch.float32:
@@ -39,9 +41,18 @@ class NativeAdam(torch.optim.Optimizer):
                 if self.step_count is None:
                     self.step_count = torch.zeros(1, dtype=torch.float32, device=p.device)
                 if adopt_half_grads and getattr(p, "_s3d_stash_ok", False):
-                    p._s3d_grad = torch.zeros(p.shape, dtype=torch.float16, device=p.device)
-                    p._s3d_half = p.detach().to(torch.float16)
-                    p._s3d_half_version = p._version
+                    adopted.append(p)
+        if adopted:
+            sizes = [(p.numel() + 7) // 8 * 8 for p in adopted]  # 16-byte aligned views
+            self.flat_half = torch.zeros(sum(sizes), dtype=torch.float16, device=adopted[0].device)
+            off = 0
+            for p, n in zip(adopted, sizes):
+                p._s3d_grad = self.flat_half[off:off + p.numel()].view(p.shape)
+                p._s3d_grad_flat = self.flat_half
+                p._s3d_grad_touched = False
+                p._s3d_half = p.detach().to(torch.float16)
+                p._s3d_half_version = p._version
+                off += n
 
     def grads(self):
         """(param, gradient tensor) for every parameter that has one: the fp16 hand-over buffer or `.grad`"""
@@ -54,11 +65,11 @@ class NativeAdam(torch.optim.Optimizer):
                     yield group, p, g
 
     def zero_grad(self, set_to_none=True):
+        if self.flat_half is not None:
+            self.flat_half.zero_()  # the backward kernels ACCUMULATE into it (several calls per step are summed)
         for group in self.param_groups:
             for p in group["params"]:
-                g = getattr(p, "_s3d_grad", None)
-                if g is not None:
-                    g.zero_()  # the table backward accumulates into it (several encoder calls per step are summed)
+                if getattr(p, "_s3d_grad", None) is not None:
                     p._s3d_grad_touched = False
                 if p.grad is not None:
                     if set_to_none:
@@ -101,8 +112,12 @@ class NativeGradScaler:
 
     def step(self, optimizer):
         self._found_inf.zero_()
-        for _, _, g in optimizer.grads():
-            _backend.grads_nonfinite(g, self._found_inf)
+        flat = getattr(optimizer, "flat_half", None)
+        if flat is not None:
+            _backend.grads_nonfinite(flat, self._found_inf)  # every handed-over gradient in one pass
+        for _, p, g in optimizer.grads():
+            if flat is None or g is not getattr(p, "_s3d_grad", None):
+                _backend.grads_nonfinite(g, self._found_inf)
         optimizer.step(grad_scale=self._scale if self.enabled else None, found_inf=self._found_inf)
 
     def update(self):

@@ -52,13 +52,19 @@ class RayShardedDP:
         """broadcast rank 0's replica and re-home every parameter gradient inside one flat bucket"""
         # tables whose gradient is handed over as an fp16 buffer (nerf/optim.py) are reduced in that buffer — half the
         # bytes on the wire; everything else is re-homed inside the flat fp32 bucket
-        self.half_grads = [p._s3d_grad for p in model.parameters() if p.requires_grad and getattr(p, "_s3d_grad", None) is not None]
+        self.half_grads, seen = [], set()
+        for p in model.parameters():
+            if p.requires_grad and getattr(p, "_s3d_grad", None) is not None:
+                buf = getattr(p, "_s3d_grad_flat", p._s3d_grad)  # the optimizer's single flat buffer when there is one
+                if buf.data_ptr() not in seen:
+                    seen.add(buf.data_ptr())
+                    self.half_grads.append(buf)
         self.params = [p for p in model.parameters() if p.requires_grad and getattr(p, "_s3d_grad", None) is None]
         if self.world > 1:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0, group=self.group)
         total = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
+        dev = next(model.parameters()).device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
         for p in self.params:
@@ -86,9 +92,10 @@ class RayShardedDP:
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
             if self.average and self.world > 1:
                 h.div_(self.world)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        if self.average:
-            self.flat.div_(self.world)
+        if self.flat.numel():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average:
+                self.flat.div_(self.world)
 
     def sync_extra_state(self, model):
         """keep the occupancy state identical on all replicas after `update_extra_state` (RNG differs per rank)"""

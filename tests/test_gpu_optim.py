@@ -97,3 +97,23 @@ def test_native_scaler_growth(hip):
     sc.step(opt)
     sc.update()
     assert sc.get_scale() == 8.0 and float(opt.step_count) == 4.0 and torch.equal(before, p.detach())
+
+
+def test_ffmlp_weight_grad_handover(hip):
+    """FFMLP weights adopted by NativeAdam: the gradient lands in the optimizer's flat fp16 buffer (not in `.grad`), with
+    the values the autograd route produces, and accumulates over two backward passes of one step."""
+    from ffmlp import FFMLP
+    from nerf.optim import NativeAdam
+    torch.manual_seed(1)
+    ma, mb = FFMLP(32, 16, 64, 2).cuda(), FFMLP(32, 16, 64, 2).cuda()
+    mb.load_state_dict(ma.state_dict())
+    opt = NativeAdam([{"params": ma.parameters()}], lr=1e-3)
+    assert opt.flat_half is not None and ma.weights._s3d_grad_flat is opt.flat_half
+    x = torch.randn(1024, 32, device="cuda")
+    opt.zero_grad()
+    for m in (ma, mb):
+        for _ in range(2):
+            with torch.autocast("cuda", dtype=torch.float16):
+                (m(x).float() ** 2).mean().backward()
+    assert ma.weights.grad is None and ma.weights._s3d_grad_touched
+    torch.testing.assert_close(ma.weights._s3d_grad.float(), mb.weights.grad, rtol=2e-3, atol=1e-4)
