@@ -250,6 +250,7 @@ def main():
     model.update_extra_state = timed_update_extra_state
 
     samples_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    captures0 = getattr(trainer, "n_captures", 0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -312,6 +313,8 @@ def main():
                            else "inside the timed region")}
 
     extra = {}
+    if graphed:
+        extra["graph_captures_in_timed_region"] = trainer.n_captures - captures0
     if ues_ms:
         extra["update_extra_state"] = {"calls_in_timed_region": len(ues_ms), "ms_per_call": sum(ues_ms) / len(ues_ms),
                                        "ms_per_step_amortised": sum(ues_ms) / args.steps}

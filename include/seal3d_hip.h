@@ -207,6 +207,17 @@ int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
 int s3d_ffmlp_allocate_splitk(size_t n);
 int s3d_ffmlp_free_splitk(void);
 
+/* ------------------------------------------------------------------ NGP head glue
+ * The elementwise steps between the two MLPs of nerf/network_ff.py:55-96 (slice / trunc_exp / SH / cat / cast /
+ * sigmoid and their backward nodes) as two streaming kernels per direction, csrc/ngp_head.hip.
+ * h, color_in, out and their gradients are fp16 row-major ([B,16], [B,32], [B,16]); sigma, rgb, dirs fp32. */
+int s3d_ngp_mid_forward(const uint16_t* h, const float* dirs, uint32_t B, float* sigma, uint16_t* color_in,
+                        s3d_stream_t stream);
+int s3d_ngp_mid_backward(const uint16_t* grad_color_in, const float* grad_sigma /* or NULL */, const uint16_t* h,
+                         uint32_t B, uint16_t* grad_h, s3d_stream_t stream);
+int s3d_ngp_rgb_forward(const uint16_t* out, uint32_t B, float* rgb, s3d_stream_t stream);
+int s3d_ngp_rgb_backward(const float* grad_rgb, const float* rgb, uint32_t B, uint16_t* grad_out, s3d_stream_t stream);
+
 /* ------------------------------------------------------------------ parameter update
  * The reference's update is torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15) under torch.cuda.amp.GradScaler
  * (nerf/utils.py:356-361, 495-537; main_SealNeRF.py:283-288).  These three calls are that update taken directly

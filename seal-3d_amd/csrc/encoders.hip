@@ -8,13 +8,11 @@
 // obtained from the reference's own expressions with a 2e-5 relative tolerance.
 // One lane = one point; the deg^2 outputs of a lane are contiguous (float4 stores).
 #include "s3d_common.hpp"
+#include "sh_eval.hpp"
 #include <math.h>
 
 namespace s3d {
 namespace {
-
-constexpr uint32_t kMaxDeg = 8;
-struct ShNorm { float k[kMaxDeg][kMaxDeg]; };  // k[l][m], m <= l
 
 template <uint32_t DEG, bool JAC>
 __global__ void __launch_bounds__(256) k_sh_forward(const float* __restrict__ inputs, float* __restrict__ outputs,
@@ -23,54 +21,9 @@ __global__ void __launch_bounds__(256) k_sh_forward(const float* __restrict__ in
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float x = inputs[(size_t)b * D], y = inputs[(size_t)b * D + 1], z = inputs[(size_t)b * D + 2];
-    float c[DEG + 1], s[DEG + 1];
-    c[0] = 1.0f; s[0] = 0.0f;
-#pragma unroll
-    for (uint32_t m = 1; m <= DEG; m++) {
-        c[m] = __builtin_fmaf(x, c[m - 1], -(y * s[m - 1]));
-        s[m] = __builtin_fmaf(x, s[m - 1], y * c[m - 1]);
-    }
-    float T[DEG][DEG + 2];
-#pragma unroll
-    for (uint32_t l = 0; l < DEG; l++)
-#pragma unroll
-        for (uint32_t m = 0; m < DEG + 2; m++) T[l][m] = 0.0f;
-#pragma unroll
-    for (uint32_t m = 0; m < DEG; m++) {
-        float dfact = 1.0f;
-#pragma unroll
-        for (uint32_t k = 1; k <= m; k++) dfact *= (float)(2 * k - 1);
-        T[m][m] = dfact;
-        if (m + 1 < DEG) T[m + 1][m] = (float)(2 * m + 1) * z * dfact;
-#pragma unroll
-        for (uint32_t l = m + 2; l < DEG; l++)
-            T[l][m] = __builtin_fmaf((float)(2 * l - 1) * z, T[l - 1][m], -((float)(l + m - 1) * T[l - 2][m])) *
-                      (1.0f / (float)(l - m));
-    }
     float o[C2];
     float jx[JAC ? C2 : 1], jy[JAC ? C2 : 1], jz[JAC ? C2 : 1];
-#pragma unroll
-    for (uint32_t l = 0; l < DEG; l++) {
-        const uint32_t base = l * l + l;
-        o[base] = K.k[l][0] * T[l][0];
-        if (JAC) { jx[base] = 0.0f; jy[base] = 0.0f; jz[base] = K.k[l][0] * T[l][1]; }
-#pragma unroll
-        for (uint32_t m = 1; m <= l; m++) {
-            const float kt = K.k[l][m] * T[l][m];
-            o[base + m] = kt * c[m];
-            o[base - m] = kt * s[m];
-            if (JAC) {
-                const float kz = K.k[l][m] * T[l][m + 1];
-                const float km = kt * (float)m;
-                jx[base + m] = km * c[m - 1];
-                jx[base - m] = km * s[m - 1];
-                jy[base + m] = -km * s[m - 1];
-                jy[base - m] = km * c[m - 1];
-                jz[base + m] = kz * c[m];
-                jz[base - m] = kz * s[m];
-            }
-        }
-    }
+    sh_eval<DEG, JAC>(x, y, z, K, o, jx, jy, jz);
     float* out = outputs + (size_t)b * C2;
 #pragma unroll
     for (uint32_t i = 0; i < C2; i++) out[i] = o[i];
@@ -126,18 +79,6 @@ __global__ void k_freq_backward(const float* __restrict__ grad, const float* __r
         g += 2 * D; o += 2 * D;
     }
     grad_inputs[t] = result;
-}
-
-void host_sh_norm(uint32_t degree, ShNorm& K) {
-    memset(&K, 0, sizeof(K));
-    for (uint32_t l = 0; l < degree; l++)
-        for (uint32_t m = 0; m <= l; m++) {
-            double ratio = 1.0;
-            for (uint32_t k = l - m + 1; k <= l + m; k++) ratio /= (double)k;
-            double n = sqrt((2.0 * l + 1.0) / (4.0 * M_PI) * ratio);
-            if (m) n *= ((m & 1) ? -1.0 : 1.0) * M_SQRT2;
-            K.k[l][m] = (float)n;
-        }
 }
 
 template <uint32_t DEG>

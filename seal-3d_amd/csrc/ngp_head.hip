@@ -1,0 +1,120 @@
+// ngp_head.hip — the elementwise glue between the two fused MLPs of the NGP network (nerf/network_ff.py:55-96 of the
+// reference: `sigma = trunc_exp(h[..., 0]); geo = h[..., 1:]; d = SH(d); rgb = sigmoid(color_net(cat[d, geo, 0]))`).
+// In torch that is ~15 kernel launches per direction (slice, exp, SH, zeros, cat with type promotion, half cast, sigmoid,
+// float casts, and their backward nodes), each a full pass over [M, 16..32] activations.  Here it is two streaming kernels
+// per direction with the same arithmetic and the same rounding points:
+//   mid  forward : h [B,16] f16, dirs [B,3] f32  ->  sigma [B] f32 = exp(float(h0))            (activation.py:8-11)
+//                                                    cin [B,32] f16 = [half(SH_4(d)) | h1..h15 | 0]
+//   mid  backward: d_cin [B,32] f16, d_sigma [B] f32, h -> d_h [B,16] f16 = [half(d_sigma * exp(clamp(h0,-15,15))) | d_cin[16..30]]
+//   rgb  forward : out [B,16] f16 -> rgb [B,3] f32 = float(half(sigmoid(float(out[:3]))))       (torch.sigmoid on fp16)
+//   rgb  backward: d_rgb [B,3] f32, rgb -> d_out [B,16] f16 = [half(float(half(d_rgb)) * y(1-y)) | 0 x 13]
+// One lane = one point; every lane reads/writes whole 16-byte pieces of its rows.
+#include "s3d_common.hpp"
+#include "sh_eval.hpp"
+
+namespace s3d {
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__global__ void __launch_bounds__(256) k_ngp_mid_forward(const _Float16* __restrict__ h, const float* __restrict__ dirs,
+                                                         uint32_t B, ShNorm K, float* __restrict__ sigma,
+                                                         _Float16* __restrict__ cin) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const h8 h0 = *reinterpret_cast<const h8*>(h + (size_t)b * 16), h1 = *reinterpret_cast<const h8*>(h + (size_t)b * 16 + 8);
+    const float x = dirs[(size_t)b * 3], y = dirs[(size_t)b * 3 + 1], z = dirs[(size_t)b * 3 + 2];
+    float o[16], j0[1], j1[1], j2[1];
+    sh_eval<4, false>(x, y, z, K, o, j0, j1, j2);
+    sigma[b] = expf((float)h0[0]);
+    h8 c0, c1, c2, c3;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c0[i] = (_Float16)o[i]; c1[i] = (_Float16)o[8 + i]; }
+#pragma unroll
+    for (int i = 0; i < 7; i++) { c2[i] = h0[i + 1]; c3[i] = h1[i + 1]; }
+    c2[7] = h1[0];
+    c3[7] = (_Float16)0.0f;
+    h8* dst = reinterpret_cast<h8*>(cin + (size_t)b * 32);
+    dst[0] = c0; dst[1] = c1; dst[2] = c2; dst[3] = c3;
+}
+
+__global__ void __launch_bounds__(256) k_ngp_mid_backward(const _Float16* __restrict__ d_cin, const float* __restrict__ d_sigma,
+                                                          const _Float16* __restrict__ h, uint32_t B,
+                                                          _Float16* __restrict__ d_h) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const h8 g2 = *reinterpret_cast<const h8*>(d_cin + (size_t)b * 32 + 16), g3 = *reinterpret_cast<const h8*>(d_cin + (size_t)b * 32 + 24);
+    const float h0 = (float)h[(size_t)b * 16];
+    const float gs = d_sigma ? d_sigma[b] * expf(fminf(15.0f, fmaxf(-15.0f, h0))) : 0.0f;  // activation.py:13-16
+    h8 o0, o1;
+    o0[0] = (_Float16)gs;
+#pragma unroll
+    for (int i = 0; i < 7; i++) { o0[i + 1] = g2[i]; o1[i + 1] = g3[i]; }
+    o1[0] = g2[7];
+    h8* dst = reinterpret_cast<h8*>(d_h + (size_t)b * 16);
+    dst[0] = o0; dst[1] = o1;
+}
+
+__global__ void __launch_bounds__(256) k_ngp_rgb_forward(const _Float16* __restrict__ out, uint32_t B, float* __restrict__ rgb) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const _Float16* o = out + (size_t)b * 16;
+#pragma unroll
+    for (int c = 0; c < 3; c++) rgb[(size_t)b * 3 + c] = (float)(_Float16)(1.0f / (1.0f + expf(-(float)o[c])));
+}
+
+__global__ void __launch_bounds__(256) k_ngp_rgb_backward(const float* __restrict__ d_rgb, const float* __restrict__ rgb,
+                                                          uint32_t B, _Float16* __restrict__ d_out) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    h8 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { o0[i] = (_Float16)0.0f; o1[i] = (_Float16)0.0f; }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float y = rgb[(size_t)b * 3 + c];
+        o0[c] = (_Float16)((float)(_Float16)d_rgb[(size_t)b * 3 + c] * (y * (1.0f - y)));
+    }
+    h8* dst = reinterpret_cast<h8*>(d_out + (size_t)b * 16);
+    dst[0] = o0; dst[1] = o1;
+}
+
+}  // namespace
+}  // namespace s3d
+
+using namespace s3d;
+
+S3D_EXPORT int s3d_ngp_mid_forward(const uint16_t* h, const float* dirs, uint32_t B, float* sigma, uint16_t* color_in,
+                                   s3d_stream_t stream) {
+    if (B == 0) return S3D_OK;
+    S3D_REQUIRE(h && dirs && sigma && color_in, "ngp_mid_forward: null pointer");
+    ShNorm K;
+    host_sh_norm(4, K);
+    hipLaunchKernelGGL(k_ngp_mid_forward, dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, as_stream(stream), (const _Float16*)h, dirs, B,
+                       K, sigma, (_Float16*)color_in);
+    return check_launch("ngp_mid_forward");
+}
+
+S3D_EXPORT int s3d_ngp_mid_backward(const uint16_t* grad_color_in, const float* grad_sigma, const uint16_t* h, uint32_t B,
+                                    uint16_t* grad_h, s3d_stream_t stream) {
+    if (B == 0) return S3D_OK;
+    S3D_REQUIRE(grad_color_in && h && grad_h, "ngp_mid_backward: null pointer");
+    hipLaunchKernelGGL(k_ngp_mid_backward, dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, as_stream(stream),
+                       (const _Float16*)grad_color_in, grad_sigma, (const _Float16*)h, B, (_Float16*)grad_h);
+    return check_launch("ngp_mid_backward");
+}
+
+S3D_EXPORT int s3d_ngp_rgb_forward(const uint16_t* out, uint32_t B, float* rgb, s3d_stream_t stream) {
+    if (B == 0) return S3D_OK;
+    S3D_REQUIRE(out && rgb, "ngp_rgb_forward: null pointer");
+    hipLaunchKernelGGL(k_ngp_rgb_forward, dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, as_stream(stream), (const _Float16*)out, B, rgb);
+    return check_launch("ngp_rgb_forward");
+}
+
+S3D_EXPORT int s3d_ngp_rgb_backward(const float* grad_rgb, const float* rgb, uint32_t B, uint16_t* grad_out, s3d_stream_t stream) {
+    if (B == 0) return S3D_OK;
+    S3D_REQUIRE(grad_rgb && rgb && grad_out, "ngp_rgb_backward: null pointer");
+    hipLaunchKernelGGL(k_ngp_rgb_backward, dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, as_stream(stream), grad_rgb, rgb, B,
+                       (_Float16*)grad_out);
+    return check_launch("ngp_rgb_backward");
+}

@@ -144,6 +144,14 @@ class FFMLP(nn.Module):
         self.weights.data.uniform_(-bound, bound)
 
     def forward(self, inputs):
+        out = self.forward_padded(inputs)
+        if self.padded_output_dim != self.output_dim:
+            out = out[:, :self.output_dim]
+        return out
+
+    def forward_padded(self, inputs):
+        """forward() before the final column slice: [B, padded_output_dim] (columns >= output_dim are exact zeros'
+        products: the padded weight rows).  Fused consumers (nerf/network_ff.py) read the 16-column rows directly."""
         B, C = inputs.shape
         # The reference always appends 128 - B % 128 zero rows (a full extra block when B is already aligned,
         # ffmlp.py:156-159) and slices them off again: results do not depend on it, and the copy is a full pass over the
@@ -163,6 +171,6 @@ class FFMLP(nn.Module):
         out = ffmlp_forward(inputs, w, self.input_dim, self.padded_output_dim, self.hidden_dim,
                             self.num_layers, self.activation, self.output_activation, not self.training,
                             inputs.requires_grad, ref, hook)
-        if B != out.shape[0] or self.padded_output_dim != self.output_dim:
-            out = out[:B, :self.output_dim]
+        if B != out.shape[0]:
+            out = out[:B]
         return out

@@ -1,12 +1,60 @@
 """NGP network with fully fused MLPs (nerf/network_ff.py of the reference, `main_nerf.py --ff`):
 hashgrid(32) -> FFMLP 32-64-64?-16 (density + 15 geo features) ; [SH16 | geo15 | 0] (32) -> FFMLP 32-64-64-3."""
-import torch
+import os
 
+import torch
+from torch.autograd import Function
+
+import s3d_hip
 from activation import trunc_exp
 from encoding import get_encoder
 from ffmlp import FFMLP
 
 from .renderer import NeRFRenderer
+
+
+_head = s3d_hip.NgpHeadBackend
+
+
+class _NgpMid(Function):
+    """sigma = trunc_exp(h[:, 0]);  colour-net input = [half(SH_4(d)) | h[:, 1:] | 0]  in one kernel per direction
+    (network_ff.py:55-96 of the reference does this with slice, exp, SH, zeros, cat and cast nodes)."""
+
+    @staticmethod
+    def forward(ctx, h, dirs):
+        B = h.shape[0]
+        sigma = torch.empty(B, dtype=torch.float32, device=h.device)
+        cin = torch.empty(B, 32, dtype=torch.float16, device=h.device)
+        _head.mid_forward(h, dirs, sigma, cin)
+        ctx.save_for_backward(h)
+        return sigma, cin
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_cin):
+        (h,) = ctx.saved_tensors
+        if g_cin is None:
+            g_cin = torch.zeros(h.shape[0], 32, dtype=torch.float16, device=h.device)
+        g_h = torch.empty_like(h)
+        _head.mid_backward(g_cin.to(torch.float16).contiguous(), None if g_sigma is None else g_sigma.float().contiguous(), h, g_h)
+        return g_h, None
+
+
+class _NgpRgb(Function):
+    """rgb = sigmoid(colour_net_output[:, :3]) as fp32, with fp16 rounding where torch.sigmoid on the fp16 tensor rounds"""
+
+    @staticmethod
+    def forward(ctx, out):
+        rgb = torch.empty(out.shape[0], 3, dtype=torch.float32, device=out.device)
+        _head.rgb_forward(out, rgb)
+        ctx.save_for_backward(rgb)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g_rgb):
+        (rgb,) = ctx.saved_tensors
+        g_out = torch.empty(rgb.shape[0], 16, dtype=torch.float16, device=rgb.device)
+        _head.rgb_backward(g_rgb.float().contiguous(), rgb, g_out)
+        return g_out
 
 
 class NeRFNetwork(NeRFRenderer):
@@ -32,7 +80,20 @@ class NeRFNetwork(NeRFRenderer):
         pad = torch.zeros_like(geo_feat[..., :1])
         return torch.sigmoid(self.color_net(torch.cat([d, geo_feat, pad], dim=-1)))
 
+    fused_head = os.environ.get("S3D_FUSED_HEAD", "1") != "0"  # tests / A-B runs: False = the reference op sequence
+
+    def _can_fuse(self, x):
+        return (self.fused_head and x.is_cuda and torch.is_autocast_enabled("cuda")
+                and torch.get_autocast_dtype("cuda") == torch.float16
+                and getattr(self.encoder_dir, "degree", None) == 4 and self.geo_feat_dim == 15
+                and self.sigma_net.padded_output_dim == 16 and self.color_net.input_dim == 32
+                and self.color_net.padded_output_dim == 16)
+
     def forward(self, x, d):
+        if self._can_fuse(x):
+            h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound))
+            sigma, cin = _NgpMid.apply(h.contiguous(), d.float().contiguous())
+            return sigma, _NgpRgb.apply(self.color_net.forward_padded(cin).contiguous())
         sigma, geo_feat = self._sigma(x)
         return sigma, self._rgb(d, geo_feat)
 

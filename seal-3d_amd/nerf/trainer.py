@@ -100,6 +100,7 @@ class GraphedTrainer(Trainer):
         self.budget_factor = budget_factor
         self.graph = None
         self.graph_opt = None
+        self.n_captures = 0
         self.budget = 0
         self.s_loss = None
         self.s_counter = torch.zeros(2, dtype=torch.int32, device=dev)
@@ -126,6 +127,7 @@ class GraphedTrainer(Trainer):
         replays: the collective stays outside graph capture, the ~120 kernel launches stay inside."""
         model = self.model
         model.train()
+        self.n_captures += 1
         self.budget = int(max(model.mean_count, 1) * self.budget_factor)
         saved = (model.mean_count, model.local_step)
         model.mean_count = self.budget
@@ -136,7 +138,9 @@ class GraphedTrainer(Trainer):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(2):  # real steps on the current batch (every rank runs the same number of all-reduces)
+            # real steps on the current batch (every rank runs the same number of all-reduces); a re-capture needs a single
+            # one — the allocator pools and lazy initialisations are already warm
+            for _ in range(2 if self.n_captures == 1 else 1):
                 model.local_step = 0
                 self._body_fb()
                 if self.dist is not None:

@@ -39,6 +39,7 @@ EXPORTS = [
     "s3d_ffmlp_fused_backward_supported",
     "s3d_ffmlp_allocate_splitk", "s3d_ffmlp_free_splitk",
     "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_advance",
+    "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
 ]
 
 
@@ -406,3 +407,31 @@ class OptimBackend:
     @staticmethod
     def adam_advance(step, found_inf):
         _check(lib().s3d_adam_advance(_p(step), _p(found_inf), _stream()), "adam_advance")
+
+
+class NgpHeadBackend:
+    """csrc/ngp_head.hip — the elementwise glue between the two MLPs of nerf/network_ff.py"""
+
+    @staticmethod
+    def mid_forward(h, dirs, sigma, color_in):
+        _need(h, torch.float16, "h"); _need(dirs, torch.float32, "dirs")
+        _need(sigma, torch.float32, "sigma"); _need(color_in, torch.float16, "color_in")
+        _check(lib().s3d_ngp_mid_forward(_p(h), _p(dirs), _u(h.shape[0]), _p(sigma), _p(color_in), _stream()), "ngp_mid_forward")
+
+    @staticmethod
+    def mid_backward(grad_color_in, grad_sigma, h, grad_h):
+        _need(grad_color_in, torch.float16, "grad_color_in"); _need(grad_h, torch.float16, "grad_h")
+        if grad_sigma is not None:
+            _need(grad_sigma, torch.float32, "grad_sigma")
+        _check(lib().s3d_ngp_mid_backward(_p(grad_color_in), _p(grad_sigma), _p(h), _u(h.shape[0]), _p(grad_h), _stream()),
+               "ngp_mid_backward")
+
+    @staticmethod
+    def rgb_forward(out, rgb):
+        _need(out, torch.float16, "out"); _need(rgb, torch.float32, "rgb")
+        _check(lib().s3d_ngp_rgb_forward(_p(out), _u(out.shape[0]), _p(rgb), _stream()), "ngp_rgb_forward")
+
+    @staticmethod
+    def rgb_backward(grad_rgb, rgb, grad_out):
+        _need(grad_rgb, torch.float32, "grad_rgb"); _need(rgb, torch.float32, "rgb"); _need(grad_out, torch.float16, "grad_out")
+        _check(lib().s3d_ngp_rgb_backward(_p(grad_rgb), _p(rgb), _u(rgb.shape[0]), _p(grad_out), _stream()), "ngp_rgb_backward")

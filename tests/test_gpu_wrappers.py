@@ -120,3 +120,34 @@ def test_ffmlp_module(hip):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         y2 = net(x)
     assert torch.equal(y2, y)
+
+
+def test_network_ff_fused_head_matches_reference_op_sequence(hip):
+    """nerf/network_ff.py forward/backward with the fused head glue (ngp_head.hip) vs the reference's torch op sequence
+    (slice, trunc_exp, SH, cat, cast, sigmoid) on the same weights: same values up to fp16 rounding of identical
+    intermediates, same gradients for the hash table and both MLPs."""
+    from nerf import network_ff
+    torch.manual_seed(0)
+    net = network_ff.NeRFNetwork(bound=1, cuda_ray=True).cuda()
+    net.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    g = torch.Generator().manual_seed(1)
+    B = 128 * 9
+    x = (torch.rand(B, 3, generator=g) * 2 - 1).cuda()
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1).cuda()
+    w_s, w_c = torch.rand(B, generator=g).cuda(), torch.rand(B, 3, generator=g).cuda()
+    res = {}
+    for fused in (True, False):
+        net.fused_head = fused
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            sigma, rgb = net(x, d)
+            loss = (sigma.float() * w_s).sum() * 1e-3 + (rgb.float() * w_c).sum()
+        loss.backward()
+        res[fused] = (sigma.float().detach().clone(), rgb.float().detach().clone(), net.encoder.embeddings.grad.clone(),
+                      net.sigma_net.weights.grad.clone(), net.color_net.weights.grad.clone())
+    net.fused_head = True
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=1e-6, atol=0)      # exp(float(h0)): same expression
+    torch.testing.assert_close(res[True][1], res[False][1], rtol=0, atol=1e-3)      # sigmoid rounded to fp16 both ways
+    for i, name in ((2, "table"), (3, "sigma_net"), (4, "color_net")):
+        a, b = res[True][i].float(), res[False][i].float()
+        assert (a - b).norm() / b.norm().clamp(min=1e-12) < 2e-3, f"{name} gradient differs: {(a - b).norm() / b.norm()}"
