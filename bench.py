@@ -333,7 +333,8 @@ def main():
         dtr = (time.perf_counter() - tr0) / nfr
         gt = torch.cat([analytic_targets(ro[0, i:i + 160000].contiguous(), rd[0, i:i + 160000].contiguous(), scene_bits, boxes, R)
                         for i in range(0, 640000, 160000)])
-        extra = {"render_infer_batch_scale": args.infer_batch_scale, "render_mrays_per_s": 0.64 / dtr, "render_ms_per_frame": dtr * 1e3, "psnr_vs_analytic_scene": psnr(out["image"][0], gt)}
+        extra.update({"render_infer_batch_scale": args.infer_batch_scale, "render_mrays_per_s": 0.64 / dtr,
+                      "render_ms_per_frame": dtr * 1e3, "psnr_vs_analytic_scene": psnr(out["image"][0], gt)})
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:

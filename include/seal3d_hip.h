@@ -175,16 +175,18 @@ int s3d_freq_encode_backward(const float* grad, const float* outputs, uint32_t B
  * ffmlp/src/ffmlp.h:8-14.  All tensors fp16 (uint16_t bit patterns).
  * weights: [W,in] | (n-1) x [W,W] | [out,W], row-major [out,in] per layer (ffmlp.cu:631-634).
  * forward_buffer / backward_buffer: [n, B, W] post-activation / pre-activation-gradient scratch.
- * B must be a multiple of 128 (ffmlp.py:156-159 pads); in % 16 == 0; out == 16; W in {16,32,64,128}. */
+ * B must be a multiple of 128 (ffmlp.py:156-159 pads); in % 16 == 0; out == 16; W in {16,32,64,128}.
+ * input_layout: 0 = inputs [B,in] row-major (the reference); 1 = level-major [in/2][B][2], i.e. the grid
+ * encoder's own output layout read in place (and grad_inputs written in it) — no permute copies in between. */
 int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                       uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                       uint32_t output_activation, uint16_t* forward_buffer, uint16_t* outputs,
-                      s3d_stream_t stream);
+                      int input_layout, s3d_stream_t stream);
 /* ffmlp.h:9: same network without storing intermediates (inference_buffer is unused scratch) */
 int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                         uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                         uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,
-                        s3d_stream_t stream);
+                        int input_layout, s3d_stream_t stream);
 /* ffmlp.h:11; grad_weights fp16 [same layout as weights], zero-initialised by the caller.
  * workspace: fp32 accumulation of the weight gradient (s3d_ffmlp_backward_workspace_size).
  * forward_buffer == backward_buffer == NULL selects the fused backward: the activations are re-computed from
@@ -200,7 +202,7 @@ int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
                        uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                        uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer,
                        uint16_t* grad_inputs, uint16_t* grad_weights, void* workspace,
-                       size_t workspace_bytes, s3d_stream_t stream);
+                       size_t workspace_bytes, int input_layout, s3d_stream_t stream);
 /* ffmlp.h:13-14: the reference allocates split-K side streams here; this build fuses the weight
  * gradient into the backward launch sequence on the caller's stream, so these are no-ops kept for
  * surface compatibility. */

@@ -94,6 +94,37 @@ __device__ __forceinline__ half8 load_bfrag_rowmajor(const _Float16* row, uint32
     return b;
 }
 
+// Network input / input gradient in the grid encoder's own layout: level-major [L][B][2] (feature f = 2*level + channel,
+// in_dim = 2L).  Reading it here (and writing the input gradient in it) removes the [L,B,C] <-> [B,L*C] permute copies that
+// gridencoder/grid.py:57,71 of the reference makes in each direction.  Lanes of a half-wave still touch 128 contiguous bytes.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half8 load_bfrag_levelmajor(const _Float16* X, uint32_t B, size_t row, uint32_t s, uint32_t h) {
+    const uint32_t l0 = 8 * s + 2 * h;
+    const half2v a = *reinterpret_cast<const half2v*>(X + ((size_t)(l0 + 0) * B + row) * 2);
+    const half2v b = *reinterpret_cast<const half2v*>(X + ((size_t)(l0 + 1) * B + row) * 2);
+    const half2v c = *reinterpret_cast<const half2v*>(X + ((size_t)(l0 + 4) * B + row) * 2);
+    const half2v d = *reinterpret_cast<const half2v*>(X + ((size_t)(l0 + 5) * B + row) * 2);
+    half8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1]; r[4] = c[0]; r[5] = c[1]; r[6] = d[0]; r[7] = d[1];
+    return r;
+}
+__device__ __forceinline__ half8 load_bfrag_input(const _Float16* X, uint32_t layout, uint32_t B, uint32_t in_dim, size_t row,
+                                                  uint32_t s, uint32_t h) {
+    return layout ? load_bfrag_levelmajor(X, B, row, s, h) : load_bfrag_rowmajor(X + row * in_dim, s, h);
+}
+// 4 consecutive features [feat, feat+4) of one point's input gradient
+__device__ __forceinline__ void store_grad_input(_Float16* G, uint32_t layout, uint32_t B, uint32_t in_dim, size_t row,
+                                                 uint32_t feat, half4 v) {
+    if (layout) {
+        half2v a, b;
+        a[0] = v[0]; a[1] = v[1]; b[0] = v[2]; b[1] = v[3];
+        *reinterpret_cast<half2v*>(G + ((size_t)(feat / 2) * B + row) * 2) = a;
+        *reinterpret_cast<half2v*>(G + ((size_t)(feat / 2 + 1) * B + row) * 2) = b;
+    } else {
+        st4(G + row * in_dim + feat, v);
+    }
+}
+
 // offset (in halfs) inside one 32-point tile of a fragment-ordered ("native") buffer
 __device__ __forceinline__ uint32_t native_off(uint32_t mblk, uint32_t q, uint32_t n, uint32_t h) {
     return ((mblk * 4 + q) * 32 + n) * 8 + h * 4;
@@ -105,7 +136,7 @@ template <int W, bool TRAIN, int ACT, int OACT>
 __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restrict__ X, const _Float16* __restrict__ Wt,
                                                        uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
                                                        uint32_t act, uint32_t out_act, _Float16* __restrict__ fwd,
-                                                       _Float16* __restrict__ out) {
+                                                       _Float16* __restrict__ out, uint32_t in_layout) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     half8* frags = reinterpret_cast<half8*>(smem_raw);
@@ -147,9 +178,8 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
         half8 bf[KS];
 #pragma unroll
         for (uint32_t m = 0; m < MB; m++) acc[m] = zero16();
-        const _Float16* xrow = X + row * in_dim;
         for (uint32_t s = 0; s < KS0; s++) {
-            const half8 b = load_bfrag_rowmajor(xrow, s, h);
+            const half8 b = load_bfrag_input(X, in_layout, B, in_dim, row, s, h);
 #pragma unroll
             for (uint32_t m = 0; m < MB; m++) acc[m] = mfma(frags[(m * KS0 + s) * 64 + lane], b, acc[m]);
         }
@@ -494,7 +524,7 @@ template <int W, int NH, int IMB, int ACT>
 __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __restrict__ grad, const _Float16* __restrict__ X,
                                                              const _Float16* __restrict__ Wt, uint32_t B, uint32_t in_dim,
                                                              uint32_t out_dim, uint32_t act, _Float16* __restrict__ grad_inputs,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, uint32_t in_layout) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -570,10 +600,9 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
         const size_t row = (size_t)tile * 32 + n;
         // ---- inputs of the tile: network input (B fragments) and output gradient (one k-step)
         half8 xf[4];  // in_dim <= 64
-        const _Float16* xrow = X + row * in_dim;
 #pragma unroll
         for (uint32_t s = 0; s < 4; s++)
-            if (s < KS0) xf[s] = load_bfrag_rowmajor(xrow, s, h);
+            if (s < KS0) xf[s] = load_bfrag_input(X, in_layout, B, in_dim, row, s, h);
         const half8 gf = load_bfrag_rowmajor(grad + row * 16, 0, h);
 
         // ---- forward re-computation (same operations and roundings as k_ffmlp_forward)
@@ -694,7 +723,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
                         half4 v;
 #pragma unroll
                         for (uint32_t e = 0; e < 4; e++) v[e] = (_Float16)gi[4 * q + e];
-                        st4(grad_inputs + row * in_dim + feat, v);
+                        store_grad_input(grad_inputs, in_layout, B, in_dim, row, feat, v);
                     }
                 }
             }
@@ -723,14 +752,14 @@ int check_shape(uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t W, uint3
 
 template <int W>
 int launch_forward(const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
-                   uint32_t act, uint32_t out_act, _Float16* fwd, _Float16* out, hipStream_t st) {
+                   uint32_t act, uint32_t out_act, _Float16* fwd, _Float16* out, uint32_t in_layout, hipStream_t st) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
     const uint32_t nfr = MB * (in_dim / 16) + (n_layers - 1) * MB * KS + KS;
     const size_t smem = (size_t)nfr * 64 * sizeof(half8);
     const uint32_t ntiles = B / 32;
     uint32_t grid = div_up<uint32_t>(ntiles, 4);
     if (grid > 1024) grid = 1024;
-#define S3D_FWD(TRAIN, A, O) hipLaunchKernelGGL((k_ffmlp_forward<W, TRAIN, A, O>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out)
+#define S3D_FWD(TRAIN, A, O) hipLaunchKernelGGL((k_ffmlp_forward<W, TRAIN, A, O>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out, in_layout)
     const bool fast = act == ACT_RELU && out_act == ACT_NONE;  // the networks of the hot path; anything else: run-time switch
     if (fwd) { if (fast) S3D_FWD(true, ACT_RELU, ACT_NONE); else S3D_FWD(true, -1, -1); }
     else { if (fast) S3D_FWD(false, ACT_RELU, ACT_NONE); else S3D_FWD(false, -1, -1); }
@@ -789,7 +818,7 @@ inline bool fused_backward_supported(uint32_t in_dim, uint32_t out_dim, uint32_t
 template <int W, int NH, int IMB, int ACT>
 int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t in_dim,
                             uint32_t out_dim, uint32_t act, _Float16* grad_inputs, _Float16* grad_weights, float* partial,
-                            hipStream_t st) {
+                            uint32_t in_layout, hipStream_t st) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
     const uint32_t nfrag = MB * (in_dim / 16) + NH * MB * KS + MB + NH * MB * KS + (grad_inputs ? IMB * KS : 0);
     size_t smem = (size_t)nfrag * 64 * sizeof(half8) + (size_t)4 * 2 * kTRows * kTRow * sizeof(_Float16);
@@ -804,7 +833,7 @@ int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Floa
     uint32_t nblk = div_up<uint32_t>(ntiles, 4);
     if (nblk > kWgradBlocks) nblk = kWgradBlocks;
     hipLaunchKernelGGL((k_ffmlp_backward_fused<W, NH, IMB, ACT>), dim3(nblk), dim3(256), smem, st, grad, X, Wt, B, in_dim, out_dim,
-                       act, grad_inputs, partial);
+                       act, grad_inputs, partial, in_layout);
     WgradPlan plan;
     memset(&plan, 0, sizeof(plan));
     plan.n = NH + 2;
@@ -820,11 +849,11 @@ int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Floa
 template <int W>
 int launch_backward_fused(const _Float16* grad, const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t in_dim,
                           uint32_t out_dim, uint32_t n_layers, uint32_t act, _Float16* gi, _Float16* gw, float* partial,
-                          hipStream_t st) {
+                          uint32_t in_layout, hipStream_t st) {
     const uint32_t NH = n_layers - 1, IMB = (in_dim + 31) / 32;
 #define S3D_FUSED(NHV, IMBV)                                                                                              \
-    (act == ACT_RELU ? launch_backward_fused_k<W, NHV, IMBV, ACT_RELU>(grad, X, Wt, B, in_dim, out_dim, act, gi, gw, partial, st) \
-                     : launch_backward_fused_k<W, NHV, IMBV, -1>(grad, X, Wt, B, in_dim, out_dim, act, gi, gw, partial, st))
+    (act == ACT_RELU ? launch_backward_fused_k<W, NHV, IMBV, ACT_RELU>(grad, X, Wt, B, in_dim, out_dim, act, gi, gw, partial, in_layout, st) \
+                     : launch_backward_fused_k<W, NHV, IMBV, -1>(grad, X, Wt, B, in_dim, out_dim, act, gi, gw, partial, in_layout, st))
     if (IMB == 1) {
         if (NH == 1) return S3D_FUSED(1, 1);
         if (NH == 2) return S3D_FUSED(2, 1);
@@ -847,24 +876,25 @@ using namespace s3d;
 S3D_EXPORT int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                                  uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                                  uint32_t output_activation, uint16_t* forward_buffer, uint16_t* outputs,
-                                 s3d_stream_t stream) {
+                                 int input_layout, s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(inputs && weights && outputs, "ffmlp_forward: null pointer");
+    S3D_REQUIRE(input_layout == 0 || input_layout == 1, "ffmlp_forward: input_layout must be 0 (row-major) or 1 (level-major [in/2][B][2])");
     if (int rc = check_shape(B, input_dim, output_dim, hidden_dim, num_layers)) return rc;
     S3D_REQUIRE(output_dim == 16, "ffmlp_forward: the output must be padded to 16 columns (ffmlp.py:117)");
     const _Float16* X = (const _Float16*)inputs; const _Float16* Wt = (const _Float16*)weights;
     _Float16* fb = (_Float16*)forward_buffer; _Float16* o = (_Float16*)outputs;
-    if (hidden_dim == 64) return launch_forward<64>(X, Wt, B, input_dim, output_dim, num_layers, activation, output_activation, fb, o, as_stream(stream));
-    return launch_forward<32>(X, Wt, B, input_dim, output_dim, num_layers, activation, output_activation, fb, o, as_stream(stream));
+    if (hidden_dim == 64) return launch_forward<64>(X, Wt, B, input_dim, output_dim, num_layers, activation, output_activation, fb, o, (uint32_t)input_layout, as_stream(stream));
+    return launch_forward<32>(X, Wt, B, input_dim, output_dim, num_layers, activation, output_activation, fb, o, (uint32_t)input_layout, as_stream(stream));
 }
 
 S3D_EXPORT int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                                    uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                                    uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,
-                                   s3d_stream_t stream) {
+                                   int input_layout, s3d_stream_t stream) {
     (void)inference_buffer;
     return s3d_ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                             output_activation, nullptr, outputs, stream);
+                             output_activation, nullptr, outputs, input_layout, stream);
 }
 
 S3D_EXPORT size_t s3d_ffmlp_backward_workspace_size(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
@@ -878,8 +908,10 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
                                   uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                                   uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer,
                                   uint16_t* grad_inputs, uint16_t* grad_weights, void* workspace, size_t workspace_bytes,
-                                  s3d_stream_t stream) {
+                                  int input_layout, s3d_stream_t stream) {
     (void)output_activation;
+    S3D_REQUIRE(input_layout == 0 || (input_layout == 1 && !forward_buffer),
+                "ffmlp_backward: the level-major input layout is implemented by the fused backward (no forward_buffer)");
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(grad && inputs && weights && grad_weights, "ffmlp_backward: null pointer");
     S3D_REQUIRE((forward_buffer == nullptr) == (backward_buffer == nullptr),
@@ -897,10 +929,10 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
         if (hidden_dim == 64)
             return launch_backward_fused<64>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights, B, input_dim,
                                              output_dim, num_layers, activation, gi, (_Float16*)grad_weights, (float*)workspace,
-                                             as_stream(stream));
+                                             (uint32_t)input_layout, as_stream(stream));
         return launch_backward_fused<32>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights, B, input_dim,
                                          output_dim, num_layers, activation, gi, (_Float16*)grad_weights, (float*)workspace,
-                                         as_stream(stream));
+                                         (uint32_t)input_layout, as_stream(stream));
     }
     if (hidden_dim == 64)
         return launch_backward<64>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights,

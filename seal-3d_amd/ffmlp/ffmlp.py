@@ -44,8 +44,8 @@ class _FFMLPForward(Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.half)
     def forward(ctx, inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
-                inference=False, calc_grad_inputs=False, param_ref=None, hook=None):
-        B = inputs.shape[0]
+                inference=False, calc_grad_inputs=False, param_ref=None, hook=None, input_layout=0):
+        B = inputs.shape[1] if input_layout else inputs.shape[0]
         # outside autocast `custom_fwd` does not cast: the kernels are fp16-only, so cast here (the autograd
         # engine converts the returned fp16 gradients back to the parameter dtype)
         inputs = inputs.to(torch.half).contiguous()
@@ -53,8 +53,12 @@ class _FFMLPForward(Function):
         outputs = torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
         if inference:
             scratch = torch.empty(B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
-            _backend.ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                                     output_activation, scratch, outputs)
+            if input_layout:
+                _backend.ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                                         output_activation, scratch, outputs, input_layout=input_layout)
+            else:
+                _backend.ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                                         output_activation, scratch, outputs)
             return outputs
         # The reference stores every layer's activations for the backward pass (forward_buffer [n, B, W]).  Where the
         # fused backward kernel covers the shape, nothing is stored: it re-computes the activations from `inputs` on chip
@@ -62,13 +66,20 @@ class _FFMLPForward(Function):
         fused = _FUSED_BACKWARD and getattr(_backend, "fused_backward_supported", None) is not None and \
             _backend.fused_backward_supported(input_dim, output_dim, hidden_dim, num_layers, activation)
         forward_buffer = None if fused else torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
-        _backend.ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                               output_activation, forward_buffer, outputs)
+        if input_layout:
+            if not fused:
+                raise RuntimeError("FFMLP: the level-major input layout needs the fused backward kernel for this shape")
+            _backend.ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                                   output_activation, forward_buffer, outputs, input_layout=input_layout)
+        else:
+            _backend.ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                                   output_activation, forward_buffer, outputs)
         if fused:
             ctx.save_for_backward(inputs, weights)
         else:
             ctx.save_for_backward(inputs, weights, forward_buffer)
         ctx.meta = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs, fused)
+        ctx.input_layout = input_layout
         ctx.param_ref = param_ref
         return outputs
 
@@ -88,9 +99,14 @@ class _FFMLPForward(Function):
                        else torch.zeros(1, device=grad.device, dtype=grad.dtype))
         grad_weights = torch.zeros_like(weights)
         backward_buffer = None if fused else torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
-        _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim,
-                                num_layers, activation, output_activation, calc_grad_inputs, backward_buffer,
-                                grad_inputs, grad_weights)
+        if ctx.input_layout:
+            _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim,
+                                    num_layers, activation, output_activation, calc_grad_inputs, backward_buffer,
+                                    grad_inputs, grad_weights, input_layout=ctx.input_layout)
+        else:
+            _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim,
+                                    num_layers, activation, output_activation, calc_grad_inputs, backward_buffer,
+                                    grad_inputs, grad_weights)
         # fp16 hand-over (nerf.optim.NativeAdam): the weight gradient is added to the optimizer's fp16 buffer instead of
         # being returned to autograd (fp32 cast + accumulate)
         stash = getattr(ctx.param_ref.param, "_s3d_grad", None) if ctx.param_ref is not None else None
@@ -98,7 +114,7 @@ class _FFMLPForward(Function):
             stash.add_(grad_weights.view(stash.shape))
             ctx.param_ref.param._s3d_grad_touched = True
             grad_weights = None
-        return ((grad_inputs if calc_grad_inputs else None), grad_weights) + (None,) * 10
+        return ((grad_inputs if calc_grad_inputs else None), grad_weights) + (None,) * 11
 
 
 ffmlp_forward = _FFMLPForward.apply
@@ -149,9 +165,15 @@ class FFMLP(nn.Module):
             out = out[:, :self.output_dim]
         return out
 
-    def forward_padded(self, inputs):
+    def forward_padded(self, inputs, level_major=False):
         """forward() before the final column slice: [B, padded_output_dim] (columns >= output_dim are exact zeros'
-        products: the padded weight rows).  Fused consumers (nerf/network_ff.py) read the 16-column rows directly."""
+        products: the padded weight rows).  Fused consumers (nerf/network_ff.py) read the 16-column rows directly.
+        `level_major=True`: `inputs` is the grid encoder's [L, B, C] tensor (input_dim = L * C, C = 2, B % 128 == 0)."""
+        if level_major:
+            L, B, C = inputs.shape
+            if C != 2 or L * C != self.input_dim or B % 128 != 0:
+                raise RuntimeError("FFMLP level-major input: need [input_dim / 2, B, 2] with B % 128 == 0")
+            return self._run(inputs, 1)
         B, C = inputs.shape
         # The reference always appends 128 - B % 128 zero rows (a full extra block when B is already aligned,
         # ffmlp.py:156-159) and slices them off again: results do not depend on it, and the copy is a full pass over the
@@ -159,6 +181,12 @@ class FFMLP(nn.Module):
         pad = (-B) % 128
         if pad > 0:
             inputs = torch.cat([inputs, torch.zeros(pad, C, dtype=inputs.dtype, device=inputs.device)], dim=0)
+        out = self._run(inputs, 0)
+        if B != out.shape[0]:
+            out = out[:B]
+        return out
+
+    def _run(self, inputs, input_layout):
         w, ref, hook = self.weights, None, None
         if getattr(w, "_s3d_grad", None) is not None and getattr(w, "_s3d_half_version", None) == w._version:
             # a native optimizer maintains the fp16 copy of the weights and takes their gradient as an fp16 buffer
@@ -170,7 +198,5 @@ class FFMLP(nn.Module):
             w = w._s3d_half
         out = ffmlp_forward(inputs, w, self.input_dim, self.padded_output_dim, self.hidden_dim,
                             self.num_layers, self.activation, self.output_activation, not self.training,
-                            inputs.requires_grad, ref, hook)
-        if B != out.shape[0]:
-            out = out[:B]
+                            inputs.requires_grad, ref, hook, input_layout)
         return out

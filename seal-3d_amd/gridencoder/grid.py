@@ -53,7 +53,7 @@ class _GridEncode(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False,
-                gridtype=0, align_corners=False, interpolation=0, cache_half=False):
+                gridtype=0, align_corners=False, interpolation=0, cache_half=False, level_major=False):
         inputs = inputs.contiguous()
         B, D = inputs.shape
         L = offsets.shape[0] - 1
@@ -75,10 +75,11 @@ class _GridEncode(Function):
                  if calc_grad_inputs else None)
         _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype,
                                      align_corners, interpolation)
-        outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
+        if not level_major:  # (a fused consumer reads the kernel's own [L, B, C] layout in place: ffmlp input_layout=1)
+            outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
 
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
-        ctx.meta = (B, D, C, L, S, H, gridtype, interpolation, align_corners)
+        ctx.meta = (B, D, C, L, S, H, gridtype, interpolation, align_corners, level_major)
         ctx.param = param
         return outputs
 
@@ -86,8 +87,11 @@ class _GridEncode(Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, grad):
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
-        B, D, C, L, S, H, gridtype, interpolation, align_corners = ctx.meta
-        grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()  # [L, B, C]
+        B, D, C, L, S, H, gridtype, interpolation, align_corners, level_major = ctx.meta
+        if level_major:
+            grad = grad.contiguous()  # already [L, B, C]
+        else:
+            grad = grad.view(B, L, C).permute(1, 0, 2).contiguous()  # [L, B, C]
         # fp16 hand-over (nerf.optim.NativeAdam): the table gradient is ACCUMULATED into the optimizer's fp16 buffer and
         # not returned to autograd, which would cast it to fp32 and add it into `.grad` (220 MB of traffic per step)
         stash = getattr(ctx.param, "_s3d_grad", None)
@@ -102,7 +106,7 @@ class _GridEncode(Function):
                                       grad_inputs, gridtype, align_corners, interpolation)
         if grad_inputs is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
-        return grad_inputs, (None if stash is not None else grad_embeddings), None, None, None, None, None, None, None, None
+        return grad_inputs, (None if stash is not None else grad_embeddings), None, None, None, None, None, None, None, None, None
 
 
 grid_encode = _GridEncode.apply
@@ -157,13 +161,17 @@ class GridEncoder(nn.Module):
                 f"params={tuple(self.embeddings.shape)} gridtype={self.gridtype} align_corners={self.align_corners} "
                 f"interpolation={self.interpolation}")
 
-    def forward(self, inputs, bound=1):
+    def forward(self, inputs, bound=1, level_major=False):
+        """`level_major=True` (build extension, 2-D inputs only) returns the kernel's own [num_levels, B, level_dim] layout
+        instead of the reference's [B, num_levels * level_dim] — what ffmlp's `input_layout=1` consumes without a copy."""
         inputs = (inputs + bound) / (2 * bound)  # [-bound, bound] -> [0, 1]
         lead = list(inputs.shape[:-1])
         inputs = inputs.view(-1, self.input_dim)
         out = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
                           inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id,
-                          not self.training)
+                          not self.training, level_major)
+        if level_major:
+            return out
         return out.view(lead + [self.output_dim])
 
     @torch.autocast("cuda", enabled=False)

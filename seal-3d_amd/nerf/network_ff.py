@@ -91,7 +91,10 @@ class NeRFNetwork(NeRFRenderer):
 
     def forward(self, x, d):
         if self._can_fuse(x):
-            h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound))
+            if x.dim() == 2 and x.shape[0] % 128 == 0:  # level-major hand-over: no permute copy in either direction
+                h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound, level_major=True), level_major=True)
+            else:
+                h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound))
             sigma, cin = _NgpMid.apply(h.contiguous(), d.float().contiguous())
             return sigma, _NgpRgb.apply(self.color_net.forward_padded(cin).contiguous())
         sigma, geo_feat = self._sigma(x)

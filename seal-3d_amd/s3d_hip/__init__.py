@@ -345,21 +345,22 @@ class FFMLPBackend:
 
     @staticmethod
     def ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                      output_activation, forward_buffer, outputs):
+                      output_activation, forward_buffer, outputs, input_layout=0):
         _need(inputs, torch.float16, "inputs")
         _need(weights, torch.float16, "weights")
         _check(lib().s3d_ffmlp_forward(_p(inputs), _p(weights), _u(B), _u(input_dim), _u(output_dim), _u(hidden_dim),
                                        _u(num_layers), _u(activation), _u(output_activation), _p(forward_buffer),
-                                       _p(outputs), _stream()), "ffmlp_forward")
+                                       _p(outputs), C.c_int(int(input_layout)), _stream()), "ffmlp_forward")
 
     @staticmethod
     def ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                        output_activation, inference_buffer, outputs):
+                        output_activation, inference_buffer, outputs, input_layout=0):
         _need(inputs, torch.float16, "inputs")
         _need(weights, torch.float16, "weights")
         _check(lib().s3d_ffmlp_inference(_p(inputs), _p(weights), _u(B), _u(input_dim), _u(output_dim),
                                          _u(hidden_dim), _u(num_layers), _u(activation), _u(output_activation),
-                                         _p(inference_buffer), _p(outputs), _stream()), "ffmlp_inference")
+                                         _p(inference_buffer), _p(outputs), C.c_int(int(input_layout)), _stream()),
+               "ffmlp_inference")
 
     @staticmethod
     def fused_backward_supported(input_dim, output_dim, hidden_dim, num_layers, activation):
@@ -369,7 +370,8 @@ class FFMLPBackend:
 
     @staticmethod
     def ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers,
-                       activation, output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights):
+                       activation, output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights,
+                       input_layout=0):
         _need(grad, torch.float16, "grad")
         nbytes = lib().s3d_ffmlp_backward_workspace_size(_u(input_dim), _u(output_dim), _u(hidden_dim),
                                                         _u(num_layers))
@@ -378,8 +380,8 @@ class FFMLPBackend:
                                         _u(output_dim), _u(hidden_dim), _u(num_layers), _u(activation),
                                         _u(output_activation), C.c_int(int(bool(calc_grad_inputs))),
                                         _p(backward_buffer), _p(grad_inputs if calc_grad_inputs else None),
-                                        _p(grad_weights), _p(ws), C.c_size_t(ws.numel()), _stream()),
-               "ffmlp_backward")
+                                        _p(grad_weights), _p(ws), C.c_size_t(ws.numel()), C.c_int(int(input_layout)),
+                                        _stream()), "ffmlp_backward")
 
 
 class OptimBackend:

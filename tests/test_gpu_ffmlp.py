@@ -115,3 +115,25 @@ def test_ffmlp_rejects_bad_shapes(hip):
     x = torch.zeros(128, 32, dtype=torch.half, device="cuda")
     with pytest.raises(RuntimeError, match="not supported"):
         hip.FFMLPBackend.ffmlp_forward(x, w, 128, 32, 16, 128, 2, 0, 6, None, torch.empty(128, 16, dtype=torch.half, device="cuda"))
+
+
+def test_ffmlp_level_major_input_layout(hip):
+    """input_layout=1 reads the grid encoder's [L, B, 2] tensor in place and writes grad_inputs in the same layout: results
+    must be bit-identical to the row-major call on the permuted data (same fragments, same MFMA sequence)."""
+    in_dim, W, n, B = 32, 64, 2, 128 * 21
+    g = torch.Generator().manual_seed(5)
+    w = _weights(in_dim, W, n).half().cuda()
+    x = (torch.randn(B, in_dim, generator=g) * 0.5).half().cuda()
+    xl = x.view(B, in_dim // 2, 2).permute(1, 0, 2).contiguous()                 # [L, B, 2]
+    grad = (torch.randn(B, 16, generator=g) * 0.1).half().cuda()
+    F = hip.FFMLPBackend
+    outs = []
+    for layout, xin in ((0, x), (1, xl)):
+        out = torch.empty(B, 16, dtype=torch.half, device="cuda")
+        F.ffmlp_forward(xin, w, B, in_dim, 16, W, n, 0, 6, None, out, input_layout=layout)
+        gi = torch.empty_like(xin)
+        gw = torch.zeros_like(w)
+        F.ffmlp_backward(grad, xin, w, None, B, in_dim, 16, W, n, 0, 6, True, None, gi, gw, input_layout=layout)
+        outs.append((out, gi if layout == 0 else gi.permute(1, 0, 2).reshape(B, in_dim), gw))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a.view(torch.int16), b.contiguous().view(torch.int16))
