@@ -120,11 +120,13 @@ void s3d_grid_level_scales(uint32_t L, float S, uint32_t H, float* scales_out /*
 /* gridencoder.h:12 void grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H,
  *                        dy_dx, gridtype, align_corners, interp)
  * inputs [B,D] f32 in [0,1]; embeddings [sO,C] dtype; offsets [L+1] i32; outputs [L,B,C] dtype;
- * dy_dx [B,L,D,C] dtype or NULL. */
+ * dy_dx [B,L,D,C] dtype or NULL.
+ * bound: 0 = inputs already in [0,1] (the reference's native contract); > 0 = raw coordinates in [-bound, bound],
+ * normalised in the kernel exactly like GridEncoder.forward does in torch (grid.py:146), dy_dx must be NULL. */
 int s3d_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets,
                             void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                             uint32_t H, void* dy_dx, uint32_t gridtype, int align_corners,
-                            uint32_t interp, int dtype, s3d_stream_t stream);
+                            uint32_t interp, int dtype, float bound, s3d_stream_t stream);
 
 /* Test hook: table row of every corner, corner_idx [B,L,2^D] u32 (0xffffffff for out-of-range points). */
 int s3d_grid_corner_indices(const float* inputs, const int32_t* offsets, uint32_t* corner_idx, uint32_t B,
@@ -146,7 +148,7 @@ int s3d_grid_encode_backward(const void* grad, const float* inputs, const void* 
                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                              const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                              uint32_t interp, int dtype, void* workspace, size_t workspace_bytes,
-                             s3d_stream_t stream);
+                             float bound, s3d_stream_t stream);
 /* experiments/tests: 0 = auto, 1 = direct atomics, 2 = binned (partition + LDS accumulate) */
 void s3d_grid_backward_set_path(int path);
 
@@ -187,7 +189,8 @@ int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_
                         uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                         uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,
                         int input_layout, s3d_stream_t stream);
-/* ffmlp.h:11; grad_weights fp16 [same layout as weights], zero-initialised by the caller.
+/* ffmlp.h:11; grad_weights fp16 [same layout as weights]: every element is written (accumulate_grad_weights = 0,
+ * the reference zero-fills it first, ffmlp.py:72) or added to (accumulate_grad_weights = 1).
  * workspace: fp32 accumulation of the weight gradient (s3d_ffmlp_backward_workspace_size).
  * forward_buffer == backward_buffer == NULL selects the fused backward: the activations are re-computed from
  * `inputs` inside one kernel that also forms the data and weight gradients, so a training forward may skip
@@ -202,7 +205,8 @@ int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
                        uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                        uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer,
                        uint16_t* grad_inputs, uint16_t* grad_weights, void* workspace,
-                       size_t workspace_bytes, int input_layout, s3d_stream_t stream);
+                       size_t workspace_bytes, int input_layout, int accumulate_grad_weights,
+                       s3d_stream_t stream);
 /* ffmlp.h:13-14: the reference allocates split-K side streams here; this build fuses the weight
  * gradient into the backward launch sequence on the caller's stream, so these are no-ops kept for
  * surface compatibility. */

@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_wgrad(WgradPlan plan, uint32_t B,
 // 256 partials was latency-bound: ~20 us), then a fixed xor-shuffle tree combines the eight.  Deterministic.
 constexpr uint32_t kReduceSplit = 8;
 __global__ void k_ffmlp_wgrad_reduce(WgradPlan plan, uint32_t nblk, const float* __restrict__ partial,
-                                     _Float16* __restrict__ grad_weights) {
+                                     _Float16* __restrict__ grad_weights, uint32_t accumulate) {
     const WgradLayer L = plan.layer[blockIdx.y];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t e = t / kReduceSplit, part = t % kReduceSplit;
@@ -454,7 +454,10 @@ __global__ void k_ffmlp_wgrad_reduce(WgradPlan plan, uint32_t nblk, const float*
     float v = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int d = 1; d < (int)kReduceSplit; d <<= 1) v += __shfl_xor(v, d, 64);
-    if (live && part == 0) grad_weights[L.w_off + e] = (_Float16)v;
+    if (live && part == 0) {
+        if (accumulate) v += (float)grad_weights[L.w_off + e];  // add to the caller's running gradient (fp16 hand-over buffer)
+        grad_weights[L.w_off + e] = (_Float16)v;
+    }
 }
 
 // ------------------------------------------------------------------------------------ backward: fused
@@ -770,7 +773,7 @@ int launch_forward(const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t i
 template <int W>
 int launch_backward(const _Float16* grad, const _Float16* X, const _Float16* Wt, const _Float16* fwd, uint32_t B,
                     uint32_t in_dim, uint32_t out_dim, uint32_t n_layers, uint32_t act, _Float16* bwd,
-                    _Float16* grad_inputs, _Float16* grad_weights, float* partial, hipStream_t st) {
+                    _Float16* grad_inputs, _Float16* grad_weights, float* partial, uint32_t accumulate, hipStream_t st) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
     const uint32_t NH = n_layers - 1;
     const uint32_t nfr = MB + NH * MB * KS + (grad_inputs ? ((in_dim + 31) / 32) * KS : 0);
@@ -802,7 +805,7 @@ int launch_backward(const _Float16* grad, const _Float16* X, const _Float16* Wt,
     if (nblk > kWgradBlocks) nblk = kWgradBlocks;
     hipLaunchKernelGGL((k_ffmlp_wgrad<W>), dim3(nblk, plan.n), dim3(256), 0, st, plan, B, partial);
     hipLaunchKernelGGL(k_ffmlp_wgrad_reduce, dim3(div_up<uint32_t>(W * W * kReduceSplit, 256), plan.n), dim3(256), 0, st, plan, nblk,
-                       (const float*)partial, grad_weights);
+                       (const float*)partial, grad_weights, accumulate);
     return check_launch("ffmlp_backward");
 }
 
@@ -818,7 +821,7 @@ inline bool fused_backward_supported(uint32_t in_dim, uint32_t out_dim, uint32_t
 template <int W, int NH, int IMB, int ACT>
 int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t in_dim,
                             uint32_t out_dim, uint32_t act, _Float16* grad_inputs, _Float16* grad_weights, float* partial,
-                            uint32_t in_layout, hipStream_t st) {
+                            uint32_t in_layout, uint32_t accumulate, hipStream_t st) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
     const uint32_t nfrag = MB * (in_dim / 16) + NH * MB * KS + MB + NH * MB * KS + (grad_inputs ? IMB * KS : 0);
     size_t smem = (size_t)nfrag * 64 * sizeof(half8) + (size_t)4 * 2 * kTRows * kTRow * sizeof(_Float16);
@@ -842,18 +845,18 @@ int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Floa
         plan.layer[1 + m] = WgradLayer{nullptr, nullptr, 0u, 0u, (uint32_t)W, (uint32_t)W, (uint32_t)(W * in_dim + m * W * W)};
     plan.layer[NH + 1] = WgradLayer{nullptr, nullptr, 0u, 0u, 16u, (uint32_t)W, (uint32_t)(W * in_dim + NH * W * W)};
     hipLaunchKernelGGL(k_ffmlp_wgrad_reduce, dim3(div_up<uint32_t>(W * W * kReduceSplit, 256), plan.n), dim3(256), 0, st, plan, nblk,
-                       (const float*)partial, grad_weights);
+                       (const float*)partial, grad_weights, accumulate);
     return check_launch("ffmlp_backward (fused)");
 }
 
 template <int W>
 int launch_backward_fused(const _Float16* grad, const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t in_dim,
                           uint32_t out_dim, uint32_t n_layers, uint32_t act, _Float16* gi, _Float16* gw, float* partial,
-                          uint32_t in_layout, hipStream_t st) {
+                          uint32_t in_layout, uint32_t accumulate, hipStream_t st) {
     const uint32_t NH = n_layers - 1, IMB = (in_dim + 31) / 32;
 #define S3D_FUSED(NHV, IMBV)                                                                                              \
-    (act == ACT_RELU ? launch_backward_fused_k<W, NHV, IMBV, ACT_RELU>(grad, X, Wt, B, in_dim, out_dim, act, gi, gw, partial, in_layout, st) \
-                     : launch_backward_fused_k<W, NHV, IMBV, -1>(grad, X, Wt, B, in_dim, out_dim, act, gi, gw, partial, in_layout, st))
+    (act == ACT_RELU ? launch_backward_fused_k<W, NHV, IMBV, ACT_RELU>(grad, X, Wt, B, in_dim, out_dim, act, gi, gw, partial, in_layout, accumulate, st) \
+                     : launch_backward_fused_k<W, NHV, IMBV, -1>(grad, X, Wt, B, in_dim, out_dim, act, gi, gw, partial, in_layout, accumulate, st))
     if (IMB == 1) {
         if (NH == 1) return S3D_FUSED(1, 1);
         if (NH == 2) return S3D_FUSED(2, 1);
@@ -908,8 +911,9 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
                                   uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                                   uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer,
                                   uint16_t* grad_inputs, uint16_t* grad_weights, void* workspace, size_t workspace_bytes,
-                                  int input_layout, s3d_stream_t stream) {
+                                  int input_layout, int accumulate_grad_weights, s3d_stream_t stream) {
     (void)output_activation;
+    const uint32_t accumulate = accumulate_grad_weights ? 1u : 0u;
     S3D_REQUIRE(input_layout == 0 || (input_layout == 1 && !forward_buffer),
                 "ffmlp_backward: the level-major input layout is implemented by the fused backward (no forward_buffer)");
     if (B == 0) return S3D_OK;
@@ -929,18 +933,18 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
         if (hidden_dim == 64)
             return launch_backward_fused<64>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights, B, input_dim,
                                              output_dim, num_layers, activation, gi, (_Float16*)grad_weights, (float*)workspace,
-                                             (uint32_t)input_layout, as_stream(stream));
+                                             (uint32_t)input_layout, accumulate, as_stream(stream));
         return launch_backward_fused<32>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights, B, input_dim,
                                          output_dim, num_layers, activation, gi, (_Float16*)grad_weights, (float*)workspace,
-                                         (uint32_t)input_layout, as_stream(stream));
+                                         (uint32_t)input_layout, accumulate, as_stream(stream));
     }
     if (hidden_dim == 64)
         return launch_backward<64>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights,
                                    (const _Float16*)forward_buffer, B, input_dim, output_dim, num_layers, activation,
-                                   (_Float16*)backward_buffer, gi, (_Float16*)grad_weights, (float*)workspace, as_stream(stream));
+                                   (_Float16*)backward_buffer, gi, (_Float16*)grad_weights, (float*)workspace, accumulate, as_stream(stream));
     return launch_backward<32>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights,
                                (const _Float16*)forward_buffer, B, input_dim, output_dim, num_layers, activation,
-                               (_Float16*)backward_buffer, gi, (_Float16*)grad_weights, (float*)workspace, as_stream(stream));
+                               (_Float16*)backward_buffer, gi, (_Float16*)grad_weights, (float*)workspace, accumulate, as_stream(stream));
 }
 
 S3D_EXPORT int s3d_ffmlp_fused_backward_supported(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,

@@ -25,7 +25,9 @@ namespace s3d {
 namespace {
 
 constexpr uint32_t kMaxLevels = 32;
-struct LevelScales { float v[kMaxLevels]; };
+// per-level scales + the optional input normalisation of GridEncoder.forward (grid.py:146: x01 = (x + bound) / (2 bound),
+// evaluated as torch's GPU kernels do: one add, one multiply by the fp32 reciprocal); bound = 0: inputs are already in [0,1]
+struct LevelScales { float v[kMaxLevels]; float bound, inv_2bound; };
 
 constexpr uint32_t kPrimes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
 
@@ -100,11 +102,12 @@ template <> struct Acc<__half> {
 };
 
 template <uint32_t D>
-__device__ __forceinline__ bool load_point(const float* __restrict__ inputs, uint32_t b, float (&x)[D]) {
+__device__ __forceinline__ bool load_point(const float* __restrict__ inputs, uint32_t b, const LevelScales& sc, float (&x)[D]) {
     bool oob = false;
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
         x[d] = inputs[(size_t)b * D + d];
+        if (sc.bound != 0.0f) x[d] = (x[d] + sc.bound) * sc.inv_2bound;
         if (x[d] < 0 || x[d] > 1) oob = true;
     }
     return oob;
@@ -139,7 +142,7 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward(const float* __restr
     const uint32_t b = (blockIdx.x / kXcds) * kFwdBlock + threadIdx.x;
     if (b >= B || xcd >= L) return;
     float x[D];
-    const bool oob = load_point<D>(inputs, b, x);
+    const bool oob = load_point<D>(inputs, b, scales, x);
 
     for (uint32_t level = xcd; level < L; level += kXcds) {
         T* out = outputs + ((size_t)level * B + b) * C;
@@ -237,7 +240,7 @@ __global__ void k_grid_corner_rows(const float* __restrict__ inputs, const int32
     const uint32_t level = blockIdx.y;
     if (b >= B) return;
     float x[D];
-    const bool oob = load_point<D>(inputs, b, x);
+    const bool oob = load_point<D>(inputs, b, scales, x);
     uint32_t* o = corner_idx + ((size_t)b * L + level) * (1u << D);
     if (oob) {
         for (uint32_t i = 0; i < (1u << D); i++) o[i] = 0xffffffffu;
@@ -269,7 +272,7 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_backward(const T* __restrict
     const uint32_t b = (blockIdx.x / kXcds) * kFwdBlock + threadIdx.x;
     if (b >= B || xcd >= L) return;
     float x[D];
-    if (load_point<D>(inputs, b, x)) return;  // grad is zero-initialised by the caller
+    if (load_point<D>(inputs, b, scales, x)) return;  // grad is zero-initialised by the caller
 
     for (uint32_t level = xcd; level < L; level += kXcds) {
         const uint32_t off = (uint32_t)offsets[level];
@@ -474,7 +477,7 @@ __global__ void __launch_bounds__(kBinCountThreads) k_bin_count(const T* __restr
             const uint32_t b = b0 + u * kBinCountThreads;
             in[u] = b < b_end;
             if (in[u]) {
-                in[u] = !load_point<D>(inputs, b, x[u]);
+                in[u] = !load_point<D>(inputs, b, scales, x[u]);
                 load_feat<T, C>(grad + ((size_t)level * B + b) * C, g[u]);
             }
         }
@@ -536,7 +539,7 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const T* __restrict__ grad
     T g[C];
     bool inside = b < B;
     if (inside) {
-        inside = !load_point<D>(inputs, b, x);
+        inside = !load_point<D>(inputs, b, scales, x);
         load_feat<T, C>(grad + ((size_t)level * B + b) * C, g);
     }
     constexpr uint32_t kPer = kBinMaxSlices / 64;
@@ -787,7 +790,7 @@ __global__ void __launch_bounds__(kFwdBlock) k_grad_tv(const float* __restrict__
     const uint32_t b = (blockIdx.x / kXcds) * kFwdBlock + threadIdx.x;
     if (b >= B || xcd >= L) return;
     float x[D];
-    if (load_point<D>(inputs, b, x)) return;
+    if (load_point<D>(inputs, b, scales, x)) return;
     for (uint32_t level = xcd; level < L; level += kXcds) {
         const uint32_t off = (uint32_t)offsets[level];
         const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
@@ -838,7 +841,9 @@ __global__ void __launch_bounds__(kFwdBlock) k_grad_tv(const float* __restrict__
     }
 }
 
-void host_scales(uint32_t L, float S, uint32_t H, LevelScales& out) {
+void host_scales(uint32_t L, float S, uint32_t H, LevelScales& out, float bound = 0.0f) {
+    out.bound = bound;
+    out.inv_2bound = bound != 0.0f ? 1.0f / (2.0f * bound) : 0.0f;
     for (uint32_t l = 0; l < kMaxLevels; l++) out.v[l] = 0.0f;
     for (uint32_t l = 0; l < L; l++) out.v[l] = fmaf(exp2f((float)l * S), (float)H, -1.0f);
 }
@@ -997,14 +1002,16 @@ S3D_EXPORT void s3d_grid_level_scales(uint32_t L, float S, uint32_t H, float* sc
 S3D_EXPORT int s3d_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets,
                                        void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                        void* dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
-                                       s3d_stream_t stream) {
+                                       float bound, s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward: null pointer");
+    S3D_REQUIRE(bound >= 0.0f && !(bound != 0.0f && dy_dx), "grid_encode_forward: bound must be >= 0 (0 = inputs in [0,1]); "
+                "the input Jacobian is only produced for pre-normalised inputs");
     S3D_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_forward: L must be in [1, %u]", kMaxLevels);
     S3D_REQUIRE(dtype == S3D_F32 || dtype == S3D_F16, "grid_encode_forward: dtype must be f32 or f16");
     S3D_REQUIRE((uint64_t)B * L * C < (1ull << 32), "grid_encode_forward: B*L*C overflows 32 bits");
     LevelScales sc;
-    host_scales(L, S, H, sc);
+    host_scales(L, S, H, sc, bound);
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
     if (dtype == S3D_F32) {
@@ -1062,8 +1069,9 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
                                         uint32_t max_level_rows, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                         const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                                         uint32_t interp, int dtype, void* workspace, size_t workspace_bytes,
-                                        s3d_stream_t stream) {
+                                        float bound, s3d_stream_t stream) {
     (void)embeddings;
+    S3D_REQUIRE(bound >= 0.0f && !(bound != 0.0f && dy_dx), "grid_encode_backward: bound must be >= 0 and 0 with an input Jacobian");
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null pointer");
     S3D_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_backward: L must be in [1, %u]", kMaxLevels);
@@ -1075,7 +1083,7 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
                     "s3d_grid_encode_backward_workspace_size() bytes");
     }
     LevelScales sc;
-    host_scales(L, S, H, sc);
+    host_scales(L, S, H, sc, bound);
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
     unsigned char* ws = (unsigned char*)workspace;

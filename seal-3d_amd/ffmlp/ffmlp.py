@@ -97,21 +97,20 @@ class _FFMLPForward(Function):
         # build allocates them uninitialised (saves two B x hidden x num_layers memsets per MLP per step)
         grad_inputs = (torch.empty_like(inputs) if calc_grad_inputs
                        else torch.zeros(1, device=grad.device, dtype=grad.dtype))
-        grad_weights = torch.zeros_like(weights)
+        # fp16 hand-over (nerf.optim.NativeAdam): the reduce kernel ADDS the weight gradient to the optimizer's fp16 buffer
+        # instead of returning it to autograd (fp32 cast + accumulate)
+        stash = getattr(ctx.param_ref.param, "_s3d_grad", None) if ctx.param_ref is not None else None
+        grad_weights = stash.view(weights.shape) if stash is not None else torch.empty_like(weights)  # every element is written
         backward_buffer = None if fused else torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
-        if ctx.input_layout:
+        if ctx.input_layout or stash is not None:
             _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim,
                                     num_layers, activation, output_activation, calc_grad_inputs, backward_buffer,
-                                    grad_inputs, grad_weights, input_layout=ctx.input_layout)
+                                    grad_inputs, grad_weights, input_layout=ctx.input_layout, accumulate=stash is not None)
         else:
             _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim,
                                     num_layers, activation, output_activation, calc_grad_inputs, backward_buffer,
                                     grad_inputs, grad_weights)
-        # fp16 hand-over (nerf.optim.NativeAdam): the weight gradient is added to the optimizer's fp16 buffer instead of
-        # being returned to autograd (fp32 cast + accumulate)
-        stash = getattr(ctx.param_ref.param, "_s3d_grad", None) if ctx.param_ref is not None else None
         if stash is not None:
-            stash.add_(grad_weights.view(stash.shape))
             ctx.param_ref.param._s3d_grad_touched = True
             grad_weights = None
         return ((grad_inputs if calc_grad_inputs else None), grad_weights) + (None,) * 11

@@ -53,7 +53,7 @@ class _GridEncode(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False,
-                gridtype=0, align_corners=False, interpolation=0, cache_half=False, level_major=False):
+                gridtype=0, align_corners=False, interpolation=0, cache_half=False, level_major=False, bound=0.0):
         inputs = inputs.contiguous()
         B, D = inputs.shape
         L = offsets.shape[0] - 1
@@ -73,13 +73,17 @@ class _GridEncode(Function):
         outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)  # level-major
         dy_dx = (torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype)
                  if calc_grad_inputs else None)
-        _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype,
-                                     align_corners, interpolation)
+        if bound:
+            _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype,
+                                         align_corners, interpolation, bound=bound)
+        else:
+            _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype,
+                                         align_corners, interpolation)
         if not level_major:  # (a fused consumer reads the kernel's own [L, B, C] layout in place: ffmlp input_layout=1)
             outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
 
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
-        ctx.meta = (B, D, C, L, S, H, gridtype, interpolation, align_corners, level_major)
+        ctx.meta = (B, D, C, L, S, H, gridtype, interpolation, align_corners, level_major, bound)
         ctx.param = param
         return outputs
 
@@ -87,7 +91,7 @@ class _GridEncode(Function):
     @custom_bwd(device_type="cuda")
     def backward(ctx, grad):
         inputs, embeddings, offsets, dy_dx = ctx.saved_tensors
-        B, D, C, L, S, H, gridtype, interpolation, align_corners, level_major = ctx.meta
+        B, D, C, L, S, H, gridtype, interpolation, align_corners, level_major, bound = ctx.meta
         if level_major:
             grad = grad.contiguous()  # already [L, B, C]
         else:
@@ -102,11 +106,15 @@ class _GridEncode(Function):
             stash = None
             grad_embeddings = torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
-        _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
-                                      grad_inputs, gridtype, align_corners, interpolation)
+        if bound:
+            _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
+                                          grad_inputs, gridtype, align_corners, interpolation, bound=bound)
+        else:
+            _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
+                                          grad_inputs, gridtype, align_corners, interpolation)
         if grad_inputs is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
-        return grad_inputs, (None if stash is not None else grad_embeddings), None, None, None, None, None, None, None, None, None
+        return grad_inputs, (None if stash is not None else grad_embeddings), None, None, None, None, None, None, None, None, None, None
 
 
 grid_encode = _GridEncode.apply
@@ -164,12 +172,20 @@ class GridEncoder(nn.Module):
     def forward(self, inputs, bound=1, level_major=False):
         """`level_major=True` (build extension, 2-D inputs only) returns the kernel's own [num_levels, B, level_dim] layout
         instead of the reference's [B, num_levels * level_dim] — what ffmlp's `input_layout=1` consumes without a copy."""
-        inputs = (inputs + bound) / (2 * bound)  # [-bound, bound] -> [0, 1]
+        # [-bound, bound] -> [0, 1] (grid.py:146): inside the kernels when the backend can, no input gradient is needed and
+        # 2 * bound is a power of two (the usual 1, 2, 4, ...: dividing and multiplying by the reciprocal then round
+        # identically, so the fused result is bit-identical to the torch expression), else here
+        fuse_bound = 0.0
+        if getattr(_backend, "supports_bound", False) and inputs.is_cuda and not inputs.requires_grad \
+                and inputs.dtype == torch.float32 and bound > 0 and math.frexp(2.0 * bound)[0] == 0.5:
+            fuse_bound = float(bound)
+        else:
+            inputs = (inputs + bound) / (2 * bound)
         lead = list(inputs.shape[:-1])
         inputs = inputs.view(-1, self.input_dim)
         out = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
                           inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id,
-                          not self.training, level_major)
+                          not self.training, level_major, fuse_bound)
         if level_major:
             return out
         return out.view(lead + [self.output_dim])

@@ -109,7 +109,8 @@ class NeRFRenderer(nn.Module):
                 self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
             mxyzs, mdirs, mmask = self.map_samples(xyzs, dirs)
             sigmas, rgbs = self(mxyzs, mdirs)
-            sigmas = self.density_scale * sigmas
+            if self.density_scale != 1:  # (x1 is the identity: skip the pass over [M])
+                sigmas = self.density_scale * sigmas
             rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)
             weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
@@ -131,7 +132,8 @@ class NeRFRenderer(nn.Module):
                     self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma, max_steps)
                 mxyzs, mdirs, mmask = self.map_samples(xyzs, dirs)
                 sigmas, rgbs = self(mxyzs, mdirs)
-                sigmas = self.density_scale * sigmas
+                if self.density_scale != 1:
+                    sigmas = self.density_scale * sigmas
                 rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)
                 raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth,
                                            image, T_thresh)

@@ -179,9 +179,8 @@ class GraphedTrainer(Trainer):
         if self.graph is None and model.mean_count <= 0:
             # no sample statistics yet (first 16 steps): eager step with the wrapper's host sync
             return self._eager_step(rays_o, rays_d, gt_rgb, bg_color)
-        self.s_ro.copy_(rays_o.reshape(-1, 3))
-        self.s_rd.copy_(rays_d.reshape(-1, 3))
-        self.s_gt.copy_(gt_rgb.reshape(-1, 3))
+        torch._foreach_copy_([self.s_ro, self.s_rd, self.s_gt],
+                             [rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), gt_rgb.reshape(-1, 3)])  # one launch
         if self.graph is None:
             self._capture()  # warm-up + capture run the step on the current batch
         self._replay()

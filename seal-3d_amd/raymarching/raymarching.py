@@ -14,6 +14,13 @@ import s3d_hip
 
 _backend = s3d_hip.RaymarchingBackend
 
+
+def _zeros_332(M, dtype, device):
+    """xyzs [M,3], dirs [M,3], deltas [M,2], zero-initialised as in the reference (raymarching.py:205-207, padding rows
+    must read as zeros) — three contiguous tensors carved out of ONE filled buffer (one fill kernel instead of three)."""
+    flat = torch.zeros(M * 8, dtype=dtype, device=device)
+    return flat[:3 * M].view(M, 3), flat[3 * M:6 * M].view(M, 3), flat[6 * M:].view(M, 2)
+
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
            "composite_rays_train", "march_rays", "composite_rays", "compact_rays_alive"]
 
@@ -136,9 +143,7 @@ class _MarchRaysTrain(Function):
         if budgeted:
             M = _align_up(mean_count, align)
 
-        xyzs = torch.zeros(M, 3, dtype=dt, device=dev)
-        dirs = torch.zeros(M, 3, dtype=dt, device=dev)
-        deltas = torch.zeros(M, 2, dtype=dt, device=dev)
+        xyzs, dirs, deltas = _zeros_332(M, dt, dev)
         rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
         if step_counter is None:
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
@@ -179,8 +184,10 @@ class _CompositeRaysTrain(Function):
     def backward(ctx, grad_weights_sum, grad_depth, grad_image):
         sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
         M, N, T_thresh = ctx.dims
-        grad_sigmas = torch.zeros_like(sigmas)
-        grad_rgbs = torch.zeros_like(rgbs)
+        # zero-initialised like the reference (raymarching.py:283-284) — one fill for both
+        flat = torch.zeros(sigmas.numel() + rgbs.numel(), dtype=sigmas.dtype, device=sigmas.device)
+        grad_sigmas = flat[:sigmas.numel()].view_as(sigmas)
+        grad_rgbs = flat[sigmas.numel():].view_as(rgbs)
         _backend.composite_rays_train_backward(grad_weights_sum.contiguous(), grad_image.contiguous(), sigmas, rgbs,
                                                deltas.contiguous(), rays, weights_sum, image, M, N, T_thresh,
                                                grad_sigmas, grad_rgbs)
@@ -200,9 +207,7 @@ class _MarchRays(Function):
         rays_o, rays_d = _rays(rays_o, rays_d)
         dev, dt = rays_o.device, rays_o.dtype
         M = _align_up(n_alive * n_step, align)
-        xyzs = torch.zeros(M, 3, dtype=dt, device=dev)
-        dirs = torch.zeros(M, 3, dtype=dt, device=dev)
-        deltas = torch.zeros(M, 2, dtype=dt, device=dev)
+        xyzs, dirs, deltas = _zeros_332(M, dt, dev)
         noises = torch.rand(n_alive, dtype=dt, device=dev) if perturb else torch.zeros(n_alive, dtype=dt, device=dev)
         _backend.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
                             density_bitfield, near, far, xyzs, dirs, deltas, noises)

@@ -253,9 +253,11 @@ def _max_level_rows(offsets):
 class GridBackend:
     """gridencoder/src/gridencoder.h:12-15"""
 
+    supports_bound = True  # forward/backward accept raw coordinates + `bound` (normalisation fused into the kernels)
+
     @staticmethod
     def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, Cc, L, S, H, dy_dx, gridtype, align_corners,
-                            interp):
+                            interp, bound=0.0):
         _need(inputs, torch.float32, "inputs")
         _need(offsets, torch.int32, "offsets")
         if outputs.dtype != embeddings.dtype:
@@ -263,7 +265,7 @@ class GridBackend:
         _check(lib().s3d_grid_encode_forward(_p(inputs), _p(embeddings), _p(offsets), _p(outputs), _u(B), _u(D),
                                              _u(Cc), _u(L), _f(S), _u(H), _p(dy_dx), _u(gridtype),
                                              C.c_int(int(align_corners)), _u(interp), C.c_int(_dt(embeddings)),
-                                             _stream()), "grid_encode_forward")
+                                             _f(bound), _stream()), "grid_encode_forward")
 
     @staticmethod
     def grid_corner_indices(inputs, offsets, corner_idx, B, D, Cc, L, S, H, gridtype, align_corners):
@@ -273,7 +275,7 @@ class GridBackend:
 
     @staticmethod
     def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, Cc, L, S, H, dy_dx,
-                             grad_inputs, gridtype, align_corners, interp):
+                             grad_inputs, gridtype, align_corners, interp, bound=0.0):
         _need(inputs, torch.float32, "inputs")
         if grad_embeddings.dtype != grad.dtype:
             raise RuntimeError("grad_embeddings must have the dtype of grad")
@@ -284,7 +286,7 @@ class GridBackend:
                                               _p(grad_embeddings), _u(mlr), _u(B), _u(D),
                                               _u(Cc), _u(L), _f(S), _u(H), _p(dy_dx), _p(grad_inputs), _u(gridtype),
                                               C.c_int(int(align_corners)), _u(interp), C.c_int(_dt(grad)), _p(ws),
-                                              C.c_size_t(ws.numel()), _stream()), "grid_encode_backward")
+                                              C.c_size_t(ws.numel()), _f(bound), _stream()), "grid_encode_backward")
 
     @staticmethod
     def set_backward_path(path):
@@ -371,7 +373,7 @@ class FFMLPBackend:
     @staticmethod
     def ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers,
                        activation, output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights,
-                       input_layout=0):
+                       input_layout=0, accumulate=False):
         _need(grad, torch.float16, "grad")
         nbytes = lib().s3d_ffmlp_backward_workspace_size(_u(input_dim), _u(output_dim), _u(hidden_dim),
                                                         _u(num_layers))
@@ -381,7 +383,7 @@ class FFMLPBackend:
                                         _u(output_activation), C.c_int(int(bool(calc_grad_inputs))),
                                         _p(backward_buffer), _p(grad_inputs if calc_grad_inputs else None),
                                         _p(grad_weights), _p(ws), C.c_size_t(ws.numel()), C.c_int(int(input_layout)),
-                                        _stream()), "ffmlp_backward")
+                                        C.c_int(int(bool(accumulate))), _stream()), "ffmlp_backward")
 
 
 class OptimBackend:

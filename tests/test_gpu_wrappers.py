@@ -151,3 +151,27 @@ def test_network_ff_fused_head_matches_reference_op_sequence(hip):
     for i, name in ((2, "table"), (3, "sigma_net"), (4, "color_net")):
         a, b = res[True][i].float(), res[False][i].float()
         assert (a - b).norm() / b.norm().clamp(min=1e-12) < 2e-3, f"{name} gradient differs: {(a - b).norm() / b.norm()}"
+
+
+@pytest.mark.parametrize("bound", [1, 2, 1.7])
+def test_grid_encoder_fused_bound_normalisation(hip, bound):
+    """GridEncoder.forward(x, bound) normalises inside the kernels when 2*bound is a power of two (else in torch); the result
+    (and the table gradient) must be bit-identical to normalising in torch first, as gridencoder/grid.py:146 does."""
+    from gridencoder import GridEncoder
+    from gridencoder.grid import grid_encode
+    torch.manual_seed(3)
+    enc = GridEncoder(num_levels=8, base_resolution=8, log2_hashmap_size=14, desired_resolution=256).cuda()
+    enc.embeddings.data.uniform_(-1, 1)
+    x = ((torch.rand(9000, 3) * 2 - 1) * bound * 1.01).cuda()  # a few points just outside
+    g = torch.randn(9000, 16, device="cuda")
+    outs = []
+    for fused in (True, False):
+        enc.zero_grad(set_to_none=True)
+        if fused:
+            y = enc(x, bound=bound)
+        else:
+            y = grid_encode((x + bound) / (2 * bound), enc.embeddings, enc.offsets, enc.per_level_scale, enc.base_resolution,
+                            False, enc.gridtype_id, enc.align_corners, enc.interp_id)
+        (y * g).sum().backward()
+        outs.append((y.detach().clone(), enc.embeddings.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
