@@ -223,6 +223,12 @@ int s3d_ngp_mid_backward(const uint16_t* grad_color_in, const float* grad_sigma 
                          uint32_t B, uint16_t* grad_h, s3d_stream_t stream);
 int s3d_ngp_rgb_forward(const uint16_t* out, uint32_t B, float* rgb, s3d_stream_t stream);
 int s3d_ngp_rgb_backward(const float* grad_rgb, const float* rgb, uint32_t B, uint16_t* grad_out, s3d_stream_t stream);
+/* Loss head of one ray batch: loss = mean((image + (1 - weights_sum) * bg - gt)^2)  (nerf/renderer.py:316 background
+ * compositing + nerf/utils.py:484 MSE); bg_rgb = 3 HOST floats; loss / grad_loss are single device floats. */
+int s3d_bg_mse_forward(const float* image, const float* weights_sum, const float* gt, const float* bg_rgb, uint32_t N,
+                       float* loss, s3d_stream_t stream);
+int s3d_bg_mse_backward(const float* image, const float* weights_sum, const float* gt, const float* bg_rgb, uint32_t N,
+                        const float* grad_loss, float* grad_image, float* grad_weights_sum, s3d_stream_t stream);
 
 /* ------------------------------------------------------------------ parameter update
  * The reference's update is torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15) under torch.cuda.amp.GradScaler

@@ -79,10 +79,74 @@ __global__ void __launch_bounds__(256) k_ngp_rgb_backward(const float* __restric
     dst[0] = o0; dst[1] = o1;
 }
 
+// ---- background compositing + MSE loss of one ray batch (nerf/renderer.py:316 `image + (1 - weights_sum) * bg_color`,
+// nerf/utils.py:484 MSE) as one kernel per direction: ~14 tiny torch launches otherwise.  One workgroup, fixed-order tree
+// reduction (deterministic); N is a ray batch (4,096), not a sample batch.
+__global__ void __launch_bounds__(1024) k_bg_mse_forward(const float* __restrict__ image, const float* __restrict__ ws,
+                                                         const float* __restrict__ gt, float bg0, float bg1, float bg2, uint32_t N,
+                                                         float* __restrict__ loss) {
+    __shared__ float part[16];
+    const float bg[3] = {bg0, bg1, bg2};
+    float acc = 0.0f;
+    for (uint32_t n = threadIdx.x; n < N; n += 1024) {
+        const float w = 1.0f - ws[n];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float d = (image[(size_t)n * 3 + c] + w * bg[c]) - gt[(size_t)n * 3 + c];
+            acc += d * d;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < 16; w++) t += part[w];
+        *loss = t / (3.0f * (float)N);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bg_mse_backward(const float* __restrict__ image, const float* __restrict__ ws,
+                                                         const float* __restrict__ gt, float bg0, float bg1, float bg2, uint32_t N,
+                                                         const float* __restrict__ grad_loss, float* __restrict__ grad_image,
+                                                         float* __restrict__ grad_ws) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float bg[3] = {bg0, bg1, bg2};
+    const float k = *grad_loss * (2.0f / (3.0f * (float)N));
+    const float w = 1.0f - ws[n];
+    float gw = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float d = k * ((image[(size_t)n * 3 + c] + w * bg[c]) - gt[(size_t)n * 3 + c]);
+        grad_image[(size_t)n * 3 + c] = d;
+        gw -= d * bg[c];
+    }
+    grad_ws[n] = gw;
+}
+
 }  // namespace
 }  // namespace s3d
 
 using namespace s3d;
+
+S3D_EXPORT int s3d_bg_mse_forward(const float* image, const float* weights_sum, const float* gt, const float* bg_rgb, uint32_t N,
+                                  float* loss, s3d_stream_t stream) {
+    S3D_REQUIRE(image && weights_sum && gt && bg_rgb && loss && N > 0, "bg_mse_forward: null pointer / empty batch");
+    hipLaunchKernelGGL(k_bg_mse_forward, dim3(1), dim3(1024), 0, as_stream(stream), image, weights_sum, gt, bg_rgb[0], bg_rgb[1],
+                       bg_rgb[2], N, loss);
+    return check_launch("bg_mse_forward");
+}
+
+S3D_EXPORT int s3d_bg_mse_backward(const float* image, const float* weights_sum, const float* gt, const float* bg_rgb, uint32_t N,
+                                   const float* grad_loss, float* grad_image, float* grad_weights_sum, s3d_stream_t stream) {
+    S3D_REQUIRE(image && weights_sum && gt && bg_rgb && grad_loss && grad_image && grad_weights_sum && N > 0,
+                "bg_mse_backward: null pointer / empty batch");
+    hipLaunchKernelGGL(k_bg_mse_backward, dim3(div_up<uint32_t>(N, 256)), dim3(256), 0, as_stream(stream), image, weights_sum, gt,
+                       bg_rgb[0], bg_rgb[1], bg_rgb[2], N, grad_loss, grad_image, grad_weights_sum);
+    return check_launch("bg_mse_backward");
+}
 
 S3D_EXPORT int s3d_ngp_mid_forward(const uint16_t* h, const float* dirs, uint32_t B, float* sigma, uint16_t* color_in,
                                    s3d_stream_t stream) {

@@ -113,7 +113,12 @@ class NeRFRenderer(nn.Module):
                 sigmas = self.density_scale * sigmas
             rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)
             weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
-            image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+            if kwargs.get("defer_background", False) and not torch.is_tensor(bg_color):
+                # the caller composites the background inside its fused loss kernel (nerf/trainer.py:bg_mse_loss)
+                results["premultiplied"] = True
+                results["bg_color"] = bg_color
+            else:
+                image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
             results["weights_sum"] = weights_sum
         else:
             dtype = torch.float32  # outputs stay fp32; only the network runs in half under autocast

@@ -14,6 +14,38 @@ def psnr(pred, target):
     return -10 * math.log10(float(torch.mean((pred.float() - target.float()) ** 2)) + 1e-20)
 
 
+class _BgMse(torch.autograd.Function):
+    """loss = mean((image + (1 - weights_sum) * bg - gt)^2): background compositing (nerf/renderer.py:316) and the MSE
+    criterion (nerf/utils.py:484) in one kernel per direction (csrc/ngp_head.hip) instead of ~14 tiny launches."""
+
+    @staticmethod
+    def forward(ctx, image, weights_sum, gt, bg):
+        import s3d_hip
+        image, weights_sum, gt = image.float().contiguous(), weights_sum.float().contiguous(), gt.float().contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=image.device)
+        s3d_hip.NgpHeadBackend.bg_mse_forward(image, weights_sum, gt, bg, loss)
+        ctx.save_for_backward(image, weights_sum, gt)
+        ctx.bg = bg
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        import s3d_hip
+        image, weights_sum, gt = ctx.saved_tensors
+        g_image, g_ws = torch.empty_like(image), torch.empty_like(weights_sum)
+        s3d_hip.NgpHeadBackend.bg_mse_backward(image, weights_sum, gt, ctx.bg, g.float().contiguous(), g_image, g_ws)
+        return g_image, g_ws, None, None
+
+
+def render_loss(out, gt_rgb):
+    """MSE between the rendered batch and the targets; uses the fused kernel when the renderer deferred the background"""
+    if out.get("premultiplied", False):
+        bg = out["bg_color"]
+        bg = (float(bg),) * 3 if not isinstance(bg, (tuple, list)) else tuple(float(v) for v in bg)
+        return _BgMse.apply(out["image"].reshape(-1, 3), out["weights_sum"].reshape(-1), gt_rgb.reshape(-1, 3), bg)
+    return F.mse_loss(out["image"], gt_rgb)
+
+
 class Trainer:
     def __init__(self, model, lr=1e-2, fp16=True, update_extra_interval=16, dist=None, max_steps=1024, dt_gamma=0,
                  T_thresh=1e-4, capturable=False, native_optim=None, optimizer=None, scaler=None):
@@ -58,8 +90,9 @@ class Trainer:
         # with it they live in the flat all-reduce bucket and are cleared in place
         self.optimizer.zero_grad(set_to_none=self.dist is None)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
-            out = model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False, **self.render_kwargs)
-            loss = F.mse_loss(out["image"], gt_rgb)
+            out = model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False,
+                               defer_background=self.native_optim, **self.render_kwargs)
+            loss = render_loss(out, gt_rgb)
         self.scaler.scale(loss).backward()
         if self.dist is not None:
             self.dist.allreduce_grads(self.scaler)
@@ -112,8 +145,9 @@ class GraphedTrainer(Trainer):
         # with it they live in the flat all-reduce bucket and are cleared in place
         self.optimizer.zero_grad(set_to_none=self.dist is None)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
-            out = model.render(self.s_ro, self.s_rd, bg_color=1, perturb=True, force_all_rays=False, **self.render_kwargs)
-            loss = F.mse_loss(out["image"], self.s_gt)
+            out = model.render(self.s_ro, self.s_rd, bg_color=1, perturb=True, force_all_rays=False,
+                               defer_background=self.native_optim, **self.render_kwargs)
+            loss = render_loss(out, self.s_gt)
         self.scaler.scale(loss).backward()
         return loss.detach()
 

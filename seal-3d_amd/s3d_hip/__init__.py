@@ -40,6 +40,7 @@ EXPORTS = [
     "s3d_ffmlp_allocate_splitk", "s3d_ffmlp_free_splitk",
     "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_advance",
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
+    "s3d_bg_mse_forward", "s3d_bg_mse_backward",
 ]
 
 
@@ -439,3 +440,18 @@ class NgpHeadBackend:
     def rgb_backward(grad_rgb, rgb, grad_out):
         _need(grad_rgb, torch.float32, "grad_rgb"); _need(rgb, torch.float32, "rgb"); _need(grad_out, torch.float16, "grad_out")
         _check(lib().s3d_ngp_rgb_backward(_p(grad_rgb), _p(rgb), _u(rgb.shape[0]), _p(grad_out), _stream()), "ngp_rgb_backward")
+
+    @staticmethod
+    def bg_mse_forward(image, weights_sum, gt, bg_rgb, loss):
+        for t, n in ((image, "image"), (weights_sum, "weights_sum"), (gt, "gt"), (loss, "loss")):
+            _need(t, torch.float32, n)
+        bg = (C.c_float * 3)(*[float(v) for v in bg_rgb])
+        _check(lib().s3d_bg_mse_forward(_p(image), _p(weights_sum), _p(gt), bg, _u(image.shape[0]), _p(loss), _stream()),
+               "bg_mse_forward")
+
+    @staticmethod
+    def bg_mse_backward(image, weights_sum, gt, bg_rgb, grad_loss, grad_image, grad_weights_sum):
+        _need(grad_loss, torch.float32, "grad_loss")
+        bg = (C.c_float * 3)(*[float(v) for v in bg_rgb])
+        _check(lib().s3d_bg_mse_backward(_p(image), _p(weights_sum), _p(gt), bg, _u(image.shape[0]), _p(grad_loss),
+                                         _p(grad_image), _p(grad_weights_sum), _stream()), "bg_mse_backward")

@@ -175,3 +175,23 @@ def test_grid_encoder_fused_bound_normalisation(hip, bound):
         (y * g).sum().backward()
         outs.append((y.detach().clone(), enc.embeddings.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_fused_background_mse_loss(hip):
+    """nerf.trainer.render_loss with a deferred background == F.mse_loss(image + (1 - ws) * bg, gt), values and gradients"""
+    from nerf.trainer import render_loss
+    g = torch.Generator().manual_seed(7)
+    N = 4096
+    img = torch.rand(N, 3, generator=g).cuda().requires_grad_(True)
+    ws = torch.rand(N, generator=g).cuda().requires_grad_(True)
+    gt = torch.rand(N, 3, generator=g).cuda()
+    for bg in (1, (0.2, 0.5, 0.9)):
+        bgt = torch.tensor(bg if isinstance(bg, tuple) else (bg,) * 3, device="cuda", dtype=torch.float32)
+        ref = torch.nn.functional.mse_loss(img + (1 - ws).unsqueeze(-1) * bgt, gt)
+        gi_ref, gw_ref = torch.autograd.grad(ref * 1024.0, (img, ws))
+        out = {"image": img, "weights_sum": ws, "premultiplied": True, "bg_color": bg}
+        loss = render_loss(out, gt)
+        gi, gw = torch.autograd.grad(loss * 1024.0, (img, ws))
+        torch.testing.assert_close(loss, ref, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(gi, gi_ref, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(gw, gw_ref, rtol=1e-5, atol=1e-7)
