@@ -244,6 +244,9 @@ int s3d_adam_step(float* param, const void* grad, int grad_dtype, float* exp_avg
                   uint16_t* param_half, size_t n, float lr, float beta1, float beta2, float eps,
                   const float* step, const float* grad_scale, const float* found_inf, s3d_stream_t stream);
 int s3d_adam_advance(float* step, const float* found_inf, s3d_stream_t stream);
+/* GradScaler.update(): scale *= backoff on overflow, *= growth after growth_interval clean steps; clears *found_inf. */
+int s3d_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, float growth_factor,
+                      float backoff_factor, int32_t growth_interval, s3d_stream_t stream);
 
 #ifdef __cplusplus
 }

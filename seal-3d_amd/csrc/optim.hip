@@ -58,6 +58,26 @@ __global__ void k_adam_advance(float* __restrict__ step, const float* __restrict
     if (!(found_inf && *found_inf != 0.0f)) *step += 1.0f;
 }
 
+// torch.amp.GradScaler.update (aten::_amp_update_scale_): back off on overflow, grow after `interval` clean steps; then
+// clear the flag for the next step (saves the separate fill launch)
+__global__ void k_scaler_update(float* __restrict__ scale, int32_t* __restrict__ growth_tracker, float* __restrict__ found_inf,
+                                float growth, float backoff, int32_t interval) {
+    if (*found_inf != 0.0f) {
+        *scale = *scale * backoff;
+        *growth_tracker = 0;
+    } else {
+        const int32_t ok = *growth_tracker + 1;
+        if (ok == interval) {
+            const float grown = *scale * growth;
+            if (grown <= 3.402823466e38f) *scale = grown;  // (torch keeps the scale when growing would overflow)
+            *growth_tracker = 0;
+        } else {
+            *growth_tracker = ok;
+        }
+    }
+    *found_inf = 0.0f;
+}
+
 }  // namespace
 }  // namespace s3d
 
@@ -95,4 +115,12 @@ S3D_EXPORT int s3d_adam_advance(float* step, const float* found_inf, s3d_stream_
     S3D_REQUIRE(step, "adam_advance: null pointer");
     hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, as_stream(stream), step, found_inf);
     return check_launch("adam_advance");
+}
+
+S3D_EXPORT int s3d_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, float growth_factor,
+                                 float backoff_factor, int32_t growth_interval, s3d_stream_t stream) {
+    S3D_REQUIRE(scale && growth_tracker && found_inf, "scaler_update: null pointer");
+    hipLaunchKernelGGL(k_scaler_update, dim3(1), dim3(1), 0, as_stream(stream), scale, growth_tracker, found_inf, growth_factor,
+                       backoff_factor, growth_interval);
+    return check_launch("scaler_update");
 }

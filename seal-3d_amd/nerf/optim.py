@@ -110,8 +110,15 @@ class NativeGradScaler:
     def get_scale(self):
         return float(self._scale.item())
 
+    def backward(self, loss):
+        """`scale(loss).backward()` without the multiply and the ones-like root: the scale IS the root gradient"""
+        if self.enabled:
+            loss.backward(gradient=self._scale.reshape(()).to(loss.dtype))
+        else:
+            loss.backward()
+
     def step(self, optimizer):
-        self._found_inf.zero_()
+        # (found_inf is cleared by update(); it starts at zero)
         flat = getattr(optimizer, "flat_half", None)
         if flat is not None:
             _backend.grads_nonfinite(flat, self._found_inf)  # every handed-over gradient in one pass
@@ -122,5 +129,7 @@ class NativeGradScaler:
 
     def update(self):
         if self.enabled:
-            torch._amp_update_scale_(self._scale, self._growth_tracker, self._found_inf, self.growth_factor,
-                                     self.backoff_factor, self.growth_interval)
+            _backend.scaler_update(self._scale, self._growth_tracker, self._found_inf, self.growth_factor,
+                                   self.backoff_factor, self.growth_interval)
+        else:
+            self._found_inf.zero_()

@@ -93,12 +93,18 @@ class Trainer:
             out = model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False,
                                defer_background=self.native_optim, **self.render_kwargs)
             loss = render_loss(out, gt_rgb)
-        self.scaler.scale(loss).backward()
+        self._backward(loss)
         if self.dist is not None:
             self.dist.allreduce_grads(self.scaler)
         self.scaler.step(self.optimizer)
         self.scaler.update()
         return loss.detach()
+
+    def _backward(self, loss):
+        if hasattr(self.scaler, "backward"):  # NativeGradScaler: the scale is passed as the root gradient
+            self.scaler.backward(loss)
+        else:
+            self.scaler.scale(loss).backward()
 
     def train_step(self, rays_o, rays_d, gt_rgb, bg_color=1):
         """rays_o/d [N,3], gt_rgb [N,3].  Returns the (detached) loss tensor; no host sync."""
@@ -148,7 +154,7 @@ class GraphedTrainer(Trainer):
             out = model.render(self.s_ro, self.s_rd, bg_color=1, perturb=True, force_all_rays=False,
                                defer_background=self.native_optim, **self.render_kwargs)
             loss = render_loss(out, self.s_gt)
-        self.scaler.scale(loss).backward()
+        self._backward(loss)
         return loss.detach()
 
     def _body_opt(self):

@@ -38,7 +38,7 @@ EXPORTS = [
     "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
     "s3d_ffmlp_fused_backward_supported",
     "s3d_ffmlp_allocate_splitk", "s3d_ffmlp_free_splitk",
-    "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_advance",
+    "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_advance", "s3d_scaler_update",
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
     "s3d_bg_mse_forward", "s3d_bg_mse_backward",
 ]
@@ -408,6 +408,12 @@ class OptimBackend:
         _check(lib().s3d_adam_step(_p(param), _p(grad), C.c_int(_dt(grad)), _p(exp_avg), _p(exp_avg_sq), _p(param_half),
                                    C.c_size_t(param.numel()), _f(lr), _f(beta1), _f(beta2), _f(eps), _p(step),
                                    _p(grad_scale), _p(found_inf), _stream()), "adam_step")
+
+    @staticmethod
+    def scaler_update(scale, growth_tracker, found_inf, growth_factor, backoff_factor, growth_interval):
+        _need(scale, torch.float32, "scale"); _need(growth_tracker, torch.int32, "growth_tracker")
+        _check(lib().s3d_scaler_update(_p(scale), _p(growth_tracker), _p(found_inf), _f(growth_factor), _f(backoff_factor),
+                                       C.c_int32(int(growth_interval)), _stream()), "scaler_update")
 
     @staticmethod
     def adam_advance(step, found_inf):
