@@ -66,6 +66,38 @@ template <int ACT> __device__ __forceinline__ float act_bwd_t(uint32_t a, float 
     else return act_bwd(a, g, fwd);
 }
 
+// ReLU on PACKED halves (the hot networks): max(x, 0) is one v_pk_max_f16 per two elements, and the backward gate
+// "g if a != 0 else 0" three packed integer ops (a = relu(.) is +0 exactly where the gate is closed) — instead of a
+// float round trip, compare and select per element.
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2p __attribute__((ext_vector_type(2)));
+typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half2p cvt2(float a, float b) {
+    float2v f;
+    f[0] = a; f[1] = b;
+    return __builtin_convertvector(f, half2p);  // round to nearest even, like (_Float16)a
+}
+__device__ __forceinline__ half2p relu2(half2p x) {  // v_pk_max_f16 (NaN -> 0 like `x > 0 ? x : 0`)
+    uint32_t xb, r;
+    __builtin_memcpy(&xb, &x, 4);
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(xb), "v"(0u));
+    half2p o;
+    __builtin_memcpy(&o, &r, 4);
+    return o;
+}
+__device__ __forceinline__ half2p gate2(half2p g, half2p a) {  // g where a > 0, else +0   (a = relu(.) >= 0 or -0)
+    uint32_t ab, gb, m;
+    __builtin_memcpy(&ab, &a, 4);
+    __builtin_memcpy(&gb, &g, 4);
+    ab &= 0x7fff7fffu;                                                          // -0 counts as closed
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(ab), "v"(0x00010001u));        // 0 / 1 per half
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(m) : "v"(m), "v"(0xffffffffu));      // 0 / 0xffff per half
+    gb &= m;
+    half2p r;
+    __builtin_memcpy(&r, &gb, 4);
+    return r;
+}
+
 // K-permutation of one 16-wide k-step: element j of lane-half h
 __device__ __forceinline__ uint32_t kperm(uint32_t h, uint32_t j) { return (j & 3u) + 8u * (j >> 2) + 4u * h; }
 
@@ -188,9 +220,18 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
 #pragma unroll
             for (uint32_t m = 0; m < MB; m++)
 #pragma unroll
-                for (uint32_t r = 0; r < 16; r++) {
-                    const float pre = (float)(_Float16)acc[m][r];
-                    bf[2 * m + (r >> 3)][r & 7] = (_Float16)act_fwd_t<ACT>(act, pre);
+                for (uint32_t r = 0; r < 16; r += 2) {
+                    if constexpr (ACT == ACT_RELU) {
+                        const half2p v = relu2(cvt2(acc[m][r], acc[m][r + 1]));
+                        bf[2 * m + (r >> 3)][r & 7] = v[0];
+                        bf[2 * m + (r >> 3)][(r & 7) + 1] = v[1];
+                    } else {
+#pragma unroll
+                        for (uint32_t q = r; q < r + 2; q++) {
+                            const float pre = (float)(_Float16)acc[m][q];
+                            bf[2 * m + (q >> 3)][q & 7] = (_Float16)act_fwd_t<ACT>(act, pre);
+                        }
+                    }
                 }
             if (TRAIN) {
                 _Float16* dst = fwd + (size_t)layer * B * W + (size_t)tile * 32 * W;
@@ -625,9 +666,18 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
 #pragma unroll
                 for (uint32_t m = 0; m < MB; m++)
 #pragma unroll
-                    for (uint32_t r = 0; r < 16; r++) {
-                        const float pre = (float)(_Float16)acc[m][r];
-                        a[layer][2 * m + (r >> 3)][r & 7] = (_Float16)act_fwd_t<ACT>(act, pre);
+                    for (uint32_t r = 0; r < 16; r += 2) {
+                        if constexpr (ACT == ACT_RELU) {
+                            const half2p v = relu2(cvt2(acc[m][r], acc[m][r + 1]));
+                            a[layer][2 * m + (r >> 3)][r & 7] = v[0];
+                            a[layer][2 * m + (r >> 3)][(r & 7) + 1] = v[1];
+                        } else {
+#pragma unroll
+                            for (uint32_t q = r; q < r + 2; q++) {
+                                const float pre = (float)(_Float16)acc[m][q];
+                                a[layer][2 * m + (q >> 3)][q & 7] = (_Float16)act_fwd_t<ACT>(act, pre);
+                            }
+                        }
                     }
                 if (layer < (uint32_t)NH) {
                     const half8* wf = ffh + (size_t)(layer * MB * KS) * 64;
@@ -667,9 +717,20 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
 #pragma unroll
             for (uint32_t m = 0; m < MB; m++)
 #pragma unroll
-                for (uint32_t r = 0; r < 16; r++) {
-                    const float g = (float)(_Float16)acc[m][r];
-                    G[2 * m + (r >> 3)][r & 7] = (_Float16)act_bwd_t<ACT>(act, g, (float)a[k][2 * m + (r >> 3)][r & 7]);
+                for (uint32_t r = 0; r < 16; r += 2) {
+                    if constexpr (ACT == ACT_RELU) {
+                        half2p av;
+                        av[0] = a[k][2 * m + (r >> 3)][r & 7]; av[1] = a[k][2 * m + (r >> 3)][(r & 7) + 1];
+                        const half2p v = gate2(cvt2(acc[m][r], acc[m][r + 1]), av);
+                        G[2 * m + (r >> 3)][r & 7] = v[0];
+                        G[2 * m + (r >> 3)][(r & 7) + 1] = v[1];
+                    } else {
+#pragma unroll
+                        for (uint32_t q = r; q < r + 2; q++) {
+                            const float g = (float)(_Float16)acc[m][q];
+                            G[2 * m + (q >> 3)][q & 7] = (_Float16)act_bwd_t<ACT>(act, g, (float)a[k][2 * m + (q >> 3)][q & 7]);
+                        }
+                    }
                 }
             transpose_store<(int)KS>(TG, G, KS, n, h);
             if (k > 0) {
