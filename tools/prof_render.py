@@ -25,7 +25,7 @@ with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         n_alive, step, log = N, 0, []
         t0 = time.perf_counter()
         while step < 1024 and n_alive > 0:
-            n_step = max(min(N // n_alive, 8), 1)
+            n_step = max(min(4 * N // n_alive, 32), 1)  # infer_batch_scale = 4 (bench default)
             e0 = ev()
             xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, alive, rays_t, ro, rd, 1.0, model.density_bitfield, 1, 128, nears, fars, 128, False, 0, 1024)
             e1 = ev()
