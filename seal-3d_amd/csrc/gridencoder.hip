@@ -366,8 +366,6 @@ constexpr uint32_t kBinAccThreads = S3D_BIN_ACC_THREADS;
 constexpr uint32_t kBinAccUnroll = S3D_BIN_ACC_UNROLL;
 constexpr uint32_t kBinMinSlices = 64;
 constexpr uint32_t kBinMaxSlices = 512;
-constexpr uint32_t kBinStageBytes = 64 * 1024;
-constexpr uint32_t kBinCtlWords = 3 * kBinMaxSlices;  // cnt / base / gbase
 
 // slices of a level: a power of two (slice / local-row arithmetic is shifts and masks), >= kBinMinSlices for balance
 __host__ __device__ inline uint32_t bin_slices(uint32_t rows, uint32_t C) {
@@ -380,12 +378,9 @@ __host__ __device__ inline uint32_t bin_slices(uint32_t rows, uint32_t C) {
 __host__ __device__ inline uint32_t bin_local_rows(uint32_t rows, uint32_t S) {
     return div_up<uint32_t>(div_up<uint32_t>(rows, kBinGroup), S) * kBinGroup;
 }
+constexpr uint32_t kBinQuad = 4;  // consecutive points handled (and merged) by one lane of k_bin_count / k_bin_scatter
 template <typename T, uint32_t D, uint32_t C>
-__host__ __device__ constexpr uint32_t bin_chunk_points() {
-    const uint32_t rec = 4 + sizeof(T) * C;
-    const uint32_t p = (kBinStageBytes / (rec << D)) / 64 * 64;
-    return p > 1024 ? 1024 : p;
-}
+__host__ __device__ constexpr uint32_t bin_chunk_points() { return 1024; }  // points per scatter workgroup (256 lanes x 4)
 
 // Level-uniform index plan (get_grid_index, gridencoder.cu:66-84): which dimensions enter the dense index (the
 // stride loop stops once stride > hashmap_size), their strides, whether the level is hashed; `% hashmap_size` is a
@@ -435,6 +430,72 @@ __device__ __forceinline__ float absmax_feat(const T (&g)[C], bool& nonzero) {
     return m;
 }
 
+// Contributions of kBinQuad CONSECUTIVE points at one level, merged where neighbours share a cell.  Samples marched along
+// a ray stay in one cell of a level for (cell width / step) consecutive samples — 37 on level 0 of the Lego config, still
+// ~2 on level 9 — and then hit the same 2^D rows: their weighted gradients w * grad are summed here in fp32 and leave as ONE
+// record per corner, rounded to T once (a single-point run is exactly the product the reference adds).  ~45 % fewer records on ray-ordered
+// samples: less HBM traffic in both directions and far fewer same-row LDS conflicts in k_bin_accumulate.  The walk is
+// deterministic (fixed quads, fixed order), so the result stays reproducible bit for bit.
+//   emit(q, idx, slice, local_row, float sum[C]) is called once per corner of each run; q is the compile-time slot (the
+//   quad position at which the run was closed), so callers can keep per-record state in registers.
+template <typename T, uint32_t D, uint32_t C, typename Emit>
+__device__ __forceinline__ void bin_quad(const float (&x)[kBinQuad][D], const T (&g)[kBinQuad][C], const bool (&in)[kBinQuad],
+                                         float lscale, bool align_corners, uint32_t interp, const LevelIndex<D>& li, uint32_t S,
+                                         uint32_t sshift, Emit&& emit) {
+    constexpr uint32_t K = 1u << D;
+    bool open = false;
+    uint32_t cell[D], lo[D];
+    float acc[K][C];
+    auto flush = [&](auto slot) {
+#pragma unroll
+        for (uint32_t idx = 0; idx < K; idx++) {
+            const uint32_t row = li.row(lo, idx);
+            const uint32_t grp = row / kBinGroup;
+            emit(slot, idx, grp & (S - 1), (grp >> sshift) * kBinGroup + row % kBinGroup, acc[idx]);
+        }
+    };
+    auto step = [&](auto qc) {
+        constexpr uint32_t q = decltype(qc)::value;
+        bool nz = false;
+        (void)absmax_feat<T, C>(g[q], nz);
+        if (!(in[q] && nz)) return;
+        float pos[D], pd[D];
+        uint32_t pos_grid[D];
+        locate<D>(x[q], lscale, align_corners, interp, pos, pd, pos_grid);
+        bool same = open;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) same = same && (pos_grid[d] == cell[d]);
+        if (!same) {
+            if constexpr (q > 0) {
+                if (open) flush(std::integral_constant<uint32_t, (q > 0 ? q - 1 : 0)>{});
+            }
+            open = true;
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) { cell[d] = pos_grid[d]; lo[d] = pos_grid[d] * li.mul[d]; }
+#pragma unroll
+            for (uint32_t idx = 0; idx < K; idx++)
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) acc[idx][c] = 0.0f;
+        }
+        float gf[C];
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) gf[c] = Acc<T>::to_f(g[q][c]);
+#pragma unroll
+        for (uint32_t idx = 0; idx < K; idx++) {
+            float w = 1;
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) w *= ((idx >> d) & 1u) ? pos[d] : 1 - pos[d];
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) acc[idx][c] += w * gf[c];  // fp32 sum of the run's products; rounded to T once, at flush
+        }
+    };
+    step(std::integral_constant<uint32_t, 0>{});
+    step(std::integral_constant<uint32_t, 1>{});
+    step(std::integral_constant<uint32_t, 2>{});
+    step(std::integral_constant<uint32_t, 3>{});
+    if (open) flush(std::integral_constant<uint32_t, kBinQuad - 1>{});
+}
+
 __global__ void __launch_bounds__(1024) k_zero_words(uint32_t* __restrict__ p, uint32_t n) {
     const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
     if (i < n) p[i] = 0;
@@ -453,8 +514,6 @@ __global__ void __launch_bounds__(kBinCountThreads) k_bin_count(const T* __restr
                                                                 uint32_t* __restrict__ hdr, uint32_t* __restrict__ tot,
                                                                 uint32_t smax, uint32_t gridtype, bool align_corners,
                                                                 uint32_t interp) {
-    constexpr uint32_t K = 1u << D;
-    constexpr uint32_t U = 4;  // points per lane in flight
     __shared__ uint32_t cnt[kBinMaxSlices];
     __shared__ float wmax[kBinCountThreads / 64];
     const uint32_t b_begin = blockIdx.x * points_per_block;
@@ -468,34 +527,29 @@ __global__ void __launch_bounds__(kBinCountThreads) k_bin_count(const T* __restr
     for (uint32_t s = threadIdx.x; s < S; s += kBinCountThreads) cnt[s] = 0;
     __syncthreads();
     float m = 0.0f;
-    for (uint32_t b0 = b_begin + threadIdx.x; b0 < b_end; b0 += U * kBinCountThreads) {
-        float x[U][D];
-        T g[U][C];
-        bool in[U];
+    const uint32_t sshift = 31 - __clz(S);
+    for (uint32_t b0 = b_begin + threadIdx.x * kBinQuad; b0 < b_end; b0 += kBinQuad * kBinCountThreads) {
+        float x[kBinQuad][D];
+        T g[kBinQuad][C];
+        bool in[kBinQuad];
 #pragma unroll
-        for (uint32_t u = 0; u < U; u++) {
-            const uint32_t b = b0 + u * kBinCountThreads;
-            in[u] = b < b_end;
-            if (in[u]) {
-                in[u] = !load_point<D>(inputs, b, scales, x[u]);
-                load_feat<T, C>(grad + ((size_t)level * B + b) * C, g[u]);
+        for (uint32_t q = 0; q < kBinQuad; q++) {
+            const uint32_t b = b0 + q;
+            in[q] = b < b_end;
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) g[q][c] = Acc<T>::zero();
+            if (in[q]) {
+                in[q] = !load_point<D>(inputs, b, scales, x[q]);
+                load_feat<T, C>(grad + ((size_t)level * B + b) * C, g[q]);
+                if (in[q]) {
+                    bool nz = false;
+                    const float a = absmax_feat<T, C>(g[q], nz);
+                    m = (a > m || a != a) ? a : m;
+                }
             }
         }
-#pragma unroll
-        for (uint32_t u = 0; u < U; u++) {
-            if (!in[u]) continue;
-            bool nz = false;
-            const float a = absmax_feat<T, C>(g[u], nz);
-            m = (a > m || a != a) ? a : m;
-            if (!nz) continue;
-            float pos[D], pd[D];
-            uint32_t pos_grid[D], lo[D];
-            locate<D>(x[u], lscale, align_corners, interp, pos, pd, pos_grid);
-#pragma unroll
-            for (uint32_t d = 0; d < D; d++) lo[d] = pos_grid[d] * li.mul[d];
-#pragma unroll
-            for (uint32_t idx = 0; idx < K; idx++) atomicAdd(&cnt[(li.row(lo, idx) / kBinGroup) & (S - 1)], 1u);
-        }
+        bin_quad<T, D, C>(x, g, in, lscale, align_corners, interp, li, S, sshift,
+                          [&](auto, uint32_t, uint32_t slice, uint32_t, const float (&)[C]) { atomicAdd(&cnt[slice], 1u); });
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const float o = __shfl_xor(m, d, 64); m = (o > m || o != o) ? o : m; }
@@ -510,37 +564,40 @@ __global__ void __launch_bounds__(kBinCountThreads) k_bin_count(const T* __restr
 }
 
 template <typename T, uint32_t D, uint32_t C>
-__global__ void __launch_bounds__(1024) k_bin_scatter(const T* __restrict__ grad, const float* __restrict__ inputs,
-                                                     const int32_t* __restrict__ offsets, uint32_t B, uint32_t level0,
-                                                     LevelScales scales, const uint32_t* __restrict__ hdr,
-                                                     const uint32_t* __restrict__ tot, uint32_t* __restrict__ cursor,
-                                                     uint32_t smax, uint32_t* __restrict__ gkeys,
-                                                     typename FeatVec<T, C>::type* __restrict__ gvals, uint32_t gridtype,
-                                                     bool align_corners, uint32_t interp) {
+__global__ void __launch_bounds__(256) k_bin_scatter(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                    const int32_t* __restrict__ offsets, uint32_t B, uint32_t level0,
+                                                    LevelScales scales, const uint32_t* __restrict__ hdr,
+                                                    const uint32_t* __restrict__ tot, uint32_t* __restrict__ cursor,
+                                                    uint32_t smax, uint32_t* __restrict__ gkeys,
+                                                    typename FeatVec<T, C>::type* __restrict__ gvals, uint32_t gridtype,
+                                                    bool align_corners, uint32_t interp) {
     using V = typename FeatVec<T, C>::type;
     constexpr uint32_t K = 1u << D;
-    constexpr uint32_t P = bin_chunk_points<T, D, C>();
+    constexpr uint32_t P = bin_chunk_points<T, D, C>();  // points per workgroup
+    constexpr uint32_t NT = P / kBinQuad;                // lanes: each walks kBinQuad consecutive points
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);
-    uint32_t* base = cnt + kBinMaxSlices;
-    uint32_t* gbase = base + kBinMaxSlices;
-    uint32_t* skeys = gbase + kBinMaxSlices;
-    V* svals = reinterpret_cast<V*>(skeys + P * K);
+    uint32_t* gbase = cnt + kBinMaxSlices;
     // 4-byte values (fp16 C=2, fp32 C=1) travel as ONE 8-byte {key, value} record: half the store / load instructions
     constexpr bool kPacked = sizeof(V) == 4;
-    uint2* srecs = reinterpret_cast<uint2*>(skeys);
 
     // all global loads of the prologue are issued before the first test (see k_bin_accumulate)
     const uint32_t level = level0 + blockIdx.y;
     const float amax = __uint_as_float(hdr[level]);
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
-    const uint32_t b = blockIdx.x * P + threadIdx.x;
-    float x[D];
-    T g[C];
-    bool inside = b < B;
-    if (inside) {
-        inside = !load_point<D>(inputs, b, scales, x);
-        load_feat<T, C>(grad + ((size_t)level * B + b) * C, g);
+    const uint32_t b0 = blockIdx.x * P + threadIdx.x * kBinQuad;
+    float x[kBinQuad][D];
+    T g[kBinQuad][C];
+    bool in[kBinQuad];
+#pragma unroll
+    for (uint32_t q = 0; q < kBinQuad; q++) {
+        in[q] = b0 + q < B;
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) g[q][c] = Acc<T>::zero();
+        if (in[q]) {
+            in[q] = !load_point<D>(inputs, b0 + q, scales, x[q]);
+            load_feat<T, C>(grad + ((size_t)level * B + b0 + q) * C, g[q]);
+        }
     }
     constexpr uint32_t kPer = kBinMaxSlices / 64;
     uint32_t my_tot[kPer];  // first wave: the level's slice totals, lane t holds slices t, t + 64, t + 128, ...
@@ -558,52 +615,32 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const T* __restrict__ grad
     LevelIndex<D> li;
     li.init(gridtype, align_corners, hashmap_size, (uint32_t)ceilf(lscale) + 1);
 
-    for (uint32_t s = threadIdx.x; s < S; s += P) cnt[s] = 0;
+    for (uint32_t s = threadIdx.x; s < S; s += NT) cnt[s] = 0;
     __syncthreads();
 
-    uint32_t key[K], rank[K];
-    V val[K];
-    bool active = false;
-    if (inside) {
-        (void)absmax_feat<T, C>(g, active);
-        if (active) {
-            float pos[D], pd[D];
-            uint32_t pos_grid[D], lo[D];
-            locate<D>(x, lscale, align_corners, interp, pos, pd, pos_grid);
+    // records of this lane: slot (q, idx) is filled when a run is closed at quad position q (at most one run per q)
+    uint32_t key[kBinQuad][K], rank[kBinQuad][K];
+    V val[kBinQuad][K];
+    uint32_t closed = 0;  // bit q: slot row q holds a run
+    bin_quad<T, D, C>(x, g, in, lscale, align_corners, interp, li, S, sshift,
+                      [&](auto qc, uint32_t idx, uint32_t slice, uint32_t local, const float (&sum)[C]) {
+                          constexpr uint32_t q = decltype(qc)::value;
+                          closed |= 1u << q;
+                          T pr[C];
 #pragma unroll
-            for (uint32_t d = 0; d < D; d++) lo[d] = pos_grid[d] * li.mul[d];
+                          for (uint32_t c = 0; c < C; c++) pr[c] = Acc<T>::from_f(sum[c]);
 #pragma unroll
-            for (uint32_t idx = 0; idx < K; idx++) {
-                float w = 1;
-#pragma unroll
-                for (uint32_t d = 0; d < D; d++) w *= ((idx >> d) & 1u) ? pos[d] : 1 - pos[d];
-                const uint32_t row = li.row(lo, idx);
-                const uint32_t grp = row / kBinGroup;
-                const uint32_t s = grp & (S - 1);
-                key[idx] = (s << 20) | ((grp >> sshift) * kBinGroup + row % kBinGroup);
-                rank[idx] = atomicAdd(&cnt[s], 1u);
-                T pr[C];
-#pragma unroll
-                for (uint32_t c = 0; c < C; c++) pr[c] = Acc<T>::from_f(w * Acc<T>::to_f(g[c]));  // the reference's product
-                __builtin_memcpy(&val[idx], pr, sizeof(V));
-            }
-        }
-    }
+                          for (uint32_t i = 0; i < K; i++)  // (idx is a loop index of an unrolled loop: resolve it statically)
+                              if (i == idx) {
+                                  key[q][i] = (slice << 20) | local;
+                                  rank[q][i] = atomicAdd(&cnt[slice], 1u);
+                                  __builtin_memcpy(&val[q][i], pr, sizeof(V));
+                              }
+                      });
     __syncthreads();
-    // first wave: exclusive scan of this chunk's slice counts (offsets into the staging buffer), 64 slices per step
     const uint32_t per = S / 64;  // S is a power of two >= 64
-    if (threadIdx.x < 64) {
-        uint32_t carry = 0;
-        for (uint32_t j = 0; j < per; j++) {
-            const uint32_t c = cnt[j * 64 + threadIdx.x];
-            const uint32_t incl = wave_incl_scan(c);
-            base[j * 64 + threadIdx.x] = carry + incl - c;
-            carry += __shfl(incl, 63, 64);
-        }
-    }
-    __syncthreads();
-    // ... then, while the other waves stage their records, the first wave reserves the chunk's run in every slice's
-    // bucket: bucket start (exclusive scan of the level's slice totals) + one returning atomic per non-empty slice
+    // the first wave reserves the chunk's run in every slice's bucket: bucket start (exclusive scan of the level's slice
+    // totals) + one returning atomic per non-empty slice
     if (threadIdx.x < 64) {
         uint32_t carry = 0;
 #pragma unroll
@@ -616,34 +653,27 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const T* __restrict__ grad
             }
         }
     }
-    if (active) {
+    __syncthreads();  // gbase complete
+    // Records go straight from registers to their place in the bucket (bucket start + the chunk's reserved run + rank).
+    // [A 64 KiB LDS staging buffer that sorted the chunk by slice for contiguous stores was dropped with the quad merge:
+    //  sized for the worst case (no merging) it left only 8 waves per CU and the kernel became latency-bound.  Each lane's
+    //  8-byte stores are scattered, but a bucket's lines fill within one workgroup's run and merge in L2.]
+    const size_t region = (size_t)blockIdx.y * K * B;  // this level's record region inside the pass
+#pragma unroll
+    for (uint32_t q = 0; q < kBinQuad; q++) {
+        if (!((closed >> q) & 1u)) continue;
 #pragma unroll
         for (uint32_t idx = 0; idx < K; idx++) {
-            const uint32_t at = base[key[idx] >> 20] + rank[idx];
+            const uint32_t sl = key[q][idx] >> 20;
+            const size_t at = region + gbase[sl] + rank[q][idx];
             if constexpr (kPacked) {
                 uint32_t bits;
-                __builtin_memcpy(&bits, &val[idx], 4);
-                srecs[at] = make_uint2(key[idx], bits);
+                __builtin_memcpy(&bits, &val[q][idx], 4);
+                reinterpret_cast<uint2*>(gkeys)[at] = make_uint2(key[q][idx] & 0xfffffu, bits);
             } else {
-                skeys[at] = key[idx];
-                svals[at] = val[idx];
+                gkeys[at] = key[q][idx] & 0xfffffu;
+                gvals[at] = val[q][idx];
             }
-        }
-    }
-    __syncthreads();
-    const uint32_t total = base[S - 1] + cnt[S - 1];
-    const size_t region = (size_t)blockIdx.y * K * B;  // this level's record region inside the pass
-    for (uint32_t i = threadIdx.x; i < total; i += P) {
-        if constexpr (kPacked) {
-            const uint2 r = srecs[i];
-            const uint32_t s = r.x >> 20;
-            reinterpret_cast<uint2*>(gkeys)[region + gbase[s] + (i - base[s])] = make_uint2(r.x & 0xfffffu, r.y);
-        } else {
-            const uint32_t k = skeys[i];
-            const uint32_t s = k >> 20;
-            const size_t at = region + gbase[s] + (i - base[s]);
-            gkeys[at] = k & 0xfffffu;
-            gvals[at] = svals[i];
         }
     }
 }
@@ -881,10 +911,9 @@ inline BinLayout bin_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint
     if (!(C == 1 || C == 2 || C == 4 || C == 8) || D < 2 || D > 5 || !max_level_rows || !L || L > kMaxLevels || !B) return o;
     const uint32_t rec = 4 + elem * C;
     o.smax = bin_slices(max_level_rows, C);  // bin_slices is monotone in rows: no level has more slices
-    const uint32_t p = (kBinStageBytes / (rec << D)) / 64 * 64;
-    o.ok = o.smax <= kBinMaxSlices && p >= 64 && ((uint64_t)B << D) < (1ull << 31);
+    o.ok = o.smax <= kBinMaxSlices && ((uint64_t)B << D) < (1ull << 31);
     if (!o.ok) return o;
-    o.chunk_points = p > 1024 ? 1024 : p;
+    o.chunk_points = 1024;  // = bin_chunk_points<T, D, C>()
     o.chunks = div_up<uint32_t>(B, o.chunk_points);
     const size_t per_level = ((size_t)B << D) * rec;
     const size_t lp = kBinPassBytes / per_level;
@@ -909,7 +938,7 @@ int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets
         using V = typename FeatVec<T, C>::type;
         constexpr uint32_t P = bin_chunk_points<T, D, C>();
         constexpr uint32_t K = 1u << D;
-        constexpr uint32_t stage = kBinCtlWords * 4 + P * K * (4 + (uint32_t)sizeof(V));
+        constexpr uint32_t stage = 2 * kBinMaxSlices * 4;  // slice counters + reserved bucket offsets
         static bool attr_set = false;
         if (!attr_set) {
             S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_scatter<T, D, C>),
@@ -932,7 +961,7 @@ int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets
                            offsets, B, ppb, sc, hdr, tot, lay.smax, gridtype, ac, interp);
         for (uint32_t l0 = 0; l0 < L; l0 += lay.levels_per_pass) {
             const uint32_t nl = (L - l0 < lay.levels_per_pass) ? L - l0 : lay.levels_per_pass;
-            hipLaunchKernelGGL((k_bin_scatter<T, D, C>), dim3(lay.chunks, nl), dim3(P), stage, st, grad, inputs, offsets, B, l0, sc,
+            hipLaunchKernelGGL((k_bin_scatter<T, D, C>), dim3(lay.chunks, nl), dim3(P / kBinQuad), stage, st, grad, inputs, offsets, B, l0, sc,
                                (const uint32_t*)hdr, (const uint32_t*)tot, cursor, lay.smax, keys, vals, gridtype, ac, interp);
             hipLaunchKernelGGL((k_bin_accumulate<T, D, C>), dim3(lay.smax, nl), dim3(kBinAccThreads), kBinAccBytes, st,
                                (const uint32_t*)keys, (const V*)vals, offsets, grad_emb, B, l0, (const uint32_t*)hdr,
