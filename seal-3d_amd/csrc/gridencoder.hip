@@ -355,6 +355,9 @@ __device__ __forceinline__ long long to_fixed64(float v, int k) {
 //
 // Slices are INTERLEAVED in groups of kBinGroup rows (slice = (row / 32) % S): a dense level's rows follow the
 // scene's geometry, and contiguous slices would leave the slabs that cover the object with most of the records.
+#ifndef S3D_BIN_CHUNK  // points per k_bin_scatter workgroup: every workgroup ends with one returning atomic per slice on the
+#define S3D_BIN_CHUNK 1024  // same cursor words (measured: 1024 beats 2048 and 4096 — the reservations are not what bounds the kernel)
+#endif
 #ifndef S3D_BIN_ACC_KB  // tuning knobs of k_bin_accumulate (tools/tune_bin.sh builds variants)
 #define S3D_BIN_ACC_KB 128
 #define S3D_BIN_ACC_THREADS 1024
@@ -380,7 +383,7 @@ __host__ __device__ inline uint32_t bin_local_rows(uint32_t rows, uint32_t S) {
 }
 constexpr uint32_t kBinQuad = 4;  // consecutive points handled (and merged) by one lane of k_bin_count / k_bin_scatter
 template <typename T, uint32_t D, uint32_t C>
-__host__ __device__ constexpr uint32_t bin_chunk_points() { return 1024; }  // points per scatter workgroup (256 lanes x 4)
+__host__ __device__ constexpr uint32_t bin_chunk_points() { return S3D_BIN_CHUNK; }  // points per scatter workgroup (lanes x 4)
 
 // Level-uniform index plan (get_grid_index, gridencoder.cu:66-84): which dimensions enter the dense index (the
 // stride loop stops once stride > hashmap_size), their strides, whether the level is hashed; `% hashmap_size` is a
@@ -564,7 +567,7 @@ __global__ void __launch_bounds__(kBinCountThreads) k_bin_count(const T* __restr
 }
 
 template <typename T, uint32_t D, uint32_t C>
-__global__ void __launch_bounds__(256) k_bin_scatter(const T* __restrict__ grad, const float* __restrict__ inputs,
+__global__ void __launch_bounds__(S3D_BIN_CHUNK / 4) k_bin_scatter(const T* __restrict__ grad, const float* __restrict__ inputs,
                                                     const int32_t* __restrict__ offsets, uint32_t B, uint32_t level0,
                                                     LevelScales scales, const uint32_t* __restrict__ hdr,
                                                     const uint32_t* __restrict__ tot, uint32_t* __restrict__ cursor,
@@ -913,7 +916,7 @@ inline BinLayout bin_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint
     o.smax = bin_slices(max_level_rows, C);  // bin_slices is monotone in rows: no level has more slices
     o.ok = o.smax <= kBinMaxSlices && ((uint64_t)B << D) < (1ull << 31);
     if (!o.ok) return o;
-    o.chunk_points = 1024;  // = bin_chunk_points<T, D, C>()
+    o.chunk_points = S3D_BIN_CHUNK;  // = bin_chunk_points<T, D, C>()
     o.chunks = div_up<uint32_t>(B, o.chunk_points);
     const size_t per_level = ((size_t)B << D) * rec;
     const size_t lp = kBinPassBytes / per_level;
