@@ -341,13 +341,13 @@ __device__ __forceinline__ long long to_fixed64(float v, int k) {
 // 64-bit fixed point, one workgroup per (level, table slice), and the (point, level, corner) contributions are first
 // PARTITIONED by slice so that each workgroup streams exactly its own records:
 //   k_bin_count    per-level |grad| max (fixes the fixed-point scale) + records per (level, slice)
-//   k_bin_scatter  one workgroup = one chunk of points at one level: forms the 2^D records of each point
-//                  {row-in-slice, w * grad rounded to T — the product the reference adds}, counting-sorts them by
-//                  slice in an LDS staging buffer, reserves a run in every slice's bucket (one atomic per slice) and
-//                  copies the sorted chunk out as contiguous runs
+//   k_bin_scatter  one workgroup = one chunk of points at one level, one lane = four consecutive points: forms the 2^D
+//                  records {row-in-slice, sum of w * grad rounded to T} of every run of same-cell points (bin_quad),
+//                  ranks them per slice with LDS counters, reserves a run in every slice's bucket (one returning
+//                  atomic per slice) and stores the records at bucket start + reserved offset + rank
 //   k_bin_accumulate  one workgroup = one (level, slice): streams its bucket, ds_add_u64 into the slice, adds the
 //                  slice into the table with coalesced stores.
-// Each contribution is computed once and costs one HBM write + one read of an 8-byte record (fp16, C = 2); integer
+// Each contribution is computed once and costs at most one HBM write + one read of an 8-byte record (fp16, C = 2); integer
 // adds commute, so the result is bit-reproducible run to run (the reference's float atomics are not) and carries
 // ~40 bits below the largest |grad| of the level.  Small batches keep the direct-atomic kernel.
 // [An earlier version skipped the partition: every (level, slice) workgroup scanned ALL points and kept the hits.
