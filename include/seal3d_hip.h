@@ -230,6 +230,17 @@ int s3d_bg_mse_forward(const float* image, const float* weights_sum, const float
 int s3d_bg_mse_backward(const float* image, const float* weights_sum, const float* gt, const float* bg_rgb, uint32_t N,
                         const float* grad_loss, float* grad_image, float* grad_weights_sum, s3d_stream_t stream);
 
+/* ------------------------------------------------------------------ Seal proxy mapper (bbox tool)
+ * SealNeRF/seal_utils.py:132-153 (map_mask), :237-279 (map_to_origin), :630-685 (two-ray Moller-Trumbore inside test)
+ * in one pass over the sample points.  points/dirs/out_* are DEVICE [M,3] f32, mask DEVICE [M] u8; everything that
+ * describes the edit is HOST data (a handful of constants): triangles [n_tris,3,3], bounds [n_bounds,2,3] (min,max),
+ * inv_transform [4,4] row-major, inv_rotation [3,3], inv_scale [3], center [3]; empty_bound [2,3] + map_source [3] or
+ * both NULL.  out_dirs/dirs may both be NULL. */
+int s3d_seal_bbox_map(const float* points, const float* dirs, uint32_t M, const float* triangles, uint32_t n_tris,
+                      const float* bounds, uint32_t n_bounds, const float* inv_transform, const float* inv_rotation,
+                      const float* inv_scale, const float* center, const float* empty_bound, const float* map_source,
+                      float* out_points, float* out_dirs, uint8_t* mask, s3d_stream_t stream);
+
 /* ------------------------------------------------------------------ parameter update
  * The reference's update is torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15) under torch.cuda.amp.GradScaler
  * (nerf/utils.py:356-361, 495-537; main_SealNeRF.py:283-288).  These three calls are that update taken directly

@@ -41,6 +41,7 @@ EXPORTS = [
     "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_advance", "s3d_scaler_update",
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
     "s3d_bg_mse_forward", "s3d_bg_mse_backward",
+    "s3d_seal_bbox_map",
 ]
 
 
@@ -461,3 +462,29 @@ class NgpHeadBackend:
         bg = (C.c_float * 3)(*[float(v) for v in bg_rgb])
         _check(lib().s3d_bg_mse_backward(_p(image), _p(weights_sum), _p(gt), bg, _u(image.shape[0]), _p(grad_loss),
                                          _p(grad_image), _p(grad_weights_sum), _stream()), "bg_mse_backward")
+
+
+class SealBackend:
+    """csrc/seal.hip — Seal-3D's bbox proxy mapper (SealNeRF/seal_utils.py:132-279, 630-685) on the device"""
+
+    @staticmethod
+    def bbox_map(points, dirs, host, out_points, out_dirs, mask):
+        """`host`: dict of float32 numpy arrays (triangles, bounds, inv_transform, inv_rotation, inv_scale, center and
+        optionally empty_bound, map_source) — the edit's constants live on the host."""
+        import numpy as np
+        _need(points, torch.float32, "points")
+        if mask.dtype != torch.uint8:
+            raise RuntimeError("mask must be uint8")
+
+        def hp(name):
+            a = host.get(name)
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            return a, a.ctypes.data_as(C.POINTER(C.c_float))
+        keep = [hp(k) for k in ("triangles", "bounds", "inv_transform", "inv_rotation", "inv_scale", "center", "empty_bound",
+                                "map_source")]
+        ptr = [k[1] for k in keep]
+        _check(lib().s3d_seal_bbox_map(_p(points), _p(dirs), _u(points.shape[0]), ptr[0], _u(keep[0][0].shape[0]), ptr[1],
+                                       _u(keep[1][0].shape[0]), ptr[2], ptr[3], ptr[4], ptr[5], ptr[6], ptr[7], _p(out_points),
+                                       _p(out_dirs), _p(mask), _stream()), "seal_bbox_map")

@@ -82,6 +82,15 @@ class SealBBoxMapper:
             self.map_data["map_source"] = torch.tensor(seal_config["mapSource"], dtype=torch.float32)
         self.map_triangles = torch.tensor(tris, dtype=torch.float32)
         self.device = torch.device("cpu")
+        # the same constants as float32 host arrays for the device kernel (csrc/seal.hip)
+        md = self.map_data
+        self._host = {"triangles": self.map_triangles.numpy().copy(),
+                      "bounds": md["map_bound"].numpy().reshape(-1, 2, 3).copy(),
+                      "inv_transform": md["transform"].numpy().copy(), "inv_rotation": md["rotation"].numpy().copy(),
+                      "inv_scale": md["scale"].numpy().copy(), "center": md["center"].numpy().copy()}
+        if "map_source" in md:
+            self._host["empty_bound"] = md["empty_bound"].numpy().copy()
+            self._host["map_source"] = md["map_source"].numpy().copy()
 
     def to(self, device):
         if device != self.device:
@@ -105,9 +114,24 @@ class SealBBoxMapper:
         mask[mask.clone()] = inside
         return mask
 
+    native = True  # GPU tensors go through the one-pass device kernel; False = the reference's torch op sequence
+
+    def _map_native(self, points, dirs):
+        import s3d_hip
+        lead = points.shape
+        p = points.reshape(-1, 3).contiguous()
+        d = dirs.reshape(-1, 3).float().contiguous() if dirs is not None else None
+        out_p = torch.empty_like(p)
+        out_d = torch.empty_like(d) if d is not None else None
+        mask = torch.empty(p.shape[0], dtype=torch.bool, device=p.device)
+        s3d_hip.SealBackend.bbox_map(p, d, self._host, out_p, out_d, mask.view(torch.uint8))
+        return out_p.view(lead), (out_d.view(dirs.shape) if dirs is not None else None), mask
+
     @torch.autocast("cuda", enabled=False)
     def map_to_origin(self, points, dirs=None):
         """seal_utils.py:237-279"""
+        if self.native and points.is_cuda and points.dtype == torch.float32 and points.shape[-1] == 3 and points.numel() > 0:
+            return self._map_native(points, dirs)
         self.to(points.device)
         mask = self.map_mask(points)
         if not mask.any():

@@ -74,3 +74,30 @@ def test_tensorf_vm48_step_on_gpu(hip):
     net.upsample_model([160] * 3)
     out = tr.render_image(ro[None, :1000], rd[None, :1000])
     assert out["image"].shape == (1, 1000, 3) and torch.isfinite(out["image"]).all()
+
+
+@pytest.mark.parametrize("kind", ["both", "to", "from"])
+def test_seal_bbox_mapper_device_kernel_matches_torch_sequence(hip, kind):
+    """csrc/seal.hip vs the torch restatement of SealNeRF/seal_utils.py:132-279 on the same points: identical masks (a point
+    exactly on a face could differ by rounding — none may in this random set), mapped points / directions within fp32 rounding."""
+    from sealnerf import SealBBoxMapper
+    cfg = dict(BBOX, boundType=kind, scale=[1.2, 0.8, 1.0],
+               transform=[[0.8, -0.6, 0, 0.3], [0.6, 0.8, 0, 0.05], [0, 0, 1, -0.1], [0, 0, 0, 1]])
+    if kind == "both":
+        cfg["mapSource"] = [0.9, 0.9, 0.9]
+    mapper = SealBBoxMapper(cfg)
+    g = torch.Generator().manual_seed(11)
+    pts = (torch.rand(200000, 3, generator=g) * 1.6 - 0.8).cuda()
+    pts[:7] = 0.0                       # `points.all(1)` rows
+    pts[7:20, 1] = 0.0
+    dirs = torch.nn.functional.normalize(torch.randn(200000, 3, generator=g), dim=-1).cuda()
+    mapper.native = True
+    p_n, d_n, m_n = mapper.map_to_origin(pts, dirs)
+    mapper.native = False
+    p_t, d_t, m_t = mapper.map_to_origin(pts, dirs)
+    assert m_n.dtype == torch.bool and 1000 < int(m_t.sum()) < 190000
+    assert torch.equal(m_n, m_t)
+    torch.testing.assert_close(p_n, p_t, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(d_n, d_t, rtol=1e-5, atol=1e-6)
+    p_only, none_d, m2 = SealBBoxMapper(cfg).map_to_origin(pts)  # without directions
+    assert none_d is None and torch.equal(m2, m_n) and torch.equal(p_only, p_n)
