@@ -77,6 +77,33 @@ class NativeAdam(torch.optim.Optimizer):
                     else:
                         p.grad.zero_()
 
+    def resync_half(self):
+        """re-make the fp16 copies after the fp32 parameters were written from outside (checkpoint load)"""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if hasattr(p, "_s3d_half"):
+                    p._s3d_half.copy_(p.detach())
+                    p._s3d_half_version = p._version
+
+    def state_dict(self):
+        """torch.optim.Adam's layout: per-parameter `step` next to exp_avg / exp_avg_sq (one shared count here)"""
+        sd = super().state_dict()
+        step = None if self.step_count is None else self.step_count.detach().reshape(()).cpu().clone()
+        for st in sd["state"].values():
+            st["step"] = step.clone()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = []
+        for p, st in self.state.items():
+            if "step" in st:
+                steps.append(float(st.pop("step")))
+            for k in ("exp_avg", "exp_avg_sq"):  # (torch casts the moments to the parameter's dtype/device already)
+                st[k] = st[k].contiguous()
+        if steps:
+            self.step_count.fill_(max(steps))
+
     @torch.no_grad()
     def step(self, grad_scale=None, found_inf=None):
         for group, p, g in self.grads():
@@ -116,6 +143,21 @@ class NativeGradScaler:
             loss.backward(gradient=self._scale.reshape(()).to(loss.dtype))
         else:
             loss.backward()
+
+    def state_dict(self):
+        """torch.amp.GradScaler.state_dict()'s keys (empty when disabled, like torch)"""
+        if not self.enabled:
+            return {}
+        return {"scale": self.get_scale(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(self._growth_tracker.item())}
+
+    def load_state_dict(self, state):
+        if not self.enabled or not state:
+            return
+        self._scale.fill_(state["scale"])
+        self._growth_tracker.fill_(state["_growth_tracker"])
+        self.growth_factor, self.backoff_factor = state["growth_factor"], state["backoff_factor"]
+        self.growth_interval = state["growth_interval"]
 
     def step(self, optimizer):
         # (found_inf is cleared by update(); it starts at zero)

@@ -69,8 +69,20 @@ class Trainer:
                                               capturable=capturable and on_gpu)
             self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
         self.global_step = 0
+        self.epoch = 0
+        self.stats = {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}
         if dist is not None:
             dist.register(model)
+
+    def save_checkpoint(self, workspace, name="ngp", full=False, best=False, remove_old=True, max_keep_ckpt=2):
+        """reference on-disk format (nerf/utils.py:1015-1076); see nerf/checkpoint.py"""
+        from .checkpoint import save_checkpoint
+        return save_checkpoint(self, workspace, name, full=full, best=best, remove_old=remove_old, max_keep_ckpt=max_keep_ckpt)
+
+    def load_checkpoint(self, checkpoint, model_only=False):
+        """reference on-disk format (nerf/utils.py:1078-1137); a file written by the reference's Trainer loads as is"""
+        from .checkpoint import load_checkpoint
+        return load_checkpoint(self, checkpoint, model_only=model_only)
 
     def _maybe_update_extra_state(self):
         model = self.model
@@ -202,6 +214,11 @@ class GraphedTrainer(Trainer):
                 self._body_opt()
         model.step_counter = ring
         model.mean_count, model.local_step = saved
+
+    def load_checkpoint(self, checkpoint, model_only=False):
+        out = super().load_checkpoint(checkpoint, model_only=model_only)
+        self.graph = self.graph_opt = None  # optimizer state tensors were replaced, mean_count may have moved: re-capture
+        return out
 
     def _replay(self):
         self.graph.replay()

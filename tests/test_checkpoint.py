@@ -1,0 +1,123 @@
+"""Checkpoint files in the reference's layout (nerf/utils.py:1015-1137 of the reference): keys, rotation, 'best' without
+density_grid, bare state-dicts, and optimizer / scaler state in torch.optim.Adam / GradScaler form."""
+import os
+import sys
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "seal-3d_amd"))
+
+from nerf.network import NeRFNetwork  # noqa: E402
+from nerf.trainer import Trainer  # noqa: E402
+
+# state-dict keys of the reference's `-O` network: parameter layout the kernels honour
+REFERENCE_KEYS = {
+    "aabb_train": (6,), "aabb_infer": (6,), "density_grid": (1, 128 ** 3), "density_bitfield": (128 ** 3 // 8,),
+    "step_counter": (16, 2), "encoder.embeddings": (6119864, 2), "encoder.offsets": (17,),
+    "sigma_net.0.weight": (64, 32), "sigma_net.1.weight": (16, 64),
+    "encoder_color.embeddings": (6119864, 2), "encoder_color.offsets": (17,),
+    "color_net.0.weight": (64, 63), "color_net.1.weight": (64, 64), "color_net.2.weight": (3, 64),
+}
+
+
+def small_model(seed=0):
+    torch.manual_seed(seed)
+    return NeRFNetwork(bound=1, cuda_ray=True)
+
+
+def test_state_dict_keys_are_the_reference_ones():
+    sd = small_model().state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == REFERENCE_KEYS
+    assert sd["density_bitfield"].dtype == torch.uint8 and sd["step_counter"].dtype == torch.int32
+    assert sd["encoder.offsets"].dtype == torch.int32
+
+
+def test_ff_network_keys():
+    from nerf.network_ff import NeRFNetwork as FF
+    sd = FF(bound=1, cuda_ray=True).state_dict()
+    assert sd["sigma_net.weights"].numel() == 32 * 64 + 64 * 64 + 64 * 16  # ffmlp.py:122 of the reference: one flat fp32 vector
+    assert sd["color_net.weights"].numel() == 32 * 64 + 64 * 64 + 64 * 16 + 64 * 64
+    assert "encoder.embeddings" in sd and "density_bitfield" in sd
+
+
+def test_save_load_roundtrip_and_rotation(tmp_path):
+    m = small_model(0)
+    t = Trainer(m, fp16=False)
+    m.mean_count, m.mean_density = 123, 0.5
+    paths = []
+    for ep in range(1, 5):
+        t.epoch, t.global_step = ep, ep * 100
+        paths.append(t.save_checkpoint(str(tmp_path), name="ngp", full=True))
+    assert os.path.basename(paths[-1]) == "ngp_ep0004.pth"
+    assert [os.path.exists(p) for p in paths] == [False, False, True, True]  # max_keep_ckpt = 2
+    ck = torch.load(paths[-1], weights_only=False)
+    assert set(ck) == {"epoch", "global_step", "stats", "mean_count", "mean_density", "model", "optimizer", "scaler"}
+    assert set(ck["model"]) == set(REFERENCE_KEYS)
+
+    m2 = small_model(1)
+    assert not torch.equal(m2.encoder.embeddings, m.encoder.embeddings)
+    t2 = Trainer(m2, fp16=False)
+    missing, unexpected = t2.load_checkpoint(paths[-1])
+    assert missing == [] and unexpected == []
+    assert (t2.epoch, t2.global_step, m2.mean_count, m2.mean_density) == (4, 400, 123, 0.5)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+
+
+def test_best_drops_density_grid_and_loads_non_strict(tmp_path):
+    m = small_model(0)
+    t = Trainer(m, fp16=False)
+    assert t.save_checkpoint(str(tmp_path), best=True) is None  # nothing evaluated yet
+    t.stats["results"].append(0.25)
+    p = t.save_checkpoint(str(tmp_path), name="ngp", best=True)
+    assert os.path.basename(p) == "ngp.pth" and t.stats["best_result"] == 0.25
+    t.stats["results"].append(0.5)
+    assert t.save_checkpoint(str(tmp_path), name="ngp", best=True) is None  # not an improvement (lower is better)
+    ck = torch.load(p, weights_only=False)
+    assert "density_grid" not in ck["model"] and "density_bitfield" in ck["model"]
+    m2 = small_model(1)
+    missing, unexpected = Trainer(m2, fp16=False).load_checkpoint(p, model_only=True)
+    assert missing == ["density_grid"] and unexpected == []
+    assert torch.equal(m2.encoder.embeddings, m.encoder.embeddings)
+
+
+def test_bare_state_dict_and_reference_written_file(tmp_path):
+    """what the reference's Trainer writes (dict built by hand here, same keys and types) loads, and so does a bare state-dict"""
+    g = torch.Generator().manual_seed(3)
+    model_sd = {}
+    for k, shape in REFERENCE_KEYS.items():
+        if k == "density_bitfield":
+            model_sd[k] = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+        elif k in ("step_counter", "encoder.offsets", "encoder_color.offsets"):
+            model_sd[k] = small_model().state_dict()[k].clone()
+        else:
+            model_sd[k] = torch.rand(shape, generator=g)
+    ref_file = {"epoch": 30, "global_step": 30000, "stats": {"loss": [0.1], "valid_loss": [], "results": [0.01],
+                                                             "checkpoints": [], "best_result": 0.01},
+                "mean_count": 250000, "mean_density": 1.25, "model": model_sd}
+    p = str(tmp_path / "ngp_ep0030.pth")
+    torch.save(ref_file, p)
+    m = small_model(0)
+    t = Trainer(m, fp16=False)
+    assert t.load_checkpoint(p) == ([], [])
+    assert t.epoch == 30 and t.global_step == 30000 and m.mean_count == 250000
+    assert torch.equal(m.density_bitfield, model_sd["density_bitfield"])
+    assert torch.equal(m.color_net[2].weight, model_sd["color_net.2.weight"])
+    bare = str(tmp_path / "bare.pth")
+    torch.save(model_sd, bare)
+    m3 = small_model(2)
+    Trainer(m3, fp16=False).load_checkpoint(bare)
+    assert torch.equal(m3.encoder_color.embeddings, model_sd["encoder_color.embeddings"])
+
+
+def test_latest_checkpoint(tmp_path):
+    from nerf.checkpoint import latest_checkpoint
+    assert latest_checkpoint(str(tmp_path)) is None
+    m = small_model(0)
+    t = Trainer(m, fp16=False)
+    for ep in (3, 12):
+        t.epoch = ep
+        t.save_checkpoint(str(tmp_path))
+    assert latest_checkpoint(str(tmp_path)).endswith("ngp_ep0012.pth")

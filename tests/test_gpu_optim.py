@@ -117,3 +117,47 @@ def test_ffmlp_weight_grad_handover(hip):
                 (m(x).float() ** 2).mean().backward()
     assert ma.weights.grad is None and ma.weights._s3d_grad_touched
     torch.testing.assert_close(ma.weights._s3d_grad.float(), mb.weights.grad, rtol=2e-3, atol=1e-4)
+
+
+def test_optimizer_and_scaler_state_dicts_interchange_with_torch(hip):
+    """a `full` checkpoint (nerf/utils.py:1031-1036 of the reference) carries torch.optim.Adam / GradScaler state: state
+    saved by the native pair resumes under torch's and the other way round, and both continue identically"""
+    from nerf.optim import NativeAdam, NativeGradScaler
+    p0 = [_mk((513, 2), 1), _mk((777,), 2)]
+
+    def grads(params, step):
+        for i, p in enumerate(params):
+            p.grad = _mk(p.shape, 100 + 10 * step + i).cuda()
+
+    pa = [torch.nn.Parameter(t.clone().cuda()) for t in p0]
+    oa = NativeAdam([{"params": pa}], lr=1e-2)
+    for step in range(3):
+        grads(pa, step)
+        oa.step()
+    sd = oa.state_dict()
+    assert all(float(st["step"]) == 3.0 and set(st) == {"step", "exp_avg", "exp_avg_sq"} for st in sd["state"].values())
+
+    pb = [torch.nn.Parameter(a.detach().clone()) for a in pa]
+    ob = torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    ob.load_state_dict(sd)
+    pc = [torch.nn.Parameter(a.detach().clone()) for a in pa]
+    oc = NativeAdam([{"params": pc}], lr=1e-2)
+    oc.load_state_dict(ob.state_dict())  # torch -> native
+    assert float(oc.step_count) == 3.0
+    for step in range(3, 6):
+        for o, ps in ((oa, pa), (ob, pb), (oc, pc)):
+            grads(ps, step)
+            o.step()
+    for a, b, c in zip(pa, pb, pc):
+        assert torch.equal(a, c)  # native resumed == native uninterrupted, bit for bit
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-6, atol=1e-7)
+
+    sa = NativeGradScaler("cuda")
+    sa._scale.fill_(4096.0)
+    sa._growth_tracker.fill_(17)
+    sb = torch.amp.GradScaler("cuda")
+    sb.load_state_dict(sa.state_dict())
+    assert sb.state_dict() == sa.state_dict()
+    sc = NativeGradScaler("cuda")
+    sc.load_state_dict(sb.state_dict())
+    assert sc.get_scale() == 4096.0 and int(sc._growth_tracker) == 17

@@ -78,3 +78,30 @@ def test_data_parallel_split_graph_step_single_rank(hip):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_checkpoint_resume_under_graph_replay(hip, tmp_path):
+    """train (graph replay, native optimizer) -> full checkpoint in the reference's format -> load into a fresh graphed
+    trainer: renders are bit-identical (the fp16 table copies followed the loaded fp32 weights) and training resumes"""
+    from nerf.trainer import GraphedTrainer
+    model, batches = _setup()
+    tr = GraphedTrainer(model, 2048, lr=1e-2, fp16=True)
+    _run(tr, batches, 40)
+    tr.epoch = 1
+    path = tr.save_checkpoint(str(tmp_path), full=True)
+    ro, rd, _ = batches[0]
+    img = tr.render_image(ro, rd)["image"].clone()
+
+    model2, _ = _setup()
+    tr2 = GraphedTrainer(model2, 2048, lr=1e-2, fp16=True)
+    _run(tr2, batches, 20)  # has a captured graph and its own optimizer state, both must be dropped by the load
+    assert tr2.load_checkpoint(path) == ([], [])
+    assert tr2.global_step == 40 and model2.mean_count == model.mean_count and tr2.graph is None
+    assert float(tr2.optimizer.step_count) == float(tr.optimizer.step_count)
+    assert tr2.scaler.get_scale() == tr.scaler.get_scale()
+    assert torch.equal(tr2.render_image(ro, rd)["image"], img)
+    emb = model2.encoder.embeddings
+    assert torch.equal(emb._s3d_half, emb.detach().half())
+    before = float(_run(tr, batches, 8).mean())
+    after = float(_run(tr2, batches, 8).mean())
+    assert tr2.graph is not None and abs(after - before) < 0.5 * before + 1e-3, (before, after)
