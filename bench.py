@@ -107,7 +107,8 @@ class KernelTimers:
                 r = __f(*a, **kw)
                 e.record()
                 self.events[__n].append((s, e))
-                self.meta[__n].append(meta_fn(__n, a))
+                nv = kw.get("n_valid")  # padded batch: the kernel works on round_up(*n_valid, 128) of the B rows
+                self.meta[__n].append((meta_fn(__n, a), None if nv is None else nv.reshape(-1)[:1].clone()))
                 return r
             setattr(self.cls, n, staticmethod(wrapped))
 
@@ -126,8 +127,9 @@ class KernelTimers:
             if not self.events[n]:
                 continue
             ms = [s.elapsed_time(e) for s, e in self.events[n]]
+            units = [B if nv is None else min(B, (max(int(nv.item()), 0) + 127) // 128 * 128) for B, nv in self.meta[n]]
             out[n] = dict(calls=len(ms), total_ms=float(sum(ms)), avg_us=float(np.mean(ms) * 1e3),
-                          units=float(np.mean(self.meta[n])))
+                          units=float(np.mean(units)))
         return out
 
 

@@ -14,7 +14,15 @@
  *     grid.py:77, raymarching.py:283-284, sphere_harmonics.py:50;
  *   - kernels never allocate; functions that need scratch take a caller-owned
  *     workspace whose size the matching *_workspace_size() reports;
- *   - dtype: S3D_F32 / S3D_F16 select the element type of `void*` tensors.
+ *   - dtype: S3D_F32 / S3D_F16 select the element type of `void*` tensors;
+ *   - n_valid (grid encoder, ffmlp, NGP head; NULL = off): DEVICE pointer to the sample count the ray marcher
+ *     left in `counter[0]` (raymarching.cu:431-437).  The training step marches into buffers of a static extent
+ *     B (raymarching.py:205-207 sizes them from a running mean) and only the first *n_valid rows hold samples;
+ *     with the pointer, rows [round_up(*n_valid, 128), B) are absent for the call — neither read nor written,
+ *     their outputs keep whatever the caller's buffer held — so the per-sample work follows the samples without
+ *     a host read-back (the step stays HIP-graph capturable with one generous B).  Strides and layouts are
+ *     those of B.  Results for the valid rows and every reduced gradient are identical to a call without it on
+ *     the same buffers with zero gradient in the tail.
  * INTEGRATION.md shows the pybind / ctypes stub a maintainer of the reference
  * would add on top of this header.
  */
@@ -126,7 +134,8 @@ void s3d_grid_level_scales(uint32_t L, float S, uint32_t H, float* scales_out /*
 int s3d_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets,
                             void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                             uint32_t H, void* dy_dx, uint32_t gridtype, int align_corners,
-                            uint32_t interp, int dtype, float bound, s3d_stream_t stream);
+                            uint32_t interp, int dtype, float bound, const int32_t* n_valid,
+                            s3d_stream_t stream);
 
 /* Test hook: table row of every corner, corner_idx [B,L,2^D] u32 (0xffffffff for out-of-range points). */
 int s3d_grid_corner_indices(const float* inputs, const int32_t* offsets, uint32_t* corner_idx, uint32_t B,
@@ -148,7 +157,7 @@ int s3d_grid_encode_backward(const void* grad, const float* inputs, const void* 
                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                              const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                              uint32_t interp, int dtype, void* workspace, size_t workspace_bytes,
-                             float bound, s3d_stream_t stream);
+                             float bound, const int32_t* n_valid, s3d_stream_t stream);
 /* experiments/tests: 0 = auto, 1 = direct atomics, 2 = binned (partition + LDS accumulate) */
 void s3d_grid_backward_set_path(int path);
 
@@ -183,7 +192,7 @@ int s3d_freq_encode_backward(const float* grad, const float* outputs, uint32_t B
 int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                       uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                       uint32_t output_activation, uint16_t* forward_buffer, uint16_t* outputs,
-                      int input_layout, s3d_stream_t stream);
+                      int input_layout, const int32_t* n_valid, s3d_stream_t stream);
 /* ffmlp.h:9: same network without storing intermediates (inference_buffer is unused scratch) */
 int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                         uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
@@ -206,7 +215,7 @@ int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
                        uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer,
                        uint16_t* grad_inputs, uint16_t* grad_weights, void* workspace,
                        size_t workspace_bytes, int input_layout, int accumulate_grad_weights,
-                       s3d_stream_t stream);
+                       const int32_t* n_valid, s3d_stream_t stream);
 /* ffmlp.h:13-14: the reference allocates split-K side streams here; this build fuses the weight
  * gradient into the backward launch sequence on the caller's stream, so these are no-ops kept for
  * surface compatibility. */
@@ -218,11 +227,12 @@ int s3d_ffmlp_free_splitk(void);
  * sigmoid and their backward nodes) as two streaming kernels per direction, csrc/ngp_head.hip.
  * h, color_in, out and their gradients are fp16 row-major ([B,16], [B,32], [B,16]); sigma, rgb, dirs fp32. */
 int s3d_ngp_mid_forward(const uint16_t* h, const float* dirs, uint32_t B, float* sigma, uint16_t* color_in,
-                        s3d_stream_t stream);
+                        const int32_t* n_valid, s3d_stream_t stream);
 int s3d_ngp_mid_backward(const uint16_t* grad_color_in, const float* grad_sigma /* or NULL */, const uint16_t* h,
-                         uint32_t B, uint16_t* grad_h, s3d_stream_t stream);
-int s3d_ngp_rgb_forward(const uint16_t* out, uint32_t B, float* rgb, s3d_stream_t stream);
-int s3d_ngp_rgb_backward(const float* grad_rgb, const float* rgb, uint32_t B, uint16_t* grad_out, s3d_stream_t stream);
+                         uint32_t B, uint16_t* grad_h, const int32_t* n_valid, s3d_stream_t stream);
+int s3d_ngp_rgb_forward(const uint16_t* out, uint32_t B, float* rgb, const int32_t* n_valid, s3d_stream_t stream);
+int s3d_ngp_rgb_backward(const float* grad_rgb, const float* rgb, uint32_t B, uint16_t* grad_out,
+                         const int32_t* n_valid, s3d_stream_t stream);
 /* Loss head of one ray batch: loss = mean((image + (1 - weights_sum) * bg - gt)^2)  (nerf/renderer.py:316 background
  * compositing + nerf/utils.py:484 MSE); bg_rgb = 3 HOST floats; loss / grad_loss are single device floats. */
 int s3d_bg_mse_forward(const float* image, const float* weights_sum, const float* gt, const float* bg_rgb, uint32_t N,

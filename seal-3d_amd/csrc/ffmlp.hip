@@ -168,7 +168,8 @@ template <int W, bool TRAIN, int ACT, int OACT>
 __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restrict__ X, const _Float16* __restrict__ Wt,
                                                        uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
                                                        uint32_t act, uint32_t out_act, _Float16* __restrict__ fwd,
-                                                       _Float16* __restrict__ out, uint32_t in_layout) {
+                                                       _Float16* __restrict__ out, uint32_t in_layout,
+                                                       const int32_t* __restrict__ n_valid) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     half8* frags = reinterpret_cast<half8*>(smem_raw);
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
     }
     __syncthreads();
 
-    const uint32_t ntiles = B / 32;
+    const uint32_t ntiles = valid_rows(B, n_valid) / 32;
     for (uint32_t tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const size_t row = (size_t)tile * 32 + n;
         float16v acc[MB];
@@ -276,7 +277,8 @@ template <int W, int ACT>
 __global__ void __launch_bounds__(256) k_ffmlp_dgrad(const _Float16* __restrict__ grad, const _Float16* __restrict__ Wt,
                                                      const _Float16* __restrict__ fwd, uint32_t B, uint32_t in_dim,
                                                      uint32_t out_dim, uint32_t n_layers, uint32_t act,
-                                                     _Float16* __restrict__ bwd, _Float16* __restrict__ grad_inputs) {
+                                                     _Float16* __restrict__ bwd, _Float16* __restrict__ grad_inputs,
+                                                     const int32_t* __restrict__ n_valid) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     half8* frags = reinterpret_cast<half8*>(smem_raw);
@@ -314,7 +316,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_dgrad(const _Float16* __restrict_
     }
     __syncthreads();
 
-    const uint32_t ntiles = B / 32;
+    const uint32_t ntiles = valid_rows(B, n_valid) / 32;
     for (uint32_t tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const size_t row = (size_t)tile * 32 + n;
         float16v acc[MB];
@@ -396,7 +398,8 @@ __device__ __forceinline__ uint32_t tile_elem(uint32_t native, uint32_t F, uint3
 
 
 template <int W>
-__global__ void __launch_bounds__(256) k_ffmlp_wgrad(WgradPlan plan, uint32_t B, float* __restrict__ partial) {
+__global__ void __launch_bounds__(256) k_ffmlp_wgrad(WgradPlan plan, uint32_t B, float* __restrict__ partial,
+                                                     const int32_t* __restrict__ n_valid) {
     constexpr uint32_t MAXB = (W + 31) / 32;  // 32-blocks per side
     __shared__ __attribute__((aligned(16))) _Float16 tiles[4][2][32 * W];
     __shared__ float red[kWgradPad * kWgradPad];
@@ -415,7 +418,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_wgrad(WgradPlan plan, uint32_t B,
 
     _Float16* tg = tiles[wave][0];
     _Float16* tx = tiles[wave][1];
-    const uint32_t ntiles = B / 32;  // B % 128 == 0: the four waves of a block always have a tile together
+    const uint32_t ntiles = valid_rows(B, n_valid) / 32;  // B % 128 == 0: the four waves of a block always have a tile together
     for (uint32_t base = blockIdx.x * 4; base < ntiles; base += gridDim.x * 4) {
         const uint32_t tile = base + wave;
         // linear 16-byte copies of the two 32-row tiles into LDS
@@ -568,7 +571,8 @@ template <int W, int NH, int IMB, int ACT>
 __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __restrict__ grad, const _Float16* __restrict__ X,
                                                              const _Float16* __restrict__ Wt, uint32_t B, uint32_t in_dim,
                                                              uint32_t out_dim, uint32_t act, _Float16* __restrict__ grad_inputs,
-                                                             float* __restrict__ partial, uint32_t in_layout) {
+                                                             float* __restrict__ partial, uint32_t in_layout,
+                                                             const int32_t* __restrict__ n_valid) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -639,7 +643,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
         dwl[a] = zero16();
     }
 
-    const uint32_t ntiles = B / 32;
+    const uint32_t ntiles = valid_rows(B, n_valid) / 32;
     for (uint32_t tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const size_t row = (size_t)tile * 32 + n;
         // ---- inputs of the tile: network input (B fragments) and output gradient (one k-step)
@@ -805,6 +809,13 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
 
 constexpr uint32_t kWgradBlocks = 256;
 
+// `n_valid` of the entry point being served on this thread (see valid_rows()); the launch helpers below pass it on
+static thread_local const int32_t* t_n_valid = nullptr;
+struct RowLimitScope {
+    explicit RowLimitScope(const int32_t* p) { t_n_valid = p; }
+    ~RowLimitScope() { t_n_valid = nullptr; }
+};
+
 int check_shape(uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t W, uint32_t n_layers) {
     S3D_REQUIRE(W == 32 || W == 64, "ffmlp: hidden_dim %u not supported by the MFMA path (32 or 64)", W);
     S3D_REQUIRE(in_dim > 0 && in_dim % 16 == 0 && in_dim <= 64, "ffmlp: input_dim must be 16*m, m in 1..4 (got %u)", in_dim);
@@ -823,7 +834,7 @@ int launch_forward(const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t i
     const uint32_t ntiles = B / 32;
     uint32_t grid = div_up<uint32_t>(ntiles, 4);
     if (grid > 1024) grid = 1024;
-#define S3D_FWD(TRAIN, A, O) hipLaunchKernelGGL((k_ffmlp_forward<W, TRAIN, A, O>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out, in_layout)
+#define S3D_FWD(TRAIN, A, O) hipLaunchKernelGGL((k_ffmlp_forward<W, TRAIN, A, O>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out, in_layout, t_n_valid)
     const bool fast = act == ACT_RELU && out_act == ACT_NONE;  // the networks of the hot path; anything else: run-time switch
     if (fwd) { if (fast) S3D_FWD(true, ACT_RELU, ACT_NONE); else S3D_FWD(true, -1, -1); }
     else { if (fast) S3D_FWD(false, ACT_RELU, ACT_NONE); else S3D_FWD(false, -1, -1); }
@@ -844,10 +855,10 @@ int launch_backward(const _Float16* grad, const _Float16* X, const _Float16* Wt,
     if (grid > 1024) grid = 1024;
     if (act == ACT_RELU)
         hipLaunchKernelGGL((k_ffmlp_dgrad<W, ACT_RELU>), dim3(grid), dim3(256), smem, st, grad, Wt, fwd, B, in_dim, out_dim, n_layers,
-                           act, bwd, grad_inputs);
+                           act, bwd, grad_inputs, t_n_valid);
     else
         hipLaunchKernelGGL((k_ffmlp_dgrad<W, -1>), dim3(grid), dim3(256), smem, st, grad, Wt, fwd, B, in_dim, out_dim, n_layers,
-                           act, bwd, grad_inputs);
+                           act, bwd, grad_inputs, t_n_valid);
 
     // weight gradients, all layers in one launch
     WgradPlan plan;
@@ -864,7 +875,7 @@ int launch_backward(const _Float16* grad, const _Float16* X, const _Float16* Wt,
     // the last layer's matrix is [out_pad=16, W]; rows >= out_dim receive the (zero) gradient of the padding
     uint32_t nblk = div_up<uint32_t>(ntiles, 4);
     if (nblk > kWgradBlocks) nblk = kWgradBlocks;
-    hipLaunchKernelGGL((k_ffmlp_wgrad<W>), dim3(nblk, plan.n), dim3(256), 0, st, plan, B, partial);
+    hipLaunchKernelGGL((k_ffmlp_wgrad<W>), dim3(nblk, plan.n), dim3(256), 0, st, plan, B, partial, t_n_valid);
     hipLaunchKernelGGL(k_ffmlp_wgrad_reduce, dim3(div_up<uint32_t>(W * W * kReduceSplit, 256), plan.n), dim3(256), 0, st, plan, nblk,
                        (const float*)partial, grad_weights, accumulate);
     return check_launch("ffmlp_backward");
@@ -897,7 +908,7 @@ int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Floa
     uint32_t nblk = div_up<uint32_t>(ntiles, 4);
     if (nblk > kWgradBlocks) nblk = kWgradBlocks;
     hipLaunchKernelGGL((k_ffmlp_backward_fused<W, NH, IMB, ACT>), dim3(nblk), dim3(256), smem, st, grad, X, Wt, B, in_dim, out_dim,
-                       act, grad_inputs, partial, in_layout);
+                       act, grad_inputs, partial, in_layout, t_n_valid);
     WgradPlan plan;
     memset(&plan, 0, sizeof(plan));
     plan.n = NH + 2;
@@ -940,8 +951,9 @@ using namespace s3d;
 S3D_EXPORT int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                                  uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                                  uint32_t output_activation, uint16_t* forward_buffer, uint16_t* outputs,
-                                 int input_layout, s3d_stream_t stream) {
+                                 int input_layout, const int32_t* n_valid, s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
+    const RowLimitScope rows(n_valid);
     S3D_REQUIRE(inputs && weights && outputs, "ffmlp_forward: null pointer");
     S3D_REQUIRE(input_layout == 0 || input_layout == 1, "ffmlp_forward: input_layout must be 0 (row-major) or 1 (level-major [in/2][B][2])");
     if (int rc = check_shape(B, input_dim, output_dim, hidden_dim, num_layers)) return rc;
@@ -958,7 +970,7 @@ S3D_EXPORT int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weigh
                                    int input_layout, s3d_stream_t stream) {
     (void)inference_buffer;
     return s3d_ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                             output_activation, nullptr, outputs, input_layout, stream);
+                             output_activation, nullptr, outputs, input_layout, nullptr, stream);
 }
 
 S3D_EXPORT size_t s3d_ffmlp_backward_workspace_size(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
@@ -972,8 +984,10 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
                                   uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                                   uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer,
                                   uint16_t* grad_inputs, uint16_t* grad_weights, void* workspace, size_t workspace_bytes,
-                                  int input_layout, int accumulate_grad_weights, s3d_stream_t stream) {
+                                  int input_layout, int accumulate_grad_weights, const int32_t* n_valid,
+                                  s3d_stream_t stream) {
     (void)output_activation;
+    const RowLimitScope rows(n_valid);
     const uint32_t accumulate = accumulate_grad_weights ? 1u : 0u;
     S3D_REQUIRE(input_layout == 0 || (input_layout == 1 && !forward_buffer),
                 "ffmlp_backward: the level-major input layout is implemented by the fused backward (no forward_buffer)");

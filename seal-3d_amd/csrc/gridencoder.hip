@@ -27,7 +27,7 @@ namespace {
 constexpr uint32_t kMaxLevels = 32;
 // per-level scales + the optional input normalisation of GridEncoder.forward (grid.py:146: x01 = (x + bound) / (2 bound),
 // evaluated as torch's GPU kernels do: one add, one multiply by the fp32 reciprocal); bound = 0: inputs are already in [0,1]
-struct LevelScales { float v[kMaxLevels]; float bound, inv_2bound; };
+struct LevelScales { float v[kMaxLevels]; float bound, inv_2bound; const int32_t* n_valid; };  // n_valid: see valid_rows()
 
 constexpr uint32_t kPrimes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
 
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward(const float* __restr
                                                             uint32_t interp) {
     const uint32_t xcd = blockIdx.x % kXcds;
     const uint32_t b = (blockIdx.x / kXcds) * kFwdBlock + threadIdx.x;
-    if (b >= B || xcd >= L) return;
+    if (b >= valid_rows(B, scales.n_valid) || xcd >= L) return;
     float x[D];
     const bool oob = load_point<D>(inputs, b, scales, x);
 
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_backward(const T* __restrict
                                                              bool align_corners, uint32_t interp) {
     const uint32_t xcd = blockIdx.x % kXcds;
     const uint32_t b = (blockIdx.x / kXcds) * kFwdBlock + threadIdx.x;
-    if (b >= B || xcd >= L) return;
+    if (b >= valid_rows(B, scales.n_valid) || xcd >= L) return;
     float x[D];
     if (load_point<D>(inputs, b, scales, x)) return;  // grad is zero-initialised by the caller
 
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(kBinCountThreads) k_bin_count(const T* __restr
     __shared__ uint32_t cnt[kBinMaxSlices];
     __shared__ float wmax[kBinCountThreads / 64];
     const uint32_t b_begin = blockIdx.x * points_per_block;
-    const uint32_t b_end = min(B, b_begin + points_per_block);
+    const uint32_t b_end = min(valid_rows(B, scales.n_valid), b_begin + points_per_block);
     const uint32_t level = blockIdx.y;
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
     const uint32_t S = bin_slices(hashmap_size, C);
@@ -588,13 +588,15 @@ __global__ void __launch_bounds__(S3D_BIN_CHUNK / 4) k_bin_scatter(const T* __re
     const uint32_t level = level0 + blockIdx.y;
     const float amax = __uint_as_float(hdr[level]);
     const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t Bv = valid_rows(B, scales.n_valid);
+    if (blockIdx.x * P >= Bv) return;  // (uniform) chunk entirely in the absent tail of a padded batch
     const uint32_t b0 = blockIdx.x * P + threadIdx.x * kBinQuad;
     float x[kBinQuad][D];
     T g[kBinQuad][C];
     bool in[kBinQuad];
 #pragma unroll
     for (uint32_t q = 0; q < kBinQuad; q++) {
-        in[q] = b0 + q < B;
+        in[q] = b0 + q < Bv;
 #pragma unroll
         for (uint32_t c = 0; c < C; c++) g[q][c] = Acc<T>::zero();
         if (in[q]) {
@@ -795,9 +797,9 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate(const uint32_
 // gridencoder.cu:340-366
 template <typename T, uint32_t D, uint32_t C>
 __global__ void k_grid_input_backward(const T* __restrict__ grad, const T* __restrict__ dy_dx, T* __restrict__ grad_inputs,
-                                      uint32_t B, uint32_t L) {
+                                      uint32_t B, uint32_t L, const int32_t* __restrict__ n_valid) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B * D) return;
+    if (t >= valid_rows(B, n_valid) * D) return;
     const uint32_t b = t / D, d = t - b * D;
     const T* j = dy_dx + (size_t)b * L * D * C;
     T r = Acc<T>::zero();
@@ -874,7 +876,8 @@ __global__ void __launch_bounds__(kFwdBlock) k_grad_tv(const float* __restrict__
     }
 }
 
-void host_scales(uint32_t L, float S, uint32_t H, LevelScales& out, float bound = 0.0f) {
+void host_scales(uint32_t L, float S, uint32_t H, LevelScales& out, float bound = 0.0f, const int32_t* n_valid = nullptr) {
+    out.n_valid = n_valid;
     out.bound = bound;
     out.inv_2bound = bound != 0.0f ? 1.0f / (2.0f * bound) : 0.0f;
     for (uint32_t l = 0; l < kMaxLevels; l++) out.v[l] = 0.0f;
@@ -976,7 +979,7 @@ int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets
     }
     if (dy_dx && grad_inputs)
         hipLaunchKernelGGL((k_grid_input_backward<T, D, C>), dim3(div_up<uint32_t>(B * D, 256)), dim3(256), 0, st, grad,
-                           dy_dx, grad_inputs, B, L);
+                           dy_dx, grad_inputs, B, L, sc.n_valid);
     return check_launch("grid_encode_backward");
 }
 
@@ -1034,7 +1037,7 @@ S3D_EXPORT void s3d_grid_level_scales(uint32_t L, float S, uint32_t H, float* sc
 S3D_EXPORT int s3d_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets,
                                        void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                        void* dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
-                                       float bound, s3d_stream_t stream) {
+                                       float bound, const int32_t* n_valid, s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward: null pointer");
     S3D_REQUIRE(bound >= 0.0f && !(bound != 0.0f && dy_dx), "grid_encode_forward: bound must be >= 0 (0 = inputs in [0,1]); "
@@ -1043,7 +1046,7 @@ S3D_EXPORT int s3d_grid_encode_forward(const float* inputs, const void* embeddin
     S3D_REQUIRE(dtype == S3D_F32 || dtype == S3D_F16, "grid_encode_forward: dtype must be f32 or f16");
     S3D_REQUIRE((uint64_t)B * L * C < (1ull << 32), "grid_encode_forward: B*L*C overflows 32 bits");
     LevelScales sc;
-    host_scales(L, S, H, sc, bound);
+    host_scales(L, S, H, sc, bound, n_valid);
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
     if (dtype == S3D_F32) {
@@ -1101,7 +1104,7 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
                                         uint32_t max_level_rows, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                         const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                                         uint32_t interp, int dtype, void* workspace, size_t workspace_bytes,
-                                        float bound, s3d_stream_t stream) {
+                                        float bound, const int32_t* n_valid, s3d_stream_t stream) {
     (void)embeddings;
     S3D_REQUIRE(bound >= 0.0f && !(bound != 0.0f && dy_dx), "grid_encode_backward: bound must be >= 0 and 0 with an input Jacobian");
     if (B == 0) return S3D_OK;
@@ -1115,7 +1118,7 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
                     "s3d_grid_encode_backward_workspace_size() bytes");
     }
     LevelScales sc;
-    host_scales(L, S, H, sc, bound);
+    host_scales(L, S, H, sc, bound, n_valid);
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
     unsigned char* ws = (unsigned char*)workspace;

@@ -19,9 +19,9 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 __global__ void __launch_bounds__(256) k_ngp_mid_forward(const _Float16* __restrict__ h, const float* __restrict__ dirs,
                                                          uint32_t B, ShNorm K, float* __restrict__ sigma,
-                                                         _Float16* __restrict__ cin) {
+                                                         _Float16* __restrict__ cin, const int32_t* __restrict__ n_valid) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= B) return;
+    if (b >= valid_rows(B, n_valid)) return;
     const h8 h0 = *reinterpret_cast<const h8*>(h + (size_t)b * 16), h1 = *reinterpret_cast<const h8*>(h + (size_t)b * 16 + 8);
     const float x = dirs[(size_t)b * 3], y = dirs[(size_t)b * 3 + 1], z = dirs[(size_t)b * 3 + 2];
     float o[16], j0[1], j1[1], j2[1];
@@ -40,9 +40,9 @@ __global__ void __launch_bounds__(256) k_ngp_mid_forward(const _Float16* __restr
 
 __global__ void __launch_bounds__(256) k_ngp_mid_backward(const _Float16* __restrict__ d_cin, const float* __restrict__ d_sigma,
                                                           const _Float16* __restrict__ h, uint32_t B,
-                                                          _Float16* __restrict__ d_h) {
+                                                          _Float16* __restrict__ d_h, const int32_t* __restrict__ n_valid) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= B) return;
+    if (b >= valid_rows(B, n_valid)) return;
     const h8 g2 = *reinterpret_cast<const h8*>(d_cin + (size_t)b * 32 + 16), g3 = *reinterpret_cast<const h8*>(d_cin + (size_t)b * 32 + 24);
     const float h0 = (float)h[(size_t)b * 16];
     const float gs = d_sigma ? d_sigma[b] * expf(fminf(15.0f, fmaxf(-15.0f, h0))) : 0.0f;  // activation.py:13-16
@@ -55,18 +55,20 @@ __global__ void __launch_bounds__(256) k_ngp_mid_backward(const _Float16* __rest
     dst[0] = o0; dst[1] = o1;
 }
 
-__global__ void __launch_bounds__(256) k_ngp_rgb_forward(const _Float16* __restrict__ out, uint32_t B, float* __restrict__ rgb) {
+__global__ void __launch_bounds__(256) k_ngp_rgb_forward(const _Float16* __restrict__ out, uint32_t B, float* __restrict__ rgb,
+                                                         const int32_t* __restrict__ n_valid) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= B) return;
+    if (b >= valid_rows(B, n_valid)) return;
     const _Float16* o = out + (size_t)b * 16;
 #pragma unroll
     for (int c = 0; c < 3; c++) rgb[(size_t)b * 3 + c] = (float)(_Float16)(1.0f / (1.0f + expf(-(float)o[c])));
 }
 
 __global__ void __launch_bounds__(256) k_ngp_rgb_backward(const float* __restrict__ d_rgb, const float* __restrict__ rgb,
-                                                          uint32_t B, _Float16* __restrict__ d_out) {
+                                                          uint32_t B, _Float16* __restrict__ d_out,
+                                                          const int32_t* __restrict__ n_valid) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= B) return;
+    if (b >= valid_rows(B, n_valid)) return;
     h8 o0, o1;
 #pragma unroll
     for (int i = 0; i < 8; i++) { o0[i] = (_Float16)0.0f; o1[i] = (_Float16)0.0f; }
@@ -149,36 +151,37 @@ S3D_EXPORT int s3d_bg_mse_backward(const float* image, const float* weights_sum,
 }
 
 S3D_EXPORT int s3d_ngp_mid_forward(const uint16_t* h, const float* dirs, uint32_t B, float* sigma, uint16_t* color_in,
-                                   s3d_stream_t stream) {
+                                   const int32_t* n_valid, s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(h && dirs && sigma && color_in, "ngp_mid_forward: null pointer");
     ShNorm K;
     host_sh_norm(4, K);
     hipLaunchKernelGGL(k_ngp_mid_forward, dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, as_stream(stream), (const _Float16*)h, dirs, B,
-                       K, sigma, (_Float16*)color_in);
+                       K, sigma, (_Float16*)color_in, n_valid);
     return check_launch("ngp_mid_forward");
 }
 
 S3D_EXPORT int s3d_ngp_mid_backward(const uint16_t* grad_color_in, const float* grad_sigma, const uint16_t* h, uint32_t B,
-                                    uint16_t* grad_h, s3d_stream_t stream) {
+                                    uint16_t* grad_h, const int32_t* n_valid, s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(grad_color_in && h && grad_h, "ngp_mid_backward: null pointer");
     hipLaunchKernelGGL(k_ngp_mid_backward, dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, as_stream(stream),
-                       (const _Float16*)grad_color_in, grad_sigma, (const _Float16*)h, B, (_Float16*)grad_h);
+                       (const _Float16*)grad_color_in, grad_sigma, (const _Float16*)h, B, (_Float16*)grad_h, n_valid);
     return check_launch("ngp_mid_backward");
 }
 
-S3D_EXPORT int s3d_ngp_rgb_forward(const uint16_t* out, uint32_t B, float* rgb, s3d_stream_t stream) {
+S3D_EXPORT int s3d_ngp_rgb_forward(const uint16_t* out, uint32_t B, float* rgb, const int32_t* n_valid, s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(out && rgb, "ngp_rgb_forward: null pointer");
-    hipLaunchKernelGGL(k_ngp_rgb_forward, dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, as_stream(stream), (const _Float16*)out, B, rgb);
+    hipLaunchKernelGGL(k_ngp_rgb_forward, dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, as_stream(stream), (const _Float16*)out, B, rgb, n_valid);
     return check_launch("ngp_rgb_forward");
 }
 
-S3D_EXPORT int s3d_ngp_rgb_backward(const float* grad_rgb, const float* rgb, uint32_t B, uint16_t* grad_out, s3d_stream_t stream) {
+S3D_EXPORT int s3d_ngp_rgb_backward(const float* grad_rgb, const float* rgb, uint32_t B, uint16_t* grad_out,
+                                    const int32_t* n_valid, s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(grad_rgb && rgb && grad_out, "ngp_rgb_backward: null pointer");
     hipLaunchKernelGGL(k_ngp_rgb_backward, dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, as_stream(stream), grad_rgb, rgb, B,
-                       (_Float16*)grad_out);
+                       (_Float16*)grad_out, n_valid);
     return check_launch("ngp_rgb_backward");
 }

@@ -62,6 +62,17 @@ inline uint32_t stream_grid(uint64_t work, uint32_t block) {
 
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
 
+// Padded sample batches (`n_valid` of seal3d_hip.h): the ray marcher leaves the number of samples it produced in device
+// memory, the buffers behind it have a static extent B.  Rows [round_up(*n_valid, 128), B) are absent for every kernel
+// that takes the pointer — not read, not written — so the work follows the samples while launch geometry and strides
+// (level-major layouts) stay those of B.  NULL = all B rows.
+__device__ __forceinline__ uint32_t valid_rows(uint32_t B, const int32_t* n_valid) {
+    if (!n_valid) return B;
+    const int32_t n = *n_valid;
+    const uint32_t v = n <= 0 ? 0u : (((uint32_t)n + 127u) & ~127u);
+    return v < B ? v : B;
+}
+
 // lane id inside the 64-wide wavefront
 __device__ __forceinline__ uint32_t lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));

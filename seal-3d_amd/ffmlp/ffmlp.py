@@ -44,7 +44,7 @@ class _FFMLPForward(Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.half)
     def forward(ctx, inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
-                inference=False, calc_grad_inputs=False, param_ref=None, hook=None, input_layout=0):
+                inference=False, calc_grad_inputs=False, param_ref=None, hook=None, input_layout=0, n_valid=None):
         B = inputs.shape[1] if input_layout else inputs.shape[0]
         # outside autocast `custom_fwd` does not cast: the kernels are fp16-only, so cast here (the autograd
         # engine converts the returned fp16 gradients back to the parameter dtype)
@@ -66,20 +66,22 @@ class _FFMLPForward(Function):
         fused = _FUSED_BACKWARD and getattr(_backend, "fused_backward_supported", None) is not None and \
             _backend.fused_backward_supported(input_dim, output_dim, hidden_dim, num_layers, activation)
         forward_buffer = None if fused else torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
+        if input_layout and not fused:
+            raise RuntimeError("FFMLP: the level-major input layout needs the fused backward kernel for this shape")
+        # (keywords only when used: a backend without these extensions is never asked for them)
+        extra = {}
         if input_layout:
-            if not fused:
-                raise RuntimeError("FFMLP: the level-major input layout needs the fused backward kernel for this shape")
-            _backend.ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                                   output_activation, forward_buffer, outputs, input_layout=input_layout)
-        else:
-            _backend.ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                                   output_activation, forward_buffer, outputs)
+            extra["input_layout"] = input_layout
+        if n_valid is not None:
+            extra["n_valid"] = n_valid  # device sample count of a padded batch: rows beyond it are skipped
+        _backend.ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                               output_activation, forward_buffer, outputs, **extra)
         if fused:
             ctx.save_for_backward(inputs, weights)
         else:
             ctx.save_for_backward(inputs, weights, forward_buffer)
         ctx.meta = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs, fused)
-        ctx.input_layout = input_layout
+        ctx.extra = extra
         ctx.param_ref = param_ref
         return outputs
 
@@ -102,18 +104,16 @@ class _FFMLPForward(Function):
         stash = getattr(ctx.param_ref.param, "_s3d_grad", None) if ctx.param_ref is not None else None
         grad_weights = stash.view(weights.shape) if stash is not None else torch.empty_like(weights)  # every element is written
         backward_buffer = None if fused else torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
-        if ctx.input_layout or stash is not None:
-            _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim,
-                                    num_layers, activation, output_activation, calc_grad_inputs, backward_buffer,
-                                    grad_inputs, grad_weights, input_layout=ctx.input_layout, accumulate=stash is not None)
-        else:
-            _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim,
-                                    num_layers, activation, output_activation, calc_grad_inputs, backward_buffer,
-                                    grad_inputs, grad_weights)
+        extra = dict(ctx.extra)
+        if stash is not None:
+            extra["accumulate"] = True
+        _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim,
+                                num_layers, activation, output_activation, calc_grad_inputs, backward_buffer,
+                                grad_inputs, grad_weights, **extra)
         if stash is not None:
             ctx.param_ref.param._s3d_grad_touched = True
             grad_weights = None
-        return ((grad_inputs if calc_grad_inputs else None), grad_weights) + (None,) * 11
+        return ((grad_inputs if calc_grad_inputs else None), grad_weights) + (None,) * 12
 
 
 ffmlp_forward = _FFMLPForward.apply
@@ -164,16 +164,22 @@ class FFMLP(nn.Module):
             out = out[:, :self.output_dim]
         return out
 
-    def forward_padded(self, inputs, level_major=False):
+    def forward_padded(self, inputs, level_major=False, n_valid=None):
         """forward() before the final column slice: [B, padded_output_dim] (columns >= output_dim are exact zeros'
         products: the padded weight rows).  Fused consumers (nerf/network_ff.py) read the 16-column rows directly.
-        `level_major=True`: `inputs` is the grid encoder's [L, B, C] tensor (input_dim = L * C, C = 2, B % 128 == 0)."""
+        `level_major=True`: `inputs` is the grid encoder's [L, B, C] tensor (input_dim = L * C, C = 2, B % 128 == 0).
+        `n_valid`: int32 GPU tensor, sample count of a padded batch (B % 128 == 0, training): rows past it (rounded up
+        to 128) are skipped in both directions (seal3d_hip.h)."""
         if level_major:
             L, B, C = inputs.shape
             if C != 2 or L * C != self.input_dim or B % 128 != 0:
                 raise RuntimeError("FFMLP level-major input: need [input_dim / 2, B, 2] with B % 128 == 0")
-            return self._run(inputs, 1)
+            return self._run(inputs, 1, n_valid)
         B, C = inputs.shape
+        if n_valid is not None:
+            if B % 128 != 0:
+                raise RuntimeError("FFMLP: n_valid needs a batch that is a multiple of 128 rows")
+            return self._run(inputs, 0, n_valid)
         # The reference always appends 128 - B % 128 zero rows (a full extra block when B is already aligned,
         # ffmlp.py:156-159) and slices them off again: results do not depend on it, and the copy is a full pass over the
         # activations, so rows are only added when the batch is ragged (the MFMA tiles are 32 points).
@@ -185,7 +191,7 @@ class FFMLP(nn.Module):
             out = out[:B]
         return out
 
-    def _run(self, inputs, input_layout):
+    def _run(self, inputs, input_layout, n_valid=None):
         w, ref, hook = self.weights, None, None
         if getattr(w, "_s3d_grad", None) is not None and getattr(w, "_s3d_half_version", None) == w._version:
             # a native optimizer maintains the fp16 copy of the weights and takes their gradient as an fp16 buffer
@@ -197,5 +203,5 @@ class FFMLP(nn.Module):
             w = w._s3d_half
         out = ffmlp_forward(inputs, w, self.input_dim, self.padded_output_dim, self.hidden_dim,
                             self.num_layers, self.activation, self.output_activation, not self.training,
-                            inputs.requires_grad, ref, hook, input_layout)
+                            inputs.requires_grad, ref, hook, input_layout, None if not self.training else n_valid)
         return out

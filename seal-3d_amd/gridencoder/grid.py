@@ -53,7 +53,8 @@ class _GridEncode(Function):
     @staticmethod
     @custom_fwd(device_type="cuda")
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False,
-                gridtype=0, align_corners=False, interpolation=0, cache_half=False, level_major=False, bound=0.0):
+                gridtype=0, align_corners=False, interpolation=0, cache_half=False, level_major=False, bound=0.0,
+                n_valid=None):
         inputs = inputs.contiguous()
         B, D = inputs.shape
         L = offsets.shape[0] - 1
@@ -73,18 +74,21 @@ class _GridEncode(Function):
         outputs = torch.empty(L, B, C, device=inputs.device, dtype=embeddings.dtype)  # level-major
         dy_dx = (torch.empty(B, L * D * C, device=inputs.device, dtype=embeddings.dtype)
                  if calc_grad_inputs else None)
+        # (keywords only when used: a backend without the fused normalisation / padded batches is never asked for them)
+        extra = {}
         if bound:
-            _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype,
-                                         align_corners, interpolation, bound=bound)
-        else:
-            _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype,
-                                         align_corners, interpolation)
+            extra["bound"] = bound
+        if n_valid is not None:
+            extra["n_valid"] = n_valid  # device sample count of a padded batch: rows beyond it are not produced
+        _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype,
+                                     align_corners, interpolation, **extra)
         if not level_major:  # (a fused consumer reads the kernel's own [L, B, C] layout in place: ffmlp input_layout=1)
             outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
 
         ctx.save_for_backward(inputs, embeddings, offsets, dy_dx)
         ctx.meta = (B, D, C, L, S, H, gridtype, interpolation, align_corners, level_major, bound)
         ctx.param = param
+        ctx.extra = extra
         return outputs
 
     @staticmethod
@@ -106,15 +110,11 @@ class _GridEncode(Function):
             stash = None
             grad_embeddings = torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
-        if bound:
-            _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
-                                          grad_inputs, gridtype, align_corners, interpolation, bound=bound)
-        else:
-            _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
-                                          grad_inputs, gridtype, align_corners, interpolation)
+        _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
+                                      grad_inputs, gridtype, align_corners, interpolation, **ctx.extra)
         if grad_inputs is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
-        return grad_inputs, (None if stash is not None else grad_embeddings), None, None, None, None, None, None, None, None, None, None
+        return grad_inputs, (None if stash is not None else grad_embeddings), None, None, None, None, None, None, None, None, None, None, None
 
 
 grid_encode = _GridEncode.apply
@@ -169,9 +169,11 @@ class GridEncoder(nn.Module):
                 f"params={tuple(self.embeddings.shape)} gridtype={self.gridtype} align_corners={self.align_corners} "
                 f"interpolation={self.interpolation}")
 
-    def forward(self, inputs, bound=1, level_major=False):
+    def forward(self, inputs, bound=1, level_major=False, n_valid=None):
         """`level_major=True` (build extension, 2-D inputs only) returns the kernel's own [num_levels, B, level_dim] layout
-        instead of the reference's [B, num_levels * level_dim] — what ffmlp's `input_layout=1` consumes without a copy."""
+        instead of the reference's [B, num_levels * level_dim] — what ffmlp's `input_layout=1` consumes without a copy.
+        `n_valid` (build extension): int32 GPU tensor, the sample count of a padded batch; rows past it (rounded up to
+        128) are neither encoded nor back-propagated (seal3d_hip.h)."""
         # [-bound, bound] -> [0, 1] (grid.py:146): inside the kernels when the backend can, no input gradient is needed and
         # 2 * bound is a power of two (the usual 1, 2, 4, ...: dividing and multiplying by the reciprocal then round
         # identically, so the fused result is bit-identical to the torch expression), else here
@@ -185,7 +187,7 @@ class GridEncoder(nn.Module):
         inputs = inputs.view(-1, self.input_dim)
         out = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
                           inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id,
-                          not self.training, level_major, fuse_bound)
+                          not self.training, level_major, fuse_bound, n_valid)
         if level_major:
             return out
         return out.view(lead + [self.output_dim])

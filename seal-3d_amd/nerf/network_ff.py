@@ -21,12 +21,13 @@ class _NgpMid(Function):
     (network_ff.py:55-96 of the reference does this with slice, exp, SH, zeros, cat and cast nodes)."""
 
     @staticmethod
-    def forward(ctx, h, dirs):
+    def forward(ctx, h, dirs, n_valid=None):
         B = h.shape[0]
         sigma = torch.empty(B, dtype=torch.float32, device=h.device)
         cin = torch.empty(B, 32, dtype=torch.float16, device=h.device)
-        _head.mid_forward(h, dirs, sigma, cin)
+        _head.mid_forward(h, dirs, sigma, cin, n_valid)
         ctx.save_for_backward(h)
+        ctx.n_valid = n_valid
         return sigma, cin
 
     @staticmethod
@@ -35,26 +36,28 @@ class _NgpMid(Function):
         if g_cin is None:
             g_cin = torch.zeros(h.shape[0], 32, dtype=torch.float16, device=h.device)
         g_h = torch.empty_like(h)
-        _head.mid_backward(g_cin.to(torch.float16).contiguous(), None if g_sigma is None else g_sigma.float().contiguous(), h, g_h)
-        return g_h, None
+        _head.mid_backward(g_cin.to(torch.float16).contiguous(), None if g_sigma is None else g_sigma.float().contiguous(), h, g_h,
+                           ctx.n_valid)
+        return g_h, None, None
 
 
 class _NgpRgb(Function):
     """rgb = sigmoid(colour_net_output[:, :3]) as fp32, with fp16 rounding where torch.sigmoid on the fp16 tensor rounds"""
 
     @staticmethod
-    def forward(ctx, out):
+    def forward(ctx, out, n_valid=None):
         rgb = torch.empty(out.shape[0], 3, dtype=torch.float32, device=out.device)
-        _head.rgb_forward(out, rgb)
+        _head.rgb_forward(out, rgb, n_valid)
         ctx.save_for_backward(rgb)
+        ctx.n_valid = n_valid
         return rgb
 
     @staticmethod
     def backward(ctx, g_rgb):
         (rgb,) = ctx.saved_tensors
         g_out = torch.empty(rgb.shape[0], 16, dtype=torch.float16, device=rgb.device)
-        _head.rgb_backward(g_rgb.float().contiguous(), rgb, g_out)
-        return g_out
+        _head.rgb_backward(g_rgb.float().contiguous(), rgb, g_out, ctx.n_valid)
+        return g_out, None
 
 
 class NeRFNetwork(NeRFRenderer):
@@ -92,9 +95,15 @@ class NeRFNetwork(NeRFRenderer):
     def forward(self, x, d):
         if self._can_fuse(x):
             if x.dim() == 2 and x.shape[0] % 128 == 0:  # level-major hand-over: no permute copy in either direction
-                h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound, level_major=True), level_major=True)
-            else:
-                h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound))
+                # every op from here to sigma / rgb is a native kernel, so a padded training batch announced by the renderer
+                # (s3d_hip.row_limit: the march's device-side sample count) is honoured end to end: the absent tail of
+                # the buffers is neither computed nor back-propagated
+                nv = s3d_hip.active_row_limit(x.shape[0]) if self.training else None
+                h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound, level_major=True, n_valid=nv),
+                                                  level_major=True, n_valid=nv)
+                sigma, cin = _NgpMid.apply(h.contiguous(), d.float().contiguous(), nv)
+                return sigma, _NgpRgb.apply(self.color_net.forward_padded(cin, n_valid=nv).contiguous(), nv)
+            h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound))
             sigma, cin = _NgpMid.apply(h.contiguous(), d.float().contiguous())
             return sigma, _NgpRgb.apply(self.color_net.forward_padded(cin).contiguous())
         sigma, geo_feat = self._sigma(x)

@@ -27,7 +27,10 @@ class NativeAdam(torch.optim.Optimizer):
     GridEncoder-style parameter that carries `_s3d_stash_ok` to the fp16 hand-over described in the module docstring."""
 
     def __init__(self, params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, adopt_half_grads=True):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # (the torch.optim.Adam keys this class has no use for keep `state_dict()` loadable by torch.optim.Adam)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=False))
         self.step_count = None
         self.flat_half = None  # ONE fp16 buffer behind every handed-over gradient: one clear, one check, one all-reduce
         adopted = []
@@ -89,8 +92,7 @@ class NativeAdam(torch.optim.Optimizer):
         """torch.optim.Adam's layout: per-parameter `step` next to exp_avg / exp_avg_sq (one shared count here)"""
         sd = super().state_dict()
         step = None if self.step_count is None else self.step_count.detach().reshape(()).cpu().clone()
-        for st in sd["state"].values():
-            st["step"] = step.clone()
+        sd["state"] = {k: dict(st, step=step.clone()) for k, st in sd["state"].items()}  # (never the live dicts)
         return sd
 
     def load_state_dict(self, state_dict):

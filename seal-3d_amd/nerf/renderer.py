@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 import raymarching
+import s3d_hip
 
 
 def _meshgrid(*args):
@@ -108,7 +109,9 @@ class NeRFRenderer(nn.Module):
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, counter,
                 self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
             mxyzs, mdirs, mmask = self.map_samples(xyzs, dirs)
-            sigmas, rgbs = self(mxyzs, mdirs)
+            # the buffers are padded to M rows (raymarching.py:205-207); counter[0] says on the device how many hold samples
+            with s3d_hip.row_limit(counter, xyzs.shape[0]):
+                sigmas, rgbs = self(mxyzs, mdirs)
             if self.density_scale != 1:  # (x1 is the identity: skip the pass over [M])
                 sigmas = self.density_scale * sigmas
             rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)

@@ -140,9 +140,14 @@ class GraphedTrainer(Trainer):
     16-step running mean — rays that do not fit are dropped exactly as in the reference, raymarching.cu:416 — fused
     Adam + GradScaler keep found_inf on the device), static input buffers, libseal3d_hip launches on the capture
     stream.  `update_extra_state` (data-dependent shapes, `.item()`) stays eager every 16 steps; the graph is
-    re-captured only when the budget has to grow."""
+    re-captured only when the budget has to grow.
 
-    def __init__(self, model, num_rays, budget_factor=1.0, **kw):
+    The budget is generous (`budget_factor` x the running mean at capture): every per-sample kernel of the step takes the
+    march's device-side sample count (`n_valid`, seal3d_hip.h) and skips the unused tail of the buffers, so a larger M
+    costs two fills, not compute — fewer dropped rays than the reference's M = running mean, and re-captures only when
+    the mean outgrows the headroom."""
+
+    def __init__(self, model, num_rays, budget_factor=1.3, **kw):
         super().__init__(model, capturable=True, **kw)
         dev = next(model.parameters()).device
         self.s_ro = torch.zeros(num_rays, 3, device=dev)
@@ -230,7 +235,7 @@ class GraphedTrainer(Trainer):
         model = self.model
         model.train()
         if self._maybe_update_extra_state() and self.graph is not None and \
-                (model.mean_count > self.budget * 1.1 or model.mean_count * 1.25 < self.budget):
+                (model.mean_count * 1.1 > self.budget or model.mean_count * 2 < self.budget):
             self.graph = None  # the running mean left the static budget's useful range: re-capture
         self.global_step += 1
         if self.graph is None and model.mean_count <= 0:

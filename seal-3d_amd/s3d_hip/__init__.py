@@ -99,6 +99,43 @@ def _u(x):
     return C.c_uint32(int(x))
 
 
+def _nv(t):
+    """`n_valid` of seal3d_hip.h: None, or an int32 GPU tensor whose first element is the sample count"""
+    if t is None:
+        return C.c_void_p(0)
+    if t.dtype != torch.int32 or not t.is_cuda:
+        raise RuntimeError("n_valid must be an int32 GPU tensor (the ray marcher's counter)")
+    return C.c_void_p(t.data_ptr())
+
+
+# The padded sample batch of the current training render: (counter tensor, rows of the padded buffers).  The renderer
+# announces it around the network call; a network whose whole sample path is native picks it up with
+# `active_row_limit(B)` and hands it to every kernel explicitly (forward AND backward), so the work follows the samples.
+_ROW_LIMIT = None
+
+
+class row_limit:
+    def __init__(self, counter, rows):
+        self.value = (counter, int(rows))
+
+    def __enter__(self):
+        global _ROW_LIMIT
+        self.saved, _ROW_LIMIT = _ROW_LIMIT, self.value
+        return self
+
+    def __exit__(self, *exc):
+        global _ROW_LIMIT
+        _ROW_LIMIT = self.saved
+        return False
+
+
+def active_row_limit(B):
+    """the announced counter when it describes a batch of exactly B rows, else None"""
+    if _ROW_LIMIT is not None and _ROW_LIMIT[1] == int(B):
+        return _ROW_LIMIT[0]
+    return None
+
+
 def _f(x):
     return C.c_float(float(x))
 
@@ -259,7 +296,7 @@ class GridBackend:
 
     @staticmethod
     def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, Cc, L, S, H, dy_dx, gridtype, align_corners,
-                            interp, bound=0.0):
+                            interp, bound=0.0, n_valid=None):
         _need(inputs, torch.float32, "inputs")
         _need(offsets, torch.int32, "offsets")
         if outputs.dtype != embeddings.dtype:
@@ -267,7 +304,7 @@ class GridBackend:
         _check(lib().s3d_grid_encode_forward(_p(inputs), _p(embeddings), _p(offsets), _p(outputs), _u(B), _u(D),
                                              _u(Cc), _u(L), _f(S), _u(H), _p(dy_dx), _u(gridtype),
                                              C.c_int(int(align_corners)), _u(interp), C.c_int(_dt(embeddings)),
-                                             _f(bound), _stream()), "grid_encode_forward")
+                                             _f(bound), _nv(n_valid), _stream()), "grid_encode_forward")
 
     @staticmethod
     def grid_corner_indices(inputs, offsets, corner_idx, B, D, Cc, L, S, H, gridtype, align_corners):
@@ -277,7 +314,7 @@ class GridBackend:
 
     @staticmethod
     def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, Cc, L, S, H, dy_dx,
-                             grad_inputs, gridtype, align_corners, interp, bound=0.0):
+                             grad_inputs, gridtype, align_corners, interp, bound=0.0, n_valid=None):
         _need(inputs, torch.float32, "inputs")
         if grad_embeddings.dtype != grad.dtype:
             raise RuntimeError("grad_embeddings must have the dtype of grad")
@@ -288,7 +325,8 @@ class GridBackend:
                                               _p(grad_embeddings), _u(mlr), _u(B), _u(D),
                                               _u(Cc), _u(L), _f(S), _u(H), _p(dy_dx), _p(grad_inputs), _u(gridtype),
                                               C.c_int(int(align_corners)), _u(interp), C.c_int(_dt(grad)), _p(ws),
-                                              C.c_size_t(ws.numel()), _f(bound), _stream()), "grid_encode_backward")
+                                              C.c_size_t(ws.numel()), _f(bound), _nv(n_valid), _stream()),
+               "grid_encode_backward")
 
     @staticmethod
     def set_backward_path(path):
@@ -349,12 +387,12 @@ class FFMLPBackend:
 
     @staticmethod
     def ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                      output_activation, forward_buffer, outputs, input_layout=0):
+                      output_activation, forward_buffer, outputs, input_layout=0, n_valid=None):
         _need(inputs, torch.float16, "inputs")
         _need(weights, torch.float16, "weights")
         _check(lib().s3d_ffmlp_forward(_p(inputs), _p(weights), _u(B), _u(input_dim), _u(output_dim), _u(hidden_dim),
                                        _u(num_layers), _u(activation), _u(output_activation), _p(forward_buffer),
-                                       _p(outputs), C.c_int(int(input_layout)), _stream()), "ffmlp_forward")
+                                       _p(outputs), C.c_int(int(input_layout)), _nv(n_valid), _stream()), "ffmlp_forward")
 
     @staticmethod
     def ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
@@ -375,7 +413,7 @@ class FFMLPBackend:
     @staticmethod
     def ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers,
                        activation, output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights,
-                       input_layout=0, accumulate=False):
+                       input_layout=0, accumulate=False, n_valid=None):
         _need(grad, torch.float16, "grad")
         nbytes = lib().s3d_ffmlp_backward_workspace_size(_u(input_dim), _u(output_dim), _u(hidden_dim),
                                                         _u(num_layers))
@@ -385,7 +423,7 @@ class FFMLPBackend:
                                         _u(output_activation), C.c_int(int(bool(calc_grad_inputs))),
                                         _p(backward_buffer), _p(grad_inputs if calc_grad_inputs else None),
                                         _p(grad_weights), _p(ws), C.c_size_t(ws.numel()), C.c_int(int(input_layout)),
-                                        C.c_int(int(bool(accumulate))), _stream()), "ffmlp_backward")
+                                        C.c_int(int(bool(accumulate))), _nv(n_valid), _stream()), "ffmlp_backward")
 
 
 class OptimBackend:
@@ -425,28 +463,30 @@ class NgpHeadBackend:
     """csrc/ngp_head.hip — the elementwise glue between the two MLPs of nerf/network_ff.py"""
 
     @staticmethod
-    def mid_forward(h, dirs, sigma, color_in):
+    def mid_forward(h, dirs, sigma, color_in, n_valid=None):
         _need(h, torch.float16, "h"); _need(dirs, torch.float32, "dirs")
         _need(sigma, torch.float32, "sigma"); _need(color_in, torch.float16, "color_in")
-        _check(lib().s3d_ngp_mid_forward(_p(h), _p(dirs), _u(h.shape[0]), _p(sigma), _p(color_in), _stream()), "ngp_mid_forward")
+        _check(lib().s3d_ngp_mid_forward(_p(h), _p(dirs), _u(h.shape[0]), _p(sigma), _p(color_in), _nv(n_valid), _stream()),
+               "ngp_mid_forward")
 
     @staticmethod
-    def mid_backward(grad_color_in, grad_sigma, h, grad_h):
+    def mid_backward(grad_color_in, grad_sigma, h, grad_h, n_valid=None):
         _need(grad_color_in, torch.float16, "grad_color_in"); _need(grad_h, torch.float16, "grad_h")
         if grad_sigma is not None:
             _need(grad_sigma, torch.float32, "grad_sigma")
-        _check(lib().s3d_ngp_mid_backward(_p(grad_color_in), _p(grad_sigma), _p(h), _u(h.shape[0]), _p(grad_h), _stream()),
-               "ngp_mid_backward")
+        _check(lib().s3d_ngp_mid_backward(_p(grad_color_in), _p(grad_sigma), _p(h), _u(h.shape[0]), _p(grad_h), _nv(n_valid),
+                                          _stream()), "ngp_mid_backward")
 
     @staticmethod
-    def rgb_forward(out, rgb):
+    def rgb_forward(out, rgb, n_valid=None):
         _need(out, torch.float16, "out"); _need(rgb, torch.float32, "rgb")
-        _check(lib().s3d_ngp_rgb_forward(_p(out), _u(out.shape[0]), _p(rgb), _stream()), "ngp_rgb_forward")
+        _check(lib().s3d_ngp_rgb_forward(_p(out), _u(out.shape[0]), _p(rgb), _nv(n_valid), _stream()), "ngp_rgb_forward")
 
     @staticmethod
-    def rgb_backward(grad_rgb, rgb, grad_out):
+    def rgb_backward(grad_rgb, rgb, grad_out, n_valid=None):
         _need(grad_rgb, torch.float32, "grad_rgb"); _need(rgb, torch.float32, "rgb"); _need(grad_out, torch.float16, "grad_out")
-        _check(lib().s3d_ngp_rgb_backward(_p(grad_rgb), _p(rgb), _u(rgb.shape[0]), _p(grad_out), _stream()), "ngp_rgb_backward")
+        _check(lib().s3d_ngp_rgb_backward(_p(grad_rgb), _p(rgb), _u(rgb.shape[0]), _p(grad_out), _nv(n_valid), _stream()),
+               "ngp_rgb_backward")
 
     @staticmethod
     def bg_mse_forward(image, weights_sum, gt, bg_rgb, loss):

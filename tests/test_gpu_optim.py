@@ -119,6 +119,14 @@ def test_ffmlp_weight_grad_handover(hip):
     torch.testing.assert_close(ma.weights._s3d_grad.float(), mb.weights.grad, rtol=2e-3, atol=1e-4)
 
 
+def _through_file(obj):
+    import io
+    buf = io.BytesIO()
+    torch.save(obj, buf)
+    buf.seek(0)
+    return torch.load(buf, weights_only=False)
+
+
 def test_optimizer_and_scaler_state_dicts_interchange_with_torch(hip):
     """a `full` checkpoint (nerf/utils.py:1031-1036 of the reference) carries torch.optim.Adam / GradScaler state: state
     saved by the native pair resumes under torch's and the other way round, and both continue identically"""
@@ -139,10 +147,10 @@ def test_optimizer_and_scaler_state_dicts_interchange_with_torch(hip):
 
     pb = [torch.nn.Parameter(a.detach().clone()) for a in pa]
     ob = torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
-    ob.load_state_dict(sd)
+    ob.load_state_dict(_through_file(sd))  # (load_state_dict keeps same-dtype tensors by reference: go through a file)
     pc = [torch.nn.Parameter(a.detach().clone()) for a in pa]
     oc = NativeAdam([{"params": pc}], lr=1e-2)
-    oc.load_state_dict(ob.state_dict())  # torch -> native
+    oc.load_state_dict(_through_file(ob.state_dict()))  # torch -> native
     assert float(oc.step_count) == 3.0
     for step in range(3, 6):
         for o, ps in ((oa, pa), (ob, pb), (oc, pc)):
