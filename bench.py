@@ -240,16 +240,17 @@ def main():
 
     # density-grid maintenance (every 16 steps, inside the timed region like in the reference's train loop): event pair per call
     ues_events = []
-    ues_inner = model.update_extra_state
+    ues_inner = trainer._maybe_update_extra_state
 
     def timed_update_extra_state(*a, **k):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         r = ues_inner(*a, **k)
         e1.record()
-        ues_events.append((e0, e1))
+        if r:  # (False: not an update step)
+            ues_events.append((e0, e1))
         return r
-    model.update_extra_state = timed_update_extra_state
+    trainer._maybe_update_extra_state = timed_update_extra_state
 
     samples_dev = torch.zeros(1, dtype=torch.int64, device=dev)
     captures0 = getattr(trainer, "n_captures", 0)
@@ -266,7 +267,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    model.update_extra_state = ues_inner
+    trainer._maybe_update_extra_state = ues_inner
     ues_ms = [a.elapsed_time(b) for a, b in ues_events]
     timer_steps = args.steps
     if graphed:

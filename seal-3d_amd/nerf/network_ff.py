@@ -75,7 +75,11 @@ class NeRFNetwork(NeRFRenderer):
                                num_layers=num_layers_color)
 
     def _sigma(self, x):
-        h = self.sigma_net(self.encoder(x, bound=self.bound))
+        if self._can_fuse(x) and x.dim() == 2 and x.shape[0] > 0 and x.shape[0] % 128 == 0:
+            # level-major hand-over (no [L,B,C] -> [B,L*C] permute copy); same values
+            h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound, level_major=True), level_major=True)
+        else:
+            h = self.sigma_net(self.encoder(x, bound=self.bound))
         return trunc_exp(h[..., 0]), h[..., 1:]
 
     def _rgb(self, d, geo_feat):

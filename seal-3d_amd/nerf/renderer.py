@@ -249,6 +249,53 @@ class NeRFRenderer(nn.Module):
             self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
         self.local_step = 0
 
+    # -- the steady-state (partial) update again, without host syncs and with static shapes: one HIP graph for a trainer
+    #    that replays its steps (nerf/trainer.py:GraphedTrainer).  Same update rule, same sampling law (H^3/4 uniform
+    #    cells + H^3/4 uniform picks among the occupied cells per cascade, jittered, EMA-max, nerf/renderer.py:497-538 of
+    #    the reference); the random stream differs from `update_extra_state` (which consumes the torch RNG exactly like
+    #    the reference): occupied cells are drawn through a prefix sum + binary search instead of nonzero() + randint.
+    @torch.no_grad()
+    def _pick_occupied(self, cas, N):
+        """N uniform draws (with replacement) among the cells of cascade `cas` with density > 0, as morton indices; no host
+        sync, static shapes.  (No occupied cell at all: the reference's randint(0, 0) raises; this returns the last cell.)"""
+        grid = self.density_grid[cas]
+        csum = torch.cumsum(grid > 0, dim=0, dtype=torch.int32)
+        pick = (torch.rand(N, device=grid.device) * csum[-1]).to(torch.int32)  # uniform in [0, #occupied)
+        return torch.searchsorted(csum, pick, right=True).clamp_(max=grid.shape[0] - 1)  # the pick-th occupied cell
+
+    @torch.no_grad()
+    def partial_grid_update_device(self, decay=0.95):
+        """density_grid <- EMA-max with fresh samples; returns mean(clamp(density_grid, 0)) as a device scalar"""
+        dev = self.density_grid.device
+        H3 = self.grid_size ** 3
+        N = H3 // 4
+        tmp_grid = torch.full_like(self.density_grid, -1)
+        for cas in range(self.cascade):
+            coords = torch.randint(0, self.grid_size, (N, 3), device=dev)
+            indices = raymarching.morton3D(coords).long()
+            occ = self._pick_occupied(cas, N)
+            occ_coords = raymarching.morton3D_invert(occ)
+            indices = torch.cat([indices, occ], dim=0)
+            coords = torch.cat([coords, occ_coords], dim=0)
+            tmp_grid[cas, indices] = self._query_cells(coords, cas).to(tmp_grid.dtype)
+        valid = (self.density_grid >= 0) & (tmp_grid >= 0)
+        self.density_grid.copy_(torch.where(valid, torch.maximum(self.density_grid * decay, tmp_grid), self.density_grid))
+        return torch.mean(self.density_grid.clamp(min=0))
+
+    @torch.no_grad()
+    def finish_extra_state(self, mean_density_dev):
+        """bitfield re-pack + mean sample count from the device results of `partial_grid_update_device`: ONE host read"""
+        total_step = min(16, self.local_step)
+        counted = self.step_counter[:max(total_step, 1), 0].sum().float()  # < 2^24: exact
+        mean_density, count_sum = torch.stack([mean_density_dev.float().reshape(()), counted]).tolist()
+        self.mean_density = mean_density
+        self.iter_density += 1
+        thresh = min(self.mean_density, self.density_thresh)
+        self.density_bitfield = raymarching.packbits(self.density_grid, thresh, self.density_bitfield)
+        if total_step > 0:
+            self.mean_count = int(count_sum / total_step)
+        self.local_step = 0
+
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
         if not self.cuda_ray:
             raise NotImplementedError("this build implements the cuda_ray (-O) path; the sampling path `run` is torch-only "

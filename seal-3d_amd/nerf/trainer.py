@@ -147,13 +147,15 @@ class GraphedTrainer(Trainer):
     costs two fills, not compute — fewer dropped rays than the reference's M = running mean, and re-captures only when
     the mean outgrows the headroom."""
 
-    def __init__(self, model, num_rays, budget_factor=1.3, **kw):
+    def __init__(self, model, num_rays, budget_factor=1.3, graph_extra_state=True, **kw):
         super().__init__(model, capturable=True, **kw)
         dev = next(model.parameters()).device
         self.s_ro = torch.zeros(num_rays, 3, device=dev)
         self.s_rd = torch.zeros(num_rays, 3, device=dev)
         self.s_gt = torch.zeros(num_rays, 3, device=dev)
         self.budget_factor = budget_factor
+        self.graph_extra_state = graph_extra_state
+        self.ues_graph, self.ues_mean, self.ues_warm = None, None, False
         self.graph = None
         self.graph_opt = None
         self.n_captures = 0
@@ -224,6 +226,33 @@ class GraphedTrainer(Trainer):
         out = super().load_checkpoint(checkpoint, model_only=model_only)
         self.graph = self.graph_opt = None  # optimizer state tensors were replaced, mean_count may have moved: re-capture
         return out
+
+    def _maybe_update_extra_state(self):
+        """steady state: the partial occupancy update replayed from its own HIP graph (~30 launches, two host syncs
+        less), then one host read for mean density / mean sample count.  First sweeps, models that extend
+        `update_extra_state`, and `graph_extra_state=False` keep the eager reference sequence."""
+        from .renderer import NeRFRenderer
+        model = self.model
+        if not (model.cuda_ray and self.global_step % self.update_extra_interval == 0):
+            return False
+        plain = type(model).update_extra_state is NeRFRenderer.update_extra_state
+        if not (self.graph_extra_state and plain and model.iter_density >= 16):
+            return super()._maybe_update_extra_state()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
+            if self.ues_graph is None and not self.ues_warm:
+                mean = model.partial_grid_update_device()  # first time: eager (lazy initialisations, allocator warm-up)
+                self.ues_warm = True
+            else:
+                if self.ues_graph is None:
+                    self.ues_graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.ues_graph):
+                        self.ues_mean = model.partial_grid_update_device()
+                self.ues_graph.replay()
+                mean = self.ues_mean
+            model.finish_extra_state(mean)
+        if self.dist is not None:
+            self.dist.sync_extra_state(model)
+        return True
 
     def _replay(self):
         self.graph.replay()

@@ -176,3 +176,56 @@ def test_ray_sharded_dp_gloo_world2(tmp_path):
     assert res.returncode == 0, res.stderr[-2000:]
     for r in (0, 1):
         assert f"RANK{r} ok=True same=True views=True" in res.stdout, res.stdout + res.stderr[-1500:]
+
+
+def test_sync_free_partial_grid_update_matches_reference_rule(oracle_wrappers):
+    """partial_grid_update_device / finish_extra_state (the capturable steady-state occupancy update) against
+    update_extra_state's rule on an analytic density: occupied picks are occupied and uniform, the EMA-max update and
+    the bitfield agree with the reference sequence up to the jitter of the random samples."""
+    import torch
+    from nerf import renderer, synthetic as syn
+    lo, hi = syn.lego_like_boxes(0)
+
+    class Analytic(renderer.NeRFRenderer):
+        def density(self, x):
+            return {"sigma": syn.box_density(x, lo, hi, sigma=40.0)}
+
+    def make():
+        R = Analytic(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10)
+        R.grid_size = 32  # small grid: CPU test
+        R.density_grid = torch.zeros(1, 32 ** 3)
+        R.density_bitfield = torch.zeros(32 ** 3 // 8, dtype=torch.uint8)
+        return R
+    torch.manual_seed(0)
+    A, B = make(), make()
+    grid0 = torch.rand(1, 32 ** 3)
+    grid0[grid0 < 0.7] = 0          # 30 % occupied
+    grid0[0, :100] = -1             # never-seen cells stay untouched
+    A.density_grid.copy_(grid0)
+    B.density_grid.copy_(grid0)
+    occ = B._pick_occupied(0, 200000)
+    assert bool((grid0[0, occ] > 0).all())
+    n_occ = int((grid0[0] > 0).sum())
+    hist = torch.bincount(occ, minlength=32 ** 3)[grid0[0] > 0].float()
+    assert hist.min() > 0 and abs(float(hist.mean()) - 200000 / n_occ) < 1e-3 and float(hist.std()) < 2.0 * (200000 / n_occ) ** 0.5
+    # steady state: start both from a full sweep of the analytic field (jitter only moves cells on the box faces)
+    A.density_grid.zero_()
+    A.iter_density = 0
+    A.update_extra_state()
+    A.density_grid[0, :100] = -1
+    B.density_grid.copy_(A.density_grid)
+    A.iter_density = B.iter_density = 16
+    A.local_step = B.local_step = 3
+    A.step_counter[:3, 0] = torch.tensor([100, 200, 303], dtype=torch.int32)
+    B.step_counter.copy_(A.step_counter)
+    for _ in range(6):
+        A.local_step = B.local_step = 3
+        A.update_extra_state()
+        B.finish_extra_state(B.partial_grid_update_device())
+    assert A.iter_density == B.iter_density == 22 and A.mean_count == B.mean_count == 201 and B.local_step == 0
+    assert bool((B.density_grid[0, :100] == -1).all())
+    assert abs(A.mean_density - B.mean_density) < 0.05 * A.mean_density
+    # occupancy bits: two runs of the reference sequence with different seeds agree on 98.7 % of the cells of this scene
+    # (jitter on the box faces); the sync-free variant is in the same band
+    same = float((np.unpackbits(A.density_bitfield.numpy()) == np.unpackbits(B.density_bitfield.numpy())).mean())
+    assert same > 0.975, same
