@@ -280,7 +280,11 @@ class NeRFRenderer(nn.Module):
             tmp_grid[cas, indices] = self._query_cells(coords, cas).to(tmp_grid.dtype)
         valid = (self.density_grid >= 0) & (tmp_grid >= 0)
         self.density_grid.copy_(torch.where(valid, torch.maximum(self.density_grid * decay, tmp_grid), self.density_grid))
-        return torch.mean(self.density_grid.clamp(min=0))
+        # mean(clamp(grid, 0)) in two row-wise stages: torch.mean over 2M elements is a multi-block reduction whose
+        # semaphores are cleared by a memset node, and memset nodes of a captured graph stop taking effect from the second
+        # replay on (ROCm 7.2) — the mean read back 0 and the bitfield filled up
+        g = self.density_grid.clamp(min=0)
+        return g.view(-1, 4096).sum(dim=1).sum() / g.numel()
 
     @torch.no_grad()
     def finish_extra_state(self, mean_density_dev):

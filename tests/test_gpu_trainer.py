@@ -117,8 +117,8 @@ def test_occupancy_update_replayed_from_its_own_graph(hip):
     tr = GraphedTrainer(model, 2048, lr=1e-2, fp16=True)
     _run(tr, batches, 17)       # two full sweeps (steps 0 and 16), eager
     model.iter_density = 16     # steady state from here on
-    losses = _run(tr, batches, 80)  # updates at 32 (eager warm-up of the capturable variant), 48 (capture), 64, 80
-    assert tr.ues_graph is not None and model.iter_density == 20 and model.mean_count > 0
+    losses = _run(tr, batches, 80)  # updates at 32 (eager warm-up of the capturable variant), 48 (capture), 64, 80, 96
+    assert tr.ues_graph is not None and model.iter_density == 21 and model.mean_count > 0
     assert torch.isfinite(losses).all() and float(losses[-8:].mean()) < 0.1
     bits_graph = np.unpackbits(model.density_bitfield.cpu().numpy())
     assert 0.005 < bits_graph.mean() < 0.5
@@ -129,7 +129,7 @@ def test_occupancy_update_replayed_from_its_own_graph(hip):
     bits_ref = np.unpackbits(model.density_bitfield.cpu().numpy())
     model.density_grid.copy_(grid0)
     model.local_step = 1
-    tr.global_step = 96
+    tr.global_step = 112
     assert tr._maybe_update_extra_state()
     bits_dev = np.unpackbits(model.density_bitfield.cpu().numpy())
     assert (bits_ref == bits_dev).mean() > 0.97, (bits_ref == bits_dev).mean()
