@@ -122,14 +122,21 @@ def test_occupancy_update_replayed_from_its_own_graph(hip):
     assert torch.isfinite(losses).all() and float(losses[-8:].mean()) < 0.1
     bits_graph = np.unpackbits(model.density_bitfield.cpu().numpy())
     assert 0.005 < bits_graph.mean() < 0.5
-    # same model, same grid: one more update through each route from the same starting state
+    # same model, same grid: one more update through each route from the same starting state; two runs of the reference
+    # sequence differ by their random jitter — the captured variant must agree with it as well as it agrees with itself
     grid0 = model.density_grid.clone()
-    with torch.autocast("cuda", dtype=torch.float16):
-        model.update_extra_state()
-    bits_ref = np.unpackbits(model.density_bitfield.cpu().numpy())
+
+    def reference_bits():
+        model.density_grid.copy_(grid0)
+        with torch.autocast("cuda", dtype=torch.float16):
+            model.update_extra_state()
+        return np.unpackbits(model.density_bitfield.cpu().numpy())
+    bits_ref, bits_ref2 = reference_bits(), reference_bits()
     model.density_grid.copy_(grid0)
     model.local_step = 1
     tr.global_step = 112
     assert tr._maybe_update_extra_state()
     bits_dev = np.unpackbits(model.density_bitfield.cpu().numpy())
-    assert (bits_ref == bits_dev).mean() > 0.97, (bits_ref == bits_dev).mean()
+    agree_ref, agree_dev = (bits_ref == bits_ref2).mean(), (bits_ref == bits_dev).mean()
+    assert agree_dev > agree_ref - 0.01 and agree_dev > 0.9, (agree_ref, agree_dev)
+    assert abs(bits_dev.mean() - bits_ref.mean()) < 0.02 * bits_ref.mean() + 1e-3
