@@ -222,6 +222,18 @@ int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
 int s3d_ffmlp_allocate_splitk(size_t n);
 int s3d_ffmlp_free_splitk(void);
 
+/* ------------------------------------------------------------------ TensoRF vector-matrix features
+ * tensoRF/network.py:112-153 get_sigma_feat / get_color_feat (12 F.grid_sample calls, bilinear, zeros padding,
+ * align_corners=True, + stack / cat / mul / sum) in one pass, csrc/tensorf.hip.
+ * x [N,3] fp32 in [-1,1] (normalised like network.py:160); planes / lines / rank / resolution: HOST arrays of 3:
+ * planes[i] device fp32 [rank[i], res[m1], res[m0]] with (m0,m1) = mat_ids[i] = (0,1),(0,2),(1,2); lines[i] device fp32
+ * [rank[i], res[vec_ids[i]]], vec_ids = 2,1,0 (network.py:37-38, :105-106).
+ * reduce = 1: out [N] = sum_i sum_r plane*line (sigma_feat); reduce = 0: out [rank0+rank1+rank2, N] = the products
+ * (the tensor the reference transposes into basis_mat, network.py:147). */
+int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
+                            const uint32_t* rank, const uint32_t* resolution, int reduce, float* out,
+                            s3d_stream_t stream);
+
 /* ------------------------------------------------------------------ NGP head glue
  * The elementwise steps between the two MLPs of nerf/network_ff.py:55-96 (slice / trunc_exp / SH / cat / cast /
  * sigmoid and their backward nodes) as two streaming kernels per direction, csrc/ngp_head.hip.

@@ -41,7 +41,7 @@ EXPORTS = [
     "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_advance", "s3d_scaler_update",
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
     "s3d_bg_mse_forward", "s3d_bg_mse_backward",
-    "s3d_seal_bbox_map",
+    "s3d_seal_bbox_map", "s3d_vm_features_forward",
 ]
 
 
@@ -528,3 +528,27 @@ class SealBackend:
         _check(lib().s3d_seal_bbox_map(_p(points), _p(dirs), _u(points.shape[0]), ptr[0], _u(keep[0][0].shape[0]), ptr[1],
                                        _u(keep[1][0].shape[0]), ptr[2], ptr[3], ptr[4], ptr[5], ptr[6], ptr[7], _p(out_points),
                                        _p(out_dirs), _p(mask), _stream()), "seal_bbox_map")
+
+
+class VmBackend:
+    """csrc/tensorf.hip — TensoRF vector-matrix features (tensoRF/network.py:112-153 of the reference)"""
+
+    @staticmethod
+    def features_forward(x, planes, lines, resolution, reduce, out):
+        """x [N,3] fp32; planes[i] [1,R_i,H,W] / lines[i] [1,R_i,D,1] fp32 (the reference's parameter shapes);
+        out [N] (reduce) or [sum R_i, N]"""
+        _need(x, torch.float32, "x"); _need(out, torch.float32, "out")
+        for t in list(planes) + list(lines):
+            _need(t, torch.float32, "factor")
+            if not t.is_cuda or not t.is_contiguous():
+                raise RuntimeError("vm features: factors must be contiguous GPU tensors")
+        if not x.is_contiguous() or x.shape[-1] != 3:
+            raise RuntimeError("vm features: x must be contiguous [N,3]")
+        ptr3 = C.c_void_p * 3
+        u3 = C.c_uint32 * 3
+        pl = ptr3(*[t.data_ptr() for t in planes])
+        ln = ptr3(*[t.data_ptr() for t in lines])
+        rank = u3(*[int(t.shape[1]) for t in planes])
+        res = u3(*[int(r) for r in resolution])
+        _check(lib().s3d_vm_features_forward(_p(x), _u(x.shape[0]), pl, ln, rank, res, C.c_int(int(bool(reduce))), _p(out),
+                                             _stream()), "vm_features_forward")

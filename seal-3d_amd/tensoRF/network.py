@@ -4,14 +4,51 @@ Density rank 16x3, colour rank 48x3 plane/line factors sampled with stock `F.gri
 kernel here either, tensoRF/network.py:125-126), `basis_mat` 144 -> 27, colour MLP on
 FreqEncoder(27, deg 2) + FreqEncoder(3, deg 2) = 150 -> 128 -> 128 -> 3.  The hot-path pieces it exercises are the
 HIP `freqencoder` and `raymarching` packages.  Parameter names follow the reference (sigma_mat/sigma_vec/color_mat/
-color_vec/basis_mat/color_net) so checkpoints keep their keys."""
+color_vec/basis_mat/color_net) so checkpoints keep their keys.
+
+On the GPU the twelve grid_sample calls + stack / cat / mul / sum of `get_sigma_feat` / `get_color_feat` run as one kernel
+per call (`s3d_vm_features_forward`, csrc/tensorf.hip).  The backward pass re-runs the reference's op
+sequence under autograd: its cost is the scatter-add of the plane gradients (global fp32 atomics, ~2.8e8 per step at the
+Lego sample count), which a fused kernel built on the same atomics would not change — see DESIGN.md §8."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import s3d_hip
 from activation import trunc_exp
 from encoding import get_encoder
 from nerf.renderer import NeRFRenderer
+
+
+class _VmFeatures(torch.autograd.Function):
+    """forward: one HIP kernel; backward: the reference's grid_sample sequence re-run under autograd (module docstring)"""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # grid_sample is an fp32 op under autocast too
+    def forward(ctx, x, net, reduce, *factors):
+        x = x.contiguous()
+        mats, vecs = factors[:3], factors[3:]
+        N = x.shape[0]
+        out = torch.empty((N,) if reduce else (sum(m.shape[1] for m in mats), N), dtype=torch.float32, device=x.device)
+        s3d_hip.VmBackend.features_forward(x, [m.contiguous() for m in mats], [v.contiguous() for v in vecs], net.resolution,
+                                           reduce, out)
+        ctx.save_for_backward(x, *factors)
+        ctx.net, ctx.reduce = net, reduce
+        return out
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        x, *factors = ctx.saved_tensors
+        with torch.enable_grad():
+            leaves = [f.detach().requires_grad_(True) for f in factors]
+            xin = x.detach().requires_grad_(ctx.needs_input_grad[0])
+            fn = ctx.net._sigma_feat_torch if ctx.reduce else ctx.net._color_prod_torch
+            out = fn(xin, leaves[:3], leaves[3:])
+            wanted = ([xin] if ctx.needs_input_grad[0] else []) + leaves
+            grads = torch.autograd.grad(out, wanted, g.contiguous())
+        gx = grads[0] if ctx.needs_input_grad[0] else None
+        return (gx, None, None) + tuple(grads[1:] if ctx.needs_input_grad[0] else grads)
 
 
 class NeRFNetwork(NeRFRenderer):
@@ -55,16 +92,31 @@ class NeRFNetwork(NeRFRenderer):
         vf = [F.grid_sample(vecs[i], vec_coord[[i]], align_corners=True).view(-1, N) for i in range(3)]
         return mf, vf
 
-    def get_sigma_feat(self, x):
-        mf, vf = self._factors(self.sigma_mat, self.sigma_vec, x)
+    fused_vm = True  # tests / A-B runs: False = the reference's grid_sample sequence on the GPU too
+
+    def _sigma_feat_torch(self, x, mats, vecs):
+        mf, vf = self._factors(mats, vecs, x)
         out = torch.zeros([x.shape[0]], device=x.device)
         for m, v in zip(mf, vf):
             out = out + torch.sum(m * v, dim=0)
         return out
 
+    def _color_prod_torch(self, x, mats, vecs):
+        mf, vf = self._factors(mats, vecs, x)
+        return torch.cat(mf, dim=0) * torch.cat(vf, dim=0)  # [3R, N]
+
+    def _use_native(self, x):
+        return self.fused_vm and x.is_cuda and x.dim() == 2 and x.shape[0] > 0
+
+    def get_sigma_feat(self, x):
+        if self._use_native(x):
+            return _VmFeatures.apply(x, self, True, *self.sigma_mat, *self.sigma_vec)
+        return self._sigma_feat_torch(x, self.sigma_mat, self.sigma_vec)
+
     def get_color_feat(self, x):
-        mf, vf = self._factors(self.color_mat, self.color_vec, x)
-        return self.basis_mat((torch.cat(mf, dim=0) * torch.cat(vf, dim=0)).T)
+        if self._use_native(x):
+            return self.basis_mat(_VmFeatures.apply(x, self, False, *self.color_mat, *self.color_vec).T)
+        return self.basis_mat(self._color_prod_torch(x, self.color_mat, self.color_vec).T)
 
     def _normalize(self, x):
         return 2 * (x - self.aabb_train[:3]) / (self.aabb_train[3:] - self.aabb_train[:3]) - 1

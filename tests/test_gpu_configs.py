@@ -101,3 +101,38 @@ def test_seal_bbox_mapper_device_kernel_matches_torch_sequence(hip, kind):
     torch.testing.assert_close(d_n, d_t, rtol=1e-5, atol=1e-6)
     p_only, none_d, m2 = SealBBoxMapper(cfg).map_to_origin(pts)  # without directions
     assert none_d is None and torch.equal(m2, m_n) and torch.equal(p_only, p_n)
+
+
+def test_tensorf_vm_features_kernel_matches_grid_sample_sequence(hip):
+    """csrc/tensorf.hip vs the reference's op sequence (tensoRF/network.py:112-153: 12 F.grid_sample + stack/cat/mul/sum) on
+    the same parameters: non-cubic resolution and unequal ranks (axis / component mix-ups would show), points inside, on the
+    border and outside [-1,1] (zeros padding).  fp32, tolerance = a few ulps of the sums (the kernel accumulates the corners
+    in the reference kernel's order but without FMA contraction; torch.sum reduces pairwise)."""
+    from tensoRF import network as trf
+    torch.manual_seed(3)
+    net = trf.NeRFNetwork(resolution=[40, 56, 72], sigma_rank=[5, 7, 3], color_rank=[9, 4, 11], bound=1, cuda_ray=True).cuda()
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(50000, 3, generator=g) * 2.6 - 1.3).cuda()
+    x[:64] = torch.tensor([-1.0, 1.0, 0.0], device="cuda")      # exactly on the border / centre
+    x[64:128] = 1.0
+    res = {}
+    for fused in (True, False):
+        net.fused_vm = fused
+        net.zero_grad(set_to_none=True)
+        s = net.get_sigma_feat(x)
+        c = net.get_color_feat(x)
+        (s * torch.linspace(-1, 1, x.shape[0], device="cuda")).sum().backward(retain_graph=True)
+        (c * torch.linspace(1, 2, 27, device="cuda")).sum().backward()
+        res[fused] = (s.detach(), c.detach(), [p.grad.clone() for p in list(net.sigma_mat) + list(net.sigma_vec) +
+                                               list(net.color_mat) + list(net.color_vec) + [net.basis_mat.weight]])
+    net.fused_vm = True
+    inside = (x.abs() <= 1).all(1)
+    assert 0.2 < float(inside.float().mean()) < 0.8
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(res[True][1], res[False][1], rtol=1e-5, atol=1e-7)
+    assert float(res[False][0][~inside].abs().max()) > 0  # partially outside points still see the in-range corners
+    for a, b in zip(res[True][2], res[False][2]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)  # (global-atomic scatter-adds: order varies run to run)
+    # under autocast (the -O configs) the features stay fp32 like grid_sample's
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert net.get_sigma_feat(x).dtype == torch.float32
