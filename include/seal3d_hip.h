@@ -233,6 +233,20 @@ int s3d_ffmlp_free_splitk(void);
 int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                             const uint32_t* rank, const uint32_t* resolution, int reduce, float* out,
                             s3d_stream_t stream);
+/* Parameter gradients of the same op (what autograd derives from the grid_sample calls: F.grid_sample's backward
+ * scatter-adds every corner with a global atomic).  Binned instead: s3d_vm_backward_keys writes keys [6,N] i32 (rows 0-2
+ * the 8x8-cell plane tile of component i, rows 3-5 its 64-row line chunk; 0x7fffffff = contributes nothing); the caller
+ * sorts each row, passes perm [6,N] i32 (point ids in key order) and start [6,n_bounds] i32 (first sorted position with
+ * key >= t, n_bounds > s3d_vm_backward_max_bins(resolution) + 1), a zero-initialised scratch gm [N, sum rank] and
+ * zero-initialised gradient buffers shaped like the factors.  grad: [N] (reduce = 1) or [N, sum rank] (reduce = 0: the
+ * gradient of the products, point-major — the memory layout autograd hands back through the reference's `.T`). */
+uint32_t s3d_vm_backward_max_bins(const uint32_t* resolution);
+int s3d_vm_backward_keys(const float* x, uint32_t N, const uint32_t* rank, const uint32_t* resolution, int32_t* keys,
+                         s3d_stream_t stream);
+int s3d_vm_features_backward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
+                             const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
+                             const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
+                             float* const* grad_planes, float* const* grad_lines, s3d_stream_t stream);
 
 /* ------------------------------------------------------------------ NGP head glue
  * The elementwise steps between the two MLPs of nerf/network_ff.py:55-96 (slice / trunc_exp / SH / cat / cast /

@@ -73,22 +73,170 @@ __global__ void __launch_bounds__(256) k_vm_features(const float* __restrict__ x
     if (REDUCE) out[n] = total;
 }
 
-}  // namespace
-}  // namespace s3d
+// ------------------------------------------------------------------ backward (parameter gradients)
+// torch's grid_sample backward scatters every corner contribution with a global fp32 atomic: 2.8e8 atomics per step at
+// the Lego sample count, ~13 ms at the 21 G/s such atomics retire on MI355X.  Here the points are
+// binned first (the caller sorts the keys k_vm_keys produces): per plane by 8x8-cell tile, per line by 64-row chunk.
+// One workgroup owns a tile: the plane values of its 9x9 cells and a zeroed accumulator live in LDS, lanes = rank
+// channels; per point it re-computes line value l_r and plane value m_r, adds g_r*l_r*w_corner into the LDS accumulator
+// and leaves g_r*m_r (what the line gradient needs) in `gm`; the tile is flushed with one global atomic per non-zero
+// cell (cells on the +1 border belong to the neighbour as well).  The line kernel does the same over z chunks.
+constexpr int kVmTile = 8, kVmTileCells = (kVmTile + 1) * (kVmTile + 1), kVmZChunk = 64;
+constexpr uint32_t kVmSkip = 0x7fffffffu;
 
-using namespace s3d;
+struct VmPoint {
+    float nw, ne, sw, se, lz0, lz1;
+    int x0, y0, z0;
+    bool valid;
+};
 
-S3D_EXPORT int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
-                                       const uint32_t* rank, const uint32_t* resolution, int reduce, float* out,
-                                       s3d_stream_t stream) {
-    if (N == 0) return S3D_OK;
-    S3D_REQUIRE(x && planes && lines && rank && resolution && out, "vm_features_forward: null pointer");
+__device__ __forceinline__ VmPoint vm_locate(const float* __restrict__ x, uint32_t n, const VmFactors& f, uint32_t i) {
+    VmPoint q;
+    const float px = x[(size_t)n * 3 + f.cu[i]], py = x[(size_t)n * 3 + f.cv[i]], pz = x[(size_t)n * 3 + f.cw[i]];
+    const float ix = unnormalize(px, f.W[i]), iy = unnormalize(py, f.H[i]), iz = unnormalize(pz, f.Dn[i]);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+    q.nw = wx0 * wy0; q.ne = wx1 * wy0; q.sw = wx0 * wy1; q.se = wx1 * wy1;
+    q.lz1 = iz - fz; q.lz0 = (fz + 1.0f) - iz;
+    const bool ok = fabsf(ix) < 1e9f && fabsf(iy) < 1e9f && fabsf(iz) < 1e9f;
+    q.x0 = ok ? (int)fx : -2; q.y0 = ok ? (int)fy : -2; q.z0 = ok ? (int)fz : -2;
+    // at least one corner of the plane cell and one of the line segment in range, else the point contributes nothing
+    q.valid = ok && q.x0 >= -1 && q.x0 < (int)f.W[i] && q.y0 >= -1 && q.y0 < (int)f.H[i] && q.z0 >= -1 && q.z0 < (int)f.Dn[i];
+    return q;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// keys [6][N]: rows 0-2 plane tile of component i, rows 3-5 line chunk; kVmSkip for points without any contribution
+__global__ void __launch_bounds__(256) k_vm_keys(const float* __restrict__ x, uint32_t N, VmFactors f, int32_t* __restrict__ keys) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+#pragma unroll
+    for (uint32_t i = 0; i < 3; i++) {
+        const VmPoint q = vm_locate(x, n, f, i);
+        const int tiles_x = ((int)f.W[i] + kVmTile - 1) / kVmTile;
+        const int tk = (clampi(q.y0, 0, (int)f.H[i] - 1) / kVmTile) * tiles_x + clampi(q.x0, 0, (int)f.W[i] - 1) / kVmTile;
+        const int zk = clampi(q.z0, 0, (int)f.Dn[i] - 1) / kVmZChunk;
+        keys[(size_t)i * N + n] = q.valid ? tk : (int32_t)kVmSkip;
+        keys[(size_t)(3 + i) * N + n] = q.valid ? zk : (int32_t)kVmSkip;
+    }
+}
+
+struct VmBackward {
+    float* d_plane[3];
+    float* d_line[3];
+    const float* g;        // REDUCE: [N]; else [N, rows] (rows = sum of ranks), channel-contiguous per point
+    float* gm;             // [N, rows], zero-initialised: g_r * m_r
+    const int32_t* perm;   // [6][N] point ids sorted by key (rows as in k_vm_keys)
+    const int32_t* start;  // [6][n_bounds]: first sorted position with key >= t
+    uint32_t n_bounds, rows;
+};
+
+// RP = lanes per point (16 or 64 >= rank); a wave handles 64 / RP points per trip
+template <int RP, bool REDUCE>
+__global__ void __launch_bounds__(256) k_vm_plane_backward(const float* __restrict__ x, uint32_t N, VmFactors f, VmBackward b) {
+    extern __shared__ float vm_smem[];
+    const uint32_t i = blockIdx.y;
+    const int W = (int)f.W[i], H = (int)f.H[i], Dn = (int)f.Dn[i];
+    const uint32_t R = f.rank[i];
+    const int tiles_x = (W + kVmTile - 1) / kVmTile, tiles_y = (H + kVmTile - 1) / kVmTile;
+    const int t = (int)blockIdx.x;
+    if (t >= tiles_x * tiles_y) return;
+    const int32_t* st = b.start + (size_t)i * b.n_bounds;
+    const uint32_t begin = (uint32_t)st[t], end = (uint32_t)st[t + 1];
+    if (begin >= end) return;  // (empty tile: nothing to add to the zero-initialised gradient)
+    const int cx0 = (t % tiles_x) * kVmTile, cy0 = (t / tiles_x) * kVmTile;
+    float* pv = vm_smem;                          // [81][R] plane values
+    float* acc = vm_smem + kVmTileCells * R;      // [81][R] gradient accumulator
+    const float* P = f.plane[i];
+    const size_t plane_stride = (size_t)H * W;
+    for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += 256) {
+        const uint32_t r = e / kVmTileCells, c = e % kVmTileCells;  // cell fastest: 9-float row segments of one channel
+        const int cy = cy0 + (int)(c / (kVmTile + 1)), cx = cx0 + (int)(c % (kVmTile + 1));
+        pv[c * R + r] = (cx < W && cy < H) ? P[r * plane_stride + (size_t)cy * W + cx] : 0.0f;
+        acc[c * R + r] = 0.0f;
+    }
+    __syncthreads();
+    constexpr uint32_t PPW = 64 / RP;  // points per wave trip
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t sub = lane / RP, r = lane % RP;
+    const int32_t* perm = b.perm + (size_t)i * N;
+    const float* Lq = f.line[i];
+    for (uint32_t k = begin + wave * PPW + sub; k < end; k += 4 * PPW) {
+        const uint32_t n = (uint32_t)perm[k];
+        const VmPoint q = vm_locate(x, n, f, i);
+        if (r >= R) continue;
+        const float g = REDUCE ? b.g[n] : b.g[(size_t)n * b.rows + f.row0[i] + r];
+        const bool bz0 = q.z0 >= 0 && q.z0 < Dn, bz1 = q.z0 + 1 >= 0 && q.z0 + 1 < Dn;
+        float l = 0.0f;
+        if (bz0) l += Lq[(size_t)r * Dn + q.z0] * q.lz0;
+        if (bz1) l += Lq[(size_t)r * Dn + q.z0 + 1] * q.lz1;
+        const int lx = q.x0 - cx0, ly = q.y0 - cy0;  // nw corner inside the tile's 9x9 window: -1 .. 7
+        const bool bx0 = q.x0 >= 0 && q.x0 < W, bx1 = q.x0 + 1 >= 0 && q.x0 + 1 < W;
+        const bool by0 = q.y0 >= 0 && q.y0 < H, by1 = q.y0 + 1 >= 0 && q.y0 + 1 < H;
+        const int c_nw = ly * (kVmTile + 1) + lx;
+        const float gl = g * l;
+        float m = 0.0f;
+        if (bx0 && by0) { m += pv[c_nw * R + r] * q.nw; atomicAdd(&acc[c_nw * R + r], gl * q.nw); }
+        if (bx1 && by0) { m += pv[(c_nw + 1) * R + r] * q.ne; atomicAdd(&acc[(c_nw + 1) * R + r], gl * q.ne); }
+        if (bx0 && by1) { m += pv[(c_nw + kVmTile + 1) * R + r] * q.sw; atomicAdd(&acc[(c_nw + kVmTile + 1) * R + r], gl * q.sw); }
+        if (bx1 && by1) { m += pv[(c_nw + kVmTile + 2) * R + r] * q.se; atomicAdd(&acc[(c_nw + kVmTile + 2) * R + r], gl * q.se); }
+        b.gm[(size_t)n * b.rows + f.row0[i] + r] = g * m;
+    }
+    __syncthreads();
+    float* dP = b.d_plane[i];
+    for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += 256) {
+        const uint32_t rr = e / kVmTileCells, c = e % kVmTileCells;
+        const int cy = cy0 + (int)(c / (kVmTile + 1)), cx = cx0 + (int)(c % (kVmTile + 1));
+        const float v = acc[c * R + rr];
+        if (v != 0.0f && cx < W && cy < H) atomicAdd(&dP[rr * plane_stride + (size_t)cy * W + cx], v);
+    }
+}
+
+template <int RP>
+__global__ void __launch_bounds__(256) k_vm_line_backward(const float* __restrict__ x, uint32_t N, VmFactors f, VmBackward b) {
+    extern __shared__ float vm_smem[];
+    const uint32_t i = blockIdx.y;
+    const int Dn = (int)f.Dn[i];
+    const uint32_t R = f.rank[i];
+    const int t = (int)blockIdx.x;
+    if (t * kVmZChunk >= Dn) return;
+    const int32_t* st = b.start + (size_t)(3 + i) * b.n_bounds;
+    const uint32_t begin = (uint32_t)st[t], end = (uint32_t)st[t + 1];
+    if (begin >= end) return;
+    const int zb = t * kVmZChunk;
+    float* acc = vm_smem;  // [65][R]
+    for (uint32_t e = threadIdx.x; e < (kVmZChunk + 1) * R; e += 256) acc[e] = 0.0f;
+    __syncthreads();
+    constexpr uint32_t PPW = 64 / RP;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t sub = lane / RP, r = lane % RP;
+    const int32_t* perm = b.perm + (size_t)(3 + i) * N;
+    for (uint32_t k = begin + wave * PPW + sub; k < end; k += 4 * PPW) {
+        const uint32_t n = (uint32_t)perm[k];
+        const VmPoint q = vm_locate(x, n, f, i);
+        if (r >= R) continue;
+        const float gm = b.gm[(size_t)n * b.rows + f.row0[i] + r];
+        const int lz = q.z0 - zb;  // -1 .. 63
+        if (q.z0 >= 0 && q.z0 < Dn) atomicAdd(&acc[lz * R + r], gm * q.lz0);
+        if (q.z0 + 1 >= 0 && q.z0 + 1 < Dn) atomicAdd(&acc[(lz + 1) * R + r], gm * q.lz1);
+    }
+    __syncthreads();
+    float* dL = b.d_line[i];
+    for (uint32_t e = threadIdx.x; e < (kVmZChunk + 1) * R; e += 256) {
+        const uint32_t z = e / R, rr = e % R;
+        const float v = acc[e];
+        if (v != 0.0f && zb + (int)z < Dn) atomicAdd(&dL[(size_t)rr * Dn + zb + z], v);
+    }
+}
+
+int fill_factors(VmFactors& f, const float* const* planes, const float* const* lines, const uint32_t* rank,
+                 const uint32_t* resolution, uint32_t& rows) {
     static const uint32_t mat_ids[3][2] = {{0, 1}, {0, 2}, {1, 2}};  // tensoRF/network.py:37-38
     static const uint32_t vec_ids[3] = {2, 1, 0};
-    VmFactors f;
-    uint32_t row = 0;
+    rows = 0;
     for (uint32_t i = 0; i < 3; i++) {
-        S3D_REQUIRE(planes[i] && lines[i] && rank[i] > 0 && resolution[i] > 0, "vm_features_forward: empty factor %u", i);
+        S3D_REQUIRE(planes[i] && lines[i] && rank[i] > 0 && resolution[i] > 0, "vm features: empty factor %u", i);
         f.plane[i] = planes[i];
         f.line[i] = lines[i];
         f.rank[i] = rank[i];
@@ -98,9 +246,91 @@ S3D_EXPORT int s3d_vm_features_forward(const float* x, uint32_t N, const float* 
         f.W[i] = resolution[mat_ids[i][0]];
         f.H[i] = resolution[mat_ids[i][1]];
         f.Dn[i] = resolution[vec_ids[i]];
-        f.row0[i] = row;
-        row += rank[i];
+        f.row0[i] = rows;
+        rows += rank[i];
     }
+    return S3D_OK;
+}
+
+}  // namespace
+}  // namespace s3d
+
+using namespace s3d;
+
+S3D_EXPORT uint32_t s3d_vm_backward_max_bins(const uint32_t* resolution) {
+    uint32_t m = 0;
+    for (uint32_t a = 0; a < 3; a++)
+        for (uint32_t c = 0; c < 3; c++) {
+            if (a == c) continue;
+            const uint32_t t = div_up<uint32_t>(resolution[a], kVmTile) * div_up<uint32_t>(resolution[c], kVmTile);
+            m = t > m ? t : m;
+        }
+    return m;  // (>= the number of line chunks of any axis as well: ceil(res / 64) <= ceil(res / 8)^2)
+}
+
+S3D_EXPORT int s3d_vm_backward_keys(const float* x, uint32_t N, const uint32_t* rank, const uint32_t* resolution, int32_t* keys,
+                                    s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(x && rank && resolution && keys, "vm_backward_keys: null pointer");
+    VmFactors f;
+    uint32_t rows;
+    const float* dummy[3] = {x, x, x};  // (only the geometry is used)
+    if (int rc = fill_factors(f, dummy, dummy, rank, resolution, rows)) return rc;
+    hipLaunchKernelGGL(k_vm_keys, dim3(div_up<uint32_t>(N, 256)), dim3(256), 0, as_stream(stream), x, N, f, keys);
+    return check_launch("vm_backward_keys");
+}
+
+S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
+                                        const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
+                                        const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
+                                        float* const* grad_planes, float* const* grad_lines, s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(x && planes && lines && rank && resolution && grad && perm && start && gm && grad_planes && grad_lines,
+                "vm_features_backward: null pointer");
+    VmFactors f;
+    VmBackward b;
+    if (int rc = fill_factors(f, planes, lines, rank, resolution, b.rows)) return rc;
+    uint32_t max_rank = 0, max_tiles = 0, max_chunks = 0;
+    for (uint32_t i = 0; i < 3; i++) {
+        S3D_REQUIRE(grad_planes[i] && grad_lines[i], "vm_features_backward: null gradient buffer %u", i);
+        b.d_plane[i] = grad_planes[i];
+        b.d_line[i] = grad_lines[i];
+        max_rank = rank[i] > max_rank ? rank[i] : max_rank;
+        const uint32_t tiles = div_up<uint32_t>(f.W[i], kVmTile) * div_up<uint32_t>(f.H[i], kVmTile);
+        max_tiles = tiles > max_tiles ? tiles : max_tiles;
+        const uint32_t chunks = div_up<uint32_t>(f.Dn[i], kVmZChunk);
+        max_chunks = chunks > max_chunks ? chunks : max_chunks;
+    }
+    S3D_REQUIRE(max_rank <= 64, "vm_features_backward: rank %u > 64 not supported", max_rank);
+    S3D_REQUIRE(n_bounds > max_tiles && n_bounds > max_chunks, "vm_features_backward: `start` needs more than %u columns", max_tiles);
+    b.g = grad;
+    b.gm = gm;
+    b.perm = perm;
+    b.start = start;
+    b.n_bounds = n_bounds;
+    hipStream_t st = as_stream(stream);
+    const size_t smem_p = (size_t)2 * kVmTileCells * max_rank * sizeof(float), smem_l = (size_t)(kVmZChunk + 1) * max_rank * sizeof(float);
+    const dim3 gp(max_tiles, 3), gl(max_chunks, 3), block(256);
+    if (max_rank <= 16) {
+        if (reduce) hipLaunchKernelGGL((k_vm_plane_backward<16, true>), gp, block, smem_p, st, x, N, f, b);
+        else hipLaunchKernelGGL((k_vm_plane_backward<16, false>), gp, block, smem_p, st, x, N, f, b);
+        hipLaunchKernelGGL((k_vm_line_backward<16>), gl, block, smem_l, st, x, N, f, b);
+    } else {
+        if (reduce) hipLaunchKernelGGL((k_vm_plane_backward<64, true>), gp, block, smem_p, st, x, N, f, b);
+        else hipLaunchKernelGGL((k_vm_plane_backward<64, false>), gp, block, smem_p, st, x, N, f, b);
+        hipLaunchKernelGGL((k_vm_line_backward<64>), gl, block, smem_l, st, x, N, f, b);
+    }
+    return check_launch("vm_features_backward");
+}
+
+S3D_EXPORT int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
+                                       const uint32_t* rank, const uint32_t* resolution, int reduce, float* out,
+                                       s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(x && planes && lines && rank && resolution && out, "vm_features_forward: null pointer");
+    VmFactors f;
+    uint32_t row;
+    if (int rc = fill_factors(f, planes, lines, rank, resolution, row)) return rc;
     S3D_REQUIRE((uint64_t)row * N < (1ull << 32) * 4, "vm_features_forward: output too large");
     const dim3 grid(div_up<uint32_t>(N, 256)), block(256);
     if (reduce) hipLaunchKernelGGL((k_vm_features<true>), grid, block, 0, as_stream(stream), x, N, f, out);

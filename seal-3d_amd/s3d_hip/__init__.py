@@ -42,6 +42,7 @@ EXPORTS = [
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
     "s3d_bg_mse_forward", "s3d_bg_mse_backward",
     "s3d_seal_bbox_map", "s3d_vm_features_forward",
+    "s3d_vm_backward_max_bins", "s3d_vm_backward_keys", "s3d_vm_features_backward",
 ]
 
 
@@ -70,6 +71,7 @@ def lib():
         for name in ("s3d_march_rays_train_workspace_size", "s3d_compact_alive_workspace_size",
                      "s3d_ffmlp_backward_workspace_size", "s3d_grid_encode_backward_workspace_size"):
             getattr(l, name).restype = C.c_size_t
+        l.s3d_vm_backward_max_bins.restype = C.c_uint32
         l.s3d_grid_level_scales.restype = None
         _lib = l
     return _lib
@@ -552,3 +554,32 @@ class VmBackend:
         res = u3(*[int(r) for r in resolution])
         _check(lib().s3d_vm_features_forward(_p(x), _u(x.shape[0]), pl, ln, rank, res, C.c_int(int(bool(reduce))), _p(out),
                                              _stream()), "vm_features_forward")
+
+    @staticmethod
+    def features_backward(x, planes, lines, resolution, reduce, grad):
+        """gradients of features_forward w.r.t. planes / lines (lists shaped like the factors).  grad: [N] (reduce) or
+        [N, sum R_i] point-major."""
+        _need(x, torch.float32, "x"); _need(grad, torch.float32, "grad")
+        N, dev = x.shape[0], x.device
+        ptr3, u3 = C.c_void_p * 3, C.c_uint32 * 3
+        rank = u3(*[int(t.shape[1]) for t in planes])
+        res = u3(*[int(r) for r in resolution])
+        rows = sum(int(t.shape[1]) for t in planes)
+        if not grad.is_contiguous() or grad.numel() != (N if reduce else N * rows):
+            raise RuntimeError("vm features backward: grad must be contiguous [N] / [N, sum rank]")
+        keys = torch.empty(6, N, dtype=torch.int32, device=dev)
+        _check(lib().s3d_vm_backward_keys(_p(x), _u(N), rank, res, _p(keys), _stream()), "vm_backward_keys")
+        skeys, perm = torch.sort(keys, dim=1)
+        n_bounds = int(lib().s3d_vm_backward_max_bins(res)) + 2
+        bounds = torch.arange(n_bounds, dtype=torch.int32, device=dev).expand(6, n_bounds).contiguous()
+        start = torch.searchsorted(skeys, bounds).to(torch.int32).contiguous()
+        perm = perm.to(torch.int32).contiguous()
+        gm = torch.zeros(N, rows, dtype=torch.float32, device=dev)
+        g_planes = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in planes]
+        g_lines = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in lines]
+        _check(lib().s3d_vm_features_backward(_p(x), _u(N), ptr3(*[t.data_ptr() for t in planes]),
+                                              ptr3(*[t.data_ptr() for t in lines]), rank, res, C.c_int(int(bool(reduce))),
+                                              _p(grad), _p(perm), _p(start), _u(n_bounds), _p(gm),
+                                              ptr3(*[t.data_ptr() for t in g_planes]), ptr3(*[t.data_ptr() for t in g_lines]),
+                                              _stream()), "vm_features_backward")
+        return g_planes, g_lines

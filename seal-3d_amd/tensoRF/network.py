@@ -7,9 +7,10 @@ HIP `freqencoder` and `raymarching` packages.  Parameter names follow the refere
 color_vec/basis_mat/color_net) so checkpoints keep their keys.
 
 On the GPU the twelve grid_sample calls + stack / cat / mul / sum of `get_sigma_feat` / `get_color_feat` run as one kernel
-per call (`s3d_vm_features_forward`, csrc/tensorf.hip).  The backward pass re-runs the reference's op
-sequence under autograd: its cost is the scatter-add of the plane gradients (global fp32 atomics, ~2.8e8 per step at the
-Lego sample count), which a fused kernel built on the same atomics would not change — see DESIGN.md §8."""
+per call (`s3d_vm_features_forward`, csrc/tensorf.hip), and so do their parameter gradients
+(`s3d_vm_features_backward`: points binned by plane tile / line chunk, LDS accumulation, instead of the ~2.8e8 global
+fp32 atomics per step grid_sample's backward issues at the Lego sample count).  A gradient w.r.t. the coordinates (not
+needed by any trainer of the reference) falls back to the grid_sample sequence under autograd."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -21,7 +22,8 @@ from nerf.renderer import NeRFRenderer
 
 
 class _VmFeatures(torch.autograd.Function):
-    """forward: one HIP kernel; backward: the reference's grid_sample sequence re-run under autograd (module docstring)"""
+    """forward: one HIP kernel; backward: binned HIP kernels for the factor gradients (coordinates' gradient, if ever
+    asked for: the reference's grid_sample sequence re-run under autograd)"""
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)  # grid_sample is an fp32 op under autocast too
@@ -40,6 +42,12 @@ class _VmFeatures(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type="cuda")
     def backward(ctx, g):
         x, *factors = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            g = g if ctx.reduce else g.t()  # [rows, N] gradient of the `.T` consumer: point-major underneath
+            gp, gl = s3d_hip.VmBackend.features_backward(x, [f.contiguous() for f in factors[:3]],
+                                                         [f.contiguous() for f in factors[3:]], ctx.net.resolution, ctx.reduce,
+                                                         g.float().contiguous())
+            return (None, None, None) + tuple(gp) + tuple(gl)
         with torch.enable_grad():
             leaves = [f.detach().requires_grad_(True) for f in factors]
             xin = x.detach().requires_grad_(ctx.needs_input_grad[0])
