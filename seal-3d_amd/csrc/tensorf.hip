@@ -143,8 +143,11 @@ __global__ void __launch_bounds__(256) k_vm_plane_backward(const float* __restri
     const int t = (int)blockIdx.x;
     if (t >= tiles_x * tiles_y) return;
     const int32_t* st = b.start + (size_t)i * b.n_bounds;
-    const uint32_t begin = (uint32_t)st[t], end = (uint32_t)st[t + 1];
-    if (begin >= end) return;  // (empty tile: nothing to add to the zero-initialised gradient)
+    // (real scenes concentrate the samples in few tiles: a tile's range is shared by gridDim.z workgroups)
+    const uint32_t lo = (uint32_t)st[t], hi = (uint32_t)st[t + 1];
+    const uint32_t begin = lo + (uint32_t)(((uint64_t)(hi - lo) * blockIdx.z) / gridDim.z);
+    const uint32_t end = lo + (uint32_t)(((uint64_t)(hi - lo) * (blockIdx.z + 1)) / gridDim.z);
+    if (begin >= end) return;  // (empty: nothing to add to the zero-initialised gradient)
     const int cx0 = (t % tiles_x) * kVmTile, cy0 = (t / tiles_x) * kVmTile;
     float* pv = vm_smem;                          // [81][R] plane values
     float* acc = vm_smem + kVmTileCells * R;      // [81][R] gradient accumulator
@@ -202,7 +205,10 @@ __global__ void __launch_bounds__(256) k_vm_line_backward(const float* __restric
     const int t = (int)blockIdx.x;
     if (t * kVmZChunk >= Dn) return;
     const int32_t* st = b.start + (size_t)(3 + i) * b.n_bounds;
-    const uint32_t begin = (uint32_t)st[t], end = (uint32_t)st[t + 1];
+    // a chunk holds ~N / 5 points: its range is shared by gridDim.z workgroups, each with its own LDS accumulator
+    const uint32_t lo = (uint32_t)st[t], hi = (uint32_t)st[t + 1];
+    const uint32_t begin = lo + (uint32_t)(((uint64_t)(hi - lo) * blockIdx.z) / gridDim.z);
+    const uint32_t end = lo + (uint32_t)(((uint64_t)(hi - lo) * (blockIdx.z + 1)) / gridDim.z);
     if (begin >= end) return;
     const int zb = t * kVmZChunk;
     float* acc = vm_smem;  // [65][R]
@@ -310,7 +316,9 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
     b.n_bounds = n_bounds;
     hipStream_t st = as_stream(stream);
     const size_t smem_p = (size_t)2 * kVmTileCells * max_rank * sizeof(float), smem_l = (size_t)(kVmZChunk + 1) * max_rank * sizeof(float);
-    const dim3 gp(max_tiles, 3), gl(max_chunks, 3), block(256);
+    // split factors: planes so that a tile holding every point still spreads over the chip; lines: few chunks, many points
+    const uint32_t split_p = max_tiles >= 1024 ? 2 : 4, split_l = 128;
+    const dim3 gp(max_tiles, 3, split_p), gl(max_chunks, 3, split_l), block(256);
     if (max_rank <= 16) {
         if (reduce) hipLaunchKernelGGL((k_vm_plane_backward<16, true>), gp, block, smem_p, st, x, N, f, b);
         else hipLaunchKernelGGL((k_vm_plane_backward<16, false>), gp, block, smem_p, st, x, N, f, b);

@@ -14,11 +14,13 @@ from tools.microbench import timeit  # noqa: E402
 
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 240000
-    for res in (128, 300):
+    only_res = [int(r) for r in sys.argv[2].split(",")] if len(sys.argv) > 2 else (128, 300)
+    modes = [m == "fused" for m in sys.argv[3].split(",")] if len(sys.argv) > 3 else (True, False)
+    for res in only_res:
         torch.manual_seed(0)
         net = trf.NeRFNetwork(resolution=[res] * 3, bound=1, cuda_ray=True).cuda()
         x = (torch.rand(N, 3, device="cuda") * 2 - 1)
-        for fused in (True, False):
+        for fused in modes:
             net.fused_vm = fused
 
             def fwd():
