@@ -146,3 +146,32 @@ def test_tensorf_vm_features_kernel_matches_grid_sample_sequence(hip):
     # under autocast (the -O configs) the features stay fp32 like grid_sample's
     with torch.autocast("cuda", dtype=torch.float16):
         assert net.get_sigma_feat(x).dtype == torch.float32
+
+
+def test_tensorf_vm_kernels_match_cpu_oracle(hip):
+    """csrc/tensorf.hip (forward + binned backward) vs oracle/vm_features.py (numpy restatement pinned against torch's CPU
+    grid_sample in tests/test_vm_oracle.py) on the same inputs"""
+    import s3d_hip
+    from oracle import vm_features as vo
+    g = torch.Generator().manual_seed(9)
+    res, ranks, N = [24, 17, 33], [3, 18, 7], 20000
+    mat_ids, vec_ids = ((0, 1), (0, 2), (1, 2)), (2, 1, 0)
+    planes = [torch.randn(1, ranks[i], res[mat_ids[i][1]], res[mat_ids[i][0]], generator=g) for i in range(3)]
+    lines = [torch.randn(1, ranks[i], res[vec_ids[i]], 1, generator=g) for i in range(3)]
+    x = torch.rand(N, 3, generator=g) * 2.4 - 1.2
+    pn, ln = [p[0].numpy() for p in planes], [l[0, :, :, 0].numpy() for l in lines]
+    pd, ld, xd = [p.cuda() for p in planes], [l.cuda() for l in lines], x.cuda()
+    rows = sum(ranks)
+    out_s = torch.empty(N, device="cuda")
+    out_c = torch.empty(rows, N, device="cuda")
+    s3d_hip.VmBackend.features_forward(xd, pd, ld, res, True, out_s)
+    s3d_hip.VmBackend.features_forward(xd, pd, ld, res, False, out_c)
+    np.testing.assert_allclose(out_s.cpu().numpy(), vo.sigma_feat(x.numpy(), pn, ln), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out_c.cpu().numpy(), vo.color_products(x.numpy(), pn, ln), rtol=1e-5, atol=1e-7)
+    gs = torch.randn(N, generator=g)
+    gc = torch.randn(N, rows, generator=g)
+    for reduce, grad, grad_rows in ((True, gs, np.tile(gs.numpy()[None], (rows, 1))), (False, gc, gc.numpy().T)):
+        gp, gl = s3d_hip.VmBackend.features_backward(xd, pd, ld, res, reduce, grad.cuda().contiguous())
+        rp, rl = vo.factor_grads(x.numpy(), pn, ln, grad_rows)
+        for a, b in zip(gp + gl, rp + rl):
+            np.testing.assert_allclose(a.cpu().numpy().reshape(b.shape), b, rtol=1e-4, atol=1e-5)

@@ -1,0 +1,52 @@
+"""CPU: oracle/vm_features.py (numpy restatement of tensoRF/network.py:112-153 + torch's grid sampler) pinned against the
+reference's own op sequence — twelve F.grid_sample calls on CPU — values and autograd gradients; and the module's CPU path."""
+import numpy as np
+import torch
+
+from oracle import vm_features as vo
+from tensoRF import network as trf
+
+
+def _setup():
+    torch.manual_seed(5)
+    net = trf.NeRFNetwork(resolution=[12, 20, 16], sigma_rank=[3, 2, 4], color_rank=[5, 6, 2], bound=1, cuda_ray=True)
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(3000, 3, generator=g) * 2.6 - 1.3
+    x[:8] = torch.tensor([[-1.0, 1.0, 0.0]])
+    x[8:16] = 1.0
+    return net, x
+
+
+def _np(params):
+    return [p.detach().numpy()[0] if p.shape[-1] != 1 else p.detach().numpy()[0, :, :, 0] for p in params]
+
+
+def test_oracle_matches_grid_sample_sequence():
+    net, x = _setup()
+    xs = x.numpy()
+    s_ref = net._sigma_feat_torch(x, net.sigma_mat, net.sigma_vec)
+    c_ref = net._color_prod_torch(x, net.color_mat, net.color_vec)
+    s = vo.sigma_feat(xs, _np(net.sigma_mat), _np(net.sigma_vec))
+    c = vo.color_products(xs, _np(net.color_mat), _np(net.color_vec))
+    np.testing.assert_allclose(s, s_ref.detach().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(c, c_ref.detach().numpy(), rtol=1e-5, atol=1e-7)
+    inside = (x.abs() <= 1).all(1).numpy()
+    assert 0.2 < inside.mean() < 0.8 and np.abs(s[~inside]).max() > 0
+    # gradients: autograd through grid_sample vs the restated scatter-add
+    w = torch.linspace(-1, 1, x.shape[0])
+    s_ref.mul(w).sum().backward()
+    gp, gl = vo.factor_grads(xs, _np(net.sigma_mat), _np(net.sigma_vec), np.tile(w.numpy()[None], (9, 1)))
+    for p, g in zip(list(net.sigma_mat) + list(net.sigma_vec), gp + gl):
+        np.testing.assert_allclose(g.reshape(p.grad.shape), p.grad.numpy(), rtol=2e-4, atol=1e-6)
+    gc = torch.randn(c_ref.shape, generator=torch.Generator().manual_seed(7))
+    c_ref.mul(gc).sum().backward()
+    gp, gl = vo.factor_grads(xs, _np(net.color_mat), _np(net.color_vec), gc.numpy())
+    for p, g in zip(list(net.color_mat) + list(net.color_vec), gp + gl):
+        np.testing.assert_allclose(g.reshape(p.grad.shape), p.grad.numpy(), rtol=2e-4, atol=1e-6)
+
+
+def test_module_cpu_path_is_the_reference_sequence(oracle_wrappers):
+    net, x = _setup()
+    assert not net._use_native(x)  # CPU tensors: the grid_sample sequence, exactly as in the reference
+    sigma, rgb = net(x, torch.nn.functional.normalize(torch.randn(x.shape[0], 3), dim=-1))
+    assert sigma.shape == (3000,) and rgb.shape == (3000, 3) and torch.isfinite(rgb).all()
