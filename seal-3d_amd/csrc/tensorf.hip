@@ -317,7 +317,8 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
     hipStream_t st = as_stream(stream);
     const size_t smem_p = (size_t)2 * kVmTileCells * max_rank * sizeof(float), smem_l = (size_t)(kVmZChunk + 1) * max_rank * sizeof(float);
     // split factors: planes so that a tile holding every point still spreads over the chip; lines: few chunks, many points
-    const uint32_t split_p = max_tiles >= 1024 ? 2 : 4, split_l = 128;
+    // (marched samples are concentrated: at the Lego scene a handful of tiles hold most points; empty shares exit at once)
+    const uint32_t split_p = 8, split_l = 128;
     const dim3 gp(max_tiles, 3, split_p), gl(max_chunks, 3, split_l), block(256);
     if (max_rank <= 16) {
         if (reduce) hipLaunchKernelGGL((k_vm_plane_backward<16, true>), gp, block, smem_p, st, x, N, f, b);

@@ -1,5 +1,6 @@
 """GPU smoke/parity of the remaining BASELINE configurations on the product path:
 config 3 (Seal bbox distillation, teacher+student NGP) and config 5 (TensoRF VM backbone with the HIP freq encoder)."""
+import numpy as np
 import pytest
 import torch
 
