@@ -133,6 +133,32 @@ class KernelTimers:
         return out
 
 
+def profile_traffic(op):
+    """HBM bytes per launch of the dominant op from the newest committed rocprofv3 PMC summary (profiles/rNN_timed_region.md:
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, gfx950 2x fetch correction applied,
+    tools/profile_bench.sh).  PMC counters cannot be collected from inside this process; None when no summary is there."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_timed_region.md")))
+    if not files:
+        return None, None
+    kernels = ("k_grid_forward",) if op == "grid_encode_forward" else ("k_bin_count", "k_bin_scatter", "k_bin_accumulate")
+    total, seen = 0.0, set()
+    for line in open(files[-1]):
+        m = re.match(r"\| `([A-Za-z0-9_]+)", line)
+        if not m or m.group(1) not in kernels or m.group(1) in seen:
+            continue
+        cols = [c.strip() for c in line.strip().strip("|").split("|")]
+        try:
+            total += (float(cols[5]) + float(cols[6])) * 1024.0  # FETCH x2 KiB + WRITE KiB
+            seen.add(m.group(1))
+        except (ValueError, IndexError):
+            return None, None
+    if len(seen) != len(kernels):
+        return None, None
+    return total, os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
+
+
 def grid_meta(name, args):
     # grid_encode_forward(inputs, embeddings, offsets, outputs, B, ...) / backward(grad, inputs, embeddings, offsets, ge, B, ...)
     return args[4] if name == "grid_encode_forward" else args[5]
@@ -307,8 +333,9 @@ def main():
     dom = max(("grid_encode_forward", "grid_encode_backward"), key=lambda n: ksum.get(n, {}).get("total_ms", 0))
     kd = ksum[dom]
     achieved = kd["units"] * bytes_pt / (kd["avg_us"] * 1e-6) / 1e9
+    traffic, traffic_src = profile_traffic(dom)
     roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_us": kd["avg_us"], "points_per_launch": kd["units"],
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_us": kd["avg_us"], "points_per_launch": kd["units"],
                 "algorithmic_bytes_per_point": bytes_pt,
                 "kernels_ms_per_step": {k: v["total_ms"] / timer_steps for k, v in ksum.items()},
                 "timing": "HIP events around each native call on the launch stream; " +
