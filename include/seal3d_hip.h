@@ -130,12 +130,15 @@ void s3d_grid_level_scales(uint32_t L, float S, uint32_t H, float* scales_out /*
  * inputs [B,D] f32 in [0,1]; embeddings [sO,C] dtype; offsets [L+1] i32; outputs [L,B,C] dtype;
  * dy_dx [B,L,D,C] dtype or NULL.
  * bound: 0 = inputs already in [0,1] (the reference's native contract); > 0 = raw coordinates in [-bound, bound],
- * normalised in the kernel exactly like GridEncoder.forward does in torch (grid.py:146), dy_dx must be NULL. */
+ * normalised in the kernel exactly like GridEncoder.forward does in torch (grid.py:146), dy_dx must be NULL.
+ * live (optional, inference): device fp32, row b is live iff live[b * live_stride] != 0; other rows are written as zeros
+ * without touching the table.  The inference loop passes `deltas` (nerf/renderer.py:355-360: march_rays leaves the
+ * unused slots of a ray's chunk zero-filled and composite_rays stops at the first deltas == 0, raymarching.cu:740). */
 int s3d_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets,
                             void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
                             uint32_t H, void* dy_dx, uint32_t gridtype, int align_corners,
                             uint32_t interp, int dtype, float bound, const int32_t* n_valid,
-                            s3d_stream_t stream);
+                            const float* live, uint32_t live_stride, s3d_stream_t stream);
 
 /* Test hook: table row of every corner, corner_idx [B,L,2^D] u32 (0xffffffff for out-of-range points). */
 int s3d_grid_corner_indices(const float* inputs, const int32_t* offsets, uint32_t* corner_idx, uint32_t B,

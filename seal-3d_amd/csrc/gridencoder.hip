@@ -27,7 +27,13 @@ namespace {
 constexpr uint32_t kMaxLevels = 32;
 // per-level scales + the optional input normalisation of GridEncoder.forward (grid.py:146: x01 = (x + bound) / (2 bound),
 // evaluated as torch's GPU kernels do: one add, one multiply by the fp32 reciprocal); bound = 0: inputs are already in [0,1]
-struct LevelScales { float v[kMaxLevels]; float bound, inv_2bound; const int32_t* n_valid; };  // n_valid: see valid_rows()
+struct LevelScales {
+    float v[kMaxLevels];
+    float bound, inv_2bound;
+    const int32_t* n_valid;   // see valid_rows()
+    const float* live;        // forward only: rows with live[b * live_stride] == 0 are written as zeros, table untouched
+    uint32_t live_stride;
+};
 
 constexpr uint32_t kPrimes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
 
@@ -142,7 +148,10 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward(const float* __restr
     const uint32_t b = (blockIdx.x / kXcds) * kFwdBlock + threadIdx.x;
     if (b >= valid_rows(B, scales.n_valid) || xcd >= L) return;
     float x[D];
-    const bool oob = load_point<D>(inputs, b, scales, x);
+    bool oob = load_point<D>(inputs, b, scales, x);
+    // unused sample slots of the inference loop (march_rays leaves them zero-filled, deltas == 0; composite_rays never
+    // reads their sigma / rgb): same treatment as out-of-range points — zeros, no gathers
+    if (scales.live && scales.live[(size_t)b * scales.live_stride] == 0.0f) oob = true;
 
     for (uint32_t level = xcd; level < L; level += kXcds) {
         T* out = outputs + ((size_t)level * B + b) * C;
@@ -878,6 +887,8 @@ __global__ void __launch_bounds__(kFwdBlock) k_grad_tv(const float* __restrict__
 
 void host_scales(uint32_t L, float S, uint32_t H, LevelScales& out, float bound = 0.0f, const int32_t* n_valid = nullptr) {
     out.n_valid = n_valid;
+    out.live = nullptr;
+    out.live_stride = 0;
     out.bound = bound;
     out.inv_2bound = bound != 0.0f ? 1.0f / (2.0f * bound) : 0.0f;
     for (uint32_t l = 0; l < kMaxLevels; l++) out.v[l] = 0.0f;
@@ -1037,9 +1048,11 @@ S3D_EXPORT void s3d_grid_level_scales(uint32_t L, float S, uint32_t H, float* sc
 S3D_EXPORT int s3d_grid_encode_forward(const float* inputs, const void* embeddings, const int32_t* offsets,
                                        void* outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                        void* dy_dx, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
-                                       float bound, const int32_t* n_valid, s3d_stream_t stream) {
+                                       float bound, const int32_t* n_valid, const float* live, uint32_t live_stride,
+                                       s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(inputs && embeddings && offsets && outputs, "grid_encode_forward: null pointer");
+    S3D_REQUIRE(!(live && dy_dx), "grid_encode_forward: `live` is an inference-time option (no input Jacobian)");
     S3D_REQUIRE(bound >= 0.0f && !(bound != 0.0f && dy_dx), "grid_encode_forward: bound must be >= 0 (0 = inputs in [0,1]); "
                 "the input Jacobian is only produced for pre-normalised inputs");
     S3D_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_forward: L must be in [1, %u]", kMaxLevels);
@@ -1047,6 +1060,8 @@ S3D_EXPORT int s3d_grid_encode_forward(const float* inputs, const void* embeddin
     S3D_REQUIRE((uint64_t)B * L * C < (1ull << 32), "grid_encode_forward: B*L*C overflows 32 bits");
     LevelScales sc;
     host_scales(L, S, H, sc, bound, n_valid);
+    sc.live = live;
+    sc.live_stride = live ? (live_stride ? live_stride : 1u) : 0u;
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
     if (dtype == S3D_F32) {

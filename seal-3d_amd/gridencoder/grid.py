@@ -54,7 +54,7 @@ class _GridEncode(Function):
     @custom_fwd(device_type="cuda")
     def forward(ctx, inputs, embeddings, offsets, per_level_scale, base_resolution, calc_grad_inputs=False,
                 gridtype=0, align_corners=False, interpolation=0, cache_half=False, level_major=False, bound=0.0,
-                n_valid=None):
+                n_valid=None, live=None):
         inputs = inputs.contiguous()
         B, D = inputs.shape
         L = offsets.shape[0] - 1
@@ -80,8 +80,11 @@ class _GridEncode(Function):
             extra["bound"] = bound
         if n_valid is not None:
             extra["n_valid"] = n_valid  # device sample count of a padded batch: rows beyond it are not produced
+        fwd_extra = dict(extra)
+        if live is not None and not torch.is_grad_enabled():
+            fwd_extra["live"] = live  # inference: rows marked dead are written as zeros without reading the table
         _backend.grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, dy_dx, gridtype,
-                                     align_corners, interpolation, **extra)
+                                     align_corners, interpolation, **fwd_extra)
         if not level_major:  # (a fused consumer reads the kernel's own [L, B, C] layout in place: ffmlp input_layout=1)
             outputs = outputs.permute(1, 0, 2).reshape(B, L * C)
 
@@ -114,7 +117,7 @@ class _GridEncode(Function):
                                       grad_inputs, gridtype, align_corners, interpolation, **ctx.extra)
         if grad_inputs is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
-        return grad_inputs, (None if stash is not None else grad_embeddings), None, None, None, None, None, None, None, None, None, None, None
+        return grad_inputs, (None if stash is not None else grad_embeddings), None, None, None, None, None, None, None, None, None, None, None, None
 
 
 grid_encode = _GridEncode.apply
@@ -169,11 +172,12 @@ class GridEncoder(nn.Module):
                 f"params={tuple(self.embeddings.shape)} gridtype={self.gridtype} align_corners={self.align_corners} "
                 f"interpolation={self.interpolation}")
 
-    def forward(self, inputs, bound=1, level_major=False, n_valid=None):
+    def forward(self, inputs, bound=1, level_major=False, n_valid=None, live=None):
         """`level_major=True` (build extension, 2-D inputs only) returns the kernel's own [num_levels, B, level_dim] layout
         instead of the reference's [B, num_levels * level_dim] — what ffmlp's `input_layout=1` consumes without a copy.
         `n_valid` (build extension): int32 GPU tensor, the sample count of a padded batch; rows past it (rounded up to
-        128) are neither encoded nor back-propagated (seal3d_hip.h)."""
+        128) are neither encoded nor back-propagated (seal3d_hip.h).  `live` (build extension, no-grad calls): fp32 GPU
+        tensor with one row per input; rows whose first element is 0 are encoded as zeros without touching the table."""
         # [-bound, bound] -> [0, 1] (grid.py:146): inside the kernels when the backend can, no input gradient is needed and
         # 2 * bound is a power of two (the usual 1, 2, 4, ...: dividing and multiplying by the reciprocal then round
         # identically, so the fused result is bit-identical to the torch expression), else here
@@ -187,7 +191,7 @@ class GridEncoder(nn.Module):
         inputs = inputs.view(-1, self.input_dim)
         out = grid_encode(inputs, self.embeddings, self.offsets, self.per_level_scale, self.base_resolution,
                           inputs.requires_grad, self.gridtype_id, self.align_corners, self.interp_id,
-                          not self.training, level_major, fuse_bound, n_valid)
+                          not self.training, level_major, fuse_bound, n_valid, live)
         if level_major:
             return out
         return out.view(lead + [self.output_dim])

@@ -139,7 +139,9 @@ class NeRFRenderer(nn.Module):
                     n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
                     self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma, max_steps)
                 mxyzs, mdirs, mmask = self.map_samples(xyzs, dirs)
-                sigmas, rgbs = self(mxyzs, mdirs)
+                # slots a ray did not fill stay zero (deltas == 0) and composite_rays never reads their sigma / rgb
+                with s3d_hip.live_rows(deltas):
+                    sigmas, rgbs = self(mxyzs, mdirs)
                 if self.density_scale != 1:
                     sigmas = self.density_scale * sigmas
                 rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)

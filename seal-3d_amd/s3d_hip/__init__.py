@@ -110,6 +110,41 @@ def _nv(t):
     return C.c_void_p(t.data_ptr())
 
 
+def _live(t, B):
+    """`live` of s3d_grid_encode_forward: None, or an fp32 GPU tensor [B, ...] whose first column marks live rows"""
+    if t is None:
+        return C.c_void_p(0), C.c_uint32(0)
+    if t.dtype != torch.float32 or not t.is_cuda or t.shape[0] != B:
+        raise RuntimeError("live must be an fp32 GPU tensor with one row per input row")
+    return C.c_void_p(t.data_ptr()), C.c_uint32(t.stride(0) if t.dim() > 1 else 1)
+
+
+# Inference counterpart of row_limit: the deltas tensor of the current march_rays chunk (zero rows = unused slots)
+_LIVE_ROWS = None
+
+
+class live_rows:
+    def __init__(self, deltas):
+        self.value = deltas
+
+    def __enter__(self):
+        global _LIVE_ROWS
+        self.saved, _LIVE_ROWS = _LIVE_ROWS, self.value
+        return self
+
+    def __exit__(self, *exc):
+        global _LIVE_ROWS
+        _LIVE_ROWS = self.saved
+        return False
+
+
+def active_live_rows(B):
+    t = _LIVE_ROWS
+    if t is not None and t.shape[0] == int(B) and t.dtype == torch.float32 and t.is_cuda:
+        return t
+    return None
+
+
 # The padded sample batch of the current training render: (counter tensor, rows of the padded buffers).  The renderer
 # announces it around the network call; a network whose whole sample path is native picks it up with
 # `active_row_limit(B)` and hands it to every kernel explicitly (forward AND backward), so the work follows the samples.
@@ -298,7 +333,7 @@ class GridBackend:
 
     @staticmethod
     def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, Cc, L, S, H, dy_dx, gridtype, align_corners,
-                            interp, bound=0.0, n_valid=None):
+                            interp, bound=0.0, n_valid=None, live=None):
         _need(inputs, torch.float32, "inputs")
         _need(offsets, torch.int32, "offsets")
         if outputs.dtype != embeddings.dtype:
@@ -306,7 +341,7 @@ class GridBackend:
         _check(lib().s3d_grid_encode_forward(_p(inputs), _p(embeddings), _p(offsets), _p(outputs), _u(B), _u(D),
                                              _u(Cc), _u(L), _f(S), _u(H), _p(dy_dx), _u(gridtype),
                                              C.c_int(int(align_corners)), _u(interp), C.c_int(_dt(embeddings)),
-                                             _f(bound), _nv(n_valid), _stream()), "grid_encode_forward")
+                                             _f(bound), _nv(n_valid), *_live(live, B), _stream()), "grid_encode_forward")
 
     @staticmethod
     def grid_corner_indices(inputs, offsets, corner_idx, B, D, Cc, L, S, H, gridtype, align_corners):

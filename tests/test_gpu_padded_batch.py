@@ -118,3 +118,49 @@ def test_ffmlp_padded_batch(hip, fused, monkeypatch):
         res.append((y[:n_eff].detach().clone(), net.weights.grad.clone(), xi.grad[:n_eff].clone()))
     for a, b in zip(*res):
         assert torch.isfinite(b.float()).all() and torch.equal(a, b)
+
+
+def test_inference_loop_skips_dead_slots_without_changing_the_image(hip, monkeypatch):
+    """`live` of s3d_grid_encode_forward: the unused slots of every march_rays chunk (deltas == 0) are encoded as zeros
+    without table gathers; composite_rays never reads them, so the rendered frame is bit-identical"""
+    import s3d_hip
+    from nerf import network_ff, synthetic as syn
+    torch.manual_seed(0)
+    net = network_ff.NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).cuda().eval()
+    net.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    net.density_grid.copy_(torch.from_numpy(grid))
+    net.density_bitfield.copy_(torch.from_numpy(bits))
+    net.infer_batch_scale = 4
+    poses = syn.orbit_poses(1, seed=0).cuda()
+    r = syn.get_rays(poses, syn.lego_intrinsics(200, 200), 200, 200)
+    ro, rd = r["rays_o"].contiguous(), r["rays_d"].contiguous()
+    seen = []
+    real = s3d_hip.active_live_rows
+
+    def spy(B):
+        t = real(B)
+        if t is not None:
+            seen.append(float((t[:, 0] == 0).float().mean()))
+        return t
+    monkeypatch.setattr(s3d_hip, "active_live_rows", spy)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        a = net.render(ro, rd, bg_color=1, perturb=False, max_steps=1024)
+    assert seen and max(seen) > 0.05  # the mask was used and some chunks had dead slots
+    monkeypatch.setattr(s3d_hip, "active_live_rows", lambda B: None)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        b = net.render(ro, rd, bg_color=1, perturb=False, max_steps=1024)
+    assert torch.equal(a["image"], b["image"]) and torch.equal(a["depth"], b["depth"])
+    # direct: masked rows are exact zeros, live rows identical
+    from tools.microbench import grid_meta
+    offs, S, total = grid_meta()
+    x = torch.rand(4096, 3, device="cuda")
+    emb = (torch.rand(total, 2, device="cuda") - 0.5).half()
+    deltas = torch.rand(4096, 2, device="cuda")
+    deltas[::3] = 0
+    o0 = torch.empty(16, 4096, 2, device="cuda", dtype=torch.half)
+    o1 = torch.empty_like(o0)
+    s3d_hip.GridBackend.grid_encode_forward(x, emb, offs, o0, 4096, 3, 2, 16, S, 16, None, 0, False, 0)
+    s3d_hip.GridBackend.grid_encode_forward(x, emb, offs, o1, 4096, 3, 2, 16, S, 16, None, 0, False, 0, live=deltas)
+    dead = deltas[:, 0] == 0
+    assert not o1[:, dead].any() and torch.equal(o1[:, ~dead], o0[:, ~dead])
