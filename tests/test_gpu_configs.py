@@ -135,7 +135,9 @@ def test_tensorf_vm_features_kernel_matches_grid_sample_sequence(hip):
     torch.testing.assert_close(res[True][1], res[False][1], rtol=1e-5, atol=1e-7)
     assert float(res[False][0][~inside].abs().max()) > 0  # partially outside points still see the in-range corners
     for a, b in zip(res[True][2], res[False][2]):
-        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)  # (global-atomic scatter-adds: order varies run to run)
+        # fp32 scatter-adds in a different (and, on both sides, run-dependent) order: the error scales with the sum of the
+        # |terms| of an element, not with its (possibly cancelling) value
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5 * float(b.abs().max()))
     # a gradient w.r.t. the coordinates falls back to the grid_sample sequence
     xg = x[:4096].clone().requires_grad_(True)
     net.get_sigma_feat(xg).sum().backward()
@@ -175,4 +177,4 @@ def test_tensorf_vm_kernels_match_cpu_oracle(hip):
         gp, gl = s3d_hip.VmBackend.features_backward(xd, pd, ld, res, reduce, grad.cuda().contiguous())
         rp, rl = vo.factor_grads(x.numpy(), pn, ln, grad_rows)
         for a, b in zip(gp + gl, rp + rl):
-            np.testing.assert_allclose(a.cpu().numpy().reshape(b.shape), b, rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(a.cpu().numpy().reshape(b.shape), b, rtol=1e-4, atol=2e-5 * float(np.abs(b).max()))
