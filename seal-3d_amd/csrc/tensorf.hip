@@ -340,7 +340,6 @@ S3D_EXPORT int s3d_vm_features_forward(const float* x, uint32_t N, const float* 
     VmFactors f;
     uint32_t row;
     if (int rc = fill_factors(f, planes, lines, rank, resolution, row)) return rc;
-    S3D_REQUIRE((uint64_t)row * N < (1ull << 32) * 4, "vm_features_forward: output too large");
     const dim3 grid(div_up<uint32_t>(N, 256)), block(256);
     if (reduce) hipLaunchKernelGGL((k_vm_features<true>), grid, block, 0, as_stream(stream), x, N, f, out);
     else hipLaunchKernelGGL((k_vm_features<false>), grid, block, 0, as_stream(stream), x, N, f, out);
