@@ -30,6 +30,8 @@ def save_checkpoint(trainer, workspace, name="ngp", full=False, best=False, remo
     if model.cuda_ray:
         state["mean_count"] = model.mean_count
         state["mean_density"] = model.mean_density
+    if hasattr(model, "upsample_model") and hasattr(model, "resolution"):
+        state["resolution"] = list(model.resolution)  # TensoRF: factor resolution at save time (tensoRF/utils.py:236)
     if full:
         state["optimizer"] = trainer.optimizer.state_dict()
         if lr_scheduler is not None:
@@ -84,6 +86,11 @@ def load_checkpoint(trainer, checkpoint, model_only=False, lr_scheduler=None, em
         model.load_state_dict(ckpt)
         _after_weights_changed(trainer)
         return [], []
+    if "resolution" in ckpt and hasattr(model, "upsample_model") and list(ckpt["resolution"]) != list(model.resolution):
+        # TensoRF: bring the factors to the checkpoint's resolution before loading them, then re-create the optimizer
+        # over the new Parameters (tensoRF/utils.py:347-352)
+        model.upsample_model(ckpt["resolution"])
+        trainer.rebuild_optimizer()
     missing, unexpected = model.load_state_dict(ckpt["model"], strict=False)
     _after_weights_changed(trainer)
     if ema is not None and "ema" in ckpt:

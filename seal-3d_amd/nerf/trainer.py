@@ -50,6 +50,7 @@ class Trainer:
     def __init__(self, model, lr=1e-2, fp16=True, update_extra_interval=16, dist=None, max_steps=1024, dt_gamma=0,
                  T_thresh=1e-4, capturable=False, native_optim=None, optimizer=None, scaler=None):
         self.model = model
+        self.lr = lr
         self.fp16 = fp16
         self.update_extra_interval = update_extra_interval
         self.dist = dist
@@ -58,21 +59,33 @@ class Trainer:
         # GPU default: Adam + loss scaling straight from the (fp16) gradients of the HIP kernels (nerf/optim.py);
         # native_optim=False keeps the reference's torch.optim.Adam + GradScaler (the only choice on CPU)
         self.native_optim = on_gpu if native_optim is None else (native_optim and on_gpu)
+        self._capturable = capturable and on_gpu
         if optimizer is not None:  # share an existing optimizer / scaler (e.g. an eager twin of a graphed trainer)
             self.optimizer, self.scaler = optimizer, scaler
-        elif self.native_optim:
-            from .optim import NativeAdam, NativeGradScaler
-            self.optimizer = NativeAdam(model.get_params(lr), lr=lr, betas=(0.9, 0.99), eps=1e-15)
-            self.scaler = NativeGradScaler(next(model.parameters()).device, enabled=fp16)
         else:
-            self.optimizer = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15, fused=on_gpu,
-                                              capturable=capturable and on_gpu)
-            self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
+            self.scaler = None
+            self.rebuild_optimizer()
         self.global_step = 0
         self.epoch = 0
         self.stats = {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}
         if dist is not None:
             dist.register(model)
+
+    def rebuild_optimizer(self):
+        """(re-)create optimizer (and, the first time, the loss scaler) over the model's CURRENT parameters — needed after
+        the parameter set changes (TensoRF upsample_model, tensoRF/utils.py:137-140 / :347-352)"""
+        model, lr, fp16 = self.model, self.lr, self.fp16
+        on_gpu = next(model.parameters()).is_cuda
+        if self.native_optim:
+            from .optim import NativeAdam, NativeGradScaler
+            self.optimizer = NativeAdam(model.get_params(lr), lr=lr, betas=(0.9, 0.99), eps=1e-15)
+            if self.scaler is None:
+                self.scaler = NativeGradScaler(next(model.parameters()).device, enabled=fp16)
+        else:
+            self.optimizer = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15, fused=on_gpu,
+                                              capturable=self._capturable)
+            if self.scaler is None:
+                self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
 
     def save_checkpoint(self, workspace, name="ngp", full=False, best=False, remove_old=True, max_keep_ckpt=2):
         """reference on-disk format (nerf/utils.py:1015-1076); see nerf/checkpoint.py"""

@@ -121,3 +121,29 @@ def test_latest_checkpoint(tmp_path):
         t.epoch = ep
         t.save_checkpoint(str(tmp_path))
     assert latest_checkpoint(str(tmp_path)).endswith("ngp_ep0012.pth")
+
+
+def test_tensorf_checkpoint_carries_resolution_and_reupsamples(tmp_path):
+    """tensoRF/utils.py:236, :347-352 of the reference: `resolution` travels with the file; loading into a model of another
+    resolution upsamples first and re-creates the optimizer over the new factor Parameters"""
+    from tensoRF import network as trf
+    torch.manual_seed(0)
+    a = trf.NeRFNetwork(resolution=[12, 12, 12], sigma_rank=[2, 2, 2], color_rank=[3, 3, 3], bound=1, cuda_ray=True)
+    ta = Trainer(a, fp16=False)
+    a.upsample_model([20, 16, 24])
+    ta.rebuild_optimizer()
+    ta.epoch = 7
+    path = ta.save_checkpoint(str(tmp_path), name="trf", full=True)
+    ck = torch.load(path, weights_only=False)
+    assert ck["resolution"] == [20, 16, 24] and "sigma_mat.0" in ck["model"] and "color_vec.2" in ck["model"]
+    assert tuple(ck["model"]["sigma_mat.0"].shape) == (1, 2, 16, 20) and tuple(ck["model"]["sigma_vec.0"].shape) == (1, 2, 24, 1)
+
+    b = trf.NeRFNetwork(resolution=[12, 12, 12], sigma_rank=[2, 2, 2], color_rank=[3, 3, 3], bound=1, cuda_ray=True)
+    tb = Trainer(b, fp16=False)
+    old_opt = tb.optimizer
+    assert tb.load_checkpoint(path) == ([], [])
+    assert b.resolution == [20, 16, 24] and tb.epoch == 7 and tb.optimizer is not old_opt
+    for k, v in a.state_dict().items():
+        assert torch.equal(v, b.state_dict()[k]), k
+    owned = {id(p) for g in tb.optimizer.param_groups for p in g["params"]}
+    assert all(id(p) in owned for p in b.parameters())
