@@ -88,13 +88,17 @@ class RayShardedDP:
                 slot.copy_(p.grad.reshape(-1))
                 p.grad = slot.view_as(p)
             off += n
+        # RCCL averages inside the collective (pre-multiplied sum): no separate divide pass over the bucket, and the fp16
+        # bucket of loss-scaled gradients cannot overflow in the sum of `world` ranks.  gloo (CPU tests) has no AVG.
+        fused_avg = self.average and dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if fused_avg else dist.ReduceOp.SUM
         for h in self.half_grads:
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
-            if self.average and self.world > 1:
+            dist.all_reduce(h, op=op, group=self.group)
+            if self.average and not fused_avg and self.world > 1:
                 h.div_(self.world)
         if self.flat.numel():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            if self.average:
+            dist.all_reduce(self.flat, op=op, group=self.group)
+            if self.average and not fused_avg:
                 self.flat.div_(self.world)
 
     def sync_extra_state(self, model):
