@@ -145,6 +145,12 @@ class Trainer:
             return self.model.render(rays_o, rays_d, bg_color=bg_color, perturb=False, **self.render_kwargs)
 
 
+# Stream capture restricts HIP calls of the CAPTURING thread only: with a process group alive, torch's RCCL watchdog thread
+# polls its work events (hipEventQuery) at any time, and under the default "global" mode such a poll during one of the
+# captures below aborts the process ("operation not permitted when stream is capturing").
+_CAPTURE_MODE = "thread_local"
+
+
 class GraphedTrainer(Trainer):
     """The same training step replayed from a HIP graph (torch.cuda.CUDAGraph): the step issues ~115 kernels whose
     launch cost (~0.3 ms of a 2.5 ms step, rocprof: GPU 79 % busy) is paid once at capture.
@@ -222,15 +228,15 @@ class GraphedTrainer(Trainer):
         self.graph = torch.cuda.CUDAGraph()
         model.local_step = 0
         if self.dist is None:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
                 self.s_loss = self._body_fb()
                 self._body_opt()
             self.graph_opt = None
         else:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
                 self.s_loss = self._body_fb()
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._body_opt()
         model.step_counter = ring
         model.mean_count, model.local_step = saved
@@ -258,7 +264,7 @@ class GraphedTrainer(Trainer):
             else:
                 if self.ues_graph is None:
                     self.ues_graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.ues_graph):
+                    with torch.cuda.graph(self.ues_graph, capture_error_mode=_CAPTURE_MODE):
                         self.ues_mean = model.partial_grid_update_device()
                 self.ues_graph.replay()
                 mean = self.ues_mean
