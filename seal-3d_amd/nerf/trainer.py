@@ -69,7 +69,11 @@ class Trainer:
         self.epoch = 0
         self.stats = {"loss": [], "valid_loss": [], "results": [], "checkpoints": [], "best_result": None}
         if dist is not None:
-            dist.register(model)
+            dist.register(model)  # broadcasts rank 0's parameters through `.data` (no version bump) ...
+            resync = getattr(self.optimizer, "resync_half", None)
+            if resync is not None:
+                resync()  # ... so the optimizer's fp16 copies are re-made from the adopted values
+            bump_weights_epoch()
 
     def rebuild_optimizer(self):
         """(re-)create optimizer (and, the first time, the loss scaler) over the model's CURRENT parameters — needed after
