@@ -44,6 +44,7 @@ class RayShardedDP:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.average = average
+        self._avg_ok = None
         self.flat = None
         self.params = []
         self.half_grads = []
@@ -71,7 +72,24 @@ class RayShardedDP:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)
             off += n
+        if self.average and (self.world > 1 or self.force_collective):
+            self._avg_supported()  # probe now (host read-back): never inside a graph capture
         return self
+
+    def _avg_supported(self):
+        """ReduceOp.AVG on this group, probed once with a real (tiny) fp16 collective: every rank takes part, so every rank
+        reaches the same verdict; anything but the exact mean falls back to SUM + divide"""
+        if self._avg_ok is None:
+            ok = False
+            if dist.get_backend(self.group) == "nccl":
+                try:
+                    probe = torch.full((8,), 3.0, dtype=torch.float16, device="cuda")
+                    dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=self.group)
+                    ok = bool((probe == 3.0).all().item())
+                except RuntimeError:
+                    ok = False
+            self._avg_ok = ok
+        return self._avg_ok
 
     def allreduce_grads(self, scaler=None):
         if self.world == 1 and not self.force_collective:
@@ -90,7 +108,7 @@ class RayShardedDP:
             off += n
         # RCCL averages inside the collective (pre-multiplied sum): no separate divide pass over the bucket, and the fp16
         # bucket of loss-scaled gradients cannot overflow in the sum of `world` ranks.  gloo (CPU tests) has no AVG.
-        fused_avg = self.average and dist.get_backend(self.group) == "nccl"
+        fused_avg = self.average and self._avg_supported()
         op = dist.ReduceOp.AVG if fused_avg else dist.ReduceOp.SUM
         for h in self.half_grads:
             dist.all_reduce(h, op=op, group=self.group)
