@@ -52,3 +52,34 @@ def test_product_sources_do_not_reference_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "s3o_" in txt:
                     bad.append(os.path.join(root, f))
     assert not bad, f"product files touching the oracle: {bad}"
+
+
+def test_ctypes_call_sites_pass_as_many_arguments_as_the_header_declares():
+    """ctypes does not check arity: a call site that drifts from include/seal3d_hip.h would corrupt the stack silently.
+    Static check: every `lib().s3d_*(...)` call in the binding passes exactly the declared number of arguments."""
+    import ast
+    import re
+    header = open(os.path.join(REPO, "include", "seal3d_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = {}
+    for m in re.finditer(r"\b(s3d_\w+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S):
+        args = m.group(2).strip()
+        declared[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    src = open(os.path.join(REPO, "seal-3d_amd", "s3d_hip", "__init__.py")).read()
+    starred_width = {"_live": 2}  # helpers that expand to several C arguments
+    seen = set()
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr.startswith("s3d_") \
+                and isinstance(node.func.value, ast.Call):
+            n = 0
+            for a in node.args:
+                if isinstance(a, ast.Starred):
+                    assert isinstance(a.value, ast.Call) and a.value.func.id in starred_width, ast.dump(a)
+                    n += starred_width[a.value.func.id]
+                else:
+                    n += 1
+            name = node.func.attr
+            assert name in declared, name
+            assert n == declared[name], f"{name}: call passes {n} arguments, header declares {declared[name]}"
+            seen.add(name)
+    assert len(seen) >= 40, len(seen)
