@@ -178,3 +178,31 @@ def test_tensorf_vm_kernels_match_cpu_oracle(hip):
         rp, rl = vo.factor_grads(x.numpy(), pn, ln, grad_rows)
         for a, b in zip(gp + gl, rp + rl):
             np.testing.assert_allclose(a.cpu().numpy().reshape(b.shape), b, rtol=1e-4, atol=2e-5 * float(np.abs(b).max()))
+
+
+def test_tensorf_vm_kernels_edge_resolutions(hip):
+    """resolution 2 along an axis, points on -1 / 0 / +1 and outside: kernels vs the CPU oracle, forward and backward"""
+    import itertools
+    import s3d_hip
+    from oracle import vm_features as vo
+    g = torch.Generator().manual_seed(13)
+    mat_ids, vec_ids = ((0, 1), (0, 2), (1, 2)), (2, 1, 0)
+    for res in ([2, 5, 3], [7, 2, 2], [4, 4, 9]):
+        ranks = [2, 1, 3]
+        planes = [torch.randn(1, ranks[i], res[mat_ids[i][1]], res[mat_ids[i][0]], generator=g) for i in range(3)]
+        lines = [torch.randn(1, ranks[i], res[vec_ids[i]], 1, generator=g) for i in range(3)]
+        corners = torch.tensor(list(itertools.product([-1.0, 0.0, 1.0, -1.0001, 1.0001, 3.0], repeat=3)))
+        x = torch.cat([corners, torch.rand(300, 3, generator=g) * 2 - 1]).contiguous()
+        N, rows = x.shape[0], sum(ranks)
+        pn, ln = [p[0].numpy() for p in planes], [l[0, :, :, 0].numpy() for l in lines]
+        pd, ld, xd = [p.cuda() for p in planes], [l.cuda() for l in lines], x.cuda()
+        out_s, out_c = torch.empty(N, device="cuda"), torch.empty(rows, N, device="cuda")
+        s3d_hip.VmBackend.features_forward(xd, pd, ld, res, True, out_s)
+        s3d_hip.VmBackend.features_forward(xd, pd, ld, res, False, out_c)
+        np.testing.assert_allclose(out_s.cpu().numpy(), vo.sigma_feat(x.numpy(), pn, ln), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(out_c.cpu().numpy(), vo.color_products(x.numpy(), pn, ln), rtol=1e-5, atol=1e-6)
+        gc = torch.randn(N, rows, generator=g)
+        gp, gl = s3d_hip.VmBackend.features_backward(xd, pd, ld, res, False, gc.cuda().contiguous())
+        rp, rl = vo.factor_grads(x.numpy(), pn, ln, gc.numpy().T)
+        for a, b in zip(gp + gl, rp + rl):
+            np.testing.assert_allclose(a.cpu().numpy().reshape(b.shape), b, rtol=1e-4, atol=2e-5 * float(np.abs(b).max()))

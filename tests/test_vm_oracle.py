@@ -50,3 +50,17 @@ def test_module_cpu_path_is_the_reference_sequence(oracle_wrappers):
     assert not net._use_native(x)  # CPU tensors: the grid_sample sequence, exactly as in the reference
     sigma, rgb = net(x, torch.nn.functional.normalize(torch.randn(x.shape[0], 3), dim=-1))
     assert sigma.shape == (3000,) and rgb.shape == (3000, 3) and torch.isfinite(rgb).all()
+
+
+def test_oracle_edge_resolutions_and_border_points():
+    """resolution 2 along an axis, points exactly on -1 / +1 / 0 and far outside: the restatement still equals grid_sample"""
+    import itertools
+    torch.manual_seed(11)
+    for res in ([2, 5, 3], [7, 2, 2], [4, 4, 9]):
+        net = trf.NeRFNetwork(resolution=res, sigma_rank=[2, 1, 3], color_rank=[1, 2, 2], bound=1, cuda_ray=True)
+        corners = torch.tensor(list(itertools.product([-1.0, 0.0, 1.0, -1.0001, 1.0001, 3.0], repeat=3)))
+        x = torch.cat([corners, torch.rand(200, 3) * 2 - 1])
+        s_ref = net._sigma_feat_torch(x, net.sigma_mat, net.sigma_vec).detach().numpy()
+        c_ref = net._color_prod_torch(x, net.color_mat, net.color_vec).detach().numpy()
+        np.testing.assert_allclose(vo.sigma_feat(x.numpy(), _np(net.sigma_mat), _np(net.sigma_vec)), s_ref, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(vo.color_products(x.numpy(), _np(net.color_mat), _np(net.color_vec)), c_ref, rtol=1e-5, atol=1e-7)
