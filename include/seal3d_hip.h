@@ -69,24 +69,21 @@ int s3d_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* b
 /* raymarching.h:13 void march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M,
  *                                        nears, fars, xyzs, dirs, deltas, rays, counter, noises)
  * Spans are packed in RAY ORDER (deterministic; one valid outcome of the reference's atomic
- * reservation, raymarching.cu:405-406).  counter[0] += total samples, counter[1] += N. */
+ * reservation, raymarching.cu:405-406).  counter[0] += total samples, counter[1] += N.
+ * path (kernel choice, same results): 0 = auto (wave-per-ray up to 16,384 rays), 1 = lane-per-ray, 2 = wave-per-ray. */
 size_t s3d_march_rays_train_workspace_size(uint32_t N, uint32_t max_steps);
-/* experiments/tests: 0 = auto (wave-per-ray up to 16,384 rays), 1 = lane-per-ray, 2 = wave-per-ray */
-void s3d_march_set_path(int path);
 int s3d_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                          float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                          uint32_t M, const float* nears, const float* fars, float* xyzs, float* dirs,
                          float* deltas, int32_t* rays, int32_t* counter, const float* noises,
-                         void* workspace, size_t workspace_bytes, s3d_stream_t stream);
-
-/* experiments/tests: 0 = wave-per-ray compositing (default), 1 = lane-per-ray (serial chain) */
-void s3d_composite_set_path(int path);
+                         void* workspace, size_t workspace_bytes, int path, s3d_stream_t stream);
 
 /* raymarching.h:14 void composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh,
- *                                                    weights_sum, depth, image) */
+ *                                                    weights_sum, depth, image)
+ * path (both directions): 0 = wave-per-ray compositing, 1 = lane-per-ray (serial chain, the reference's order). */
 int s3d_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
                                      const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
-                                     float* weights_sum, float* depth, float* image,
+                                     float* weights_sum, float* depth, float* image, int path,
                                      s3d_stream_t stream);
 
 /* raymarching.h:15 void composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas,
@@ -95,7 +92,7 @@ int s3d_composite_rays_train_backward(const float* grad_weights_sum, const float
                                       const float* sigmas, const float* rgbs, const float* deltas,
                                       const int32_t* rays, const float* weights_sum, const float* image,
                                       uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas,
-                                      float* grad_rgbs, s3d_stream_t stream);
+                                      float* grad_rgbs, int path, s3d_stream_t stream);
 
 /* raymarching.h:17 void march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
  *                       max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas, noises) */
@@ -152,7 +149,8 @@ int s3d_grid_corner_indices(const float* inputs, const int32_t* offsets, uint32_
  * grid.py:104-112, so it knows it; 0 = unknown).
  * workspace (s3d_grid_encode_backward_workspace_size bytes; 0 = configuration not supported) enables the
  * binned path used for B >= 8192: contributions are partitioned by table slice and summed in LDS as 64-bit
- * fixed point — deterministic, no global atomics.  Without it (NULL) direct atomics are used. */
+ * fixed point — deterministic, no global atomics.  Without it (NULL) direct atomics are used.
+ * path: 0 = auto, 1 = direct atomics, 2 = binned (an error when the workspace is missing). */
 size_t s3d_grid_encode_backward_workspace_size(uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                                uint32_t max_level_rows, int dtype);
 int s3d_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
@@ -160,9 +158,7 @@ int s3d_grid_encode_backward(const void* grad, const float* inputs, const void* 
                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                              const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                              uint32_t interp, int dtype, void* workspace, size_t workspace_bytes,
-                             float bound, const int32_t* n_valid, s3d_stream_t stream);
-/* experiments/tests: 0 = auto, 1 = direct atomics, 2 = binned (partition + LDS accumulate) */
-void s3d_grid_backward_set_path(int path);
+                             float bound, const int32_t* n_valid, int path, s3d_stream_t stream);
 
 /* gridencoder.h:15 void grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H,
  *                        gridtype, align_corners) — fp32 only (grid.py:162 disables autocast) */

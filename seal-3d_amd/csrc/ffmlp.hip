@@ -898,11 +898,12 @@ int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Floa
     const uint32_t nfrag = MB * (in_dim / 16) + NH * MB * KS + MB + NH * MB * KS + (grad_inputs ? IMB * KS : 0);
     size_t smem = (size_t)nfrag * 64 * sizeof(half8) + (size_t)4 * 2 * kTRows * kTRow * sizeof(_Float16);
     if (smem < 4 * kWgradPad * kWgradPad * sizeof(float)) smem = 4 * kWgradPad * kWgradPad * sizeof(float);  // epilogue planes
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev;
+    if (device_needs_setup(attr_devs, &dev)) {
         S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_backward_fused<W, NH, IMB, ACT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        device_setup_done(attr_devs, dev);
     }
     const uint32_t ntiles = B / 32;
     uint32_t nblk = div_up<uint32_t>(ntiles, 4);

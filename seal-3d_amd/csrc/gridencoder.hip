@@ -956,13 +956,14 @@ int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets
         constexpr uint32_t P = bin_chunk_points<T, D, C>();
         constexpr uint32_t K = 1u << D;
         constexpr uint32_t stage = 2 * kBinMaxSlices * 4;  // slice counters + reserved bucket offsets
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<uint64_t> attr_devs{0};
+        int dev;
+        if (device_needs_setup(attr_devs, &dev)) {
             S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_scatter<T, D, C>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage));
             S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_accumulate<T, D, C>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinAccBytes));
-            attr_set = true;
+            device_setup_done(attr_devs, dev);
         }
         uint32_t* hdr = reinterpret_cast<uint32_t*>(ws);
         uint32_t* tot = reinterpret_cast<uint32_t*>(ws + lay.tot);
@@ -1110,23 +1111,21 @@ S3D_EXPORT size_t s3d_grid_encode_backward_workspace_size(uint32_t B, uint32_t D
     return lay.ok ? lay.total : 0;
 }
 
-// process-wide override for experiments/tests: 0 = auto, 1 = direct atomics, 2 = binned (partition + LDS accumulate)
-static int g_backward_path = 0;
-S3D_EXPORT void s3d_grid_backward_set_path(int path) { g_backward_path = path; }
-
 S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
                                         const int32_t* offsets, void* grad_embeddings,
                                         uint32_t max_level_rows, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                         const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                                         uint32_t interp, int dtype, void* workspace, size_t workspace_bytes,
-                                        float bound, const int32_t* n_valid, s3d_stream_t stream) {
+                                        float bound, const int32_t* n_valid, int path, s3d_stream_t stream) {
+    // path: 0 = auto (binned from 8,192 points), 1 = direct global atomics, 2 = binned (partition + LDS accumulate)
     (void)embeddings;
+    S3D_REQUIRE(path >= 0 && path <= 2, "grid_encode_backward: path must be 0 (auto), 1 (atomics) or 2 (binned)");
     S3D_REQUIRE(bound >= 0.0f && !(bound != 0.0f && dy_dx), "grid_encode_backward: bound must be >= 0 and 0 with an input Jacobian");
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null pointer");
     S3D_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_backward: L must be in [1, %u]", kMaxLevels);
     S3D_REQUIRE(dtype == S3D_F32 || dtype == S3D_F16, "grid_encode_backward: dtype must be f32 or f16");
-    if (g_backward_path == 2) {
+    if (path == 2) {
         const BinLayout lay = bin_layout(B, D, C, L, max_level_rows, dtype == S3D_F16 ? 2u : 4u);
         S3D_REQUIRE(lay.ok && workspace && workspace_bytes >= lay.total,
                     "grid_encode_backward: the binned path needs max_level_rows and a workspace of "
@@ -1137,7 +1136,7 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
     unsigned char* ws = (unsigned char*)workspace;
-    const int fp = g_backward_path;
+    const int fp = path;
     if (dtype == S3D_F32) {
         const float* g = (const float*)grad; float* ge = (float*)grad_embeddings;
         const float* j = (const float*)dy_dx; float* gi = (float*)grad_inputs;

@@ -855,16 +855,14 @@ S3D_EXPORT size_t s3d_march_rays_train_workspace_size(uint32_t N, uint32_t max_s
     return lane_path;
 }
 
-// experiments/tests: 0 = auto (wave-per-ray up to 16,384 rays), 1 = lane-per-ray, 2 = wave-per-ray
-static int g_march_path = 0;
-S3D_EXPORT void s3d_march_set_path(int path) { g_march_path = path; }
-
 S3D_EXPORT int s3d_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                                     float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                     const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                                     int32_t* rays, int32_t* counter, const float* noises, void* workspace,
-                                    size_t workspace_bytes, s3d_stream_t stream) {
+                                    size_t workspace_bytes, int path, s3d_stream_t stream) {
+    // path: 0 = auto (wave-per-ray up to 16,384 rays), 1 = lane-per-ray kernels, 2 = wave-per-ray kernels
     if (N == 0) return S3D_OK;
+    S3D_REQUIRE(path >= 0 && path <= 2, "march_rays_train: path must be 0 (auto), 1 (lane per ray) or 2 (wave per ray)");
     S3D_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises, "march_rays_train: null pointer");
     S3D_REQUIRE(M == 0 || (xyzs && dirs && deltas), "march_rays_train: null output");
     S3D_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024, "march_rays_train: unsupported cascade/grid size C=%u H=%u", C, H);
@@ -873,7 +871,7 @@ S3D_EXPORT int s3d_march_rays_train(const float* rays_o, const float* rays_d, co
     const uint32_t nw = div_up<uint32_t>(N, 64);
     uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
     const bool wave_ok = workspace_bytes >= march_wave_ws(N, max_steps) && max_steps >= 1;
-    const bool use_wave = (g_march_path == 2 && wave_ok) || (g_march_path == 0 && wave_ok && N <= kWaveMarchMaxRays);
+    const bool use_wave = (path == 2 && wave_ok) || (path == 0 && wave_ok && N <= kWaveMarchMaxRays);
     if (use_wave) {
         if (dt_gamma == 0.0f)
             hipLaunchKernelGGL(k_march_count_wave<true>, dim3(N), dim3(64), 0, as_stream(stream), rays_o, rays_d, grid, bound,
@@ -893,17 +891,15 @@ S3D_EXPORT int s3d_march_rays_train(const float* rays_o, const float* rays_d, co
     return check_launch("march_rays_train");
 }
 
-// experiments/tests: 0/2 = wave-per-ray (default), 1 = lane-per-ray (serial chain, the oracle's summation order)
-static int g_composite_path = 0;
-S3D_EXPORT void s3d_composite_set_path(int path) { g_composite_path = path; }
-
 S3D_EXPORT int s3d_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
                                                 const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
-                                                float* weights_sum, float* depth, float* image, s3d_stream_t stream) {
+                                                float* weights_sum, float* depth, float* image, int path,
+                                                s3d_stream_t stream) {
+    // path: 0 = wave-per-ray (default), 1 = lane-per-ray (serial chain, the oracle's summation order)
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(rays && weights_sum && depth && image, "composite_rays_train_forward: null pointer");
     S3D_REQUIRE(M == 0 || (sigmas && rgbs && deltas), "composite_rays_train_forward: null input");
-    if (g_composite_path == 1)
+    if (path == 1)
         hipLaunchKernelGGL(k_composite_train_fwd, dim3(div_up<uint32_t>(N, 64)), dim3(64), 0, as_stream(stream), sigmas, rgbs,
                            deltas, rays, M, N, T_thresh, weights_sum, depth, image);
     else
@@ -916,11 +912,11 @@ S3D_EXPORT int s3d_composite_rays_train_backward(const float* grad_weights_sum, 
                                                  const float* sigmas, const float* rgbs, const float* deltas,
                                                  const int32_t* rays, const float* weights_sum, const float* image,
                                                  uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas,
-                                                 float* grad_rgbs, s3d_stream_t stream) {
+                                                 float* grad_rgbs, int path, s3d_stream_t stream) {
     if (N == 0 || M == 0) return S3D_OK;
     S3D_REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image &&
                     grad_sigmas && grad_rgbs, "composite_rays_train_backward: null pointer");
-    if (g_composite_path == 1)
+    if (path == 1)
         hipLaunchKernelGGL(k_composite_train_bwd, dim3(div_up<uint32_t>(N, 64)), dim3(64), 0, as_stream(stream),
                            grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh,
                            grad_sigmas, grad_rgbs);

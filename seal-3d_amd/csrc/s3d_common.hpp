@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <atomic>
 #include <stdio.h>
 #include <string.h>
 
@@ -46,6 +47,19 @@ inline int check_launch(const char* what) {
             return S3D_ERR_HIP;                                              \
         }                                                                    \
     } while (0)
+
+// One-time per-device kernel attribute setup (dynamic LDS opt-in): `flags` is a per-call-site static, one bit per device
+// ordinal, so a second GPU in the same process gets its own hipFuncSetAttribute calls and concurrent host threads at worst
+// repeat an idempotent call.
+inline bool device_needs_setup(std::atomic<uint64_t>& flags, int* dev_out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) { *dev_out = -1; return true; }
+    *dev_out = dev;
+    return ((flags.load(std::memory_order_acquire) >> dev) & 1ull) == 0;
+}
+inline void device_setup_done(std::atomic<uint64_t>& flags, int dev) {
+    if (dev >= 0) flags.fetch_or(1ull << dev, std::memory_order_release);
+}
 
 template <typename T>
 __host__ __device__ inline T div_up(T a, T b) { return (a + b - 1) / b; }

@@ -28,11 +28,11 @@ F32, F16 = 0, 1
 EXPORTS = [
     "s3d_last_error", "s3d_version",
     "s3d_near_far_from_aabb", "s3d_sph_from_ray", "s3d_morton3D", "s3d_morton3D_invert", "s3d_packbits",
-    "s3d_march_rays_train_workspace_size", "s3d_march_set_path", "s3d_march_rays_train",
-    "s3d_composite_set_path", "s3d_composite_rays_train_forward", "s3d_composite_rays_train_backward",
+    "s3d_march_rays_train_workspace_size", "s3d_march_rays_train",
+    "s3d_composite_rays_train_forward", "s3d_composite_rays_train_backward",
     "s3d_march_rays", "s3d_composite_rays", "s3d_compact_alive_workspace_size", "s3d_compact_alive",
     "s3d_grid_level_scales", "s3d_grid_encode_forward", "s3d_grid_corner_indices", "s3d_grid_encode_backward",
-    "s3d_grid_encode_backward_workspace_size", "s3d_grid_backward_set_path",
+    "s3d_grid_encode_backward_workspace_size",
     "s3d_grad_total_variation",
     "s3d_sh_encode_forward", "s3d_sh_encode_backward", "s3d_freq_encode_forward", "s3d_freq_encode_backward",
     "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
@@ -253,14 +253,16 @@ class RaymarchingBackend:
         _check(lib().s3d_march_rays_train(_p(rays_o), _p(rays_d), _p(grid), _f(bound), _f(dt_gamma), _u(max_steps),
                                           _u(N), _u(Cc), _u(H), _u(M), _p(nears), _p(fars), _p(xyzs), _p(dirs),
                                           _p(deltas), _p(rays), _p(counter), _p(noises), _p(ws),
-                                          C.c_size_t(ws.numel()), _stream()), "march_rays_train")
+                                          C.c_size_t(ws.numel()), C.c_int(RaymarchingBackend._march_path), _stream()),
+               "march_rays_train")
 
     @staticmethod
     def composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image):
         _need(sigmas, torch.float32, "sigmas")
         _check(lib().s3d_composite_rays_train_forward(_p(sigmas), _p(rgbs), _p(deltas), _p(rays), _u(M), _u(N),
                                                       _f(T_thresh), _p(weights_sum), _p(depth), _p(image),
-                                                      _stream()), "composite_rays_train_forward")
+                                                      C.c_int(RaymarchingBackend._composite_path), _stream()),
+               "composite_rays_train_forward")
 
     @staticmethod
     def composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image,
@@ -269,7 +271,8 @@ class RaymarchingBackend:
         _check(lib().s3d_composite_rays_train_backward(_p(grad_weights_sum), _p(grad_image), _p(sigmas), _p(rgbs),
                                                        _p(deltas), _p(rays), _p(weights_sum), _p(image), _u(M),
                                                        _u(N), _f(T_thresh), _p(grad_sigmas), _p(grad_rgbs),
-                                                       _stream()), "composite_rays_train_backward")
+                                                       C.c_int(RaymarchingBackend._composite_path), _stream()),
+               "composite_rays_train_backward")
 
     @staticmethod
     def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, Cc, H, grid,
@@ -287,15 +290,20 @@ class RaymarchingBackend:
                                         _p(sigmas), _p(rgbs), _p(deltas), _p(weights_sum), _p(depth), _p(image),
                                         _stream()), "composite_rays")
 
+    # kernel choice handed to the library with every call (`path` arguments of seal3d_hip.h); binding-side state for
+    # tests / experiments — the library itself keeps no process-wide switches
+    _march_path = 0
+    _composite_path = 0
+
     @staticmethod
     def set_composite_path(path):
         """0 = wave-per-ray compositing, 1 = lane-per-ray (tests / experiments)"""
-        lib().s3d_composite_set_path(C.c_int(int(path)))
+        RaymarchingBackend._composite_path = int(path)
 
     @staticmethod
     def set_march_path(path):
         """0 = auto, 1 = lane-per-ray kernels, 2 = wave-per-ray kernels (tests / experiments)"""
-        lib().s3d_march_set_path(C.c_int(int(path)))
+        RaymarchingBackend._march_path = int(path)
 
     # --- build extension (not in the reference's native surface) ---
     @staticmethod
@@ -362,13 +370,15 @@ class GridBackend:
                                               _p(grad_embeddings), _u(mlr), _u(B), _u(D),
                                               _u(Cc), _u(L), _f(S), _u(H), _p(dy_dx), _p(grad_inputs), _u(gridtype),
                                               C.c_int(int(align_corners)), _u(interp), C.c_int(_dt(grad)), _p(ws),
-                                              C.c_size_t(ws.numel()), _f(bound), _nv(n_valid), _stream()),
-               "grid_encode_backward")
+                                              C.c_size_t(ws.numel()), _f(bound), _nv(n_valid),
+                                              C.c_int(GridBackend._backward_path), _stream()), "grid_encode_backward")
+
+    _backward_path = 0  # `path` argument of s3d_grid_encode_backward (binding-side state for tests / experiments)
 
     @staticmethod
     def set_backward_path(path):
         """0 = auto, 1 = direct global atomics, 2 = binned: partition + LDS accumulate (tests / experiments)"""
-        lib().s3d_grid_backward_set_path(C.c_int(int(path)))
+        GridBackend._backward_path = int(path)
 
     @staticmethod
     def grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, Cc, L, S, H, gridtype, align_corners):
