@@ -19,6 +19,7 @@
 //    table slice and summed in LDS as 64-bit fixed point (see "binned backward" below): deterministic, no global atomics.
 #include "s3d_common.hpp"
 #include <math.h>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace s3d {
@@ -237,6 +238,122 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward(const float* __restr
                 store_feat<T, C>(jac + gd * C, g);
             }
         }
+    }
+}
+
+// ---- forward, lane pairs -------------------------------------------------------------------------------------
+// The two x-corners of a (y,z,..) corner pair are neighbouring rows: always on dense levels, and on hashed levels too —
+// the hash is `x ^ (y * p1) ^ (z * p2)`, so for fixed (y, z) the 32 rows of a 128-byte line (fp16, C = 2) are 32
+// consecutive x cells.  With one lane per point the two x-corners are fetched by two DIFFERENT gather instructions, each
+// of which presents 64 distinct lines to the L1 / L2 (the measured ceiling of this kernel is the request rate, not
+// bytes).  Here lanes 2k and 2k+1 share their two points P, Q: in the first half of a level's gathers both lanes address
+// point P (lane 2k its x0 corners, lane 2k+1 its x1 corners — the same lines, inside one instruction, which the
+// address unit merges), in the second half point Q; the halves a lane fetched for its partner travel by DPP
+// (quad_perm [1,0,3,2], no LDS), and each lane then reduces ITS point in the reference's corner order: same values bit
+// for bit, half the distinct lines per gather instruction.
+__device__ __forceinline__ uint32_t dpp_swap1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // lane ^ 1
+}
+__device__ __forceinline__ float dpp_swap1(float v) { return __uint_as_float(dpp_swap1(__float_as_uint(v))); }
+
+template <typename T, uint32_t D, uint32_t C>
+__global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __restrict__ inputs, const T* __restrict__ grid,
+                                                                 const int32_t* __restrict__ offsets, T* __restrict__ outputs,
+                                                                 uint32_t B, uint32_t L, LevelScales scales, uint32_t gridtype,
+                                                                 bool align_corners, uint32_t interp) {
+    static_assert((sizeof(T) * C) % 4 == 0, "feature vectors travel between lanes as 32-bit words");
+    constexpr uint32_t NW = sizeof(T) * C / 4;   // words per feature vector
+    constexpr uint32_t J = 1u << (D - 1);        // corner pairs per point
+    const uint32_t xcd = blockIdx.x % kXcds;
+    const uint32_t b = (blockIdx.x / kXcds) * kFwdBlock + threadIdx.x;
+    const uint32_t Bv = valid_rows(B, scales.n_valid);
+    // a wave leaves as a whole (its lanes exchange data below): Bv is a multiple of the block size or the last block is ragged
+    if ((b & ~63u) >= Bv || xcd >= L) return;
+    const bool valid = b < Bv;
+    const uint32_t side = threadIdx.x & 1u;  // which x-corner this lane fetches, for both points of the pair
+    float x[D];
+    bool oob = true;
+    if (valid) {
+        oob = load_point<D>(inputs, b, scales, x);
+        if (scales.live && scales.live[(size_t)b * scales.live_stride] == 0.0f) oob = true;
+    } else {
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) x[d] = 0.0f;
+    }
+    const bool oob_partner = dpp_swap1(oob ? 1u : 0u) != 0u;
+    const bool oobP = side ? oob_partner : oob, oobQ = side ? oob : oob_partner;
+
+    for (uint32_t level = xcd; level < L; level += kXcds) {
+        const uint32_t off = (uint32_t)offsets[level];
+        const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
+        const T* table = grid + (size_t)off * C;
+        const float scale = scales.v[level];
+        const uint32_t resolution = (uint32_t)ceilf(scale) + 1;
+        float pos[D], pos_deriv[D];
+        uint32_t pg[D], pg_partner[D];
+        locate<D>(x, scale, align_corners, interp, pos, pos_deriv, pg);
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) pg_partner[d] = dpp_swap1(pg[d]);
+
+        uint32_t g1[J][NW], g2[J][NW];  // this lane's x-side of point P / of point Q
+#pragma unroll
+        for (uint32_t half_ = 0; half_ < 2; half_++) {
+            const bool skip = half_ ? oobQ : oobP;
+            // target point of this half: P = the even lane's point
+            uint32_t tg[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) tg[d] = (side == half_) ? pg[d] : pg_partner[d];
+#pragma unroll
+            for (uint32_t j = 0; j < J; j++) {
+                uint32_t pgl[D];
+                pgl[0] = tg[0] + side;
+#pragma unroll
+                for (uint32_t d = 1; d < D; d++) pgl[d] = tg[d] + ((j >> (d - 1)) & 1u);
+                uint32_t w[NW];
+#pragma unroll
+                for (uint32_t k = 0; k < NW; k++) w[k] = 0u;
+                if (!skip) {
+                    const uint32_t row = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
+                    T f[C];
+                    load_feat<T, C>(table + (size_t)row * C, f);
+                    __builtin_memcpy(w, f, sizeof(T) * C);
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < NW; k++) { if (half_) g2[j][k] = w[k]; else g1[j][k] = w[k]; }
+            }
+        }
+        // lane 2k keeps g1 (P, x0) and needs lane 2k+1's g1 (P, x1); lane 2k+1 keeps g2 (Q, x1) and needs lane 2k's g2 (Q, x0)
+        T feat[1u << D][C];
+#pragma unroll
+        for (uint32_t j = 0; j < J; j++) {
+            uint32_t own[NW], got[NW];
+#pragma unroll
+            for (uint32_t k = 0; k < NW; k++) {
+                own[k] = side ? g2[j][k] : g1[j][k];
+                got[k] = dpp_swap1(side ? g1[j][k] : g2[j][k]);
+            }
+            uint32_t f0[NW], f1[NW];
+#pragma unroll
+            for (uint32_t k = 0; k < NW; k++) { f0[k] = side ? got[k] : own[k]; f1[k] = side ? own[k] : got[k]; }
+            __builtin_memcpy(feat[(j << 1)], f0, sizeof(T) * C);
+            __builtin_memcpy(feat[(j << 1) | 1u], f1, sizeof(T) * C);
+        }
+        if (!valid) continue;
+        T* out = outputs + ((size_t)level * B + b) * C;
+        T res[C];
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) res[c] = Acc<T>::zero();
+        if (!oob) {
+#pragma unroll
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1;
+#pragma unroll
+                for (uint32_t d = 0; d < D; d++) w *= ((idx >> d) & 1u) ? pos[d] : 1 - pos[d];
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) res[c] = Acc<T>::fma(w, feat[idx][c], res[c]);
+            }
+        }
+        store_feat<T, C>(out, res);
     }
 }
 
@@ -902,6 +1019,21 @@ int launch_forward(const float* inputs, const T* emb, const int32_t* offsets, T*
                    uint32_t L, const LevelScales& sc, T* dy_dx, uint32_t gridtype, bool ac, uint32_t interp,
                    hipStream_t st) {
     const dim3 grid(xcd_grid(B)), block(kFwdBlock);
+    static const int variant = getenv("S3D_GRID_FWD") ? atoi(getenv("S3D_GRID_FWD")) : 0;  // EXPERIMENT switch
+    if (variant == 1 && !dy_dx && (sizeof(T) * C) % 4 == 0) {
+        if constexpr (sizeof(T) == 4) {
+            switch (C) {
+                case 1: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 1>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp); return check_launch("grid_encode_forward");
+                default: break;
+            }
+        }
+        switch (C) {
+            case 2: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 2>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp); return check_launch("grid_encode_forward");
+            case 4: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 4>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp); return check_launch("grid_encode_forward");
+            case 8: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 8>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp); return check_launch("grid_encode_forward");
+            default: break;
+        }
+    }
     switch (C) {
         case 1: hipLaunchKernelGGL((k_grid_forward<T, D, 1>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, dy_dx, gridtype, ac, interp); break;
         case 2: hipLaunchKernelGGL((k_grid_forward<T, D, 2>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, dy_dx, gridtype, ac, interp); break;

@@ -21,6 +21,77 @@ def _box_vertices(lo, hi):
     return np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])], dtype=np.float64)
 
 
+def _min_area_rect(p2):
+    """minimum-area enclosing rectangle of 2-D points: (area, angle of the rectangle's first axis); one side of the optimum
+    is collinear with a hull edge, so the hull edges are the only candidates"""
+    from scipy.spatial import ConvexHull
+    hull = p2[ConvexHull(p2).vertices]
+    best = (np.inf, 0.0)
+    for a, b in zip(hull, np.roll(hull, -1, axis=0)):
+        e = b - a
+        n = np.linalg.norm(e)
+        if n < 1e-12:
+            continue
+        e = e / n
+        q = p2 @ np.stack([e, [-e[1], e[0]]], axis=1)
+        area = np.prod(q.max(0) - q.min(0))
+        if area < best[0]:
+            best = (area, np.arctan2(e[1], e[0]))
+    return best
+
+
+def oriented_box_vertices(points, snap=1e-9):
+    """8 corners of the minimum-volume oriented bounding box of `points` — what the reference gets from
+    `trimesh.PointCloud(raw).bounding_box_oriented` (seal_utils.py:587-588; trimesh.bounds.oriented_bounds: one face of
+    the optimum is parallel to a convex-hull facet, so every facet normal is tried with the minimum-area rectangle of the
+    projection).  Corner order is that of `_box_vertices` (index bits = side along the box's own x, y, z axes), so
+    `_BOX_FACES` triangulates it.  A box whose axes are the coordinate axes (within `snap`) is returned as the exact
+    min / max corners; coplanar or fewer than 4 points fall back to the axis-aligned box."""
+    pts = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+    lo, hi = pts.min(0), pts.max(0)
+    aabb = _box_vertices(lo, hi)
+    try:
+        from scipy.spatial import ConvexHull
+        hull = ConvexHull(pts)
+    except Exception:  # degenerate input (QhullError) or no scipy: the axis-aligned box
+        return aabb
+    hp = pts[hull.vertices]
+    best = None
+    seen = []
+    for eq in hull.equations:
+        n = eq[:3] / np.linalg.norm(eq[:3])
+        if n[np.argmax(np.abs(n))] < 0:
+            n = -n  # a normal and its opposite give the same box
+        if any(abs(abs(n @ m) - 1) < 1e-12 for m in seen):
+            continue
+        seen.append(n)
+        ref = np.eye(3)[np.argmin(np.abs(n))]
+        u = np.cross(n, ref)
+        u /= np.linalg.norm(u)
+        v = np.cross(n, u)
+        area, ang = _min_area_rect(hp @ np.stack([u, v], axis=1))
+        h = hp @ n
+        vol = area * (h.max() - h.min())
+        if best is None or vol < best[0] * (1 - 1e-12):
+            c, s_ = np.cos(ang), np.sin(ang)
+            best = (vol, np.stack([c * u + s_ * v, -s_ * u + c * v, n]))  # rows = box axes
+    vol_aabb = np.prod(hi - lo)
+    R = best[1]
+    # the box's axes up to order / sign are the coordinate axes -> the exact AABB (also when it is not smaller)
+    if best[0] >= vol_aabb * (1 - 1e-12) or np.all(np.abs(np.abs(R).max(1) - 1) < snap):
+        return aabb
+    # canonical axis order / sign: each box axis is assigned to the coordinate axis it is closest to, pointing along +
+    order = []
+    for k in range(3):
+        cand = [i for i in range(3) if i not in order]
+        order.append(max(cand, key=lambda i: abs(R[i, k])))
+    R = R[order]
+    R = R * np.where(R[np.arange(3), np.arange(3)] < 0, -1.0, 1.0)[:, None]
+    q = pts @ R.T
+    qlo, qhi = q.min(0), q.max(0)
+    return _box_vertices(qlo, qhi) @ R
+
+
 def moller_trumbore_any(ray_o, ray_d, tris, eps=1e-8):
     """does ray i hit any triangle?  (n_rays, 3), (n_rays, 3), (n_faces, 3, 3)  — seal_utils.py:630-665"""
     E1 = tris[:, 1] - tris[:, 0]
@@ -48,8 +119,8 @@ class SealBBoxMapper:
         T = np.array(seal_config["transform"], dtype=np.float64)
         scale = np.array(seal_config["scale"], dtype=np.float64)
         raw = np.array(seal_config["raw"], dtype=np.float64)
-        lo, hi = raw.min(0), raw.max(0)  # axis-aligned source box (`bounding_box_oriented` of 8 box corners)
-        from_v = _box_vertices(lo, hi)
+        # the reference's `get_trimesh_box(raw)`: the ORIENTED bounding box of the raw points (seal_utils.py:186-188, 587-588)
+        from_v = oriented_box_vertices(raw)
         center = from_v.mean(0)
         to_v = (from_v - center) * scale + center
         to_v = to_v @ T[:3, :3].T + T[:3, 3]
