@@ -142,7 +142,7 @@ def profile_traffic(op):
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_timed_region.md")))
     if not files:
         return None, None
-    kernels = ("k_grid_forward",) if op == "grid_encode_forward" else ("k_bin_count", "k_bin_scatter", "k_bin_accumulate")
+    kernels = ("k_grid_forward_pair",) if op == "grid_encode_forward" else ("k_bin_scatter4", "k_bin_accumulate4")
     total, seen = 0.0, set()
     for line in open(files[-1]):
         m = re.match(r"\| `([A-Za-z0-9_]+)", line)

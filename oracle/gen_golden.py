@@ -365,7 +365,7 @@ def gen_train():
     depths = _seeded((1, 512), 43, 1.0, 4.0)
     # -- Trainer.train_step executed unbound on a minimal `self`
     opt = types.SimpleNamespace(color_space="srgb", patch_size=1, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
-    me = types.SimpleNamespace(model=net, opt=opt, criterion=torch.nn.MSELoss(reduction="none"),
+    me = types.SimpleNamespace(model=net, opt=opt, _backbone=strainer.BackBoneTypes.NGP, criterion=torch.nn.MSELoss(reduction="none"),
                                criterion_depth=torch.nn.L1Loss(), error_map=None)
     net.train()
     torch.manual_seed(5)
@@ -465,7 +465,10 @@ def gen_seal():
         assert d2 is None and torch.equal(m, m2) and torch.equal(p, p2)
         out.update({f"{tag}_raw": np.array(cfg["raw"]), f"{tag}_points": pts.numpy(), f"{tag}_dirs": dirs.numpy(),
                     f"{tag}_out_points": p.numpy(), f"{tag}_out_dirs": d.numpy(), f"{tag}_mask": m.numpy(),
-                    f"{tag}_triangles": mb.map_triangles.numpy(), f"{tag}_map_bound": mb.map_data["map_bound"].numpy()})
+                    f"{tag}_triangles": mb.map_triangles.numpy(), f"{tag}_map_bound": mb.map_data["map_bound"].numpy(),
+                    f"{tag}_transform": np.array(cfg["transform"], dtype=np.float64), f"{tag}_scale": np.array(cfg["scale"], dtype=np.float64),
+                    f"{tag}_bound_type": np.array(cfg["boundType"]),
+                    f"{tag}_map_source": np.array(cfg.get("mapSource", []), dtype=np.float64)})
         print(f"seal[{tag}]: {int(m.sum())} of {pts.shape[0]} points mapped")
     np.savez_compressed(os.path.join(OUT, "seal_bbox.npz"), **out)
     print("seal: wrote seal_bbox.npz with", len(out), "arrays")

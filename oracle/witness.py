@@ -1,0 +1,148 @@
+"""Second witness for the two oracle files whose arithmetic no reference fixture pins (TEST INFRASTRUCTURE ONLY).
+
+`oracle/src/s3o_gridencoder.c` and `s3o_raymarching.c` restate the reference's CUDA kernels statement by statement; the
+reference ships no golden outputs for them and its CUDA cannot run here, so a transcription error in the restatement would
+go unnoticed (the HIP kernels were written from the same reading).  This module states the same MATHEMATICS a second time,
+independently of the C text: vectorised numpy, float64, from the definitions —
+
+  * multiresolution grid encoding (Instant-NGP §3; gridencoder.cu:87-242 only for the conventions that are not in the
+    paper: per-level scale `2^(l*S)*H - 1`, resolution `ceil(scale)+1`, the `+0.5` cell offset without align_corners,
+    dense index while the running stride fits the level's table, else `xor_d (x_d * prime_d)`, all in uint32, `% size`);
+  * emission-absorption compositing with early termination (NeRF eq. 3; raymarching.cu:501-693 for the termination rule
+    `T < T_thresh` checked after the sample is accumulated, and the depth convention `t = deltas[:,1]` cumulative),
+    and its analytic gradient obtained here by DIFFERENTIATING THE FORWARD NUMERICALLY-EXACTLY in float64 (closed form of
+    d/dsigma of the discrete sum), not by copying the kernel's recurrence;
+  * morton codes by bit interleaving, packbits by numpy.packbits(bitorder='little').
+
+Agreement of the C oracle (fp32) with this witness (float64) within fp32 rounding, and exact agreement of every integer
+(cell coordinates, table rows, morton codes, packed bits), is checked in tests/test_witness.py."""
+import numpy as np
+
+PRIMES = np.array([1, 2654435761, 805459861, 3674653429, 2097192037, 1434869437, 2165219737], dtype=np.uint64)
+
+
+def level_geometry(L, S, H):
+    """per-level (scale, resolution) in the reference's float32 arithmetic (the only place fp32 matters: it fixes cells)"""
+    lv = np.arange(L, dtype=np.float32)
+    # exp2f(level * S) rounded to float32, then `* H - 1` with ONE rounding (nvcc contracts a * b - c into an fma)
+    e = np.exp2((lv * np.float32(S)).astype(np.float64)).astype(np.float32)
+    scale = (e.astype(np.float64) * float(H) - 1.0).astype(np.float32)
+    return scale, np.ceil(scale).astype(np.uint32) + 1
+
+
+def grid_rows(cells, size, resolution, gridtype="hash", align_corners=False):
+    """table row of integer cell coordinates `cells` [..., D] (uint32 wrap-around arithmetic)"""
+    D = cells.shape[-1]
+    cells = cells.astype(np.uint64)
+    stride, index = np.uint64(1), np.zeros(cells.shape[:-1], dtype=np.uint64)
+    dense = True
+    for d in range(D):
+        if stride <= size:
+            index = (index + cells[..., d] * stride) & np.uint64(0xFFFFFFFF)
+            stride = (stride * np.uint64(resolution if align_corners else resolution + 1)) & np.uint64(0xFFFFFFFF)
+    if gridtype == "hash" and stride > size:
+        index = np.zeros(cells.shape[:-1], dtype=np.uint64)
+        for d in range(D):
+            index ^= (cells[..., d] * PRIMES[d]) & np.uint64(0xFFFFFFFF)
+        dense = False
+    return (index % np.uint64(size)).astype(np.int64), dense
+
+
+def grid_encode(x01, table, offsets, S, H, gridtype="hash", align_corners=False, smoothstep=False):
+    """x01 [B, D] in [0, 1] (float32 values), table [rows, C] -> features [B, L*C] float64, rows [B, L, 2^D], weights"""
+    B, D = x01.shape
+    L = len(offsets) - 1
+    C = table.shape[1]
+    scale, res = level_geometry(L, S, H)
+    out = np.zeros((B, L, C))
+    all_rows = np.zeros((B, L, 1 << D), dtype=np.int64)
+    all_w = np.zeros((B, L, 1 << D))
+    x32 = x01.astype(np.float32)
+    inside = ((x32 >= 0) & (x32 <= 1)).all(1)
+    for l in range(L):
+        size = int(offsets[l + 1] - offsets[l])
+        # the cell is decided in float32 exactly as the kernels do (fused multiply-add, then floor); the fractional
+        # position and everything after it is float64
+        pos32 = (x32.astype(np.float64) * float(scale[l]) + (0.0 if align_corners else 0.5)).astype(np.float32)
+        cell = np.floor(pos32).astype(np.int64)
+        frac = pos32.astype(np.float64) - cell
+        if smoothstep:
+            frac = frac * frac * (3.0 - 2.0 * frac)
+        for corner in range(1 << D):
+            bits = np.array([(corner >> d) & 1 for d in range(D)])
+            w = np.prod(np.where(bits, frac, 1.0 - frac), axis=1)
+            rows, _ = grid_rows((cell + bits).astype(np.uint64), size, int(res[l]), gridtype, align_corners)
+            all_rows[:, l, corner], all_w[:, l, corner] = rows, w
+            out[:, l] += w[:, None] * table[int(offsets[l]) + rows].astype(np.float64)
+    out[~inside] = 0
+    all_w[~inside] = 0
+    return out.reshape(B, L * C), all_rows, all_w
+
+
+def grid_encode_backward(grad, rows, weights, offsets, n_rows, C):
+    """grad [B, L*C] -> table gradient [n_rows, C] (float64 scatter-add of w * grad)"""
+    B, L, K = rows.shape
+    g = np.zeros((n_rows, C))
+    grad = grad.reshape(B, L, C).astype(np.float64)
+    for l in range(L):
+        for k in range(K):
+            np.add.at(g, int(offsets[l]) + rows[:, l, k], weights[:, l, k][:, None] * grad[:, l])
+    return g
+
+
+def composite_train(sigmas, rgbs, deltas, rays, T_thresh=1e-4):
+    """rays [N, 3] (index, offset, count) -> weights_sum [N], depth [N], image [N, 3]; per-sample weights and the kept count"""
+    N = rays.shape[0]
+    ws, depth, image = np.zeros(N), np.zeros(N), np.zeros((N, 3))
+    weights = np.zeros(sigmas.shape[0])
+    kept = np.zeros(N, dtype=np.int64)
+    for n in range(N):
+        idx, off, cnt = (int(v) for v in rays[n])
+        s = sigmas[off:off + cnt].astype(np.float64)
+        dl = deltas[off:off + cnt].astype(np.float64)
+        alpha = 1.0 - np.exp(-s * dl[:, 0])
+        T = np.concatenate([[1.0], np.cumprod(1.0 - alpha)])  # transmittance BEFORE each sample, then after the last
+        # a sample is accumulated, THEN the ray stops once the remaining transmittance is below the threshold
+        stop = np.nonzero(T[1:] < T_thresh)[0]
+        k = cnt if stop.size == 0 else int(stop[0]) + 1
+        w = alpha[:k] * T[:k]
+        weights[off:off + k] = w
+        kept[n] = k
+        t = np.cumsum(dl[:k, 1])
+        ws[idx], depth[idx] = w.sum(), (w * t).sum()
+        image[idx] = (w[:, None] * rgbs[off:off + k].astype(np.float64)).sum(0)
+    return ws, depth, image, weights, kept
+
+
+def composite_train_grads(g_ws, g_image, sigmas, rgbs, deltas, rays, T_thresh=1e-4):
+    """d(loss)/d sigma, d(loss)/d rgb with loss = <g_ws, weights_sum> + <g_image, image>, differentiating
+    w_i = (1 - exp(-s_i d_i)) * prod_{j<i} exp(-s_j d_j) directly:
+      dw_i/ds_i = d_i * (T_i - w_i) = d_i * T_{i+1},   dw_k/ds_i = -d_i * w_k  (k > i)"""
+    ws, depth, image, weights, kept = composite_train(sigmas, rgbs, deltas, rays, T_thresh)
+    gs, gc = np.zeros(sigmas.shape[0]), np.zeros((sigmas.shape[0], 3))
+    for n in range(rays.shape[0]):
+        idx, off, cnt = (int(v) for v in rays[n])
+        k = int(kept[n])
+        w = weights[off:off + k]
+        c = rgbs[off:off + k].astype(np.float64)
+        d = deltas[off:off + k, 0].astype(np.float64)
+        s = sigmas[off:off + k].astype(np.float64)
+        T_after = np.cumprod(np.exp(-s * d))
+        per = g_ws[idx] + c @ g_image[idx].astype(np.float64)      # d loss / d w_k
+        tail = np.concatenate([np.cumsum((w * per)[::-1])[::-1][1:], [0.0]])  # sum_{k>i} w_k * per_k
+        gs[off:off + k] = d * (T_after * per - tail)
+        gc[off:off + k] = w[:, None] * g_image[idx].astype(np.float64)
+    return gs, gc
+
+
+def morton3d(xyz):
+    """bit interleave x (bit 0), y (bit 1), z (bit 2) of 10-bit coordinates"""
+    code = np.zeros(xyz.shape[0], dtype=np.uint64)
+    for b in range(10):
+        for d in range(3):
+            code |= ((xyz[:, d].astype(np.uint64) >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + d)
+    return code.astype(np.int64)
+
+
+def packbits(grid, thresh):
+    return np.packbits((grid.reshape(-1) > thresh).astype(np.uint8), bitorder="little")

@@ -92,16 +92,30 @@ class SealTrainer(Trainer):
         for g in self.optimizer.param_groups:
             g["lr"] = lr
 
-    def pretrain_step(self, points, dirs, gt_sigma, gt_color, n_total=None):
-        """L1(sigma) + L1(colour) on one point shard; `n_total` = size of the un-sharded chunk (mean over all ranks)"""
-        self.model.train()
-        self.optimizer.zero_grad(set_to_none=False)
+    def pretrain_loss(self, points, dirs, gt_sigma, gt_color, n_total=None):
+        """SealNeRF/trainer.py:455-469: L1Loss(sigma) + L1Loss(colour) (means) of the student on one point chunk.  With a
+        shard of the chunk, `n_total` is the size of the whole chunk: the shard's sums are normalised by the global count."""
         n_total = n_total or points.shape[0]
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             sigma, color = self.model(points, dirs)
-            world = self.dist.world if self.dist is not None else 1
-            # sums over the shard, normalised by the global count; x world because the DP layer averages
-            loss = ((sigma.float() - gt_sigma).abs().sum() / n_total + (color.float() - gt_color).abs().sum() / (n_total * 3)) * world
+            return (sigma.float() - gt_sigma).abs().sum() / n_total + (color.float() - gt_color).abs().sum() / (n_total * 3)
+
+    def finetune_loss(self, rays_o, rays_d, gt_rgb, gt_depth=None, bg_color=1):
+        """nerf/utils.py:436-537 with Seal's depth target: mean over rays of (MSE over channels + L1Loss(depth)) = MSE + L1"""
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
+            out = self.model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False, **self.render_kwargs)
+            loss = F.mse_loss(out["image"], gt_rgb)
+            if gt_depth is not None:
+                loss = loss + self.depth_weight * F.l1_loss(torch.nan_to_num(out["depth"], nan=0.0).view(gt_depth.shape), gt_depth)
+        return loss, out
+
+    def pretrain_step(self, points, dirs, gt_sigma, gt_color, n_total=None):
+        """one optimizer step on one point shard; `n_total` = size of the un-sharded chunk (mean over all ranks)"""
+        self.model.train()
+        self.optimizer.zero_grad(set_to_none=False)
+        world = self.dist.world if self.dist is not None else 1
+        # x world because the DP layer averages the shards' gradients
+        loss = self.pretrain_loss(points, dirs, gt_sigma, gt_color, n_total) * world
         self.scaler.scale(loss).backward()
         if self.dist is not None:
             self.dist.allreduce_grads(self.scaler)
@@ -143,16 +157,10 @@ class SealTrainer(Trainer):
             gt_rgb, gt_depth = self.proxy_truth(rays_o, rays_d)
         model = self.model
         model.train()
-        if model.cuda_ray and self.global_step % self.update_extra_interval == 0:
-            with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
-                model.update_extra_state()
+        self._maybe_update_extra_state()  # (with data parallelism: occupancy state re-synchronised over the ranks)
         self.global_step += 1
         self.optimizer.zero_grad(set_to_none=False)
-        with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
-            out = model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False, **self.render_kwargs)
-            loss = F.mse_loss(out["image"], gt_rgb)
-            if gt_depth is not None:
-                loss = loss + self.depth_weight * F.l1_loss(torch.nan_to_num(out["depth"], nan=0.0).view(gt_depth.shape), gt_depth)
+        loss, _ = self.finetune_loss(rays_o, rays_d, gt_rgb, gt_depth, bg_color)
         self.scaler.scale(loss).backward()
         if self.dist is not None:
             self.dist.allreduce_grads(self.scaler)

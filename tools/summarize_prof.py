@@ -58,6 +58,8 @@ def pmc(kind, counter):
 fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
 sq = {c: pmc("sq", c) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY",
                                  "SQ_WAIT_ANY", "SQ_INSTS_VMEM_RD")}
+mf = {c: pmc("mfma", c) for c in ("SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE")}
+ca = {c: pmc("cache", c) for c in ("TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum")}
 with open(f"profiles/{tag}_timed_region.md", "w") as f:
     f.write(f"# rocprofv3 summary `{tag}` — `python bench.py --steps 32 --warmup 8 --no_cpu_baseline --no_render`\n\n")
     f.write(f"Timed region (last 32 steps, profiler attached): {window/1e6/32:.3f} ms/step wall, GPU busy {busy/1e6/32:.3f} ms/step "
@@ -72,4 +74,26 @@ with open(f"profiles/{tag}_timed_region.md", "w") as f:
         f.write(f"| `{n}` | {cnt[n]/32:.1f} | {v/cnt[n]/1e3:.1f} | {v/32/1e3:.1f} | {fetch.get(n, float('nan')):.0f} | "
                 f"{2*fetch.get(n, float('nan')):.0f} | {write.get(n, float('nan')):.0f} | "
                 f"{(valu/wv if wv and valu else float('nan')):.0f} | {(100*wa/wc if wc and wa else float('nan')):.0f} |\n")
+    # ---- matrix-core utilisation of the MLP kernels
+    # SQ_INSTS_VALU_MFMA_MOPS_F16: 512 flop per count (rocprofiler's MOPS unit); SQ_VALU_MFMA_BUSY_CYCLES: cycles the matrix
+    # pipes were busy, summed over the chip's 1,024 SIMDs (32 cycles per v_mfma_f32_32x32x16_f16, MI355X_MICROARCH.md);
+    # utilisation = busy cycles / (1,024 SIMDs x kernel duration x the shader clock read from GRBM_GUI_ACTIVE (8 XCDs)).
+    rows = [(n, v) for n, v in agg.most_common(40) if "ffmlp" in n and mf["SQ_VALU_MFMA_BUSY_CYCLES"].get(n)]
+    if rows:
+        f.write("\n## Matrix cores (ffmlp kernels)\n\n| kernel | us/launch | MFMA insts | TFLOP/s (MOPS x 512) | frac of 2.5 PF | MFMA busy cycles / SIMD | matrix-pipe utilisation |\n|---|---|---|---|---|---|---|\n")
+        for n, v in rows:
+            us = v / cnt[n] / 1e3
+            mops = mf["SQ_INSTS_VALU_MFMA_MOPS_F16"].get(n, float("nan"))
+            busy = mf["SQ_VALU_MFMA_BUSY_CYCLES"].get(n, float("nan"))
+            gui = mf["GRBM_GUI_ACTIVE"].get(n, float("nan")) / 8.0  # cycles the kernel was resident, per XCD
+            tf = mops * 512 / (us * 1e-6) / 1e12
+            f.write(f"| `{n[:70]}` | {us:.1f} | {mf['SQ_INSTS_MFMA'].get(n, float('nan')):.0f} | {tf:.1f} | {tf/2500:.3f} | {busy/1024:.0f} | {busy/1024/gui:.3f} |\n")
+    rows = [(n, v) for n, v in agg.most_common(40) if ("k_grid" in n or "k_bin" in n) and ca["TCC_REQ_sum"].get(n)]
+    if rows:
+        f.write("\n## L1 / L2 traffic of the grid kernels (per launch)\n\n| kernel | us/launch | TCP accesses | TCP->TCC read requests | TCC requests | TCC hit rate | TCC requests/us |\n|---|---|---|---|---|---|---|\n")
+        for n, v in rows:
+            us = v / cnt[n] / 1e3
+            hit, miss = ca["TCC_HIT_sum"].get(n, 0.0), ca["TCC_MISS_sum"].get(n, 0.0)
+            f.write(f"| `{n[:70]}` | {us:.1f} | {ca['TCP_TOTAL_CACHE_ACCESSES_sum'].get(n, float('nan')):.3g} | {ca['TCP_TCC_READ_REQ_sum'].get(n, float('nan')):.3g} | "
+                    f"{ca['TCC_REQ_sum'][n]:.3g} | {hit / max(hit + miss, 1):.3f} | {ca['TCC_REQ_sum'][n] / us:.3g} |\n")
 print(open(f"profiles/{tag}_timed_region.md").read())
