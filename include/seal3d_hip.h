@@ -255,6 +255,14 @@ int s3d_ngp_mid_forward(const uint16_t* h, const float* dirs, uint32_t B, float*
                         const int32_t* n_valid, s3d_stream_t stream);
 int s3d_ngp_mid_backward(const uint16_t* grad_color_in, const float* grad_sigma /* or NULL */, const uint16_t* h,
                          uint32_t B, uint16_t* grad_h, const int32_t* n_valid, s3d_stream_t stream);
+/* Two-encoder network (nerf/network.py:99-128 — the net Seal-3D trains): colour-net input [B,64] =
+ * [half(SH_4(d)) | h1..h15 | encoder_color(x) (32) | 0]; enc_color and grad_enc_color (may be NULL) are level-major
+ * [16][B][2] fp16, the grid kernels' own layout. */
+int s3d_ngp_mid2_forward(const uint16_t* h, const float* dirs, const uint16_t* enc_color, uint32_t B, float* sigma,
+                         uint16_t* color_in, const int32_t* n_valid, s3d_stream_t stream);
+int s3d_ngp_mid2_backward(const uint16_t* grad_color_in, const float* grad_sigma /* or NULL */, const uint16_t* h,
+                          uint32_t B, uint16_t* grad_h, uint16_t* grad_enc_color /* or NULL */, const int32_t* n_valid,
+                          s3d_stream_t stream);
 int s3d_ngp_rgb_forward(const uint16_t* out, uint32_t B, float* rgb, const int32_t* n_valid, s3d_stream_t stream);
 int s3d_ngp_rgb_backward(const float* grad_rgb, const float* rgb, uint32_t B, uint16_t* grad_out,
                          const int32_t* n_valid, s3d_stream_t stream);

@@ -55,6 +55,75 @@ __global__ void __launch_bounds__(256) k_ngp_mid_backward(const _Float16* __rest
     dst[0] = o0; dst[1] = o1;
 }
 
+// Two-encoder network of Seal-3D (nerf/network.py:99-128): the colour net's input is `cat[SH_4(d), geo_feat, encoder_color(x)]`
+// (16 + 15 + 32 = 63 columns, padded to 64 with a zero so that the MFMA MLP reads whole 16-byte pieces).  The second
+// encoder's features arrive — and their gradient leaves — in the grid kernels' own level-major layout [16][B][2]: no
+// permute copy on either side.
+//   mid2 forward : h [B,16], dirs [B,3] f32, enc [16][B][2] -> sigma [B] f32, cin [B,64] = [half(SH) | h1..h15 | enc | 0]
+//   mid2 backward: d_cin [B,64], d_sigma, h -> d_h [B,16] (as mid backward), d_enc [16][B][2] = d_cin[31..62]
+__global__ void __launch_bounds__(256) k_ngp_mid2_forward(const _Float16* __restrict__ h, const float* __restrict__ dirs,
+                                                          const _Float16* __restrict__ enc, uint32_t B, ShNorm K,
+                                                          float* __restrict__ sigma, _Float16* __restrict__ cin,
+                                                          const int32_t* __restrict__ n_valid) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= valid_rows(B, n_valid)) return;
+    const h8 h0 = *reinterpret_cast<const h8*>(h + (size_t)b * 16), h1 = *reinterpret_cast<const h8*>(h + (size_t)b * 16 + 8);
+    const float x = dirs[(size_t)b * 3], y = dirs[(size_t)b * 3 + 1], z = dirs[(size_t)b * 3 + 2];
+    float o[16], j0[1], j1[1], j2[1];
+    sh_eval<4, false>(x, y, z, K, o, j0, j1, j2);
+    sigma[b] = expf((float)h0[0]);
+    _Float16 row[64];
+#pragma unroll
+    for (int i = 0; i < 16; i++) row[i] = (_Float16)o[i];
+#pragma unroll
+    for (int i = 0; i < 7; i++) { row[16 + i] = h0[i + 1]; row[24 + i] = h1[i + 1]; }
+    row[23] = h1[0];
+#pragma unroll
+    for (int l = 0; l < 16; l++) {  // one 4-byte load per level, consecutive lanes on consecutive addresses
+        const __half2 e = *reinterpret_cast<const __half2*>(enc + ((size_t)l * B + b) * 2);
+        row[31 + 2 * l] = (_Float16)__low2half(e);
+        row[32 + 2 * l] = (_Float16)__high2half(e);
+    }
+    row[63] = (_Float16)0.0f;
+    h8* dst = reinterpret_cast<h8*>(cin + (size_t)b * 64);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        h8 v;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = row[8 * k + i];
+        dst[k] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ngp_mid2_backward(const _Float16* __restrict__ d_cin, const float* __restrict__ d_sigma,
+                                                           const _Float16* __restrict__ h, uint32_t B, _Float16* __restrict__ d_h,
+                                                           _Float16* __restrict__ d_enc, const int32_t* __restrict__ n_valid) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= valid_rows(B, n_valid)) return;
+    _Float16 row[48];  // columns 16..63
+    const h8* src = reinterpret_cast<const h8*>(d_cin + (size_t)b * 64 + 16);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const h8 v = src[k];
+#pragma unroll
+        for (int i = 0; i < 8; i++) row[8 * k + i] = v[i];
+    }
+    const float h0 = (float)h[(size_t)b * 16];
+    const float gs = d_sigma ? d_sigma[b] * expf(fminf(15.0f, fmaxf(-15.0f, h0))) : 0.0f;  // activation.py:13-16
+    h8 o0, o1;
+    o0[0] = (_Float16)gs;
+#pragma unroll
+    for (int i = 0; i < 7; i++) { o0[i + 1] = row[i]; o1[i + 1] = row[8 + i]; }
+    o1[0] = row[7];
+    h8* dst = reinterpret_cast<h8*>(d_h + (size_t)b * 16);
+    dst[0] = o0; dst[1] = o1;
+    if (d_enc) {
+#pragma unroll
+        for (int l = 0; l < 16; l++)
+            *reinterpret_cast<__half2*>(d_enc + ((size_t)l * B + b) * 2) = __halves2half2((__half)row[15 + 2 * l], (__half)row[16 + 2 * l]);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_ngp_rgb_forward(const _Float16* __restrict__ out, uint32_t B, float* __restrict__ rgb,
                                                          const int32_t* __restrict__ n_valid) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
@@ -168,6 +237,27 @@ S3D_EXPORT int s3d_ngp_mid_backward(const uint16_t* grad_color_in, const float* 
     hipLaunchKernelGGL(k_ngp_mid_backward, dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, as_stream(stream),
                        (const _Float16*)grad_color_in, grad_sigma, (const _Float16*)h, B, (_Float16*)grad_h, n_valid);
     return check_launch("ngp_mid_backward");
+}
+
+S3D_EXPORT int s3d_ngp_mid2_forward(const uint16_t* h, const float* dirs, const uint16_t* enc_color, uint32_t B, float* sigma,
+                                    uint16_t* color_in, const int32_t* n_valid, s3d_stream_t stream) {
+    if (B == 0) return S3D_OK;
+    S3D_REQUIRE(h && dirs && enc_color && sigma && color_in, "ngp_mid2_forward: null pointer");
+    ShNorm K;
+    host_sh_norm(4, K);
+    hipLaunchKernelGGL(k_ngp_mid2_forward, dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, as_stream(stream), (const _Float16*)h, dirs,
+                       (const _Float16*)enc_color, B, K, sigma, (_Float16*)color_in, n_valid);
+    return check_launch("ngp_mid2_forward");
+}
+
+S3D_EXPORT int s3d_ngp_mid2_backward(const uint16_t* grad_color_in, const float* grad_sigma, const uint16_t* h, uint32_t B,
+                                     uint16_t* grad_h, uint16_t* grad_enc_color, const int32_t* n_valid, s3d_stream_t stream) {
+    if (B == 0) return S3D_OK;
+    S3D_REQUIRE(grad_color_in && h && grad_h, "ngp_mid2_backward: null pointer");
+    hipLaunchKernelGGL(k_ngp_mid2_backward, dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, as_stream(stream),
+                       (const _Float16*)grad_color_in, grad_sigma, (const _Float16*)h, B, (_Float16*)grad_h,
+                       (_Float16*)grad_enc_color, n_valid);
+    return check_launch("ngp_mid2_backward");
 }
 
 S3D_EXPORT int s3d_ngp_rgb_forward(const uint16_t* out, uint32_t B, float* rgb, const int32_t* n_valid, s3d_stream_t stream) {

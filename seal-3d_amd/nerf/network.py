@@ -1,13 +1,51 @@
 """NGP network used by Seal-3D (nerf/network.py of the reference): TWO hash encoders (density and colour),
 degree-4 SH on the view direction, bias-free nn.Linear MLPs, `trunc_exp` density, sigmoid colour."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from torch.autograd import Function
 
+import s3d_hip
 from activation import trunc_exp
 from encoding import get_encoder
+from ffmlp.ffmlp import ffmlp_forward
 
+from .network_ff import _NgpRgb
 from .renderer import NeRFRenderer
+
+_head = s3d_hip.NgpHeadBackend
+
+
+class _SealMid(Function):
+    """sigma = trunc_exp(h[:, 0]);  colour-net input [B, 64] = [half(SH_4(d)) | h[:, 1:] | encoder_color(x) | 0] in one
+    kernel per direction (nerf/network.py:106-126 of the reference: slice, exp, SH, cat with type promotion, cast);
+    `enc_color` and its gradient stay in the grid kernels' level-major layout [16, B, 2]."""
+
+    @staticmethod
+    def forward(ctx, h, dirs, enc_color, n_valid=None):
+        B = h.shape[0]
+        sigma = torch.empty(B, dtype=torch.float32, device=h.device)
+        cin = torch.empty(B, 64, dtype=torch.float16, device=h.device)
+        _head.mid2_forward(h, dirs, enc_color, sigma, cin, n_valid)
+        ctx.save_for_backward(h)
+        ctx.n_valid = n_valid
+        ctx.enc_grad = enc_color.requires_grad
+        return sigma, cin
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_cin):
+        (h,) = ctx.saved_tensors
+        B = h.shape[0]
+        if g_cin is None:
+            g_cin = torch.zeros(B, 64, dtype=torch.float16, device=h.device)
+        g_h = torch.empty_like(h)
+        # (rows past n_valid are never read downstream: the grid backward takes the same n_valid)
+        g_enc = torch.empty(16, B, 2, dtype=torch.float16, device=h.device) if ctx.enc_grad else None
+        _head.mid2_backward(g_cin.to(torch.float16).contiguous(), None if g_sigma is None else g_sigma.float().contiguous(), h, g_h,
+                            g_enc, ctx.n_valid)
+        return g_h, None, g_enc, None
 
 
 def _mlp(dims):
@@ -39,6 +77,45 @@ class NeRFNetwork(NeRFRenderer):
                               + [hidden_dim_color] * (num_layers_color - 1) + [3])
         if self.bg_radius > 0:
             raise NotImplementedError("background model (bg_radius > 0) is outside the BASELINE configs")
+        self.register_buffer("_eye_hidden", torch.eye(hidden_dim), persistent=False)  # (not a checkpoint key)
+
+    # ---- MI355X path under `-O` (fp16 autocast): both MLPs run as fused MFMA kernels (csrc/ffmlp.hip) on weights PACKED
+    # from the nn.Linear parameters — the parameters, their names and shapes (checkpoint keys) are the reference's.
+    #   sigma net 32 -> 64 -> 16      = ffmlp [W0 | I_64 | W1]: relu(I relu(a)) == relu(a) exactly, so the inserted identity
+    #                                    layer changes neither values nor gradients (its own gradient is discarded)
+    #   colour net 63 -> 64 -> 64 -> 3 = ffmlp [W0 padded to 64 columns | W1 | W2 padded to 16 rows]
+    # Same arithmetic as the reference's autocast path: fp16 operands, fp32 accumulation, fp16 activations; SH values
+    # rounded to fp16 where the first Linear's input cast rounds them; sigmoid evaluated in fp32 and rounded to fp16.
+    fused_mlp = os.environ.get("S3D_FUSED_SEAL", "1") != "0"  # tests / A-B runs: False = nn.Linear op sequence
+
+    def _can_fuse(self, x):
+        return (self.fused_mlp and x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and x.shape[0] % 128 == 0
+                and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16
+                and self.num_layers == 2 and self.hidden_dim == 64 and self.geo_feat_dim == 15 and self.in_dim == 32
+                and self.num_layers_color == 3 and self.hidden_dim_color == 64 and self.in_dim_color == 32
+                and getattr(self.encoder_dir, "degree", None) == 4
+                and getattr(self.encoder, "level_dim", 0) == 2 and getattr(self.encoder_color, "level_dim", 0) == 2)
+
+    def _packed_weights(self):
+        s0, s1 = self.sigma_net[0].weight, self.sigma_net[1].weight
+        c0, c1, c2 = (l.weight for l in self.color_net)
+        ws = torch.cat([s0.reshape(-1), self._eye_hidden.reshape(-1), s1.reshape(-1)])
+        wc = torch.cat([F.pad(c0, (0, 1)).reshape(-1), c1.reshape(-1), F.pad(c2, (0, 0, 0, 13)).reshape(-1)])
+        return ws, wc
+
+    def _forward_fused(self, x, d, want_rgb=True):
+        nv = s3d_hip.active_row_limit(x.shape[0]) if self.training else None
+        live = None if (self.training or torch.is_grad_enabled()) else s3d_hip.active_live_rows(x.shape[0])
+        ws, wc = self._packed_weights()
+        infer = not self.training
+        e0 = self.encoder(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
+        h = ffmlp_forward(e0, ws, 32, 16, 64, 2, 0, 6, infer, e0.requires_grad, None, None, 1, None if infer else nv)
+        if not want_rgb:
+            return h
+        e1 = self.encoder_color(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
+        sigma, cin = _SealMid.apply(h.contiguous(), d.float().contiguous(), e1.contiguous(), nv)
+        out = ffmlp_forward(cin, wc, 64, 16, 64, 2, 0, 6, infer, cin.requires_grad, None, None, 0, None if infer else nv)
+        return sigma, _NgpRgb.apply(out.contiguous(), nv)
 
     def _sigma(self, x):
         h = _run_mlp(self.sigma_net, self.encoder(x, bound=self.bound))
@@ -49,10 +126,15 @@ class NeRFNetwork(NeRFRenderer):
         return torch.sigmoid(_run_mlp(self.color_net, h))
 
     def forward(self, x, d):
+        if self._can_fuse(x):
+            return self._forward_fused(x, d)
         sigma, geo_feat = self._sigma(x)
         return sigma, self._rgb(x, d, geo_feat)
 
     def density(self, x):
+        if self._can_fuse(x):
+            h = self._forward_fused(x, None, want_rgb=False)
+            return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
         sigma, geo_feat = self._sigma(x)
         return {"sigma": sigma, "geo_feat": geo_feat}
 

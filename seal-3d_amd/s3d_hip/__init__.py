@@ -39,7 +39,7 @@ EXPORTS = [
     "s3d_ffmlp_fused_backward_supported",
     "s3d_ffmlp_allocate_splitk", "s3d_ffmlp_free_splitk",
     "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_advance", "s3d_scaler_update",
-    "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
+    "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_mid2_forward", "s3d_ngp_mid2_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
     "s3d_bg_mse_forward", "s3d_bg_mse_backward",
     "s3d_seal_bbox_map", "s3d_vm_features_forward",
     "s3d_vm_backward_max_bins", "s3d_vm_backward_keys", "s3d_vm_features_backward",
@@ -523,6 +523,27 @@ class NgpHeadBackend:
             _need(grad_sigma, torch.float32, "grad_sigma")
         _check(lib().s3d_ngp_mid_backward(_p(grad_color_in), _p(grad_sigma), _p(h), _u(h.shape[0]), _p(grad_h), _nv(n_valid),
                                           _stream()), "ngp_mid_backward")
+
+    @staticmethod
+    def mid2_forward(h, dirs, enc_color, sigma, color_in, n_valid=None):
+        """two-encoder network: color_in [B,64] = [SH | geo | enc_color | 0]; enc_color level-major [16,B,2] fp16"""
+        _need(h, torch.float16, "h"); _need(dirs, torch.float32, "dirs"); _need(enc_color, torch.float16, "enc_color")
+        _need(sigma, torch.float32, "sigma"); _need(color_in, torch.float16, "color_in")
+        B = h.shape[0]
+        if tuple(enc_color.shape) != (16, B, 2) or tuple(color_in.shape) != (B, 64):
+            raise RuntimeError("mid2_forward: enc_color must be [16,B,2], color_in [B,64]")
+        _check(lib().s3d_ngp_mid2_forward(_p(h), _p(dirs), _p(enc_color), _u(B), _p(sigma), _p(color_in), _nv(n_valid), _stream()),
+               "ngp_mid2_forward")
+
+    @staticmethod
+    def mid2_backward(grad_color_in, grad_sigma, h, grad_h, grad_enc_color, n_valid=None):
+        _need(grad_color_in, torch.float16, "grad_color_in"); _need(grad_h, torch.float16, "grad_h")
+        if grad_sigma is not None:
+            _need(grad_sigma, torch.float32, "grad_sigma")
+        if grad_enc_color is not None:
+            _need(grad_enc_color, torch.float16, "grad_enc_color")
+        _check(lib().s3d_ngp_mid2_backward(_p(grad_color_in), _p(grad_sigma), _p(h), _u(h.shape[0]), _p(grad_h), _p(grad_enc_color),
+                                           _nv(n_valid), _stream()), "ngp_mid2_backward")
 
     @staticmethod
     def rgb_forward(out, rgb, n_valid=None):

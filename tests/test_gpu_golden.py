@@ -297,3 +297,27 @@ def test_seal_bbox_kernel_vs_reference_map_to_origin(hip, tag):
     assert torch.equal(m.cpu(), ref_m)
     _close(p, S[f"{tag}_out_points"], rtol=1e-5, atol=1e-6)
     _close(d, S[f"{tag}_out_dirs"], rtol=1e-5, atol=1e-6)
+
+
+def test_finetune_step_fp16_fused_path_vs_reference(hip, T, cpu_random):
+    """The same fine-tuning loss on the `-O` path (fp16 autocast: fp16 tables, MFMA MLPs, glue kernels, level-major hand-over)
+    against the reference's fp32 result: the integer outcome (marching, sample count) is identical, the loss and the image
+    agree to fp16 accuracy — the bound is the precision of the reference's own `-O` mode, not of this build."""
+    from sealnerf import SealTrainer
+    net = _golden_student()
+    net.mean_count = int(T["ts_mean_count"])
+    tr = SealTrainer(net, net, lr=1e-2, fp16=True, native_optim=False)
+    net.train()
+    ro, rd = torch.from_numpy(T["ts_rays_o"]).cuda(), torch.from_numpy(T["ts_rays_d"]).cuda()
+    torch.manual_seed(5)
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert net._can_fuse(torch.zeros(128, 3, device="cuda"))
+    loss, out = tr.finetune_loss(ro, rd, torch.from_numpy(T["ts_images"]).cuda(), torch.from_numpy(T["ts_depths"]).cuda(), bg_color=1)
+    assert np.array_equal(net.step_counter[0].cpu().numpy(), T["ts_counter"])
+    assert abs(float(loss.detach()) - float(T["ts_loss"])) <= 5e-3 * float(T["ts_loss"])
+    assert _relmax(out["image"], T["ts_pred"]) < 2e-2
+    net.zero_grad()
+    loss.backward()
+    for k, p in net.named_parameters():
+        ref = float(T[f"ts_grad_{k.replace('.', '_')}_norm"])
+        assert abs(float(p.grad.double().norm()) - ref) <= 3e-2 * ref, (k, float(p.grad.double().norm()), ref)

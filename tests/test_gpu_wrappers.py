@@ -195,3 +195,46 @@ def test_fused_background_mse_loss(hip):
         torch.testing.assert_close(loss, ref, rtol=1e-5, atol=1e-7)
         torch.testing.assert_close(gi, gi_ref, rtol=1e-5, atol=1e-7)
         torch.testing.assert_close(gw, gw_ref, rtol=1e-5, atol=1e-7)
+
+
+def test_seal_network_fused_mlps_match_linear_op_sequence(hip):
+    """nerf/network.py (the two-encoder net Seal-3D trains) under fp16 autocast: MFMA MLPs on weights packed from the nn.Linear
+    parameters + the mid2 / rgb glue kernels vs the reference's op sequence (two GridEncoder calls, cat, hipBLASLt Linears,
+    relu, trunc_exp, sigmoid) on the same parameters: same values up to fp16 rounding of identical intermediates, same
+    gradients for both hash tables and all five Linear weights; density() agrees with forward()."""
+    from nerf import network
+    torch.manual_seed(0)
+    net = network.NeRFNetwork(bound=1, cuda_ray=True, log2_hashmap_size=16).cuda()
+    net.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    net.encoder_color.embeddings.data.uniform_(-0.5, 0.5)
+    g = torch.Generator().manual_seed(1)
+    B = 128 * 9
+    x = (torch.rand(B, 3, generator=g) * 2 - 1).cuda()
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1).cuda()
+    w_s, w_c = torch.rand(B, generator=g).cuda(), torch.rand(B, 3, generator=g).cuda()
+    res = {}
+    net.train()
+    for fused in (True, False):
+        net.fused_mlp = fused
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            assert net._can_fuse(x) == fused
+            sigma, rgb = net(x, d)
+            dens = net.density(x)["sigma"]
+            loss = (sigma.float() * w_s).sum() * 1e-3 + (rgb.float() * w_c).sum()
+        loss.backward()
+        res[fused] = (sigma.float().detach().clone(), rgb.float().detach().clone(), dens.float().detach().clone(),
+                      [p.grad.clone() for p in net.parameters()])
+    net.fused_mlp = True
+    # sigma = exp(h0) amplifies the fp16 rounding of h0 (|h0| up to a few units, half ulp 2^-10 relative): 4e-3
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=4e-3, atol=1e-6)
+    torch.testing.assert_close(res[True][2], res[True][0], rtol=0, atol=0)          # density() == forward()'s sigma
+    torch.testing.assert_close(res[True][1], res[False][1], rtol=0, atol=2e-3)      # sigmoid output rounded to fp16 both ways
+    for (name, _), a, b in zip(net.named_parameters(), res[True][3], res[False][3]):
+        a, b = a.float(), b.float()
+        assert (a - b).norm() / b.norm().clamp(min=1e-12) < 5e-3, f"{name} gradient differs: {(a - b).norm() / b.norm()}"
+    # inference mode (no stored activations) gives the training-mode values
+    net.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        s2, c2 = net(x, d)
+    assert torch.equal(s2.float(), res[True][0]) and torch.equal(c2.float(), res[True][1])
