@@ -186,16 +186,19 @@ class GraphedTrainer(Trainer):
         self.s_loss = None
         self.s_counter = torch.zeros(2, dtype=torch.int32, device=dev)
 
+    def _static_loss(self):
+        """the step's loss on the static input buffers (subclasses: other criteria, e.g. Seal's depth term)"""
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
+            out = self.model.render(self.s_ro, self.s_rd, bg_color=1, perturb=True, force_all_rays=False,
+                                    defer_background=self.native_optim, **self.render_kwargs)
+            return render_loss(out, self.s_gt)
+
     def _body_fb(self):
         """zero grads -> render -> loss -> scaled backward"""
-        model = self.model
         # without data parallelism the gradients are simply replaced each step (no 49 MB zero fill + 147 MB accumulate);
         # with it they live in the flat all-reduce bucket and are cleared in place
         self.optimizer.zero_grad(set_to_none=self.dist is None)
-        with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
-            out = model.render(self.s_ro, self.s_rd, bg_color=1, perturb=True, force_all_rays=False,
-                               defer_background=self.native_optim, **self.render_kwargs)
-            loss = render_loss(out, self.s_gt)
+        loss = self._static_loss()
         self._backward(loss)
         return loss.detach()
 
@@ -277,6 +280,10 @@ class GraphedTrainer(Trainer):
             self.dist.sync_extra_state(model)
         return True
 
+    def _stage_inputs(self, rays_o, rays_d, gt_rgb):
+        torch._foreach_copy_([self.s_ro, self.s_rd, self.s_gt],
+                             [rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), gt_rgb.reshape(-1, 3)])  # one launch
+
     def _replay(self):
         self.graph.replay()
         if self.graph_opt is not None:
@@ -293,8 +300,7 @@ class GraphedTrainer(Trainer):
         if self.graph is None and model.mean_count <= 0:
             # no sample statistics yet (first 16 steps): eager step with the wrapper's host sync
             return self._eager_step(rays_o, rays_d, gt_rgb, bg_color)
-        torch._foreach_copy_([self.s_ro, self.s_rd, self.s_gt],
-                             [rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), gt_rgb.reshape(-1, 3)])  # one launch
+        self._stage_inputs(rays_o, rays_d, gt_rgb)
         if self.graph is None:
             self._capture()  # warm-up + capture run the step on the current batch
         self._replay()

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from nerf.trainer import Trainer
+from nerf.trainer import _CAPTURE_MODE, GraphedTrainer, Trainer
 
 
 def _euler_dirs(angle_step):
@@ -47,11 +47,11 @@ def freeze_module(module, freeze):
         p.requires_grad = not freeze
 
 
-class SealTrainer(Trainer):
-    def __init__(self, student, teacher, lr=1e-2, fp16=True, dist=None, depth_weight=1.0, **kw):
-        super().__init__(student, lr=lr, fp16=fp16, dist=dist, **kw)
+class SealSteps:
+    """the distillation steps, shared by the eager and the graph-replayed trainer (mixed into a nerf.trainer.Trainer)"""
+
+    def _init_seal(self, teacher, lr, depth_weight):
         self.teacher = teacher
-        self.teacher.eval()
         self.depth_weight = depth_weight
         self.pretraining_data = {}
         self.base_lr = lr
@@ -95,9 +95,16 @@ class SealTrainer(Trainer):
     def pretrain_loss(self, points, dirs, gt_sigma, gt_color, n_total=None):
         """SealNeRF/trainer.py:455-469: L1Loss(sigma) + L1Loss(colour) (means) of the student on one point chunk.  With a
         shard of the chunk, `n_total` is the size of the whole chunk: the shard's sums are normalised by the global count."""
-        n_total = n_total or points.shape[0]
+        n = points.shape[0]
+        n_total = n_total or n
+        if points.is_cuda and n % 128:
+            # the fused network path works on whole 128-row tiles: pad, and slice the padding off the outputs (its gradient
+            # is exactly zero, so the table gradients are those of the unpadded chunk)
+            pad = 128 - n % 128
+            points, dirs = F.pad(points, (0, 0, 0, pad)), F.pad(dirs, (0, 0, 0, pad), value=1.0)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             sigma, color = self.model(points, dirs)
+            sigma, color = sigma[:n], color[:n]
             return (sigma.float() - gt_sigma).abs().sum() / n_total + (color.float() - gt_color).abs().sum() / (n_total * 3)
 
     def finetune_loss(self, rays_o, rays_d, gt_rgb, gt_depth=None, bg_color=1):
@@ -116,12 +123,45 @@ class SealTrainer(Trainer):
         world = self.dist.world if self.dist is not None else 1
         # x world because the DP layer averages the shards' gradients
         loss = self.pretrain_loss(points, dirs, gt_sigma, gt_color, n_total) * world
-        self.scaler.scale(loss).backward()
+        self._backward(loss)
         if self.dist is not None:
             self.dist.allreduce_grads(self.scaler)
         self.scaler.step(self.optimizer)
         self.scaler.update()
         return loss.detach() / world
+
+    graph_pretraining = True  # GPU: every point chunk's step is replayed from its own HIP graph (static chunk tensors)
+
+    def _pretrain_chunk(self, key, sl, n_total):
+        """one optimizer step on the (static) chunk `sl` of the local points; GPU + native optimizer: captured once per chunk
+        and replayed — the chunk's tensors never move, the learning rate and the frozen MLPs are part of the capture"""
+        src = self.pretraining_data["local"]
+        args = (src["points"][sl], src["dirs"][sl], src["sigma"][sl], src["color"][sl])
+        on_gpu = args[0].is_cuda
+        if not (self.graph_pretraining and on_gpu and self.native_optim):
+            return self.pretrain_step(*args, n_total=n_total)
+        if not hasattr(self, "_pt_graphs"):
+            self._pt_graphs = {}
+        ent = self._pt_graphs.get(key)
+        if ent is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                warm = self.pretrain_step(*args, n_total=n_total).clone()  # warm-up: a real step, this call's step
+            torch.cuda.current_stream().wait_stream(side)
+            world = self.dist.world if self.dist is not None else 1
+            if world > 1:
+                return warm  # (collective between backward and step: the steps stay eager; no entry is cached)
+            g = torch.cuda.CUDAGraph()
+            pool = next(iter(self._pt_graphs.values()))[0].pool() if self._pt_graphs else None
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=_CAPTURE_MODE):
+                loss = self.pretrain_step(*args, n_total=n_total)
+            self._pt_graphs[key] = (g, loss)
+            return warm  # (the capture itself does not execute)
+        ent[0].replay()
+        from gridencoder.grid import bump_weights_epoch
+        bump_weights_epoch()
+        return ent[1]
 
     def pretrain_one_epoch(self):
         """one pass over the local points (trainer.py:363-452); every rank processes its shard of each chunk"""
@@ -133,10 +173,9 @@ class SealTrainer(Trainer):
         src = self.pretraining_data["local"]
         rank, world = (self.dist.rank, self.dist.world) if self.dist is not None else (0, 1)
         total, n = 0.0, 0
-        for a, b in zip(src["steps"][:-1], src["steps"][1:]):
+        for k, (a, b) in enumerate(zip(src["steps"][:-1], src["steps"][1:])):
             lo, hi = shard_slice(b - a, rank, world)
-            sl = slice(a + lo, a + hi)
-            total = total + self.pretrain_step(src["points"][sl], src["dirs"][sl], src["sigma"][sl], src["color"][sl], n_total=b - a)
+            total = total + self._pretrain_chunk(k, slice(a + lo, a + hi), b - a)
             n += 1
         self.freeze_mlp(False)
         self.set_lr(self.base_lr)
@@ -148,22 +187,70 @@ class SealTrainer(Trainer):
         """teacher-rendered RGB + depth targets for a ray batch (force_all_rays, no perturbation) — trainer.py:506-586"""
         if not self.teacher.density_bitfield_hacked:
             self.teacher.hack_bitfield()
-        with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
-            out = self.teacher.render(rays_o, rays_d, bg_color=None, perturb=False, force_all_rays=True, **self.render_kwargs)
+        # The reference never puts the teacher in eval mode: its render takes run_cuda's TRAINING branch (`force_all_rays` is
+        # an argument of that branch only) — one march over every ray, depth accumulated from the first sample like the
+        # student's (raymarching.cu:536-552), not from the camera like the inference loop's (:844-872).  The two depth
+        # conventions differ by the ray's entry distance, so targets from the inference loop would put a constant floor
+        # under the L1 depth term.
+        was_training = self.teacher.training
+        self.teacher.train()
+        try:
+            with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
+                out = self.teacher.render(rays_o, rays_d, bg_color=None, perturb=False, force_all_rays=True, **self.render_kwargs)
+        finally:
+            self.teacher.train(was_training)
         return torch.nan_to_num(out["image"], nan=0.0), torch.nan_to_num(out["depth"], nan=0.0)
 
-    def train_step(self, rays_o, rays_d, gt_rgb=None, gt_depth=None, bg_color=1):
-        if gt_rgb is None:
-            gt_rgb, gt_depth = self.proxy_truth(rays_o, rays_d)
-        model = self.model
-        model.train()
-        self._maybe_update_extra_state()  # (with data parallelism: occupancy state re-synchronised over the ranks)
-        self.global_step += 1
+    def _seal_step(self, rays_o, rays_d, gt_rgb, gt_depth, bg_color=1):
+        """zero grads -> fine-tuning loss -> backward -> (all-reduce) -> loss-scaled Adam, launched eagerly"""
         self.optimizer.zero_grad(set_to_none=False)
         loss, _ = self.finetune_loss(rays_o, rays_d, gt_rgb, gt_depth, bg_color)
-        self.scaler.scale(loss).backward()
+        self._backward(loss)
         if self.dist is not None:
             self.dist.allreduce_grads(self.scaler)
         self.scaler.step(self.optimizer)
         self.scaler.update()
         return loss.detach()
+
+
+class SealTrainer(SealSteps, Trainer):
+    def __init__(self, student, teacher, lr=1e-2, fp16=True, dist=None, depth_weight=1.0, **kw):
+        Trainer.__init__(self, student, lr=lr, fp16=fp16, dist=dist, **kw)
+        self._init_seal(teacher, lr, depth_weight)
+
+    def train_step(self, rays_o, rays_d, gt_rgb=None, gt_depth=None, bg_color=1):
+        if gt_rgb is None:
+            gt_rgb, gt_depth = self.proxy_truth(rays_o, rays_d)
+        self.model.train()
+        self._maybe_update_extra_state()  # (with data parallelism: occupancy state re-synchronised over the ranks)
+        self.global_step += 1
+        return self._seal_step(rays_o, rays_d, gt_rgb, gt_depth, bg_color)
+
+
+class GraphedSealTrainer(SealSteps, GraphedTrainer):
+    """Seal fine-tuning with the student's step replayed from a HIP graph (nerf.trainer.GraphedTrainer): the teacher's proxy
+    render produces the targets eagerly (its sample count is data dependent and it takes no gradient), they are copied into
+    static buffers, and zero-grad -> march -> two encoders -> MFMA MLPs -> composite -> MSE + L1(depth) -> backward ->
+    loss-scaled Adam is one replay.  Pretraining uses SealTrainer's per-chunk graphs."""
+
+    def __init__(self, student, teacher, num_rays, lr=1e-2, fp16=True, dist=None, depth_weight=1.0, **kw):
+        GraphedTrainer.__init__(self, student, num_rays, lr=lr, fp16=fp16, dist=dist, **kw)
+        self._init_seal(teacher, lr, depth_weight)
+        self.s_depth = torch.zeros(num_rays, device=self.s_ro.device)
+
+    def _static_loss(self):
+        loss, _ = self.finetune_loss(self.s_ro, self.s_rd, self.s_gt, self.s_depth, bg_color=1)
+        return loss
+
+    def _stage_inputs(self, rays_o, rays_d, gt_rgb):
+        gt_rgb, gt_depth = gt_rgb
+        torch._foreach_copy_([self.s_ro, self.s_rd, self.s_gt, self.s_depth],
+                             [rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), gt_rgb.reshape(-1, 3), gt_depth.reshape(-1)])
+
+    def _eager_step(self, rays_o, rays_d, gt, bg_color=1):
+        return self._seal_step(rays_o, rays_d, gt[0], gt[1], bg_color)
+
+    def train_step(self, rays_o, rays_d, gt_rgb=None, gt_depth=None, bg_color=1):
+        if gt_rgb is None:
+            gt_rgb, gt_depth = self.proxy_truth(rays_o, rays_d)
+        return GraphedTrainer.train_step(self, rays_o, rays_d, (gt_rgb, gt_depth), bg_color)
