@@ -47,7 +47,10 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_render", action="store_true")
     ap.add_argument("--infer_batch_scale", type=int, default=4, help="inference samples/ray/iteration multiplier (1 = reference heuristic)")
-    ap.add_argument("--cpu_steps", type=int, default=2)
+    ap.add_argument("--cpu_steps", type=int, default=5, help="timed CPU-baseline steps (median), after 2 warm-ups")
+    ap.add_argument("--cpu_rays", type=int, default=1024, help="rays per CPU-baseline step (bounded sample of the 4096-ray step)")
+    ap.add_argument("--no_seal", action="store_true", help="skip the configs[2] (Seal bbox distillation) section")
+    ap.add_argument("--seal_teacher_steps", type=int, default=256)
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -190,21 +193,138 @@ def cpu_baseline(args, num_rays):
         tr = Trainer(net, fp16=False, update_extra_interval=10 ** 9)
         tr.global_step = 1
         boxes = syn.lego_like_boxes(0)
-        batches, _ = make_batches(2, num_rays, 0, "cpu", ob.RaymarchingBackend, torch.from_numpy(bits), boxes)
-        ro, rd, gt = batches[0]
-        tr.train_step(ro, rd, gt)  # warm-up
-        t0 = time.perf_counter()
-        samples = 0
+        batches, poses = make_batches(2, num_rays, 0, "cpu", ob.RaymarchingBackend, torch.from_numpy(bits), boxes)
+        for i in range(2):  # 2 warm-ups, then the median of the timed steps
+            tr.train_step(*batches[i % 2])
+        rates, samples, t_all = [], 0, time.perf_counter()
         for i in range(args.cpu_steps):
-            ro, rd, gt = batches[i % 2]
-            tr.train_step(ro, rd, gt)
-            samples += int(net.step_counter[(net.local_step - 1) % 16, 0])
-        dt = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            tr.train_step(*batches[i % 2])
+            n = int(net.step_counter[(net.local_step - 1) % 16, 0])
+            rates.append(n / (time.perf_counter() - t0))
+            samples += n
+        dt = time.perf_counter() - t_all
+        # a 64x64 full render (4,096 rays) through the inference loop
+        r = syn.get_rays(poses[:1], syn.lego_intrinsics(64, 64), 64, 64)
+        net.device_compaction = False
+        t0 = time.perf_counter()
+        tr.render_image(r["rays_o"].contiguous(), r["rays_d"].contiguous())
+        render_s = time.perf_counter() - t0
     finally:
         rm._backend, gg._backend, sh._backend = saved
-    return {"value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{args.cpu_steps} training steps x {num_rays} rays ({samples} samples, {dt:.1f} s) of the same synthetic "
-                      "scene, fp32, two-encoder nn.Linear network (the reference's --ff-off path), native ops = CPU oracle + OpenMP"}
+    return {"value": float(np.median(rates)), "unit": "samples/s", "cores": cores, "kind": "port",
+            "render_64x64_rays_per_s": 4096 / render_s,
+            "sample": f"median of {args.cpu_steps} training steps (after 2 warm-ups) x {num_rays} rays ({samples} samples, {dt:.1f} s) of the "
+                      "same synthetic scene, fp32, two-encoder nn.Linear network (the reference's --ff-off path), native ops = CPU "
+                      f"oracle + OpenMP; one 64x64 inference render ({render_s:.1f} s)"}
+
+
+# ----------------------------------------------------------------------------- PSNR of the HIP render against the oracle render
+def psnr_vs_oracle(model, make_model, poses, scene_bits, boxes, dev, R):
+    """north_star: PSNR within 0.1 dB of the reference path.  One 64x64 frame of the TRAINED model rendered (a) by the HIP
+    path and (b) by the CPU oracle under the same Python (same weights, same precision: fp32 tables, fp16 MLPs, no autocast);
+    PSNR of each against the analytic target with the reference's PSNRMeter formula (nerf/utils.py:226-233)."""
+    from oracle import oracle_backend as ob
+    import raymarching.raymarching as rm
+    import gridencoder.grid as gg
+    import shencoder.sphere_harmonics as sh
+    import ffmlp.ffmlp as ff
+    from nerf import synthetic as syn
+    from nerf.trainer import psnr
+    ob.build()
+    r = syn.get_rays(poses[:1].to(dev), syn.lego_intrinsics(64, 64), 64, 64)
+    ro, rd = r["rays_o"].contiguous(), r["rays_d"].contiguous()
+    target = analytic_targets(ro[0].contiguous(), rd[0].contiguous(), scene_bits, boxes, R)
+    kw = dict(bg_color=1, perturb=False, max_steps=1024, T_thresh=1e-4, dt_gamma=0)
+    model.eval()
+    with torch.no_grad():
+        hip = model.render(ro, rd, **kw)["image"][0]
+    cpu_model = make_model()  # a fresh CPU instance with the trained state (no GPU-side optimizer attachments)
+    cpu_model.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    cpu_model.eval()
+    cpu_model.device_compaction = False
+    saved = (rm._backend, gg._backend, sh._backend, ff._backend)
+    rm._backend, gg._backend, sh._backend, ff._backend = ob.RaymarchingBackend, ob.GridBackend, ob.SHBackend, ob.FFMLPBackend
+    try:
+        ob.set_threads(os.cpu_count() or 1)
+        with torch.no_grad():
+            ora = cpu_model.render(ro.cpu(), rd.cpu(), **kw)["image"][0]
+    finally:
+        rm._backend, gg._backend, sh._backend, ff._backend = saved
+    model.train()
+    p_hip, p_ora = psnr(hip.cpu(), target.cpu()), psnr(ora, target.cpu())
+    return {"hip_vs_target_db": p_hip, "oracle_vs_target_db": p_ora, "delta_db": abs(p_hip - p_ora),
+            "hip_vs_oracle_render_db": psnr(hip.cpu(), ora), "within_0p1_db": bool(abs(p_hip - p_ora) <= 0.1),
+            "frame": "64x64, trained weights, fp32 tables + fp16 MLPs on both sides, PSNRMeter formula"}
+
+
+# ----------------------------------------------------------------------------- configs[2]: Seal bbox distillation
+SEAL_BBOX = {"type": "bbox", "raw": [[x, y, z] for x in (-0.2, 0.2) for y in (0.0, 0.3) for z in (-0.2, 0.2)],
+             "transform": [[1, 0, 0, 0.3], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], "scale": [1, 1, 1], "boundType": "both"}
+
+
+def seal_section(args, dev, batches, note=lambda m: None):
+    """BASELINE configs[2] on one GPU: teacher = the two-encoder NGP net trained on the synthetic scene,
+    student = its copy, bbox edit translate (0.3, 0, 0), pretraining_local_point_step 0.005 (~7.7e5 lattice points, one
+    chunk), then fine-tuning on 4,096-ray batches whose RGB + depth targets the teacher renders through the proxy."""
+    from nerf import network
+    from nerf.trainer import GraphedTrainer
+    from sealnerf import GraphedSealTrainer, SealBBoxMapper, make_student, make_teacher
+    kw = dict(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10)
+    torch.manual_seed(args.seed + 17)
+    teacher = make_teacher(network.NeRFNetwork, **kw).to(dev)
+    ttr = GraphedTrainer(teacher, args.num_rays, lr=1e-2, fp16=True, update_extra_interval=16)
+    for i in range(args.seal_teacher_steps):
+        ttr.train_step(*batches[i % len(batches)])
+    del ttr
+    student = make_student(network.NeRFNetwork, **kw).to(dev)
+    student.load_state_dict(teacher.state_dict())
+    student.mean_count, student.mean_density, student.iter_density = teacher.mean_count, teacher.mean_density, teacher.iter_density
+    mapper = SealBBoxMapper(SEAL_BBOX)
+    teacher.init_mapper(mapper)
+    student.init_mapper(mapper)
+    note("seal: teacher trained; pretraining")
+    tr = GraphedSealTrainer(student, teacher, args.num_rays, lr=1e-2, fp16=True, update_extra_interval=16)
+    n_local = tr.init_pretraining(batch_size=6144000, lr=0.05, local_point_step=0.005)
+
+    def sync_time(fn, reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            fn(i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    l0 = float(tr.pretrain_one_epoch())
+    tr.pretrain_one_epoch()  # (second epoch: the chunk's graph is captured)
+    ep = sync_time(lambda i: tr.pretrain_one_epoch(), 8)
+    l1 = float(tr.pretrain_one_epoch())
+    note(f"seal: pretraining timed ({ep * 1e3:.2f} ms/epoch); proxy truth")
+    proxy = sync_time(lambda i: tr.proxy_truth(batches[i % len(batches)][0], batches[i % len(batches)][1]), 8)
+    note("seal: fine-tuning")
+    for i in range(40):  # fine-tuning warm-up: 16 eager steps (sample statistics), capture, replays
+        tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
+    samples = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def ft(i):
+        tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
+        samples.add_(student.step_counter[(student.local_step - 1) % 16, 0].long())
+    step = sync_time(ft, 32)
+    targets = [tr.proxy_truth(b[0], b[1]) for b in batches[:8]]
+    samples2 = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def ft_cached(i):
+        tr.train_step(batches[i % 8][0], batches[i % 8][1], *targets[i % 8])
+        samples2.add_(student.step_counter[(student.local_step - 1) % 16, 0].long())
+    step_cached = sync_time(ft_cached, 32)
+    return {"workload": "configs[2]: lego_bbox-shaped edit (bbox translate 0.3), teacher+student two-encoder NGP, "
+                        "pretraining_local_point_step=0.005, 4096 rays/step, 1 GPU, HIP-graph replay",
+            "local_points": int(n_local),
+            "seal_pretrain_points_per_s": n_local / ep, "pretrain_ms_per_epoch": ep * 1e3, "pretrain_loss_first_last": [l0, l1],
+            "proxy_truth_mrays_per_s": args.num_rays / proxy / 1e6, "proxy_truth_ms_per_batch": proxy * 1e3,
+            "seal_train_samples_per_s": float(samples.item()) / 32 / step, "seal_train_ms_per_step": step * 1e3,
+            "seal_train_samples_per_s_cached_targets": float(samples2.item()) / 32 / step_cached,
+            "seal_train_ms_per_step_cached_targets": step_cached * 1e3,
+            "graph_captures": tr.n_captures}
 
 
 # ----------------------------------------------------------------------------- main
@@ -342,7 +462,26 @@ def main():
                           ("eager pass of 8 identical steps right after the graph-replayed timed region" if graphed
                            else "inside the timed region")}
 
-    extra = {}
+    # --- matrix-core roofline of the fused MLPs (north_star: MFMA utilisation on ffmlp against chip peak; SURVEY §8d: the
+    # bound is min(MFMA peak, arithmetic intensity x HBM peak)).  Both ffmlp nets of this config are 32-64-64-16 (3 matmuls,
+    # 7,168 MAC per sample forward); the training forward stores no activations (the fused backward re-computes them), so the
+    # forward moves 2*32 + 2*16 bytes per sample and the backward 2*32 (input) + 2*16 (output grad) + 2*32 (input grad).
+    # Backward flops: re-computed forward + data gradient + weight gradient = 3x the forward's.
+    mfma_peak = 2500.0  # TFLOP/s dense fp16, MI355X_MICROARCH.md
+    roofline_ffmlp = {}
+    for name, flops, byts in (("ffmlp_forward", 2 * 7168, 96), ("ffmlp_backward", 6 * 7168, 160)):
+        k = ksum.get(name)
+        if not k or not k["units"]:
+            continue
+        ach = k["units"] * flops / (k["avg_us"] * 1e-6) / 1e12
+        bound = min(mfma_peak, flops / byts * HBM_PEAK_GBS / 1e3)
+        roofline_ffmlp[name] = {"achieved": ach, "unit": "TFLOP/s", "bound": bound, "bound_is": "mfma" if bound == mfma_peak else "AI x hbm",
+                                "frac_of_bound": ach / bound, "frac_of_mfma_peak": ach / mfma_peak, "avg_us": k["avg_us"],
+                                "samples_per_launch": k["units"], "flop_per_sample": flops, "algorithmic_bytes_per_sample": byts}
+    if roofline_ffmlp:
+        roofline_ffmlp["counters"] = "profiles/r04_timed_region.md (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F16 per kernel)"
+
+    extra = {"roofline_ffmlp": roofline_ffmlp}
     if graphed:
         extra["graph_captures_in_timed_region"] = trainer.n_captures - captures0
     if ues_ms:
@@ -366,9 +505,20 @@ def main():
         extra.update({"render_infer_batch_scale": args.infer_batch_scale, "render_mrays_per_s": 0.64 / dtr,
                       "render_ms_per_frame": dtr * 1e3, "psnr_vs_analytic_scene": psnr(out["image"][0], gt)})
 
+    def note(msg):
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+    if world == 1 and not args.no_render:
+        note("psnr vs oracle render")
+        extra["psnr"] = psnr_vs_oracle(model, lambda: Net(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10),
+                                       poses, scene_bits, boxes, dev, R)
+    if world == 1 and not args.no_seal and args.net == "ff":
+        note("seal section")
+        del trainer
+        extra["seal"] = seal_section(args, dev, batches, note)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args, args.num_rays)
+        note("cpu baseline")
+        cpu = cpu_baseline(args, args.cpu_rays)
 
     line = {
         "metric": "train samples/s (NGP -O step on synthetic Lego 800x800 rays)", "value": samples / elapsed, "unit": "samples/s",

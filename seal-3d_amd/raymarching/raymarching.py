@@ -168,7 +168,9 @@ class _CompositeRaysTrain(Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, sigmas, rgbs, deltas, rays, T_thresh=1e-4):
-        sigmas, rgbs = sigmas.contiguous(), rgbs.contiguous()
+        # the kernels are fp32 (the reference reaches them through autocast's cast_inputs); outside autocast a half-precision
+        # network output (ffmlp always computes in fp16) is converted here instead of being misread
+        sigmas, rgbs = sigmas.float().contiguous(), rgbs.float().contiguous()
         M, N = sigmas.shape[0], rays.shape[0]
         weights_sum = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
         depth = torch.empty(N, dtype=sigmas.dtype, device=sigmas.device)
@@ -224,8 +226,8 @@ class _CompositeRays(Function):
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
                 T_thresh=1e-2):
-        _backend.composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas.contiguous(), rgbs.contiguous(),
-                                deltas.contiguous(), weights_sum, depth, image)
+        _backend.composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas.float().contiguous(),
+                                rgbs.float().contiguous(), deltas.float().contiguous(), weights_sum, depth, image)
         return tuple()
 
 

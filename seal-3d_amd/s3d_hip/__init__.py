@@ -258,7 +258,8 @@ class RaymarchingBackend:
 
     @staticmethod
     def composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image):
-        _need(sigmas, torch.float32, "sigmas")
+        for t, n in ((sigmas, "sigmas"), (rgbs, "rgbs"), (deltas, "deltas")):
+            _need(t, torch.float32, n)
         _check(lib().s3d_composite_rays_train_forward(_p(sigmas), _p(rgbs), _p(deltas), _p(rays), _u(M), _u(N),
                                                       _f(T_thresh), _p(weights_sum), _p(depth), _p(image),
                                                       C.c_int(RaymarchingBackend._composite_path), _stream()),
@@ -267,7 +268,9 @@ class RaymarchingBackend:
     @staticmethod
     def composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image,
                                       M, N, T_thresh, grad_sigmas, grad_rgbs):
-        _need(grad_image, torch.float32, "grad_image")
+        for t, n in ((grad_image, "grad_image"), (grad_weights_sum, "grad_weights_sum"), (sigmas, "sigmas"), (rgbs, "rgbs"),
+                     (deltas, "deltas")):
+            _need(t, torch.float32, n)
         _check(lib().s3d_composite_rays_train_backward(_p(grad_weights_sum), _p(grad_image), _p(sigmas), _p(rgbs),
                                                        _p(deltas), _p(rays), _p(weights_sum), _p(image), _u(M),
                                                        _u(N), _f(T_thresh), _p(grad_sigmas), _p(grad_rgbs),
@@ -285,7 +288,9 @@ class RaymarchingBackend:
     @staticmethod
     def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth,
                        image):
-        _need(image, torch.float32, "image")
+        for t, n in ((image, "image"), (sigmas, "sigmas"), (rgbs, "rgbs"), (deltas, "deltas"), (weights_sum, "weights_sum"),
+                     (depth, "depth"), (rays_t, "rays_t")):
+            _need(t, torch.float32, n)
         _check(lib().s3d_composite_rays(_u(n_alive), _u(n_step), _f(T_thresh), _p(rays_alive), _p(rays_t),
                                         _p(sigmas), _p(rgbs), _p(deltas), _p(weights_sum), _p(depth), _p(image),
                                         _stream()), "composite_rays")
