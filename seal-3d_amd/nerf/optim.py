@@ -49,7 +49,10 @@ class NativeAdam(torch.optim.Optimizer):
             sizes = [(p.numel() + 7) // 8 * 8 for p in adopted]  # 16-byte aligned views
             self.flat_half = torch.zeros(sum(sizes), dtype=torch.float16, device=adopted[0].device)
             off = 0
+            self.flat_half._s3d_param_cuts = []  # parameter boundaries (elements): where a chunked all-reduce may cut
             for p, n in zip(adopted, sizes):
+                self.flat_half._s3d_param_cuts.append(off)
+                p._s3d_flat_range = (off, off + p.numel())
                 p._s3d_grad = self.flat_half[off:off + p.numel()].view(p.shape)
                 p._s3d_grad_flat = self.flat_half
                 p._s3d_grad_touched = False
@@ -105,10 +108,28 @@ class NativeAdam(torch.optim.Optimizer):
                 st[k] = st[k].contiguous()
         if steps:
             self.step_count.fill_(max(steps))
+        for group in self.param_groups:  # a parameter the checkpoint did not know starts from zero moments
+            for p in group["params"]:
+                st = self.state[p]
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if k not in st:
+                        st[k] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+
+    def mark_all_touched(self):
+        """after a gradient all-reduce every stashed gradient is the replicas' mean on EVERY rank, also on a rank whose own
+        batch never reached that table: all ranks must take the same update"""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if getattr(p, "_s3d_grad", None) is not None:
+                    p._s3d_grad_touched = True
 
     @torch.no_grad()
-    def step(self, grad_scale=None, found_inf=None):
+    def step(self, grad_scale=None, found_inf=None, before_param=None):
+        """`before_param(p)`: called before parameter p is updated (data parallelism: wait for the all-reduce pieces that
+        cover p's gradient while later pieces are still on the wire)"""
         for group, p, g in self.grads():
+            if before_param is not None:
+                before_param(p)
             st = self.state[p]
             half = getattr(p, "_s3d_half", None)
             if half is not None and p._s3d_half_version != p._version:
@@ -161,15 +182,43 @@ class NativeGradScaler:
         self.growth_factor, self.backoff_factor = state["growth_factor"], state["backoff_factor"]
         self.growth_interval = state["growth_interval"]
 
-    def step(self, optimizer):
-        # (found_inf is cleared by update(); it starts at zero)
+    def _check(self, optimizer):
         flat = getattr(optimizer, "flat_half", None)
         if flat is not None:
             _backend.grads_nonfinite(flat, self._found_inf)  # every handed-over gradient in one pass
         for _, p, g in optimizer.grads():
             if flat is None or g is not getattr(p, "_s3d_grad", None):
                 _backend.grads_nonfinite(g, self._found_inf)
-        optimizer.step(grad_scale=self._scale if self.enabled else None, found_inf=self._found_inf)
+
+    def step(self, optimizer, dist=None):
+        """check + unscale + Adam.  With a data-parallel layer (`dist`, parallel/dist.py) whose gradients have NOT been reduced
+        yet, the reduction is pipelined with the update: the local gradients are checked first and the flag is reduced (MAX)
+        next to the gradient pieces — RCCL's averaging cannot overflow, so "any rank saw a non-finite gradient" is exactly
+        "the reduced gradient is non-finite" — and every parameter is updated as soon as the pieces covering its gradient
+        have arrived, while the later pieces are still on the wire."""
+        # (found_inf is cleared by update(); it starts at zero)
+        self._check(optimizer)
+        if dist is None or (dist.world == 1 and not dist.force_collective):
+            optimizer.step(grad_scale=self._scale if self.enabled else None, found_inf=self._found_inf)
+            return
+        pending = dist.allreduce_grads_async()
+        dist.allreduce_flag(self._found_inf)
+        if hasattr(optimizer, "mark_all_touched"):
+            optimizer.mark_all_touched()
+
+        def before_param(p):
+            rng = getattr(p, "_s3d_flat_range", None)
+            buf = getattr(p, "_s3d_grad_flat", None)
+            while pending:
+                h = pending[0]
+                # pieces were issued in buffer order: everything up to the end of p's range (or, for a parameter of the
+                # fp32 bucket, everything) must have arrived
+                if rng is not None and h[0] is buf and h[1] >= rng[1]:
+                    break
+                dist.finish_chunk(pending.pop(0))
+        optimizer.step(grad_scale=self._scale if self.enabled else None, found_inf=self._found_inf, before_param=before_param)
+        while pending:
+            dist.finish_chunk(pending.pop(0))
 
     def update(self):
         if self.enabled:

@@ -45,6 +45,10 @@ class NeRFRenderer(nn.Module):
         self.register_buffer("aabb_train", aabb)
         self.register_buffer("aabb_infer", aabb.clone())
 
+        # data parallelism (parallel/dist.py): when set, the density queries of the occupancy sweep are split over the ranks
+        # and all-gathered, and the sweep draws its random numbers from a generator every rank seeds alike, so
+        # all replicas end up with bit-identical grids without a broadcast
+        self.dist_shard = None
         self.cuda_ray = cuda_ray
         if cuda_ray:
             self.register_buffer("density_grid", torch.zeros([self.cascade, self.grid_size ** 3]))
@@ -199,15 +203,38 @@ class NeRFRenderer(nn.Module):
                             count[cas, indices] += mask
         self.density_grid[count == 0] = -1
 
+    def _sweep_generator(self):
+        """None (torch's global generator, the reference's stream) or, with a sharded sweep, a generator seeded from the
+        update count: the same coordinates and jitter on every rank"""
+        if self.dist_shard is None:
+            return None
+        g = torch.Generator(device=self.density_grid.device)
+        g.manual_seed(0x5EA13D + int(self.iter_density))
+        return g
+
+    def _rand(self, shape, gen, like):
+        if gen is None:
+            return torch.rand_like(like)
+        return torch.rand(shape, generator=gen, dtype=like.dtype, device=like.device)
+
+    def _randint(self, high, shape, gen, device, dtype=torch.int64):
+        if gen is None:
+            return torch.randint(0, high, shape, dtype=dtype, device=device)
+        return torch.randint(0, high, shape, generator=gen, dtype=dtype, device=device)
+
     @torch.no_grad()
-    def _query_cells(self, coords, cas):
+    def _query_cells(self, coords, cas, gen=None):
         """jittered cell centres of cascade `cas` -> density (nerf/renderer.py:468-482)"""
         bound, hgs = self._cascade_geometry(cas)
         xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
         cas_xyzs = xyzs * (bound - hgs)
-        cas_xyzs += (torch.rand_like(cas_xyzs) * 2 - 1) * hgs
-        sigmas = self.density(cas_xyzs)["sigma"].reshape(-1).detach()
-        return sigmas * self.density_scale
+        cas_xyzs += (self._rand(cas_xyzs.shape, gen, cas_xyzs) * 2 - 1) * hgs
+
+        def query(x):
+            return self.density(x)["sigma"].reshape(-1).detach() * self.density_scale
+        if self.dist_shard is not None:
+            return self.dist_shard.sharded_map(query, cas_xyzs)
+        return query(cas_xyzs)
 
     @torch.no_grad()
     def update_extra_state(self, decay=0.95, S=128):
@@ -215,6 +242,7 @@ class NeRFRenderer(nn.Module):
         if not self.cuda_ray:
             return
         dev = self.density_bitfield.device
+        gen = self._sweep_generator()
         tmp_grid = -torch.ones_like(self.density_grid)
         if self.iter_density < 16:  # full sweeps first
             axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
@@ -225,19 +253,19 @@ class NeRFRenderer(nn.Module):
                         coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
                         indices = raymarching.morton3D(coords).long()
                         for cas in range(self.cascade):
-                            tmp_grid[cas, indices] = self._query_cells(coords, cas).to(tmp_grid.dtype)
+                            tmp_grid[cas, indices] = self._query_cells(coords, cas, gen).to(tmp_grid.dtype)
         else:  # then H^3/4 uniform + H^3/4 occupied cells per cascade
             N = self.grid_size ** 3 // 4
             for cas in range(self.cascade):
-                coords = torch.randint(0, self.grid_size, (N, 3), device=dev)
+                coords = self._randint(self.grid_size, (N, 3), gen, dev)
                 indices = raymarching.morton3D(coords).long()
                 occ = torch.nonzero(self.density_grid[cas] > 0).squeeze(-1)
-                pick = torch.randint(0, occ.shape[0], [N], dtype=torch.long, device=dev)
+                pick = self._randint(occ.shape[0], [N], gen, dev, torch.long)
                 occ = occ[pick]
                 occ_coords = raymarching.morton3D_invert(occ)
                 indices = torch.cat([indices, occ], dim=0)
                 coords = torch.cat([coords, occ_coords], dim=0)
-                tmp_grid[cas, indices] = self._query_cells(coords, cas).to(tmp_grid.dtype)
+                tmp_grid[cas, indices] = self._query_cells(coords, cas, gen).to(tmp_grid.dtype)
 
         valid = (self.density_grid >= 0) & (tmp_grid >= 0)
         self.density_grid[valid] = torch.maximum(self.density_grid[valid] * decay, tmp_grid[valid])

@@ -123,11 +123,19 @@ class Trainer:
                                defer_background=self.native_optim, **self.render_kwargs)
             loss = render_loss(out, gt_rgb)
         self._backward(loss)
-        if self.dist is not None:
-            self.dist.allreduce_grads(self.scaler)
-        self.scaler.step(self.optimizer)
-        self.scaler.update()
+        self._reduce_and_step()
         return loss.detach()
+
+    def _reduce_and_step(self):
+        """gradient all-reduce (data parallelism) + optimizer step.  Native optimizer: the reduction is issued in pieces and
+        pipelined with the per-parameter updates (NativeGradScaler.step); torch optimizer: one reduction, then the step."""
+        if self.dist is not None and self.native_optim:
+            self.scaler.step(self.optimizer, dist=self.dist)
+        else:
+            if self.dist is not None:
+                self.dist.allreduce_grads(self.scaler)
+            self.scaler.step(self.optimizer)
+        self.scaler.update()
 
     def _backward(self, loss):
         if hasattr(self.scaler, "backward"):  # NativeGradScaler: the scale is passed as the root gradient
@@ -262,8 +270,8 @@ class GraphedTrainer(Trainer):
         if not (model.cuda_ray and self.global_step % self.update_extra_interval == 0):
             return False
         plain = type(model).update_extra_state is NeRFRenderer.update_extra_state
-        if not (self.graph_extra_state and plain and model.iter_density >= 16):
-            return super()._maybe_update_extra_state()
+        if not (self.graph_extra_state and plain and model.iter_density >= 16) or getattr(model, "dist_shard", None) is not None:
+            return super()._maybe_update_extra_state()  # (sharded over the ranks: density queries split + all-gather)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             if self.ues_graph is None and not self.ues_warm:
                 mean = model.partial_grid_update_device()  # first time: eager (lazy initialisations, allocator warm-up)

@@ -38,7 +38,8 @@ def shard_slice(n, rank, world):
 
 
 class RayShardedDP:
-    def __init__(self, group=None, average=True, force_collective=False):
+    def __init__(self, group=None, average=True, force_collective=False, shard_occupancy=True):
+        self.shard_occupancy = shard_occupancy  # False: every rank sweeps the whole grid, rank 0's result is broadcast
         self.group = group
         self.force_collective = force_collective  # issue the collectives even for world == 1 (single-GPU test of the path)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -74,6 +75,8 @@ class RayShardedDP:
             off += n
         if self.average and (self.world > 1 or self.force_collective):
             self._avg_supported()  # probe now (host read-back): never inside a graph capture
+        if self.shard_occupancy and hasattr(model, "dist_shard"):
+            model.dist_shard = self  # the occupancy sweep is split over the ranks (nerf/renderer.py)
         return self
 
     def _avg_supported(self):
@@ -91,9 +94,62 @@ class RayShardedDP:
             self._avg_ok = ok
         return self._avg_ok
 
-    def allreduce_grads(self, scaler=None):
+    # ---- chunked, asynchronous reduction ---------------------------------------------------------------------
+    # One collective over the whole flat fp16 buffer finishes before the first parameter can be updated.  `grad_chunks()`
+    # cuts the buffers at parameter boundaries into pieces of about `chunk_bytes`; `allreduce_grads_async()` issues one
+    # collective per piece (async_op: they queue on the process group's communication stream, in order) and returns the
+    # handles; the optimizer waits for piece k, updates the parameters inside it, and lets pieces k+1.. travel meanwhile
+    # (nerf/optim.py: NativeGradScaler.step(chunks=...)).  xGMI is point to point (7 links per GPU): pieces of a few MB
+    # keep every link busy while the update kernels of the previous piece run; tiny pieces would be latency bound.
+    chunk_bytes = 8 << 20
+
+    def grad_chunks(self):
+        """[(buffer, start, stop)] element ranges of the registered gradient buffers, cut at parameter boundaries"""
+        out = []
+        for h in self.half_grads:
+            cuts = sorted(set(getattr(h, "_s3d_param_cuts", [])) | {0, h.numel()})
+            per = max(self.chunk_bytes // h.element_size(), 1)
+            start = 0
+            for c in cuts[1:]:
+                if c - start >= per or c == h.numel():
+                    # a parameter larger than the piece size is itself split evenly (a hash table is 24 MB)
+                    n = max((c - start + per - 1) // per, 1)
+                    step = ((c - start + n - 1) // n + 7) // 8 * 8
+                    a = start
+                    while a < c:
+                        out.append((h, a, min(a + step, c)))
+                        a = min(a + step, c)
+                    start = c
+        if self.flat is not None and self.flat.numel():
+            out.append((self.flat, 0, self.flat.numel()))
+        return out
+
+    def allreduce_grads_async(self):
+        """issue the reduction piece by piece; returns [(buffer, start, stop, work)] in issue order (work.wait() before use)"""
         if self.world == 1 and not self.force_collective:
-            return
+            return []
+        self._rehome_grads()
+        fused_avg = self.average and self._avg_supported()
+        op = dist.ReduceOp.AVG if fused_avg else dist.ReduceOp.SUM
+        handles = []
+        for buf, a, b in self.grad_chunks():
+            view = buf[a:b]
+            work = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+            handles.append((buf, a, b, work, not fused_avg and self.average and self.world > 1))
+        return handles
+
+    def allreduce_flag(self, flag):
+        """a device-side overflow flag: non-zero on any rank -> non-zero everywhere"""
+        if self.world > 1 or self.force_collective:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+
+    def finish_chunk(self, handle):
+        buf, a, b, work, divide = handle
+        work.wait()
+        if divide:
+            buf[a:b].div_(self.world)
+
+    def _rehome_grads(self):
         # safety: a grad that autograd re-allocated is copied back into its bucket slot
         off = 0
         for p in self.params:
@@ -106,22 +162,66 @@ class RayShardedDP:
                 slot.copy_(p.grad.reshape(-1))
                 p.grad = slot.view_as(p)
             off += n
-        # RCCL averages inside the collective (pre-multiplied sum): no separate divide pass over the bucket, and the fp16
-        # bucket of loss-scaled gradients cannot overflow in the sum of `world` ranks.  gloo (CPU tests) has no AVG.
-        fused_avg = self.average and self._avg_supported()
-        op = dist.ReduceOp.AVG if fused_avg else dist.ReduceOp.SUM
-        for h in self.half_grads:
-            dist.all_reduce(h, op=op, group=self.group)
-            if self.average and not fused_avg and self.world > 1:
-                h.div_(self.world)
-        if self.flat.numel():
-            dist.all_reduce(self.flat, op=op, group=self.group)
-            if self.average and not fused_avg:
-                self.flat.div_(self.world)
+
+    # ---- sharded evaluation with an all-gather ------------------------------------------------------------------
+    def shard_rows(self, n):
+        """this rank's contiguous slice [lo, hi) of n rows"""
+        return shard_slice(n, self.rank, self.world)
+
+    def all_gather_rows(self, local, n):
+        """rows [lo, hi) computed by every rank -> the full [n, ...] tensor on every rank (ranks hold unequal slices:
+        padded to the largest, gathered, trimmed)"""
+        if self.world == 1 and not self.force_collective:
+            return local
+        per = (n + self.world - 1) // self.world
+        pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad, group=self.group)
+        out = []
+        for r, part in enumerate(parts):
+            lo, hi = shard_slice(n, r, self.world)
+            out.append(part[:hi - lo])
+        return torch.cat(out, dim=0)
+
+    def sharded_map(self, fn, *tensors):
+        """fn on this rank's row slice of every tensor, results all-gathered: the full result on every rank.  fn may return a
+        tensor or a tuple of tensors (first dimension = rows)."""
+        n = tensors[0].shape[0]
+        lo, hi = self.shard_rows(n)
+        res = fn(*[t[lo:hi] for t in tensors])
+        if isinstance(res, (tuple, list)):
+            return tuple(self.all_gather_rows(r.contiguous(), n) for r in res)
+        return self.all_gather_rows(res.contiguous(), n)
+
+    def sharded_render(self, model, rays_o, rays_d, **kwargs):
+        """SURVEY §8(e): a full frame (teacher proxy render, evaluation) split into contiguous pixel ranges, one per rank;
+        image + depth all-gathered (640,000 rays x 16 B = 10 MB per frame)"""
+        ro, rd = rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)
+
+        def part(o, d):
+            out = model.render(o.contiguous(), d.contiguous(), **kwargs)
+            return out["image"].reshape(-1, 3), out["depth"].reshape(-1)
+        image, depth = self.sharded_map(part, ro, rd)
+        return {"image": image.view(*rays_o.shape[:-1], 3), "depth": depth.view(*rays_o.shape[:-1])}
+
+    def allreduce_grads(self, scaler=None):
+        """blocking form: every piece issued, then awaited (RCCL averages inside the collective — pre-multiplied sum: no
+        divide pass, and the fp16 bucket of loss-scaled gradients cannot overflow in the sum of `world` ranks; gloo (CPU
+        tests) has no AVG: SUM + divide)"""
+        for h in self.allreduce_grads_async():
+            self.finish_chunk(h)
 
     def sync_extra_state(self, model):
-        """keep the occupancy state identical on all replicas after `update_extra_state` (RNG differs per rank)"""
+        """keep the occupancy state identical on all replicas after `update_extra_state` (RNG differs per rank).  A model
+        whose occupancy sweep is itself sharded (`model.dist_shard`, nerf/renderer.py) already holds identical grids: only
+        the sample budget is agreed on."""
         if (self.world == 1 and not self.force_collective) or not getattr(model, "cuda_ray", False):
+            return
+        if getattr(model, "dist_shard", None) is self:
+            t = torch.tensor([float(model.mean_count)], device=model.density_grid.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            model.mean_count = int(t[0].item())
             return
         dist.broadcast(model.density_grid, src=0, group=self.group)
         dist.broadcast(model.density_bitfield, src=0, group=self.group)

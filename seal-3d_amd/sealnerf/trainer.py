@@ -124,10 +124,7 @@ class SealSteps:
         # x world because the DP layer averages the shards' gradients
         loss = self.pretrain_loss(points, dirs, gt_sigma, gt_color, n_total) * world
         self._backward(loss)
-        if self.dist is not None:
-            self.dist.allreduce_grads(self.scaler)
-        self.scaler.step(self.optimizer)
-        self.scaler.update()
+        self._reduce_and_step()
         return loss.detach() / world
 
     graph_pretraining = True  # GPU: every point chunk's step is replayed from its own HIP graph (static chunk tensors)
@@ -206,10 +203,7 @@ class SealSteps:
         self.optimizer.zero_grad(set_to_none=False)
         loss, _ = self.finetune_loss(rays_o, rays_d, gt_rgb, gt_depth, bg_color)
         self._backward(loss)
-        if self.dist is not None:
-            self.dist.allreduce_grads(self.scaler)
-        self.scaler.step(self.optimizer)
-        self.scaler.update()
+        self._reduce_and_step()
         return loss.detach()
 
 

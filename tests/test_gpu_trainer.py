@@ -80,6 +80,42 @@ def test_data_parallel_split_graph_step_single_rank(hip):
             dist.destroy_process_group()
 
 
+def test_pipelined_gradient_reduction_single_rank_equals_plain_step(hip):
+    """eager trainer, native optimizer, data-parallel layer on a 1-rank RCCL group: the gradient buffer is reduced in pieces
+    (cut at parameter boundaries), the overflow flag travels beside them, every parameter is updated once its pieces have
+    arrived — with one rank the result must equal the step without the layer bit for bit"""
+    import torch.distributed as dist
+    from nerf.trainer import Trainer
+    from parallel import RayShardedDP
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29578")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    try:
+        res = {}
+        for with_dp in (False, True):
+            model, batches = _setup()
+            model.iter_density = 100
+            dp = RayShardedDP(force_collective=True, shard_occupancy=False) if with_dp else None
+            if dp is not None:
+                dp.chunk_bytes = 1 << 20  # many pieces: the 24 MB table is cut ~24 times
+            tr = Trainer(model, lr=1e-2, fp16=True, update_extra_interval=10 ** 9, dist=dp)
+            tr.global_step = 1
+            torch.manual_seed(7)
+            for i in range(4):
+                tr.train_step(*batches[i % len(batches)])
+            if dp is not None:
+                pieces = dp.grad_chunks()
+                assert len(pieces) > 10 and pieces[0][1] == 0 and pieces[-1][2] == pieces[-1][0].numel()
+            res[with_dp] = [p.detach().clone() for p in model.parameters()]
+        for a, b in zip(res[False], res[True]):
+            assert torch.equal(a, b)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_checkpoint_resume_under_graph_replay(hip, tmp_path):
     """train (graph replay, native optimizer) -> full checkpoint in the reference's format -> load into a fresh graphed
     trainer: renders are bit-identical (the fp16 table copies followed the loaded fp32 weights) and training resumes"""

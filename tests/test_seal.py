@@ -135,7 +135,17 @@ tr = SealTrainer(student, teacher, lr=1e-2, fp16=False, dist=dp)
 tr.init_pretraining(batch_size=100000, lr=0.05, local_point_step=0.05)
 loss = float(tr.pretrain_one_epoch())
 emb = student.encoder.embeddings.detach().clone()
-torch.save({"loss": loss, "emb": emb}, os.environ["S3D_OUT"] + f".{world}.{rank}")
+# two fine-tuning steps, each rank on its own rays, occupancy update before every step (ADVICE r1: the replicas' grids
+# must stay identical — the sweep is sharded over the ranks with a common random stream)
+from nerf import synthetic as syn
+tr.update_extra_interval = 1
+torch.manual_seed(50 + rank)
+r = syn.get_rays(syn.orbit_poses(2, seed=1)[rank:rank + 1], syn.lego_intrinsics(24, 24), 24, 24)
+for _ in range(2):
+    ft = float(tr.train_step(r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous()))
+torch.save({"loss": loss, "emb": emb, "bits": student.density_bitfield.clone(), "grid": student.density_grid.clone(),
+            "emb_ft": student.encoder.embeddings.detach().clone(), "mean_count": student.mean_count, "ft": ft},
+           os.environ["S3D_OUT"] + f".{world}.{rank}")
 if world > 1: dist.destroy_process_group()
 '''
 
@@ -156,3 +166,7 @@ def test_sharded_pretraining_equals_single_process(tmp_path):
     assert torch.equal(b0["emb"], b1["emb"]), "replicas diverged"
     torch.testing.assert_close(b0["emb"], a["emb"], rtol=1e-4, atol=1e-6)   # Adam step of summed shard grads == full grad
     assert abs(b0["loss"] + b1["loss"] - a["loss"]) < 1e-4 * max(1.0, abs(a["loss"]))
+    # after fine-tuning steps with occupancy updates: identical occupancy state and identical weights on both replicas
+    assert torch.equal(b0["bits"], b1["bits"]) and torch.equal(b0["grid"], b1["grid"]) and b0["mean_count"] == b1["mean_count"]
+    assert torch.equal(b0["emb_ft"], b1["emb_ft"]) and not torch.equal(b0["emb_ft"], b0["emb"])
+    assert int(b0["bits"].sum()) > 0 and b0["ft"] == b0["ft"]
