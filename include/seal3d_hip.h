@@ -100,20 +100,26 @@ int s3d_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive,
                    const float* rays_o, const float* rays_d, float bound, float dt_gamma,
                    uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* nears,
                    const float* fars, float* xyzs, float* dirs, float* deltas, const float* noises,
-                   s3d_stream_t stream);
+                   const int32_t* n_alive_dev, int32_t* n_rows_out, s3d_stream_t stream);
 
 /* raymarching.h:18 void composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs,
  *                       deltas, weights_sum, depth, image) — in place */
 int s3d_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive,
                        float* rays_t, const float* sigmas, const float* rgbs, const float* deltas,
-                       float* weights_sum, float* depth, float* image, s3d_stream_t stream);
+                       float* weights_sum, float* depth, float* image, const int32_t* n_alive_dev,
+                       s3d_stream_t stream);
 
 /* Device-side replacement of the host compaction `rays_alive = rays_alive[rays_alive >= 0]`
  * (nerf/renderer.py:363): stable wave-ballot compaction of `in[0..n)` into `out`, count -> *n_out
  * (device int32).  Not in the reference's native surface; used by the build's renderer. */
 size_t s3d_compact_alive_workspace_size(uint32_t n);
 int s3d_compact_alive(const int32_t* in, uint32_t n, int32_t* out, int32_t* n_out, void* workspace,
-                      size_t workspace_bytes, s3d_stream_t stream);
+                      size_t workspace_bytes, const int32_t* n_in_dev, s3d_stream_t stream);
+/* Sync-free inference loop (nerf/renderer.py:341-367 reads the alive count back on every iteration): `n_alive` / `n` of
+ * march_rays, composite_rays and compact_alive are then the host's UPPER BOUND (launch geometry, buffer extents) and the
+ * optional `n_alive_dev` / `n_in_dev` point at the real count in device memory (NULL: the bound is the count); entries
+ * past it are ignored.  march_rays leaves `*n_alive_dev * n_step` in `n_rows_out` (optional) — the `n_valid` of the
+ * network kernels that follow.  The host refreshes its bound every few iterations only. */
 
 /* ------------------------------------------------------------------ gridencoder
  * gridencoder/src/gridencoder.h:12-15 (bindings.cpp:6-8).
@@ -196,7 +202,7 @@ int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t 
 int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                         uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                         uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,
-                        int input_layout, s3d_stream_t stream);
+                        int input_layout, const int32_t* n_valid, s3d_stream_t stream);
 /* ffmlp.h:11; grad_weights fp16 [same layout as weights]: every element is written (accumulate_grad_weights = 0,
  * the reference zero-fills it first, ffmlp.py:72) or added to (accumulate_grad_weights = 1).
  * workspace: fp32 accumulation of the weight gradient (s3d_ffmlp_backward_workspace_size).

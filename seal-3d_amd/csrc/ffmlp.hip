@@ -968,10 +968,10 @@ S3D_EXPORT int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights
 S3D_EXPORT int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                                    uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                                    uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,
-                                   int input_layout, s3d_stream_t stream) {
+                                   int input_layout, const int32_t* n_valid, s3d_stream_t stream) {
     (void)inference_buffer;
     return s3d_ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                             output_activation, nullptr, outputs, input_layout, nullptr, stream);
+                             output_activation, nullptr, outputs, input_layout, n_valid, stream);
 }
 
 S3D_EXPORT size_t s3d_ffmlp_backward_workspace_size(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,

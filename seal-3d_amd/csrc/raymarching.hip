@@ -708,15 +708,25 @@ __global__ void __launch_bounds__(256) k_composite_train_bwd_wave(const float* _
 }
 
 // ---------------------------------------------------------------- inference
+__device__ __forceinline__ uint32_t alive_count(uint32_t bound, const int32_t* __restrict__ dev) {
+    if (!dev) return bound;
+    const int32_t v = *dev;
+    return v <= 0 ? 0u : ((uint32_t)v < bound ? (uint32_t)v : bound);
+}
+
 __global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive,
                                                    const float* __restrict__ rays_t, const float* __restrict__ rays_o,
                                                    const float* __restrict__ rays_d, float bound, float dt_gamma,
                                                    uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
                                                    const float* __restrict__ fars, float* __restrict__ xyzs,
                                                    float* __restrict__ dirs, float* __restrict__ deltas,
-                                                   const float* __restrict__ noises) {
+                                                   const float* __restrict__ noises, const int32_t* __restrict__ n_alive_dev,
+                                                   int32_t* __restrict__ n_rows_out) {
+    // sync-free loop: `n_alive` is the host's upper bound (launch geometry, buffer extents), *n_alive_dev the real count
     const uint32_t n = blockIdx.x * 64 + threadIdx.x;
-    if (n >= n_alive) return;
+    const uint32_t live = alive_count(n_alive, n_alive_dev);
+    if (n == 0 && n_rows_out) *n_rows_out = (int32_t)(live * n_step);
+    if (n >= live) return;
     const uint32_t index = (uint32_t)rays_alive[n];
     const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
     const Ray r = load_ray(rays_o, rays_d, index);
@@ -745,9 +755,10 @@ __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_
                                                        int32_t* __restrict__ rays_alive, float* __restrict__ rays_t,
                                                        const float* __restrict__ sigmas, const float* __restrict__ rgbs,
                                                        const float* __restrict__ deltas, float* __restrict__ weights_sum,
-                                                       float* __restrict__ depth, float* __restrict__ image) {
+                                                       float* __restrict__ depth, float* __restrict__ image,
+                                                       const int32_t* __restrict__ n_alive_dev) {
     const uint32_t n = blockIdx.x * 64 + threadIdx.x;
-    if (n >= n_alive) return;
+    if (n >= alive_count(n_alive, n_alive_dev)) return;
     const uint32_t index = (uint32_t)rays_alive[n];
     const float* s = sigmas + (size_t)n * n_step;
     const float* c = rgbs + (size_t)n * n_step * 3;
@@ -779,20 +790,22 @@ __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_
 // ---------------------------------------------------------------- alive-ray compaction
 // Stable compaction with wave ballots.  Pass 1: per-wave survivor counts.  Pass 2: wave base by
 // strided reduction over earlier waves (same scheme as march_write), rank by mbcnt of the ballot.
-__global__ void __launch_bounds__(64) k_compact_count(const int32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ ws) {
+__global__ void __launch_bounds__(64) k_compact_count(const int32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ ws,
+                                                      const int32_t* __restrict__ n_in_dev) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    const bool keep = i < n && in[i] >= 0;
+    const bool keep = i < alive_count(n, n_in_dev) && in[i] >= 0;
     const unsigned long long m = __ballot(keep);
     if (threadIdx.x == 0) ws[blockIdx.x] = (uint32_t)__popcll(m);
 }
 __global__ void __launch_bounds__(64) k_compact_write(const int32_t* __restrict__ in, uint32_t n, int32_t* __restrict__ out,
-                                                      int32_t* __restrict__ n_out, const uint32_t* __restrict__ ws) {
+                                                      int32_t* __restrict__ n_out, const uint32_t* __restrict__ ws,
+                                                      const int32_t* __restrict__ n_in_dev) {
     uint32_t part = 0;
     for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 64) part += ws[i];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
-    const int32_t v = i < n ? in[i] : -1;
+    const int32_t v = i < alive_count(n, n_in_dev) ? in[i] : -1;  // (n_in_dev may alias n_out: read before the store below)
     const bool keep = v >= 0;
     const unsigned long long m = __ballot(keep);
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -930,7 +943,8 @@ S3D_EXPORT int s3d_composite_rays_train_backward(const float* grad_weights_sum, 
 S3D_EXPORT int s3d_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
                               const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
                               uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
-                              float* xyzs, float* dirs, float* deltas, const float* noises, s3d_stream_t stream) {
+                              float* xyzs, float* dirs, float* deltas, const float* noises, const int32_t* n_alive_dev,
+                              int32_t* n_rows_out, s3d_stream_t stream) {
     (void)nears;
     if (n_alive == 0 || n_step == 0) return S3D_OK;
     S3D_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && noises,
@@ -938,18 +952,19 @@ S3D_EXPORT int s3d_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* 
     S3D_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024, "march_rays: unsupported cascade/grid size C=%u H=%u", C, H);
     hipLaunchKernelGGL(k_march_rays, dim3(div_up<uint32_t>(n_alive, 64)), dim3(64), 0, as_stream(stream), n_alive, n_step,
                        rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs,
-                       deltas, noises);
+                       deltas, noises, n_alive_dev, n_rows_out);
     return check_launch("march_rays");
 }
 
 S3D_EXPORT int s3d_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive,
                                   float* rays_t, const float* sigmas, const float* rgbs, const float* deltas,
-                                  float* weights_sum, float* depth, float* image, s3d_stream_t stream) {
+                                  float* weights_sum, float* depth, float* image, const int32_t* n_alive_dev,
+                                  s3d_stream_t stream) {
     if (n_alive == 0) return S3D_OK;
     S3D_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image,
                 "composite_rays: null pointer");
     hipLaunchKernelGGL(k_composite_rays, dim3(div_up<uint32_t>(n_alive, 64)), dim3(64), 0, as_stream(stream), n_alive,
-                       n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+                       n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, n_alive_dev);
     return check_launch("composite_rays");
 }
 
@@ -958,14 +973,14 @@ S3D_EXPORT size_t s3d_compact_alive_workspace_size(uint32_t n) {
 }
 
 S3D_EXPORT int s3d_compact_alive(const int32_t* in, uint32_t n, int32_t* out, int32_t* n_out, void* workspace,
-                                 size_t workspace_bytes, s3d_stream_t stream) {
+                                 size_t workspace_bytes, const int32_t* n_in_dev, s3d_stream_t stream) {
     S3D_REQUIRE(n_out, "compact_alive: null n_out");
     if (n == 0) { S3D_HIP(hipMemsetAsync(n_out, 0, sizeof(int32_t), as_stream(stream))); return S3D_OK; }
     S3D_REQUIRE(in && out && workspace && workspace_bytes >= s3d_compact_alive_workspace_size(n),
                 "compact_alive: bad arguments");
     const uint32_t nw = div_up<uint32_t>(n, 64);
-    hipLaunchKernelGGL(k_compact_count, dim3(nw), dim3(64), 0, as_stream(stream), in, n, (uint32_t*)workspace);
+    hipLaunchKernelGGL(k_compact_count, dim3(nw), dim3(64), 0, as_stream(stream), in, n, (uint32_t*)workspace, n_in_dev);
     hipLaunchKernelGGL(k_compact_write, dim3(nw), dim3(64), 0, as_stream(stream), in, n, out, n_out,
-                       (const uint32_t*)workspace);
+                       (const uint32_t*)workspace, n_in_dev);
     return check_launch("compact_alive");
 }

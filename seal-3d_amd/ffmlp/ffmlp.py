@@ -53,12 +53,13 @@ class _FFMLPForward(Function):
         outputs = torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
         if inference:
             scratch = torch.empty(B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
+            extra = {}
             if input_layout:
-                _backend.ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                                         output_activation, scratch, outputs, input_layout=input_layout)
-            else:
-                _backend.ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                                         output_activation, scratch, outputs)
+                extra["input_layout"] = input_layout
+            if n_valid is not None:
+                extra["n_valid"] = n_valid  # sync-free inference loop: rows behind the alive rays are skipped
+            _backend.ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
+                                     output_activation, scratch, outputs, **extra)
             return outputs
         # The reference stores every layer's activations for the backward pass (forward_buffer [n, B, W]).  Where the
         # fused backward kernel covers the shape, nothing is stored: it re-computes the activations from `inputs` on chip
@@ -203,5 +204,5 @@ class FFMLP(nn.Module):
             w = w._s3d_half
         out = ffmlp_forward(inputs, w, self.input_dim, self.padded_output_dim, self.hidden_dim,
                             self.num_layers, self.activation, self.output_activation, not self.training,
-                            inputs.requires_grad, ref, hook, input_layout, None if not self.training else n_valid)
+                            inputs.requires_grad, ref, hook, input_layout, n_valid)
         return out

@@ -197,8 +197,11 @@ class GridEncoder(nn.Module):
         return out.view(lead + [self.output_dim])
 
     @torch.autocast("cuda", enabled=False)
-    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000):
-        """grid.py:162-185: adds the TV gradient into `embeddings.grad` (call between backward() and step())."""
+    def grad_total_variation(self, weight=1e-7, inputs=None, bound=1, B=1000000, grad_scale=None):
+        """grid.py:162-185: adds the TV gradient into `embeddings.grad` (call between backward() and step()).
+        With nerf.optim.NativeAdam the table gradient lives in the optimizer's fp16 buffer, multiplied by the loss scale:
+        pass that scale as `grad_scale` (float or tensor, e.g. `scaler._scale`); the TV term is computed in fp32, scaled
+        and added to the buffer."""
         D, C, L = self.input_dim, self.embeddings.shape[1], self.offsets.shape[0] - 1
         S, H = float(np.log2(self.per_level_scale)), self.base_resolution
         if inputs is None:
@@ -206,6 +209,16 @@ class GridEncoder(nn.Module):
         else:
             inputs = ((inputs + bound) / (2 * bound)).view(-1, self.input_dim)
             B = inputs.shape[0]
+        stash = getattr(self.embeddings, "_s3d_grad", None)
+        if stash is not None and getattr(self.embeddings, "_s3d_grad_touched", False):
+            if grad_scale is None:
+                raise ValueError("grad_total_variation: this table's gradient is the optimizer's loss-scaled fp16 buffer "
+                                 "(nerf.optim.NativeAdam); pass grad_scale=<the scaler's scale>")
+            tv = torch.zeros_like(self.embeddings, dtype=torch.float32)
+            _backend.grad_total_variation(inputs.contiguous(), self.embeddings.detach().float(), tv, self.offsets, weight, B, D, C, L,
+                                          S, H, self.gridtype_id, self.align_corners)
+            stash.add_((tv * grad_scale).to(stash.dtype))
+            return
         if self.embeddings.grad is None:
             raise ValueError("grad is None, should be called after loss.backward() and before optimizer.step()!")
         _backend.grad_total_variation(inputs.contiguous(), self.embeddings, self.embeddings.grad, self.offsets, weight,

@@ -104,17 +104,17 @@ class NeRFNetwork(NeRFRenderer):
         return ws, wc
 
     def _forward_fused(self, x, d, want_rgb=True):
-        nv = s3d_hip.active_row_limit(x.shape[0]) if self.training else None
+        nv = s3d_hip.active_row_limit(x.shape[0])  # (training: the march's sample count; inference: alive rays x n_step)
         live = None if (self.training or torch.is_grad_enabled()) else s3d_hip.active_live_rows(x.shape[0])
         ws, wc = self._packed_weights()
         infer = not self.training
         e0 = self.encoder(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
-        h = ffmlp_forward(e0, ws, 32, 16, 64, 2, 0, 6, infer, e0.requires_grad, None, None, 1, None if infer else nv)
+        h = ffmlp_forward(e0, ws, 32, 16, 64, 2, 0, 6, infer, e0.requires_grad, None, None, 1, nv)
         if not want_rgb:
             return h
         e1 = self.encoder_color(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
         sigma, cin = _SealMid.apply(h.contiguous(), d.float().contiguous(), e1.contiguous(), nv)
-        out = ffmlp_forward(cin, wc, 64, 16, 64, 2, 0, 6, infer, cin.requires_grad, None, None, 0, None if infer else nv)
+        out = ffmlp_forward(cin, wc, 64, 16, 64, 2, 0, 6, infer, cin.requires_grad, None, None, 0, nv)
         return sigma, _NgpRgb.apply(out.contiguous(), nv)
 
     def _sigma(self, x):

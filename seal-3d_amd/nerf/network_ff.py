@@ -102,7 +102,7 @@ class NeRFNetwork(NeRFRenderer):
                 # every op from here to sigma / rgb is a native kernel, so a padded training batch announced by the renderer
                 # (s3d_hip.row_limit: the march's device-side sample count) is honoured end to end: the absent tail of
                 # the buffers is neither computed nor back-propagated
-                nv = s3d_hip.active_row_limit(x.shape[0]) if self.training else None
+                nv = s3d_hip.active_row_limit(x.shape[0])  # (training: the march's sample count; inference: alive rays x n_step)
                 # inference loop: unused sample slots (deltas == 0, announced by the renderer) skip the table gathers
                 live = None if (self.training or torch.is_grad_enabled()) else s3d_hip.active_live_rows(x.shape[0])
                 h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound, level_major=True, n_valid=nv, live=live),

@@ -20,6 +20,11 @@ import raymarching
 import s3d_hip
 
 
+import contextlib
+
+_null_context = contextlib.nullcontext
+
+
 def _meshgrid(*args):
     return torch.meshgrid(*args, indexing="ij")
 
@@ -36,6 +41,10 @@ class NeRFRenderer(nn.Module):
         self.density_thresh = density_thresh
         self.bg_radius = bg_radius
         self.device_compaction = device_compaction
+        # inference loop: the host reads the alive-ray count back only every `sync_every` iterations; in between, the kernels
+        # take the count from device memory and the launch geometry / buffers are sized by the last known count (an upper
+        # bound).  1 = a read-back per iteration, as the reference's boolean-mask compaction implies.
+        self.sync_every = 4
         # inference: samples marched per alive ray and iteration = min(scale*N // n_alive, 8*scale).  1 = the reference's
         # heuristic (keeps ~N samples per iteration, nerf/renderer.py:352); larger values trade a few wasted samples of
         # rays that terminate mid-chunk for fewer, fuller iterations.  The composited result does not depend on it.
@@ -136,28 +145,48 @@ class NeRFRenderer(nn.Module):
             rays_alive = torch.arange(n_alive, dtype=torch.int32, device=device)
             rays_t = nears.clone()
             use_dev_compaction = self.device_compaction and device.type == "cuda"
-            step = 0
+            sync_free = use_dev_compaction and self.sync_every > 1
+            # sync-free variant: `n_alive` is the host's upper bound, `cnt` (device) the real count; every kernel of the
+            # iteration takes the count from the device, the bound is refreshed every `sync_every` iterations
+            cnt = torch.full((1,), N, dtype=torch.int32, device=device) if sync_free else None
+            rows = torch.zeros(1, dtype=torch.int32, device=device) if sync_free else None
+            step = it = 0
             while step < max_steps and n_alive > 0:
                 n_step = max(min(self.infer_batch_scale * N // n_alive, 8 * self.infer_batch_scale), 1)
-                xyzs, dirs, deltas = raymarching.march_rays(
-                    n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
-                    self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma, max_steps)
+                if sync_free:
+                    xyzs, dirs, deltas = raymarching.march_rays(
+                        n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                        self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma, max_steps, cnt, rows)
+                else:
+                    xyzs, dirs, deltas = raymarching.march_rays(
+                        n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                        self.grid_size, nears, fars, 128, perturb if step == 0 else False, dt_gamma, max_steps)
                 mxyzs, mdirs, mmask = self.map_samples(xyzs, dirs)
-                # slots a ray did not fill stay zero (deltas == 0) and composite_rays never reads their sigma / rgb
-                with s3d_hip.live_rows(deltas):
+                # slots a ray did not fill stay zero (deltas == 0) and composite_rays never reads their sigma / rgb; with a
+                # device-side count the rows behind the last alive ray are skipped altogether (row_limit -> n_valid)
+                with s3d_hip.live_rows(deltas), s3d_hip.row_limit(rows, xyzs.shape[0]) if sync_free else _null_context():
                     sigmas, rgbs = self(mxyzs, mdirs)
                 if self.density_scale != 1:
                     sigmas = self.density_scale * sigmas
                 rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)
-                raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth,
-                                           image, T_thresh)
-                if use_dev_compaction:
-                    rays_alive, cnt = raymarching.compact_rays_alive(rays_alive, n_alive)
-                    n_alive = int(cnt.item())
-                    rays_alive = rays_alive[:n_alive]
+                if sync_free:
+                    raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth,
+                                               image, T_thresh, cnt)
+                    rays_alive, cnt = raymarching.compact_rays_alive(rays_alive, n_alive, cnt)
+                    it += 1
+                    if it % self.sync_every == 0:
+                        n_alive = int(cnt.item())
+                        rays_alive = rays_alive[:max(n_alive, 1)]
                 else:
-                    rays_alive = rays_alive[rays_alive >= 0]
-                    n_alive = rays_alive.shape[0]
+                    raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth,
+                                               image, T_thresh)
+                    if use_dev_compaction:
+                        rays_alive, c = raymarching.compact_rays_alive(rays_alive, n_alive)
+                        n_alive = int(c.item())
+                        rays_alive = rays_alive[:n_alive]
+                    else:
+                        rays_alive = rays_alive[rays_alive >= 0]
+                        n_alive = rays_alive.shape[0]
                 step += n_step
             image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
 

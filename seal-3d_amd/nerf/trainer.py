@@ -231,14 +231,15 @@ class GraphedTrainer(Trainer):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            # real steps on the current batch (every rank runs the same number of all-reduces); a re-capture needs a single
-            # one — the allocator pools and lazy initialisations are already warm
-            for _ in range(2 if self.n_captures == 1 else 1):
-                model.local_step = 0
-                self._body_fb()
-                if self.dist is not None:
-                    self.dist.allreduce_grads(self.scaler)
-                self._body_opt()
+            # ONE real step on the current batch, launched eagerly on a side stream: it is this call's training step (the
+            # capture below records without executing, and train_step does not replay after a capture), and it warms the
+            # allocator pools the capture will draw from (the eager steps before the first capture did the rest); every
+            # rank runs the same number of all-reduces
+            model.local_step = 0
+            self.s_warm_loss = self._body_fb().clone()
+            if self.dist is not None:
+                self.dist.allreduce_grads(self.scaler)
+            self._body_opt()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         model.local_step = 0
@@ -308,11 +309,17 @@ class GraphedTrainer(Trainer):
         if self.graph is None and model.mean_count <= 0:
             # no sample statistics yet (first 16 steps): eager step with the wrapper's host sync
             return self._eager_step(rays_o, rays_d, gt_rgb, bg_color)
+        if bg_color != 1:
+            raise ValueError("GraphedTrainer: the captured step composites on the white background (bg_color=1) of the "
+                             "BASELINE configs; use Trainer for per-batch background colours")
         self._stage_inputs(rays_o, rays_d, gt_rgb)
         if self.graph is None:
-            self._capture()  # warm-up + capture run the step on the current batch
-        self._replay()
+            self._capture()  # runs this step eagerly (one optimizer update), then records the graph
+            loss = self.s_warm_loss
+        else:
+            self._replay()
+            loss = self.s_loss.clone()  # (the static buffer is overwritten by the next replay)
         bump_weights_epoch()  # replays update the parameters without touching Tensor._version
         model.step_counter[model.local_step % 16].copy_(self.s_counter)
         model.local_step += 1
-        return self.s_loss
+        return loss

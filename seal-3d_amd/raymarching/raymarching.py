@@ -205,14 +205,17 @@ class _MarchRays(Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C, H, near, far,
-                align=-1, perturb=False, dt_gamma=0, max_steps=1024):
+                align=-1, perturb=False, dt_gamma=0, max_steps=1024, n_alive_dev=None, n_rows_out=None):
+        """`n_alive_dev` / `n_rows_out` (build extension, sync-free loop): `n_alive` is then an upper bound, the int32 GPU
+        tensor `n_alive_dev` holds the real count, and `n_rows_out` receives count * n_step (seal3d_hip.h)"""
         rays_o, rays_d = _rays(rays_o, rays_d)
         dev, dt = rays_o.device, rays_o.dtype
         M = _align_up(n_alive * n_step, align)
         xyzs, dirs, deltas = _zeros_332(M, dt, dev)
         noises = torch.rand(n_alive, dtype=dt, device=dev) if perturb else torch.zeros(n_alive, dtype=dt, device=dev)
+        extra = {} if n_alive_dev is None else {"n_alive_dev": n_alive_dev, "n_rows_out": n_rows_out}
         _backend.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
-                            density_bitfield, near, far, xyzs, dirs, deltas, noises)
+                            density_bitfield, near, far, xyzs, dirs, deltas, noises, **extra)
         return xyzs, dirs, deltas
 
 
@@ -225,19 +228,24 @@ class _CompositeRays(Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
-                T_thresh=1e-2):
+                T_thresh=1e-2, n_alive_dev=None):
+        extra = {} if n_alive_dev is None else {"n_alive_dev": n_alive_dev}
         _backend.composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas.float().contiguous(),
-                                rgbs.float().contiguous(), deltas.float().contiguous(), weights_sum, depth, image)
+                                rgbs.float().contiguous(), deltas.float().contiguous(), weights_sum, depth, image, **extra)
         return tuple()
 
 
 composite_rays = _CompositeRays.apply
 
 
-def compact_rays_alive(rays_alive, n_alive):
+def compact_rays_alive(rays_alive, n_alive, n_in_dev=None):
     """Device-side equivalent of `rays_alive[rays_alive >= 0]` (nerf/renderer.py:363): stable wave-ballot
-    compaction.  Returns (compacted buffer, device int32 count); the caller decides when to read the count."""
+    compaction.  Returns (compacted buffer, device int32 count); the caller decides when to read the count.
+    `n_in_dev`: int32 GPU tensor with the number of meaningful entries when `n_alive` is only an upper bound."""
     out = torch.empty_like(rays_alive)
     n_out = torch.empty(1, dtype=torch.int32, device=rays_alive.device)
-    _backend.compact_alive(rays_alive, n_alive, out, n_out)
+    if n_in_dev is None:
+        _backend.compact_alive(rays_alive, n_alive, out, n_out)
+    else:
+        _backend.compact_alive(rays_alive, n_alive, out, n_out, n_in_dev=n_in_dev)
     return out, n_out

@@ -279,21 +279,23 @@ class RaymarchingBackend:
 
     @staticmethod
     def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, Cc, H, grid,
-                   nears, fars, xyzs, dirs, deltas, noises):
+                   nears, fars, xyzs, dirs, deltas, noises, n_alive_dev=None, n_rows_out=None):
+        """n_alive_dev / n_rows_out (build extension): device-side alive count and the sample-row count it implies"""
         _need(rays_o, torch.float32, "rays_o")
         _check(lib().s3d_march_rays(_u(n_alive), _u(n_step), _p(rays_alive), _p(rays_t), _p(rays_o), _p(rays_d),
                                     _f(bound), _f(dt_gamma), _u(max_steps), _u(Cc), _u(H), _p(grid), _p(nears),
-                                    _p(fars), _p(xyzs), _p(dirs), _p(deltas), _p(noises), _stream()), "march_rays")
+                                    _p(fars), _p(xyzs), _p(dirs), _p(deltas), _p(noises), _nv(n_alive_dev), _nv(n_rows_out),
+                                    _stream()), "march_rays")
 
     @staticmethod
     def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth,
-                       image):
+                       image, n_alive_dev=None):
         for t, n in ((image, "image"), (sigmas, "sigmas"), (rgbs, "rgbs"), (deltas, "deltas"), (weights_sum, "weights_sum"),
                      (depth, "depth"), (rays_t, "rays_t")):
             _need(t, torch.float32, n)
         _check(lib().s3d_composite_rays(_u(n_alive), _u(n_step), _f(T_thresh), _p(rays_alive), _p(rays_t),
                                         _p(sigmas), _p(rgbs), _p(deltas), _p(weights_sum), _p(depth), _p(image),
-                                        _stream()), "composite_rays")
+                                        _nv(n_alive_dev), _stream()), "composite_rays")
 
     # kernel choice handed to the library with every call (`path` arguments of seal3d_hip.h); binding-side state for
     # tests / experiments — the library itself keeps no process-wide switches
@@ -312,11 +314,11 @@ class RaymarchingBackend:
 
     # --- build extension (not in the reference's native surface) ---
     @staticmethod
-    def compact_alive(rays_alive, n, out, n_out):
+    def compact_alive(rays_alive, n, out, n_out, n_in_dev=None):
         nbytes = lib().s3d_compact_alive_workspace_size(_u(n))
         ws = _ws.get(nbytes, rays_alive.device)
         _check(lib().s3d_compact_alive(_p(rays_alive), _u(n), _p(out), _p(n_out), _p(ws), C.c_size_t(ws.numel()),
-                                       _stream()), "compact_alive")
+                                       _nv(n_in_dev), _stream()), "compact_alive")
 
 
 _level_rows_cache = {}  # id(tensor) -> (weakref, version, rows)
@@ -448,13 +450,13 @@ class FFMLPBackend:
 
     @staticmethod
     def ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                        output_activation, inference_buffer, outputs, input_layout=0):
+                        output_activation, inference_buffer, outputs, input_layout=0, n_valid=None):
         _need(inputs, torch.float16, "inputs")
         _need(weights, torch.float16, "weights")
         _check(lib().s3d_ffmlp_inference(_p(inputs), _p(weights), _u(B), _u(input_dim), _u(output_dim),
                                          _u(hidden_dim), _u(num_layers), _u(activation), _u(output_activation),
-                                         _p(inference_buffer), _p(outputs), C.c_int(int(input_layout)), _stream()),
-               "ffmlp_inference")
+                                         _p(inference_buffer), _p(outputs), C.c_int(int(input_layout)), _nv(n_valid),
+                                         _stream()), "ffmlp_inference")
 
     @staticmethod
     def fused_backward_supported(input_dim, output_dim, hidden_dim, num_layers, activation):

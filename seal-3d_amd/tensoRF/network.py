@@ -159,3 +159,33 @@ class NeRFNetwork(NeRFRenderer):
         up(self.sigma_mat, self.sigma_vec)
         up(self.color_mat, self.color_vec)
         self.resolution = list(resolution)
+
+    @torch.no_grad()
+    def shrink_model(self):
+        """crop aabb_train and every factor to the bounding box of the occupied cells of the coarsest density grid
+        (tensoRF/network.py:273-318).  Returns (tl, br): the kept index range per axis.  The parameter set changes:
+        re-create the optimizer afterwards (Trainer.rebuild_optimizer), as after upsample_model."""
+        import raymarching
+        hgs = self.bound / self.grid_size
+        thresh = min(self.density_thresh, self.mean_density)
+        occupied = self.density_grid[self.cascade - 1] > thresh
+        pos = raymarching.morton3D_invert(torch.nonzero(occupied).squeeze(-1))
+        if pos.shape[0] == 0:
+            raise RuntimeError("shrink_model: no cell of the coarsest cascade is above the density threshold")
+        pos = (2 * pos / (self.grid_size - 1) - 1) * (self.bound - hgs)
+        min_pos, max_pos = pos.amin(0) - hgs, pos.amax(0) + hgs
+        reso = torch.tensor(self.resolution, dtype=torch.long, device=self.aabb_train.device)
+        units = (self.aabb_train[3:] - self.aabb_train[:3]) / reso
+        tl = torch.round((min_pos - self.aabb_train[:3]) / units).long().clamp(min=0)
+        br = torch.minimum(torch.round((max_pos - self.aabb_train[:3]) / units).long(), reso)
+        tl_h, br_h = tl.tolist(), br.tolist()
+        for i, vec_id in enumerate(self.vec_ids):
+            m0, m1 = self.mat_ids[i]
+            for vecs, mats in ((self.sigma_vec, self.sigma_mat), (self.color_vec, self.color_mat)):
+                vecs[i] = nn.Parameter(vecs[i].data[..., tl_h[vec_id]:br_h[vec_id], :].contiguous())
+                mats[i] = nn.Parameter(mats[i].data[..., tl_h[m1]:br_h[m1], tl_h[m0]:br_h[m0]].contiguous())
+        self.aabb_train = torch.cat([min_pos, max_pos], dim=0).to(self.aabb_train.dtype)
+        # (the reference leaves `self.resolution` stale after the crop — it only reads it again in the next upsample; the
+        #  fused feature kernels take the factor extents from it, so it follows the parameters here)
+        self.resolution = [b - a for a, b in zip(tl_h, br_h)]
+        return tl_h, br_h

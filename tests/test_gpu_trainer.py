@@ -176,3 +176,33 @@ def test_occupancy_update_replayed_from_its_own_graph(hip):
     agree_ref, agree_dev = (bits_ref == bits_ref2).mean(), (bits_ref == bits_dev).mean()
     assert agree_dev > agree_ref - 0.01 and agree_dev > 0.9, (agree_ref, agree_dev)
     assert abs(bits_dev.mean() - bits_ref.mean()) < 0.02 * bits_ref.mean() + 1e-3
+
+
+@pytest.mark.parametrize("net_kind", ["ff", "seal"])
+def test_sync_free_inference_loop_renders_the_same_frame(hip, net_kind):
+    """nerf/renderer.py:341-367 with the alive-ray count kept on the device (read back every `sync_every` iterations, kernels
+    bounded by the device count, rows behind the alive rays skipped through n_valid) against a read-back per iteration and
+    against the reference's host boolean-mask compaction: the same frame bit for bit, image and depth."""
+    from nerf import network, network_ff, synthetic as syn
+    torch.manual_seed(0)
+    Net = network_ff.NeRFNetwork if net_kind == "ff" else network.NeRFNetwork
+    model = Net(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).cuda()
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    model.density_grid.copy_(torch.from_numpy(grid))
+    model.density_bitfield.copy_(torch.from_numpy(bits))
+    for name, p in model.named_parameters():
+        if "embeddings" in name:
+            p.data.uniform_(-0.5, 0.5)
+    model.eval()
+    poses = syn.orbit_poses(1, seed=3).cuda()
+    r = syn.get_rays(poses, syn.lego_intrinsics(160, 160), 160, 160)
+    ro, rd = r["rays_o"].contiguous(), r["rays_d"].contiguous()
+    frames = {}
+    for tag, compaction, every, scale in (("host", False, 1, 1), ("dev1", True, 1, 1), ("dev4", True, 4, 1), ("dev16", True, 16, 4)):
+        model.device_compaction, model.sync_every, model.infer_batch_scale = compaction, every, scale
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            out = model.render(ro, rd, bg_color=1, perturb=False, max_steps=1024, T_thresh=1e-4)
+        frames[tag] = (out["image"].clone(), out["depth"].clone())
+    assert float(frames["host"][0].std()) > 0.01
+    for tag in ("dev1", "dev4", "dev16"):
+        assert torch.equal(frames[tag][0], frames["host"][0]) and torch.equal(frames[tag][1], frames["host"][1]), tag

@@ -229,3 +229,35 @@ def test_sync_free_partial_grid_update_matches_reference_rule(oracle_wrappers):
     # (jitter on the box faces); the sync-free variant is in the same band
     same = float((np.unpackbits(A.density_bitfield.numpy()) == np.unpackbits(B.density_bitfield.numpy())).mean())
     assert same > 0.975, same
+
+
+def test_tensorf_shrink_model_crops_factors_and_aabb(oracle_wrappers):
+    """tensoRF/network.py:273-318: the factors and aabb_train are cropped to the occupied region of the coarsest cascade;
+    a point keeps its features (its normalised coordinate moves with the box: same cells, same weights) when the crop
+    falls on factor-grid lines"""
+    import torch
+    from tensoRF import network as trf
+    torch.manual_seed(0)
+    net = trf.NeRFNetwork(resolution=[33, 33, 33], sigma_rank=[2, 2, 2], color_rank=[3, 3, 3], bound=1, cuda_ray=True, density_thresh=10)
+    net.fused_vm = False
+    # occupied: the cells whose centres lie in [-0.5, 0.5]^3
+    H = net.grid_size
+    import raymarching
+    idx = torch.arange(H ** 3)
+    c = raymarching.morton3D_invert(idx.int()).float()
+    centre = (2 * c / (H - 1) - 1) * (1 - 1 / H)
+    net.density_grid[0] = ((centre.abs() <= 0.5).all(1)).float() * 100.0
+    net.mean_density = float(net.density_grid.clamp(min=0).mean())
+    x = (torch.rand(200, 3) - 0.5) * 0.8
+    before = net.get_sigma_feat(net._normalize(x)).detach().clone()
+    factors = lambda: sum(p.numel() for grp in (net.sigma_mat, net.sigma_vec, net.color_mat, net.color_vec) for p in grp)
+    n_before = factors()
+    tl, br = net.shrink_model()
+    assert all(0 < a < b < 33 for a, b in zip(tl, br)) and net.resolution == [b - a for a, b in zip(tl, br)]
+    assert factors() < 0.5 * n_before
+    assert tuple(net.sigma_mat[0].shape[-2:]) == (net.resolution[1], net.resolution[0]) and net.sigma_vec[0].shape[-2] == net.resolution[2]
+    assert torch.all(net.aabb_train[:3] > -0.6) and torch.all(net.aabb_train[3:] < 0.6) and torch.all(net.aabb_train[3:] >= 0.49)
+    # features survive to the accuracy of the box / grid-line mismatch (the crop is rounded to grid lines: the new box is not
+    # exactly the span of the kept rows, as in the reference) — a smooth field changes little
+    after = net.get_sigma_feat(net._normalize(x)).detach()
+    assert torch.isfinite(after).all() and float((after - before).abs().mean()) < 0.6 * float(before.abs().mean())
