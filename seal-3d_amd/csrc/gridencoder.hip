@@ -55,8 +55,56 @@ __device__ __forceinline__ uint32_t grid_row(uint32_t gridtype, bool align_corne
         for (uint32_t i = 0; i < D; i++) r ^= pg[i] * kPrimes[i];
         index = r;
     }
-    return index % hashmap_size;
+    // `index % hashmap_size` without the ~25-instruction division by a run-time value on the paths that never need it:
+    // hashed levels have power-of-two sizes (a mask), dense rows lie below the size (nothing to do); what is left (tiled
+    // grids whose strides overflow the table) divides
+    const uint32_t mask = hashmap_size - 1;
+    if ((hashmap_size & mask) == 0) return index & mask;
+    if (__builtin_expect(index >= hashmap_size, 0)) index %= hashmap_size;
+    return index;
 }
+
+// Level-uniform index plan (get_grid_index, gridencoder.cu:66-84): which dimensions enter the dense index (the
+// stride loop stops once stride > hashmap_size), their strides, whether the level is hashed; `% hashmap_size` is a
+// mask for power-of-two sizes and a no-op for dense rows below the size.  Same rows as grid_row, fewer divisions.
+template <uint32_t D>
+struct LevelIndex {
+    uint32_t mul[D];  // per-dimension multiplier: prime (hashed) or stride (dense; 0 = dimension dropped)
+    uint32_t size, mask;
+    bool hashed, pow2, need_mod;
+    __device__ __forceinline__ void init(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution) {
+        uint32_t st = 1;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            if (st <= hashmap_size) { mul[d] = st; st *= align_corners ? resolution : (resolution + 1); }
+            else mul[d] = 0;
+        }
+        hashed = (gridtype == 0 && st > hashmap_size);
+        if (hashed) {
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) mul[d] = kPrimes[d];
+        }
+        size = hashmap_size;
+        mask = hashmap_size - 1;
+        pow2 = (hashmap_size & mask) == 0;
+        // can a dense index reach the table size at all?  (cell coordinates are <= resolution + 1)
+        unsigned long long top = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) top += (unsigned long long)(resolution + 1) * mul[d];
+        need_mod = hashed || top >= hashmap_size;
+    }
+    __device__ __forceinline__ uint32_t row(const uint32_t (&lo)[D], uint32_t idx) const {  // lo[d] = pos_grid[d] * mul[d]
+        uint32_t index = 0;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {
+            const uint32_t t = ((idx >> d) & 1u) ? lo[d] + mul[d] : lo[d];
+            index = hashed ? (index ^ t) : (index + t);
+        }
+        if (pow2) return index & mask;
+        if (!need_mod) return index;  // (wave-uniform: dense levels skip the division by a run-time value altogether)
+        return index < size ? index : index % size;
+    }
+};
 
 // ---- feature vector load/store: one memory instruction per corner ----
 template <typename T, uint32_t C> struct FeatVec;
@@ -296,30 +344,58 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __
         for (uint32_t d = 0; d < D; d++) pg_partner[d] = dpp_swap1(pg[d]);
 
         uint32_t g1[J][NW], g2[J][NW];  // this lane's x-side of point P / of point Q
+        // level-uniform index plan: per-dimension multipliers, hashed or dense, mask or (rarely) a division — decided once
+        // per level on the scalar unit, so that the J gathers of a half are straight-line code issued back to back
+        LevelIndex<D> li;
+        li.init(gridtype, align_corners, hashmap_size, resolution);
+        auto gather = [&](auto hashed_c, const uint32_t (&tg)[D], bool skip, uint32_t (&dst)[J][NW]) {
+            constexpr bool kHashed = decltype(hashed_c)::value;
+            uint32_t lo[D], hi[D];
 #pragma unroll
-        for (uint32_t half_ = 0; half_ < 2; half_++) {
-            const bool skip = half_ ? oobQ : oobP;
-            // target point of this half: P = the even lane's point
-            uint32_t tg[D];
-#pragma unroll
-            for (uint32_t d = 0; d < D; d++) tg[d] = (side == half_) ? pg[d] : pg_partner[d];
+            for (uint32_t d = 0; d < D; d++) { lo[d] = tg[d] * li.mul[d]; hi[d] = lo[d] + li.mul[d]; }
+            const uint32_t x0 = side ? hi[0] : lo[0];
+            uint32_t rows[J];
 #pragma unroll
             for (uint32_t j = 0; j < J; j++) {
-                uint32_t pgl[D];
-                pgl[0] = tg[0] + side;
+                uint32_t index = x0;
 #pragma unroll
-                for (uint32_t d = 1; d < D; d++) pgl[d] = tg[d] + ((j >> (d - 1)) & 1u);
-                uint32_t w[NW];
-#pragma unroll
-                for (uint32_t k = 0; k < NW; k++) w[k] = 0u;
-                if (!skip) {
-                    const uint32_t row = grid_row<D>(gridtype, align_corners, hashmap_size, resolution, pgl);
-                    T f[C];
-                    load_feat<T, C>(table + (size_t)row * C, f);
-                    __builtin_memcpy(w, f, sizeof(T) * C);
+                for (uint32_t d = 1; d < D; d++) {
+                    const uint32_t t = ((j >> (d - 1)) & 1u) ? hi[d] : lo[d];
+                    index = kHashed ? (index ^ t) : (index + t);
                 }
+                rows[j] = index;
+            }
+            if (li.pow2) {
 #pragma unroll
-                for (uint32_t k = 0; k < NW; k++) { if (half_) g2[j][k] = w[k]; else g1[j][k] = w[k]; }
+                for (uint32_t j = 0; j < J; j++) rows[j] &= li.mask;
+            } else if (li.need_mod) {
+#pragma unroll
+                for (uint32_t j = 0; j < J; j++) rows[j] = rows[j] < li.size ? rows[j] : rows[j] % li.size;
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < J; j++)
+#pragma unroll
+                for (uint32_t k = 0; k < NW; k++) dst[j][k] = 0u;
+            if (!skip) {
+#pragma unroll
+                for (uint32_t j = 0; j < J; j++) {
+                    T f[C];
+                    load_feat<T, C>(table + (size_t)rows[j] * C, f);
+                    __builtin_memcpy(dst[j], f, sizeof(T) * C);
+                }
+            }
+        };
+        {
+            // first half: both lanes address point P (the even lane's point), second half: point Q
+            uint32_t tgP[D], tgQ[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) { tgP[d] = side ? pg_partner[d] : pg[d]; tgQ[d] = side ? pg[d] : pg_partner[d]; }
+            if (li.hashed) {
+                gather(std::true_type{}, tgP, oobP, g1);
+                gather(std::true_type{}, tgQ, oobQ, g2);
+            } else {
+                gather(std::false_type{}, tgP, oobP, g1);
+                gather(std::false_type{}, tgQ, oobQ, g2);
             }
         }
         // lane 2k keeps g1 (P, x0) and needs lane 2k+1's g1 (P, x1); lane 2k+1 keeps g2 (Q, x1) and needs lane 2k's g2 (Q, x0)
@@ -513,42 +589,6 @@ __host__ __device__ inline uint32_t bin_local_rows(uint32_t rows, uint32_t S) {
 constexpr uint32_t kBinQuad = 4;  // consecutive points handled (and merged) by one lane of k_bin_count / k_bin_scatter
 template <typename T, uint32_t D, uint32_t C>
 __host__ __device__ constexpr uint32_t bin_chunk_points() { return S3D_BIN_CHUNK; }  // points per scatter workgroup (lanes x 4)
-
-// Level-uniform index plan (get_grid_index, gridencoder.cu:66-84): which dimensions enter the dense index (the
-// stride loop stops once stride > hashmap_size), their strides, whether the level is hashed; `% hashmap_size` is a
-// mask for power-of-two sizes and a no-op for dense rows below the size.  Same rows as grid_row, fewer divisions.
-template <uint32_t D>
-struct LevelIndex {
-    uint32_t mul[D];  // per-dimension multiplier: prime (hashed) or stride (dense; 0 = dimension dropped)
-    uint32_t size, mask;
-    bool hashed, pow2;
-    __device__ __forceinline__ void init(uint32_t gridtype, bool align_corners, uint32_t hashmap_size, uint32_t resolution) {
-        uint32_t st = 1;
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++) {
-            if (st <= hashmap_size) { mul[d] = st; st *= align_corners ? resolution : (resolution + 1); }
-            else mul[d] = 0;
-        }
-        hashed = (gridtype == 0 && st > hashmap_size);
-        if (hashed) {
-#pragma unroll
-            for (uint32_t d = 0; d < D; d++) mul[d] = kPrimes[d];
-        }
-        size = hashmap_size;
-        mask = hashmap_size - 1;
-        pow2 = (hashmap_size & mask) == 0;
-    }
-    __device__ __forceinline__ uint32_t row(const uint32_t (&lo)[D], uint32_t idx) const {  // lo[d] = pos_grid[d] * mul[d]
-        uint32_t index = 0;
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++) {
-            const uint32_t t = ((idx >> d) & 1u) ? lo[d] + mul[d] : lo[d];
-            index = hashed ? (index ^ t) : (index + t);
-        }
-        if (pow2) return index & mask;
-        return index < size ? index : index % size;
-    }
-};
 
 template <typename T, uint32_t C>
 __device__ __forceinline__ float absmax_feat(const T (&g)[C], bool& nonzero) {
