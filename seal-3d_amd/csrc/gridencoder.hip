@@ -331,19 +331,22 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __
     const bool oob_partner = dpp_swap1(oob ? 1u : 0u) != 0u;
     const bool oobP = side ? oob_partner : oob, oobQ = side ? oob : oob_partner;
 
-    for (uint32_t level = xcd; level < L; level += kXcds) {
+    struct LevelState {
+        float pos[D];
+        uint32_t g1[J][NW], g2[J][NW];  // this lane's x-side of point P / of point Q
+    };
+    // phase 1 of a level: cell + weights of the own point, rows of the lane's x-side for both points, gathers issued
+    auto issue = [&](uint32_t level, LevelState& st) {
         const uint32_t off = (uint32_t)offsets[level];
         const uint32_t hashmap_size = (uint32_t)offsets[level + 1] - off;
         const T* table = grid + (size_t)off * C;
         const float scale = scales.v[level];
         const uint32_t resolution = (uint32_t)ceilf(scale) + 1;
-        float pos[D], pos_deriv[D];
+        float pos_deriv[D];
         uint32_t pg[D], pg_partner[D];
-        locate<D>(x, scale, align_corners, interp, pos, pos_deriv, pg);
+        locate<D>(x, scale, align_corners, interp, st.pos, pos_deriv, pg);
 #pragma unroll
         for (uint32_t d = 0; d < D; d++) pg_partner[d] = dpp_swap1(pg[d]);
-
-        uint32_t g1[J][NW], g2[J][NW];  // this lane's x-side of point P / of point Q
         // level-uniform index plan: per-dimension multipliers, hashed or dense, mask or (rarely) a division — decided once
         // per level on the scalar unit, so that the J gathers of a half are straight-line code issued back to back
         LevelIndex<D> li;
@@ -385,19 +388,20 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __
                 }
             }
         };
-        {
-            // first half: both lanes address point P (the even lane's point), second half: point Q
-            uint32_t tgP[D], tgQ[D];
+        // first half: both lanes address point P (the even lane's point), second half: point Q
+        uint32_t tgP[D], tgQ[D];
 #pragma unroll
-            for (uint32_t d = 0; d < D; d++) { tgP[d] = side ? pg_partner[d] : pg[d]; tgQ[d] = side ? pg[d] : pg_partner[d]; }
-            if (li.hashed) {
-                gather(std::true_type{}, tgP, oobP, g1);
-                gather(std::true_type{}, tgQ, oobQ, g2);
-            } else {
-                gather(std::false_type{}, tgP, oobP, g1);
-                gather(std::false_type{}, tgQ, oobQ, g2);
-            }
+        for (uint32_t d = 0; d < D; d++) { tgP[d] = side ? pg_partner[d] : pg[d]; tgQ[d] = side ? pg[d] : pg_partner[d]; }
+        if (li.hashed) {
+            gather(std::true_type{}, tgP, oobP, st.g1);
+            gather(std::true_type{}, tgQ, oobQ, st.g2);
+        } else {
+            gather(std::false_type{}, tgP, oobP, st.g1);
+            gather(std::false_type{}, tgQ, oobQ, st.g2);
         }
+    };
+    // phase 2: the halves fetched for the partner change lanes, the own point is reduced in the reference's corner order
+    auto finish = [&](uint32_t level, const LevelState& st) {
         // lane 2k keeps g1 (P, x0) and needs lane 2k+1's g1 (P, x1); lane 2k+1 keeps g2 (Q, x1) and needs lane 2k's g2 (Q, x0)
         T feat[1u << D][C];
 #pragma unroll
@@ -405,8 +409,8 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __
             uint32_t own[NW], got[NW];
 #pragma unroll
             for (uint32_t k = 0; k < NW; k++) {
-                own[k] = side ? g2[j][k] : g1[j][k];
-                got[k] = dpp_swap1(side ? g1[j][k] : g2[j][k]);
+                own[k] = side ? st.g2[j][k] : st.g1[j][k];
+                got[k] = dpp_swap1(side ? st.g1[j][k] : st.g2[j][k]);
             }
             uint32_t f0[NW], f1[NW];
 #pragma unroll
@@ -414,7 +418,7 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __
             __builtin_memcpy(feat[(j << 1)], f0, sizeof(T) * C);
             __builtin_memcpy(feat[(j << 1) | 1u], f1, sizeof(T) * C);
         }
-        if (!valid) continue;
+        if (!valid) return;
         T* out = outputs + ((size_t)level * B + b) * C;
         T res[C];
 #pragma unroll
@@ -424,12 +428,21 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __
             for (uint32_t idx = 0; idx < (1u << D); idx++) {
                 float w = 1;
 #pragma unroll
-                for (uint32_t d = 0; d < D; d++) w *= ((idx >> d) & 1u) ? pos[d] : 1 - pos[d];
+                for (uint32_t d = 0; d < D; d++) w *= ((idx >> d) & 1u) ? st.pos[d] : 1 - st.pos[d];
 #pragma unroll
                 for (uint32_t c = 0; c < C; c++) res[c] = Acc<T>::fma(w, feat[idx][c], res[c]);
             }
         }
         store_feat<T, C>(out, res);
+    };
+    // two levels of this XCD in flight at a time: the second level's gathers are issued before the first one's are awaited
+    for (uint32_t level = xcd; level < L; level += 2 * kXcds) {
+        LevelState s0, s1;
+        const bool two = level + kXcds < L;  // (uniform)
+        issue(level, s0);
+        if (two) issue(level + kXcds, s1);
+        finish(level, s0);
+        if (two) finish(level + kXcds, s1);
     }
 }
 
