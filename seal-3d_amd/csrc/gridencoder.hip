@@ -998,6 +998,16 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate(const uint32_
 //    the serial work per lane and KS times the waves for the same LDS.
 constexpr uint32_t kFixedExp = 24;
 
+// fixed-point sum -> float: the two 32-bit limbs of the MAGNITUDE converted separately and joined by one fma (|error| <= 1 ulp
+// of the fp32 result, which is then rounded to the table's type), sign restored last — a handful of instructions instead of
+// the int64 -> double -> float route.  (Limbs of the two's-complement value would not do: a small negative sum has a low
+// limb just below 2^32, whose conversion to float rounds the whole value away.)
+__device__ __forceinline__ float fixed_to_float(long long q, int kexp) {
+    const unsigned long long a = q < 0 ? 0ull - (unsigned long long)q : (unsigned long long)q;
+    const float v = ldexpf(__builtin_fmaf((float)(uint32_t)(a >> 32), 4294967296.0f, (float)(uint32_t)a), -kexp);
+    return q < 0 ? -v : v;
+}
+
 // v * 2^24 as a 64-bit integer for a value that IS a multiple of 2^-24 below 2^16 in magnitude (every binary16): the scaled
 // value is exact in fp32, and so are its two 16-bit-apart limbs — two truncating conversions, no rounding anywhere.
 __device__ __forceinline__ long long fixed24_exact(float v) {
@@ -1261,7 +1271,6 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate4(const uint2*
         (void)frexpf(amax, &e);
         kexp = 62 - e - (int)(32 - __clz(B)) - (int)D;
     }
-    const double inv_scale = ldexp(1.0, -kexp);
     const uint2* recs = grecs + ((size_t)blockIdx.y * smax + slice) * cap;
 #ifndef S3D_ACC_FASTFIX
 #define S3D_ACC_FASTFIX 1
@@ -1398,7 +1407,7 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate4(const uint2*
                 T o[C];
                 __builtin_memcpy(o, &old[w], sizeof(V));
 #pragma unroll
-                for (uint32_t c = 0; c < C; c++) o[c] = Acc<T>::from_f(Acc<T>::to_f(o[c]) + (float)((double)q[w][c] * inv_scale));
+                for (uint32_t c = 0; c < C; c++) o[c] = Acc<T>::from_f(Acc<T>::to_f(o[c]) + fixed_to_float(q[w][c], kexp));
                 store_feat<T, C>(table + (size_t)row_of_local(r0 + w * kBinAccThreads) * C, o);
             }
         }

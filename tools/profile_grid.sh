@@ -5,7 +5,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-r04}
-FV=${2:-"0"}
+FV=${2:-"0"}   # (forward / backward variant switches of past experiments; the library has none now)
 BV=${3:-"0"}
 OUT=$ROOT/gpurun_out/grid_$TAG
 mkdir -p "$OUT"
@@ -26,12 +26,12 @@ for fv in $FV; do for bv in $BV; do
              ${S3D_PMC_EXTRA:-}; do
     i=$((i+1))
     timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$P/pmc$i" -- python "$ROOT/tools/bench_grid.py" $ARGS > "$P.pmc$i.log" 2>&1 || echo "pmc pass $i failed" >> "$OUT/pmc_$v.txt"
-    for k in k_grid_forward k_bin_count k_bin_scatter k_bin_accumulate k_bin_; do
+    for k in k_grid_forward k_bin_scatter k_bin_accumulate; do
       if ls "$P/pmc$i" >/dev/null 2>&1; then echo "## $k  [$set]" >> "$OUT/pmc_$v.txt"; python "$ROOT/tools/pmc_kernel.py" "$P/pmc$i" $k >> "$OUT/pmc_$v.txt" 2>/dev/null; fi
     done
   done
   tail -3 "$P.pmc1.log" | cut -c1-300
   rm -rf "$P"
 done; done
-cat "$OUT"/stats_*.txt | head -60
-cat "$OUT"/pmc_*.txt | head -150
+cd "$ROOT" && python tools/summarize_grid.py "$TAG" > "$OUT/summary.log" 2>&1; tail -60 "$OUT/summary.log"
+mkdir -p "$ROOT/gpurun_out/profiles_out" && cp "$ROOT"/profiles/${TAG}_grid_isolated.md "$ROOT/gpurun_out/profiles_out/" 2>/dev/null
