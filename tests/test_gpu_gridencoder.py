@@ -237,3 +237,43 @@ def test_grid_errors_raise(hip):
     with pytest.raises(RuntimeError, match="D must be 2, 3, 4, or 5"):
         hip.GridBackend.grid_encode_forward(torch.rand(8, 6).cuda(), torch.rand(8, 2).cuda(), offs,
                                             torch.empty(1, 8, 2, device="cuda"), 8, 6, 2, 1, 1.0, 16, None, 0, False, 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_grid_backward_binned_training_size_vs_oracle(oracle, hip, dtype):
+    """The binned backward on a training-shaped batch (Lego configuration, 40,000 samples marched along rays — consecutive
+    samples share coarse cells, so the quad merging, the sorted bucket runs and the exact 2^24 fixed-point sum (fp16) are all
+    exercised) against the CPU oracle: the oracle's fp32 sum of the same products for fp16 (the binned sum is exact and
+    rounded once, the reference's half atomics are not), the oracle's own result for fp32."""
+    from nerf import synthetic as syn
+    D, L, C, base = 3, 16, 2, 16
+    offsets, S, total = _enc_meta(D, L, C, base, 19, 2048, False)
+    # ray-ordered points: 500 rays x 80 samples with the Lego step (2 sqrt(3) / 1024 in world units, half that in [0,1])
+    g = torch.Generator().manual_seed(11)
+    o = torch.rand(500, 3, generator=g) * 0.2 + 0.05
+    d = torch.nn.functional.normalize(torch.rand(500, 3, generator=g) + 0.1, dim=-1)
+    t = torch.arange(80).float() * (3.383e-3 / 2)
+    x = (o[:, None, :] + d[:, None, :] * t[None, :, None]).reshape(-1, 3).contiguous()
+    B = x.shape[0]
+    assert B == 40000 and float(x.max()) < 1.0
+    grad = (torch.randn(L, B, C, generator=g) * 1e-2).to(dtype)
+    grad[:, torch.rand(B, generator=g) < 0.25] = 0     # terminated samples
+    emb = torch.zeros(total, C, dtype=dtype)
+    ge_ref = torch.zeros(total, C, dtype=torch.float32)
+    oracle.GridBackend.grid_encode_backward(grad.float(), x, emb.float(), offsets, ge_ref, B, D, C, L, S, base, None, None, 0, False, 0)
+    hip.GridBackend.set_backward_path(2)
+    try:
+        ge = torch.zeros(total, C, dtype=dtype, device="cuda")
+        hip.GridBackend.grid_encode_backward(grad.cuda(), x.cuda(), emb.cuda(), offsets.cuda(), ge, B, D, C, L, S, base, None, None, 0,
+                                             False, 0)
+    finally:
+        hip.GridBackend.set_backward_path(0)
+    got = ge.cpu().float()
+    scale = float(ge_ref.abs().max())
+    if dtype == torch.float32:
+        torch.testing.assert_close(got, ge_ref, rtol=1e-4, atol=1e-5 * scale)
+    else:
+        # products rounded to fp16 (2^-11 relative each, as in the reference), merged runs rounded once: the error of a row
+        # is a random walk of its contributions' roundings — bounded here by 2e-3 of the largest row plus 2e-3 relative
+        torch.testing.assert_close(got, ge_ref, rtol=2e-3, atol=2e-3 * scale)
+    assert int((got != 0).any(1).sum()) > 10000
