@@ -392,12 +392,23 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __
         uint32_t tgP[D], tgQ[D];
 #pragma unroll
         for (uint32_t d = 0; d < D; d++) { tgP[d] = side ? pg_partner[d] : pg[d]; tgQ[d] = side ? pg[d] : pg_partner[d]; }
+        // samples marched along a ray stay in one cell of a coarse level for many consecutive samples: when P and Q share
+        // their cell, Q's corners ARE P's — the second half's gathers are masked off and the values copied
+        bool same = !oobP && !oobQ;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) same = same && (tgP[d] == tgQ[d]);
         if (li.hashed) {
             gather(std::true_type{}, tgP, oobP, st.g1);
-            gather(std::true_type{}, tgQ, oobQ, st.g2);
+            gather(std::true_type{}, tgQ, oobQ || same, st.g2);
         } else {
             gather(std::false_type{}, tgP, oobP, st.g1);
-            gather(std::false_type{}, tgQ, oobQ, st.g2);
+            gather(std::false_type{}, tgQ, oobQ || same, st.g2);
+        }
+        if (same) {
+#pragma unroll
+            for (uint32_t j = 0; j < J; j++)
+#pragma unroll
+                for (uint32_t k = 0; k < NW; k++) st.g2[j][k] = st.g1[j][k];
         }
     };
     // phase 2: the halves fetched for the partner change lanes, the own point is reduced in the reference's corner order

@@ -18,10 +18,17 @@ from test_gpu_trainer import _setup, _run  # noqa: E402
 
 
 def main():
-    scale = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    scales = [int(v) for v in sys.argv[1:]] or [4]
     model, batches = _setup(n_rays=4096, n_batches=16)
     tr = GraphedTrainer(model, 4096, lr=1e-2, fp16=True)
     _run(tr, batches, 400)
+    for scale in scales:
+        for every in (1, 4, 8):
+            model.sync_every = every
+            _one(model, tr, scale)
+
+
+def _one(model, tr, scale):
     model.infer_batch_scale = scale
     poses = syn.orbit_poses(1, seed=0).cuda()
     r = syn.get_rays(poses[:1], syn.lego_intrinsics(), 800, 800)
@@ -45,7 +52,9 @@ def main():
         tr.render_image(ro, rd)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / nfr
-    print(f"render 800x800 infer_batch_scale={scale}: {dt*1e3:.2f} ms/frame, {0.64/dt:.1f} Mrays/s, "
+    rm.march_rays = inner
+    nr.raymarching.march_rays = inner
+    print(f"render 800x800 infer_batch_scale={scale} sync_every={model.sync_every}: {dt*1e3:.2f} ms/frame, {0.64/dt:.1f} Mrays/s, "
           f"{calls['n']/nfr:.0f} loop iterations, {calls['pts']/nfr/1e6:.2f} M sample slots per frame", flush=True)
 
 
