@@ -288,7 +288,8 @@ int s3d_bg_mse_backward(const float* image, const float* weights_sum, const floa
 int s3d_seal_bbox_map(const float* points, const float* dirs, uint32_t M, const float* triangles, uint32_t n_tris,
                       const float* bounds, uint32_t n_bounds, const float* inv_transform, const float* inv_rotation,
                       const float* inv_scale, const float* center, const float* empty_bound, const float* map_source,
-                      float* out_points, float* out_dirs, uint8_t* mask, s3d_stream_t stream);
+                      float* out_points, float* out_dirs, uint8_t* mask, const int32_t* n_valid /* padded sample batch: rows past it are skipped, or NULL */,
+                      s3d_stream_t stream);
 
 /* ------------------------------------------------------------------ parameter update
  * The reference's update is torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15) under torch.cuda.amp.GradScaler

@@ -44,9 +44,9 @@ __device__ __forceinline__ bool hit_any(const SealMap& m, float ox, float oy, fl
 
 __global__ void __launch_bounds__(256) k_seal_map(const float* __restrict__ points, const float* __restrict__ dirs, uint32_t M,
                                                   SealMap m, float* __restrict__ out_p, float* __restrict__ out_d,
-                                                  uint8_t* __restrict__ mask) {
+                                                  uint8_t* __restrict__ mask, const int32_t* __restrict__ n_valid) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
+    if (i >= valid_rows(M, n_valid)) return;
     const float px = points[(size_t)i * 3], py = points[(size_t)i * 3 + 1], pz = points[(size_t)i * 3 + 2];
     bool in = false;
     for (uint32_t b = 0; b < m.n_bounds; b++)
@@ -91,7 +91,8 @@ using namespace s3d;
 S3D_EXPORT int s3d_seal_bbox_map(const float* points, const float* dirs, uint32_t M, const float* triangles, uint32_t n_tris,
                                  const float* bounds, uint32_t n_bounds, const float* inv_transform, const float* inv_rotation,
                                  const float* inv_scale, const float* center, const float* empty_bound, const float* map_source,
-                                 float* out_points, float* out_dirs, uint8_t* mask, s3d_stream_t stream) {
+                                 float* out_points, float* out_dirs, uint8_t* mask, const int32_t* n_valid,
+                                 s3d_stream_t stream) {
     if (M == 0) return S3D_OK;
     S3D_REQUIRE(points && triangles && bounds && inv_transform && inv_rotation && inv_scale && center && out_points && mask,
                 "seal_bbox_map: null pointer");
@@ -116,6 +117,6 @@ S3D_EXPORT int s3d_seal_bbox_map(const float* points, const float* dirs, uint32_
     }
     m.n_tris = n_tris; m.n_bounds = n_bounds;
     hipLaunchKernelGGL(k_seal_map, dim3(div_up<uint32_t>(M, 256)), dim3(256), 0, as_stream(stream), points, dirs, M, m, out_points,
-                       out_dirs, mask);
+                       out_dirs, mask, n_valid);
     return check_launch("seal_bbox_map");
 }

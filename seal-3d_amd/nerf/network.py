@@ -88,8 +88,14 @@ class NeRFNetwork(NeRFRenderer):
     # rounded to fp16 where the first Linear's input cast rounds them; sigmoid evaluated in fp32 and rounded to fp16.
     fused_mlp = os.environ.get("S3D_FUSED_SEAL", "1") != "0"  # tests / A-B runs: False = nn.Linear op sequence
 
+    def honours_row_limit(self, rows):
+        return self._can_fuse_rows(self.density_bitfield.is_cuda, 2, rows)
+
     def _can_fuse(self, x):
-        return (self.fused_mlp and x.is_cuda and x.dim() == 2 and x.shape[0] > 0 and x.shape[0] % 128 == 0
+        return self._can_fuse_rows(x.is_cuda, x.dim(), x.shape[0])
+
+    def _can_fuse_rows(self, is_cuda, ndim, rows):
+        return (self.fused_mlp and is_cuda and ndim == 2 and rows > 0 and rows % 128 == 0
                 and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16
                 and self.num_layers == 2 and self.hidden_dim == 64 and self.geo_feat_dim == 15 and self.in_dim == 32
                 and self.num_layers_color == 3 and self.hidden_dim_color == 64 and self.in_dim_color == 32

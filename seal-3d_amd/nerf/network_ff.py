@@ -89,8 +89,14 @@ class NeRFNetwork(NeRFRenderer):
 
     fused_head = os.environ.get("S3D_FUSED_HEAD", "1") != "0"  # tests / A-B runs: False = the reference op sequence
 
+    def honours_row_limit(self, rows):
+        return self._can_fuse_on(self.density_bitfield.is_cuda) and rows > 0 and rows % 128 == 0
+
     def _can_fuse(self, x):
-        return (self.fused_head and x.is_cuda and torch.is_autocast_enabled("cuda")
+        return self._can_fuse_on(x.is_cuda)
+
+    def _can_fuse_on(self, is_cuda):
+        return (self.fused_head and is_cuda and torch.is_autocast_enabled("cuda")
                 and torch.get_autocast_dtype("cuda") == torch.float16
                 and getattr(self.encoder_dir, "degree", None) == 4 and self.geo_feat_dim == 15
                 and self.sigma_net.padded_output_dim == 16 and self.color_net.input_dim == 32

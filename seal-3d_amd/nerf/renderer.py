@@ -68,6 +68,16 @@ class NeRFRenderer(nn.Module):
             self.mean_count = 0
             self.local_step = 0
 
+    def honours_row_limit(self, rows):
+        """True when forward() on a [rows, 3] batch takes the announced device-side sample count (s3d_hip.row_limit) on its
+        whole path — then run_cuda keeps un-budgeted sample buffers at their full static extent instead of reading the
+        count back to trim them"""
+        return False
+
+    def honours_row_limit_under_autocast(self, rows):
+        with torch.autocast("cuda", dtype=torch.float16):
+            return bool(self.honours_row_limit(rows))
+
     # ---- per-sample hooks (identity here; the Seal teacher overrides them, SealNeRF/renderer.py:291-316, 381-399)
     def map_samples(self, xyzs, dirs):
         return xyzs, dirs, None
@@ -118,13 +128,22 @@ class NeRFRenderer(nn.Module):
             counter = self.step_counter[self.local_step % 16]
             counter.zero_()
             self.local_step += 1
+            budgeted = (not force_all_rays) and self.mean_count > 0
+            trim = budgeted or not self.honours_row_limit(N * max_steps)  # (no budget: N * max_steps rows, 128-aligned)
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, counter,
-                self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
-            mxyzs, mdirs, mmask = self.map_samples(xyzs, dirs)
+                self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps, *(() if trim else (False,)))
             # the buffers are padded to M rows (raymarching.py:205-207); counter[0] says on the device how many hold samples
-            with s3d_hip.row_limit(counter, xyzs.shape[0]):
-                sigmas, rgbs = self(mxyzs, mdirs)
+            # (a proxy mapper skips the rows behind the count only when the network behind it skips them too: otherwise the
+            #  network would read rows the mapper never wrote)
+            if self.honours_row_limit(xyzs.shape[0]):
+                with s3d_hip.row_limit(counter, xyzs.shape[0]):
+                    mxyzs, mdirs, mmask = self.map_samples(xyzs, dirs)
+                    sigmas, rgbs = self(mxyzs, mdirs)
+            else:
+                mxyzs, mdirs, mmask = self.map_samples(xyzs, dirs)
+                with s3d_hip.row_limit(counter, xyzs.shape[0]):
+                    sigmas, rgbs = self(mxyzs, mdirs)
             if self.density_scale != 1:  # (x1 is the identity: skip the pass over [M])
                 sigmas = self.density_scale * sigmas
             rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)

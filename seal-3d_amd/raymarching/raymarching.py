@@ -131,7 +131,10 @@ class _MarchRaysTrain(Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
-                perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
+                perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, trim=True):
+        """`trim=False` (build extension): without a sample budget the reference reads the sample count back and trims the
+        N * max_steps buffers (raymarching.py:223-231: a device->host sync).  A caller whose whole sample path takes the
+        device-side count (`n_valid`, seal3d_hip.h) keeps the full buffers instead: no sync, static shapes."""
         rays_o, rays_d = _rays(rays_o, rays_d)
         density_bitfield = _on_device(density_bitfield).contiguous()
         dev, dt = rays_o.device, rays_o.dtype
@@ -152,7 +155,7 @@ class _MarchRaysTrain(Function):
         _backend.march_rays_train(rays_o, rays_d, density_bitfield, bound, dt_gamma, max_steps, N, C, H, M,
                                   nears.contiguous(), fars.contiguous(), xyzs, dirs, deltas, rays, step_counter, noises)
 
-        if not budgeted:
+        if not budgeted and trim:
             # first iterations only: one D2H read to trim the over-allocation (raymarching.py:223-231)
             m = _align_up(int(step_counter[0].item()), align)
             xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]

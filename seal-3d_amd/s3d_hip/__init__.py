@@ -583,7 +583,7 @@ class SealBackend:
     """csrc/seal.hip — Seal-3D's bbox proxy mapper (SealNeRF/seal_utils.py:132-279, 630-685) on the device"""
 
     @staticmethod
-    def bbox_map(points, dirs, host, out_points, out_dirs, mask):
+    def bbox_map(points, dirs, host, out_points, out_dirs, mask, n_valid=None):
         """`host`: dict of float32 numpy arrays (triangles, bounds, inv_transform, inv_rotation, inv_scale, center and
         optionally empty_bound, map_source) — the edit's constants live on the host."""
         import numpy as np
@@ -602,7 +602,7 @@ class SealBackend:
         ptr = [k[1] for k in keep]
         _check(lib().s3d_seal_bbox_map(_p(points), _p(dirs), _u(points.shape[0]), ptr[0], _u(keep[0][0].shape[0]), ptr[1],
                                        _u(keep[1][0].shape[0]), ptr[2], ptr[3], ptr[4], ptr[5], ptr[6], ptr[7], _p(out_points),
-                                       _p(out_dirs), _p(mask), _stream()), "seal_bbox_map")
+                                       _p(out_dirs), _p(mask), _nv(n_valid), _stream()), "seal_bbox_map")
 
 
 class VmBackend:

@@ -195,7 +195,9 @@ class SealBBoxMapper:
         out_p = torch.empty_like(p)
         out_d = torch.empty_like(d) if d is not None else None
         mask = torch.empty(p.shape[0], dtype=torch.bool, device=p.device)
-        s3d_hip.SealBackend.bbox_map(p, d, self._host, out_p, out_d, mask.view(torch.uint8))
+        # inside a renderer's announced padded batch (s3d_hip.row_limit) the rows behind the sample count are skipped, like
+        # in every other per-sample kernel of that path
+        s3d_hip.SealBackend.bbox_map(p, d, self._host, out_p, out_d, mask.view(torch.uint8), s3d_hip.active_row_limit(p.shape[0]))
         return out_p.view(lead), (out_d.view(dirs.shape) if dirs is not None else None), mask
 
     @torch.autocast("cuda", enabled=False)

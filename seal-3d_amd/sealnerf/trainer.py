@@ -231,6 +231,28 @@ class GraphedSealTrainer(SealSteps, GraphedTrainer):
         GraphedTrainer.__init__(self, student, num_rays, lr=lr, fp16=fp16, dist=dist, **kw)
         self._init_seal(teacher, lr, depth_weight)
         self.s_depth = torch.zeros(num_rays, device=self.s_ro.device)
+        self.proxy_graph = None
+
+    graph_proxy = True  # the teacher's proxy render replayed from its own HIP graph (static rays in, static targets out)
+
+    def _proxy_replay(self):
+        """teacher proxy render of the rays in s_ro / s_rd into s_gt / s_depth.  The render takes run_cuda's un-budgeted
+        training branch (force_all_rays): N * max_steps sample rows of static extent, the real count on the device (every
+        kernel of the two-encoder network takes it as n_valid) — no host read-back, so it can be captured."""
+        def body():
+            img, dep = self.proxy_truth(self.s_ro, self.s_rd)
+            torch._foreach_copy_([self.s_gt, self.s_depth], [img.reshape(-1, 3), dep.reshape(-1)])
+        if self.proxy_graph is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                body()  # warm-up = this call's render
+            torch.cuda.current_stream().wait_stream(side)
+            self.proxy_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.proxy_graph, capture_error_mode=_CAPTURE_MODE):
+                body()
+            return
+        self.proxy_graph.replay()
 
     def _static_loss(self):
         loss, _ = self.finetune_loss(self.s_ro, self.s_rd, self.s_gt, self.s_depth, bg_color=1)
@@ -238,6 +260,8 @@ class GraphedSealTrainer(SealSteps, GraphedTrainer):
 
     def _stage_inputs(self, rays_o, rays_d, gt_rgb):
         gt_rgb, gt_depth = gt_rgb
+        if gt_rgb is self.s_gt:  # targets (and rays) were staged by the proxy graph's caller
+            return
         torch._foreach_copy_([self.s_ro, self.s_rd, self.s_gt, self.s_depth],
                              [rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), gt_rgb.reshape(-1, 3), gt_depth.reshape(-1)])
 
@@ -246,5 +270,12 @@ class GraphedSealTrainer(SealSteps, GraphedTrainer):
 
     def train_step(self, rays_o, rays_d, gt_rgb=None, gt_depth=None, bg_color=1):
         if gt_rgb is None:
-            gt_rgb, gt_depth = self.proxy_truth(rays_o, rays_d)
+            ok = (self.graph_proxy and self.fp16 and rays_o.is_cuda and rays_o.numel() == self.s_ro.numel()
+                  and self.teacher.honours_row_limit_under_autocast(rays_o.numel() // 3 * self.render_kwargs["max_steps"]))
+            if ok:
+                torch._foreach_copy_([self.s_ro, self.s_rd], [rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)])
+                self._proxy_replay()
+                gt_rgb, gt_depth = self.s_gt, self.s_depth
+            else:
+                gt_rgb, gt_depth = self.proxy_truth(rays_o, rays_d)
         return GraphedTrainer.train_step(self, rays_o, rays_d, (gt_rgb, gt_depth), bg_color)
