@@ -407,9 +407,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    # samples are counted from the renderer's own 16-step counter ring, read when it is about to be restarted (not per step:
+    # the bookkeeping is not part of the reference's step either)
+    ring_from = model.local_step % 16
     for i in range(args.steps):
         step(i)
-        samples_dev += model.step_counter[(model.local_step - 1) % 16, 0].long()
+        if model.local_step % 16 == 0 or trainer.global_step % trainer.update_extra_interval == 0:
+            samples_dev += model.step_counter[ring_from:(model.local_step - 1) % 16 + 1, 0].sum()
+            ring_from = 0 if trainer.global_step % trainer.update_extra_interval == 0 else model.local_step % 16
+    if model.local_step % 16 != ring_from:
+        samples_dev += model.step_counter[ring_from:model.local_step % 16, 0].sum()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -308,6 +308,12 @@ int s3d_adam_advance(float* step, const float* found_inf, s3d_stream_t stream);
 /* GradScaler.update(): scale *= backoff on overflow, *= growth after growth_interval clean steps; clears *found_inf. */
 int s3d_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, float growth_factor,
                       float backoff_factor, int32_t growth_interval, s3d_stream_t stream);
+/* Build extension (graph-replayed step): the renderer keeps the marcher's {samples, rays} counters of the last 16 training
+ * steps (nerf/renderer.py:106, 352-356: `step_counter[local_step % 16]`).  Device-side equivalent of that bookkeeping:
+ * slot = *cursor; loss_ring[slot] = *loss (both optional); counter_ring[slot] = counter[0..1]; counter[0..1] = 0;
+ * *cursor = (slot + 1) % ring. */
+int s3d_step_ring_push(const float* loss, int32_t* counter, float* loss_ring, int32_t* counter_ring, int32_t* cursor,
+                       int32_t ring, s3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -567,7 +567,9 @@ __device__ __forceinline__ void flush_matrix(float* __restrict__ red, float* __r
     }
 }
 
-template <int W, int NH, int IMB, int ACT>
+// KS0T: compile-time in_dim / 16 (0 = run-time).  With a run-time count every layer-0 MFMA step sits in its own branch and
+// the compiler shuttles the accumulators between VGPRs and AGPRs around each one (~1000 v_accvgpr moves per tile).
+template <int W, int NH, int IMB, int ACT, int KS0T>
 __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __restrict__ grad, const _Float16* __restrict__ X,
                                                              const _Float16* __restrict__ Wt, uint32_t B, uint32_t in_dim,
                                                              uint32_t out_dim, uint32_t act, _Float16* __restrict__ grad_inputs,
@@ -577,7 +579,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = lane & 31, h = lane >> 5;
-    const uint32_t KS0 = in_dim / 16;
+    const uint32_t KS0 = KS0T ? (uint32_t)KS0T : in_dim / 16;
     // LDS: forward A frags [layer0: MB*KS0 | hidden: NH*MB*KS] | transposed A frags [last^T: MB | hidden^T: NH*MB*KS |
     //      first^T: IMB*KS (only with grad_inputs)] | per-wave transpose tiles TG, TX | (aliased at the end) red[64*64]
     const uint32_t nf_f0 = MB * KS0, nf_fh = NH * MB * KS;
@@ -890,7 +892,7 @@ inline bool fused_backward_supported(uint32_t in_dim, uint32_t out_dim, uint32_t
            n_layers >= 2 && n_layers - 1 <= fused_max_hidden(W) && act != ACT_SINE;
 }
 
-template <int W, int NH, int IMB, int ACT>
+template <int W, int NH, int IMB, int ACT, int KS0T>
 int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t in_dim,
                             uint32_t out_dim, uint32_t act, _Float16* grad_inputs, _Float16* grad_weights, float* partial,
                             uint32_t in_layout, uint32_t accumulate, hipStream_t st) {
@@ -901,14 +903,14 @@ int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Floa
     static std::atomic<uint64_t> attr_devs{0};
     int dev;
     if (device_needs_setup(attr_devs, &dev)) {
-        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_backward_fused<W, NH, IMB, ACT>),
+        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_backward_fused<W, NH, IMB, ACT, KS0T>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         device_setup_done(attr_devs, dev);
     }
     const uint32_t ntiles = B / 32;
     uint32_t nblk = div_up<uint32_t>(ntiles, 4);
     if (nblk > kWgradBlocks) nblk = kWgradBlocks;
-    hipLaunchKernelGGL((k_ffmlp_backward_fused<W, NH, IMB, ACT>), dim3(nblk), dim3(256), smem, st, grad, X, Wt, B, in_dim, out_dim,
+    hipLaunchKernelGGL((k_ffmlp_backward_fused<W, NH, IMB, ACT, KS0T>), dim3(nblk), dim3(256), smem, st, grad, X, Wt, B, in_dim, out_dim,
                        act, grad_inputs, partial, in_layout, t_n_valid);
     WgradPlan plan;
     memset(&plan, 0, sizeof(plan));
@@ -927,9 +929,12 @@ int launch_backward_fused(const _Float16* grad, const _Float16* X, const _Float1
                           uint32_t out_dim, uint32_t n_layers, uint32_t act, _Float16* gi, _Float16* gw, float* partial,
                           uint32_t in_layout, uint32_t accumulate, hipStream_t st) {
     const uint32_t NH = n_layers - 1, IMB = (in_dim + 31) / 32;
-#define S3D_FUSED(NHV, IMBV)                                                                                              \
-    (act == ACT_RELU ? launch_backward_fused_k<W, NHV, IMBV, ACT_RELU>(grad, X, Wt, B, in_dim, out_dim, act, gi, gw, partial, in_layout, accumulate, st) \
-                     : launch_backward_fused_k<W, NHV, IMBV, -1>(grad, X, Wt, B, in_dim, out_dim, act, gi, gw, partial, in_layout, accumulate, st))
+#define S3D_FUSED_K(NHV, IMBV, ACTV, KSV) \
+    launch_backward_fused_k<W, NHV, IMBV, ACTV, KSV>(grad, X, Wt, B, in_dim, out_dim, act, gi, gw, partial, in_layout, accumulate, st)
+    // the hot path's networks (ReLU, in_dim a multiple of 32) get the layer-0 step count at compile time
+#define S3D_FUSED(NHV, IMBV)                                                                                  \
+    (act == ACT_RELU ? (in_dim == 32u * IMBV ? S3D_FUSED_K(NHV, IMBV, ACT_RELU, 2 * IMBV) : S3D_FUSED_K(NHV, IMBV, ACT_RELU, 0)) \
+                     : S3D_FUSED_K(NHV, IMBV, -1, 0))
     if (IMB == 1) {
         if (NH == 1) return S3D_FUSED(1, 1);
         if (NH == 2) return S3D_FUSED(2, 1);
@@ -942,6 +947,7 @@ int launch_backward_fused(const _Float16* grad, const _Float16* X, const _Float1
     set_error("ffmlp_backward: fused kernel does not cover %u hidden matrices at width %d", NH, W);
     return S3D_ERR_UNSUPPORTED;
 #undef S3D_FUSED
+#undef S3D_FUSED_K
 }
 
 }  // namespace

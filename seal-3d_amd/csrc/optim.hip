@@ -30,23 +30,74 @@ __global__ void __launch_bounds__(256) k_grads_nonfinite(const G* __restrict__ g
     if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) *found_inf = 1.0f;  // benign race: everyone writes 1
 }
 
+struct AdamCoef {
+    float beta1, beta2, eps, inv_scale, step_size, bc2_sqrt;
+};
+__device__ __forceinline__ void adam_update(const AdamCoef& c, float g, float& m, float& v, float& p) {
+    const float gi = g * c.inv_scale;
+    m = m + (1.0f - c.beta1) * (gi - m);
+    v = c.beta2 * v + (1.0f - c.beta2) * gi * gi;
+    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+    p = p - c.step_size * (m / denom);
+}
+
+template <typename G> struct GradVec4;
+template <> struct GradVec4<float> {
+    static __device__ __forceinline__ void load(const float* g, size_t i, float (&o)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(g + i);
+        o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+    }
+};
+template <> struct GradVec4<__half> {
+    static __device__ __forceinline__ void load(const __half* g, size_t i, float (&o)[4]) {
+        const uint2 t = *reinterpret_cast<const uint2*>(g + i);
+        const __half2 a = *reinterpret_cast<const __half2*>(&t.x), b = *reinterpret_cast<const __half2*>(&t.y);
+        o[0] = __low2float(a); o[1] = __high2float(a); o[2] = __low2float(b); o[3] = __high2float(b);
+    }
+};
+
+// Four consecutive elements per lane and trip (16-byte accesses of the fp32 state, 8-byte of the fp16 gradient / copy): the
+// update streams 28 B per element and is HBM-bound; `vec` is false for a tensor whose pointers are not 16-byte aligned.
 template <typename G>
 __global__ void __launch_bounds__(256) k_adam_step(float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, __half* __restrict__ p_half, size_t n, float lr,
                                                    float beta1, float beta2, float eps, const float* __restrict__ step,
-                                                   const float* __restrict__ grad_scale, const float* __restrict__ found_inf) {
+                                                   const float* __restrict__ grad_scale, const float* __restrict__ found_inf,
+                                                   uint32_t vec) {
     if (found_inf && *found_inf != 0.0f) return;  // the whole step is skipped (GradScaler.step)
     const float t = *step + 1.0f;                 // this update's step number; k_adam_advance stores it afterwards
-    const float inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
+    AdamCoef c;
+    c.beta1 = beta1; c.beta2 = beta2; c.eps = eps;
+    c.inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
     const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
-    const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float gi = grad_to_f<G>(g[i]) * inv_scale;
+    c.step_size = lr / bc1;
+    c.bc2_sqrt = sqrtf(bc2);
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
+    const size_t n4 = vec ? n / 4 : 0;
+    for (size_t q = tid; q < n4; q += nthreads) {
+        const size_t i = q * 4;
+        float gi[4];
+        GradVec4<G>::load(g, i, gi);
+        float4 mi = *reinterpret_cast<const float4*>(m + i), vi = *reinterpret_cast<const float4*>(v + i),
+               pi = *reinterpret_cast<const float4*>(p + i);
+        adam_update(c, gi[0], mi.x, vi.x, pi.x);
+        adam_update(c, gi[1], mi.y, vi.y, pi.y);
+        adam_update(c, gi[2], mi.z, vi.z, pi.z);
+        adam_update(c, gi[3], mi.w, vi.w, pi.w);
+        *reinterpret_cast<float4*>(m + i) = mi;
+        *reinterpret_cast<float4*>(v + i) = vi;
+        *reinterpret_cast<float4*>(p + i) = pi;
+        if (p_half) {
+            const __half2 a = __floats2half2_rn(pi.x, pi.y), b = __floats2half2_rn(pi.z, pi.w);
+            uint2 o;
+            o.x = *reinterpret_cast<const uint32_t*>(&a);
+            o.y = *reinterpret_cast<const uint32_t*>(&b);
+            *reinterpret_cast<uint2*>(p_half + i) = o;
+        }
+    }
+    for (size_t i = n4 * 4 + tid; i < n; i += nthreads) {
         float mi = m[i], vi = v[i], pi = p[i];
-        mi = mi + (1.0f - beta1) * (gi - mi);
-        vi = beta2 * vi + (1.0f - beta2) * gi * gi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi = pi - step_size * (mi / denom);
+        adam_update(c, grad_to_f<G>(g[i]), mi, vi, pi);
         m[i] = mi;
         v[i] = vi;
         p[i] = pi;
@@ -78,6 +129,21 @@ __global__ void k_scaler_update(float* __restrict__ scale, int32_t* __restrict__
     *found_inf = 0.0f;
 }
 
+// End of a graph-replayed training step: file the step's loss and the marcher's {samples, rays} counter in their 16-slot rings
+// (nerf/renderer.py keeps the counters of the last 16 steps for `mean_count`), clear the counter for the next replay and
+// advance the slot — what the host otherwise does with two copies and a fill per step.
+__global__ void k_step_ring_push(const float* __restrict__ loss, int32_t* __restrict__ counter, float* __restrict__ loss_ring,
+                                 int32_t* __restrict__ counter_ring, int32_t* __restrict__ cursor, int32_t ring) {
+    int32_t c = *cursor;
+    if (c < 0 || c >= ring) c = 0;
+    if (loss && loss_ring) loss_ring[c] = *loss;
+    counter_ring[2 * c] = counter[0];
+    counter_ring[2 * c + 1] = counter[1];
+    counter[0] = 0;
+    counter[1] = 0;
+    *cursor = (c + 1) % ring;
+}
+
 }  // namespace
 }  // namespace s3d
 
@@ -101,13 +167,16 @@ S3D_EXPORT int s3d_adam_step(float* param, const void* grad, int grad_dtype, flo
     if (n == 0) return S3D_OK;
     S3D_REQUIRE(param && grad && exp_avg && exp_avg_sq && step, "adam_step: null pointer");
     S3D_REQUIRE(grad_dtype == S3D_F32 || grad_dtype == S3D_F16, "adam_step: grad dtype must be f32 or f16");
-    const uint32_t grid = stream_grid(n / 4 + 1, 256);
+    const uint32_t grid = stream_grid(n / 8 + 1, 256);
+    const uintptr_t bits = (uintptr_t)param | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | ((uintptr_t)grad << (grad_dtype == S3D_F16 ? 1 : 0)) |
+                           ((uintptr_t)param_half << 1);
+    const uint32_t vec = (bits & 15) == 0;
     if (grad_dtype == S3D_F16)
         hipLaunchKernelGGL(k_adam_step<__half>, dim3(grid), dim3(256), 0, as_stream(stream), param, (const __half*)grad, exp_avg,
-                           exp_avg_sq, (__half*)param_half, n, lr, beta1, beta2, eps, step, grad_scale, found_inf);
+                           exp_avg_sq, (__half*)param_half, n, lr, beta1, beta2, eps, step, grad_scale, found_inf, vec);
     else
         hipLaunchKernelGGL(k_adam_step<float>, dim3(grid), dim3(256), 0, as_stream(stream), param, (const float*)grad, exp_avg,
-                           exp_avg_sq, (__half*)param_half, n, lr, beta1, beta2, eps, step, grad_scale, found_inf);
+                           exp_avg_sq, (__half*)param_half, n, lr, beta1, beta2, eps, step, grad_scale, found_inf, vec);
     return check_launch("adam_step");
 }
 
@@ -123,4 +192,11 @@ S3D_EXPORT int s3d_scaler_update(float* scale, int32_t* growth_tracker, float* f
     hipLaunchKernelGGL(k_scaler_update, dim3(1), dim3(1), 0, as_stream(stream), scale, growth_tracker, found_inf, growth_factor,
                        backoff_factor, growth_interval);
     return check_launch("scaler_update");
+}
+
+S3D_EXPORT int s3d_step_ring_push(const float* loss, int32_t* counter, float* loss_ring, int32_t* counter_ring, int32_t* cursor,
+                                  int32_t ring, s3d_stream_t stream) {
+    S3D_REQUIRE(counter && counter_ring && cursor && ring > 0, "step_ring_push: null pointer or empty ring");
+    hipLaunchKernelGGL(k_step_ring_push, dim3(1), dim3(1), 0, as_stream(stream), loss, counter, loss_ring, counter_ring, cursor, ring);
+    return check_launch("step_ring_push");
 }

@@ -126,7 +126,8 @@ class NeRFRenderer(nn.Module):
         results = {}
         if self.training:
             counter = self.step_counter[self.local_step % 16]
-            counter.zero_()
+            if not getattr(self, "_counter_prezeroed", False):  # (a graph-replayed step clears it behind itself, nerf/trainer.py)
+                counter.zero_()
             self.local_step += 1
             budgeted = (not force_all_rays) and self.mean_count > 0
             trim = budgeted or not self.honours_row_limit(N * max_steps)  # (no budget: N * max_steps rows, 128-aligned)

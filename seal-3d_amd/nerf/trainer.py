@@ -161,6 +161,7 @@ class Trainer:
 # polls its work events (hipEventQuery) at any time, and under the default "global" mode such a poll during one of the
 # captures below aborts the process ("operation not permitted when stream is capturing").
 _CAPTURE_MODE = "thread_local"
+_RING_PUSH = __import__("os").environ.get("S3D_RING_PUSH", "1") != "0"  # A/B switch: 0 = host-side ring bookkeeping
 
 
 class GraphedTrainer(Trainer):
@@ -193,6 +194,10 @@ class GraphedTrainer(Trainer):
         self.budget = 0
         self.s_loss = None
         self.s_counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        # the graph itself files each step's loss and sample counter in 16-slot rings (seal3d_hip.h: s3d_step_ring_push)
+        self.loss_ring = torch.zeros(16, dtype=torch.float32, device=dev)
+        self.s_cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._counter_ring = None
 
     def _static_loss(self):
         """the step's loss on the static input buffers (subclasses: other criteria, e.g. Seal's depth term)"""
@@ -208,7 +213,12 @@ class GraphedTrainer(Trainer):
         self.optimizer.zero_grad(set_to_none=self.dist is None)
         loss = self._static_loss()
         self._backward(loss)
-        return loss.detach()
+        loss = loss.detach()
+        if self._counter_ring is not None:
+            import s3d_hip
+            s3d_hip.OptimBackend.step_ring_push(loss.float().reshape(()), self.s_counter, self.loss_ring, self._counter_ring,
+                                                self.s_cursor)
+        return loss
 
     def _body_opt(self):
         self.scaler.step(self.optimizer)
@@ -224,9 +234,14 @@ class GraphedTrainer(Trainer):
         self.budget = int(max(model.mean_count, 1) * self.budget_factor)
         saved = (model.mean_count, model.local_step)
         model.mean_count = self.budget
-        # the graph always writes counter slot 0 of a private buffer; the ring buffer is maintained outside
+        # the marcher always counts in a private buffer; the last kernel of the step files it in the ring slot of a device
+        # cursor (which follows `local_step % 16`), and leaves the private counter cleared for the next replay
         ring = model.step_counter
+        self._counter_ring = ring if ring.is_contiguous() and ring.dtype == torch.int32 and _RING_PUSH else None
+        self.s_counter.zero_()
+        self.s_cursor.fill_(saved[1] % 16)
         model.step_counter = self.s_counter.view(1, 2).expand(16, 2)
+        model._counter_prezeroed = self._counter_ring is not None
         model.local_step = 0
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -255,10 +270,12 @@ class GraphedTrainer(Trainer):
             with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._body_opt()
         model.step_counter = ring
+        model._counter_prezeroed = False
         model.mean_count, model.local_step = saved
 
     def load_checkpoint(self, checkpoint, model_only=False):
         out = super().load_checkpoint(checkpoint, model_only=model_only)
+        self._counter_ring = None
         self.graph = self.graph_opt = None  # optimizer state tensors were replaced, mean_count may have moved: re-capture
         return out
 
@@ -302,9 +319,10 @@ class GraphedTrainer(Trainer):
     def train_step(self, rays_o, rays_d, gt_rgb, bg_color=1):
         model = self.model
         model.train()
-        if self._maybe_update_extra_state() and self.graph is not None and \
-                (model.mean_count * 1.1 > self.budget or model.mean_count * 2 < self.budget):
-            self.graph = None  # the running mean left the static budget's useful range: re-capture
+        if self._maybe_update_extra_state():
+            self.s_cursor.zero_()  # (update_extra_state restarts the counter ring: local_step = 0)
+            if self.graph is not None and (model.mean_count * 1.1 > self.budget or model.mean_count * 2 < self.budget):
+                self.graph = None  # the running mean left the static budget's useful range: re-capture
         self.global_step += 1
         if self.graph is None and model.mean_count <= 0:
             # no sample statistics yet (first 16 steps): eager step with the wrapper's host sync
@@ -316,10 +334,14 @@ class GraphedTrainer(Trainer):
         if self.graph is None:
             self._capture()  # runs this step eagerly (one optimizer update), then records the graph
             loss = self.s_warm_loss
+            filed = self._counter_ring is not None
         else:
             self._replay()
-            loss = self.s_loss.clone()  # (the static buffer is overwritten by the next replay)
+            filed = self._counter_ring is not None
+            # (the static loss buffer is overwritten by the next replay; a ring slot only 16 steps later)
+            loss = self.loss_ring[model.local_step % 16] if filed else self.s_loss.clone()
         bump_weights_epoch()  # replays update the parameters without touching Tensor._version
-        model.step_counter[model.local_step % 16].copy_(self.s_counter)
+        if not filed:
+            model.step_counter[model.local_step % 16].copy_(self.s_counter)
         model.local_step += 1
         return loss

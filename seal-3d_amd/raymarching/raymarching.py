@@ -182,6 +182,7 @@ class _CompositeRaysTrain(Function):
                                               depth, image)
         ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
         ctx.dims = (M, N, T_thresh)
+        ctx.set_materialize_grads(False)  # depth takes no gradient (below): no zero tensor made for it every step
         return weights_sum, depth, image
 
     @staticmethod
@@ -189,6 +190,12 @@ class _CompositeRaysTrain(Function):
     def backward(ctx, grad_weights_sum, grad_depth, grad_image):
         sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
         M, N, T_thresh = ctx.dims
+        if grad_weights_sum is None and grad_image is None:
+            return None, None, None, None, None
+        if grad_weights_sum is None:
+            grad_weights_sum = torch.zeros_like(weights_sum)
+        if grad_image is None:
+            grad_image = torch.zeros_like(image)
         # zero-initialised like the reference (raymarching.py:283-284) — one fill for both
         flat = torch.zeros(sigmas.numel() + rgbs.numel(), dtype=sigmas.dtype, device=sigmas.device)
         grad_sigmas = flat[:sigmas.numel()].view_as(sigmas)

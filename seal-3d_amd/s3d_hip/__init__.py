@@ -38,7 +38,7 @@ EXPORTS = [
     "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
     "s3d_ffmlp_fused_backward_supported",
     "s3d_ffmlp_allocate_splitk", "s3d_ffmlp_free_splitk",
-    "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_advance", "s3d_scaler_update",
+    "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_advance", "s3d_scaler_update", "s3d_step_ring_push",
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_mid2_forward", "s3d_ngp_mid2_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
     "s3d_bg_mse_forward", "s3d_bg_mse_backward",
     "s3d_seal_bbox_map", "s3d_vm_features_forward",
@@ -191,16 +191,24 @@ def _need(t, dtype, name):
 
 
 class _Workspace:
-    """Per-device scratch owned by the binding (grown on demand, reused)."""
+    """Per-device, per-stream scratch owned by the binding (grown on demand, reused).  While the stream is being captured
+    into a HIP graph the scratch is a plain temporary instead: a cached tensor would come out of THAT graph's private memory
+    pool and dangle for every later caller once the graph is destroyed (torch captures every graph on the same stream)."""
 
     def __init__(self):
         self.buf = {}
 
     def get(self, nbytes, device):
+        n = max(int(nbytes), 1 << 16)
+        if torch.cuda.is_current_stream_capturing():
+            return torch.empty(n, dtype=torch.uint8, device=device)
         key = (device.index, torch.cuda.current_stream(device).cuda_stream)
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
-            b = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+            if b is None and len(self.buf) >= 16:  # (streams come and go: drop the oldest entries)
+                for k in list(self.buf)[:8]:
+                    del self.buf[k]
+            b = torch.empty(n, dtype=torch.uint8, device=device)
             self.buf[key] = b
         return b
 
@@ -511,6 +519,19 @@ class OptimBackend:
     @staticmethod
     def adam_advance(step, found_inf):
         _check(lib().s3d_adam_advance(_p(step), _p(found_inf), _stream()), "adam_advance")
+
+    @staticmethod
+    def step_ring_push(loss, counter, loss_ring, counter_ring, cursor):
+        """file `loss` [] / `counter` [2] in slot *cursor of the rings, clear the counter, advance the cursor (seal3d_hip.h)"""
+        _need(counter, torch.int32, "counter"); _need(counter_ring, torch.int32, "counter_ring")
+        _need(cursor, torch.int32, "cursor")
+        if loss is not None:
+            _need(loss, torch.float32, "loss"); _need(loss_ring, torch.float32, "loss_ring")
+        ring = counter_ring.shape[0]
+        if not counter_ring.is_contiguous() or counter_ring.numel() != 2 * ring or (loss is not None and loss_ring.numel() != ring):
+            raise RuntimeError("step_ring_push: rings must be contiguous [ring, 2] / [ring]")
+        _check(lib().s3d_step_ring_push(_p(loss), _p(counter), _p(loss_ring if loss is not None else None), _p(counter_ring),
+                                        _p(cursor), C.c_int32(ring), _stream()), "step_ring_push")
 
 
 class NgpHeadBackend:

@@ -56,6 +56,29 @@ def test_training_variants_converge_alike(hip, variant):
         assert model.encoder.embeddings.grad is not None and not hasattr(model.encoder.embeddings, "_s3d_grad")
 
 
+def test_second_graphed_trainer_after_the_first_is_gone(hip):
+    """Scratch buffers of the binding must not come out of a graph's private memory pool: a second trainer in the same
+    process used to replay kernels on scratch that died with the first trainer's graph (illegal memory access)."""
+    import gc
+    from nerf.trainer import GraphedTrainer
+    model, batches = _setup()
+    tr = GraphedTrainer(model, 2048, lr=1e-2, fp16=True)
+    _run(tr, batches, 24)
+    assert tr.graph is not None
+    del tr, model
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    model, batches = _setup()
+    tr = GraphedTrainer(model, 2048, lr=1e-2, fp16=True)
+    losses = _run(tr, batches, 40)
+    torch.cuda.synchronize()
+    assert tr.graph is not None and torch.isfinite(losses).all()
+    # the step's loss and sample counter are filed by the graph itself: the ring matches the marcher's private counter
+    assert int(model.step_counter[(model.local_step - 1) % 16, 0]) > 0
+    assert float(losses[-1]) == float(tr.loss_ring[(model.local_step - 1) % 16])
+
+
 def test_data_parallel_split_graph_step_single_rank(hip):
     """The multi-GPU step (two graphs with an eager all-reduce in between, fp16 flat bucket) on a 1-rank RCCL group."""
     import torch.distributed as dist

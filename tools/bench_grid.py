@@ -33,6 +33,27 @@ def timeit(fn, iters, warm=2):
     return s.elapsed_time(e) / iters * 1e-3
 
 
+_FLUSH = None
+
+
+def timeit_cold(fn, iters, mbytes=1024):
+    """per-launch HIP events with a cache-thrashing pass (read-modify-write of `mbytes` MiB) before every launch: the time
+    of a launch that finds neither the table nor the points in L2 / MALL, as inside a training step"""
+    global _FLUSH
+    if _FLUSH is None:
+        _FLUSH = torch.zeros(mbytes << 18, dtype=torch.float32, device="cuda")
+    tot = 0.0
+    for _ in range(iters):
+        _FLUSH.add_(1.0)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        torch.cuda.synchronize()
+        tot += s.elapsed_time(e)
+    return tot / iters * 1e-3
+
+
 def grid_meta(dev):
     pls = np.exp2(np.log2(2048 / 16) / 15)
     offs, off = [], 0
@@ -80,7 +101,11 @@ def main():
     ap.add_argument("--no_bwd", action="store_true")
     ap.add_argument("--no_fwd", action="store_true")
     ap.add_argument("--sum", action="store_true")
+    ap.add_argument("--cold", action="store_true", help="thrash L2/MALL before every timed launch")
     a = ap.parse_args()
+    if a.cold:
+        global timeit
+        timeit = lambda fn, iters, warm=2: timeit_cold(fn, iters)  # noqa: E731
     dev = "cuda"
     torch.manual_seed(0)
     G = s3d_hip.GridBackend
