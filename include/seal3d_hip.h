@@ -48,9 +48,13 @@ const char* s3d_version(void);
 /* ------------------------------------------------------------------ raymarching
  * raymarching/src/raymarching.h:7-18 (bindings.cpp:6-17) */
 
-/* raymarching.h:7  void near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars) */
+/* raymarching.h:7  void near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars)
+ * Build extension (all optional, NULL/0 = the reference call): noises [N] receives the per-ray jitter of march_rays_train's
+ * `perturb` (raymarching.py:211 draws it with torch.rand) as a counter-based uniform u01(noise_key, *noise_step, ray) —
+ * the step number lives in device memory, so a graph-replayed step draws fresh jitter without host-side RNG state. */
 int s3d_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N,
-                           float min_near, float* nears, float* fars, s3d_stream_t stream);
+                           float min_near, float* nears, float* fars, float* noises, const int32_t* noise_step,
+                           uint32_t noise_key, s3d_stream_t stream);
 
 /* raymarching.h:8  void sph_from_ray(rays_o, rays_d, radius, N, coords) */
 int s3d_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
@@ -305,13 +309,27 @@ int s3d_adam_step(float* param, const void* grad, int grad_dtype, float* exp_avg
                   uint16_t* param_half, size_t n, float lr, float beta1, float beta2, float eps,
                   const float* step, const float* grad_scale, const float* found_inf, s3d_stream_t stream);
 int s3d_adam_advance(float* step, const float* found_inf, s3d_stream_t stream);
-/* GradScaler.update(): scale *= backoff on overflow, *= growth after growth_interval clean steps; clears *found_inf. */
+/* s3d_adam_step for every tensor of the optimizer in one launch (same arithmetic per element). */
+typedef struct s3d_adam_tensor {
+    float* param;
+    const void* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    uint16_t* param_half; /* optional fp16 copy of the updated parameters */
+    size_t n;
+    float lr, beta1, beta2, eps;
+    int grad_dtype; /* S3D_F32 or S3D_F16 */
+} s3d_adam_tensor;
+int s3d_adam_step_multi(const s3d_adam_tensor* tensors /* host array */, int32_t n_tensors, const float* step,
+                        const float* grad_scale, const float* found_inf, s3d_stream_t stream);
+/* GradScaler.update(): scale *= backoff on overflow, *= growth after growth_interval clean steps; clears *found_inf.
+ * adam_step (optional): s3d_adam_advance of that step count folded into the same launch (before the flag is cleared). */
 int s3d_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, float growth_factor,
-                      float backoff_factor, int32_t growth_interval, s3d_stream_t stream);
+                      float backoff_factor, int32_t growth_interval, float* adam_step, s3d_stream_t stream);
 /* Build extension (graph-replayed step): the renderer keeps the marcher's {samples, rays} counters of the last 16 training
  * steps (nerf/renderer.py:106, 352-356: `step_counter[local_step % 16]`).  Device-side equivalent of that bookkeeping:
- * slot = *cursor; loss_ring[slot] = *loss (both optional); counter_ring[slot] = counter[0..1]; counter[0..1] = 0;
- * *cursor = (slot + 1) % ring. */
+ * slot = cursor[0]; loss_ring[slot] = *loss (both optional); counter_ring[slot] = counter[0..1]; counter[0..1] = 0;
+ * cursor[0] = (slot + 1) % ring; cursor[1] += 1 (running step number, the `noise_step` of s3d_near_far_from_aabb). */
 int s3d_step_ring_push(const float* loss, int32_t* counter, float* loss_ring, int32_t* counter_ring, int32_t* cursor,
                        int32_t ring, s3d_stream_t stream);
 

@@ -56,23 +56,10 @@ template <> struct GradVec4<__half> {
     }
 };
 
-// Four consecutive elements per lane and trip (16-byte accesses of the fp32 state, 8-byte of the fp16 gradient / copy): the
-// update streams 28 B per element and is HBM-bound; `vec` is false for a tensor whose pointers are not 16-byte aligned.
 template <typename G>
-__global__ void __launch_bounds__(256) k_adam_step(float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, __half* __restrict__ p_half, size_t n, float lr,
-                                                   float beta1, float beta2, float eps, const float* __restrict__ step,
-                                                   const float* __restrict__ grad_scale, const float* __restrict__ found_inf,
-                                                   uint32_t vec) {
-    if (found_inf && *found_inf != 0.0f) return;  // the whole step is skipped (GradScaler.step)
-    const float t = *step + 1.0f;                 // this update's step number; k_adam_advance stores it afterwards
-    AdamCoef c;
-    c.beta1 = beta1; c.beta2 = beta2; c.eps = eps;
-    c.inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
-    const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
-    c.step_size = lr / bc1;
-    c.bc2_sqrt = sqrtf(bc2);
-    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nthreads = (size_t)gridDim.x * 256;
+__device__ __forceinline__ void adam_range(const AdamCoef& c, float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m,
+                                           float* __restrict__ v, __half* __restrict__ p_half, size_t n, bool vec, size_t tid,
+                                           size_t nthreads) {
     const size_t n4 = vec ? n / 4 : 0;
     for (size_t q = tid; q < n4; q += nthreads) {
         const size_t i = q * 4;
@@ -105,6 +92,62 @@ __global__ void __launch_bounds__(256) k_adam_step(float* __restrict__ p, const 
     }
 }
 
+// Four consecutive elements per lane and trip (16-byte accesses of the fp32 state, 8-byte of the fp16 gradient / copy): the
+// update streams 28 B per element and is HBM-bound; `vec` is false for a tensor whose pointers are not 16-byte aligned.
+template <typename G>
+__global__ void __launch_bounds__(256) k_adam_step(float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, __half* __restrict__ p_half, size_t n, float lr,
+                                                   float beta1, float beta2, float eps, const float* __restrict__ step,
+                                                   const float* __restrict__ grad_scale, const float* __restrict__ found_inf,
+                                                   uint32_t vec) {
+    if (found_inf && *found_inf != 0.0f) return;  // the whole step is skipped (GradScaler.step)
+    const float t = *step + 1.0f;                 // this update's step number; k_adam_advance stores it afterwards
+    AdamCoef c;
+    c.beta1 = beta1; c.beta2 = beta2; c.eps = eps;
+    c.inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
+    const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
+    c.step_size = lr / bc1;
+    c.bc2_sqrt = sqrtf(bc2);
+    adam_range<G>(c, p, g, m, v, p_half, n, vec != 0, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+
+// Every tensor of the optimizer in ONE launch (the hot path updates a 12 M-element hash table and two ~10 K-element MLPs: the
+// small ones cost a launch each otherwise).  Blocks [first_block[i], first_block[i+1]) stride over tensor i.
+constexpr int kAdamMaxTensors = 16;
+struct AdamBatch {
+    float* p[kAdamMaxTensors];
+    const void* g[kAdamMaxTensors];
+    float* m[kAdamMaxTensors];
+    float* v[kAdamMaxTensors];
+    __half* h[kAdamMaxTensors];
+    size_t n[kAdamMaxTensors];
+    float lr[kAdamMaxTensors], beta1[kAdamMaxTensors], beta2[kAdamMaxTensors], eps[kAdamMaxTensors];
+    uint32_t first_block[kAdamMaxTensors + 1];
+    uint8_t half_grad[kAdamMaxTensors], vec[kAdamMaxTensors];
+    int32_t count;
+};
+
+__global__ void __launch_bounds__(256) k_adam_step_multi(AdamBatch b, const float* __restrict__ step,
+                                                         const float* __restrict__ grad_scale,
+                                                         const float* __restrict__ found_inf) {
+    if (found_inf && *found_inf != 0.0f) return;
+    int i = 0;
+    while (i + 1 < b.count && blockIdx.x >= b.first_block[i + 1]) i++;
+    const float t = *step + 1.0f;
+    AdamCoef c;
+    c.beta1 = b.beta1[i]; c.beta2 = b.beta2[i]; c.eps = b.eps[i];
+    c.inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
+    const float bc1 = 1.0f - powf(c.beta1, t), bc2 = 1.0f - powf(c.beta2, t);
+    c.step_size = b.lr[i] / bc1;
+    c.bc2_sqrt = sqrtf(bc2);
+    const size_t tid = (size_t)(blockIdx.x - b.first_block[i]) * 256 + threadIdx.x;
+    const size_t nthreads = (size_t)(b.first_block[i + 1] - b.first_block[i]) * 256;
+    if (b.half_grad[i])
+        adam_range<__half>(c, b.p[i], (const __half*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.vec[i] != 0, tid, nthreads);
+    else
+        adam_range<float>(c, b.p[i], (const float*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.vec[i] != 0, tid, nthreads);
+}
+
 __global__ void k_adam_advance(float* __restrict__ step, const float* __restrict__ found_inf) {
     if (!(found_inf && *found_inf != 0.0f)) *step += 1.0f;
 }
@@ -112,7 +155,8 @@ __global__ void k_adam_advance(float* __restrict__ step, const float* __restrict
 // torch.amp.GradScaler.update (aten::_amp_update_scale_): back off on overflow, grow after `interval` clean steps; then
 // clear the flag for the next step (saves the separate fill launch)
 __global__ void k_scaler_update(float* __restrict__ scale, int32_t* __restrict__ growth_tracker, float* __restrict__ found_inf,
-                                float growth, float backoff, int32_t interval) {
+                                float growth, float backoff, int32_t interval, float* __restrict__ adam_step) {
+    if (adam_step && *found_inf == 0.0f) *adam_step += 1.0f;  // (k_adam_advance folded in: one launch less per step)
     if (*found_inf != 0.0f) {
         *scale = *scale * backoff;
         *growth_tracker = 0;
@@ -141,7 +185,8 @@ __global__ void k_step_ring_push(const float* __restrict__ loss, int32_t* __rest
     counter_ring[2 * c + 1] = counter[1];
     counter[0] = 0;
     counter[1] = 0;
-    *cursor = (c + 1) % ring;
+    cursor[0] = (c + 1) % ring;
+    cursor[1] += 1;
 }
 
 }  // namespace
@@ -180,6 +225,35 @@ S3D_EXPORT int s3d_adam_step(float* param, const void* grad, int grad_dtype, flo
     return check_launch("adam_step");
 }
 
+S3D_EXPORT int s3d_adam_step_multi(const s3d_adam_tensor* tensors, int32_t n_tensors, const float* step, const float* grad_scale,
+                                   const float* found_inf, s3d_stream_t stream) {
+    S3D_REQUIRE(n_tensors >= 0 && (tensors || n_tensors == 0) && step, "adam_step_multi: null pointer");
+    for (int32_t base = 0; base < n_tensors; base += kAdamMaxTensors) {
+        AdamBatch b;
+        memset(&b, 0, sizeof(b));
+        uint32_t blocks = 0;
+        for (int32_t k = base; k < n_tensors && b.count < kAdamMaxTensors; k++) {
+            const s3d_adam_tensor& t = tensors[k];
+            if (t.n == 0) continue;
+            S3D_REQUIRE(t.param && t.grad && t.exp_avg && t.exp_avg_sq, "adam_step_multi: null pointer in tensor %d", k);
+            S3D_REQUIRE(t.grad_dtype == S3D_F32 || t.grad_dtype == S3D_F16, "adam_step_multi: grad dtype must be f32 or f16");
+            const int i = b.count++;
+            b.p[i] = t.param; b.g[i] = t.grad; b.m[i] = t.exp_avg; b.v[i] = t.exp_avg_sq; b.h[i] = (__half*)t.param_half;
+            b.n[i] = t.n; b.lr[i] = t.lr; b.beta1[i] = t.beta1; b.beta2[i] = t.beta2; b.eps[i] = t.eps;
+            b.half_grad[i] = t.grad_dtype == S3D_F16;
+            const uintptr_t bits = (uintptr_t)t.param | (uintptr_t)t.exp_avg | (uintptr_t)t.exp_avg_sq |
+                                   ((uintptr_t)t.grad << (t.grad_dtype == S3D_F16 ? 1 : 0)) | ((uintptr_t)t.param_half << 1);
+            b.vec[i] = (bits & 15) == 0;
+            b.first_block[i] = blocks;
+            blocks += stream_grid(t.n / 8 + 1, 256);
+            b.first_block[i + 1] = blocks;
+        }
+        if (b.count == 0) continue;
+        hipLaunchKernelGGL(k_adam_step_multi, dim3(blocks), dim3(256), 0, as_stream(stream), b, step, grad_scale, found_inf);
+    }
+    return check_launch("adam_step_multi");
+}
+
 S3D_EXPORT int s3d_adam_advance(float* step, const float* found_inf, s3d_stream_t stream) {
     S3D_REQUIRE(step, "adam_advance: null pointer");
     hipLaunchKernelGGL(k_adam_advance, dim3(1), dim3(1), 0, as_stream(stream), step, found_inf);
@@ -187,10 +261,10 @@ S3D_EXPORT int s3d_adam_advance(float* step, const float* found_inf, s3d_stream_
 }
 
 S3D_EXPORT int s3d_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, float growth_factor,
-                                 float backoff_factor, int32_t growth_interval, s3d_stream_t stream) {
+                                 float backoff_factor, int32_t growth_interval, float* adam_step, s3d_stream_t stream) {
     S3D_REQUIRE(scale && growth_tracker && found_inf, "scaler_update: null pointer");
     hipLaunchKernelGGL(k_scaler_update, dim3(1), dim3(1), 0, as_stream(stream), scale, growth_tracker, found_inf, growth_factor,
-                       backoff_factor, growth_interval);
+                       backoff_factor, growth_interval, adam_step);
     return check_launch("scaler_update");
 }
 

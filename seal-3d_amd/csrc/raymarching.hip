@@ -40,11 +40,25 @@ __device__ __forceinline__ uint32_t morton3d_invert(uint32_t x) {
 }
 
 // ---------------------------------------------------------------- small utilities
+// counter-based per-ray jitter for a graph-replayed step: u01(key, step, ray) with the step number read from device memory
+// (torch.rand inside a captured graph costs its own kernel plus two seed/offset fills before every replay)
+__device__ __forceinline__ uint32_t pcg_hash(uint32_t v) {
+    v = v * 747796405u + 2891336453u;
+    const uint32_t w = ((v >> ((v >> 28u) + 4u)) ^ v) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+__device__ __forceinline__ float ray_noise(uint32_t key, uint32_t step, uint32_t n) {
+    return (float)(pcg_hash(pcg_hash(key ^ (step * 0x9E3779B9u)) + n) >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
+
 __global__ void k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                            const float* __restrict__ aabb, uint32_t N, float min_near,
-                           float* __restrict__ nears, float* __restrict__ fars) {
+                           float* __restrict__ nears, float* __restrict__ fars, float* __restrict__ noises,
+                           const int32_t* __restrict__ noise_step, uint32_t noise_key) {
     const float a0 = aabb[0], a1 = aabb[1], a2 = aabb[2], a3 = aabb[3], a4 = aabb[4], a5 = aabb[5];
+    const uint32_t step = (noises && noise_step) ? (uint32_t)*noise_step : 0u;
     for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        if (noises) noises[n] = ray_noise(noise_key, step, n);
         const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
         const float rdx = 1 / rays_d[n * 3], rdy = 1 / rays_d[n * 3 + 1], rdz = 1 / rays_d[n * 3 + 2];
         float near = (a0 - ox) * rdx, far = (a3 - ox) * rdx;
@@ -819,11 +833,12 @@ __global__ void __launch_bounds__(64) k_compact_write(const int32_t* __restrict_
 using namespace s3d;
 
 S3D_EXPORT int s3d_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N,
-                                      float min_near, float* nears, float* fars, s3d_stream_t stream) {
+                                      float min_near, float* nears, float* fars, float* noises, const int32_t* noise_step,
+                                      uint32_t noise_key, s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(rays_o && rays_d && aabb && nears && fars, "near_far_from_aabb: null pointer");
     hipLaunchKernelGGL(k_near_far, dim3(stream_grid(N, 256)), dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, N,
-                       min_near, nears, fars);
+                       min_near, nears, fars, noises, noise_step, noise_key);
     return check_launch("near_far_from_aabb");
 }
 

@@ -124,9 +124,11 @@ class NativeAdam(torch.optim.Optimizer):
                     p._s3d_grad_touched = True
 
     @torch.no_grad()
-    def step(self, grad_scale=None, found_inf=None, before_param=None):
+    def step(self, grad_scale=None, found_inf=None, before_param=None, advance=True):
         """`before_param(p)`: called before parameter p is updated (data parallelism: wait for the all-reduce pieces that
-        cover p's gradient while later pieces are still on the wire)"""
+        cover p's gradient while later pieces are still on the wire); without it all tensors are updated by ONE launch.
+        `advance=False`: the caller advances `step_count` itself (NativeGradScaler.update folds it into its own launch)."""
+        batch, stale = [], []
         for group, p, g in self.grads():
             if before_param is not None:
                 before_param(p)
@@ -135,12 +137,20 @@ class NativeAdam(torch.optim.Optimizer):
             if half is not None and p._s3d_half_version != p._version:
                 half = None  # somebody wrote the parameter through torch: the fp16 copy is re-made below
             b1, b2 = group["betas"]
-            _backend.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], half, group["lr"], b1, b2, group["eps"],
-                               self.step_count, grad_scale, found_inf)
+            item = (p.data, g, st["exp_avg"], st["exp_avg_sq"], half, group["lr"], b1, b2, group["eps"])
+            if before_param is not None:
+                _backend.adam_step(*item, self.step_count, grad_scale, found_inf)
+            else:
+                batch.append(item)
             if half is None and hasattr(p, "_s3d_half"):
-                p._s3d_half.copy_(p.detach())
-                p._s3d_half_version = p._version
-        _backend.adam_advance(self.step_count, found_inf)
+                stale.append(p)
+        if batch:
+            _backend.adam_step_multi(batch, self.step_count, grad_scale, found_inf)
+        for p in stale:
+            p._s3d_half.copy_(p.detach())
+            p._s3d_half_version = p._version
+        if advance:
+            _backend.adam_advance(self.step_count, found_inf)
 
 
 class NativeGradScaler:
@@ -153,6 +163,7 @@ class NativeGradScaler:
         self._scale = torch.full((1,), init_scale if enabled else 1.0, dtype=torch.float32, device=device)
         self._growth_tracker = torch.zeros(1, dtype=torch.int32, device=device)
         self._found_inf = torch.zeros(1, dtype=torch.float32, device=device)
+        self._advance = None  # step count of the optimizer whose advance rides in update()'s launch
 
     def scale(self, loss):
         return loss * self._scale.to(loss.dtype) if self.enabled else loss
@@ -198,8 +209,12 @@ class NativeGradScaler:
         have arrived, while the later pieces are still on the wire."""
         # (found_inf is cleared by update(); it starts at zero)
         self._check(optimizer)
+        # the step-count advance of (one) optimizer is folded into update()'s launch: both are single-thread kernels
+        fold = self.enabled and self._advance is None and getattr(optimizer, "step_count", None) is not None
+        if fold:
+            self._advance = optimizer.step_count
         if dist is None or (dist.world == 1 and not dist.force_collective):
-            optimizer.step(grad_scale=self._scale if self.enabled else None, found_inf=self._found_inf)
+            optimizer.step(grad_scale=self._scale if self.enabled else None, found_inf=self._found_inf, advance=not fold)
             return
         pending = dist.allreduce_grads_async()
         dist.allreduce_flag(self._found_inf)
@@ -216,13 +231,15 @@ class NativeGradScaler:
                 if rng is not None and h[0] is buf and h[1] >= rng[1]:
                     break
                 dist.finish_chunk(pending.pop(0))
-        optimizer.step(grad_scale=self._scale if self.enabled else None, found_inf=self._found_inf, before_param=before_param)
+        optimizer.step(grad_scale=self._scale if self.enabled else None, found_inf=self._found_inf, before_param=before_param,
+                       advance=not fold)
         while pending:
             dist.finish_chunk(pending.pop(0))
 
     def update(self):
         if self.enabled:
             _backend.scaler_update(self._scale, self._growth_tracker, self._found_inf, self.growth_factor,
-                                   self.backoff_factor, self.growth_interval)
+                                   self.backoff_factor, self.growth_interval, self._advance)
+            self._advance = None
         else:
             self._found_inf.zero_()

@@ -115,7 +115,13 @@ class NeRFRenderer(nn.Module):
         device = rays_o.device
 
         aabb = self.aabb_train if self.training else self.aabb_infer
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+        noises = None
+        noise_step = getattr(self, "_noise_step", None) if (self.training and perturb) else None
+        if noise_step is not None:  # graph-replayed step (nerf/trainer.py): the jitter comes out of the same kernel
+            nears, fars, noises = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near, noise_step,
+                                                                 getattr(self, "_noise_key", 0))
+        else:
+            nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
 
         if self.bg_radius > 0:
             sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
@@ -133,7 +139,8 @@ class NeRFRenderer(nn.Module):
             trim = budgeted or not self.honours_row_limit(N * max_steps)  # (no budget: N * max_steps rows, 128-aligned)
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, counter,
-                self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps, *(() if trim else (False,)))
+                self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps,
+                *(() if trim and noises is None else (trim, noises)))
             # the buffers are padded to M rows (raymarching.py:205-207); counter[0] says on the device how many hold samples
             # (a proxy mapper skips the rows behind the count only when the network behind it skips them too: otherwise the
             #  network would read rows the mapper never wrote)

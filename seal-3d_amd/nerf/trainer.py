@@ -196,7 +196,8 @@ class GraphedTrainer(Trainer):
         self.s_counter = torch.zeros(2, dtype=torch.int32, device=dev)
         # the graph itself files each step's loss and sample counter in 16-slot rings (seal3d_hip.h: s3d_step_ring_push)
         self.loss_ring = torch.zeros(16, dtype=torch.float32, device=dev)
-        self.s_cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.s_cursor = torch.zeros(2, dtype=torch.int32, device=dev)  # {ring slot, running step number}
+        self.noise_key = (torch.initial_seed() * 0x9E3779B1 + (self.dist.rank if self.dist is not None else 0) * 0x85EBCA6B) & 0xFFFFFFFF
         self._counter_ring = None
 
     def _static_loss(self):
@@ -239,9 +240,11 @@ class GraphedTrainer(Trainer):
         ring = model.step_counter
         self._counter_ring = ring if ring.is_contiguous() and ring.dtype == torch.int32 and _RING_PUSH else None
         self.s_counter.zero_()
-        self.s_cursor.fill_(saved[1] % 16)
+        self.s_cursor[0].fill_(saved[1] % 16)
         model.step_counter = self.s_counter.view(1, 2).expand(16, 2)
         model._counter_prezeroed = self._counter_ring is not None
+        if self._counter_ring is not None:  # per-ray jitter drawn from the device-side step number instead of torch.rand
+            model._noise_step, model._noise_key = self.s_cursor[1:], self.noise_key
         model.local_step = 0
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -271,6 +274,7 @@ class GraphedTrainer(Trainer):
                 self._body_opt()
         model.step_counter = ring
         model._counter_prezeroed = False
+        model._noise_step = None
         model.mean_count, model.local_step = saved
 
     def load_checkpoint(self, checkpoint, model_only=False):
@@ -320,7 +324,7 @@ class GraphedTrainer(Trainer):
         model = self.model
         model.train()
         if self._maybe_update_extra_state():
-            self.s_cursor.zero_()  # (update_extra_state restarts the counter ring: local_step = 0)
+            self.s_cursor[0].zero_()  # (update_extra_state restarts the counter ring: local_step = 0)
             if self.graph is not None and (model.mean_count * 1.1 > self.budget or model.mean_count * 2 < self.budget):
                 self.graph = None  # the running mean left the static budget's useful range: re-capture
         self.global_step += 1

@@ -49,13 +49,20 @@ class _NearFarFromAABB(Function):
 
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, rays_o, rays_d, aabb, min_near=0.2):
+    def forward(ctx, rays_o, rays_d, aabb, min_near=0.2, noise_step=None, noise_key=0):
+        """`noise_step` (build extension, seal3d_hip.h): int32 GPU tensor holding the running step number — a third output,
+        the per-ray jitter for march_rays_train(noises=...), is drawn by the same kernel"""
         rays_o, rays_d = _rays(rays_o, rays_d)
         N = rays_o.shape[0]
         nears = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
         fars = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
-        _backend.near_far_from_aabb(rays_o, rays_d, aabb.contiguous(), N, min_near, nears, fars)
-        return nears, fars
+        if noise_step is None:
+            _backend.near_far_from_aabb(rays_o, rays_d, aabb.contiguous(), N, min_near, nears, fars)
+            return nears, fars
+        noises = torch.empty(N, dtype=rays_o.dtype, device=rays_o.device)
+        _backend.near_far_from_aabb(rays_o, rays_d, aabb.contiguous(), N, min_near, nears, fars, noises=noises,
+                                    noise_step=noise_step, noise_key=noise_key)
+        return nears, fars, noises
 
 
 near_far_from_aabb = _NearFarFromAABB.apply
@@ -131,10 +138,11 @@ class _MarchRaysTrain(Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
-                perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, trim=True):
+                perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, trim=True, noises=None):
         """`trim=False` (build extension): without a sample budget the reference reads the sample count back and trims the
         N * max_steps buffers (raymarching.py:223-231: a device->host sync).  A caller whose whole sample path takes the
-        device-side count (`n_valid`, seal3d_hip.h) keeps the full buffers instead: no sync, static shapes."""
+        device-side count (`n_valid`, seal3d_hip.h) keeps the full buffers instead: no sync, static shapes.
+        `noises` (build extension): the per-ray jitter [N] in [0, 1) when the caller has drawn it already (perturb)."""
         rays_o, rays_d = _rays(rays_o, rays_d)
         density_bitfield = _on_device(density_bitfield).contiguous()
         dev, dt = rays_o.device, rays_o.dtype
@@ -150,7 +158,10 @@ class _MarchRaysTrain(Function):
         rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
         if step_counter is None:
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
-        noises = torch.rand(N, dtype=dt, device=dev) if perturb else torch.zeros(N, dtype=dt, device=dev)
+        if not perturb:
+            noises = torch.zeros(N, dtype=dt, device=dev)
+        elif noises is None:
+            noises = torch.rand(N, dtype=dt, device=dev)
 
         _backend.march_rays_train(rays_o, rays_d, density_bitfield, bound, dt_gamma, max_steps, N, C, H, M,
                                   nears.contiguous(), fars.contiguous(), xyzs, dirs, deltas, rays, step_counter, noises)

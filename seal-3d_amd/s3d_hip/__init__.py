@@ -38,7 +38,7 @@ EXPORTS = [
     "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
     "s3d_ffmlp_fused_backward_supported",
     "s3d_ffmlp_allocate_splitk", "s3d_ffmlp_free_splitk",
-    "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_advance", "s3d_scaler_update", "s3d_step_ring_push",
+    "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_step_multi", "s3d_adam_advance", "s3d_scaler_update", "s3d_step_ring_push",
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_mid2_forward", "s3d_ngp_mid2_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
     "s3d_bg_mse_forward", "s3d_bg_mse_backward",
     "s3d_seal_bbox_map", "s3d_vm_features_forward",
@@ -226,10 +226,15 @@ class RaymarchingBackend:
     """raymarching/src/raymarching.h:7-18"""
 
     @staticmethod
-    def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars):
+    def near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars, noises=None, noise_step=None, noise_key=0):
         _need(rays_o, torch.float32, "rays_o")
+        if noises is not None:
+            _need(noises, torch.float32, "noises")
+            if noise_step is not None:
+                _need(noise_step, torch.int32, "noise_step")
         _check(lib().s3d_near_far_from_aabb(_p(rays_o), _p(rays_d), _p(aabb), _u(N), _f(min_near), _p(nears),
-                                            _p(fars), _stream()), "near_far_from_aabb")
+                                            _p(fars), _p(noises), _p(noise_step), _u(int(noise_key) & 0xFFFFFFFF), _stream()),
+               "near_far_from_aabb")
 
     @staticmethod
     def sph_from_ray(rays_o, rays_d, radius, N, coords):
@@ -488,6 +493,13 @@ class FFMLPBackend:
                                         C.c_int(int(bool(accumulate))), _nv(n_valid), _stream()), "ffmlp_backward")
 
 
+class _AdamTensor(C.Structure):
+    """seal3d_hip.h: s3d_adam_tensor"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("param_half", C.c_void_p), ("n", C.c_size_t), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("grad_dtype", C.c_int)]
+
+
 class OptimBackend:
     """csrc/optim.hip — Adam + GradScaler bookkeeping straight from the (fp16) gradients"""
 
@@ -511,10 +523,31 @@ class OptimBackend:
                                    _p(grad_scale), _p(found_inf), _stream()), "adam_step")
 
     @staticmethod
-    def scaler_update(scale, growth_tracker, found_inf, growth_factor, backoff_factor, growth_interval):
+    def adam_step_multi(items, step, grad_scale, found_inf):
+        """`items`: (param, grad, exp_avg, exp_avg_sq, param_half or None, lr, beta1, beta2, eps) per tensor — adam_step for
+        all of them in one launch"""
+        arr = (_AdamTensor * len(items))()
+        for a, (param, grad, exp_avg, exp_avg_sq, param_half, lr, beta1, beta2, eps) in zip(arr, items):
+            _need(param, torch.float32, "param"); _need(exp_avg, torch.float32, "exp_avg"); _need(exp_avg_sq, torch.float32, "exp_avg_sq")
+            if grad.numel() != param.numel() or not grad.is_contiguous() or not param.is_contiguous():
+                raise RuntimeError("adam_step_multi: param and grad must be contiguous and of equal size")
+            if param_half is not None:
+                _need(param_half, torch.float16, "param_half")
+            a.param, a.grad, a.exp_avg, a.exp_avg_sq = _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq)
+            a.param_half = _p(param_half)
+            a.n = param.numel()
+            a.lr, a.beta1, a.beta2, a.eps = float(lr), float(beta1), float(beta2), float(eps)
+            a.grad_dtype = _dt(grad)
+        _check(lib().s3d_adam_step_multi(arr, C.c_int32(len(items)), _p(step), _p(grad_scale), _p(found_inf), _stream()),
+               "adam_step_multi")
+
+    @staticmethod
+    def scaler_update(scale, growth_tracker, found_inf, growth_factor, backoff_factor, growth_interval, adam_step=None):
         _need(scale, torch.float32, "scale"); _need(growth_tracker, torch.int32, "growth_tracker")
+        if adam_step is not None:
+            _need(adam_step, torch.float32, "adam_step")
         _check(lib().s3d_scaler_update(_p(scale), _p(growth_tracker), _p(found_inf), _f(growth_factor), _f(backoff_factor),
-                                       C.c_int32(int(growth_interval)), _stream()), "scaler_update")
+                                       C.c_int32(int(growth_interval)), _p(adam_step), _stream()), "scaler_update")
 
     @staticmethod
     def adam_advance(step, found_inf):
@@ -525,6 +558,8 @@ class OptimBackend:
         """file `loss` [] / `counter` [2] in slot *cursor of the rings, clear the counter, advance the cursor (seal3d_hip.h)"""
         _need(counter, torch.int32, "counter"); _need(counter_ring, torch.int32, "counter_ring")
         _need(cursor, torch.int32, "cursor")
+        if cursor.numel() < 2:
+            raise RuntimeError("step_ring_push: cursor is int32[2] = {slot, running step number}")
         if loss is not None:
             _need(loss, torch.float32, "loss"); _need(loss_ring, torch.float32, "loss_ring")
         ring = counter_ring.shape[0]

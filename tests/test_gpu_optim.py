@@ -37,6 +37,66 @@ def test_native_adam_matches_torch_adam(hip):
         torch.testing.assert_close(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
 
 
+def test_adam_multi_tensor_launch_is_the_per_tensor_update_bit_for_bit(hip):
+    """s3d_adam_step_multi == s3d_adam_step per tensor: fp16 and fp32 gradients, sizes with vector tails, a tensor whose
+    pointers are not 16-byte aligned (scalar path), fp16 parameter copies; a raised flag skips every tensor."""
+    import s3d_hip
+    O = s3d_hip.OptimBackend
+    torch.manual_seed(3)
+    sizes = [12_000_003, 11264, 7168, 5, 4099]
+    step = torch.full((1,), 4.0, device="cuda")
+    scale = torch.full((1,), 1024.0, device="cuda")
+    flag = torch.zeros(1, device="cuda")
+
+    def make():
+        out = []
+        for k, n in enumerate(sizes):
+            off = 1 if k == 4 else 0  # tensor 4: views shifted by one element -> unaligned
+            p = torch.randn(n + off, device="cuda")[off:]
+            g = (torch.randn(n + off, device="cuda") * 1024.0)
+            g = (g.half() if k < 3 else g)[off:]
+            m = (torch.randn(n + off, device="cuda") * 0.1)[off:]
+            v = (torch.rand(n + off, device="cuda") * 0.01)[off:]
+            h = torch.empty(n + off, device="cuda", dtype=torch.half)[off:] if k in (0, 1, 4) else None
+            out.append([p, g, m, v, h])
+        return out
+    torch.manual_seed(3); a = make()
+    torch.manual_seed(3); b = make()
+    for x, y in zip(a, b):
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1])
+    for p, g, m, v, h in a:
+        O.adam_step(p, g, m, v, h, 1e-2, 0.9, 0.99, 1e-15, step, scale, flag)
+    O.adam_step_multi([(p, g, m, v, h, 1e-2, 0.9, 0.99, 1e-15) for p, g, m, v, h in b], step, scale, flag)
+    for x, y in zip(a, b):
+        for k in (0, 2, 3):
+            assert torch.equal(x[k], y[k])
+        if x[4] is not None:
+            assert torch.equal(x[4], y[4]) and torch.equal(x[4], x[0].half())
+    before = [t[0].clone() for t in b]
+    flag.fill_(1.0)
+    O.adam_step_multi([(p, g, m, v, h, 1e-2, 0.9, 0.99, 1e-15) for p, g, m, v, h in b], step, scale, flag)
+    assert all(torch.equal(x, t[0]) for x, t in zip(before, b))
+
+
+def test_scaler_update_carries_the_step_count_advance(hip):
+    """NativeGradScaler.step + update: the optimizer's step count advances exactly once per clean step (folded into update's
+    launch) and not at all on an overflow step"""
+    from nerf.optim import NativeAdam, NativeGradScaler
+    p = torch.nn.Parameter(torch.randn(1000, device="cuda"))
+    opt = NativeAdam([{"params": [p]}], lr=1e-2)
+    sc = NativeGradScaler(p.device, enabled=True)
+    for k in range(4):
+        p.grad = torch.randn(1000, device="cuda") * float(sc._scale)
+        if k == 2:
+            p.grad[5] = float("inf")
+        before = p.detach().clone()
+        sc.step(opt)
+        sc.update()
+        assert float(opt.step_count) == (k + 1 if k < 2 else k)
+        assert torch.equal(before, p.detach()) == (k == 2)
+    assert float(sc._found_inf) == 0.0 and float(sc._scale) == 2.0 ** 15
+
+
 def test_grid_encoder_half_grad_handover_matches_reference_update(hip):
     """Same data through (a) autograd fp32 grads + torch Adam + GradScaler and (b) fp16 hand-over + NativeAdam +
     NativeGradScaler: the tables must follow the same trajectory (the fp16 gradient values are identical, only their

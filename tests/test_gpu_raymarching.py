@@ -83,6 +83,42 @@ def test_near_far_incl_misses_and_axis_parallel(oracle, hip):
     assert (cpu[5][16:24] == 0.2).all()
 
 
+def test_near_far_draws_the_per_ray_jitter_from_a_device_step_number(oracle, hip):
+    """build extension of near_far_from_aabb: nears/fars unchanged, noises = u01(key, *step, ray) in [0, 1) — uniform, a new
+    draw for every step number and key, reproducible for equal ones; march_rays_train(noises=...) uses it as given"""
+    R = hip.RaymarchingBackend
+    ro, rd = _rays(1 << 16, seed=5)
+    ro, rd = ro.cuda(), rd.cuda()
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1], device="cuda")
+    N = ro.shape[0]
+    ref = [torch.empty(N, device="cuda") for _ in range(2)]
+    R.near_far_from_aabb(ro, rd, aabb, N, 0.2, *ref)
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    draws = {}
+    for key in (1, 2):
+        for st in (0, 1, 7):
+            step.fill_(st)
+            out = [torch.empty(N, device="cuda") for _ in range(3)]
+            R.near_far_from_aabb(ro, rd, aabb, N, 0.2, out[0], out[1], noises=out[2], noise_step=step, noise_key=key)
+            assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+            u = out[2]
+            assert float(u.min()) >= 0.0 and float(u.max()) < 1.0
+            assert abs(float(u.mean()) - 0.5) < 0.01 and abs(float(u.var()) - 1 / 12) < 0.005
+            hist = torch.histc(u, bins=16, min=0, max=1) / N
+            assert float((hist - 1 / 16).abs().max()) < 0.01
+            assert abs(float(torch.corrcoef(torch.stack([u[:-1], u[1:]]))[0, 1])) < 0.02  # neighbouring rays independent
+            draws[(key, st)] = u
+    keys = list(draws)
+    for i in range(len(keys)):
+        for j in range(i + 1, len(keys)):
+            assert abs(float(torch.corrcoef(torch.stack([draws[keys[i]], draws[keys[j]]]))[0, 1])) < 0.02
+    step.fill_(7)
+    again = torch.empty(N, device="cuda")
+    R.near_far_from_aabb(ro, rd, aabb, N, 0.2, torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), noises=again,
+                         noise_step=step, noise_key=2)
+    assert torch.equal(again, draws[(2, 7)])
+
+
 def test_sph_from_ray(oracle, hip):
     ro, rd = _rays(2048, seed=2)
     N = ro.shape[0]
