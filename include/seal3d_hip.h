@@ -309,10 +309,11 @@ int s3d_adam_step(float* param, const void* grad, int grad_dtype, float* exp_avg
                   uint16_t* param_half, size_t n, float lr, float beta1, float beta2, float eps,
                   const float* step, const float* grad_scale, const float* found_inf, s3d_stream_t stream);
 int s3d_adam_advance(float* step, const float* found_inf, s3d_stream_t stream);
-/* s3d_adam_step for every tensor of the optimizer in one launch (same arithmetic per element). */
+/* s3d_adam_step for every tensor of the optimizer in one launch (same arithmetic per element).  consume_grads != 0: every
+ * gradient is cleared behind the read — also on a skipped (*found_inf != 0) step — for producers that accumulate into it. */
 typedef struct s3d_adam_tensor {
     float* param;
-    const void* grad;
+    void* grad; /* written only with consume_grads */
     float* exp_avg;
     float* exp_avg_sq;
     uint16_t* param_half; /* optional fp16 copy of the updated parameters */
@@ -321,7 +322,7 @@ typedef struct s3d_adam_tensor {
     int grad_dtype; /* S3D_F32 or S3D_F16 */
 } s3d_adam_tensor;
 int s3d_adam_step_multi(const s3d_adam_tensor* tensors /* host array */, int32_t n_tensors, const float* step,
-                        const float* grad_scale, const float* found_inf, s3d_stream_t stream);
+                        const float* grad_scale, const float* found_inf, int consume_grads, s3d_stream_t stream);
 /* GradScaler.update(): scale *= backoff on overflow, *= growth after growth_interval clean steps; clears *found_inf.
  * adam_step (optional): s3d_adam_advance of that step count folded into the same launch (before the flag is cleared). */
 int s3d_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, float growth_factor,

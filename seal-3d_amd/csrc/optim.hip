@@ -47,6 +47,7 @@ template <> struct GradVec4<float> {
         const float4 t = *reinterpret_cast<const float4*>(g + i);
         o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
     }
+    static __device__ __forceinline__ void zero(float* g, size_t i) { *reinterpret_cast<float4*>(g + i) = make_float4(0, 0, 0, 0); }
 };
 template <> struct GradVec4<__half> {
     static __device__ __forceinline__ void load(const __half* g, size_t i, float (&o)[4]) {
@@ -54,17 +55,28 @@ template <> struct GradVec4<__half> {
         const __half2 a = *reinterpret_cast<const __half2*>(&t.x), b = *reinterpret_cast<const __half2*>(&t.y);
         o[0] = __low2float(a); o[1] = __high2float(a); o[2] = __low2float(b); o[3] = __high2float(b);
     }
+    static __device__ __forceinline__ void zero(__half* g, size_t i) { *reinterpret_cast<uint2*>(g + i) = make_uint2(0u, 0u); }
 };
 
+// `consume`: the gradient is cleared behind the read (the producers of the next step ACCUMULATE into it: saves the
+// optimizer's separate zero fill); `skip`: overflow step, nothing is updated but a consumed gradient is still cleared
 template <typename G>
-__device__ __forceinline__ void adam_range(const AdamCoef& c, float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m,
+__device__ __forceinline__ void clear_range(G* __restrict__ g, size_t n, bool vec, size_t tid, size_t nthreads) {
+    const size_t n4 = vec ? n / 4 : 0;
+    for (size_t q = tid; q < n4; q += nthreads) GradVec4<G>::zero(g, q * 4);
+    for (size_t i = n4 * 4 + tid; i < n; i += nthreads) g[i] = G(0.0f);
+}
+
+template <typename G>
+__device__ __forceinline__ void adam_range(const AdamCoef& c, float* __restrict__ p, G* __restrict__ g, float* __restrict__ m,
                                            float* __restrict__ v, __half* __restrict__ p_half, size_t n, bool vec, size_t tid,
-                                           size_t nthreads) {
+                                           size_t nthreads, bool consume) {
     const size_t n4 = vec ? n / 4 : 0;
     for (size_t q = tid; q < n4; q += nthreads) {
         const size_t i = q * 4;
         float gi[4];
         GradVec4<G>::load(g, i, gi);
+        if (consume) GradVec4<G>::zero(g, i);
         float4 mi = *reinterpret_cast<const float4*>(m + i), vi = *reinterpret_cast<const float4*>(v + i),
                pi = *reinterpret_cast<const float4*>(p + i);
         adam_update(c, gi[0], mi.x, vi.x, pi.x);
@@ -85,6 +97,7 @@ __device__ __forceinline__ void adam_range(const AdamCoef& c, float* __restrict_
     for (size_t i = n4 * 4 + tid; i < n; i += nthreads) {
         float mi = m[i], vi = v[i], pi = p[i];
         adam_update(c, grad_to_f<G>(g[i]), mi, vi, pi);
+        if (consume) g[i] = G(0.0f);
         m[i] = mi;
         v[i] = vi;
         p[i] = pi;
@@ -108,7 +121,8 @@ __global__ void __launch_bounds__(256) k_adam_step(float* __restrict__ p, const 
     const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
     c.step_size = lr / bc1;
     c.bc2_sqrt = sqrtf(bc2);
-    adam_range<G>(c, p, g, m, v, p_half, n, vec != 0, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+    adam_range<G>(c, p, const_cast<G*>(g), m, v, p_half, n, vec != 0, (size_t)blockIdx.x * 256 + threadIdx.x,
+                  (size_t)gridDim.x * 256, false);
 }
 
 // Every tensor of the optimizer in ONE launch (the hot path updates a 12 M-element hash table and two ~10 K-element MLPs: the
@@ -116,7 +130,7 @@ __global__ void __launch_bounds__(256) k_adam_step(float* __restrict__ p, const 
 constexpr int kAdamMaxTensors = 16;
 struct AdamBatch {
     float* p[kAdamMaxTensors];
-    const void* g[kAdamMaxTensors];
+    void* g[kAdamMaxTensors];
     float* m[kAdamMaxTensors];
     float* v[kAdamMaxTensors];
     __half* h[kAdamMaxTensors];
@@ -124,15 +138,23 @@ struct AdamBatch {
     float lr[kAdamMaxTensors], beta1[kAdamMaxTensors], beta2[kAdamMaxTensors], eps[kAdamMaxTensors];
     uint32_t first_block[kAdamMaxTensors + 1];
     uint8_t half_grad[kAdamMaxTensors], vec[kAdamMaxTensors];
-    int32_t count;
+    int32_t count, consume;
 };
 
 __global__ void __launch_bounds__(256) k_adam_step_multi(AdamBatch b, const float* __restrict__ step,
                                                          const float* __restrict__ grad_scale,
                                                          const float* __restrict__ found_inf) {
-    if (found_inf && *found_inf != 0.0f) return;
     int i = 0;
     while (i + 1 < b.count && blockIdx.x >= b.first_block[i + 1]) i++;
+    const size_t tid = (size_t)(blockIdx.x - b.first_block[i]) * 256 + threadIdx.x;
+    const size_t nthreads = (size_t)(b.first_block[i + 1] - b.first_block[i]) * 256;
+    if (found_inf && *found_inf != 0.0f) {  // skipped step: nothing is updated
+        if (b.consume) {
+            if (b.half_grad[i]) clear_range<__half>((__half*)b.g[i], b.n[i], b.vec[i] != 0, tid, nthreads);
+            else clear_range<float>((float*)b.g[i], b.n[i], b.vec[i] != 0, tid, nthreads);
+        }
+        return;
+    }
     const float t = *step + 1.0f;
     AdamCoef c;
     c.beta1 = b.beta1[i]; c.beta2 = b.beta2[i]; c.eps = b.eps[i];
@@ -140,12 +162,10 @@ __global__ void __launch_bounds__(256) k_adam_step_multi(AdamBatch b, const floa
     const float bc1 = 1.0f - powf(c.beta1, t), bc2 = 1.0f - powf(c.beta2, t);
     c.step_size = b.lr[i] / bc1;
     c.bc2_sqrt = sqrtf(bc2);
-    const size_t tid = (size_t)(blockIdx.x - b.first_block[i]) * 256 + threadIdx.x;
-    const size_t nthreads = (size_t)(b.first_block[i + 1] - b.first_block[i]) * 256;
     if (b.half_grad[i])
-        adam_range<__half>(c, b.p[i], (const __half*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.vec[i] != 0, tid, nthreads);
+        adam_range<__half>(c, b.p[i], (__half*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.vec[i] != 0, tid, nthreads, b.consume != 0);
     else
-        adam_range<float>(c, b.p[i], (const float*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.vec[i] != 0, tid, nthreads);
+        adam_range<float>(c, b.p[i], (float*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.vec[i] != 0, tid, nthreads, b.consume != 0);
 }
 
 __global__ void k_adam_advance(float* __restrict__ step, const float* __restrict__ found_inf) {
@@ -226,11 +246,12 @@ S3D_EXPORT int s3d_adam_step(float* param, const void* grad, int grad_dtype, flo
 }
 
 S3D_EXPORT int s3d_adam_step_multi(const s3d_adam_tensor* tensors, int32_t n_tensors, const float* step, const float* grad_scale,
-                                   const float* found_inf, s3d_stream_t stream) {
+                                   const float* found_inf, int consume_grads, s3d_stream_t stream) {
     S3D_REQUIRE(n_tensors >= 0 && (tensors || n_tensors == 0) && step, "adam_step_multi: null pointer");
     for (int32_t base = 0; base < n_tensors; base += kAdamMaxTensors) {
         AdamBatch b;
         memset(&b, 0, sizeof(b));
+        b.consume = consume_grads ? 1 : 0;
         uint32_t blocks = 0;
         for (int32_t k = base; k < n_tensors && b.count < kAdamMaxTensors; k++) {
             const s3d_adam_tensor& t = tensors[k];
@@ -238,7 +259,7 @@ S3D_EXPORT int s3d_adam_step_multi(const s3d_adam_tensor* tensors, int32_t n_ten
             S3D_REQUIRE(t.param && t.grad && t.exp_avg && t.exp_avg_sq, "adam_step_multi: null pointer in tensor %d", k);
             S3D_REQUIRE(t.grad_dtype == S3D_F32 || t.grad_dtype == S3D_F16, "adam_step_multi: grad dtype must be f32 or f16");
             const int i = b.count++;
-            b.p[i] = t.param; b.g[i] = t.grad; b.m[i] = t.exp_avg; b.v[i] = t.exp_avg_sq; b.h[i] = (__half*)t.param_half;
+            b.p[i] = t.param; b.g[i] = const_cast<void*>(t.grad); b.m[i] = t.exp_avg; b.v[i] = t.exp_avg_sq; b.h[i] = (__half*)t.param_half;
             b.n[i] = t.n; b.lr[i] = t.lr; b.beta1[i] = t.beta1; b.beta2[i] = t.beta2; b.eps[i] = t.eps;
             b.half_grad[i] = t.grad_dtype == S3D_F16;
             const uintptr_t bits = (uintptr_t)t.param | (uintptr_t)t.exp_avg | (uintptr_t)t.exp_avg_sq |

@@ -26,12 +26,14 @@ class NativeAdam(torch.optim.Optimizer):
     """Adam (no amsgrad, no weight decay) with device-side step count.  `adopt_half_grads=True` switches every
     GridEncoder-style parameter that carries `_s3d_stash_ok` to the fp16 hand-over described in the module docstring."""
 
-    def __init__(self, params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, adopt_half_grads=True):
+    def __init__(self, params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15, adopt_half_grads=True, consume_grads=True):
         # (the torch.optim.Adam keys this class has no use for keep `state_dict()` loadable by torch.optim.Adam)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False,
                                       foreach=None, capturable=False, differentiable=False, fused=None,
                                       decoupled_weight_decay=False))
         self.step_count = None
+        # the update launch clears every handed-over gradient behind its read: the next zero_grad() has nothing to fill
+        self.consume_grads = consume_grads
         self.flat_half = None  # ONE fp16 buffer behind every handed-over gradient: one clear, one check, one all-reduce
         adopted = []
         for group in self.param_groups:
@@ -56,6 +58,7 @@ class NativeAdam(torch.optim.Optimizer):
                 p._s3d_grad = self.flat_half[off:off + p.numel()].view(p.shape)
                 p._s3d_grad_flat = self.flat_half
                 p._s3d_grad_touched = False
+                p._s3d_grad_consumed = False
                 p._s3d_half = p.detach().to(torch.float16)
                 p._s3d_half_version = p._version
                 off += n
@@ -72,11 +75,17 @@ class NativeAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=True):
         if self.flat_half is not None:
-            self.flat_half.zero_()  # the backward kernels ACCUMULATE into it (several calls per step are summed)
+            # the backward kernels ACCUMULATE into it (several calls per step are summed).  Written since the last clear and not
+            # consumed by step(): fill; otherwise it is still all zeros
+            dirty = any(getattr(p, "_s3d_grad_touched", False) and not getattr(p, "_s3d_grad_consumed", False)
+                        for group in self.param_groups for p in group["params"] if getattr(p, "_s3d_grad", None) is not None)
+            if dirty:
+                self.flat_half.zero_()
         for group in self.param_groups:
             for p in group["params"]:
                 if getattr(p, "_s3d_grad", None) is not None:
                     p._s3d_grad_touched = False
+                    p._s3d_grad_consumed = False
                 if p.grad is not None:
                     if set_to_none:
                         p.grad = None
@@ -128,7 +137,7 @@ class NativeAdam(torch.optim.Optimizer):
         """`before_param(p)`: called before parameter p is updated (data parallelism: wait for the all-reduce pieces that
         cover p's gradient while later pieces are still on the wire); without it all tensors are updated by ONE launch.
         `advance=False`: the caller advances `step_count` itself (NativeGradScaler.update folds it into its own launch)."""
-        batch, stale = [], []
+        batch, stale, consumed = [], [], []
         for group, p, g in self.grads():
             if before_param is not None:
                 before_param(p)
@@ -142,10 +151,17 @@ class NativeAdam(torch.optim.Optimizer):
                 _backend.adam_step(*item, self.step_count, grad_scale, found_inf)
             else:
                 batch.append(item)
+                if g is getattr(p, "_s3d_grad", None):
+                    consumed.append(p)
             if half is None and hasattr(p, "_s3d_half"):
                 stale.append(p)
         if batch:
-            _backend.adam_step_multi(batch, self.step_count, grad_scale, found_inf)
+            # (only when every tensor of the launch is a hand-over buffer: a `.grad` stays readable after the step)
+            consume = self.consume_grads and len(consumed) == len(batch)
+            _backend.adam_step_multi(batch, self.step_count, grad_scale, found_inf, consume_grads=consume)
+            if consume:
+                for p in consumed:
+                    p._s3d_grad_consumed = True
         for p in stale:
             p._s3d_half.copy_(p.detach())
             p._s3d_half_version = p._version

@@ -523,9 +523,9 @@ class OptimBackend:
                                    _p(grad_scale), _p(found_inf), _stream()), "adam_step")
 
     @staticmethod
-    def adam_step_multi(items, step, grad_scale, found_inf):
+    def adam_step_multi(items, step, grad_scale, found_inf, consume_grads=False):
         """`items`: (param, grad, exp_avg, exp_avg_sq, param_half or None, lr, beta1, beta2, eps) per tensor — adam_step for
-        all of them in one launch"""
+        all of them in one launch; `consume_grads`: the gradients are cleared behind the read (seal3d_hip.h)"""
         arr = (_AdamTensor * len(items))()
         for a, (param, grad, exp_avg, exp_avg_sq, param_half, lr, beta1, beta2, eps) in zip(arr, items):
             _need(param, torch.float32, "param"); _need(exp_avg, torch.float32, "exp_avg"); _need(exp_avg_sq, torch.float32, "exp_avg_sq")
@@ -538,8 +538,8 @@ class OptimBackend:
             a.n = param.numel()
             a.lr, a.beta1, a.beta2, a.eps = float(lr), float(beta1), float(beta2), float(eps)
             a.grad_dtype = _dt(grad)
-        _check(lib().s3d_adam_step_multi(arr, C.c_int32(len(items)), _p(step), _p(grad_scale), _p(found_inf), _stream()),
-               "adam_step_multi")
+        _check(lib().s3d_adam_step_multi(arr, C.c_int32(len(items)), _p(step), _p(grad_scale), _p(found_inf),
+                                         C.c_int(int(bool(consume_grads))), _stream()), "adam_step_multi")
 
     @staticmethod
     def scaler_update(scale, growth_tracker, found_inf, growth_factor, backoff_factor, growth_interval, adam_step=None):
