@@ -74,7 +74,12 @@ int s3d_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* b
  *                                        nears, fars, xyzs, dirs, deltas, rays, counter, noises)
  * Spans are packed in RAY ORDER (deterministic; one valid outcome of the reference's atomic
  * reservation, raymarching.cu:405-406).  counter[0] += total samples, counter[1] += N.
- * path (kernel choice, same results): 0 = auto (wave-per-ray up to 16,384 rays), 1 = lane-per-ray, 2 = wave-per-ray. */
+ * path (kernel choice, same results): 0 = auto (wave-per-ray up to 16,384 rays), 1 = lane-per-ray, 2 = wave-per-ray.
+ * Rows no ray fills are written as zeros where a consumer bounded by the device-side count (`n_valid`: the count rounded
+ * up to 128 rows, at most M) still reads them: [total, round_up(total, 128)) and, for the one ray that straddles the
+ * budget (offset < M < offset + steps, dropped like in the reference), [offset, M).  The reference zero-fills all M rows
+ * beforehand (raymarching.py:205-207); callers that read every row must still do so.  s3d_composite_rays_train_backward
+ * does the same for grad_sigmas / grad_rgbs (plus the samples behind a ray's early termination). */
 size_t s3d_march_rays_train_workspace_size(uint32_t N, uint32_t max_steps);
 int s3d_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                          float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
@@ -333,6 +338,10 @@ int s3d_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, f
  * cursor[0] = (slot + 1) % ring; cursor[1] += 1 (running step number, the `noise_step` of s3d_near_far_from_aabb). */
 int s3d_step_ring_push(const float* loss, int32_t* counter, float* loss_ring, int32_t* counter_ring, int32_t* cursor,
                        int32_t ring, s3d_stream_t stream);
+/* s3d_scaler_update followed by s3d_step_ring_push, one launch. */
+int s3d_step_epilogue(float* scale, int32_t* growth_tracker, float* found_inf, float growth_factor, float backoff_factor,
+                      int32_t growth_interval, float* adam_step, const float* loss, int32_t* counter, float* loss_ring,
+                      int32_t* counter_ring, int32_t* cursor, int32_t ring, s3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -174,8 +174,9 @@ __global__ void k_adam_advance(float* __restrict__ step, const float* __restrict
 
 // torch.amp.GradScaler.update (aten::_amp_update_scale_): back off on overflow, grow after `interval` clean steps; then
 // clear the flag for the next step (saves the separate fill launch)
-__global__ void k_scaler_update(float* __restrict__ scale, int32_t* __restrict__ growth_tracker, float* __restrict__ found_inf,
-                                float growth, float backoff, int32_t interval, float* __restrict__ adam_step) {
+__device__ __forceinline__ void scaler_update(float* __restrict__ scale, int32_t* __restrict__ growth_tracker,
+                                              float* __restrict__ found_inf, float growth, float backoff, int32_t interval,
+                                              float* __restrict__ adam_step) {
     if (adam_step && *found_inf == 0.0f) *adam_step += 1.0f;  // (k_adam_advance folded in: one launch less per step)
     if (*found_inf != 0.0f) {
         *scale = *scale * backoff;
@@ -192,12 +193,17 @@ __global__ void k_scaler_update(float* __restrict__ scale, int32_t* __restrict__
     }
     *found_inf = 0.0f;
 }
+__global__ void k_scaler_update(float* __restrict__ scale, int32_t* __restrict__ growth_tracker, float* __restrict__ found_inf,
+                                float growth, float backoff, int32_t interval, float* __restrict__ adam_step) {
+    scaler_update(scale, growth_tracker, found_inf, growth, backoff, interval, adam_step);
+}
 
 // End of a graph-replayed training step: file the step's loss and the marcher's {samples, rays} counter in their 16-slot rings
 // (nerf/renderer.py keeps the counters of the last 16 steps for `mean_count`), clear the counter for the next replay and
 // advance the slot — what the host otherwise does with two copies and a fill per step.
-__global__ void k_step_ring_push(const float* __restrict__ loss, int32_t* __restrict__ counter, float* __restrict__ loss_ring,
-                                 int32_t* __restrict__ counter_ring, int32_t* __restrict__ cursor, int32_t ring) {
+__device__ __forceinline__ void step_ring_push(const float* __restrict__ loss, int32_t* __restrict__ counter,
+                                               float* __restrict__ loss_ring, int32_t* __restrict__ counter_ring,
+                                               int32_t* __restrict__ cursor, int32_t ring) {
     int32_t c = *cursor;
     if (c < 0 || c >= ring) c = 0;
     if (loss && loss_ring) loss_ring[c] = *loss;
@@ -207,6 +213,18 @@ __global__ void k_step_ring_push(const float* __restrict__ loss, int32_t* __rest
     counter[1] = 0;
     cursor[0] = (c + 1) % ring;
     cursor[1] += 1;
+}
+__global__ void k_step_ring_push(const float* __restrict__ loss, int32_t* __restrict__ counter, float* __restrict__ loss_ring,
+                                 int32_t* __restrict__ counter_ring, int32_t* __restrict__ cursor, int32_t ring) {
+    step_ring_push(loss, counter, loss_ring, counter_ring, cursor, ring);
+}
+// both single-thread epilogues of a step in one launch
+__global__ void k_step_epilogue(float* __restrict__ scale, int32_t* __restrict__ growth_tracker, float* __restrict__ found_inf,
+                                float growth, float backoff, int32_t interval, float* __restrict__ adam_step,
+                                const float* __restrict__ loss, int32_t* __restrict__ counter, float* __restrict__ loss_ring,
+                                int32_t* __restrict__ counter_ring, int32_t* __restrict__ cursor, int32_t ring) {
+    scaler_update(scale, growth_tracker, found_inf, growth, backoff, interval, adam_step);
+    step_ring_push(loss, counter, loss_ring, counter_ring, cursor, ring);
 }
 
 }  // namespace
@@ -294,4 +312,15 @@ S3D_EXPORT int s3d_step_ring_push(const float* loss, int32_t* counter, float* lo
     S3D_REQUIRE(counter && counter_ring && cursor && ring > 0, "step_ring_push: null pointer or empty ring");
     hipLaunchKernelGGL(k_step_ring_push, dim3(1), dim3(1), 0, as_stream(stream), loss, counter, loss_ring, counter_ring, cursor, ring);
     return check_launch("step_ring_push");
+}
+
+S3D_EXPORT int s3d_step_epilogue(float* scale, int32_t* growth_tracker, float* found_inf, float growth_factor,
+                                 float backoff_factor, int32_t growth_interval, float* adam_step, const float* loss,
+                                 int32_t* counter, float* loss_ring, int32_t* counter_ring, int32_t* cursor, int32_t ring,
+                                 s3d_stream_t stream) {
+    S3D_REQUIRE(scale && growth_tracker && found_inf, "step_epilogue: null pointer (scaler)");
+    S3D_REQUIRE(counter && counter_ring && cursor && ring > 0, "step_epilogue: null pointer or empty ring");
+    hipLaunchKernelGGL(k_step_epilogue, dim3(1), dim3(1), 0, as_stream(stream), scale, growth_tracker, found_inf, growth_factor,
+                       backoff_factor, growth_interval, adam_step, loss, counter, loss_ring, counter_ring, cursor, ring);
+    return check_launch("step_epilogue");
 }

@@ -51,6 +51,29 @@ __device__ __forceinline__ float ray_noise(uint32_t key, uint32_t step, uint32_t
     return (float)(pcg_hash(pcg_hash(key ^ (step * 0x9E3779B9u)) + n) >> 8) * (1.0f / 16777216.0f);  // [0, 1)
 }
 
+// Rows of a padded sample batch that no ray fills but the consumers still process (seal3d_hip.h: `n_valid` rounds the sample
+// count up to 128 rows; a ray that does not fit the budget M leaves [offset, M) empty).  The training kernels write them as
+// zeros themselves, so the caller's buffers need no zero fill: `lane`/`nlanes` = the lanes sharing the work.
+__device__ __forceinline__ uint32_t pad_end(uint32_t total, uint32_t M) {
+    const uint32_t e = (total + 127u) & ~127u;
+    return e < M ? e : M;
+}
+__device__ __forceinline__ void zero_sample_rows(float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas,
+                                                 uint32_t lo, uint32_t hi, uint32_t lane, uint32_t nlanes) {
+    for (size_t o = (size_t)lo + lane; o < hi; o += nlanes) {
+        xyzs[o * 3] = 0.0f; xyzs[o * 3 + 1] = 0.0f; xyzs[o * 3 + 2] = 0.0f;
+        dirs[o * 3] = 0.0f; dirs[o * 3 + 1] = 0.0f; dirs[o * 3 + 2] = 0.0f;
+        deltas[o * 2] = 0.0f; deltas[o * 2 + 1] = 0.0f;
+    }
+}
+__device__ __forceinline__ void zero_grad_rows(float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs, uint32_t lo,
+                                               uint32_t hi, uint32_t lane, uint32_t nlanes) {
+    for (size_t o = (size_t)lo + lane; o < hi; o += nlanes) {
+        grad_sigmas[o] = 0.0f;
+        grad_rgbs[o * 3] = 0.0f; grad_rgbs[o * 3 + 1] = 0.0f; grad_rgbs[o * 3 + 2] = 0.0f;
+    }
+}
+
 __global__ void k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                            const float* __restrict__ aabb, uint32_t N, float min_near,
                            float* __restrict__ nears, float* __restrict__ fars, float* __restrict__ noises,
@@ -257,6 +280,8 @@ __global__ void __launch_bounds__(64) k_march_write(const float* __restrict__ ra
     const uint32_t num_steps = (uint32_t)rays[n * 3 + 2];
     const uint32_t off = base + (uint32_t)rays[n * 3 + 1];
     rays[n * 3 + 1] = (int32_t)off;
+    if (n == N - 1 && off + num_steps < M) zero_sample_rows(xyzs, dirs, deltas, off + num_steps, pad_end(off + num_steps, M), 0, 1);
+    if (num_steps != 0 && off < M && off + num_steps > M) zero_sample_rows(xyzs, dirs, deltas, off, M, 0, 1);
     if (num_steps == 0 || off + num_steps > M) return;
 
     const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
@@ -515,6 +540,8 @@ __global__ void __launch_bounds__(64) k_march_write_wave(const float* __restrict
         rays[n * 3 + 1] = (int32_t)off;
         if (n == N - 1) { counter[0] = (int32_t)(off + num_steps); counter[1] = counter[1] + (int32_t)N; }
     }
+    if (n == N - 1 && off + num_steps < M) zero_sample_rows(xyzs, dirs, deltas, off + num_steps, pad_end(off + num_steps, M), lane, 64);
+    if (num_steps != 0 && off < M && off + num_steps > M) zero_sample_rows(xyzs, dirs, deltas, off, M, lane, 64);
     if (num_steps == 0 || off + num_steps > M) return;
     const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, nullptr);
     const Ray r = load_ray(rays_o, rays_d, n);
@@ -582,6 +609,8 @@ __global__ void __launch_bounds__(64) k_composite_train_bwd(const float* __restr
     const uint32_t n = blockIdx.x * 64 + threadIdx.x;
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (n == N - 1 && offset + num_steps < M) zero_grad_rows(grad_sigmas, grad_rgbs, offset + num_steps, pad_end(offset + num_steps, M), 0, 1);
+    if (num_steps != 0 && offset < M && offset + num_steps > M) zero_grad_rows(grad_sigmas, grad_rgbs, offset, M, 0, 1);
     if (num_steps == 0 || offset + num_steps > M) return;
     const float gws = grad_weights_sum[index];
     const float gi0 = grad_image[index * 3], gi1 = grad_image[index * 3 + 1], gi2 = grad_image[index * 3 + 2];
@@ -607,7 +636,10 @@ __global__ void __launch_bounds__(64) k_composite_train_bwd(const float* __restr
         acc = __builtin_fmaf(gi2, __builtin_fmaf(T, c2, -(b_final - b)), acc);
         acc = __builtin_fmaf(gws, 1 - ws_final, acc);
         gs[step] = dd.x * acc;
-        if (T < T_thresh) break;
+        if (T < T_thresh) {  // samples behind the termination take no gradient
+            zero_grad_rows(grad_sigmas, grad_rgbs, offset + step + 1, offset + num_steps, 0, 1);
+            break;
+        }
     }
 }
 
@@ -686,6 +718,8 @@ __global__ void __launch_bounds__(256) k_composite_train_bwd_wave(const float* _
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    if (n == N - 1 && offset + num_steps < M) zero_grad_rows(grad_sigmas, grad_rgbs, offset + num_steps, pad_end(offset + num_steps, M), lane, 64);
+    if (num_steps != 0 && offset < M && offset + num_steps > M) zero_grad_rows(grad_sigmas, grad_rgbs, offset, M, lane, 64);
     if (num_steps == 0 || offset + num_steps > M) return;
     const float gws = grad_weights_sum[index];
     const float gi0 = grad_image[index * 3], gi1 = grad_image[index * 3 + 1], gi2 = grad_image[index * 3 + 2];
@@ -714,10 +748,16 @@ __global__ void __launch_bounds__(256) k_composite_train_bwd_wave(const float* _
             acc += gi2 * (Tn * c2 - (bf - bb));
             acc += gws * (1 - wsf);
             grad_sigmas[o] = d0 * acc;
+        } else if (valid) {  // behind the termination: no gradient
+            grad_rgbs[o * 3] = 0.0f; grad_rgbs[o * 3 + 1] = 0.0f; grad_rgbs[o * 3 + 2] = 0.0f;
+            grad_sigmas[o] = 0.0f;
         }
         T_carry *= __shfl(P, 63, 64);
         rc = __shfl(rr, 63, 64); gc = __shfl(gg, 63, 64); bc = __shfl(bb, 63, 64);
-        if (T_carry < T_thresh) break;
+        if (T_carry < T_thresh) {
+            zero_grad_rows(grad_sigmas, grad_rgbs, offset + base + 64, offset + num_steps, lane, 64);
+            break;
+        }
     }
 }
 

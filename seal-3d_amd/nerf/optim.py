@@ -252,10 +252,18 @@ class NativeGradScaler:
         while pending:
             dist.finish_chunk(pending.pop(0))
 
-    def update(self):
-        if self.enabled:
+    def update(self, ring_push=None):
+        """`ring_push` = (loss, counter, loss_ring, counter_ring, cursor): a graph-replayed trainer's end-of-step bookkeeping
+        (OptimBackend.step_ring_push) rides in the same single-thread launch"""
+        if self.enabled and ring_push is not None:
+            _backend.step_epilogue(self._scale, self._growth_tracker, self._found_inf, self.growth_factor, self.backoff_factor,
+                                   self.growth_interval, self._advance, *ring_push)
+            self._advance = None
+        elif self.enabled:
             _backend.scaler_update(self._scale, self._growth_tracker, self._found_inf, self.growth_factor,
                                    self.backoff_factor, self.growth_interval, self._advance)
             self._advance = None
         else:
             self._found_inf.zero_()
+            if ring_push is not None:
+                _backend.step_ring_push(*ring_push)

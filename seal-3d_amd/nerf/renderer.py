@@ -78,6 +78,10 @@ class NeRFRenderer(nn.Module):
         with torch.autocast("cuda", dtype=torch.float16):
             return bool(self.honours_row_limit(rows))
 
+    def _plain_sample_path(self):
+        """no per-sample hook between the marcher and the network (a hook may read sample rows as whole tensors)"""
+        return type(self).map_samples is NeRFRenderer.map_samples and type(self).map_colors is NeRFRenderer.map_colors
+
     # ---- per-sample hooks (identity here; the Seal teacher overrides them, SealNeRF/renderer.py:291-316, 381-399)
     def map_samples(self, xyzs, dirs):
         return xyzs, dirs, None
@@ -137,10 +141,14 @@ class NeRFRenderer(nn.Module):
             self.local_step += 1
             budgeted = (not force_all_rays) and self.mean_count > 0
             trim = budgeted or not self.honours_row_limit(N * max_steps)  # (no budget: N * max_steps rows, 128-aligned)
+            # every consumer of the sample rows takes the device-side count: nothing reads behind it, the HIP kernels keep the
+            # unfilled rows in front of it zero themselves -> no zero fill of the M-row buffers (forward and gradients)
+            M_rows = self.mean_count + 128 - self.mean_count % 128 if budgeted else N * max_steps  # (the marcher's M)
+            lean = rays_o.is_cuda and (budgeted or not trim) and self.honours_row_limit(M_rows) and self._plain_sample_path()
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, counter,
                 self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps,
-                *(() if trim and noises is None else (trim, noises)))
+                *(() if trim and noises is None and not lean else (trim, noises, not lean)))
             # the buffers are padded to M rows (raymarching.py:205-207); counter[0] says on the device how many hold samples
             # (a proxy mapper skips the rows behind the count only when the network behind it skips them too: otherwise the
             #  network would read rows the mapper never wrote)
@@ -155,7 +163,8 @@ class NeRFRenderer(nn.Module):
             if self.density_scale != 1:  # (x1 is the identity: skip the pass over [M])
                 sigmas = self.density_scale * sigmas
             rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)
-            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
+            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh,
+                                                                         *(() if not lean else (False,)))
             if kwargs.get("defer_background", False) and not torch.is_tensor(bg_color):
                 # the caller composites the background inside its fused loss kernel (nerf/trainer.py:bg_mse_loss)
                 results["premultiplied"] = True

@@ -199,6 +199,7 @@ class GraphedTrainer(Trainer):
         self.s_cursor = torch.zeros(2, dtype=torch.int32, device=dev)  # {ring slot, running step number}
         self.noise_key = (torch.initial_seed() * 0x9E3779B1 + (self.dist.rank if self.dist is not None else 0) * 0x85EBCA6B) & 0xFFFFFFFF
         self._counter_ring = None
+        self._ring_args = None
 
     def _static_loss(self):
         """the step's loss on the static input buffers (subclasses: other criteria, e.g. Seal's depth term)"""
@@ -215,15 +216,23 @@ class GraphedTrainer(Trainer):
         loss = self._static_loss()
         self._backward(loss)
         loss = loss.detach()
+        self._ring_args = None
         if self._counter_ring is not None:
-            import s3d_hip
-            s3d_hip.OptimBackend.step_ring_push(loss.float().reshape(()), self.s_counter, self.loss_ring, self._counter_ring,
-                                                self.s_cursor)
+            args = (loss.float().reshape(()), self.s_counter, self.loss_ring, self._counter_ring, self.s_cursor)
+            if self.native_optim:
+                self._ring_args = args  # rides in the scaler update's launch (_body_opt)
+            else:
+                import s3d_hip
+                s3d_hip.OptimBackend.step_ring_push(*args)
         return loss
 
     def _body_opt(self):
         self.scaler.step(self.optimizer)
-        self.scaler.update()
+        if self._ring_args is not None:
+            self.scaler.update(ring_push=self._ring_args)
+            self._ring_args = None
+        else:
+            self.scaler.update()
 
     def _capture(self):
         """One graph for the whole step on a single GPU.  With data parallelism the step is captured as TWO graphs

@@ -15,6 +15,11 @@ import s3d_hip
 _backend = s3d_hip.RaymarchingBackend
 
 
+def _empty_332(M, dtype, device):
+    flat = torch.empty(M * 8, dtype=dtype, device=device)
+    return flat[:3 * M].view(M, 3), flat[3 * M:6 * M].view(M, 3), flat[6 * M:].view(M, 2)
+
+
 def _zeros_332(M, dtype, device):
     """xyzs [M,3], dirs [M,3], deltas [M,2], zero-initialised as in the reference (raymarching.py:205-207, padding rows
     must read as zeros) — three contiguous tensors carved out of ONE filled buffer (one fill kernel instead of three)."""
@@ -138,11 +143,15 @@ class _MarchRaysTrain(Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
-                perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, trim=True, noises=None):
+                perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, trim=True, noises=None,
+                zero_fill=True):
         """`trim=False` (build extension): without a sample budget the reference reads the sample count back and trims the
         N * max_steps buffers (raymarching.py:223-231: a device->host sync).  A caller whose whole sample path takes the
         device-side count (`n_valid`, seal3d_hip.h) keeps the full buffers instead: no sync, static shapes.
-        `noises` (build extension): the per-ray jitter [N] in [0, 1) when the caller has drawn it already (perturb)."""
+        `noises` (build extension): the per-ray jitter [N] in [0, 1) when the caller has drawn it already (perturb).
+        `zero_fill=False` (build extension, HIP backend): the reference zero-fills the M-row buffers; the HIP kernels write
+        zeros to every unfilled row below the sample count rounded up to 128 themselves (seal3d_hip.h), which is all a caller
+        reads whose sample path takes the device-side count — it can skip the fill."""
         rays_o, rays_d = _rays(rays_o, rays_d)
         density_bitfield = _on_device(density_bitfield).contiguous()
         dev, dt = rays_o.device, rays_o.dtype
@@ -154,7 +163,7 @@ class _MarchRaysTrain(Function):
         if budgeted:
             M = _align_up(mean_count, align)
 
-        xyzs, dirs, deltas = _zeros_332(M, dt, dev)
+        xyzs, dirs, deltas = _zeros_332(M, dt, dev) if zero_fill else _empty_332(M, dt, dev)
         rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
         if step_counter is None:
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
@@ -181,7 +190,9 @@ class _CompositeRaysTrain(Function):
 
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, sigmas, rgbs, deltas, rays, T_thresh=1e-4):
+    def forward(ctx, sigmas, rgbs, deltas, rays, T_thresh=1e-4, zero_grads=True):
+        """`zero_grads=False` (build extension, HIP backend): as `zero_fill` of march_rays_train, for the gradient buffers"""
+        ctx.zero_grads = zero_grads
         # the kernels are fp32 (the reference reaches them through autocast's cast_inputs); outside autocast a half-precision
         # network output (ffmlp always computes in fp16) is converted here instead of being misread
         sigmas, rgbs = sigmas.float().contiguous(), rgbs.float().contiguous()
@@ -202,19 +213,20 @@ class _CompositeRaysTrain(Function):
         sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
         M, N, T_thresh = ctx.dims
         if grad_weights_sum is None and grad_image is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         if grad_weights_sum is None:
             grad_weights_sum = torch.zeros_like(weights_sum)
         if grad_image is None:
             grad_image = torch.zeros_like(image)
         # zero-initialised like the reference (raymarching.py:283-284) — one fill for both
-        flat = torch.zeros(sigmas.numel() + rgbs.numel(), dtype=sigmas.dtype, device=sigmas.device)
+        alloc = torch.zeros if ctx.zero_grads else torch.empty
+        flat = alloc(sigmas.numel() + rgbs.numel(), dtype=sigmas.dtype, device=sigmas.device)
         grad_sigmas = flat[:sigmas.numel()].view_as(sigmas)
         grad_rgbs = flat[sigmas.numel():].view_as(rgbs)
         _backend.composite_rays_train_backward(grad_weights_sum.contiguous(), grad_image.contiguous(), sigmas, rgbs,
                                                deltas.contiguous(), rays, weights_sum, image, M, N, T_thresh,
                                                grad_sigmas, grad_rgbs)
-        return grad_sigmas, grad_rgbs, None, None, None
+        return grad_sigmas, grad_rgbs, None, None, None, None
 
 
 composite_rays_train = _CompositeRaysTrain.apply

@@ -38,7 +38,7 @@ EXPORTS = [
     "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
     "s3d_ffmlp_fused_backward_supported",
     "s3d_ffmlp_allocate_splitk", "s3d_ffmlp_free_splitk",
-    "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_step_multi", "s3d_adam_advance", "s3d_scaler_update", "s3d_step_ring_push",
+    "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_step_multi", "s3d_adam_advance", "s3d_scaler_update", "s3d_step_ring_push", "s3d_step_epilogue",
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_mid2_forward", "s3d_ngp_mid2_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
     "s3d_bg_mse_forward", "s3d_bg_mse_backward",
     "s3d_seal_bbox_map", "s3d_vm_features_forward",
@@ -552,6 +552,24 @@ class OptimBackend:
     @staticmethod
     def adam_advance(step, found_inf):
         _check(lib().s3d_adam_advance(_p(step), _p(found_inf), _stream()), "adam_advance")
+
+    @staticmethod
+    def step_epilogue(scale, growth_tracker, found_inf, growth_factor, backoff_factor, growth_interval, adam_step, loss, counter,
+                      loss_ring, counter_ring, cursor):
+        """scaler_update + step_ring_push in one launch (seal3d_hip.h)"""
+        _need(scale, torch.float32, "scale"); _need(growth_tracker, torch.int32, "growth_tracker")
+        _need(counter, torch.int32, "counter"); _need(counter_ring, torch.int32, "counter_ring"); _need(cursor, torch.int32, "cursor")
+        if adam_step is not None:
+            _need(adam_step, torch.float32, "adam_step")
+        if loss is not None:
+            _need(loss, torch.float32, "loss"); _need(loss_ring, torch.float32, "loss_ring")
+        ring = counter_ring.shape[0]
+        if cursor.numel() < 2 or counter_ring.numel() != 2 * ring or (loss is not None and loss_ring.numel() != ring):
+            raise RuntimeError("step_epilogue: cursor is int32[2], rings are [ring, 2] / [ring]")
+        _check(lib().s3d_step_epilogue(_p(scale), _p(growth_tracker), _p(found_inf), _f(growth_factor), _f(backoff_factor),
+                                       C.c_int32(int(growth_interval)), _p(adam_step), _p(loss),
+                                       _p(counter), _p(loss_ring if loss is not None else None), _p(counter_ring), _p(cursor),
+                                       C.c_int32(ring), _stream()), "step_epilogue")
 
     @staticmethod
     def step_ring_push(loss, counter, loss_ring, counter_ring, cursor):

@@ -188,6 +188,48 @@ def test_march_rays_train_capped_budget_and_empty(oracle, hip, march_path):
         assert torch.equal(cpu[15], gpu[15].cpu()) and torch.equal(cpu[16], gpu[16].cpu())
 
 
+@pytest.mark.parametrize("M", [4096 * 256, 20000], ids=["roomy", "capped-budget"])
+def test_training_kernels_zero_the_unfilled_rows_they_expose(hip, march_path, M):
+    """seal3d_hip.h: with garbage (NaN) in the caller's buffers, march_rays_train and composite_rays_train_backward leave
+    every row a consumer bounded by the device-side count can read — [0, min(round_up(total, 128), M)) — exactly as with
+    zero-filled buffers (samples, zero pads, the dropped straddling ray's rows, samples behind an early termination)."""
+    R = hip.RaymarchingBackend
+    _, bits = _scene(seed=0)
+    ro, rd = _rays(4096, seed=4)
+    base = [a.cuda() if torch.is_tensor(a) else a for a in _march_train_args(ro, rd, bits, 1, 1.0, M, True)]
+    dirty = list(base)
+    for k in (12, 13, 14):
+        dirty[k] = torch.full_like(base[k], float("nan"))
+    dirty[15], dirty[16] = torch.empty_like(base[15]), torch.zeros_like(base[16])
+    R.march_rays_train(*base)
+    R.march_rays_train(*dirty)
+    total = int(base[16][0])
+    assert (total > M) == (M == 20000)
+    end = min((total + 127) // 128 * 128, M)
+    assert torch.equal(base[15], dirty[15]) and torch.equal(base[16], dirty[16])
+    for k in (12, 13, 14):
+        assert torch.equal(base[k][:end], dirty[k][:end])
+        assert end == M or torch.isnan(dirty[k][end:]).all()  # nothing written behind the exposed rows
+    # gradients: dense sigmas (early terminations), NaN-filled gradient buffers
+    N, rays, deltas = 4096, base[15], base[14]
+    g = torch.Generator().manual_seed(1)
+    sigmas = torch.exp(torch.randn(M, generator=g) * 2 + 1).cuda()
+    rgbs = torch.rand(M, 3, generator=g).cuda()
+    ws, dp, im = (torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, 3, device="cuda"))
+    for cpath in (0, 1):
+        R.set_composite_path(cpath)
+        R.composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, 1e-4, ws, dp, im)
+        gws, gim = torch.randn(N, generator=g).cuda(), torch.randn(N, 3, generator=g).cuda()
+        out = []
+        for fill in (0.0, float("nan")):
+            gs, gc = torch.full((M,), fill, device="cuda"), torch.full((M, 3), fill, device="cuda")
+            R.composite_rays_train_backward(gws, gim, sigmas, rgbs, deltas, rays, ws, im, M, N, 1e-4, gs, gc)
+            out.append((gs, gc))
+        assert torch.equal(out[0][0][:end], out[1][0][:end]) and torch.equal(out[0][1][:end], out[1][1][:end])
+        assert (out[0][0][:end] == 0).any() and (out[0][0][:end] != 0).any()
+    R.set_composite_path(0)
+
+
 def _composite_inputs(oracle, seed=0, n_rays=4096):
     _, bits = _scene(seed=0)
     ro, rd = _rays(n_rays, seed=seed)
