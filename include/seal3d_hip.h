@@ -165,7 +165,10 @@ int s3d_grid_corner_indices(const float* inputs, const int32_t* offsets, uint32_
  * workspace (s3d_grid_encode_backward_workspace_size bytes; 0 = configuration not supported) enables the
  * binned path used for B >= 8192: contributions are partitioned by table slice and summed in LDS as 64-bit
  * fixed point — deterministic, no global atomics.  Without it (NULL) direct atomics are used.
- * path: 0 = auto, 1 = direct atomics, 2 = binned (an error when the workspace is missing). */
+ * path: 0 = auto, 1 = direct atomics, 2 = binned (an error when the workspace is missing).
+ * found_inf (optional, build extension): a device float raised to 1 when grad_embeddings holds a non-finite value after
+ * the call (torch.amp.GradScaler's check, nerf/utils.py:495-537, made where the gradient is produced: the binned fp16 path
+ * reports while it writes the sums, the other paths scan the table once).  Never cleared here. */
 size_t s3d_grid_encode_backward_workspace_size(uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                                uint32_t max_level_rows, int dtype);
 int s3d_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
@@ -173,7 +176,8 @@ int s3d_grid_encode_backward(const void* grad, const float* inputs, const void* 
                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                              const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                              uint32_t interp, int dtype, void* workspace, size_t workspace_bytes,
-                             float bound, const int32_t* n_valid, int path, s3d_stream_t stream);
+                             float bound, const int32_t* n_valid, int path, float* found_inf,
+                             s3d_stream_t stream);
 
 /* gridencoder.h:15 void grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H,
  *                        gridtype, align_corners) — fp32 only (grid.py:162 disables autocast) */
@@ -218,7 +222,9 @@ int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_
  * forward_buffer == backward_buffer == NULL selects the fused backward: the activations are re-computed from
  * `inputs` inside one kernel that also forms the data and weight gradients, so a training forward may skip
  * forward_buffer altogether (call s3d_ffmlp_forward with forward_buffer = NULL).  Shapes it covers:
- * s3d_ffmlp_fused_backward_supported() != 0 (hidden 32/64, <= 3 hidden matrices, no sine). */
+ * s3d_ffmlp_fused_backward_supported() != 0 (hidden 32/64, <= 3 hidden matrices, no sine).
+ * found_inf (optional, build extension): device float raised to 1 when a written grad_weights element is non-finite
+ * (GradScaler's check made by the kernel that writes the gradient).  Never cleared here. */
 int s3d_ffmlp_fused_backward_supported(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                                        uint32_t num_layers, uint32_t activation);
 size_t s3d_ffmlp_backward_workspace_size(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
@@ -229,7 +235,7 @@ int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
                        uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer,
                        uint16_t* grad_inputs, uint16_t* grad_weights, void* workspace,
                        size_t workspace_bytes, int input_layout, int accumulate_grad_weights,
-                       const int32_t* n_valid, s3d_stream_t stream);
+                       const int32_t* n_valid, float* found_inf, s3d_stream_t stream);
 /* ffmlp.h:13-14: the reference allocates split-K side streams here; this build fuses the weight
  * gradient into the backward launch sequence on the caller's stream, so these are no-ops kept for
  * surface compatibility. */

@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_wgrad(WgradPlan plan, uint32_t B,
 // 256 partials was latency-bound: ~20 us), then a fixed xor-shuffle tree combines the eight.  Deterministic.
 constexpr uint32_t kReduceSplit = 8;
 __global__ void k_ffmlp_wgrad_reduce(WgradPlan plan, uint32_t nblk, const float* __restrict__ partial,
-                                     _Float16* __restrict__ grad_weights, uint32_t accumulate) {
+                                     _Float16* __restrict__ grad_weights, uint32_t accumulate, float* __restrict__ found_inf) {
     const WgradLayer L = plan.layer[blockIdx.y];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t e = t / kReduceSplit, part = t % kReduceSplit;
@@ -500,7 +500,10 @@ __global__ void k_ffmlp_wgrad_reduce(WgradPlan plan, uint32_t nblk, const float*
     for (int d = 1; d < (int)kReduceSplit; d <<= 1) v += __shfl_xor(v, d, 64);
     if (live && part == 0) {
         if (accumulate) v += (float)grad_weights[L.w_off + e];  // add to the caller's running gradient (fp16 hand-over buffer)
-        grad_weights[L.w_off + e] = (_Float16)v;
+        const _Float16 h = (_Float16)v;
+        grad_weights[L.w_off + e] = h;
+        // GradScaler's non-finite check made where the gradient is written (benign race: everyone writes 1)
+        if (found_inf && !(fabsf((float)h) <= 65504.0f)) *found_inf = 1.0f;
     }
 }
 
@@ -813,9 +816,10 @@ constexpr uint32_t kWgradBlocks = 256;
 
 // `n_valid` of the entry point being served on this thread (see valid_rows()); the launch helpers below pass it on
 static thread_local const int32_t* t_n_valid = nullptr;
+static thread_local float* t_found_inf = nullptr;  // s3d_ffmlp_backward(found_inf) of the call being served
 struct RowLimitScope {
-    explicit RowLimitScope(const int32_t* p) { t_n_valid = p; }
-    ~RowLimitScope() { t_n_valid = nullptr; }
+    explicit RowLimitScope(const int32_t* p, float* found_inf = nullptr) { t_n_valid = p; t_found_inf = found_inf; }
+    ~RowLimitScope() { t_n_valid = nullptr; t_found_inf = nullptr; }
 };
 
 int check_shape(uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t W, uint32_t n_layers) {
@@ -879,7 +883,7 @@ int launch_backward(const _Float16* grad, const _Float16* X, const _Float16* Wt,
     if (nblk > kWgradBlocks) nblk = kWgradBlocks;
     hipLaunchKernelGGL((k_ffmlp_wgrad<W>), dim3(nblk, plan.n), dim3(256), 0, st, plan, B, partial, t_n_valid);
     hipLaunchKernelGGL(k_ffmlp_wgrad_reduce, dim3(div_up<uint32_t>(W * W * kReduceSplit, 256), plan.n), dim3(256), 0, st, plan, nblk,
-                       (const float*)partial, grad_weights, accumulate);
+                       (const float*)partial, grad_weights, accumulate, t_found_inf);
     return check_launch("ffmlp_backward");
 }
 
@@ -920,7 +924,7 @@ int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Floa
         plan.layer[1 + m] = WgradLayer{nullptr, nullptr, 0u, 0u, (uint32_t)W, (uint32_t)W, (uint32_t)(W * in_dim + m * W * W)};
     plan.layer[NH + 1] = WgradLayer{nullptr, nullptr, 0u, 0u, 16u, (uint32_t)W, (uint32_t)(W * in_dim + NH * W * W)};
     hipLaunchKernelGGL(k_ffmlp_wgrad_reduce, dim3(div_up<uint32_t>(W * W * kReduceSplit, 256), plan.n), dim3(256), 0, st, plan, nblk,
-                       (const float*)partial, grad_weights, accumulate);
+                       (const float*)partial, grad_weights, accumulate, t_found_inf);
     return check_launch("ffmlp_backward (fused)");
 }
 
@@ -991,10 +995,10 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
                                   uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                                   uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer,
                                   uint16_t* grad_inputs, uint16_t* grad_weights, void* workspace, size_t workspace_bytes,
-                                  int input_layout, int accumulate_grad_weights, const int32_t* n_valid,
+                                  int input_layout, int accumulate_grad_weights, const int32_t* n_valid, float* found_inf,
                                   s3d_stream_t stream) {
     (void)output_activation;
-    const RowLimitScope rows(n_valid);
+    const RowLimitScope rows(n_valid, found_inf);
     const uint32_t accumulate = accumulate_grad_weights ? 1u : 0u;
     S3D_REQUIRE(input_layout == 0 || (input_layout == 1 && !forward_buffer),
                 "ffmlp_backward: the level-major input layout is implemented by the fused backward (no forward_buffer)");

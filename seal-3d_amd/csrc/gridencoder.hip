@@ -1245,7 +1245,7 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate4(const uint2*
                                                                    uint32_t B, uint32_t level0, const uint32_t* __restrict__ hdr,
                                                                    const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ ovn,
                                                                    const uint2* __restrict__ ovl, uint32_t smax, uint32_t nchunks,
-                                                                   uint32_t cap) {
+                                                                   uint32_t cap, float* __restrict__ found_inf) {
     using V = typename FeatVec<T, C>::type;
     static_assert(sizeof(V) == 4, "packed records");
     constexpr uint32_t K = 1u << D;
@@ -1271,6 +1271,7 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate4(const uint2*
             const uint32_t row = row_of_local(i / C);
             if (row < rows) table[(size_t)row * C + i % C] = Acc<T>::from_f(NAN);
         }
+        if (found_inf && threadIdx.x == 0) *found_inf = 1.0f;  // (benign race: everyone writes 1)
         return;
     }
     if (!FIXED24 && !(amax > 0.0f)) return;
@@ -1396,6 +1397,7 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate4(const uint2*
     }
     __syncthreads();
     constexpr uint32_t W = 8;
+    bool overflow = false;  // a finite sum that leaves the range of T (fp16: |v| > 65504) — what GradScaler looks for
     for (uint32_t r0 = threadIdx.x; r0 < local_rows; r0 += W * kBinAccThreads) {
         long long q[W][C];
         V old[W];
@@ -1418,12 +1420,30 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate4(const uint2*
                 T o[C];
                 __builtin_memcpy(o, &old[w], sizeof(V));
 #pragma unroll
-                for (uint32_t c = 0; c < C; c++) o[c] = Acc<T>::from_f(Acc<T>::to_f(o[c]) + fixed_to_float(q[w][c], kexp));
+                for (uint32_t c = 0; c < C; c++) {
+                    o[c] = Acc<T>::from_f(Acc<T>::to_f(o[c]) + fixed_to_float(q[w][c], kexp));
+                    overflow |= !(fabsf(Acc<T>::to_f(o[c])) <= 3.402823466e38f);
+                }
                 store_feat<T, C>(table + (size_t)row_of_local(r0 + w * kBinAccThreads) * C, o);
             }
         }
     }
+    if (found_inf && overflow) *found_inf = 1.0f;
 }
+
+// s3d_grid_encode_backward(found_inf): the paths that do not report while they accumulate check the table afterwards
+template <typename T>
+__global__ void __launch_bounds__(256) k_table_nonfinite(const T* __restrict__ table, const int32_t* __restrict__ offsets, uint32_t L,
+                                                         uint32_t C, float* __restrict__ found_inf) {
+    const size_t n = (size_t)offsets[L] * C;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        bad |= !(fabsf(Acc<T>::to_f(table[i])) <= 3.402823466e38f);
+    if (bad) *found_inf = 1.0f;
+}
+// found_inf of the entry point being served on this thread, and whether the path taken has reported into it
+static thread_local float* t_found_inf = nullptr;
+static thread_local bool t_reported = false;
 
 // gridencoder.cu:340-366
 template <typename T, uint32_t D, uint32_t C>
@@ -1644,8 +1664,10 @@ int launch_binned2(const T* grad, const float* inputs, const int32_t* offsets, T
                            ac, interp);
         hipLaunchKernelGGL((k_bin_accumulate4<T, D, C, FIXED24>), dim3(lay.smax, nl), dim3(kBinAccThreads), kBinAccBytes, st,
                            (const uint2*)recs, (const uint2*)spill, offsets, grad_emb, B, l0, (const uint32_t*)hdr,
-                           (const uint32_t*)cursor, (const uint32_t*)ovn, (const uint2*)ovl, lay.smax, lay.chunks, lay.cap);
+                           (const uint32_t*)cursor, (const uint32_t*)ovn, (const uint2*)ovl, lay.smax, lay.chunks, lay.cap,
+                           t_found_inf);
     }
+    t_reported = true;
     return check_launch("grid_encode_backward");
 }
 
@@ -1839,7 +1861,8 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
                                         uint32_t max_level_rows, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                         const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                                         uint32_t interp, int dtype, void* workspace, size_t workspace_bytes,
-                                        float bound, const int32_t* n_valid, int path, s3d_stream_t stream) {
+                                        float bound, const int32_t* n_valid, int path, float* found_inf,
+                                        s3d_stream_t stream) {
     // path: 0 = auto (binned from 8,192 points), 1 = direct global atomics, 2 = binned (partition + LDS accumulate)
     (void)embeddings;
     S3D_REQUIRE(path >= 0 && path <= 2, "grid_encode_backward: path must be 0 (auto), 1 (atomics) or 2 (binned)");
@@ -1860,6 +1883,9 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
     const bool ac = align_corners != 0;
     unsigned char* ws = (unsigned char*)workspace;
     const int fp = path;
+    t_found_inf = found_inf;
+    t_reported = false;
+    const auto run = [&]() -> int {
     if (dtype == S3D_F32) {
         const float* g = (const float*)grad; float* ge = (float*)grad_embeddings;
         const float* j = (const float*)dy_dx; float* gi = (float*)grad_inputs;
@@ -1875,6 +1901,15 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
                        (launch_backward<__half, 4>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
                        (launch_backward<__half, 5>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)))
     }
+    };
+    const int rc = run();
+    t_found_inf = nullptr;
+    if (rc != S3D_OK || !found_inf || t_reported) return rc;
+    if (dtype == S3D_F32)
+        hipLaunchKernelGGL(k_table_nonfinite<float>, dim3(kMaxStreamBlocks), dim3(256), 0, st, (const float*)grad_embeddings, offsets, L, C, found_inf);
+    else
+        hipLaunchKernelGGL(k_table_nonfinite<__half>, dim3(kMaxStreamBlocks), dim3(256), 0, st, (const __half*)grad_embeddings, offsets, L, C, found_inf);
+    return check_launch("grid_encode_backward (gradient check)");
 }
 
 S3D_EXPORT int s3d_grad_total_variation(const float* inputs, const float* embeddings, float* grad,

@@ -108,6 +108,9 @@ class _FFMLPForward(Function):
         extra = dict(ctx.extra)
         if stash is not None:
             extra["accumulate"] = True
+            found_inf = getattr(ctx.param_ref.param, "_s3d_found_inf", None)  # GradScaler's check made by the writing kernel
+            if found_inf is not None:
+                extra["found_inf"] = found_inf
         _backend.ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim,
                                 num_layers, activation, output_activation, calc_grad_inputs, backward_buffer,
                                 grad_inputs, grad_weights, **extra)

@@ -109,12 +109,16 @@ class _GridEncode(Function):
         if stash is not None and stash.dtype == embeddings.dtype and stash.shape == embeddings.shape:
             grad_embeddings = stash
             ctx.param._s3d_grad_touched = True
+            found_inf = getattr(ctx.param, "_s3d_found_inf", None)  # GradScaler's check made by the writing kernel
         else:
             stash = None
             grad_embeddings = torch.zeros_like(embeddings)
         grad_inputs = torch.zeros_like(inputs, dtype=embeddings.dtype) if dy_dx is not None else None
+        extra = ctx.extra
+        if stash is not None and found_inf is not None:
+            extra = dict(extra, found_inf=found_inf)
         _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
-                                      grad_inputs, gridtype, align_corners, interpolation, **ctx.extra)
+                                      grad_inputs, gridtype, align_corners, interpolation, **extra)
         if grad_inputs is not None:
             grad_inputs = grad_inputs.to(inputs.dtype)
         return grad_inputs, (None if stash is not None else grad_embeddings), None, None, None, None, None, None, None, None, None, None, None, None
@@ -218,6 +222,7 @@ class GridEncoder(nn.Module):
             _backend.grad_total_variation(inputs.contiguous(), self.embeddings.detach().float(), tv, self.offsets, weight, B, D, C, L,
                                           S, H, self.gridtype_id, self.align_corners)
             stash.add_((tv * grad_scale).to(stash.dtype))
+            self.embeddings._s3d_unchecked = True  # written by a torch op: the scaler checks the buffer itself
             return
         if self.embeddings.grad is None:
             raise ValueError("grad is None, should be called after loss.backward() and before optimizer.step()!")

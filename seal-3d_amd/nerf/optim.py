@@ -86,6 +86,7 @@ class NativeAdam(torch.optim.Optimizer):
                 if getattr(p, "_s3d_grad", None) is not None:
                     p._s3d_grad_touched = False
                     p._s3d_grad_consumed = False
+                    p._s3d_unchecked = False
                 if p.grad is not None:
                     if set_to_none:
                         p.grad = None
@@ -209,9 +210,24 @@ class NativeGradScaler:
         self.growth_factor, self.backoff_factor = state["growth_factor"], state["backoff_factor"]
         self.growth_interval = state["growth_interval"]
 
+    def attach(self, optimizer):
+        """the kernels that WRITE the handed-over gradients (grid / ffmlp backward) raise this scaler's flag themselves
+        (seal3d_hip.h: `found_inf` of s3d_grid_encode_backward / s3d_ffmlp_backward): no separate pass over the 24.5 MB
+        buffer per step.  Single replica only: after an averaging all-reduce the REDUCED gradient is what must be checked."""
+        for group in optimizer.param_groups:
+            for p in group["params"]:
+                if getattr(p, "_s3d_grad", None) is not None:
+                    p._s3d_found_inf = self._found_inf
+                    p._s3d_unchecked = False
+
+    def _checked_at_source(self, optimizer):
+        adopted = [p for group in optimizer.param_groups for p in group["params"] if getattr(p, "_s3d_grad", None) is not None]
+        return bool(adopted) and all(getattr(p, "_s3d_found_inf", None) is self._found_inf and
+                                     not getattr(p, "_s3d_unchecked", False) for p in adopted)
+
     def _check(self, optimizer):
         flat = getattr(optimizer, "flat_half", None)
-        if flat is not None:
+        if flat is not None and not self._checked_at_source(optimizer):
             _backend.grads_nonfinite(flat, self._found_inf)  # every handed-over gradient in one pass
         for _, p, g in optimizer.grads():
             if flat is None or g is not getattr(p, "_s3d_grad", None):

@@ -85,6 +85,8 @@ class Trainer:
             self.optimizer = NativeAdam(model.get_params(lr), lr=lr, betas=(0.9, 0.99), eps=1e-15)
             if self.scaler is None:
                 self.scaler = NativeGradScaler(next(model.parameters()).device, enabled=fp16)
+            if self.dist is None:
+                self.scaler.attach(self.optimizer)
         else:
             self.optimizer = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15, fused=on_gpu,
                                               capturable=self._capturable)

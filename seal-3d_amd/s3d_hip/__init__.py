@@ -379,8 +379,10 @@ class GridBackend:
 
     @staticmethod
     def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, Cc, L, S, H, dy_dx,
-                             grad_inputs, gridtype, align_corners, interp, bound=0.0, n_valid=None):
+                             grad_inputs, gridtype, align_corners, interp, bound=0.0, n_valid=None, found_inf=None):
         _need(inputs, torch.float32, "inputs")
+        if found_inf is not None:
+            _need(found_inf, torch.float32, "found_inf")
         if grad_embeddings.dtype != grad.dtype:
             raise RuntimeError("grad_embeddings must have the dtype of grad")
         mlr = _max_level_rows(offsets)
@@ -391,7 +393,8 @@ class GridBackend:
                                               _u(Cc), _u(L), _f(S), _u(H), _p(dy_dx), _p(grad_inputs), _u(gridtype),
                                               C.c_int(int(align_corners)), _u(interp), C.c_int(_dt(grad)), _p(ws),
                                               C.c_size_t(ws.numel()), _f(bound), _nv(n_valid),
-                                              C.c_int(GridBackend._backward_path), _stream()), "grid_encode_backward")
+                                              C.c_int(GridBackend._backward_path), _p(found_inf), _stream()),
+               "grid_encode_backward")
 
     _backward_path = 0  # `path` argument of s3d_grid_encode_backward (binding-side state for tests / experiments)
 
@@ -480,8 +483,10 @@ class FFMLPBackend:
     @staticmethod
     def ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers,
                        activation, output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights,
-                       input_layout=0, accumulate=False, n_valid=None):
+                       input_layout=0, accumulate=False, n_valid=None, found_inf=None):
         _need(grad, torch.float16, "grad")
+        if found_inf is not None:
+            _need(found_inf, torch.float32, "found_inf")
         nbytes = lib().s3d_ffmlp_backward_workspace_size(_u(input_dim), _u(output_dim), _u(hidden_dim),
                                                         _u(num_layers))
         ws = _ws.get(nbytes, grad.device)
@@ -490,7 +495,8 @@ class FFMLPBackend:
                                         _u(output_activation), C.c_int(int(bool(calc_grad_inputs))),
                                         _p(backward_buffer), _p(grad_inputs if calc_grad_inputs else None),
                                         _p(grad_weights), _p(ws), C.c_size_t(ws.numel()), C.c_int(int(input_layout)),
-                                        C.c_int(int(bool(accumulate))), _nv(n_valid), _stream()), "ffmlp_backward")
+                                        C.c_int(int(bool(accumulate))), _nv(n_valid), _p(found_inf), _stream()),
+               "ffmlp_backward")
 
 
 class _AdamTensor(C.Structure):

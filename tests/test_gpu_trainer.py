@@ -79,6 +79,34 @@ def test_second_graphed_trainer_after_the_first_is_gone(hip):
     assert float(losses[-1]) == float(tr.loss_ring[(model.local_step - 1) % 16])
 
 
+@pytest.mark.parametrize("graphed", [False, True], ids=["eager", "graph"])
+def test_overflow_step_is_skipped_with_the_check_made_by_the_gradient_kernels(hip, graphed):
+    """single replica: no separate pass over the gradient buffer — the grid / ffmlp backward kernels raise the scaler's flag.
+    A batch with non-finite targets must leave every parameter and the Adam step count untouched and halve the scale."""
+    from nerf.trainer import GraphedTrainer, Trainer
+    model, batches = _setup()
+    tr = GraphedTrainer(model, 2048, lr=1e-2, fp16=True) if graphed else Trainer(model, lr=1e-2, fp16=True)
+    assert tr.scaler._checked_at_source(tr.optimizer)
+    _run(tr, batches, 24)
+    if graphed:
+        assert tr.graph is not None
+    torch.cuda.synchronize()
+    before = [p.detach().clone() for p in model.parameters()]
+    steps0, scale0 = float(tr.optimizer.step_count), tr.scaler.get_scale()
+    ro, rd, gt = batches[0]
+    bad = gt.clone()
+    bad[::3] = float("inf")
+    tr.train_step(ro, rd, bad)
+    torch.cuda.synchronize()
+    assert float(tr.optimizer.step_count) == steps0 and tr.scaler.get_scale() == 0.5 * scale0
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
+    assert float(tr.scaler._found_inf) == 0.0
+    # ... and training goes on: the next clean step updates again, on clean (consumed) gradient buffers
+    losses = _run(tr, batches, 8)
+    assert float(tr.optimizer.step_count) == steps0 + 8 and torch.isfinite(losses).all()
+    assert not all(torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
+
+
 def test_data_parallel_split_graph_step_single_rank(hip):
     """The multi-GPU step (two graphs with an eager all-reduce in between, fp16 flat bucket) on a 1-rank RCCL group."""
     import torch.distributed as dist
