@@ -70,6 +70,23 @@ int s3d_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, s3d
 int s3d_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield,
                  s3d_stream_t stream);
 
+/* Build extension — the steady-state occupancy sweep of NeRFRenderer.update_extra_state (nerf/renderer.py:497-538: H^3/4
+ * uniform cells + H^3/4 uniform picks among the occupied cells per cascade, jittered inside the cell, density queried by the
+ * caller, then density_grid = max(density_grid * decay, sample) where both are >= 0) without host syncs or index tensors:
+ * s3d_sweep_draw: u_uniform / u_occupied [N] doubles in [0, 1) (ascending order makes the queries walk the Z-curve),
+ *   occ_csum [H^3] = inclusive prefix count of cells with density > 0 -> cells [2N] (morton index = density_grid index)
+ *   and xyzs [2N, 3] (jitter = counter-based u01(noise_key, *noise_step, 3 i + d); noise_step may be NULL = 0).
+ * s3d_sweep_update: one cascade's density_grid [n_cells] updated in place from (cells, sigma * density_scale) [n]; of the
+ *   samples that fall in one cell the largest is kept (the reference's indexed assignment keeps an arbitrary one);
+ *   *grid_sum = sum(max(density_grid, 0)) afterwards (fixed summation order); step_counter (optional) += 1. */
+int s3d_sweep_draw(const double* u_uniform, const double* u_occupied, const int32_t* occ_csum, uint32_t N, uint32_t H,
+                   float bound, float half_cell, uint32_t noise_key, const int32_t* noise_step, int32_t* cells,
+                   float* xyzs, s3d_stream_t stream);
+size_t s3d_sweep_update_workspace_size(uint32_t n_cells);
+int s3d_sweep_update(float* density_grid, uint32_t n_cells, const int32_t* cells, const void* sigma, int sigma_dtype,
+                     uint32_t n, float density_scale, float decay, void* workspace, size_t workspace_bytes,
+                     float* grid_sum, int32_t* step_counter, s3d_stream_t stream);
+
 /* raymarching.h:13 void march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M,
  *                                        nears, fars, xyzs, dirs, deltas, rays, counter, noises)
  * Spans are packed in RAY ORDER (deterministic; one valid outcome of the reference's atomic

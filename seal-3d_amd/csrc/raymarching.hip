@@ -151,6 +151,92 @@ __global__ void k_packbits(const float* __restrict__ grid, uint32_t N, float thr
     }
 }
 
+// ---------------------------------------------------------------- occupancy sweep (density-grid maintenance)
+// The steady-state update of the reference (nerf/renderer.py:497-538) as three launches around the density query instead of
+// ~40 elementwise torch kernels: cells + jittered positions out of two sorted uniform streams, then scatter / EMA-max / mean.
+//   draw:   i <  N: cell = floor(u_uniform[i] * H^3)                         (uniform cells; morton index = cell id)
+//           i >= N: cell = the floor(u_occupied[i-N] * #occupied)-th cell with density > 0   (binary search in the prefix counts)
+//           xyz = (2 c / (H-1) - 1) * (bound - half_cell) + (2 r - 1) * half_cell,  r = counter-based u01(key, step, 3 i + d)
+__global__ void __launch_bounds__(256) k_sweep_draw(const double* __restrict__ u_uniform, const double* __restrict__ u_occupied,
+                                                    const int32_t* __restrict__ occ_csum, uint32_t N, uint32_t H, float bound,
+                                                    float half_cell, uint32_t noise_key, const int32_t* __restrict__ noise_step,
+                                                    int32_t* __restrict__ cells, float* __restrict__ xyzs) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * N) return;
+    const uint32_t H3 = H * H * H;
+    uint32_t cell;
+    if (i < N) {
+        const double v = u_uniform[i] * (double)H3;
+        cell = v >= (double)(H3 - 1) ? H3 - 1 : (uint32_t)v;
+    } else {
+        const int32_t total = occ_csum[H3 - 1];
+        const int32_t pick = (int32_t)(u_occupied[i - N] * (double)total);
+        // first cell whose inclusive count exceeds `pick` (torch.searchsorted(csum, pick, right=True)), clamped
+        uint32_t lo = 0, hi = H3;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (occ_csum[mid] > pick) hi = mid; else lo = mid + 1;
+        }
+        cell = lo < H3 ? lo : H3 - 1;
+    }
+    cells[i] = (int32_t)cell;
+    const uint32_t step = noise_step ? (uint32_t)*noise_step : 0u;
+    const float inv = 2.0f / (float)(H - 1), span = bound - half_cell;
+#pragma unroll
+    for (uint32_t d = 0; d < 3; d++) {
+        const float c = (float)morton3d_invert(cell >> d);
+        const float r = ray_noise(noise_key, step, 3u * i + d);
+        xyzs[(size_t)i * 3 + d] = __builtin_fmaf(__builtin_fmaf(2.0f, r, -1.0f), half_cell, (c * inv - 1.0f) * span);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sweep_fill(float* __restrict__ tmp, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) tmp[i] = -1.0f;
+}
+// tmp[cell] = max over the samples of the cell (the reference's indexed assignment keeps an arbitrary one of them; the max is one
+// of its outcomes and does not depend on the order).  Densities are >= 0 or NaN: as int32 patterns non-negative floats order
+// like the floats and lie above -1.0f; a NaN (0x7fc00000) wins, i.e. poisons the cell exactly like in the reference.
+template <typename T>
+__global__ void __launch_bounds__(256) k_sweep_scatter(const int32_t* __restrict__ cells, const T* __restrict__ sigma, uint32_t n,
+                                                       float scale, float* __restrict__ tmp) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = (float)sigma[i] * scale;
+    atomicMax(reinterpret_cast<int32_t*>(tmp) + cells[i], __float_as_int(v));
+}
+// grid = max(grid * decay, tmp) where both are >= 0 (renderer.py:529-531); per-block sums of clamp(grid, 0) for the mean
+__global__ void __launch_bounds__(256) k_sweep_update(float* __restrict__ grid, const float* __restrict__ tmp, uint32_t n, float decay,
+                                                      float* __restrict__ partial) {
+    __shared__ float wsum[4];
+    float acc = 0.0f;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float g = grid[i];
+        const float t = tmp[i];
+        if (g >= 0.0f && t >= 0.0f) { g = fmaxf(g * decay, t); grid[i] = g; }
+        acc += g > 0.0f ? g : 0.0f;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+__global__ void __launch_bounds__(256) k_sweep_mean(const float* __restrict__ partial, uint32_t nblocks, float inv_n, float* __restrict__ mean,
+                                                    int32_t* __restrict__ step_counter) {
+    __shared__ float wsum[4];
+    float acc = 0.0f;
+    for (uint32_t i = threadIdx.x; i < nblocks; i += 256) acc += partial[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *mean = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) * inv_n;
+        if (step_counter) *step_counter += 1;
+    }
+}
+
 // ---------------------------------------------------------------- DDA core
 struct Ray {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
@@ -1038,4 +1124,43 @@ S3D_EXPORT int s3d_compact_alive(const int32_t* in, uint32_t n, int32_t* out, in
     hipLaunchKernelGGL(k_compact_write, dim3(nw), dim3(64), 0, as_stream(stream), in, n, out, n_out,
                        (const uint32_t*)workspace, n_in_dev);
     return check_launch("compact_alive");
+}
+
+constexpr uint32_t kSweepBlocks = 1024;
+
+S3D_EXPORT int s3d_sweep_draw(const double* u_uniform, const double* u_occupied, const int32_t* occ_csum, uint32_t N, uint32_t H,
+                              float bound, float half_cell, uint32_t noise_key, const int32_t* noise_step, int32_t* cells,
+                              float* xyzs, s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(u_uniform && u_occupied && occ_csum && cells && xyzs, "sweep_draw: null pointer");
+    S3D_REQUIRE(H >= 2 && H <= 1024 && (uint64_t)2 * N < (1ull << 31), "sweep_draw: unsupported grid size H=%u or N=%u", H, N);
+    hipLaunchKernelGGL(k_sweep_draw, dim3(div_up<uint32_t>(2 * N, 256)), dim3(256), 0, as_stream(stream), u_uniform, u_occupied,
+                       occ_csum, N, H, bound, half_cell, noise_key, noise_step, cells, xyzs);
+    return check_launch("sweep_draw");
+}
+
+S3D_EXPORT size_t s3d_sweep_update_workspace_size(uint32_t n_cells) { return ((size_t)n_cells + kSweepBlocks) * sizeof(float); }
+
+S3D_EXPORT int s3d_sweep_update(float* density_grid, uint32_t n_cells, const int32_t* cells, const void* sigma, int sigma_dtype,
+                                uint32_t n, float density_scale, float decay, void* workspace, size_t workspace_bytes,
+                                float* grid_sum, int32_t* step_counter, s3d_stream_t stream) {
+    S3D_REQUIRE(density_grid && n_cells > 0 && (n == 0 || (cells && sigma)) && grid_sum, "sweep_update: null pointer");
+    S3D_REQUIRE(sigma_dtype == S3D_F32 || sigma_dtype == S3D_F16, "sweep_update: sigma dtype must be f32 or f16");
+    S3D_REQUIRE(workspace && workspace_bytes >= s3d_sweep_update_workspace_size(n_cells), "sweep_update: workspace too small");
+    hipStream_t st = as_stream(stream);
+    float* tmp = (float*)workspace;
+    float* partial = tmp + n_cells;
+    hipLaunchKernelGGL(k_sweep_fill, dim3(div_up<uint32_t>(n_cells, 256)), dim3(256), 0, st, tmp, n_cells);
+    if (n) {
+        if (sigma_dtype == S3D_F16)
+            hipLaunchKernelGGL(k_sweep_scatter<_Float16>, dim3(div_up<uint32_t>(n, 256)), dim3(256), 0, st, cells, (const _Float16*)sigma, n,
+                               density_scale, tmp);
+        else
+            hipLaunchKernelGGL(k_sweep_scatter<float>, dim3(div_up<uint32_t>(n, 256)), dim3(256), 0, st, cells, (const float*)sigma, n,
+                               density_scale, tmp);
+    }
+    const uint32_t blocks = std::min<uint32_t>(kSweepBlocks, div_up<uint32_t>(n_cells, 256));
+    hipLaunchKernelGGL(k_sweep_update, dim3(blocks), dim3(256), 0, st, density_grid, (const float*)tmp, n_cells, decay, partial);
+    hipLaunchKernelGGL(k_sweep_mean, dim3(1), dim3(256), 0, st, (const float*)partial, blocks, 1.0f, grid_sum, step_counter);
+    return check_launch("sweep_update");
 }

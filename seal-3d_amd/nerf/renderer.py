@@ -375,6 +375,27 @@ class NeRFRenderer(nn.Module):
         dev = self.density_grid.device
         H3 = self.grid_size ** 3
         N = H3 // 4
+        if dev.type == "cuda" and self.density_grid.dtype == torch.float32:
+            # native sweep (csrc/raymarching.hip): cells + jittered positions in one launch, scatter / EMA-max / mean in four —
+            # instead of ~40 elementwise torch kernels around the density query
+            R = s3d_hip.RaymarchingBackend
+            if getattr(self, "_sweep_step", None) is None or self._sweep_step.device != dev:
+                self._sweep_step = torch.zeros(1, dtype=torch.int32, device=dev)
+                self._sweep_key = torch.initial_seed() & 0xFFFFFFFF
+            total = None
+            for cas in range(self.cascade):
+                bound, hgs = self._cascade_geometry(cas)
+                grid = self.density_grid[cas]
+                csum = torch.cumsum(grid > 0, dim=0, dtype=torch.int32)
+                cells, xyzs = R.sweep_draw(self._sorted_uniform(N, dev), self._sorted_uniform(N, dev), csum, self.grid_size, bound,
+                                           hgs, self._sweep_key + cas, self._sweep_step)
+                sigma = self.density(xyzs)["sigma"].reshape(-1).detach()
+                if sigma.dtype not in (torch.float16, torch.float32):
+                    sigma = sigma.float()
+                part = R.sweep_update(grid, cells, sigma.contiguous(), self.density_scale, decay,
+                                      self._sweep_step if cas == self.cascade - 1 else None)
+                total = part if total is None else total + part
+            return total / self.density_grid.numel()
         tmp_grid = torch.full_like(self.density_grid, -1)
         for cas in range(self.cascade):
             # (uniform cells: a uniform morton index IS a uniform cell — the curve is a bijection of the H^3 grid)

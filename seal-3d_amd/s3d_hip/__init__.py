@@ -29,6 +29,7 @@ EXPORTS = [
     "s3d_last_error", "s3d_version",
     "s3d_near_far_from_aabb", "s3d_sph_from_ray", "s3d_morton3D", "s3d_morton3D_invert", "s3d_packbits",
     "s3d_march_rays_train_workspace_size", "s3d_march_rays_train",
+    "s3d_sweep_draw", "s3d_sweep_update_workspace_size", "s3d_sweep_update",
     "s3d_composite_rays_train_forward", "s3d_composite_rays_train_backward",
     "s3d_march_rays", "s3d_composite_rays", "s3d_compact_alive_workspace_size", "s3d_compact_alive",
     "s3d_grid_level_scales", "s3d_grid_encode_forward", "s3d_grid_corner_indices", "s3d_grid_encode_backward",
@@ -235,6 +236,39 @@ class RaymarchingBackend:
         _check(lib().s3d_near_far_from_aabb(_p(rays_o), _p(rays_d), _p(aabb), _u(N), _f(min_near), _p(nears),
                                             _p(fars), _p(noises), _p(noise_step), _u(int(noise_key) & 0xFFFFFFFF), _stream()),
                "near_far_from_aabb")
+
+    @staticmethod
+    def sweep_draw(u_uniform, u_occupied, occ_csum, H, bound, half_cell, noise_key=0, noise_step=None):
+        """cells [2N] int32 + jittered positions [2N, 3] of one cascade's occupancy sweep (seal3d_hip.h)"""
+        _need(u_uniform, torch.float64, "u_uniform"); _need(u_occupied, torch.float64, "u_occupied")
+        _need(occ_csum, torch.int32, "occ_csum")
+        N = u_uniform.numel()
+        if u_occupied.numel() != N or occ_csum.numel() != H ** 3:
+            raise RuntimeError("sweep_draw: u_uniform / u_occupied are [N], occ_csum is [H^3]")
+        if noise_step is not None:
+            _need(noise_step, torch.int32, "noise_step")
+        cells = torch.empty(2 * N, dtype=torch.int32, device=u_uniform.device)
+        xyzs = torch.empty(2 * N, 3, dtype=torch.float32, device=u_uniform.device)
+        _check(lib().s3d_sweep_draw(_p(u_uniform), _p(u_occupied), _p(occ_csum), _u(N), _u(H), _f(bound), _f(half_cell),
+                                    _u(int(noise_key) & 0xFFFFFFFF), _p(noise_step), _p(cells), _p(xyzs), _stream()), "sweep_draw")
+        return cells, xyzs
+
+    @staticmethod
+    def sweep_update(density_grid, cells, sigma, density_scale, decay, step_counter=None):
+        """EMA-max update of one cascade's density grid [H^3] (a contiguous fp32 view, in place) from the samples; returns the
+        device scalar sum(max(grid, 0)) (seal3d_hip.h)"""
+        _need(density_grid, torch.float32, "density_grid"); _need(cells, torch.int32, "cells")
+        if sigma.dtype not in (torch.float16, torch.float32) or sigma.numel() != cells.numel():
+            raise RuntimeError("sweep_update: sigma must be fp16 / fp32, one per cell sample")
+        if step_counter is not None:
+            _need(step_counter, torch.int32, "step_counter")
+        n_cells = density_grid.numel()
+        ws = _ws.get(lib().s3d_sweep_update_workspace_size(_u(n_cells)), density_grid.device)
+        out = torch.empty((), dtype=torch.float32, device=density_grid.device)
+        _check(lib().s3d_sweep_update(_p(density_grid), _u(n_cells), _p(cells), _p(sigma), C.c_int(_dt(sigma)), _u(cells.numel()),
+                                      _f(density_scale), _f(decay), _p(ws), C.c_size_t(ws.numel()), _p(out), _p(step_counter),
+                                      _stream()), "sweep_update")
+        return out
 
     @staticmethod
     def sph_from_ray(rays_o, rays_d, radius, N, coords):

@@ -119,6 +119,55 @@ def test_near_far_draws_the_per_ray_jitter_from_a_device_step_number(oracle, hip
     assert torch.equal(again, draws[(2, 7)])
 
 
+def test_native_occupancy_sweep_against_the_torch_rule(hip):
+    """s3d_sweep_draw / s3d_sweep_update (the graph-replayed update_extra_state steady state) against the torch op sequence of
+    nerf/renderer.py: same cells for the same uniforms, positions inside their cells, EMA-max update bit for bit (the largest
+    sample of a cell where several fall into it), never-seen cells (-1) and NaN samples left alone, fixed-order sum."""
+    import s3d_hip
+    R = hip.RaymarchingBackend
+    H, N = 64, 64 ** 3 // 4
+    H3 = H ** 3
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    grid = torch.rand(H3, device=dev, generator=g)
+    grid[grid < 0.8] = 0
+    grid[:777] = -1
+    u1 = torch.sort(torch.rand(N, device=dev, dtype=torch.float64, generator=g)).values
+    u2 = torch.sort(torch.rand(N, device=dev, dtype=torch.float64, generator=g)).values
+    csum = torch.cumsum(grid > 0, dim=0, dtype=torch.int32)
+    step = torch.full((1,), 5, dtype=torch.int32, device=dev)
+    bound, hgs = 1.0, 1.0 / H
+    cells, xyzs = R.sweep_draw(u1, u2, csum, H, bound, hgs, 99, step)
+    ref_uniform = (u1 * H3).long().clamp_(max=H3 - 1)
+    ref_occ = torch.searchsorted(csum, (u2 * csum[-1]).to(torch.int32), right=True).clamp_(max=H3 - 1)
+    assert torch.equal(cells.long(), torch.cat([ref_uniform, ref_occ]))
+    assert bool((grid[cells[N:].long()] > 0).all())
+    coords = torch.empty(2 * N, 3, dtype=torch.int32, device=dev)
+    R.morton3D_invert(cells, 2 * N, coords)
+    centre = (2 * coords.float() / (H - 1) - 1) * (bound - hgs)
+    off = (xyzs - centre) / hgs
+    assert float(off.abs().max()) <= 1.0 + 1e-5 and abs(float(off.mean())) < 5e-3 and abs(float(off.var()) - 1 / 3) < 5e-3
+    cells2, xyzs2 = R.sweep_draw(u1, u2, csum, H, bound, hgs, 99, step + 1)
+    assert torch.equal(cells, cells2) and not torch.equal(xyzs, xyzs2)  # fresh jitter for the next step number
+    # update: samples incl. duplicates, exact zeros, a NaN
+    for dt in (torch.float32, torch.float16):
+        sigma = (torch.rand(2 * N, device=dev, generator=g) * 3).to(dt)
+        sigma[::5] = 0
+        sigma[7] = float("nan")
+        mine = grid.clone()
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        total = R.sweep_update(mine, cells, sigma, 2.0, 0.95, counter)
+        tmp = torch.full_like(grid, -1)
+        tmp.index_reduce_(0, cells.long(), torch.nan_to_num(sigma.float() * 2.0, nan=-1.0), "amax", include_self=True)
+        valid = (grid >= 0) & (tmp >= 0)
+        nan_cell = int(cells[7])
+        valid[nan_cell] = False  # the NaN wins its cell and leaves it unchanged, like `tmp >= 0` in the reference
+        ref = torch.where(valid, torch.maximum(grid * 0.95, tmp), grid)
+        assert torch.equal(mine, ref)
+        assert bool((mine[:777] == -1).all()) and int(counter) == 1
+        torch.testing.assert_close(total, ref.clamp(min=0).sum(), rtol=1e-5, atol=0)
+
+
 def test_sph_from_ray(oracle, hip):
     ro, rd = _rays(2048, seed=2)
     N = ro.shape[0]

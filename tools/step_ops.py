@@ -34,12 +34,20 @@ def main():
     for _ in range(2):
         tr._body_fb(); tr._body_opt()
     torch.cuda.synchronize()
+    ues = "--ues" in sys.argv
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
-        tr._body_fb()
-        tr._body_opt()
+        if ues:  # the occupancy sweep instead of the step
+            with torch.autocast("cuda", dtype=torch.float16):
+                model.partial_grid_update_device()
+        else:
+            tr._body_fb()
+            tr._body_opt()
         torch.cuda.synchronize()
     model.mean_count = saved
     # kernel -> launching op via the correlation the profiler keeps: walk CPU ops, list their device kernels
+    if ues:
+        print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=60))
+        return
     rows = []
     for ev in prof.events():
         if ev.device_type == torch.autograd.DeviceType.CPU and ev.kernels:
