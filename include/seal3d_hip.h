@@ -223,16 +223,20 @@ int s3d_freq_encode_backward(const float* grad, const float* outputs, uint32_t B
  * forward_buffer / backward_buffer: [n, B, W] post-activation / pre-activation-gradient scratch.
  * B must be a multiple of 128 (ffmlp.py:156-159 pads); in % 16 == 0; out == 16; W in {16,32,64,128}.
  * input_layout: 0 = inputs [B,in] row-major (the reference); 1 = level-major [in/2][B][2], i.e. the grid
- * encoder's own output layout read in place (and grad_inputs written in it) — no permute copies in between. */
+ * encoder's own output layout read in place (and grad_inputs written in it) — no permute copies in between.
+ * rgb_head (optional, build extension): fp32 [B, 3] = sigmoid(output[:, 0:3]) written INSTEAD of `outputs` (which may then
+ * be NULL) — the colour network's `torch.sigmoid(h)` (nerf/network_ff.py:103) folded into the last layer's store, with the
+ * fp16 roundings of the op sequence.  s3d_ffmlp_backward then takes grad_rgb (fp32 [B, 3], gradient w.r.t. that output)
+ * and rgb_head instead of `grad`. */
 int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                       uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                       uint32_t output_activation, uint16_t* forward_buffer, uint16_t* outputs,
-                      int input_layout, const int32_t* n_valid, s3d_stream_t stream);
+                      int input_layout, const int32_t* n_valid, float* rgb_head, s3d_stream_t stream);
 /* ffmlp.h:9: same network without storing intermediates (inference_buffer is unused scratch) */
 int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                         uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                         uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,
-                        int input_layout, const int32_t* n_valid, s3d_stream_t stream);
+                        int input_layout, const int32_t* n_valid, float* rgb_head, s3d_stream_t stream);
 /* ffmlp.h:11; grad_weights fp16 [same layout as weights]: every element is written (accumulate_grad_weights = 0,
  * the reference zero-fills it first, ffmlp.py:72) or added to (accumulate_grad_weights = 1).
  * workspace: fp32 accumulation of the weight gradient (s3d_ffmlp_backward_workspace_size).
@@ -252,7 +256,8 @@ int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
                        uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer,
                        uint16_t* grad_inputs, uint16_t* grad_weights, void* workspace,
                        size_t workspace_bytes, int input_layout, int accumulate_grad_weights,
-                       const int32_t* n_valid, float* found_inf, s3d_stream_t stream);
+                       const int32_t* n_valid, float* found_inf, const float* grad_rgb, const float* rgb_head,
+                       s3d_stream_t stream);
 /* ffmlp.h:13-14: the reference allocates split-K side streams here; this build fuses the weight
  * gradient into the backward launch sequence on the caller's stream, so these are no-ops kept for
  * surface compatibility. */

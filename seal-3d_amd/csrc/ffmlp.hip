@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
                                                        uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
                                                        uint32_t act, uint32_t out_act, _Float16* __restrict__ fwd,
                                                        _Float16* __restrict__ out, uint32_t in_layout,
-                                                       const int32_t* __restrict__ n_valid) {
+                                                       const int32_t* __restrict__ n_valid, float* __restrict__ rgb_head) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     half8* frags = reinterpret_cast<half8*>(smem_raw);
@@ -260,6 +260,18 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
         const half8* a = frags + (size_t)(nf0 + nfh) * 64;
 #pragma unroll
         for (uint32_t s = 0; s < KS; s++) o = mfma(a[s * 64 + lane], bf[s], o);
+        if (rgb_head) {
+            // colour head (network_ff.py:103 `torch.sigmoid(h)` on the fp16 output, then compositing in fp32): outputs 0..2 go
+            // out as fp32 sigmoid values, rounded where the fp16 op sequence rounds — the [B, 16] fp16 tensor never exists
+            if (h == 0) {
+#pragma unroll
+                for (uint32_t c = 0; c < 3; c++) {
+                    const _Float16 v = (_Float16)act_fwd_t<OACT>(out_act, (float)(_Float16)o[c]);
+                    rgb_head[row * 3 + c] = (float)(_Float16)(1.0f / (1.0f + expf(-(float)v)));
+                }
+            }
+            continue;
+        }
         _Float16* orow = out + row * 16;
 #pragma unroll
         for (uint32_t q = 0; q < 2; q++) {
@@ -577,7 +589,8 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
                                                              const _Float16* __restrict__ Wt, uint32_t B, uint32_t in_dim,
                                                              uint32_t out_dim, uint32_t act, _Float16* __restrict__ grad_inputs,
                                                              float* __restrict__ partial, uint32_t in_layout,
-                                                             const int32_t* __restrict__ n_valid) {
+                                                             const int32_t* __restrict__ n_valid,
+                                                             const float* __restrict__ d_rgb, const float* __restrict__ rgb_head) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -656,7 +669,20 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
 #pragma unroll
         for (uint32_t s = 0; s < 4; s++)
             if (s < KS0) xf[s] = load_bfrag_input(X, in_layout, B, in_dim, row, s, h);
-        const half8 gf = load_bfrag_rowmajor(grad + row * 16, 0, h);
+        half8 gf;
+        if (d_rgb) {  // colour head: d(out_c) = d(rgb_c) * y (1 - y) formed here from the fp32 gradient of the compositing
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) gf[j] = (_Float16)0.0f;
+            if (h == 0) {
+#pragma unroll
+                for (uint32_t c = 0; c < 3; c++) {  // (kperm(0, c) == c for c < 4)
+                    const float y = rgb_head[row * 3 + c];
+                    gf[c] = (_Float16)((float)(_Float16)d_rgb[row * 3 + c] * (y * (1.0f - y)));
+                }
+            }
+        } else {
+            gf = load_bfrag_rowmajor(grad + row * 16, 0, h);
+        }
 
         // ---- forward re-computation (same operations and roundings as k_ffmlp_forward)
         half8 a[NH + 1][KS];
@@ -817,6 +843,9 @@ constexpr uint32_t kWgradBlocks = 256;
 // `n_valid` of the entry point being served on this thread (see valid_rows()); the launch helpers below pass it on
 static thread_local const int32_t* t_n_valid = nullptr;
 static thread_local float* t_found_inf = nullptr;  // s3d_ffmlp_backward(found_inf) of the call being served
+static thread_local float* t_rgb_out = nullptr;          // colour head of the forward call being served (fp32 [B, 3] out)
+static thread_local const float* t_d_rgb = nullptr;      // ... of the backward call: gradient w.r.t. the head's output
+static thread_local const float* t_rgb_in = nullptr;     // ... and the head's output
 struct RowLimitScope {
     explicit RowLimitScope(const int32_t* p, float* found_inf = nullptr) { t_n_valid = p; t_found_inf = found_inf; }
     ~RowLimitScope() { t_n_valid = nullptr; t_found_inf = nullptr; }
@@ -840,7 +869,7 @@ int launch_forward(const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t i
     const uint32_t ntiles = B / 32;
     uint32_t grid = div_up<uint32_t>(ntiles, 4);
     if (grid > 1024) grid = 1024;
-#define S3D_FWD(TRAIN, A, O) hipLaunchKernelGGL((k_ffmlp_forward<W, TRAIN, A, O>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out, in_layout, t_n_valid)
+#define S3D_FWD(TRAIN, A, O) hipLaunchKernelGGL((k_ffmlp_forward<W, TRAIN, A, O>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out, in_layout, t_n_valid, t_rgb_out)
     const bool fast = act == ACT_RELU && out_act == ACT_NONE;  // the networks of the hot path; anything else: run-time switch
     if (fwd) { if (fast) S3D_FWD(true, ACT_RELU, ACT_NONE); else S3D_FWD(true, -1, -1); }
     else { if (fast) S3D_FWD(false, ACT_RELU, ACT_NONE); else S3D_FWD(false, -1, -1); }
@@ -915,7 +944,7 @@ int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Floa
     uint32_t nblk = div_up<uint32_t>(ntiles, 4);
     if (nblk > kWgradBlocks) nblk = kWgradBlocks;
     hipLaunchKernelGGL((k_ffmlp_backward_fused<W, NH, IMB, ACT, KS0T>), dim3(nblk), dim3(256), smem, st, grad, X, Wt, B, in_dim, out_dim,
-                       act, grad_inputs, partial, in_layout, t_n_valid);
+                       act, grad_inputs, partial, in_layout, t_n_valid, t_d_rgb, t_rgb_in);
     WgradPlan plan;
     memset(&plan, 0, sizeof(plan));
     plan.n = NH + 2;
@@ -962,10 +991,12 @@ using namespace s3d;
 S3D_EXPORT int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                                  uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                                  uint32_t output_activation, uint16_t* forward_buffer, uint16_t* outputs,
-                                 int input_layout, const int32_t* n_valid, s3d_stream_t stream) {
+                                 int input_layout, const int32_t* n_valid, float* rgb_head, s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     const RowLimitScope rows(n_valid);
-    S3D_REQUIRE(inputs && weights && outputs, "ffmlp_forward: null pointer");
+    struct HeadScope { explicit HeadScope(float* p) { t_rgb_out = p; } ~HeadScope() { t_rgb_out = nullptr; } } head(rgb_head);
+    S3D_REQUIRE(inputs && weights && (outputs || rgb_head), "ffmlp_forward: null pointer");
+    S3D_REQUIRE(!rgb_head || output_dim >= 3, "ffmlp_forward: the colour head reads outputs 0..2");
     S3D_REQUIRE(input_layout == 0 || input_layout == 1, "ffmlp_forward: input_layout must be 0 (row-major) or 1 (level-major [in/2][B][2])");
     if (int rc = check_shape(B, input_dim, output_dim, hidden_dim, num_layers)) return rc;
     S3D_REQUIRE(output_dim == 16, "ffmlp_forward: the output must be padded to 16 columns (ffmlp.py:117)");
@@ -978,10 +1009,10 @@ S3D_EXPORT int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights
 S3D_EXPORT int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                                    uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                                    uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,
-                                   int input_layout, const int32_t* n_valid, s3d_stream_t stream) {
+                                   int input_layout, const int32_t* n_valid, float* rgb_head, s3d_stream_t stream) {
     (void)inference_buffer;
     return s3d_ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                             output_activation, nullptr, outputs, input_layout, n_valid, stream);
+                             output_activation, nullptr, outputs, input_layout, n_valid, rgb_head, stream);
 }
 
 S3D_EXPORT size_t s3d_ffmlp_backward_workspace_size(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
@@ -996,14 +1027,20 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
                                   uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer,
                                   uint16_t* grad_inputs, uint16_t* grad_weights, void* workspace, size_t workspace_bytes,
                                   int input_layout, int accumulate_grad_weights, const int32_t* n_valid, float* found_inf,
-                                  s3d_stream_t stream) {
+                                  const float* grad_rgb, const float* rgb_head, s3d_stream_t stream) {
     (void)output_activation;
     const RowLimitScope rows(n_valid, found_inf);
+    struct HeadScope {
+        HeadScope(const float* g, const float* y) { t_d_rgb = g; t_rgb_in = y; }
+        ~HeadScope() { t_d_rgb = nullptr; t_rgb_in = nullptr; }
+    } head(grad_rgb, rgb_head);
+    S3D_REQUIRE((grad_rgb == nullptr) == (rgb_head == nullptr), "ffmlp_backward: the colour head needs both grad_rgb and rgb_head");
+    S3D_REQUIRE(!grad_rgb || (!forward_buffer && output_dim >= 3), "ffmlp_backward: the colour head is implemented by the fused backward");
     const uint32_t accumulate = accumulate_grad_weights ? 1u : 0u;
     S3D_REQUIRE(input_layout == 0 || (input_layout == 1 && !forward_buffer),
                 "ffmlp_backward: the level-major input layout is implemented by the fused backward (no forward_buffer)");
     if (B == 0) return S3D_OK;
-    S3D_REQUIRE(grad && inputs && weights && grad_weights, "ffmlp_backward: null pointer");
+    S3D_REQUIRE((grad || grad_rgb) && inputs && weights && grad_weights, "ffmlp_backward: null pointer");
     S3D_REQUIRE((forward_buffer == nullptr) == (backward_buffer == nullptr),
                 "ffmlp_backward: pass both forward_buffer and backward_buffer, or neither (fused re-computing backward)");
     if (int rc = check_shape(B, input_dim, output_dim, hidden_dim, num_layers)) return rc;

@@ -44,13 +44,17 @@ class _FFMLPForward(Function):
     @staticmethod
     @custom_fwd(device_type="cuda", cast_inputs=torch.half)
     def forward(ctx, inputs, weights, input_dim, output_dim, hidden_dim, num_layers, activation, output_activation,
-                inference=False, calc_grad_inputs=False, param_ref=None, hook=None, input_layout=0, n_valid=None):
+                inference=False, calc_grad_inputs=False, param_ref=None, hook=None, input_layout=0, n_valid=None,
+                rgb_head=False):
+        """`rgb_head` (build extension, seal3d_hip.h): the result is fp32 [B, 3] = sigmoid(output[:, :3]) straight from the last
+        layer's store (the colour network's head), and backward() takes the gradient w.r.t. it"""
         B = inputs.shape[1] if input_layout else inputs.shape[0]
         # outside autocast `custom_fwd` does not cast: the kernels are fp16-only, so cast here (the autograd
         # engine converts the returned fp16 gradients back to the parameter dtype)
         inputs = inputs.to(torch.half).contiguous()
         weights = weights.to(torch.half).contiguous()
-        outputs = torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
+        rgb = torch.empty(B, 3, device=inputs.device, dtype=torch.float32) if rgb_head else None
+        outputs = None if rgb_head else torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
         if inference:
             scratch = torch.empty(B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
             extra = {}
@@ -58,9 +62,11 @@ class _FFMLPForward(Function):
                 extra["input_layout"] = input_layout
             if n_valid is not None:
                 extra["n_valid"] = n_valid  # sync-free inference loop: rows behind the alive rays are skipped
+            if rgb_head:
+                extra["rgb_head"] = rgb
             _backend.ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
                                      output_activation, scratch, outputs, **extra)
-            return outputs
+            return rgb if rgb_head else outputs
         # The reference stores every layer's activations for the backward pass (forward_buffer [n, B, W]).  Where the
         # fused backward kernel covers the shape, nothing is stored: it re-computes the activations from `inputs` on chip
         # (256-384 B per sample less HBM traffic in each direction).
@@ -69,6 +75,8 @@ class _FFMLPForward(Function):
         forward_buffer = None if fused else torch.empty(num_layers, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
         if input_layout and not fused:
             raise RuntimeError("FFMLP: the level-major input layout needs the fused backward kernel for this shape")
+        if rgb_head and not fused:
+            raise RuntimeError("FFMLP: the colour head needs the fused backward kernel for this shape")
         # (keywords only when used: a backend without these extensions is never asked for them)
         extra = {}
         if input_layout:
@@ -76,15 +84,18 @@ class _FFMLPForward(Function):
         if n_valid is not None:
             extra["n_valid"] = n_valid  # device sample count of a padded batch: rows beyond it are skipped
         _backend.ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                               output_activation, forward_buffer, outputs, **extra)
-        if fused:
+                               output_activation, forward_buffer, outputs, **(dict(extra, rgb_head=rgb) if rgb_head else extra))
+        ctx.rgb_head = rgb_head
+        if rgb_head:
+            ctx.save_for_backward(inputs, weights, rgb)
+        elif fused:
             ctx.save_for_backward(inputs, weights)
         else:
             ctx.save_for_backward(inputs, weights, forward_buffer)
         ctx.meta = (input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs, fused)
         ctx.extra = extra
         ctx.param_ref = param_ref
-        return outputs
+        return rgb if rgb_head else outputs
 
     @staticmethod
     @custom_bwd(device_type="cuda")
@@ -92,20 +103,26 @@ class _FFMLPForward(Function):
         B = grad.shape[0]
         grad = grad.contiguous()
         input_dim, output_dim, hidden_dim, num_layers, activation, output_activation, calc_grad_inputs, fused = ctx.meta
-        if fused:
+        rgb = None
+        if ctx.rgb_head:
+            (inputs, weights, rgb), forward_buffer = ctx.saved_tensors, None
+            grad = grad.float()
+        elif fused:
             (inputs, weights), forward_buffer = ctx.saved_tensors, None
         else:
             inputs, weights, forward_buffer = ctx.saved_tensors
         # the reference zero-fills these three (ffmlp.py:67-73); the HIP kernels overwrite every element, so the
         # build allocates them uninitialised (saves two B x hidden x num_layers memsets per MLP per step)
         grad_inputs = (torch.empty_like(inputs) if calc_grad_inputs
-                       else torch.zeros(1, device=grad.device, dtype=grad.dtype))
+                       else torch.zeros(1, device=grad.device, dtype=inputs.dtype))
         # fp16 hand-over (nerf.optim.NativeAdam): the reduce kernel ADDS the weight gradient to the optimizer's fp16 buffer
         # instead of returning it to autograd (fp32 cast + accumulate)
         stash = getattr(ctx.param_ref.param, "_s3d_grad", None) if ctx.param_ref is not None else None
         grad_weights = stash.view(weights.shape) if stash is not None else torch.empty_like(weights)  # every element is written
         backward_buffer = None if fused else torch.empty(num_layers, B, hidden_dim, device=grad.device, dtype=grad.dtype)
         extra = dict(ctx.extra)
+        if rgb is not None:
+            extra["grad_rgb"], extra["rgb_head"], grad = grad, rgb, None
         if stash is not None:
             extra["accumulate"] = True
             found_inf = getattr(ctx.param_ref.param, "_s3d_found_inf", None)  # GradScaler's check made by the writing kernel
@@ -117,7 +134,7 @@ class _FFMLPForward(Function):
         if stash is not None:
             ctx.param_ref.param._s3d_grad_touched = True
             grad_weights = None
-        return ((grad_inputs if calc_grad_inputs else None), grad_weights) + (None,) * 12
+        return ((grad_inputs if calc_grad_inputs else None), grad_weights) + (None,) * 13
 
 
 ffmlp_forward = _FFMLPForward.apply
@@ -168,6 +185,17 @@ class FFMLP(nn.Module):
             out = out[:, :self.output_dim]
         return out
 
+    def rgb_head_supported(self):
+        return (self.output_dim >= 3 and _FUSED_BACKWARD and getattr(_backend, "fused_backward_supported", None) is not None
+                and _backend.fused_backward_supported(self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
+                                                      self.activation))
+
+    def forward_rgb(self, inputs, n_valid=None):
+        """the colour network with its head: fp32 [B, 3] = sigmoid(net(inputs)[:, :3]) from ONE launch (B % 128 == 0)"""
+        if inputs.shape[0] % 128 != 0:
+            raise RuntimeError("FFMLP.forward_rgb: needs a batch that is a multiple of 128 rows")
+        return self._run(inputs, 0, n_valid, rgb_head=True)
+
     def forward_padded(self, inputs, level_major=False, n_valid=None):
         """forward() before the final column slice: [B, padded_output_dim] (columns >= output_dim are exact zeros'
         products: the padded weight rows).  Fused consumers (nerf/network_ff.py) read the 16-column rows directly.
@@ -195,7 +223,7 @@ class FFMLP(nn.Module):
             out = out[:B]
         return out
 
-    def _run(self, inputs, input_layout, n_valid=None):
+    def _run(self, inputs, input_layout, n_valid=None, rgb_head=False):
         w, ref, hook = self.weights, None, None
         if getattr(w, "_s3d_grad", None) is not None and getattr(w, "_s3d_half_version", None) == w._version:
             # a native optimizer maintains the fp16 copy of the weights and takes their gradient as an fp16 buffer
@@ -207,5 +235,5 @@ class FFMLP(nn.Module):
             w = w._s3d_half
         out = ffmlp_forward(inputs, w, self.input_dim, self.padded_output_dim, self.hidden_dim,
                             self.num_layers, self.activation, self.output_activation, not self.training,
-                            inputs.requires_grad, ref, hook, input_layout, n_valid)
+                            inputs.requires_grad, ref, hook, input_layout, n_valid, rgb_head)
         return out

@@ -114,9 +114,13 @@ class NeRFNetwork(NeRFRenderer):
                 h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound, level_major=True, n_valid=nv, live=live),
                                                   level_major=True, n_valid=nv)
                 sigma, cin = _NgpMid.apply(h.contiguous(), d.float().contiguous(), nv)
+                if self.color_net.rgb_head_supported():  # sigmoid + fp32 hand-over inside the last layer's store
+                    return sigma, self.color_net.forward_rgb(cin, n_valid=nv)
                 return sigma, _NgpRgb.apply(self.color_net.forward_padded(cin, n_valid=nv).contiguous(), nv)
             h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound))
             sigma, cin = _NgpMid.apply(h.contiguous(), d.float().contiguous())
+            if cin.shape[0] % 128 == 0 and self.color_net.rgb_head_supported():
+                return sigma, self.color_net.forward_rgb(cin)
             return sigma, _NgpRgb.apply(self.color_net.forward_padded(cin).contiguous())
         sigma, geo_feat = self._sigma(x)
         return sigma, self._rgb(d, geo_feat)

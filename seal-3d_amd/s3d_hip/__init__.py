@@ -491,22 +491,27 @@ class FFMLPBackend:
 
     @staticmethod
     def ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                      output_activation, forward_buffer, outputs, input_layout=0, n_valid=None):
+                      output_activation, forward_buffer, outputs, input_layout=0, n_valid=None, rgb_head=None):
         _need(inputs, torch.float16, "inputs")
         _need(weights, torch.float16, "weights")
+        if rgb_head is not None:
+            _need(rgb_head, torch.float32, "rgb_head")
         _check(lib().s3d_ffmlp_forward(_p(inputs), _p(weights), _u(B), _u(input_dim), _u(output_dim), _u(hidden_dim),
                                        _u(num_layers), _u(activation), _u(output_activation), _p(forward_buffer),
-                                       _p(outputs), C.c_int(int(input_layout)), _nv(n_valid), _stream()), "ffmlp_forward")
+                                       _p(outputs), C.c_int(int(input_layout)), _nv(n_valid), _p(rgb_head), _stream()),
+               "ffmlp_forward")
 
     @staticmethod
     def ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                        output_activation, inference_buffer, outputs, input_layout=0, n_valid=None):
+                        output_activation, inference_buffer, outputs, input_layout=0, n_valid=None, rgb_head=None):
         _need(inputs, torch.float16, "inputs")
         _need(weights, torch.float16, "weights")
+        if rgb_head is not None:
+            _need(rgb_head, torch.float32, "rgb_head")
         _check(lib().s3d_ffmlp_inference(_p(inputs), _p(weights), _u(B), _u(input_dim), _u(output_dim),
                                          _u(hidden_dim), _u(num_layers), _u(activation), _u(output_activation),
                                          _p(inference_buffer), _p(outputs), C.c_int(int(input_layout)), _nv(n_valid),
-                                         _stream()), "ffmlp_inference")
+                                         _p(rgb_head), _stream()), "ffmlp_inference")
 
     @staticmethod
     def fused_backward_supported(input_dim, output_dim, hidden_dim, num_layers, activation):
@@ -517,20 +522,23 @@ class FFMLPBackend:
     @staticmethod
     def ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers,
                        activation, output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights,
-                       input_layout=0, accumulate=False, n_valid=None, found_inf=None):
-        _need(grad, torch.float16, "grad")
+                       input_layout=0, accumulate=False, n_valid=None, found_inf=None, grad_rgb=None, rgb_head=None):
+        if grad_rgb is not None:
+            _need(grad_rgb, torch.float32, "grad_rgb"); _need(rgb_head, torch.float32, "rgb_head")
+        else:
+            _need(grad, torch.float16, "grad")
         if found_inf is not None:
             _need(found_inf, torch.float32, "found_inf")
         nbytes = lib().s3d_ffmlp_backward_workspace_size(_u(input_dim), _u(output_dim), _u(hidden_dim),
                                                         _u(num_layers))
-        ws = _ws.get(nbytes, grad.device)
+        ws = _ws.get(nbytes, inputs.device)
         _check(lib().s3d_ffmlp_backward(_p(grad), _p(inputs), _p(weights), _p(forward_buffer), _u(B), _u(input_dim),
                                         _u(output_dim), _u(hidden_dim), _u(num_layers), _u(activation),
                                         _u(output_activation), C.c_int(int(bool(calc_grad_inputs))),
                                         _p(backward_buffer), _p(grad_inputs if calc_grad_inputs else None),
                                         _p(grad_weights), _p(ws), C.c_size_t(ws.numel()), C.c_int(int(input_layout)),
-                                        C.c_int(int(bool(accumulate))), _nv(n_valid), _p(found_inf), _stream()),
-               "ffmlp_backward")
+                                        C.c_int(int(bool(accumulate))), _nv(n_valid), _p(found_inf), _p(grad_rgb), _p(rgb_head),
+                                        _stream()), "ffmlp_backward")
 
 
 class _AdamTensor(C.Structure):

@@ -137,3 +137,36 @@ def test_ffmlp_level_major_input_layout(hip):
         outs.append((out, gi if layout == 0 else gi.permute(1, 0, 2).reshape(B, in_dim), gw))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a.view(torch.int16), b.contiguous().view(torch.int16))
+
+
+@pytest.mark.parametrize("B", [128, 128 * 700])
+def test_colour_head_in_the_last_layer_is_the_two_kernel_sequence_bit_for_bit(hip, B):
+    """FFMLP.forward_rgb (seal3d_hip.h: rgb_head) == forward_padded + the separate sigmoid head kernels of nerf/network_ff.py:
+    fp32 [B, 3] output, weight gradient and input gradient, training and inference, with and without a device row count."""
+    from ffmlp import FFMLP
+    from nerf.network_ff import _NgpRgb
+    torch.manual_seed(5)
+    net = FFMLP(32, 3, 64, 3).cuda()
+    assert net.rgb_head_supported()
+    x0 = torch.randn(B, 32, device="cuda").half()
+    g = torch.randn(B, 3, device="cuda")
+    for nv in (None, torch.tensor([max(B - 300, 77)], dtype=torch.int32, device="cuda")):
+        rows = B if nv is None else min(B, (int(nv) + 127) // 128 * 128)
+        res = []
+        for fused in (False, True):
+            net.train()
+            net.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.float16):
+                rgb = net.forward_rgb(x, n_valid=nv) if fused else _NgpRgb.apply(net.forward_padded(x, n_valid=nv).contiguous(), nv)
+            assert rgb.dtype == torch.float32 and rgb.shape == (B, 3)
+            (rgb[:rows] * g[:rows]).sum().backward()
+            res.append((rgb.detach()[:rows].clone(), net.weights.grad.clone(), x.grad[:rows].clone()))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+        assert float(res[0][1].abs().max()) > 0
+        net.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            a = net.forward_rgb(x0, n_valid=nv)[:rows]
+            b = _NgpRgb.apply(net.forward_padded(x0, n_valid=nv).contiguous(), nv)[:rows]
+        assert torch.equal(a, b) and torch.equal(a, res[0][0])
