@@ -531,23 +531,46 @@ __global__ void k_ffmlp_wgrad_reduce(WgradPlan plan, uint32_t nblk, const float*
 // (MFMA accumulation VGPRs) for all tiles of the wave; at the end the four waves are summed through LDS in a fixed
 // order and one fp32 partial per workgroup goes to the same reduce kernel as the two-kernel path.  Deterministic.
 // HBM traffic per point: in*2 + 32 B read (+ in*2 B grad_inputs) instead of ~1.2 KB.
-constexpr uint32_t kTRow = 40;  // halfs per row of a transposed tile (32 points + 8 pad)
+constexpr uint32_t kTRow = 72;   // halfs per row of a per-wave tile: 64 features + 8 pad (144 B: 8-byte aligned segments)
+constexpr uint32_t kTRows = 32;  // rows = the 32 points of the tile
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
-constexpr uint32_t kTRows = 64;  // features per transposed tile (hidden width and input width are both <= 64)
+// The tile is stored the way the lanes hold it — row = point, 64 features side by side: a lane's fragment is two runs of four
+// consecutive features per k-step (k index (j&3) + 8(j>>2) + 4h), i.e. two 8-byte stores — and read back TRANSPOSED by
+// gfx950's ds_read_b64_tr_b16: the 16 lanes of a group hand in the sixteen 8-byte segments of a [4 points][16 features] block
+// (lane i: point i/4, features 4(i%4)..+3) and lane i receives feature i of the four points (tools/ubench/tr16.hip prints the
+// mapping).  Two such reads are a lane's 8 consecutive points of one feature: the A / B operand of the weight-gradient MFMA.
+// [Before: transposed tile T[feature][point], 8 two-byte stores per k-step and lane, one 16-byte load per fragment: 216
+//  ds_write_b16 per 32-point tile, a quarter of the kernel's LDS instructions and their address arithmetic.]
+#ifndef S3D_FF_EXPERIMENT  // kernel-timing experiments only: 1 = fused backward without its weight-gradient half
+#define S3D_FF_EXPERIMENT 0
+#endif
 template <int NS>
 __device__ __forceinline__ void transpose_store(_Float16* __restrict__ T, const half8 (&bf)[NS], uint32_t ksteps,
                                                 uint32_t n, uint32_t h) {
+    if (S3D_FF_EXPERIMENT == 1) return;
 #pragma unroll
     for (uint32_t s = 0; s < (uint32_t)NS; s++)
         if (s < ksteps) {
+            half4 lo, hi;
 #pragma unroll
-            for (uint32_t j = 0; j < 8; j++) T[(16 * s + kperm(h, j)) * kTRow + n] = bf[s][j];
+            for (uint32_t j = 0; j < 4; j++) { lo[j] = bf[s][j]; hi[j] = bf[s][4 + j]; }
+            _Float16* row = T + n * kTRow + 16 * s + 4 * h;
+            *reinterpret_cast<half4*>(row) = lo;
+            *reinterpret_cast<half4*>(row + 8) = hi;
         }
 }
 // fragment (A or B operand of the weight-gradient MFMA) for feature block `blk`, k-step (16 points) s
 __device__ __forceinline__ half8 transpose_load(const _Float16* __restrict__ T, uint32_t blk, uint32_t s, uint32_t fl,
                                                 uint32_t h, uint32_t nfeat) {
-    half8 v = *reinterpret_cast<const half8*>(T + (blk * 32 + fl) * kTRow + 16 * s + 8 * h);
+    const uint32_t i = fl & 15, g1 = fl >> 4;  // lane = 32 h + fl: 16-lane group 2 h + g1
+    const _Float16* p = T + (16 * s + 8 * h + i / 4) * kTRow + 32 * blk + 16 * g1 + 4 * (i % 4);
+    typedef __attribute__((address_space(3))) fp16x4 lds_fp16x4;
+    const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)p);
+    const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(p + 4 * kTRow));
+    half8 v;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) { v[j] = (_Float16)a[j]; v[4 + j] = (_Float16)b[j]; }
     if (blk * 32 + fl >= nfeat) {
 #pragma unroll
         for (uint32_t j = 0; j < 8; j++) v[j] = (_Float16)0.0f;
@@ -613,7 +636,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
     const _Float16* w_hid = Wt + (size_t)W * in_dim;
     const _Float16* w_last = w_hid + (size_t)NH * W * W;
 
-    for (uint32_t f = wave; f < nfrag; f += 4) {
+    for (uint32_t f = wave; f < (S3D_FF_EXPERIMENT == 3 ? 0u : nfrag); f += 4) {
         half8 v;
         if (f < nf_f0) {  // forward, layer 0: A[row = hidden feature][k = input]
             const uint32_t mblk = f / KS0, s = f % KS0;
@@ -736,7 +759,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
             for (uint32_t s = 0; s < 2; s++) {
                 const half8 af = transpose_load(TG, 0, s, n, h, 16);
 #pragma unroll
-                for (uint32_t ni = 0; ni < MB; ni++) dwl[ni] = mfma(af, transpose_load(TX, ni, s, n, h, W), dwl[ni]);
+                for (uint32_t ni = 0; ni < MB; ni++) if (S3D_FF_EXPERIMENT != 1) dwl[ni] = mfma(af, transpose_load(TX, ni, s, n, h, W), dwl[ni]);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -780,7 +803,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
                     for (uint32_t mo = 0; mo < MB; mo++) {
                         const half8 af = transpose_load(TG, mo, s, n, h, W);
 #pragma unroll
-                        for (uint32_t ni = 0; ni < MB; ni++) dwh[k - 1][mo][ni] = mfma(af, bfr[ni], dwh[k - 1][mo][ni]);
+                        for (uint32_t ni = 0; ni < MB; ni++) if (S3D_FF_EXPERIMENT != 1) dwh[k - 1][mo][ni] = mfma(af, bfr[ni], dwh[k - 1][mo][ni]);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -803,7 +826,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
                     for (uint32_t mo = 0; mo < MB; mo++) {
                         const half8 af = transpose_load(TG, mo, s, n, h, W);
 #pragma unroll
-                        for (uint32_t ni = 0; ni < (uint32_t)IMB; ni++) dw0[mo][ni] = mfma(af, bfr[ni], dw0[mo][ni]);
+                        for (uint32_t ni = 0; ni < (uint32_t)IMB; ni++) if (S3D_FF_EXPERIMENT != 1) dw0[mo][ni] = mfma(af, bfr[ni], dw0[mo][ni]);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -829,6 +852,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
         }
     }
 
+    if (S3D_FF_EXPERIMENT == 2) return;
     // ---- sum the four waves in a fixed order through LDS, one [64][64] fp32 partial per (matrix, workgroup)
     float* red = reinterpret_cast<float*>(smem_raw);  // 4 planes x 16 KiB over the (no longer needed) fragments and tiles
     flush_matrix<MB, IMB>(red, partial, 0, wave, n, h, [&](auto mo, auto ni) { return dw0[mo][ni]; });

@@ -70,7 +70,8 @@ def lib():
         l.s3d_last_error.restype = C.c_char_p
         l.s3d_version.restype = C.c_char_p
         for name in ("s3d_march_rays_train_workspace_size", "s3d_compact_alive_workspace_size",
-                     "s3d_ffmlp_backward_workspace_size", "s3d_grid_encode_backward_workspace_size"):
+                     "s3d_ffmlp_backward_workspace_size", "s3d_grid_encode_backward_workspace_size",
+                     "s3d_sweep_update_workspace_size"):
             getattr(l, name).restype = C.c_size_t
         l.s3d_vm_backward_max_bins.restype = C.c_uint32
         l.s3d_grid_level_scales.restype = None

@@ -6,7 +6,7 @@ import s3d_hip
 from tools.microbench import timeit
 F = s3d_hip.FFMLPBackend
 for (inn, W, n) in ((32, 64, 2), (32, 64, 3)):
-    for B in (1 << 17, 1 << 18, 1 << 20):
+    for B in [int(b) for b in os.environ.get('S3D_BENCH_SIZES', '').split(',') if b] or (1 << 17, 1 << 18, 1 << 20):
         x = torch.randn(B, inn, device="cuda").half()
         w = (torch.rand(W * (inn + W * (n - 1) + 16), device="cuda") - 0.5).half()
         fb = torch.empty(n, B, W, device="cuda", dtype=torch.half)
