@@ -581,23 +581,26 @@ __device__ __forceinline__ half8 transpose_load(const _Float16* __restrict__ T, 
 // Sum one weight-gradient matrix over the four waves of the workgroup and write the workgroup's fp32 partial.
 // Each wave stores its accumulator blocks to its OWN [64][64] LDS plane (independent stores, no read-modify-write
 // chains), then all 256 threads add the four planes in a fixed order.
-template <uint32_t MBLK, uint32_t NBLK, typename Get>
+template <uint32_t MBLK, uint32_t NBLK, uint32_t THREADS = 256, typename Get>
 __device__ __forceinline__ void flush_matrix(float* __restrict__ red, float* __restrict__ partial, uint32_t matrix, uint32_t wave,
                                              uint32_t n, uint32_t h, Get&& get) {
+    // (THREADS > 256: the waves behind the fourth hold no accumulators — `wave` >= 4 — and only help with the sum)
     constexpr uint32_t kPlane = kWgradPad * kWgradPad;
     __syncthreads();
     float* mine = red + (size_t)wave * kPlane;
+    if (wave < 4) {
 #pragma unroll
-    for (uint32_t mo = 0; mo < MBLK; mo++)
+        for (uint32_t mo = 0; mo < MBLK; mo++)
 #pragma unroll
-        for (uint32_t ni = 0; ni < NBLK; ni++) {
-            const float16v v = get(mo, ni);
+            for (uint32_t ni = 0; ni < NBLK; ni++) {
+                const float16v v = get(mo, ni);
 #pragma unroll
-            for (uint32_t r = 0; r < 16; r++) mine[(mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * kWgradPad + ni * 32 + n] = v[r];
-        }
+                for (uint32_t r = 0; r < 16; r++) mine[(mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * kWgradPad + ni * 32 + n] = v[r];
+            }
+    }
     __syncthreads();
     float* dst = partial + ((size_t)matrix * gridDim.x + blockIdx.x) * kPlane;
-    for (uint32_t i = threadIdx.x; i < kPlane; i += 256) {
+    for (uint32_t i = threadIdx.x; i < kPlane; i += THREADS) {
         const uint32_t o = i / kWgradPad, c = i % kWgradPad;
         float v = 0.0f;
         if (o < MBLK * 32 && c < NBLK * 32) v = ((red[i] + red[kPlane + i]) + red[2 * kPlane + i]) + red[3 * kPlane + i];
@@ -862,6 +865,312 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
     flush_matrix<1, MB>(red, partial, NH + 1, wave, n, h, [&](auto mo, auto ni) { (void)mo; return dwl[ni]; });
 }
 
+template <typename F, uint32_t... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<uint32_t, I...>) {
+    (f(std::integral_constant<uint32_t, I>{}), ...);
+}
+template <uint32_t N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<uint32_t, N>{}); }
+
+// ------------------------------------------------------------------------------------ backward: fused, two roles
+// The fused kernel above runs ONE 456-register wave per SIMD: nothing hides the latencies of its MFMA chains, conversions and
+// LDS round trips, and it spends ~70 % of a launch in the re-computation + data-gradient chain and ~30 % in the weight-gradient
+// MFMAs (measured by switching the halves off).  Here the two halves are different WAVES: workgroup = 4 pairs; the compute
+// wave of a pair re-computes the activations and walks the data gradient, storing each layer's (gradient, activation) tile to
+// LDS; its partner keeps the weight-gradient accumulators (192 registers) and consumes the tiles one stage behind, through a
+// double-buffered slot and one workgroup barrier per stage.  Two waves of <= 256 registers per SIMD: the matrix pipe, the VALU
+// and the LDS overlap across the pair.  Same per-wave tile sequence, same MFMA order per accumulator: bit-identical results.
+template <int W, int NH, int IMB, int ACT, int KS0T>
+__global__ void __launch_bounds__(512) k_ffmlp_backward_duo(const _Float16* __restrict__ grad, const _Float16* __restrict__ X,
+                                                            const _Float16* __restrict__ Wt, uint32_t B, uint32_t in_dim,
+                                                            uint32_t out_dim, uint32_t act, _Float16* __restrict__ grad_inputs,
+                                                            float* __restrict__ partial, uint32_t in_layout,
+                                                            const int32_t* __restrict__ n_valid,
+                                                            const float* __restrict__ d_rgb, const float* __restrict__ rgb_head) {
+    constexpr uint32_t MB = W / 32, KS = W / 16, NS = NH + 2;  // NS stages per tile: last | hidden NH..1 | first
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t role = wave >> 2, pair = wave & 3;  // role 0: compute, 1: weight gradient
+    const uint32_t n = lane & 31, h = lane >> 5;
+    const uint32_t KS0 = KS0T ? (uint32_t)KS0T : in_dim / 16;
+    const uint32_t nf_f0 = MB * KS0, nf_fh = NH * MB * KS;
+    const uint32_t nf_bl = MB, nf_bh = NH * MB * KS, nf_b0 = grad_inputs ? IMB * KS : 0;
+    const uint32_t nfrag = nf_f0 + nf_fh + nf_bl + nf_bh + nf_b0;
+    half8* frags = reinterpret_cast<half8*>(smem_raw);
+    half8* ff0 = frags;
+    half8* ffh = ff0 + (size_t)nf_f0 * 64;
+    half8* fbl = ffh + (size_t)nf_fh * 64;
+    half8* fbh = fbl + (size_t)nf_bl * 64;
+    half8* fb0 = fbh + (size_t)nf_bh * 64;
+    _Float16* tiles = reinterpret_cast<_Float16*>(frags + (size_t)nfrag * 64);
+    constexpr uint32_t kTile = kTRows * kTRow;
+    _Float16* slots = tiles + (size_t)pair * 4 * kTile;  // [slot 0: TG | TX][slot 1: TG | TX]
+    const _Float16* w_hid = Wt + (size_t)W * in_dim;
+    const _Float16* w_last = w_hid + (size_t)NH * W * W;
+
+    for (uint32_t f = wave; f < nfrag; f += 8) {
+        half8 v;
+        if (f < nf_f0) {  // forward, layer 0: A[row = hidden feature][k = input]
+            const uint32_t mblk = f / KS0, s = f % KS0;
+            const _Float16* r = Wt + (size_t)(mblk * 32 + n) * in_dim + 16 * s;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) v[j] = r[kperm(h, j)];
+        } else if (f < nf_f0 + nf_fh) {  // forward, hidden k
+            const uint32_t g = f - nf_f0, k = g / (MB * KS), mblk = (g / KS) % MB, s = g % KS;
+            const _Float16* r = w_hid + (size_t)k * W * W + (size_t)(mblk * 32 + n) * W + 16 * s;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) v[j] = r[kperm(h, j)];
+        } else if (f < nf_f0 + nf_fh + nf_bl) {  // last^T: A[i = hidden feature][k = output] = W_last[k][i]
+            const uint32_t i = (f - nf_f0 - nf_fh) * 32 + n;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const uint32_t k = kperm(h, j);
+                v[j] = (k < out_dim) ? w_last[(size_t)k * W + i] : (_Float16)0.0f;
+            }
+        } else if (f < nf_f0 + nf_fh + nf_bl + nf_bh) {  // hidden^T: A[i = in feature][k = out feature] = W_k[k][i]
+            const uint32_t g = f - nf_f0 - nf_fh - nf_bl, k = g / (MB * KS), mblk = (g / KS) % MB, s = g % KS;
+            const _Float16* wk = w_hid + (size_t)k * W * W;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) v[j] = wk[(size_t)(16 * s + kperm(h, j)) * W + mblk * 32 + n];
+        } else {  // first^T: A[i = network input][k = first hidden feature] = W_0[k][i]
+            const uint32_t g = f - nf_f0 - nf_fh - nf_bl - nf_bh, mblk = g / KS, s = g % KS;
+            const uint32_t i = mblk * 32 + n;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++)
+                v[j] = (i < in_dim) ? Wt[(size_t)(16 * s + kperm(h, j)) * in_dim + i] : (_Float16)0.0f;
+        }
+        frags[f * 64 + lane] = v;
+    }
+    __syncthreads();
+
+    // tiles of this pair: blockIdx.x * 4 + pair + i * gridDim.x * 4; every wave of the workgroup runs `nit` rounds of NS
+    // stages plus one draining stage, whatever its own tile count (the barriers are workgroup-wide)
+    const uint32_t ntiles = valid_rows(B, n_valid) / 32;
+    const uint32_t first = blockIdx.x * 4, stride = gridDim.x * 4;
+    const uint32_t nit = ntiles > first ? (ntiles - first - 1) / stride + 1 : 0;  // rounds of pair 0 (the most)
+    auto tile_of = [&](uint32_t i) { return first + pair + i * stride; };
+    auto slot_of = [&](uint32_t i, uint32_t st) { return slots + (size_t)((i * NS + st) & 1u) * 2 * kTile; };
+
+    if (role == 0) {
+        // =============================================================== compute wave
+        for (uint32_t i = 0; i < nit; i++) {
+            const uint32_t tile = tile_of(i);
+            const bool live = tile < ntiles;
+            const size_t row = (size_t)(live ? tile : 0) * 32 + n;
+            half8 xf[4];
+            half8 gf;
+            half8 a[NH + 1][KS];
+            float16v acc[MB];
+            half8 G[KS];
+            if (live) {
+#pragma unroll
+                for (uint32_t s = 0; s < 4; s++)
+                    if (s < KS0) xf[s] = load_bfrag_input(X, in_layout, B, in_dim, row, s, h);
+                if (d_rgb) {
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) gf[j] = (_Float16)0.0f;
+                    if (h == 0) {
+#pragma unroll
+                        for (uint32_t c = 0; c < 3; c++) {
+                            const float y = rgb_head[row * 3 + c];
+                            gf[c] = (_Float16)((float)(_Float16)d_rgb[row * 3 + c] * (y * (1.0f - y)));
+                        }
+                    }
+                } else {
+                    gf = load_bfrag_rowmajor(grad + row * 16, 0, h);
+                }
+                // forward re-computation (same operations and roundings as k_ffmlp_forward)
+#pragma unroll
+                for (uint32_t m = 0; m < MB; m++) acc[m] = zero16();
+#pragma unroll
+                for (uint32_t s = 0; s < 4; s++)
+                    if (s < KS0) {
+#pragma unroll
+                        for (uint32_t m = 0; m < MB; m++) acc[m] = mfma(ff0[(m * KS0 + s) * 64 + lane], xf[s], acc[m]);
+                    }
+#pragma unroll
+                for (uint32_t layer = 0; layer <= (uint32_t)NH; layer++) {
+#pragma unroll
+                    for (uint32_t m = 0; m < MB; m++)
+#pragma unroll
+                        for (uint32_t r = 0; r < 16; r += 2) {
+                            if constexpr (ACT == ACT_RELU) {
+                                const half2p v = relu2(cvt2(acc[m][r], acc[m][r + 1]));
+                                a[layer][2 * m + (r >> 3)][r & 7] = v[0];
+                                a[layer][2 * m + (r >> 3)][(r & 7) + 1] = v[1];
+                            } else {
+#pragma unroll
+                                for (uint32_t q = r; q < r + 2; q++) {
+                                    const float pre = (float)(_Float16)acc[m][q];
+                                    a[layer][2 * m + (q >> 3)][q & 7] = (_Float16)act_fwd_t<ACT>(act, pre);
+                                }
+                            }
+                        }
+                    if (layer < (uint32_t)NH) {
+                        const half8* wf = ffh + (size_t)(layer * MB * KS) * 64;
+#pragma unroll
+                        for (uint32_t m = 0; m < MB; m++) {
+                            acc[m] = zero16();
+#pragma unroll
+                            for (uint32_t s = 0; s < KS; s++) acc[m] = mfma(wf[(m * KS + s) * 64 + lane], a[layer][s], acc[m]);
+                        }
+                    }
+                }
+                // stage 0: tiles of the last layer, then through it
+                _Float16* T = slot_of(i, 0);
+                const half8 gtmp[1] = {gf};
+                transpose_store<1>(T, gtmp, 1, n, h);
+                transpose_store<(int)KS>(T + kTile, a[NH], KS, n, h);
+#pragma unroll
+                for (uint32_t m = 0; m < MB; m++) acc[m] = mfma(fbl[m * 64 + lane], gf, zero16());
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = NH; k >= 0; k--) {
+                const uint32_t st = (uint32_t)(NH - k) + 1;
+                if (live) {
+                    // gradient w.r.t. the pre-activation of hidden layer k (activation transfer with the re-computed output)
+#pragma unroll
+                    for (uint32_t m = 0; m < MB; m++)
+#pragma unroll
+                        for (uint32_t r = 0; r < 16; r += 2) {
+                            if constexpr (ACT == ACT_RELU) {
+                                half2p av;
+                                av[0] = a[k][2 * m + (r >> 3)][r & 7]; av[1] = a[k][2 * m + (r >> 3)][(r & 7) + 1];
+                                const half2p v = gate2(cvt2(acc[m][r], acc[m][r + 1]), av);
+                                G[2 * m + (r >> 3)][r & 7] = v[0];
+                                G[2 * m + (r >> 3)][(r & 7) + 1] = v[1];
+                            } else {
+#pragma unroll
+                                for (uint32_t q = r; q < r + 2; q++) {
+                                    const float g = (float)(_Float16)acc[m][q];
+                                    G[2 * m + (q >> 3)][q & 7] = (_Float16)act_bwd_t<ACT>(act, g, (float)a[k][2 * m + (q >> 3)][q & 7]);
+                                }
+                            }
+                        }
+                    _Float16* T = slot_of(i, st);
+                    transpose_store<(int)KS>(T, G, KS, n, h);
+                    if (k > 0) {
+                        transpose_store<(int)KS>(T + kTile, a[k - 1], KS, n, h);
+                        const half8* wf = fbh + (size_t)((k - 1) * MB * KS) * 64;
+#pragma unroll
+                        for (uint32_t m = 0; m < MB; m++) {
+                            acc[m] = zero16();
+#pragma unroll
+                            for (uint32_t s = 0; s < KS; s++) acc[m] = mfma(wf[(m * KS + s) * 64 + lane], G[s], acc[m]);
+                        }
+                    } else {
+                        transpose_store<4>(T + kTile, xf, KS0, n, h);
+                        if (grad_inputs) {
+#pragma unroll
+                            for (uint32_t m = 0; m < (uint32_t)IMB; m++) {
+                                float16v gi = zero16();
+#pragma unroll
+                                for (uint32_t s = 0; s < KS; s++) gi = mfma(fb0[(m * KS + s) * 64 + lane], G[s], gi);
+#pragma unroll
+                                for (uint32_t q = 0; q < 4; q++) {
+                                    const uint32_t feat = m * 32 + 8 * q + 4 * h;
+                                    if (feat < in_dim) {
+                                        half4 v;
+#pragma unroll
+                                        for (uint32_t e = 0; e < 4; e++) v[e] = (_Float16)gi[4 * q + e];
+                                        store_grad_input(grad_inputs, in_layout, B, in_dim, row, feat, v);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (nit) __syncthreads();  // the partner's draining stage
+    } else {
+        // =============================================================== weight-gradient wave
+        float16v dw0[MB][IMB], dwh[NH > 0 ? NH : 1][MB][MB], dwl[MB];
+#pragma unroll
+        for (uint32_t p = 0; p < MB; p++) {
+#pragma unroll
+            for (uint32_t q = 0; q < (uint32_t)IMB; q++) dw0[p][q] = zero16();
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t)NH; k++)
+#pragma unroll
+                for (uint32_t q = 0; q < MB; q++) dwh[k][p][q] = zero16();
+            dwl[p] = zero16();
+        }
+        // stage st of round i is consumed while the partner produces the next one: one barrier behind
+        auto consume = [&](uint32_t i, auto stc) {
+            constexpr uint32_t st = decltype(stc)::value;
+            if (tile_of(i) >= ntiles) return;
+            const _Float16* T = slot_of(i, st);
+            const _Float16* TXs = T + kTile;
+            if constexpr (st == 0) {
+#pragma unroll
+                for (uint32_t s = 0; s < 2; s++) {
+                    const half8 af = transpose_load(T, 0, s, n, h, 16);
+#pragma unroll
+                    for (uint32_t ni = 0; ni < MB; ni++) dwl[ni] = mfma(af, transpose_load(TXs, ni, s, n, h, W), dwl[ni]);
+                }
+            } else if constexpr (st <= (uint32_t)NH) {
+                constexpr uint32_t k = NH - (st - 1);  // hidden layer whose pre-activation gradient is in T
+#pragma unroll
+                for (uint32_t s = 0; s < 2; s++) {
+                    half8 bfr[MB];
+#pragma unroll
+                    for (uint32_t ni = 0; ni < MB; ni++) bfr[ni] = transpose_load(TXs, ni, s, n, h, W);
+#pragma unroll
+                    for (uint32_t mo = 0; mo < MB; mo++) {
+                        const half8 af = transpose_load(T, mo, s, n, h, W);
+#pragma unroll
+                        for (uint32_t ni = 0; ni < MB; ni++) dwh[k - 1][mo][ni] = mfma(af, bfr[ni], dwh[k - 1][mo][ni]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (uint32_t s = 0; s < 2; s++) {
+                    half8 bfr[IMB];
+#pragma unroll
+                    for (uint32_t ni = 0; ni < (uint32_t)IMB; ni++) bfr[ni] = transpose_load(TXs, ni, s, n, h, in_dim);
+#pragma unroll
+                    for (uint32_t mo = 0; mo < MB; mo++) {
+                        const half8 af = transpose_load(T, mo, s, n, h, W);
+#pragma unroll
+                        for (uint32_t ni = 0; ni < (uint32_t)IMB; ni++) dw0[mo][ni] = mfma(af, bfr[ni], dw0[mo][ni]);
+                    }
+                }
+            }
+        };
+        for (uint32_t i = 0; i < nit; i++) {
+            if (i > 0) consume(i - 1, std::integral_constant<uint32_t, NS - 1>{});
+            __syncthreads();
+            static_for<NS - 1>([&](auto stc) {
+                consume(i, stc);
+                __syncthreads();
+            });
+        }
+        if (nit) {
+            consume(nit - 1, std::integral_constant<uint32_t, NS - 1>{});
+            __syncthreads();
+        }
+        // ---- sum the four weight-gradient waves in a fixed order through LDS (all 512 threads add), one partial per matrix
+        float* red = reinterpret_cast<float*>(smem_raw);
+        flush_matrix<MB, IMB, 512>(red, partial, 0, pair, n, h, [&](auto mo, auto ni) { return dw0[mo][ni]; });
+#pragma unroll
+        for (uint32_t k = 0; k < (uint32_t)NH; k++)
+            flush_matrix<MB, MB, 512>(red, partial, 1 + k, pair, n, h, [&](auto mo, auto ni) { return dwh[k][mo][ni]; });
+        flush_matrix<1, MB, 512>(red, partial, NH + 1, pair, n, h, [&](auto mo, auto ni) { (void)mo; return dwl[ni]; });
+        return;
+    }
+    // compute waves: the same barriers as the flushes above, and their share of the sums
+    float* red = reinterpret_cast<float*>(smem_raw);
+    const float16v none = zero16();
+    flush_matrix<MB, IMB, 512>(red, partial, 0, 4 + pair, n, h, [&](auto, auto) { return none; });
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)NH; k++) flush_matrix<MB, MB, 512>(red, partial, 1 + k, 4 + pair, n, h, [&](auto, auto) { return none; });
+    flush_matrix<1, MB, 512>(red, partial, NH + 1, 4 + pair, n, h, [&](auto, auto) { return none; });
+}
+
 constexpr uint32_t kWgradBlocks = 256;
 
 // `n_valid` of the entry point being served on this thread (see valid_rows()); the launch helpers below pass it on
@@ -957,18 +1266,26 @@ int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Floa
     const uint32_t nfrag = MB * (in_dim / 16) + NH * MB * KS + MB + NH * MB * KS + (grad_inputs ? IMB * KS : 0);
     size_t smem = (size_t)nfrag * 64 * sizeof(half8) + (size_t)4 * 2 * kTRows * kTRow * sizeof(_Float16);
     if (smem < 4 * kWgradPad * kWgradPad * sizeof(float)) smem = 4 * kWgradPad * kWgradPad * sizeof(float);  // epilogue planes
+    static const bool duo = [] { const char* e = getenv("S3D_FFMLP_DUO"); return !(e && e[0] == '0'); }();  // A/B switch
+    if (duo) smem += (size_t)4 * 2 * kTRows * kTRow * sizeof(_Float16);  // second tile slot per pair
     static std::atomic<uint64_t> attr_devs{0};
     int dev;
     if (device_needs_setup(attr_devs, &dev)) {
         S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_backward_fused<W, NH, IMB, ACT, KS0T>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_backward_duo<W, NH, IMB, ACT, KS0T>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         device_setup_done(attr_devs, dev);
     }
     const uint32_t ntiles = B / 32;
     uint32_t nblk = div_up<uint32_t>(ntiles, 4);
     if (nblk > kWgradBlocks) nblk = kWgradBlocks;
-    hipLaunchKernelGGL((k_ffmlp_backward_fused<W, NH, IMB, ACT, KS0T>), dim3(nblk), dim3(256), smem, st, grad, X, Wt, B, in_dim, out_dim,
-                       act, grad_inputs, partial, in_layout, t_n_valid, t_d_rgb, t_rgb_in);
+    if (duo)
+        hipLaunchKernelGGL((k_ffmlp_backward_duo<W, NH, IMB, ACT, KS0T>), dim3(nblk), dim3(512), smem, st, grad, X, Wt, B, in_dim,
+                           out_dim, act, grad_inputs, partial, in_layout, t_n_valid, t_d_rgb, t_rgb_in);
+    else
+        hipLaunchKernelGGL((k_ffmlp_backward_fused<W, NH, IMB, ACT, KS0T>), dim3(nblk), dim3(256), smem, st, grad, X, Wt, B, in_dim,
+                           out_dim, act, grad_inputs, partial, in_layout, t_n_valid, t_d_rgb, t_rgb_in);
     WgradPlan plan;
     memset(&plan, 0, sizeof(plan));
     plan.n = NH + 2;
