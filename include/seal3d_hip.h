@@ -96,13 +96,16 @@ int s3d_sweep_update(float* density_grid, uint32_t n_cells, const int32_t* cells
  * up to 128 rows, at most M) still reads them: [total, round_up(total, 128)) and, for the one ray that straddles the
  * budget (offset < M < offset + steps, dropped like in the reference), [offset, M).  The reference zero-fills all M rows
  * beforehand (raymarching.py:205-207); callers that read every row must still do so.  s3d_composite_rays_train_backward
- * does the same for grad_sigmas / grad_rgbs (plus the samples behind a ray's early termination). */
+ * does the same for grad_sigmas / grad_rgbs (plus the samples behind a ray's early termination).
+ * aabb != NULL (build extension): s3d_near_far_from_aabb(aabb, min_near, noise_step, noise_key) is part of this call —
+ * nears / fars and, with noise_step, noises are then OUTPUTS (written before they are used; same values). */
 size_t s3d_march_rays_train_workspace_size(uint32_t N, uint32_t max_steps);
 int s3d_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                          float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                          uint32_t M, const float* nears, const float* fars, float* xyzs, float* dirs,
                          float* deltas, int32_t* rays, int32_t* counter, const float* noises,
-                         void* workspace, size_t workspace_bytes, int path, s3d_stream_t stream);
+                         void* workspace, size_t workspace_bytes, int path, const float* aabb, float min_near,
+                         const int32_t* noise_step, uint32_t noise_key, s3d_stream_t stream);
 
 /* raymarching.h:14 void composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh,
  *                                                    weights_sum, depth, image)

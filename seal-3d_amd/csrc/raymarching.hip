@@ -74,35 +74,44 @@ __device__ __forceinline__ void zero_grad_rows(float* __restrict__ grad_sigmas, 
     }
 }
 
+// raymarching.cu:near_far_from_aabb — slab test against the box, near clamped to min_near; a miss gives FLT_MAX twice
+__device__ __forceinline__ void near_far_of(const float* __restrict__ rays_o, const float* __restrict__ rays_d, uint32_t n,
+                                            const float (&a)[6], float min_near, float& near_out, float& far_out) {
+    const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
+    const float rdx = 1 / rays_d[n * 3], rdy = 1 / rays_d[n * 3 + 1], rdz = 1 / rays_d[n * 3 + 2];
+    float near = (a[0] - ox) * rdx, far = (a[3] - ox) * rdx;
+    if (near > far) { float t = near; near = far; far = t; }
+    float near_y = (a[1] - oy) * rdy, far_y = (a[4] - oy) * rdy;
+    if (near_y > far_y) { float t = near_y; near_y = far_y; far_y = t; }
+    bool miss = (near > far_y || near_y > far);
+    if (!miss) {
+        if (near_y > near) near = near_y;
+        if (far_y < far) far = far_y;
+        float near_z = (a[2] - oz) * rdz, far_z = (a[5] - oz) * rdz;
+        if (near_z > far_z) { float t = near_z; near_z = far_z; far_z = t; }
+        miss = (near > far_z || near_z > far);
+        if (!miss) {
+            if (near_z > near) near = near_z;
+            if (far_z < far) far = far_z;
+            if (near < min_near) near = min_near;
+        }
+    }
+    near_out = miss ? 3.402823466e+38f : near;
+    far_out = miss ? 3.402823466e+38f : far;
+}
+
 __global__ void k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                            const float* __restrict__ aabb, uint32_t N, float min_near,
                            float* __restrict__ nears, float* __restrict__ fars, float* __restrict__ noises,
                            const int32_t* __restrict__ noise_step, uint32_t noise_key) {
-    const float a0 = aabb[0], a1 = aabb[1], a2 = aabb[2], a3 = aabb[3], a4 = aabb[4], a5 = aabb[5];
+    const float a[6] = {aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5]};
     const uint32_t step = (noises && noise_step) ? (uint32_t)*noise_step : 0u;
     for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
         if (noises) noises[n] = ray_noise(noise_key, step, n);
-        const float ox = rays_o[n * 3], oy = rays_o[n * 3 + 1], oz = rays_o[n * 3 + 2];
-        const float rdx = 1 / rays_d[n * 3], rdy = 1 / rays_d[n * 3 + 1], rdz = 1 / rays_d[n * 3 + 2];
-        float near = (a0 - ox) * rdx, far = (a3 - ox) * rdx;
-        if (near > far) { float t = near; near = far; far = t; }
-        float near_y = (a1 - oy) * rdy, far_y = (a4 - oy) * rdy;
-        if (near_y > far_y) { float t = near_y; near_y = far_y; far_y = t; }
-        bool miss = (near > far_y || near_y > far);
-        if (!miss) {
-            if (near_y > near) near = near_y;
-            if (far_y < far) far = far_y;
-            float near_z = (a2 - oz) * rdz, far_z = (a5 - oz) * rdz;
-            if (near_z > far_z) { float t = near_z; near_z = far_z; far_z = t; }
-            miss = (near > far_z || near_z > far);
-            if (!miss) {
-                if (near_z > near) near = near_z;
-                if (far_z < far) far = far_z;
-                if (near < min_near) near = min_near;
-            }
-        }
-        nears[n] = miss ? 3.402823466e+38f : near;
-        fars[n] = miss ? 3.402823466e+38f : far;
+        float near, far;
+        near_far_of(rays_o, rays_d, n, a, min_near, near, far);
+        nears[n] = near;
+        fars[n] = far;
     }
 }
 
@@ -418,9 +427,11 @@ template <bool CONST_DT>
 __global__ void __launch_bounds__(64) k_march_count_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                          const uint8_t* __restrict__ grid, float bound, float dt_gamma,
                                                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
-                                                         const float* __restrict__ nears, const float* __restrict__ fars,
-                                                         const float* __restrict__ noises, int32_t* __restrict__ rays,
-                                                         const int32_t* __restrict__ counter, uint32_t* __restrict__ ws) {
+                                                         float* __restrict__ nears, float* __restrict__ fars,
+                                                         float* __restrict__ noises, int32_t* __restrict__ rays,
+                                                         const int32_t* __restrict__ counter, uint32_t* __restrict__ ws,
+                                                         const float* __restrict__ aabb, float min_near,
+                                                         const int32_t* __restrict__ noise_step, uint32_t noise_key) {
     __shared__ float T[kWin + 8];
     __shared__ uint16_t nxt[kWin];          // kOcc = occupied, else the skip target index
     __shared__ uint16_t J[2][kWin + 2];     // jump tables of the pointer-doubling rounds
@@ -429,11 +440,24 @@ __global__ void __launch_bounds__(64) k_march_count_wave(const float* __restrict
     const uint32_t n = blockIdx.x, lane = threadIdx.x;
     const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
     const Ray r = load_ray(rays_o, rays_d, n);
-    const float far = fars[n];
+    float far, t_carry, noise;
+    if (aabb) {  // near / far / jitter of the ray made here (k_near_far's arithmetic) and left for the write pass and the caller
+        const float a[6] = {aabb[0], aabb[1], aabb[2], aabb[3], aabb[4], aabb[5]};
+        near_far_of(rays_o, rays_d, n, a, min_near, t_carry, far);
+        noise = noises ? (noise_step ? ray_noise(noise_key, (uint32_t)*noise_step, n) : noises[n]) : 0.0f;
+        if (lane == 0) {
+            nears[n] = t_carry;
+            fars[n] = far;
+            if (noises && noise_step) noises[n] = noise;
+        }
+    } else {
+        far = fars[n];
+        t_carry = nears[n];
+        noise = noises[n];
+    }
     const float dt0 = clampf(0.0f, p.dt_min, p.dt_max);  // the step when dt_gamma == 0 (dt_max if max_steps is tiny)
     auto dtf = [&](float t) { return CONST_DT ? dt0 : clampf(t * dt_gamma, p.dt_min, p.dt_max); };
-    float t_carry = nears[n];
-    t_carry = __builtin_fmaf(clampf(t_carry * dt_gamma, p.dt_min, p.dt_max), noises[n], t_carry);
+    t_carry = __builtin_fmaf(clampf(t_carry * dt_gamma, p.dt_min, p.dt_max), noise, t_carry);
     float* tout = reinterpret_cast<float*>(ws + kWsHeader + N) + (size_t)n * max_steps;
 
     uint32_t num_steps = 0;       // wave-uniform
@@ -1013,7 +1037,8 @@ S3D_EXPORT int s3d_march_rays_train(const float* rays_o, const float* rays_d, co
                                     float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                                     const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                                     int32_t* rays, int32_t* counter, const float* noises, void* workspace,
-                                    size_t workspace_bytes, int path, s3d_stream_t stream) {
+                                    size_t workspace_bytes, int path, const float* aabb, float min_near,
+                                    const int32_t* noise_step, uint32_t noise_key, s3d_stream_t stream) {
     // path: 0 = auto (wave-per-ray up to 16,384 rays), 1 = lane-per-ray kernels, 2 = wave-per-ray kernels
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(path >= 0 && path <= 2, "march_rays_train: path must be 0 (auto), 1 (lane per ray) or 2 (wave per ray)");
@@ -1026,13 +1051,23 @@ S3D_EXPORT int s3d_march_rays_train(const float* rays_o, const float* rays_d, co
     uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
     const bool wave_ok = workspace_bytes >= march_wave_ws(N, max_steps) && max_steps >= 1;
     const bool use_wave = (path == 2 && wave_ok) || (path == 0 && wave_ok && N <= kWaveMarchMaxRays);
+    // aabb given: nears / fars (and, with noise_step, noises) are OUTPUTS of this call — made by the wave-per-ray count kernel
+    // itself, by k_near_far in front of the lane-per-ray kernels
+    float* nears_w = const_cast<float*>(nears);
+    float* fars_w = const_cast<float*>(fars);
+    float* noises_w = const_cast<float*>(noises);
+    if (aabb && !use_wave)
+        hipLaunchKernelGGL(k_near_far, dim3(stream_grid(N, 256)), dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, N,
+                           min_near, nears_w, fars_w, noise_step ? noises_w : nullptr, noise_step, noise_key);
     if (use_wave) {
         if (dt_gamma == 0.0f)
             hipLaunchKernelGGL(k_march_count_wave<true>, dim3(N), dim3(64), 0, as_stream(stream), rays_o, rays_d, grid, bound,
-                               dt_gamma, max_steps, N, C, H, nears, fars, noises, rays, (const int32_t*)counter, ws);
+                               dt_gamma, max_steps, N, C, H, nears_w, fars_w, noises_w, rays, (const int32_t*)counter, ws, aabb,
+                               min_near, noise_step, noise_key);
         else
             hipLaunchKernelGGL(k_march_count_wave<false>, dim3(N), dim3(64), 0, as_stream(stream), rays_o, rays_d, grid, bound,
-                               dt_gamma, max_steps, N, C, H, nears, fars, noises, rays, (const int32_t*)counter, ws);
+                               dt_gamma, max_steps, N, C, H, nears_w, fars_w, noises_w, rays, (const int32_t*)counter, ws, aabb,
+                               min_near, noise_step, noise_key);
         hipLaunchKernelGGL(k_march_write_wave, dim3(N), dim3(64), 0, as_stream(stream), rays_o, rays_d, bound, dt_gamma,
                            max_steps, N, C, H, M, nears, noises, xyzs, dirs, deltas, rays, counter, (const uint32_t*)ws);
         return check_launch("march_rays_train");

@@ -121,9 +121,8 @@ class NeRFRenderer(nn.Module):
         aabb = self.aabb_train if self.training else self.aabb_infer
         noises = None
         noise_step = getattr(self, "_noise_step", None) if (self.training and perturb) else None
-        if noise_step is not None:  # graph-replayed step (nerf/trainer.py): the jitter comes out of the same kernel
-            nears, fars, noises = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near, noise_step,
-                                                                 getattr(self, "_noise_key", 0))
+        if noise_step is not None:  # graph-replayed step (nerf/trainer.py): near / far and the jitter are made by the marcher
+            nears = fars = None
         else:
             nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
 
@@ -148,7 +147,9 @@ class NeRFRenderer(nn.Module):
             xyzs, dirs, deltas, rays = raymarching.march_rays_train(
                 rays_o, rays_d, self.bound, self.density_bitfield, self.cascade, self.grid_size, nears, fars, counter,
                 self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps,
-                *(() if trim and noises is None and not lean else (trim, noises, not lean)))
+                *(() if trim and noises is None and not lean and noise_step is None else
+                  (trim, noises, not lean) + (() if noise_step is None else
+                                              (aabb, self.min_near, noise_step, getattr(self, "_noise_key", 0)))))
             # the buffers are padded to M rows (raymarching.py:205-207); counter[0] says on the device how many hold samples
             # (a proxy mapper skips the rows behind the count only when the network behind it skips them too: otherwise the
             #  network would read rows the mapper never wrote)

@@ -144,14 +144,16 @@ class _MarchRaysTrain(Function):
     @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
                 perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, trim=True, noises=None,
-                zero_fill=True):
+                zero_fill=True, aabb=None, min_near=0.2, noise_step=None, noise_key=0):
         """`trim=False` (build extension): without a sample budget the reference reads the sample count back and trims the
         N * max_steps buffers (raymarching.py:223-231: a device->host sync).  A caller whose whole sample path takes the
         device-side count (`n_valid`, seal3d_hip.h) keeps the full buffers instead: no sync, static shapes.
         `noises` (build extension): the per-ray jitter [N] in [0, 1) when the caller has drawn it already (perturb).
         `zero_fill=False` (build extension, HIP backend): the reference zero-fills the M-row buffers; the HIP kernels write
         zeros to every unfilled row below the sample count rounded up to 128 themselves (seal3d_hip.h), which is all a caller
-        reads whose sample path takes the device-side count — it can skip the fill."""
+        reads whose sample path takes the device-side count — it can skip the fill.
+        `aabb` (build extension, HIP backend): near_far_from_aabb(aabb, min_near[, noise_step, noise_key]) is made by the
+        marcher itself; `nears` / `fars` may then be None."""
         rays_o, rays_d = _rays(rays_o, rays_d)
         density_bitfield = _on_device(density_bitfield).contiguous()
         dev, dt = rays_o.device, rays_o.dtype
@@ -167,13 +169,22 @@ class _MarchRaysTrain(Function):
         rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
         if step_counter is None:
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        extra = {}
+        if aabb is not None:
+            nears = torch.empty(N, dtype=dt, device=dev)
+            fars = torch.empty(N, dtype=dt, device=dev)
+            extra = dict(aabb=aabb.contiguous(), min_near=min_near)
+            if perturb and noises is None and noise_step is not None:
+                noises = torch.empty(N, dtype=dt, device=dev)
+                extra.update(noise_step=noise_step, noise_key=noise_key)
         if not perturb:
             noises = torch.zeros(N, dtype=dt, device=dev)
         elif noises is None:
             noises = torch.rand(N, dtype=dt, device=dev)
 
         _backend.march_rays_train(rays_o, rays_d, density_bitfield, bound, dt_gamma, max_steps, N, C, H, M,
-                                  nears.contiguous(), fars.contiguous(), xyzs, dirs, deltas, rays, step_counter, noises)
+                                  nears.contiguous(), fars.contiguous(), xyzs, dirs, deltas, rays, step_counter, noises,
+                                  **extra)
 
         if not budgeted and trim:
             # first iterations only: one D2H read to trim the over-allocation (raymarching.py:223-231)

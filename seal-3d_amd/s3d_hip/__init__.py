@@ -294,14 +294,21 @@ class RaymarchingBackend:
 
     @staticmethod
     def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, Cc, H, M, nears, fars, xyzs, dirs,
-                         deltas, rays, counter, noises):
+                         deltas, rays, counter, noises, aabb=None, min_near=0.0, noise_step=None, noise_key=0):
+        """`aabb` (build extension): near_far_from_aabb is part of the call — nears / fars (and noises, with `noise_step`) are
+        outputs (seal3d_hip.h)"""
         _need(rays_o, torch.float32, "rays_o")
+        if aabb is not None:
+            _need(aabb, torch.float32, "aabb"); _need(nears, torch.float32, "nears"); _need(fars, torch.float32, "fars")
+        if noise_step is not None:
+            _need(noise_step, torch.int32, "noise_step")
         nbytes = lib().s3d_march_rays_train_workspace_size(_u(N), _u(max_steps))
         ws = _ws.get(nbytes, rays_o.device)
         _check(lib().s3d_march_rays_train(_p(rays_o), _p(rays_d), _p(grid), _f(bound), _f(dt_gamma), _u(max_steps),
                                           _u(N), _u(Cc), _u(H), _u(M), _p(nears), _p(fars), _p(xyzs), _p(dirs),
                                           _p(deltas), _p(rays), _p(counter), _p(noises), _p(ws),
-                                          C.c_size_t(ws.numel()), C.c_int(RaymarchingBackend._march_path), _stream()),
+                                          C.c_size_t(ws.numel()), C.c_int(RaymarchingBackend._march_path), _p(aabb),
+                                          _f(min_near), _p(noise_step), _u(int(noise_key) & 0xFFFFFFFF), _stream()),
                "march_rays_train")
 
     @staticmethod

@@ -168,6 +168,34 @@ def test_native_occupancy_sweep_against_the_torch_rule(hip):
         torch.testing.assert_close(total, ref.clamp(min=0).sum(), rtol=1e-5, atol=0)
 
 
+def test_march_rays_train_makes_near_far_and_jitter_itself(hip, march_path):
+    """build extension `aabb` of s3d_march_rays_train: near_far_from_aabb (+ the counter-based jitter) inside the marcher ==
+    the two calls in sequence, bit for bit, on both kernel paths"""
+    R = hip.RaymarchingBackend
+    _, bits = _scene(seed=0)
+    ro, rd = _rays(4096, seed=9)
+    ro, rd, bits = ro.cuda(), rd.cuda(), bits.cuda()
+    N, M = 4096, 4096 * 200
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1], device="cuda")
+    step = torch.full((1,), 11, dtype=torch.int32, device="cuda")
+
+    def buffers():
+        return (torch.zeros(M, 3, device="cuda"), torch.zeros(M, 3, device="cuda"), torch.zeros(M, 2, device="cuda"),
+                torch.empty(N, 3, dtype=torch.int32, device="cuda"), torch.zeros(2, dtype=torch.int32, device="cuda"))
+    nears, fars, noises = (torch.empty(N, device="cuda") for _ in range(3))
+    R.near_far_from_aabb(ro, rd, aabb, N, 0.2, nears, fars, noises=noises, noise_step=step, noise_key=7)
+    a = buffers()
+    R.march_rays_train(ro, rd, bits, 1.0, 0.0, 1024, N, 1, 128, M, nears, fars, *a, noises)
+    n2, f2, z2 = (torch.full((N,), float("nan"), device="cuda") for _ in range(3))
+    b = buffers()
+    R.march_rays_train(ro, rd, bits, 1.0, 0.0, 1024, N, 1, 128, M, n2, f2, *b, z2, aabb=aabb, min_near=0.2, noise_step=step,
+                       noise_key=7)
+    assert torch.equal(nears, n2) and torch.equal(fars, f2) and torch.equal(noises, z2)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert int(a[4][0]) > N
+
+
 def test_sph_from_ray(oracle, hip):
     ro, rd = _rays(2048, seed=2)
     N = ro.shape[0]
