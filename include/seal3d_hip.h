@@ -230,16 +230,23 @@ int s3d_freq_encode_backward(const float* grad, const float* outputs, uint32_t B
  * rgb_head (optional, build extension): fp32 [B, 3] = sigmoid(output[:, 0:3]) written INSTEAD of `outputs` (which may then
  * be NULL) — the colour network's `torch.sigmoid(h)` (nerf/network_ff.py:103) folded into the last layer's store, with the
  * fp16 roundings of the op sequence.  s3d_ffmlp_backward then takes grad_rgb (fp32 [B, 3], gradient w.r.t. that output)
- * and rgb_head instead of `grad`. */
+ * and rgb_head instead of `grad`.
+ * mid_* (optional, build extension; mid_color_in != NULL switches it on): the density network's head of
+ * nerf/network_ff.py:55-96 folded into the last layer — mid_sigma [B] f32 = trunc_exp(output[:, 0]), mid_color_in [B, 32] f16
+ * = [half(SH_4(mid_dirs)) | output[:, 1:16] | 0] (the colour network's input), mid_h0 [B] f16 = output[:, 0]; `outputs` may
+ * then be NULL.  s3d_ffmlp_backward takes mid_grad_sigma [B] f32 (may be NULL), mid_grad_color_in [B, 32] f16 and mid_h0
+ * instead of `grad`.  Same arithmetic and roundings as s3d_ngp_mid_forward / _backward. */
 int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                       uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                       uint32_t output_activation, uint16_t* forward_buffer, uint16_t* outputs,
-                      int input_layout, const int32_t* n_valid, float* rgb_head, s3d_stream_t stream);
+                      int input_layout, const int32_t* n_valid, float* rgb_head, const float* mid_dirs,
+                      float* mid_sigma, uint16_t* mid_color_in, uint16_t* mid_h0, s3d_stream_t stream);
 /* ffmlp.h:9: same network without storing intermediates (inference_buffer is unused scratch) */
 int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                         uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                         uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,
-                        int input_layout, const int32_t* n_valid, float* rgb_head, s3d_stream_t stream);
+                        int input_layout, const int32_t* n_valid, float* rgb_head, const float* mid_dirs,
+                      float* mid_sigma, uint16_t* mid_color_in, uint16_t* mid_h0, s3d_stream_t stream);
 /* ffmlp.h:11; grad_weights fp16 [same layout as weights]: every element is written (accumulate_grad_weights = 0,
  * the reference zero-fills it first, ffmlp.py:72) or added to (accumulate_grad_weights = 1).
  * workspace: fp32 accumulation of the weight gradient (s3d_ffmlp_backward_workspace_size).
@@ -260,6 +267,7 @@ int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
                        uint16_t* grad_inputs, uint16_t* grad_weights, void* workspace,
                        size_t workspace_bytes, int input_layout, int accumulate_grad_weights,
                        const int32_t* n_valid, float* found_inf, const float* grad_rgb, const float* rgb_head,
+                       const float* mid_grad_sigma, const uint16_t* mid_grad_color_in, const uint16_t* mid_h0,
                        s3d_stream_t stream);
 /* ffmlp.h:13-14: the reference allocates split-K side streams here; this build fuses the weight
  * gradient into the backward launch sequence on the caller's stream, so these are no-ops kept for

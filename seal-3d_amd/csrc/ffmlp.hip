@@ -21,6 +21,7 @@
 // Numerics: fp16 storage between layers, fp32 accumulate (the reference accumulates in fp16 inside
 // WMMA; parity target is the dense math of testing/test_ffmlp.py's torch twin, fp16 tolerance).
 #include "s3d_common.hpp"
+#include "sh_eval.hpp"
 
 namespace s3d {
 namespace {
@@ -162,6 +163,46 @@ __device__ __forceinline__ uint32_t native_off(uint32_t mblk, uint32_t q, uint32
     return ((mblk * 4 + q) * 32 + n) * 8 + h * 4;
 }
 
+// NGP "mid" head of the density network (nerf/network_ff.py:55-96: sigma = trunc_exp(h[:, 0]); colour-net input =
+// [half(SH_4(d)) | h[:, 1:] | 0]) folded into the MLP kernels (seal3d_hip.h: mid_* arguments of s3d_ffmlp_forward/backward).
+// Same arithmetic and rounding points as k_ngp_mid_forward / k_ngp_mid_backward (ngp_head.hip).
+struct MidFwd {
+    const float* dirs;   // [B, 3]
+    float* sigma;        // [B] out
+    _Float16* cin;       // [B, 32] out; nullptr = head off
+    _Float16* h0;        // [B] out: the pre-activation of sigma (its gradient needs exp(clamp(h0)))
+    ShNorm K;
+};
+struct MidBwd {
+    const float* g_sigma;   // [B] or nullptr
+    const _Float16* g_cin;  // [B, 32]; nullptr = head off
+    const _Float16* h0;     // [B]
+};
+constexpr uint32_t kMidRow = 40;  // halfs per row of the per-wave [32 points][32 columns] staging tile (80 B: 16-byte aligned)
+
+// output-gradient fragment of the density network from the head's gradients: output k = 0 is sigma's pre-activation, 1..15 the
+// geometry features = columns 16..30 of the colour-net input
+__device__ __forceinline__ half8 mid_grad_fragment(const MidBwd& mb, size_t row, uint32_t h) {
+    const half8 c2 = *reinterpret_cast<const half8*>(mb.g_cin + row * 32 + 16);
+    const half8 c3 = *reinterpret_cast<const half8*>(mb.g_cin + row * 32 + 24);
+    _Float16 col[16];  // col[i] = d cin[16 + i]
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++) { col[i] = c2[i]; col[8 + i] = c3[i]; }
+    half8 lo, hi;  // the fragments of the two lane halves (k = (j&3) + 8(j>>2) + 4h)
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+        const uint32_t k0 = (j & 3u) + 8u * (j >> 2), k1 = k0 + 4u;
+        lo[j] = k0 == 0 ? (_Float16)0.0f : col[k0 - 1];
+        hi[j] = col[k1 - 1];
+    }
+    half8 g = h ? hi : lo;
+    if (h == 0) {
+        const float h0 = (float)mb.h0[row];
+        g[0] = (_Float16)(mb.g_sigma ? mb.g_sigma[row] * expf(fminf(15.0f, fmaxf(-15.0f, h0))) : 0.0f);  // activation.py:13-16
+    }
+    return g;
+}
+
 // ------------------------------------------------------------------------------------ forward
 // LDS fragment directory: layer 0: MB*KS0 frags | hidden k: MB*KS frags each | last: KS frags
 template <int W, bool TRAIN, int ACT, int OACT>
@@ -169,7 +210,8 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
                                                        uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
                                                        uint32_t act, uint32_t out_act, _Float16* __restrict__ fwd,
                                                        _Float16* __restrict__ out, uint32_t in_layout,
-                                                       const int32_t* __restrict__ n_valid, float* __restrict__ rgb_head) {
+                                                       const int32_t* __restrict__ n_valid, float* __restrict__ rgb_head,
+                                                       const MidFwd mid) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     half8* frags = reinterpret_cast<half8*>(smem_raw);
@@ -178,6 +220,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
     const uint32_t n = lane & 31, h = lane >> 5;
     const uint32_t KS0 = in_dim / 16, NH = n_layers - 1;
     const uint32_t nf0 = MB * KS0, nfh = NH * MB * KS, total = nf0 + nfh + KS;
+    _Float16* Tm = reinterpret_cast<_Float16*>(frags + (size_t)total * 64) + (size_t)wave * 32 * kMidRow;  // (mid head only)
     const _Float16* w_hid = Wt + (size_t)W * in_dim;
     const _Float16* w_last = w_hid + (size_t)NH * W * W;
 
@@ -260,6 +303,40 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
         const half8* a = frags + (size_t)(nf0 + nfh) * 64;
 #pragma unroll
         for (uint32_t s = 0; s < KS; s++) o = mfma(a[s * 64 + lane], bf[s], o);
+        if (mid.cin) {
+            // density head: the lanes' output features go through a per-wave LDS tile so that every colour-net input row
+            // leaves as whole 16-byte pieces: [half(SH_4(d)) (16) | outputs 1..15 | 0]
+#pragma unroll
+            for (uint32_t q = 0; q < 2; q++)
+#pragma unroll
+                for (uint32_t e = 0; e < 4; e++) {
+                    const uint32_t f = 8 * q + 4 * h + e;  // output feature of o[4 q + e]
+                    const _Float16 v = (_Float16)act_fwd_t<OACT>(out_act, (float)(_Float16)o[4 * q + e]);
+                    if (f == 0) {
+                        mid.sigma[row] = expf((float)v);  // activation.py:8-11
+                        mid.h0[row] = v;
+                    } else {
+                        Tm[n * kMidRow + 15 + f] = v;
+                    }
+                }
+            if (h == 1) Tm[n * kMidRow + 31] = (_Float16)0.0f;
+            {
+                const float x = mid.dirs[row * 3], y = mid.dirs[row * 3 + 1], z = mid.dirs[row * 3 + 2];
+                float sh[16], j0[1], j1[1], j2[1];
+                sh_eval<4, false>(x, y, z, mid.K, sh, j0, j1, j2);
+                half8 v;
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) v[i] = (_Float16)(h ? sh[8 + i] : sh[i]);
+                *reinterpret_cast<half8*>(Tm + n * kMidRow + 8 * h) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (uint32_t c = 0; c < 2; c++)
+                *reinterpret_cast<half8*>(mid.cin + row * 32 + 8 * (2 * h + c)) =
+                    *reinterpret_cast<const half8*>(Tm + n * kMidRow + 8 * (2 * h + c));
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         if (rgb_head) {
             // colour head (network_ff.py:103 `torch.sigmoid(h)` on the fp16 output, then compositing in fp32): outputs 0..2 go
             // out as fp32 sigmoid values, rounded where the fp16 op sequence rounds — the [B, 16] fp16 tensor never exists
@@ -616,7 +693,8 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
                                                              uint32_t out_dim, uint32_t act, _Float16* __restrict__ grad_inputs,
                                                              float* __restrict__ partial, uint32_t in_layout,
                                                              const int32_t* __restrict__ n_valid,
-                                                             const float* __restrict__ d_rgb, const float* __restrict__ rgb_head) {
+                                                             const float* __restrict__ d_rgb, const float* __restrict__ rgb_head,
+                                                             const MidBwd midb) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -706,6 +784,8 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
                     gf[c] = (_Float16)((float)(_Float16)d_rgb[row * 3 + c] * (y * (1.0f - y)));
                 }
             }
+        } else if (midb.g_cin) {
+            gf = mid_grad_fragment(midb, row, h);
         } else {
             gf = load_bfrag_rowmajor(grad + row * 16, 0, h);
         }
@@ -886,7 +966,8 @@ __global__ void __launch_bounds__(512) k_ffmlp_backward_duo(const _Float16* __re
                                                             uint32_t out_dim, uint32_t act, _Float16* __restrict__ grad_inputs,
                                                             float* __restrict__ partial, uint32_t in_layout,
                                                             const int32_t* __restrict__ n_valid,
-                                                            const float* __restrict__ d_rgb, const float* __restrict__ rgb_head) {
+                                                            const float* __restrict__ d_rgb, const float* __restrict__ rgb_head,
+                                                            const MidBwd midb) {
     constexpr uint32_t MB = W / 32, KS = W / 16, NS = NH + 2;  // NS stages per tile: last | hidden NH..1 | first
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const uint32_t lane = threadIdx.x & 63;
@@ -977,6 +1058,8 @@ __global__ void __launch_bounds__(512) k_ffmlp_backward_duo(const _Float16* __re
                             gf[c] = (_Float16)((float)(_Float16)d_rgb[row * 3 + c] * (y * (1.0f - y)));
                         }
                     }
+                } else if (midb.g_cin) {
+                    gf = mid_grad_fragment(midb, row, h);
                 } else {
                     gf = load_bfrag_rowmajor(grad + row * 16, 0, h);
                 }
@@ -1179,6 +1262,8 @@ static thread_local float* t_found_inf = nullptr;  // s3d_ffmlp_backward(found_i
 static thread_local float* t_rgb_out = nullptr;          // colour head of the forward call being served (fp32 [B, 3] out)
 static thread_local const float* t_d_rgb = nullptr;      // ... of the backward call: gradient w.r.t. the head's output
 static thread_local const float* t_rgb_in = nullptr;     // ... and the head's output
+static thread_local MidFwd t_mid_fwd = {};               // density ("mid") head of the forward call being served
+static thread_local MidBwd t_mid_bwd = {};               // ... of the backward call
 struct RowLimitScope {
     explicit RowLimitScope(const int32_t* p, float* found_inf = nullptr) { t_n_valid = p; t_found_inf = found_inf; }
     ~RowLimitScope() { t_n_valid = nullptr; t_found_inf = nullptr; }
@@ -1198,11 +1283,11 @@ int launch_forward(const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t i
                    uint32_t act, uint32_t out_act, _Float16* fwd, _Float16* out, uint32_t in_layout, hipStream_t st) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
     const uint32_t nfr = MB * (in_dim / 16) + (n_layers - 1) * MB * KS + KS;
-    const size_t smem = (size_t)nfr * 64 * sizeof(half8);
+    const size_t smem = (size_t)nfr * 64 * sizeof(half8) + (t_mid_fwd.cin ? (size_t)4 * 32 * kMidRow * sizeof(_Float16) : 0);
     const uint32_t ntiles = B / 32;
     uint32_t grid = div_up<uint32_t>(ntiles, 4);
     if (grid > 1024) grid = 1024;
-#define S3D_FWD(TRAIN, A, O) hipLaunchKernelGGL((k_ffmlp_forward<W, TRAIN, A, O>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out, in_layout, t_n_valid, t_rgb_out)
+#define S3D_FWD(TRAIN, A, O) hipLaunchKernelGGL((k_ffmlp_forward<W, TRAIN, A, O>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out, in_layout, t_n_valid, t_rgb_out, t_mid_fwd)
     const bool fast = act == ACT_RELU && out_act == ACT_NONE;  // the networks of the hot path; anything else: run-time switch
     if (fwd) { if (fast) S3D_FWD(true, ACT_RELU, ACT_NONE); else S3D_FWD(true, -1, -1); }
     else { if (fast) S3D_FWD(false, ACT_RELU, ACT_NONE); else S3D_FWD(false, -1, -1); }
@@ -1282,10 +1367,10 @@ int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Floa
     if (nblk > kWgradBlocks) nblk = kWgradBlocks;
     if (duo)
         hipLaunchKernelGGL((k_ffmlp_backward_duo<W, NH, IMB, ACT, KS0T>), dim3(nblk), dim3(512), smem, st, grad, X, Wt, B, in_dim,
-                           out_dim, act, grad_inputs, partial, in_layout, t_n_valid, t_d_rgb, t_rgb_in);
+                           out_dim, act, grad_inputs, partial, in_layout, t_n_valid, t_d_rgb, t_rgb_in, t_mid_bwd);
     else
         hipLaunchKernelGGL((k_ffmlp_backward_fused<W, NH, IMB, ACT, KS0T>), dim3(nblk), dim3(256), smem, st, grad, X, Wt, B, in_dim,
-                           out_dim, act, grad_inputs, partial, in_layout, t_n_valid, t_d_rgb, t_rgb_in);
+                           out_dim, act, grad_inputs, partial, in_layout, t_n_valid, t_d_rgb, t_rgb_in, t_mid_bwd);
     WgradPlan plan;
     memset(&plan, 0, sizeof(plan));
     plan.n = NH + 2;
@@ -1332,11 +1417,24 @@ using namespace s3d;
 S3D_EXPORT int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                                  uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                                  uint32_t output_activation, uint16_t* forward_buffer, uint16_t* outputs,
-                                 int input_layout, const int32_t* n_valid, float* rgb_head, s3d_stream_t stream) {
+                                 int input_layout, const int32_t* n_valid, float* rgb_head, const float* mid_dirs,
+                                 float* mid_sigma, uint16_t* mid_color_in, uint16_t* mid_h0, s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     const RowLimitScope rows(n_valid);
-    struct HeadScope { explicit HeadScope(float* p) { t_rgb_out = p; } ~HeadScope() { t_rgb_out = nullptr; } } head(rgb_head);
-    S3D_REQUIRE(inputs && weights && (outputs || rgb_head), "ffmlp_forward: null pointer");
+    struct HeadScope {
+        HeadScope(float* p, const float* d, float* s, uint16_t* c, uint16_t* h0) {
+            t_rgb_out = p;
+            t_mid_fwd = MidFwd{};
+            if (c) {
+                t_mid_fwd.dirs = d; t_mid_fwd.sigma = s; t_mid_fwd.cin = (_Float16*)c; t_mid_fwd.h0 = (_Float16*)h0;
+                host_sh_norm(4, t_mid_fwd.K);
+            }
+        }
+        ~HeadScope() { t_rgb_out = nullptr; t_mid_fwd = MidFwd{}; }
+    } head(rgb_head, mid_dirs, mid_sigma, mid_color_in, mid_h0);
+    S3D_REQUIRE(!mid_color_in || (mid_dirs && mid_sigma && mid_h0 && !rgb_head && output_dim == 16),
+                "ffmlp_forward: the density head needs dirs, sigma, color_in and h0 (and no colour head)");
+    S3D_REQUIRE(inputs && weights && (outputs || rgb_head || mid_color_in), "ffmlp_forward: null pointer");
     S3D_REQUIRE(!rgb_head || output_dim >= 3, "ffmlp_forward: the colour head reads outputs 0..2");
     S3D_REQUIRE(input_layout == 0 || input_layout == 1, "ffmlp_forward: input_layout must be 0 (row-major) or 1 (level-major [in/2][B][2])");
     if (int rc = check_shape(B, input_dim, output_dim, hidden_dim, num_layers)) return rc;
@@ -1350,10 +1448,12 @@ S3D_EXPORT int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights
 S3D_EXPORT int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                                    uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                                    uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,
-                                   int input_layout, const int32_t* n_valid, float* rgb_head, s3d_stream_t stream) {
+                                   int input_layout, const int32_t* n_valid, float* rgb_head, const float* mid_dirs,
+                                   float* mid_sigma, uint16_t* mid_color_in, uint16_t* mid_h0, s3d_stream_t stream) {
     (void)inference_buffer;
     return s3d_ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                             output_activation, nullptr, outputs, input_layout, n_valid, rgb_head, stream);
+                             output_activation, nullptr, outputs, input_layout, n_valid, rgb_head, mid_dirs, mid_sigma,
+                             mid_color_in, mid_h0, stream);
 }
 
 S3D_EXPORT size_t s3d_ffmlp_backward_workspace_size(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
@@ -1368,20 +1468,26 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
                                   uint32_t output_activation, int calc_grad_inputs, uint16_t* backward_buffer,
                                   uint16_t* grad_inputs, uint16_t* grad_weights, void* workspace, size_t workspace_bytes,
                                   int input_layout, int accumulate_grad_weights, const int32_t* n_valid, float* found_inf,
-                                  const float* grad_rgb, const float* rgb_head, s3d_stream_t stream) {
+                                  const float* grad_rgb, const float* rgb_head, const float* mid_grad_sigma,
+                                  const uint16_t* mid_grad_color_in, const uint16_t* mid_h0, s3d_stream_t stream) {
     (void)output_activation;
     const RowLimitScope rows(n_valid, found_inf);
     struct HeadScope {
-        HeadScope(const float* g, const float* y) { t_d_rgb = g; t_rgb_in = y; }
-        ~HeadScope() { t_d_rgb = nullptr; t_rgb_in = nullptr; }
-    } head(grad_rgb, rgb_head);
+        HeadScope(const float* g, const float* y, const float* gs, const uint16_t* gc, const uint16_t* h0) {
+            t_d_rgb = g; t_rgb_in = y;
+            t_mid_bwd = MidBwd{gs, (const _Float16*)gc, (const _Float16*)h0};
+        }
+        ~HeadScope() { t_d_rgb = nullptr; t_rgb_in = nullptr; t_mid_bwd = MidBwd{}; }
+    } head(grad_rgb, rgb_head, mid_grad_sigma, mid_grad_color_in, mid_h0);
+    S3D_REQUIRE(!mid_grad_color_in || (mid_h0 && !forward_buffer && !grad_rgb && output_dim == 16),
+                "ffmlp_backward: the density head needs grad_color_in and h0 and is implemented by the fused backward");
     S3D_REQUIRE((grad_rgb == nullptr) == (rgb_head == nullptr), "ffmlp_backward: the colour head needs both grad_rgb and rgb_head");
     S3D_REQUIRE(!grad_rgb || (!forward_buffer && output_dim >= 3), "ffmlp_backward: the colour head is implemented by the fused backward");
     const uint32_t accumulate = accumulate_grad_weights ? 1u : 0u;
     S3D_REQUIRE(input_layout == 0 || (input_layout == 1 && !forward_buffer),
                 "ffmlp_backward: the level-major input layout is implemented by the fused backward (no forward_buffer)");
     if (B == 0) return S3D_OK;
-    S3D_REQUIRE((grad || grad_rgb) && inputs && weights && grad_weights, "ffmlp_backward: null pointer");
+    S3D_REQUIRE((grad || grad_rgb || mid_grad_color_in) && inputs && weights && grad_weights, "ffmlp_backward: null pointer");
     S3D_REQUIRE((forward_buffer == nullptr) == (backward_buffer == nullptr),
                 "ffmlp_backward: pass both forward_buffer and backward_buffer, or neither (fused re-computing backward)");
     if (int rc = check_shape(B, input_dim, output_dim, hidden_dim, num_layers)) return rc;

@@ -140,6 +140,63 @@ class _FFMLPForward(Function):
 ffmlp_forward = _FFMLPForward.apply
 
 
+class _FFMLPNgpMid(Function):
+    """The density network of nerf/network_ff.py with its head (seal3d_hip.h: mid_* of s3d_ffmlp_forward / _backward):
+    (encoder output, dirs) -> sigma f32 [B] = trunc_exp(h[:, 0]), colour-net input f16 [B, 32] = [half(SH_4(d)) | h[:, 1:] | 0]
+    from ONE launch per direction; the [B, 16] output h and its gradient never exist."""
+
+    @staticmethod
+    def forward(ctx, inputs, weights, dirs, dims, inference, param_ref, hook, input_layout, n_valid):
+        input_dim, hidden_dim, num_layers, activation, output_activation = dims
+        B = inputs.shape[1] if input_layout else inputs.shape[0]
+        inputs = inputs.to(torch.half).contiguous()
+        weights = weights.to(torch.half).contiguous()
+        dirs = dirs.float().contiguous()
+        sigma = torch.empty(B, device=inputs.device, dtype=torch.float32)
+        cin = torch.empty(B, 32, device=inputs.device, dtype=torch.half)
+        h0 = torch.empty(B, device=inputs.device, dtype=torch.half)
+        extra = {}
+        if input_layout:
+            extra["input_layout"] = input_layout
+        if n_valid is not None:
+            extra["n_valid"] = n_valid
+        fn = _backend.ffmlp_inference if inference else _backend.ffmlp_forward
+        fn(inputs, weights, B, input_dim, 16, hidden_dim, num_layers, activation, output_activation, None, None,
+           mid=(dirs, sigma, cin, h0), **extra)
+        if not inference:
+            ctx.save_for_backward(inputs, weights, h0)
+            ctx.dims, ctx.extra, ctx.param_ref = dims, extra, param_ref
+            ctx.calc_grad_inputs = inputs.requires_grad
+            ctx.set_materialize_grads(False)
+        return sigma, cin
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_cin):
+        inputs, weights, h0 = ctx.saved_tensors
+        input_dim, hidden_dim, num_layers, activation, output_activation = ctx.dims
+        B = h0.shape[0]
+        if g_cin is None:
+            g_cin = torch.zeros(B, 32, dtype=torch.half, device=h0.device)
+        g_cin = g_cin.to(torch.half).contiguous()
+        g_sigma = None if g_sigma is None else g_sigma.float().contiguous()
+        calc = ctx.calc_grad_inputs
+        grad_inputs = torch.empty_like(inputs) if calc else torch.zeros(1, device=h0.device, dtype=inputs.dtype)
+        stash = getattr(ctx.param_ref.param, "_s3d_grad", None) if ctx.param_ref is not None else None
+        grad_weights = stash.view(weights.shape) if stash is not None else torch.empty_like(weights)
+        extra = dict(ctx.extra)
+        if stash is not None:
+            extra["accumulate"] = True
+            found_inf = getattr(ctx.param_ref.param, "_s3d_found_inf", None)
+            if found_inf is not None:
+                extra["found_inf"] = found_inf
+        _backend.ffmlp_backward(None, inputs, weights, None, B, input_dim, 16, hidden_dim, num_layers, activation,
+                                output_activation, calc, None, grad_inputs, grad_weights, mid=(g_sigma, g_cin, h0), **extra)
+        if stash is not None:
+            ctx.param_ref.param._s3d_grad_touched = True
+            grad_weights = None
+        return ((grad_inputs if calc else None), grad_weights) + (None,) * 7
+
+
 class FFMLP(nn.Module):
     """ffmlp.py:99-169"""
 
@@ -189,6 +246,20 @@ class FFMLP(nn.Module):
         return (self.output_dim >= 3 and _FUSED_BACKWARD and getattr(_backend, "fused_backward_supported", None) is not None
                 and _backend.fused_backward_supported(self.input_dim, self.padded_output_dim, self.hidden_dim, self.num_layers,
                                                       self.activation))
+
+    def forward_ngp_mid(self, inputs, dirs, level_major=False, n_valid=None):
+        """density network + head (see _FFMLPNgpMid): returns (sigma f32 [B], colour-net input f16 [B, 32])"""
+        B = inputs.shape[1] if level_major else inputs.shape[0]
+        if B % 128 != 0 or self.padded_output_dim != 16:
+            raise RuntimeError("FFMLP.forward_ngp_mid: needs B % 128 == 0 and a 16-column output")
+        w, ref, hook = self.weights, None, None
+        if getattr(w, "_s3d_grad", None) is not None and getattr(w, "_s3d_half_version", None) == w._version:
+            if torch.is_grad_enabled() and w.requires_grad:
+                ref = _ParamRef(w)
+                hook = self._autograd_hook
+            w = w._s3d_half
+        dims = (self.input_dim, self.hidden_dim, self.num_layers, self.activation, self.output_activation)
+        return _FFMLPNgpMid.apply(inputs, w, dirs, dims, not self.training, ref, hook, 1 if level_major else 0, n_valid)
 
     def forward_rgb(self, inputs, n_valid=None):
         """the colour network with its head: fp32 [B, 3] = sigmoid(net(inputs)[:, :3]) from ONE launch (B % 128 == 0)"""

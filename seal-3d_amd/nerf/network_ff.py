@@ -88,6 +88,7 @@ class NeRFNetwork(NeRFRenderer):
         return torch.sigmoid(self.color_net(torch.cat([d, geo_feat, pad], dim=-1)))
 
     fused_head = os.environ.get("S3D_FUSED_HEAD", "1") != "0"  # tests / A-B runs: False = the reference op sequence
+    fused_mid = os.environ.get("S3D_FUSED_MID", "1") != "0"    # A-B runs: False = separate mid kernels between the two MLPs
 
     def honours_row_limit(self, rows):
         return self._can_fuse_on(self.density_bitfield.is_cuda) and rows > 0 and rows % 128 == 0
@@ -111,9 +112,13 @@ class NeRFNetwork(NeRFRenderer):
                 nv = s3d_hip.active_row_limit(x.shape[0])  # (training: the march's sample count; inference: alive rays x n_step)
                 # inference loop: unused sample slots (deltas == 0, announced by the renderer) skip the table gathers
                 live = None if (self.training or torch.is_grad_enabled()) else s3d_hip.active_live_rows(x.shape[0])
-                h = self.sigma_net.forward_padded(self.encoder(x, bound=self.bound, level_major=True, n_valid=nv, live=live),
-                                                  level_major=True, n_valid=nv)
-                sigma, cin = _NgpMid.apply(h.contiguous(), d.float().contiguous(), nv)
+                enc = self.encoder(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
+                if self.fused_mid and self.sigma_net.rgb_head_supported():  # (same shape condition: the fused backward kernel)
+                    # trunc_exp / SH / concat folded into the density network's last layer (and its backward's first load)
+                    sigma, cin = self.sigma_net.forward_ngp_mid(enc, d, level_major=True, n_valid=nv)
+                else:
+                    h = self.sigma_net.forward_padded(enc, level_major=True, n_valid=nv)
+                    sigma, cin = _NgpMid.apply(h.contiguous(), d.float().contiguous(), nv)
                 if self.color_net.rgb_head_supported():  # sigmoid + fp32 hand-over inside the last layer's store
                     return sigma, self.color_net.forward_rgb(cin, n_valid=nv)
                 return sigma, _NgpRgb.apply(self.color_net.forward_padded(cin, n_valid=nv).contiguous(), nv)

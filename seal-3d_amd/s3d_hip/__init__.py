@@ -499,19 +499,20 @@ class FFMLPBackend:
 
     @staticmethod
     def ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                      output_activation, forward_buffer, outputs, input_layout=0, n_valid=None, rgb_head=None):
+                      output_activation, forward_buffer, outputs, input_layout=0, n_valid=None, rgb_head=None, mid=None):
+        """`mid` = (dirs f32 [B,3], sigma f32 [B], color_in f16 [B,32], h0 f16 [B]): the density head (seal3d_hip.h)"""
         _need(inputs, torch.float16, "inputs")
         _need(weights, torch.float16, "weights")
         if rgb_head is not None:
             _need(rgb_head, torch.float32, "rgb_head")
         _check(lib().s3d_ffmlp_forward(_p(inputs), _p(weights), _u(B), _u(input_dim), _u(output_dim), _u(hidden_dim),
                                        _u(num_layers), _u(activation), _u(output_activation), _p(forward_buffer),
-                                       _p(outputs), C.c_int(int(input_layout)), _nv(n_valid), _p(rgb_head), _stream()),
-               "ffmlp_forward")
+                                       _p(outputs), C.c_int(int(input_layout)), _nv(n_valid), _p(rgb_head), *_mid_fwd_args(mid, B),
+                                       _stream()), "ffmlp_forward")
 
     @staticmethod
     def ffmlp_inference(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
-                        output_activation, inference_buffer, outputs, input_layout=0, n_valid=None, rgb_head=None):
+                        output_activation, inference_buffer, outputs, input_layout=0, n_valid=None, rgb_head=None, mid=None):
         _need(inputs, torch.float16, "inputs")
         _need(weights, torch.float16, "weights")
         if rgb_head is not None:
@@ -519,7 +520,7 @@ class FFMLPBackend:
         _check(lib().s3d_ffmlp_inference(_p(inputs), _p(weights), _u(B), _u(input_dim), _u(output_dim),
                                          _u(hidden_dim), _u(num_layers), _u(activation), _u(output_activation),
                                          _p(inference_buffer), _p(outputs), C.c_int(int(input_layout)), _nv(n_valid),
-                                         _p(rgb_head), _stream()), "ffmlp_inference")
+                                         _p(rgb_head), *_mid_fwd_args(mid, B), _stream()), "ffmlp_inference")
 
     @staticmethod
     def fused_backward_supported(input_dim, output_dim, hidden_dim, num_layers, activation):
@@ -530,10 +531,12 @@ class FFMLPBackend:
     @staticmethod
     def ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers,
                        activation, output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights,
-                       input_layout=0, accumulate=False, n_valid=None, found_inf=None, grad_rgb=None, rgb_head=None):
+                       input_layout=0, accumulate=False, n_valid=None, found_inf=None, grad_rgb=None, rgb_head=None, mid=None):
+        """`mid` = (grad_sigma f32 [B] or None, grad_color_in f16 [B,32], h0 f16 [B]): the density head's gradients instead of
+        `grad` (seal3d_hip.h)"""
         if grad_rgb is not None:
             _need(grad_rgb, torch.float32, "grad_rgb"); _need(rgb_head, torch.float32, "rgb_head")
-        else:
+        elif mid is None:
             _need(grad, torch.float16, "grad")
         if found_inf is not None:
             _need(found_inf, torch.float32, "found_inf")
@@ -546,7 +549,31 @@ class FFMLPBackend:
                                         _p(backward_buffer), _p(grad_inputs if calc_grad_inputs else None),
                                         _p(grad_weights), _p(ws), C.c_size_t(ws.numel()), C.c_int(int(input_layout)),
                                         C.c_int(int(bool(accumulate))), _nv(n_valid), _p(found_inf), _p(grad_rgb), _p(rgb_head),
-                                        _stream()), "ffmlp_backward")
+                                        *_mid_bwd_args(mid, B), _stream()), "ffmlp_backward")
+
+
+def _mid_fwd_args(mid, B):
+    """the four density-head arguments of s3d_ffmlp_forward / _inference from (dirs, sigma, color_in, h0) or None"""
+    if mid is None:
+        return (C.c_void_p(0),) * 4
+    dirs, sigma, cin, h0 = mid
+    _need(dirs, torch.float32, "mid dirs"); _need(sigma, torch.float32, "mid sigma")
+    _need(cin, torch.float16, "mid color_in"); _need(h0, torch.float16, "mid h0")
+    if dirs.numel() != 3 * B or sigma.numel() != B or cin.numel() != 32 * B or h0.numel() != B:
+        raise RuntimeError("ffmlp density head: dirs [B,3], sigma [B], color_in [B,32], h0 [B]")
+    return _p(dirs), _p(sigma), _p(cin), _p(h0)
+
+
+def _mid_bwd_args(mid, B):
+    """the three density-head arguments of s3d_ffmlp_backward from (grad_sigma or None, grad_color_in, h0) or None"""
+    if mid is None:
+        return (C.c_void_p(0),) * 3
+    if mid[0] is not None:
+        _need(mid[0], torch.float32, "mid grad_sigma")
+    _need(mid[1], torch.float16, "mid grad_color_in"); _need(mid[2], torch.float16, "mid h0")
+    if mid[1].numel() != 32 * B or mid[2].numel() != B or (mid[0] is not None and mid[0].numel() != B):
+        raise RuntimeError("ffmlp density head: grad_sigma [B], grad_color_in [B,32], h0 [B]")
+    return _p(mid[0]), _p(mid[1]), _p(mid[2])
 
 
 class _AdamTensor(C.Structure):

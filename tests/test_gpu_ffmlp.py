@@ -170,3 +170,44 @@ def test_colour_head_in_the_last_layer_is_the_two_kernel_sequence_bit_for_bit(hi
             a = net.forward_rgb(x0, n_valid=nv)[:rows]
             b = _NgpRgb.apply(net.forward_padded(x0, n_valid=nv).contiguous(), nv)[:rows]
         assert torch.equal(a, b) and torch.equal(a, res[0][0])
+
+
+@pytest.mark.parametrize("B", [128, 128 * 700])
+def test_density_head_in_the_mlp_kernels_is_the_mid_kernel_sequence_bit_for_bit(hip, B):
+    """FFMLP.forward_ngp_mid (seal3d_hip.h: mid_*) == forward_padded + k_ngp_mid_forward / _backward of nerf/network_ff.py:
+    sigma, colour-net input, weight gradient and input gradient; training and inference; with a device row count."""
+    from ffmlp import FFMLP
+    from nerf.network_ff import _NgpMid
+    torch.manual_seed(7)
+    net = FFMLP(32, 16, 64, 2).cuda()
+    x0 = torch.randn(16, B, 2, device="cuda").half()  # level-major encoder output
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device="cuda"), dim=-1)
+    gs, gc = torch.randn(B, device="cuda"), (torch.randn(B, 32, device="cuda") * 0.1).half()
+    for nv in (None, torch.tensor([max(B - 300, 77)], dtype=torch.int32, device="cuda")):
+        rows = B if nv is None else min(B, (int(nv) + 127) // 128 * 128)
+        res = []
+        for fused in (False, True):
+            net.train()
+            net.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.float16):
+                if fused:
+                    sigma, cin = net.forward_ngp_mid(x, d, level_major=True, n_valid=nv)
+                else:
+                    sigma, cin = _NgpMid.apply(net.forward_padded(x, level_major=True, n_valid=nv).contiguous(), d, nv)
+            ((sigma[:rows] * gs[:rows]).sum() + (cin[:rows].float() * gc[:rows].float()).sum()).backward()
+            res.append((sigma.detach()[:rows].clone(), cin.detach()[:rows].clone(), net.weights.grad.clone(),
+                        x.grad[:, :rows].clone()))
+        (s_a, c_a, w_a, x_a), (s_b, c_b, w_b, x_b) = res
+        assert torch.equal(s_a, s_b) and torch.equal(w_a, w_b) and torch.equal(x_a, x_b)
+        assert torch.equal(c_a[:, 16:], c_b[:, 16:])  # geometry features + zero pad: bit for bit
+        # SH columns: the same sh_eval source inlined into two kernels; hipcc associates `K * T * cos` differently in the two
+        # (fp32 results one ulp apart), which flips the fp16 rounding of a few values per 10^5
+        sh_a, sh_b = c_a[:, :16].float(), c_b[:, :16].float()
+        assert float((sh_a != sh_b).float().mean()) < 1e-4
+        torch.testing.assert_close(sh_a, sh_b, rtol=1.0 / 1024, atol=2.0 ** -24)
+        assert float(w_a.abs().max()) > 0 and float(sh_a.abs().max()) > 0
+        net.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            s1, c1 = net.forward_ngp_mid(x0, d, level_major=True, n_valid=nv)
+        assert torch.equal(s1[:rows], s_b) and torch.equal(c1[:rows], c_b)
