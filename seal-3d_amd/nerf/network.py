@@ -120,6 +120,9 @@ class NeRFNetwork(NeRFRenderer):
             return h
         e1 = self.encoder_color(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
         sigma, cin = _SealMid.apply(h.contiguous(), d.float().contiguous(), e1.contiguous(), nv)
+        if cin.shape[0] % 128 == 0 and (infer or s3d_hip.FFMLPBackend.fused_backward_supported(64, 16, 64, 2, 0)):
+            # colour head inside the MLP kernels (seal3d_hip.h: rgb_head): fp32 sigmoid(out[:, :3]) straight from the last layer
+            return sigma, ffmlp_forward(cin, wc, 64, 16, 64, 2, 0, 6, infer, cin.requires_grad, None, None, 0, nv, True)
         out = ffmlp_forward(cin, wc, 64, 16, 64, 2, 0, 6, infer, cin.requires_grad, None, None, 0, nv)
         return sigma, _NgpRgb.apply(out.contiguous(), nv)
 
