@@ -321,9 +321,12 @@ int s3d_ngp_rgb_forward(const uint16_t* out, uint32_t B, float* rgb, const int32
 int s3d_ngp_rgb_backward(const float* grad_rgb, const float* rgb, uint32_t B, uint16_t* grad_out,
                          const int32_t* n_valid, s3d_stream_t stream);
 /* Loss head of one ray batch: loss = mean((image + (1 - weights_sum) * bg - gt)^2)  (nerf/renderer.py:316 background
- * compositing + nerf/utils.py:484 MSE); bg_rgb = 3 HOST floats; loss / grad_loss are single device floats. */
+ * compositing + nerf/utils.py:484 MSE); bg_rgb = 3 HOST floats; loss / grad_loss are single device floats.
+ * s3d_bg_mse_forward with grad_loss != NULL also writes what s3d_bg_mse_backward would for that upstream gradient (under
+ * loss scaling the loss's upstream gradient is the scale, known before the backward pass): one launch instead of two. */
 int s3d_bg_mse_forward(const float* image, const float* weights_sum, const float* gt, const float* bg_rgb, uint32_t N,
-                       float* loss, s3d_stream_t stream);
+                       float* loss, const float* grad_loss, float* grad_image, float* grad_weights_sum,
+                       s3d_stream_t stream);
 int s3d_bg_mse_backward(const float* image, const float* weights_sum, const float* gt, const float* bg_rgb, uint32_t N,
                         const float* grad_loss, float* grad_image, float* grad_weights_sum, s3d_stream_t stream);
 

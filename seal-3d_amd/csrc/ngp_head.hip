@@ -155,17 +155,28 @@ __global__ void __launch_bounds__(256) k_ngp_rgb_backward(const float* __restric
 // reduction (deterministic); N is a ray batch (4,096), not a sample batch.
 __global__ void __launch_bounds__(1024) k_bg_mse_forward(const float* __restrict__ image, const float* __restrict__ ws,
                                                          const float* __restrict__ gt, float bg0, float bg1, float bg2, uint32_t N,
-                                                         float* __restrict__ loss) {
+                                                         float* __restrict__ loss, const float* __restrict__ grad_loss,
+                                                         float* __restrict__ grad_image, float* __restrict__ grad_ws) {
     __shared__ float part[16];
     const float bg[3] = {bg0, bg1, bg2};
+    // grad_loss given: the gradient the backward kernel would write for that upstream gradient is written here as well
+    // (same formula, same order: bit-identical) — under loss scaling the upstream gradient of the loss is known in advance
+    const float k = grad_loss ? *grad_loss * (2.0f / (3.0f * (float)N)) : 0.0f;
     float acc = 0.0f;
     for (uint32_t n = threadIdx.x; n < N; n += 1024) {
         const float w = 1.0f - ws[n];
+        float gw = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const float d = (image[(size_t)n * 3 + c] + w * bg[c]) - gt[(size_t)n * 3 + c];
             acc += d * d;
+            if (grad_loss) {
+                const float gd = k * d;
+                grad_image[(size_t)n * 3 + c] = gd;
+                gw -= gd * bg[c];
+            }
         }
+        if (grad_loss) grad_ws[n] = gw;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
@@ -203,10 +214,12 @@ __global__ void __launch_bounds__(256) k_bg_mse_backward(const float* __restrict
 using namespace s3d;
 
 S3D_EXPORT int s3d_bg_mse_forward(const float* image, const float* weights_sum, const float* gt, const float* bg_rgb, uint32_t N,
-                                  float* loss, s3d_stream_t stream) {
+                                  float* loss, const float* grad_loss, float* grad_image, float* grad_weights_sum,
+                                  s3d_stream_t stream) {
     S3D_REQUIRE(image && weights_sum && gt && bg_rgb && loss && N > 0, "bg_mse_forward: null pointer / empty batch");
+    S3D_REQUIRE(!grad_loss || (grad_image && grad_weights_sum), "bg_mse_forward: grad_loss needs grad_image and grad_weights_sum");
     hipLaunchKernelGGL(k_bg_mse_forward, dim3(1), dim3(1024), 0, as_stream(stream), image, weights_sum, gt, bg_rgb[0], bg_rgb[1],
-                       bg_rgb[2], N, loss);
+                       bg_rgb[2], N, loss, grad_loss, grad_image, grad_weights_sum);
     return check_launch("bg_mse_forward");
 }
 

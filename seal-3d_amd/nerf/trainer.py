@@ -19,11 +19,19 @@ class _BgMse(torch.autograd.Function):
     criterion (nerf/utils.py:484) in one kernel per direction (csrc/ngp_head.hip) instead of ~14 tiny launches."""
 
     @staticmethod
-    def forward(ctx, image, weights_sum, gt, bg):
+    def forward(ctx, image, weights_sum, gt, bg, expected_grad=None):
+        """`expected_grad`: the (device scalar) upstream gradient the loss WILL receive — the loss scale under GradScaler; the
+        forward launch then writes the backward's result as well and backward() launches nothing when it is handed that tensor"""
         import s3d_hip
         image, weights_sum, gt = image.float().contiguous(), weights_sum.float().contiguous(), gt.float().contiguous()
         loss = torch.empty((), dtype=torch.float32, device=image.device)
-        s3d_hip.NgpHeadBackend.bg_mse_forward(image, weights_sum, gt, bg, loss)
+        ctx.pre = None
+        if expected_grad is not None and expected_grad.dtype == torch.float32 and expected_grad.numel() == 1:
+            g_image, g_ws = torch.empty_like(image), torch.empty_like(weights_sum)
+            s3d_hip.NgpHeadBackend.bg_mse_forward(image, weights_sum, gt, bg, loss, expected_grad, g_image, g_ws)
+            ctx.pre = (g_image, g_ws, expected_grad.data_ptr(), expected_grad._version)
+        else:
+            s3d_hip.NgpHeadBackend.bg_mse_forward(image, weights_sum, gt, bg, loss)
         ctx.save_for_backward(image, weights_sum, gt)
         ctx.bg = bg
         return loss
@@ -31,18 +39,21 @@ class _BgMse(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         import s3d_hip
+        if ctx.pre is not None and g.dtype == torch.float32 and g.data_ptr() == ctx.pre[2] and g._version == ctx.pre[3]:
+            return ctx.pre[0], ctx.pre[1], None, None, None  # (the announced upstream gradient: already computed)
         image, weights_sum, gt = ctx.saved_tensors
         g_image, g_ws = torch.empty_like(image), torch.empty_like(weights_sum)
         s3d_hip.NgpHeadBackend.bg_mse_backward(image, weights_sum, gt, ctx.bg, g.float().contiguous(), g_image, g_ws)
-        return g_image, g_ws, None, None
+        return g_image, g_ws, None, None, None
 
 
-def render_loss(out, gt_rgb):
-    """MSE between the rendered batch and the targets; uses the fused kernel when the renderer deferred the background"""
+def render_loss(out, gt_rgb, expected_grad=None):
+    """MSE between the rendered batch and the targets; uses the fused kernel when the renderer deferred the background
+    (`expected_grad`: see _BgMse.forward)"""
     if out.get("premultiplied", False):
         bg = out["bg_color"]
         bg = (float(bg),) * 3 if not isinstance(bg, (tuple, list)) else tuple(float(v) for v in bg)
-        return _BgMse.apply(out["image"].reshape(-1, 3), out["weights_sum"].reshape(-1), gt_rgb.reshape(-1, 3), bg)
+        return _BgMse.apply(out["image"].reshape(-1, 3), out["weights_sum"].reshape(-1), gt_rgb.reshape(-1, 3), bg, expected_grad)
     return F.mse_loss(out["image"], gt_rgb)
 
 
@@ -123,7 +134,7 @@ class Trainer:
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             out = model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False,
                                defer_background=self.native_optim, **self.render_kwargs)
-            loss = render_loss(out, gt_rgb)
+            loss = render_loss(out, gt_rgb, self._expected_grad())
         self._backward(loss)
         self._reduce_and_step()
         return loss.detach()
@@ -138,6 +149,11 @@ class Trainer:
                 self.dist.allreduce_grads(self.scaler)
             self.scaler.step(self.optimizer)
         self.scaler.update()
+
+    def _expected_grad(self):
+        """the upstream gradient `_backward` will hand to the loss (NativeGradScaler: its scale tensor), if known in advance"""
+        sc = self.scaler
+        return sc._scale.reshape(()) if (hasattr(sc, "backward") and getattr(sc, "enabled", False)) else None
 
     def _backward(self, loss):
         if hasattr(self.scaler, "backward"):  # NativeGradScaler: the scale is passed as the root gradient
@@ -208,7 +224,7 @@ class GraphedTrainer(Trainer):
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             out = self.model.render(self.s_ro, self.s_rd, bg_color=1, perturb=True, force_all_rays=False,
                                     defer_background=self.native_optim, **self.render_kwargs)
-            return render_loss(out, self.s_gt)
+            return render_loss(out, self.s_gt, self._expected_grad())
 
     def _body_fb(self):
         """zero grads -> render -> loss -> scaled backward"""

@@ -721,12 +721,15 @@ class NgpHeadBackend:
                "ngp_rgb_backward")
 
     @staticmethod
-    def bg_mse_forward(image, weights_sum, gt, bg_rgb, loss):
+    def bg_mse_forward(image, weights_sum, gt, bg_rgb, loss, grad_loss=None, grad_image=None, grad_weights_sum=None):
         for t, n in ((image, "image"), (weights_sum, "weights_sum"), (gt, "gt"), (loss, "loss")):
             _need(t, torch.float32, n)
+        if grad_loss is not None:
+            for t, n in ((grad_loss, "grad_loss"), (grad_image, "grad_image"), (grad_weights_sum, "grad_weights_sum")):
+                _need(t, torch.float32, n)
         bg = (C.c_float * 3)(*[float(v) for v in bg_rgb])
-        _check(lib().s3d_bg_mse_forward(_p(image), _p(weights_sum), _p(gt), bg, _u(image.shape[0]), _p(loss), _stream()),
-               "bg_mse_forward")
+        _check(lib().s3d_bg_mse_forward(_p(image), _p(weights_sum), _p(gt), bg, _u(image.shape[0]), _p(loss), _p(grad_loss),
+                                        _p(grad_image), _p(grad_weights_sum), _stream()), "bg_mse_forward")
 
     @staticmethod
     def bg_mse_backward(image, weights_sum, gt, bg_rgb, grad_loss, grad_image, grad_weights_sum):
