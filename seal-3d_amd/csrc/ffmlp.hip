@@ -619,13 +619,9 @@ typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 // mapping).  Two such reads are a lane's 8 consecutive points of one feature: the A / B operand of the weight-gradient MFMA.
 // [Before: transposed tile T[feature][point], 8 two-byte stores per k-step and lane, one 16-byte load per fragment: 216
 //  ds_write_b16 per 32-point tile, a quarter of the kernel's LDS instructions and their address arithmetic.]
-#ifndef S3D_FF_EXPERIMENT  // kernel-timing experiments only: 1 = fused backward without its weight-gradient half
-#define S3D_FF_EXPERIMENT 0
-#endif
 template <int NS>
 __device__ __forceinline__ void transpose_store(_Float16* __restrict__ T, const half8 (&bf)[NS], uint32_t ksteps,
                                                 uint32_t n, uint32_t h) {
-    if (S3D_FF_EXPERIMENT == 1) return;
 #pragma unroll
     for (uint32_t s = 0; s < (uint32_t)NS; s++)
         if (s < ksteps) {
@@ -717,7 +713,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
     const _Float16* w_hid = Wt + (size_t)W * in_dim;
     const _Float16* w_last = w_hid + (size_t)NH * W * W;
 
-    for (uint32_t f = wave; f < (S3D_FF_EXPERIMENT == 3 ? 0u : nfrag); f += 4) {
+    for (uint32_t f = wave; f < nfrag; f += 4) {
         half8 v;
         if (f < nf_f0) {  // forward, layer 0: A[row = hidden feature][k = input]
             const uint32_t mblk = f / KS0, s = f % KS0;
@@ -842,7 +838,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
             for (uint32_t s = 0; s < 2; s++) {
                 const half8 af = transpose_load(TG, 0, s, n, h, 16);
 #pragma unroll
-                for (uint32_t ni = 0; ni < MB; ni++) if (S3D_FF_EXPERIMENT != 1) dwl[ni] = mfma(af, transpose_load(TX, ni, s, n, h, W), dwl[ni]);
+                for (uint32_t ni = 0; ni < MB; ni++) dwl[ni] = mfma(af, transpose_load(TX, ni, s, n, h, W), dwl[ni]);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -886,7 +882,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
                     for (uint32_t mo = 0; mo < MB; mo++) {
                         const half8 af = transpose_load(TG, mo, s, n, h, W);
 #pragma unroll
-                        for (uint32_t ni = 0; ni < MB; ni++) if (S3D_FF_EXPERIMENT != 1) dwh[k - 1][mo][ni] = mfma(af, bfr[ni], dwh[k - 1][mo][ni]);
+                        for (uint32_t ni = 0; ni < MB; ni++) dwh[k - 1][mo][ni] = mfma(af, bfr[ni], dwh[k - 1][mo][ni]);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -909,7 +905,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
                     for (uint32_t mo = 0; mo < MB; mo++) {
                         const half8 af = transpose_load(TG, mo, s, n, h, W);
 #pragma unroll
-                        for (uint32_t ni = 0; ni < (uint32_t)IMB; ni++) if (S3D_FF_EXPERIMENT != 1) dw0[mo][ni] = mfma(af, bfr[ni], dw0[mo][ni]);
+                        for (uint32_t ni = 0; ni < (uint32_t)IMB; ni++) dw0[mo][ni] = mfma(af, bfr[ni], dw0[mo][ni]);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -935,7 +931,6 @@ __global__ void __launch_bounds__(256) k_ffmlp_backward_fused(const _Float16* __
         }
     }
 
-    if (S3D_FF_EXPERIMENT == 2) return;
     // ---- sum the four waves in a fixed order through LDS, one [64][64] fp32 partial per (matrix, workgroup)
     float* red = reinterpret_cast<float*>(smem_raw);  // 4 planes x 16 KiB over the (no longer needed) fragments and tiles
     flush_matrix<MB, IMB>(red, partial, 0, wave, n, h, [&](auto mo, auto ni) { return dw0[mo][ni]; });
