@@ -231,6 +231,26 @@ def test_sync_free_partial_grid_update_matches_reference_rule(oracle_wrappers):
     assert same > 0.975, same
 
 
+def test_sorted_uniform_stream_is_the_order_statistics_of_iid_uniforms():
+    """NeRFRenderer._sorted_uniform (cells of the graph-replayed occupancy sweep): ascending, inside [0, 1), and distributed like
+    sorted iid uniforms — Kolmogorov-Smirnov distance of the values, uniform spacings (exponential with mean 1/N), and the
+    k-th value's mean k/(N+1)"""
+    import torch
+    from nerf.renderer import NeRFRenderer
+    torch.manual_seed(3)
+    N = 200000
+    u = NeRFRenderer._sorted_uniform(N, torch.device("cpu"))
+    assert u.dtype == torch.float64 and u.shape == (N,)
+    assert float(u[0]) >= 0.0 and float(u[-1]) < 1.0 and bool((u[1:] >= u[:-1]).all())
+    ecdf = torch.arange(1, N + 1, dtype=torch.float64) / N
+    assert float((ecdf - u).abs().max()) < 1.63 / N ** 0.5  # KS critical value at alpha = 0.01
+    gaps = (u[1:] - u[:-1]) * N
+    assert abs(float(gaps.mean()) - 1.0) < 0.01 and abs(float(gaps.var()) - 1.0) < 0.03
+    reps = torch.stack([NeRFRenderer._sorted_uniform(999, torch.device("cpu"))[[0, 499, 998]] for _ in range(400)])
+    want = torch.tensor([1.0, 500.0, 999.0], dtype=torch.float64) / 1000.0
+    assert float((reps.mean(0) - want).abs().max()) < 0.003
+
+
 def test_tensorf_shrink_model_crops_factors_and_aabb(oracle_wrappers):
     """tensoRF/network.py:273-318: the factors and aabb_train are cropped to the occupied region of the coarsest cascade;
     a point keeps its features (its normalised coordinate moves with the box: same cells, same weights) when the crop
