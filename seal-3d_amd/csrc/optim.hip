@@ -77,15 +77,21 @@ __device__ __forceinline__ void adam_range(const AdamCoef& c, float* __restrict_
         float gi[4];
         GradVec4<G>::load(g, i, gi);
         if (consume) GradVec4<G>::zero(g, i);
-        float4 mi = *reinterpret_cast<const float4*>(m + i), vi = *reinterpret_cast<const float4*>(v + i),
-               pi = *reinterpret_cast<const float4*>(p + i);
+        // the 24 B per element of fp32 state stream through once per step: non-temporal, so that they do not push the fp16
+        // table copy (read by the next forward) and the gradient buffer out of the L2 / Infinity Cache
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v mv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(m + i));
+        const f4v vv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(v + i));
+        const f4v pv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p + i));
+        float4 mi = make_float4(mv.x, mv.y, mv.z, mv.w), vi = make_float4(vv.x, vv.y, vv.z, vv.w),
+               pi = make_float4(pv.x, pv.y, pv.z, pv.w);
         adam_update(c, gi[0], mi.x, vi.x, pi.x);
         adam_update(c, gi[1], mi.y, vi.y, pi.y);
         adam_update(c, gi[2], mi.z, vi.z, pi.z);
         adam_update(c, gi[3], mi.w, vi.w, pi.w);
-        *reinterpret_cast<float4*>(m + i) = mi;
-        *reinterpret_cast<float4*>(v + i) = vi;
-        *reinterpret_cast<float4*>(p + i) = pi;
+        __builtin_nontemporal_store(f4v{mi.x, mi.y, mi.z, mi.w}, reinterpret_cast<f4v*>(m + i));
+        __builtin_nontemporal_store(f4v{vi.x, vi.y, vi.z, vi.w}, reinterpret_cast<f4v*>(v + i));
+        __builtin_nontemporal_store(f4v{pi.x, pi.y, pi.z, pi.w}, reinterpret_cast<f4v*>(p + i));
         if (p_half) {
             const __half2 a = __floats2half2_rn(pi.x, pi.y), b = __floats2half2_rn(pi.z, pi.w);
             uint2 o;
