@@ -1281,7 +1281,9 @@ int launch_forward(const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t i
     const size_t smem = (size_t)nfr * 64 * sizeof(half8) + (t_mid_fwd.cin ? (size_t)4 * 32 * kMidRow * sizeof(_Float16) : 0);
     const uint32_t ntiles = B / 32;
     uint32_t grid = div_up<uint32_t>(ntiles, 4);
-    if (grid > 1024) grid = 1024;
+    // (measured at 2.6e5 points: 768 workgroups 11.8 / 14.6 us for the 2- / 3-matrix net, 1024: 12.7 / 16.2, 2048: 16.9 / 21.6,
+    //  512: 12.2 / 14.7 — every workgroup stages all weights once, three per CU still hide the tile latencies)
+    if (grid > 768) grid = 768;
 #define S3D_FWD(TRAIN, A, O) hipLaunchKernelGGL((k_ffmlp_forward<W, TRAIN, A, O>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out, in_layout, t_n_valid, t_rgb_out, t_mid_fwd)
     const bool fast = act == ACT_RELU && out_act == ACT_NONE;  // the networks of the hot path; anything else: run-time switch
     if (fwd) { if (fast) S3D_FWD(true, ACT_RELU, ACT_NONE); else S3D_FWD(true, -1, -1); }
