@@ -433,7 +433,9 @@ __global__ void __launch_bounds__(64) k_march_count_wave(const float* __restrict
                                                          const float* __restrict__ aabb, float min_near,
                                                          const int32_t* __restrict__ noise_step, uint32_t noise_key) {
     __shared__ float T[kWin + 8];
-    __shared__ uint16_t nxt[kWin];          // kOcc = occupied, else the skip target index
+    // (occupancy of the probes lives in a per-lane bit mask — bit i = entry lane + 64 i, like `mk` — not in a third LDS table:
+    //  8.5 KB instead of 10.5 KB per single-wave workgroup is 16 instead of 15 resident per CU, i.e. all 4,096 rays of a
+    //  training batch in ONE round on 256 CUs instead of a 3,840 + 256 split)
     __shared__ uint16_t J[2][kWin + 2];     // jump tables of the pointer-doubling rounds
     __shared__ uint32_t mk[64];             // visited bits: entry k = lane + 64 i is bit i of mk[lane] (kWin / 64 + 1 <= 32 bits)
     __shared__ uint32_t s_wn;
@@ -538,6 +540,7 @@ __global__ void __launch_bounds__(64) k_march_count_wave(const float* __restrict
         S3D_TICK(0)
         const uint32_t wn = s_wn;
         // ---- B: probe every t_k
+        uint32_t occm = 0;  // bit i: entry lane + 64 i is occupied
         for (uint32_t k = lane; k < wn; k += 64) {
             float x, y, z, dt, tt;
             uint16_t e = kOcc;
@@ -545,8 +548,9 @@ __global__ void __launch_bounds__(64) k_march_count_wave(const float* __restrict
                 uint32_t m = k + 1;
                 while (m < wn && T[m] < tt) m++;
                 e = (uint16_t)m;  // == wn: leaves the window (carry) or the ray (T[wn] >= far)
+            } else {
+                occm |= 1u << (k >> 6);
             }
-            nxt[k] = e;
             J[0][k] = (e == kOcc) ? (uint16_t)(k + 1) : e;
         }
         S3D_TICK(1)
@@ -596,7 +600,7 @@ __global__ void __launch_bounds__(64) k_march_count_wave(const float* __restrict
         for (uint32_t k0 = 0; k0 < wn && num_steps < max_steps; k0 += 64) {
             const uint32_t k = k0 + lane;
             const bool vis = k < wn && ((mk[lane] >> (k0 >> 6)) & 1u);
-            const bool emit = vis && nxt[k] == kOcc;
+            const bool emit = vis && ((occm >> (k0 >> 6)) & 1u);
             if (vis && !emit) { last_empty = k; any_empty = true; }
             const unsigned long long m = __ballot(emit);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -609,10 +613,11 @@ __global__ void __launch_bounds__(64) k_march_count_wave(const float* __restrict
         for (int d = 32; d >= 1; d >>= 1) le = max(le, (uint32_t)__shfl_xor((int)le, d, 64));
         const bool had_empty = __ballot(any_empty) != 0;
         const bool more = (wn == kWin) && (num_steps < max_steps);
-        if (more && had_empty && nxt[le] == (uint16_t)wn) {
+        if (more && had_empty) {
+            // (its skip target index was wn  <=>  no later entry of the window reaches the target: T is increasing)
             float x, y, z, dt, tt;
             (void)probe(r, p, T[le], x, y, z, dt, tt);
-            pending_tt = tt;
+            if (le + 1 >= wn || T[wn - 1] < tt) pending_tt = tt;
         }
         t_carry = T[kWin];  // only meaningful when the window was full
         __syncthreads();
