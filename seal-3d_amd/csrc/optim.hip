@@ -277,7 +277,7 @@ S3D_EXPORT int s3d_adam_step_multi(const s3d_adam_tensor* tensors, int32_t n_ten
         memset(&b, 0, sizeof(b));
         b.consume = consume_grads ? 1 : 0;
         uint32_t blocks = 0;
-        for (int32_t k = base; k < n_tensors && b.count < kAdamMaxTensors; k++) {
+        for (int32_t k = base; k < n_tensors && k < base + kAdamMaxTensors; k++) {  // (exactly this batch's index range)
             const s3d_adam_tensor& t = tensors[k];
             if (t.n == 0) continue;
             S3D_REQUIRE(t.param && t.grad && t.exp_avg && t.exp_avg_sq, "adam_step_multi: null pointer in tensor %d", k);
