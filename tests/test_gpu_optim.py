@@ -43,7 +43,7 @@ def test_adam_multi_tensor_launch_is_the_per_tensor_update_bit_for_bit(hip):
     import s3d_hip
     O = s3d_hip.OptimBackend
     torch.manual_seed(3)
-    sizes = [12_000_003, 11264, 7168, 5, 4099]
+    sizes = [12_000_003, 11264, 7168, 5, 4099] + [0, 33, 64] * 5  # 20 tensors: more than one launch's worth, some empty
     step = torch.full((1,), 4.0, device="cuda")
     scale = torch.full((1,), 1024.0, device="cuda")
     flag = torch.zeros(1, device="cuda")
@@ -57,7 +57,7 @@ def test_adam_multi_tensor_launch_is_the_per_tensor_update_bit_for_bit(hip):
             g = (g.half() if k < 3 else g)[off:]
             m = (torch.randn(n + off, device="cuda") * 0.1)[off:]
             v = (torch.rand(n + off, device="cuda") * 0.01)[off:]
-            h = torch.empty(n + off, device="cuda", dtype=torch.half)[off:] if k in (0, 1, 4) else None
+            h = torch.empty(n + off, device="cuda", dtype=torch.half)[off:] if k in (0, 1, 4, 7, 12) else None
             out.append([p, g, m, v, h])
         return out
     torch.manual_seed(3); a = make()
@@ -65,7 +65,8 @@ def test_adam_multi_tensor_launch_is_the_per_tensor_update_bit_for_bit(hip):
     for x, y in zip(a, b):
         assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1])
     for p, g, m, v, h in a:
-        O.adam_step(p, g, m, v, h, 1e-2, 0.9, 0.99, 1e-15, step, scale, flag)
+        if p.numel():
+            O.adam_step(p, g, m, v, h, 1e-2, 0.9, 0.99, 1e-15, step, scale, flag)
     O.adam_step_multi([(p, g, m, v, h, 1e-2, 0.9, 0.99, 1e-15) for p, g, m, v, h in b], step, scale, flag)
     for x, y in zip(a, b):
         for k in (0, 2, 3):
