@@ -367,6 +367,7 @@ typedef struct s3d_adam_tensor {
     size_t n;
     float lr, beta1, beta2, eps;
     int grad_dtype; /* S3D_F32 or S3D_F16 */
+    int consume;    /* != 0: this tensor's gradient is cleared behind the read (as consume_grads, per tensor) */
 } s3d_adam_tensor;
 int s3d_adam_step_multi(const s3d_adam_tensor* tensors /* host array */, int32_t n_tensors, const float* step,
                         const float* grad_scale, const float* found_inf, int consume_grads, s3d_stream_t stream);

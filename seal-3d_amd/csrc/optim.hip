@@ -143,8 +143,8 @@ struct AdamBatch {
     size_t n[kAdamMaxTensors];
     float lr[kAdamMaxTensors], beta1[kAdamMaxTensors], beta2[kAdamMaxTensors], eps[kAdamMaxTensors];
     uint32_t first_block[kAdamMaxTensors + 1];
-    uint8_t half_grad[kAdamMaxTensors], vec[kAdamMaxTensors];
-    int32_t count, consume;
+    uint8_t half_grad[kAdamMaxTensors], vec[kAdamMaxTensors], consume[kAdamMaxTensors];
+    int32_t count;
 };
 
 __global__ void __launch_bounds__(256) k_adam_step_multi(AdamBatch b, const float* __restrict__ step,
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) k_adam_step_multi(AdamBatch b, const floa
     const size_t tid = (size_t)(blockIdx.x - b.first_block[i]) * 256 + threadIdx.x;
     const size_t nthreads = (size_t)(b.first_block[i + 1] - b.first_block[i]) * 256;
     if (found_inf && *found_inf != 0.0f) {  // skipped step: nothing is updated
-        if (b.consume) {
+        if (b.consume[i]) {
             if (b.half_grad[i]) clear_range<__half>((__half*)b.g[i], b.n[i], b.vec[i] != 0, tid, nthreads);
             else clear_range<float>((float*)b.g[i], b.n[i], b.vec[i] != 0, tid, nthreads);
         }
@@ -169,9 +169,9 @@ __global__ void __launch_bounds__(256) k_adam_step_multi(AdamBatch b, const floa
     c.step_size = b.lr[i] / bc1;
     c.bc2_sqrt = sqrtf(bc2);
     if (b.half_grad[i])
-        adam_range<__half>(c, b.p[i], (__half*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.vec[i] != 0, tid, nthreads, b.consume != 0);
+        adam_range<__half>(c, b.p[i], (__half*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.vec[i] != 0, tid, nthreads, b.consume[i] != 0);
     else
-        adam_range<float>(c, b.p[i], (float*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.vec[i] != 0, tid, nthreads, b.consume != 0);
+        adam_range<float>(c, b.p[i], (float*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.vec[i] != 0, tid, nthreads, b.consume[i] != 0);
 }
 
 __global__ void k_adam_advance(float* __restrict__ step, const float* __restrict__ found_inf) {
@@ -275,7 +275,6 @@ S3D_EXPORT int s3d_adam_step_multi(const s3d_adam_tensor* tensors, int32_t n_ten
     for (int32_t base = 0; base < n_tensors; base += kAdamMaxTensors) {
         AdamBatch b;
         memset(&b, 0, sizeof(b));
-        b.consume = consume_grads ? 1 : 0;
         uint32_t blocks = 0;
         for (int32_t k = base; k < n_tensors && k < base + kAdamMaxTensors; k++) {  // (exactly this batch's index range)
             const s3d_adam_tensor& t = tensors[k];
@@ -286,6 +285,7 @@ S3D_EXPORT int s3d_adam_step_multi(const s3d_adam_tensor* tensors, int32_t n_ten
             b.p[i] = t.param; b.g[i] = const_cast<void*>(t.grad); b.m[i] = t.exp_avg; b.v[i] = t.exp_avg_sq; b.h[i] = (__half*)t.param_half;
             b.n[i] = t.n; b.lr[i] = t.lr; b.beta1[i] = t.beta1; b.beta2[i] = t.beta2; b.eps[i] = t.eps;
             b.half_grad[i] = t.grad_dtype == S3D_F16;
+            b.consume[i] = (consume_grads || t.consume) ? 1 : 0;
             const uintptr_t bits = (uintptr_t)t.param | (uintptr_t)t.exp_avg | (uintptr_t)t.exp_avg_sq |
                                    ((uintptr_t)t.grad << (t.grad_dtype == S3D_F16 ? 1 : 0)) | ((uintptr_t)t.param_half << 1);
             b.vec[i] = (bits & 15) == 0;

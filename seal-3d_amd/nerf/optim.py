@@ -151,18 +151,17 @@ class NativeAdam(torch.optim.Optimizer):
             if before_param is not None:
                 _backend.adam_step(*item, self.step_count, grad_scale, found_inf)
             else:
-                batch.append(item)
-                if g is getattr(p, "_s3d_grad", None):
+                # (a hand-over buffer is cleared behind the read; a `.grad` stays readable after the step)
+                mine = self.consume_grads and g is getattr(p, "_s3d_grad", None)
+                batch.append(item + (mine,))
+                if mine:
                     consumed.append(p)
             if half is None and hasattr(p, "_s3d_half"):
                 stale.append(p)
         if batch:
-            # (only when every tensor of the launch is a hand-over buffer: a `.grad` stays readable after the step)
-            consume = self.consume_grads and len(consumed) == len(batch)
-            _backend.adam_step_multi(batch, self.step_count, grad_scale, found_inf, consume_grads=consume)
-            if consume:
-                for p in consumed:
-                    p._s3d_grad_consumed = True
+            _backend.adam_step_multi(batch, self.step_count, grad_scale, found_inf)
+            for p in consumed:
+                p._s3d_grad_consumed = True
         for p in stale:
             p._s3d_half.copy_(p.detach())
             p._s3d_half_version = p._version

@@ -580,7 +580,7 @@ class _AdamTensor(C.Structure):
     """seal3d_hip.h: s3d_adam_tensor"""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("param_half", C.c_void_p), ("n", C.c_size_t), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
-                ("eps", C.c_float), ("grad_dtype", C.c_int)]
+                ("eps", C.c_float), ("grad_dtype", C.c_int), ("consume", C.c_int)]
 
 
 class OptimBackend:
@@ -607,10 +607,13 @@ class OptimBackend:
 
     @staticmethod
     def adam_step_multi(items, step, grad_scale, found_inf, consume_grads=False):
-        """`items`: (param, grad, exp_avg, exp_avg_sq, param_half or None, lr, beta1, beta2, eps) per tensor — adam_step for
-        all of them in one launch; `consume_grads`: the gradients are cleared behind the read (seal3d_hip.h)"""
+        """`items`: (param, grad, exp_avg, exp_avg_sq, param_half or None, lr, beta1, beta2, eps[, consume]) per tensor — adam_step
+        for all of them in one launch; `consume_grads` (all tensors) / the optional tenth element (that tensor): the gradient
+        is cleared behind the read (seal3d_hip.h)"""
         arr = (_AdamTensor * len(items))()
-        for a, (param, grad, exp_avg, exp_avg_sq, param_half, lr, beta1, beta2, eps) in zip(arr, items):
+        for a, item in zip(arr, items):
+            param, grad, exp_avg, exp_avg_sq, param_half, lr, beta1, beta2, eps = item[:9]
+            a.consume = int(bool(item[9])) if len(item) > 9 else 0
             _need(param, torch.float32, "param"); _need(exp_avg, torch.float32, "exp_avg"); _need(exp_avg_sq, torch.float32, "exp_avg_sq")
             if grad.numel() != param.numel() or not grad.is_contiguous() or not param.is_contiguous():
                 raise RuntimeError("adam_step_multi: param and grad must be contiguous and of equal size")
