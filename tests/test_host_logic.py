@@ -231,6 +231,34 @@ def test_sync_free_partial_grid_update_matches_reference_rule(oracle_wrappers):
     assert same > 0.975, same
 
 
+def test_scaler_skips_its_gradient_pass_only_when_every_writer_reports():
+    """NativeGradScaler._checked_at_source (host logic): the separate non-finite pass over the hand-over buffer is skipped only
+    if EVERY adopted parameter reports into THIS scaler's flag and no producer that cannot report (TV term: a torch op) has
+    written since zero_grad; a parameter attached to another scaler, or none adopted, keeps the pass."""
+    import types
+    import torch
+    from nerf.optim import NativeGradScaler
+    sc, other = NativeGradScaler("cpu"), NativeGradScaler("cpu")
+
+    def param(adopted=True):
+        p = types.SimpleNamespace()
+        if adopted:
+            p._s3d_grad = torch.zeros(4, dtype=torch.float16)
+        return p
+    a, b, plain = param(), param(), param(adopted=False)
+    opt = types.SimpleNamespace(param_groups=[{"params": [a, plain]}, {"params": [b]}])
+    assert not sc._checked_at_source(opt)              # nobody attached
+    sc.attach(opt)
+    assert a._s3d_found_inf is sc._found_inf and not hasattr(plain, "_s3d_found_inf")
+    assert sc._checked_at_source(opt) and not other._checked_at_source(opt)
+    b._s3d_unchecked = True                            # e.g. GridEncoder.grad_total_variation added to the buffer
+    assert not sc._checked_at_source(opt)
+    b._s3d_unchecked = False
+    b._s3d_found_inf = other._found_inf                # attached elsewhere
+    assert not sc._checked_at_source(opt)
+    assert not sc._checked_at_source(types.SimpleNamespace(param_groups=[{"params": [plain]}]))  # nothing adopted
+
+
 def test_sorted_uniform_stream_is_the_order_statistics_of_iid_uniforms():
     """NeRFRenderer._sorted_uniform (cells of the graph-replayed occupancy sweep): ascending, inside [0, 1), and distributed like
     sorted iid uniforms — Kolmogorov-Smirnov distance of the values, uniform spacings (exponential with mean 1/N), and the
