@@ -185,19 +185,25 @@ int s3d_grid_corner_indices(const float* inputs, const int32_t* offsets, uint32_
  * workspace (s3d_grid_encode_backward_workspace_size bytes; 0 = configuration not supported) enables the
  * binned path used for B >= 8192: contributions are partitioned by table slice and summed in LDS as 64-bit
  * fixed point — deterministic, no global atomics.  Without it (NULL) direct atomics are used.
- * path: 0 = auto, 1 = direct atomics, 2 = binned (an error when the workspace is missing).
+ * path: 0 = auto, 1 = direct atomics, 2 = binned (an error when the workspace is missing), 3 = binned with the
+ * previous generation's 8-byte records (kept for A/B runs and as the fallback of the shapes it alone covers).
  * found_inf (optional, build extension): a device float raised to 1 when grad_embeddings holds a non-finite value after
  * the call (torch.amp.GradScaler's check, nerf/utils.py:495-537, made where the gradient is produced: the binned fp16 path
- * reports while it writes the sums, the other paths scan the table once).  Never cleared here. */
+ * reports while it writes the sums, the other paths scan the table once).  Never cleared here.
+ * control (optional, build extension): s3d_grid_encode_backward_control_size() bytes of device memory (a few hundred KB,
+ * independent of B) that the CALLER zero-fills once after allocating it; every call finds it all-zero and leaves it all-zero
+ * (the accumulate kernel clears the bucket cursors it has consumed), so the binned path needs no clearing launch of its
+ * own.  Not to be shared by calls that may run concurrently.  NULL: the words live in `workspace` and are cleared per call. */
 size_t s3d_grid_encode_backward_workspace_size(uint32_t B, uint32_t D, uint32_t C, uint32_t L,
                                                uint32_t max_level_rows, int dtype);
+size_t s3d_grid_encode_backward_control_size(uint32_t D, uint32_t C, uint32_t L, uint32_t max_level_rows, int dtype);
 int s3d_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
                              const int32_t* offsets, void* grad_embeddings, uint32_t max_level_rows,
                              uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                              const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                              uint32_t interp, int dtype, void* workspace, size_t workspace_bytes,
                              float bound, const int32_t* n_valid, int path, float* found_inf,
-                             s3d_stream_t stream);
+                             void* control, size_t control_bytes, s3d_stream_t stream);
 
 /* gridencoder.h:15 void grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H,
  *                        gridtype, align_corners) — fp32 only (grid.py:162 disables autocast) */

@@ -587,9 +587,13 @@ __device__ __forceinline__ long long to_fixed64(float v, int k) {
 #ifndef S3D_BIN_KS  // lanes sharing a quad of points in the scatter (corners split between them)
 #define S3D_BIN_KS 2
 #endif
-#ifndef S3D_BIN_ACC_KB  // tuning knobs of k_bin_accumulate (tools/tune_bin.sh builds variants)
+#ifndef S3D_BIN_ACC_KB  // tuning knobs of k_bin_accumulate (tools/build_variants.sh builds variants)
 #define S3D_BIN_ACC_KB 128
+#endif
+#ifndef S3D_BIN_ACC_THREADS
 #define S3D_BIN_ACC_THREADS 1024
+#endif
+#ifndef S3D_BIN_ACC_UNROLL
 #define S3D_BIN_ACC_UNROLL 4
 #endif
 constexpr uint32_t kBinGroup = 32;
@@ -1431,6 +1435,565 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate4(const uint2*
     if (found_inf && overflow) *found_inf = 1.0f;
 }
 
+// ---- binned backward, third generation -------------------------------------------------------------------------
+// Measured on generation two (profiles/r07_timed_region.md): the 8-byte records were written once and read once — 548 B per
+// point, as much as the whole algorithmic budget of the op — and the scatter spent more than half of its wave-cycles parked
+// (one returning global atomic per slice in the middle of every workgroup's phase chain, every barrier draining the
+// vector-memory queue).  This generation keeps the structure (partition by table slice, exact 64-bit fixed-point sums in
+// LDS) and cuts the bytes and the bubbles:
+//  * 6-byte records in two streams: a 16-bit row-in-slice and the 32-bit value word.  The accumulate reads four records
+//    with one 8-byte and one 16-byte load.
+//  * one lane = one point, and the run merge is WAVE-wide: consecutive samples of a ray share a cell of a coarse level for
+//    tens of samples (37 on level 0 of the Lego configuration, ~2 on level 9); a head-flagged segmented scan sums the 2^D x C
+//    products of a run across its lanes in fp32 (fixed tree, deterministic) and the run's LAST lane emits one record per
+//    corner.  The scan stops as soon as no run is open (one ballot per wave on the fine levels, where nothing merges).
+//  * XCD-private sub-buckets: a (level, slice) bucket is split in 8; a workgroup appends to the part of the XCD it runs on
+//    (HW_REG_XCC_ID), so every 64-byte line of a bucket is written by ONE L2 and leaves it whole — runs of a few dozen
+//    records from different XCDs no longer share lines.  Placement changes speed only: any sub-bucket choice gives the same
+//    sums (integer adds commute).
+//  * the bucket reservations (returning global atomics) are issued, the workgroup stages its records in LDS meanwhile
+//    (barriers wait for LDS only), and the results are consumed just before the copy-out.
+#ifndef S3D_BIN3_P
+#define S3D_BIN3_P 512
+#endif
+#ifndef S3D_BIN3_NSUB   // XCD-private sub-buckets per (level, slice): 8x fewer same-word cursor atomics (r08: 152 -> 131 us), 1 = off
+#define S3D_BIN3_NSUB 8
+#endif
+#ifndef S3D_BIN3_MERGE   // 0: no wave-wide merge (A/B)
+#define S3D_BIN3_MERGE 1
+#endif
+#ifndef S3D_BIN3_MIN_MERGES  // fewer continuing lanes than this in a wave: no merge there (the scan costs more than it saves)
+#define S3D_BIN3_MIN_MERGES 6
+#endif
+#ifndef S3D_BIN3_LDSBAR  // 0: plain __syncthreads() (A/B)
+#define S3D_BIN3_LDSBAR 1
+#endif
+#ifndef S3D_BIN3_LEVEL_FAST  // 1: consecutive workgroups of the scatter serve different LEVELS of one chunk (cursor words of 16 levels in play)
+#define S3D_BIN3_LEVEL_FAST 0
+#endif
+#ifndef S3D_BIN3_CURSOR_STRIDE  // words between two cursors (16 = one cursor per 64-byte line)
+#define S3D_BIN3_CURSOR_STRIDE 16
+#endif
+constexpr uint32_t kCurStride = S3D_BIN3_CURSOR_STRIDE;
+#ifdef S3D_BIN3_PROF  // per-workgroup phase stamps (shader clock) of the two kernels: tools/debug only
+__device__ unsigned long long s3d_prof_buf[2][16384][8];
+#define S3D_STAMP(kern, wg, k) do { if (threadIdx.x == 0 && (wg) < 16384) s3d_prof_buf[kern][wg][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define S3D_STAMP(kern, wg, k) do { } while (0)
+#endif
+constexpr uint32_t kBin3Sub = S3D_BIN3_NSUB;
+static_assert(kBin3Sub == 1 || kBin3Sub == 2 || kBin3Sub == 4 || kBin3Sub == 8, "sub-buckets follow the XCD id");
+
+// workgroup barrier that waits for this wave's LDS traffic only (a __syncthreads() also drains the vector-memory queue)
+__device__ __forceinline__ void lds_barrier() {
+#if S3D_BIN3_LDSBAR
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#else
+    __syncthreads();
+#endif
+}
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 7u;
+}
+
+// ---- wave-wide segmented scan by DPP (no LDS traffic) ----
+// f = 1 once the lane has absorbed its run's head.  In-row steps (row_shr 1, 2, 4, 8 inside the 16-lane rows), then the two
+// carry steps of a wave scan (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3): a lane takes the carry only
+// while it is still open, and inherits the flag of the lane it took from.  Fixed tree: the fp32 sums are deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_take(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+// One step = ONE instruction per value: v += dpp(v) * m with m = 1.0 on the lanes that are still open and 0.0 on the closed
+// ones (v_fmac_f32 with a DPP source; lanes without a source lane read 0, rows outside row_mask are not written), and
+// f |= dpp(f).  u * 1 + v is the fp32 sum bit for bit; a closed lane next to a non-finite product turns NaN (0 * inf),
+// which poisons the level exactly as that product does on its own.  Inline asm: four values per statement behind one
+// `s_nop 1` (VALU write -> DPP read of the same VGPR needs two wait states; inside a statement every instruction reads a
+// register written at least a statement earlier).
+#define S3D_SEG_STEP4(CTRL, a, b, c, d, m)                                                                  \
+    asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %4 " CTRL "\n\tv_fmac_f32_dpp %1, %1, %4 " CTRL          \
+                 "\n\tv_fmac_f32_dpp %2, %2, %4 " CTRL "\n\tv_fmac_f32_dpp %3, %3, %4 " CTRL                  \
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(m))
+#define S3D_SEG_FLAG(CTRL, f) asm volatile("s_nop 1\n\tv_or_b32_dpp %0, %0, %0 " CTRL : "+v"(f))
+#define S3D_SEG_STEP(CTRL)                                                                   \
+    {                                                                                        \
+        if (__ballot(f == 0u) == 0ull) return;                                               \
+        const float m = f == 0u ? 1.0f : 0.0f;                                               \
+        _Pragma("unroll") for (uint32_t i = 0; i < N; i += 4) S3D_SEG_STEP4(CTRL, v[i], v[i + 1], v[i + 2], v[i + 3], m); \
+        S3D_SEG_FLAG(CTRL, f);                                                               \
+    }
+template <uint32_t N>
+__device__ __forceinline__ void seg_scan_wave(float (&v)[N], bool head, uint32_t lane) {
+    static_assert(N % 4 == 0, "four values per asm statement");
+    (void)lane;
+    uint32_t f = head ? 1u : 0u;
+    S3D_SEG_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+    S3D_SEG_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+    S3D_SEG_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+    S3D_SEG_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+    S3D_SEG_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")  // lane 15 of rows 0 / 2 -> rows 1 / 3
+    S3D_SEG_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")  // lane 31 -> rows 2, 3
+}
+#undef S3D_SEG_STEP
+#undef S3D_SEG_FLAG
+#undef S3D_SEG_STEP4
+
+// inclusive wave64 prefix sum by DPP (row_shr inside the 16-lane rows, then the two row_bcast carries)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v, uint32_t lane) {
+    const uint32_t rl = lane & 15u, row = lane >> 4;
+    uint32_t u;
+    u = dpp_take<0x111, 0xF>(v); v += rl >= 1 ? u : 0u;
+    u = dpp_take<0x112, 0xF>(v); v += rl >= 2 ? u : 0u;
+    u = dpp_take<0x114, 0xF>(v); v += rl >= 4 ? u : 0u;
+    u = dpp_take<0x118, 0xF>(v); v += rl >= 8 ? u : 0u;
+    u = dpp_take<0x142, 0xA>(v); v += (row & 1u) ? u : 0u;
+    u = dpp_take<0x143, 0xC>(v); v += row >= 2u ? u : 0u;
+    return v;
+}
+
+// Bucket (level, slice, sub) = `cap` records: keys at gkeys[((level_in_pass * smax + slice) * kBin3Sub + sub) * cap], values
+// at the same index of gvals; cursor[((level * smax + slice) * kBin3Sub + sub) * kCurStride] counts the records reserved in
+// it (it may run past cap: the excess lives in the spill regions, as in generation two).
+// Phases of a workgroup (profiled with -DS3D_BIN3_PROF, tools/debug/prof_bwd.py): loads in flight across the first
+// (LDS-only) barrier -> products + wave scan -> LDS rank atomics, arrival counter -> the LAST wave to arrive scans the
+// slice counts and puts the bucket reservations in flight -> barrier -> staging (sorted by slice) while the reservations
+// return -> barrier -> copy-out, four records per lane in flight.
+template <typename T, uint32_t D, uint32_t C, bool FIXED24, uint32_t P>
+__global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, const float* __restrict__ inputs,
+                                                    const int32_t* __restrict__ offsets, uint32_t B, uint32_t level0,
+                                                    LevelScales scales, uint32_t* __restrict__ hdr, uint32_t* __restrict__ cursor,
+                                                    uint32_t* __restrict__ ovn, uint2* __restrict__ ovl, uint32_t smax,
+                                                    uint32_t nchunks, uint32_t cap, uint16_t* __restrict__ gkeys,
+                                                    uint32_t* __restrict__ gvals, uint16_t* __restrict__ skeys,
+                                                    uint32_t* __restrict__ svals, uint32_t gridtype, bool align_corners,
+                                                    uint32_t interp) {
+    using V = typename FeatVec<T, C>::type;
+    static_assert(sizeof(V) == 4, "records carry one 32-bit value word");
+    constexpr uint32_t K = 1u << D;
+    constexpr uint32_t NWV = P / 64;
+    static_assert(P * K < 65536 && P % 64 == 0, "positions inside a chunk are 16-bit fields");
+    static_assert(kBinAccBytes / (8 * C) <= 65536, "row-in-slice is a 16-bit key");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);           // records of the chunk per slice
+    uint32_t* lo = cnt + kBinMaxSlices;                               // run start in the chunk's sorted order
+    uint2* tab = reinterpret_cast<uint2*>(lo + kBinMaxSlices);        // {bucket position of the run - run start, run start | records that fit << 16}
+    uint2* stage = tab + kBinMaxSlices;                               // [P * K] {value, slice << 16 | row-in-slice}
+    __shared__ uint32_t total_s, arrived;
+
+    const uint32_t lip = S3D_BIN3_LEVEL_FAST ? blockIdx.x : blockIdx.y;  // level inside the pass
+    const uint32_t level = level0 + lip, chunk = S3D_BIN3_LEVEL_FAST ? blockIdx.y : blockIdx.x;
+    const uint32_t wg_lin = blockIdx.y * gridDim.x + blockIdx.x;
+    (void)wg_lin;
+    S3D_STAMP(0, wg_lin, 0);
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t Bv = valid_rows(B, scales.n_valid);
+    if (chunk * P >= Bv) return;  // (uniform) chunk entirely in the absent tail of a padded batch
+    if constexpr (!FIXED24) {
+        const float amax = __uint_as_float(hdr[level]);
+        if (!(amax > 0.0f) || amax == INFINITY) return;  // zero / non-finite levels carry no records (uniform exit)
+    }
+    const uint32_t b = chunk * P + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    float x[D];
+    T g[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) g[c] = Acc<T>::zero();
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) x[d] = 0.0f;
+    const bool in = b < Bv;
+    const uint32_t S = bin_slices(hashmap_size, C);
+    const uint32_t sshift = 31 - __clz(S);
+    const uint32_t sub = xcc_id() & (kBin3Sub - 1);
+    const float lscale = scales.v[level];
+    LevelIndex<D> li;
+    li.init(gridtype, align_corners, hashmap_size, (uint32_t)ceilf(lscale) + 1);
+    for (uint32_t s = threadIdx.x; s < S; s += P) cnt[s] = 0;
+    if (threadIdx.x == 0) arrived = 0;
+    lds_barrier();  // counters cleared before anybody ranks a record (all waves are at their start: the barrier is free)
+    if (in) {
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) x[d] = inputs[(size_t)b * D + d];
+        load_feat<T, C>(grad + ((size_t)level * B + b) * C, g);
+    }
+
+    bool active = in;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {  // load_point()'s normalisation and range test
+        if (scales.bound != 0.0f) x[d] = (x[d] + scales.bound) * scales.inv_2bound;
+        if (x[d] < 0 || x[d] > 1) active = false;
+    }
+    bool nz = false;
+    (void)absmax_feat<T, C>(g, nz);
+    active = active && nz;  // samples behind a ray's termination (and padding rows) carry exact zeros
+    S3D_STAMP(0, wg_lin, 1);
+    float pos[D], pd[D];
+    uint32_t pg[D];
+    locate<D>(x, lscale, align_corners, interp, pos, pd, pg);
+    float v[K * C];
+#pragma unroll
+    for (uint32_t idx = 0; idx < K; idx++) {
+        float w = 1;
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) w *= ((idx >> d) & 1u) ? pos[d] : 1 - pos[d];
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) v[idx * C + c] = active ? w * Acc<T>::to_f(g[c]) : 0.0f;
+    }
+    // run = maximal stretch of consecutive ACTIVE lanes of the wave in one cell.  An inactive lane (zero gradient, out of
+    // range) ends the run before it: in training those are the samples behind a ray's termination, i.e. the tail of a ray,
+    // and the next active lane belongs to another ray anyway — and head flags that depend on the previous lane only keep
+    // the scan at log2(longest run) steps.
+    // (every cross-lane read is executed by the whole wave: under a partial exec mask disabled lanes read as 0)
+    const uint32_t pa = dpp_take<0x138, 0xF>(active ? 1u : 0u);  // wave_shr:1 (lane 0 keeps its own value: excluded below)
+    bool cells_equal = active && pa != 0u && lane > 0;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) cells_equal &= (dpp_take<0x138, 0xF>(pg[d]) == pg[d]);
+    bool same = S3D_BIN3_MERGE ? cells_equal : false;  // continues the run of lane - 1
+    // a wave in which (almost) nothing merges skips the scan: every active lane is its own run
+    const unsigned long long smask = __ballot(same);
+    if (__popcll(smask) < S3D_BIN3_MIN_MERGES) same = false;
+    else seg_scan_wave<K * C>(v, !same, lane);
+    const uint32_t next_same = dpp_take<0x130, 0xF>(same ? 1u : 0u);  // wave_shl:1
+    const bool tail = active && (lane == 63u || next_same == 0u);  // the run's last lane holds its sums
+    S3D_STAMP(0, wg_lin, 2);
+
+    uint32_t key[K], rank[K], val[K];
+    bool bad = false;
+    if (tail) {
+        uint32_t lo_[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) lo_[d] = pg[d] * li.mul[d];
+#pragma unroll
+        for (uint32_t idx = 0; idx < K; idx++) {
+            const uint32_t row = li.row(lo_, idx);
+            const uint32_t grp = row / kBinGroup;
+            const uint32_t slice = grp & (S - 1);
+            T pr[C];
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) pr[c] = Acc<T>::from_f(v[idx * C + c]);
+            uint32_t bits;
+            __builtin_memcpy(&bits, pr, 4);
+            if constexpr (FIXED24)  // inf / NaN after rounding to binary16: an all-ones exponent in either half
+                bad |= ((bits & 0x7c00u) == 0x7c00u) || ((bits & 0x7c000000u) == 0x7c000000u);
+            key[idx] = (slice << 16) | ((grp >> sshift) * kBinGroup + row % kBinGroup);
+            rank[idx] = atomicAdd(&cnt[slice], 1u);
+            val[idx] = bits;
+        }
+    }
+    if (FIXED24 && bad) atomicMax(hdr + level, 0x7fc00000u);  // poison marker (a NaN pattern sorts above every finite value)
+    // the last wave to arrive (its arrival is ordered behind every wave's rank atomics) finds the run starts and puts the
+    // bucket reservations in flight; everybody else goes straight to the barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    uint32_t order = 0;
+    if (lane == 0) order = atomicAdd(&arrived, 1u);
+    order = __builtin_amdgcn_readfirstlane(order);
+    const bool last = order == NWV - 1;
+    S3D_STAMP(0, wg_lin, 3);
+    constexpr uint32_t kPer = kBinMaxSlices / 64;
+    uint32_t at[kPer];
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; j++) at[j] = 0;
+    if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        uint32_t carry = 0;
+        {  // slices 0..63 (every level has them): the atomic is unconditional — a branch around it would make hipcc wait for
+           // the result at the join (`at` becomes a phi of arrays), and the point is to let it fly across the barrier
+            const uint32_t c = cnt[lane];
+            const uint32_t incl = wave_incl_scan_dpp(c, lane);
+            lo[lane] = incl - c;
+            carry = __shfl(incl, 63, 64);
+            at[0] = atomicAdd(&cursor[(((size_t)level * smax + lane) * kBin3Sub + sub) * kCurStride], c);
+        }
+        if (S > 64) {  // (tables beyond 64 slices: the results are awaited here)
+#pragma unroll
+            for (uint32_t j = 1; j < kPer; j++) {
+                if (j * 64 < S) {
+                    const uint32_t sl = j * 64 + lane, c = cnt[sl];
+                    const uint32_t incl = wave_incl_scan_dpp(c, lane);
+                    lo[sl] = carry + incl - c;
+                    carry += __shfl(incl, 63, 64);
+                    if (c) at[j] = atomicAdd(&cursor[(((size_t)level * smax + sl) * kBin3Sub + sub) * kCurStride], c);
+                }
+            }
+        }
+        if (lane == 0) total_s = carry;
+    }
+    lds_barrier();  // run starts visible; the reservations are still on their way
+    S3D_STAMP(0, wg_lin, 4);
+    if (tail) {
+#pragma unroll
+        for (uint32_t idx = 0; idx < K; idx++) stage[lo[key[idx] >> 16] + rank[idx]] = make_uint2(val[idx], key[idx]);
+    }
+    if (last) {  // reservations back: what fits the bucket, where it goes, what is spilled
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) {
+            if (j * 64 < S) {
+                const uint32_t sl = j * 64 + lane, c = cnt[sl], l0 = lo[sl], a = at[j];
+                const uint32_t ft = a >= cap ? 0u : (cap - a < c ? cap - a : c);
+                tab[sl] = make_uint2((uint32_t)((int32_t)((sl * kBin3Sub + sub) * cap + a) - (int32_t)l0), l0 | (ft << 16));
+                if (ft < c) {
+                    const uint32_t k = atomicAdd(&ovn[level * smax + sl], 1u);
+                    ovl[((size_t)level * smax + sl) * nchunks + k] = make_uint2((chunk << 16) | (l0 + ft), c - ft);
+                }
+            }
+        }
+    }
+    lds_barrier();
+    S3D_STAMP(0, wg_lin, 5);
+    const uint32_t total = total_s;
+    const size_t bucket0 = (size_t)lip * smax * kBin3Sub * cap;
+    const size_t mine = ((size_t)lip * nchunks + chunk) * (P * K);
+    constexpr uint32_t UC = 4;
+    for (uint32_t i0 = threadIdx.x; i0 < total; i0 += UC * P) {
+        uint2 r[UC], t[UC];
+#pragma unroll
+        for (uint32_t u = 0; u < UC; u++) {
+            const uint32_t i = i0 + u * P;
+            r[u] = stage[i < total ? i : 0];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < UC; u++) t[u] = tab[r[u].y >> 16];
+#pragma unroll
+        for (uint32_t u = 0; u < UC; u++) {
+            const uint32_t i = i0 + u * P;
+            if (i < total) {
+                if (i - (t[u].y & 0xffffu) < (t[u].y >> 16)) {
+                    const size_t p = bucket0 + (size_t)((int32_t)i + (int32_t)t[u].x);
+                    gkeys[p] = (uint16_t)r[u].y;
+                    gvals[p] = r[u].x;
+                } else {
+                    skeys[mine + i] = (uint16_t)r[u].y;
+                    svals[mine + i] = r[u].x;
+                }
+            }
+        }
+    }
+    S3D_STAMP(0, wg_lin, 6);
+#ifdef S3D_BIN3_PROF
+    __builtin_amdgcn_s_waitcnt(0);
+    S3D_STAMP(0, wg_lin, 7);
+#endif
+}
+
+// Accumulate, persistent: one workgroup per CU (the 128 KiB of accumulators fill its LDS) walks the (level, slice) items
+// w, w + G, w + 2G, ... of the pass.  Between two items nothing is re-initialised: the write-out clears every accumulator
+// behind its read, so only the first item pays the 128 KiB zero fill; the table rows a lane will add to are requested
+// before the streaming phase.  Profiled (tools/debug/prof_bwd.py): the streaming phase runs at the LDS rate of 64-bit
+// atomics (~4 per clock and CU, two per record) — that, not HBM, is this kernel's floor.
+// The kernel also leaves the control block the way it found it (all zero): every item clears its cursors and its spill
+// count after reading them, and the last workgroup to finish (ticket) clears the levels' header words — the caller's next
+// call needs no clearing launch.
+template <typename T, uint32_t D, uint32_t C, bool FIXED24, uint32_t P>
+__global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate6(const uint16_t* __restrict__ gkeys, const uint32_t* __restrict__ gvals,
+                                                                   const uint16_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+                                                                   const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
+                                                                   uint32_t B, uint32_t level0, uint32_t nl, uint32_t* __restrict__ hdr,
+                                                                   uint32_t* __restrict__ done, uint32_t* __restrict__ cursor,
+                                                                   uint32_t* __restrict__ ovn, const uint2* __restrict__ ovl,
+                                                                   uint32_t smax, uint32_t nchunks, uint32_t cap,
+                                                                   float* __restrict__ found_inf) {
+    using V = typename FeatVec<T, C>::type;
+    static_assert(sizeof(V) == 4, "records carry one 32-bit value word");
+    constexpr uint32_t K = 1u << D;
+    constexpr uint32_t NS = kBin3Sub;
+    constexpr uint32_t NW = kBinAccThreads / 64;
+    static_assert(NW % NS == 0, "whole waves per sub-bucket");
+    constexpr uint32_t STEP = (NW / NS) * 64;  // quads of one sub-bucket taken per step by its waves
+    constexpr uint32_t W = 8;                  // table rows per lane and round of the write-out
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);  // [C][local_rows]
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t sj = wave % NS;  // sub-bucket streamed by this wave: count, base and trip count are wave-uniform
+    const uint32_t n_items = smax * nl;
+    bool overflow = false;  // a finite sum that leaves the range of T (fp16: |v| > 65504) — what GradScaler looks for
+    bool dirty = true;      // accumulators not known to be zero (first item)
+    uint32_t it_no = 0;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x, it_no++) {
+        const uint32_t lip = item / smax, slice = item - lip * smax;  // level inside the pass
+        const uint32_t level = level0 + lip;
+        const uint32_t wg_lin = item;
+        (void)wg_lin;
+        // every global word of the prologue is requested before the first one is tested
+        const uint32_t off = (uint32_t)offsets[level];
+        const uint32_t rows = (uint32_t)offsets[level + 1] - off;
+        const uint32_t hbits = hdr[level];
+        uint32_t* cur_w = cursor + ((size_t)level * smax + slice) * NS * kCurStride;
+        uint32_t reserved = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < NS; j++) reserved |= cur_w[j * kCurStride];
+        uint32_t cj = cur_w[sj * kCurStride];
+        const uint32_t nspill = ovn[level * smax + slice];
+        S3D_STAMP(1, wg_lin, 0);
+        const uint32_t S = bin_slices(rows, C);
+        if (slice >= S) continue;  // (no such slice: its control words were never touched)
+        const uint32_t local_rows = bin_local_rows(rows, S);
+        auto row_of_local = [&](uint32_t local) { return ((local / kBinGroup) * S + slice) * kBinGroup + local % kBinGroup; };
+        T* table = grad_grid + (size_t)off * C;
+        const float amax = __uint_as_float(hbits);
+        const bool poisoned = FIXED24 ? hbits != 0u : (amax != amax || amax == INFINITY);
+        // the control words of this item go back to zero (all of its readers — this workgroup's lanes — hold them in registers;
+        // the barrier below, or the end of the kernel, orders the stores behind the loads)
+        const bool touched = reserved != 0u;  // (a spilled run implies a reservation)
+        if (touched) {
+            __syncthreads();
+            if (threadIdx.x < NS) cur_w[threadIdx.x * kCurStride] = 0u;
+            if (threadIdx.x == NS) ovn[level * smax + slice] = 0u;
+        }
+        if (poisoned) {
+            for (uint32_t i = threadIdx.x; i < local_rows * C; i += kBinAccThreads) {
+                const uint32_t row = row_of_local(i / C);
+                if (row < rows) table[(size_t)row * C + i % C] = Acc<T>::from_f(NAN);
+            }
+            if (found_inf && threadIdx.x == 0) *found_inf = 1.0f;  // (benign race: everyone writes 1)
+            continue;
+        }
+        if (!FIXED24 && !(amax > 0.0f)) continue;
+        if (!touched) continue;
+        cj = cj < cap ? cj : cap;
+        const uint32_t nquads = (cj + 3) / 4;  // groups of four records in this wave's sub-bucket
+        int kexp = (int)kFixedExp;
+        if constexpr (!FIXED24) {
+            int e;
+            (void)frexpf(amax, &e);
+            kexp = 62 - e - (int)(32 - __clz(B)) - (int)D;
+        }
+        const size_t base = (((size_t)lip * smax + slice) * NS + sj) * cap;  // cap is a multiple of 64: 8- / 16-byte aligned
+        auto add = [&](uint32_t key, uint32_t bits) {
+            T pr[C];
+            __builtin_memcpy(pr, &bits, 4);
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) {
+                const float v = Acc<T>::to_f(pr[c]);
+                const long long q = FIXED24 ? fixed24_exact(v) : to_fixed64(v, kexp);
+                atomicAdd(&acc[c * local_rows + key], (unsigned long long)q);
+            }
+        };
+        struct Quad { uint2 k; uint4 v; uint32_t n; };
+        auto fetch = [&](uint32_t qi) {
+            Quad q;
+            q.n = 0;
+            q.k = make_uint2(0u, 0u);
+            q.v = make_uint4(0u, 0u, 0u, 0u);
+            if (qi < nquads) {
+                q.k = *reinterpret_cast<const uint2*>(gkeys + base + 4 * (size_t)qi);
+                q.v = *reinterpret_cast<const uint4*>(gvals + base + 4 * (size_t)qi);
+                q.n = cj - 4 * qi < 4u ? cj - 4 * qi : 4u;
+            }
+            return q;
+        };
+        auto consume = [&](const Quad& q) {
+            if (q.n > 0) add(q.k.x & 0xffffu, q.v.x);
+            if (q.n > 1) add(q.k.x >> 16, q.v.y);
+            if (q.n > 2) add(q.k.y & 0xffffu, q.v.z);
+            if (q.n > 3) add(q.k.y >> 16, q.v.w);
+        };
+        S3D_STAMP(1, wg_lin, 1);
+        // the first batch of records and the table rows of the write-out's first round are in flight while the accumulators
+        // are cleared (first item only)
+        constexpr uint32_t U = 2;
+        const uint32_t q0 = (wave / NS) * 64 + (threadIdx.x & 63u);
+        Quad cur[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) cur[u] = fetch(q0 + u * STEP);
+        V old0[W];
+#pragma unroll
+        for (uint32_t w = 0; w < W; w++) {
+            const uint32_t rr = threadIdx.x + w * kBinAccThreads;
+            uint32_t zero = 0;
+            __builtin_memcpy(&old0[w], &zero, 4);
+            if (rr < local_rows) {
+                const uint32_t row = row_of_local(rr);
+                if (row < rows) old0[w] = *reinterpret_cast<const V*>(table + (size_t)row * C);
+            }
+        }
+        if (dirty) {
+            for (uint32_t i = threadIdx.x; i < kBinAccBytes / 8; i += kBinAccThreads) acc[i] = 0ull;
+            dirty = false;
+        }
+        __syncthreads();  // accumulators clear (this item's fill, or the previous item's write-out)
+        S3D_STAMP(1, wg_lin, 2);
+        for (uint32_t b0 = 0; b0 < nquads; b0 += U * STEP) {  // (wave-uniform trip count)
+            Quad nx[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) nx[u] = fetch(b0 + q0 + (U + u) * STEP);
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) consume(cur[u]);
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) cur[u] = nx[u];
+        }
+        S3D_STAMP(1, wg_lin, 3);
+        // spilled runs (clustered samples only): one wave per descriptor
+        for (uint32_t k = threadIdx.x >> 6; k < nspill; k += kBinAccThreads / 64) {
+            const uint2 d = ovl[((size_t)level * smax + slice) * nchunks + k];
+            const size_t run = ((size_t)lip * nchunks + (d.x >> 16)) * (P * K) + (d.x & 0xffffu);
+            for (uint32_t j = threadIdx.x & 63u; j < d.y; j += 64) add(skeys[run + j], svals[run + j]);
+        }
+        __syncthreads();
+        S3D_STAMP(1, wg_lin, 4);
+        for (uint32_t r0 = threadIdx.x; r0 < local_rows; r0 += W * kBinAccThreads) {
+            long long q[W][C];
+            V old[W];
+            bool nz[W];
+#pragma unroll
+            for (uint32_t w = 0; w < W; w++) {
+                const uint32_t rr = r0 + w * kBinAccThreads;
+                nz[w] = false;
+                if (rr < local_rows) {
+#pragma unroll
+                    for (uint32_t c = 0; c < C; c++) {
+                        q[w][c] = (long long)acc[c * local_rows + rr];
+                        nz[w] |= (q[w][c] != 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (uint32_t w = 0; w < W; w++) {  // clear behind the read: the next item finds zeros
+                const uint32_t rr = r0 + w * kBinAccThreads;
+                if (nz[w]) {
+#pragma unroll
+                    for (uint32_t c = 0; c < C; c++) acc[c * local_rows + rr] = 0ull;
+                }
+            }
+            if (r0 == threadIdx.x) {
+#pragma unroll
+                for (uint32_t w = 0; w < W; w++) old[w] = old0[w];
+            } else {
+#pragma unroll
+                for (uint32_t w = 0; w < W; w++)
+                    if (nz[w]) old[w] = *reinterpret_cast<const V*>(table + (size_t)row_of_local(r0 + w * kBinAccThreads) * C);
+            }
+#pragma unroll
+            for (uint32_t w = 0; w < W; w++) {
+                if (nz[w]) {
+                    T o[C];
+                    __builtin_memcpy(o, &old[w], sizeof(V));
+#pragma unroll
+                    for (uint32_t c = 0; c < C; c++) {
+                        o[c] = Acc<T>::from_f(Acc<T>::to_f(o[c]) + fixed_to_float(q[w][c], kexp));
+                        overflow |= !(fabsf(Acc<T>::to_f(o[c])) <= 3.402823466e38f);
+                    }
+                    store_feat<T, C>(table + (size_t)row_of_local(r0 + w * kBinAccThreads) * C, o);
+                }
+            }
+        }
+        S3D_STAMP(1, wg_lin, 5);
+    }
+    if (found_inf && overflow) *found_inf = 1.0f;
+    // the last workgroup to get here clears the header words of the pass's levels and the ticket itself (every workgroup has
+    // read its header words before it takes a ticket)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(done, 1u);
+        if (t == gridDim.x - 1) {
+            for (uint32_t l = 0; l < nl; l++) hdr[level0 + l] = 0u;
+            *done = 0u;
+        }
+    }
+}
+
 // s3d_grid_encode_backward(found_inf): the paths that do not report while they accumulate check the table afterwards
 template <typename T>
 __global__ void __launch_bounds__(256) k_table_nonfinite(const T* __restrict__ table, const int32_t* __restrict__ offsets, uint32_t L,
@@ -1671,15 +2234,129 @@ int launch_binned2(const T* grad, const float* inputs, const int32_t* offsets, T
     return check_launch("grid_encode_backward");
 }
 
+// third-generation layout: hdr[kMaxLevels] | cursor[L][smax][NSUB] | ovn[L][smax] | ovl[L][smax][nchunks] (8 B) |
+//   bucket keys [levels_per_pass][smax][NSUB][cap] (2 B) | bucket values (4 B) | spill keys [levels_per_pass][nchunks][P * K] | spill values
+struct BinLayout3 {
+    uint32_t levels_per_pass, chunks, smax, cap;
+    size_t cursor, ovn, ovl, keys, vals, skeys, svals, total;
+    bool ok;
+};
+inline BinLayout3 bin_layout3(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level_rows, uint32_t elem) {
+    BinLayout3 o{};
+    constexpr uint32_t P = S3D_BIN3_P;
+    if (elem * C != 4 || D < 2 || D > 5 || !max_level_rows || !L || L > kMaxLevels || !B) return o;
+    o.smax = bin_slices(max_level_rows, C);
+    o.ok = o.smax <= kBinMaxSlices && ((uint64_t)B << D) < (1ull << 30) && ((uint64_t)P << D) < 65536 &&
+           kBinAccBytes / (8 * C) <= 65536;
+    if (!o.ok) return o;
+    o.chunks = div_up<uint32_t>(B, P);
+    // per sub-bucket: 2x the mean of a uniformly hit level without any merging, split over the XCDs, + slack for tiny batches
+    o.cap = (uint32_t)((((uint64_t)B << (D + 1)) / kBinMinSlices / kBin3Sub + 256 + 63) & ~63ull);
+    const size_t recs = (size_t)o.smax * kBin3Sub * o.cap, srecs = (size_t)o.chunks * P << D;
+    const size_t per_level = (recs + srecs) * 6;
+    const size_t lp = kBinPassBytes / per_level;
+    o.levels_per_pass = (uint32_t)(lp < 1 ? 1 : (lp > L ? L : lp));
+    o.cursor = 256;
+    o.ovn = o.cursor + (size_t)L * o.smax * kBin3Sub * kCurStride * 4;
+    o.ovl = align256(o.ovn + (size_t)L * o.smax * 4);
+    o.keys = align256(o.ovl + (size_t)L * o.smax * o.chunks * 8);
+    o.vals = align256(o.keys + (size_t)o.levels_per_pass * recs * 2);
+    o.skeys = align256(o.vals + (size_t)o.levels_per_pass * recs * 4);
+    o.svals = align256(o.skeys + (size_t)o.levels_per_pass * srecs * 2);
+    o.total = align256(o.svals + (size_t)o.levels_per_pass * srecs * 4);
+    return o;
+}
+
+// CUs of the current device (workgroups of the persistent accumulate), cached per device ordinal
+inline uint32_t device_cus() {
+    static std::atomic<uint32_t> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 256;
+    uint32_t n = cus[dev].load(std::memory_order_relaxed);
+    if (!n) {
+        int v = 0;
+        n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? (uint32_t)v : 256u;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+// control block of the third generation: hdr[kMaxLevels] | ticket (byte 128) | cursor[L][smax][NSUB] (x kCurStride words) | ovn[L][smax]
+inline size_t bin3_control_bytes(const BinLayout3& lay, uint32_t L) { return align256(lay.ovn + (size_t)L * lay.smax * 4); }
+
+template <typename T, uint32_t D, uint32_t C, bool FIXED24>
+int launch_binned3(const T* grad, const float* inputs, const int32_t* offsets, T* grad_emb, uint32_t B, uint32_t L,
+                   const LevelScales& sc, uint32_t gridtype, bool ac, uint32_t interp, unsigned char* ws, const BinLayout3& lay,
+                   unsigned char* control, hipStream_t st) {
+    constexpr uint32_t P = S3D_BIN3_P;
+    constexpr uint32_t K = 1u << D;
+    constexpr uint32_t stage = 4 * kBinMaxSlices * 4 + P * K * 8;  // counters, run starts, run table (8 B), staged records
+    static std::atomic<uint64_t> attr_devs{0};
+    int dev;
+    if (device_needs_setup(attr_devs, &dev)) {
+        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_scatter6<T, D, C, FIXED24, P>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage));
+        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_accumulate6<T, D, C, FIXED24, P>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinAccBytes));
+        device_setup_done(attr_devs, dev);
+    }
+    // a caller-owned control block is all zero between calls (the accumulate leaves it so); without one the words live at
+    // the head of the workspace and are cleared by a launch of their own
+    unsigned char* cb = control ? control : ws;
+    uint32_t* hdr = reinterpret_cast<uint32_t*>(cb);
+    uint32_t* done = reinterpret_cast<uint32_t*>(cb + 128);
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(cb + lay.cursor);
+    uint32_t* ovn = reinterpret_cast<uint32_t*>(cb + lay.ovn);
+    uint2* ovl = reinterpret_cast<uint2*>(ws + lay.ovl);
+    uint16_t* keys = reinterpret_cast<uint16_t*>(ws + lay.keys);
+    uint32_t* vals = reinterpret_cast<uint32_t*>(ws + lay.vals);
+    uint16_t* skeys = reinterpret_cast<uint16_t*>(ws + lay.skeys);
+    uint32_t* svals = reinterpret_cast<uint32_t*>(ws + lay.svals);
+    if (!control) {
+        const uint32_t clear_words = (uint32_t)(bin3_control_bytes(lay, L) / 4);
+        hipLaunchKernelGGL(k_zero_words, dim3(div_up<uint32_t>(clear_words, 1024)), dim3(1024), 0, st, hdr, clear_words);
+    }
+    if constexpr (!FIXED24)
+        hipLaunchKernelGGL((k_bin_amax<T, D, C>), dim3(std::min<uint32_t>(div_up<uint32_t>(B, 1024), 64u), L), dim3(1024), 0, st, grad,
+                           inputs, B, sc, hdr);
+    const uint32_t cus = device_cus();
+    for (uint32_t l0 = 0; l0 < L; l0 += lay.levels_per_pass) {
+        const uint32_t nl = (L - l0 < lay.levels_per_pass) ? L - l0 : lay.levels_per_pass;
+        hipLaunchKernelGGL((k_bin_scatter6<T, D, C, FIXED24, P>), S3D_BIN3_LEVEL_FAST ? dim3(nl, lay.chunks) : dim3(lay.chunks, nl), dim3(P), stage, st, grad, inputs, offsets, B, l0,
+                           sc, hdr, cursor, ovn, ovl, lay.smax, lay.chunks, lay.cap, keys, vals, skeys, svals, gridtype, ac, interp);
+        const uint32_t items = lay.smax * nl;
+        hipLaunchKernelGGL((k_bin_accumulate6<T, D, C, FIXED24, P>), dim3(std::min(items, cus)), dim3(kBinAccThreads), kBinAccBytes, st,
+                           (const uint16_t*)keys, (const uint32_t*)vals, (const uint16_t*)skeys, (const uint32_t*)svals, offsets,
+                           grad_emb, B, l0, nl, hdr, done, cursor, ovn, (const uint2*)ovl, lay.smax, lay.chunks, lay.cap, t_found_inf);
+    }
+    t_reported = true;
+    return check_launch("grid_encode_backward");
+}
+
 template <typename T, uint32_t D, uint32_t C>
 int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets, uint32_t max_level_rows, T* grad_emb,
                       uint32_t B, uint32_t L, const LevelScales& sc, const T* dy_dx, T* grad_inputs, uint32_t gridtype, bool ac,
-                      uint32_t interp, unsigned char* ws, size_t ws_bytes, int force_path, hipStream_t st) {
+                      uint32_t interp, unsigned char* ws, size_t ws_bytes, int force_path, unsigned char* control, size_t control_bytes,
+                      hipStream_t st) {
     const BinLayout lay = bin_layout(B, D, C, L, max_level_rows, sizeof(T));
     const bool bin_ok = lay.ok && ws && ws_bytes >= lay.total;
     // 0 auto: binned for large batches; 1 direct atomics; 2 binned
-    const bool binned = bin_ok && (force_path == 2 || (force_path == 0 && B >= kBinnedMinPoints));
-    if constexpr (sizeof(T) * C == 4) {  // 8-byte records (fp16 C = 2, fp32 C = 1): second-generation kernels
+    const bool binned = bin_ok && (force_path >= 2 || (force_path == 0 && B >= kBinnedMinPoints));
+    if constexpr (sizeof(T) * C == 4) {  // one 32-bit value word per record (fp16 C = 2, fp32 C = 1)
+        const BinLayout3 lay3 = bin_layout3(B, D, C, L, max_level_rows, sizeof(T));
+        if (binned && force_path != 3 && lay3.ok && ws && ws_bytes >= lay3.total) {  // third generation: 6-byte records
+            int rc;
+            unsigned char* cb = (control && control_bytes >= bin3_control_bytes(lay3, L)) ? control : nullptr;
+            if (sizeof(T) == 2 && ((uint64_t)B << D) <= (1ull << 23))
+                rc = launch_binned3<T, D, C, true>(grad, inputs, offsets, grad_emb, B, L, sc, gridtype, ac, interp, ws, lay3, cb, st);
+            else
+                rc = launch_binned3<T, D, C, false>(grad, inputs, offsets, grad_emb, B, L, sc, gridtype, ac, interp, ws, lay3, cb, st);
+            if (rc != S3D_OK) return rc;
+            if (dy_dx && grad_inputs)
+                hipLaunchKernelGGL((k_grid_input_backward<T, D, C>), dim3(div_up<uint32_t>(B * D, 256)), dim3(256), 0, st, grad,
+                                   dy_dx, grad_inputs, B, L, sc.n_valid);
+            return check_launch("grid_encode_backward");
+        }
         const BinLayout2 lay2 = bin_layout2(B, D, C, L, max_level_rows, sizeof(T));
         if (binned && lay2.ok && ws && ws_bytes >= lay2.total) {
             int rc;
@@ -1741,16 +2418,17 @@ int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets
 template <typename T, uint32_t D>
 int launch_backward(const T* grad, const float* inputs, const int32_t* offsets, uint32_t max_level_rows,
                     T* grad_emb, uint32_t B, uint32_t C, uint32_t L, const LevelScales& sc, const T* dy_dx, T* grad_inputs, uint32_t gridtype,
-                    bool ac, uint32_t interp, unsigned char* ws, size_t ws_bytes, int force_path, hipStream_t st) {
+                    bool ac, uint32_t interp, unsigned char* ws, size_t ws_bytes, int force_path, unsigned char* control, size_t control_bytes,
+                    hipStream_t st) {
     switch (C) {
         case 1:
             if constexpr (sizeof(T) == 2) {
                 set_error("GridEncoding: fp16 tables need an even C (the reference forces fp32 when C is odd, grid.py:42)");
                 return S3D_ERR_UNSUPPORTED;
-            } else return launch_backward_c<T, D, 1>(grad, inputs, offsets, max_level_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
-        case 2: return launch_backward_c<T, D, 2>(grad, inputs, offsets, max_level_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
-        case 4: return launch_backward_c<T, D, 4>(grad, inputs, offsets, max_level_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
-        case 8: return launch_backward_c<T, D, 8>(grad, inputs, offsets, max_level_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, st);
+            } else return launch_backward_c<T, D, 1>(grad, inputs, offsets, max_level_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, control, control_bytes, st);
+        case 2: return launch_backward_c<T, D, 2>(grad, inputs, offsets, max_level_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, control, control_bytes, st);
+        case 4: return launch_backward_c<T, D, 4>(grad, inputs, offsets, max_level_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, control, control_bytes, st);
+        case 8: return launch_backward_c<T, D, 8>(grad, inputs, offsets, max_level_rows, grad_emb, B, L, sc, dy_dx, grad_inputs, gridtype, ac, interp, ws, ws_bytes, force_path, control, control_bytes, st);
         default: set_error("GridEncoding: C must be 1, 2, 4, or 8."); return S3D_ERR_UNSUPPORTED;
     }
 }
@@ -1773,6 +2451,20 @@ int launch_tv(const float* inputs, const float* emb, float* grad, const int32_t*
 }  // namespace s3d
 
 using namespace s3d;
+
+#ifdef S3D_BIN3_PROF
+S3D_EXPORT int s3d_debug_prof_read(unsigned long long* dst, size_t bytes, int clear) {
+    if (hipDeviceSynchronize() != hipSuccess) return S3D_ERR_HIP;
+    if (bytes > sizeof(unsigned long long) * 2 * 16384 * 8) bytes = sizeof(unsigned long long) * 2 * 16384 * 8;
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(s3d_prof_buf), bytes) != hipSuccess) return S3D_ERR_HIP;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(s3d_prof_buf)) != hipSuccess) return S3D_ERR_HIP;
+        if (hipMemset(p, 0, sizeof(unsigned long long) * 2 * 16384 * 8) != hipSuccess) return S3D_ERR_HIP;
+    }
+    return S3D_OK;
+}
+#endif
 
 S3D_EXPORT void s3d_grid_level_scales(uint32_t L, float S, uint32_t H, float* scales_out) {
     LevelScales sc;
@@ -1852,8 +2544,14 @@ S3D_EXPORT size_t s3d_grid_encode_backward_workspace_size(uint32_t B, uint32_t D
                                                           int dtype) {
     const BinLayout lay = bin_layout(B, D, C, L, max_level_rows, dtype == S3D_F16 ? 2u : 4u);
     const BinLayout2 lay2 = bin_layout2(B, D, C, L, max_level_rows, dtype == S3D_F16 ? 2u : 4u);
-    const size_t a = lay.ok ? lay.total : 0, b = lay2.ok ? lay2.total : 0;
-    return a > b ? a : b;
+    const BinLayout3 lay3 = bin_layout3(B, D, C, L, max_level_rows, dtype == S3D_F16 ? 2u : 4u);
+    const size_t a = lay.ok ? lay.total : 0, b = lay2.ok ? lay2.total : 0, c = lay3.ok ? lay3.total : 0;
+    return std::max(a, std::max(b, c));
+}
+
+S3D_EXPORT size_t s3d_grid_encode_backward_control_size(uint32_t D, uint32_t C, uint32_t L, uint32_t max_level_rows, int dtype) {
+    const BinLayout3 lay3 = bin_layout3(1u << 16, D, C, L, max_level_rows, dtype == S3D_F16 ? 2u : 4u);  // (the block does not depend on B)
+    return lay3.ok ? bin3_control_bytes(lay3, L) : 0;
 }
 
 S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, const void* embeddings,
@@ -1862,16 +2560,16 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
                                         const void* dy_dx, void* grad_inputs, uint32_t gridtype, int align_corners,
                                         uint32_t interp, int dtype, void* workspace, size_t workspace_bytes,
                                         float bound, const int32_t* n_valid, int path, float* found_inf,
-                                        s3d_stream_t stream) {
+                                        void* control, size_t control_bytes, s3d_stream_t stream) {
     // path: 0 = auto (binned from 8,192 points), 1 = direct global atomics, 2 = binned (partition + LDS accumulate)
     (void)embeddings;
-    S3D_REQUIRE(path >= 0 && path <= 2, "grid_encode_backward: path must be 0 (auto), 1 (atomics) or 2 (binned)");
+    S3D_REQUIRE(path >= 0 && path <= 3, "grid_encode_backward: path must be 0 (auto), 1 (atomics), 2 (binned) or 3 (binned, 8-byte records)");
     S3D_REQUIRE(bound >= 0.0f && !(bound != 0.0f && dy_dx), "grid_encode_backward: bound must be >= 0 and 0 with an input Jacobian");
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null pointer");
     S3D_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_backward: L must be in [1, %u]", kMaxLevels);
     S3D_REQUIRE(dtype == S3D_F32 || dtype == S3D_F16, "grid_encode_backward: dtype must be f32 or f16");
-    if (path == 2) {
+    if (path >= 2) {
         const BinLayout lay = bin_layout(B, D, C, L, max_level_rows, dtype == S3D_F16 ? 2u : 4u);
         S3D_REQUIRE(lay.ok && workspace && workspace_bytes >= lay.total,
                     "grid_encode_backward: the binned path needs max_level_rows and a workspace of "
@@ -1882,6 +2580,7 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
     hipStream_t st = as_stream(stream);
     const bool ac = align_corners != 0;
     unsigned char* ws = (unsigned char*)workspace;
+    unsigned char* cb = (unsigned char*)control;
     const int fp = path;
     t_found_inf = found_inf;
     t_reported = false;
@@ -1889,17 +2588,17 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
     if (dtype == S3D_F32) {
         const float* g = (const float*)grad; float* ge = (float*)grad_embeddings;
         const float* j = (const float*)dy_dx; float* gi = (float*)grad_inputs;
-        S3D_DISPATCH_D(D, (launch_backward<float, 2>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
-                       (launch_backward<float, 3>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
-                       (launch_backward<float, 4>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
-                       (launch_backward<float, 5>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)))
+        S3D_DISPATCH_D(D, (launch_backward<float, 2>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, cb, control_bytes, st)),
+                       (launch_backward<float, 3>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, cb, control_bytes, st)),
+                       (launch_backward<float, 4>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, cb, control_bytes, st)),
+                       (launch_backward<float, 5>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, cb, control_bytes, st)))
     } else {
         const __half* g = (const __half*)grad; __half* ge = (__half*)grad_embeddings;
         const __half* j = (const __half*)dy_dx; __half* gi = (__half*)grad_inputs;
-        S3D_DISPATCH_D(D, (launch_backward<__half, 2>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
-                       (launch_backward<__half, 3>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
-                       (launch_backward<__half, 4>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)),
-                       (launch_backward<__half, 5>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, st)))
+        S3D_DISPATCH_D(D, (launch_backward<__half, 2>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, cb, control_bytes, st)),
+                       (launch_backward<__half, 3>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, cb, control_bytes, st)),
+                       (launch_backward<__half, 4>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, cb, control_bytes, st)),
+                       (launch_backward<__half, 5>(g, inputs, offsets, max_level_rows, ge, B, C, L, sc, j, gi, gridtype, ac, interp, ws, workspace_bytes, fp, cb, control_bytes, st)))
     }
     };
     const int rc = run();

@@ -33,7 +33,7 @@ EXPORTS = [
     "s3d_composite_rays_train_forward", "s3d_composite_rays_train_backward",
     "s3d_march_rays", "s3d_composite_rays", "s3d_compact_alive_workspace_size", "s3d_compact_alive",
     "s3d_grid_level_scales", "s3d_grid_encode_forward", "s3d_grid_corner_indices", "s3d_grid_encode_backward",
-    "s3d_grid_encode_backward_workspace_size",
+    "s3d_grid_encode_backward_workspace_size", "s3d_grid_encode_backward_control_size",
     "s3d_grad_total_variation",
     "s3d_sh_encode_forward", "s3d_sh_encode_backward", "s3d_freq_encode_forward", "s3d_freq_encode_backward",
     "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
@@ -71,6 +71,7 @@ def lib():
         l.s3d_version.restype = C.c_char_p
         for name in ("s3d_march_rays_train_workspace_size", "s3d_compact_alive_workspace_size",
                      "s3d_ffmlp_backward_workspace_size", "s3d_grid_encode_backward_workspace_size",
+                     "s3d_grid_encode_backward_control_size",
                      "s3d_sweep_update_workspace_size"):
             getattr(l, name).restype = C.c_size_t
         l.s3d_vm_backward_max_bins.restype = C.c_uint32
@@ -216,6 +217,35 @@ class _Workspace:
 
 
 _ws = _Workspace()
+
+
+class _ControlBlocks:
+    """Zero-filled, self-cleaning control blocks of the binned grid backward (include/seal3d_hip.h: `control`), one per
+    device, allocated OUTSIDE graph captures only: a block first requested while the stream is capturing would live in
+    that graph's private pool (see _Workspace), so the call then runs without one (the library clears its control words
+    with a launch of its own, as it does for any caller that passes none).  One block per device, not per stream: a
+    captured step replays on whatever stream its owner picks, and the binding's callers issue their grid backwards in
+    stream order (two of them running concurrently on different streams of one device would have to bring their own)."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes, device):
+        if nbytes <= 0:
+            return None
+        b = self.buf.get(device.index)
+        if b is not None and b.numel() >= nbytes:
+            return b
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        if b is not None:
+            torch.cuda.synchronize(device)  # (the old block may be in use by queued work)
+        b = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+        self.buf[device.index] = b
+        return b
+
+
+_ctl = _ControlBlocks()
 
 
 def level_scales(L, S, H):
@@ -430,12 +460,15 @@ class GridBackend:
         mlr = _max_level_rows(offsets)
         ws = _ws.get(lib().s3d_grid_encode_backward_workspace_size(_u(B), _u(D), _u(Cc), _u(L), _u(mlr),
                                                                    C.c_int(_dt(grad))), grad.device)
+        ctl = _ctl.get(lib().s3d_grid_encode_backward_control_size(_u(D), _u(Cc), _u(L), _u(mlr), C.c_int(_dt(grad))),
+                       grad.device) if B >= 8192 else None
         _check(lib().s3d_grid_encode_backward(_p(grad), _p(inputs), _p(embeddings), _p(offsets),
                                               _p(grad_embeddings), _u(mlr), _u(B), _u(D),
                                               _u(Cc), _u(L), _f(S), _u(H), _p(dy_dx), _p(grad_inputs), _u(gridtype),
                                               C.c_int(int(align_corners)), _u(interp), C.c_int(_dt(grad)), _p(ws),
                                               C.c_size_t(ws.numel()), _f(bound), _nv(n_valid),
-                                              C.c_int(GridBackend._backward_path), _p(found_inf), _stream()),
+                                              C.c_int(GridBackend._backward_path), _p(found_inf), _p(ctl),
+                                              C.c_size_t(ctl.numel() if ctl is not None else 0), _stream()),
                "grid_encode_backward")
 
     _backward_path = 0  # `path` argument of s3d_grid_encode_backward (binding-side state for tests / experiments)

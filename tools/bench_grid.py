@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--no_fwd", action="store_true")
     ap.add_argument("--sum", action="store_true")
     ap.add_argument("--cold", action="store_true", help="thrash L2/MALL before every timed launch")
+    ap.add_argument("--bwd_path", type=int, default=0, help="`path` of s3d_grid_encode_backward (3 = the 8-byte-record generation)")
     a = ap.parse_args()
     if a.cold:
         global timeit
@@ -109,6 +110,7 @@ def main():
     dev = "cuda"
     torch.manual_seed(0)
     G = s3d_hip.GridBackend
+    G.set_backward_path(a.bwd_path)
     offs, S, total = grid_meta(dev)
     emb = (torch.rand(total, 2, device=dev) * 2 - 1).half()
     print("device:", torch.cuda.get_device_name(0), " S3D_GRID_FWD=", os.environ.get("S3D_GRID_FWD", ""), " S3D_GRID_BWD=",
@@ -123,8 +125,9 @@ def main():
                       + (f"  sum={out.float().double().sum().item():.10e} absum={out.float().abs().double().sum().item():.10e}" if a.sum else ""))
             if not a.no_bwd:
                 grad = (torch.randn(16, B, 2, device=dev) * 1e-3).half()
-                if order == "ray":  # samples behind a ray's termination carry exact-zero gradients in training
-                    grad[:, torch.rand(B, device=dev) < 0.2] = 0
+                if order == "ray":  # samples behind a ray's termination carry exact-zero gradients in training: the last
+                    # fifth of every 64-sample stretch (a ray of the Lego step has ~64 samples), not scattered singles
+                    grad[:, (torch.arange(B, device=dev) % 64) >= 51] = 0
                 ge = torch.zeros(total, 2, device=dev, dtype=torch.half)
 
                 def bwd():
