@@ -1582,7 +1582,7 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
     uint32_t* lo = cnt + kBinMaxSlices;                               // run start in the chunk's sorted order
     uint2* tab = reinterpret_cast<uint2*>(lo + kBinMaxSlices);        // {bucket position of the run - run start, run start | records that fit << 16}
     uint2* stage = tab + kBinMaxSlices;                               // [P * K] {value, slice << 16 | row-in-slice}
-    __shared__ uint32_t total_s, arrived;
+    __shared__ uint32_t total_s, arrived, spilled_s;
 
     const uint32_t lip = S3D_BIN3_LEVEL_FAST ? blockIdx.x : blockIdx.y;  // level inside the pass
     const uint32_t level = level0 + lip, chunk = S3D_BIN3_LEVEL_FAST ? blockIdx.y : blockIdx.x;
@@ -1612,7 +1612,7 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
     LevelIndex<D> li;
     li.init(gridtype, align_corners, hashmap_size, (uint32_t)ceilf(lscale) + 1);
     for (uint32_t s = threadIdx.x; s < S; s += P) cnt[s] = 0;
-    if (threadIdx.x == 0) arrived = 0;
+    if (threadIdx.x == 0) { arrived = 0; spilled_s = 0; }
     lds_barrier();  // counters cleared before anybody ranks a record (all waves are at their start: the barrier is free)
     if (in) {
 #pragma unroll
@@ -1634,13 +1634,20 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
     uint32_t pg[D];
     locate<D>(x, lscale, align_corners, interp, pos, pd, pg);
     float v[K * C];
+    float gf[C];
+    bool gbad = false;  // a non-finite gradient on an active lane poisons the level (FIXED24)
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) {
+        gf[c] = active ? Acc<T>::to_f(g[c]) : 0.0f;  // (inactive lanes: zero products, whatever their position)
+        gbad |= !(fabsf(gf[c]) <= 3.402823466e38f);
+    }
 #pragma unroll
     for (uint32_t idx = 0; idx < K; idx++) {
         float w = 1;
 #pragma unroll
         for (uint32_t d = 0; d < D; d++) w *= ((idx >> d) & 1u) ? pos[d] : 1 - pos[d];
 #pragma unroll
-        for (uint32_t c = 0; c < C; c++) v[idx * C + c] = active ? w * Acc<T>::to_f(g[c]) : 0.0f;
+        for (uint32_t c = 0; c < C; c++) v[idx * C + c] = w * gf[c];
     }
     // run = maximal stretch of consecutive ACTIVE lanes of the wave in one cell.  An inactive lane (zero gradient, out of
     // range) ends the run before it: in training those are the samples behind a ray's termination, i.e. the tail of a ray,
@@ -1661,7 +1668,19 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
     S3D_STAMP(0, wg_lin, 2);
 
     uint32_t key[K], rank[K], val[K];
-    bool bad = false;
+    if constexpr (FIXED24) {
+        // hdr[level]: 0 = every record of the level is below 64 in magnitude (the accumulate converts with one multiply and one
+        // conversion), 1 = larger values present (general conversion), NaN pattern = a record is non-finite after rounding
+        // to binary16 (|sum| >= 65520 or a non-finite gradient): the level is poisoned like a float sum would be.
+        // One maximum per lane instead of a test per record; at most one atomic per wave.
+        float m = 0.0f;
+#pragma unroll
+        for (uint32_t i = 0; i < K * C; i++) m = fmaxf(m, fabsf(v[i]));
+        const bool bad = (active && gbad) || (tail && m >= 65520.0f);
+        const bool big = tail && m >= 64.0f;
+        const unsigned long long anybad = __ballot(bad), anybig = __ballot(big);
+        if ((anybad | anybig) && lane == 0) atomicMax(hdr + level, anybad ? 0x7fc00000u : 1u);
+    }
     if (tail) {
         uint32_t lo_[D];
 #pragma unroll
@@ -1676,14 +1695,11 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
             for (uint32_t c = 0; c < C; c++) pr[c] = Acc<T>::from_f(v[idx * C + c]);
             uint32_t bits;
             __builtin_memcpy(&bits, pr, 4);
-            if constexpr (FIXED24)  // inf / NaN after rounding to binary16: an all-ones exponent in either half
-                bad |= ((bits & 0x7c00u) == 0x7c00u) || ((bits & 0x7c000000u) == 0x7c000000u);
             key[idx] = (slice << 16) | ((grp >> sshift) * kBinGroup + row % kBinGroup);
             rank[idx] = atomicAdd(&cnt[slice], 1u);
             val[idx] = bits;
         }
     }
-    if (FIXED24 && bad) atomicMax(hdr + level, 0x7fc00000u);  // poison marker (a NaN pattern sorts above every finite value)
     // the last wave to arrive (its arrival is ordered behind every wave's rank atomics) finds the run starts and puts the
     // bucket reservations in flight; everybody else goes straight to the barrier
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -1735,6 +1751,7 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
                 const uint32_t ft = a >= cap ? 0u : (cap - a < c ? cap - a : c);
                 tab[sl] = make_uint2((uint32_t)((int32_t)((sl * kBin3Sub + sub) * cap + a) - (int32_t)l0), l0 | (ft << 16));
                 if (ft < c) {
+                    spilled_s = 1u;  // (benign race: every writer stores 1)
                     const uint32_t k = atomicAdd(&ovn[level * smax + sl], 1u);
                     ovl[((size_t)level * smax + sl) * nchunks + k] = make_uint2((chunk << 16) | (l0 + ft), c - ft);
                 }
@@ -1744,29 +1761,57 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
     lds_barrier();
     S3D_STAMP(0, wg_lin, 5);
     const uint32_t total = total_s;
-    const size_t bucket0 = (size_t)lip * smax * kBin3Sub * cap;
-    const size_t mine = ((size_t)lip * nchunks + chunk) * (P * K);
+    // (uniform bases + 32-bit record indices: the stores take the scalar-base form, no 64-bit address arithmetic per record)
+    uint16_t* const gk = gkeys + (size_t)lip * smax * kBin3Sub * cap;
+    uint32_t* const gv = gvals + (size_t)lip * smax * kBin3Sub * cap;
+    uint16_t* const sk = skeys + ((size_t)lip * nchunks + chunk) * (P * K);
+    uint32_t* const sv = svals + ((size_t)lip * nchunks + chunk) * (P * K);
     constexpr uint32_t UC = 4;
-    for (uint32_t i0 = threadIdx.x; i0 < total; i0 += UC * P) {
-        uint2 r[UC], t[UC];
+    if (!spilled_s) {
+        // every run fits its bucket (the rule; tested once per workgroup, not per record): position = sorted index + the
+        // run's bucket offset
+        for (uint32_t i0 = threadIdx.x; i0 < total; i0 += UC * P) {
+            uint2 r[UC];
+            uint32_t gd[UC];
 #pragma unroll
-        for (uint32_t u = 0; u < UC; u++) {
-            const uint32_t i = i0 + u * P;
-            r[u] = stage[i < total ? i : 0];
+            for (uint32_t u = 0; u < UC; u++) {
+                const uint32_t i = i0 + u * P;
+                r[u] = stage[i < total ? i : 0];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < UC; u++) gd[u] = tab[r[u].y >> 16].x;
+#pragma unroll
+            for (uint32_t u = 0; u < UC; u++) {
+                const uint32_t i = i0 + u * P;
+                if (i < total) {
+                    const uint32_t p = i + gd[u];  // (mod 2^32: gd = bucket position - run start)
+                    gk[p] = (uint16_t)r[u].y;
+                    gv[p] = r[u].x;
+                }
+            }
         }
+    } else {
+        for (uint32_t i0 = threadIdx.x; i0 < total; i0 += UC * P) {
+            uint2 r[UC], t[UC];
 #pragma unroll
-        for (uint32_t u = 0; u < UC; u++) t[u] = tab[r[u].y >> 16];
+            for (uint32_t u = 0; u < UC; u++) {
+                const uint32_t i = i0 + u * P;
+                r[u] = stage[i < total ? i : 0];
+            }
 #pragma unroll
-        for (uint32_t u = 0; u < UC; u++) {
-            const uint32_t i = i0 + u * P;
-            if (i < total) {
-                if (i - (t[u].y & 0xffffu) < (t[u].y >> 16)) {
-                    const size_t p = bucket0 + (size_t)((int32_t)i + (int32_t)t[u].x);
-                    gkeys[p] = (uint16_t)r[u].y;
-                    gvals[p] = r[u].x;
-                } else {
-                    skeys[mine + i] = (uint16_t)r[u].y;
-                    svals[mine + i] = r[u].x;
+            for (uint32_t u = 0; u < UC; u++) t[u] = tab[r[u].y >> 16];
+#pragma unroll
+            for (uint32_t u = 0; u < UC; u++) {
+                const uint32_t i = i0 + u * P;
+                if (i < total) {
+                    if (i - (t[u].y & 0xffffu) < (t[u].y >> 16)) {
+                        const uint32_t p = i + t[u].x;
+                        gk[p] = (uint16_t)r[u].y;
+                        gv[p] = r[u].x;
+                    } else {
+                        sk[i] = (uint16_t)r[u].y;
+                        sv[i] = r[u].x;
+                    }
                 }
             }
         }
@@ -1833,7 +1878,8 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate6(const uint16
         auto row_of_local = [&](uint32_t local) { return ((local / kBinGroup) * S + slice) * kBinGroup + local % kBinGroup; };
         T* table = grad_grid + (size_t)off * C;
         const float amax = __uint_as_float(hbits);
-        const bool poisoned = FIXED24 ? hbits != 0u : (amax != amax || amax == INFINITY);
+        const bool poisoned = FIXED24 ? hbits >= 0x7f800000u : (amax != amax || amax == INFINITY);
+        const bool small = FIXED24 && hbits == 0u;  // every record of the level below 64: v * 2^24 fits 31 bits
         // the control words of this item go back to zero (all of its readers — this workgroup's lanes — hold them in registers;
         // the barrier below, or the end of the kernel, orders the stores behind the loads)
         const bool touched = reserved != 0u;  // (a spilled run implies a reservation)
@@ -1861,16 +1907,19 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate6(const uint16
             kexp = 62 - e - (int)(32 - __clz(B)) - (int)D;
         }
         const size_t base = (((size_t)lip * smax + slice) * NS + sj) * cap;  // cap is a multiple of 64: 8- / 16-byte aligned
-        auto add = [&](uint32_t key, uint32_t bits) {
+        auto add_t = [&](auto small_c, uint32_t key, uint32_t bits) {
             T pr[C];
             __builtin_memcpy(pr, &bits, 4);
 #pragma unroll
             for (uint32_t c = 0; c < C; c++) {
                 const float v = Acc<T>::to_f(pr[c]);
-                const long long q = FIXED24 ? fixed24_exact(v) : to_fixed64(v, kexp);
+                long long q;
+                if constexpr (decltype(small_c)::value) q = (long long)(int)(v * 16777216.0f);  // exact: a multiple of 2^-24 below 64
+                else q = FIXED24 ? fixed24_exact(v) : to_fixed64(v, kexp);
                 atomicAdd(&acc[c * local_rows + key], (unsigned long long)q);
             }
         };
+        auto add = [&](uint32_t key, uint32_t bits) { add_t(std::false_type{}, key, bits); };
         struct Quad { uint2 k; uint4 v; uint32_t n; };
         auto fetch = [&](uint32_t qi) {
             Quad q;
@@ -1884,11 +1933,17 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate6(const uint16
             }
             return q;
         };
-        auto consume = [&](const Quad& q) {
-            if (q.n > 0) add(q.k.x & 0xffffu, q.v.x);
-            if (q.n > 1) add(q.k.x >> 16, q.v.y);
-            if (q.n > 2) add(q.k.y & 0xffffu, q.v.z);
-            if (q.n > 3) add(q.k.y >> 16, q.v.w);
+        auto consume = [&](auto small_c, const Quad& q) {
+            if (q.n == 4) {  // (all but the last group of a sub-bucket)
+                add_t(small_c, q.k.x & 0xffffu, q.v.x);
+                add_t(small_c, q.k.x >> 16, q.v.y);
+                add_t(small_c, q.k.y & 0xffffu, q.v.z);
+                add_t(small_c, q.k.y >> 16, q.v.w);
+            } else {
+                if (q.n > 0) add_t(small_c, q.k.x & 0xffffu, q.v.x);
+                if (q.n > 1) add_t(small_c, q.k.x >> 16, q.v.y);
+                if (q.n > 2) add_t(small_c, q.k.y & 0xffffu, q.v.z);
+            }
         };
         S3D_STAMP(1, wg_lin, 1);
         // the first batch of records and the table rows of the write-out's first round are in flight while the accumulators
@@ -1915,15 +1970,19 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate6(const uint16
         }
         __syncthreads();  // accumulators clear (this item's fill, or the previous item's write-out)
         S3D_STAMP(1, wg_lin, 2);
-        for (uint32_t b0 = 0; b0 < nquads; b0 += U * STEP) {  // (wave-uniform trip count)
-            Quad nx[U];
+        auto stream = [&](auto small_c) {
+            for (uint32_t b0 = 0; b0 < nquads; b0 += U * STEP) {  // (wave-uniform trip count)
+                Quad nx[U];
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) nx[u] = fetch(b0 + q0 + (U + u) * STEP);
+                for (uint32_t u = 0; u < U; u++) nx[u] = fetch(b0 + q0 + (U + u) * STEP);
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) consume(cur[u]);
+                for (uint32_t u = 0; u < U; u++) consume(small_c, cur[u]);
 #pragma unroll
-            for (uint32_t u = 0; u < U; u++) cur[u] = nx[u];
-        }
+                for (uint32_t u = 0; u < U; u++) cur[u] = nx[u];
+            }
+        };
+        if (small) stream(std::true_type{});
+        else stream(std::false_type{});
         S3D_STAMP(1, wg_lin, 3);
         // spilled runs (clustered samples only): one wave per descriptor
         for (uint32_t k = threadIdx.x >> 6; k < nspill; k += kBinAccThreads / 64) {
@@ -1933,12 +1992,16 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate6(const uint16
         }
         __syncthreads();
         S3D_STAMP(1, wg_lin, 4);
-        for (uint32_t r0 = threadIdx.x; r0 < local_rows; r0 += W * kBinAccThreads) {
-            long long q[W][C];
-            V old[W];
-            bool nz[W];
+        // write-out in rounds of WR rows per lane; the first W / WR rounds use the rows requested before the streaming phase
+        constexpr uint32_t WR = 4;
+        static_assert(W % WR == 0, "prefetched rows are consumed in whole rounds");
+        uint32_t round = 0;
+        for (uint32_t r0 = threadIdx.x; r0 < local_rows; r0 += WR * kBinAccThreads, round++) {
+            long long q[WR][C];
+            V old[WR];
+            bool nz[WR];
 #pragma unroll
-            for (uint32_t w = 0; w < W; w++) {
+            for (uint32_t w = 0; w < WR; w++) {
                 const uint32_t rr = r0 + w * kBinAccThreads;
                 nz[w] = false;
                 if (rr < local_rows) {
@@ -1950,23 +2013,27 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate6(const uint16
                 }
             }
 #pragma unroll
-            for (uint32_t w = 0; w < W; w++) {  // clear behind the read: the next item finds zeros
+            for (uint32_t w = 0; w < WR; w++) {  // clear behind the read: the next item finds zeros
                 const uint32_t rr = r0 + w * kBinAccThreads;
                 if (nz[w]) {
 #pragma unroll
                     for (uint32_t c = 0; c < C; c++) acc[c * local_rows + rr] = 0ull;
                 }
             }
-            if (r0 == threadIdx.x) {
+            if (round < W / WR) {
 #pragma unroll
-                for (uint32_t w = 0; w < W; w++) old[w] = old0[w];
+                for (uint32_t k = 0; k < W / WR; k++)
+                    if (round == k) {
+#pragma unroll
+                        for (uint32_t w = 0; w < WR; w++) old[w] = old0[k * WR + w];
+                    }
             } else {
 #pragma unroll
-                for (uint32_t w = 0; w < W; w++)
+                for (uint32_t w = 0; w < WR; w++)
                     if (nz[w]) old[w] = *reinterpret_cast<const V*>(table + (size_t)row_of_local(r0 + w * kBinAccThreads) * C);
             }
 #pragma unroll
-            for (uint32_t w = 0; w < W; w++) {
+            for (uint32_t w = 0; w < WR; w++) {
                 if (nz[w]) {
                     T o[C];
                     __builtin_memcpy(o, &old[w], sizeof(V));

@@ -277,3 +277,108 @@ def test_grid_backward_binned_training_size_vs_oracle(oracle, hip, dtype):
         # is a random walk of its contributions' roundings — bounded here by 2e-3 of the largest row plus 2e-3 relative
         torch.testing.assert_close(got, ge_ref, rtol=2e-3, atol=2e-3 * scale)
     assert int((got != 0).any(1).sum()) > 10000
+
+
+def _ray_points(n_rays, n_steps, seed):
+    g = torch.Generator().manual_seed(seed)
+    o = torch.rand(n_rays, 3, generator=g) * 0.2 + 0.05
+    d = torch.nn.functional.normalize(torch.rand(n_rays, 3, generator=g) + 0.1, dim=-1)
+    t = torch.arange(n_steps).float() * (3.383e-3 / 2)
+    return (o[:, None, :] + d[:, None, :] * t[None, :, None]).reshape(-1, 3).contiguous(), g
+
+
+def test_grid_backward_fp16_large_values_and_clean_control_block(oracle, hip):
+    """Third-generation binned backward, fp16: (1) records of 64 and more in magnitude take the general fixed-point conversion
+    (the level's header word says so) and still match the oracle's fp32 sum; (2) a non-finite gradient poisons ITS level
+    only and raises found_inf; (3) the self-cleaning control block is all-zero again after each of these calls, so the
+    plain call that follows is bit-identical to the one before."""
+    D, L, C, base = 3, 16, 2, 16
+    offsets, S, total = _enc_meta(D, L, C, base, 19, 2048, False)
+    x, g = _ray_points(400, 64, seed=21)
+    B = x.shape[0]
+    emb = torch.zeros(total, C, dtype=torch.float16)
+    og, xg = offsets.cuda(), x.cuda()
+
+    def run(grad, found=None):
+        ge = torch.zeros(total, C, dtype=torch.float16, device="cuda")
+        hip.GridBackend.grid_encode_backward(grad.cuda(), xg, emb.cuda(), og, ge, B, D, C, L, S, base, None, None, 0, False, 0,
+                                             found_inf=found)
+        return ge.cpu()
+
+    def ref(grad):
+        r = torch.zeros(total, C, dtype=torch.float32)
+        oracle.GridBackend.grid_encode_backward(grad.float(), x, emb.float(), offsets, r, B, D, C, L, S, base, None, None, 0, False, 0)
+        return r
+
+    small = (torch.randn(L, B, C, generator=g) * 1e-2).half()
+    small[:, (torch.arange(B) % 64) >= 50] = 0            # ray tails behind the termination
+    a0 = run(small)
+    r0 = ref(small)
+    torch.testing.assert_close(a0.float(), r0, rtol=2e-3, atol=2e-3 * float(r0.abs().max()))
+    # (1) large records on some levels: |v| up to ~400 (level 3 and 9), the rest small
+    big = small.clone()
+    big[3] = (torch.randn(B, C, generator=g) * 100).half()
+    big[9] = (torch.randn(B, C, generator=g) * 100).half()
+    big[:, (torch.arange(B) % 64) >= 50] = 0
+    a1 = run(big)
+    r1 = ref(big)
+    for l in range(L):
+        sl = slice(int(offsets[l]), int(offsets[l + 1]))
+        torch.testing.assert_close(a1[sl].float(), r1[sl], rtol=2e-3, atol=2e-3 * float(r1[sl].abs().max()))
+    assert torch.equal(run(small).view(torch.int16), a0.view(torch.int16)), "control block not clean after the large-value call"
+    # (2) non-finite gradient on level 5
+    bad = small.clone()
+    bad[5, 1234, 1] = float("inf")
+    found = torch.zeros(1, device="cuda")
+    a2 = run(bad, found)
+    assert float(found) == 1.0
+    lv = a2[int(offsets[5]):int(offsets[6])]
+    assert torch.isnan(lv.float()).all(), "non-finite gradient must poison its level"
+    keep = torch.ones(total, dtype=torch.bool)
+    keep[int(offsets[5]):int(offsets[6])] = False
+    assert torch.equal(a2[keep].view(torch.int16), a0[keep].view(torch.int16)), "other levels must be untouched by the poison"
+    # (3) ... and the next call is clean again
+    assert torch.equal(run(small).view(torch.int16), a0.view(torch.int16)), "control block not clean after the poisoned call"
+    # a merged run whose sum leaves binary16 (64 samples of one cell, 2000 each): poisoned as well
+    xs = torch.full((8192, 3), 0.31)
+    gs = torch.zeros(L, 8192, C, dtype=torch.float16)
+    gs[0] = 2000.0
+    ge = torch.zeros(total, C, dtype=torch.float16, device="cuda")
+    found.zero_()
+    hip.GridBackend.grid_encode_backward(gs.cuda(), xs.cuda(), emb.cuda(), og, ge, 8192, D, C, L, S, base, None, None, 0, False, 0,
+                                         found_inf=found)
+    assert float(found) == 1.0 and torch.isnan(ge[: int(offsets[1])].float()).all()
+    assert torch.equal(run(small).view(torch.int16), a0.view(torch.int16))
+
+
+def test_grid_backward_binned_inside_graph_capture(hip):
+    """The binned backward captured into a HIP graph (the control block comes from the binding, allocated outside the
+    capture): replays are bit-identical to the eager call."""
+    D, L, C, base = 3, 16, 2, 16
+    offsets, S, total = _enc_meta(D, L, C, base, 19, 2048, False)
+    x, g = _ray_points(300, 64, seed=5)
+    B = x.shape[0]
+    grad = (torch.randn(L, B, C, generator=g) * 1e-2).half().cuda()
+    xg, og = x.cuda(), offsets.cuda()
+    emb = torch.zeros(total, C, dtype=torch.float16, device="cuda")
+    ge = torch.zeros(total, C, dtype=torch.float16, device="cuda")
+
+    def call():
+        hip.GridBackend.grid_encode_backward(grad, xg, emb, og, ge, B, D, C, L, S, base, None, None, 0, False, 0)
+    call()
+    want = ge.clone()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        ge.zero_()
+        call()
+    torch.cuda.current_stream().wait_stream(st)
+    graph = torch.cuda.CUDAGraph()
+    ge.zero_()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        call()
+    for _ in range(3):
+        ge.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(ge.view(torch.int16), want.view(torch.int16))
