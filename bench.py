@@ -454,6 +454,30 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         elapsed, samples = float(mx[0]), float(tt[1])
 
+    # data-parallel runs: what the gradient all-reduce costs on its own on every rank (eager, outside the timed region), and how
+    # many ranks actually took part — so that a scaling curve can be read against the wire time
+    dp_info = None
+    if dp is not None:
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)
+        for _ in range(3):
+            dp.allreduce_grads()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        for _ in range(10):
+            dp.allreduce_grads()
+        a1.record()
+        torch.cuda.synchronize()
+        mine = torch.tensor([a0.elapsed_time(a1) / 10], dtype=torch.float32, device=dev)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        nbytes = sum(h.numel() * h.element_size() for h in dp.half_grads) + (dp.flat.numel() * 4 if dp.flat is not None else 0)
+        dp_info = {"n_ranks_seen": int(seen.item()), "allreduce_ms_per_rank": [round(float(t.item()), 4) for t in per_rank],
+                   "gradient_bytes": int(nbytes), "collectives_in_graph": bool(getattr(trainer, "collectives_in_graph", False)),
+                   "reduce_op": "avg (in the collective)" if dp.fused_avg() else "sum + divide"}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -545,10 +569,13 @@ def main():
                                "Seal NGP net (two hash encoders + nn.Linear MLPs), 800x800 cameras, 4096 rays/step/GPU",
                    "num_rays_per_gpu": args.num_rays, "samples_per_step": samples / args.steps / world,
                    "parallelism": f"ray-sharded dp{world}", "pretrain_steps": args.pretrain,
-                   "launch": ("hip-graph replay" + (" (fwd+bwd | all-reduce | optimizer)" if dp is not None else "")) if graphed else "eager"},
+                   "launch": ("hip-graph replay" + ((" (one graph incl. the RCCL all-reduce)" if getattr(trainer, "collectives_in_graph", False)
+                                                  else " (fwd+bwd | all-reduce | optimizer)") if dp is not None else "")) if graphed else "eager"},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     line.update(extra)
+    if dp_info is not None:
+        line["data_parallel"] = dp_info
     if dist.is_initialized():
         dist.destroy_process_group()
     # RCCL writes a version banner to C stdout, which is flushed at exit — after Python's buffer.  Flush it now so the

@@ -81,6 +81,9 @@ class NativeAdam(torch.optim.Optimizer):
                         for group in self.param_groups for p in group["params"] if getattr(p, "_s3d_grad", None) is not None)
             if dirty:
                 self.flat_half.zero_()
+            # (under graph capture this decision is frozen into the graph: a capture that finds the buffer clean records no
+            #  fill and relies on every replay being preceded by a consuming step — GraphedTrainer._replay checks the flags
+            #  again on the host before each replay, clear_unconsumed())
         for group in self.param_groups:
             for p in group["params"]:
                 if getattr(p, "_s3d_grad", None) is not None:
@@ -92,6 +95,23 @@ class NativeAdam(torch.optim.Optimizer):
                         p.grad = None
                     else:
                         p.grad.zero_()
+
+    def clear_unconsumed(self):
+        """Gradients written into the hand-over buffer and NOT consumed by a step (an eager backward whose step never came):
+        clear them now.  Called before a captured step is replayed — that step was recorded on a clean buffer, so it holds no
+        fill of its own (the consuming Adam of the previous replay clears behind its read).  Host-side flags only."""
+        if self.flat_half is None:
+            return False
+        dirty = False
+        for group in self.param_groups:
+            for p in group["params"]:
+                if getattr(p, "_s3d_grad", None) is not None and getattr(p, "_s3d_grad_touched", False) \
+                        and not getattr(p, "_s3d_grad_consumed", False):
+                    dirty = True
+                    p._s3d_grad_touched = False
+        if dirty:
+            self.flat_half.zero_()
+        return dirty
 
     def resync_half(self):
         """re-make the fp16 copies after the fp32 parameters were written from outside (checkpoint load)"""
@@ -247,8 +267,26 @@ class NativeGradScaler:
         if dist is None or (dist.world == 1 and not dist.force_collective):
             optimizer.step(grad_scale=self._scale if self.enabled else None, found_inf=self._found_inf, advance=not fold)
             return
-        pending = dist.allreduce_grads_async()
+        if not dist.fused_avg():
+            # SUM + divide fallback (gloo, or no AVG): the sum of `world` finite loss-scaled fp16 gradients can overflow although
+            # no rank saw a non-finite value, so it is the REDUCED buffers that are checked — all of them, before the first
+            # parameter is touched (a step is skipped as a whole).  No pipelining on this path.
+            dist.allreduce_grads()
+            if hasattr(optimizer, "mark_all_touched"):
+                optimizer.mark_all_touched()
+            flat = getattr(optimizer, "flat_half", None)
+            if flat is not None:
+                _backend.grads_nonfinite(flat, self._found_inf)
+            for _, p, g in optimizer.grads():
+                if flat is None or g is not getattr(p, "_s3d_grad", None):
+                    _backend.grads_nonfinite(g, self._found_inf)
+            dist.allreduce_flag(self._found_inf)  # (identical on every rank already; keeps the replicas' decisions tied)
+            optimizer.step(grad_scale=self._scale if self.enabled else None, found_inf=self._found_inf, advance=not fold)
+            return
+        # the 4-byte flag goes first: a process group runs its collectives in issue order, and every update kernel reads the
+        # flag — behind the gradient pieces it would hold the first Adam launch until the last piece has arrived
         dist.allreduce_flag(self._found_inf)
+        pending = dist.allreduce_grads_async()
         if hasattr(optimizer, "mark_all_touched"):
             optimizer.mark_all_touched()
 

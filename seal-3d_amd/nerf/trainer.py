@@ -197,8 +197,10 @@ class GraphedTrainer(Trainer):
     costs two fills, not compute — fewer dropped rays than the reference's M = running mean, and re-captures only when
     the mean outgrows the headroom."""
 
-    def __init__(self, model, num_rays, budget_factor=1.3, graph_extra_state=True, **kw):
+    def __init__(self, model, num_rays, budget_factor=1.3, graph_extra_state=True, capture_collectives=True, **kw):
         super().__init__(model, capturable=True, **kw)
+        self.capture_collectives = capture_collectives  # False: two graphs with the all-reduce issued eagerly between them
+        self.collectives_in_graph = False
         dev = next(model.parameters()).device
         self.s_ro = torch.zeros(num_rays, 3, device=dev)
         self.s_rd = torch.zeros(num_rays, 3, device=dev)
@@ -253,9 +255,10 @@ class GraphedTrainer(Trainer):
             self.scaler.update()
 
     def _capture(self):
-        """One graph for the whole step on a single GPU.  With data parallelism the step is captured as TWO graphs
-        (forward+backward | unscale+Adam+scaler update) and the gradient all-reduce is issued eagerly between the two
-        replays: the collective stays outside graph capture, the ~120 kernel launches stay inside."""
+        """One graph for the whole step — with data parallelism too when the process group's collectives can be captured
+        (RCCL; probed once, parallel/dist.py: capture_supported).  Otherwise (gloo, `capture_collectives=False`) the step
+        is captured as TWO graphs (forward+backward | check+Adam+scaler update) and the gradient all-reduce is issued eagerly
+        between the two replays."""
         model = self.model
         model.train()
         self.n_captures += 1
@@ -293,12 +296,28 @@ class GraphedTrainer(Trainer):
                 self.s_loss = self._body_fb()
                 self._body_opt()
             self.graph_opt = None
+        elif self.capture_collectives and self.dist.capture_supported():
+            # data parallelism, ONE graph: forward + backward, the gradient all-reduce (RCCL records into the capture: its
+            # kernels run on the process group's stream, forked from and joined back into the step's stream by event edges),
+            # check + Adam + scale update.  One collective per gradient buffer — every fork / join edge costs ~9 us here.
+            saved_chunk = self.dist.chunk_bytes
+            self.dist.chunk_bytes = 1 << 40
+            try:
+                with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
+                    self.s_loss = self._body_fb()
+                    self.dist.allreduce_grads(self.scaler)
+                    self._body_opt()
+            finally:
+                self.dist.chunk_bytes = saved_chunk
+            self.graph_opt = None
+            self.collectives_in_graph = True
         else:
             with torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
                 self.s_loss = self._body_fb()
             self.graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), capture_error_mode=_CAPTURE_MODE):
                 self._body_opt()
+            self.collectives_in_graph = False
         model.step_counter = ring
         model._counter_prezeroed = False
         model._noise_step = None
@@ -342,6 +361,11 @@ class GraphedTrainer(Trainer):
                              [rays_o.reshape(-1, 3), rays_d.reshape(-1, 3), gt_rgb.reshape(-1, 3)])  # one launch
 
     def _replay(self):
+        # an eager backward without a step since the last replay left gradients in the hand-over buffer that the captured
+        # step (recorded with a clean buffer: no fill) would accumulate onto: clear them first (host-side flags, no sync)
+        dirty = getattr(self.optimizer, "clear_unconsumed", None)
+        if dirty is not None:
+            dirty()
         self.graph.replay()
         if self.graph_opt is not None:
             self.dist.allreduce_grads(self.scaler)
@@ -369,7 +393,9 @@ class GraphedTrainer(Trainer):
         else:
             self._replay()
             filed = self._counter_ring is not None
-            # (the static loss buffer is overwritten by the next replay; a ring slot only 16 steps later)
+            # (the static loss buffer is overwritten by the next replay; a ring slot only 16 steps later — and the ring restarts
+            #  at slot 0 after every update_extra_state: a caller that keeps loss TENSORS for longer clones them, `.item()` /
+            #  `float()` callers need nothing.  No clone here: it would be one more launch per step)
             loss = self.loss_ring[model.local_step % 16] if filed else self.s_loss.clone()
         bump_weights_epoch()  # replays update the parameters without touching Tensor._version
         if not filed:

@@ -138,6 +138,36 @@ class RayShardedDP:
             handles.append((buf, a, b, work, not fused_avg and self.average and self.world > 1))
         return handles
 
+    def capture_supported(self):
+        """Can this group's all-reduce be recorded into a HIP graph and replayed?  Probed once with a throw-away graph holding
+        one tiny collective (every rank runs the probe at the same point of its program, so every rank reaches the same
+        verdict): RCCL supports stream capture, gloo does not."""
+        if getattr(self, "_capture_ok", None) is None:
+            ok = False
+            if dist.is_initialized() and dist.get_backend(self.group) == "nccl" and torch.cuda.is_available():
+                try:
+                    probe = torch.full((256,), 2.0, dtype=torch.float16, device="cuda")
+                    dist.all_reduce(probe, op=dist.ReduceOp.SUM, group=self.group)  # (communicator warm before the capture)
+                    probe.fill_(2.0)
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        dist.all_reduce(probe, op=dist.ReduceOp.SUM, group=self.group)
+                    probe.fill_(2.0)
+                    g.replay()
+                    torch.cuda.synchronize()
+                    ok = bool((probe == 2.0 * self.world).all().item())
+                    del g
+                except Exception:  # noqa: BLE001  (any failure = not supported; the two-graph path is taken)
+                    ok = False
+            self._capture_ok = ok
+        return self._capture_ok
+
+    def fused_avg(self):
+        """True when the mean over the ranks comes out of the collective itself (RCCL AVG: a pre-multiplied sum that cannot
+        overflow on the wire); False on the SUM + divide fallback (gloo, or AVG not available)"""
+        return bool(self.average and self._avg_supported())
+
     def allreduce_flag(self, flag):
         """a device-side overflow flag: non-zero on any rank -> non-zero everywhere"""
         if self.world > 1 or self.force_collective:

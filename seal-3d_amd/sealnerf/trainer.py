@@ -80,7 +80,28 @@ class SealSteps:
             steps.append(pts.shape[0])
         self.pretraining_data["local"] = {"points": pts, "dirs": dirs, "sigma": gt_sigma, "color": gt_color, "steps": steps}
         self.pretraining_lr = lr
+        self.invalidate_graphs()  # (the per-chunk graphs hold raw pointers into the previous point / target tensors)
         return pts.shape[0]
+
+    def invalidate_graphs(self):
+        """Drop every captured graph that bakes in state this trainer can replace: the per-chunk pretraining graphs (slices
+        of `pretraining_data`, the optimizer's moment tensors, the learning rate), and the teacher's proxy-render graph (the
+        mapper's parameters are kernel arguments, the teacher's bitfield / tables are raw pointers).  Called by
+        init_pretraining(), load_checkpoint() and set_teacher(); call it after changing the teacher's mapper or occupancy
+        state in place."""
+        self._pt_graphs = {}
+        if hasattr(self, "proxy_graph"):
+            self.proxy_graph = None
+
+    def set_teacher(self, teacher):
+        """replace the teacher (a new edit): its graphs go with it"""
+        self.teacher = teacher
+        self.invalidate_graphs()
+
+    def load_checkpoint(self, checkpoint, model_only=False):
+        out = super().load_checkpoint(checkpoint, model_only=model_only)
+        self.invalidate_graphs()  # (optimizer state tensors were replaced)
+        return out
 
     def freeze_mlp(self, freeze=True):
         for name in ("sigma_net", "color_net", "bg_net"):
@@ -139,7 +160,12 @@ class SealSteps:
             return self.pretrain_step(*args, n_total=n_total)
         if not hasattr(self, "_pt_graphs"):
             self._pt_graphs = {}
+        # the entry is valid for exactly the tensors it was captured on (a replaced chunk tensor or optimizer moment = re-capture)
+        sig = (key, args[0].data_ptr(), args[2].data_ptr(), tuple(st["exp_avg"].data_ptr() for st in self.optimizer.state.values()
+                                                                   if "exp_avg" in st), float(self.pretraining_lr))
         ent = self._pt_graphs.get(key)
+        if ent is not None and ent[2] != sig:
+            ent = None
         if ent is None:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -153,7 +179,7 @@ class SealSteps:
             pool = next(iter(self._pt_graphs.values()))[0].pool() if self._pt_graphs else None
             with torch.cuda.graph(g, pool=pool, capture_error_mode=_CAPTURE_MODE):
                 loss = self.pretrain_step(*args, n_total=n_total)
-            self._pt_graphs[key] = (g, loss)
+            self._pt_graphs[key] = (g, loss, sig)
             return warm  # (the capture itself does not execute)
         ent[0].replay()
         from gridencoder.grid import bump_weights_epoch

@@ -107,8 +107,11 @@ def test_overflow_step_is_skipped_with_the_check_made_by_the_gradient_kernels(hi
     assert not all(torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
 
 
-def test_data_parallel_split_graph_step_single_rank(hip):
-    """The multi-GPU step (two graphs with an eager all-reduce in between, fp16 flat bucket) on a 1-rank RCCL group."""
+@pytest.mark.parametrize("capture_collectives", [True, False])
+def test_data_parallel_graph_step_single_rank(hip, capture_collectives):
+    """The multi-GPU step on a 1-rank RCCL group, fp16 flat bucket: (True) ONE graph with the RCCL all-reduce recorded
+    inside it, (False) two graphs with an eager all-reduce in between.  Averaging over one rank is the identity, so
+    both must train like the single-GPU step."""
     import torch.distributed as dist
     from nerf.trainer import GraphedTrainer
     from parallel import RayShardedDP
@@ -120,12 +123,60 @@ def test_data_parallel_split_graph_step_single_rank(hip):
     try:
         model, batches = _setup()
         dp = RayShardedDP(force_collective=True)
-        tr = GraphedTrainer(model, 2048, lr=1e-2, fp16=True, dist=dp)
+        tr = GraphedTrainer(model, 2048, lr=1e-2, fp16=True, dist=dp, capture_collectives=capture_collectives)
         losses = _run(tr, batches, 56)
-        assert tr.graph is not None and tr.graph_opt is not None, "the step must be captured as two graphs"
+        assert tr.graph is not None
+        if capture_collectives:
+            assert dp.capture_supported(), "RCCL collectives must be capturable on this stack"
+            assert tr.graph_opt is None and tr.collectives_in_graph, "the step (all-reduce included) must be ONE graph"
+        else:
+            assert tr.graph_opt is not None and not tr.collectives_in_graph, "the step must be captured as two graphs"
         assert len(dp.half_grads) == 1 and dp.half_grads[0] is tr.optimizer.flat_half
         assert dp.flat.numel() == 0  # every trainable tensor of this network rides in the fp16 buffer
         assert torch.isfinite(losses).all() and float(losses[-8:].mean()) < 0.5 * float(losses[:8].mean())
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_sum_fallback_checks_the_reduced_gradient(hip):
+    """SUM + divide reduction (no fused AVG: here a gloo group on GPU tensors): the sum over the ranks can overflow fp16
+    although every local gradient is finite, so the REDUCED buffers are checked before any parameter is touched.  Emulated
+    on one rank by an all-reduce hook that doubles the buffer (two ranks holding the same large gradient)."""
+    import torch.distributed as dist
+    from nerf.trainer import Trainer
+    from parallel import RayShardedDP
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29579")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="gloo", rank=0, world_size=1)
+    try:
+        model, batches = _setup()
+        model.iter_density = 100
+        dp = RayShardedDP(force_collective=True, shard_occupancy=False)
+        tr = Trainer(model, lr=1e-2, fp16=True, update_extra_interval=10 ** 9, dist=dp)
+        tr.global_step = 1
+        assert not dp.fused_avg()
+        tr.train_step(*batches[0])  # a clean step first
+        before = [p.detach().clone() for p in model.parameters()]
+        steps0 = float(tr.optimizer.step_count)
+        scale0 = tr.scaler.get_scale()
+        orig = dp.allreduce_grads
+
+        def overflowing_sum(scaler=None):
+            orig(scaler)
+            for h in dp.half_grads:  # what a second rank's equal contribution would do to a large entry
+                h[:8] = 60000.0
+                h[:8] += h[:8]
+        dp.allreduce_grads = overflowing_sum
+        tr.train_step(*batches[1])
+        dp.allreduce_grads = orig
+        assert float(tr.optimizer.step_count) == steps0, "a step whose REDUCED gradient is non-finite must be skipped"
+        assert all(torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
+        assert tr.scaler.get_scale() == scale0 * 0.5
+        tr.train_step(*batches[2])
+        assert float(tr.optimizer.step_count) == steps0 + 1
     finally:
         if created:
             dist.destroy_process_group()
