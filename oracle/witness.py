@@ -146,3 +146,169 @@ def morton3d(xyz):
 
 def packbits(grid, thresh):
     return np.packbits((grid.reshape(-1) > thresh).astype(np.uint8), bitorder="little")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Ray marching: near/far slab test and the two-pass DDA of march_rays_train, stated a second time.
+#
+# Written from raymarching.cu:92-156 (near_far_from_aabb), :20-60 (clamp / signf / mip_from_pos / mip_from_dt / morton) and
+# :312-480 (kernel_march_rays_train) WITHOUT consulting oracle/src/s3o_raymarching.c: one Python loop per ray, every
+# intermediate an explicit numpy float32 (or the float64 the CUDA expression promotes to: `0.5 * (...) * H` has a double
+# literal), nvcc's default contraction of `a * b + c` into one fused multiply-add spelled out (fma32 below).  Ray-ordered
+# span reservation (the reference's atomicAdd order is arbitrary; ray order is the deterministic one the build pins).
+# tests/test_witness.py compares per-ray sample counts, span offsets, counters and every sample position / delta with the C
+# oracle bit for bit.
+F32 = np.float32
+
+
+def fma32(a, b, c):
+    """float32 fused multiply-add: the product of two float32 is exact in 80-bit extended precision, one rounding to float32"""
+    return F32(np.longdouble(a) * np.longdouble(b) + np.longdouble(c))
+
+
+def _clamp32(x, lo, hi):
+    return F32(min(F32(hi), max(F32(lo), F32(x))))  # fminf(max, fmaxf(min, x))
+
+
+def near_far_from_aabb(rays_o, rays_d, aabb, min_near):
+    """raymarching.cu:92-147: slab test on x, then y, then z; a miss -> both FLT_MAX; near clamped from below by min_near"""
+    N = rays_o.shape[0]
+    nears, fars = np.empty(N, dtype=F32), np.empty(N, dtype=F32)
+    fmax = np.finfo(F32).max
+    a = aabb.astype(F32)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        for n in range(N):
+            o, d = rays_o[n].astype(F32), rays_d[n].astype(F32)
+            rd = F32(1) / d
+            near, far = (a[0] - o[0]) * rd[0], (a[3] - o[0]) * rd[0]
+            if near > far:
+                near, far = far, near
+            miss = False
+            for ax in (1, 2):
+                n2, f2 = (a[ax] - o[ax]) * rd[ax], (a[3 + ax] - o[ax]) * rd[ax]
+                if n2 > f2:
+                    n2, f2 = f2, n2
+                if near > f2 or n2 > far:
+                    miss = True
+                    break
+                if n2 > near:
+                    near = n2
+                if f2 < far:
+                    far = f2
+            if miss:
+                nears[n] = fars[n] = fmax
+                continue
+            if near < F32(min_near):
+                near = F32(min_near)
+            nears[n], fars[n] = near, far
+    return nears, fars
+
+
+def _expand_bits(v):
+    v = (v * 0x00010001) & 0xFF0000FF
+    v = (v * 0x00000101) & 0x0F00F00F
+    v = (v * 0x00000011) & 0xC30C30C3
+    v = (v * 0x00000005) & 0x49249249
+    return v & 0xFFFFFFFF
+
+
+def _morton(x, y, z):
+    return _expand_bits(x) | (_expand_bits(y) << 1) | (_expand_bits(z) << 2)
+
+
+def _frexp_exponent(v):
+    return int(np.frexp(F32(v))[1])  # frexpf(0) -> exponent 0
+
+
+def _mip_from_pos(x, y, z, C):
+    e = _frexp_exponent(max(abs(F32(x)), abs(F32(y)), abs(F32(z))))
+    return int(min(C - 1, max(0, e)))
+
+
+def _mip_from_dt(dt, H, C):
+    e = _frexp_exponent(F32(np.float64(F32(dt) * F32(H)) * 0.5))  # `dt * H * 0.5`: float product, double literal
+    return int(min(C - 1, max(0, e)))
+
+
+def march_rays_train(rays_o, rays_d, bitfield, bound, dt_gamma, max_steps, C, H, M, nears, fars, noises):
+    """raymarching.cu:312-480 -> (xyzs [M,3], dirs [M,3], deltas [M,2] float32 zero-initialised, rays [N,3] int32
+    (id, offset, count), counter [2])"""
+    N = rays_o.shape[0]
+    bound, dt_gamma = F32(bound), F32(dt_gamma)
+    rH = F32(1) / F32(H)
+    H3 = H * H * H
+    SQRT3 = F32(1.7320508075688772)
+    dt_min = F32(2) * SQRT3 / F32(max_steps)
+    dt_max = F32(2) * SQRT3 * F32(1 << (C - 1)) / F32(H)
+    xyzs, dirs, deltas = np.zeros((M, 3), F32), np.zeros((M, 3), F32), np.zeros((M, 2), F32)
+    rays = np.zeros((N, 3), np.int32)
+    bits = np.asarray(bitfield, dtype=np.uint8)
+
+    def cell(t, o, d):
+        x = _clamp32(fma32(t, d[0], o[0]), -bound, bound)  # ox + t * dx, contracted
+        y = _clamp32(fma32(t, d[1], o[1]), -bound, bound)
+        z = _clamp32(fma32(t, d[2], o[2]), -bound, bound)
+        dt = _clamp32(t * dt_gamma, dt_min, dt_max)
+        level = max(_mip_from_pos(x, y, z, C), _mip_from_dt(dt, H, C))
+        mip_bound = F32(min(F32(np.ldexp(F32(1), level)), bound))
+        mip_rbound = F32(1) / mip_bound
+
+        def grid_coord(v):  # clamp(0.5 * (v * mip_rbound + 1) * H, 0.0f, (float)(H - 1)) -> int (truncation)
+            inner = fma32(v, mip_rbound, F32(1))            # float: v * mip_rbound + 1, contracted
+            val = np.float64(0.5) * np.float64(inner) * np.float64(H)  # double: 0.5 is a double literal, H converts exactly
+            return int(_clamp32(F32(val), F32(0), F32(H - 1)))
+        nx, ny, nz = grid_coord(x), grid_coord(y), grid_coord(z)
+        index = level * H3 + _morton(nx, ny, nz)
+        occ = (int(bits[index // 8]) >> (index % 8)) & 1
+        return x, y, z, dt, mip_bound, (nx, ny, nz), bool(occ)
+
+    def skip(t, x, y, z, n3, mip_bound, d, rd):
+        """distance to the next voxel of this mip level, then steps of the t sequence until it is passed"""
+        def axis(nc, dc, c, rdc):
+            sgn = F32(np.copysign(F32(1), dc))
+            edge = F32(nc) + F32(0.5) + F32(0.5) * sgn              # half-integers: exact
+            u = F32(F32(edge * rH) * F32(2)) - F32(1)                  # (edge * rH * 2 - 1): the doubling is exact
+            return F32(F32(F32(u * mip_bound) - c) * rdc)             # mip_bound is a power of two (or the bound itself)
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            tx, ty, tz = axis(n3[0], d[0], x, rd[0]), axis(n3[1], d[1], y, rd[1]), axis(n3[2], d[2], z, rd[2])
+            tt = F32(t + F32(max(F32(0), min(tx, min(ty, tz)))))
+        while True:
+            t = F32(t + _clamp32(t * dt_gamma, dt_min, dt_max))
+            if not (t < tt):
+                return t
+
+    point_index = 0
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        for n in range(N):
+            o, d = rays_o[n].astype(F32), rays_d[n].astype(F32)
+            rd = F32(1) / d
+            near, far, noise = F32(nears[n]), F32(fars[n]), F32(noises[n])
+            t0 = fma32(_clamp32(near * dt_gamma, dt_min, dt_max), noise, near)  # t0 += clamp(...) * noise, contracted
+            # first pass: count
+            t, num = t0, 0
+            while t < far and num < max_steps:
+                x, y, z, dt, mip_bound, n3, occ = cell(t, o, d)
+                if occ:
+                    num += 1
+                    t = F32(t + dt)
+                else:
+                    t = skip(t, x, y, z, n3, mip_bound, d, rd)
+            rays[n] = (n, point_index, num)
+            start = point_index
+            point_index += num
+            if num == 0 or start + num > M:
+                continue
+            # second pass: write
+            t, step, last_t = t0, 0, t0
+            while t < far and step < num:
+                x, y, z, dt, mip_bound, n3, occ = cell(t, o, d)
+                if occ:
+                    xyzs[start + step] = (x, y, z)
+                    dirs[start + step] = d
+                    t = F32(t + dt)
+                    deltas[start + step] = (dt, F32(t - last_t))
+                    last_t = t
+                    step += 1
+                else:
+                    t = skip(t, x, y, z, n3, mip_bound, d, rd)
+    return xyzs, dirs, deltas, rays, np.array([point_index, N], dtype=np.int32)

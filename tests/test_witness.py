@@ -99,3 +99,60 @@ def test_morton_and_packbits_oracle_vs_witness(oracle):
     bits = torch.empty(1024, dtype=torch.uint8)
     oracle.RaymarchingBackend.packbits(grid, 1024, 0.37, bits)
     assert np.array_equal(bits.numpy(), W.packbits(grid.numpy(), np.float32(0.37)))
+
+
+def _rays_and_scene(n, seed, cascade, bound):
+    """rays aimed at a box scene from outside (the construction of tests/test_gpu_raymarching.py, kept local)"""
+    from nerf import synthetic as syn
+    g = torch.Generator().manual_seed(seed)
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    o = -d * (2.2 * bound) + (torch.rand(n, 3, generator=g) - 0.5) * 0.8 * bound
+    d[0] = torch.tensor([1.0, 0.0, 0.0])      # axis-parallel: two of the reciprocal directions are infinite
+    o[0] = torch.tensor([-3.0 * bound, 0.1, -0.2])
+    d[1] = torch.tensor([0.0, 0.0, -1.0])
+    o[1] = torch.tensor([0.3, 0.2, 3.0 * bound])
+    o[2] = torch.tensor([5.0 * bound, 5.0 * bound, 0.0])  # misses the box
+    d[2] = torch.tensor([0.0, 0.0, 1.0])
+    H = 128
+    grid = np.zeros((cascade, H ** 3), dtype=np.float32)
+    base, _ = syn.lego_like_density_grid(seed=seed)
+    grid[0] = base.reshape(-1)[: H ** 3] if base.size >= H ** 3 else base.reshape(-1)
+    rng = np.random.default_rng(seed)
+    for c in range(1, cascade):
+        grid[c] = (rng.random(H ** 3) < 0.02) * 20.0
+    bits = np.packbits((grid.reshape(-1) > 10.0).astype(np.uint8), bitorder="little")
+    return o.contiguous(), d.contiguous(), torch.from_numpy(bits)
+
+
+@pytest.mark.parametrize("perturb", [False, True])
+@pytest.mark.parametrize("cascade,bound,dt_gamma,max_steps", [(1, 1.0, 0.0, 1024), (2, 2.0, 1.0 / 128, 1024), (3, 4.0, 0.0, 4096),
+                                                              (1, 1.0, 0.0, 20)])
+def test_marcher_oracle_vs_independent_witness(oracle, perturb, cascade, bound, dt_gamma, max_steps):
+    """near_far_from_aabb and the two-pass DDA of march_rays_train: the C oracle against the numpy statement written from the
+    CUDA text alone (oracle/witness.py) — per-ray counts, span offsets, counters, sample positions, directions and deltas,
+    all bit for bit, on the four marcher configurations of the GPU parity test."""
+    N, M = 160, 160 * 160
+    ro, rd, bits = _rays_and_scene(N, seed=cascade, cascade=cascade, bound=bound)
+    aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32)
+    nears, fars = torch.empty(N), torch.empty(N)
+    oracle.RaymarchingBackend.near_far_from_aabb(ro, rd, aabb, N, 0.2, nears, fars)
+    w_near, w_far = W.near_far_from_aabb(ro.numpy(), rd.numpy(), aabb.numpy(), 0.2)
+    assert np.array_equal(nears.numpy().view(np.uint32), w_near.view(np.uint32))
+    assert np.array_equal(fars.numpy().view(np.uint32), w_far.view(np.uint32))
+    assert float(nears[2]) == np.finfo(np.float32).max and float(nears[0]) < 10
+    g = torch.Generator().manual_seed(5)
+    noises = torch.rand(N, generator=g) if perturb else torch.zeros(N)
+    xyzs, dirs, deltas = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
+    rays = torch.empty(N, 3, dtype=torch.int32)
+    counter = torch.zeros(2, dtype=torch.int32)
+    oracle.RaymarchingBackend.march_rays_train(ro, rd, bits, bound, dt_gamma, max_steps, N, cascade, 128, M, nears, fars, xyzs, dirs,
+                                               deltas, rays, counter, noises)
+    wx, wd, wdl, wrays, wcount = W.march_rays_train(ro.numpy(), rd.numpy(), bits.numpy(), bound, dt_gamma, max_steps, cascade, 128, M,
+                                                    nears.numpy(), fars.numpy(), noises.numpy())
+    assert np.array_equal(rays.numpy(), wrays), "per-ray (id, offset, count) differ"
+    assert np.array_equal(counter.numpy(), wcount)
+    assert int(counter[0]) > N, "the scene must produce samples"
+    if max_steps == 20:
+        assert int(rays[:, 2].max()) == 20
+    for got, want in ((xyzs, wx), (dirs, wd), (deltas, wdl)):
+        assert np.array_equal(got.numpy().view(np.uint32), want.view(np.uint32))
