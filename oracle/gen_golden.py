@@ -470,6 +470,28 @@ def gen_seal():
                     f"{tag}_bound_type": np.array(cfg["boundType"]),
                     f"{tag}_map_source": np.array(cfg.get("mapSource", []), dtype=np.float64)})
         print(f"seal[{tag}]: {int(m.sum())} of {pts.shape[0]} points mapped")
+    # colour remapping of the bbox tool (seal_utils.py:48-58): the reference's map_color EXECUTED with hsv / rgb options on
+    # seeded colours (greys, pure channels, ties between channels, hue wrap-around past 1.0 included)
+    g = torch.Generator().manual_seed(99)
+    cols = torch.rand(4000, 3, generator=g)
+    cols[:8] = torch.tensor([[0.5, 0.5, 0.5], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0],
+                             [0.7, 0.7, 0.2], [0.3, 0.9, 0.9]])
+    out["color_in"] = cols.numpy()
+    for name, opts in (("hsv", {"hsv": [0.12, -0.05, 0.03]}), ("rgb", {"rgb": [0.8, 0.2, 0.1], "rgbLightOffset": 0.05}),
+                       ("both", {"hsv": [0.4, 0.1, -0.1], "rgb": [0.1, 0.6, 0.9]})):
+        ref = su.SealBBoxMapper.__new__(su.SealBBoxMapper)
+        su.SealMapper.__init__(ref, {})
+        ref.map_data = {}
+        if "hsv" in opts:
+            ref.map_data["hsv"] = torch.tensor(opts["hsv"], dtype=torch.float32)
+        if "rgb" in opts:
+            ref.map_data["rgb"] = torch.tensor(opts["rgb"], dtype=torch.float32)
+            ref.map_data["rgb_light_offset"] = opts.get("rgbLightOffset", 0)
+        res = ref.map_color(None, None, cols.clone())
+        out[f"color_{name}"] = res.numpy()
+        out[f"color_{name}_opts"] = np.array([opts.get("hsv", [np.nan] * 3), opts.get("rgb", [np.nan] * 3),
+                                              [opts.get("rgbLightOffset", 0), 0, 0]], dtype=np.float64)
+        print(f"seal[color {name}]: mean {res.mean(0).tolist()}")
     np.savez_compressed(os.path.join(OUT, "seal_bbox.npz"), **out)
     print("seal: wrote seal_bbox.npz with", len(out), "arrays")
 

@@ -4,7 +4,8 @@ Only the bounding-box tool of BASELINE configs 3/4 is implemented (`SealBBoxMapp
 config keys `type: bbox`, `raw` (points spanning the source box), `transform` (4x4 source->target), `scale` (3),
 `boundType` ('to' | 'from' | 'both'), optional `mapSource`.  No trimesh / pytorch3d: the box meshes are built
 directly (12 triangles per box) and the inside test is the reference's two-ray Moller-Trumbore parity test
-(seal_utils.py:630-685) in plain torch.  Colour remapping (hsv/rgb/image) is outside the configs and not implemented.
+(seal_utils.py:630-685) in plain torch.  Colour remapping: the bbox tool's `hsv` / `rgb` options (seal_utils.py:48-58,
+739-769, color_utils.py:33-66); the brush tool's image remap is not part of the bbox configuration.
 """
 import json
 
@@ -113,6 +114,59 @@ def points_in_mesh(points, triangles):
     return hit[:points.shape[0]] & hit[points.shape[0]:]
 
 
+def rgb_to_hsv(rgb):
+    """color_utils.py:33-46 (`rgb2hsv_torch`) on [N, 3], closed form instead of boolean-mask scatters: hue from the FIRST
+    maximal channel (torch.max's tie rule), `%` = floored modulo, grey (delta == 0) -> hue 0; no host sync"""
+    r, g, b = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+    cmax, idx = torch.max(rgb, dim=1)
+    cmin = torch.min(rgb, dim=1)[0]
+    delta = cmax - cmin
+    safe = torch.where(delta == 0, torch.ones_like(delta), delta)
+    h0 = torch.remainder((g - b) / safe, 6.0)
+    h1 = (b - r) / safe + 2.0
+    h2 = (r - g) / safe + 4.0
+    h = torch.where(idx == 0, h0, torch.where(idx == 1, h1, h2))
+    h = torch.where(delta == 0, torch.zeros_like(h), h) / 6.0
+    s = torch.where(cmax == 0, torch.zeros_like(cmax), delta / torch.where(cmax == 0, torch.ones_like(cmax), cmax))
+    return torch.stack([h, s, cmax], dim=1)
+
+
+def hsv_to_rgb(hsv):
+    """color_utils.py:49-66 (`hsv2rgb_torch`) on [N, 3]; the sextant is `(h * 6)` cast to uint8, modulo 6, as there"""
+    h, s, v = hsv[:, 0], hsv[:, 1], hsv[:, 2]
+    c = v * s
+    x = c * (-torch.abs(torch.remainder(h * 6.0, 2.0) - 1.0) + 1.0)
+    m = v - c
+    o = torch.zeros_like(c)
+    idx = (h * 6.0).to(torch.uint8) % 6
+    table = torch.stack([torch.stack([c, x, o], 1), torch.stack([x, c, o], 1), torch.stack([o, c, x], 1),
+                         torch.stack([o, x, c], 1), torch.stack([x, o, c], 1), torch.stack([c, o, x], 1)], dim=1)  # [N, 6, 3]
+    rgb = table.gather(1, idx.long()[:, None, None].expand(-1, 1, 3))[:, 0]
+    return rgb + m[:, None]
+
+
+def modify_hsv(rgb, modification):
+    """seal_utils.py:739-750: rgb -> hsv, add the offsets, -> rgb"""
+    if rgb.shape[0] == 0:
+        return rgb
+    hsv = rgb_to_hsv(rgb)
+    mod = torch.as_tensor(modification, dtype=rgb.dtype, device=rgb.device)
+    return hsv_to_rgb(hsv + mod[None, :3])
+
+
+def modify_rgb(rgb, modification, light_offset=0):
+    """seal_utils.py:753-769: hue and saturation of the target colour, value = the target's value + the sample's offset from
+    the batch's mean value (+ light_offset), clamped to [0, 1]"""
+    if rgb.shape[0] == 0:
+        return rgb
+    hsv = rgb_to_hsv(rgb)
+    mod = rgb_to_hsv(torch.as_tensor(modification, dtype=rgb.dtype, device=rgb.device).view(-1, 3))
+    raw = hsv[:, 2]
+    val = torch.clamp(mod[:, 2] + (raw - raw.mean()) + light_offset, 0.0, 1.0)
+    out = torch.stack([mod[:, 0].expand_as(val), mod[:, 1].expand_as(val), val], dim=1)
+    return hsv_to_rgb(out)
+
+
 class SealBBoxMapper:
     def __init__(self, seal_config):
         self.config = seal_config
@@ -148,6 +202,11 @@ class SealBBoxMapper:
             "scale": torch.tensor(1.0 / scale, dtype=torch.float32),
             "center": torch.tensor(center, dtype=torch.float32),
         }
+        if "hsv" in seal_config:  # seal_utils.py:226-230
+            self.map_data["hsv"] = torch.tensor(seal_config["hsv"], dtype=torch.float32)
+        if "rgb" in seal_config:
+            self.map_data["rgb"] = torch.tensor(seal_config["rgb"], dtype=torch.float32)
+            self.map_data["rgb_light_offset"] = float(seal_config.get("rgbLightOffset", 0))
         if seal_config.get("mapSource"):
             self.map_data["empty_bound"] = torch.tensor(from_b, dtype=torch.float32)
             self.map_data["map_source"] = torch.tensor(seal_config["mapSource"], dtype=torch.float32)
@@ -224,7 +283,14 @@ class SealBBoxMapper:
         return out_p, out_d, mask
 
     def map_color(self, points, dirs, colors):
-        return colors  # hsv / rgb / image remaps are outside the BASELINE configs
+        """seal_utils.py:48-81 for the bbox tool (`hsv` / `rgb` of seal.json, :226-230): hue / saturation / value offsets, then
+        re-colouring towards a target RGB that keeps each sample's brightness offset from the batch mean.  The image remap
+        (`image`) belongs to the brush tool and is not part of the bbox configuration."""
+        if "hsv" in self.map_data:
+            colors = modify_hsv(colors, self.map_data["hsv"])
+        if "rgb" in self.map_data:
+            colors = modify_rgb(colors, self.map_data["rgb"], self.map_data.get("rgb_light_offset", 0))
+        return colors
 
 
 def get_seal_mapper(config_dict=None, config_file=None):

@@ -49,3 +49,28 @@ def test_rotated_raw_points_give_an_oriented_source_box(S):
     assert d.max() < 1e-12  # the eight corners are the raw points themselves
     lo, hi = raw.min(0), raw.max(0)
     assert np.prod(hi - lo) > 1.2 * 0.4 * 0.3 * 0.4  # (the axis-aligned hull is visibly larger)
+
+
+@pytest.mark.parametrize("name", ["hsv", "rgb", "both"])
+def test_map_color_matches_reference_execution(S, name):
+    """colour remapping of the bbox tool (seal_utils.py:48-58, 739-769; color_utils.py:33-66): the reference's `map_color`
+    executed on 4,000 seeded colours (greys, pure channels, channel ties, hue wrap-around) vs the build's closed-form torch
+    twin — the reference assigns through boolean masks, the twin selects with `where`/`gather`: same values to 1 ulp."""
+    from sealnerf import SealBBoxMapper
+    opts = S[f"color_{name}_opts"]
+    cfg = case_config("to", S)
+    if not np.isnan(opts[0]).any():
+        cfg["hsv"] = opts[0].tolist()
+    if not np.isnan(opts[1]).any():
+        cfg["rgb"] = opts[1].tolist()
+        cfg["rgbLightOffset"] = float(opts[2, 0])
+    mapper = SealBBoxMapper(cfg)
+    cols = torch.from_numpy(S["color_in"])
+    got = mapper.map_color(None, None, cols.clone())
+    want = torch.from_numpy(S[f"color_{name}"])
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    torch.testing.assert_close(got, want, rtol=0, atol=2e-7)
+    assert not torch.allclose(got, cols, atol=1e-3), "the remap must change the colours"
+    # identity without options (the BASELINE configs)
+    plain = SealBBoxMapper(case_config("to", S))
+    assert plain.map_color(None, None, cols) is cols
