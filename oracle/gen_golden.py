@@ -262,6 +262,29 @@ def gen_wrappers():
                rend_train_image=tr["image"][0].numpy(), rend_train_depth=tr["depth"][0].numpy(),
                rend_eval_image=ev["image"][0].numpy(), rend_eval_depth=ev["depth"][0].numpy(),
                rend_step_counter=R.step_counter.numpy().copy())
+    # the sampling path without the occupancy grid (`cuda_ray` off, nerf/renderer.py:125-253 + sample_pdf :12-46) on the same
+    # analytic scene: stratified + importance samples, torch compositing; eval (deterministic importance samples) and train
+    # (perturbed, torch.rand from a fixed seed); masked colour evaluation as in the reference's networks
+    class AnalyticRun(renderer.NeRFRenderer):
+        def density(self, x):
+            return {"sigma": syn.box_density(x, lo, hi, sigma=40.0)}
+
+        def color(self, x, dd, mask=None, **kw):
+            rgb = (x * 0.5 + 0.5).clamp(0, 1) * (0.5 + 0.5 * dd.abs())
+            if mask is None:
+                return rgb
+            out_ = torch.zeros(mask.shape[0], 3, dtype=x.dtype)
+            out_[mask] = rgb[mask]
+            return out_
+    R2 = AnalyticRun(bound=1, cuda_ray=False, density_scale=1, min_near=0.2)
+    R2.eval()
+    rv = R2.render(ro[None], rd[None], staged=True, max_ray_batch=1500, bg_color=1, perturb=False, num_steps=64, upsample_steps=48)
+    R2.train()
+    torch.manual_seed(11)
+    rt = R2.render(ro[None, :1024], rd[None, :1024], bg_color=1, perturb=True, num_steps=64, upsample_steps=48)
+    out.update(run_eval_image=rv["image"][0].numpy(), run_eval_depth=rv["depth"][0].numpy(),
+               run_train_image=rt["image"][0].numpy(), run_train_depth=rt["depth"][0].numpy(),
+               run_train_weights_sum=rt["weights_sum"].numpy())
     # reference network (nerf/network.py): parameter names/shapes and a forward on fixed weights
     network = importlib.import_module("nerf.network")
     _assert_reference(network)

@@ -1,6 +1,7 @@
 """NeRFRenderer — the build's counterpart of nerf/renderer.py (the caller of the hot path).
 
-Reproduces the behaviour of `run_cuda` (training branch :256-321, inference loop :323-372),
+Reproduces the behaviour of `run` (:125-253, the sampling path without the occupancy grid) and `sample_pdf` (:12-46),
+`run_cuda` (training branch :256-321, inference loop :323-372),
 `update_extra_state` (:444-538), `mark_untrained_grid` (:379-441) and `reset_extra_state` on top of the
 drop-in `raymarching` package.  Buffers and attribute names are the reference's (`density_grid`,
 `density_bitfield`, `step_counter`, `mean_count`, `mean_density`, `iter_density`, `local_step`) so
@@ -27,6 +28,32 @@ _null_context = contextlib.nullcontext
 
 def _meshgrid(*args):
     return torch.meshgrid(*args, indexing="ij")
+
+
+def sample_pdf(bins, weights, n_samples, det=False):
+    """inverse-CDF sampling of `n_samples` depths per ray from the piecewise-constant density `weights` over `bins`
+    (nerf/renderer.py:12-46): bins [B, T], weights [B, T - 1] -> [B, n_samples]"""
+    weights = weights + 1e-5
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    if det:
+        u = torch.linspace(0.0 + 0.5 / n_samples, 1.0 - 0.5 / n_samples, steps=n_samples).to(weights.device)
+        u = u.expand(list(cdf.shape[:-1]) + [n_samples])
+    else:
+        u = torch.rand(list(cdf.shape[:-1]) + [n_samples]).to(weights.device)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.clamp(inds - 1, min=0)
+    above = torch.clamp(inds, max=cdf.shape[-1] - 1)
+    pick = torch.stack([below, above], -1)
+    shape = [pick.shape[0], pick.shape[1], cdf.shape[-1]]
+    cdf_g = torch.gather(cdf.unsqueeze(1).expand(shape), 2, pick)
+    bins_g = torch.gather(bins.unsqueeze(1).expand(shape), 2, pick)
+    denom = cdf_g[..., 1] - cdf_g[..., 0]
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    t = (u - cdf_g[..., 0]) / denom
+    return bins_g[..., 0] + t * (bins_g[..., 1] - bins_g[..., 0])
 
 
 class NeRFRenderer(nn.Module):
@@ -429,8 +456,80 @@ class NeRFRenderer(nn.Module):
             self.mean_count = int(count_sum / total_step)
         self.local_step = 0
 
+    def run(self, rays_o, rays_d, num_steps=128, upsample_steps=128, bg_color=None, perturb=False, **kwargs):
+        """The sampling path without the occupancy grid (`cuda_ray` off; nerf/renderer.py:125-253): `num_steps` stratified
+        samples between the ray's near and far, `upsample_steps` more drawn from the coarse weights (sample_pdf), alpha
+        compositing with torch ops, colours evaluated only where the weight exceeds 1e-4.  BASELINE configs[0] renders its
+        64x64 plumbing frame through this path (`num_steps=512`, main_SealNeRF.py:47).  The only native op is
+        near_far_from_aabb (the reference's `run` calls the extension for it too, :141)."""
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3)
+        rays_d = rays_d.contiguous().view(-1, 3)
+        N, device = rays_o.shape[0], rays_o.device
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
+        nears, fars = nears.unsqueeze(-1), fars.unsqueeze(-1)
+        z_vals = torch.linspace(0.0, 1.0, num_steps, device=device).unsqueeze(0).expand((N, num_steps))
+        z_vals = nears + (fars - nears) * z_vals
+        sample_dist = (fars - nears) / num_steps
+        if perturb:
+            z_vals = z_vals + (torch.rand(z_vals.shape, device=device) - 0.5) * sample_dist
+
+        def points(z):
+            x = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z.unsqueeze(-1)
+            return torch.min(torch.max(x, aabb[:3]), aabb[3:])
+
+        def alpha_weights(z, sigma):
+            d = torch.cat([z[..., 1:] - z[..., :-1], sample_dist * torch.ones_like(z[..., :1])], dim=-1)
+            alphas = 1 - torch.exp(-d * self.density_scale * sigma)
+            shifted = torch.cat([torch.ones_like(alphas[..., :1]), 1 - alphas + 1e-15], dim=-1)
+            return alphas * torch.cumprod(shifted, dim=-1)[..., :-1], d
+
+        xyzs = points(z_vals)
+        dens = {k: v.view(N, num_steps, -1) for k, v in self.density(xyzs.reshape(-1, 3)).items()}
+        if upsample_steps > 0:
+            with torch.no_grad():
+                weights, deltas = alpha_weights(z_vals, dens["sigma"].squeeze(-1))
+                z_mid = z_vals[..., :-1] + 0.5 * deltas[..., :-1]
+                new_z = sample_pdf(z_mid, weights[:, 1:-1], upsample_steps, det=not self.training).detach()
+                new_xyzs = points(new_z)
+            new_dens = {k: v.view(N, upsample_steps, -1) for k, v in self.density(new_xyzs.reshape(-1, 3)).items()}
+            z_vals, order = torch.sort(torch.cat([z_vals, new_z], dim=1), dim=1)
+            xyzs = torch.cat([xyzs, new_xyzs], dim=1)
+            xyzs = torch.gather(xyzs, dim=1, index=order.unsqueeze(-1).expand_as(xyzs))
+            for k in dens:
+                both = torch.cat([dens[k], new_dens[k]], dim=1)
+                dens[k] = torch.gather(both, dim=1, index=order.unsqueeze(-1).expand_as(both))
+        weights, _ = alpha_weights(z_vals, dens["sigma"].squeeze(-1))
+        dirs = rays_d.view(-1, 1, 3).expand_as(xyzs)
+        dens = {k: v.view(-1, v.shape[-1]) for k, v in dens.items()}
+        mask = weights > 1e-4
+        rgbs = self.color(xyzs.reshape(-1, 3), dirs.reshape(-1, 3), mask=mask.reshape(-1), **dens).view(N, -1, 3)
+        weights_sum = weights.sum(dim=-1)
+        depth = torch.sum(weights * ((z_vals - nears) / (fars - nears)).clamp(0, 1), dim=-1)
+        image = torch.sum(weights.unsqueeze(-1) * rgbs, dim=-2)
+        if self.bg_radius > 0:
+            sph = raymarching.sph_from_ray(rays_o, rays_d, self.bg_radius)
+            bg_color = self.background(sph, rays_d.reshape(-1, 3))
+        elif bg_color is None:
+            bg_color = 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        return {"depth": depth.view(*prefix), "image": image.view(*prefix, 3), "weights_sum": weights_sum}
+
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
-        if not self.cuda_ray:
-            raise NotImplementedError("this build implements the cuda_ray (-O) path; the sampling path `run` is torch-only "
-                                      "in the reference and out of the hot-path scope")
-        return self.run_cuda(rays_o, rays_d, **kwargs)
+        """nerf/renderer.py:541-577: run_cuda with `cuda_ray`, else `run` — staged over ray chunks on request (never staged
+        with cuda_ray, like the reference)"""
+        if self.cuda_ray:
+            return self.run_cuda(rays_o, rays_d, **kwargs)
+        if not staged:
+            return self.run(rays_o, rays_d, **kwargs)
+        B, N = rays_o.shape[:2]
+        depth = torch.empty((B, N), device=rays_o.device)
+        image = torch.empty((B, N, 3), device=rays_o.device)
+        for b in range(B):
+            for head in range(0, N, max_ray_batch):
+                tail = min(head + max_ray_batch, N)
+                part = self.run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], **kwargs)
+                depth[b:b + 1, head:tail] = part["depth"]
+                image[b:b + 1, head:tail] = part["image"]
+        return {"depth": depth, "image": image}

@@ -120,6 +120,40 @@ def test_renderer_matches_reference(oracle_wrappers, G):
     assert np.array_equal(ev["image"][0].numpy(), G["rend_eval_image"]) and np.array_equal(ev["depth"][0].numpy(), G["rend_eval_depth"])
 
 
+def test_sampling_path_without_occupancy_grid_matches_reference(oracle_wrappers, G):
+    """`NeRFRenderer.run` (cuda_ray off: stratified + importance sampling, torch compositing; nerf/renderer.py:125-253) and
+    `sample_pdf` (:12-46) — BASELINE configs[0]'s path — against the reference's own `run` executed on the same analytic
+    scene: the 64x64 frame staged in chunks of 1,500 rays (eval), and a perturbed training batch (torch.rand, seed 11)."""
+    from nerf import renderer, synthetic as syn
+    lo, hi = syn.lego_like_boxes(0)
+
+    class AnalyticRun(renderer.NeRFRenderer):
+        def density(self, x):
+            return {"sigma": syn.box_density(x, lo, hi, sigma=40.0)}
+
+        def color(self, x, dd, mask=None, **kw):
+            rgb = (x * 0.5 + 0.5).clamp(0, 1) * (0.5 + 0.5 * dd.abs())
+            if mask is None:
+                return rgb
+            out = torch.zeros(mask.shape[0], 3, dtype=x.dtype)
+            out[mask] = rgb[mask]
+            return out
+    ro, rd = torch.from_numpy(G["march_ro"]), torch.from_numpy(G["march_rd"])
+    R = AnalyticRun(bound=1, cuda_ray=False, density_scale=1, min_near=0.2)
+    R.eval()
+    ev = R.render(ro[None], rd[None], staged=True, max_ray_batch=1500, bg_color=1, perturb=False, num_steps=64, upsample_steps=48)
+    # (rays that miss the box have near = far = FLT_MAX: the reference's normalised depth is 0 / 0 = NaN there, and so is ours)
+    assert np.array_equal(ev["image"][0].numpy(), G["run_eval_image"], equal_nan=True)
+    assert np.array_equal(ev["depth"][0].numpy(), G["run_eval_depth"], equal_nan=True)
+    R.train()
+    torch.manual_seed(11)
+    tr = R.render(ro[None, :1024], rd[None, :1024], bg_color=1, perturb=True, num_steps=64, upsample_steps=48)
+    assert np.array_equal(tr["image"][0].numpy(), G["run_train_image"], equal_nan=True)
+    assert np.array_equal(tr["depth"][0].numpy(), G["run_train_depth"], equal_nan=True)
+    assert np.array_equal(tr["weights_sum"].numpy(), G["run_train_weights_sum"], equal_nan=True)
+    assert float(torch.nan_to_num(ev["image"]).std()) > 0.05 and 0.05 < float(torch.nan_to_num(tr["weights_sum"]).mean()) < 0.95  # (a real picture, not a blank)
+
+
 def test_network_matches_reference(oracle_wrappers, G):
     """same parameter names/shapes as nerf/network.py (checkpoint compatibility) and the same forward"""
     from nerf import network
