@@ -47,11 +47,13 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_render", action="store_true")
     ap.add_argument("--infer_batch_scale", type=int, default=4, help="inference samples/ray/iteration multiplier (1 = reference heuristic)")
-    ap.add_argument("--cpu_steps", type=int, default=2, help="timed CPU-baseline steps (median), after --cpu_warmup warm-ups")
-    ap.add_argument("--cpu_warmup", type=int, default=1)
-    ap.add_argument("--cpu_rays", type=int, default=4096, help="rays per CPU-baseline step")
-    ap.add_argument("--cpu_render", action="store_true", help="also time one 64x64 inference render on the CPU oracle (~2 min)")
+    ap.add_argument("--cpu_steps", type=int, default=5, help="timed CPU-baseline steps (median), after --cpu_warmup warm-ups (BASELINE.md §3: 2 + 5)")
+    ap.add_argument("--cpu_warmup", type=int, default=2)
+    ap.add_argument("--cpu_rays", type=int, default=1024, help="rays per CPU-baseline step (a bounded sample of the 4,096-ray step)")
+    ap.add_argument("--no_cpu_render", action="store_true", help="skip the 64x64 CPU renders (cuda_ray on and off) of BASELINE.md §3 (i)")
     ap.add_argument("--no_seal", action="store_true", help="skip the configs[2] (Seal bbox distillation) section")
+    ap.add_argument("--no_long_run", action="store_true", help="skip the 2 x 3,000-step convergence comparison (psnr.long_run)")
+    ap.add_argument("--long_run_steps", type=int, default=3000)
     ap.add_argument("--seal_teacher_steps", type=int, default=256)
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
@@ -144,18 +146,32 @@ class KernelTimers:
         return out
 
 
+def source_digest(rel="seal-3d_amd/csrc/gridencoder.hip"):
+    """sha256 (first 16 hex digits) of a kernel source file: profiles/rNN_timed_region.md records the one it was measured on"""
+    import hashlib
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), rel), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def profile_traffic(op):
     """HBM bytes per launch of the dominant op from the newest committed rocprofv3 PMC summary (profiles/rNN_timed_region.md:
     separate --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, gfx950 2x fetch correction applied,
-    tools/profile_bench.sh).  PMC counters cannot be collected from inside this process; None when no summary is there."""
+    tools/profile_bench.sh).  PMC counters cannot be collected from inside this process.  The summary names the sha256 of the
+    grid-encoder source it was measured on: a summary of OTHER kernels than the ones this run launches is refused (None)
+    rather than quoted — as is a summary without the digest line."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_timed_region.md")))
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_timed_region.md")))
     if not files:
         return None, None
-    kernels = ("k_grid_forward_pair",) if op == "grid_encode_forward" else ("k_bin_scatter4", "k_bin_accumulate4")
+    text = open(files[-1]).read()
+    m = re.search(r"gridencoder\.hip sha256:([0-9a-f]{16})", text)
+    if not m or m.group(1) != source_digest():
+        return None, f"{os.path.relpath(files[-1], here)} is stale (measured on another gridencoder.hip)"
+    kernels = ("k_grid_forward_pair",) if op == "grid_encode_forward" else ("k_bin_scatter6", "k_bin_accumulate6")
     total, seen = 0.0, set()
-    for line in open(files[-1]):
+    for line in text.splitlines():
         m = re.match(r"\| `([A-Za-z0-9_]+)", line)
         if not m or m.group(1) not in kernels or m.group(1) in seen:
             continue
@@ -167,7 +183,7 @@ def profile_traffic(op):
             return None, None
     if len(seen) != len(kernels):
         return None, None
-    return total, os.path.relpath(files[-1], os.path.dirname(os.path.abspath(__file__)))
+    return total, os.path.relpath(files[-1], here)
 
 
 def grid_meta(name, args):
@@ -213,15 +229,34 @@ def cpu_baseline(args, num_rays):
             samples += n
         dt = time.perf_counter() - t_all
         render = {}
-        if args.cpu_render:  # a 64x64 full render (4,096 rays) through the inference loop
+        if not args.no_cpu_render:  # a 64x64 full render (4,096 rays), `cuda_ray` on (inference loop) ...
             r = syn.get_rays(poses[:1], syn.lego_intrinsics(64, 64), 64, 64)
             net.device_compaction = False
             t0 = time.perf_counter()
             tr.render_image(r["rays_o"].contiguous(), r["rays_d"].contiguous())
-            render = {"render_64x64_rays_per_s": 4096 / (time.perf_counter() - t0)}
+            render["render_64x64_rays_per_s"] = 4096 / (time.perf_counter() - t0)
+            # ... and off: NeRFRenderer.run, 512 + 128 samples per ray (main_SealNeRF.py:47), staged like the reference's test loop
+            net.cuda_ray = False
+            net.eval()
+            try:
+                t0 = time.perf_counter()
+                with torch.no_grad():
+                    net.render(r["rays_o"].contiguous(), r["rays_d"].contiguous(), staged=True, max_ray_batch=1024, bg_color=1,
+                               perturb=False, num_steps=512, upsample_steps=128)
+                render["render_64x64_rays_per_s_cuda_ray_off"] = 4096 / (time.perf_counter() - t0)
+            finally:
+                net.cuda_ray = True
     finally:
         rm._backend, gg._backend, sh._backend = saved
-    return {"value": float(np.median(rates)), "unit": "samples/s", "cores": cores, "kind": "port", **render,
+    model_name = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                model_name = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": float(np.median(rates)), "unit": "samples/s", "cores": cores, "cpu_model": model_name, "kind": "port", **render,
             "sample": f"median of {args.cpu_steps} training steps (after {args.cpu_warmup} warm-up) x {num_rays} rays ({samples} samples, "
                       f"{dt:.1f} s) of the same synthetic scene, fp32, two-encoder nn.Linear network (the reference's --ff-off path), "
                       "native ops = CPU oracle + OpenMP"}
@@ -335,6 +370,50 @@ def seal_section(args, dev, batches, note=lambda m: None):
             "graph_captures": tr.n_captures}
 
 
+# ----------------------------------------------------------------------------- quality over a long run
+def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m: None):
+    """Does the native fp16 path (fp16 table gradients, exact fixed-point sums, native Adam + loss scaling, HIP-graph replay)
+    CONVERGE like the reference arrangement (torch.optim.Adam on fp32 `.grad`s + torch GradScaler, eager)?  Both train
+    configs[1]'s network from the same initial weights on the same batches for `steps` steps (lr 1e-2 decayed to 0.1x as
+    main_SealNeRF.py:283-288); PSNR (nerf/utils.py:226-233) on four HELD-OUT 200x200 views against the analytic scene."""
+    from nerf import network_ff, synthetic as syn
+    from nerf.trainer import GraphedTrainer, Trainer, psnr
+    kw = dict(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10)
+    pool, _ = make_batches(768, args.num_rays, 4242, dev, R, scene_bits, boxes)  # 3.1 M distinct rays of the 100 training cameras
+    views = syn.orbit_poses(4, seed=977)  # not among the 100 training cameras (seed 0)
+    rays = [syn.get_rays(views[i:i + 1].to(dev), syn.lego_intrinsics(200, 200), 200, 200) for i in range(4)]
+    gts = [analytic_targets(r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous(), scene_bits, boxes, R) for r in rays]
+    torch.manual_seed(args.seed + 5)
+    init = network_ff.NeRFNetwork(**kw).to(dev).state_dict()
+    out = {}
+    for tag, native in (("native_fp16_graph", True), ("torch_adam_fp32_eager", False)):
+        torch.manual_seed(args.seed + 6)
+        m = network_ff.NeRFNetwork(**kw).to(dev)
+        m.load_state_dict(init)
+        tr = GraphedTrainer(m, args.num_rays, lr=1e-2, fp16=True) if native else Trainer(m, lr=1e-2, fp16=True, native_optim=False)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            lr = 1e-2 * 0.1 ** min(i / steps, 1.0)
+            for g in tr.optimizer.param_groups:
+                g["lr"] = lr
+            if native and tr.graph is not None and i % 100 == 0:
+                tr.graph = None  # (the learning rate is a kernel argument of the captured step: re-capture on the decay schedule)
+            tr.train_step(*pool[i % len(pool)])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        vals = []
+        for r, gt in zip(rays, gts):
+            img = tr.render_image(r["rays_o"].contiguous(), r["rays_d"].contiguous())["image"][0]
+            vals.append(psnr(img, gt))
+        out[tag] = {"psnr_db_per_view": [round(v, 3) for v in vals], "psnr_db": float(np.mean(vals)), "train_s": round(dt, 2)}
+        note(f"long run [{tag}]: {np.mean(vals):.2f} dB in {dt:.1f} s")
+        del tr, m
+    out["steps"] = steps
+    out["delta_db"] = out["native_fp16_graph"]["psnr_db"] - out["torch_adam_fp32_eager"]["psnr_db"]
+    out["views"] = "4 held-out 200x200 orbit cameras (seed 977), analytic box scene"
+    return out
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     args = parse()
@@ -430,6 +509,23 @@ def main():
     elapsed = time.perf_counter() - t0
     trainer._maybe_update_extra_state = ues_inner
     ues_ms = [a.elapsed_time(b) for a, b in ues_events]
+    # secondary figure over (at least) 64 steps = four whole occupancy-update periods: `ms_per_step` of a short timed region moves
+    # by +-5 % with where the 16-step boundary falls (one 0.5 ms update inside 20 steps is 5 % of them)
+    long_steps = max(64, (args.steps + 15) // 16 * 16)
+    s64 = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    t64 = time.perf_counter()
+    ring_from = model.local_step % 16
+    for i in range(long_steps):
+        step(args.steps + i)
+        if model.local_step % 16 == 0 or trainer.global_step % trainer.update_extra_interval == 0:
+            s64 += model.step_counter[ring_from:(model.local_step - 1) % 16 + 1, 0].sum()
+            ring_from = 0 if trainer.global_step % trainer.update_extra_interval == 0 else model.local_step % 16
+    if model.local_step % 16 != ring_from:
+        s64 += model.step_counter[ring_from:model.local_step % 16, 0].sum()
+    torch.cuda.synchronize()
+    t64 = time.perf_counter() - t64
+    long_run = {"steps": long_steps, "ms_per_step": t64 / long_steps * 1e3, "samples_per_s_this_rank": float(s64.item()) / t64}
     timer_steps = args.steps
     if graphed:
         # HIP events cannot be recorded inside a graph replay: time the individual kernels in an eager pass of the
@@ -521,7 +617,7 @@ def main():
     if roofline_ffmlp:
         roofline_ffmlp["counters"] = "profiles/r07_timed_region.md (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F16 per kernel)"
 
-    extra = {"roofline_ffmlp": roofline_ffmlp}
+    extra = {"roofline_ffmlp": roofline_ffmlp, "samples_per_s_64steps": long_run}
     if graphed:
         extra["graph_captures_in_timed_region"] = trainer.n_captures - captures0
     if ues_ms:
@@ -551,6 +647,9 @@ def main():
         note("psnr vs oracle render")
         extra["psnr"] = psnr_vs_oracle(model, lambda: Net(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10),
                                        poses, scene_bits, boxes, dev, R)
+    if world == 1 and not args.no_long_run and args.net == "ff":
+        lr_ = long_run_quality(args, dev, R, scene_bits, boxes, steps=args.long_run_steps, note=note)
+        extra.setdefault("psnr", {})["long_run"] = lr_
     if world == 1 and not args.no_seal and args.net == "ff":
         note("seal section")
         del trainer

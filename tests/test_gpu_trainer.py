@@ -308,3 +308,21 @@ def test_sync_free_inference_loop_renders_the_same_frame(hip, net_kind):
     assert float(frames["host"][0].std()) > 0.01
     for tag in ("dev1", "dev4", "dev16"):
         assert torch.equal(frames[tag][0], frames["host"][0]) and torch.equal(frames[tag][1], frames["host"][1]), tag
+
+
+def test_long_run_native_fp16_path_converges_like_fp32_adam(hip):
+    """3,000 steps of configs[1]'s network from the same initial weights on the same 3.1 M-ray pool: the native path (fp16
+    gradient hand-over, exact fixed-point table sums, native Adam + loss scaling, HIP-graph replay) against torch.optim.Adam
+    on fp32 `.grad`s + torch GradScaler (eager).  PSNR on four held-out 200x200 views of the analytic scene: both above
+    28 dB, and within 0.5 dB of each other (the two trajectories are chaotic twins — different rounding, different RNG
+    consumption under capture — and land 0.05-0.3 dB apart from seed to seed; bench.py reports the pair as psnr.long_run)."""
+    import argparse
+    import bench
+    from nerf import synthetic as syn
+    dev = torch.device("cuda")
+    _, bits = syn.lego_like_density_grid(seed=0)
+    args = argparse.Namespace(num_rays=4096, seed=0)
+    out = bench.long_run_quality(args, dev, hip.RaymarchingBackend, torch.from_numpy(bits).to(dev), syn.lego_like_boxes(0), steps=3000)
+    a, b = out["native_fp16_graph"]["psnr_db"], out["torch_adam_fp32_eager"]["psnr_db"]
+    assert a >= 28.0 and b >= 28.0, out
+    assert abs(a - b) <= 0.5, out

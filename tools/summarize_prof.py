@@ -62,6 +62,10 @@ mf = {c: pmc("mfma", c) for c in ("SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_VALU_MFMA_B
 ca = {c: pmc("cache", c) for c in ("TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum")}
 with open(f"profiles/{tag}_timed_region.md", "w") as f:
     f.write(f"# rocprofv3 summary `{tag}` — `python bench.py --steps 32 --warmup 8 --no_cpu_baseline --no_render --no_seal`\n\n")
+    import hashlib
+    digest = hashlib.sha256(open("seal-3d_amd/csrc/gridencoder.hip", "rb").read()).hexdigest()[:16]
+    f.write(f"Measured on gridencoder.hip sha256:{digest} (bench.py quotes `roofline.traffic` from this file only while the source "
+            "still has this digest).\n\n")
     f.write(f"Timed region (last 32 steps, profiler attached): {window/1e6/32:.3f} ms/step wall, GPU busy {busy/1e6/32:.3f} ms/step "
             f"({100*busy/window:.0f} %), {len(sel)/32:.0f} kernel launches/step.\n\n")
     f.write("FETCH_SIZE / WRITE_SIZE are per-dispatch averages over the WHOLE run (KiB, raw counter values; on gfx950 FETCH_SIZE "
