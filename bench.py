@@ -640,6 +640,22 @@ def main():
                         for i in range(0, 640000, 160000)])
         extra.update({"render_infer_batch_scale": args.infer_batch_scale, "render_mrays_per_s": 0.64 / dtr,
                       "render_ms_per_frame": dtr * 1e3, "psnr_vs_analytic_scene": psnr(out["image"][0], gt)})
+        # roofline of the render's dominant kernel (the hash-grid forward of the inference loop): one more frame with HIP events
+        # around every grid_encode_forward call; points = the rows the kernel actually works on (device-side counts, n_valid)
+        rtm = KernelTimers(s3d_hip.GridBackend, ["grid_encode_forward"])
+        rtm.install(grid_meta)
+        trainer.render_image(ro, rd)
+        torch.cuda.synchronize()
+        rtm.remove()
+        rk = rtm.summary().get("grid_encode_forward")
+        if rk:
+            pts = rk["units"] * rk["calls"]
+            ach = pts * 588 / (rk["total_ms"] * 1e-3) / 1e9
+            extra["roofline_render"] = {"kernel": "grid_encode_forward (inference loop)", "bound": "hbm", "achieved": ach,
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                        "points_per_frame": pts, "launches_per_frame": rk["calls"],
+                                        "grid_forward_ms_per_frame": rk["total_ms"], "frame_ms": dtr * 1e3,
+                                        "mrays_per_s": 0.64 / dtr, "algorithmic_bytes_per_point": 588}
 
     def note(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)

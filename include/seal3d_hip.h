@@ -124,18 +124,25 @@ int s3d_composite_rays_train_backward(const float* grad_weights_sum, const float
                                       float* grad_rgbs, int path, s3d_stream_t stream);
 
 /* raymarching.h:17 void march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
- *                       max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas, noises) */
+ *                       max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas, noises)
+ * noises may be NULL (= all zero: no perturbation).  zero_unfilled (build extension): the reference's wrapper zero-fills
+ * xyzs / dirs / deltas before every call (raymarching.py:324-326: unfilled slots must read as zeros, deltas == 0 ends a
+ * ray's chunk); with zero_unfilled != 0 the kernel writes those zeros itself — the slots a ray does not fill and the rows
+ * behind the last ray up to rows_total (up to the next multiple of 128 of the live rows when n_alive_dev is given) — and
+ * the caller passes uninitialised buffers of rows_total rows. */
 int s3d_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
                    const float* rays_o, const float* rays_d, float bound, float dt_gamma,
                    uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* nears,
                    const float* fars, float* xyzs, float* dirs, float* deltas, const float* noises,
-                   const int32_t* n_alive_dev, int32_t* n_rows_out, s3d_stream_t stream);
+                   const int32_t* n_alive_dev, int32_t* n_rows_out, uint32_t rows_total, int zero_unfilled,
+                   s3d_stream_t stream);
 
 /* raymarching.h:18 void composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs,
  *                       deltas, weights_sum, depth, image) — in place */
 int s3d_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive,
-                       float* rays_t, const float* sigmas, const float* rgbs, const float* deltas,
+                       float* rays_t, const void* sigmas, const void* rgbs, const float* deltas,
                        float* weights_sum, float* depth, float* image, const int32_t* n_alive_dev,
+                       int sigmas_dtype /* S3D_F32 | S3D_F16: the network's outputs as they come */, int rgbs_dtype,
                        s3d_stream_t stream);
 
 /* Device-side replacement of the host compaction `rays_alive = rays_alive[rays_alive >= 0]`

@@ -890,12 +890,27 @@ __global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_
                                                    const float* __restrict__ fars, float* __restrict__ xyzs,
                                                    float* __restrict__ dirs, float* __restrict__ deltas,
                                                    const float* __restrict__ noises, const int32_t* __restrict__ n_alive_dev,
-                                                   int32_t* __restrict__ n_rows_out) {
+                                                   int32_t* __restrict__ n_rows_out, uint32_t rows_total, bool zero_unfilled) {
     // sync-free loop: `n_alive` is the host's upper bound (launch geometry, buffer extents), *n_alive_dev the real count
     const uint32_t n = blockIdx.x * 64 + threadIdx.x;
     const uint32_t live = alive_count(n_alive, n_alive_dev);
     if (n == 0 && n_rows_out) *n_rows_out = (int32_t)(live * n_step);
-    if (n >= live) return;
+    if (n >= live) {
+        // zero_unfilled: the caller's buffers are NOT pre-filled; rows behind the live rays that a consumer may read — up to the
+        // next multiple of 128 of the live rows when the count is on the device (n_valid), the whole buffer otherwise — are
+        // zeroed here (the slots a live ray does not fill are zeroed by its own lane below)
+        if (!zero_unfilled) return;
+        const uint32_t live_rows = live * n_step;
+        const uint32_t end = n_alive_dev ? min(rows_total, (live_rows + 127u) & ~127u) : rows_total;
+        for (uint32_t s = 0; s < n_step; s++) {
+            const size_t row = (size_t)n * n_step + s;
+            if (row >= end) break;
+            xyzs[row * 3] = 0.0f; xyzs[row * 3 + 1] = 0.0f; xyzs[row * 3 + 2] = 0.0f;
+            dirs[row * 3] = 0.0f; dirs[row * 3 + 1] = 0.0f; dirs[row * 3 + 2] = 0.0f;
+            deltas[row * 2] = 0.0f; deltas[row * 2 + 1] = 0.0f;
+        }
+        return;
+    }
     const uint32_t index = (uint32_t)rays_alive[n];
     const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
     const Ray r = load_ray(rays_o, rays_d, index);
@@ -904,7 +919,7 @@ __global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_
     float* pl = deltas + (size_t)n * n_step * 2;
     float t = rays_t[index];
     const float far = fars[index];
-    t = __builtin_fmaf(clampf(t * dt_gamma, p.dt_min, p.dt_max), noises[n], t);
+    t = __builtin_fmaf(clampf(t * dt_gamma, p.dt_min, p.dt_max), noises ? noises[n] : 0.0f, t);  // (no noise: t + x * 0 = t)
     float last_t = t;
     uint32_t step = 0;
     while (t < far && step < n_step) {
@@ -918,19 +933,30 @@ __global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_
             px += 3; pd += 3; pl += 2; step++;
         } else t = skip_to(p, t, tt);
     }
+    if (zero_unfilled) {
+        for (; step < n_step; step++) {
+            px[0] = 0.0f; px[1] = 0.0f; px[2] = 0.0f;
+            pd[0] = 0.0f; pd[1] = 0.0f; pd[2] = 0.0f;
+            pl[0] = 0.0f; pl[1] = 0.0f;
+            px += 3; pd += 3; pl += 2;
+        }
+    }
 }
 
+// TS / TC: float or __half — the network's outputs are taken as they come (the reference's wrapper casts them to fp32 first,
+// raymarching.py:356 custom_fwd; converting a binary16 on load gives the same value without the two cast launches per iteration)
+template <typename TS, typename TC>
 __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
                                                        int32_t* __restrict__ rays_alive, float* __restrict__ rays_t,
-                                                       const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                       const TS* __restrict__ sigmas, const TC* __restrict__ rgbs,
                                                        const float* __restrict__ deltas, float* __restrict__ weights_sum,
                                                        float* __restrict__ depth, float* __restrict__ image,
                                                        const int32_t* __restrict__ n_alive_dev) {
     const uint32_t n = blockIdx.x * 64 + threadIdx.x;
     if (n >= alive_count(n_alive, n_alive_dev)) return;
     const uint32_t index = (uint32_t)rays_alive[n];
-    const float* s = sigmas + (size_t)n * n_step;
-    const float* c = rgbs + (size_t)n * n_step * 3;
+    const TS* s = sigmas + (size_t)n * n_step;
+    const TC* c = rgbs + (size_t)n * n_step * 3;
     const float2* dl = reinterpret_cast<const float2*>(deltas) + (size_t)n * n_step;
     float t = rays_t[index];
     float weight_sum = weights_sum[index], d = depth[index];
@@ -939,15 +965,15 @@ __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_
     while (step < n_step) {
         const float2 dd = dl[step];
         if (dd.x == 0) break;
-        const float alpha = 1.0f - __expf(-s[step] * dd.x);
+        const float alpha = 1.0f - __expf(-(float)s[step] * dd.x);
         const float T = 1 - weight_sum;
         const float weight = alpha * T;
         weight_sum += weight;
         t += dd.y;
         d = __builtin_fmaf(weight, t, d);
-        r = __builtin_fmaf(weight, c[step * 3], r);
-        g = __builtin_fmaf(weight, c[step * 3 + 1], g);
-        b = __builtin_fmaf(weight, c[step * 3 + 2], b);
+        r = __builtin_fmaf(weight, (float)c[step * 3], r);
+        g = __builtin_fmaf(weight, (float)c[step * 3 + 1], g);
+        b = __builtin_fmaf(weight, (float)c[step * 3 + 2], b);
         if (T < T_thresh) break;
         step++;
     }
@@ -1125,27 +1151,40 @@ S3D_EXPORT int s3d_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* 
                               const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
                               uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
                               float* xyzs, float* dirs, float* deltas, const float* noises, const int32_t* n_alive_dev,
-                              int32_t* n_rows_out, s3d_stream_t stream) {
+                              int32_t* n_rows_out, uint32_t rows_total, int zero_unfilled, s3d_stream_t stream) {
     (void)nears;
     if (n_alive == 0 || n_step == 0) return S3D_OK;
-    S3D_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas && noises,
-                "march_rays: null pointer");
+    S3D_REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && fars && xyzs && dirs && deltas, "march_rays: null pointer");
     S3D_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024, "march_rays: unsupported cascade/grid size C=%u H=%u", C, H);
-    hipLaunchKernelGGL(k_march_rays, dim3(div_up<uint32_t>(n_alive, 64)), dim3(64), 0, as_stream(stream), n_alive, n_step,
+    S3D_REQUIRE(!zero_unfilled || rows_total >= n_alive * n_step, "march_rays: rows_total (the extent of xyzs / dirs / deltas) is "
+                "smaller than n_alive * n_step");
+    // with zero_unfilled the launch also covers the padding rows behind the last ray's chunk
+    const uint32_t lanes = zero_unfilled ? std::max(n_alive, div_up<uint32_t>(rows_total, n_step)) : n_alive;
+    hipLaunchKernelGGL(k_march_rays, dim3(div_up<uint32_t>(lanes, 64)), dim3(64), 0, as_stream(stream), n_alive, n_step,
                        rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs,
-                       deltas, noises, n_alive_dev, n_rows_out);
+                       deltas, noises, n_alive_dev, n_rows_out, rows_total, zero_unfilled != 0);
     return check_launch("march_rays");
 }
 
 S3D_EXPORT int s3d_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive,
-                                  float* rays_t, const float* sigmas, const float* rgbs, const float* deltas,
+                                  float* rays_t, const void* sigmas, const void* rgbs, const float* deltas,
                                   float* weights_sum, float* depth, float* image, const int32_t* n_alive_dev,
-                                  s3d_stream_t stream) {
+                                  int sigmas_dtype, int rgbs_dtype, s3d_stream_t stream) {
     if (n_alive == 0) return S3D_OK;
     S3D_REQUIRE(rays_alive && rays_t && sigmas && rgbs && deltas && weights_sum && depth && image,
                 "composite_rays: null pointer");
-    hipLaunchKernelGGL(k_composite_rays, dim3(div_up<uint32_t>(n_alive, 64)), dim3(64), 0, as_stream(stream), n_alive,
-                       n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, n_alive_dev);
+    S3D_REQUIRE((sigmas_dtype == S3D_F32 || sigmas_dtype == S3D_F16) && (rgbs_dtype == S3D_F32 || rgbs_dtype == S3D_F16),
+                "composite_rays: sigmas / rgbs must be f32 or f16");
+    const dim3 grid(div_up<uint32_t>(n_alive, 64)), block(64);
+    hipStream_t st = as_stream(stream);
+#define S3D_COMPOSITE(TS, TC)                                                                                              \
+    hipLaunchKernelGGL((k_composite_rays<TS, TC>), grid, block, 0, st, n_alive, n_step, T_thresh, rays_alive, rays_t,        \
+                       (const TS*)sigmas, (const TC*)rgbs, deltas, weights_sum, depth, image, n_alive_dev)
+    if (sigmas_dtype == S3D_F32 && rgbs_dtype == S3D_F32) S3D_COMPOSITE(float, float);
+    else if (sigmas_dtype == S3D_F32) S3D_COMPOSITE(float, __half);
+    else if (rgbs_dtype == S3D_F32) S3D_COMPOSITE(__half, float);
+    else S3D_COMPOSITE(__half, __half);
+#undef S3D_COMPOSITE
     return check_launch("composite_rays");
 }
 

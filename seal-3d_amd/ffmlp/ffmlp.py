@@ -197,6 +197,14 @@ class _FFMLPNgpMid(Function):
         return ((grad_inputs if calc else None), grad_weights) + (None,) * 7
 
 
+def _cached_half(w):
+    """fp16 copy of the weights for inference calls (custom_fwd(cast_inputs=half) casts on EVERY call: two launches per
+    iteration of the inference loop for a model that has no optimizer attached), cached per parameter version like the grid
+    encoder's table (gridencoder/grid.py: _half_table)"""
+    from gridencoder.grid import _half_table
+    return _half_table(w, True)
+
+
 class FFMLP(nn.Module):
     """ffmlp.py:99-169"""
 
@@ -258,6 +266,8 @@ class FFMLP(nn.Module):
                 ref = _ParamRef(w)
                 hook = self._autograd_hook
             w = w._s3d_half
+        elif not torch.is_grad_enabled() and w.is_cuda:
+            w = _cached_half(w)
         dims = (self.input_dim, self.hidden_dim, self.num_layers, self.activation, self.output_activation)
         return _FFMLPNgpMid.apply(inputs, w, dirs, dims, not self.training, ref, hook, 1 if level_major else 0, n_valid)
 
@@ -304,6 +314,8 @@ class FFMLP(nn.Module):
                 # in the graph when the inputs do not require a gradient either
                 hook = self._autograd_hook
             w = w._s3d_half
+        elif not torch.is_grad_enabled() and w.is_cuda:
+            w = _cached_half(w)  # (inference without an optimizer: one cast per weight version, not one per call)
         out = ffmlp_forward(inputs, w, self.input_dim, self.padded_output_dim, self.hidden_dim,
                             self.num_layers, self.activation, self.output_activation, not self.training,
                             inputs.requires_grad, ref, hook, input_layout, n_valid, rgb_head)

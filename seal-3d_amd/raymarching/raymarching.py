@@ -255,9 +255,16 @@ class _MarchRays(Function):
         rays_o, rays_d = _rays(rays_o, rays_d)
         dev, dt = rays_o.device, rays_o.dtype
         M = _align_up(n_alive * n_step, align)
-        xyzs, dirs, deltas = _zeros_332(M, dt, dev)
-        noises = torch.rand(n_alive, dtype=dt, device=dev) if perturb else torch.zeros(n_alive, dtype=dt, device=dev)
         extra = {} if n_alive_dev is None else {"n_alive_dev": n_alive_dev, "n_rows_out": n_rows_out}
+        if getattr(_backend, "zero_fills_march_rays", False):
+            # HIP backend: the kernel zeroes the slots it does not fill and takes `no noise` as a null pointer — the two fill
+            # launches per iteration of the inference loop (zero-initialised outputs, zero noises) are gone
+            xyzs, dirs, deltas = _empty_332(M, dt, dev)
+            noises = torch.rand(n_alive, dtype=dt, device=dev) if perturb else None
+            extra["zero_unfilled"] = True
+        else:
+            xyzs, dirs, deltas = _zeros_332(M, dt, dev)
+            noises = torch.rand(n_alive, dtype=dt, device=dev) if perturb else torch.zeros(n_alive, dtype=dt, device=dev)
         _backend.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H,
                             density_bitfield, near, far, xyzs, dirs, deltas, noises, **extra)
         return xyzs, dirs, deltas
@@ -270,12 +277,17 @@ class _CompositeRays(Function):
     """raymarching.py:351-373 — accumulates into weights_sum/depth/image IN PLACE, marks dead rays with -1."""
 
     @staticmethod
-    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
                 T_thresh=1e-2, n_alive_dev=None):
+        # the reference casts every input to fp32 (custom_fwd(cast_inputs=float32), raymarching.py:354).  The HIP kernel reads
+        # fp16 sigmas / rgbs as they leave the network and converts on load — the same values, two cast launches per iteration
+        # of the inference loop less; everything else (and every backend without that ability) is cast as in the reference
         extra = {} if n_alive_dev is None else {"n_alive_dev": n_alive_dev}
-        _backend.composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas.float().contiguous(),
-                                rgbs.float().contiguous(), deltas.float().contiguous(), weights_sum, depth, image, **extra)
+        half_ok = getattr(_backend, "zero_fills_march_rays", False)
+
+        def as_input(t):
+            return t.contiguous() if (half_ok and t.dtype == torch.float16) else t.float().contiguous()
+        _backend.composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, as_input(sigmas), as_input(rgbs), deltas.float().contiguous(), weights_sum, depth, image, **extra)
         return tuple()
 
 

@@ -362,25 +362,27 @@ class RaymarchingBackend:
                                                        C.c_int(RaymarchingBackend._composite_path), _stream()),
                "composite_rays_train_backward")
 
+    zero_fills_march_rays = True  # march_rays(zero_unfilled=True): the kernel writes the zeros of the unfilled slots itself
+
     @staticmethod
     def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, Cc, H, grid,
-                   nears, fars, xyzs, dirs, deltas, noises, n_alive_dev=None, n_rows_out=None):
-        """n_alive_dev / n_rows_out (build extension): device-side alive count and the sample-row count it implies"""
+                   nears, fars, xyzs, dirs, deltas, noises, n_alive_dev=None, n_rows_out=None, zero_unfilled=False):
+        """n_alive_dev / n_rows_out (build extension): device-side alive count and the sample-row count it implies;
+        zero_unfilled: xyzs / dirs / deltas arrive uninitialised, the kernel zeroes what it does not fill; noises may be None"""
         _need(rays_o, torch.float32, "rays_o")
         _check(lib().s3d_march_rays(_u(n_alive), _u(n_step), _p(rays_alive), _p(rays_t), _p(rays_o), _p(rays_d),
                                     _f(bound), _f(dt_gamma), _u(max_steps), _u(Cc), _u(H), _p(grid), _p(nears),
                                     _p(fars), _p(xyzs), _p(dirs), _p(deltas), _p(noises), _nv(n_alive_dev), _nv(n_rows_out),
-                                    _stream()), "march_rays")
+                                    _u(xyzs.shape[0]), C.c_int(int(zero_unfilled)), _stream()), "march_rays")
 
     @staticmethod
     def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth,
                        image, n_alive_dev=None):
-        for t, n in ((image, "image"), (sigmas, "sigmas"), (rgbs, "rgbs"), (deltas, "deltas"), (weights_sum, "weights_sum"),
-                     (depth, "depth"), (rays_t, "rays_t")):
+        for t, n in ((image, "image"), (deltas, "deltas"), (weights_sum, "weights_sum"), (depth, "depth"), (rays_t, "rays_t")):
             _need(t, torch.float32, n)
         _check(lib().s3d_composite_rays(_u(n_alive), _u(n_step), _f(T_thresh), _p(rays_alive), _p(rays_t),
                                         _p(sigmas), _p(rgbs), _p(deltas), _p(weights_sum), _p(depth), _p(image),
-                                        _nv(n_alive_dev), _stream()), "composite_rays")
+                                        _nv(n_alive_dev), C.c_int(_dt(sigmas)), C.c_int(_dt(rgbs)), _stream()), "composite_rays")
 
     # kernel choice handed to the library with every call (`path` arguments of seal3d_hip.h); binding-side state for
     # tests / experiments — the library itself keeps no process-wide switches
