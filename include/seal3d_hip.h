@@ -237,7 +237,11 @@ int s3d_freq_encode_backward(const float* grad, const float* outputs, uint32_t B
  * ffmlp/src/ffmlp.h:8-14.  All tensors fp16 (uint16_t bit patterns).
  * weights: [W,in] | (n-1) x [W,W] | [out,W], row-major [out,in] per layer (ffmlp.cu:631-634).
  * forward_buffer / backward_buffer: [n, B, W] post-activation / pre-activation-gradient scratch.
- * B must be a multiple of 128 (ffmlp.py:156-159 pads); in % 16 == 0; out == 16; W in {16,32,64,128}.
+ * B must be a multiple of 128 (ffmlp.py:156-159 pads); in % 16 == 0; out == 16; W in {16,32,64,128,256} (ffmlp.cu:40-44).
+ * W in {32,64} with in <= 64 (every network of the BASELINE configs) run on the register-resident MFMA kernels and have all
+ * the extensions below; the other shapes take a layer-by-layer path (one rocBLAS GEMM per matrix, fp16 storage / fp32
+ * accumulation, csrc/ffmlp_generic.hip) that implements the reference's interface only: forward_buffer / backward_buffer
+ * are then REQUIRED for training (plain row-major [n, B, W]) and inference_buffer must hold [2, B, W].
  * input_layout: 0 = inputs [B,in] row-major (the reference); 1 = level-major [in/2][B][2], i.e. the grid
  * encoder's own output layout read in place (and grad_inputs written in it) — no permute copies in between.
  * rgb_head (optional, build extension): fp32 [B, 3] = sigmoid(output[:, 0:3]) written INSTEAD of `outputs` (which may then
@@ -254,7 +258,8 @@ int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights, uint32_t 
                       uint32_t output_activation, uint16_t* forward_buffer, uint16_t* outputs,
                       int input_layout, const int32_t* n_valid, float* rgb_head, const float* mid_dirs,
                       float* mid_sigma, uint16_t* mid_color_in, uint16_t* mid_h0, s3d_stream_t stream);
-/* ffmlp.h:9: same network without storing intermediates (inference_buffer is unused scratch) */
+/* ffmlp.h:9: same network without storing intermediates (inference_buffer: unused by the MFMA kernels, [2, B, W] ping-pong
+ * scratch for the layer-by-layer shapes) */
 int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_t B, uint32_t input_dim,
                         uint32_t output_dim, uint32_t hidden_dim, uint32_t num_layers, uint32_t activation,
                         uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,

@@ -1250,6 +1250,15 @@ __global__ void __launch_bounds__(512) k_ffmlp_backward_duo(const _Float16* __re
 }
 
 constexpr uint32_t kWgradBlocks = 256;
+}  // namespace
+// csrc/ffmlp_generic.hip: the shapes the register-resident kernels do not cover (hidden 16 / 128 / 256, input_dim > 64)
+bool ffmlp_native_shape(uint32_t in_dim, uint32_t W);
+int ffmlp_generic_forward(const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t in_dim, uint32_t W, uint32_t n_layers, uint32_t act,
+                          uint32_t out_act, _Float16* acts, bool training, _Float16* out, hipStream_t st);
+int ffmlp_generic_backward(const _Float16* grad, const _Float16* X, const _Float16* Wt, const _Float16* fwd, uint32_t B, uint32_t in_dim,
+                           uint32_t W, uint32_t n_layers, uint32_t act, _Float16* bwd, _Float16* grad_inputs, _Float16* grad_weights,
+                           bool accumulate, float* found_inf, hipStream_t st);
+namespace {
 
 // `n_valid` of the entry point being served on this thread (see valid_rows()); the launch helpers below pass it on
 static thread_local const int32_t* t_n_valid = nullptr;
@@ -1259,14 +1268,16 @@ static thread_local const float* t_d_rgb = nullptr;      // ... of the backward 
 static thread_local const float* t_rgb_in = nullptr;     // ... and the head's output
 static thread_local MidFwd t_mid_fwd = {};               // density ("mid") head of the forward call being served
 static thread_local MidBwd t_mid_bwd = {};               // ... of the backward call
+static thread_local _Float16* t_generic_scratch = nullptr;  // inference_buffer of the s3d_ffmlp_inference call being served
 struct RowLimitScope {
     explicit RowLimitScope(const int32_t* p, float* found_inf = nullptr) { t_n_valid = p; t_found_inf = found_inf; }
     ~RowLimitScope() { t_n_valid = nullptr; t_found_inf = nullptr; }
 };
 
 int check_shape(uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t W, uint32_t n_layers) {
-    S3D_REQUIRE(W == 32 || W == 64, "ffmlp: hidden_dim %u not supported by the MFMA path (32 or 64)", W);
-    S3D_REQUIRE(in_dim > 0 && in_dim % 16 == 0 && in_dim <= 64, "ffmlp: input_dim must be 16*m, m in 1..4 (got %u)", in_dim);
+    S3D_REQUIRE(W == 16 || W == 32 || W == 64 || W == 128 || W == 256,
+                "FFMLP only support hidden_dim in [16, 32, 64, 128, 256], but got %u", W);  // ffmlp.cu:40-44
+    S3D_REQUIRE(in_dim > 0 && in_dim % 16 == 0, "ffmlp: input_dim must be a multiple of 16 (got %u)", in_dim);
     S3D_REQUIRE(out_dim >= 1 && out_dim <= 16, "FFMLP current only supports output dim <= 16, but got %u", out_dim);
     S3D_REQUIRE(n_layers >= 2 && n_layers + 1 <= kMaxMlpLayers, "ffmlp: num_layers must be in [2, %u]", kMaxMlpLayers - 1);
     S3D_REQUIRE(B % 128 == 0, "ffmlp: batch size must be a multiple of 128 (got %u)", B);
@@ -1336,6 +1347,7 @@ int launch_backward(const _Float16* grad, const _Float16* X, const _Float16* Wt,
 inline uint32_t fused_max_hidden(uint32_t W) { return W == 64 ? 2u : 3u; }
 
 inline bool fused_backward_supported(uint32_t in_dim, uint32_t out_dim, uint32_t W, uint32_t n_layers, uint32_t act) {
+    if (!ffmlp_native_shape(in_dim, W)) return false;
     return (W == 32 || W == 64) && in_dim % 16 == 0 && in_dim >= 16 && in_dim <= 64 && out_dim >= 1 && out_dim <= 16 &&
            n_layers >= 2 && n_layers - 1 <= fused_max_hidden(W) && act != ACT_SINE;
 }
@@ -1438,6 +1450,15 @@ S3D_EXPORT int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights
     S3D_REQUIRE(output_dim == 16, "ffmlp_forward: the output must be padded to 16 columns (ffmlp.py:117)");
     const _Float16* X = (const _Float16*)inputs; const _Float16* Wt = (const _Float16*)weights;
     _Float16* fb = (_Float16*)forward_buffer; _Float16* o = (_Float16*)outputs;
+    if (!ffmlp_native_shape(input_dim, hidden_dim)) {
+        S3D_REQUIRE(input_layout == 0 && !n_valid && !rgb_head && !mid_color_in && outputs,
+                    "ffmlp_forward: hidden_dim %u / input_dim %u take the layer-by-layer path, which implements the reference's "
+                    "interface only (row-major inputs, no heads, no n_valid)", hidden_dim, input_dim);
+        S3D_REQUIRE(forward_buffer || t_generic_scratch, "ffmlp_forward: this shape needs forward_buffer [n, B, W] (training) or "
+                    "inference_buffer [2, B, W] (inference)");
+        return ffmlp_generic_forward(X, Wt, B, input_dim, hidden_dim, num_layers, activation, output_activation,
+                                     fb ? fb : t_generic_scratch, fb != nullptr, o, as_stream(stream));
+    }
     if (hidden_dim == 64) return launch_forward<64>(X, Wt, B, input_dim, output_dim, num_layers, activation, output_activation, fb, o, (uint32_t)input_layout, as_stream(stream));
     return launch_forward<32>(X, Wt, B, input_dim, output_dim, num_layers, activation, output_activation, fb, o, (uint32_t)input_layout, as_stream(stream));
 }
@@ -1447,7 +1468,8 @@ S3D_EXPORT int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weigh
                                    uint32_t output_activation, uint16_t* inference_buffer, uint16_t* outputs,
                                    int input_layout, const int32_t* n_valid, float* rgb_head, const float* mid_dirs,
                                    float* mid_sigma, uint16_t* mid_color_in, uint16_t* mid_h0, s3d_stream_t stream) {
-    (void)inference_buffer;
+    struct Scratch { explicit Scratch(_Float16* p) { t_generic_scratch = p; } ~Scratch() { t_generic_scratch = nullptr; } }
+        scratch((_Float16*)inference_buffer);  // (only the layer-by-layer path of the non-native shapes uses it: [2, B, W])
     return s3d_ffmlp_forward(inputs, weights, B, input_dim, output_dim, hidden_dim, num_layers, activation,
                              output_activation, nullptr, outputs, input_layout, n_valid, rgb_head, mid_dirs, mid_sigma,
                              mid_color_in, mid_h0, stream);
@@ -1494,6 +1516,14 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
     S3D_REQUIRE(workspace && workspace_bytes >= s3d_ffmlp_backward_workspace_size(input_dim, output_dim, hidden_dim, num_layers),
                 "ffmlp_backward: workspace too small");
     _Float16* gi = calc_grad_inputs ? (_Float16*)grad_inputs : nullptr;
+    if (!ffmlp_native_shape(input_dim, hidden_dim)) {
+        S3D_REQUIRE(forward_buffer && backward_buffer && grad && input_layout == 0 && !n_valid && !grad_rgb && !mid_grad_color_in,
+                    "ffmlp_backward: hidden_dim %u / input_dim %u take the layer-by-layer path: forward_buffer and backward_buffer "
+                    "[n, B, W], row-major inputs, no heads, no n_valid", hidden_dim, input_dim);
+        return ffmlp_generic_backward((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights, (const _Float16*)forward_buffer,
+                                      B, input_dim, hidden_dim, num_layers, activation, (_Float16*)backward_buffer, gi,
+                                      (_Float16*)grad_weights, accumulate != 0, found_inf, as_stream(stream));
+    }
     if (!forward_buffer) {
         S3D_REQUIRE(fused_backward_supported(input_dim, 16, hidden_dim, num_layers, activation),
                     "ffmlp_backward: this network shape needs forward_buffer/backward_buffer (s3d_ffmlp_fused_backward_supported)");

@@ -56,7 +56,9 @@ class _FFMLPForward(Function):
         rgb = torch.empty(B, 3, device=inputs.device, dtype=torch.float32) if rgb_head else None
         outputs = None if rgb_head else torch.empty(B, output_dim, device=inputs.device, dtype=inputs.dtype)
         if inference:
-            scratch = torch.empty(B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
+            # (the reference's inference_buffer is [B, hidden]; the layer-by-layer path of the widths the fused kernels do not
+            #  cover ping-pongs between two such buffers, the fused kernels use none)
+            scratch = torch.empty(2, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
             extra = {}
             if input_layout:
                 extra["input_layout"] = input_layout

@@ -15,6 +15,12 @@ NETS = [  # in, W, n_layers, out(real), activation
     (64, 64, 2, 8, 0),    # in == W
     (32, 32, 4, 16, 0),   # W = 32, deeper
     (48, 64, 2, 16, 3),   # sigmoid, in = 48
+    # the widths ffmlp.cu:40-44 dispatches beside 32 / 64, and an input wider than 64: layer-by-layer path (csrc/ffmlp_generic.hip)
+    (32, 16, 2, 16, 0),
+    (32, 128, 3, 16, 0),
+    (64, 256, 2, 3, 0),
+    (128, 64, 2, 16, 0),
+    (32, 128, 2, 16, 3),  # sigmoid
 ]
 
 
@@ -55,7 +61,7 @@ def test_ffmlp_forward_backward(oracle, hip, in_dim, W, n, out, act, B):
     out_g = torch.empty(B, 16, dtype=torch.half, device="cuda")
     hip.FFMLPBackend.ffmlp_forward(xg, wg, B, in_dim, 16, W, n, act, 6, fb_g, out_g)
     out_i = torch.empty(B, 16, dtype=torch.half, device="cuda")
-    hip.FFMLPBackend.ffmlp_inference(xg, wg, B, in_dim, 16, W, n, act, 6, torch.empty(B, W, dtype=torch.half, device="cuda"), out_i)
+    hip.FFMLPBackend.ffmlp_inference(xg, wg, B, in_dim, 16, W, n, act, 6, torch.empty(2, B, W, dtype=torch.half, device="cuda"), out_i)
     torch.cuda.synchronize()
     assert torch.equal(out_g, out_i), "training and inference kernels must agree exactly"
     torch.testing.assert_close(out_g.cpu().float(), out_c.float(), rtol=2e-2, atol=2e-2)
@@ -104,7 +110,7 @@ def test_ffmlp_forward_backward(oracle, hip, in_dim, W, n, out, act, B):
         hip.FFMLPBackend.ffmlp_backward(grad.cuda(), xg, wg, None, B, in_dim, 16, W, n, act, 6, False, None, None, gw_n)
         assert torch.equal(gw_n.cpu().view(torch.int16), runs[0][1].view(torch.int16))
     else:
-        assert W == 64 and n - 1 > 2 or act == 2
+        assert W == 64 and n - 1 > 2 or act == 2 or W not in (32, 64) or in_dim > 64
 
 
 def test_ffmlp_rejects_bad_shapes(hip):
@@ -113,8 +119,11 @@ def test_ffmlp_rejects_bad_shapes(hip):
     with pytest.raises(RuntimeError, match="multiple of 128"):
         hip.FFMLPBackend.ffmlp_forward(x, w, 100, 32, 16, 64, 2, 0, 6, None, torch.empty(100, 16, dtype=torch.half, device="cuda"))
     x = torch.zeros(128, 32, dtype=torch.half, device="cuda")
-    with pytest.raises(RuntimeError, match="not supported"):
-        hip.FFMLPBackend.ffmlp_forward(x, w, 128, 32, 16, 128, 2, 0, 6, None, torch.empty(128, 16, dtype=torch.half, device="cuda"))
+    with pytest.raises(RuntimeError, match="only support hidden_dim"):  # (the reference's message, ffmlp.cu:44)
+        hip.FFMLPBackend.ffmlp_forward(x, w, 128, 32, 16, 48, 2, 0, 6, None, torch.empty(128, 16, dtype=torch.half, device="cuda"))
+    with pytest.raises(RuntimeError, match="needs forward_buffer"):  # hidden 128 trains through forward_buffer / backward_buffer
+        hip.FFMLPBackend.ffmlp_forward(x, torch.zeros(128 * (32 + 128 + 16), dtype=torch.half, device="cuda"), 128, 32, 16, 128, 2, 0, 6, None,
+                                       torch.empty(128, 16, dtype=torch.half, device="cuda"))
 
 
 def test_ffmlp_level_major_input_layout(hip):
@@ -211,3 +220,40 @@ def test_density_head_in_the_mlp_kernels_is_the_mid_kernel_sequence_bit_for_bit(
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
             s1, c1 = net.forward_ngp_mid(x0, d, level_major=True, n_valid=nv)
         assert torch.equal(s1[:rows], s_b) and torch.equal(c1[:rows], c_b)
+
+
+@pytest.mark.parametrize("W,in_dim,n", [(16, 32, 2), (128, 32, 3), (256, 64, 2), (64, 128, 2)])
+def test_ffmlp_module_other_widths_train_like_the_torch_twin(hip, W, in_dim, n):
+    """`FFMLP` with the hidden widths ffmlp.cu:40-44 dispatches beside 32 / 64 (and an input wider than 64): forward, input
+    gradient and weight gradient through the module's autograd path against the bias-free torch MLP on the same (fp16-rounded)
+    weights — the reference's own comparison (testing/test_ffmlp.py:11-43)."""
+    from ffmlp import FFMLP
+    torch.manual_seed(W + n)
+    net = FFMLP(in_dim, 3, W, n).cuda()
+    x = (torch.randn(128 * 5 + 17, in_dim, device="cuda") * 0.5).requires_grad_(True)  # ragged batch: the module pads to 128
+    with torch.autocast("cuda", dtype=torch.float16):
+        y = net(x)
+    assert y.shape == (x.shape[0], 3)
+    go = torch.randn_like(y.float()) * 0.1
+    y.float().backward(go)
+    w16 = net.weights.detach().half().float()
+    mats = _split(w16, in_dim, W, n)
+    xr = x.detach().half().float().requires_grad_(True)
+    wr = [m.clone().requires_grad_(True) for m in mats]
+    h = xr
+    for i, m in enumerate(wr):
+        h = h @ m.t()
+        if i != n:
+            h = torch.relu(h)
+    ref = h[:, :3]
+    ref.backward(go)
+    torch.testing.assert_close(y.float(), ref.detach(), rtol=3e-2, atol=3e-2)
+    assert (x.grad.float() - xr.grad).norm() / xr.grad.norm() < 3e-2
+    gw_ref = torch.cat([m.grad.reshape(-1) for m in wr])
+    gw = net.weights.grad.float()
+    assert (gw - gw_ref).abs().max() / gw_ref.abs().max() < 3e-2
+    # inference path (no_grad) gives the same outputs
+    net.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        yi = net(x.detach())
+    torch.testing.assert_close(yi.float(), y.detach().float(), rtol=1e-3, atol=1e-3)
