@@ -1948,7 +1948,10 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate6(const uint16
         S3D_STAMP(1, wg_lin, 1);
         // the first batch of records and the table rows of the write-out's first round are in flight while the accumulators
         // are cleared (first item only)
-        constexpr uint32_t U = 2;
+#ifndef S3D_BIN3_ACC_U  // groups of four records in flight per lane (plus as many prefetched).  Measured (r08, 2.6e5 ray-ordered points): 1: 104.8 us, 2: 107-112, 3: 122.8, 4: 155.4 (register spills) for the whole backward
+#define S3D_BIN3_ACC_U 1
+#endif
+        constexpr uint32_t U = S3D_BIN3_ACC_U;
         const uint32_t q0 = (wave / NS) * 64 + (threadIdx.x & 63u);
         Quad cur[U];
 #pragma unroll

@@ -251,8 +251,7 @@ struct Ray {
     float ox, oy, oz, dx, dy, dz, rdx, rdy, rdz;
 };
 struct MarchParams {
-    float bound, dt_gamma, dt_min, dt_max, rH, H3, Cf, Hf, Hm1;
-    double Hd;
+    float bound, dt_gamma, dt_min, dt_max, rH, H3, Cf, Hf, Hm1, halfH;
     const uint8_t* grid;
 };
 
@@ -264,7 +263,7 @@ __device__ __forceinline__ MarchParams make_params(float bound, float dt_gamma, 
     p.dt_max = 2 * kSqrt3 * (float)(1 << (C - 1)) / (float)H;
     p.rH = 1 / (float)H;
     p.H3 = (float)(H * H * H);
-    p.Cf = (float)C; p.Hf = (float)H; p.Hm1 = (float)(H - 1); p.Hd = (double)H;
+    p.Cf = (float)C; p.Hf = (float)H; p.Hm1 = (float)(H - 1); p.halfH = 0.5f * (float)H;
     p.grid = grid;
     return p;
 }
@@ -281,7 +280,7 @@ __device__ __forceinline__ int mip_level(float x, float y, float z, float dt, co
     int e1, e2;
     (void)frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e1);
     const int la = (int)fminf(p.Cf - 1, fmaxf(0.0f, (float)e1));
-    (void)frexpf((float)((double)(dt * p.Hf) * 0.5), &e2);
+    (void)frexpf((dt * p.Hf) * 0.5f, &e2);  // (`dt * H * 0.5`: the float product halved in double — halving is exact in float too)
     const int lb = (int)fminf(p.Cf - 1, fmaxf(0.0f, (float)e2));
     return la > lb ? la : lb;
 }
@@ -296,9 +295,14 @@ __device__ __forceinline__ bool probe(const Ray& r, const MarchParams& p, float 
     const int level = mip_level(x, y, z, dt, p);
     const float mip_bound = fminf(ldexpf(1.0f, level), p.bound);
     const float mip_rbound = 1 / mip_bound;
-    const int nx = (int)clampf((float)(0.5 * (double)__builtin_fmaf(x, mip_rbound, 1.0f) * p.Hd), 0.0f, p.Hm1);
-    const int ny = (int)clampf((float)(0.5 * (double)__builtin_fmaf(y, mip_rbound, 1.0f) * p.Hd), 0.0f, p.Hm1);
-    const int nz = (int)clampf((float)(0.5 * (double)__builtin_fmaf(z, mip_rbound, 1.0f) * p.Hd), 0.0f, p.Hm1);
+    // raymarching.cu:366-368 `0.5 * (x * mip_rbound + 1) * H` is a DOUBLE product of the float v = fma(x, mip_rbound, 1) (24
+    // significant bits) with the integer H <= 1,024: v * H / 2 has at most 35 bits, so the double holds the exact real number
+    // and the conversion back to float rounds it once — which is what ONE fp32 multiply of v by the exactly representable
+    // constant H / 2 does as well (IEEE: the correctly rounded exact product).  Bit-identical cells, no fp64 on the hot loop
+    // (quarter-rate on CDNA; the wave-per-ray count kernel spent a tenth of its 2,797 vector instructions here).
+    const int nx = (int)clampf(__builtin_fmaf(x, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);
+    const int ny = (int)clampf(__builtin_fmaf(y, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);
+    const int nz = (int)clampf(__builtin_fmaf(z, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);
     const uint32_t index = (uint32_t)((float)level * p.H3 + (float)morton3d((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
     const bool occ = (p.grid[index >> 3] & (1u << (index & 7u))) != 0;
     if (!occ) {
