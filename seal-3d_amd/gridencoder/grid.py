@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 from torch.amp import custom_bwd, custom_fwd
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
 
 import s3d_hip
 
@@ -31,6 +32,16 @@ def bump_weights_epoch():
     `Tensor._version`), so that cached fp16 tables are refreshed."""
     global _weights_epoch
     _weights_epoch += 1
+
+
+def _on_optimizer_step(optimizer, args, kwargs):
+    bump_weights_epoch()
+
+
+# torch's fused optimizers (Adam(fused=True) under GradScaler is the reference trainer's default on GPU) update the
+# parameters in place WITHOUT bumping `Tensor._version` (measured: version stays 0 across steps), so the version alone
+# cannot key a cache of casts: every torch optimizer step, of any optimizer, advances the epoch.
+_register_step_hook(_on_optimizer_step)
 
 
 def _half_table(embeddings, cache):

@@ -238,3 +238,42 @@ def test_seal_network_fused_mlps_match_linear_op_sequence(hip):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         s2, c2 = net(x, d)
     assert torch.equal(s2.float(), res[True][0]) and torch.equal(c2.float(), res[True][1])
+
+
+def test_cached_half_weights_follow_a_fused_torch_optimizer(hip):
+    """Adam(fused=True) updates parameters in place WITHOUT bumping Tensor._version; the no-grad / eval-mode caches of
+    fp16 casts (grid table, FFMLP weights) must still see every step (they key on the optimizer-step epoch)."""
+    import gridencoder.grid as gg
+    from ffmlp import FFMLP
+    torch.manual_seed(0)
+    enc = gg.GridEncoder(desired_resolution=256, log2_hashmap_size=14).cuda()
+    enc.embeddings.data.uniform_(-1, 1)
+    mlp = FFMLP(32, 16, 64, 2).cuda()
+    opt = torch.optim.Adam(list(enc.parameters()) + list(mlp.parameters()), lr=1e-1, fused=True)
+    scaler = torch.amp.GradScaler("cuda")
+    x = torch.rand(4096, 3, device="cuda") * 2 - 1
+
+    def infer():
+        enc.eval(), mlp.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            h = enc(x)
+            return h.float().clone(), mlp(h).float().clone()
+
+    e0, m0 = infer()
+    e0b, m0b = infer()  # second call: served from the cache
+    assert torch.equal(e0, e0b) and torch.equal(m0, m0b)
+    for _ in range(3):
+        enc.train(), mlp.train()
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = (mlp(enc(x)).float() ** 2).mean()
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+    e1, m1 = infer()
+    assert not torch.equal(e0, e1), "eval-mode grid output is stale after optimizer steps"
+    assert not torch.equal(m0, m1), "no-grad FFMLP output is stale after optimizer steps"
+    # and equals what freshly cast weights give
+    gg._half_cache.clear()
+    e2, m2 = infer()
+    assert torch.equal(e1, e2) and torch.equal(m1, m2)

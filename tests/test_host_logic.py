@@ -309,3 +309,15 @@ def test_tensorf_shrink_model_crops_factors_and_aabb(oracle_wrappers):
     # exactly the span of the kept rows, as in the reference) — a smooth field changes little
     after = net.get_sigma_feat(net._normalize(x)).detach()
     assert torch.isfinite(after).all() and float((after - before).abs().mean()) < 0.6 * float(before.abs().mean())
+
+
+def test_any_torch_optimizer_step_advances_the_weights_epoch(oracle_wrappers):
+    """Fused torch optimizers do not bump Tensor._version, so the fp16-cast caches key on an epoch that every
+    optimizer step advances (gridencoder/grid.py)."""
+    import gridencoder.grid as gg
+    p = torch.nn.Parameter(torch.ones(4))
+    opt = torch.optim.SGD([p], lr=0.1)
+    p.grad = torch.ones(4)
+    before = gg._weights_epoch
+    opt.step()
+    assert gg._weights_epoch == before + 1

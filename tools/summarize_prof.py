@@ -61,7 +61,7 @@ sq = {c: pmc("sq", c) for c in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "S
 mf = {c: pmc("mfma", c) for c in ("SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_MFMA", "GRBM_GUI_ACTIVE")}
 ca = {c: pmc("cache", c) for c in ("TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum")}
 with open(f"profiles/{tag}_timed_region.md", "w") as f:
-    f.write(f"# rocprofv3 summary `{tag}` — `python bench.py --steps 32 --warmup 8 --no_cpu_baseline --no_render --no_seal`\n\n")
+    f.write(f"# rocprofv3 summary `{tag}` — `python bench.py --steps 32 --warmup 8 --no_cpu_baseline --no_render --no_seal --no_long_run`\n\n")
     import hashlib
     digest = hashlib.sha256(open("seal-3d_amd/csrc/gridencoder.hip", "rb").read()).hexdigest()[:16]
     f.write(f"Measured on gridencoder.hip sha256:{digest} (bench.py quotes `roofline.traffic` from this file only while the source "
