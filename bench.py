@@ -615,7 +615,7 @@ def main():
                                 "frac_of_bound": ach / bound, "frac_of_mfma_peak": ach / mfma_peak, "avg_us": k["avg_us"],
                                 "samples_per_launch": k["units"], "flop_per_sample": flops, "algorithmic_bytes_per_sample": byts}
     if roofline_ffmlp:
-        roofline_ffmlp["counters"] = "profiles/r07_timed_region.md (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F16 per kernel)"
+        roofline_ffmlp["counters"] = "profiles/r08_timed_region.md (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F16 per kernel)"
 
     extra = {"roofline_ffmlp": roofline_ffmlp, "samples_per_s_64steps": long_run}
     if graphed:

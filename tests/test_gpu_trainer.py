@@ -326,3 +326,54 @@ def test_long_run_native_fp16_path_converges_like_fp32_adam(hip):
     a, b = out["native_fp16_graph"]["psnr_db"], out["torch_adam_fp32_eager"]["psnr_db"]
     assert a >= 28.0 and b >= 28.0, out
     assert abs(a - b) <= 0.5, out
+
+
+_DP2_SCRIPT = r'''
+import os, sys, torch, torch.distributed as dist
+REPO = os.environ["S3D_REPO"]
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "seal-3d_amd")); sys.path.insert(0, os.path.join(REPO, "tests"))
+import bench, s3d_hip
+from nerf import network_ff, synthetic as syn
+from nerf.trainer import GraphedTrainer
+from parallel import RayShardedDP, init_from_env
+rank, world, _ = init_from_env("gloo")
+torch.cuda.set_device(0)                      # both ranks share the box's one GPU: gloo moves CUDA tensors through the host
+torch.manual_seed(100 + rank)                 # replicas start DIFFERENT; register() adopts rank 0's parameters
+model = network_ff.NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).cuda()
+grid, bits = syn.lego_like_density_grid(seed=0)
+batches, _ = bench.make_batches(8, 2048, 0, torch.device("cuda"), s3d_hip.RaymarchingBackend,
+                                torch.from_numpy(bits).cuda(), syn.lego_like_boxes(0))
+dp = RayShardedDP()
+tr = GraphedTrainer(model, 2048, lr=1e-2, fp16=True, dist=dp)
+losses = []
+for i in range(44):                           # 16 eager steps (no sample statistics yet), capture, then replays
+    losses.append(float(tr.train_step(*batches[(2 * i + rank) % len(batches)])))   # each rank marches its own rays
+torch.cuda.synchronize()
+two_graphs = tr.graph is not None and tr.graph_opt is not None and not tr.collectives_in_graph
+flat = torch.cat([p.detach().float().reshape(-1) for p in model.parameters()] +
+                 [model.density_grid.reshape(-1), model.density_bitfield.float().reshape(-1)]).cpu()
+w = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(w, flat)
+same = all(torch.equal(w[0], t) for t in w)
+falls = sum(losses[-8:]) < 0.5 * sum(losses[:8])
+print(f"RANK{rank} two_graphs={two_graphs} same={same} falls={falls} finite={bool(torch.isfinite(flat).all())} "
+      f"fused_avg={dp.fused_avg()} replays={44 - 16 - tr.n_captures}")
+dist.destroy_process_group()
+'''
+
+
+def test_two_graph_dp_step_on_two_gloo_ranks(hip, tmp_path):
+    """GraphedTrainer's two-graph data-parallel step end to end on TWO ranks (gloo, both on this box's one GPU): forward +
+    backward graph, eager SUM all-reduce of the fp16 gradient buffer + divide, check + Adam graph; each rank marches its own
+    rays; after 44 steps (occupancy updates included) the replicas' parameters and occupancy grids are bit-identical."""
+    import subprocess
+    script = tmp_path / "dp2.py"
+    script.write_text(_DP2_SCRIPT)
+    env = dict(os.environ, S3D_REPO=REPO, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-3000:]
+    for r in (0, 1):
+        line = [l for l in res.stdout.splitlines() if l.startswith(f"RANK{r} ")]
+        assert line and "two_graphs=True same=True falls=True finite=True fused_avg=False" in line[0], res.stdout + res.stderr[-1500:]
