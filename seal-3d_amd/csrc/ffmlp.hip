@@ -117,6 +117,13 @@ __device__ __forceinline__ float16v zero16() {
 __device__ __forceinline__ half4 ld4(const _Float16* p) { return *reinterpret_cast<const half4*>(p); }
 __device__ __forceinline__ void st4(_Float16* p, half4 v) { *reinterpret_cast<half4*>(p) = v; }
 
+__device__ __forceinline__ half8 zero_half8() {
+    half8 z;
+#pragma unroll
+    for (int i = 0; i < 8; i++) z[i] = (_Float16)0.0f;
+    return z;
+}
+
 // B fragment of k-step s from a row-major [rows, width] matrix: row = this lane's batch point
 __device__ __forceinline__ half8 load_bfrag_rowmajor(const _Float16* row, uint32_t s, uint32_t h) {
     const half4 lo = ld4(row + 16 * s + 4 * h);
@@ -205,7 +212,7 @@ __device__ __forceinline__ half8 mid_grad_fragment(const MidBwd& mb, size_t row,
 
 // ------------------------------------------------------------------------------------ forward
 // LDS fragment directory: layer 0: MB*KS0 frags | hidden k: MB*KS frags each | last: KS frags
-template <int W, bool TRAIN, int ACT, int OACT>
+template <int W, bool TRAIN, int ACT, int OACT, int KS0T>  // KS0T: layer-0 k-steps known at compile time (2 / 4: the hot input widths 32 / 64), 0 = run-time
 __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restrict__ X, const _Float16* __restrict__ Wt,
                                                        uint32_t B, uint32_t in_dim, uint32_t out_dim, uint32_t n_layers,
                                                        uint32_t act, uint32_t out_act, _Float16* __restrict__ fwd,
@@ -224,41 +231,73 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
     const _Float16* w_hid = Wt + (size_t)W * in_dim;
     const _Float16* w_last = w_hid + (size_t)NH * W * W;
 
-    // stage all weights as A fragments (row = output feature, k permuted)
+    // stage all weights as A fragments (row = output feature, k permuted).  Element j of lane-half h is k = (j&3) + 8(j>>2) + 4h:
+    // two runs of four consecutive halfs, i.e. two 8-byte loads per fragment (rows are 32-byte aligned: widths are multiples
+    // of 16) instead of eight 2-byte ones
+#pragma unroll 1
     for (uint32_t f = wave; f < total; f += 4) {
-        half8 v;
+        const _Float16* r;
+        bool live = true;
         if (f < nf0) {
             const uint32_t mblk = f / KS0, s = f % KS0;
-            const _Float16* r = Wt + (size_t)(mblk * 32 + n) * in_dim + 16 * s;
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) v[j] = r[kperm(h, j)];
+            r = Wt + (size_t)(mblk * 32 + n) * in_dim + 16 * s;
         } else if (f < nf0 + nfh) {
             const uint32_t g = f - nf0, k = g / (MB * KS), mblk = (g / KS) % MB, s = g % KS;
-            const _Float16* r = w_hid + (size_t)k * W * W + (size_t)(mblk * 32 + n) * W + 16 * s;
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) v[j] = r[kperm(h, j)];
+            r = w_hid + (size_t)k * W * W + (size_t)(mblk * 32 + n) * W + 16 * s;
         } else {
             const uint32_t s = f - nf0 - nfh;
-            const _Float16* r = w_last + (size_t)n * W + 16 * s;
-#pragma unroll
-            for (uint32_t j = 0; j < 8; j++) v[j] = (n < out_dim) ? r[kperm(h, j)] : (_Float16)0.0f;
+            live = n < out_dim;
+            r = w_last + (size_t)(live ? n : 0) * W + 16 * s;
         }
-        frags[f * 64 + lane] = v;
+        frags[f * 64 + lane] = live ? load_bfrag_rowmajor(r, 0, h) : zero_half8();
     }
     __syncthreads();
 
     const uint32_t ntiles = valid_rows(B, n_valid) / 32;
-    for (uint32_t tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    // the NEXT tile's inputs (and view directions, for the density head) are requested before this tile's arithmetic: a wave
+    // walks 3 (training batch) to 15 (inference-loop batch) tiles, and with three waves per SIMD an exposed load latency per
+    // tile was most of a tile's time.  Only for the input widths instantiated with a compile-time step count: with a run-time
+    // count every layer-0 MFMA sits in its own branch and the accumulators are shuttled between the register files.
+    constexpr uint32_t KP = KS0T > 0 ? KS0T : 1;
+    const uint32_t tstride = gridDim.x * 4;
+    half8 bin[KP];
+    float dir[3] = {0.0f, 0.0f, 0.0f};
+    auto request = [&](uint32_t t, half8 (&dst)[KP], float (&d)[3]) {
+        const size_t r = (size_t)t * 32 + n;
+        if constexpr (KS0T > 0) {
+#pragma unroll
+            for (uint32_t s = 0; s < KP; s++) dst[s] = load_bfrag_input(X, in_layout, B, in_dim, r, s, h);
+        }
+        if (mid.cin) { d[0] = mid.dirs[r * 3]; d[1] = mid.dirs[r * 3 + 1]; d[2] = mid.dirs[r * 3 + 2]; }
+    };
+    uint32_t tile = blockIdx.x * 4 + wave;
+    if (tile < ntiles) request(tile, bin, dir);
+    for (; tile < ntiles; tile += tstride) {
         const size_t row = (size_t)tile * 32 + n;
         float16v acc[MB];
         half8 bf[KS];
+        half8 bnx[KP];
+        float dnx[3] = {0.0f, 0.0f, 0.0f};
+        if (tile + tstride < ntiles) request(tile + tstride, bnx, dnx);
 #pragma unroll
         for (uint32_t m = 0; m < MB; m++) acc[m] = zero16();
-        for (uint32_t s = 0; s < KS0; s++) {
-            const half8 b = load_bfrag_input(X, in_layout, B, in_dim, row, s, h);
+        if constexpr (KS0T > 0) {
 #pragma unroll
-            for (uint32_t m = 0; m < MB; m++) acc[m] = mfma(frags[(m * KS0 + s) * 64 + lane], b, acc[m]);
+            for (uint32_t s = 0; s < KP; s++) {
+#pragma unroll
+                for (uint32_t m = 0; m < MB; m++) acc[m] = mfma(frags[(m * KP + s) * 64 + lane], bin[s], acc[m]);
+            }
+#pragma unroll
+            for (uint32_t s = 0; s < KP; s++) bin[s] = bnx[s];
+        } else {
+            for (uint32_t s = 0; s < KS0; s++) {
+                const half8 b = load_bfrag_input(X, in_layout, B, in_dim, row, s, h);
+#pragma unroll
+                for (uint32_t m = 0; m < MB; m++) acc[m] = mfma(frags[(m * KS0 + s) * 64 + lane], b, acc[m]);
+            }
         }
+        const float dx = dir[0], dy = dir[1], dz = dir[2];
+        dir[0] = dnx[0]; dir[1] = dnx[1]; dir[2] = dnx[2];
         for (uint32_t layer = 0;; layer++) {
             // activation, fp16 rounding, re-use as next B operand
 #pragma unroll
@@ -321,7 +360,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
                 }
             if (h == 1) Tm[n * kMidRow + 31] = (_Float16)0.0f;
             {
-                const float x = mid.dirs[row * 3], y = mid.dirs[row * 3 + 1], z = mid.dirs[row * 3 + 2];
+                const float x = dx, y = dy, z = dz;
                 float sh[16], j0[1], j1[1], j2[1];
                 sh_eval<4, false>(x, y, z, mid.K, sh, j0, j1, j2);
                 half8 v;
@@ -1295,10 +1334,12 @@ int launch_forward(const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t i
     // (measured at 2.6e5 points: 768 workgroups 11.8 / 14.6 us for the 2- / 3-matrix net, 1024: 12.7 / 16.2, 2048: 16.9 / 21.6,
     //  512: 12.2 / 14.7 — every workgroup stages all weights once, three per CU still hide the tile latencies)
     if (grid > 768) grid = 768;
-#define S3D_FWD(TRAIN, A, O) hipLaunchKernelGGL((k_ffmlp_forward<W, TRAIN, A, O>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out, in_layout, t_n_valid, t_rgb_out, t_mid_fwd)
+#define S3D_FWD_K(TRAIN, A, O, K0) hipLaunchKernelGGL((k_ffmlp_forward<W, TRAIN, A, O, K0>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out, in_layout, t_n_valid, t_rgb_out, t_mid_fwd)
+#define S3D_FWD(TRAIN, A, O) do { if (in_dim == 32) S3D_FWD_K(TRAIN, A, O, 2); else if (in_dim == 64) S3D_FWD_K(TRAIN, A, O, 4); else S3D_FWD_K(TRAIN, A, O, 0); } while (0)
     const bool fast = act == ACT_RELU && out_act == ACT_NONE;  // the networks of the hot path; anything else: run-time switch
     if (fwd) { if (fast) S3D_FWD(true, ACT_RELU, ACT_NONE); else S3D_FWD(true, -1, -1); }
     else { if (fast) S3D_FWD(false, ACT_RELU, ACT_NONE); else S3D_FWD(false, -1, -1); }
+#undef S3D_FWD_K
 #undef S3D_FWD
     return check_launch("ffmlp_forward");
 }

@@ -20,11 +20,14 @@ namespace {
 constexpr float kSqrt3 = 1.7320508075688772f;
 constexpr float kRPi = 0.3183098861837907f;
 
+// (raymarching.cu:56-63 spreads the bits with multiplies by 0x00010001, 0x101, 0x11, 5; after each mask the shifted copy
+//  never overlaps the original, so `v * (1 + 2^k)` == `v | v << k` bit for bit — and a 32-bit integer multiply is a
+//  quarter-rate instruction here while shift-or is one full-rate v_lshl_or_b32: 12 multiplies per occupancy probe gone)
 __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
+    v = (v | (v << 16)) & 0xFF0000FFu;
+    v = (v | (v << 8)) & 0x0F00F00Fu;
+    v = (v | (v << 4)) & 0xC30C30C3u;
+    v = (v | (v << 2)) & 0x49249249u;
     return v;
 }
 __device__ __forceinline__ uint32_t morton3d(uint32_t x, uint32_t y, uint32_t z) {
@@ -887,7 +890,7 @@ __device__ __forceinline__ uint32_t alive_count(uint32_t bound, const int32_t* _
     return v <= 0 ? 0u : ((uint32_t)v < bound ? (uint32_t)v : bound);
 }
 
-__global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive,
+__global__ void __launch_bounds__(64) k_march_rays_v1(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive,
                                                    const float* __restrict__ rays_t, const float* __restrict__ rays_o,
                                                    const float* __restrict__ rays_d, float bound, float dt_gamma,
                                                    uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
@@ -945,6 +948,152 @@ __global__ void __launch_bounds__(64) k_march_rays(uint32_t n_alive, uint32_t n_
             px += 3; pd += 3; pl += 2;
         }
     }
+}
+
+// ---- march_rays, second generation: two launches ----
+// Measured on the first one (r08, 800x800 frame, tools/run_pmc_render.sh): 6,400 vector instructions per wave at 35 % active
+// lanes — a ray ends after n_step samples or at its far plane, its lane idles until the slowest of the wave's 64 rays is
+// done — 12 quarter-rate integer multiplies per probe in the morton code, and 32 bytes per sample leaving in 4-byte stores
+// 32 * n_step bytes apart (186 MB of HBM writes per launch for 80 MB of samples).  Now:
+//  (1) k_march_rays_t walks the rays and records, per emitted sample, only (t, previous t) into the sample's own `deltas` row.
+//      A wave owns a POOL of consecutive ray slots (64 ... 256) and hands the next one to a lane that has finished its ray
+//      (ballot + prefix count, no atomics): lanes stay busy until the pool runs dry.  Morton codes come from a per-workgroup
+//      LDS table of spread coordinates; single-cascade grids (bound <= 1) skip the mip-level arithmetic.
+//  (2) k_march_rays_expand, one lane per sample row, turns (t, previous t) into xyz / dir / (dt, t' - previous t) with the
+//      reference's expressions (raymarching.cu:759-775) and writes whole rows side by side; slots a ray did not fill and the
+//      padding rows are zeroed here.
+// Same samples, bit for bit (the t sequence and every emitted value are computed by the same float expressions).
+template <bool C1>
+__device__ __forceinline__ bool probe_lut(const Ray& r, const MarchParams& p, const uint32_t* __restrict__ lut, float t,
+                                          float& dt, float& t_skip) {
+    const float x = clampf(__builtin_fmaf(t, r.dx, r.ox), -p.bound, p.bound);
+    const float y = clampf(__builtin_fmaf(t, r.dy, r.oy), -p.bound, p.bound);
+    const float z = clampf(__builtin_fmaf(t, r.dz, r.oz), -p.bound, p.bound);
+    dt = clampf(t * p.dt_gamma, p.dt_min, p.dt_max);
+    int level = 0;
+    float mip_bound, mip_rbound;
+    if constexpr (C1) {  // one cascade: both exponents clamp to level 0 (mip_level with Cf = 1)
+        mip_bound = fminf(1.0f, p.bound);
+        mip_rbound = 1 / mip_bound;
+    } else {
+        level = mip_level(x, y, z, dt, p);
+        mip_bound = fminf(ldexpf(1.0f, level), p.bound);
+        mip_rbound = 1 / mip_bound;
+    }
+    const int nx = (int)clampf(__builtin_fmaf(x, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);  // (see probe(): no fp64 needed)
+    const int ny = (int)clampf(__builtin_fmaf(y, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);
+    const int nz = (int)clampf(__builtin_fmaf(z, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);
+    const uint32_t m = lut[nx] | (lut[ny] << 1) | (lut[nz] << 2);
+    uint32_t index;
+    if constexpr (C1) index = (uint32_t)(float)m;  // raymarching.cu:769 forms `level * H3 + morton` in float: 0 * H3 + (float)m
+    else index = (uint32_t)((float)level * p.H3 + (float)m);
+    const bool occ = (p.grid[index >> 3] & (1u << (index & 7u))) != 0;
+    if (!occ) {
+        const float sx = copysignf(1.0f, r.dx), sy = copysignf(1.0f, r.dy), sz = copysignf(1.0f, r.dz);
+        const float tx = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.5f, sx, (float)nx + 0.5f) * p.rH, 2.0f, -1.0f), mip_bound, -x) * r.rdx;
+        const float ty = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.5f, sy, (float)ny + 0.5f) * p.rH, 2.0f, -1.0f), mip_bound, -y) * r.rdy;
+        const float tz = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.5f, sz, (float)nz + 0.5f) * p.rH, 2.0f, -1.0f), mip_bound, -z) * r.rdz;
+        t_skip = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    }
+    return occ;
+}
+
+constexpr uint32_t kMarchRefill = 16;  // idle lanes of a wave before the next ray slots of its pool are handed out
+
+template <bool C1>
+__global__ void __launch_bounds__(256) k_march_rays_t(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive,
+                                                      const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                                                      const float* __restrict__ rays_d, float bound, float dt_gamma,
+                                                      uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                                                      const float* __restrict__ fars, float2* __restrict__ tl,
+                                                      const float* __restrict__ noises, const int32_t* __restrict__ n_alive_dev,
+                                                      int32_t* __restrict__ n_rows_out, uint32_t pool) {
+    __shared__ uint32_t lut[1024];
+    for (uint32_t i = threadIdx.x; i < H; i += 256) lut[i] = expand_bits(i);
+    __syncthreads();
+    const uint32_t live = alive_count(n_alive, n_alive_dev);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_rows_out) *n_rows_out = (int32_t)(live * n_step);
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint32_t next = wave * pool;  // (wave-uniform) first slot of the pool not handed out yet
+    const uint32_t pool_end = min(next + pool, live);
+    if (next >= pool_end) return;
+    const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
+    Ray r{};
+    float t = 0.0f, last_t = 0.0f, far = 0.0f;
+    uint32_t step = 0;
+    float2* row = tl;
+    bool busy = false;
+    for (;;) {
+        const unsigned long long idle = __ballot(!busy);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (next < pool_end && (n_idle >= kMarchRefill || n_idle == 64u)) {
+            if (!busy) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const uint32_t n = next + rank;
+                if (n < pool_end) {
+                    const uint32_t index = (uint32_t)rays_alive[n];
+                    r = load_ray(rays_o, rays_d, index);
+                    t = rays_t[index];
+                    far = fars[index];
+                    t = __builtin_fmaf(clampf(t * dt_gamma, p.dt_min, p.dt_max), noises ? noises[n] : 0.0f, t);  // (no noise: t + x * 0 = t)
+                    last_t = t;
+                    step = 0;
+                    row = tl + (size_t)n * n_step;
+                    busy = true;
+                }
+            }
+            next += n_idle;
+        } else if (n_idle == 64u) break;  // nothing running, nothing left to hand out
+        if (busy) {
+            if (t < far && step < n_step) {
+                float dt, tt;
+                if (probe_lut<C1>(r, p, lut, t, dt, tt)) {
+                    row[step] = make_float2(t, last_t);
+                    t += dt;
+                    last_t = t;
+                    step++;
+                } else t = skip_to(p, t, tt);
+            } else {
+                for (; step < n_step; step++) row[step] = make_float2(-1.0f, 0.0f);  // unfilled slot: (t < 0)
+                busy = false;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_march_rays_expand(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive,
+                                                           const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                           float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                                                           float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                           float2* __restrict__ deltas, const int32_t* __restrict__ n_alive_dev,
+                                                           uint32_t rows_total, bool zero_unfilled) {
+    const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t live = alive_count(n_alive, n_alive_dev);
+    const uint32_t live_rows = live * n_step;
+    float x = 0.0f, y = 0.0f, z = 0.0f, dx = 0.0f, dy = 0.0f, dz = 0.0f, d0 = 0.0f, d1 = 0.0f;
+    if (row >= live_rows) {
+        // rows behind the live rays that a consumer may read — up to the next multiple of 128 of the live rows when the count is
+        // on the device (n_valid), the whole buffer otherwise — are zeroed when the caller's buffers arrive uninitialised
+        const uint32_t end = n_alive_dev ? min(rows_total, (live_rows + 127u) & ~127u) : rows_total;
+        if (!zero_unfilled || row >= end) return;
+    } else {
+        const float2 v = deltas[row];
+        if (v.x >= 0.0f) {
+            const uint32_t n = row / n_step;
+            const uint32_t index = (uint32_t)rays_alive[n];
+            const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, nullptr);
+            const float t = v.x;
+            dx = rays_d[index * 3]; dy = rays_d[index * 3 + 1]; dz = rays_d[index * 3 + 2];
+            x = clampf(__builtin_fmaf(t, dx, rays_o[index * 3]), -bound, bound);
+            y = clampf(__builtin_fmaf(t, dy, rays_o[index * 3 + 1]), -bound, bound);
+            z = clampf(__builtin_fmaf(t, dz, rays_o[index * 3 + 2]), -bound, bound);
+            d0 = clampf(t * dt_gamma, p.dt_min, p.dt_max);
+            d1 = (t + d0) - v.y;
+        }
+    }
+    xyzs[(size_t)row * 3] = x; xyzs[(size_t)row * 3 + 1] = y; xyzs[(size_t)row * 3 + 2] = z;
+    dirs[(size_t)row * 3] = dx; dirs[(size_t)row * 3 + 1] = dy; dirs[(size_t)row * 3 + 2] = dz;
+    deltas[row] = make_float2(d0, d1);
 }
 
 // TS / TC: float or __half — the network's outputs are taken as they come (the reference's wrapper casts them to fp32 first,
@@ -1162,11 +1311,31 @@ S3D_EXPORT int s3d_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* 
     S3D_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024, "march_rays: unsupported cascade/grid size C=%u H=%u", C, H);
     S3D_REQUIRE(!zero_unfilled || rows_total >= n_alive * n_step, "march_rays: rows_total (the extent of xyzs / dirs / deltas) is "
                 "smaller than n_alive * n_step");
+#ifdef S3D_MARCH_RAYS_V1  // first generation (one launch, lane per ray): variant builds for A/B runs only
     // with zero_unfilled the launch also covers the padding rows behind the last ray's chunk
     const uint32_t lanes = zero_unfilled ? std::max(n_alive, div_up<uint32_t>(rows_total, n_step)) : n_alive;
-    hipLaunchKernelGGL(k_march_rays, dim3(div_up<uint32_t>(lanes, 64)), dim3(64), 0, as_stream(stream), n_alive, n_step,
+    hipLaunchKernelGGL(k_march_rays_v1, dim3(div_up<uint32_t>(lanes, 64)), dim3(64), 0, as_stream(stream), n_alive, n_step,
                        rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs,
                        deltas, noises, n_alive_dev, n_rows_out, rows_total, zero_unfilled != 0);
+#else
+    S3D_REQUIRE((uint64_t)n_alive * n_step < (1ull << 32) && (zero_unfilled || rows_total >= n_alive * n_step || rows_total == 0),
+                "march_rays: n_alive * n_step does not fit the sample buffers");
+    // ray slots per wave: enough waves to fill the chip (>= 4 per SIMD while the rays last), pools no larger than 256
+    uint32_t pool = (n_alive / 4096u) & ~63u;
+    pool = pool < 64u ? 64u : (pool > 256u ? 256u : pool);
+    const dim3 g1(div_up<uint32_t>(n_alive, 4 * pool)), b(256);
+    float2* tl = reinterpret_cast<float2*>(deltas);
+    if (C == 1)
+        hipLaunchKernelGGL(k_march_rays_t<true>, g1, b, 0, as_stream(stream), n_alive, n_step, rays_alive, rays_t, rays_o, rays_d,
+                           bound, dt_gamma, max_steps, C, H, grid, fars, tl, noises, n_alive_dev, n_rows_out, pool);
+    else
+        hipLaunchKernelGGL(k_march_rays_t<false>, g1, b, 0, as_stream(stream), n_alive, n_step, rays_alive, rays_t, rays_o, rays_d,
+                           bound, dt_gamma, max_steps, C, H, grid, fars, tl, noises, n_alive_dev, n_rows_out, pool);
+    const uint32_t rows = zero_unfilled ? std::max(n_alive * n_step, rows_total) : n_alive * n_step;
+    hipLaunchKernelGGL(k_march_rays_expand, dim3(div_up<uint32_t>(rows, 256)), b, 0, as_stream(stream), n_alive, n_step, rays_alive,
+                       rays_o, rays_d, bound, dt_gamma, max_steps, C, H, xyzs, dirs, tl, n_alive_dev, rows_total,
+                       zero_unfilled != 0);
+#endif
     return check_launch("march_rays");
 }
 

@@ -394,6 +394,60 @@ def test_march_and_composite_inference_trace(oracle, hip):
     assert (st["cpu"][0][2][2] == -1).any()
 
 
+@pytest.mark.parametrize("cascade,bound,dt_gamma,n_alive,n_step", [
+    (1, 1.0, 0.0, 640000, 4),        # first iterations of an 800x800 frame: every ray alive (wave pools of 128 slots)
+    (1, 1.0, 0.0, 300000, 9),        # later iteration: a subset alive, rays_t advanced into the scene
+    (2, 2.0, 1 / 128, 290000, 7),    # two cascades, growing steps (the general mip-level path)
+    (1, 1.0, 0.0, 1000, 32),         # tail of the loop
+])
+def test_march_rays_full_frame_bit_exact(oracle, hip, cascade, bound, dt_gamma, n_alive, n_step):
+    """s3d_march_rays at frame size (two launches: t walk with lane refill from wave pools, then row expansion) vs the
+    oracle's per-ray loop: every sample row bit for bit, unfilled slots and padding rows zero although the buffers arrive
+    as garbage (zero_unfilled), device-side alive count included."""
+    _, bits = _scene(seed=0, cascade=cascade, bound=bound)
+    N = 800 * 800
+    poses = syn.orbit_poses(1, seed=9)
+    r = syn.get_rays(poses, syn.lego_intrinsics(), 800, 800)
+    ro, rd = r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous()
+    aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound])
+    nears, fars = torch.empty(N), torch.empty(N)
+    oracle.RaymarchingBackend.near_far_from_aabb(ro, rd, aabb, N, 0.2, nears, fars)
+    g = torch.Generator().manual_seed(11)
+    alive = torch.randperm(N, generator=g)[:n_alive].sort().values.int()
+    rays_t = nears + torch.rand(N, generator=g) * (0.0 if n_alive == N else 1.5)  # (later iterations start inside the scene)
+    noises = torch.rand(n_alive, generator=g)
+    M = n_alive * n_step
+    M += 128 - M % 128
+    H = 128
+    x0, d0, l0 = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
+    oracle.RaymarchingBackend.march_rays(n_alive, n_step, alive, rays_t, ro, rd, bound, dt_gamma, 1024, cascade, H, bits, nears,
+                                         fars, x0, d0, l0, noises)
+    c = lambda t: t.cuda()
+    for dev_count in (False, True):
+        # device-side count: the launch is sized for an upper bound, the real count sits in device memory
+        bound_n = n_alive if not dev_count else min(N, n_alive + 4097)
+        alive_g = torch.full((bound_n,), -7, dtype=torch.int32)
+        alive_g[:n_alive] = alive
+        Mg = max(M, bound_n * n_step + 128)
+        xg, dg, lg = (torch.full((Mg, k), float("nan"), device="cuda") for k in (3, 3, 2))
+        cnt = torch.tensor([n_alive], dtype=torch.int32, device="cuda") if dev_count else None
+        rows = torch.zeros(1, dtype=torch.int32, device="cuda") if dev_count else None
+        noise_g = torch.zeros(bound_n)
+        noise_g[:n_alive] = noises
+        hip.RaymarchingBackend.march_rays(bound_n, n_step, c(alive_g), c(rays_t), c(ro), c(rd), bound, dt_gamma, 1024, cascade, H,
+                                          c(bits), c(nears), c(fars), xg, dg, lg, c(noise_g), n_alive_dev=cnt, n_rows_out=rows,
+                                          zero_unfilled=True)
+        torch.cuda.synchronize()
+        if dev_count:
+            assert int(rows) == n_alive * n_step
+        live = n_alive * n_step
+        end = ((live + 127) // 128) * 128 if dev_count else Mg   # rows a count-bounded consumer may read / the whole buffer
+        for a, b, k in ((x0, xg, 3), (d0, dg, 3), (l0, lg, 2)):
+            assert np.array_equal(a[:live].numpy().view(np.uint32), b[:live].cpu().numpy().view(np.uint32))
+            assert float(b[live:end].abs().sum()) == 0.0, "padding rows must be zero"
+    assert (l0[:n_alive * n_step, 0] == 0).any() and (l0[:, 0] != 0).any()
+
+
 def test_full_size_properties(hip):
     """BASELINE size (800x800 rays): size-independent properties instead of an oracle run."""
     _, bits = _scene(seed=0)
