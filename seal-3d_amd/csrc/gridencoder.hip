@@ -1578,10 +1578,12 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
     static_assert(P * K < 65536 && P % 64 == 0, "positions inside a chunk are 16-bit fields");
     static_assert(kBinAccBytes / (8 * C) <= 65536, "row-in-slice is a 16-bit key");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);           // records of the chunk per slice
-    uint32_t* lo = cnt + kBinMaxSlices;                               // run start in the chunk's sorted order
-    uint2* tab = reinterpret_cast<uint2*>(lo + kBinMaxSlices);        // {bucket position of the run - run start, run start | records that fit << 16}
-    uint2* stage = tab + kBinMaxSlices;                               // [P * K] {value, slice << 16 | row-in-slice}
+    // (tables sized by the call's largest slice count, not by kBinMaxSlices: at 64 slices the workgroup needs 33 KB instead of
+    //  40 KB + 12 B — which was 52 bytes too much for a FOURTH workgroup per CU)
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);           // [smax] records of the chunk per slice
+    uint32_t* lo = cnt + smax;                                        // [smax] run start in the chunk's sorted order
+    uint2* tab = reinterpret_cast<uint2*>(lo + smax);                 // [smax] {bucket position of the run - run start, run start | records that fit << 16}
+    uint2* stage = tab + smax;                                        // [P * K] {value, slice << 16 | row-in-slice}
     __shared__ uint32_t total_s, arrived, spilled_s;
 
     const uint32_t lip = S3D_BIN3_LEVEL_FAST ? blockIdx.x : blockIdx.y;  // level inside the pass
@@ -2360,12 +2362,13 @@ int launch_binned3(const T* grad, const float* inputs, const int32_t* offsets, T
                    unsigned char* control, hipStream_t st) {
     constexpr uint32_t P = S3D_BIN3_P;
     constexpr uint32_t K = 1u << D;
-    constexpr uint32_t stage = 4 * kBinMaxSlices * 4 + P * K * 8;  // counters, run starts, run table (8 B), staged records
+    constexpr uint32_t stage_max = 4 * kBinMaxSlices * 4 + P * K * 8;  // counters, run starts, run table (8 B), staged records
+    const uint32_t stage = 4 * lay.smax * 4 + P * K * 8;
     static std::atomic<uint64_t> attr_devs{0};
     int dev;
     if (device_needs_setup(attr_devs, &dev)) {
         S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_scatter6<T, D, C, FIXED24, P>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage));
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_max));
         S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_accumulate6<T, D, C, FIXED24, P>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinAccBytes));
         device_setup_done(attr_devs, dev);

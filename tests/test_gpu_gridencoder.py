@@ -382,3 +382,49 @@ def test_grid_backward_binned_inside_graph_capture(hip):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(ge.view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize("dtype,C,gridtype", [(torch.float16, 2, 0), (torch.float32, 1, 0), (torch.float16, 2, 1)])
+def test_grid_backward_plane_of_group_boundary_cells(oracle, hip, dtype, C, gridtype):
+    """Binned backward on a batch built against the slice interleave: half of the points sit in x cells that are 31 mod 32 on
+    one level — the two x-corners of every corner pair then fall into DIFFERENT 32-row groups, i.e. different table slices —
+    in distinct cells (nothing merges), on hashed and on tiled (wrapping, non power-of-two) tables; the other half random.
+    All: equal to the oracle's sums; fp16 on that level: bit-identical between the record generations (exact sums)."""
+    D, L, base = 3, 16, 16
+    offsets, S, total = _enc_meta(D, L, C, base, 19, 2048, False)
+    g = torch.Generator().manual_seed(5)
+    B = 24000
+    lvl = 9
+    scale = float(2.0 ** (lvl * S) * base - 1.0)
+    res = int(np.ceil(scale)) + 1
+    cells = torch.arange(31, res - 1, 32)
+    cx = cells[torch.randint(0, len(cells), (B,), generator=g)].float()
+    x = torch.rand(B, D, generator=g)
+    x[:, 0] = (cx + 0.25 - 0.5) / scale            # pos = x * scale + 0.5 -> cell cx, fraction 0.25
+    x[B // 2:] = torch.rand(B - B // 2, D, generator=g)
+    assert float(x.min()) >= 0 and float(x.max()) <= 1
+    pg = torch.floor(x[: B // 2, 0] * scale + 0.5).long()
+    assert bool((pg % 32 == 31).all())
+    grad = (torch.randn(L, B, C, generator=g) * 1e-2).to(dtype)
+    emb = torch.zeros(total, C, dtype=dtype)
+    ge_ref = torch.zeros(total, C, dtype=torch.float32)
+    oracle.GridBackend.grid_encode_backward(grad.float(), x, emb.float(), offsets, ge_ref, B, D, C, L, S, base, None, None, gridtype,
+                                            False, 0)
+    out = {}
+    try:
+        for path in (2, 3):
+            hip.GridBackend.set_backward_path(path)
+            ge = torch.zeros(total, C, dtype=dtype, device="cuda")
+            hip.GridBackend.grid_encode_backward(grad.cuda(), x.cuda(), emb.cuda(), offsets.cuda(), ge, B, D, C, L, S, base, None, None,
+                                                 gridtype, False, 0)
+            out[path] = ge.cpu()
+    finally:
+        hip.GridBackend.set_backward_path(0)
+    if dtype == torch.float16:
+        # (the two generations merge same-cell runs in different trees before the one rounding to binary16: equal up to that)
+        for path in (2, 3):
+            torch.testing.assert_close(out[path].float(), ge_ref, rtol=2e-3, atol=2e-3 * float(ge_ref.abs().max()))
+        lo, hi = int(offsets[lvl]), int(offsets[lvl + 1])  # nothing merges on the split level: the sums are exact on both paths
+        assert torch.equal(out[2][lo:hi].view(torch.int16), out[3][lo:hi].view(torch.int16))
+    else:
+        torch.testing.assert_close(out[2], ge_ref, rtol=1e-4, atol=1e-5 * float(ge_ref.abs().max()))

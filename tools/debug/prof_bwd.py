@@ -27,7 +27,7 @@ lib.s3d_debug_prof_read(buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), C.c_size_t
 run()
 lib.s3d_debug_prof_read(buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), C.c_size_t(buf.nbytes), 0)
 chunks = (B + P - 1) // P
-for kern, name, nph, nwg in ((0, "scatter", 8, chunks * 16), (1, "accumulate", 7, 1024)):
+for kern, name, nph, nwg in ((0, "scatter", 8, chunks * 16), (1, "accumulate", 6, 1024)):
     t = buf[kern, :nwg, :nph].astype(np.int64)
     ok = t[:, 0] > 0
     t0 = t[ok, 0].min()
