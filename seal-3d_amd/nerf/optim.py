@@ -199,6 +199,7 @@ class NativeGradScaler:
         self._scale = torch.full((1,), init_scale if enabled else 1.0, dtype=torch.float32, device=device)
         self._growth_tracker = torch.zeros(1, dtype=torch.int32, device=device)
         self._found_inf = torch.zeros(1, dtype=torch.float32, device=device)
+        self._one = torch.ones(1, dtype=torch.float32, device=device)  # unit inverse scale of the multi-tensor check
         self._advance = None  # step count of the optimizer whose advance rides in update()'s launch
 
     def scale(self, loss):
@@ -248,8 +249,17 @@ class NativeGradScaler:
         flat = getattr(optimizer, "flat_half", None)
         if flat is not None and not self._checked_at_source(optimizer):
             _backend.grads_nonfinite(flat, self._found_inf)  # every handed-over gradient in one pass
-        for _, p, g in optimizer.grads():
-            if flat is None or g is not getattr(p, "_s3d_grad", None):
+        self._check_plain(optimizer, flat)
+
+    def _check_plain(self, optimizer, flat):
+        """the gradients that are NOT hand-over buffers (`.grad` of the nn.Linear weights of the Seal net, ...): one
+        multi-tensor launch for all of them (aten's check-and-unscale with a unit scale raises the same flag; one launch per
+        tensor was 5 x 5 us of a 0.9 ms Seal step, profiles/r08_seal.md), the native per-tensor kernel for a single one"""
+        rest = [g for _, p, g in optimizer.grads() if flat is None or g is not getattr(p, "_s3d_grad", None)]
+        if len(rest) > 1 and all(g.is_cuda and g.dtype == rest[0].dtype and g.layout == torch.strided for g in rest):
+            torch._amp_foreach_non_finite_check_and_unscale_(rest, self._found_inf, self._one)
+        else:
+            for g in rest:
                 _backend.grads_nonfinite(g, self._found_inf)
 
     def step(self, optimizer, dist=None):
@@ -277,9 +287,7 @@ class NativeGradScaler:
             flat = getattr(optimizer, "flat_half", None)
             if flat is not None:
                 _backend.grads_nonfinite(flat, self._found_inf)
-            for _, p, g in optimizer.grads():
-                if flat is None or g is not getattr(p, "_s3d_grad", None):
-                    _backend.grads_nonfinite(g, self._found_inf)
+            self._check_plain(optimizer, flat)
             dist.allreduce_flag(self._found_inf)  # (identical on every rank already; keeps the replicas' decisions tied)
             optimizer.step(grad_scale=self._scale if self.enabled else None, found_inf=self._found_inf, advance=not fold)
             return
