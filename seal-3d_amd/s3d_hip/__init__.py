@@ -229,6 +229,7 @@ class _ControlBlocks:
 
     def __init__(self):
         self.buf = {}
+        self.retired = []  # smaller blocks that were replaced: never freed — a captured graph may still hold their address
 
     def get(self, nbytes, device):
         if nbytes <= 0:
@@ -239,7 +240,7 @@ class _ControlBlocks:
         if torch.cuda.is_current_stream_capturing():
             return None
         if b is not None:
-            torch.cuda.synchronize(device)  # (the old block may be in use by queued work)
+            self.retired.append(b)  # (all-zero between calls like every control block; a few hundred KB)
         b = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
         self.buf[device.index] = b
         return b
