@@ -998,6 +998,10 @@ __device__ __forceinline__ bool probe_lut(const Ray& r, const MarchParams& p, co
     return occ;
 }
 
+#ifndef S3D_MARCH_GROUP_MAX
+#define S3D_MARCH_GROUP_MAX 320000
+#endif
+constexpr uint32_t kMarchGroupMaxRays = S3D_MARCH_GROUP_MAX;  // alive rays up to which the 16-lanes-per-ray walk is used (0 = never)
 constexpr uint32_t kMarchRefill = 16;  // idle lanes of a wave before the next ray slots of its pool are handed out
 
 template <bool C1>
@@ -1058,6 +1062,127 @@ __global__ void __launch_bounds__(256) k_march_rays_t(uint32_t n_alive, uint32_t
                 busy = false;
             }
         }
+    }
+}
+
+// ---- the t walk with SIXTEEN lanes per ray (later iterations of the loop: fewer rays, more steps each) ----
+// With a lane per ray, 1.5e5 alive rays are 2.4 waves per SIMD, each a chain of ~40 dependent probes (110 us per launch at
+// 13 us of vector work).  The walk only ever visits elements of ONE sequence t_0, t_1 = t_0 + dt(t_0), ... — an occupied
+// sample advances by one element, an empty one to the first element at or behind its voxel exit (raymarching.cu:777-786) —
+// so a group of 16 lanes probes 16 consecutive elements at once and then resolves which of them the reference's loop
+// visits: next[j] = j + 1 (occupied) or the number of window elements in front of the exit (empty; binary search over the
+// group's sorted t by ds_bpermute), the nodes on the path from the start by pointer doubling on 16-bit reach masks, the
+// occupied visited ones are emitted in order.  A skip that leaves the window is carried as `pending` into the next one.
+// Every cross-lane read is executed by all lanes of a group (a disabled lane reads as 0).
+template <bool C1, bool G0>  // C1: one cascade; G0: dt_gamma == 0 (constant step: clamp(t * 0) = dt_min)
+__global__ void __launch_bounds__(256) k_march_rays_g(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive,
+                                                      const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                                                      const float* __restrict__ rays_d, float bound, float dt_gamma,
+                                                      uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
+                                                      const float* __restrict__ fars, float2* __restrict__ tl,
+                                                      const float* __restrict__ noises, const int32_t* __restrict__ n_alive_dev,
+                                                      int32_t* __restrict__ n_rows_out) {
+    __shared__ uint32_t lut[1024];
+    for (uint32_t i = threadIdx.x; i < H; i += 256) lut[i] = expand_bits(i);
+    __syncthreads();
+    const uint32_t live = alive_count(n_alive, n_alive_dev);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_rows_out) *n_rows_out = (int32_t)(live * n_step);
+    const uint32_t g = (blockIdx.x * 256 + threadIdx.x) >> 4;  // ray slot of this group
+    const uint32_t j = threadIdx.x & 15u;
+    if (g >= live) return;  // (whole groups leave)
+    const uint32_t gbase = threadIdx.x & 48u;  // first lane of the group inside its wave
+    const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
+    const uint32_t index = (uint32_t)rays_alive[g];
+    const Ray r = load_ray(rays_o, rays_d, index);
+    const float far = fars[index];
+    float t_base = rays_t[index];
+    t_base = __builtin_fmaf(clampf(t_base * dt_gamma, p.dt_min, p.dt_max), noises ? noises[g] : 0.0f, t_base);
+    float last_t = t_base;
+    float pending = -1.0f;  // voxel exit of a skip that left the previous window (t is positive: -1 = none)
+    uint32_t step = 0;
+    float2* row = tl + (size_t)g * n_step;
+    auto grp = [&](auto v, uint32_t lane_in_group) { return __shfl(v, (int)(gbase + lane_in_group), 64); };
+    // elements of the window in front of x (0 .. 16); the window's t are ascending
+    auto count_before = [&](float t, float x) {
+        const float t15 = grp(t, 15u);
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t sft = 8; sft >= 1; sft >>= 1) {
+            const float v = grp(t, c + sft - 1u);
+            if (v < x) c += sft;
+        }
+        return t15 < x ? 16u : c;
+    };
+    for (;;) {
+        // lane j holds element j of the window: j applications of t += dt(t) to the window's first element
+        auto dt_of = [&](float tt) { return G0 ? clampf(0.0f, p.dt_min, p.dt_max) : clampf(tt * dt_gamma, p.dt_min, p.dt_max); };
+        float t = t_base;
+#pragma unroll
+        for (uint32_t k = 0; k < 15; k++) {
+            const float tn = t + dt_of(t);
+            t = k < j ? tn : t;
+        }
+        const float t_next = t + dt_of(t);  // element j + 1
+        const float t16 = grp(t_next, 15u);
+        const bool valid = t < far;
+        bool occ = false;
+        float tskip = 0.0f, dtj;
+        if (valid) occ = probe_lut<C1>(r, p, lut, t, dtj, tskip);
+        const bool empty = valid && !occ;
+        const unsigned long long wocc = __ballot(occ), wval = __ballot(valid);
+        const uint32_t occm = (uint32_t)(wocc >> gbase) & 0xffffu, valm = (uint32_t)(wval >> gbase) & 0xffffu;
+        // (the branches below are taken by whole groups: the cross-lane reads inside see all 16 lanes of their group)
+        const uint32_t start = pending < 0.0f ? 0u : count_before(t, pending);
+        uint32_t nxt = !valid ? 16u : j + 1u;  // node the reference's loop goes to from here
+        uint32_t visited;
+        if ((valm & ~occm) == 0u) {
+            // no empty element in the window (inside an object): the walk takes every element from the start on
+            visited = start < 16u ? (0xffffu << start) & 0xffffu : 0u;
+            if (valm != 0xffffu) visited &= (valm << 1) | 1u;  // ... up to and including the first one behind the far plane
+        } else {
+            const uint32_t cb = count_before(t, empty ? tskip : t);
+            if (empty) nxt = cb > j + 1u ? cb : j + 1u;
+            // nodes on the path from each node, by pointer doubling (a path has at most 16 hops)
+            uint32_t reach = 1u << j, jump = nxt;
+#pragma unroll
+            for (uint32_t rd = 0; rd < 4; rd++) {
+                const uint32_t src = jump < 16u ? jump : 15u;
+                const uint32_t rj = grp(reach, src), jj = grp(jump, src);
+                if (jump < 16u) { reach |= rj; jump = jj; }
+            }
+            visited = start < 16u ? grp(reach, start) : 0u;
+        }
+        const uint32_t emit = visited & occm & valm;
+        const uint32_t room = n_step - step;
+        const uint32_t rank = (uint32_t)__popc(emit & ((1u << j) - 1u));
+        const bool mine = ((emit >> j) & 1u) != 0u && rank < room;
+        // previous emitted element of the window (highest emit bit below j): its t_next is this sample's `last_t`
+        const uint32_t below = emit & ((1u << j) - 1u);
+        const uint32_t prev = below ? 31u - (uint32_t)__clz(below) : 0u;
+        const float lt_prev = grp(t_next, prev);
+        if (mine) row[step + rank] = make_float2(t, below ? lt_prev : last_t);
+        const uint32_t ne = min((uint32_t)__popc(emit), room);
+        if (ne) {  // (group-uniform) the last emitted element's t_next is the new last_t
+            const unsigned long long wl = __ballot(mine && rank == ne - 1u);
+            const uint32_t q = (uint32_t)__ffsll((long long)((wl >> gbase) & 0xffffull)) - 1u;
+            last_t = grp(t_next, q);
+            step += ne;
+        } else {
+            (void)__ballot(false);
+            (void)grp(t_next, 0u);
+        }
+        // the walk ends at n_step samples or at the first visited element behind the far plane
+        const bool far_hit = (visited & ~valm) != 0u || valm == 0u;  // (a window entirely behind the far plane: so is whatever comes next)
+        if (step >= n_step || far_hit) {
+            for (uint32_t sidx = step + j; sidx < n_step; sidx += 16) row[sidx] = make_float2(-1.0f, 0.0f);  // unfilled slots: (t < 0)
+            break;
+        }
+        // next window; a skip that pointed behind this one is carried
+        const uint32_t lastv = visited ? 31u - (uint32_t)__clz(visited) : 0u;
+        const float carry = grp(occ ? -1.0f : tskip, lastv);
+        const uint32_t nl = grp(nxt, lastv);
+        if (visited) pending = nl >= 16u ? carry : -1.0f;  // (no node visited: the whole window lies in front of `pending`)
+        t_base = t16;
     }
 }
 
@@ -1325,7 +1450,16 @@ S3D_EXPORT int s3d_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* 
     pool = pool < 64u ? 64u : (pool > 256u ? 256u : pool);
     const dim3 g1(div_up<uint32_t>(n_alive, 4 * pool)), b(256);
     float2* tl = reinterpret_cast<float2*>(deltas);
-    if (C == 1)
+    if (n_alive <= kMarchGroupMaxRays) {  // few rays, many steps each: sixteen lanes per ray
+        const dim3 gg(div_up<uint32_t>(n_alive, 16));
+#define S3D_MARCH_G(C1_, G0_) hipLaunchKernelGGL((k_march_rays_g<C1_, G0_>), gg, b, 0, as_stream(stream), n_alive, n_step, rays_alive, rays_t, \
+                                                rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, tl, noises, n_alive_dev, n_rows_out)
+        if (C == 1 && dt_gamma == 0.0f) S3D_MARCH_G(true, true);
+        else if (C == 1) S3D_MARCH_G(true, false);
+        else if (dt_gamma == 0.0f) S3D_MARCH_G(false, true);
+        else S3D_MARCH_G(false, false);
+#undef S3D_MARCH_G
+    } else if (C == 1)
         hipLaunchKernelGGL(k_march_rays_t<true>, g1, b, 0, as_stream(stream), n_alive, n_step, rays_alive, rays_t, rays_o, rays_d,
                            bound, dt_gamma, max_steps, C, H, grid, fars, tl, noises, n_alive_dev, n_rows_out, pool);
     else

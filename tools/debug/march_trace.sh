@@ -12,7 +12,7 @@ names = ("k_march_rays", "k_composite_rays", "k_grid_forward_pair", "k_ffmlp_for
 seq = [(r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size", "?"))) for r in rows if any(n in r["Kernel_Name"] for n in names)]
 # last frame only: the last 32 march launches
 idx = [i for i, s in enumerate(seq) if "k_march_rays" in s[0]]
-start = idx[-32] if len(idx) >= 32 else idx[0]
+start = idx[-64] if len(idx) >= 64 else idx[0]
 it = -1
 for name, us, grid in seq[start:]:
     short = [n for n in names if n in name][0]
