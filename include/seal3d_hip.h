@@ -129,7 +129,10 @@ int s3d_composite_rays_train_backward(const float* grad_weights_sum, const float
  * xyzs / dirs / deltas before every call (raymarching.py:324-326: unfilled slots must read as zeros, deltas == 0 ends a
  * ray's chunk); with zero_unfilled != 0 the kernel writes those zeros itself — the slots a ray does not fill and the rows
  * behind the last ray up to rows_total (up to the next multiple of 128 of the live rows when n_alive_dev is given) — and
- * the caller passes uninitialised buffers of rows_total rows. */
+ * the caller passes uninitialised buffers of rows_total rows.
+ * Two launches on `stream` (a walk that records (t, previous t) per emitted sample in the sample's own `deltas` row — one
+ * lane per ray with lane refill, or sixteen lanes per ray once few rays are alive — then one lane per row expanding it to
+ * xyz / dir / (dt, t' - previous t)); n_alive * n_step must fit 32 bits. */
 int s3d_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
                    const float* rays_o, const float* rays_d, float bound, float dt_gamma,
                    uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* grid, const float* nears,
