@@ -1229,7 +1229,7 @@ __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_
                                                        const TS* __restrict__ sigmas, const TC* __restrict__ rgbs,
                                                        const float* __restrict__ deltas, float* __restrict__ weights_sum,
                                                        float* __restrict__ depth, float* __restrict__ image,
-                                                       const int32_t* __restrict__ n_alive_dev) {
+                                                       const int32_t* __restrict__ n_alive_dev, bool vec4) {
     const uint32_t n = blockIdx.x * 64 + threadIdx.x;
     if (n >= alive_count(n_alive, n_alive_dev)) return;
     const uint32_t index = (uint32_t)rays_alive[n];
@@ -1240,20 +1240,43 @@ __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_
     float weight_sum = weights_sum[index], d = depth[index];
     float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
     uint32_t step = 0;
-    while (step < n_step) {
-        const float2 dd = dl[step];
-        if (dd.x == 0) break;
-        const float alpha = 1.0f - __expf(-(float)s[step] * dd.x);
+    // one sample: returns true when the ray's chunk ends here (raymarching.cu:847-880: the order of the tests and updates)
+    auto sample = [&](float sg, float c0, float c1, float c2, float2 dd) {
+        if (dd.x == 0) return true;
+        const float alpha = 1.0f - __expf(-sg * dd.x);
         const float T = 1 - weight_sum;
         const float weight = alpha * T;
         weight_sum += weight;
         t += dd.y;
         d = __builtin_fmaf(weight, t, d);
-        r = __builtin_fmaf(weight, (float)c[step * 3], r);
-        g = __builtin_fmaf(weight, (float)c[step * 3 + 1], g);
-        b = __builtin_fmaf(weight, (float)c[step * 3 + 2], b);
-        if (T < T_thresh) break;
+        r = __builtin_fmaf(weight, c0, r);
+        g = __builtin_fmaf(weight, c1, g);
+        b = __builtin_fmaf(weight, c2, b);
+        if (T < T_thresh) return true;
         step++;
+        return false;
+    };
+    if (vec4) {  // (n_step a multiple of four and every buffer 16-byte aligned)
+        // four samples per trip through 16-byte (fp16: 8-byte) loads: a lane's rows are contiguous but 64 lanes are 64 different
+        // cache lines per load instruction — the kernel was bound by the L1's line rate (5 loads per sample and wave), not by
+        // bytes; same arithmetic in the same order
+        struct alignas(4 * sizeof(TS)) S4 { TS v[4]; };
+        struct alignas(4 * sizeof(TC)) C4 { TC v[4]; };
+        bool stop = false;
+        for (uint32_t s0 = 0; s0 < n_step && !stop; s0 += 4) {
+            const S4 sv = *reinterpret_cast<const S4*>(s + s0);
+            const C4 ca = *reinterpret_cast<const C4*>(c + s0 * 3), cb = *reinterpret_cast<const C4*>(c + s0 * 3 + 4),
+                     cc = *reinterpret_cast<const C4*>(c + s0 * 3 + 8);
+            const float4 da = *reinterpret_cast<const float4*>(dl + s0), db = *reinterpret_cast<const float4*>(dl + s0 + 2);
+            stop = sample((float)sv.v[0], (float)ca.v[0], (float)ca.v[1], (float)ca.v[2], make_float2(da.x, da.y)) ||
+                   sample((float)sv.v[1], (float)ca.v[3], (float)cb.v[0], (float)cb.v[1], make_float2(da.z, da.w)) ||
+                   sample((float)sv.v[2], (float)cb.v[2], (float)cb.v[3], (float)cc.v[0], make_float2(db.x, db.y)) ||
+                   sample((float)sv.v[3], (float)cc.v[1], (float)cc.v[2], (float)cc.v[3], make_float2(db.z, db.w));
+        }
+    } else {
+        while (step < n_step) {
+            if (sample((float)s[step], (float)c[step * 3], (float)c[step * 3 + 1], (float)c[step * 3 + 2], dl[step])) break;
+        }
     }
     if (step < n_step) rays_alive[n] = -1; else rays_t[index] = t;
     weights_sum[index] = weight_sum; depth[index] = d;
@@ -1484,9 +1507,10 @@ S3D_EXPORT int s3d_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thr
                 "composite_rays: sigmas / rgbs must be f32 or f16");
     const dim3 grid(div_up<uint32_t>(n_alive, 64)), block(64);
     hipStream_t st = as_stream(stream);
+    const bool vec4 = (n_step & 3u) == 0u && (((uintptr_t)sigmas | (uintptr_t)rgbs | (uintptr_t)deltas) & 15u) == 0u;
 #define S3D_COMPOSITE(TS, TC)                                                                                              \
     hipLaunchKernelGGL((k_composite_rays<TS, TC>), grid, block, 0, st, n_alive, n_step, T_thresh, rays_alive, rays_t,        \
-                       (const TS*)sigmas, (const TC*)rgbs, deltas, weights_sum, depth, image, n_alive_dev)
+                       (const TS*)sigmas, (const TC*)rgbs, deltas, weights_sum, depth, image, n_alive_dev, vec4)
     if (sigmas_dtype == S3D_F32 && rgbs_dtype == S3D_F32) S3D_COMPOSITE(float, float);
     else if (sigmas_dtype == S3D_F32) S3D_COMPOSITE(float, __half);
     else if (rgbs_dtype == S3D_F32) S3D_COMPOSITE(__half, float);

@@ -448,6 +448,41 @@ def test_march_rays_full_frame_bit_exact(oracle, hip, cascade, bound, dt_gamma, 
     assert (l0[:n_alive * n_step, 0] == 0).any() and (l0[:, 0] != 0).any()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_composite_rays_four_samples_per_trip_is_the_scalar_loop(oracle, hip, dtype):
+    """composite_rays with n_step a multiple of four reads a ray's rows with 16-byte loads (8-byte for fp16 inputs); a buffer
+    that is not 16-byte aligned takes the one-sample-per-trip loop: both must give the same bits, and the oracle's values."""
+    g = torch.Generator().manual_seed(3)
+    n_alive, n_step, N = 5000, 12, 6000
+    alive = torch.randperm(N, generator=g)[:n_alive].int()
+    sig = torch.rand(n_alive * n_step, generator=g) * 30
+    rgb = torch.rand(n_alive * n_step, 3, generator=g)
+    deltas = torch.rand(n_alive * n_step, 2, generator=g) * 0.01 + 1e-3
+    cut = torch.randint(0, n_step + 1, (n_alive,), generator=g)           # slots a ray did not fill: deltas == 0
+    fill = (torch.arange(n_step)[None, :] < cut[:, None]).reshape(-1)
+    deltas[~fill] = 0
+    state = lambda dev: (alive.clone().to(dev), torch.rand(N, generator=torch.Generator().manual_seed(5)).to(dev) + 0.2,
+                         torch.rand(N, generator=torch.Generator().manual_seed(6)).to(dev) * 0.5, torch.zeros(N, device=dev),
+                         torch.zeros(N, 3, device=dev))
+    a0, t0, w0, d0, i0 = state("cpu")
+    oracle.RaymarchingBackend.composite_rays(n_alive, n_step, 1e-2, a0, t0, sig, rgb, deltas, w0, d0, i0)
+    outs = []
+    for misalign in (0, 1):
+        a, t, w, d, im = state("cuda")
+        sg = torch.zeros(sig.numel() + 4, dtype=dtype, device="cuda")[misalign: misalign + sig.numel()]
+        sg.copy_(sig)
+        cg = torch.zeros(rgb.numel() + 4, dtype=dtype, device="cuda")[misalign: misalign + rgb.numel()].view(-1, 3)
+        cg.copy_(rgb)
+        hip.RaymarchingBackend.composite_rays(n_alive, n_step, 1e-2, a, t, sg, cg, deltas.cuda(), w, d, im)
+        outs.append((a.cpu(), t.cpu(), w.cpu(), d.cpu(), im.cpu()))
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y), "vector and scalar loops differ"
+    if dtype == torch.float32:
+        assert torch.equal(outs[0][0], a0), "kill pattern differs from the oracle"
+        for x, y in zip(outs[0][1:], (t0, w0, d0, i0)):
+            torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-6)
+
+
 def test_full_size_properties(hip):
     """BASELINE size (800x800 rays): size-independent properties instead of an oracle run."""
     _, bits = _scene(seed=0)
