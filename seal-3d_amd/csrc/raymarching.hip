@@ -1256,23 +1256,28 @@ __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_
         step++;
         return false;
     };
-    if (vec4) {  // (n_step a multiple of four and every buffer 16-byte aligned)
+    if (vec4) {
         // four samples per trip through 16-byte (fp16: 8-byte) loads: a lane's rows are contiguous but 64 lanes are 64 different
         // cache lines per load instruction — the kernel was bound by the L1's line rate (5 loads per sample and wave), not by
-        // bytes; same arithmetic in the same order
-        struct alignas(4 * sizeof(TS)) S4 { TS v[4]; };
-        struct alignas(4 * sizeof(TC)) C4 { TC v[4]; };
+        // bytes; same arithmetic in the same order.  fp32 rows need only their natural 4-byte alignment (global memory takes
+        // misaligned multi-dword accesses), so any n_step works; fp16 rows are vectorised when the launcher found them aligned.
+        struct alignas(sizeof(TS) == 4 ? 4 : 8) S4 { TS v[4]; };
+        struct alignas(sizeof(TC) == 4 ? 4 : 8) C4 { TC v[4]; };
+        struct alignas(4) D4 { float x, y, z, w; };
         bool stop = false;
-        for (uint32_t s0 = 0; s0 < n_step && !stop; s0 += 4) {
+        uint32_t s0 = 0;
+        for (; s0 + 4 <= n_step && !stop; s0 += 4) {
             const S4 sv = *reinterpret_cast<const S4*>(s + s0);
             const C4 ca = *reinterpret_cast<const C4*>(c + s0 * 3), cb = *reinterpret_cast<const C4*>(c + s0 * 3 + 4),
                      cc = *reinterpret_cast<const C4*>(c + s0 * 3 + 8);
-            const float4 da = *reinterpret_cast<const float4*>(dl + s0), db = *reinterpret_cast<const float4*>(dl + s0 + 2);
+            const D4 da = *reinterpret_cast<const D4*>(dl + s0), db = *reinterpret_cast<const D4*>(dl + s0 + 2);
             stop = sample((float)sv.v[0], (float)ca.v[0], (float)ca.v[1], (float)ca.v[2], make_float2(da.x, da.y)) ||
                    sample((float)sv.v[1], (float)ca.v[3], (float)cb.v[0], (float)cb.v[1], make_float2(da.z, da.w)) ||
                    sample((float)sv.v[2], (float)cb.v[2], (float)cb.v[3], (float)cc.v[0], make_float2(db.x, db.y)) ||
                    sample((float)sv.v[3], (float)cc.v[1], (float)cc.v[2], (float)cc.v[3], make_float2(db.z, db.w));
         }
+        while (!stop && step < n_step)  // (n_step % 4 samples left)
+            stop = sample((float)s[step], (float)c[step * 3], (float)c[step * 3 + 1], (float)c[step * 3 + 2], dl[step]);
     } else {
         while (step < n_step) {
             if (sample((float)s[step], (float)c[step * 3], (float)c[step * 3 + 1], (float)c[step * 3 + 2], dl[step])) break;
@@ -1507,7 +1512,10 @@ S3D_EXPORT int s3d_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thr
                 "composite_rays: sigmas / rgbs must be f32 or f16");
     const dim3 grid(div_up<uint32_t>(n_alive, 64)), block(64);
     hipStream_t st = as_stream(stream);
-    const bool vec4 = (n_step & 3u) == 0u && (((uintptr_t)sigmas | (uintptr_t)rgbs | (uintptr_t)deltas) & 15u) == 0u;
+    // vector loads: fp32 buffers as they come (4-byte aligned by type); an fp16 buffer needs 8-byte aligned rows
+    const bool half_in = sigmas_dtype == S3D_F16 || rgbs_dtype == S3D_F16;
+    const bool vec4 = n_step >= 4 && (((uintptr_t)sigmas | (uintptr_t)rgbs | (uintptr_t)deltas) & 3u) == 0u &&
+                      (!half_in || ((n_step & 3u) == 0u && (((uintptr_t)sigmas | (uintptr_t)rgbs) & 7u) == 0u));
 #define S3D_COMPOSITE(TS, TC)                                                                                              \
     hipLaunchKernelGGL((k_composite_rays<TS, TC>), grid, block, 0, st, n_alive, n_step, T_thresh, rays_alive, rays_t,        \
                        (const TS*)sigmas, (const TC*)rgbs, deltas, weights_sum, depth, image, n_alive_dev, vec4)

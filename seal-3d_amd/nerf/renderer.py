@@ -217,10 +217,6 @@ class NeRFRenderer(nn.Module):
             step = it = 0
             while step < max_steps and n_alive > 0:
                 n_step = max(min(self.infer_batch_scale * N // n_alive, 8 * self.infer_batch_scale), 1)
-                if self.infer_batch_scale > 1 and n_step > 4:
-                    # (build extension, like the scale itself: whole groups of four samples per ray, so that composite_rays reads a
-                    #  ray's sigma / rgb / deltas rows with 16-byte loads; the reference's schedule is infer_batch_scale = 1)
-                    n_step &= ~3
                 if sync_free:
                     xyzs, dirs, deltas = raymarching.march_rays(
                         n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,

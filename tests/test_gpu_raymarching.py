@@ -448,12 +448,13 @@ def test_march_rays_full_frame_bit_exact(oracle, hip, cascade, bound, dt_gamma, 
     assert (l0[:n_alive * n_step, 0] == 0).any() and (l0[:, 0] != 0).any()
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-def test_composite_rays_four_samples_per_trip_is_the_scalar_loop(oracle, hip, dtype):
-    """composite_rays with n_step a multiple of four reads a ray's rows with 16-byte loads (8-byte for fp16 inputs); a buffer
-    that is not 16-byte aligned takes the one-sample-per-trip loop: both must give the same bits, and the oracle's values."""
+@pytest.mark.parametrize("dtype,n_step", [(torch.float32, 12), (torch.float32, 11), (torch.float16, 12)])
+def test_composite_rays_four_samples_per_trip_is_the_scalar_loop(oracle, hip, dtype, n_step):
+    """composite_rays reads a ray's rows four samples per trip (fp32: multi-dword loads on the rows' natural alignment, any
+    n_step, the n_step % 4 tail one by one; fp16: 8-byte loads when n_step is a multiple of four and the rows are aligned —
+    a buffer offset by one element takes the one-sample loop): same bits either way, the oracle's kill pattern and values."""
     g = torch.Generator().manual_seed(3)
-    n_alive, n_step, N = 5000, 12, 6000
+    n_alive, N = 5000, 6000
     alive = torch.randperm(N, generator=g)[:n_alive].int()
     sig = torch.rand(n_alive * n_step, generator=g) * 30
     rgb = torch.rand(n_alive * n_step, 3, generator=g)
