@@ -230,18 +230,15 @@ def _mip_from_dt(dt, H, C):
     return int(min(C - 1, max(0, e)))
 
 
-def march_rays_train(rays_o, rays_d, bitfield, bound, dt_gamma, max_steps, C, H, M, nears, fars, noises):
-    """raymarching.cu:312-480 -> (xyzs [M,3], dirs [M,3], deltas [M,2] float32 zero-initialised, rays [N,3] int32
-    (id, offset, count), counter [2])"""
-    N = rays_o.shape[0]
+def _march_kit(bitfield, bound, dt_gamma, max_steps, C, H):
+    """the per-sample pieces the training and the inference marcher share: cell(t, o, d) — position, step, mip level,
+    occupancy of the sample at t — and skip(...) — the t sequence advanced behind the current voxel"""
     bound, dt_gamma = F32(bound), F32(dt_gamma)
     rH = F32(1) / F32(H)
     H3 = H * H * H
     SQRT3 = F32(1.7320508075688772)
     dt_min = F32(2) * SQRT3 / F32(max_steps)
     dt_max = F32(2) * SQRT3 * F32(1 << (C - 1)) / F32(H)
-    xyzs, dirs, deltas = np.zeros((M, 3), F32), np.zeros((M, 3), F32), np.zeros((M, 2), F32)
-    rays = np.zeros((N, 3), np.int32)
     bits = np.asarray(bitfield, dtype=np.uint8)
 
     def cell(t, o, d):
@@ -277,6 +274,16 @@ def march_rays_train(rays_o, rays_d, bitfield, bound, dt_gamma, max_steps, C, H,
             if not (t < tt):
                 return t
 
+    return cell, skip, dt_min, dt_max, dt_gamma
+
+
+def march_rays_train(rays_o, rays_d, bitfield, bound, dt_gamma, max_steps, C, H, M, nears, fars, noises):
+    """raymarching.cu:312-480 -> (xyzs [M,3], dirs [M,3], deltas [M,2] float32 zero-initialised, rays [N,3] int32
+    (id, offset, count), counter [2])"""
+    N = rays_o.shape[0]
+    cell, skip, dt_min, dt_max, dt_gamma = _march_kit(bitfield, bound, dt_gamma, max_steps, C, H)
+    xyzs, dirs, deltas = np.zeros((M, 3), F32), np.zeros((M, 3), F32), np.zeros((M, 2), F32)
+    rays = np.zeros((N, 3), np.int32)
     point_index = 0
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         for n in range(N):
@@ -312,3 +319,63 @@ def march_rays_train(rays_o, rays_d, bitfield, bound, dt_gamma, max_steps, C, H,
                 else:
                     t = skip(t, x, y, z, n3, mip_bound, d, rd)
     return xyzs, dirs, deltas, rays, np.array([point_index, N], dtype=np.int32)
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bitfield, bound, dt_gamma, max_steps, C, H, fars, noises):
+    """One iteration of the inference loop (raymarching.cu:701-800): every alive ray continues from its own t and records up
+    to n_step samples; slots it does not fill stay zero.  -> xyzs [n_alive * n_step, 3], dirs, deltas [.., 2] float32"""
+    cell, skip, dt_min, dt_max, dt_gamma = _march_kit(bitfield, bound, dt_gamma, max_steps, C, H)
+    M = n_alive * n_step
+    xyzs, dirs, deltas = np.zeros((M, 3), F32), np.zeros((M, 3), F32), np.zeros((M, 2), F32)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        for n in range(n_alive):
+            ray = int(rays_alive[n])
+            o, d = rays_o[ray].astype(F32), rays_d[ray].astype(F32)
+            rd = F32(1) / d
+            far = F32(fars[ray])
+            t = F32(rays_t[ray])
+            t = fma32(_clamp32(t * dt_gamma, dt_min, dt_max), F32(noises[n]), t)  # t += clamp(...) * noise, contracted
+            last_t, step, row = t, 0, n * n_step
+            while t < far and step < n_step:
+                x, y, z, dt, mip_bound, n3, occ = cell(t, o, d)
+                if occ:
+                    xyzs[row + step] = (x, y, z)
+                    dirs[row + step] = d
+                    t = F32(t + dt)
+                    deltas[row + step] = (dt, F32(t - last_t))
+                    last_t = t
+                    step += 1
+                else:
+                    t = skip(t, x, y, z, n3, mip_bound, d, rd)
+    return xyzs, dirs, deltas
+
+
+def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+    """The compositing half of an iteration (raymarching.cu:808-895), in float64: w = alpha * (1 - sum of earlier w), a chunk
+    ends at the first empty slot (delta == 0) or once the transmittance in front of a sample has fallen below T_thresh — that
+    sample still counts; a ray whose chunk ended early is dead (-1), the others advance their t.  In place on copies;
+    -> (rays_alive, rays_t, weights_sum, depth, image)"""
+    alive, rt = np.array(rays_alive, np.int32), np.array(rays_t, np.float64)
+    ws, dp, im = np.array(weights_sum, np.float64), np.array(depth, np.float64), np.array(image, np.float64)
+    for n in range(n_alive):
+        ray = int(alive[n])
+        t, step = rt[ray], 0
+        while step < n_step:
+            k = n * n_step + step
+            if deltas[k, 0] == 0:
+                break
+            alpha = 1.0 - np.exp(-np.float64(sigmas[k]) * np.float64(deltas[k, 0]))
+            T = 1.0 - ws[ray]
+            w = alpha * T
+            ws[ray] += w
+            t += np.float64(deltas[k, 1])
+            dp[ray] += w * t
+            im[ray] += w * np.asarray(rgbs[k], np.float64)
+            if T < T_thresh:
+                break
+            step += 1
+        if step < n_step:
+            alive[n] = -1
+        else:
+            rt[ray] = t
+    return alive, rt, ws, dp, im

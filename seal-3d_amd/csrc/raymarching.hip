@@ -960,7 +960,7 @@ __global__ void __launch_bounds__(64) k_march_rays_v1(uint32_t n_alive, uint32_t
 //      (ballot + prefix count, no atomics): lanes stay busy until the pool runs dry.  Morton codes come from a per-workgroup
 //      LDS table of spread coordinates; single-cascade grids (bound <= 1) skip the mip-level arithmetic.
 //  (2) k_march_rays_expand, one lane per sample row, turns (t, previous t) into xyz / dir / (dt, t' - previous t) with the
-//      reference's expressions (raymarching.cu:759-775) and writes whole rows side by side; slots a ray did not fill and the
+//      reference's expressions (raymarching.cu:750-785) and writes whole rows side by side; slots a ray did not fill and the
 //      padding rows are zeroed here.
 // Same samples, bit for bit (the t sequence and every emitted value are computed by the same float expressions).
 template <bool C1>
@@ -1068,7 +1068,7 @@ __global__ void __launch_bounds__(256) k_march_rays_t(uint32_t n_alive, uint32_t
 // ---- the t walk with SIXTEEN lanes per ray (later iterations of the loop: fewer rays, more steps each) ----
 // With a lane per ray, 1.5e5 alive rays are 2.4 waves per SIMD, each a chain of ~40 dependent probes (110 us per launch at
 // 13 us of vector work).  The walk only ever visits elements of ONE sequence t_0, t_1 = t_0 + dt(t_0), ... — an occupied
-// sample advances by one element, an empty one to the first element at or behind its voxel exit (raymarching.cu:777-786) —
+// sample advances by one element, an empty one to the first element at or behind its voxel exit (raymarching.cu:788-799) —
 // so a group of 16 lanes probes 16 consecutive elements at once and then resolves which of them the reference's loop
 // visits: next[j] = j + 1 (occupied) or the number of window elements in front of the exit (empty; binary search over the
 // group's sorted t by ds_bpermute), the nodes on the path from the start by pointer doubling on 16-bit reach masks, the
@@ -1240,7 +1240,7 @@ __global__ void __launch_bounds__(64) k_composite_rays(uint32_t n_alive, uint32_
     float weight_sum = weights_sum[index], d = depth[index];
     float r = image[index * 3], g = image[index * 3 + 1], b = image[index * 3 + 2];
     uint32_t step = 0;
-    // one sample: returns true when the ray's chunk ends here (raymarching.cu:847-880: the order of the tests and updates)
+    // one sample: returns true when the ray's chunk ends here (raymarching.cu:848-889: the order of the tests and updates)
     auto sample = [&](float sg, float c0, float c1, float c2, float2 dd) {
         if (dd.x == 0) return true;
         const float alpha = 1.0f - __expf(-sg * dd.x);

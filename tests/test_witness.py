@@ -156,3 +156,57 @@ def test_marcher_oracle_vs_independent_witness(oracle, perturb, cascade, bound, 
         assert int(rays[:, 2].max()) == 20
     for got, want in ((xyzs, wx), (dirs, wd), (deltas, wdl)):
         assert np.array_equal(got.numpy().view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("cascade,bound,dt_gamma,n_step", [(1, 1.0, 0.0, 5), (2, 2.0, 1.0 / 128, 8), (1, 1.0, 0.0, 1)])
+def test_inference_iteration_oracle_vs_independent_witness(oracle, cascade, bound, dt_gamma, n_step):
+    """march_rays + composite_rays (one iteration of the run_cuda eval loop, raymarching.cu:701-895): the C oracle against the
+    numpy statement of the same iteration — sample rows bit for bit (incl. the zero rows of unfilled slots), the kill
+    pattern identical, accumulated weights / depth / colour within fp32 rounding of the float64 values; three iterations, each
+    on the survivors with their advanced t."""
+    N = 200
+    ro, rd, bits = _rays_and_scene(N, seed=cascade + 3, cascade=cascade, bound=bound)
+    aabb = torch.tensor([-bound, -bound, -bound, bound, bound, bound], dtype=torch.float32)
+    nears, fars = torch.empty(N), torch.empty(N)
+    oracle.RaymarchingBackend.near_far_from_aabb(ro, rd, aabb, N, 0.2, nears, fars)
+    g = torch.Generator().manual_seed(9)
+    alive = torch.arange(N, dtype=torch.int32)
+    rays_t = nears.clone()
+    ws, dp, im = torch.zeros(N), torch.zeros(N), torch.zeros(N, 3)
+    w_alive, w_t = alive.numpy().copy(), rays_t.numpy().astype(np.float64)
+    w_ws, w_dp, w_im = np.zeros(N), np.zeros(N), np.zeros((N, 3))
+    killed = unfilled = 0
+    for it in range(3):
+        n_alive = alive.shape[0]
+        M = n_alive * n_step
+        noises = torch.rand(n_alive, generator=g) if it == 0 else torch.zeros(n_alive)
+        xyzs, dirs, deltas = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
+        oracle.RaymarchingBackend.march_rays(n_alive, n_step, alive, rays_t, ro, rd, bound, dt_gamma, 1024, cascade, 128, bits, nears,
+                                             fars, xyzs, dirs, deltas, noises)
+        wx, wd, wdl = W.march_rays(n_alive, n_step, alive.numpy(), rays_t.numpy(), ro.numpy(), rd.numpy(), bits.numpy(), bound,
+                                   dt_gamma, 1024, cascade, 128, fars.numpy(), noises.numpy())
+        for got, want in ((xyzs, wx), (dirs, wd), (deltas, wdl)):
+            assert np.array_equal(got.numpy().view(np.uint32), want.view(np.uint32))
+        unfilled += int((deltas[:, 0] == 0).sum())
+        assert (deltas[:, 0] != 0).any()
+        sig = torch.rand(M, generator=g) * 40
+        rgb = torch.rand(M, 3, generator=g)
+        # the witness works on ITS OWN state (float64 t), fed the same samples
+        w_alive_it, w_t, w_ws, w_dp, w_im = W.composite_rays(n_alive, n_step, 1e-2, w_alive, w_t, sig.numpy(), rgb.numpy(),
+                                                              deltas.numpy(), w_ws, w_dp, w_im)
+        oracle.RaymarchingBackend.composite_rays(n_alive, n_step, 1e-2, alive, rays_t, sig, rgb, deltas, ws, dp, im)
+        assert np.array_equal(alive.numpy(), w_alive_it), "kill pattern differs"
+        np.testing.assert_allclose(ws.numpy(), w_ws, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(dp.numpy(), w_dp, rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(im.numpy(), w_im, rtol=2e-5, atol=1e-6)
+        keep = alive >= 0
+        np.testing.assert_allclose(rays_t.numpy()[alive[keep].long().numpy()], w_t[w_alive_it[w_alive_it >= 0]], rtol=2e-6)
+        killed += int((~keep).sum())
+        alive = alive[keep].contiguous()
+        w_alive = w_alive_it[w_alive_it >= 0]
+        # (the marcher of the next iteration starts from the ORACLE's float32 t on both sides: the witness checks one
+        #  iteration's arithmetic at a time)
+        w_t = rays_t.numpy().astype(np.float64)
+        if alive.numel() == 0:
+            break
+    assert killed > 0 and (unfilled > 0 or n_step == 1)
