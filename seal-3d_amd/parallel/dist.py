@@ -153,6 +153,7 @@ class RayShardedDP:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         dist.all_reduce(probe, op=dist.ReduceOp.SUM, group=self.group)
+                        probe.add_(0.0)  # (a one-rank all-reduce records nothing: the probe graph is never an EMPTY graph)
                     probe.fill_(2.0)
                     g.replay()
                     torch.cuda.synchronize()
