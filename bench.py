@@ -9,8 +9,10 @@ A "step" is one NGP training step of BASELINE.json configs[1] on synthetic Lego-
 `value` = real marched samples (sum of step_counter[:,0] over the timed steps and over ranks) / wall time.
 
 Multi-GPU (`python -m torch.distributed.run ... bench.py --gpus N`): weak scaling, every rank trains on its own
-4,096-ray batches; one flat-bucket gradient all-reduce (RCCL) per step, issued eagerly between the two graph
-replays of the step (forward+backward | optimizer) — the collective itself is never captured.
+4,096-ray batches; one gradient all-reduce (RCCL) per step over the optimizer's flat fp16 buffer, recorded INSIDE the step's
+HIP graph when the process group supports capture (two graphs with an eager collective between them otherwise).
+`python bench.py --gpus N` without torchrun re-launches itself as N ranks and refuses (exit 2) when fewer GPUs are visible;
+rank 0 checks that N ranks took part in the gradient all-reduce before it prints the line.
 
 Extra objects on the JSON line:
   roofline      dominant hot kernel of the timed region, timed with HIP events on the launch stream
@@ -56,6 +58,9 @@ def parse():
     ap.add_argument("--long_run_steps", type=int, default=3000)
     ap.add_argument("--seal_teacher_steps", type=int, default=256)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="process-group backend (default: nccl = RCCL)")
+    ap.add_argument("--rendezvous_only", action="store_true",
+                    help="launch check: the ranks rendezvous, count themselves with an all-reduce, rank 0 prints the count; no measurement")
     return ap.parse_args()
 
 
@@ -417,9 +422,29 @@ def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m:
 # ----------------------------------------------------------------------------- main
 def main():
     args = parse()
-    from parallel import RayShardedDP, init_from_env
-    rank, world, local = init_from_env()
+    from parallel import RayShardedDP, init_from_env, launched_by_torchrun, spawn_ranks
+    if args.gpus > 1 and not launched_by_torchrun():
+        # `python bench.py --gpus N` typed as it stands: become N ranks (one per GPU) under torch.distributed.run
+        spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:], need_gpus=args.backend != "gloo")
+    rank, world, local = init_from_env(args.backend)
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus}, but {world} rank(s) were launched (WORLD_SIZE): refusing to report a number "
+                 "for another GPU count than the one asked for")
+    if args.rendezvous_only:
+        import torch.distributed as dist
+        seen = torch.ones(1, device=torch.device("cuda", local) if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(seen)
+        if world > 1:
+            dist.destroy_process_group()
+        if int(seen.item()) != args.gpus:
+            sys.exit(f"bench.py: {int(seen.item())} ranks answered the all-reduce, {args.gpus} expected")
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": int(seen.item()), "backend": args.backend or "nccl"}), flush=True)
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    if torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} GPUs requested, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import s3d_hip
@@ -574,6 +599,8 @@ def main():
         dp_info = {"n_ranks_seen": int(seen.item()), "allreduce_ms_per_rank": [round(float(t.item()), 4) for t in per_rank],
                    "gradient_bytes": int(nbytes), "collectives_in_graph": bool(getattr(trainer, "collectives_in_graph", False)),
                    "reduce_op": "avg (in the collective)" if dp.fused_avg() else "sum + divide"}
+        if dp_info["n_ranks_seen"] != args.gpus:
+            sys.exit(f"bench.py: {dp_info['n_ranks_seen']} ranks took part in the gradient all-reduce, --gpus {args.gpus}")
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -618,6 +645,7 @@ def main():
         roofline_ffmlp["counters"] = "profiles/r08_timed_region.md (SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F16 per kernel)"
 
     extra = {"roofline_ffmlp": roofline_ffmlp, "samples_per_s_64steps": long_run}
+    collectives_in_graph = bool(getattr(trainer, "collectives_in_graph", False))  # (the Seal section below drops `trainer`)
     if graphed:
         extra["graph_captures_in_timed_region"] = trainer.n_captures - captures0
     if ues_ms:
@@ -684,7 +712,7 @@ def main():
                                "Seal NGP net (two hash encoders + nn.Linear MLPs), 800x800 cameras, 4096 rays/step/GPU",
                    "num_rays_per_gpu": args.num_rays, "samples_per_step": samples / args.steps / world,
                    "parallelism": f"ray-sharded dp{world}", "pretrain_steps": args.pretrain,
-                   "launch": ("hip-graph replay" + ((" (one graph incl. the RCCL all-reduce)" if getattr(trainer, "collectives_in_graph", False)
+                   "launch": ("hip-graph replay" + ((" (one graph incl. the RCCL all-reduce)" if collectives_in_graph
                                                   else " (fwd+bwd | all-reduce | optimizer)") if dp is not None else "")) if graphed else "eager"},
         "roofline": roofline, "cpu_baseline": cpu,
     }

@@ -58,7 +58,9 @@ class _FFMLPForward(Function):
         if inference:
             # (the reference's inference_buffer is [B, hidden]; the layer-by-layer path of the widths the fused kernels do not
             #  cover ping-pongs between two such buffers, the fused kernels use none)
-            scratch = torch.empty(2, B, hidden_dim, device=inputs.device, dtype=inputs.dtype)
+            native = getattr(_backend, "fused_backward_supported", None) is not None and \
+                _backend.fused_backward_supported(input_dim, output_dim, hidden_dim, num_layers, activation)
+            scratch = torch.empty((1,) if native else (2, B, hidden_dim), device=inputs.device, dtype=inputs.dtype)
             extra = {}
             if input_layout:
                 extra["input_layout"] = input_layout
@@ -245,12 +247,21 @@ class FFMLP(nn.Module):
         torch.manual_seed(42)  # the reference reseeds the global RNG here (ffmlp.py:142)
         bound = math.sqrt(3 / self.hidden_dim)
         self.weights.data.uniform_(-bound, bound)
+        from gridencoder.grid import bump_weights_epoch
+        bump_weights_epoch()  # (a `.data` write bumps no version: cached fp16 copies are stale now)
 
     def forward(self, inputs):
         out = self.forward_padded(inputs)
         if self.padded_output_dim != self.output_dim:
             out = out[:, :self.output_dim]
         return out
+
+    def fused_supported(self):
+        """True when the hand-written MFMA kernels (re-computing fused backward, level-major input, `n_valid`, heads) serve
+        this shape; False = the layer-by-layer path, which implements the reference's interface only"""
+        return (_FUSED_BACKWARD and getattr(_backend, "fused_backward_supported", None) is not None
+                and bool(_backend.fused_backward_supported(self.input_dim, self.padded_output_dim, self.hidden_dim,
+                                                           self.num_layers, self.activation)))
 
     def rgb_head_supported(self):
         return (self.output_dim >= 3 and _FUSED_BACKWARD and getattr(_backend, "fused_backward_supported", None) is not None

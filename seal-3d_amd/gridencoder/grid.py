@@ -6,8 +6,6 @@ libseal3d_hip (s3d_hip.GridBackend).
 """
 import math
 
-import weakref
-
 import numpy as np
 import torch
 import torch.nn as nn
@@ -23,13 +21,13 @@ _GRIDTYPE = {"hash": 0, "tiled": 1}
 _INTERP = {"linear": 0, "smoothstep": 1}
 
 
-_half_cache = {}  # id(parameter) -> (weakref, version, epoch, half copy)
 _weights_epoch = 0
 
 
 def bump_weights_epoch():
     """Called by trainers that update parameters WITHOUT Python-side in-place ops (HIP-graph replays do not bump
-    `Tensor._version`), so that cached fp16 tables are refreshed."""
+    `Tensor._version`), so that cached fp16 tables are refreshed.  Anything that writes parameters through `.data`
+    (`reset_parameters`, an EMA's `copy_to` / `restore`) has to call it too: `.data` writes bump no version either."""
     global _weights_epoch
     _weights_epoch += 1
 
@@ -50,11 +48,13 @@ def _half_table(embeddings, cache):
     weight update instead of one per call."""
     if not cache or torch.cuda.is_current_stream_capturing():
         return embeddings.to(torch.half)
-    hit = _half_cache.get(id(embeddings))
-    if hit is not None and hit[0]() is embeddings and hit[1] == embeddings._version and hit[2] == _weights_epoch:
-        return hit[3]
+    # the copy lives ON the parameter object, so it is freed with it (a replaced teacher's 73 MB table does not stay pinned
+    # in a module-level dict)
+    hit = getattr(embeddings, "_s3d_eval_half", None)
+    if hit is not None and hit[0] == embeddings._version and hit[1] == _weights_epoch and hit[2].device == embeddings.device:
+        return hit[2]
     h = embeddings.detach().to(torch.half)
-    _half_cache[id(embeddings)] = (weakref.ref(embeddings), embeddings._version, _weights_epoch, h)
+    embeddings._s3d_eval_half = (embeddings._version, _weights_epoch, h)
     return h
 
 
@@ -179,6 +179,7 @@ class GridEncoder(nn.Module):
 
     def reset_parameters(self):
         self.embeddings.data.uniform_(-1e-4, 1e-4)
+        bump_weights_epoch()  # (a `.data` write bumps no version: cached fp16 copies are stale now)
 
     def __repr__(self):
         top = int(round(self.base_resolution * self.per_level_scale ** (self.num_levels - 1)))

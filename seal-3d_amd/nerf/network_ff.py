@@ -101,7 +101,16 @@ class NeRFNetwork(NeRFRenderer):
                 and torch.get_autocast_dtype("cuda") == torch.float16
                 and getattr(self.encoder_dir, "degree", None) == 4 and self.geo_feat_dim == 15
                 and self.sigma_net.padded_output_dim == 16 and self.color_net.input_dim == 32
-                and self.color_net.padded_output_dim == 16)
+                and self.color_net.padded_output_dim == 16
+                # widths the fused MFMA kernels do not cover (hidden 16 / 128 / 256: rocBLAS layer path) take the reference's
+                # op sequence: the level-major / n_valid / head routes exist in the fused kernels only
+                and self._fused_mlps())
+
+    def _fused_mlps(self):
+        ok = getattr(self, "_fused_mlps_ok", None)
+        if ok is None:
+            ok = self._fused_mlps_ok = bool(self.sigma_net.fused_supported() and self.color_net.fused_supported())
+        return ok
 
     def forward(self, x, d):
         if self._can_fuse(x):

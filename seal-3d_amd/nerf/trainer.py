@@ -393,10 +393,9 @@ class GraphedTrainer(Trainer):
         else:
             self._replay()
             filed = self._counter_ring is not None
-            # (the static loss buffer is overwritten by the next replay; a ring slot only 16 steps later — and the ring restarts
-            #  at slot 0 after every update_extra_state: a caller that keeps loss TENSORS for longer clones them, `.item()` /
-            #  `float()` callers need nothing.  No clone here: it would be one more launch per step)
-            loss = self.loss_ring[model.local_step % 16] if filed else self.s_loss.clone()
+            # the static loss buffer is overwritten by the next replay and a ring slot 16 steps later (the ring restarts at slot 0
+            # after every update_extra_state): the caller gets its own copy, like the tensor the reference's step returns
+            loss = (self.loss_ring[model.local_step % 16] if filed else self.s_loss).clone()
         bump_weights_epoch()  # replays update the parameters without touching Tensor._version
         if not filed:
             model.step_counter[model.local_step % 16].copy_(self.s_counter)

@@ -1,1 +1,1 @@
-from .dist import RayShardedDP, init_from_env, shard_slice  # noqa: F401
+from .dist import RayShardedDP, free_port, init_from_env, launched_by_torchrun, shard_slice, spawn_ranks  # noqa: F401

@@ -30,6 +30,35 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def launched_by_torchrun():
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, script, argv, need_gpus=True):
+    """`python script --gpus n` typed WITHOUT torchrun: replace this process by
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... script argv` (one rank per GPU, rendezvous on
+    127.0.0.1 at a free port).  Refuses — non-zero exit, a sentence on stderr — when the node shows fewer than n GPUs:
+    a run that quietly measured one GPU would be read as an n-GPU number.  Does not return."""
+    import sys
+    if need_gpus:
+        seen = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if seen < n:
+            sys.stderr.write(f"{os.path.basename(script)}: {n} GPUs requested, {seen} visible\n")
+            sys.exit(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script] + list(argv)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def shard_slice(n, rank, world):
     """contiguous shard [lo, hi) of n units for `rank` (remainder spread over the first ranks)"""
     base, rem = divmod(n, world)

@@ -382,3 +382,27 @@ def test_two_graph_dp_step_on_two_gloo_ranks(hip, tmp_path):
     for r in (0, 1):
         line = [l for l in res.stdout.splitlines() if l.startswith(f"RANK{r} ")]
         assert line and "two_graphs=True same=True falls=True finite=True fused_avg=False" in line[0], res.stdout + res.stderr[-1500:]
+
+
+@pytest.mark.parametrize("hidden", [128, 16])
+def test_network_with_library_path_widths_trains_and_renders(hip, hidden):
+    """FFMLP accepts hidden 16 / 128 / 256 through the layer-by-layer path, which has no level-major / n_valid /
+    head routes — a NeRFNetwork of such a width must take the reference's op sequence instead of crashing in train_step,
+    update_extra_state or render."""
+    import bench
+    import s3d_hip
+    from nerf import network_ff, synthetic as syn
+    from nerf.trainer import Trainer
+    torch.manual_seed(0)
+    model = network_ff.NeRFNetwork(hidden_dim=hidden, hidden_dim_color=hidden, bound=1, cuda_ray=True, density_scale=1,
+                                   min_near=0.2, density_thresh=10).cuda()
+    assert not model._fused_mlps()
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    batches, poses = bench.make_batches(4, 1024, 0, torch.device("cuda"), s3d_hip.RaymarchingBackend,
+                                        torch.from_numpy(bits).cuda(), syn.lego_like_boxes(0))
+    tr = Trainer(model, lr=1e-2, fp16=True, update_extra_interval=16)
+    losses = _run(tr, batches, 40)  # (covers two occupancy updates)
+    assert torch.isfinite(losses).all() and float(losses[-4:].mean()) < float(losses[:4].mean())
+    r = syn.get_rays(poses[:1].cuda(), syn.lego_intrinsics(32, 32), 32, 32)
+    img = tr.render_image(r["rays_o"].contiguous(), r["rays_d"].contiguous())["image"]
+    assert img.shape[-1] == 3 and torch.isfinite(img).all()

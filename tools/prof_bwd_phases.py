@@ -1,7 +1,7 @@
 """Per-phase shader-clock stamps of the third-generation binned backward (library built with -DS3D_BIN3_PROF)."""
 import ctypes as C, os, sys
 import numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "seal-3d_amd")); sys.path.insert(0, os.path.join(REPO, "tools"))
 import s3d_hip
 from bench_grid import grid_meta, ray_ordered_points

@@ -10,7 +10,7 @@ for v in "$@"; do
   echo "== $v"; S3D_HIP_LIB=$ROOT/seal-3d_amd/csrc/build/variants/lib_$v.so timeout 300 python tools/bench_grid.py --no_fwd --sum --iters 60 --sizes 262144 2>&1 | tee $OUT/$v.log | grep grid_bwd
 done
 if [ -f $ROOT/seal-3d_amd/csrc/build/variants/lib_prof.so ]; then
-  S3D_HIP_LIB=$ROOT/seal-3d_amd/csrc/build/variants/lib_prof.so timeout 300 python tools/debug/prof_bwd.py ray 2>&1 | tee $OUT/prof_ray.log
+  S3D_HIP_LIB=$ROOT/seal-3d_amd/csrc/build/variants/lib_prof.so timeout 300 python tools/prof_bwd_phases.py ray 2>&1 | tee $OUT/prof_ray.log
 fi
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $ROOT/tools/bench_grid.py --no_fwd --iters 10 --sizes 262144 --orders ray > $OUT/trace.log 2>&1
