@@ -25,8 +25,12 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# (host-side only: OpenMP teams of the CPU baseline wait passively — two runtimes with spinning teams, torch's and the
+#  oracle's, starve each other on a many-core host.  Has to be in the environment before libgomp initialises.)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 for p in (REPO, os.path.join(REPO, "seal-3d_amd")):
@@ -51,11 +55,12 @@ def parse():
     ap.add_argument("--infer_batch_scale", type=int, default=4, help="inference samples/ray/iteration multiplier (1 = reference heuristic)")
     ap.add_argument("--cpu_steps", type=int, default=5, help="timed CPU-baseline steps (median), after --cpu_warmup warm-ups (BASELINE.md §3: 2 + 5)")
     ap.add_argument("--cpu_warmup", type=int, default=2)
-    ap.add_argument("--cpu_rays", type=int, default=1024, help="rays per CPU-baseline step (a bounded sample of the 4,096-ray step)")
+    ap.add_argument("--cpu_rays", type=int, default=4096, help="rays per CPU-baseline step (BASELINE.md §3 (ii): 4,096)")
     ap.add_argument("--no_cpu_render", action="store_true", help="skip the 64x64 CPU renders (cuda_ray on and off) of BASELINE.md §3 (i)")
     ap.add_argument("--no_seal", action="store_true", help="skip the configs[2] (Seal bbox distillation) section")
     ap.add_argument("--no_long_run", action="store_true", help="skip the 2 x 3,000-step convergence comparison (psnr.long_run)")
     ap.add_argument("--long_run_steps", type=int, default=3000)
+    ap.add_argument("--long_run_seeds", type=int, default=3)
     ap.add_argument("--seal_teacher_steps", type=int, default=256)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="process-group backend (default: nccl = RCCL)")
@@ -199,7 +204,12 @@ def grid_meta(name, args):
 # ----------------------------------------------------------------------------- CPU baseline (oracle port)
 def cpu_baseline(args, num_rays):
     """the same training step (two-pass marching, hash encode, nn.Linear MLPs = the reference's `--ff`-off network,
-    composite, backward) on the host cores, native ops by the CPU oracle (OpenMP).  Bounded sample."""
+    composite, backward, Adam) on the host cores, native ops by the CPU oracle (OpenMP).  BASELINE.md §3 (ii): 4,096 rays per
+    step, 2 warm-ups + median of 5.  The step is a chain of small parallel regions (torch's intra-op pool for the MLPs and
+    Adam, the oracle's OpenMP teams for the native ops): on a many-core host the thread count that wins is NOT "all of them"
+    (round 3 ran both pools at 256 threads and measured 10.7 s per 1,024-ray step — two spinning teams of 256 taking turns),
+    so the step is timed at {16, 64, all} threads (both pools at the same count, passive waiting) and the best is reported
+    with its thread count; a setting whose first step takes more than 3 s is cut to one timed step."""
     from oracle import oracle_backend as ob
     import raymarching.raymarching as rm
     import gridencoder.grid as gg
@@ -208,31 +218,50 @@ def cpu_baseline(args, num_rays):
     from nerf.trainer import Trainer
     ob.build()
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    ob.set_threads(cores)
+    sweep = sorted({t for t in (16, 64, cores) if t <= cores} or {cores})
     saved = (rm._backend, gg._backend, sh._backend)
     rm._backend, gg._backend, sh._backend = ob.RaymarchingBackend, ob.GridBackend, ob.SHBackend
     try:
-        torch.manual_seed(0)
-        net = network.NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10)
         grid, bits = syn.lego_like_density_grid(seed=0)
-        net.density_grid.copy_(torch.from_numpy(grid))
-        net.density_bitfield.copy_(torch.from_numpy(bits))
-        net.iter_density = 100  # skip the full-sweep grid update: the sample is the steady-state step
-        tr = Trainer(net, fp16=False, update_extra_interval=10 ** 9)
-        tr.global_step = 1
         boxes = syn.lego_like_boxes(0)
         batches, poses = make_batches(2, num_rays, 0, "cpu", ob.RaymarchingBackend, torch.from_numpy(bits), boxes)
-        for i in range(args.cpu_warmup):  # warm-ups, then the median of the timed steps (BASELINE.md §3 asks for 2 + 5: ~2 min
-            tr.train_step(*batches[i % 2])  # of CPU time at 11 s per step — `--cpu_warmup 2 --cpu_steps 5`; the default is bounded)
-        rates, samples, t_all = [], 0, time.perf_counter()
-        for i in range(args.cpu_steps):
+
+        def fresh():
+            torch.manual_seed(0)
+            net = network.NeRFNetwork(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10)
+            net.density_grid.copy_(torch.from_numpy(grid))
+            net.density_bitfield.copy_(torch.from_numpy(bits))
+            net.iter_density = 100  # skip the full-sweep grid update: the sample is the steady-state step
+            tr = Trainer(net, fp16=False, update_extra_interval=10 ** 9)
+            tr.global_step = 1
+            return net, tr
+
+        def one_step(net, tr, i):
             t0 = time.perf_counter()
             tr.train_step(*batches[i % 2])
-            n = int(net.step_counter[(net.local_step - 1) % 16, 0])
-            rates.append(n / (time.perf_counter() - t0))
-            samples += n
-        dt = time.perf_counter() - t_all
+            dt = time.perf_counter() - t0
+            return int(net.step_counter[(net.local_step - 1) % 16, 0]), dt
+        by_threads, t_all, samples = {}, time.perf_counter(), 0
+        for t in sweep:
+            torch.set_num_threads(t)
+            ob.set_threads(t)
+            net, tr = fresh()
+            n, dt = one_step(net, tr, 0)  # first warm-up, also the probe
+            slow = dt > 3.0
+            for i in range(1, 1 if slow else args.cpu_warmup):
+                one_step(net, tr, i)
+            rates = []
+            for i in range(1 if slow else args.cpu_steps):
+                n, dt = one_step(net, tr, i)
+                rates.append(n / dt)
+                samples += n
+            by_threads[t] = {"samples_per_s": float(np.median(rates)), "timed_steps": len(rates),
+                             "ms_per_step": float(np.median([1e3 * n / r for r in rates]))}
+        dt_all = time.perf_counter() - t_all
+        best = max(by_threads, key=lambda t: by_threads[t]["samples_per_s"])
+        torch.set_num_threads(best)
+        ob.set_threads(best)
+        net, tr = fresh()
         render = {}
         if not args.no_cpu_render:  # a 64x64 full render (4,096 rays), `cuda_ray` on (inference loop) ...
             r = syn.get_rays(poses[:1], syn.lego_intrinsics(64, 64), 64, 64)
@@ -253,6 +282,7 @@ def cpu_baseline(args, num_rays):
                 net.cuda_ray = True
     finally:
         rm._backend, gg._backend, sh._backend = saved
+        torch.set_num_threads(cores)
     model_name = "unknown"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -261,10 +291,12 @@ def cpu_baseline(args, num_rays):
                 break
     except OSError:
         pass
-    return {"value": float(np.median(rates)), "unit": "samples/s", "cores": cores, "cpu_model": model_name, "kind": "port", **render,
-            "sample": f"median of {args.cpu_steps} training steps (after {args.cpu_warmup} warm-up) x {num_rays} rays ({samples} samples, "
-                      f"{dt:.1f} s) of the same synthetic scene, fp32, two-encoder nn.Linear network (the reference's --ff-off path), "
-                      "native ops = CPU oracle + OpenMP"}
+    return {"value": by_threads[best]["samples_per_s"], "unit": "samples/s", "cores": best, "host_cores": cores, "cpu_model": model_name,
+            "kind": "port", "thread_sweep": {str(t): v for t, v in by_threads.items()}, **render,
+            "sample": f"median of {args.cpu_steps} training steps (after {args.cpu_warmup} warm-ups) x {num_rays} rays per thread setting "
+                      f"{sweep} ({samples} samples, {dt_all:.1f} s in all), best setting reported; same synthetic scene, fp32, two-encoder "
+                      "nn.Linear network (the reference's --ff-off path), native ops = CPU oracle + OpenMP; the 64x64 renders use the "
+                      "best setting"}
 
 
 # ----------------------------------------------------------------------------- PSNR of the HIP render against the oracle render
@@ -376,11 +408,14 @@ def seal_section(args, dev, batches, note=lambda m: None):
 
 
 # ----------------------------------------------------------------------------- quality over a long run
-def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m: None):
+def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m: None, seeds=3):
     """Does the native fp16 path (fp16 table gradients, exact fixed-point sums, native Adam + loss scaling, HIP-graph replay)
     CONVERGE like the reference arrangement (torch.optim.Adam on fp32 `.grad`s + torch GradScaler, eager)?  Both train
     configs[1]'s network from the same initial weights on the same batches for `steps` steps (lr 1e-2 decayed to 0.1x as
-    main_SealNeRF.py:283-288); PSNR (nerf/utils.py:226-233) on four HELD-OUT 200x200 views against the analytic scene."""
+    main_SealNeRF.py:283-288); PSNR (nerf/utils.py:226-233) on four HELD-OUT 200x200 views against the analytic scene.
+    The two trajectories are chaotic twins (different rounding, different RNG consumption under capture), so ONE pair says
+    little: the comparison is repeated for `seeds` initialisations and reported as mean +- sample standard deviation of
+    each arrangement and of the paired difference."""
     from nerf import network_ff, synthetic as syn
     from nerf.trainer import GraphedTrainer, Trainer, psnr
     kw = dict(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10)
@@ -388,33 +423,44 @@ def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m:
     views = syn.orbit_poses(4, seed=977)  # not among the 100 training cameras (seed 0)
     rays = [syn.get_rays(views[i:i + 1].to(dev), syn.lego_intrinsics(200, 200), 200, 200) for i in range(4)]
     gts = [analytic_targets(r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous(), scene_bits, boxes, R) for r in rays]
-    torch.manual_seed(args.seed + 5)
-    init = network_ff.NeRFNetwork(**kw).to(dev).state_dict()
+    tags = (("native_fp16_graph", True), ("torch_adam_fp32_eager", False))
+    runs = {t: [] for t, _ in tags}
+    for k in range(seeds):
+        torch.manual_seed(args.seed + 5 + 101 * k)
+        init = network_ff.NeRFNetwork(**kw).to(dev).state_dict()
+        for tag, native in tags:
+            torch.manual_seed(args.seed + 6 + 101 * k)
+            m = network_ff.NeRFNetwork(**kw).to(dev)
+            m.load_state_dict(init)
+            tr = GraphedTrainer(m, args.num_rays, lr=1e-2, fp16=True) if native else Trainer(m, lr=1e-2, fp16=True, native_optim=False)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                lr = 1e-2 * 0.1 ** min(i / steps, 1.0)
+                for g in tr.optimizer.param_groups:
+                    g["lr"] = lr
+                if native and tr.graph is not None and i % 100 == 0:
+                    tr.graph = None  # (the learning rate is a kernel argument of the captured step: re-capture on the decay schedule)
+                tr.train_step(*pool[(i + 257 * k) % len(pool)])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            vals = []
+            for r, gt in zip(rays, gts):
+                img = tr.render_image(r["rays_o"].contiguous(), r["rays_d"].contiguous())["image"][0]
+                vals.append(psnr(img, gt))
+            runs[tag].append({"psnr_db_per_view": [round(v, 3) for v in vals], "psnr_db": float(np.mean(vals)), "train_s": round(dt, 2)})
+            note(f"long run [{tag}, seed {k}]: {np.mean(vals):.2f} dB in {dt:.1f} s")
+            del tr, m
     out = {}
-    for tag, native in (("native_fp16_graph", True), ("torch_adam_fp32_eager", False)):
-        torch.manual_seed(args.seed + 6)
-        m = network_ff.NeRFNetwork(**kw).to(dev)
-        m.load_state_dict(init)
-        tr = GraphedTrainer(m, args.num_rays, lr=1e-2, fp16=True) if native else Trainer(m, lr=1e-2, fp16=True, native_optim=False)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            lr = 1e-2 * 0.1 ** min(i / steps, 1.0)
-            for g in tr.optimizer.param_groups:
-                g["lr"] = lr
-            if native and tr.graph is not None and i % 100 == 0:
-                tr.graph = None  # (the learning rate is a kernel argument of the captured step: re-capture on the decay schedule)
-            tr.train_step(*pool[i % len(pool)])
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        vals = []
-        for r, gt in zip(rays, gts):
-            img = tr.render_image(r["rays_o"].contiguous(), r["rays_d"].contiguous())["image"][0]
-            vals.append(psnr(img, gt))
-        out[tag] = {"psnr_db_per_view": [round(v, 3) for v in vals], "psnr_db": float(np.mean(vals)), "train_s": round(dt, 2)}
-        note(f"long run [{tag}]: {np.mean(vals):.2f} dB in {dt:.1f} s")
-        del tr, m
-    out["steps"] = steps
-    out["delta_db"] = out["native_fp16_graph"]["psnr_db"] - out["torch_adam_fp32_eager"]["psnr_db"]
+    for tag, _ in tags:
+        v = [r["psnr_db"] for r in runs[tag]]
+        out[tag] = {"psnr_db": float(np.mean(v)), "psnr_db_std": float(np.std(v, ddof=1)) if len(v) > 1 else 0.0,
+                    "psnr_db_per_seed": [round(x, 3) for x in v], "runs": runs[tag]}
+    d = [a["psnr_db"] - b["psnr_db"] for a, b in zip(runs["native_fp16_graph"], runs["torch_adam_fp32_eager"])]
+    out["steps"], out["seeds"] = steps, seeds
+    out["delta_db_per_seed"] = [round(x, 3) for x in d]
+    out["delta_db"] = float(np.mean(d))
+    out["delta_db_std"] = float(np.std(d, ddof=1)) if len(d) > 1 else 0.0
+    out["within_0p1_db"] = bool(abs(out["delta_db"]) <= 0.1)
     out["views"] = "4 held-out 200x200 orbit cameras (seed 977), analytic box scene"
     return out
 
@@ -692,7 +738,7 @@ def main():
         extra["psnr"] = psnr_vs_oracle(model, lambda: Net(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10),
                                        poses, scene_bits, boxes, dev, R)
     if world == 1 and not args.no_long_run and args.net == "ff":
-        lr_ = long_run_quality(args, dev, R, scene_bits, boxes, steps=args.long_run_steps, note=note)
+        lr_ = long_run_quality(args, dev, R, scene_bits, boxes, steps=args.long_run_steps, note=note, seeds=args.long_run_seeds)
         extra.setdefault("psnr", {})["long_run"] = lr_
     if world == 1 and not args.no_seal and args.net == "ff":
         note("seal section")

@@ -195,8 +195,7 @@ int s3d_grid_corner_indices(const float* inputs, const int32_t* offsets, uint32_
  * workspace (s3d_grid_encode_backward_workspace_size bytes; 0 = configuration not supported) enables the
  * binned path used for B >= 8192: contributions are partitioned by table slice and summed in LDS as 64-bit
  * fixed point — deterministic, no global atomics.  Without it (NULL) direct atomics are used.
- * path: 0 = auto, 1 = direct atomics, 2 = binned (an error when the workspace is missing), 3 = binned with the
- * previous generation's 8-byte records (kept for A/B runs and as the fallback of the shapes it alone covers).
+ * path: 0 = auto, 1 = direct atomics, 2 = binned (an error when the workspace is missing).
  * found_inf (optional, build extension): a device float raised to 1 when grad_embeddings holds a non-finite value after
  * the call (torch.amp.GradScaler's check, nerf/utils.py:495-537, made where the gradient is produced: the binned fp16 path
  * reports while it writes the sums, the other paths scan the table once).  Never cleared here.

@@ -584,9 +584,6 @@ __device__ __forceinline__ long long to_fixed64(float v, int k) {
 #ifndef S3D_BIN_CHUNK  // points per k_bin_scatter workgroup: every workgroup ends with one returning atomic per slice on the
 #define S3D_BIN_CHUNK 1024  // same cursor words (measured: 1024 beats 2048 and 4096 — the reservations are not what bounds the kernel)
 #endif
-#ifndef S3D_BIN_KS  // lanes sharing a quad of points in the scatter (corners split between them)
-#define S3D_BIN_KS 2
-#endif
 #ifndef S3D_BIN_ACC_KB  // tuning knobs of k_bin_accumulate (tools/build_variants.sh builds variants)
 #define S3D_BIN_ACC_KB 128
 #endif
@@ -991,26 +988,20 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate(const uint32_
     }
 }
 
-// ---- binned backward, second generation ------------------------------------------------------------------------
-// Measured (profiles/r04_grid_isolated.md): k_bin_scatter was bound by the L2 REQUEST rate (every 8-byte record left its
-// lane as its own request: 18.6 M requests per launch at B = 2^18) and by the latency of its own serial phases (one wave per
-// SIMD, 32 records per lane), k_bin_count re-derived every index only to size the buckets and to find the level's |grad|
-// maximum, and a cursor atomic per (chunk, slice) tied the buckets together.  This generation:
+// ---- exact fixed-point sums (fp16, one 32-bit value word per record) --------------------------------------------
+// The three-kernel path above (count -> scatter -> accumulate, a counting pass, 4 + elem * C byte records) stays the path
+// of the WIDE records (fp32 C >= 2, fp16 C >= 4).  Where a record's value is one 32-bit word (fp16 C = 2 under -O, fp32
+// C = 1) the kernels further down replace it.  What they share:
 //  * fp16 gradients need no maximum: every binary16 value (subnormals included) is an integer multiple of 2^-24, so with
 //    the FIXED scale 2^24 the LDS sum is EXACT (|v| * 2^24 < 2^40; 2^D * B <= 2^23 contributions keep it below 2^63).
 //    fp32 gradients (and fp16 batches beyond that bound) keep the data-dependent scale: one streaming max pass
 //    (k_bin_amax: no index arithmetic).
 //  * buckets of FIXED capacity (2x the no-merge mean of a uniformly hit level; real levels merge on top), so no counting
-//    pass; a scatter workgroup sorts the records of its chunk (1,024 points, one level) by slice in LDS, reserves its run
-//    in every slice's bucket (one returning atomic per non-empty slice) and writes each run with consecutive lanes on
-//    consecutive addresses — full lines instead of one request per record.  What does not fit a bucket (samples
-//    clustered in a few coarse cells) is SPILLED to the chunk's own region and listed per slice: exact and reproducible
-//    in every case, the accumulate kernel reads a spilled run like a bucket.
-//    [A purely chunk-local layout (no buckets, no cursors: a run table [level][slice][chunk] and a flat walk over the
-//     concatenated runs with a binary search per record) was measured first: the scatter got faster (15 vs 21 us per
-//     workgroup), the accumulate twice as slow (36 vs 15 us: search + 1 KB segments instead of one stream).]
-//  * the 2^D corners of a quad are split between KS lanes (same points, disjoint corners): the same merged records, 1/KS of
-//    the serial work per lane and KS times the waves for the same LDS.
+//    pass; a scatter workgroup sorts the records of its chunk by slice in LDS, reserves its run in every slice's bucket and
+//    writes each run with consecutive lanes on consecutive addresses.  What does not fit a bucket (samples clustered in a
+//    few coarse cells) is SPILLED to the chunk's own region and listed per slice: exact and reproducible in every case.
+// (The 8-byte-record pair k_bin_scatter4 / k_bin_accumulate4 of round 2 — `path = 3` — left the library in round 4; it is
+//  in the history at ace1d33.)
 constexpr uint32_t kFixedExp = 24;
 
 // fixed-point sum -> float: the two 32-bit limbs of the MAGNITUDE converted separately and joined by one fma (|error| <= 1 ulp
@@ -1058,385 +1049,8 @@ __global__ void __launch_bounds__(1024) k_bin_amax(const T* __restrict__ grad, c
     }
 }
 
-// bin_quad restricted to the corners [sub * K / KS, (sub + 1) * K / KS) (KS lanes share a quad of points; the x-pair of a
-// corner pair stays in one lane).  emit(q, j, slice, local_row, sum[C]) with j = corner index inside the lane's subset.
-template <typename T, uint32_t D, uint32_t C, uint32_t KS, typename Emit>
-__device__ __forceinline__ void bin_quad_split(const float (&x)[kBinQuad][D], const T (&g)[kBinQuad][C], const bool (&in)[kBinQuad],
-                                               float lscale, bool align_corners, uint32_t interp, const LevelIndex<D>& li,
-                                               uint32_t S, uint32_t sshift, uint32_t sub, Emit&& emit) {
-    constexpr uint32_t K = 1u << D, KL = K / KS;
-    bool open = false;
-    uint32_t cell[D], lo[D];
-    float acc[KL][C];
-    auto flush = [&](auto slot) {
-#pragma unroll
-        for (uint32_t j = 0; j < KL; j++) {
-            const uint32_t row = li.row(lo, sub * KL + j);
-            const uint32_t grp = row / kBinGroup;
-            emit(slot, j, grp & (S - 1), (grp >> sshift) * kBinGroup + row % kBinGroup, acc[j]);
-        }
-    };
-    auto step = [&](auto qc) {
-        constexpr uint32_t q = decltype(qc)::value;
-        bool nz = false;
-        (void)absmax_feat<T, C>(g[q], nz);
-        if (!(in[q] && nz)) return;
-        float pos[D], pd[D];
-        uint32_t pos_grid[D];
-        locate<D>(x[q], lscale, align_corners, interp, pos, pd, pos_grid);
-        bool same = open;
-#pragma unroll
-        for (uint32_t d = 0; d < D; d++) same = same && (pos_grid[d] == cell[d]);
-        if (!same) {
-            if constexpr (q > 0) {
-                if (open) flush(std::integral_constant<uint32_t, (q > 0 ? q - 1 : 0)>{});
-            }
-            open = true;
-#pragma unroll
-            for (uint32_t d = 0; d < D; d++) { cell[d] = pos_grid[d]; lo[d] = pos_grid[d] * li.mul[d]; }
-#pragma unroll
-            for (uint32_t j = 0; j < KL; j++)
-#pragma unroll
-                for (uint32_t c = 0; c < C; c++) acc[j][c] = 0.0f;
-        }
-        float gf[C];
-#pragma unroll
-        for (uint32_t c = 0; c < C; c++) gf[c] = Acc<T>::to_f(g[q][c]);
-#pragma unroll
-        for (uint32_t j = 0; j < KL; j++) {
-            const uint32_t idx = sub * KL + j;
-            float w = 1;
-#pragma unroll
-            for (uint32_t d = 0; d < D; d++) w *= ((idx >> d) & 1u) ? pos[d] : 1 - pos[d];
-#pragma unroll
-            for (uint32_t c = 0; c < C; c++) acc[j][c] += w * gf[c];
-        }
-    };
-    step(std::integral_constant<uint32_t, 0>{});
-    step(std::integral_constant<uint32_t, 1>{});
-    step(std::integral_constant<uint32_t, 2>{});
-    step(std::integral_constant<uint32_t, 3>{});
-    if (open) flush(std::integral_constant<uint32_t, kBinQuad - 1>{});
-}
-
-// hdr[level]: FIXED24 = 0, or a non-finite bit pattern once a non-finite record value was seen (the level is poisoned like
-// a float sum would be); otherwise the level's |grad| maximum from k_bin_amax.
-// Buckets: bucket (level, slice) = `cap` records at grecs[(level_in_pass * smax + slice) * cap]; cursor[level * smax + slice]
-// counts the records reserved in it (it may run past cap: the excess lives in the spill regions).
-// Spill: a chunk's run that does not fit its bucket stays — whole or its tail — in the chunk's own spill region
-// (spill[(level_in_pass * nchunks + chunk) * P * K + position in the chunk's sorted order]), and one descriptor
-// {chunk << 16 | first position, count} is appended to the slice's list ovl[(level * smax + slice) * nchunks + k],
-// k = ovn[level * smax + slice]++.  Samples clustered in a few coarse cells (a Seal pretraining lattice inside a small box)
-// overflow the buckets of a handful of slices; the result stays exact and reproducible, only the fast path is left.
-template <typename T, uint32_t D, uint32_t C, bool FIXED24, uint32_t KS>
-__global__ void __launch_bounds__(S3D_BIN_CHUNK / 4 * KS) k_bin_scatter4(const T* __restrict__ grad, const float* __restrict__ inputs,
-                                                     const int32_t* __restrict__ offsets, uint32_t B, uint32_t level0,
-                                                     LevelScales scales, uint32_t* __restrict__ hdr, uint32_t* __restrict__ cursor,
-                                                     uint32_t* __restrict__ ovn, uint2* __restrict__ ovl, uint32_t smax,
-                                                     uint32_t nchunks, uint32_t cap, uint2* __restrict__ grecs,
-                                                     uint2* __restrict__ spill, uint32_t gridtype, bool align_corners,
-                                                     uint32_t interp) {
-    using V = typename FeatVec<T, C>::type;
-    static_assert(sizeof(V) == 4, "packed records: one 32-bit value word");
-    constexpr uint32_t K = 1u << D, KL = K / KS;
-    constexpr uint32_t P = bin_chunk_points<T, D, C>();
-    constexpr uint32_t NT = P / kBinQuad * KS;
-    static_assert(P * K < 65536, "positions inside a chunk are 16-bit fields");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);   // records of the chunk per slice
-    uint32_t* lr = cnt + kBinMaxSlices;                       // run start (exclusive scan of cnt) << 16 | records that fit the bucket
-    int32_t* gdelta = reinterpret_cast<int32_t*>(lr + kBinMaxSlices);  // bucket position of the run - run start
-    uint2* stage = reinterpret_cast<uint2*>(gdelta + kBinMaxSlices);   // [P * K] records sorted by slice
-    __shared__ uint32_t total_s;
-
-    const uint32_t level = level0 + blockIdx.y, chunk = blockIdx.x;
-    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
-    const uint32_t Bv = valid_rows(B, scales.n_valid);
-    if (chunk * P >= Bv) return;  // (uniform) chunk entirely in the absent tail of a padded batch
-    if constexpr (!FIXED24) {
-        const float amax = __uint_as_float(hdr[level]);
-        if (!(amax > 0.0f) || amax == INFINITY) return;  // zero / non-finite levels carry no records (uniform exit)
-    }
-    const uint32_t S = bin_slices(hashmap_size, C);
-    const uint32_t sub = threadIdx.x % KS;
-    const uint32_t b0 = chunk * P + (threadIdx.x / KS) * kBinQuad;
-    float x[kBinQuad][D];
-    T g[kBinQuad][C];
-    bool in[kBinQuad];
-#pragma unroll
-    for (uint32_t q = 0; q < kBinQuad; q++) {
-        in[q] = b0 + q < Bv;
-#pragma unroll
-        for (uint32_t c = 0; c < C; c++) g[q][c] = Acc<T>::zero();
-        if (in[q]) {
-            in[q] = !load_point<D>(inputs, b0 + q, scales, x[q]);
-            load_feat<T, C>(grad + ((size_t)level * B + b0 + q) * C, g[q]);
-        }
-    }
-    const uint32_t sshift = 31 - __clz(S);
-    const float lscale = scales.v[level];
-    LevelIndex<D> li;
-    li.init(gridtype, align_corners, hashmap_size, (uint32_t)ceilf(lscale) + 1);
-    for (uint32_t s = threadIdx.x; s < S; s += NT) cnt[s] = 0;
-    __syncthreads();
-
-    uint32_t key[kBinQuad][KL], rank[kBinQuad][KL], val[kBinQuad][KL];
-    uint32_t closed = 0;
-    bool bad = false;
-    bin_quad_split<T, D, C, KS>(x, g, in, lscale, align_corners, interp, li, S, sshift, sub,
-                      [&](auto qc, uint32_t j, uint32_t slice, uint32_t local, const float (&sum)[C]) {
-                          constexpr uint32_t q = decltype(qc)::value;
-                          closed |= 1u << q;
-                          T pr[C];
-#pragma unroll
-                          for (uint32_t c = 0; c < C; c++) pr[c] = Acc<T>::from_f(sum[c]);
-                          uint32_t bits;
-                          __builtin_memcpy(&bits, pr, 4);
-                          if constexpr (FIXED24)  // inf / NaN after rounding to binary16: an all-ones exponent in either half
-                              bad |= ((bits & 0x7c00u) == 0x7c00u) || ((bits & 0x7c000000u) == 0x7c000000u);
-#pragma unroll
-                          for (uint32_t i = 0; i < KL; i++)
-                              if (i == j) {
-                                  key[q][i] = (slice << 20) | local;
-                                  rank[q][i] = atomicAdd(&cnt[slice], 1u);
-                                  val[q][i] = bits;
-                              }
-                      });
-    if (FIXED24 && bad) atomicMax(hdr + level, 0x7fc00000u);  // poison marker (a NaN pattern sorts above every finite value)
-    __syncthreads();
-    if (threadIdx.x < 64) {  // first wave: run starts, one bucket reservation per non-empty slice, spill descriptors
-        uint32_t carry = 0;
-        for (uint32_t j = 0; j < S / 64; j++) {
-            const uint32_t sl = j * 64 + threadIdx.x, c = cnt[sl];
-            const uint32_t incl = wave_incl_scan(c);
-            const uint32_t lo = carry + incl - c;
-            uint32_t at = 0;
-            if (c) at = atomicAdd(&cursor[level * smax + sl], c);
-            const uint32_t fit = at >= cap ? 0u : (cap - at < c ? cap - at : c);
-            lr[sl] = (lo << 16) | fit;  // both < 65536 (static_assert on P * K)
-            gdelta[sl] = (int32_t)(sl * cap + at) - (int32_t)lo;
-            if (fit < c) {
-                const uint32_t k = atomicAdd(&ovn[level * smax + sl], 1u);
-                ovl[((size_t)level * smax + sl) * nchunks + k] = make_uint2((chunk << 16) | (lo + fit), c - fit);
-            }
-            carry += __shfl(incl, 63, 64);
-        }
-        if (threadIdx.x == 0) total_s = carry;
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t q = 0; q < kBinQuad; q++) {
-        if (!((closed >> q) & 1u)) continue;
-#pragma unroll
-        for (uint32_t j = 0; j < KL; j++) stage[(lr[key[q][j] >> 20] >> 16) + rank[q][j]] = make_uint2(key[q][j], val[q][j]);
-    }
-    __syncthreads();
-    const uint32_t total = total_s;
-    uint2* bucket0 = grecs + (size_t)blockIdx.y * smax * cap;
-    uint2* mine = spill + ((size_t)blockIdx.y * nchunks + chunk) * (P * K);
-    for (uint32_t i = threadIdx.x; i < total; i += NT) {
-        const uint2 r = stage[i];
-        const uint32_t sl = r.x >> 20, w = lr[sl];
-        const uint2 rec = make_uint2(r.x & 0xfffffu, r.y);
-        if (i - (w >> 16) < (w & 0xffffu)) bucket0[(size_t)((int32_t)i + gdelta[sl])] = rec;
-        else mine[i] = rec;
-    }
-}
-
-template <typename T, uint32_t D, uint32_t C, bool FIXED24>
-__global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate4(const uint2* __restrict__ grecs, const uint2* __restrict__ spill,
-                                                                   const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
-                                                                   uint32_t B, uint32_t level0, const uint32_t* __restrict__ hdr,
-                                                                   const uint32_t* __restrict__ cursor, const uint32_t* __restrict__ ovn,
-                                                                   const uint2* __restrict__ ovl, uint32_t smax, uint32_t nchunks,
-                                                                   uint32_t cap, float* __restrict__ found_inf) {
-    using V = typename FeatVec<T, C>::type;
-    static_assert(sizeof(V) == 4, "packed records");
-    constexpr uint32_t K = 1u << D;
-    constexpr uint32_t P = bin_chunk_points<T, D, C>();
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);  // [C][local_rows]
-    const uint32_t level = level0 + blockIdx.y, slice = blockIdx.x;
-    // every global word of the prologue is requested before the first one is tested
-    const uint32_t off = (uint32_t)offsets[level];
-    const uint32_t rows = (uint32_t)offsets[level + 1] - off;
-    const uint32_t hbits = hdr[level];
-    const uint32_t reserved = cursor[level * smax + slice];
-    const uint32_t nspill = ovn[level * smax + slice];
-    const uint32_t S = bin_slices(rows, C);
-    if (slice >= S) return;
-    const uint32_t local_rows = bin_local_rows(rows, S);
-    auto row_of_local = [&](uint32_t local) { return ((local / kBinGroup) * S + slice) * kBinGroup + local % kBinGroup; };
-    T* table = grad_grid + (size_t)off * C;
-    const float amax = __uint_as_float(hbits);
-    const bool poisoned = FIXED24 ? hbits != 0u : (amax != amax || amax == INFINITY);
-    if (poisoned) {
-        for (uint32_t i = threadIdx.x; i < local_rows * C; i += kBinAccThreads) {
-            const uint32_t row = row_of_local(i / C);
-            if (row < rows) table[(size_t)row * C + i % C] = Acc<T>::from_f(NAN);
-        }
-        if (found_inf && threadIdx.x == 0) *found_inf = 1.0f;  // (benign race: everyone writes 1)
-        return;
-    }
-    if (!FIXED24 && !(amax > 0.0f)) return;
-    if (reserved == 0) return;
-    const uint32_t count = reserved < cap ? reserved : cap;
-    int kexp = (int)kFixedExp;
-    if constexpr (!FIXED24) {
-        int e;
-        (void)frexpf(amax, &e);
-        kexp = 62 - e - (int)(32 - __clz(B)) - (int)D;
-    }
-    const uint2* recs = grecs + ((size_t)blockIdx.y * smax + slice) * cap;
-#ifndef S3D_ACC_FASTFIX
-#define S3D_ACC_FASTFIX 1
-#endif
-#ifndef S3D_ACC_COMBINE  // rounds of in-wave combining of equal keys before the LDS atomics (0 = off: measured slower)
-#define S3D_ACC_COMBINE 0
-#endif
-    auto fixed = [&](const uint2& r, long long (&q)[C]) {
-        T pr[C];
-        __builtin_memcpy(pr, &r.y, 4);
-#pragma unroll
-        for (uint32_t c = 0; c < C; c++) {
-            const float v = Acc<T>::to_f(pr[c]);
-            q[c] = (FIXED24 && S3D_ACC_FASTFIX) ? fixed24_exact(v) : to_fixed64(v, kexp);
-        }
-    };
-    auto add = [&](const uint2& r) {
-        long long q[C];
-        fixed(r, q);
-#pragma unroll
-        for (uint32_t c = 0; c < C; c++) atomicAdd(&acc[c * local_rows + r.x], (unsigned long long)q[c]);
-    };
-    // One wave-instruction of `add` is 64 LDS atomics; records that sit next to each other in a bucket come from one scatter
-    // instruction of neighbouring lanes, i.e. — on the coarse levels, where a whole wave's samples lie in one cell — they
-    // carry the SAME row, and same-address LDS atomics serialise (the level-0..2 workgroups were the long poles of the
-    // launch: 34 / 19 / 27 us against ~12 us).  Called by the whole wave: lanes that share the key of the first pending
-    // lane are summed across the wave (integer adds: still exact, still order-independent) and leave as ONE atomic; a few
-    // rounds of that, then whatever is left goes the plain way.
-    // [MEASURED, off by default: 71 -> 103 us per launch in the training step.  The ballot / compare / 64-bit shuffle
-    //  sequence costs every batch more than the serialised atomics cost the few hot ones.]
-    auto add_wave = [&](const uint2& r, bool valid) {
-        long long q[C];
-        fixed(r, q);
-        const uint32_t lane = threadIdx.x & 63u;
-        unsigned long long todo = __ballot(valid);
-#pragma unroll 1
-        for (int it = 0; it < S3D_ACC_COMBINE && todo; it++) {
-            const int lead = __ffsll((long long)todo) - 1;
-            const uint32_t k0 = (uint32_t)__shfl((int)r.x, lead, 64);
-            const bool same = ((todo >> lane) & 1ull) && r.x == k0;
-            const unsigned long long m = __ballot(same);
-            if (__popcll(m) < 8) break;
-#pragma unroll
-            for (uint32_t c = 0; c < C; c++) {
-                long long v = same ? q[c] : 0ll;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-                if ((int)lane == lead) atomicAdd(&acc[c * local_rows + k0], (unsigned long long)v);
-            }
-            todo &= ~m;
-        }
-        if ((todo >> lane) & 1ull) {
-#pragma unroll
-            for (uint32_t c = 0; c < C; c++) atomicAdd(&acc[c * local_rows + r.x], (unsigned long long)q[c]);
-        }
-    };
-#ifndef S3D_ACC_PREFETCH
-#define S3D_ACC_PREFETCH 1
-#endif
-#if S3D_ACC_PREFETCH
-    // the first batch of records is in flight while the accumulators are cleared
-    constexpr uint32_t U = 8;
-    uint2 r[U];
-#pragma unroll
-    for (uint32_t u = 0; u < U; u++) {
-        const uint32_t i = threadIdx.x + u * kBinAccThreads;
-        r[u] = make_uint2(0u, 0u);
-        if (i < count) r[u] = recs[i];
-    }
-    for (uint32_t i = threadIdx.x; i < local_rows * C; i += kBinAccThreads) acc[i] = 0ull;
-    __syncthreads();
-    for (uint32_t base = 0; base < count; base += U * kBinAccThreads) {  // (uniform trip count: add_wave needs whole waves)
-        const uint32_t i0 = base + threadIdx.x;
-        uint2 nx[U];
-#pragma unroll
-        for (uint32_t u = 0; u < U; u++) {  // next batch requested before this one is added
-            const uint32_t i = i0 + (U + u) * kBinAccThreads;
-            nx[u] = make_uint2(0u, 0u);
-            if (i < count) nx[u] = recs[i];
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < U; u++) {
-            if (S3D_ACC_COMBINE > 0) add_wave(r[u], i0 + u * kBinAccThreads < count);
-            else if (i0 + u * kBinAccThreads < count) add(r[u]);
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < U; u++) r[u] = nx[u];
-    }
-#else
-    for (uint32_t i = threadIdx.x; i < local_rows * C; i += kBinAccThreads) acc[i] = 0ull;
-    __syncthreads();
-    {
-        constexpr uint32_t U = kBinAccUnroll;
-        for (uint32_t i0 = threadIdx.x; i0 < count; i0 += U * kBinAccThreads) {
-            uint2 r[U];
-#pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t i = i0 + u * kBinAccThreads;
-                if (i < count) r[u] = recs[i];
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < U; u++)
-                if (i0 + u * kBinAccThreads < count) add(r[u]);
-        }
-    }
-#endif
-    // spilled runs (clustered samples only): one wave per descriptor
-    for (uint32_t k = threadIdx.x >> 6; k < nspill; k += kBinAccThreads / 64) {
-        const uint2 d = ovl[((size_t)level * smax + slice) * nchunks + k];
-        const uint2* run = spill + ((size_t)blockIdx.y * nchunks + (d.x >> 16)) * (P * K) + (d.x & 0xffffu);
-        for (uint32_t j = threadIdx.x & 63u; j < d.y; j += 64) add(run[j]);
-    }
-    __syncthreads();
-    constexpr uint32_t W = 8;
-    bool overflow = false;  // a finite sum that leaves the range of T (fp16: |v| > 65504) — what GradScaler looks for
-    for (uint32_t r0 = threadIdx.x; r0 < local_rows; r0 += W * kBinAccThreads) {
-        long long q[W][C];
-        V old[W];
-        bool nz[W];
-#pragma unroll
-        for (uint32_t w = 0; w < W; w++) {
-            const uint32_t rr = r0 + w * kBinAccThreads;
-            nz[w] = false;
-            if (rr < local_rows) {
-#pragma unroll
-                for (uint32_t c = 0; c < C; c++) { q[w][c] = (long long)acc[c * local_rows + rr]; nz[w] |= (q[w][c] != 0); }
-            }
-        }
-#pragma unroll
-        for (uint32_t w = 0; w < W; w++)
-            if (nz[w]) old[w] = *reinterpret_cast<const V*>(table + (size_t)row_of_local(r0 + w * kBinAccThreads) * C);
-#pragma unroll
-        for (uint32_t w = 0; w < W; w++) {
-            if (nz[w]) {
-                T o[C];
-                __builtin_memcpy(o, &old[w], sizeof(V));
-#pragma unroll
-                for (uint32_t c = 0; c < C; c++) {
-                    o[c] = Acc<T>::from_f(Acc<T>::to_f(o[c]) + fixed_to_float(q[w][c], kexp));
-                    overflow |= !(fabsf(Acc<T>::to_f(o[c])) <= 3.402823466e38f);
-                }
-                store_feat<T, C>(table + (size_t)row_of_local(r0 + w * kBinAccThreads) * C, o);
-            }
-        }
-    }
-    if (found_inf && overflow) *found_inf = 1.0f;
-}
-
 // ---- binned backward, third generation -------------------------------------------------------------------------
-// Measured on generation two (profiles/r07_timed_region.md): the 8-byte records were written once and read once — 548 B per
+// Measured on round 2's 8-byte-record kernels (profiles/r07_timed_region.md): the records were written once and read once — 548 B per
 // point, as much as the whole algorithmic budget of the op — and the scatter spent more than half of its wave-cycles parked
 // (one returning global atomic per slice in the middle of every workgroup's phase chain, every barrier draining the
 // vector-memory queue).  This generation keeps the structure (partition by table slice, exact 64-bit fixed-point sums in
@@ -1557,7 +1171,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v, uint32_t lane
 
 // Bucket (level, slice, sub) = `cap` records: keys at gkeys[((level_in_pass * smax + slice) * kBin3Sub + sub) * cap], values
 // at the same index of gvals; cursor[((level * smax + slice) * kBin3Sub + sub) * kCurStride] counts the records reserved in
-// it (it may run past cap: the excess lives in the spill regions, as in generation two).
+// it (it may run past cap: the excess lives in the spill regions).
 // Phases of a workgroup (profiled with -DS3D_BIN3_PROF, tools/debug/prof_bwd.py): loads in flight across the first
 // (LDS-only) barrier -> products + wave scan -> LDS rank atomics, arrival counter -> the LAST wave to arrive scans the
 // slice counts and puts the bucket reservations in flight -> barrier -> staging (sorted by slice) while the reservations
@@ -2236,76 +1850,6 @@ inline BinLayout bin_layout(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint
     return o;
 }
 
-// second-generation layout: hdr[kMaxLevels] | cursor[L][smax] | ovn[L][smax] | ovl[L][smax][nchunks] (8 B) |
-//                           buckets [levels_per_pass][smax][cap] (8 B) | spill [levels_per_pass][nchunks][P * K] (8 B)
-struct BinLayout2 {
-    uint32_t levels_per_pass, chunks, smax, cap;
-    size_t cursor, ovn, ovl, recs, spill, total;
-    bool ok;
-};
-inline BinLayout2 bin_layout2(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level_rows, uint32_t elem) {
-    BinLayout2 o{};
-    if (elem * C != 4 || D < 2 || D > 5 || !max_level_rows || !L || L > kMaxLevels || !B) return o;
-    o.smax = bin_slices(max_level_rows, C);
-    o.ok = o.smax <= kBinMaxSlices && ((uint64_t)B << D) < (1ull << 30) && ((uint64_t)S3D_BIN_CHUNK << D) < 65536;
-    if (!o.ok) return o;
-    o.chunks = div_up<uint32_t>(B, S3D_BIN_CHUNK);
-    // 2x the mean of a uniformly hit level without any merging, + one chunk's worth of slack for tiny batches
-    o.cap = (uint32_t)((((uint64_t)B << (D + 1)) / kBinMinSlices + 1024 + 63) & ~63ull);
-    const size_t per_level = ((size_t)o.smax * o.cap + ((size_t)o.chunks * S3D_BIN_CHUNK << D)) * 8;
-    const size_t lp = kBinPassBytes / per_level;
-    o.levels_per_pass = (uint32_t)(lp < 1 ? 1 : (lp > L ? L : lp));
-    o.cursor = 256;
-    o.ovn = o.cursor + (size_t)L * o.smax * 4;
-    o.ovl = align256(o.ovn + (size_t)L * o.smax * 4);
-    o.recs = align256(o.ovl + (size_t)L * o.smax * o.chunks * 8);
-    o.spill = align256(o.recs + (size_t)o.levels_per_pass * o.smax * o.cap * 8);
-    o.total = align256(o.spill + (size_t)o.levels_per_pass * ((size_t)o.chunks * S3D_BIN_CHUNK << D) * 8);
-    return o;
-}
-
-template <typename T, uint32_t D, uint32_t C, bool FIXED24>
-int launch_binned2(const T* grad, const float* inputs, const int32_t* offsets, T* grad_emb, uint32_t B, uint32_t L,
-                   const LevelScales& sc, uint32_t gridtype, bool ac, uint32_t interp, unsigned char* ws, const BinLayout2& lay,
-                   hipStream_t st) {
-    constexpr uint32_t P = bin_chunk_points<T, D, C>();
-    constexpr uint32_t K = 1u << D;
-    constexpr uint32_t KS = K >= 8 ? S3D_BIN_KS : 1;  // lanes sharing a quad of points
-    constexpr uint32_t stage = 3 * kBinMaxSlices * 4 + P * K * 8;
-    static std::atomic<uint64_t> attr_devs{0};
-    int dev;
-    if (device_needs_setup(attr_devs, &dev)) {
-        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_scatter4<T, D, C, FIXED24, KS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage));
-        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_accumulate4<T, D, C, FIXED24>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinAccBytes));
-        device_setup_done(attr_devs, dev);
-    }
-    uint32_t* hdr = reinterpret_cast<uint32_t*>(ws);
-    uint32_t* cursor = reinterpret_cast<uint32_t*>(ws + lay.cursor);
-    uint32_t* ovn = reinterpret_cast<uint32_t*>(ws + lay.ovn);
-    uint2* ovl = reinterpret_cast<uint2*>(ws + lay.ovl);
-    uint2* recs = reinterpret_cast<uint2*>(ws + lay.recs);
-    uint2* spill = reinterpret_cast<uint2*>(ws + lay.spill);
-    const uint32_t clear_words = (uint32_t)((lay.ovn + (size_t)L * lay.smax * 4) / 4);  // hdr, cursors, spill counts
-    hipLaunchKernelGGL(k_zero_words, dim3(div_up<uint32_t>(clear_words, 1024)), dim3(1024), 0, st, hdr, clear_words);
-    if constexpr (!FIXED24)
-        hipLaunchKernelGGL((k_bin_amax<T, D, C>), dim3(std::min<uint32_t>(div_up<uint32_t>(B, 1024), 64u), L), dim3(1024), 0, st, grad,
-                           inputs, B, sc, hdr);
-    for (uint32_t l0 = 0; l0 < L; l0 += lay.levels_per_pass) {
-        const uint32_t nl = (L - l0 < lay.levels_per_pass) ? L - l0 : lay.levels_per_pass;
-        hipLaunchKernelGGL((k_bin_scatter4<T, D, C, FIXED24, KS>), dim3(lay.chunks, nl), dim3(P / kBinQuad * KS), stage, st, grad,
-                           inputs, offsets, B, l0, sc, hdr, cursor, ovn, ovl, lay.smax, lay.chunks, lay.cap, recs, spill, gridtype,
-                           ac, interp);
-        hipLaunchKernelGGL((k_bin_accumulate4<T, D, C, FIXED24>), dim3(lay.smax, nl), dim3(kBinAccThreads), kBinAccBytes, st,
-                           (const uint2*)recs, (const uint2*)spill, offsets, grad_emb, B, l0, (const uint32_t*)hdr,
-                           (const uint32_t*)cursor, (const uint32_t*)ovn, (const uint2*)ovl, lay.smax, lay.chunks, lay.cap,
-                           t_found_inf);
-    }
-    t_reported = true;
-    return check_launch("grid_encode_backward");
-}
-
 // third-generation layout: hdr[kMaxLevels] | cursor[L][smax][NSUB] | ovn[L][smax] | ovl[L][smax][nchunks] (8 B) |
 //   bucket keys [levels_per_pass][smax][NSUB][cap] (2 B) | bucket values (4 B) | spill keys [levels_per_pass][nchunks][P * K] | spill values
 struct BinLayout3 {
@@ -2417,26 +1961,13 @@ int launch_backward_c(const T* grad, const float* inputs, const int32_t* offsets
     const bool binned = bin_ok && (force_path >= 2 || (force_path == 0 && B >= kBinnedMinPoints));
     if constexpr (sizeof(T) * C == 4) {  // one 32-bit value word per record (fp16 C = 2, fp32 C = 1)
         const BinLayout3 lay3 = bin_layout3(B, D, C, L, max_level_rows, sizeof(T));
-        if (binned && force_path != 3 && lay3.ok && ws && ws_bytes >= lay3.total) {  // third generation: 6-byte records
+        if (binned && lay3.ok && ws && ws_bytes >= lay3.total) {  // 6-byte records, XCD-private sub-buckets
             int rc;
             unsigned char* cb = (control && control_bytes >= bin3_control_bytes(lay3, L)) ? control : nullptr;
             if (sizeof(T) == 2 && ((uint64_t)B << D) <= (1ull << 23))
                 rc = launch_binned3<T, D, C, true>(grad, inputs, offsets, grad_emb, B, L, sc, gridtype, ac, interp, ws, lay3, cb, st);
             else
                 rc = launch_binned3<T, D, C, false>(grad, inputs, offsets, grad_emb, B, L, sc, gridtype, ac, interp, ws, lay3, cb, st);
-            if (rc != S3D_OK) return rc;
-            if (dy_dx && grad_inputs)
-                hipLaunchKernelGGL((k_grid_input_backward<T, D, C>), dim3(div_up<uint32_t>(B * D, 256)), dim3(256), 0, st, grad,
-                                   dy_dx, grad_inputs, B, L, sc.n_valid);
-            return check_launch("grid_encode_backward");
-        }
-        const BinLayout2 lay2 = bin_layout2(B, D, C, L, max_level_rows, sizeof(T));
-        if (binned && lay2.ok && ws && ws_bytes >= lay2.total) {
-            int rc;
-            if (sizeof(T) == 2 && ((uint64_t)B << D) <= (1ull << 23))
-                rc = launch_binned2<T, D, C, true>(grad, inputs, offsets, grad_emb, B, L, sc, gridtype, ac, interp, ws, lay2, st);
-            else
-                rc = launch_binned2<T, D, C, false>(grad, inputs, offsets, grad_emb, B, L, sc, gridtype, ac, interp, ws, lay2, st);
             if (rc != S3D_OK) return rc;
             if (dy_dx && grad_inputs)
                 hipLaunchKernelGGL((k_grid_input_backward<T, D, C>), dim3(div_up<uint32_t>(B * D, 256)), dim3(256), 0, st, grad,
@@ -2616,10 +2147,9 @@ S3D_EXPORT int s3d_grid_corner_indices(const float* inputs, const int32_t* offse
 S3D_EXPORT size_t s3d_grid_encode_backward_workspace_size(uint32_t B, uint32_t D, uint32_t C, uint32_t L, uint32_t max_level_rows,
                                                           int dtype) {
     const BinLayout lay = bin_layout(B, D, C, L, max_level_rows, dtype == S3D_F16 ? 2u : 4u);
-    const BinLayout2 lay2 = bin_layout2(B, D, C, L, max_level_rows, dtype == S3D_F16 ? 2u : 4u);
     const BinLayout3 lay3 = bin_layout3(B, D, C, L, max_level_rows, dtype == S3D_F16 ? 2u : 4u);
-    const size_t a = lay.ok ? lay.total : 0, b = lay2.ok ? lay2.total : 0, c = lay3.ok ? lay3.total : 0;
-    return std::max(a, std::max(b, c));
+    const size_t a = lay.ok ? lay.total : 0, c = lay3.ok ? lay3.total : 0;
+    return std::max(a, c);
 }
 
 S3D_EXPORT size_t s3d_grid_encode_backward_control_size(uint32_t D, uint32_t C, uint32_t L, uint32_t max_level_rows, int dtype) {
@@ -2636,7 +2166,7 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
                                         void* control, size_t control_bytes, s3d_stream_t stream) {
     // path: 0 = auto (binned from 8,192 points), 1 = direct global atomics, 2 = binned (partition + LDS accumulate)
     (void)embeddings;
-    S3D_REQUIRE(path >= 0 && path <= 3, "grid_encode_backward: path must be 0 (auto), 1 (atomics), 2 (binned) or 3 (binned, 8-byte records)");
+    S3D_REQUIRE(path >= 0 && path <= 2, "grid_encode_backward: path must be 0 (auto), 1 (atomics) or 2 (binned)");
     S3D_REQUIRE(bound >= 0.0f && !(bound != 0.0f && dy_dx), "grid_encode_backward: bound must be >= 0 and 0 with an input Jacobian");
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(grad && inputs && offsets && grad_embeddings, "grid_encode_backward: null pointer");

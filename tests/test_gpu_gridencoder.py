@@ -389,7 +389,7 @@ def test_grid_backward_plane_of_group_boundary_cells(oracle, hip, dtype, C, grid
     """Binned backward on a batch built against the slice interleave: half of the points sit in x cells that are 31 mod 32 on
     one level — the two x-corners of every corner pair then fall into DIFFERENT 32-row groups, i.e. different table slices —
     in distinct cells (nothing merges), on hashed and on tiled (wrapping, non power-of-two) tables; the other half random.
-    All: equal to the oracle's sums; fp16 on that level: bit-identical between the record generations (exact sums)."""
+    All: equal to the oracle's sums; fp16: the binned sums are exact, i.e. bit-identical from run to run."""
     D, L, base = 3, 16, 16
     offsets, S, total = _enc_meta(D, L, C, base, 19, 2048, False)
     g = torch.Generator().manual_seed(5)
@@ -412,19 +412,18 @@ def test_grid_backward_plane_of_group_boundary_cells(oracle, hip, dtype, C, grid
                                             False, 0)
     out = {}
     try:
-        for path in (2, 3):
+        for tag, path in ((2, 2), ("again", 2), (1, 1)):
             hip.GridBackend.set_backward_path(path)
             ge = torch.zeros(total, C, dtype=dtype, device="cuda")
             hip.GridBackend.grid_encode_backward(grad.cuda(), x.cuda(), emb.cuda(), offsets.cuda(), ge, B, D, C, L, S, base, None, None,
                                                  gridtype, False, 0)
-            out[path] = ge.cpu()
+            out[tag] = ge.cpu()
     finally:
         hip.GridBackend.set_backward_path(0)
     if dtype == torch.float16:
-        # (the two generations merge same-cell runs in different trees before the one rounding to binary16: equal up to that)
-        for path in (2, 3):
-            torch.testing.assert_close(out[path].float(), ge_ref, rtol=2e-3, atol=2e-3 * float(ge_ref.abs().max()))
-        lo, hi = int(offsets[lvl]), int(offsets[lvl + 1])  # nothing merges on the split level: the sums are exact on both paths
-        assert torch.equal(out[2][lo:hi].view(torch.int16), out[3][lo:hi].view(torch.int16))
+        # (binned: one rounding to binary16 after an exact sum; atomics: one rounding per add, arrival order)
+        torch.testing.assert_close(out[2].float(), ge_ref, rtol=2e-3, atol=2e-3 * float(ge_ref.abs().max()))
+        torch.testing.assert_close(out[1].float(), ge_ref, rtol=2e-2, atol=2e-2 * float(ge_ref.abs().max()))
+        assert torch.equal(out[2].view(torch.int16), out["again"].view(torch.int16))  # exact sums: the same bits every time
     else:
         torch.testing.assert_close(out[2], ge_ref, rtol=1e-4, atol=1e-5 * float(ge_ref.abs().max()))

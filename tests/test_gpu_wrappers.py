@@ -274,6 +274,14 @@ def test_cached_half_weights_follow_a_fused_torch_optimizer(hip):
     assert not torch.equal(e0, e1), "eval-mode grid output is stale after optimizer steps"
     assert not torch.equal(m0, m1), "no-grad FFMLP output is stale after optimizer steps"
     # and equals what freshly cast weights give
-    gg._half_cache.clear()
+    for p in list(enc.parameters()) + list(mlp.parameters()):  # (the cached copies live on the parameters)
+        if hasattr(p, "_s3d_eval_half"):
+            del p._s3d_eval_half
     e2, m2 = infer()
     assert torch.equal(e1, e2) and torch.equal(m1, m2)
+    # writes through `.data` bump no version: reset_parameters() announces them itself
+    mlp.reset_parameters()
+    enc.reset_parameters()
+    e3, m3 = infer()
+    assert not torch.equal(e2, e3) and not torch.equal(m2, m3), "stale fp16 copies after reset_parameters()"
+    assert enc.embeddings._s3d_eval_half[2].data_ptr() != 0 and not hasattr(gg, "_half_cache")  # freed with the parameter

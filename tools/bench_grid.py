@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--no_fwd", action="store_true")
     ap.add_argument("--sum", action="store_true")
     ap.add_argument("--cold", action="store_true", help="thrash L2/MALL before every timed launch")
-    ap.add_argument("--bwd_path", type=int, default=0, help="`path` of s3d_grid_encode_backward (3 = the 8-byte-record generation)")
+    ap.add_argument("--bwd_path", type=int, default=0, help="`path` of s3d_grid_encode_backward (0 auto, 1 atomics, 2 binned)")
     a = ap.parse_args()
     if a.cold:
         global timeit
