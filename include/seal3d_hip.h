@@ -343,12 +343,31 @@ int s3d_ngp_rgb_backward(const float* grad_rgb, const float* rgb, uint32_t B, ui
 /* Loss head of one ray batch: loss = mean((image + (1 - weights_sum) * bg - gt)^2)  (nerf/renderer.py:316 background
  * compositing + nerf/utils.py:484 MSE); bg_rgb = 3 HOST floats; loss / grad_loss are single device floats.
  * s3d_bg_mse_forward with grad_loss != NULL also writes what s3d_bg_mse_backward would for that upstream gradient (under
- * loss scaling the loss's upstream gradient is the scale, known before the backward pass): one launch instead of two. */
+ * loss scaling the loss's upstream gradient is the scale, known before the backward pass): one launch instead of two.
+ * depth / gt_depth [N] (optional, both or neither) add Seal-3D's depth term depth_weight * mean(|nan_to_num(depth) - gt_depth|)
+ * (nerf/utils.py:486-489) to the VALUE of the loss; like the reference's composite backward (raymarching.py:274: "grad_depth is
+ * not used now") it contributes no gradient. */
 int s3d_bg_mse_forward(const float* image, const float* weights_sum, const float* gt, const float* bg_rgb, uint32_t N,
                        float* loss, const float* grad_loss, float* grad_image, float* grad_weights_sum,
-                       s3d_stream_t stream);
+                       const float* depth, const float* gt_depth, float depth_weight, s3d_stream_t stream);
 int s3d_bg_mse_backward(const float* image, const float* weights_sum, const float* gt, const float* bg_rgb, uint32_t N,
                         const float* grad_loss, float* grad_image, float* grad_weights_sum, s3d_stream_t stream);
+/* Build extension — targets of a teacher-rendered ray batch (SealNeRF/trainer.py:506-586 `proxy_truth`): out_rgb [N,3] =
+ * nan_to_num(image + (1 - weights_sum) * bg) (nerf/renderer.py:316), out_depth [N] (optional) = nan_to_num(depth), nan -> 0 and
+ * +-inf -> +-FLT_MAX as torch.nan_to_num(nan=0.); bg_rgb = 3 HOST floats. */
+int s3d_bg_targets(const float* image, const float* weights_sum, const float* depth, const float* bg_rgb, uint32_t N,
+                   float* out_rgb, float* out_depth, s3d_stream_t stream);
+/* Build extension — Seal-3D's local-pretraining loss on one point chunk (SealNeRF/trainer.py:455-469: L1Loss(sigma) +
+ * L1Loss(colour), means): loss = sum|sigma - gt_sigma| / n_total + sum|color - gt_color| / (3 n_total); n_total >= n is the
+ * size of the whole chunk when the call sees one rank's shard of it; sigma / color (and the gradients) hold n_rows >= n rows,
+ * rows [n, n_rows) being padding of the prediction (no term, zero gradient; the targets hold n rows).  grad_loss != NULL (a device float, the loss scale):
+ * grad_sigma [n] and grad_color [n,3] = sign(.) * *grad_loss / n_total resp. / (3 n_total) are written by the same launch.
+ * workspace: s3d_l1_pair_workspace_size() bytes, zero-filled ONCE by the caller (the kernel leaves its ticket word zero);
+ * the value is summed in a fixed order (reproducible). */
+size_t s3d_l1_pair_workspace_size(void);
+int s3d_l1_pair_loss(const float* sigma, const float* color, const float* gt_sigma, const float* gt_color, uint32_t n,
+                     uint32_t n_rows, uint32_t n_total, float* loss, const float* grad_loss, float* grad_sigma, float* grad_color,
+                     void* workspace, s3d_stream_t stream);
 
 /* ------------------------------------------------------------------ Seal proxy mapper (bbox tool)
  * SealNeRF/seal_utils.py:132-153 (map_mask), :237-279 (map_to_origin), :630-685 (two-ray Moller-Trumbore inside test)
@@ -388,6 +407,10 @@ typedef struct s3d_adam_tensor {
     float lr, beta1, beta2, eps;
     int grad_dtype; /* S3D_F32 or S3D_F16 */
     int consume;    /* != 0: this tensor's gradient is cleared behind the read (as consume_grads, per tensor) */
+    /* pack_stride != 0: `grad` and `param_half` are views into a PACKED weight buffer — element (r, c) of the [n / pack_cols,
+     * pack_cols] parameter lives at r * pack_stride + c (the nn.Linear weights of nerf/network.py inside the fused MLP
+     * kernels' padded [out, in] layout); param / exp_avg / exp_avg_sq stay contiguous.  0: contiguous (the reference case). */
+    uint32_t pack_cols, pack_stride;
 } s3d_adam_tensor;
 int s3d_adam_step_multi(const s3d_adam_tensor* tensors /* host array */, int32_t n_tensors, const float* step,
                         const float* grad_scale, const float* found_inf, int consume_grads, s3d_stream_t stream);

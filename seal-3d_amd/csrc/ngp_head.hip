@@ -156,8 +156,10 @@ __global__ void __launch_bounds__(256) k_ngp_rgb_backward(const float* __restric
 __global__ void __launch_bounds__(1024) k_bg_mse_forward(const float* __restrict__ image, const float* __restrict__ ws,
                                                          const float* __restrict__ gt, float bg0, float bg1, float bg2, uint32_t N,
                                                          float* __restrict__ loss, const float* __restrict__ grad_loss,
-                                                         float* __restrict__ grad_image, float* __restrict__ grad_ws) {
-    __shared__ float part[16];
+                                                         float* __restrict__ grad_image, float* __restrict__ grad_ws,
+                                                         const float* __restrict__ depth, const float* __restrict__ gt_depth,
+                                                         float depth_weight) {
+    __shared__ float part[16], dpart[16];
     const float bg[3] = {bg0, bg1, bg2};
     // grad_loss given: the gradient the backward kernel would write for that upstream gradient is written here as well
     // (same formula, same order: bit-identical) — under loss scaling the upstream gradient of the loss is known in advance
@@ -178,14 +180,104 @@ __global__ void __launch_bounds__(1024) k_bg_mse_forward(const float* __restrict
         }
         if (grad_loss) grad_ws[n] = gw;
     }
+    // Seal's depth term (nerf/utils.py:486-489: `loss += L1Loss(nan_to_num(depth), gt_depth)`): a VALUE only — the reference's
+    // composite backward does not propagate the depth gradient (raymarching.py:274 "grad_depth is not used now")
+    float dacc = 0.0f;
+    if (depth) {
+        for (uint32_t n = threadIdx.x; n < N; n += 1024) {
+            float dv = depth[n];
+            dv = dv != dv ? 0.0f : fminf(fmaxf(dv, -3.402823466e38f), 3.402823466e38f);  // torch.nan_to_num(nan=0.)
+            dacc += fabsf(dv - gt_depth[n]);
+        }
+    }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    for (int d = 32; d >= 1; d >>= 1) { acc += __shfl_xor(acc, d, 64); dacc += __shfl_xor(dacc, d, 64); }
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = acc; dpart[threadIdx.x >> 6] = dacc; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float t = 0.0f;
-        for (int w = 0; w < 16; w++) t += part[w];
-        *loss = t / (3.0f * (float)N);
+        float t = 0.0f, td = 0.0f;
+        for (int w = 0; w < 16; w++) { t += part[w]; td += dpart[w]; }
+        t = t / (3.0f * (float)N);
+        if (depth) t = t + depth_weight * (td / (float)N);
+        *loss = t;
+    }
+}
+
+// Targets of a teacher-rendered ray batch (SealNeRF/trainer.py:506-586): rgb = nan_to_num(image + (1 - weights_sum) * bg),
+// depth = nan_to_num(depth) — nerf/renderer.py:316 + the two nan_to_num(nan=0.) of proxy_truth — written straight into the
+// caller's (static) target buffers: one launch for a rsub, a mul, an add, two nan_to_num and two copies.
+__device__ __forceinline__ float nan_to_num0(float v) { return v != v ? 0.0f : fminf(fmaxf(v, -3.402823466e38f), 3.402823466e38f); }
+__global__ void __launch_bounds__(256) k_bg_targets(const float* __restrict__ image, const float* __restrict__ ws,
+                                                    const float* __restrict__ depth, float bg0, float bg1, float bg2, uint32_t N,
+                                                    float* __restrict__ out_rgb, float* __restrict__ out_depth) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float bg[3] = {bg0, bg1, bg2};
+    const float w = 1.0f - ws[n];
+#pragma unroll
+    for (int c = 0; c < 3; c++) out_rgb[(size_t)n * 3 + c] = nan_to_num0(image[(size_t)n * 3 + c] + w * bg[c]);
+    if (out_depth) out_depth[n] = nan_to_num0(depth[n]);
+}
+
+// Local-pretraining loss of Seal-3D on one point chunk (SealNeRF/trainer.py:455-469): L1Loss(sigma) + L1Loss(colour), both
+// means, with the shard normalisation of parallel/dist.py (`n_total` = points of the whole chunk):
+//   loss = sum |sigma - gt_sigma| / n_total + sum |color - gt_color| / (3 n_total)
+// and, for a known upstream gradient (the loss scale), the gradients sign(.) * g / n_total resp. / (3 n_total) in the same
+// launch.  Partial sums per workgroup in a fixed order, the last workgroup to arrive (ticket) adds them up in index order:
+// the value does not depend on the arrival order.  `partial` = gridDim.x + 1 floats, `ticket` one zeroed word the kernel
+// leaves zeroed.
+constexpr uint32_t kL1Blocks = 256;
+__global__ void __launch_bounds__(256) k_l1_pair(const float* __restrict__ sigma, const float* __restrict__ color,
+                                                 const float* __restrict__ gt_sigma, const float* __restrict__ gt_color, uint32_t n,
+                                                 uint32_t n_rows, float inv_total, float* __restrict__ loss, const float* __restrict__ grad_loss,
+                                                 float* __restrict__ g_sigma, float* __restrict__ g_color, float* __restrict__ partial,
+                                                 uint32_t* __restrict__ ticket) {
+    __shared__ float part[4];
+    __shared__ uint32_t is_last;
+    const float gs = grad_loss ? *grad_loss * inv_total : 0.0f, gc = gs * (1.0f / 3.0f);
+    float a = 0.0f, b = 0.0f;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_rows; i += gridDim.x * 256) {
+        if (i >= n) {  // padding rows of the prediction (whole 128-row tiles of the fused network path): no term, zero gradient
+            if (grad_loss) {
+                g_sigma[i] = 0.0f;
+                g_color[(size_t)i * 3] = 0.0f; g_color[(size_t)i * 3 + 1] = 0.0f; g_color[(size_t)i * 3 + 2] = 0.0f;
+            }
+            continue;
+        }
+        const float ds = sigma[i] - gt_sigma[i];
+        a += fabsf(ds);
+        if (grad_loss) g_sigma[i] = ds > 0.0f ? gs : (ds < 0.0f ? -gs : 0.0f);  // torch: sign(0) = 0
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float dc = color[(size_t)i * 3 + c] - gt_color[(size_t)i * 3 + c];
+            b += fabsf(dc);
+            if (grad_loss) g_color[(size_t)i * 3 + c] = dc > 0.0f ? gc : (dc < 0.0f ? -gc : 0.0f);
+        }
+    }
+    float t = a * inv_total + b * (inv_total * (1.0f / 3.0f));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        is_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    float s = 0.0f;
+    for (uint32_t k = threadIdx.x; k < gridDim.x; k += 256) s += __hip_atomic_load(partial + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *loss = (part[0] + part[1]) + (part[2] + part[3]);
+        *ticket = 0u;
     }
 }
 
@@ -215,12 +307,38 @@ using namespace s3d;
 
 S3D_EXPORT int s3d_bg_mse_forward(const float* image, const float* weights_sum, const float* gt, const float* bg_rgb, uint32_t N,
                                   float* loss, const float* grad_loss, float* grad_image, float* grad_weights_sum,
-                                  s3d_stream_t stream) {
+                                  const float* depth, const float* gt_depth, float depth_weight, s3d_stream_t stream) {
     S3D_REQUIRE(image && weights_sum && gt && bg_rgb && loss && N > 0, "bg_mse_forward: null pointer / empty batch");
     S3D_REQUIRE(!grad_loss || (grad_image && grad_weights_sum), "bg_mse_forward: grad_loss needs grad_image and grad_weights_sum");
+    S3D_REQUIRE(!depth == !gt_depth, "bg_mse_forward: depth and gt_depth come together");
     hipLaunchKernelGGL(k_bg_mse_forward, dim3(1), dim3(1024), 0, as_stream(stream), image, weights_sum, gt, bg_rgb[0], bg_rgb[1],
-                       bg_rgb[2], N, loss, grad_loss, grad_image, grad_weights_sum);
+                       bg_rgb[2], N, loss, grad_loss, grad_image, grad_weights_sum, depth, gt_depth, depth_weight);
     return check_launch("bg_mse_forward");
+}
+
+S3D_EXPORT int s3d_bg_targets(const float* image, const float* weights_sum, const float* depth, const float* bg_rgb, uint32_t N,
+                              float* out_rgb, float* out_depth, s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(image && weights_sum && bg_rgb && out_rgb && (!out_depth || depth), "bg_targets: null pointer");
+    hipLaunchKernelGGL(k_bg_targets, dim3(div_up<uint32_t>(N, 256)), dim3(256), 0, as_stream(stream), image, weights_sum, depth,
+                       bg_rgb[0], bg_rgb[1], bg_rgb[2], N, out_rgb, out_depth);
+    return check_launch("bg_targets");
+}
+
+S3D_EXPORT size_t s3d_l1_pair_workspace_size(void) { return (size_t)(kL1Blocks + 2) * sizeof(float); }
+
+S3D_EXPORT int s3d_l1_pair_loss(const float* sigma, const float* color, const float* gt_sigma, const float* gt_color, uint32_t n,
+                                uint32_t n_rows, uint32_t n_total, float* loss, const float* grad_loss, float* grad_sigma, float* grad_color,
+                                void* workspace, s3d_stream_t stream) {
+    S3D_REQUIRE(sigma && color && gt_sigma && gt_color && loss && workspace && n > 0 && n_total >= n && n_rows >= n,
+                "l1_pair_loss: null pointer / empty batch / n_total < n / n_rows < n");
+    S3D_REQUIRE(!grad_loss || (grad_sigma && grad_color), "l1_pair_loss: grad_loss needs grad_sigma and grad_color");
+    const uint32_t blocks = std::min<uint32_t>(kL1Blocks, div_up<uint32_t>(n_rows, 256));
+    float* partial = (float*)workspace;
+    uint32_t* ticket = (uint32_t*)(partial + kL1Blocks);  // zeroed once by the caller, left zeroed by every call
+    hipLaunchKernelGGL(k_l1_pair, dim3(blocks), dim3(256), 0, as_stream(stream), sigma, color, gt_sigma, gt_color, n,
+                       n_rows, 1.0f / (float)n_total, loss, grad_loss, grad_sigma, grad_color, partial, ticket);
+    return check_launch("l1_pair_loss");
 }
 
 S3D_EXPORT int s3d_bg_mse_backward(const float* image, const float* weights_sum, const float* gt, const float* bg_rgb, uint32_t N,

@@ -111,6 +111,25 @@ __device__ __forceinline__ void adam_range(const AdamCoef& c, float* __restrict_
     }
 }
 
+// A parameter whose fp16 gradient and fp16 copy live inside a PACKED weight buffer (the nn.Linear weights of the two-encoder
+// Seal network inside the fused MLP kernels' [out, in_padded] layout): element i = (row, col) of the [rows, cols] parameter
+// sits at row * stride + col of `g` and `p_half`; the fp32 state stays contiguous.  ~10 K elements per tensor: scalar accesses.
+template <typename G>
+__device__ __forceinline__ void adam_range_packed(const AdamCoef& c, float* __restrict__ p, G* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, __half* __restrict__ p_half, size_t n, uint32_t cols,
+                                                  uint32_t stride, size_t tid, size_t nthreads, bool consume) {
+    for (size_t i = tid; i < n; i += nthreads) {
+        const size_t j = (i / cols) * stride + i % cols;
+        float mi = m[i], vi = v[i], pi = p[i];
+        adam_update(c, grad_to_f<G>(g[j]), mi, vi, pi);
+        if (consume) g[j] = G(0.0f);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi;
+        if (p_half) p_half[j] = __float2half(pi);
+    }
+}
+
 // Four consecutive elements per lane and trip (16-byte accesses of the fp32 state, 8-byte of the fp16 gradient / copy): the
 // update streams 28 B per element and is HBM-bound; `vec` is false for a tensor whose pointers are not 16-byte aligned.
 template <typename G>
@@ -143,6 +162,7 @@ struct AdamBatch {
     size_t n[kAdamMaxTensors];
     float lr[kAdamMaxTensors], beta1[kAdamMaxTensors], beta2[kAdamMaxTensors], eps[kAdamMaxTensors];
     uint32_t first_block[kAdamMaxTensors + 1];
+    uint32_t cols[kAdamMaxTensors], stride[kAdamMaxTensors];  // stride != 0: packed layout of g / h (adam_range_packed)
     uint8_t half_grad[kAdamMaxTensors], vec[kAdamMaxTensors], consume[kAdamMaxTensors];
     int32_t count;
 };
@@ -155,7 +175,13 @@ __global__ void __launch_bounds__(256) k_adam_step_multi(AdamBatch b, const floa
     const size_t tid = (size_t)(blockIdx.x - b.first_block[i]) * 256 + threadIdx.x;
     const size_t nthreads = (size_t)(b.first_block[i + 1] - b.first_block[i]) * 256;
     if (found_inf && *found_inf != 0.0f) {  // skipped step: nothing is updated
-        if (b.consume[i]) {
+        if (b.consume[i] && b.stride[i]) {
+            for (size_t k = tid; k < b.n[i]; k += nthreads) {
+                const size_t j = (k / b.cols[i]) * b.stride[i] + k % b.cols[i];
+                if (b.half_grad[i]) ((__half*)b.g[i])[j] = __half(0.0f);
+                else ((float*)b.g[i])[j] = 0.0f;
+            }
+        } else if (b.consume[i]) {
             if (b.half_grad[i]) clear_range<__half>((__half*)b.g[i], b.n[i], b.vec[i] != 0, tid, nthreads);
             else clear_range<float>((float*)b.g[i], b.n[i], b.vec[i] != 0, tid, nthreads);
         }
@@ -168,7 +194,12 @@ __global__ void __launch_bounds__(256) k_adam_step_multi(AdamBatch b, const floa
     const float bc1 = 1.0f - powf(c.beta1, t), bc2 = 1.0f - powf(c.beta2, t);
     c.step_size = b.lr[i] / bc1;
     c.bc2_sqrt = sqrtf(bc2);
-    if (b.half_grad[i])
+    if (b.stride[i]) {
+        if (b.half_grad[i])
+            adam_range_packed<__half>(c, b.p[i], (__half*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.cols[i], b.stride[i], tid, nthreads, b.consume[i] != 0);
+        else
+            adam_range_packed<float>(c, b.p[i], (float*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.cols[i], b.stride[i], tid, nthreads, b.consume[i] != 0);
+    } else if (b.half_grad[i])
         adam_range<__half>(c, b.p[i], (__half*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.vec[i] != 0, tid, nthreads, b.consume[i] != 0);
     else
         adam_range<float>(c, b.p[i], (float*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.vec[i] != 0, tid, nthreads, b.consume[i] != 0);
@@ -286,6 +317,10 @@ S3D_EXPORT int s3d_adam_step_multi(const s3d_adam_tensor* tensors, int32_t n_ten
             b.n[i] = t.n; b.lr[i] = t.lr; b.beta1[i] = t.beta1; b.beta2[i] = t.beta2; b.eps[i] = t.eps;
             b.half_grad[i] = t.grad_dtype == S3D_F16;
             b.consume[i] = (consume_grads || t.consume) ? 1 : 0;
+            S3D_REQUIRE((t.pack_stride == 0) || (t.pack_cols > 0 && t.pack_cols <= t.pack_stride && t.n % t.pack_cols == 0),
+                        "adam_step_multi: tensor %d: packed layout needs 0 < pack_cols <= pack_stride and whole rows", k);
+            b.cols[i] = t.pack_stride ? t.pack_cols : 1u;
+            b.stride[i] = t.pack_stride;
             const uintptr_t bits = (uintptr_t)t.param | (uintptr_t)t.exp_avg | (uintptr_t)t.exp_avg_sq |
                                    ((uintptr_t)t.grad << (t.grad_dtype == S3D_F16 ? 1 : 0)) | ((uintptr_t)t.param_half << 1);
             b.vec[i] = (bits & 15) == 0;

@@ -128,7 +128,8 @@ class _FFMLPForward(Function):
         if rgb is not None:
             extra["grad_rgb"], extra["rgb_head"], grad = grad, rgb, None
         if stash is not None:
-            extra["accumulate"] = True
+            # (a packed nn.Linear pack, nerf/network.py: PackedWeights, is OVERWRITTEN: one backward per step writes it)
+            extra["accumulate"] = not getattr(ctx.param_ref.param, "_s3d_overwrite", False)
             found_inf = getattr(ctx.param_ref.param, "_s3d_found_inf", None)  # GradScaler's check made by the writing kernel
             if found_inf is not None:
                 extra["found_inf"] = found_inf

@@ -32,6 +32,10 @@ def bump_weights_epoch():
     _weights_epoch += 1
 
 
+def _weights_epoch_now():
+    return _weights_epoch
+
+
 def _on_optimizer_step(optimizer, args, kwargs):
     bump_weights_epoch()
 

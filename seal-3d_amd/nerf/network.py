@@ -10,7 +10,7 @@ from torch.autograd import Function
 import s3d_hip
 from activation import trunc_exp
 from encoding import get_encoder
-from ffmlp.ffmlp import ffmlp_forward
+from ffmlp.ffmlp import _ParamRef, ffmlp_forward
 
 from .network_ff import _NgpRgb
 from .renderer import NeRFRenderer
@@ -48,6 +48,110 @@ class _SealMid(Function):
         return g_h, None, g_enc, None
 
 
+class PackedWeights:
+    """The nn.Linear weights of one MLP inside the fused MLP kernels' flat fp16 layout ([out, in_padded] per layer, csrc/ffmlp.hip).
+
+    The parameters stay what they are in the reference — names, shapes, fp32 values, optimizer state (checkpoint keys) — and this
+    object holds their fp16 image `half` [numel]: member (parameter, offset, row stride) sits at rows `offset + r * stride`,
+    constant blocks (an identity layer, zero padding) in between.  Two ways to keep it current:
+      * adopted by nerf.optim.NativeAdam: the MLP backward writes the packed fp16 weight gradient into the pack's twin inside
+        the optimizer's flat gradient buffer (`_s3d_grad`, overwritten each call), and the Adam launch reads it through a
+        row-strided view per member and writes the updated fp16 weights into `half` through the same view — the step never
+        assembles (cat / pad / cast) or splits anything;
+      * otherwise (teacher, evaluation, frozen MLPs): `refreshed()` re-copies the members when one of them has changed (tensor
+        version or optimizer epoch), i.e. once per weight update instead of once per call."""
+
+    _s3d_overwrite = True  # the MLP backward REPLACES the gradient twin (constant blocks would pile up under accumulation)
+
+    def __init__(self, members, numel, constants=()):
+        self.members, self.numel, self.constants = list(members), int(numel), list(constants)
+        self.half = None
+        self.adopted = False
+        self._s3d_grad = None
+        self._key = None
+        self.hook = torch.zeros((), requires_grad=True)  # keeps the autograd node alive when only the pack needs a gradient
+        for p, off, stride in self.members:
+            p._s3d_pack_spec = (self, off, stride)
+
+    @staticmethod
+    def usable_on(device):
+        return device.type == "cuda"
+
+    def _view(self, buf, p, off, stride):
+        rows, cols = p.shape
+        return buf[off:off + (rows - 1) * stride + cols].as_strided((rows, cols), (stride, 1))
+
+    def _ensure(self, dev):
+        if self.half is None or self.half.device != dev:
+            self.half = torch.zeros(self.numel, dtype=torch.float16, device=dev)
+            for off, block in self.constants:
+                self.half[off:off + block.numel()].copy_(block.reshape(-1))
+            self._key = None
+
+    def adopt(self, grad_region, flat, flat_range):
+        """nerf.optim.NativeAdam: `grad_region` = this pack's [numel] slice of the optimizer's flat fp16 gradient buffer"""
+        self._ensure(grad_region.device)
+        self._s3d_grad = grad_region
+        for p, off, stride in self.members:
+            rows, cols = p.shape
+            p._s3d_grad = self._view(grad_region, p, off, stride)
+            p._s3d_half = self._view(self.half, p, off, stride)
+            p._s3d_half.copy_(p.detach())
+            p._s3d_half_version = p._version
+            p._s3d_grad_flat = flat
+            p._s3d_flat_range = (flat_range[0] + off, flat_range[0] + off + (rows - 1) * stride + cols)
+            p._s3d_grad_touched = False
+            p._s3d_grad_consumed = False
+        self.adopted = True
+
+    # what the MLP backward reads / sets on the object it is handed as `param_ref.param` (ffmlp/ffmlp.py)
+    @property
+    def _s3d_found_inf(self):
+        return getattr(self.members[0][0], "_s3d_found_inf", None)
+
+    @property
+    def _s3d_grad_touched(self):
+        return any(getattr(p, "_s3d_grad_touched", False) for p, _, _ in self.members)
+
+    @_s3d_grad_touched.setter
+    def _s3d_grad_touched(self, v):
+        for p, _, _ in self.members:
+            if p.requires_grad or not v:
+                p._s3d_grad_touched = v
+
+    def trainable(self):
+        return any(p.requires_grad for p, _, _ in self.members)
+
+    def current(self):
+        """the pack as maintained by the optimizer, or None when a member was written from outside since (or never adopted)"""
+        if not self.adopted or self.half is None or self.half.device != self.members[0][0].device:
+            return None
+        if any(getattr(p, "_s3d_half_version", None) != p._version for p, _, _ in self.members):
+            return None
+        return self.half
+
+    @torch.no_grad()
+    def refreshed(self):
+        """the pack re-copied from the parameters when one of them has changed (no-grad / frozen use)"""
+        from gridencoder.grid import _weights_epoch_now
+        dev = self.members[0][0].device
+        self._ensure(dev)
+        cur = self.current()
+        if cur is not None:
+            return cur
+        key = tuple((p.data_ptr(), p._version) for p, _, _ in self.members) + (_weights_epoch_now(),)
+        if key != self._key and not torch.cuda.is_current_stream_capturing():
+            for p, off, stride in self.members:
+                self._view(self.half, p, off, stride).copy_(p.detach())
+            self._key = key
+        elif key != self._key:  # (inside a capture a cached copy cannot be trusted and must not be cached)
+            tmp = self.half.clone()
+            for p, off, stride in self.members:
+                self._view(tmp, p, off, stride).copy_(p.detach())
+            return tmp
+        return self.half
+
+
 def _mlp(dims):
     return nn.ModuleList([nn.Linear(i, o, bias=False) for i, o in zip(dims[:-1], dims[1:])])
 
@@ -78,6 +182,14 @@ class NeRFNetwork(NeRFRenderer):
         if self.bg_radius > 0:
             raise NotImplementedError("background model (bg_radius > 0) is outside the BASELINE configs")
         self.register_buffer("_eye_hidden", torch.eye(hidden_dim), persistent=False)  # (not a checkpoint key)
+        self._packs = None
+        if (num_layers == 2 and hidden_dim == 64 and geo_feat_dim == 15 and self.in_dim == 32 and num_layers_color == 3
+                and hidden_dim_color == 64 and self.in_dim_color == 32 and self.in_dim_dir == 16):
+            s0, s1 = self.sigma_net[0].weight, self.sigma_net[1].weight
+            c0, c1, c2 = (l.weight for l in self.color_net)
+            # sigma pack [W0 64x32 | I 64x64 | W1 16x64]; colour pack [W0 64x63 in 64-wide rows | W1 64x64 | W2 3x64 in 16 rows]
+            self._packs = (PackedWeights([(s0, 0, 32), (s1, 6144, 64)], 7168, [(2048, torch.eye(64))]),
+                           PackedWeights([(c0, 0, 64), (c1, 4096, 64), (c2, 8192, 64)], 9216))
 
     # ---- MI355X path under `-O` (fp16 autocast): both MLPs run as fused MFMA kernels (csrc/ffmlp.hip) on weights PACKED
     # from the nn.Linear parameters — the parameters, their names and shapes (checkpoint keys) are the reference's.
@@ -109,21 +221,44 @@ class NeRFNetwork(NeRFRenderer):
         wc = torch.cat([F.pad(c0, (0, 1)).reshape(-1), c1.reshape(-1), F.pad(c2, (0, 0, 0, 13)).reshape(-1)])
         return ws, wc
 
+    def _weights_for_kernels(self):
+        """(sigma pack, colour pack, sigma ref, colour ref): the fp16 packed weights the MFMA kernels read, and — when the
+        optimizer maintains them (PackedWeights.adopt) — the objects that receive their packed gradient"""
+        packs = self._packs
+        if packs is None:
+            return self._packed_weights() + (None, None)
+        grads = torch.is_grad_enabled()
+        out, refs = [], []
+        for pk in packs:
+            need = grads and pk.trainable()
+            cur = pk.current()
+            if cur is not None:
+                out.append(cur)
+                refs.append(pk if need else None)
+            elif not need:
+                out.append(pk.refreshed())
+                refs.append(None)
+            else:
+                return self._packed_weights() + (None, None)  # (torch optimizer: the differentiable cat / pad assembly)
+        return out[0], out[1], refs[0], refs[1]
+
     def _forward_fused(self, x, d, want_rgb=True):
         nv = s3d_hip.active_row_limit(x.shape[0])  # (training: the march's sample count; inference: alive rays x n_step)
         live = None if (self.training or torch.is_grad_enabled()) else s3d_hip.active_live_rows(x.shape[0])
-        ws, wc = self._packed_weights()
+        ws, wc, rs, rc = self._weights_for_kernels()
+        rs, hs = (None, None) if rs is None else (_ParamRef(rs), rs.hook)
+        rc, hc = (None, None) if rc is None else (_ParamRef(rc), rc.hook)
         infer = not self.training
         e0 = self.encoder(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
-        h = ffmlp_forward(e0, ws, 32, 16, 64, 2, 0, 6, infer, e0.requires_grad, None, None, 1, nv)
+        h = ffmlp_forward(e0, ws, 32, 16, 64, 2, 0, 6, infer, e0.requires_grad, rs, hs, 1, nv)
         if not want_rgb:
             return h
         e1 = self.encoder_color(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
         sigma, cin = _SealMid.apply(h.contiguous(), d.float().contiguous(), e1.contiguous(), nv)
         if cin.shape[0] % 128 == 0 and (infer or s3d_hip.FFMLPBackend.fused_backward_supported(64, 16, 64, 2, 0)):
             # colour head inside the MLP kernels (seal3d_hip.h: rgb_head): fp32 sigmoid(out[:, :3]) straight from the last layer
-            return sigma, ffmlp_forward(cin, wc, 64, 16, 64, 2, 0, 6, infer, cin.requires_grad, None, None, 0, nv, True)
-        out = ffmlp_forward(cin, wc, 64, 16, 64, 2, 0, 6, infer, cin.requires_grad, None, None, 0, nv)
+            return sigma, ffmlp_forward(cin, wc, 64, 16, 64, 2, 0, 6, infer, cin.requires_grad, rc, hc, 0, nv, True)
+        out = ffmlp_forward(cin, wc, 64, 16, 64, 2, 0, 6, infer, cin.requires_grad, rc, hc, 0, nv)
         return sigma, _NgpRgb.apply(out.contiguous(), nv)
 
     def _sigma(self, x):

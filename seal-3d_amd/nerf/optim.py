@@ -35,7 +35,7 @@ class NativeAdam(torch.optim.Optimizer):
         # the update launch clears every handed-over gradient behind its read: the next zero_grad() has nothing to fill
         self.consume_grads = consume_grads
         self.flat_half = None  # ONE fp16 buffer behind every handed-over gradient: one clear, one check, one all-reduce
-        adopted = []
+        adopted, packs = [], []
         for group in self.param_groups:
             for p in group["params"]:
                 if not p.is_cuda or p.dtype != torch.float32:
@@ -47,9 +47,19 @@ class NativeAdam(torch.optim.Optimizer):
                     self.step_count = torch.zeros(1, dtype=torch.float32, device=p.device)
                 if adopt_half_grads and getattr(p, "_s3d_stash_ok", False):
                     adopted.append(p)
-        if adopted:
+                pk = getattr(p, "_s3d_pack_spec", None) if adopt_half_grads else None
+                if pk is not None and pk[0].usable_on(p.device) and not any(pk[0] is q for q in packs):
+                    packs.append(pk[0])
+        # PackedWeights (nerf/network.py): nn.Linear weights that the fused MLP kernels read from ONE padded fp16 buffer per
+        # network.  The optimizer takes their gradient where the MLP backward writes it (the pack's fp16 gradient twin, a region
+        # of the flat buffer) and writes the updated fp16 weights straight into the pack — no cat / pad / cast per step, no
+        # split of the fp16 weight gradient back into five fp32 `.grad`s.
+        packs = [pk for pk in packs if all(id(m) in {id(q) for g in self.param_groups for q in g["params"]} for m, _, _ in pk.members)]
+        if adopted or packs:
             sizes = [(p.numel() + 7) // 8 * 8 for p in adopted]  # 16-byte aligned views
-            self.flat_half = torch.zeros(sum(sizes), dtype=torch.float16, device=adopted[0].device)
+            psizes = [(pk.numel + 7) // 8 * 8 for pk in packs]
+            dev = (adopted[0] if adopted else packs[0].members[0][0]).device
+            self.flat_half = torch.zeros(sum(sizes) + sum(psizes), dtype=torch.float16, device=dev)
             off = 0
             self.flat_half._s3d_param_cuts = []  # parameter boundaries (elements): where a chunked all-reduce may cut
             for p, n in zip(adopted, sizes):
@@ -62,6 +72,11 @@ class NativeAdam(torch.optim.Optimizer):
                 p._s3d_half = p.detach().to(torch.float16)
                 p._s3d_half_version = p._version
                 off += n
+            for pk, n in zip(packs, psizes):
+                self.flat_half._s3d_param_cuts.append(off)
+                pk.adopt(self.flat_half[off:off + pk.numel], self.flat_half, (off, off + pk.numel))
+                off += n
+        self.packs = packs
 
     def grads(self):
         """(param, gradient tensor) for every parameter that has one: the fp16 hand-over buffer or `.grad`"""
@@ -150,7 +165,7 @@ class NativeAdam(torch.optim.Optimizer):
         batch never reached that table: all ranks must take the same update"""
         for group in self.param_groups:
             for p in group["params"]:
-                if getattr(p, "_s3d_grad", None) is not None:
+                if getattr(p, "_s3d_grad", None) is not None and p.requires_grad:  # (frozen MLPs of Seal's pretraining stay put)
                     p._s3d_grad_touched = True
 
     @torch.no_grad()
@@ -167,9 +182,20 @@ class NativeAdam(torch.optim.Optimizer):
             if half is not None and p._s3d_half_version != p._version:
                 half = None  # somebody wrote the parameter through torch: the fp16 copy is re-made below
             b1, b2 = group["betas"]
+            packed = getattr(p, "_s3d_pack_spec", None) is not None and g is getattr(p, "_s3d_grad", None)
+            if half is not None and not packed and not half.is_contiguous():
+                half = None  # a pack member updated from a plain `.grad` (nn.Linear route): its strided fp16 image is re-copied below
             item = (p.data, g, st["exp_avg"], st["exp_avg_sq"], half, group["lr"], b1, b2, group["eps"])
-            if before_param is not None:
+            if before_param is not None and packed:
+                # (row-strided views of the pack: the multi-tensor entry point knows the layout.  The MLP backward OVERWRITES
+                #  the pack's gradient twin, so nothing is cleared behind the read)
+                _backend.adam_step_multi([item + (False,)], self.step_count, grad_scale, found_inf)
+                p._s3d_grad_consumed = True
+            elif before_param is not None:
                 _backend.adam_step(*item, self.step_count, grad_scale, found_inf)
+            elif packed:
+                batch.append(item + (False,))
+                consumed.append(p)  # (nothing to clear: the next backward overwrites the pack's gradient twin)
             else:
                 # (a hand-over buffer is cleared behind the read; a `.grad` stays readable after the step)
                 mine = self.consume_grads and g is getattr(p, "_s3d_grad", None)
@@ -183,7 +209,7 @@ class NativeAdam(torch.optim.Optimizer):
             for p in consumed:
                 p._s3d_grad_consumed = True
         for p in stale:
-            p._s3d_half.copy_(p.detach())
+            p._s3d_half.copy_(p.detach())  # (a strided view into the pack for packed parameters)
             p._s3d_half_version = p._version
         if advance:
             _backend.adam_advance(self.step_count, found_inf)

@@ -16,22 +16,28 @@ def psnr(pred, target):
 
 class _BgMse(torch.autograd.Function):
     """loss = mean((image + (1 - weights_sum) * bg - gt)^2): background compositing (nerf/renderer.py:316) and the MSE
-    criterion (nerf/utils.py:484) in one kernel per direction (csrc/ngp_head.hip) instead of ~14 tiny launches."""
+    criterion (nerf/utils.py:484) in one kernel per direction (csrc/ngp_head.hip) instead of ~14 tiny launches.  With
+    `depth` / `gt_depth`: + depth_weight * L1Loss(nan_to_num(depth), gt_depth), Seal-3D's depth term (nerf/utils.py:486-489)
+    — a value only: the reference's composite backward drops the depth gradient (raymarching.py:274)."""
 
     @staticmethod
-    def forward(ctx, image, weights_sum, gt, bg, expected_grad=None):
+    def forward(ctx, image, weights_sum, gt, bg, expected_grad=None, depth=None, gt_depth=None, depth_weight=1.0):
         """`expected_grad`: the (device scalar) upstream gradient the loss WILL receive — the loss scale under GradScaler; the
         forward launch then writes the backward's result as well and backward() launches nothing when it is handed that tensor"""
         import s3d_hip
         image, weights_sum, gt = image.float().contiguous(), weights_sum.float().contiguous(), gt.float().contiguous()
         loss = torch.empty((), dtype=torch.float32, device=image.device)
         ctx.pre = None
+        extra = {}
+        if depth is not None:
+            extra = dict(depth=depth.detach().float().contiguous().reshape(-1), gt_depth=gt_depth.float().contiguous().reshape(-1),
+                         depth_weight=float(depth_weight))
         if expected_grad is not None and expected_grad.dtype == torch.float32 and expected_grad.numel() == 1:
             g_image, g_ws = torch.empty_like(image), torch.empty_like(weights_sum)
-            s3d_hip.NgpHeadBackend.bg_mse_forward(image, weights_sum, gt, bg, loss, expected_grad, g_image, g_ws)
+            s3d_hip.NgpHeadBackend.bg_mse_forward(image, weights_sum, gt, bg, loss, expected_grad, g_image, g_ws, **extra)
             ctx.pre = (g_image, g_ws, expected_grad.data_ptr(), expected_grad._version)
         else:
-            s3d_hip.NgpHeadBackend.bg_mse_forward(image, weights_sum, gt, bg, loss)
+            s3d_hip.NgpHeadBackend.bg_mse_forward(image, weights_sum, gt, bg, loss, **extra)
         ctx.save_for_backward(image, weights_sum, gt)
         ctx.bg = bg
         return loss
@@ -40,21 +46,27 @@ class _BgMse(torch.autograd.Function):
     def backward(ctx, g):
         import s3d_hip
         if ctx.pre is not None and g.dtype == torch.float32 and g.data_ptr() == ctx.pre[2] and g._version == ctx.pre[3]:
-            return ctx.pre[0], ctx.pre[1], None, None, None  # (the announced upstream gradient: already computed)
+            return (ctx.pre[0], ctx.pre[1]) + (None,) * 6  # (the announced upstream gradient: already computed)
         image, weights_sum, gt = ctx.saved_tensors
         g_image, g_ws = torch.empty_like(image), torch.empty_like(weights_sum)
         s3d_hip.NgpHeadBackend.bg_mse_backward(image, weights_sum, gt, ctx.bg, g.float().contiguous(), g_image, g_ws)
-        return g_image, g_ws, None, None, None
+        return (g_image, g_ws) + (None,) * 6
 
 
-def render_loss(out, gt_rgb, expected_grad=None):
-    """MSE between the rendered batch and the targets; uses the fused kernel when the renderer deferred the background
-    (`expected_grad`: see _BgMse.forward)"""
+def render_loss(out, gt_rgb, expected_grad=None, gt_depth=None, depth_weight=1.0):
+    """MSE between the rendered batch and the targets (+ Seal-3D's L1 depth term when `gt_depth` is given); uses the fused
+    kernel when the renderer deferred the background (`expected_grad`: see _BgMse.forward)"""
     if out.get("premultiplied", False):
         bg = out["bg_color"]
         bg = (float(bg),) * 3 if not isinstance(bg, (tuple, list)) else tuple(float(v) for v in bg)
+        if gt_depth is not None:
+            return _BgMse.apply(out["image"].reshape(-1, 3), out["weights_sum"].reshape(-1), gt_rgb.reshape(-1, 3), bg, expected_grad,
+                                out["depth"], gt_depth, depth_weight)
         return _BgMse.apply(out["image"].reshape(-1, 3), out["weights_sum"].reshape(-1), gt_rgb.reshape(-1, 3), bg, expected_grad)
-    return F.mse_loss(out["image"], gt_rgb)
+    loss = F.mse_loss(out["image"], gt_rgb)
+    if gt_depth is not None:
+        loss = loss + depth_weight * F.l1_loss(torch.nan_to_num(out["depth"], nan=0.0).view(gt_depth.shape), gt_depth)
+    return loss
 
 
 class Trainer:
@@ -337,7 +349,10 @@ class GraphedTrainer(Trainer):
         model = self.model
         if not (model.cuda_ray and self.global_step % self.update_extra_interval == 0):
             return False
-        plain = type(model).update_extra_state is NeRFRenderer.update_extra_state
+        # (a model may extend update_extra_state by a pure epilogue — the Seal renderers re-mark the edit region in the
+        #  bitfield, SealNeRF/renderer.py:50-66 — and say so: `after_extra_state`)
+        epilogue = getattr(model, "after_extra_state", None) if getattr(type(model), "extra_state_epilogue_only", False) else None
+        plain = type(model).update_extra_state is NeRFRenderer.update_extra_state or epilogue is not None
         if not (self.graph_extra_state and plain and model.iter_density >= 16) or getattr(model, "dist_shard", None) is not None:
             return super()._maybe_update_extra_state()  # (sharded over the ranks: density queries split + all-gather)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
@@ -352,6 +367,8 @@ class GraphedTrainer(Trainer):
                 self.ues_graph.replay()
                 mean = self.ues_mean
             model.finish_extra_state(mean)
+            if epilogue is not None:
+                epilogue()
         if self.dist is not None:
             self.dist.sync_extra_state(model)
         return True

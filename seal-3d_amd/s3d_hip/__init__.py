@@ -41,7 +41,7 @@ EXPORTS = [
     "s3d_ffmlp_allocate_splitk", "s3d_ffmlp_free_splitk",
     "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_step_multi", "s3d_adam_advance", "s3d_scaler_update", "s3d_step_ring_push", "s3d_step_epilogue",
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_mid2_forward", "s3d_ngp_mid2_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
-    "s3d_bg_mse_forward", "s3d_bg_mse_backward",
+    "s3d_bg_mse_forward", "s3d_bg_mse_backward", "s3d_bg_targets", "s3d_l1_pair_workspace_size", "s3d_l1_pair_loss",
     "s3d_seal_bbox_map", "s3d_vm_features_forward",
     "s3d_vm_backward_max_bins", "s3d_vm_backward_keys", "s3d_vm_features_backward",
 ]
@@ -71,7 +71,7 @@ def lib():
         l.s3d_version.restype = C.c_char_p
         for name in ("s3d_march_rays_train_workspace_size", "s3d_compact_alive_workspace_size",
                      "s3d_ffmlp_backward_workspace_size", "s3d_grid_encode_backward_workspace_size",
-                     "s3d_grid_encode_backward_control_size",
+                     "s3d_grid_encode_backward_control_size", "s3d_l1_pair_workspace_size",
                      "s3d_sweep_update_workspace_size"):
             getattr(l, name).restype = C.c_size_t
         l.s3d_vm_backward_max_bins.restype = C.c_uint32
@@ -616,7 +616,8 @@ class _AdamTensor(C.Structure):
     """seal3d_hip.h: s3d_adam_tensor"""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("param_half", C.c_void_p), ("n", C.c_size_t), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
-                ("eps", C.c_float), ("grad_dtype", C.c_int), ("consume", C.c_int)]
+                ("eps", C.c_float), ("grad_dtype", C.c_int), ("consume", C.c_int), ("pack_cols", C.c_uint32),
+                ("pack_stride", C.c_uint32)]
 
 
 class OptimBackend:
@@ -651,12 +652,23 @@ class OptimBackend:
             param, grad, exp_avg, exp_avg_sq, param_half, lr, beta1, beta2, eps = item[:9]
             a.consume = int(bool(item[9])) if len(item) > 9 else 0
             _need(param, torch.float32, "param"); _need(exp_avg, torch.float32, "exp_avg"); _need(exp_avg_sq, torch.float32, "exp_avg_sq")
-            if grad.numel() != param.numel() or not grad.is_contiguous() or not param.is_contiguous():
-                raise RuntimeError("adam_step_multi: param and grad must be contiguous and of equal size")
-            if param_half is not None:
-                _need(param_half, torch.float16, "param_half")
-            a.param, a.grad, a.exp_avg, a.exp_avg_sq = _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq)
-            a.param_half = _p(param_half)
+            packed = grad.dim() == 2 and not grad.is_contiguous()
+            if packed:
+                # [rows, cols] views into a packed weight buffer (row stride > cols): gradient and fp16 copy share the layout
+                if (tuple(grad.shape) != tuple(param.shape) or grad.stride(1) != 1 or not grad.is_cuda or not param.is_contiguous()
+                        or (param_half is not None and (param_half.stride() != grad.stride() or param_half.dtype != torch.float16
+                                                        or not param_half.is_cuda))):
+                    raise RuntimeError("adam_step_multi: a packed gradient is a [rows, cols] row-strided view; the fp16 copy shares its strides")
+                a.pack_cols, a.pack_stride = int(grad.shape[1]), int(grad.stride(0))
+                a.param, a.grad, a.exp_avg, a.exp_avg_sq = _p(param), C.c_void_p(grad.data_ptr()), _p(exp_avg), _p(exp_avg_sq)
+                a.param_half = C.c_void_p(param_half.data_ptr() if param_half is not None else 0)
+            else:
+                if grad.numel() != param.numel() or not grad.is_contiguous() or not param.is_contiguous():
+                    raise RuntimeError("adam_step_multi: param and grad must be contiguous and of equal size")
+                if param_half is not None:
+                    _need(param_half, torch.float16, "param_half")
+                a.param, a.grad, a.exp_avg, a.exp_avg_sq = _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq)
+                a.param_half = _p(param_half)
             a.n = param.numel()
             a.lr, a.beta1, a.beta2, a.eps = float(lr), float(beta1), float(beta2), float(eps)
             a.grad_dtype = _dt(grad)
@@ -760,15 +772,60 @@ class NgpHeadBackend:
                "ngp_rgb_backward")
 
     @staticmethod
-    def bg_mse_forward(image, weights_sum, gt, bg_rgb, loss, grad_loss=None, grad_image=None, grad_weights_sum=None):
+    def bg_mse_forward(image, weights_sum, gt, bg_rgb, loss, grad_loss=None, grad_image=None, grad_weights_sum=None,
+                       depth=None, gt_depth=None, depth_weight=1.0):
+        """`depth`, `gt_depth` (both or neither): + depth_weight * L1(nan_to_num(depth), gt_depth) in the loss VALUE (seal3d_hip.h)"""
         for t, n in ((image, "image"), (weights_sum, "weights_sum"), (gt, "gt"), (loss, "loss")):
             _need(t, torch.float32, n)
         if grad_loss is not None:
             for t, n in ((grad_loss, "grad_loss"), (grad_image, "grad_image"), (grad_weights_sum, "grad_weights_sum")):
                 _need(t, torch.float32, n)
+        if depth is not None:
+            _need(depth, torch.float32, "depth"); _need(gt_depth, torch.float32, "gt_depth")
+            if depth.numel() != image.shape[0] or gt_depth.numel() != image.shape[0]:
+                raise RuntimeError("bg_mse_forward: depth and gt_depth hold one value per ray")
         bg = (C.c_float * 3)(*[float(v) for v in bg_rgb])
         _check(lib().s3d_bg_mse_forward(_p(image), _p(weights_sum), _p(gt), bg, _u(image.shape[0]), _p(loss), _p(grad_loss),
-                                        _p(grad_image), _p(grad_weights_sum), _stream()), "bg_mse_forward")
+                                        _p(grad_image), _p(grad_weights_sum), _p(depth), _p(gt_depth), _f(depth_weight), _stream()),
+               "bg_mse_forward")
+
+    @staticmethod
+    def bg_targets(image, weights_sum, depth, bg_rgb, out_rgb, out_depth=None):
+        """out_rgb = nan_to_num(image + (1 - weights_sum) * bg), out_depth = nan_to_num(depth): a teacher render's targets"""
+        for t, n in ((image, "image"), (weights_sum, "weights_sum"), (out_rgb, "out_rgb")):
+            _need(t, torch.float32, n)
+        N = image.shape[0]
+        if out_rgb.numel() != 3 * N or weights_sum.numel() != N:
+            raise RuntimeError("bg_targets: image / out_rgb [N,3], weights_sum [N]")
+        if out_depth is not None:
+            _need(depth, torch.float32, "depth"); _need(out_depth, torch.float32, "out_depth")
+            if depth.numel() != N or out_depth.numel() != N:
+                raise RuntimeError("bg_targets: depth / out_depth [N]")
+        bg = (C.c_float * 3)(*[float(v) for v in bg_rgb])
+        _check(lib().s3d_bg_targets(_p(image), _p(weights_sum), _p(depth if out_depth is not None else None), bg, _u(N),
+                                    _p(out_rgb), _p(out_depth), _stream()), "bg_targets")
+
+    _l1_ws = {}
+
+    @staticmethod
+    def l1_pair_loss(sigma, color, gt_sigma, gt_color, n_total, loss, grad_loss=None, grad_sigma=None, grad_color=None):
+        """Seal-3D's pretraining loss L1(sigma) + L1(colour) (+ its gradients for a known upstream gradient), seal3d_hip.h"""
+        for t, n in ((sigma, "sigma"), (color, "color"), (gt_sigma, "gt_sigma"), (gt_color, "gt_color"), (loss, "loss")):
+            _need(t, torch.float32, n)
+        n, n_rows = gt_sigma.numel(), sigma.numel()
+        if color.numel() != 3 * n_rows or n_rows < n or gt_color.numel() != 3 * n:
+            raise RuntimeError("l1_pair_loss: sigma [n_rows] / color [n_rows,3], gt_sigma [n] / gt_color [n,3], n_rows >= n")
+        if grad_loss is not None:
+            for t, nm in ((grad_loss, "grad_loss"), (grad_sigma, "grad_sigma"), (grad_color, "grad_color")):
+                _need(t, torch.float32, nm)
+        key = sigma.device.index
+        ws = NgpHeadBackend._l1_ws.get(key)
+        if ws is None:  # (zeroed once, outside any capture: the kernel leaves its ticket word zero)
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("l1_pair_loss: first call on this device must not be inside a graph capture (workspace)")
+            ws = NgpHeadBackend._l1_ws[key] = torch.zeros(lib().s3d_l1_pair_workspace_size() // 4, dtype=torch.float32, device=sigma.device)
+        _check(lib().s3d_l1_pair_loss(_p(sigma), _p(color), _p(gt_sigma), _p(gt_color), _u(n), _u(n_rows), _u(n_total), _p(loss), _p(grad_loss),
+                                      _p(grad_sigma), _p(grad_color), _p(ws), _stream()), "l1_pair_loss")
 
     @staticmethod
     def bg_mse_backward(image, weights_sum, gt, bg_rgb, grad_loss, grad_image, grad_weights_sum):

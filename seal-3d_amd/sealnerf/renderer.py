@@ -48,8 +48,24 @@ class SealTeacherMixin:
 
     def update_extra_state(self, decay=0.95, S=128):
         super().update_extra_state(decay, S)
+        self.after_extra_state()
+
+    # update_extra_state = the backbone's sweep + this epilogue (nerf/trainer.py replays the sweep from a graph and calls it)
+    extra_state_epilogue_only = True
+
+    def after_extra_state(self):
         if self.seal_mapper is not None:
             self.hack_bitfield()
+
+    def _plain_sample_path(self):
+        """nerf/renderer.py: may run_cuda skip the zero fills of the sample buffers?  Yes without a proxy (student), and with
+        the native bbox mapper too: it takes the device-side sample count like every other per-sample kernel (rows behind
+        the count are neither read nor written; the marcher keeps the pad rows up to the next 128 zero, the mapper maps them).
+        A colour edit (`map_color`: torch ops over whole tensors) keeps the conservative path."""
+        if self.seal_mapper is None or not self.proxy_enabled:
+            return True
+        m = self.seal_mapper
+        return bool(getattr(m, "native", False)) and "hsv" not in m.map_data and "rgb" not in m.map_data
 
     # teacher only: proxy the samples
     def map_samples(self, xyzs, dirs):

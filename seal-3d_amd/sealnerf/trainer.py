@@ -41,6 +41,40 @@ def sample_points(bounds, point_step=0.005, angle_step=45):
     return torch.cat(pts), torch.cat(dirs)
 
 
+class _L1Pair(torch.autograd.Function):
+    """loss = L1Loss(sigma, gt_sigma) + L1Loss(color, gt_color) (means; SealNeRF/trainer.py:455-469) and, for the upstream gradient
+    announced in advance (the loss scale), both gradients — one launch (csrc/ngp_head.hip: k_l1_pair) for sub / abs / sum / div x 2,
+    add and their backward nodes.  `sigma` / `color` may carry padding rows behind the targets' n (no term, zero gradient)."""
+
+    @staticmethod
+    def forward(ctx, sigma, color, gt_sigma, gt_color, n_total, expected_grad=None):
+        import s3d_hip
+        sigma, color = sigma.float().contiguous(), color.float().contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=sigma.device)
+        ctx.pre = None
+        if expected_grad is not None and expected_grad.dtype == torch.float32 and expected_grad.numel() == 1:
+            g_sigma, g_color = torch.empty_like(sigma), torch.empty_like(color)
+            s3d_hip.NgpHeadBackend.l1_pair_loss(sigma, color, gt_sigma, gt_color, n_total, loss, expected_grad, g_sigma, g_color)
+            ctx.pre = (g_sigma, g_color, expected_grad.data_ptr(), expected_grad._version)
+        else:
+            s3d_hip.NgpHeadBackend.l1_pair_loss(sigma, color, gt_sigma, gt_color, n_total, loss)
+        ctx.save_for_backward(sigma, color, gt_sigma, gt_color)
+        ctx.n_total = n_total
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        import s3d_hip
+        if ctx.pre is not None and g.dtype == torch.float32 and g.data_ptr() == ctx.pre[2] and g._version == ctx.pre[3]:
+            return ctx.pre[0], ctx.pre[1], None, None, None, None
+        sigma, color, gt_sigma, gt_color = ctx.saved_tensors
+        g_sigma, g_color = torch.empty_like(sigma), torch.empty_like(color)
+        scratch = torch.empty((), dtype=torch.float32, device=sigma.device)
+        s3d_hip.NgpHeadBackend.l1_pair_loss(sigma, color, gt_sigma, gt_color, ctx.n_total, scratch, g.float().reshape(1).contiguous(),
+                                            g_sigma, g_color)
+        return g_sigma, g_color, None, None, None, None
+
+
 def freeze_module(module, freeze):
     module.training = not freeze
     for p in module.parameters():
@@ -79,6 +113,7 @@ class SealSteps:
         if steps[-1] != pts.shape[0]:
             steps.append(pts.shape[0])
         self.pretraining_data["local"] = {"points": pts, "dirs": dirs, "sigma": gt_sigma, "color": gt_color, "steps": steps}
+        self.pretraining_data.pop("_padded", None)
         self.pretraining_lr = lr
         self.invalidate_graphs()  # (the per-chunk graphs hold raw pointers into the previous point / target tensors)
         return pts.shape[0]
@@ -115,26 +150,32 @@ class SealSteps:
 
     def pretrain_loss(self, points, dirs, gt_sigma, gt_color, n_total=None):
         """SealNeRF/trainer.py:455-469: L1Loss(sigma) + L1Loss(colour) (means) of the student on one point chunk.  With a
-        shard of the chunk, `n_total` is the size of the whole chunk: the shard's sums are normalised by the global count."""
-        n = points.shape[0]
+        shard of the chunk, `n_total` is the size of the whole chunk: the shard's sums are normalised by the global count.
+        `points` / `dirs` may already be padded to whole 128-row tiles (the targets say how many rows count)."""
+        n = gt_sigma.shape[0]
         n_total = n_total or n
-        if points.is_cuda and n % 128:
-            # the fused network path works on whole 128-row tiles: pad, and slice the padding off the outputs (its gradient
-            # is exactly zero, so the table gradients are those of the unpadded chunk)
-            pad = 128 - n % 128
+        if points.is_cuda and points.shape[0] % 128:
+            # the fused network path works on whole 128-row tiles: pad; the padding rows take no part in the loss (their
+            # gradient is exactly zero, so the table gradients are those of the unpadded chunk)
+            pad = 128 - points.shape[0] % 128
             points, dirs = F.pad(points, (0, 0, 0, pad)), F.pad(dirs, (0, 0, 0, pad), value=1.0)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             sigma, color = self.model(points, dirs)
+            if sigma.is_cuda and self.native_optim:
+                return _L1Pair.apply(sigma.reshape(-1), color.reshape(-1, 3), gt_sigma.float().contiguous(), gt_color.float().contiguous(),
+                                     n_total, self._expected_grad())
             sigma, color = sigma[:n], color[:n]
             return (sigma.float() - gt_sigma).abs().sum() / n_total + (color.float() - gt_color).abs().sum() / (n_total * 3)
 
     def finetune_loss(self, rays_o, rays_d, gt_rgb, gt_depth=None, bg_color=1):
-        """nerf/utils.py:436-537 with Seal's depth target: mean over rays of (MSE over channels + L1Loss(depth)) = MSE + L1"""
+        """nerf/utils.py:436-537 with Seal's depth target: mean over rays of (MSE over channels + L1Loss(depth)) = MSE + L1.
+        On the native path background compositing, both criteria and the backward of the MSE are one launch (nerf/trainer.py:
+        _BgMse); the depth term has a value but — as in the reference, raymarching.py:274 — no gradient."""
+        from nerf.trainer import render_loss
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
-            out = self.model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False, **self.render_kwargs)
-            loss = F.mse_loss(out["image"], gt_rgb)
-            if gt_depth is not None:
-                loss = loss + self.depth_weight * F.l1_loss(torch.nan_to_num(out["depth"], nan=0.0).view(gt_depth.shape), gt_depth)
+            out = self.model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False,
+                                    defer_background=self.native_optim and not torch.is_tensor(bg_color), **self.render_kwargs)
+            loss = render_loss(out, gt_rgb, self._expected_grad(), gt_depth, self.depth_weight)
         return loss, out
 
     def pretrain_step(self, points, dirs, gt_sigma, gt_color, n_total=None):
@@ -143,10 +184,12 @@ class SealSteps:
         self.optimizer.zero_grad(set_to_none=False)
         world = self.dist.world if self.dist is not None else 1
         # x world because the DP layer averages the shards' gradients
-        loss = self.pretrain_loss(points, dirs, gt_sigma, gt_color, n_total) * world
+        loss = self.pretrain_loss(points, dirs, gt_sigma, gt_color, n_total)
+        if world != 1:
+            loss = loss * world
         self._backward(loss)
         self._reduce_and_step()
-        return loss.detach() / world
+        return loss.detach() / world if world != 1 else loss.detach()
 
     graph_pretraining = True  # GPU: every point chunk's step is replayed from its own HIP graph (static chunk tensors)
 
@@ -156,6 +199,16 @@ class SealSteps:
         src = self.pretraining_data["local"]
         args = (src["points"][sl], src["dirs"][sl], src["sigma"][sl], src["color"][sl])
         on_gpu = args[0].is_cuda
+        if on_gpu and args[0].shape[0] % 128:
+            # the chunk's points and directions padded to whole 128-row tiles ONCE (they are static): pretrain_loss would pad
+            # them again on every step otherwise (two fills + two copies per replay)
+            cache = self.pretraining_data.setdefault("_padded", {})
+            ent = cache.get(key)
+            if ent is None or ent[0] != (args[0].data_ptr(), args[0].shape[0]):
+                pad = 128 - args[0].shape[0] % 128
+                ent = ((args[0].data_ptr(), args[0].shape[0]), F.pad(args[0], (0, 0, 0, pad)), F.pad(args[1], (0, 0, 0, pad), value=1.0))
+                cache[key] = ent
+            args = (ent[1], ent[2], args[2], args[3])
         if not (self.graph_pretraining and on_gpu and self.native_optim):
             return self.pretrain_step(*args, n_total=n_total)
         if not hasattr(self, "_pt_graphs"):
@@ -195,19 +248,19 @@ class SealSteps:
         self.freeze_mlp(True)
         src = self.pretraining_data["local"]
         rank, world = (self.dist.rank, self.dist.world) if self.dist is not None else (0, 1)
-        total, n = 0.0, 0
+        losses = []
         for k, (a, b) in enumerate(zip(src["steps"][:-1], src["steps"][1:])):
             lo, hi = shard_slice(b - a, rank, world)
-            total = total + self._pretrain_chunk(k, slice(a + lo, a + hi), b - a)
-            n += 1
+            losses.append(self._pretrain_chunk(k, slice(a + lo, a + hi), b - a))
         self.freeze_mlp(False)
         self.set_lr(self.base_lr)
-        return total / max(n, 1)
+        return losses[0] if len(losses) == 1 else torch.stack([l.reshape(()) for l in losses]).mean()
 
     # ------------------------------------------------------------------ global fine-tuning
     @torch.no_grad()
-    def proxy_truth(self, rays_o, rays_d):
-        """teacher-rendered RGB + depth targets for a ray batch (force_all_rays, no perturbation) — trainer.py:506-586"""
+    def proxy_truth(self, rays_o, rays_d, out_rgb=None, out_depth=None):
+        """teacher-rendered RGB + depth targets for a ray batch (force_all_rays, no perturbation) — trainer.py:506-586;
+        `out_rgb` [N,3] / `out_depth` [N]: write them there (fp32, contiguous)"""
         if not self.teacher.density_bitfield_hacked:
             self.teacher.hack_bitfield()
         # The reference never puts the teacher in eval mode: its render takes run_cuda's TRAINING branch (`force_all_rays` is
@@ -217,12 +270,30 @@ class SealSteps:
         # under the L1 depth term.
         was_training = self.teacher.training
         self.teacher.train()
+        native = rays_o.is_cuda and (out_rgb is not None or self.native_optim)
         try:
             with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
-                out = self.teacher.render(rays_o, rays_d, bg_color=None, perturb=False, force_all_rays=True, **self.render_kwargs)
+                out = self.teacher.render(rays_o, rays_d, bg_color=None, perturb=False, force_all_rays=True,
+                                          defer_background=native, **self.render_kwargs)
         finally:
             self.teacher.train(was_training)
-        return torch.nan_to_num(out["image"], nan=0.0), torch.nan_to_num(out["depth"], nan=0.0)
+        if out.get("premultiplied", False):
+            # background (nerf/renderer.py:316) + the two nan_to_num of the reference in one launch, written where the caller
+            # wants the targets (the graph-replayed trainer: its static buffers)
+            import s3d_hip
+            n = out["weights_sum"].numel()
+            rgb = out_rgb if out_rgb is not None else torch.empty(n, 3, device=rays_o.device)
+            dep = out_depth if out_depth is not None else torch.empty(n, device=rays_o.device)
+            bg = out["bg_color"]
+            bg = (float(bg),) * 3 if not isinstance(bg, (tuple, list)) else tuple(float(v) for v in bg)
+            s3d_hip.NgpHeadBackend.bg_targets(out["image"].reshape(-1, 3).float().contiguous(), out["weights_sum"].reshape(-1).float().contiguous(),
+                                              out["depth"].reshape(-1).float().contiguous(), bg, rgb, dep)
+            return rgb.view(out["image"].shape), dep.view(out["depth"].shape)
+        rgb, dep = torch.nan_to_num(out["image"], nan=0.0), torch.nan_to_num(out["depth"], nan=0.0)
+        if out_rgb is not None:
+            torch._foreach_copy_([out_rgb, out_depth], [rgb.reshape(-1, 3), dep.reshape(-1)])
+            return out_rgb.view(rgb.shape), out_depth.view(dep.shape)
+        return rgb, dep
 
     def _seal_step(self, rays_o, rays_d, gt_rgb, gt_depth, bg_color=1):
         """zero grads -> fine-tuning loss -> backward -> (all-reduce) -> loss-scaled Adam, launched eagerly"""
@@ -266,8 +337,7 @@ class GraphedSealTrainer(SealSteps, GraphedTrainer):
         training branch (force_all_rays): N * max_steps sample rows of static extent, the real count on the device (every
         kernel of the two-encoder network takes it as n_valid) — no host read-back, so it can be captured."""
         def body():
-            img, dep = self.proxy_truth(self.s_ro, self.s_rd)
-            torch._foreach_copy_([self.s_gt, self.s_depth], [img.reshape(-1, 3), dep.reshape(-1)])
+            self.proxy_truth(self.s_ro, self.s_rd, self.s_gt, self.s_depth)
         if self.proxy_graph is None:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

@@ -285,3 +285,49 @@ def test_cached_half_weights_follow_a_fused_torch_optimizer(hip):
     e3, m3 = infer()
     assert not torch.equal(e2, e3) and not torch.equal(m2, m3), "stale fp16 copies after reset_parameters()"
     assert enc.embeddings._s3d_eval_half[2].data_ptr() != 0 and not hasattr(gg, "_half_cache")  # freed with the parameter
+
+
+def test_packed_linear_weights_in_the_native_optimizer_match_the_assembled_path(hip):
+    """nerf/network.py: PackedWeights.  With NativeAdam the five nn.Linear weights of the Seal network live as row-strided
+    views of two packed fp16 buffers (weights + gradient twin): the MLP backward writes the packed gradient, the Adam launch
+    reads / writes through the views.  Against the same model whose packs are switched off (weights assembled by cat / pad per
+    call, fp16 weight gradient split back into fp32 `.grad`s by autograd): identical parameters after three steps — the fp32
+    `.grad`s are exact images of the fp16 values, the update arithmetic is the same — and the pack holds the fp16 image of the
+    assembled weights."""
+    import bench
+    import s3d_hip
+    from nerf import network, synthetic as syn
+    from nerf.trainer import Trainer
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    batches, _ = bench.make_batches(3, 1024, 0, torch.device("cuda"), s3d_hip.RaymarchingBackend, torch.from_numpy(bits).cuda(),
+                                    syn.lego_like_boxes(0))
+    out = {}
+    for packed in (True, False):
+        torch.manual_seed(0)
+        net = network.NeRFNetwork(bound=1, cuda_ray=True, log2_hashmap_size=15, density_scale=1, min_near=0.2, density_thresh=10).cuda()
+        net.density_grid.copy_(torch.from_numpy(grid))
+        net.density_bitfield.copy_(torch.from_numpy(bits))
+        net.iter_density = 100
+        if not packed:
+            for pk in net._packs:
+                for p, _, _ in pk.members:
+                    del p._s3d_pack_spec
+            net._packs = None
+        tr = Trainer(net, lr=1e-2, fp16=True, update_extra_interval=10 ** 9)
+        tr.global_step = 1
+        assert tr.native_optim and (net._packs is None or all(pk.adopted for pk in net._packs))
+        losses = []
+        for i in range(3):
+            torch.manual_seed(100 + i)  # (the marcher's jitter)
+            losses.append(float(tr.train_step(*batches[i])))
+        if packed:
+            for pk in net._packs:
+                assert pk.current() is not None
+                for p, _, _ in pk.members:
+                    assert p.grad is None and p._s3d_grad_consumed  # the gradient never became a `.grad`
+            ws, wc = net._packed_weights()
+            assert torch.equal(net._packs[0].half, ws.half()) and torch.equal(net._packs[1].half, wc.half())
+        out[packed] = (losses, {k: v.detach().clone() for k, v in net.named_parameters()})
+    assert out[True][0] == out[False][0], (out[True][0], out[False][0])
+    for k, v in out[True][1].items():
+        assert torch.equal(v, out[False][1][k]), k
