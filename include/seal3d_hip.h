@@ -421,13 +421,15 @@ int s3d_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, f
 /* Build extension (graph-replayed step): the renderer keeps the marcher's {samples, rays} counters of the last 16 training
  * steps (nerf/renderer.py:106, 352-356: `step_counter[local_step % 16]`).  Device-side equivalent of that bookkeeping:
  * slot = cursor[0]; loss_ring[slot] = *loss (both optional); counter_ring[slot] = counter[0..1]; counter[0..1] = 0;
- * cursor[0] = (slot + 1) % ring; cursor[1] += 1 (running step number, the `noise_step` of s3d_near_far_from_aabb). */
+ * cursor[0] = (slot + 1) % ring; cursor[1] += 1 (running step number, the `noise_step` of s3d_near_far_from_aabb).
+ * loss_slots > 0: loss_ring has loss_slots entries of its own and the loss is filed at cursor[1] % loss_slots (before the
+ * increment) — a longer history than the counter ring, so that a loss handed out as a view stays valid for loss_slots steps. */
 int s3d_step_ring_push(const float* loss, int32_t* counter, float* loss_ring, int32_t* counter_ring, int32_t* cursor,
-                       int32_t ring, s3d_stream_t stream);
+                       int32_t ring, int32_t loss_slots, s3d_stream_t stream);
 /* s3d_scaler_update followed by s3d_step_ring_push, one launch. */
 int s3d_step_epilogue(float* scale, int32_t* growth_tracker, float* found_inf, float growth_factor, float backoff_factor,
                       int32_t growth_interval, float* adam_step, const float* loss, int32_t* counter, float* loss_ring,
-                      int32_t* counter_ring, int32_t* cursor, int32_t ring, s3d_stream_t stream);
+                      int32_t* counter_ring, int32_t* cursor, int32_t ring, int32_t loss_slots, s3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -304,19 +304,27 @@ __device__ __forceinline__ uint32_t dpp_swap1(uint32_t v) {
 }
 __device__ __forceinline__ float dpp_swap1(float v) { return __uint_as_float(dpp_swap1(__float_as_uint(v))); }
 
+// Which levels workgroup (xcd, chunk) serves: bit l of mask[xcd][chunk % kFwdResidues].  Every (level, chunk) pair belongs to
+// exactly one XCD (balance_forward_plan() below): a level's table stays in the L2 of the few XCDs that serve it.
+constexpr uint32_t kFwdResidues = 16;
+struct FwdPlan {
+    uint32_t mask[kXcds][kFwdResidues];
+};
+
 template <typename T, uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __restrict__ inputs, const T* __restrict__ grid,
                                                                  const int32_t* __restrict__ offsets, T* __restrict__ outputs,
                                                                  uint32_t B, uint32_t L, LevelScales scales, uint32_t gridtype,
-                                                                 bool align_corners, uint32_t interp) {
+                                                                 bool align_corners, uint32_t interp, FwdPlan plan) {
     static_assert((sizeof(T) * C) % 4 == 0, "feature vectors travel between lanes as 32-bit words");
     constexpr uint32_t NW = sizeof(T) * C / 4;   // words per feature vector
     constexpr uint32_t J = 1u << (D - 1);        // corner pairs per point
     const uint32_t xcd = blockIdx.x % kXcds;
     const uint32_t b = (blockIdx.x / kXcds) * kFwdBlock + threadIdx.x;
     const uint32_t Bv = valid_rows(B, scales.n_valid);
+    uint32_t todo = plan.mask[xcd][(blockIdx.x / kXcds) % kFwdResidues];  // (uniform) this workgroup's levels
     // a wave leaves as a whole (its lanes exchange data below): Bv is a multiple of the block size or the last block is ragged
-    if ((b & ~63u) >= Bv || xcd >= L) return;
+    if ((b & ~63u) >= Bv || todo == 0u) return;
     const bool valid = b < Bv;
     const uint32_t side = threadIdx.x & 1u;  // which x-corner this lane fetches, for both points of the pair
     float x[D];
@@ -446,14 +454,19 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __
         }
         store_feat<T, C>(out, res);
     };
-    // two levels of this XCD in flight at a time: the second level's gathers are issued before the first one's are awaited
-    for (uint32_t level = xcd; level < L; level += 2 * kXcds) {
+    // two levels in flight at a time: the second level's gathers are issued before the first one's are awaited
+    (void)L;
+    while (todo) {
         LevelState s0, s1;
-        const bool two = level + kXcds < L;  // (uniform)
-        issue(level, s0);
-        if (two) issue(level + kXcds, s1);
-        finish(level, s0);
-        if (two) finish(level + kXcds, s1);
+        const uint32_t l0 = (uint32_t)__builtin_ctz(todo);
+        todo &= todo - 1u;
+        const bool two = todo != 0u;  // (uniform)
+        const uint32_t l1 = two ? (uint32_t)__builtin_ctz(todo) : 0u;
+        if (two) todo &= todo - 1u;
+        issue(l0, s0);
+        if (two) issue(l1, s1);
+        finish(l0, s0);
+        if (two) finish(l1, s1);
     }
 }
 
@@ -1788,24 +1801,106 @@ void host_scales(uint32_t L, float S, uint32_t H, LevelScales& out, float bound 
 
 inline uint32_t xcd_grid(uint32_t B) { return kXcds * div_up<uint32_t>(B, kFwdBlock); }
 
+// Level -> XCD plan of the lane-pair forward.  The kernel is bound by the L2's request rate, and every XCD has its own L2:
+// with level l served by XCD l % 8 alone (the round-1 mapping) the XCDs finish at different times.  Measured on ray-ordered
+// points (tools/fwd_levels.py, one level alone on its home XCD, B = 2^18, Lego configuration; profiles/r09_grid_forward_plan.md):
+// levels 0 - 5 (resolution <= 81) cost 10 - 11 us each whatever their table, from there the cost grows with the resolution —
+// a marching step crosses more and more cells, the 64 lanes of a gather share fewer and fewer lines — to 36 us from resolution
+// ~700 on.  Home mapping: XCD 0 serves levels 0 + 8 = 28 us, XCD 7 levels 7 + 15 = 51 us; the launch ends with XCD 7.
+// Here the work is cut in (level, chunk residue) slices — chunk = 256 points, residue = chunk % 16 — that start on XCD l % 8
+// and are moved from the most to the least loaded XCD until nothing improves.  What may move: only home slices, and a
+// receiver never holds more than two LARGE tables ((res + 1)^3 >= 2^18 rows: 2 MiB of fp16 pairs at the default hash size, an
+// L2 is 4 MiB); preferred are levels the receiver already serves, then small (dense) levels, then the cheapest (most coherent)
+// level.  Cost model fitted to the measurement: 0.29 up to resolution 81, linear to 1 at resolution ~700.  (Uniformly random
+// points cost ~39 us on every level from 3 on, i.e. the home mapping is balanced for them and this plan costs them ~10 %; every
+// product caller presents ray-, Morton- or lattice-ordered points.)  Placement only: every point is computed by the same
+// instructions as before — results are bit-identical (tests/test_gpu_gridencoder.py runs against the oracle unchanged).
+#ifndef S3D_FWD_BALANCE  // 0: the round-1 mapping (A/B)
+#define S3D_FWD_BALANCE 1
+#endif
+inline FwdPlan balance_forward_plan(uint32_t L, const LevelScales& sc) {
+    FwdPlan p;
+    memset(&p, 0, sizeof(p));
+    float cost[kMaxLevels], load[kXcds] = {0};
+    bool big[kMaxLevels];
+    uint8_t owner[kMaxLevels][kFwdResidues];
+    for (uint32_t l = 0; l < L; l++) {
+        const float res = ceilf(sc.v[l]) + 1.0f;
+        const float c = 0.29f + 0.71f * (res - 81.0f) / 620.0f;
+        cost[l] = (c < 0.29f ? 0.29f : (c > 1.0f ? 1.0f : c)) / (float)kFwdResidues;  // per slice
+        big[l] = (res + 1.0f) * (res + 1.0f) * (res + 1.0f) >= 262144.0f;
+        for (uint32_t k = 0; k < kFwdResidues; k++) owner[l][k] = (uint8_t)(l % kXcds);
+        load[l % kXcds] += cost[l] * kFwdResidues;
+    }
+    auto serves = [&](uint32_t x, uint32_t l) {
+        for (uint32_t k = 0; k < kFwdResidues; k++) if (owner[l][k] == x) return true;
+        return false;
+    };
+    for (int it = 0; S3D_FWD_BALANCE && it < 1024; it++) {
+        uint32_t hi = 0;
+        for (uint32_t x = 1; x < kXcds; x++) if (load[x] > load[hi]) hi = x;
+        uint32_t order[kXcds];
+        for (uint32_t x = 0; x < kXcds; x++) order[x] = x;
+        for (uint32_t i = 1; i < kXcds; i++)
+            for (uint32_t j = i; j > 0 && load[order[j]] < load[order[j - 1]]; j--) { const uint32_t t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+        bool moved = false;
+        for (uint32_t oi = 0; oi < kXcds && !moved; oi++) {  // receivers from the least loaded up
+            const uint32_t lo = order[oi];
+            if (lo == hi) break;
+            uint32_t n_big = 0;
+            for (uint32_t l = 0; l < L; l++) n_big += (big[l] && serves(lo, l)) ? 1u : 0u;
+            int best_l = -1, best_k = -1;
+            float best_key = 0.0f;
+            for (uint32_t l = 0; l < L; l++) {
+                if (l % kXcds != hi) continue;  // (only home slices travel, and only once)
+                if (load[hi] - cost[l] < load[lo] + cost[l]) continue;
+                int k_own = -1;
+                for (uint32_t k = 0; k < kFwdResidues; k++) if (owner[l][k] == hi) k_own = (int)k;
+                if (k_own < 0) continue;
+                const bool has = serves(lo, l);
+                if (big[l] && !has && n_big >= 2u) continue;
+                const float key = (has ? 0.0f : 100.0f) + (big[l] ? 10.0f : 0.0f) + cost[l];  // smaller = preferred
+                if (best_l < 0 || key < best_key) { best_l = (int)l; best_k = k_own; best_key = key; }
+            }
+            if (best_l < 0) continue;
+            owner[best_l][best_k] = (uint8_t)lo;
+            load[hi] -= cost[best_l];
+            load[lo] += cost[best_l];
+            moved = true;
+        }
+        if (!moved) break;
+    }
+#ifdef S3D_FWD_PLAN_ENV  // calibration builds only (tools/fwd_levels.py): ONE level, all of it on its home XCD
+    if (const char* only = getenv("S3D_FWD_ONLY_LEVEL")) {
+        const uint32_t l = (uint32_t)atoi(only);
+        for (uint32_t k = 0; k < kFwdResidues; k++) p.mask[l % kXcds][k] = l < L ? 1u << l : 0u;
+        return p;
+    }
+#endif
+    for (uint32_t l = 0; l < L; l++)
+        for (uint32_t k = 0; k < kFwdResidues; k++) p.mask[owner[l][k]][k] |= 1u << l;
+    return p;
+}
+
 template <typename T, uint32_t D>
 int launch_forward(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t C,
                    uint32_t L, const LevelScales& sc, T* dy_dx, uint32_t gridtype, bool ac, uint32_t interp,
                    hipStream_t st) {
     const dim3 grid(xcd_grid(B)), block(kFwdBlock);
+    const FwdPlan plan = balance_forward_plan(L, sc);
     // lane-pair kernel whenever the feature vector is whole 32-bit words and no input Jacobian is asked for (the training and
     // inference paths of every configuration); k_grid_forward keeps fp16 C = 1 and the Jacobian
     if (!dy_dx && (sizeof(T) * C) % 4 == 0) {
         if constexpr (sizeof(T) == 4) {
             switch (C) {
-                case 1: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 1>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp); return check_launch("grid_encode_forward");
+                case 1: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 1>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan); return check_launch("grid_encode_forward");
                 default: break;
             }
         }
         switch (C) {
-            case 2: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 2>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp); return check_launch("grid_encode_forward");
-            case 4: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 4>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp); return check_launch("grid_encode_forward");
-            case 8: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 8>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp); return check_launch("grid_encode_forward");
+            case 2: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 2>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan); return check_launch("grid_encode_forward");
+            case 4: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 4>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan); return check_launch("grid_encode_forward");
+            case 8: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 8>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan); return check_launch("grid_encode_forward");
             default: break;
         }
     }

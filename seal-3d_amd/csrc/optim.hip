@@ -240,10 +240,12 @@ __global__ void k_scaler_update(float* __restrict__ scale, int32_t* __restrict__
 // advance the slot — what the host otherwise does with two copies and a fill per step.
 __device__ __forceinline__ void step_ring_push(const float* __restrict__ loss, int32_t* __restrict__ counter,
                                                float* __restrict__ loss_ring, int32_t* __restrict__ counter_ring,
-                                               int32_t* __restrict__ cursor, int32_t ring) {
+                                               int32_t* __restrict__ cursor, int32_t ring, int32_t loss_slots) {
     int32_t c = *cursor;
     if (c < 0 || c >= ring) c = 0;
-    if (loss && loss_ring) loss_ring[c] = *loss;
+    // the loss history may be longer than the counter ring: slot = running step number % loss_slots (a tensor handed to the
+    // caller for step k stays valid until step k + loss_slots); loss_slots <= 0: the counter ring's slot
+    if (loss && loss_ring) loss_ring[loss_slots > 0 ? (int32_t)((uint32_t)cursor[1] % (uint32_t)loss_slots) : c] = *loss;
     counter_ring[2 * c] = counter[0];
     counter_ring[2 * c + 1] = counter[1];
     counter[0] = 0;
@@ -252,16 +254,16 @@ __device__ __forceinline__ void step_ring_push(const float* __restrict__ loss, i
     cursor[1] += 1;
 }
 __global__ void k_step_ring_push(const float* __restrict__ loss, int32_t* __restrict__ counter, float* __restrict__ loss_ring,
-                                 int32_t* __restrict__ counter_ring, int32_t* __restrict__ cursor, int32_t ring) {
-    step_ring_push(loss, counter, loss_ring, counter_ring, cursor, ring);
+                                 int32_t* __restrict__ counter_ring, int32_t* __restrict__ cursor, int32_t ring, int32_t loss_slots) {
+    step_ring_push(loss, counter, loss_ring, counter_ring, cursor, ring, loss_slots);
 }
 // both single-thread epilogues of a step in one launch
 __global__ void k_step_epilogue(float* __restrict__ scale, int32_t* __restrict__ growth_tracker, float* __restrict__ found_inf,
                                 float growth, float backoff, int32_t interval, float* __restrict__ adam_step,
                                 const float* __restrict__ loss, int32_t* __restrict__ counter, float* __restrict__ loss_ring,
-                                int32_t* __restrict__ counter_ring, int32_t* __restrict__ cursor, int32_t ring) {
+                                int32_t* __restrict__ counter_ring, int32_t* __restrict__ cursor, int32_t ring, int32_t loss_slots) {
     scaler_update(scale, growth_tracker, found_inf, growth, backoff, interval, adam_step);
-    step_ring_push(loss, counter, loss_ring, counter_ring, cursor, ring);
+    step_ring_push(loss, counter, loss_ring, counter_ring, cursor, ring, loss_slots);
 }
 
 }  // namespace
@@ -349,19 +351,19 @@ S3D_EXPORT int s3d_scaler_update(float* scale, int32_t* growth_tracker, float* f
 }
 
 S3D_EXPORT int s3d_step_ring_push(const float* loss, int32_t* counter, float* loss_ring, int32_t* counter_ring, int32_t* cursor,
-                                  int32_t ring, s3d_stream_t stream) {
+                                  int32_t ring, int32_t loss_slots, s3d_stream_t stream) {
     S3D_REQUIRE(counter && counter_ring && cursor && ring > 0, "step_ring_push: null pointer or empty ring");
-    hipLaunchKernelGGL(k_step_ring_push, dim3(1), dim3(1), 0, as_stream(stream), loss, counter, loss_ring, counter_ring, cursor, ring);
+    hipLaunchKernelGGL(k_step_ring_push, dim3(1), dim3(1), 0, as_stream(stream), loss, counter, loss_ring, counter_ring, cursor, ring, loss_slots);
     return check_launch("step_ring_push");
 }
 
 S3D_EXPORT int s3d_step_epilogue(float* scale, int32_t* growth_tracker, float* found_inf, float growth_factor,
                                  float backoff_factor, int32_t growth_interval, float* adam_step, const float* loss,
                                  int32_t* counter, float* loss_ring, int32_t* counter_ring, int32_t* cursor, int32_t ring,
-                                 s3d_stream_t stream) {
+                                 int32_t loss_slots, s3d_stream_t stream) {
     S3D_REQUIRE(scale && growth_tracker && found_inf, "step_epilogue: null pointer (scaler)");
     S3D_REQUIRE(counter && counter_ring && cursor && ring > 0, "step_epilogue: null pointer or empty ring");
     hipLaunchKernelGGL(k_step_epilogue, dim3(1), dim3(1), 0, as_stream(stream), scale, growth_tracker, found_inf, growth_factor,
-                       backoff_factor, growth_interval, adam_step, loss, counter, loss_ring, counter_ring, cursor, ring);
+                       backoff_factor, growth_interval, adam_step, loss, counter, loss_ring, counter_ring, cursor, ring, loss_slots);
     return check_launch("step_epilogue");
 }

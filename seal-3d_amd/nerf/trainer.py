@@ -227,7 +227,10 @@ class GraphedTrainer(Trainer):
         self.s_loss = None
         self.s_counter = torch.zeros(2, dtype=torch.int32, device=dev)
         # the graph itself files each step's loss and sample counter in 16-slot rings (seal3d_hip.h: s3d_step_ring_push)
-        self.loss_ring = torch.zeros(16, dtype=torch.float32, device=dev)
+        # (the loss history is longer than the counter ring: the tensor train_step() hands out for step k is a view of slot
+        #  k % 1024 and stays valid for the next 1,023 steps — a caller that keeps loss tensors longer clones them)
+        self.loss_ring = torch.zeros(1024, dtype=torch.float32, device=dev)
+        self._pushes = 0  # ring pushes executed so far = the device's running step number (s_cursor[1])
         self.s_cursor = torch.zeros(2, dtype=torch.int32, device=dev)  # {ring slot, running step number}
         self.noise_key = (torch.initial_seed() * 0x9E3779B1 + (self.dist.rank if self.dist is not None else 0) * 0x85EBCA6B) & 0xFFFFFFFF
         self._counter_ring = None
@@ -407,12 +410,14 @@ class GraphedTrainer(Trainer):
             self._capture()  # runs this step eagerly (one optimizer update), then records the graph
             loss = self.s_warm_loss
             filed = self._counter_ring is not None
+            self._pushes += 1 if filed else 0  # (the warm-up step filed its loss too)
         else:
             self._replay()
             filed = self._counter_ring is not None
-            # the static loss buffer is overwritten by the next replay and a ring slot 16 steps later (the ring restarts at slot 0
-            # after every update_extra_state): the caller gets its own copy, like the tensor the reference's step returns
-            loss = (self.loss_ring[model.local_step % 16] if filed else self.s_loss).clone()
+            # the static loss buffer is overwritten by the next replay; the graph files each step's loss in a 1,024-slot
+            # history (no extra launch per step): the caller gets the view of this step's slot, untouched for 1,023 more steps
+            loss = self.loss_ring[self._pushes % self.loss_ring.numel()] if filed else self.s_loss.clone()
+            self._pushes += 1 if filed else 0
         bump_weights_epoch()  # replays update the parameters without touching Tensor._version
         if not filed:
             model.step_counter[model.local_step % 16].copy_(self.s_counter)

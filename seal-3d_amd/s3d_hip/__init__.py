@@ -698,12 +698,13 @@ class OptimBackend:
         if loss is not None:
             _need(loss, torch.float32, "loss"); _need(loss_ring, torch.float32, "loss_ring")
         ring = counter_ring.shape[0]
-        if cursor.numel() < 2 or counter_ring.numel() != 2 * ring or (loss is not None and loss_ring.numel() != ring):
-            raise RuntimeError("step_epilogue: cursor is int32[2], rings are [ring, 2] / [ring]")
+        if cursor.numel() < 2 or counter_ring.numel() != 2 * ring or (loss is not None and loss_ring.numel() < 1):
+            raise RuntimeError("step_epilogue: cursor is int32[2], rings are [ring, 2] / [loss_slots]")
+        slots = 0 if loss is None or loss_ring.numel() == ring else loss_ring.numel()
         _check(lib().s3d_step_epilogue(_p(scale), _p(growth_tracker), _p(found_inf), _f(growth_factor), _f(backoff_factor),
                                        C.c_int32(int(growth_interval)), _p(adam_step), _p(loss),
                                        _p(counter), _p(loss_ring if loss is not None else None), _p(counter_ring), _p(cursor),
-                                       C.c_int32(ring), _stream()), "step_epilogue")
+                                       C.c_int32(ring), C.c_int32(slots), _stream()), "step_epilogue")
 
     @staticmethod
     def step_ring_push(loss, counter, loss_ring, counter_ring, cursor):
@@ -715,10 +716,11 @@ class OptimBackend:
         if loss is not None:
             _need(loss, torch.float32, "loss"); _need(loss_ring, torch.float32, "loss_ring")
         ring = counter_ring.shape[0]
-        if not counter_ring.is_contiguous() or counter_ring.numel() != 2 * ring or (loss is not None and loss_ring.numel() != ring):
-            raise RuntimeError("step_ring_push: rings must be contiguous [ring, 2] / [ring]")
+        if not counter_ring.is_contiguous() or counter_ring.numel() != 2 * ring or (loss is not None and loss_ring.numel() < 1):
+            raise RuntimeError("step_ring_push: rings must be contiguous [ring, 2] / [loss_slots]")
+        slots = 0 if loss is None or loss_ring.numel() == ring else loss_ring.numel()
         _check(lib().s3d_step_ring_push(_p(loss), _p(counter), _p(loss_ring if loss is not None else None), _p(counter_ring),
-                                        _p(cursor), C.c_int32(ring), _stream()), "step_ring_push")
+                                        _p(cursor), C.c_int32(ring), C.c_int32(slots), _stream()), "step_ring_push")
 
 
 class NgpHeadBackend:

@@ -161,7 +161,7 @@ class SealSteps:
             points, dirs = F.pad(points, (0, 0, 0, pad)), F.pad(dirs, (0, 0, 0, pad), value=1.0)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             sigma, color = self.model(points, dirs)
-            if sigma.is_cuda and self.native_optim:
+            if sigma.is_cuda and self.native_optim and self.fused_losses:
                 return _L1Pair.apply(sigma.reshape(-1), color.reshape(-1, 3), gt_sigma.float().contiguous(), gt_color.float().contiguous(),
                                      n_total, self._expected_grad())
             sigma, color = sigma[:n], color[:n]
@@ -192,6 +192,7 @@ class SealSteps:
         return loss.detach() / world if world != 1 else loss.detach()
 
     graph_pretraining = True  # GPU: every point chunk's step is replayed from its own HIP graph (static chunk tensors)
+    fused_losses = True       # GPU + native optimizer: one-launch criteria (False: the reference's torch op sequences, A/B runs)
 
     def _pretrain_chunk(self, key, sl, n_total):
         """one optimizer step on the (static) chunk `sl` of the local points; GPU + native optimizer: captured once per chunk

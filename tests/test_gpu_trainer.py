@@ -76,7 +76,12 @@ def test_second_graphed_trainer_after_the_first_is_gone(hip):
     assert tr.graph is not None and torch.isfinite(losses).all()
     # the step's loss and sample counter are filed by the graph itself: the ring matches the marcher's private counter
     assert int(model.step_counter[(model.local_step - 1) % 16, 0]) > 0
-    assert float(losses[-1]) == float(tr.loss_ring[(model.local_step - 1) % 16])
+    assert float(losses[-1]) == float(tr.loss_ring[(tr._pushes - 1) % tr.loss_ring.numel()])
+    # loss tensors handed out by train_step stay valid for 1,023 further steps: keep 40, train on, compare
+    kept = [tr.train_step(*batches[i % len(batches)]) for i in range(40)]
+    vals = [float(k) for k in kept]
+    _run(tr, batches, 40)
+    assert vals == [float(k) for k in kept] and len(set(vals)) > 1
 
 
 @pytest.mark.parametrize("graphed", [False, True], ids=["eager", "graph"])

@@ -331,3 +331,59 @@ def test_packed_linear_weights_in_the_native_optimizer_match_the_assembled_path(
     assert out[True][0] == out[False][0], (out[True][0], out[False][0])
     for k, v in out[True][1].items():
         assert torch.equal(v, out[False][1][k]), k
+
+
+def test_seal_loss_heads_match_the_torch_op_sequences(hip):
+    """The Seal-3D loss glue as single launches (csrc/ngp_head.hip) against the reference's op sequences: fine-tuning criterion
+    MSE + L1(nan_to_num(depth)) (nerf/utils.py:484-489; the depth term has a value and no gradient, raymarching.py:274),
+    pretraining criterion L1(sigma) + L1(colour) with padding rows (SealNeRF/trainer.py:455-469), teacher targets
+    nan_to_num(image + (1 - ws) * bg) / nan_to_num(depth) (SealNeRF/trainer.py:572-582)."""
+    from nerf.trainer import render_loss
+    from sealnerf.trainer import _L1Pair
+    g = torch.Generator().manual_seed(3)
+    N = 4096
+    img = torch.rand(N, 3, generator=g).cuda().requires_grad_(True)
+    ws = torch.rand(N, generator=g).cuda().requires_grad_(True)
+    gt = torch.rand(N, 3, generator=g).cuda()
+    depth = (torch.rand(N, generator=g) * 3).cuda()
+    depth[::97] = float("nan")
+    gtd = (torch.rand(N, generator=g) * 3).cuda()
+    scale = torch.tensor(512.0, device="cuda")
+    ref = torch.nn.functional.mse_loss(img + (1 - ws).unsqueeze(-1) * 1.0, gt) + 0.7 * torch.nn.functional.l1_loss(torch.nan_to_num(depth, nan=0.0), gtd)
+    gi_ref, gw_ref = torch.autograd.grad(ref * scale, (img, ws))
+    out = {"image": img, "weights_sum": ws, "depth": depth, "premultiplied": True, "bg_color": 1}
+    for expected in (None, scale):
+        loss = render_loss(out, gt, expected, gtd, 0.7)
+        gi, gw = torch.autograd.grad(loss, (img, ws), grad_outputs=scale)
+        torch.testing.assert_close(loss, ref, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(gi, gi_ref, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(gw, gw_ref, rtol=1e-5, atol=1e-7)
+    # pretraining criterion, 300,000 points + 37 padding rows, shard normalisation
+    n, pad, n_total = 300000, 37, 450000
+    sig = (torch.rand(n + pad, generator=g) * 4).cuda().requires_grad_(True)
+    col = torch.rand(n + pad, 3, generator=g).cuda().requires_grad_(True)
+    gs, gc = (torch.rand(n, generator=g) * 4).cuda(), torch.rand(n, 3, generator=g).cuda()
+    with torch.no_grad():
+        sig[5], col[7, 1] = gs[5], gc[7, 1]  # exact ties: sign(0) = 0
+    ref = (sig[:n] - gs).abs().sum() / n_total + (col[:n] - gc).abs().sum() / (3 * n_total)
+    rs, rc = torch.autograd.grad(ref * scale, (sig, col))
+    vals = []
+    for expected in (None, scale):
+        loss = _L1Pair.apply(sig, col, gs, gc, n_total, expected)
+        a, b = torch.autograd.grad(loss, (sig, col), grad_outputs=scale)
+        torch.testing.assert_close(loss, ref, rtol=2e-5, atol=1e-7)
+        torch.testing.assert_close(a, rs, rtol=1e-6, atol=0)
+        torch.testing.assert_close(b, rc, rtol=1e-6, atol=0)
+        assert float(a[n:].abs().max()) == 0.0 and float(b[n:].abs().max()) == 0.0 and float(a[5]) == 0.0 and float(b[7, 1]) == 0.0
+        vals.append(float(loss))
+    assert vals[0] == vals[1] == float(_L1Pair.apply(sig, col, gs, gc, n_total, None))  # fixed summation order
+    # teacher targets
+    image = torch.rand(N, 3, generator=g).cuda()
+    image[3, 1] = float("nan")
+    w = torch.rand(N, generator=g).cuda()
+    dep = depth.clone()
+    dep[11] = float("inf")
+    o_rgb, o_dep = torch.empty(N, 3, device="cuda"), torch.empty(N, device="cuda")
+    hip.NgpHeadBackend.bg_targets(image, w, dep, (1.0, 1.0, 1.0), o_rgb, o_dep)
+    assert torch.equal(o_rgb, torch.nan_to_num(image + (1 - w).unsqueeze(-1) * 1, nan=0.0))
+    assert torch.equal(o_dep, torch.nan_to_num(dep, nan=0.0))
