@@ -310,21 +310,25 @@ constexpr uint32_t kFwdResidues = 16;
 struct FwdPlan {
     uint32_t mask[kXcds][kFwdResidues];
 };
+// [0]: the home mapping (level l on XCD l % 8), [1]: the balanced plan for coherent points.  Every WAVE picks one for its 64
+// points from the points themselves (the same decision in all eight workgroups that hold these points), see the kernel.
+struct FwdPlans {
+    FwdPlan p[2];
+};
 
 template <typename T, uint32_t D, uint32_t C>
 __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __restrict__ inputs, const T* __restrict__ grid,
                                                                  const int32_t* __restrict__ offsets, T* __restrict__ outputs,
                                                                  uint32_t B, uint32_t L, LevelScales scales, uint32_t gridtype,
-                                                                 bool align_corners, uint32_t interp, FwdPlan plan) {
+                                                                 bool align_corners, uint32_t interp, FwdPlans plans) {
     static_assert((sizeof(T) * C) % 4 == 0, "feature vectors travel between lanes as 32-bit words");
     constexpr uint32_t NW = sizeof(T) * C / 4;   // words per feature vector
     constexpr uint32_t J = 1u << (D - 1);        // corner pairs per point
     const uint32_t xcd = blockIdx.x % kXcds;
     const uint32_t b = (blockIdx.x / kXcds) * kFwdBlock + threadIdx.x;
     const uint32_t Bv = valid_rows(B, scales.n_valid);
-    uint32_t todo = plan.mask[xcd][(blockIdx.x / kXcds) % kFwdResidues];  // (uniform) this workgroup's levels
     // a wave leaves as a whole (its lanes exchange data below): Bv is a multiple of the block size or the last block is ragged
-    if ((b & ~63u) >= Bv || todo == 0u) return;
+    if ((b & ~63u) >= Bv) return;
     const bool valid = b < Bv;
     const uint32_t side = threadIdx.x & 1u;  // which x-corner this lane fetches, for both points of the pair
     float x[D];
@@ -338,6 +342,21 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __
     }
     const bool oob_partner = dpp_swap1(oob ? 1u : 0u) != 0u;
     const bool oobP = side ? oob_partner : oob, oobQ = side ? oob : oob_partner;
+    // Which plan serves these 64 points?  The balanced plan pays off on coherent points (samples along rays, Morton- or
+    // lattice-ordered cells: coarse levels are cheap there, so their XCDs take slices of the busy ones) and costs ~50 % on
+    // scattered points (every level costs the same: the home mapping IS balanced).  Coherent = a quarter or more of the neighbours in the wave lie
+    // within 0.02 (L1, unit cube) of each other — a pure function of the wave's points, so the eight workgroups that hold
+    // them (one per XCD) agree, and each (level, 64 points) is still served exactly once.
+    float dl1 = 0.0f;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++)
+        dl1 += fabsf(x[d] - __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x[d]), 0x138, 0xF, 0xF, true)));  // wave_shr:1
+    const unsigned long long near_mask = __ballot(valid && (threadIdx.x & 63u) != 0u && dl1 < 0.02f);
+    // (a `live` mask comes with the inference loop's slot rows — n_step consecutive slots per ray, unfilled ones parked at the
+    //  origin: ray-ordered by construction, though the parked rows break the neighbour test)
+    const uint32_t coherent = (scales.live != nullptr || __popcll(near_mask) >= 16) ? 1u : 0u;  // (wave-uniform)
+    uint32_t todo = plans.p[coherent].mask[xcd][(blockIdx.x / kXcds) % kFwdResidues];  // (wave-uniform) this wave's levels
+    if (todo == 0u) return;
 
     struct LevelState {
         float pos[D];
@@ -1818,7 +1837,7 @@ inline uint32_t xcd_grid(uint32_t B) { return kXcds * div_up<uint32_t>(B, kFwdBl
 #ifndef S3D_FWD_BALANCE  // 0: the round-1 mapping (A/B)
 #define S3D_FWD_BALANCE 1
 #endif
-inline FwdPlan balance_forward_plan(uint32_t L, const LevelScales& sc) {
+inline FwdPlan balance_forward_plan(uint32_t L, const LevelScales& sc, bool balance) {
     FwdPlan p;
     memset(&p, 0, sizeof(p));
     float cost[kMaxLevels], load[kXcds] = {0};
@@ -1836,7 +1855,7 @@ inline FwdPlan balance_forward_plan(uint32_t L, const LevelScales& sc) {
         for (uint32_t k = 0; k < kFwdResidues; k++) if (owner[l][k] == x) return true;
         return false;
     };
-    for (int it = 0; S3D_FWD_BALANCE && it < 1024; it++) {
+    for (int it = 0; S3D_FWD_BALANCE && balance && it < 1024; it++) {
         uint32_t hi = 0;
         for (uint32_t x = 1; x < kXcds; x++) if (load[x] > load[hi]) hi = x;
         uint32_t order[kXcds];
@@ -1887,7 +1906,9 @@ int launch_forward(const float* inputs, const T* emb, const int32_t* offsets, T*
                    uint32_t L, const LevelScales& sc, T* dy_dx, uint32_t gridtype, bool ac, uint32_t interp,
                    hipStream_t st) {
     const dim3 grid(xcd_grid(B)), block(kFwdBlock);
-    const FwdPlan plan = balance_forward_plan(L, sc);
+    FwdPlans plan;
+    plan.p[0] = balance_forward_plan(L, sc, false);
+    plan.p[1] = balance_forward_plan(L, sc, true);
     // lane-pair kernel whenever the feature vector is whole 32-bit words and no input Jacobian is asked for (the training and
     // inference paths of every configuration); k_grid_forward keeps fp16 C = 1 and the Jacobian
     if (!dy_dx && (sizeof(T) * C) % 4 == 0) {
