@@ -1127,6 +1127,10 @@ __device__ unsigned long long s3d_prof_buf[2][16384][8];
 #else
 #define S3D_STAMP(kern, wg, k) do { } while (0)
 #endif
+#ifndef S3D_BIN3_LEAN  // 0: round 3's instruction sequences in the scatter (A/B)
+#define S3D_BIN3_LEAN 1
+#endif
+static_assert(kBinGroup == 32, "the scatter's key arithmetic shifts by 5");
 constexpr uint32_t kBin3Sub = S3D_BIN3_NSUB;
 static_assert(kBin3Sub == 1 || kBin3Sub == 2 || kBin3Sub == 4 || kBin3Sub == 8, "sub-buckets follow the XCD id");
 
@@ -1187,6 +1191,27 @@ __device__ __forceinline__ void seg_scan_wave(float (&v)[N], bool head, uint32_t
 #undef S3D_SEG_STEP
 #undef S3D_SEG_FLAG
 #undef S3D_SEG_STEP4
+
+// the 32-bit value word of a record: the C products rounded to T (fp16 C = 2: one v_cvt_pk_f16_f32, round to nearest even
+// like the two single conversions)
+template <typename T, uint32_t C>
+__device__ __forceinline__ uint32_t pack_record(const float* v) {
+    uint32_t bits;
+    if constexpr (sizeof(T) == 2 && C == 2) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        f2 f;
+        f[0] = v[0]; f[1] = v[1];
+        const h2 h = __builtin_convertvector(f, h2);
+        __builtin_memcpy(&bits, &h, 4);
+    } else {
+        T pr[C];
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) pr[c] = Acc<T>::from_f(v[c]);
+        __builtin_memcpy(&bits, pr, 4);
+    }
+    return bits;
+}
 
 // inclusive wave64 prefix sum by DPP (row_shr inside the 16-lane rows, then the two row_bcast carries)
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v, uint32_t lane) {
@@ -1284,10 +1309,12 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
     float v[K * C];
     float gf[C];
     bool gbad = false;  // a non-finite gradient on an active lane poisons the level (FIXED24)
+    float gmax = 0.0f;  // (NaN-propagating: v_max would drop a NaN operand)
 #pragma unroll
     for (uint32_t c = 0; c < C; c++) {
         gf[c] = active ? Acc<T>::to_f(g[c]) : 0.0f;  // (inactive lanes: zero products, whatever their position)
         gbad |= !(fabsf(gf[c]) <= 3.402823466e38f);
+        gmax = (fabsf(gf[c]) > gmax || gf[c] != gf[c]) ? fabsf(gf[c]) : gmax;
     }
 #pragma unroll
     for (uint32_t idx = 0; idx < K; idx++) {
@@ -1321,31 +1348,50 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
         // conversion), 1 = larger values present (general conversion), NaN pattern = a record is non-finite after rounding
         // to binary16 (|sum| >= 65520 or a non-finite gradient): the level is poisoned like a float sum would be.
         // One maximum per lane instead of a test per record; at most one atomic per wave.
-        float m = 0.0f;
+        // (|w| <= 1 and a run has at most 64 lanes: a wave whose gradients all lie below 1 in magnitude cannot hold a record of
+        //  64 or more — one maximum and one ballot instead of 2^D x C maxima; NaN fails the comparison and takes the full test)
+        if (S3D_BIN3_LEAN == 0 || __ballot(!(gmax < 1.0f)) != 0ull) {
+            float m = 0.0f;
 #pragma unroll
-        for (uint32_t i = 0; i < K * C; i++) m = fmaxf(m, fabsf(v[i]));
-        const bool bad = (active && gbad) || (tail && m >= 65520.0f);
-        const bool big = tail && m >= 64.0f;
-        const unsigned long long anybad = __ballot(bad), anybig = __ballot(big);
-        if ((anybad | anybig) && lane == 0) atomicMax(hdr + level, anybad ? 0x7fc00000u : 1u);
+            for (uint32_t i = 0; i < K * C; i++) m = fmaxf(m, fabsf(v[i]));
+            const bool bad = (active && gbad) || (tail && m >= 65520.0f);
+            const bool big = tail && m >= 64.0f;
+            const unsigned long long anybad = __ballot(bad), anybig = __ballot(big);
+            if ((anybad | anybig) && lane == 0) atomicMax(hdr + level, anybad ? 0x7fc00000u : 1u);
+        }
     }
     if (tail) {
-        uint32_t lo_[D];
+        uint32_t row[K];
+        if (S3D_BIN3_LEAN && li.hashed && li.pow2) {
+            // (level-uniform branch) hashed level of power-of-two size: the 2^D rows are XORs of 2 D terms, one mask each —
+            // no select between the dense and the hashed rule, no division path
+            uint32_t t0[D], t1[D];
 #pragma unroll
-        for (uint32_t d = 0; d < D; d++) lo_[d] = pg[d] * li.mul[d];
+            for (uint32_t d = 0; d < D; d++) {
+                t0[d] = pg[d] * kPrimes[d];
+                t1[d] = t0[d] + kPrimes[d];
+            }
+#pragma unroll
+            for (uint32_t idx = 0; idx < K; idx++) {
+                uint32_t r = (idx & 1u) ? t1[0] : t0[0];
+#pragma unroll
+                for (uint32_t d = 1; d < D; d++) r ^= ((idx >> d) & 1u) ? t1[d] : t0[d];
+                row[idx] = r & li.mask;
+            }
+        } else {
+            uint32_t lo_[D];
+#pragma unroll
+            for (uint32_t d = 0; d < D; d++) lo_[d] = pg[d] * li.mul[d];
+#pragma unroll
+            for (uint32_t idx = 0; idx < K; idx++) row[idx] = li.row(lo_, idx);
+        }
+        const uint32_t hshift = sshift + 5;  // (kBinGroup == 32)
 #pragma unroll
         for (uint32_t idx = 0; idx < K; idx++) {
-            const uint32_t row = li.row(lo_, idx);
-            const uint32_t grp = row / kBinGroup;
-            const uint32_t slice = grp & (S - 1);
-            T pr[C];
-#pragma unroll
-            for (uint32_t c = 0; c < C; c++) pr[c] = Acc<T>::from_f(v[idx * C + c]);
-            uint32_t bits;
-            __builtin_memcpy(&bits, pr, 4);
-            key[idx] = (slice << 16) | ((grp >> sshift) * kBinGroup + row % kBinGroup);
+            const uint32_t slice = (row[idx] >> 5) & (S - 1);
+            key[idx] = (slice << 16) | ((row[idx] >> hshift) << 5) | (row[idx] & 31u);
             rank[idx] = atomicAdd(&cnt[slice], 1u);
-            val[idx] = bits;
+            val[idx] = pack_record<T, C>(&v[idx * C]);
         }
     }
     // the last wave to arrive (its arrival is ordered behind every wave's rank atomics) finds the run starts and puts the
@@ -1415,9 +1461,32 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
     uint16_t* const sk = skeys + ((size_t)lip * nchunks + chunk) * (P * K);
     uint32_t* const sv = svals + ((size_t)lip * nchunks + chunk) * (P * K);
     constexpr uint32_t UC = 4;
-    if (!spilled_s) {
+    if (S3D_BIN3_LEAN && !spilled_s) {
         // every run fits its bucket (the rule; tested once per workgroup, not per record): position = sorted index + the
-        // run's bucket offset
+        // run's bucket offset.  Whole trips of UC x P records carry no per-record range test (the trip count is uniform);
+        // the remainder goes one record per lane and trip.
+        uint32_t base = 0;
+        for (; base + UC * P <= total; base += UC * P) {
+            uint2 r[UC];
+            uint32_t gd[UC];
+#pragma unroll
+            for (uint32_t u = 0; u < UC; u++) r[u] = stage[base + threadIdx.x + u * P];
+#pragma unroll
+            for (uint32_t u = 0; u < UC; u++) gd[u] = tab[r[u].y >> 16].x;
+#pragma unroll
+            for (uint32_t u = 0; u < UC; u++) {
+                const uint32_t p = base + threadIdx.x + u * P + gd[u];  // (mod 2^32: gd = bucket position - run start)
+                gk[p] = (uint16_t)r[u].y;
+                gv[p] = r[u].x;
+            }
+        }
+        for (uint32_t i = base + threadIdx.x; i < total; i += P) {
+            const uint2 r = stage[i];
+            const uint32_t p = i + tab[r.y >> 16].x;
+            gk[p] = (uint16_t)r.y;
+            gv[p] = r.x;
+        }
+    } else if (!spilled_s) {
         for (uint32_t i0 = threadIdx.x; i0 < total; i0 += UC * P) {
             uint2 r[UC];
             uint32_t gd[UC];
