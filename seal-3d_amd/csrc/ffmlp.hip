@@ -363,9 +363,18 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
                 const float x = dx, y = dy, z = dz;
                 float sh[16], j0[1], j1[1], j2[1];
                 sh_eval<4, false>(x, y, z, mid.K, sh, j0, j1, j2);
-                half8 v;
+                // (two separate half-vectors and a select per element: `h ? sh[8 + i] : sh[i]` is turned into ONE indexed read of
+                //  sh[], i.e. sixteen scratch stores and eight scratch loads per lane and tile)
+                half8 vlo, vhi;
 #pragma unroll
-                for (uint32_t i = 0; i < 8; i++) v[i] = (_Float16)(h ? sh[8 + i] : sh[i]);
+                for (uint32_t i = 0; i < 8; i++) { vlo[i] = (_Float16)sh[i]; vhi[i] = (_Float16)sh[8 + i]; }
+                uint32_t wl[4], wh[4], wv[4];
+                __builtin_memcpy(wl, &vlo, 16);
+                __builtin_memcpy(wh, &vhi, 16);
+#pragma unroll
+                for (uint32_t i = 0; i < 4; i++) wv[i] = h ? wh[i] : wl[i];
+                half8 v;
+                __builtin_memcpy(&v, wv, 16);
                 *reinterpret_cast<half8*>(Tm + n * kMidRow + 8 * h) = v;
             }
             __builtin_amdgcn_wave_barrier();
