@@ -285,6 +285,35 @@ class FFMLP(nn.Module):
         dims = (self.input_dim, self.hidden_dim, self.num_layers, self.activation, self.output_activation)
         return _FFMLPNgpMid.apply(inputs, w, dirs, dims, not self.training, ref, hook, 1 if level_major else 0, n_valid)
 
+    def _inference_weights(self):
+        """fp16 weights for a call that takes no gradient: the optimizer's copy while it is current, else one cast per version"""
+        w = self.weights
+        if getattr(w, "_s3d_grad", None) is not None and getattr(w, "_s3d_half_version", None) == w._version:
+            return w._s3d_half
+        return _cached_half(w) if w.is_cuda else w.half()
+
+    def pair_supported(self, color_net):
+        """can `forward_ngp_pair` serve this density network with `color_net`?  (the one-launch inference kernel: hidden 64,
+        32-wide inputs, ReLU, 16-column outputs)"""
+        return (self.hidden_dim == 64 and color_net.hidden_dim == 64 and self.input_dim == 32 and color_net.input_dim == 32
+                and self.padded_output_dim == 16 and color_net.padded_output_dim == 16
+                and self.activation == 0 and color_net.activation == 0 and self.output_activation == 6
+                and color_net.output_activation == 6)
+
+    @torch.no_grad()
+    def forward_ngp_pair(self, inputs, dirs, color_net, level_major=False, n_valid=None):
+        """inference only: density network + head + colour network + sigmoid in ONE launch (s3d_ffmlp_ngp_pair_inference):
+        returns (sigma f32 [B], rgb f32 [B, 3]) — the same bits as forward_ngp_mid followed by color_net.forward_rgb"""
+        B = inputs.shape[1] if level_major else inputs.shape[0]
+        if B % 128 != 0 or not self.pair_supported(color_net):
+            raise RuntimeError("FFMLP.forward_ngp_pair: needs B % 128 == 0 and two 64-wide ReLU networks with 32 inputs / 16 outputs")
+        sigma = torch.empty(B, dtype=torch.float32, device=inputs.device)
+        rgb = torch.empty(B, 3, dtype=torch.float32, device=inputs.device)
+        _backend.ngp_pair_inference(inputs.contiguous(), self._inference_weights(), color_net._inference_weights(), B,
+                                    self.hidden_dim, self.num_layers, color_net.num_layers, dirs.float().contiguous(), sigma, rgb,
+                                    1 if level_major else 0, n_valid)
+        return sigma, rgb
+
     def forward_rgb(self, inputs, n_valid=None):
         """the colour network with its head: fp32 [B, 3] = sigmoid(net(inputs)[:, :3]) from ONE launch (B % 128 == 0)"""
         if inputs.shape[0] % 128 != 0:

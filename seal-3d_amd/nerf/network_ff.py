@@ -88,6 +88,7 @@ class NeRFNetwork(NeRFRenderer):
         return torch.sigmoid(self.color_net(torch.cat([d, geo_feat, pad], dim=-1)))
 
     fused_head = os.environ.get("S3D_FUSED_HEAD", "1") != "0"  # tests / A-B runs: False = the reference op sequence
+    fused_pair = os.environ.get("S3D_FUSED_PAIR", "1") != "0"  # A-B runs: False = one launch per network in the inference loop
     fused_mid = os.environ.get("S3D_FUSED_MID", "1") != "0"    # A-B runs: False = separate mid kernels between the two MLPs
 
     def honours_row_limit(self, rows):
@@ -122,6 +123,10 @@ class NeRFNetwork(NeRFRenderer):
                 # inference loop: unused sample slots (deltas == 0, announced by the renderer) skip the table gathers
                 live = None if (self.training or torch.is_grad_enabled()) else s3d_hip.active_live_rows(x.shape[0])
                 enc = self.encoder(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
+                if (self.fused_pair and not torch.is_grad_enabled() and self.fused_mid and self.sigma_net.rgb_head_supported()
+                        and self.color_net.rgb_head_supported() and self.sigma_net.pair_supported(self.color_net)):
+                    # inference: both networks and both heads in one launch — the colour-net input never leaves the chip
+                    return self.sigma_net.forward_ngp_pair(enc, d, self.color_net, level_major=True, n_valid=nv)
                 if self.fused_mid and self.sigma_net.rgb_head_supported():  # (same shape condition: the fused backward kernel)
                     # trunc_exp / SH / concat folded into the density network's last layer (and its backward's first load)
                     sigma, cin = self.sigma_net.forward_ngp_mid(enc, d, level_major=True, n_valid=nv)

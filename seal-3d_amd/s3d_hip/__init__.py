@@ -36,7 +36,7 @@ EXPORTS = [
     "s3d_grid_encode_backward_workspace_size", "s3d_grid_encode_backward_control_size",
     "s3d_grad_total_variation",
     "s3d_sh_encode_forward", "s3d_sh_encode_backward", "s3d_freq_encode_forward", "s3d_freq_encode_backward",
-    "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
+    "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_ngp_pair_inference", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
     "s3d_ffmlp_fused_backward_supported",
     "s3d_ffmlp_allocate_splitk", "s3d_ffmlp_free_splitk",
     "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_step_multi", "s3d_adam_advance", "s3d_scaler_update", "s3d_step_ring_push", "s3d_step_epilogue",
@@ -557,6 +557,19 @@ class FFMLPBackend:
                                          _u(hidden_dim), _u(num_layers), _u(activation), _u(output_activation),
                                          _p(inference_buffer), _p(outputs), C.c_int(int(input_layout)), _nv(n_valid),
                                          _p(rgb_head), *_mid_fwd_args(mid, B), _stream()), "ffmlp_inference")
+
+    @staticmethod
+    def ngp_pair_inference(inputs, weights_sigma, weights_color, B, hidden_dim, num_layers_sigma, num_layers_color, dirs,
+                           sigma, rgb, input_layout=0, n_valid=None, color_in=None):
+        """density network + head + colour network + sigmoid in one launch (seal3d_hip.h: s3d_ffmlp_ngp_pair_inference)"""
+        for t, n in ((inputs, "inputs"), (weights_sigma, "weights_sigma"), (weights_color, "weights_color")):
+            _need(t, torch.float16, n)
+        for t, n in ((dirs, "dirs"), (sigma, "sigma"), (rgb, "rgb")):
+            _need(t, torch.float32, n)
+        _check(lib().s3d_ffmlp_ngp_pair_inference(_p(inputs), _p(weights_sigma), _p(weights_color), _u(B), _u(hidden_dim),
+                                                  _u(num_layers_sigma), _u(num_layers_color), C.c_int(int(input_layout)),
+                                                  _nv(n_valid), _p(dirs), _p(sigma), _p(rgb), _p(color_in), _stream()),
+               "ffmlp_ngp_pair_inference")
 
     @staticmethod
     def fused_backward_supported(input_dim, output_dim, hidden_dim, num_layers, activation):

@@ -222,6 +222,36 @@ def test_density_head_in_the_mlp_kernels_is_the_mid_kernel_sequence_bit_for_bit(
         assert torch.equal(s1[:rows], s_b) and torch.equal(c1[:rows], c_b)
 
 
+@pytest.mark.parametrize("B", [128, 128 * 37, 128 * 2100])
+def test_ngp_pair_matches_the_two_launches(hip, B):
+    """FFMLP.forward_ngp_pair (s3d_ffmlp_ngp_pair_inference: density net + head + colour net + sigmoid in one launch, the
+    inference loop's call) against forward_ngp_mid + forward_rgb: sigma bit for bit; rgb bit for bit except where the SH
+    columns of the colour-net input differ by one fp16 ulp (a third inlined copy of sh_eval — see the density-head test)"""
+    from ffmlp import FFMLP
+    torch.manual_seed(11)
+    sig, col = FFMLP(32, 16, 64, 2).cuda().eval(), FFMLP(32, 3, 64, 3).cuda().eval()
+    assert sig.pair_supported(col)
+    x = torch.randn(16, B, 2, device="cuda").half()  # level-major encoder output
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device="cuda"), dim=-1)
+    for nv in (None, torch.tensor([max(B - 300, 77)], dtype=torch.int32, device="cuda")):
+        rows = B if nv is None else min(B, (int(nv) + 127) // 128 * 128)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+            s_a, cin = sig.forward_ngp_mid(x, d, level_major=True, n_valid=nv)
+            rgb_a = col.forward_rgb(cin, n_valid=nv)
+            s_b, rgb_b = sig.forward_ngp_pair(x, d, col, level_major=True, n_valid=nv)
+        assert torch.equal(s_a[:rows], s_b[:rows])
+        assert rgb_b.dtype == torch.float32 and rgb_b.shape == (B, 3)
+        diff = (rgb_a[:rows] != rgb_b[:rows]).any(-1).float().mean()
+        assert float(diff) < 2e-3, float(diff)
+        torch.testing.assert_close(rgb_b[:rows], rgb_a[:rows], rtol=0, atol=4e-3)
+        assert float(rgb_a[:rows].std()) > 1e-3
+    x_row = x.permute(1, 0, 2).reshape(B, 32).contiguous()  # row-major inputs take the same kernel
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        s_c, rgb_c = sig.forward_ngp_pair(x_row, d, col)
+        s_d, rgb_d = sig.forward_ngp_pair(x, d, col, level_major=True)
+    assert torch.equal(s_c, s_d) and torch.equal(rgb_c, rgb_d)
+
+
 @pytest.mark.parametrize("W,in_dim,n", [(16, 32, 2), (128, 32, 3), (256, 64, 2), (64, 128, 2)])
 def test_ffmlp_module_other_widths_train_like_the_torch_twin(hip, W, in_dim, n):
     """`FFMLP` with the hidden widths ffmlp.cu:40-44 dispatches beside 32 / 64 (and an input wider than 64): forward, input
