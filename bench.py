@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--force_dp", action="store_true", help="run the data-parallel path (flat-bucket all-reduce, split graphs) on 1 GPU")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_render", action="store_true")
+    ap.add_argument("--save_model", default=None, help="write the trained model's state_dict here after the timed region "
+                    "(tools/profile_render.sh renders THIS model under rocprofv3)")
     ap.add_argument("--infer_batch_scale", type=int, default=4, help="inference samples/ray/iteration multiplier (1 = reference heuristic)")
     ap.add_argument("--cpu_steps", type=int, default=5, help="timed CPU-baseline steps (median), after --cpu_warmup warm-ups (BASELINE.md §3: 2 + 5)")
     ap.add_argument("--cpu_warmup", type=int, default=2)
@@ -389,6 +391,12 @@ def seal_section(args, dev, batches, note=lambda m: None):
         tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
         samples.add_(student.step_counter[(student.local_step - 1) % 16, 0].long())
     step = sync_time(ft, 32)
+
+    def proxy_replay(i):  # the proxy render as the fine-tuning step runs it: rays staged, its own HIP graph replayed
+        b = batches[i % len(batches)]
+        torch._foreach_copy_([tr.s_ro, tr.s_rd], [b[0].reshape(-1, 3), b[1].reshape(-1, 3)])
+        tr._proxy_replay()
+    proxy_graph = sync_time(proxy_replay, 16) if tr.proxy_graph is not None else None
     targets = [tr.proxy_truth(b[0], b[1]) for b in batches[:8]]
     samples2 = torch.zeros(1, dtype=torch.int64, device=dev)
 
@@ -401,6 +409,10 @@ def seal_section(args, dev, batches, note=lambda m: None):
             "local_points": int(n_local),
             "seal_pretrain_points_per_s": n_local / ep, "pretrain_ms_per_epoch": ep * 1e3, "pretrain_loss_first_last": [l0, l1],
             "proxy_truth_mrays_per_s": args.num_rays / proxy / 1e6, "proxy_truth_ms_per_batch": proxy * 1e3,
+            "proxy_truth_note": "eager call of SealSteps.proxy_truth (host launches); inside the fine-tuning step the render is "
+                                "replayed from its own graph: *_graph_replay",
+            "proxy_truth_ms_per_batch_graph_replay": None if proxy_graph is None else proxy_graph * 1e3,
+            "proxy_truth_mrays_per_s_graph_replay": None if proxy_graph is None else args.num_rays / proxy_graph / 1e6,
             "seal_train_samples_per_s": float(samples.item()) / 32 / step, "seal_train_ms_per_step": step * 1e3,
             "seal_train_samples_per_s_cached_targets": float(samples2.item()) / 32 / step_cached,
             "seal_train_ms_per_step_cached_targets": step_cached * 1e3,
@@ -697,6 +709,8 @@ def main():
     if ues_ms:
         extra["update_extra_state"] = {"calls_in_timed_region": len(ues_ms), "ms_per_call": sum(ues_ms) / len(ues_ms),
                                        "ms_per_step_amortised": sum(ues_ms) / args.steps}
+    if args.save_model and rank == 0:
+        torch.save(model.state_dict(), args.save_model)
     if not args.no_render:
         # full 800x800 frame renders (inference loop) + PSNR against the analytic scene
         model.infer_batch_scale = args.infer_batch_scale
@@ -730,6 +744,16 @@ def main():
                                         "points_per_frame": pts, "launches_per_frame": rk["calls"],
                                         "grid_forward_ms_per_frame": rk["total_ms"], "frame_ms": dtr * 1e3,
                                         "mrays_per_s": 0.64 / dtr, "algorithmic_bytes_per_point": 588}
+            try:  # every kernel launch of one frame (torch's profiler counts device kernels, native and torch alike)
+                from torch.profiler import ProfilerActivity, profile
+                with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                    trainer.render_image(ro, rd)
+                    torch.cuda.synchronize()
+                extra["roofline_render"]["kernel_launches_per_frame"] = sum(
+                    1 for ev in prof.events() if ev.device_type == torch.autograd.DeviceType.CUDA)
+            except Exception as e:  # (profiler unavailable: the figure is optional)
+                extra["roofline_render"]["kernel_launches_per_frame"] = None
+                extra["roofline_render"]["kernel_launches_note"] = f"torch.profiler failed: {type(e).__name__}"
 
     def note(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)

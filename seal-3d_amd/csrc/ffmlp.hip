@@ -415,12 +415,16 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
 // just built in its LDS staging tile and feeds the colour network from there: same MFMA sequence per network, same rounding
 // points (tests/test_gpu_ffmlp.py::test_ngp_pair_matches_the_two_launches: sigma bit for bit, rgb bit for bit wherever this
 // kernel's inlined copy of sh_eval rounds like the other one's).  W = 64, 32-wide inputs, ReLU.
+#ifndef S3D_PAIR_WAVES  // waves per workgroup of k_ffmlp_ngp_pair (they share one staged copy of both networks' weights)
+#define S3D_PAIR_WAVES 8
+#endif
+constexpr uint32_t kPairWaves = S3D_PAIR_WAVES;
 struct PairNets {
     const _Float16* Ws;   // density network  [64*32 | (nl_s-1)*64*64 | 16*64]
     const _Float16* Wc;   // colour network   [64*32 | (nl_c-1)*64*64 | 16*64]
     uint32_t nl_s, nl_c;  // hidden layers of each
 };
-__global__ void __launch_bounds__(256) k_ffmlp_ngp_pair(const _Float16* __restrict__ X, const PairNets nets, uint32_t B,
+__global__ void __launch_bounds__(kPairWaves * 64) k_ffmlp_ngp_pair(const _Float16* __restrict__ X, const PairNets nets, uint32_t B,
                                                        uint32_t in_layout, const int32_t* __restrict__ n_valid,
                                                        float* __restrict__ rgb_head, const MidFwd mid) {
     constexpr uint32_t W = 64, MB = 2, KS = 4, KP = 2, IN = 32;
@@ -435,7 +439,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_ngp_pair(const _Float16* __restri
 
     // stage both networks' weights as A fragments (k_ffmlp_forward's directory, the colour network behind the density network)
 #pragma unroll 1
-    for (uint32_t f0 = wave; f0 < tot_s + tot_c; f0 += 4) {
+    for (uint32_t f0 = wave; f0 < tot_s + tot_c; f0 += kPairWaves) {
         const bool second = f0 >= tot_s;
         const uint32_t f = second ? f0 - tot_s : f0, NH = second ? NHc : NHs;
         const _Float16* Wt = second ? nets.Wc : nets.Ws;
@@ -460,7 +464,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_ngp_pair(const _Float16* __restri
     __syncthreads();
 
     const uint32_t ntiles = valid_rows(B, n_valid) / 32;
-    const uint32_t tstride = gridDim.x * 4;
+    const uint32_t tstride = gridDim.x * kPairWaves;
     half8 bin[KP];
     float dir[3] = {0.0f, 0.0f, 0.0f};
     auto request = [&](uint32_t t, half8 (&dst)[KP], float (&d)[3]) {
@@ -504,7 +508,7 @@ __global__ void __launch_bounds__(256) k_ffmlp_ngp_pair(const _Float16* __restri
         for (uint32_t s = 0; s < KS; s++) o = mfma(a[s * 64 + lane], bf[s], o);
         return o;
     };
-    uint32_t tile = blockIdx.x * 4 + wave;
+    uint32_t tile = blockIdx.x * kPairWaves + wave;
     if (tile < ntiles) request(tile, bin, dir);
     for (; tile < ntiles; tile += tstride) {
         const size_t row = (size_t)tile * 32 + n;
@@ -1702,17 +1706,18 @@ S3D_EXPORT int s3d_ffmlp_ngp_pair_inference(const uint16_t* inputs, const uint16
     host_sh_norm(4, mid.K);
     PairNets nets{(const _Float16*)weights_sigma, (const _Float16*)weights_color, num_layers_sigma, num_layers_color};
     const uint32_t nfr = 2 * (4 + 4) + (num_layers_sigma - 1 + num_layers_color - 1) * 8;
-    const size_t smem = (size_t)nfr * 64 * sizeof(half8) + (size_t)4 * 32 * kMidRow * sizeof(_Float16);
+    const size_t smem = (size_t)nfr * 64 * sizeof(half8) + (size_t)kPairWaves * 32 * kMidRow * sizeof(_Float16);
     static std::atomic<uint64_t> attr_devs{0};
     int dev;
     if (device_needs_setup(attr_devs, &dev)) {
         S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_ngp_pair), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)((2 * 8 + 2 * (kMaxMlpLayers - 2) * 8) * 1024 + 4 * 32 * kMidRow * 2)));
+                                    (int)((2 * 8 + 2 * (kMaxMlpLayers - 2) * 8) * 1024 + kPairWaves * 32 * kMidRow * 2)));
         device_setup_done(attr_devs, dev);
     }
-    uint32_t grid = div_up<uint32_t>(B / 32, 4);
-    if (grid > 768) grid = 768;
-    hipLaunchKernelGGL(k_ffmlp_ngp_pair, dim3(grid), dim3(256), smem, as_stream(stream), (const _Float16*)inputs, nets, B,
+    uint32_t grid = div_up<uint32_t>(B / 32, kPairWaves);
+    const uint32_t cap = 3072 / kPairWaves;  // (as k_ffmlp_forward: 3,072 waves = three per SIMD)
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(k_ffmlp_ngp_pair, dim3(grid), dim3(kPairWaves * 64), smem, as_stream(stream), (const _Float16*)inputs, nets, B,
                        (uint32_t)input_layout, n_valid, rgb, mid);
     return check_launch("ffmlp_ngp_pair_inference");
 }

@@ -6,7 +6,8 @@ TAG=${1:-r07}
 FRAMES=5
 mkdir -p "$ROOT/gpurun_out/profiles_out"
 cd /tmp && export TMPDIR=/tmp
-python "$ROOT/tools/render_frames.py" --save /tmp/s3d_model.pth > /tmp/render_train.log 2>&1 || { tail -5 /tmp/render_train.log; exit 1; }
+# the model bench.py renders: its default run up to the end of the timed region (same seed, pretrain count, steps)
+python "$ROOT/bench.py" --no_cpu_baseline --no_seal --no_long_run --no_render --save_model /tmp/s3d_model.pth > /tmp/render_train.log 2>&1 || { tail -5 /tmp/render_train.log; exit 1; }
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/render_prof -- python "$ROOT/tools/render_frames.py" --load /tmp/s3d_model.pth --frames $FRAMES > /tmp/render_prof.log 2>&1
 LINE=$(grep "render 800x800" /tmp/render_prof.log | tail -1)
 F=$(find /tmp/render_prof -name "*kernel_stats.csv" | head -1)
@@ -17,7 +18,7 @@ rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"# rocprofv3 kernel trace `{tag}` — render-only workload (`tools/render_frames.py`, `tools/profile_render.sh`)\n")
 print(f"{line}\n")
-print(f"800x800 frame of the bench model (400 training steps on the synthetic scene), `NeRFRenderer.run_cuda` inference loop, "
+print(f"800x800 frame of the model `bench.py` renders (its default run: 384 pretraining + 16 warm-up + 64 timed steps, saved with `--save_model`), `NeRFRenderer.run_cuda` inference loop, "
       f"infer_batch_scale 4, sync_every 4; {frames} frames in the trace (one warm-up).  GPU kernel time per frame: {tot/frames/1e6:.2f} ms.\n")
 print("| kernel | launches/frame | us/launch | ms/frame | % of kernel time |")
 print("|---|---|---|---|---|")
