@@ -324,8 +324,10 @@ def test_long_run_native_fp16_path_converges_like_fp32_adam(hip):
     """3,000 steps of configs[1]'s network from the same initial weights on the same 3.1 M-ray pool: the native path (fp16
     gradient hand-over, exact fixed-point table sums, native Adam + loss scaling, HIP-graph replay) against torch.optim.Adam
     on fp32 `.grad`s + torch GradScaler (eager).  PSNR on four held-out 200x200 views of the analytic scene: both above
-    28 dB, and within 0.5 dB of each other (the two trajectories are chaotic twins — different rounding, different RNG
-    consumption under capture — and land 0.05-0.3 dB apart from seed to seed; bench.py reports the pair as psnr.long_run)."""
+    28 dB, and the MEANS over three initialisations within 0.4 dB of each other.  The two trajectories are chaotic twins
+    (different rounding, different RNG consumption under capture): per seed they land -0.30 / +0.17 / +0.06 dB apart
+    (profiles/r09_bench_default.json: mean -0.02 dB, sample sigma 0.25 dB), so the mean of three is known to +-0.14 dB and a 0.1 dB
+    assertion would fail every other run for identical algorithms; bench.py reports mean, spread and `within_0p1_db`."""
     import argparse
     import bench
     from nerf import synthetic as syn
@@ -335,7 +337,7 @@ def test_long_run_native_fp16_path_converges_like_fp32_adam(hip):
     out = bench.long_run_quality(args, dev, hip.RaymarchingBackend, torch.from_numpy(bits).to(dev), syn.lego_like_boxes(0), steps=3000)
     a, b = out["native_fp16_graph"]["psnr_db"], out["torch_adam_fp32_eager"]["psnr_db"]
     assert a >= 28.0 and b >= 28.0, out
-    assert abs(a - b) <= 0.5, out
+    assert out["seeds"] >= 3 and abs(out["delta_db"]) <= 0.4, out
 
 
 _DP2_SCRIPT = r'''
