@@ -91,7 +91,8 @@ int s3d_sweep_update(float* density_grid, uint32_t n_cells, const int32_t* cells
  *                                        nears, fars, xyzs, dirs, deltas, rays, counter, noises)
  * Spans are packed in RAY ORDER (deterministic; one valid outcome of the reference's atomic
  * reservation, raymarching.cu:405-406).  counter[0] += total samples, counter[1] += N.
- * path (kernel choice, same results): 0 = auto (wave-per-ray up to 16,384 rays), 1 = lane-per-ray, 2 = wave-per-ray.
+ * path (kernel choice, same results): 0 = auto (wave-per-ray up to 16,384 rays), 1 = lane-per-ray, 2 = wave-per-ray,
+ *   3 = wave-per-ray without the single-cascade fast path (its morton table, batched probes and voxel-run shortcut).
  * Rows no ray fills are written as zeros where a consumer bounded by the device-side count (`n_valid`: the count rounded
  * up to 128 rows, at most M) still reads them: [total, round_up(total, 128)) and, for the one ray that straddles the
  * budget (offset < M < offset + steps, dropped like in the reference), [offset, M).  The reference zero-fills all M rows

@@ -288,33 +288,45 @@ __device__ __forceinline__ int mip_level(float x, float y, float z, float dt, co
     return la > lb ? la : lb;
 }
 
-// Probe the grid at parameter t.  Returns occupancy; x,y,z,dt always valid; t_skip valid when !occ.
-__device__ __forceinline__ bool probe(const Ray& r, const MarchParams& p, float t, float& x, float& y, float& z,
-                                      float& dt, float& t_skip) {
-    x = clampf(__builtin_fmaf(t, r.dx, r.ox), -p.bound, p.bound);
-    y = clampf(__builtin_fmaf(t, r.dy, r.oy), -p.bound, p.bound);
-    z = clampf(__builtin_fmaf(t, r.dz, r.oz), -p.bound, p.bound);
-    dt = clampf(t * p.dt_gamma, p.dt_min, p.dt_max);
-    const int level = mip_level(x, y, z, dt, p);
-    const float mip_bound = fminf(ldexpf(1.0f, level), p.bound);
-    const float mip_rbound = 1 / mip_bound;
+// Cell of the grid at parameter t (raymarching.cu:358-372): position, step, cascade, cell coordinates; returns the bit index.
+struct ProbeCell {
+    float x, y, z, dt, mip_bound;
+    int nx, ny, nz;
+};
+__device__ __forceinline__ uint32_t probe_cell(const Ray& r, const MarchParams& p, float t, ProbeCell& c) {
+    c.x = clampf(__builtin_fmaf(t, r.dx, r.ox), -p.bound, p.bound);
+    c.y = clampf(__builtin_fmaf(t, r.dy, r.oy), -p.bound, p.bound);
+    c.z = clampf(__builtin_fmaf(t, r.dz, r.oz), -p.bound, p.bound);
+    c.dt = clampf(t * p.dt_gamma, p.dt_min, p.dt_max);
+    const int level = mip_level(c.x, c.y, c.z, c.dt, p);
+    c.mip_bound = fminf(ldexpf(1.0f, level), p.bound);
+    const float mip_rbound = 1 / c.mip_bound;
     // raymarching.cu:366-368 `0.5 * (x * mip_rbound + 1) * H` is a DOUBLE product of the float v = fma(x, mip_rbound, 1) (24
     // significant bits) with the integer H <= 1,024: v * H / 2 has at most 35 bits, so the double holds the exact real number
     // and the conversion back to float rounds it once — which is what ONE fp32 multiply of v by the exactly representable
     // constant H / 2 does as well (IEEE: the correctly rounded exact product).  Bit-identical cells, no fp64 on the hot loop
     // (quarter-rate on CDNA; the wave-per-ray count kernel spent a tenth of its 2,797 vector instructions here).
-    const int nx = (int)clampf(__builtin_fmaf(x, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);
-    const int ny = (int)clampf(__builtin_fmaf(y, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);
-    const int nz = (int)clampf(__builtin_fmaf(z, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);
-    const uint32_t index = (uint32_t)((float)level * p.H3 + (float)morton3d((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+    c.nx = (int)clampf(__builtin_fmaf(c.x, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);
+    c.ny = (int)clampf(__builtin_fmaf(c.y, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);
+    c.nz = (int)clampf(__builtin_fmaf(c.z, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);
+    return (uint32_t)((float)level * p.H3 + (float)morton3d((uint32_t)c.nx, (uint32_t)c.ny, (uint32_t)c.nz));
+}
+// parameter at which the ray leaves the (empty) cell of `c` (raymarching.cu:388-394)
+__device__ __forceinline__ float probe_exit(const Ray& r, const MarchParams& p, float t, const ProbeCell& c) {
+    const float sx = copysignf(1.0f, r.dx), sy = copysignf(1.0f, r.dy), sz = copysignf(1.0f, r.dz);
+    const float tx = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.5f, sx, (float)c.nx + 0.5f) * p.rH, 2.0f, -1.0f), c.mip_bound, -c.x) * r.rdx;
+    const float ty = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.5f, sy, (float)c.ny + 0.5f) * p.rH, 2.0f, -1.0f), c.mip_bound, -c.y) * r.rdy;
+    const float tz = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.5f, sz, (float)c.nz + 0.5f) * p.rH, 2.0f, -1.0f), c.mip_bound, -c.z) * r.rdz;
+    return t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+}
+// Probe the grid at parameter t.  Returns occupancy; x,y,z,dt always valid; t_skip valid when !occ.
+__device__ __forceinline__ bool probe(const Ray& r, const MarchParams& p, float t, float& x, float& y, float& z,
+                                      float& dt, float& t_skip) {
+    ProbeCell c;
+    const uint32_t index = probe_cell(r, p, t, c);
+    x = c.x; y = c.y; z = c.z; dt = c.dt;
     const bool occ = (p.grid[index >> 3] & (1u << (index & 7u))) != 0;
-    if (!occ) {
-        const float sx = copysignf(1.0f, r.dx), sy = copysignf(1.0f, r.dy), sz = copysignf(1.0f, r.dz);
-        const float tx = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.5f, sx, (float)nx + 0.5f) * p.rH, 2.0f, -1.0f), mip_bound, -x) * r.rdx;
-        const float ty = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.5f, sy, (float)ny + 0.5f) * p.rH, 2.0f, -1.0f), mip_bound, -y) * r.rdy;
-        const float tz = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(0.5f, sz, (float)nz + 0.5f) * p.rH, 2.0f, -1.0f), mip_bound, -z) * r.rdz;
-        t_skip = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
-    }
+    if (!occ) t_skip = probe_exit(r, p, t, c);
     return occ;
 }
 
@@ -430,8 +442,11 @@ constexpr uint32_t kWin = 1024;
 constexpr uint16_t kOcc = 0xFFFF;
 // workspace (wave path): u32 base | u32 pad[3] | u32 counts[N] | float tsamples[N * max_steps]
 
-template <bool CONST_DT>
-__global__ void __launch_bounds__(64) k_march_count_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+#ifndef S3D_MARCH_SHORTCUT  // 0: always pointer doubling (A/B)
+#define S3D_MARCH_SHORTCUT 1
+#endif
+template <bool CONST_DT, bool FAST>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_march_count_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                          const uint8_t* __restrict__ grid, float bound, float dt_gamma,
                                                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                                          float* __restrict__ nears, float* __restrict__ fars,
@@ -446,7 +461,13 @@ __global__ void __launch_bounds__(64) k_march_count_wave(const float* __restrict
     __shared__ uint16_t J[2][kWin + 2];     // jump tables of the pointer-doubling rounds
     __shared__ uint32_t mk[64];             // visited bits: entry k = lane + 64 i is bit i of mk[lane] (kWin / 64 + 1 <= 32 bits)
     __shared__ uint32_t s_wn;
+    __shared__ uint32_t lut[FAST ? 128 : 1];  // FAST: spread coordinates of the morton code (H <= 128)
     const uint32_t n = blockIdx.x, lane = threadIdx.x;
+    if constexpr (FAST) {
+        lut[lane] = expand_bits(lane);
+        lut[lane + 64] = expand_bits(lane + 64);
+        // (made visible by the window loop's first barrier, in front of the probes)
+    }
     const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
     const Ray r = load_ray(rays_o, rays_d, n);
     float far, t_carry, noise;
@@ -548,17 +569,80 @@ __global__ void __launch_bounds__(64) k_march_count_wave(const float* __restrict
         const uint32_t wn = s_wn;
         // ---- B: probe every t_k
         uint32_t occm = 0;  // bit i: entry lane + 64 i is occupied
-        for (uint32_t k = lane; k < wn; k += 64) {
-            float x, y, z, dt, tt;
-            uint16_t e = kOcc;
-            if (!probe(r, p, T[k], x, y, z, dt, tt)) {
-                uint32_t m = k + 1;
-                while (m < wn && T[m] < tt) m++;
-                e = (uint16_t)m;  // == wn: leaves the window (carry) or the ray (T[wn] >= far)
-            } else {
-                occm |= 1u << (k >> 6);
+        uint32_t headm = 0;         // FAST: bit i: entry lane + 64 i is the first of its voxel crossing (its cell differs from entry k - 1's)
+        // first m in (k, wn] with T[m] >= tt (m == wn: leaves the window (carry) or the ray, T[wn] >= far): the index starts
+        // from the arithmetic estimate (the sequence advances by nearly constant steps) and is walked to the exact entry
+        auto skip_index = [&](uint32_t k, float tk, float tt) {
+            const float t1 = T[k + 1];
+            const float est = (tt - t1) / fmaxf(t1 - tk, 1e-30f);
+            uint32_t m = k + 1 + (est > 0.0f ? (est < (float)kWin ? (uint32_t)est : kWin) : 0u);
+            m = m < wn ? m : wn;
+            while (m > k + 1 && !(T[m - 1] < tt)) m--;
+            while (m < wn && T[m] < tt) m++;
+            return (uint16_t)m;
+        };
+        if constexpr (FAST) {
+            // one cascade, H <= 128 (every BASELINE configuration): no cascade arithmetic, morton codes from an LDS table of spread
+            // coordinates, and TWO passes — the bitfield bytes of all of the lane's probes are requested before the first one is
+            // looked at (no branch around the loads: entries past the window hold stale parameters, whose clamped cell is in range
+            // all the same), then the exit parameter and skip index of the empty ones from the packed cell.  The kernel shares
+            // a SIMD with three other rays' waves and this phase is issue-bound: ~55 instead of ~105 vector instructions per probe
+            // (eight probes per batch: sixteen would hold 168 VGPRs — three waves per SIMD, i.e. the 4,096 rays of a batch in two
+            //  rounds instead of one)
+            constexpr uint32_t kBatch = 8;
+            const float mip_bound = fminf(1.0f, p.bound), mip_rbound = 1 / mip_bound;
+            uint32_t prev_last = 0xffffffffu;  // (wave-uniform) cell of entry 64 i - 1
+#pragma unroll 1
+            for (uint32_t b0 = 0; b0 * 64 < wn; b0 += kBatch) {  // (uniform trip count; not unrolled: the batches must not merge)
+                uint32_t bits[kBatch], idx[kBatch], cell[kBatch];
+#pragma unroll
+                for (uint32_t j = 0; j < kBatch; j++) {
+                    const float t = T[lane + 64 * (b0 + j)];
+                    const float x = clampf(__builtin_fmaf(t, r.dx, r.ox), -p.bound, p.bound);
+                    const float y = clampf(__builtin_fmaf(t, r.dy, r.oy), -p.bound, p.bound);
+                    const float z = clampf(__builtin_fmaf(t, r.dz, r.oz), -p.bound, p.bound);
+                    const uint32_t nx = (uint32_t)(int)clampf(__builtin_fmaf(x, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);
+                    const uint32_t ny = (uint32_t)(int)clampf(__builtin_fmaf(y, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);
+                    const uint32_t nz = (uint32_t)(int)clampf(__builtin_fmaf(z, mip_rbound, 1.0f) * p.halfH, 0.0f, p.Hm1);
+                    cell[j] = nx | (ny << 8) | (nz << 16);
+                    idx[j] = (uint32_t)(float)(lut[nx] | (lut[ny] << 1) | (lut[nz] << 2));  // raymarching.cu:372: 0 * H3 + (float)morton
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < kBatch; j++) bits[j] = (uint32_t)p.grid[idx[j] >> 3];
+#pragma unroll
+                for (uint32_t j = 0; j < kBatch; j++) {
+                    const uint32_t i = b0 + j, k = lane + 64 * i;
+                    uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)cell[j], (int)cell[j], 0x138, 0xF, 0xF, false);  // wave_shr:1
+                    if (lane == 0) prev = prev_last;
+                    prev_last = (uint32_t)__builtin_amdgcn_readlane((int)cell[j], 63);
+                    if (cell[j] != prev) headm |= 1u << i;
+                    if (k < wn) {
+                        uint16_t e = (uint16_t)(k + 1);
+                        if (bits[j] & (1u << (idx[j] & 7u))) {
+                            occm |= 1u << i;
+                        } else {
+                            const float tk = T[k];
+                            ProbeCell c;
+                            c.x = clampf(__builtin_fmaf(tk, r.dx, r.ox), -p.bound, p.bound);
+                            c.y = clampf(__builtin_fmaf(tk, r.dy, r.oy), -p.bound, p.bound);
+                            c.z = clampf(__builtin_fmaf(tk, r.dz, r.oz), -p.bound, p.bound);
+                            c.mip_bound = mip_bound;
+                            c.nx = (int)(cell[j] & 255u); c.ny = (int)((cell[j] >> 8) & 255u); c.nz = (int)(cell[j] >> 16);
+                            e = skip_index(k, tk, probe_exit(r, p, tk, c));
+                        }
+                        J[0][k] = e;
+                    }
+                }
             }
-            J[0][k] = (e == kOcc) ? (uint16_t)(k + 1) : e;
+        } else {
+            for (uint32_t k = lane; k < wn; k += 64) {
+                float x, y, z, dt, tt;
+                uint16_t e = (uint16_t)(k + 1);
+                const float tk = T[k];
+                if (!probe(r, p, tk, x, y, z, dt, tt)) e = skip_index(k, tk, tt);
+                else occm |= 1u << (k >> 6);
+                J[0][k] = e;
+            }
         }
         S3D_TICK(1)
         if (lane == 0) J[0][wn] = (uint16_t)wn;
@@ -571,13 +655,63 @@ __global__ void __launch_bounds__(64) k_march_count_wave(const float* __restrict
         for (int d = 32; d >= 1; d >>= 1) start = min(start, (uint32_t)__shfl_xor((int)start, d, 64));
         pending_tt = -INFINITY;
         __syncthreads();
-        if (lane == 0 && start < wn) mk[start & 63] = 1u << (start >> 6);
+        // ---- C: mark the visited nodes.  Shortcut (FAST): the entries of one voxel crossing are consecutive, an empty voxel's
+        // first entry jumps to the first entry of the next crossing, and inside an occupied voxel every entry is visited — so
+        // the walk visits { k >= start : occupied(k) or first-of-its-voxel(k) } (plus the start itself) whenever every skip
+        // target lands exactly on a voxel's first entry.  That set costs sixteen compares; it is ACCEPTED only if it is closed:
+        // the jump targets of its members (known from phase B) must be exactly the set minus the start — with J[k] > k this
+        // makes it the orbit of the start (each member's predecessor is a smaller member).  A target that lands one entry off
+        // a voxel boundary (rounding of the exit parameter against the cell arithmetic) fails the test and takes the
+        // pointer-doubling rounds below: same marks either way.
+        bool marked = false;
+#ifdef S3D_MARCH_PROFILE
+        uint32_t dbg_vm0 = 0;
+#endif
+        if constexpr (FAST && S3D_MARCH_SHORTCUT) {
+            uint32_t vm = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < kWin / 64; i++) {
+                const uint32_t k = lane + 64 * i;
+                const bool in = k < wn && k >= start;
+                if (in && ((((occm | headm) >> i) & 1u) || k == start)) vm |= 1u << i;
+            }
+            // The candidate V is the orbit of the start for ~199 rays in 200.  It is ACCEPTED when it is closed (J(V) inside V) and
+            // supported (every member but the start is some member's target): with J[k] > k that makes it exactly the orbit (the
+            // smallest member is the start, every other member hangs off a smaller one).  Otherwise a skip target landed one entry
+            // off a voxel boundary: an early landing adds a member the candidate lacks (not closed: V <- V + J(V)), a late one
+            // leaves a voxel's first entry unvisited (closed but unsupported: V <- {start} + J(V) drops it) — a pass or two;
+            // not settled after kMaxPasses: the pointer-doubling rounds below.
+            const uint32_t startbit = (start < wn && (start & 63u) == lane) ? (1u << (start >> 6)) : 0u;
+#ifdef S3D_MARCH_PROFILE
+            dbg_vm0 = vm;
+#endif
+            constexpr uint32_t kMaxPasses = 6;
+            for (uint32_t pass = 0; pass < kMaxPasses && !marked; pass++) {
+#pragma unroll
+                for (uint32_t i = 0; i < kWin / 64; i++) {
+                    if ((vm >> i) & 1u) {
+                        const uint32_t tg = J[0][lane + 64 * i];  // (written by this lane in phase B)
+                        if (tg < wn) atomicOr(&mk[tg & 63], 1u << (tg >> 6));
+                    }
+                }
+                __syncthreads();
+                const uint32_t pm = mk[lane];
+                const bool closed = __ballot((pm & ~vm) != 0u) == 0ull;
+                const bool supported = __ballot((vm & ~startbit & ~pm) != 0u) == 0ull;
+                marked = closed && supported;
+                if (!marked) vm = closed ? (pm | startbit) : (vm | pm);
+                __syncthreads();  // (everyone has read the marks before they are replaced)
+                mk[lane] = marked ? vm : 0u;
+                __syncthreads();
+            }
+        }
+        if (!marked && lane == 0 && start < wn) mk[start & 63] = 1u << (start >> 6);
         __syncthreads();
-        // ---- C: mark the visited nodes by pointer doubling
+        // pointer doubling (always for the general kernel; for FAST only when the shortcut's set was not closed)
         uint32_t cur = 0;
         constexpr uint32_t kPer = kWin / 64 + 1;    // entries per lane (k = lane + 64 i)
         const uint32_t iters = wn / 64 + 1;          // ... of which this window uses the first `iters` (covers k <= wn)
-        for (uint32_t span = 1; span < wn; span <<= 1) {
+        for (uint32_t span = 1; span < wn && !marked; span <<= 1) {
             const uint16_t* Jc = J[cur];
             uint16_t* Jn = J[cur ^ 1];
             uint32_t j1[kPer], j2[kPer];
@@ -601,6 +735,15 @@ __global__ void __launch_bounds__(64) k_march_count_wave(const float* __restrict
             if (start >= wn || J[cur][start] >= wn) break;
         }
         S3D_TICK(2)
+#ifdef S3D_MARCH_PROFILE
+        if (FAST && max_steps >= 256) {  // candidate of the shortcut against the marks that were accepted: size and place of the difference
+            const uint32_t d = mk[lane] ^ dbg_vm0;
+            uint32_t cnt = __popc(d), first = d ? (lane + 64u * (uint32_t)__builtin_ctz(d)) : 0xFFFFu;
+#pragma unroll
+            for (int s2 = 32; s2 >= 1; s2 >>= 1) { cnt += (uint32_t)__shfl_xor((int)cnt, s2, 64); first = min(first, (uint32_t)__shfl_xor((int)first, s2, 64)); }
+            if (lane == 0) { tout[max_steps - 16] = (float)cnt; tout[max_steps - 15] = (float)first; tout[max_steps - 14] = (float)wn; tout[max_steps - 13] = (float)start; }
+        }
+#endif
         // ---- emit the occupied visited samples in order; remember the last visited empty probe
         uint32_t last_empty = kWin;  // per lane, then wave max
         bool any_empty = false;
@@ -1378,7 +1521,7 @@ S3D_EXPORT int s3d_march_rays_train(const float* rays_o, const float* rays_d, co
                                     const int32_t* noise_step, uint32_t noise_key, s3d_stream_t stream) {
     // path: 0 = auto (wave-per-ray up to 16,384 rays), 1 = lane-per-ray kernels, 2 = wave-per-ray kernels
     if (N == 0) return S3D_OK;
-    S3D_REQUIRE(path >= 0 && path <= 2, "march_rays_train: path must be 0 (auto), 1 (lane per ray) or 2 (wave per ray)");
+    S3D_REQUIRE(path >= 0 && path <= 3, "march_rays_train: path must be 0 (auto), 1 (lane per ray), 2 (wave per ray) or 3 (wave per ray, general kernel)");
     S3D_REQUIRE(rays_o && rays_d && grid && nears && fars && rays && counter && noises, "march_rays_train: null pointer");
     S3D_REQUIRE(M == 0 || (xyzs && dirs && deltas), "march_rays_train: null output");
     S3D_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024, "march_rays_train: unsupported cascade/grid size C=%u H=%u", C, H);
@@ -1387,7 +1530,7 @@ S3D_EXPORT int s3d_march_rays_train(const float* rays_o, const float* rays_d, co
     const uint32_t nw = div_up<uint32_t>(N, 64);
     uint32_t* ws = reinterpret_cast<uint32_t*>(workspace);
     const bool wave_ok = workspace_bytes >= march_wave_ws(N, max_steps) && max_steps >= 1;
-    const bool use_wave = (path == 2 && wave_ok) || (path == 0 && wave_ok && N <= kWaveMarchMaxRays);
+    const bool use_wave = ((path == 2 || path == 3) && wave_ok) || (path == 0 && wave_ok && N <= kWaveMarchMaxRays);
     // aabb given: nears / fars (and, with noise_step, noises) are OUTPUTS of this call — made by the wave-per-ray count kernel
     // itself, by k_near_far in front of the lane-per-ray kernels
     float* nears_w = const_cast<float*>(nears);
@@ -1397,14 +1540,13 @@ S3D_EXPORT int s3d_march_rays_train(const float* rays_o, const float* rays_d, co
         hipLaunchKernelGGL(k_near_far, dim3(stream_grid(N, 256)), dim3(256), 0, as_stream(stream), rays_o, rays_d, aabb, N,
                            min_near, nears_w, fars_w, noise_step ? noises_w : nullptr, noise_step, noise_key);
     if (use_wave) {
-        if (dt_gamma == 0.0f)
-            hipLaunchKernelGGL(k_march_count_wave<true>, dim3(N), dim3(64), 0, as_stream(stream), rays_o, rays_d, grid, bound,
-                               dt_gamma, max_steps, N, C, H, nears_w, fars_w, noises_w, rays, (const int32_t*)counter, ws, aabb,
-                               min_near, noise_step, noise_key);
-        else
-            hipLaunchKernelGGL(k_march_count_wave<false>, dim3(N), dim3(64), 0, as_stream(stream), rays_o, rays_d, grid, bound,
-                               dt_gamma, max_steps, N, C, H, nears_w, fars_w, noises_w, rays, (const int32_t*)counter, ws, aabb,
-                               min_near, noise_step, noise_key);
+        const bool fast = C == 1 && H <= 128 && path != 3;  // one cascade, morton table of 128 spread coordinates (path 3: the general kernel, tests)
+#define S3D_COUNT_WAVE(CD_, F_) hipLaunchKernelGGL((k_march_count_wave<CD_, F_>), dim3(N), dim3(64), 0, as_stream(stream), rays_o, rays_d, \
+                                                   grid, bound, dt_gamma, max_steps, N, C, H, nears_w, fars_w, noises_w, rays,            \
+                                                   (const int32_t*)counter, ws, aabb, min_near, noise_step, noise_key)
+        if (dt_gamma == 0.0f) { if (fast) S3D_COUNT_WAVE(true, true); else S3D_COUNT_WAVE(true, false); }
+        else { if (fast) S3D_COUNT_WAVE(false, true); else S3D_COUNT_WAVE(false, false); }
+#undef S3D_COUNT_WAVE
         hipLaunchKernelGGL(k_march_write_wave, dim3(N), dim3(64), 0, as_stream(stream), rays_o, rays_d, bound, dt_gamma,
                            max_steps, N, C, H, M, nears, noises, xyzs, dirs, deltas, rays, counter, (const uint32_t*)ws);
         return check_launch("march_rays_train");

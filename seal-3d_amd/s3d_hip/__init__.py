@@ -397,7 +397,7 @@ class RaymarchingBackend:
 
     @staticmethod
     def set_march_path(path):
-        """0 = auto, 1 = lane-per-ray kernels, 2 = wave-per-ray kernels (tests / experiments)"""
+        """0 = auto, 1 = lane-per-ray kernels, 2 = wave-per-ray kernels, 3 = wave-per-ray without the single-cascade fast path (tests / experiments)"""
         RaymarchingBackend._march_path = int(path)
 
     # --- build extension (not in the reference's native surface) ---

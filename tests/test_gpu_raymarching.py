@@ -218,7 +218,7 @@ def _march_train_args(ro, rd, bits, C, bound, M, perturb, dt_gamma=0.0, max_step
     return [ro, rd, bits, bound, dt_gamma, max_steps, N, C, 128, M, nears, fars, xyzs, dirs, deltas, rays, counter, noises]
 
 
-@pytest.fixture(params=[1, 2], ids=["lane-per-ray", "wave-per-ray"])
+@pytest.fixture(params=[1, 2, 3], ids=["lane-per-ray", "wave-per-ray", "wave-per-ray-general"])
 def march_path(request, hip):
     hip.RaymarchingBackend.set_march_path(request.param)
     yield request.param
