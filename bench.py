@@ -544,13 +544,13 @@ def main():
 
     timers = KernelTimers(s3d_hip.GridBackend, ["grid_encode_forward", "grid_encode_backward"])
     rt = KernelTimers(s3d_hip.RaymarchingBackend, ["march_rays_train", "composite_rays_train_forward", "composite_rays_train_backward"])
-    ft = KernelTimers(s3d_hip.FFMLPBackend, ["ffmlp_forward", "ffmlp_backward"])
+    ft = KernelTimers(s3d_hip.FFMLPBackend, ["ffmlp_forward", "ngp_pair_inference", "ffmlp_backward"])
     graphed = not args.no_graph
 
     def install_timers(queue_ahead=False):
         timers.install(grid_meta, queue_ahead)
         rt.install(lambda n, a: 0, queue_ahead)
-        ft.install(lambda n, a: a[2] if n == "ffmlp_forward" else a[4], queue_ahead)
+        ft.install(lambda n, a: a[2] if n == "ffmlp_forward" else (a[3] if n == "ngp_pair_inference" else a[4]), queue_ahead)
     if not graphed:
         install_timers()
 
@@ -696,7 +696,10 @@ def main():
     # (the timers average over the launches of both networks: density net 32-64-64-16 = 7,168 MAC, colour net 32-64-64-64-16 =
     #  11,264 MAC per sample; rounds 1-3 priced both at 7,168)
     macs = sum(mlp_macs(n) for n in nets) / len(nets) if nets else 7168
-    for name, flops, byts in (("ffmlp_forward", 2 * macs, 96), ("ffmlp_backward", 6 * macs, 160)):
+    # (round 4: the training forward of both networks is ONE launch, `ngp_pair_inference` = k_ffmlp_ngp_pair: both networks'
+    #  flops; 64 B encoder features + 12 B directions in, 64 B colour-net input + 4 + 2 + 12 B out per sample)
+    for name, flops, byts in (("ffmlp_forward", 2 * macs, 96), ("ngp_pair_inference", 2 * macs * len(nets), 158),
+                              ("ffmlp_backward", 6 * macs, 160)):
         k = ksum.get(name)
         if not k or not k["units"]:
             continue

@@ -271,12 +271,14 @@ int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_
 /* Build extension for the inference loop (nerf/renderer.py:341-367 calls density and colour network back to back on the same
  * rows; nerf/network_ff.py:55-105): both fused MLPs and the two heads in ONE launch — inputs [B, 32] fp16 (or level-major
  * [16][B][2]), dirs [B, 3] fp32 -> sigma [B] fp32 = trunc_exp(h[:, 0]), rgb [B, 3] fp32 = sigmoid(colour(...)[:, :3]);
- * color_in (optional) [B, 32] fp16 receives the colour-net input rows.  Same arithmetic and rounding points as
- * s3d_ffmlp_inference(density head) + s3d_ffmlp_inference(colour head).  hidden_dim 64, ReLU, 16-column outputs. */
+ * color_in (optional) [B, 32] fp16 receives the colour-net input rows and h0 (optional) [B] fp16 the pre-activation of
+ * sigma — what the two networks' backward calls need (s3d_ffmlp_backward: colour head on color_in, density head on h0), so a
+ * training forward takes the same launch.  Same arithmetic and rounding points as s3d_ffmlp_inference(density head) +
+ * s3d_ffmlp_inference(colour head).  hidden_dim 64, ReLU, 16-column outputs. */
 int s3d_ffmlp_ngp_pair_inference(const uint16_t* inputs, const uint16_t* weights_sigma, const uint16_t* weights_color,
                                  uint32_t B, uint32_t hidden_dim, uint32_t num_layers_sigma, uint32_t num_layers_color,
                                  int input_layout, const int32_t* n_valid, const float* dirs, float* sigma, float* rgb,
-                                 uint16_t* color_in, s3d_stream_t stream);
+                                 uint16_t* color_in, uint16_t* h0, s3d_stream_t stream);
 /* ffmlp.h:11; grad_weights fp16 [same layout as weights]: every element is written (accumulate_grad_weights = 0,
  * the reference zero-fills it first, ffmlp.py:72) or added to (accumulate_grad_weights = 1).
  * workspace: fp32 accumulation of the weight gradient (s3d_ffmlp_backward_workspace_size).

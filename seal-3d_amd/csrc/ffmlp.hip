@@ -1694,7 +1694,7 @@ S3D_EXPORT int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weigh
 S3D_EXPORT int s3d_ffmlp_ngp_pair_inference(const uint16_t* inputs, const uint16_t* weights_sigma, const uint16_t* weights_color,
                                            uint32_t B, uint32_t hidden_dim, uint32_t num_layers_sigma, uint32_t num_layers_color,
                                            int input_layout, const int32_t* n_valid, const float* dirs, float* sigma,
-                                           float* rgb, uint16_t* color_in, s3d_stream_t stream) {
+                                           float* rgb, uint16_t* color_in, uint16_t* h0, s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(inputs && weights_sigma && weights_color && dirs && sigma && rgb, "ffmlp_ngp_pair_inference: null pointer");
     S3D_REQUIRE(hidden_dim == 64, "ffmlp_ngp_pair_inference: hidden_dim 64 (got %u)", hidden_dim);
@@ -1702,7 +1702,7 @@ S3D_EXPORT int s3d_ffmlp_ngp_pair_inference(const uint16_t* inputs, const uint16
     if (int rc = check_shape(B, 32, 16, hidden_dim, num_layers_sigma)) return rc;
     if (int rc = check_shape(B, 32, 16, hidden_dim, num_layers_color)) return rc;
     MidFwd mid{};
-    mid.dirs = dirs; mid.sigma = sigma; mid.cin = (_Float16*)color_in; mid.h0 = nullptr;
+    mid.dirs = dirs; mid.sigma = sigma; mid.cin = (_Float16*)color_in; mid.h0 = (_Float16*)h0;
     host_sh_norm(4, mid.K);
     PairNets nets{(const _Float16*)weights_sigma, (const _Float16*)weights_color, num_layers_sigma, num_layers_color};
     const uint32_t nfr = 2 * (4 + 4) + (num_layers_sigma - 1 + num_layers_color - 1) * 8;

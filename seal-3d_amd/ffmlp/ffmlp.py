@@ -202,6 +202,70 @@ class _FFMLPNgpMid(Function):
         return ((grad_inputs if calc else None), grad_weights) + (None,) * 7
 
 
+class _FFMLPNgpPair(Function):
+    """Density network + head + colour network + sigmoid of nerf/network_ff.py:55-105 as ONE forward launch
+    (s3d_ffmlp_ngp_pair_inference with its color_in / h0 outputs); backward = the colour network's fused backward (colour head)
+    followed by the density network's (density head), exactly the two calls the separate Functions make."""
+
+    @staticmethod
+    def forward(ctx, inputs, w_sigma, w_color, dirs, dims_s, dims_c, refs, hook_s, hook_c, input_layout, n_valid):
+        # (hook_s / hook_c: 0-dim leaves that keep the node in the graph when only the fp16 hand-over wants a gradient)
+        B = inputs.shape[1] if input_layout else inputs.shape[0]
+        inputs = inputs.to(torch.half).contiguous()
+        w_sigma, w_color = w_sigma.to(torch.half).contiguous(), w_color.to(torch.half).contiguous()
+        dirs = dirs.float().contiguous()
+        sigma = torch.empty(B, device=inputs.device, dtype=torch.float32)
+        rgb = torch.empty(B, 3, device=inputs.device, dtype=torch.float32)
+        cin = torch.empty(B, 32, device=inputs.device, dtype=torch.half)
+        h0 = torch.empty(B, device=inputs.device, dtype=torch.half)
+        _backend.ngp_pair_inference(inputs, w_sigma, w_color, B, dims_s[1], dims_s[2], dims_c[2], dirs, sigma, rgb,
+                                    input_layout, n_valid, cin, h0)
+        ctx.save_for_backward(inputs, w_sigma, w_color, h0, cin, rgb)
+        ctx.dims_s, ctx.dims_c, ctx.refs = dims_s, dims_c, refs
+        ctx.extra = dict(({"input_layout": input_layout} if input_layout else {}), **({"n_valid": n_valid} if n_valid is not None else {}))
+        ctx.calc_grad_inputs = inputs.requires_grad
+        ctx.set_materialize_grads(False)
+        return sigma, rgb
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb):
+        inputs, w_sigma, w_color, h0, cin, rgb = ctx.saved_tensors
+        B = h0.shape[0]
+        dev = h0.device
+
+        def target(ref, w):
+            stash = getattr(ref.param, "_s3d_grad", None) if ref is not None else None
+            extra = {}
+            if stash is not None:
+                extra["accumulate"] = not getattr(ref.param, "_s3d_overwrite", False)
+                found_inf = getattr(ref.param, "_s3d_found_inf", None)
+                if found_inf is not None:
+                    extra["found_inf"] = found_inf
+            return stash, (stash.view(w.shape) if stash is not None else torch.empty_like(w)), extra
+        ref_s, ref_c = ctx.refs
+        nv = {"n_valid": ctx.extra["n_valid"]} if "n_valid" in ctx.extra else {}
+        # colour network: gradient w.r.t. its fp32 head output -> gradient of the colour-net input rows
+        in_c, W_c, nl_c, act_c, oact_c = ctx.dims_c
+        stash_c, gw_c, extra_c = target(ref_c, w_color)
+        g_cin = torch.empty_like(cin)
+        if g_rgb is None:
+            g_rgb = torch.zeros_like(rgb)
+        _backend.ffmlp_backward(None, cin, w_color, None, B, in_c, 16, W_c, nl_c, act_c, oact_c, True, None, g_cin, gw_c,
+                                grad_rgb=g_rgb.float().contiguous(), rgb_head=rgb, **nv, **extra_c)
+        # density network: the head's two gradients
+        in_s, W_s, nl_s, act_s, oact_s = ctx.dims_s
+        stash_s, gw_s, extra_s = target(ref_s, w_sigma)
+        calc = ctx.calc_grad_inputs
+        grad_inputs = torch.empty_like(inputs) if calc else torch.zeros(1, device=dev, dtype=inputs.dtype)
+        g_sigma = None if g_sigma is None else g_sigma.float().contiguous()
+        _backend.ffmlp_backward(None, inputs, w_sigma, None, B, in_s, 16, W_s, nl_s, act_s, oact_s, calc, None, grad_inputs, gw_s,
+                                mid=(g_sigma, g_cin, h0), **ctx.extra, **extra_s)
+        for stash, ref in ((stash_s, ref_s), (stash_c, ref_c)):
+            if stash is not None:
+                ref.param._s3d_grad_touched = True
+        return ((grad_inputs if calc else None), (None if stash_s is not None else gw_s), (None if stash_c is not None else gw_c)) + (None,) * 8
+
+
 def _cached_half(w):
     """fp16 copy of the weights for inference calls (custom_fwd(cast_inputs=half) casts on EVERY call: two launches per
     iteration of the inference loop for a model that has no optimizer attached), cached per parameter version like the grid
@@ -300,13 +364,34 @@ class FFMLP(nn.Module):
                 and self.activation == 0 and color_net.activation == 0 and self.output_activation == 6
                 and color_net.output_activation == 6)
 
-    @torch.no_grad()
+    def _train_weights(self):
+        """(weights tensor for a call that records a gradient, _ParamRef for the fp16 hand-over, hook)"""
+        w = self.weights
+        if getattr(w, "_s3d_grad", None) is not None and getattr(w, "_s3d_half_version", None) == w._version:
+            if torch.is_grad_enabled() and w.requires_grad:
+                return w._s3d_half, _ParamRef(w), self._autograd_hook
+            return w._s3d_half, None, None
+        return w, None, None
+
     def forward_ngp_pair(self, inputs, dirs, color_net, level_major=False, n_valid=None):
-        """inference only: density network + head + colour network + sigmoid in ONE launch (s3d_ffmlp_ngp_pair_inference):
-        returns (sigma f32 [B], rgb f32 [B, 3]) — the same bits as forward_ngp_mid followed by color_net.forward_rgb"""
+        """density network + head + colour network + sigmoid in ONE launch (s3d_ffmlp_ngp_pair_inference): returns
+        (sigma f32 [B], rgb f32 [B, 3]) — the same bits as forward_ngp_mid followed by color_net.forward_rgb; with gradients
+        enabled the backward runs the two networks' fused backward kernels as the separate calls would"""
         B = inputs.shape[1] if level_major else inputs.shape[0]
         if B % 128 != 0 or not self.pair_supported(color_net):
             raise RuntimeError("FFMLP.forward_ngp_pair: needs B % 128 == 0 and two 64-wide ReLU networks with 32 inputs / 16 outputs")
+        if torch.is_grad_enabled() and (inputs.requires_grad or self.weights.requires_grad or color_net.weights.requires_grad):
+            w_s, ref_s, hook_s = self._train_weights()
+            w_c, ref_c, hook_c = color_net._train_weights()
+            dims_s = (self.input_dim, self.hidden_dim, self.num_layers, self.activation, self.output_activation)
+            dims_c = (color_net.input_dim, color_net.hidden_dim, color_net.num_layers, color_net.activation, color_net.output_activation)
+            return _FFMLPNgpPair.apply(inputs, w_s, w_c, dirs, dims_s, dims_c, (ref_s, ref_c), hook_s, hook_c,
+                                       1 if level_major else 0, n_valid)
+        return self._forward_ngp_pair_nograd(inputs, dirs, color_net, level_major, n_valid)
+
+    @torch.no_grad()
+    def _forward_ngp_pair_nograd(self, inputs, dirs, color_net, level_major=False, n_valid=None):
+        B = inputs.shape[1] if level_major else inputs.shape[0]
         sigma = torch.empty(B, dtype=torch.float32, device=inputs.device)
         rgb = torch.empty(B, 3, dtype=torch.float32, device=inputs.device)
         _backend.ngp_pair_inference(inputs.contiguous(), self._inference_weights(), color_net._inference_weights(), B,

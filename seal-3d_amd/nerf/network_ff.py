@@ -123,9 +123,10 @@ class NeRFNetwork(NeRFRenderer):
                 # inference loop: unused sample slots (deltas == 0, announced by the renderer) skip the table gathers
                 live = None if (self.training or torch.is_grad_enabled()) else s3d_hip.active_live_rows(x.shape[0])
                 enc = self.encoder(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
-                if (self.fused_pair and not torch.is_grad_enabled() and self.fused_mid and self.sigma_net.rgb_head_supported()
+                if (self.fused_pair and self.fused_mid and self.sigma_net.rgb_head_supported()
                         and self.color_net.rgb_head_supported() and self.sigma_net.pair_supported(self.color_net)):
-                    # inference: both networks and both heads in one launch — the colour-net input never leaves the chip
+                    # both networks and both heads in one forward launch (inference: the colour-net input never leaves the chip;
+                    # training: it is written once for the backward instead of written and read back)
                     return self.sigma_net.forward_ngp_pair(enc, d, self.color_net, level_major=True, n_valid=nv)
                 if self.fused_mid and self.sigma_net.rgb_head_supported():  # (same shape condition: the fused backward kernel)
                     # trunc_exp / SH / concat folded into the density network's last layer (and its backward's first load)

@@ -560,7 +560,7 @@ class FFMLPBackend:
 
     @staticmethod
     def ngp_pair_inference(inputs, weights_sigma, weights_color, B, hidden_dim, num_layers_sigma, num_layers_color, dirs,
-                           sigma, rgb, input_layout=0, n_valid=None, color_in=None):
+                           sigma, rgb, input_layout=0, n_valid=None, color_in=None, h0=None):
         """density network + head + colour network + sigmoid in one launch (seal3d_hip.h: s3d_ffmlp_ngp_pair_inference)"""
         for t, n in ((inputs, "inputs"), (weights_sigma, "weights_sigma"), (weights_color, "weights_color")):
             _need(t, torch.float16, n)
@@ -568,7 +568,7 @@ class FFMLPBackend:
             _need(t, torch.float32, n)
         _check(lib().s3d_ffmlp_ngp_pair_inference(_p(inputs), _p(weights_sigma), _p(weights_color), _u(B), _u(hidden_dim),
                                                   _u(num_layers_sigma), _u(num_layers_color), C.c_int(int(input_layout)),
-                                                  _nv(n_valid), _p(dirs), _p(sigma), _p(rgb), _p(color_in), _stream()),
+                                                  _nv(n_valid), _p(dirs), _p(sigma), _p(rgb), _p(color_in), _p(h0), _stream()),
                "ffmlp_ngp_pair_inference")
 
     @staticmethod

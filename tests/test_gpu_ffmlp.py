@@ -252,6 +252,40 @@ def test_ngp_pair_matches_the_two_launches(hip, B):
     assert torch.equal(s_c, s_d) and torch.equal(rgb_c, rgb_d)
 
 
+@pytest.mark.parametrize("B", [128 * 37, 128 * 2100])
+def test_ngp_pair_training_step_matches_the_two_functions(hip, B):
+    """FFMLP.forward_ngp_pair with gradients (one forward launch, the two fused backward kernels) against forward_ngp_mid +
+    forward_rgb: outputs as in the inference test, every gradient to fp16 accuracy (the colour-net input's SH columns may differ
+    by one fp16 ulp in a few rows per 10^5 between the kernels' inlined copies of sh_eval)"""
+    from ffmlp import FFMLP
+    torch.manual_seed(5)
+    sig, col = FFMLP(32, 16, 64, 2).cuda(), FFMLP(32, 3, 64, 3).cuda()
+    x0 = torch.randn(16, B, 2, device="cuda").half()
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device="cuda"), dim=-1)
+    gs, gr = torch.randn(B, device="cuda") * 0.1, torch.randn(B, 3, device="cuda")
+    nv = torch.tensor([B - 200], dtype=torch.int32, device="cuda")
+    rows = min(B, (int(nv) + 127) // 128 * 128)
+    res = []
+    for pair in (False, True):
+        sig.zero_grad(); col.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            if pair:
+                sigma, rgb = sig.forward_ngp_pair(x, d, col, level_major=True, n_valid=nv)
+            else:
+                sigma, cin = sig.forward_ngp_mid(x, d, level_major=True, n_valid=nv)
+                rgb = col.forward_rgb(cin, n_valid=nv)
+        ((sigma[:rows] * gs[:rows]).sum() + (rgb[:rows] * gr[:rows]).sum()).backward()
+        res.append((sigma.detach()[:rows].clone(), rgb.detach()[:rows].clone(), sig.weights.grad.clone(), col.weights.grad.clone(),
+                    x.grad[:, :rows].clone()))
+    (s_a, r_a, ws_a, wc_a, x_a), (s_b, r_b, ws_b, wc_b, x_b) = res
+    assert torch.equal(s_a, s_b)
+    assert float((r_a != r_b).any(-1).float().mean()) < 2e-3
+    for a, b in ((ws_a, ws_b), (wc_a, wc_b), (x_a.float(), x_b.float())):
+        assert float(a.abs().max()) > 0
+        torch.testing.assert_close(b, a, rtol=2e-2, atol=2e-3 * float(a.abs().max()))
+
+
 @pytest.mark.parametrize("W,in_dim,n", [(16, 32, 2), (128, 32, 3), (256, 64, 2), (64, 128, 2)])
 def test_ffmlp_module_other_widths_train_like_the_torch_twin(hip, W, in_dim, n):
     """`FFMLP` with the hidden widths ffmlp.cu:40-44 dispatches beside 32 / 64 (and an input wider than 64): forward, input
