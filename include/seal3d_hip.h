@@ -301,6 +301,15 @@ int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint1
                        const int32_t* n_valid, float* found_inf, const float* grad_rgb, const float* rgb_head,
                        const float* mid_grad_sigma, const uint16_t* mid_grad_color_in, const uint16_t* mid_h0,
                        s3d_stream_t stream);
+/* Build extension: s3d_ffmlp_backward with accumulate_grad_weights = 2 (fused backward only) leaves the per-workgroup partial
+ * sums of the weight gradient in `workspace` and skips its reduce launch; this call finishes TWO such networks (the colour and
+ * the density network of one step, each with its own workspace) in one launch: grad_weights_x fp16 written (accumulate_x = 0)
+ * or added to (1), found_inf_x raised like s3d_ffmlp_backward's.  B_x etc.: the arguments of the backward call it finishes. */
+int s3d_ffmlp_wgrad_reduce_pair(const void* workspace_a, uint32_t B_a, uint32_t input_dim_a, uint32_t hidden_dim_a,
+                                uint32_t num_layers_a, uint16_t* grad_weights_a, int accumulate_a, float* found_inf_a,
+                                const void* workspace_b, uint32_t B_b, uint32_t input_dim_b, uint32_t hidden_dim_b,
+                                uint32_t num_layers_b, uint16_t* grad_weights_b, int accumulate_b, float* found_inf_b,
+                                s3d_stream_t stream);
 /* ffmlp.h:13-14: the reference allocates split-K side streams here; this build fuses the weight
  * gradient into the backward launch sequence on the caller's stream, so these are no-ops kept for
  * surface compatibility. */

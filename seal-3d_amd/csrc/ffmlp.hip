@@ -778,6 +778,21 @@ __global__ void __launch_bounds__(256) k_ffmlp_wgrad(WgradPlan plan, uint32_t B,
 // Eight lanes per matrix element: each sums every 8th workgroup partial with independent accumulators (a single chain over
 // 256 partials was latency-bound: ~20 us), then a fixed xor-shuffle tree combines the eight.  Deterministic.
 constexpr uint32_t kReduceSplit = 8;
+// The same reduction for the weight gradients of SEVERAL networks in one launch (s3d_ffmlp_wgrad_reduce_pair: the backward calls
+// of the colour and the density network leave their partial sums in their workspaces, accumulate_grad_weights = 2, and this
+// launch finishes both — one launch of the step's 18 gone).  Same per-element order of additions as k_ffmlp_wgrad_reduce.
+struct ReduceJob {
+    const float* partial;   // [nblk][64][64] planes of this layer
+    _Float16* gw;           // the network's grad_weights
+    float* found_inf;
+    uint32_t Fo, Fi, w_off, nblk, accumulate;
+};
+struct ReduceJobs {
+    ReduceJob job[2 * kMaxMlpLayers];
+    uint32_t n;
+};
+__global__ void k_ffmlp_wgrad_reduce_jobs(ReduceJobs jobs);
+
 __global__ void k_ffmlp_wgrad_reduce(WgradPlan plan, uint32_t nblk, const float* __restrict__ partial,
                                      _Float16* __restrict__ grad_weights, uint32_t accumulate, float* __restrict__ found_inf) {
     const WgradLayer L = plan.layer[blockIdx.y];
@@ -807,6 +822,36 @@ __global__ void k_ffmlp_wgrad_reduce(WgradPlan plan, uint32_t nblk, const float*
         grad_weights[L.w_off + e] = h;
         // GradScaler's non-finite check made where the gradient is written (benign race: everyone writes 1)
         if (found_inf && !(fabsf((float)h) <= 65504.0f)) *found_inf = 1.0f;
+    }
+}
+
+__global__ void k_ffmlp_wgrad_reduce_jobs(ReduceJobs jobs) {
+    const ReduceJob L = jobs.job[blockIdx.y];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t e = t / kReduceSplit, part = t % kReduceSplit;
+    const bool live = e < L.Fo * L.Fi;
+    const uint32_t o = live ? e / L.Fi : 0, i = live ? e - o * L.Fi : 0;
+    const float* p = L.partial + o * kWgradPad + i;
+    constexpr size_t kPlane = (size_t)kWgradPad * kWgradPad;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (live) {
+        uint32_t b = part;
+        for (; b + 3 * kReduceSplit < L.nblk; b += 4 * kReduceSplit) {
+            s0 += p[(size_t)(b + 0 * kReduceSplit) * kPlane];
+            s1 += p[(size_t)(b + 1 * kReduceSplit) * kPlane];
+            s2 += p[(size_t)(b + 2 * kReduceSplit) * kPlane];
+            s3 += p[(size_t)(b + 3 * kReduceSplit) * kPlane];
+        }
+        for (; b < L.nblk; b += kReduceSplit) s0 += p[(size_t)b * kPlane];
+    }
+    float v = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int d = 1; d < (int)kReduceSplit; d <<= 1) v += __shfl_xor(v, d, 64);
+    if (live && part == 0) {
+        if (L.accumulate) v += (float)L.gw[L.w_off + e];
+        const _Float16 h = (_Float16)v;
+        L.gw[L.w_off + e] = h;
+        if (L.found_inf && !(fabsf((float)h) <= 65504.0f)) *L.found_inf = 1.0f;
     }
 }
 
@@ -1603,8 +1648,9 @@ int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Floa
     for (uint32_t m = 0; m < (uint32_t)NH; m++)
         plan.layer[1 + m] = WgradLayer{nullptr, nullptr, 0u, 0u, (uint32_t)W, (uint32_t)W, (uint32_t)(W * in_dim + m * W * W)};
     plan.layer[NH + 1] = WgradLayer{nullptr, nullptr, 0u, 0u, 16u, (uint32_t)W, (uint32_t)(W * in_dim + NH * W * W)};
-    hipLaunchKernelGGL(k_ffmlp_wgrad_reduce, dim3(div_up<uint32_t>(W * W * kReduceSplit, 256), plan.n), dim3(256), 0, st, plan, nblk,
-                       (const float*)partial, grad_weights, accumulate, t_found_inf);
+    if (accumulate != 2u)  // (2: the caller finishes several networks with one s3d_ffmlp_wgrad_reduce_pair)
+        hipLaunchKernelGGL(k_ffmlp_wgrad_reduce, dim3(div_up<uint32_t>(W * W * kReduceSplit, 256), plan.n), dim3(256), 0, st, plan, nblk,
+                           (const float*)partial, grad_weights, accumulate, t_found_inf);
     return check_launch("ffmlp_backward (fused)");
 }
 
@@ -1722,6 +1768,40 @@ S3D_EXPORT int s3d_ffmlp_ngp_pair_inference(const uint16_t* inputs, const uint16
     return check_launch("ffmlp_ngp_pair_inference");
 }
 
+S3D_EXPORT int s3d_ffmlp_wgrad_reduce_pair(const void* workspace_a, uint32_t B_a, uint32_t input_dim_a, uint32_t hidden_dim_a,
+                                          uint32_t num_layers_a, uint16_t* grad_weights_a, int accumulate_a, float* found_inf_a,
+                                          const void* workspace_b, uint32_t B_b, uint32_t input_dim_b, uint32_t hidden_dim_b,
+                                          uint32_t num_layers_b, uint16_t* grad_weights_b, int accumulate_b, float* found_inf_b,
+                                          s3d_stream_t stream) {
+    S3D_REQUIRE(workspace_a && grad_weights_a && workspace_b && grad_weights_b, "ffmlp_wgrad_reduce_pair: null pointer");
+    S3D_REQUIRE(num_layers_a >= 2 && num_layers_b >= 2 && num_layers_a + num_layers_b + 2 <= 2 * kMaxMlpLayers,
+                "ffmlp_wgrad_reduce_pair: too many layers");
+    S3D_REQUIRE(input_dim_a <= kWgradPad && input_dim_b <= kWgradPad && hidden_dim_a <= kWgradPad && hidden_dim_b <= kWgradPad,
+                "ffmlp_wgrad_reduce_pair: the fused backward's shapes only");
+    ReduceJobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
+    uint32_t wmax = 0;
+    auto add = [&](const void* ws, uint32_t B, uint32_t in_dim, uint32_t W, uint32_t nl, uint16_t* gw, int acc, float* fi) {
+        uint32_t nblk = div_up<uint32_t>(B / 32, 4);  // (launch_backward_fused_k's partial count)
+        if (nblk > kWgradBlocks) nblk = kWgradBlocks;
+        const uint32_t NH = nl - 1, layers = NH + 2;
+        for (uint32_t l = 0; l < layers; l++) {
+            ReduceJob& j = jobs.job[jobs.n++];
+            j.partial = (const float*)ws + (size_t)l * nblk * kWgradPad * kWgradPad;
+            j.gw = (_Float16*)gw; j.found_inf = fi; j.nblk = nblk; j.accumulate = acc ? 1u : 0u;
+            j.Fo = l == layers - 1 ? 16u : W;
+            j.Fi = l == 0 ? in_dim : W;
+            j.w_off = l == 0 ? 0u : W * in_dim + (l - 1) * W * W;
+        }
+        wmax = W > wmax ? W : wmax;
+    };
+    add(workspace_a, B_a, input_dim_a, hidden_dim_a, num_layers_a, grad_weights_a, accumulate_a, found_inf_a);
+    add(workspace_b, B_b, input_dim_b, hidden_dim_b, num_layers_b, grad_weights_b, accumulate_b, found_inf_b);
+    hipLaunchKernelGGL(k_ffmlp_wgrad_reduce_jobs, dim3(div_up<uint32_t>(wmax * kWgradPad * kReduceSplit, 256), jobs.n), dim3(256), 0,
+                       as_stream(stream), jobs);
+    return check_launch("ffmlp_wgrad_reduce_pair");
+}
+
 S3D_EXPORT size_t s3d_ffmlp_backward_workspace_size(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                                                     uint32_t num_layers) {
     (void)input_dim; (void)output_dim; (void)hidden_dim;
@@ -1749,7 +1829,10 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
                 "ffmlp_backward: the density head needs grad_color_in and h0 and is implemented by the fused backward");
     S3D_REQUIRE((grad_rgb == nullptr) == (rgb_head == nullptr), "ffmlp_backward: the colour head needs both grad_rgb and rgb_head");
     S3D_REQUIRE(!grad_rgb || (!forward_buffer && output_dim >= 3), "ffmlp_backward: the colour head is implemented by the fused backward");
-    const uint32_t accumulate = accumulate_grad_weights ? 1u : 0u;
+    const uint32_t accumulate = accumulate_grad_weights == 2 ? 2u : (accumulate_grad_weights ? 1u : 0u);
+    S3D_REQUIRE(accumulate != 2u || (!forward_buffer && ffmlp_native_shape(input_dim, hidden_dim) &&
+                                     fused_backward_supported(input_dim, output_dim, hidden_dim, num_layers, activation)),
+                "ffmlp_backward: accumulate_grad_weights = 2 (deferred reduce) is implemented by the fused backward");
     S3D_REQUIRE(input_layout == 0 || (input_layout == 1 && !forward_buffer),
                 "ffmlp_backward: the level-major input layout is implemented by the fused backward (no forward_buffer)");
     if (B == 0) return S3D_OK;

@@ -795,8 +795,22 @@ __global__ void __launch_bounds__(64) k_march_write_wave(const float* __restrict
                                                          int32_t* __restrict__ rays, int32_t* __restrict__ counter,
                                                          const uint32_t* __restrict__ ws) {
     const uint32_t n = blockIdx.x, lane = threadIdx.x;
+    // offset of this ray's span = the counts of all earlier rays: every workgroup sums them itself (a scan kernel in between
+    // would cost a launch, a chained scan a dependency across 4,096 workgroups).  Sixteen bytes per lane and trip, four
+    // independent partial sums (the counts sit 16-byte aligned behind the 4-word header): up to 16 trips instead of 64
     uint32_t part = 0;
-    for (uint32_t i = lane; i < n; i += 64) part += ws[kWsHeader + i];
+    {
+        const uint4* c4 = reinterpret_cast<const uint4*>(ws + kWsHeader);
+        const uint32_t n4 = n / 4;
+        uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        for (uint32_t i = lane; i < n4; i += 64) {
+            const uint4 v = c4[i];
+            p0 += v.x; p1 += v.y; p2 += v.z; p3 += v.w;
+        }
+        part = (p0 + p1) + (p2 + p3);
+        const uint32_t r0 = n4 * 4 + lane;
+        if (r0 < n) part += ws[kWsHeader + r0];  // (n % 4 < 4 <= 64 lanes)
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
     const uint32_t off = ws[0] + part;

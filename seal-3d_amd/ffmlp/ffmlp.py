@@ -244,22 +244,29 @@ class _FFMLPNgpPair(Function):
             return stash, (stash.view(w.shape) if stash is not None else torch.empty_like(w)), extra
         ref_s, ref_c = ctx.refs
         nv = {"n_valid": ctx.extra["n_valid"]} if "n_valid" in ctx.extra else {}
-        # colour network: gradient w.r.t. its fp32 head output -> gradient of the colour-net input rows
+        # both calls leave their weight-gradient partial sums in their half of one scratch tensor: ONE reduce launch for the two
         in_c, W_c, nl_c, act_c, oact_c = ctx.dims_c
+        in_s, W_s, nl_s, act_s, oact_s = ctx.dims_s
+        nb_c = (_backend.backward_workspace_bytes(in_c, 16, W_c, nl_c) + 255) // 256 * 256
+        nb_s = _backend.backward_workspace_bytes(in_s, 16, W_s, nl_s)
+        scratch = torch.empty(nb_c + nb_s, dtype=torch.uint8, device=dev)
+        ws_c, ws_s = scratch[:nb_c], scratch[nb_c:]
+        # colour network: gradient w.r.t. its fp32 head output -> gradient of the colour-net input rows
         stash_c, gw_c, extra_c = target(ref_c, w_color)
         g_cin = torch.empty_like(cin)
         if g_rgb is None:
             g_rgb = torch.zeros_like(rgb)
         _backend.ffmlp_backward(None, cin, w_color, None, B, in_c, 16, W_c, nl_c, act_c, oact_c, True, None, g_cin, gw_c,
-                                grad_rgb=g_rgb.float().contiguous(), rgb_head=rgb, **nv, **extra_c)
+                                grad_rgb=g_rgb.float().contiguous(), rgb_head=rgb, workspace=ws_c, defer_reduce=True, **nv, **extra_c)
         # density network: the head's two gradients
-        in_s, W_s, nl_s, act_s, oact_s = ctx.dims_s
         stash_s, gw_s, extra_s = target(ref_s, w_sigma)
         calc = ctx.calc_grad_inputs
         grad_inputs = torch.empty_like(inputs) if calc else torch.zeros(1, device=dev, dtype=inputs.dtype)
         g_sigma = None if g_sigma is None else g_sigma.float().contiguous()
         _backend.ffmlp_backward(None, inputs, w_sigma, None, B, in_s, 16, W_s, nl_s, act_s, oact_s, calc, None, grad_inputs, gw_s,
-                                mid=(g_sigma, g_cin, h0), **ctx.extra, **extra_s)
+                                mid=(g_sigma, g_cin, h0), workspace=ws_s, defer_reduce=True, **ctx.extra, **extra_s)
+        _backend.wgrad_reduce_pair((ws_c, B, in_c, W_c, nl_c, gw_c, extra_c.get("accumulate", False), extra_c.get("found_inf")),
+                                   (ws_s, B, in_s, W_s, nl_s, gw_s, extra_s.get("accumulate", False), extra_s.get("found_inf")))
         for stash, ref in ((stash_s, ref_s), (stash_c, ref_c)):
             if stash is not None:
                 ref.param._s3d_grad_touched = True

@@ -36,7 +36,7 @@ EXPORTS = [
     "s3d_grid_encode_backward_workspace_size", "s3d_grid_encode_backward_control_size",
     "s3d_grad_total_variation",
     "s3d_sh_encode_forward", "s3d_sh_encode_backward", "s3d_freq_encode_forward", "s3d_freq_encode_backward",
-    "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_ngp_pair_inference", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
+    "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_ngp_pair_inference", "s3d_ffmlp_wgrad_reduce_pair", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
     "s3d_ffmlp_fused_backward_supported",
     "s3d_ffmlp_allocate_splitk", "s3d_ffmlp_free_splitk",
     "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_step_multi", "s3d_adam_advance", "s3d_scaler_update", "s3d_step_ring_push", "s3d_step_epilogue",
@@ -580,9 +580,11 @@ class FFMLPBackend:
     @staticmethod
     def ffmlp_backward(grad, inputs, weights, forward_buffer, B, input_dim, output_dim, hidden_dim, num_layers,
                        activation, output_activation, calc_grad_inputs, backward_buffer, grad_inputs, grad_weights,
-                       input_layout=0, accumulate=False, n_valid=None, found_inf=None, grad_rgb=None, rgb_head=None, mid=None):
+                       input_layout=0, accumulate=False, n_valid=None, found_inf=None, grad_rgb=None, rgb_head=None, mid=None,
+                       workspace=None, defer_reduce=False):
         """`mid` = (grad_sigma f32 [B] or None, grad_color_in f16 [B,32], h0 f16 [B]): the density head's gradients instead of
-        `grad` (seal3d_hip.h)"""
+        `grad` (seal3d_hip.h); `defer_reduce` + `workspace` (a caller-owned uint8 tensor of ffmlp_backward_workspace_size bytes):
+        the weight gradient stays as partial sums in it for wgrad_reduce_pair"""
         if grad_rgb is not None:
             _need(grad_rgb, torch.float32, "grad_rgb"); _need(rgb_head, torch.float32, "rgb_head")
         elif mid is None:
@@ -591,14 +593,29 @@ class FFMLPBackend:
             _need(found_inf, torch.float32, "found_inf")
         nbytes = lib().s3d_ffmlp_backward_workspace_size(_u(input_dim), _u(output_dim), _u(hidden_dim),
                                                         _u(num_layers))
-        ws = _ws.get(nbytes, inputs.device)
+        ws = workspace if workspace is not None else _ws.get(nbytes, inputs.device)
+        if ws.numel() * ws.element_size() < nbytes:
+            raise RuntimeError("ffmlp_backward: workspace too small")
         _check(lib().s3d_ffmlp_backward(_p(grad), _p(inputs), _p(weights), _p(forward_buffer), _u(B), _u(input_dim),
                                         _u(output_dim), _u(hidden_dim), _u(num_layers), _u(activation),
                                         _u(output_activation), C.c_int(int(bool(calc_grad_inputs))),
                                         _p(backward_buffer), _p(grad_inputs if calc_grad_inputs else None),
                                         _p(grad_weights), _p(ws), C.c_size_t(ws.numel()), C.c_int(int(input_layout)),
-                                        C.c_int(int(bool(accumulate))), _nv(n_valid), _p(found_inf), _p(grad_rgb), _p(rgb_head),
+                                        C.c_int(2 if defer_reduce else int(bool(accumulate))), _nv(n_valid), _p(found_inf), _p(grad_rgb), _p(rgb_head),
                                         *_mid_bwd_args(mid, B), _stream()), "ffmlp_backward")
+
+    @staticmethod
+    def backward_workspace_bytes(input_dim, output_dim, hidden_dim, num_layers):
+        return int(lib().s3d_ffmlp_backward_workspace_size(_u(input_dim), _u(output_dim), _u(hidden_dim), _u(num_layers)))
+
+    @staticmethod
+    def wgrad_reduce_pair(a, b):
+        """finish two deferred backward calls: a, b = (workspace, B, input_dim, hidden_dim, num_layers, grad_weights, accumulate, found_inf)"""
+        args = []
+        for ws, B, in_dim, hid, nl, gw, acc, fi in (a, b):
+            _need(gw, torch.float16, "grad_weights")
+            args += [_p(ws), _u(B), _u(in_dim), _u(hid), _u(nl), _p(gw), C.c_int(int(bool(acc))), _p(fi)]
+        _check(lib().s3d_ffmlp_wgrad_reduce_pair(*args, _stream()), "ffmlp_wgrad_reduce_pair")
 
 
 def _mid_fwd_args(mid, B):
