@@ -182,6 +182,13 @@ int s3d_grid_encode_forward(const float* inputs, const void* embeddings, const i
                             uint32_t H, void* dy_dx, uint32_t gridtype, int align_corners,
                             uint32_t interp, int dtype, float bound, const int32_t* n_valid,
                             const float* live, uint32_t live_stride, s3d_stream_t stream);
+/* Build extension: TWO tables of identical geometry (offsets, C, L, S, H, gridtype, ...) encoded for the same points in one
+ * launch — the density and the colour encoder of the network Seal-3D trains (nerf/network.py:99-128 calls them on the same x):
+ * outputs_a / outputs_b [L, B, C] as s3d_grid_encode_forward writes them; no input Jacobian.  Same values as two calls. */
+int s3d_grid_encode_forward_pair(const float* inputs, const void* embeddings_a, const void* embeddings_b, const int32_t* offsets,
+                                 void* outputs_a, void* outputs_b, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S,
+                                 uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype, float bound,
+                                 const int32_t* n_valid, const float* live, uint32_t live_stride, s3d_stream_t stream);
 
 /* Test hook: table row of every corner, corner_idx [B,L,2^D] u32 (0xffffffff for out-of-range points). */
 int s3d_grid_corner_indices(const float* inputs, const int32_t* offsets, uint32_t* corner_idx, uint32_t B,

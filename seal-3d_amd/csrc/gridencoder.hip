@@ -317,11 +317,16 @@ struct FwdPlans {
 };
 
 template <typename T, uint32_t D, uint32_t C>
-__global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __restrict__ inputs, const T* __restrict__ grid,
-                                                                 const int32_t* __restrict__ offsets, T* __restrict__ outputs,
+__global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __restrict__ inputs, const T* __restrict__ grid_a,
+                                                                 const int32_t* __restrict__ offsets, T* __restrict__ outputs_a,
                                                                  uint32_t B, uint32_t L, LevelScales scales, uint32_t gridtype,
-                                                                 bool align_corners, uint32_t interp, FwdPlans plans) {
+                                                                 bool align_corners, uint32_t interp, FwdPlans plans,
+                                                                 const T* __restrict__ grid_b, T* __restrict__ outputs_b) {
     static_assert((sizeof(T) * C) % 4 == 0, "feature vectors travel between lanes as 32-bit words");
+    // blockIdx.y = 1: the SECOND table of a two-encoder call on the same points (s3d_grid_encode_forward_pair: the density and
+    // the colour encoder of the network Seal-3D trains share geometry and inputs — one launch, one ramp and one tail for both)
+    const T* __restrict__ grid = blockIdx.y ? grid_b : grid_a;
+    T* __restrict__ outputs = blockIdx.y ? outputs_b : outputs_a;
     constexpr uint32_t NW = sizeof(T) * C / 4;   // words per feature vector
     constexpr uint32_t J = 1u << (D - 1);        // corner pairs per point
     const uint32_t xcd = blockIdx.x % kXcds;
@@ -1973,8 +1978,13 @@ inline FwdPlan balance_forward_plan(uint32_t L, const LevelScales& sc, bool bala
 template <typename T, uint32_t D>
 int launch_forward(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t C,
                    uint32_t L, const LevelScales& sc, T* dy_dx, uint32_t gridtype, bool ac, uint32_t interp,
-                   hipStream_t st) {
-    const dim3 grid(xcd_grid(B)), block(kFwdBlock);
+                   hipStream_t st, const T* emb_b = nullptr, T* outputs_b = nullptr) {
+    const dim3 grid(xcd_grid(B), emb_b ? 2u : 1u), block(kFwdBlock);
+    if (emb_b && (dy_dx || (sizeof(T) * C) % 4 != 0 || (sizeof(T) == 4 && C != 1 && C != 2 && C != 4 && C != 8) ||
+                  (sizeof(T) == 2 && C != 2 && C != 4 && C != 8))) {
+        set_error("grid_encode_forward_pair: served by the lane-pair kernel (whole 32-bit feature words, no input Jacobian)");
+        return S3D_ERR_UNSUPPORTED;
+    }
     FwdPlans plan;
     plan.p[0] = balance_forward_plan(L, sc, false);
     plan.p[1] = balance_forward_plan(L, sc, true);
@@ -1983,14 +1993,14 @@ int launch_forward(const float* inputs, const T* emb, const int32_t* offsets, T*
     if (!dy_dx && (sizeof(T) * C) % 4 == 0) {
         if constexpr (sizeof(T) == 4) {
             switch (C) {
-                case 1: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 1>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan); return check_launch("grid_encode_forward");
+                case 1: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 1>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b); return check_launch("grid_encode_forward");
                 default: break;
             }
         }
         switch (C) {
-            case 2: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 2>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan); return check_launch("grid_encode_forward");
-            case 4: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 4>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan); return check_launch("grid_encode_forward");
-            case 8: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 8>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan); return check_launch("grid_encode_forward");
+            case 2: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 2>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b); return check_launch("grid_encode_forward");
+            case 4: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 4>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b); return check_launch("grid_encode_forward");
+            case 8: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 8>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b); return check_launch("grid_encode_forward");
             default: break;
         }
     }
@@ -2301,6 +2311,40 @@ S3D_EXPORT int s3d_grid_encode_forward(const float* inputs, const void* embeddin
                        (launch_forward<__half, 3>(inputs, e, offsets, o, B, C, L, sc, j, gridtype, ac, interp, st)),
                        (launch_forward<__half, 4>(inputs, e, offsets, o, B, C, L, sc, j, gridtype, ac, interp, st)),
                        (launch_forward<__half, 5>(inputs, e, offsets, o, B, C, L, sc, j, gridtype, ac, interp, st)))
+    }
+}
+
+S3D_EXPORT int s3d_grid_encode_forward_pair(const float* inputs, const void* embeddings_a, const void* embeddings_b,
+                                            const int32_t* offsets, void* outputs_a, void* outputs_b, uint32_t B, uint32_t D,
+                                            uint32_t C, uint32_t L, float S, uint32_t H, uint32_t gridtype, int align_corners,
+                                            uint32_t interp, int dtype, float bound, const int32_t* n_valid, const float* live,
+                                            uint32_t live_stride, s3d_stream_t stream) {
+    if (B == 0) return S3D_OK;
+    S3D_REQUIRE(inputs && embeddings_a && embeddings_b && offsets && outputs_a && outputs_b, "grid_encode_forward_pair: null pointer");
+    S3D_REQUIRE(bound >= 0.0f, "grid_encode_forward_pair: bound must be >= 0 (0 = inputs in [0,1])");
+    S3D_REQUIRE(L >= 1 && L <= kMaxLevels, "grid_encode_forward_pair: L must be in [1, %u]", kMaxLevels);
+    S3D_REQUIRE(dtype == S3D_F32 || dtype == S3D_F16, "grid_encode_forward_pair: dtype must be f32 or f16");
+    S3D_REQUIRE((uint64_t)B * L * C < (1ull << 32), "grid_encode_forward_pair: B*L*C overflows 32 bits");
+    LevelScales sc;
+    host_scales(L, S, H, sc, bound, n_valid);
+    sc.live = live;
+    sc.live_stride = live ? (live_stride ? live_stride : 1u) : 0u;
+    hipStream_t st = as_stream(stream);
+    const bool ac = align_corners != 0;
+    if (dtype == S3D_F32) {
+        const float* e = (const float*)embeddings_a; float* o = (float*)outputs_a;
+        const float* e2 = (const float*)embeddings_b; float* o2 = (float*)outputs_b;
+        S3D_DISPATCH_D(D, (launch_forward<float, 2>(inputs, e, offsets, o, B, C, L, sc, nullptr, gridtype, ac, interp, st, e2, o2)),
+                       (launch_forward<float, 3>(inputs, e, offsets, o, B, C, L, sc, nullptr, gridtype, ac, interp, st, e2, o2)),
+                       (launch_forward<float, 4>(inputs, e, offsets, o, B, C, L, sc, nullptr, gridtype, ac, interp, st, e2, o2)),
+                       (launch_forward<float, 5>(inputs, e, offsets, o, B, C, L, sc, nullptr, gridtype, ac, interp, st, e2, o2)))
+    } else {
+        const __half* e = (const __half*)embeddings_a; __half* o = (__half*)outputs_a;
+        const __half* e2 = (const __half*)embeddings_b; __half* o2 = (__half*)outputs_b;
+        S3D_DISPATCH_D(D, (launch_forward<__half, 2>(inputs, e, offsets, o, B, C, L, sc, nullptr, gridtype, ac, interp, st, e2, o2)),
+                       (launch_forward<__half, 3>(inputs, e, offsets, o, B, C, L, sc, nullptr, gridtype, ac, interp, st, e2, o2)),
+                       (launch_forward<__half, 4>(inputs, e, offsets, o, B, C, L, sc, nullptr, gridtype, ac, interp, st, e2, o2)),
+                       (launch_forward<__half, 5>(inputs, e, offsets, o, B, C, L, sc, nullptr, gridtype, ac, interp, st, e2, o2)))
     }
 }
 

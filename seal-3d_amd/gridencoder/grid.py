@@ -142,6 +142,106 @@ class _GridEncode(Function):
 grid_encode = _GridEncode.apply
 
 
+def _table_for_kernels(param, cache_half):
+    """(table the kernels read, Parameter): the optimizer's fp16 copy, a cached cast, or the parameter itself (_GridEncode.forward)"""
+    emb = param
+    if torch.is_autocast_enabled("cuda") and param.shape[1] % 2 == 0:
+        half = getattr(param, "_s3d_half", None)
+        if half is not None and param._s3d_half_version == param._version:
+            emb = half
+        else:
+            emb = _half_table(param, cache_half)
+    return emb.contiguous()
+
+
+class _GridEncodePair(Function):
+    """Two encoders of identical geometry on the same points (the density and the colour encoder of nerf/network.py:99-128) in ONE
+    forward launch (s3d_grid_encode_forward_pair); level-major outputs, no input gradient; backward = the two encoders' backward
+    calls, as two _GridEncode nodes would make them."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda")
+    def forward(ctx, inputs, emb_a, emb_b, offsets, per_level_scale, base_resolution, gridtype, align_corners, interpolation,
+                cache_half, bound, n_valid, live):
+        inputs = inputs.contiguous()
+        B, D = inputs.shape
+        L = offsets.shape[0] - 1
+        C = emb_a.shape[1]
+        S = float(np.log2(per_level_scale))
+        H = base_resolution
+        pa, pb = emb_a, emb_b
+        ta, tb = _table_for_kernels(pa, cache_half), _table_for_kernels(pb, cache_half)
+        out_a = torch.empty(L, B, C, device=inputs.device, dtype=ta.dtype)
+        out_b = torch.empty(L, B, C, device=inputs.device, dtype=ta.dtype)
+        extra = {}
+        if bound:
+            extra["bound"] = bound
+        if n_valid is not None:
+            extra["n_valid"] = n_valid
+        fwd_extra = dict(extra)
+        if live is not None and not torch.is_grad_enabled():
+            fwd_extra["live"] = live
+        _backend.grid_encode_forward_pair(inputs, ta, tb, offsets, out_a, out_b, B, D, C, L, S, H, gridtype, align_corners,
+                                          interpolation, **fwd_extra)
+        ctx.save_for_backward(inputs, ta, tb, offsets)
+        ctx.meta = (B, D, C, L, S, H, gridtype, interpolation, align_corners)
+        ctx.params = (pa, pb)
+        ctx.extra = extra
+        ctx.set_materialize_grads(False)
+        return out_a, out_b
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, ga, gb):
+        inputs, ta, tb, offsets = ctx.saved_tensors
+        B, D, C, L, S, H, gridtype, interpolation, align_corners = ctx.meta
+        outs = []
+        for grad, table, param in ((ga, ta, ctx.params[0]), (gb, tb, ctx.params[1])):
+            if grad is None:
+                outs.append(None)
+                continue
+            grad = grad.contiguous()
+            stash = getattr(param, "_s3d_grad", None)
+            extra = ctx.extra
+            if stash is not None and stash.dtype == table.dtype and stash.shape == table.shape:
+                grad_embeddings = stash
+                param._s3d_grad_touched = True
+                found_inf = getattr(param, "_s3d_found_inf", None)
+                if found_inf is not None:
+                    extra = dict(extra, found_inf=found_inf)
+            else:
+                stash = None
+                grad_embeddings = torch.zeros_like(table)
+            _backend.grid_encode_backward(grad, inputs, table, offsets, grad_embeddings, B, D, C, L, S, H, None, None, gridtype,
+                                          align_corners, interpolation, **extra)
+            outs.append(None if stash is not None else grad_embeddings)
+        return (None, outs[0], outs[1]) + (None,) * 10
+
+
+def grid_encode_pair(enc_a, enc_b, inputs, bound=1, n_valid=None, live=None):
+    """level-major outputs of two GridEncoder modules of identical geometry for the same [B, D] points from one launch, or None
+    when the pair call does not apply (the caller then encodes one after the other)"""
+    if not (getattr(_backend, "supports_bound", False) and hasattr(_backend, "grid_encode_forward_pair") and inputs.is_cuda
+            and inputs.dim() == 2 and not inputs.requires_grad and inputs.dtype == torch.float32 and bound > 0
+            and math.frexp(2.0 * bound)[0] == 0.5):
+        return None
+    same = (enc_a.embeddings.shape == enc_b.embeddings.shape and enc_a.per_level_scale == enc_b.per_level_scale
+            and enc_a.base_resolution == enc_b.base_resolution and enc_a.gridtype_id == enc_b.gridtype_id
+            and enc_a.align_corners == enc_b.align_corners and enc_a.interp_id == enc_b.interp_id
+            and enc_a.input_dim == enc_b.input_dim and enc_a.training == enc_b.training
+            # (the offsets follow from these and the table size — compared on the host: a tensor comparison would synchronise,
+            #  which a stream that is being captured does not allow)
+            and enc_a.num_levels == enc_b.num_levels and enc_a.level_dim == enc_b.level_dim
+            and enc_a.max_params == enc_b.max_params)
+    C = enc_a.embeddings.shape[1]
+    halfed = torch.is_autocast_enabled("cuda") and C % 2 == 0
+    if not same or (C * (2 if halfed else enc_a.embeddings.element_size())) % 4:  # (the lane-pair kernel: whole 32-bit feature words)
+        return None
+    return _GridEncodePair.apply(inputs, enc_a.embeddings, enc_b.embeddings, enc_a.offsets, enc_a.per_level_scale,
+                                 enc_a.base_resolution, enc_a.gridtype_id, enc_a.align_corners, enc_a.interp_id,
+                                 not enc_a.training, float(bound), n_valid, live)
+
+
 class GridEncoder(nn.Module):
     """grid.py:96-185"""
 

@@ -11,6 +11,7 @@ import s3d_hip
 from activation import trunc_exp
 from encoding import get_encoder
 from ffmlp.ffmlp import _ParamRef, ffmlp_forward
+from gridencoder.grid import grid_encode_pair
 
 from .network_ff import _NgpRgb
 from .renderer import NeRFRenderer
@@ -198,6 +199,7 @@ class NeRFNetwork(NeRFRenderer):
     #   colour net 63 -> 64 -> 64 -> 3 = ffmlp [W0 padded to 64 columns | W1 | W2 padded to 16 rows]
     # Same arithmetic as the reference's autocast path: fp16 operands, fp32 accumulation, fp16 activations; SH values
     # rounded to fp16 where the first Linear's input cast rounds them; sigmoid evaluated in fp32 and rounded to fp16.
+    fused_encoders = os.environ.get("S3D_FUSED_ENCODERS", "1") != "0"  # A-B runs: False = one forward launch per encoder
     fused_mlp = os.environ.get("S3D_FUSED_SEAL", "1") != "0"  # tests / A-B runs: False = nn.Linear op sequence
 
     def honours_row_limit(self, rows):
@@ -249,11 +251,13 @@ class NeRFNetwork(NeRFRenderer):
         rs, hs = (None, None) if rs is None else (_ParamRef(rs), rs.hook)
         rc, hc = (None, None) if rc is None else (_ParamRef(rc), rc.hook)
         infer = not self.training
-        e0 = self.encoder(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
+        # both encoders read the same points: one launch for the two tables when the colour is wanted too
+        pair = grid_encode_pair(self.encoder, self.encoder_color, x, self.bound, nv, live) if (want_rgb and self.fused_encoders) else None
+        e0 = pair[0] if pair is not None else self.encoder(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
         h = ffmlp_forward(e0, ws, 32, 16, 64, 2, 0, 6, infer, e0.requires_grad, rs, hs, 1, nv)
         if not want_rgb:
             return h
-        e1 = self.encoder_color(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
+        e1 = pair[1] if pair is not None else self.encoder_color(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
         sigma, cin = _SealMid.apply(h.contiguous(), d.float().contiguous(), e1.contiguous(), nv)
         if cin.shape[0] % 128 == 0 and (infer or s3d_hip.FFMLPBackend.fused_backward_supported(64, 16, 64, 2, 0)):
             # colour head inside the MLP kernels (seal3d_hip.h: rgb_head): fp32 sigmoid(out[:, :3]) straight from the last layer

@@ -32,7 +32,7 @@ EXPORTS = [
     "s3d_sweep_draw", "s3d_sweep_update_workspace_size", "s3d_sweep_update",
     "s3d_composite_rays_train_forward", "s3d_composite_rays_train_backward",
     "s3d_march_rays", "s3d_composite_rays", "s3d_compact_alive_workspace_size", "s3d_compact_alive",
-    "s3d_grid_level_scales", "s3d_grid_encode_forward", "s3d_grid_corner_indices", "s3d_grid_encode_backward",
+    "s3d_grid_level_scales", "s3d_grid_encode_forward", "s3d_grid_encode_forward_pair", "s3d_grid_corner_indices", "s3d_grid_encode_backward",
     "s3d_grid_encode_backward_workspace_size", "s3d_grid_encode_backward_control_size",
     "s3d_grad_total_variation",
     "s3d_sh_encode_forward", "s3d_sh_encode_backward", "s3d_freq_encode_forward", "s3d_freq_encode_backward",
@@ -445,6 +445,19 @@ class GridBackend:
                                              _u(Cc), _u(L), _f(S), _u(H), _p(dy_dx), _u(gridtype),
                                              C.c_int(int(align_corners)), _u(interp), C.c_int(_dt(embeddings)),
                                              _f(bound), _nv(n_valid), *_live(live, B), _stream()), "grid_encode_forward")
+
+    @staticmethod
+    def grid_encode_forward_pair(inputs, emb_a, emb_b, offsets, out_a, out_b, B, D, Cc, L, S, H, gridtype, align_corners,
+                                 interp, bound=0.0, n_valid=None, live=None):
+        """two tables of one geometry on the same points in one launch (seal3d_hip.h: s3d_grid_encode_forward_pair)"""
+        _need(inputs, torch.float32, "inputs")
+        _need(offsets, torch.int32, "offsets")
+        if not (out_a.dtype == emb_a.dtype == emb_b.dtype == out_b.dtype) or emb_a.shape != emb_b.shape:
+            raise RuntimeError("grid_encode_forward_pair: both tables and both outputs share dtype and shape")
+        _check(lib().s3d_grid_encode_forward_pair(_p(inputs), _p(emb_a), _p(emb_b), _p(offsets), _p(out_a), _p(out_b), _u(B), _u(D),
+                                                  _u(Cc), _u(L), _f(S), _u(H), _u(gridtype), C.c_int(int(align_corners)),
+                                                  _u(interp), C.c_int(_dt(emb_a)), _f(bound), _nv(n_valid), *_live(live, B),
+                                                  _stream()), "grid_encode_forward_pair")
 
     @staticmethod
     def grid_corner_indices(inputs, offsets, corner_idx, B, D, Cc, L, S, H, gridtype, align_corners):

@@ -177,6 +177,45 @@ def test_grid_encoder_fused_bound_normalisation(hip, bound):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("autocast", [False, True])
+def test_two_encoders_in_one_launch_match_two_calls(hip, autocast):
+    """gridencoder.grid.grid_encode_pair (s3d_grid_encode_forward_pair: the density and the colour encoder of nerf/network.py on the
+    same points) == the two GridEncoder calls: outputs and both table gradients bit for bit, with a device row count and a live mask"""
+    from gridencoder import GridEncoder
+    from gridencoder.grid import grid_encode_pair
+    torch.manual_seed(9)
+    a = GridEncoder(num_levels=16, base_resolution=16, log2_hashmap_size=15, desired_resolution=1024).cuda()
+    b = GridEncoder(num_levels=16, base_resolution=16, log2_hashmap_size=15, desired_resolution=1024).cuda()
+    a.embeddings.data.uniform_(-1, 1); b.embeddings.data.uniform_(-1, 1)
+    B = 128 * 70
+    x = ((torch.rand(B, 3) * 2 - 1) * 1.01).cuda()
+    ga, gb = torch.randn(16, B, 2, device="cuda"), torch.randn(16, B, 2, device="cuda")
+    nv = torch.tensor([B - 300], dtype=torch.int32, device="cuda")
+    rows = (int(nv) + 127) // 128 * 128
+    res = []
+    for pair in (False, True):
+        a.zero_grad(set_to_none=True); b.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16, enabled=autocast):
+            if pair:
+                out = grid_encode_pair(a, b, x, 1, nv, None)
+                assert out is not None
+                ya, yb = out
+            else:
+                ya, yb = a(x, bound=1, level_major=True, n_valid=nv), b(x, bound=1, level_major=True, n_valid=nv)
+        ((ya[:, :rows].float() * ga[:, :rows]).sum() + (yb[:, :rows].float() * gb[:, :rows]).sum()).backward()
+        res.append((ya.detach()[:, :rows].clone(), yb.detach()[:, :rows].clone(), a.embeddings.grad.clone(), b.embeddings.grad.clone()))
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
+    assert float(res[0][0].float().abs().max()) > 0 and float(res[0][3].abs().max()) > 0
+    # inference: a live mask (rows whose first element is 0 come out as zeros)
+    live = (torch.rand(B, 2, device="cuda") > 0.3).float()
+    a.eval(); b.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=autocast):
+        ya, yb = grid_encode_pair(a, b, x, 1, None, live)
+        za, zb = a(x, bound=1, level_major=True, live=live), b(x, bound=1, level_major=True, live=live)
+    assert torch.equal(ya, za) and torch.equal(yb, zb)
+
+
 def test_fused_background_mse_loss(hip):
     """nerf.trainer.render_loss with a deferred background == F.mse_loss(image + (1 - ws) * bg, gt), values and gradients"""
     from nerf.trainer import render_loss
