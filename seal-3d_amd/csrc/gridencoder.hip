@@ -1757,6 +1757,16 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate6(const uint16
                 for (uint32_t w = 0; w < WR; w++)
                     if (nz[w]) old[w] = *reinterpret_cast<const V*>(table + (size_t)row_of_local(r0 + w * kBinAccThreads) * C);
             }
+            // (this phase is bound by vector-instruction issue: a wave whose sums all fit 32 bits — the rule: |sum| < 128 at the
+            //  fixed scale 2^24 — converts them with one cvt + one ldexp each instead of the two-limb route; same rounding)
+            bool fits = true;
+#pragma unroll
+            for (uint32_t w = 0; w < WR; w++)
+                if (nz[w]) {
+#pragma unroll
+                    for (uint32_t c = 0; c < C; c++) fits &= (q[w][c] == (long long)(int)q[w][c]);
+                }
+            const bool narrow = __ballot(!fits) == 0ull;
 #pragma unroll
             for (uint32_t w = 0; w < WR; w++) {
                 if (nz[w]) {
@@ -1764,7 +1774,8 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate6(const uint16
                     __builtin_memcpy(o, &old[w], sizeof(V));
 #pragma unroll
                     for (uint32_t c = 0; c < C; c++) {
-                        o[c] = Acc<T>::from_f(Acc<T>::to_f(o[c]) + fixed_to_float(q[w][c], kexp));
+                        const float sum = narrow ? ldexpf((float)(int)q[w][c], -kexp) : fixed_to_float(q[w][c], kexp);
+                        o[c] = Acc<T>::from_f(Acc<T>::to_f(o[c]) + sum);
                         overflow |= !(fabsf(Acc<T>::to_f(o[c])) <= 3.402823466e38f);
                     }
                     store_feat<T, C>(table + (size_t)row_of_local(r0 + w * kBinAccThreads) * C, o);
