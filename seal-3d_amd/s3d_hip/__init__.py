@@ -624,11 +624,11 @@ class FFMLPBackend:
     @staticmethod
     def wgrad_reduce_pair(a, b):
         """finish two deferred backward calls: a, b = (workspace, B, input_dim, hidden_dim, num_layers, grad_weights, accumulate, found_inf)"""
-        args = []
-        for ws, B, in_dim, hid, nl, gw, acc, fi in (a, b):
-            _need(gw, torch.float16, "grad_weights")
-            args += [_p(ws), _u(B), _u(in_dim), _u(hid), _u(nl), _p(gw), C.c_int(int(bool(acc))), _p(fi)]
-        _check(lib().s3d_ffmlp_wgrad_reduce_pair(*args, _stream()), "ffmlp_wgrad_reduce_pair")
+        (ws_a, B_a, in_a, hid_a, nl_a, gw_a, acc_a, fi_a), (ws_b, B_b, in_b, hid_b, nl_b, gw_b, acc_b, fi_b) = a, b
+        _need(gw_a, torch.float16, "grad_weights"); _need(gw_b, torch.float16, "grad_weights")
+        _check(lib().s3d_ffmlp_wgrad_reduce_pair(_p(ws_a), _u(B_a), _u(in_a), _u(hid_a), _u(nl_a), _p(gw_a), C.c_int(int(bool(acc_a))),
+                                                 _p(fi_a), _p(ws_b), _u(B_b), _u(in_b), _u(hid_b), _u(nl_b), _p(gw_b),
+                                                 C.c_int(int(bool(acc_b))), _p(fi_b), _stream()), "ffmlp_wgrad_reduce_pair")
 
 
 def _mid_fwd_args(mid, B):
