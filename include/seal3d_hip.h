@@ -281,11 +281,13 @@ int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weights, uint32_
  * color_in (optional) [B, 32] fp16 receives the colour-net input rows and h0 (optional) [B] fp16 the pre-activation of
  * sigma — what the two networks' backward calls need (s3d_ffmlp_backward: colour head on color_in, density head on h0), so a
  * training forward takes the same launch.  Same arithmetic and rounding points as s3d_ffmlp_inference(density head) +
- * s3d_ffmlp_inference(colour head).  hidden_dim 64, ReLU, 16-column outputs. */
+ * s3d_ffmlp_inference(colour head).  hidden_dim 64, ReLU, 16-column outputs.  enc_color (optional) fp16 level-major [16][B][2]:
+ * the network Seal-3D trains (nerf/network.py:99-128) — the colour network then takes the 64-wide row of s3d_ngp_mid2_forward,
+ * [half(SH_4(d)) | h1..h15 | enc_color | 0], built on chip (weights_color [64*64 | ...], color_in [B, 64]). */
 int s3d_ffmlp_ngp_pair_inference(const uint16_t* inputs, const uint16_t* weights_sigma, const uint16_t* weights_color,
                                  uint32_t B, uint32_t hidden_dim, uint32_t num_layers_sigma, uint32_t num_layers_color,
                                  int input_layout, const int32_t* n_valid, const float* dirs, float* sigma, float* rgb,
-                                 uint16_t* color_in, uint16_t* h0, s3d_stream_t stream);
+                                 uint16_t* color_in, uint16_t* h0, const uint16_t* enc_color, s3d_stream_t stream);
 /* ffmlp.h:11; grad_weights fp16 [same layout as weights]: every element is written (accumulate_grad_weights = 0,
  * the reference zero-fills it first, ffmlp.py:72) or added to (accumulate_grad_weights = 1).
  * workspace: fp32 accumulation of the weight gradient (s3d_ffmlp_backward_workspace_size).
@@ -363,6 +365,7 @@ int s3d_ngp_mid_backward(const uint16_t* grad_color_in, const float* grad_sigma 
 int s3d_ngp_mid2_forward(const uint16_t* h, const float* dirs, const uint16_t* enc_color, uint32_t B, float* sigma,
                          uint16_t* color_in, const int32_t* n_valid, s3d_stream_t stream);
 int s3d_ngp_mid2_backward(const uint16_t* grad_color_in, const float* grad_sigma /* or NULL */, const uint16_t* h,
+                          uint32_t h_stride /* 16: h is the density network's [B, 16] output; 1: its first column [B] alone */,
                           uint32_t B, uint16_t* grad_h, uint16_t* grad_enc_color /* or NULL */, const int32_t* n_valid,
                           s3d_stream_t stream);
 int s3d_ngp_rgb_forward(const uint16_t* out, uint32_t B, float* rgb, const int32_t* n_valid, s3d_stream_t stream);

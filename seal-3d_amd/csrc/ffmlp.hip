@@ -421,41 +421,86 @@ __global__ void __launch_bounds__(256) k_ffmlp_forward(const _Float16* __restric
 constexpr uint32_t kPairWaves = S3D_PAIR_WAVES;
 struct PairNets {
     const _Float16* Ws;   // density network  [64*32 | (nl_s-1)*64*64 | 16*64]
-    const _Float16* Wc;   // colour network   [64*32 | (nl_c-1)*64*64 | 16*64]
+    const _Float16* Wc;   // colour network   [64*IN_C | (nl_c-1)*64*64 | 16*64]
     uint32_t nl_s, nl_c;  // hidden layers of each
+    const _Float16* enc_c;  // SEAL: the second encoder's features, level-major [16][B][2]
 };
+// one network on the fragments `a0` (layer 0: MB * KPX | hidden: NH * MB * KS | last: KS), layer-0 operands in b0
+template <uint32_t KPX>
+__device__ __forceinline__ float16v pair_network(const half8* a0, uint32_t NH, const half8 (&b0)[KPX], uint32_t lane) {
+    constexpr uint32_t MB = 2, KS = 4, nf0 = MB * KPX;
+    float16v acc[MB];
+    half8 bf[KS];
+#pragma unroll
+    for (uint32_t m = 0; m < MB; m++) acc[m] = zero16();
+#pragma unroll
+    for (uint32_t s = 0; s < KPX; s++) {
+#pragma unroll
+        for (uint32_t m = 0; m < MB; m++) acc[m] = mfma(a0[(m * KPX + s) * 64 + lane], b0[s], acc[m]);
+    }
+    for (uint32_t layer = 0;; layer++) {
+#pragma unroll
+        for (uint32_t m = 0; m < MB; m++)
+#pragma unroll
+            for (uint32_t r = 0; r < 16; r += 2) {
+                const half2p v = relu2(cvt2(acc[m][r], acc[m][r + 1]));
+                bf[2 * m + (r >> 3)][r & 7] = v[0];
+                bf[2 * m + (r >> 3)][(r & 7) + 1] = v[1];
+            }
+        if (layer == NH) break;
+        const half8* a = a0 + (size_t)(nf0 + layer * MB * KS) * 64;
+#pragma unroll
+        for (uint32_t m = 0; m < MB; m++) {
+            acc[m] = zero16();
+#pragma unroll
+            for (uint32_t s = 0; s < KS; s++) acc[m] = mfma(a[(m * KS + s) * 64 + lane], bf[s], acc[m]);
+        }
+    }
+    float16v o = zero16();
+    const half8* a = a0 + (size_t)(nf0 + NH * MB * KS) * 64;
+#pragma unroll
+    for (uint32_t s = 0; s < KS; s++) o = mfma(a[s * 64 + lane], bf[s], o);
+    return o;
+}
+// SEAL = the two-encoder network Seal-3D trains (nerf/network.py:99-128): the colour-net input row is 64 wide,
+// [half(SH_4(d)) | h1..h15 | encoder_color(x) (32) | 0] — k_ngp_mid2_forward's row, built in the wave's tile; the second encoder's
+// features are requested with the next tile's inputs.
+template <bool SEAL>
 __global__ void __launch_bounds__(kPairWaves * 64) k_ffmlp_ngp_pair(const _Float16* __restrict__ X, const PairNets nets, uint32_t B,
-                                                       uint32_t in_layout, const int32_t* __restrict__ n_valid,
-                                                       float* __restrict__ rgb_head, const MidFwd mid) {
+                                                                   uint32_t in_layout, const int32_t* __restrict__ n_valid,
+                                                                   float* __restrict__ rgb_head, const MidFwd mid) {
     constexpr uint32_t W = 64, MB = 2, KS = 4, KP = 2, IN = 32;
+    constexpr uint32_t KPC = SEAL ? 4 : 2, INC = 16 * KPC;      // colour network: layer-0 k-steps, input width
+    constexpr uint32_t kRow = SEAL ? 72 : kMidRow;              // halfs per tile row (16-byte aligned)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     half8* frags = reinterpret_cast<half8*>(smem_raw);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t n = lane & 31, h = lane >> 5;
     const uint32_t NHs = nets.nl_s - 1, NHc = nets.nl_c - 1;
-    constexpr uint32_t nf0 = MB * KP;
-    const uint32_t tot_s = nf0 + NHs * MB * KS + KS, tot_c = nf0 + NHc * MB * KS + KS;
-    _Float16* Tm = reinterpret_cast<_Float16*>(frags + (size_t)(tot_s + tot_c) * 64) + (size_t)wave * 32 * kMidRow;
+    constexpr uint32_t nf0 = MB * KP, nf0c = MB * KPC;
+    const uint32_t tot_s = nf0 + NHs * MB * KS + KS, tot_c = nf0c + NHc * MB * KS + KS;
+    _Float16* Tm = reinterpret_cast<_Float16*>(frags + (size_t)(tot_s + tot_c) * 64) + (size_t)wave * 32 * kRow;
 
     // stage both networks' weights as A fragments (k_ffmlp_forward's directory, the colour network behind the density network)
 #pragma unroll 1
     for (uint32_t f0 = wave; f0 < tot_s + tot_c; f0 += kPairWaves) {
         const bool second = f0 >= tot_s;
         const uint32_t f = second ? f0 - tot_s : f0, NH = second ? NHc : NHs;
+        const uint32_t in_w = second ? INC : IN, ks0 = second ? KPC : KP, n0 = MB * ks0;
         const _Float16* Wt = second ? nets.Wc : nets.Ws;
-        const _Float16* w_hid = Wt + (size_t)W * IN;
+        const _Float16* w_hid = Wt + (size_t)W * in_w;
         const _Float16* w_last = w_hid + (size_t)NH * W * W;
         const uint32_t nfh = NH * MB * KS;
         const _Float16* r;
         bool live = true;
-        if (f < nf0) {
-            const uint32_t mblk = f / KP, s = f % KP;
-            r = Wt + (size_t)(mblk * 32 + n) * IN + 16 * s;
-        } else if (f < nf0 + nfh) {
-            const uint32_t g = f - nf0, k = g / (MB * KS), mblk = (g / KS) % MB, s = g % KS;
+        if (f < n0) {
+            const uint32_t mblk = f / ks0, s = f % ks0;
+            r = Wt + (size_t)(mblk * 32 + n) * in_w + 16 * s;
+        } else if (f < n0 + nfh) {
+            const uint32_t g = f - n0, k = g / (MB * KS), mblk = (g / KS) % MB, s = g % KS;
             r = w_hid + (size_t)k * W * W + (size_t)(mblk * 32 + n) * W + 16 * s;
         } else {
-            const uint32_t s = f - nf0 - nfh;
+            const uint32_t s = f - n0 - nfh;
             live = n < 16;
             r = w_last + (size_t)(live ? n : 0) * W + 16 * s;
         }
@@ -465,57 +510,34 @@ __global__ void __launch_bounds__(kPairWaves * 64) k_ffmlp_ngp_pair(const _Float
 
     const uint32_t ntiles = valid_rows(B, n_valid) / 32;
     const uint32_t tstride = gridDim.x * kPairWaves;
+    constexpr uint32_t NE = SEAL ? 8 : 1;  // level pairs of the second encoder per lane (lane half h: levels 8 h .. 8 h + 7)
     half8 bin[KP];
     float dir[3] = {0.0f, 0.0f, 0.0f};
-    auto request = [&](uint32_t t, half8 (&dst)[KP], float (&d)[3]) {
+    uint32_t enc[NE];
+    auto request = [&](uint32_t t, half8 (&dst)[KP], float (&d)[3], uint32_t (&e)[NE]) {
         const size_t r = (size_t)t * 32 + n;
 #pragma unroll
         for (uint32_t s = 0; s < KP; s++) dst[s] = load_bfrag_input(X, in_layout, B, IN, r, s, h);
         d[0] = mid.dirs[r * 3]; d[1] = mid.dirs[r * 3 + 1]; d[2] = mid.dirs[r * 3 + 2];
-    };
-    // one network on the fragments `a0` (layer 0: nf0 | hidden: NH * MB * KS | last: KS), layer-0 operands in b0
-    auto network = [&](const half8* a0, uint32_t NH, const half8 (&b0)[KP]) {
-        float16v acc[MB];
-        half8 bf[KS];
+        if constexpr (SEAL) {
 #pragma unroll
-        for (uint32_t m = 0; m < MB; m++) acc[m] = zero16();
-#pragma unroll
-        for (uint32_t s = 0; s < KP; s++) {
-#pragma unroll
-            for (uint32_t m = 0; m < MB; m++) acc[m] = mfma(a0[(m * KP + s) * 64 + lane], b0[s], acc[m]);
+            for (uint32_t l = 0; l < NE; l++)
+                e[l] = *reinterpret_cast<const uint32_t*>(nets.enc_c + ((size_t)(8 * h + l) * B + r) * 2);
         }
-        for (uint32_t layer = 0;; layer++) {
-#pragma unroll
-            for (uint32_t m = 0; m < MB; m++)
-#pragma unroll
-                for (uint32_t r = 0; r < 16; r += 2) {
-                    const half2p v = relu2(cvt2(acc[m][r], acc[m][r + 1]));
-                    bf[2 * m + (r >> 3)][r & 7] = v[0];
-                    bf[2 * m + (r >> 3)][(r & 7) + 1] = v[1];
-                }
-            if (layer == NH) break;
-            const half8* a = a0 + (size_t)(nf0 + layer * MB * KS) * 64;
-#pragma unroll
-            for (uint32_t m = 0; m < MB; m++) {
-                acc[m] = zero16();
-#pragma unroll
-                for (uint32_t s = 0; s < KS; s++) acc[m] = mfma(a[(m * KS + s) * 64 + lane], bf[s], acc[m]);
-            }
-        }
-        float16v o = zero16();
-        const half8* a = a0 + (size_t)(nf0 + NH * MB * KS) * 64;
-#pragma unroll
-        for (uint32_t s = 0; s < KS; s++) o = mfma(a[s * 64 + lane], bf[s], o);
-        return o;
     };
     uint32_t tile = blockIdx.x * kPairWaves + wave;
-    if (tile < ntiles) request(tile, bin, dir);
+#pragma unroll
+    for (uint32_t l = 0; l < NE; l++) enc[l] = 0u;
+    if (tile < ntiles) request(tile, bin, dir, enc);
     for (; tile < ntiles; tile += tstride) {
         const size_t row = (size_t)tile * 32 + n;
         half8 bnx[KP];
         float dnx[3] = {0.0f, 0.0f, 0.0f};
-        if (tile + tstride < ntiles) request(tile + tstride, bnx, dnx);
-        const float16v o = network(frags, NHs, bin);
+        uint32_t enx[NE];
+#pragma unroll
+        for (uint32_t l = 0; l < NE; l++) enx[l] = 0u;
+        if (tile + tstride < ntiles) request(tile + tstride, bnx, dnx, enx);
+        const float16v o = pair_network<KP>(frags, NHs, bin, lane);
 #pragma unroll
         for (uint32_t s = 0; s < KP; s++) bin[s] = bnx[s];
         const float dx = dir[0], dy = dir[1], dz = dir[2];
@@ -531,10 +553,27 @@ __global__ void __launch_bounds__(kPairWaves * 64) k_ffmlp_ngp_pair(const _Float
                     mid.sigma[row] = expf((float)v);  // activation.py:8-11
                     if (mid.h0) mid.h0[row] = v;
                 } else {
-                    Tm[n * kMidRow + 15 + f] = v;
+                    Tm[n * kRow + 15 + f] = v;
                 }
             }
-        if (h == 1) Tm[n * kMidRow + 31] = (_Float16)0.0f;
+        if constexpr (SEAL) {
+            // columns 31 .. 62: the second encoder's 32 features (level l: columns 31 + 2 l, 32 + 2 l), 63: the zero pad
+#pragma unroll
+            for (uint32_t l = 0; l < NE; l++) {
+                const uint32_t c0 = 31 + 2 * (8 * h + l);
+                _Float16 lo, hi;
+                const uint16_t lo16 = (uint16_t)(enc[l] & 0xFFFFu), hi16 = (uint16_t)(enc[l] >> 16);
+                __builtin_memcpy(&lo, &lo16, 2);
+                __builtin_memcpy(&hi, &hi16, 2);
+                Tm[n * kRow + c0] = lo;
+                Tm[n * kRow + c0 + 1] = hi;
+            }
+            if (h == 1) Tm[n * kRow + 63] = (_Float16)0.0f;
+#pragma unroll
+            for (uint32_t l = 0; l < NE; l++) enc[l] = enx[l];
+        } else {
+            if (h == 1) Tm[n * kRow + 31] = (_Float16)0.0f;
+        }
         {
             float sh[16], j0[1], j1[1], j2[1];
             sh_eval<4, false>(dx, dy, dz, mid.K, sh, j0, j1, j2);
@@ -548,20 +587,21 @@ __global__ void __launch_bounds__(kPairWaves * 64) k_ffmlp_ngp_pair(const _Float
             for (uint32_t i = 0; i < 4; i++) wv[i] = h ? wh[i] : wl[i];
             half8 v;
             __builtin_memcpy(&v, wv, 16);
-            *reinterpret_cast<half8*>(Tm + n * kMidRow + 8 * h) = v;
+            *reinterpret_cast<half8*>(Tm + n * kRow + 8 * h) = v;
         }
         __builtin_amdgcn_wave_barrier();
-        half8 bc[KP];
+        half8 bc[KPC];
 #pragma unroll
-        for (uint32_t s = 0; s < KP; s++) bc[s] = load_bfrag_rowmajor(Tm + n * kMidRow, s, h);
-        if (mid.cin) {  // (optional: the colour-net input rows for a caller that wants them)
+        for (uint32_t s = 0; s < KPC; s++) bc[s] = load_bfrag_rowmajor(Tm + n * kRow, s, h);
+        if (mid.cin) {  // (optional: the colour-net input rows — a training forward keeps them for the backward)
+            constexpr uint32_t PC = INC / 16;  // 16-byte pieces per lane half
 #pragma unroll
-            for (uint32_t c = 0; c < 2; c++)
-                *reinterpret_cast<half8*>(mid.cin + row * 32 + 8 * (2 * h + c)) =
-                    *reinterpret_cast<const half8*>(Tm + n * kMidRow + 8 * (2 * h + c));
+            for (uint32_t c = 0; c < PC; c++)
+                *reinterpret_cast<half8*>(mid.cin + row * INC + 8 * (PC * h + c)) =
+                    *reinterpret_cast<const half8*>(Tm + n * kRow + 8 * (PC * h + c));
         }
         __builtin_amdgcn_wave_barrier();  // (the tile is free for the next row block once every lane has its fragments)
-        const float16v oc = network(frags + (size_t)tot_s * 64, NHc, bc);
+        const float16v oc = pair_network<KPC>(frags + (size_t)tot_s * 64, NHc, bc, lane);
         // colour head (network_ff.py:103 `torch.sigmoid(h)` on the fp16 output): outputs 0..2 as fp32 sigmoid values, rounded
         // where the fp16 op sequence rounds
         if (h == 0) {
@@ -1740,31 +1780,39 @@ S3D_EXPORT int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weigh
 S3D_EXPORT int s3d_ffmlp_ngp_pair_inference(const uint16_t* inputs, const uint16_t* weights_sigma, const uint16_t* weights_color,
                                            uint32_t B, uint32_t hidden_dim, uint32_t num_layers_sigma, uint32_t num_layers_color,
                                            int input_layout, const int32_t* n_valid, const float* dirs, float* sigma,
-                                           float* rgb, uint16_t* color_in, uint16_t* h0, s3d_stream_t stream) {
+                                           float* rgb, uint16_t* color_in, uint16_t* h0, const uint16_t* enc_color,
+                                           s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(inputs && weights_sigma && weights_color && dirs && sigma && rgb, "ffmlp_ngp_pair_inference: null pointer");
     S3D_REQUIRE(hidden_dim == 64, "ffmlp_ngp_pair_inference: hidden_dim 64 (got %u)", hidden_dim);
     S3D_REQUIRE(input_layout == 0 || input_layout == 1, "ffmlp_ngp_pair_inference: input_layout must be 0 (row-major) or 1 (level-major [16][B][2])");
+    const bool seal = enc_color != nullptr;
     if (int rc = check_shape(B, 32, 16, hidden_dim, num_layers_sigma)) return rc;
-    if (int rc = check_shape(B, 32, 16, hidden_dim, num_layers_color)) return rc;
+    if (int rc = check_shape(B, seal ? 64 : 32, 16, hidden_dim, num_layers_color)) return rc;
     MidFwd mid{};
     mid.dirs = dirs; mid.sigma = sigma; mid.cin = (_Float16*)color_in; mid.h0 = (_Float16*)h0;
     host_sh_norm(4, mid.K);
-    PairNets nets{(const _Float16*)weights_sigma, (const _Float16*)weights_color, num_layers_sigma, num_layers_color};
-    const uint32_t nfr = 2 * (4 + 4) + (num_layers_sigma - 1 + num_layers_color - 1) * 8;
-    const size_t smem = (size_t)nfr * 64 * sizeof(half8) + (size_t)kPairWaves * 32 * kMidRow * sizeof(_Float16);
+    PairNets nets{(const _Float16*)weights_sigma, (const _Float16*)weights_color, num_layers_sigma, num_layers_color,
+                  (const _Float16*)enc_color};
+    const uint32_t nfr = (4 + 4) + (seal ? 8 + 4 : 4 + 4) + (num_layers_sigma - 1 + num_layers_color - 1) * 8;
+    const size_t smem = (size_t)nfr * 64 * sizeof(half8) + (size_t)kPairWaves * 32 * (seal ? 72 : kMidRow) * sizeof(_Float16);
     static std::atomic<uint64_t> attr_devs{0};
     int dev;
     if (device_needs_setup(attr_devs, &dev)) {
-        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_ngp_pair), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)((2 * 8 + 2 * (kMaxMlpLayers - 2) * 8) * 1024 + kPairWaves * 32 * kMidRow * 2)));
+        const int cap = (int)((8 + 12 + 2 * (kMaxMlpLayers - 2) * 8) * 1024 + kPairWaves * 32 * 72 * 2);
+        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_ngp_pair<false>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_ngp_pair<true>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
         device_setup_done(attr_devs, dev);
     }
     uint32_t grid = div_up<uint32_t>(B / 32, kPairWaves);
     const uint32_t cap = 3072 / kPairWaves;  // (as k_ffmlp_forward: 3,072 waves = three per SIMD)
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(k_ffmlp_ngp_pair, dim3(grid), dim3(kPairWaves * 64), smem, as_stream(stream), (const _Float16*)inputs, nets, B,
-                       (uint32_t)input_layout, n_valid, rgb, mid);
+    if (seal)
+        hipLaunchKernelGGL(k_ffmlp_ngp_pair<true>, dim3(grid), dim3(kPairWaves * 64), smem, as_stream(stream), (const _Float16*)inputs, nets, B,
+                           (uint32_t)input_layout, n_valid, rgb, mid);
+    else
+        hipLaunchKernelGGL(k_ffmlp_ngp_pair<false>, dim3(grid), dim3(kPairWaves * 64), smem, as_stream(stream), (const _Float16*)inputs, nets, B,
+                           (uint32_t)input_layout, n_valid, rgb, mid);
     return check_launch("ffmlp_ngp_pair_inference");
 }
 

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) k_ngp_mid2_forward(const _Float16* __rest
 }
 
 __global__ void __launch_bounds__(256) k_ngp_mid2_backward(const _Float16* __restrict__ d_cin, const float* __restrict__ d_sigma,
-                                                           const _Float16* __restrict__ h, uint32_t B, _Float16* __restrict__ d_h,
+                                                           const _Float16* __restrict__ h, uint32_t h_stride, uint32_t B, _Float16* __restrict__ d_h,
                                                            _Float16* __restrict__ d_enc, const int32_t* __restrict__ n_valid) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= valid_rows(B, n_valid)) return;
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) k_ngp_mid2_backward(const _Float16* __res
 #pragma unroll
         for (int i = 0; i < 8; i++) row[8 * k + i] = v[i];
     }
-    const float h0 = (float)h[(size_t)b * 16];
+    const float h0 = (float)h[(size_t)b * h_stride];
     const float gs = d_sigma ? d_sigma[b] * expf(fminf(15.0f, fmaxf(-15.0f, h0))) : 0.0f;  // activation.py:13-16
     h8 o0, o1;
     o0[0] = (_Float16)gs;
@@ -381,12 +381,14 @@ S3D_EXPORT int s3d_ngp_mid2_forward(const uint16_t* h, const float* dirs, const 
     return check_launch("ngp_mid2_forward");
 }
 
-S3D_EXPORT int s3d_ngp_mid2_backward(const uint16_t* grad_color_in, const float* grad_sigma, const uint16_t* h, uint32_t B,
-                                     uint16_t* grad_h, uint16_t* grad_enc_color, const int32_t* n_valid, s3d_stream_t stream) {
+S3D_EXPORT int s3d_ngp_mid2_backward(const uint16_t* grad_color_in, const float* grad_sigma, const uint16_t* h, uint32_t h_stride,
+                                     uint32_t B, uint16_t* grad_h, uint16_t* grad_enc_color, const int32_t* n_valid,
+                                     s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(grad_color_in && h && grad_h, "ngp_mid2_backward: null pointer");
+    S3D_REQUIRE(h_stride == 16 || h_stride == 1, "ngp_mid2_backward: h_stride is 16 (rows of the density network's output) or 1 (its first column alone)");
     hipLaunchKernelGGL(k_ngp_mid2_backward, dim3(div_up<uint32_t>(B, 256)), dim3(256), 0, as_stream(stream),
-                       (const _Float16*)grad_color_in, grad_sigma, (const _Float16*)h, B, (_Float16*)grad_h,
+                       (const _Float16*)grad_color_in, grad_sigma, (const _Float16*)h, h_stride, B, (_Float16*)grad_h,
                        (_Float16*)grad_enc_color, n_valid);
     return check_launch("ngp_mid2_backward");
 }

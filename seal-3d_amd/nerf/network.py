@@ -9,6 +9,7 @@ from torch.autograd import Function
 
 import s3d_hip
 from activation import trunc_exp
+_ffb = s3d_hip.FFMLPBackend
 from encoding import get_encoder
 from ffmlp.ffmlp import _ParamRef, ffmlp_forward
 from gridencoder.grid import grid_encode_pair
@@ -47,6 +48,72 @@ class _SealMid(Function):
         _head.mid2_backward(g_cin.to(torch.float16).contiguous(), None if g_sigma is None else g_sigma.float().contiguous(), h, g_h,
                             g_enc, ctx.n_valid)
         return g_h, None, g_enc, None
+
+
+class _SealPair(Function):
+    """The whole network head of nerf/network.py:99-128 behind the two encoders — density MLP, trunc_exp, the colour-net input
+    row [half(SH_4(d)) | h[:, 1:] | encoder_color(x) | 0], colour MLP, sigmoid — as ONE forward launch
+    (s3d_ffmlp_ngp_pair_inference with enc_color: k_ffmlp_ngp_pair<true>; the row never leaves the chip in inference and is written
+    once for the backward in training).  Backward = the calls the separate Functions make: colour MLP (colour head) -> mid2 backward
+    -> density MLP, with ONE weight-gradient reduce launch for the two (s3d_ffmlp_wgrad_reduce_pair)."""
+
+    @staticmethod
+    def forward(ctx, e0, e1, w_sigma, w_color, dirs, refs, hook_s, hook_c, n_valid, keep):
+        B = e0.shape[1]
+        e0, e1 = e0.to(torch.half).contiguous(), e1.to(torch.half).contiguous()
+        w_sigma, w_color = w_sigma.to(torch.half).contiguous(), w_color.to(torch.half).contiguous()
+        dirs = dirs.float().contiguous()
+        sigma = torch.empty(B, device=e0.device, dtype=torch.float32)
+        rgb = torch.empty(B, 3, device=e0.device, dtype=torch.float32)
+        cin = torch.empty(B, 64, device=e0.device, dtype=torch.half) if keep else None
+        h0 = torch.empty(B, device=e0.device, dtype=torch.half) if keep else None
+        _ffb.ngp_pair_inference(e0, w_sigma, w_color, B, 64, 2, 2, dirs, sigma, rgb, 1, n_valid, cin, h0, e1)
+        if keep:
+            ctx.save_for_backward(e0, w_sigma, w_color, h0, cin, rgb)
+            ctx.refs, ctx.n_valid = refs, n_valid
+            ctx.need = (e0.requires_grad, e1.requires_grad)
+            ctx.set_materialize_grads(False)
+        return sigma, rgb
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_rgb):
+        e0, w_sigma, w_color, h0, cin, rgb = ctx.saved_tensors
+        B, dev = h0.shape[0], h0.device
+        nv = {"n_valid": ctx.n_valid} if ctx.n_valid is not None else {}
+
+        def target(ref, w):
+            stash = getattr(ref.param, "_s3d_grad", None) if ref is not None else None
+            acc, fi = False, None
+            if stash is not None:
+                acc = not getattr(ref.param, "_s3d_overwrite", False)
+                fi = getattr(ref.param, "_s3d_found_inf", None)
+            return stash, (stash.view(w.shape) if stash is not None else torch.empty_like(w)), acc, fi
+        ref_s, ref_c = ctx.refs
+        nb_c = (_ffb.backward_workspace_bytes(64, 16, 64, 2) + 255) // 256 * 256
+        nb_s = _ffb.backward_workspace_bytes(32, 16, 64, 2)
+        scratch = torch.empty(nb_c + nb_s, dtype=torch.uint8, device=dev)
+        ws_c, ws_s = scratch[:nb_c], scratch[nb_c:]
+        stash_c, gw_c, acc_c, fi_c = target(ref_c, w_color)
+        g_cin = torch.empty_like(cin)
+        if g_rgb is None:
+            g_rgb = torch.zeros_like(rgb)
+        ex_c = {"found_inf": fi_c} if fi_c is not None else {}
+        _ffb.ffmlp_backward(None, cin, w_color, None, B, 64, 16, 64, 2, 0, 6, True, None, g_cin, gw_c,
+                            grad_rgb=g_rgb.float().contiguous(), rgb_head=rgb, workspace=ws_c, defer_reduce=True, **nv, **ex_c)
+        g_h = torch.empty(B, 16, dtype=torch.half, device=dev)
+        g_e1 = torch.empty(16, B, 2, dtype=torch.half, device=dev) if ctx.need[1] else None
+        _head.mid2_backward(g_cin, None if g_sigma is None else g_sigma.float().contiguous(), h0, g_h, g_e1, ctx.n_valid)
+        stash_s, gw_s, acc_s, fi_s = target(ref_s, w_sigma)
+        g_e0 = torch.empty_like(e0) if ctx.need[0] else torch.zeros(1, device=dev, dtype=e0.dtype)
+        ex_s = {"found_inf": fi_s} if fi_s is not None else {}
+        _ffb.ffmlp_backward(g_h, e0, w_sigma, None, B, 32, 16, 64, 2, 0, 6, ctx.need[0], None, g_e0, gw_s, input_layout=1,
+                            workspace=ws_s, defer_reduce=True, **nv, **ex_s)
+        _ffb.wgrad_reduce_pair((ws_c, B, 64, 64, 2, gw_c, acc_c, fi_c), (ws_s, B, 32, 64, 2, gw_s, acc_s, fi_s))
+        for stash, ref in ((stash_s, ref_s), (stash_c, ref_c)):
+            if stash is not None:
+                ref.param._s3d_grad_touched = True
+        return ((g_e0 if ctx.need[0] else None), g_e1, (None if stash_s is not None else gw_s),
+                (None if stash_c is not None else gw_c)) + (None,) * 6
 
 
 class PackedWeights:
@@ -199,6 +266,7 @@ class NeRFNetwork(NeRFRenderer):
     #   colour net 63 -> 64 -> 64 -> 3 = ffmlp [W0 padded to 64 columns | W1 | W2 padded to 16 rows]
     # Same arithmetic as the reference's autocast path: fp16 operands, fp32 accumulation, fp16 activations; SH values
     # rounded to fp16 where the first Linear's input cast rounds them; sigmoid evaluated in fp32 and rounded to fp16.
+    fused_pair = os.environ.get("S3D_FUSED_PAIR", "1") != "0"  # A-B runs: False = density MLP, head kernel and colour MLP as three launches
     fused_encoders = os.environ.get("S3D_FUSED_ENCODERS", "1") != "0"  # A-B runs: False = one forward launch per encoder
     fused_mlp = os.environ.get("S3D_FUSED_SEAL", "1") != "0"  # tests / A-B runs: False = nn.Linear op sequence
 
@@ -254,6 +322,12 @@ class NeRFNetwork(NeRFRenderer):
         # both encoders read the same points: one launch for the two tables when the colour is wanted too
         pair = grid_encode_pair(self.encoder, self.encoder_color, x, self.bound, nv, live) if (want_rgb and self.fused_encoders) else None
         e0 = pair[0] if pair is not None else self.encoder(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
+        if want_rgb and self.fused_pair and x.shape[0] % 128 == 0 and s3d_hip.FFMLPBackend.fused_backward_supported(64, 16, 64, 2, 0):
+            # density MLP + head + colour MLP + sigmoid in one launch (the colour-net input row is built on chip)
+            e1 = pair[1] if pair is not None else self.encoder_color(x, bound=self.bound, level_major=True, n_valid=nv, live=live)
+            keep = torch.is_grad_enabled() and (e0.requires_grad or e1.requires_grad or ws.requires_grad or wc.requires_grad
+                                                or rs is not None or rc is not None)
+            return _SealPair.apply(e0, e1, ws, wc, d, (rs, rc), hs, hc, nv, keep)
         h = ffmlp_forward(e0, ws, 32, 16, 64, 2, 0, 6, infer, e0.requires_grad, rs, hs, 1, nv)
         if not want_rgb:
             return h

@@ -573,7 +573,7 @@ class FFMLPBackend:
 
     @staticmethod
     def ngp_pair_inference(inputs, weights_sigma, weights_color, B, hidden_dim, num_layers_sigma, num_layers_color, dirs,
-                           sigma, rgb, input_layout=0, n_valid=None, color_in=None, h0=None):
+                           sigma, rgb, input_layout=0, n_valid=None, color_in=None, h0=None, enc_color=None):
         """density network + head + colour network + sigmoid in one launch (seal3d_hip.h: s3d_ffmlp_ngp_pair_inference)"""
         for t, n in ((inputs, "inputs"), (weights_sigma, "weights_sigma"), (weights_color, "weights_color")):
             _need(t, torch.float16, n)
@@ -581,7 +581,8 @@ class FFMLPBackend:
             _need(t, torch.float32, n)
         _check(lib().s3d_ffmlp_ngp_pair_inference(_p(inputs), _p(weights_sigma), _p(weights_color), _u(B), _u(hidden_dim),
                                                   _u(num_layers_sigma), _u(num_layers_color), C.c_int(int(input_layout)),
-                                                  _nv(n_valid), _p(dirs), _p(sigma), _p(rgb), _p(color_in), _p(h0), _stream()),
+                                                  _nv(n_valid), _p(dirs), _p(sigma), _p(rgb), _p(color_in), _p(h0), _p(enc_color),
+                                                  _stream()),
                "ffmlp_ngp_pair_inference")
 
     @staticmethod
@@ -802,8 +803,10 @@ class NgpHeadBackend:
             _need(grad_sigma, torch.float32, "grad_sigma")
         if grad_enc_color is not None:
             _need(grad_enc_color, torch.float16, "grad_enc_color")
-        _check(lib().s3d_ngp_mid2_backward(_p(grad_color_in), _p(grad_sigma), _p(h), _u(h.shape[0]), _p(grad_h), _p(grad_enc_color),
-                                           _nv(n_valid), _stream()), "ngp_mid2_backward")
+        # h: the density network's [B, 16] output, or its first column [B] alone (the one-launch pair keeps only that)
+        _need(h, torch.float16, "h")
+        _check(lib().s3d_ngp_mid2_backward(_p(grad_color_in), _p(grad_sigma), _p(h), _u(16 if h.dim() == 2 else 1), _u(h.shape[0]),
+                                           _p(grad_h), _p(grad_enc_color), _nv(n_valid), _stream()), "ngp_mid2_backward")
 
     @staticmethod
     def rgb_forward(out, rgb, n_valid=None):

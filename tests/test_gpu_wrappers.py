@@ -9,6 +9,13 @@ from nerf import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
+def s3d_ctx(counter, rows):
+    """the renderer's announcement of a device-side row count (s3d_hip.row_limit), or nothing"""
+    import contextlib
+    import s3d_hip
+    return s3d_hip.row_limit(counter, rows) if counter is not None else contextlib.nullcontext()
+
+
 def test_grid_encoder_module_autocast_and_grads(oracle, hip):
     import gridencoder.grid as gg
     torch.manual_seed(0)
@@ -277,6 +284,50 @@ def test_seal_network_fused_mlps_match_linear_op_sequence(hip):
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
         s2, c2 = net(x, d)
     assert torch.equal(s2.float(), res[True][0]) and torch.equal(c2.float(), res[True][1])
+
+
+@pytest.mark.parametrize("B,ragged", [(128 * 9, 0), (128 * 40, 333)])
+def test_seal_network_one_launch_pair_matches_the_three_launches(hip, B, ragged):
+    """nerf/network.py's fused path with the one-launch MLP pair (k_ffmlp_ngp_pair<true>: density MLP, trunc_exp, colour-net input
+    row with the second encoder's features, colour MLP, sigmoid) against the same path as three launches (density MLP, mid2
+    kernel, colour MLP): sigma bit for bit, rgb equal except where an inlined SH term rounds the other way (one fp16 ulp of a
+    colour-net input), every gradient to fp16 accuracy; with a device-side row limit the rows behind it are never read back."""
+    from nerf import network
+    torch.manual_seed(3)
+    net = network.NeRFNetwork(bound=1, cuda_ray=True, log2_hashmap_size=16).cuda()
+    net.encoder.embeddings.data.uniform_(-0.5, 0.5)
+    net.encoder_color.embeddings.data.uniform_(-0.5, 0.5)
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(B, 3, generator=g) * 2 - 1).cuda()
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1).cuda()
+    w_s, w_c = torch.rand(B, generator=g).cuda(), torch.rand(B, 3, generator=g).cuda()
+    rows = B
+    if ragged:
+        nv = torch.tensor([B - ragged], dtype=torch.int32, device="cuda")
+        rows = B - ragged
+    res = {}
+    net.train()
+    for pair in (True, False):
+        net.fused_pair = pair
+        net.zero_grad(set_to_none=True)
+        with s3d_ctx(nv if ragged else None, B), torch.autocast("cuda", dtype=torch.float16):
+            sigma, rgb = net(x, d)
+            loss = (sigma.float()[:rows] * w_s[:rows]).sum() * 1e-3 + (rgb.float()[:rows] * w_c[:rows]).sum()
+        loss.backward()
+        res[pair] = (sigma.float().detach()[:rows].clone(), rgb.float().detach()[:rows].clone(),
+                     [p.grad.clone() for p in net.parameters()])
+    net.fused_pair = True
+    assert torch.equal(res[True][0], res[False][0])
+    assert float((res[True][1] != res[False][1]).any(-1).float().mean()) < 2e-3
+    torch.testing.assert_close(res[True][1], res[False][1], rtol=0, atol=2e-3)
+    for (name, _), a, b in zip(net.named_parameters(), res[True][2], res[False][2]):
+        a, b = a.float(), b.float()
+        assert float(b.abs().max()) > 0, name
+        assert (a - b).norm() / b.norm() < 5e-3, f"{name} gradient differs: {(a - b).norm() / b.norm()}"
+    net.eval()
+    with torch.no_grad(), s3d_ctx(nv if ragged else None, B), torch.autocast("cuda", dtype=torch.float16):
+        s2, c2 = net(x, d)
+    assert torch.equal(s2.float()[:rows], res[True][0]) and torch.equal(c2.float()[:rows], res[True][1])
 
 
 def test_cached_half_weights_follow_a_fused_torch_optimizer(hip):
