@@ -22,6 +22,7 @@
 // WMMA; parity target is the dense math of testing/test_ffmlp.py's torch twin, fp16 tolerance).
 #include "s3d_common.hpp"
 #include "sh_eval.hpp"
+#include <stdlib.h>
 
 namespace s3d {
 namespace {
@@ -466,7 +467,17 @@ __device__ __forceinline__ float16v pair_network(const half8* a0, uint32_t NH, c
 // [half(SH_4(d)) | h1..h15 | encoder_color(x) (32) | 0] — k_ngp_mid2_forward's row, built in the wave's tile; the second encoder's
 // features are requested with the next tile's inputs.
 template <bool SEAL>
-__global__ void __launch_bounds__(kPairWaves * 64) k_ffmlp_ngp_pair(const _Float16* __restrict__ X, const PairNets nets, uint32_t B,
+// (occupancy, measured with tools/bench_pair.py at 1.6e6 rows: the NGP variant needs 114 registers — two 8-wave workgroups per
+//  CU; the Seal variant 148: forced down to 128 it spills 14 and takes 104 - 118 us against 98 with ONE workgroup per CU)
+#ifndef S3D_PAIR_WPE
+#define S3D_PAIR_WPE 0
+#endif
+#if S3D_PAIR_WPE
+#define S3D_PAIR_OCC __attribute__((amdgpu_waves_per_eu(S3D_PAIR_WPE, S3D_PAIR_WPE)))
+#else
+#define S3D_PAIR_OCC
+#endif
+__global__ void __launch_bounds__(kPairWaves * 64) S3D_PAIR_OCC k_ffmlp_ngp_pair(const _Float16* __restrict__ X, const PairNets nets, uint32_t B,
                                                                    uint32_t in_layout, const int32_t* __restrict__ n_valid,
                                                                    float* __restrict__ rgb_head, const MidFwd mid) {
     constexpr uint32_t W = 64, MB = 2, KS = 4, KP = 2, IN = 32;
@@ -1777,6 +1788,20 @@ S3D_EXPORT int s3d_ffmlp_inference(const uint16_t* inputs, const uint16_t* weigh
                              mid_color_in, mid_h0, stream);
 }
 
+// CUs of the current device, cached per device ordinal (resident-workgroup counts of the persistent kernels)
+static uint32_t cu_count() {
+    static std::atomic<uint32_t> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 256;
+    uint32_t n = cus[dev].load(std::memory_order_relaxed);
+    if (!n) {
+        int v = 0;
+        n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? (uint32_t)v : 256u;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 S3D_EXPORT int s3d_ffmlp_ngp_pair_inference(const uint16_t* inputs, const uint16_t* weights_sigma, const uint16_t* weights_color,
                                            uint32_t B, uint32_t hidden_dim, uint32_t num_layers_sigma, uint32_t num_layers_color,
                                            int input_layout, const int32_t* n_valid, const float* dirs, float* sigma,
@@ -1805,7 +1830,14 @@ S3D_EXPORT int s3d_ffmlp_ngp_pair_inference(const uint16_t* inputs, const uint16
         device_setup_done(attr_devs, dev);
     }
     uint32_t grid = div_up<uint32_t>(B / 32, kPairWaves);
-    const uint32_t cap = 3072 / kPairWaves;  // (as k_ffmlp_forward: 3,072 waves = three per SIMD)
+    // persistent workgroups, as many as are resident at once: two per CU (NGP: 60 KB of LDS, 114 registers), one per CU (Seal:
+    // 148 registers).  [384 workgroups — three waves per SIMD on paper — left half of the CUs with two workgroups and half with
+    // one: 93 us per render iteration of 1.6e6 rows against 79 at 512; Seal variant 118 against 98 at 256]
+#ifdef S3D_PAIR_CAP  // (variant builds for A/B runs)
+    const uint32_t cap = S3D_PAIR_CAP;
+#else
+    const uint32_t cap = (seal ? 1u : 2u) * cu_count() * 8u / kPairWaves;
+#endif
     if (grid > cap) grid = cap;
     if (seal)
         hipLaunchKernelGGL(k_ffmlp_ngp_pair<true>, dim3(grid), dim3(kPairWaves * 64), smem, as_stream(stream), (const _Float16*)inputs, nets, B,
