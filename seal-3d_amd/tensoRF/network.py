@@ -59,6 +59,51 @@ class _VmFeatures(torch.autograd.Function):
         return (gx, None, None) + tuple(grads[1:] if ctx.needs_input_grad[0] else grads)
 
 
+class _TallLinear(torch.autograd.Function):
+    """y = x W^T of a bias-free nn.Linear on [N, in] rows with N >> out * in (basis_mat 144 -> 27 and the colour MLP of
+    tensoRF/network.py:71-83 at ~1e5 samples per step).  Forward and data gradient are the library GEMMs nn.Linear runs under
+    autocast; the WEIGHT gradient dW = G^T X has the batch as its reduction dimension and an output of a few tiles — the
+    library's pick for it (one 16x16 tile per workgroup, 18 workgroups walking 1e5 rows) took 0.72 ms for basis_mat and 0.32 ms
+    per 128-wide layer, a third of the training step (profiles/r09_tensorf.md).  Here the rows are cut into chunks of 1,024:
+    one batched GEMM gives a partial sum per chunk (hundreds of workgroups), summed in fp32."""
+    CHUNK = 1024
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float16)
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return F.linear(x, weight)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type="cuda")
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            R = _TallLinear.CHUNK
+            N = x.shape[0]
+            nfull = N // R
+            gw = torch.zeros(weight.shape, dtype=torch.float32, device=x.device)
+            if nfull:
+                xc = x[:nfull * R].reshape(nfull, R, x.shape[1])
+                gc = g[:nfull * R].reshape(nfull, R, g.shape[1])
+                gw += torch.bmm(gc.transpose(1, 2), xc).sum(0, dtype=torch.float32)
+            if nfull * R < N:
+                gw += (g[nfull * R:].t() @ x[nfull * R:]).float()
+            gw = gw.to(weight.dtype)
+        return gx, gw
+
+
+def _linear(layer, x):
+    """a bias-free nn.Linear; tall batches that record a weight gradient go through _TallLinear"""
+    if (layer.bias is None and x.is_cuda and x.dim() == 2 and x.shape[0] >= 8 * _TallLinear.CHUNK and torch.is_grad_enabled()
+            and layer.weight.requires_grad and torch.is_autocast_enabled("cuda")):
+        return _TallLinear.apply(x, layer.weight)
+    return layer(x)
+
+
 class NeRFNetwork(NeRFRenderer):
     def __init__(self, resolution=(128, 128, 128), sigma_rank=(16, 16, 16), color_rank=(48, 48, 48), color_feat_dim=27,
                  num_layers=3, hidden_dim=128, bound=1, **kwargs):
@@ -123,8 +168,8 @@ class NeRFNetwork(NeRFRenderer):
 
     def get_color_feat(self, x):
         if self._use_native(x):
-            return self.basis_mat(_VmFeatures.apply(x, self, False, *self.color_mat, *self.color_vec).T)
-        return self.basis_mat(self._color_prod_torch(x, self.color_mat, self.color_vec).T)
+            return _linear(self.basis_mat, _VmFeatures.apply(x, self, False, *self.color_mat, *self.color_vec).T)
+        return _linear(self.basis_mat, self._color_prod_torch(x, self.color_mat, self.color_vec).T)
 
     def _normalize(self, x):
         return 2 * (x - self.aabb_train[:3]) / (self.aabb_train[3:] - self.aabb_train[:3]) - 1
@@ -134,7 +179,7 @@ class NeRFNetwork(NeRFRenderer):
         sigma = trunc_exp(self.get_sigma_feat(x))
         h = torch.cat([self.encoder(self.get_color_feat(x)), self.encoder_dir(d)], dim=-1)
         for k, layer in enumerate(self.color_net):
-            h = layer(h)
+            h = _linear(layer, h)
             if k != self.num_layers - 1:
                 h = F.relu(h, inplace=True)
         return sigma, torch.sigmoid(h)

@@ -138,6 +138,34 @@ def test_tensorf_vm48_step_on_gpu(hip):
     assert out["image"].shape == (1, 1000, 3) and torch.isfinite(out["image"]).all()
 
 
+@pytest.mark.parametrize("N,shape", [(100_000 + 37, (27, 144)), (16 * 1024, (128, 150)), (9000, (3, 128))])
+def test_tensorf_tall_linear_matches_nn_linear_under_autocast(hip, N, shape):
+    """tensoRF/network.py:_TallLinear (weight gradient as a batched GEMM over 1,024-row chunks, summed in fp32) vs nn.Linear
+    under fp16 autocast — the reference's basis_mat / colour-MLP layers (tensoRF/network.py:71-83): same forward values, same
+    data gradient, weight gradient within fp16 rounding of a 1e5-term sum."""
+    from tensoRF import network as trf
+    torch.manual_seed(N)
+    layer = torch.nn.Linear(shape[1], shape[0], bias=False).cuda()
+    x0 = torch.randn(N, shape[1], device="cuda")
+    go = torch.randn(N, shape[0], device="cuda") * 1e-2
+    res = []
+    for tall in (True, False):
+        layer.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            y = trf._linear(layer, x) if tall else layer(x)
+            if tall:
+                assert y.grad_fn.__class__.__name__.startswith("_TallLinear")
+        y.backward(go.to(y.dtype))
+        res.append((y.detach().float(), x.grad.clone(), layer.weight.grad.clone()))
+    (y_a, gx_a, gw_a), (y_b, gx_b, gw_b) = res
+    assert torch.equal(y_a, y_b) and torch.equal(gx_a, gx_b)
+    gw_ref = (go.half().double().t() @ x0.half().double()).float()
+    scale = float(gw_ref.abs().max())
+    assert float((gw_a - gw_ref).abs().max()) <= 2e-3 * scale
+    assert float((gw_a - gw_ref).abs().max()) <= float((gw_b - gw_ref).abs().max()) + 1e-3 * scale  # no worse than the library's single GEMM
+
+
 @pytest.mark.parametrize("kind", ["both", "to", "from"])
 def test_seal_bbox_mapper_device_kernel_matches_torch_sequence(hip, kind):
     """csrc/seal.hip vs the torch restatement of SealNeRF/seal_utils.py:132-279 on the same points: identical masks (a point
