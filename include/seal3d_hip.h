@@ -351,6 +351,22 @@ int s3d_vm_features_backward(const float* x, uint32_t N, const float* const* pla
                              const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
                              float* const* grad_planes, float* const* grad_lines, s3d_stream_t stream);
 
+/* The colour features with basis_mat applied inside the kernel (tensoRF/network.py:149-153: `basis_mat((mat * vec).T)`, an
+ * nn.Linear(sum rank, basis_rows, bias=False) that runs under fp16 autocast): out [N, basis_rows] fp16 =
+ * half(sum_row half(basis[c][row]) * half(product[row][n])) with fp32 accumulation; the [sum rank, N] products are never
+ * written.  basis: fp16 [basis_rows, sum rank] (the Linear's weight), basis_rows <= 32.
+ * s3d_vm_color_backward: from grad_out [N, basis_rows] fp16 (the gradient of that output) the factor gradients as
+ * s3d_vm_features_backward writes them (same perm / start / gm / zero-initialised buffers) and grad_basis fp32
+ * [basis_rows, sum rank] (zero-initialised; accumulated with atomics). */
+int s3d_vm_color_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
+                         const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
+                         uint16_t* out, s3d_stream_t stream);
+int s3d_vm_color_backward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
+                          const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
+                          const uint16_t* grad_out, const int32_t* perm, const int32_t* start, uint32_t n_bounds,
+                          float* gm, float* const* grad_planes, float* const* grad_lines, float* grad_basis,
+                          s3d_stream_t stream);
+
 /* ------------------------------------------------------------------ NGP head glue
  * The elementwise steps between the two MLPs of nerf/network_ff.py:55-96 (slice / trunc_exp / SH / cat / cast /
  * sigmoid and their backward nodes) as two streaming kernels per direction, csrc/ngp_head.hip.

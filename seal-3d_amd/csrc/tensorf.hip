@@ -73,6 +73,77 @@ __global__ void __launch_bounds__(256) k_vm_features(const float* __restrict__ x
     if (REDUCE) out[n] = total;
 }
 
+// ---- the colour features with basis_mat applied on the spot (tensoRF/network.py:149-153: basis_mat((mat * vec).T)) ----
+// The products never leave the lane: out[n][c] = sum_row W[c][row] * prod[row], the arithmetic of the fp16 autocast
+// nn.Linear the reference runs (operands rounded to binary16, fp32 accumulation, binary16 result).  W sits in LDS as
+// fp32 [rows][kVmBasisPad]; every lane reads the same row (broadcast, four columns per ds_read_b128).  Saves the
+// [sum R, N] fp32 round trip (2 x 60 MB per step at 1e5 samples), the transposing fp16 cast and the GEMM launch.
+constexpr uint32_t kVmBasisPad = 32;  // output channels held per lane (basis_mat: 27)
+
+__global__ void __launch_bounds__(256) k_vm_color_basis(const float* __restrict__ x, uint32_t N, VmFactors f,
+                                                        const _Float16* __restrict__ basis, uint32_t Cb, uint32_t rows,
+                                                        _Float16* __restrict__ out) {
+    extern __shared__ float vm_smem[];  // [rows][kVmBasisPad]
+    for (uint32_t e = threadIdx.x; e < rows * kVmBasisPad; e += 256) {
+        const uint32_t row = e / kVmBasisPad, c = e % kVmBasisPad;
+        vm_smem[e] = c < Cb ? (float)basis[(size_t)c * rows + row] : 0.0f;
+    }
+    __syncthreads();
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float p[3] = {x[(size_t)n * 3], x[(size_t)n * 3 + 1], x[(size_t)n * 3 + 2]};
+    float acc[kVmBasisPad];
+#pragma unroll
+    for (uint32_t c = 0; c < kVmBasisPad; c++) acc[c] = 0.0f;
+#pragma unroll 1
+    for (uint32_t i = 0; i < 3; i++) {
+        const int W = (int)f.W[i], H = (int)f.H[i], Dn = (int)f.Dn[i];
+        const float ix = unnormalize(p[f.cu[i]], f.W[i]), iy = unnormalize(p[f.cv[i]], f.H[i]), iz = unnormalize(p[f.cw[i]], f.Dn[i]);
+        const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+        const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+        const float nw = wx0 * wy0, ne = wx1 * wy0, sw = wx0 * wy1, se = wx1 * wy1;
+        const float lz1 = iz - fz, lz0 = (fz + 1.0f) - iz;
+        const bool okx = fabsf(ix) < 1e9f, oky = fabsf(iy) < 1e9f, okz = fabsf(iz) < 1e9f;
+        const int x0 = okx ? (int)fx : -2, y0 = oky ? (int)fy : -2, z0 = okz ? (int)fz : -2;
+        const bool bx0 = x0 >= 0 && x0 < W, bx1 = x0 + 1 >= 0 && x0 + 1 < W;
+        const bool by0 = y0 >= 0 && y0 < H, by1 = y0 + 1 >= 0 && y0 + 1 < H;
+        const bool bz0 = z0 >= 0 && z0 < Dn, bz1 = z0 + 1 >= 0 && z0 + 1 < Dn;
+        const float* P = f.plane[i];
+        const float* Lq = f.line[i];
+        const size_t plane_stride = (size_t)H * W;
+        const int o_nw = y0 * W + x0;
+        for (uint32_t r = 0; r < f.rank[i]; r++) {
+            const float* pr = P + r * plane_stride;
+            const float* lr = Lq + (size_t)r * Dn;
+            const float v_nw = (bx0 && by0) ? pr[o_nw] : 0.0f, v_ne = (bx1 && by0) ? pr[o_nw + 1] : 0.0f;
+            const float v_sw = (bx0 && by1) ? pr[o_nw + W] : 0.0f, v_se = (bx1 && by1) ? pr[o_nw + W + 1] : 0.0f;
+            const float l0 = bz0 ? lr[z0] : 0.0f, l1 = bz1 ? lr[z0 + 1] : 0.0f;
+            float m = 0.0f;
+            if (bx0 && by0) m += v_nw * nw;
+            if (bx1 && by0) m += v_ne * ne;
+            if (bx0 && by1) m += v_sw * sw;
+            if (bx1 && by1) m += v_se * se;
+            float l = 0.0f;
+            if (bz0) l += l0 * lz0;
+            if (bz1) l += l1 * lz1;
+            const float prod = (float)(_Float16)(m * l);  // (the autocast Linear's fp16 input)
+            const float4* wrow = reinterpret_cast<const float4*>(vm_smem + (size_t)(f.row0[i] + r) * kVmBasisPad);
+#pragma unroll
+            for (uint32_t q = 0; q < kVmBasisPad / 4; q++) {
+                const float4 w = wrow[q];
+                acc[4 * q] = __builtin_fmaf(prod, w.x, acc[4 * q]);
+                acc[4 * q + 1] = __builtin_fmaf(prod, w.y, acc[4 * q + 1]);
+                acc[4 * q + 2] = __builtin_fmaf(prod, w.z, acc[4 * q + 2]);
+                acc[4 * q + 3] = __builtin_fmaf(prod, w.w, acc[4 * q + 3]);
+            }
+        }
+    }
+    _Float16* o = out + (size_t)n * Cb;
+#pragma unroll
+    for (uint32_t c = 0; c < kVmBasisPad; c++)
+        if (c < Cb) o[c] = (_Float16)acc[c];
+}
+
 // ------------------------------------------------------------------ backward (parameter gradients)
 // torch's grid_sample backward scatters every corner contribution with a global fp32 atomic: 2.8e8 atomics per step at
 // the Lego sample count, ~13 ms at the 21 G/s such atomics retire on MI355X.  Here the points are
@@ -130,11 +201,22 @@ struct VmBackward {
     const int32_t* perm;   // [6][N] point ids sorted by key (rows as in k_vm_keys)
     const int32_t* start;  // [6][n_bounds]: first sorted position with key >= t
     uint32_t n_bounds, rows;
+    // basis_mat behind the products (BASIS kernels): g = [N, Cb] fp16 gradient of the Linear's OUTPUT instead of the products'
+    const _Float16* basis;   // [Cb][rows]
+    const _Float16* g_out;   // [N][Cb]
+    float* d_basis;          // [Cb][rows] fp32, zero-initialised
+    uint32_t Cb;
 };
 
 // RP = lanes per point (16 or 64 >= rank); a wave handles 64 / RP points per trip
-template <int RP, bool REDUCE>
+// BASIS (colour features behind basis_mat, REDUCE = false): lane r derives its product gradient from the Linear's output
+// gradient, g_r = sum_c W[c][row0 + r] * g_out[n][c] (its column of W lives in registers, the point's Cb gradients are the
+// same for the whole 64-lane group), and accumulates basis_mat's own gradient dW[c][row0 + r] += g_out[n][c] * prod_r in
+// registers — flushed with one atomic per (c, r) and workgroup.  Every (point, component) is visited by exactly one lane group
+// of this kernel, so the three components' launches cover dW once.
+template <int RP, bool REDUCE, bool BASIS = false>
 __global__ void __launch_bounds__(256) k_vm_plane_backward(const float* __restrict__ x, uint32_t N, VmFactors f, VmBackward b) {
+    static_assert(!BASIS || (RP == 64 && !REDUCE), "basis_mat sits behind the 48-rank colour products");
     extern __shared__ float vm_smem[];
     const uint32_t i = blockIdx.y;
     const int W = (int)f.W[i], H = (int)f.H[i], Dn = (int)f.Dn[i];
@@ -165,11 +247,32 @@ __global__ void __launch_bounds__(256) k_vm_plane_backward(const float* __restri
     const uint32_t sub = lane / RP, r = lane % RP;
     const int32_t* perm = b.perm + (size_t)i * N;
     const float* Lq = f.line[i];
+    float wcol[BASIS ? kVmBasisPad : 1], dw[BASIS ? kVmBasisPad : 1];
+    if constexpr (BASIS) {
+#pragma unroll
+        for (uint32_t c = 0; c < kVmBasisPad; c++) {
+            wcol[c] = (c < b.Cb && r < R) ? (float)b.basis[(size_t)c * b.rows + f.row0[i] + r] : 0.0f;
+            dw[c] = 0.0f;
+        }
+    }
     for (uint32_t k = begin + wave * PPW + sub; k < end; k += 4 * PPW) {
-        const uint32_t n = (uint32_t)perm[k];
+        uint32_t n = (uint32_t)perm[k];
+        if constexpr (BASIS) n = __builtin_amdgcn_readfirstlane(n);  // (RP = 64: one point per wave trip)
         const VmPoint q = vm_locate(x, n, f, i);
         if (r >= R) continue;
-        const float g = REDUCE ? b.g[n] : b.g[(size_t)n * b.rows + f.row0[i] + r];
+        float g;
+        float go[BASIS ? kVmBasisPad : 1];
+        if constexpr (BASIS) {
+            const _Float16* gp = b.g_out + (size_t)n * b.Cb;
+            g = 0.0f;
+#pragma unroll
+            for (uint32_t c = 0; c < kVmBasisPad; c++) {
+                go[c] = c < b.Cb ? (float)gp[c] : 0.0f;
+                g = __builtin_fmaf(go[c], wcol[c], g);
+            }
+        } else {
+            g = REDUCE ? b.g[n] : b.g[(size_t)n * b.rows + f.row0[i] + r];
+        }
         const bool bz0 = q.z0 >= 0 && q.z0 < Dn, bz1 = q.z0 + 1 >= 0 && q.z0 + 1 < Dn;
         float l = 0.0f;
         if (bz0) l += Lq[(size_t)r * Dn + q.z0] * q.lz0;
@@ -185,6 +288,18 @@ __global__ void __launch_bounds__(256) k_vm_plane_backward(const float* __restri
         if (bx0 && by1) { m += pv[(c_nw + kVmTile + 1) * R + r] * q.sw; atomicAdd(&acc[(c_nw + kVmTile + 1) * R + r], gl * q.sw); }
         if (bx1 && by1) { m += pv[(c_nw + kVmTile + 2) * R + r] * q.se; atomicAdd(&acc[(c_nw + kVmTile + 2) * R + r], gl * q.se); }
         b.gm[(size_t)n * b.rows + f.row0[i] + r] = g * m;
+        if constexpr (BASIS) {
+            const float prod = (float)(_Float16)(m * l);  // (the Linear's fp16 input, as in the forward)
+#pragma unroll
+            for (uint32_t c = 0; c < kVmBasisPad; c++) dw[c] = __builtin_fmaf(go[c], prod, dw[c]);
+        }
+    }
+    if constexpr (BASIS) {
+        if (r < R) {
+#pragma unroll
+            for (uint32_t c = 0; c < kVmBasisPad; c++)
+                if (c < b.Cb && dw[c] != 0.0f) atomicAdd(&b.d_basis[(size_t)c * b.rows + f.row0[i] + r], dw[c]);
+        }
     }
     __syncthreads();
     float* dP = b.d_plane[i];
@@ -314,6 +429,7 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
     b.perm = perm;
     b.start = start;
     b.n_bounds = n_bounds;
+    b.basis = nullptr; b.g_out = nullptr; b.d_basis = nullptr; b.Cb = 0;
     hipStream_t st = as_stream(stream);
     const size_t smem_p = (size_t)2 * kVmTileCells * max_rank * sizeof(float), smem_l = (size_t)(kVmZChunk + 1) * max_rank * sizeof(float);
     // split factors: planes so that a tile holding every point still spreads over the chip; lines: few chunks, many points
@@ -330,6 +446,66 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
         hipLaunchKernelGGL((k_vm_line_backward<64>), gl, block, smem_l, st, x, N, f, b);
     }
     return check_launch("vm_features_backward");
+}
+
+S3D_EXPORT int s3d_vm_color_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
+                                    const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
+                                    uint16_t* out, s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(x && planes && lines && rank && resolution && basis && out, "vm_color_forward: null pointer");
+    VmFactors f;
+    uint32_t rows;
+    if (int rc = fill_factors(f, planes, lines, rank, resolution, rows)) return rc;
+    S3D_REQUIRE(basis_rows >= 1 && basis_rows <= kVmBasisPad, "vm_color_forward: basis_mat with %u outputs (1 .. %u supported)",
+                basis_rows, kVmBasisPad);
+    S3D_REQUIRE(rows * kVmBasisPad * sizeof(float) <= 64 * 1024, "vm_color_forward: %u product rows do not fit the LDS table", rows);
+    hipLaunchKernelGGL(k_vm_color_basis, dim3(div_up<uint32_t>(N, 256)), dim3(256), rows * kVmBasisPad * sizeof(float), as_stream(stream),
+                       x, N, f, (const _Float16*)basis, basis_rows, rows, (_Float16*)out);
+    return check_launch("vm_color_forward");
+}
+
+S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
+                                     const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
+                                     const uint16_t* grad_out, const int32_t* perm, const int32_t* start, uint32_t n_bounds,
+                                     float* gm, float* const* grad_planes, float* const* grad_lines, float* grad_basis,
+                                     s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(x && planes && lines && rank && resolution && basis && grad_out && perm && start && gm && grad_planes && grad_lines &&
+                grad_basis, "vm_color_backward: null pointer");
+    VmFactors f;
+    VmBackward b;
+    if (int rc = fill_factors(f, planes, lines, rank, resolution, b.rows)) return rc;
+    S3D_REQUIRE(basis_rows >= 1 && basis_rows <= kVmBasisPad, "vm_color_backward: basis_mat with %u outputs (1 .. %u supported)",
+                basis_rows, kVmBasisPad);
+    uint32_t max_rank = 0, max_tiles = 0, max_chunks = 0;
+    for (uint32_t i = 0; i < 3; i++) {
+        S3D_REQUIRE(grad_planes[i] && grad_lines[i], "vm_color_backward: null gradient buffer %u", i);
+        b.d_plane[i] = grad_planes[i];
+        b.d_line[i] = grad_lines[i];
+        max_rank = rank[i] > max_rank ? rank[i] : max_rank;
+        const uint32_t tiles = div_up<uint32_t>(f.W[i], kVmTile) * div_up<uint32_t>(f.H[i], kVmTile);
+        max_tiles = tiles > max_tiles ? tiles : max_tiles;
+        const uint32_t chunks = div_up<uint32_t>(f.Dn[i], kVmZChunk);
+        max_chunks = chunks > max_chunks ? chunks : max_chunks;
+    }
+    S3D_REQUIRE(max_rank <= 64, "vm_color_backward: rank %u > 64 not supported", max_rank);
+    S3D_REQUIRE(n_bounds > max_tiles && n_bounds > max_chunks, "vm_color_backward: `start` needs more than %u columns", max_tiles);
+    b.g = nullptr;
+    b.gm = gm;
+    b.perm = perm;
+    b.start = start;
+    b.n_bounds = n_bounds;
+    b.basis = (const _Float16*)basis;
+    b.g_out = (const _Float16*)grad_out;
+    b.d_basis = grad_basis;
+    b.Cb = basis_rows;
+    hipStream_t st = as_stream(stream);
+    const size_t smem_p = (size_t)2 * kVmTileCells * max_rank * sizeof(float), smem_l = (size_t)(kVmZChunk + 1) * max_rank * sizeof(float);
+    const uint32_t split_p = 8, split_l = 128;  // (as s3d_vm_features_backward)
+    const dim3 gp(max_tiles, 3, split_p), gl(max_chunks, 3, split_l), block(256);
+    hipLaunchKernelGGL((k_vm_plane_backward<64, false, true>), gp, block, smem_p, st, x, N, f, b);
+    hipLaunchKernelGGL((k_vm_line_backward<64>), gl, block, smem_l, st, x, N, f, b);
+    return check_launch("vm_color_backward");
 }
 
 S3D_EXPORT int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,

@@ -43,7 +43,7 @@ EXPORTS = [
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_mid2_forward", "s3d_ngp_mid2_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
     "s3d_bg_mse_forward", "s3d_bg_mse_backward", "s3d_bg_targets", "s3d_l1_pair_workspace_size", "s3d_l1_pair_loss",
     "s3d_seal_bbox_map", "s3d_vm_features_forward",
-    "s3d_vm_backward_max_bins", "s3d_vm_backward_keys", "s3d_vm_features_backward",
+    "s3d_vm_backward_max_bins", "s3d_vm_backward_keys", "s3d_vm_features_backward", "s3d_vm_color_forward", "s3d_vm_color_backward",
 ]
 
 
@@ -933,17 +933,13 @@ class VmBackend:
                                              _stream()), "vm_features_forward")
 
     @staticmethod
-    def features_backward(x, planes, lines, resolution, reduce, grad):
-        """gradients of features_forward w.r.t. planes / lines (lists shaped like the factors).  grad: [N] (reduce) or
-        [N, sum R_i] point-major."""
-        _need(x, torch.float32, "x"); _need(grad, torch.float32, "grad")
+    def backward_bins(x, planes, resolution):
+        """(perm [6,N] i32, start [6,n_bounds] i32, n_bounds): the points sorted by plane tile / line chunk, as the backward
+        kernels want them.  Depends on x and the resolution only — the density and the colour factors of one network share it."""
         N, dev = x.shape[0], x.device
-        ptr3, u3 = C.c_void_p * 3, C.c_uint32 * 3
+        u3 = C.c_uint32 * 3
         rank = u3(*[int(t.shape[1]) for t in planes])
         res = u3(*[int(r) for r in resolution])
-        rows = sum(int(t.shape[1]) for t in planes)
-        if not grad.is_contiguous() or grad.numel() != (N if reduce else N * rows):
-            raise RuntimeError("vm features backward: grad must be contiguous [N] / [N, sum rank]")
         keys = torch.empty(6, N, dtype=torch.int32, device=dev)
         _check(lib().s3d_vm_backward_keys(_p(x), _u(N), rank, res, _p(keys), _stream()), "vm_backward_keys")
         # one radix sort over all six rows (row number in the high word) instead of six segment sorts: torch sorts a [6, N]
@@ -954,6 +950,21 @@ class VmBackend:
         bounds = (rows6 << 32) | torch.arange(n_bounds, dtype=torch.int64, device=dev).unsqueeze(0)
         start = (torch.searchsorted(skeys, bounds.view(-1)).view(6, n_bounds) - rows6 * N).to(torch.int32).contiguous()
         perm = (order.view(6, N) - rows6 * N).to(torch.int32).contiguous()
+        return perm, start, n_bounds
+
+    @staticmethod
+    def features_backward(x, planes, lines, resolution, reduce, grad, bins=None):
+        """gradients of features_forward w.r.t. planes / lines (lists shaped like the factors).  grad: [N] (reduce) or
+        [N, sum R_i] point-major.  `bins`: a backward_bins() result for the same x / resolution."""
+        _need(x, torch.float32, "x"); _need(grad, torch.float32, "grad")
+        N, dev = x.shape[0], x.device
+        ptr3, u3 = C.c_void_p * 3, C.c_uint32 * 3
+        rank = u3(*[int(t.shape[1]) for t in planes])
+        res = u3(*[int(r) for r in resolution])
+        rows = sum(int(t.shape[1]) for t in planes)
+        if not grad.is_contiguous() or grad.numel() != (N if reduce else N * rows):
+            raise RuntimeError("vm features backward: grad must be contiguous [N] / [N, sum rank]")
+        perm, start, n_bounds = bins if bins is not None else VmBackend.backward_bins(x, planes, resolution)
         gm = torch.zeros(N, rows, dtype=torch.float32, device=dev)
         g_planes = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in planes]
         g_lines = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in lines]
@@ -963,3 +974,43 @@ class VmBackend:
                                               ptr3(*[t.data_ptr() for t in g_planes]), ptr3(*[t.data_ptr() for t in g_lines]),
                                               _stream()), "vm_features_backward")
         return g_planes, g_lines
+
+    @staticmethod
+    def color_forward(x, planes, lines, resolution, basis, out):
+        """colour products with basis_mat applied in the kernel: basis fp16 [Cb, sum R_i] (the Linear's weight), out fp16 [N, Cb]"""
+        _need(x, torch.float32, "x"); _need(basis, torch.float16, "basis"); _need(out, torch.float16, "out")
+        for t in list(planes) + list(lines):
+            _need(t, torch.float32, "factor")
+            if not t.is_cuda or not t.is_contiguous():
+                raise RuntimeError("vm features: factors must be contiguous GPU tensors")
+        rows = sum(int(t.shape[1]) for t in planes)
+        if not x.is_contiguous() or x.shape[-1] != 3 or not basis.is_contiguous() or basis.shape[1] != rows:
+            raise RuntimeError("vm color: x must be contiguous [N,3], basis contiguous [Cb, sum rank]")
+        if not out.is_contiguous() or out.numel() != x.shape[0] * basis.shape[0]:
+            raise RuntimeError("vm color: out must be contiguous [N, Cb]")
+        ptr3, u3 = C.c_void_p * 3, C.c_uint32 * 3
+        _check(lib().s3d_vm_color_forward(_p(x), _u(x.shape[0]), ptr3(*[t.data_ptr() for t in planes]),
+                                          ptr3(*[t.data_ptr() for t in lines]), u3(*[int(t.shape[1]) for t in planes]),
+                                          u3(*[int(r) for r in resolution]), _p(basis), _u(basis.shape[0]), _p(out), _stream()),
+               "vm_color_forward")
+
+    @staticmethod
+    def color_backward(x, planes, lines, resolution, basis, grad_out, bins=None):
+        """gradients of color_forward w.r.t. planes / lines / basis from grad_out fp16 [N, Cb]: (g_planes, g_lines, g_basis fp32)"""
+        _need(x, torch.float32, "x"); _need(basis, torch.float16, "basis"); _need(grad_out, torch.float16, "grad_out")
+        N, dev = x.shape[0], x.device
+        ptr3, u3 = C.c_void_p * 3, C.c_uint32 * 3
+        rows = sum(int(t.shape[1]) for t in planes)
+        if not grad_out.is_contiguous() or grad_out.numel() != N * basis.shape[0] or not basis.is_contiguous() or basis.shape[1] != rows:
+            raise RuntimeError("vm color backward: grad_out must be contiguous [N, Cb], basis contiguous [Cb, sum rank]")
+        perm, start, n_bounds = bins if bins is not None else VmBackend.backward_bins(x, planes, resolution)
+        gm = torch.zeros(N, rows, dtype=torch.float32, device=dev)
+        g_planes = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in planes]
+        g_lines = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in lines]
+        g_basis = torch.zeros(basis.shape, dtype=torch.float32, device=dev)
+        _check(lib().s3d_vm_color_backward(_p(x), _u(N), ptr3(*[t.data_ptr() for t in planes]),
+                                           ptr3(*[t.data_ptr() for t in lines]), u3(*[int(t.shape[1]) for t in planes]),
+                                           u3(*[int(r) for r in resolution]), _p(basis), _u(basis.shape[0]), _p(grad_out),
+                                           _p(perm), _p(start), _u(n_bounds), _p(gm), ptr3(*[t.data_ptr() for t in g_planes]),
+                                           ptr3(*[t.data_ptr() for t in g_lines]), _p(g_basis), _stream()), "vm_color_backward")
+        return g_planes, g_lines, g_basis

@@ -46,7 +46,7 @@ class _VmFeatures(torch.autograd.Function):
             g = g if ctx.reduce else g.t()  # [rows, N] gradient of the `.T` consumer: point-major underneath
             gp, gl = s3d_hip.VmBackend.features_backward(x, [f.contiguous() for f in factors[:3]],
                                                          [f.contiguous() for f in factors[3:]], ctx.net.resolution, ctx.reduce,
-                                                         g.float().contiguous())
+                                                         g.float().contiguous(), _bins(ctx.net, x, factors[:3]))
             return (None, None, None) + tuple(gp) + tuple(gl)
         with torch.enable_grad():
             leaves = [f.detach().requires_grad_(True) for f in factors]
@@ -57,6 +57,43 @@ class _VmFeatures(torch.autograd.Function):
             grads = torch.autograd.grad(out, wanted, g.contiguous())
         gx = grads[0] if ctx.needs_input_grad[0] else None
         return (gx, None, None) + tuple(grads[1:] if ctx.needs_input_grad[0] else grads)
+
+
+def _bins(net, x, mats):
+    """the points of x sorted by plane tile / line chunk (VmBackend.backward_bins): x and the resolution decide it, so the
+    density and the colour features of one forward share the sort.  Kept on the network, keyed by the storage of x (alive
+    until both backward nodes have run), dropped at the next forward."""
+    cache = net.__dict__.setdefault("_vm_bins", {})
+    key = (x.data_ptr(), x.shape[0], tuple(net.resolution))
+    if key not in cache:
+        cache[key] = s3d_hip.VmBackend.backward_bins(x, [m.contiguous() for m in mats], net.resolution)
+    return cache[key]
+
+
+class _VmColorBasis(torch.autograd.Function):
+    """basis_mat((mat * vec).T) of tensoRF/network.py:149-153 in ONE kernel per direction (s3d_vm_color_forward / _backward): the
+    [144, N] products stay in registers, the Linear's weight in LDS; the backward derives each product's gradient from the
+    Linear's output gradient on the fly and accumulates basis_mat's own gradient next to the plane gradients.  Arithmetic of the
+    fp16 autocast Linear: operands rounded to binary16, fp32 accumulation, binary16 output."""
+
+    @staticmethod
+    def forward(ctx, x, net, weight, *factors):
+        x = x.float().contiguous()
+        mats, vecs = [f.float().contiguous() for f in factors[:3]], [f.float().contiguous() for f in factors[3:]]
+        w16 = weight.detach().to(torch.float16).contiguous()
+        out = torch.empty(x.shape[0], w16.shape[0], dtype=torch.float16, device=x.device)
+        s3d_hip.VmBackend.color_forward(x, mats, vecs, net.resolution, w16, out)
+        ctx.save_for_backward(x, w16, *factors)
+        ctx.net = net
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w16, *factors = ctx.saved_tensors
+        mats, vecs = [f.float().contiguous() for f in factors[:3]], [f.float().contiguous() for f in factors[3:]]
+        gp, gl, gw = s3d_hip.VmBackend.color_backward(x, mats, vecs, ctx.net.resolution, w16, g.to(torch.float16).contiguous(),
+                                                      _bins(ctx.net, x, mats))
+        return (None, None, gw) + tuple(gp) + tuple(gl)
 
 
 class _TallLinear(torch.autograd.Function):
@@ -166,8 +203,14 @@ class NeRFNetwork(NeRFRenderer):
             return _VmFeatures.apply(x, self, True, *self.sigma_mat, *self.sigma_vec)
         return self._sigma_feat_torch(x, self.sigma_mat, self.sigma_vec)
 
+    fused_basis = True  # A-B runs: False = the products through HBM and basis_mat as an nn.Linear
+
     def get_color_feat(self, x):
         if self._use_native(x):
+            if (self.fused_basis and not x.requires_grad and self.basis_mat.bias is None and self.basis_mat.out_features <= 32
+                    and sum(self.color_rank) <= 512 and max(self.color_rank) <= 64 and torch.is_autocast_enabled("cuda")
+                    and torch.get_autocast_dtype("cuda") == torch.float16):
+                return _VmColorBasis.apply(x, self, self.basis_mat.weight, *self.color_mat, *self.color_vec)
             return _linear(self.basis_mat, _VmFeatures.apply(x, self, False, *self.color_mat, *self.color_vec).T)
         return _linear(self.basis_mat, self._color_prod_torch(x, self.color_mat, self.color_vec).T)
 
@@ -176,6 +219,7 @@ class NeRFNetwork(NeRFRenderer):
 
     def forward(self, x, d):
         x = self._normalize(x)
+        self.__dict__["_vm_bins"] = {}  # (the previous forward's sorted points)
         sigma = trunc_exp(self.get_sigma_feat(x))
         h = torch.cat([self.encoder(self.get_color_feat(x)), self.encoder_dir(d)], dim=-1)
         for k, layer in enumerate(self.color_net):

@@ -240,6 +240,47 @@ def test_tensorf_vm_features_kernel_matches_grid_sample_sequence(hip):
         assert net.get_sigma_feat(x).dtype == torch.float32
 
 
+def test_tensorf_color_features_with_basis_mat_in_the_kernel(hip):
+    """s3d_vm_color_forward / _backward (basis_mat applied inside the feature kernels, tensoRF/network.py:149-153) under fp16
+    autocast vs the reference's op sequence on the GPU (grid_sample x 12, cat, mul, `.T`, nn.Linear under autocast) and vs the
+    two-step native path (product kernel + Linear): outputs to an fp16 ulp of a 144-term sum, gradients of all twelve factors and
+    of basis_mat's weight within the tolerance of the unfused kernels; non-cubic resolution, unequal ranks, points outside."""
+    from tensoRF import network as trf
+    torch.manual_seed(5)
+    net = trf.NeRFNetwork(resolution=[40, 56, 72], sigma_rank=[5, 7, 3], color_rank=[9, 20, 48], bound=1, cuda_ray=True).cuda()
+    g = torch.Generator().manual_seed(6)
+    N = 60000
+    x = (torch.rand(N, 3, generator=g) * 2.4 - 1.2).cuda()
+    x[:64] = torch.tensor([-1.0, 1.0, 0.0], device="cuda")
+    go = (torch.randn(N, 27, generator=g) * 0.05).cuda()
+    res = {}
+    for mode in ("basis", "kernel+linear", "torch"):
+        net.fused_vm, net.fused_basis = mode != "torch", mode == "basis"
+        net.zero_grad(set_to_none=True)
+        net.__dict__["_vm_bins"] = {}
+        with torch.autocast("cuda", dtype=torch.float16):
+            c = net.get_color_feat(x)
+        assert c.dtype == torch.float16 and c.shape == (N, 27)
+        if mode == "basis":
+            assert c.grad_fn.name().startswith("_VmColorBasis")
+        c.backward(go.half())
+        res[mode] = (c.detach().float(), [p.grad.float().clone() for p in list(net.color_mat) + list(net.color_vec) + [net.basis_mat.weight]])
+    net.fused_vm = net.fused_basis = True
+    ref_c, ref_g = res["torch"]
+    scale = float(ref_c.abs().max())
+    assert scale > 0
+    for mode in ("basis", "kernel+linear"):
+        c, grads = res[mode]
+        assert float((c - ref_c).abs().max()) <= 2e-3 * scale, mode     # fp16 output of a 77-term fp32 sum, fp16 operands
+        for a, b in zip(grads, ref_g):
+            assert float(b.abs().max()) > 0
+            # the product gradient is an fp16 tensor on the reference side (the Linear's data gradient), fp32 inside the kernel
+            torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-3 * float(b.abs().max()), msg=lambda m, mode=mode: f"{mode}: {m}")
+    # inference: same values without a graph
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        assert torch.equal(net.get_color_feat(x).float(), res["basis"][0])
+
+
 def test_tensorf_vm_kernels_match_cpu_oracle(hip):
     """csrc/tensorf.hip (forward + binned backward) vs oracle/vm_features.py (numpy restatement pinned against torch's CPU
     grid_sample in tests/test_vm_oracle.py) on the same inputs"""
