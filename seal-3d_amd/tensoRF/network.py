@@ -64,10 +64,13 @@ def _bins(net, x, mats):
     density and the colour features of one forward share the sort.  Kept on the network, keyed by the storage of x (alive
     until both backward nodes have run), dropped at the next forward."""
     cache = net.__dict__.setdefault("_vm_bins", {})
-    key = (x.data_ptr(), x.shape[0], tuple(net.resolution))
+    key = (x.data_ptr(), x._version, x.shape[0], tuple(net.resolution))
     if key not in cache:
-        cache[key] = s3d_hip.VmBackend.backward_bins(x, [m.contiguous() for m in mats], net.resolution)
-    return cache[key]
+        if len(cache) >= 4:
+            cache.clear()
+        # (the entry keeps x itself: while it is cached no other tensor can live at its address)
+        cache[key] = (x, s3d_hip.VmBackend.backward_bins(x, [m.contiguous() for m in mats], net.resolution))
+    return cache[key][1]
 
 
 class _VmColorBasis(torch.autograd.Function):

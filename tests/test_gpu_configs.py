@@ -257,7 +257,6 @@ def test_tensorf_color_features_with_basis_mat_in_the_kernel(hip):
     for mode in ("basis", "kernel+linear", "torch"):
         net.fused_vm, net.fused_basis = mode != "torch", mode == "basis"
         net.zero_grad(set_to_none=True)
-        net.__dict__["_vm_bins"] = {}
         with torch.autocast("cuda", dtype=torch.float16):
             c = net.get_color_feat(x)
         assert c.dtype == torch.float16 and c.shape == (N, 27)
