@@ -307,6 +307,7 @@ __device__ __forceinline__ float dpp_swap1(float v) { return __uint_as_float(dpp
 // Which levels workgroup (xcd, chunk) serves: bit l of mask[xcd][chunk % kFwdResidues].  Every (level, chunk) pair belongs to
 // exactly one XCD (balance_forward_plan() below): a level's table stays in the L2 of the few XCDs that serve it.
 constexpr uint32_t kFwdResidues = 16;
+constexpr uint32_t kFwdMaxChunks = 2048;  // chunk slots per XCD of a launch (a multiple of kFwdResidues)
 struct FwdPlan {
     uint32_t mask[kXcds][kFwdResidues];
 };
@@ -316,7 +317,7 @@ struct FwdPlans {
     FwdPlan p[2];
 };
 
-template <typename T, uint32_t D, uint32_t C>
+template <typename T, uint32_t D, uint32_t C, bool STRIDED = false>
 __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __restrict__ inputs, const T* __restrict__ grid_a,
                                                                  const int32_t* __restrict__ offsets, T* __restrict__ outputs_a,
                                                                  uint32_t B, uint32_t L, LevelScales scales, uint32_t gridtype,
@@ -330,10 +331,17 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __
     constexpr uint32_t NW = sizeof(T) * C / 4;   // words per feature vector
     constexpr uint32_t J = 1u << (D - 1);        // corner pairs per point
     const uint32_t xcd = blockIdx.x % kXcds;
-    const uint32_t b = (blockIdx.x / kXcds) * kFwdBlock + threadIdx.x;
     const uint32_t Bv = valid_rows(B, scales.n_valid);
+    // STRIDED (batches of more than kFwdMaxChunks chunks outside the inference loop): the launch holds kFwdMaxChunks chunk slots
+    // per XCD and a workgroup walks the chunks slot, slot + slots, ... while they hold valid rows.  (A padded batch of
+    // N x max_steps rows with 2e5 of them filled — the teacher's proxy render of the Seal step — dispatched 250,000 workgroups
+    // that left at once: 30 of that launch's 113 us.)  One workgroup per chunk otherwise: chunks dispatched in order keep
+    // neighbouring rays in flight together (a fully valid 2^21-point batch loses 6 % when it is walked in strides).
+    uint32_t chunk = blockIdx.x / kXcds;
+    do {
+    const uint32_t b = chunk * kFwdBlock + threadIdx.x;
     // a wave leaves as a whole (its lanes exchange data below): Bv is a multiple of the block size or the last block is ragged
-    if ((b & ~63u) >= Bv) return;
+    if ((b & ~63u) >= Bv) return;  // (rows ascend with the chunk: nothing behind this one either)
     const bool valid = b < Bv;
     const uint32_t side = threadIdx.x & 1u;  // which x-corner this lane fetches, for both points of the pair
     float x[D];
@@ -360,8 +368,11 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __
     // (a `live` mask comes with the inference loop's slot rows — n_step consecutive slots per ray, unfilled ones parked at the
     //  origin: ray-ordered by construction, though the parked rows break the neighbour test)
     const uint32_t coherent = (scales.live != nullptr || __popcll(near_mask) >= 16) ? 1u : 0u;  // (wave-uniform)
-    uint32_t todo = plans.p[coherent].mask[xcd][(blockIdx.x / kXcds) % kFwdResidues];  // (wave-uniform) this wave's levels
-    if (todo == 0u) return;
+    uint32_t todo = plans.p[coherent].mask[xcd][chunk % kFwdResidues];  // (wave-uniform) this wave's levels
+    if (todo == 0u) {
+        if constexpr (STRIDED) continue;
+        else return;
+    }
 
     struct LevelState {
         float pos[D];
@@ -492,6 +503,7 @@ __global__ void __launch_bounds__(kFwdBlock) k_grid_forward_pair(const float* __
         finish(l0, s0);
         if (two) finish(l1, s1);
     }
+    } while (STRIDED && ((chunk += gridDim.x / kXcds), true));
 }
 
 // test hook: rows of all corners
@@ -1990,6 +2002,11 @@ template <typename T, uint32_t D>
 int launch_forward(const float* inputs, const T* emb, const int32_t* offsets, T* outputs, uint32_t B, uint32_t C,
                    uint32_t L, const LevelScales& sc, T* dy_dx, uint32_t gridtype, bool ac, uint32_t interp,
                    hipStream_t st, const T* emb_b = nullptr, T* outputs_b = nullptr) {
+    // (chunk slots of the lane-pair kernel: the inference loop's launches — `live` rows, all of them filled — keep one
+    //  workgroup per chunk; everything else walks its chunks from 2,048 slots per XCD, i.e. unchanged up to 2^19 rows)
+    const uint32_t chunks = div_up<uint32_t>(B, kFwdBlock);
+    const bool strided = !sc.live && sc.n_valid && chunks > kFwdMaxChunks;  // (a device-side row count: the extent may be mostly padding)
+    const dim3 grid_pair(kXcds * (strided ? kFwdMaxChunks : chunks), emb_b ? 2u : 1u);
     const dim3 grid(xcd_grid(B), emb_b ? 2u : 1u), block(kFwdBlock);
     if (emb_b && (dy_dx || (sizeof(T) * C) % 4 != 0 || (sizeof(T) == 4 && C != 1 && C != 2 && C != 4 && C != 8) ||
                   (sizeof(T) == 2 && C != 2 && C != 4 && C != 8))) {
@@ -2004,14 +2021,22 @@ int launch_forward(const float* inputs, const T* emb, const int32_t* offsets, T*
     if (!dy_dx && (sizeof(T) * C) % 4 == 0) {
         if constexpr (sizeof(T) == 4) {
             switch (C) {
-                case 1: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 1>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b); return check_launch("grid_encode_forward");
+                case 1: if (strided) hipLaunchKernelGGL((k_grid_forward_pair<T, D, 1, true>), grid_pair, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b);
+                    else hipLaunchKernelGGL((k_grid_forward_pair<T, D, 1>), grid_pair, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b);
+                    return check_launch("grid_encode_forward");
                 default: break;
             }
         }
         switch (C) {
-            case 2: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 2>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b); return check_launch("grid_encode_forward");
-            case 4: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 4>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b); return check_launch("grid_encode_forward");
-            case 8: hipLaunchKernelGGL((k_grid_forward_pair<T, D, 8>), grid, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b); return check_launch("grid_encode_forward");
+            case 2: if (strided) hipLaunchKernelGGL((k_grid_forward_pair<T, D, 2, true>), grid_pair, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b);
+                    else hipLaunchKernelGGL((k_grid_forward_pair<T, D, 2>), grid_pair, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b);
+                    return check_launch("grid_encode_forward");
+            case 4: if (strided) hipLaunchKernelGGL((k_grid_forward_pair<T, D, 4, true>), grid_pair, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b);
+                    else hipLaunchKernelGGL((k_grid_forward_pair<T, D, 4>), grid_pair, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b);
+                    return check_launch("grid_encode_forward");
+            case 8: if (strided) hipLaunchKernelGGL((k_grid_forward_pair<T, D, 8, true>), grid_pair, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b);
+                    else hipLaunchKernelGGL((k_grid_forward_pair<T, D, 8>), grid_pair, block, 0, st, inputs, emb, offsets, outputs, B, L, sc, gridtype, ac, interp, plan, emb_b, outputs_b);
+                    return check_launch("grid_encode_forward");
             default: break;
         }
     }

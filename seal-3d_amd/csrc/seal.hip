@@ -7,6 +7,7 @@
 //   p'     = (T^-1 [p;1] - c) * (1/s) + c ,  dir' = R^-1 dir        for masked points; optionally the source box is emptied
 //   (points inside `empty_bound` are sent to `map_source`) before that, as in the reference.
 #include "s3d_common.hpp"
+#include <algorithm>
 
 namespace s3d {
 namespace {
@@ -45,8 +46,10 @@ __device__ __forceinline__ bool hit_any(const SealMap& m, float ox, float oy, fl
 __global__ void __launch_bounds__(256) k_seal_map(const float* __restrict__ points, const float* __restrict__ dirs, uint32_t M,
                                                   SealMap m, float* __restrict__ out_p, float* __restrict__ out_d,
                                                   uint8_t* __restrict__ mask, const int32_t* __restrict__ n_valid) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= valid_rows(M, n_valid)) return;
+    // (grid-stride: a padded batch of N x max_steps rows with 2e5 of them filled would otherwise dispatch 16,000 workgroups
+    //  that leave at once — ~13 of this kernel's 19 us in the teacher's proxy render)
+    const uint32_t Mv = valid_rows(M, n_valid);
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < Mv; i += gridDim.x * 256) {
     const float px = points[(size_t)i * 3], py = points[(size_t)i * 3 + 1], pz = points[(size_t)i * 3 + 2];
     bool in = false;
     for (uint32_t b = 0; b < m.n_bounds; b++)
@@ -81,6 +84,7 @@ __global__ void __launch_bounds__(256) k_seal_map(const float* __restrict__ poin
         out_d[(size_t)i * 3] = rx; out_d[(size_t)i * 3 + 1] = ry; out_d[(size_t)i * 3 + 2] = rz;
     }
     mask[i] = in ? 1 : 0;
+    }
 }
 
 }  // namespace
@@ -116,7 +120,7 @@ S3D_EXPORT int s3d_seal_bbox_map(const float* points, const float* dirs, uint32_
         m.has_source = 1;
     }
     m.n_tris = n_tris; m.n_bounds = n_bounds;
-    hipLaunchKernelGGL(k_seal_map, dim3(div_up<uint32_t>(M, 256)), dim3(256), 0, as_stream(stream), points, dirs, M, m, out_points,
+    hipLaunchKernelGGL(k_seal_map, dim3(std::min<uint32_t>(div_up<uint32_t>(M, 256), 2048u)), dim3(256), 0, as_stream(stream), points, dirs, M, m, out_points,
                        out_dirs, mask, n_valid);
     return check_launch("seal_bbox_map");
 }
