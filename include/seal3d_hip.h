@@ -355,7 +355,8 @@ int s3d_vm_features_backward(const float* x, uint32_t N, const float* const* pla
  * nn.Linear(sum rank, basis_rows, bias=False) that runs under fp16 autocast): out [N, basis_rows] fp16 =
  * half(sum_row half(basis[c][row]) * half(product[row][n])) with fp32 accumulation; the [sum rank, N] products are never
  * written.  basis: fp16 [basis_rows, sum rank] (the Linear's weight), basis_rows <= 32.
- * s3d_vm_color_backward: from grad_out [N, basis_rows] fp16 (the gradient of that output) the factor gradients as
+ * s3d_vm_color_backward: from grad_out fp16 [N, 32] (the gradient of that output, rows zero-padded to 32 columns = 64 bytes,
+ * 16-byte aligned) the factor gradients as
  * s3d_vm_features_backward writes them (same perm / start / gm / zero-initialised buffers) and grad_basis fp32
  * [basis_rows, sum rank] (zero-initialised; accumulated with atomics). */
 int s3d_vm_color_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,

@@ -203,7 +203,7 @@ struct VmBackward {
     uint32_t n_bounds, rows;
     // basis_mat behind the products (BASIS kernels): g = [N, Cb] fp16 gradient of the Linear's OUTPUT instead of the products'
     const _Float16* basis;   // [Cb][rows]
-    const _Float16* g_out;   // [N][Cb]
+    const _Float16* g_out;   // [N][kVmBasisPad] (rows padded to 64 bytes: four 16-byte loads per point)
     float* d_basis;          // [Cb][rows] fp32, zero-initialised
     uint32_t Cb;
 };
@@ -263,12 +263,18 @@ __global__ void __launch_bounds__(256) k_vm_plane_backward(const float* __restri
         float g;
         float go[BASIS ? kVmBasisPad : 1];
         if constexpr (BASIS) {
-            const _Float16* gp = b.g_out + (size_t)n * b.Cb;
+            typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+            const half8v* gp = reinterpret_cast<const half8v*>(b.g_out + (size_t)n * kVmBasisPad);
             g = 0.0f;
 #pragma unroll
-            for (uint32_t c = 0; c < kVmBasisPad; c++) {
-                go[c] = c < b.Cb ? (float)gp[c] : 0.0f;
-                g = __builtin_fmaf(go[c], wcol[c], g);
+            for (uint32_t q = 0; q < kVmBasisPad / 8; q++) {
+                const half8v h = gp[q];
+#pragma unroll
+                for (uint32_t j = 0; j < 8; j++) {
+                    const uint32_t c = 8 * q + j;
+                    go[c] = (float)h[j];  // (columns behind Cb are the caller's zero padding)
+                    g = __builtin_fmaf(go[c], wcol[c], g);
+                }
             }
         } else {
             g = REDUCE ? b.g[n] : b.g[(size_t)n * b.rows + f.row0[i] + r];

@@ -1001,8 +1001,10 @@ class VmBackend:
         N, dev = x.shape[0], x.device
         ptr3, u3 = C.c_void_p * 3, C.c_uint32 * 3
         rows = sum(int(t.shape[1]) for t in planes)
-        if not grad_out.is_contiguous() or grad_out.numel() != N * basis.shape[0] or not basis.is_contiguous() or basis.shape[1] != rows:
-            raise RuntimeError("vm color backward: grad_out must be contiguous [N, Cb], basis contiguous [Cb, sum rank]")
+        if grad_out.shape != (N, basis.shape[0]) or not basis.is_contiguous() or basis.shape[1] != rows or basis.shape[0] > 32:
+            raise RuntimeError("vm color backward: grad_out must be [N, Cb <= 32], basis contiguous [Cb, sum rank]")
+        # the kernel reads a point's gradients as four 16-byte words: rows padded to 32 columns
+        grad_out = torch.nn.functional.pad(grad_out, (0, 32 - basis.shape[0])).contiguous()
         perm, start, n_bounds = bins if bins is not None else VmBackend.backward_bins(x, planes, resolution)
         gm = torch.zeros(N, rows, dtype=torch.float32, device=dev)
         g_planes = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in planes]
