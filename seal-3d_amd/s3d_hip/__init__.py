@@ -942,14 +942,19 @@ class VmBackend:
         res = u3(*[int(r) for r in resolution])
         keys = torch.empty(6, N, dtype=torch.int32, device=dev)
         _check(lib().s3d_vm_backward_keys(_p(x), _u(N), rank, res, _p(keys), _stream()), "vm_backward_keys")
-        # one radix sort over all six rows (row number in the high word) instead of six segment sorts: torch sorts a [6, N]
-        # int32 tensor along dim 1 with ~20 merge passes per call
-        rows6 = torch.arange(6, dtype=torch.int64, device=dev).unsqueeze(1)
-        skeys, order = torch.sort(((rows6 << 32) | keys.to(torch.int64)).view(-1))
+        # one sort over all six rows (row number above the key bits) instead of six segment sorts: torch sorts a [6, N] int32
+        # tensor along dim 1 with ~20 merge passes per call.  Keys stay 32 bits wide (row: 3 bits, bin: `bits`; a point that
+        # contributes nothing — 0x7fffffff — takes the largest bin number, behind every real one): half the radix passes and
+        # half the bytes of a 64-bit sort
         n_bounds = int(lib().s3d_vm_backward_max_bins(res)) + 2
-        bounds = (rows6 << 32) | torch.arange(n_bounds, dtype=torch.int64, device=dev).unsqueeze(0)
+        bits = max(int(n_bounds).bit_length(), 1)
+        if bits > 27:
+            raise RuntimeError("vm features backward: resolution too large for 32-bit sort keys")
+        rows6 = torch.arange(6, dtype=torch.int32, device=dev).unsqueeze(1)
+        skeys, order = torch.sort(((rows6 << bits) | keys.clamp_(max=(1 << bits) - 1)).view(-1))
+        bounds = (rows6 << bits) | torch.arange(n_bounds, dtype=torch.int32, device=dev).unsqueeze(0)
         start = (torch.searchsorted(skeys, bounds.view(-1)).view(6, n_bounds) - rows6 * N).to(torch.int32).contiguous()
-        perm = (order.view(6, N) - rows6 * N).to(torch.int32).contiguous()
+        perm = (order.view(6, N) - rows6.long() * N).to(torch.int32).contiguous()
         return perm, start, n_bounds
 
     @staticmethod
