@@ -964,14 +964,14 @@ __device__ __forceinline__ half8 transpose_load(const _Float16* __restrict__ T, 
 // Sum one weight-gradient matrix over the four waves of the workgroup and write the workgroup's fp32 partial.
 // Each wave stores its accumulator blocks to its OWN [64][64] LDS plane (independent stores, no read-modify-write
 // chains), then all 256 threads add the four planes in a fixed order.
-template <uint32_t MBLK, uint32_t NBLK, uint32_t THREADS = 256, typename Get>
+template <uint32_t MBLK, uint32_t NBLK, uint32_t THREADS = 256, uint32_t NPL = 4, typename Get>
 __device__ __forceinline__ void flush_matrix(float* __restrict__ red, float* __restrict__ partial, uint32_t matrix, uint32_t wave,
                                              uint32_t n, uint32_t h, Get&& get) {
     // (THREADS > 256: the waves behind the fourth hold no accumulators — `wave` >= 4 — and only help with the sum)
     constexpr uint32_t kPlane = kWgradPad * kWgradPad;
     __syncthreads();
     float* mine = red + (size_t)wave * kPlane;
-    if (wave < 4) {
+    if (wave < NPL) {
 #pragma unroll
         for (uint32_t mo = 0; mo < MBLK; mo++)
 #pragma unroll
@@ -986,7 +986,11 @@ __device__ __forceinline__ void flush_matrix(float* __restrict__ red, float* __r
     for (uint32_t i = threadIdx.x; i < kPlane; i += THREADS) {
         const uint32_t o = i / kWgradPad, c = i % kWgradPad;
         float v = 0.0f;
-        if (o < MBLK * 32 && c < NBLK * 32) v = ((red[i] + red[kPlane + i]) + red[2 * kPlane + i]) + red[3 * kPlane + i];
+        if (o < MBLK * 32 && c < NBLK * 32) {
+            v = red[i];
+#pragma unroll
+            for (uint32_t p = 1; p < NPL; p++) v += red[p * kPlane + i];  // (fixed order: ((p0 + p1) + p2) + ...)
+        }
         dst[i] = v;
     }
 }
@@ -1265,8 +1269,10 @@ __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make
 // LDS; its partner keeps the weight-gradient accumulators (192 registers) and consumes the tiles one stage behind, through a
 // double-buffered slot and one workgroup barrier per stage.  Two waves of <= 256 registers per SIMD: the matrix pipe, the VALU
 // and the LDS overlap across the pair.  Same per-wave tile sequence, same MFMA order per accumulator: bit-identical results.
-template <int W, int NH, int IMB, int ACT, int KS0T>
-__global__ void __launch_bounds__(512) k_ffmlp_backward_duo(const _Float16* __restrict__ grad, const _Float16* __restrict__ X,
+// NP = pairs per workgroup: 4, or 6 where the registers allow three waves per SIMD (the density network: 150 registers) — a third
+// more waves in flight behind the same weights in LDS.
+template <int W, int NH, int IMB, int ACT, int KS0T, int NP = 4>
+__global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16* __restrict__ grad, const _Float16* __restrict__ X,
                                                             const _Float16* __restrict__ Wt, uint32_t B, uint32_t in_dim,
                                                             uint32_t out_dim, uint32_t act, _Float16* __restrict__ grad_inputs,
                                                             float* __restrict__ partial, uint32_t in_layout,
@@ -1277,7 +1283,7 @@ __global__ void __launch_bounds__(512) k_ffmlp_backward_duo(const _Float16* __re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t role = wave >> 2, pair = wave & 3;  // role 0: compute, 1: weight gradient
+    const uint32_t role = wave / NP, pair = wave % NP;  // role 0: compute, 1: weight gradient
     const uint32_t n = lane & 31, h = lane >> 5;
     const uint32_t KS0 = KS0T ? (uint32_t)KS0T : in_dim / 16;
     const uint32_t nf_f0 = MB * KS0, nf_fh = NH * MB * KS;
@@ -1295,7 +1301,7 @@ __global__ void __launch_bounds__(512) k_ffmlp_backward_duo(const _Float16* __re
     const _Float16* w_hid = Wt + (size_t)W * in_dim;
     const _Float16* w_last = w_hid + (size_t)NH * W * W;
 
-    for (uint32_t f = wave; f < nfrag; f += 8) {
+    for (uint32_t f = wave; f < nfrag; f += 2 * NP) {
         half8 v;
         if (f < nf_f0) {  // forward, layer 0: A[row = hidden feature][k = input]
             const uint32_t mblk = f / KS0, s = f % KS0;
@@ -1333,7 +1339,7 @@ __global__ void __launch_bounds__(512) k_ffmlp_backward_duo(const _Float16* __re
     // tiles of this pair: blockIdx.x * 4 + pair + i * gridDim.x * 4; every wave of the workgroup runs `nit` rounds of NS
     // stages plus one draining stage, whatever its own tile count (the barriers are workgroup-wide)
     const uint32_t ntiles = valid_rows(B, n_valid) / 32;
-    const uint32_t first = blockIdx.x * 4, stride = gridDim.x * 4;
+    const uint32_t first = blockIdx.x * NP, stride = gridDim.x * NP;
     const uint32_t nit = ntiles > first ? (ntiles - first - 1) / stride + 1 : 0;  // rounds of pair 0 (the most)
     auto tile_of = [&](uint32_t i) { return first + pair + i * stride; };
     auto slot_of = [&](uint32_t i, uint32_t st) { return slots + (size_t)((i * NS + st) & 1u) * 2 * kTile; };
@@ -1543,20 +1549,20 @@ __global__ void __launch_bounds__(512) k_ffmlp_backward_duo(const _Float16* __re
         }
         // ---- sum the four weight-gradient waves in a fixed order through LDS (all 512 threads add), one partial per matrix
         float* red = reinterpret_cast<float*>(smem_raw);
-        flush_matrix<MB, IMB, 512>(red, partial, 0, pair, n, h, [&](auto mo, auto ni) { return dw0[mo][ni]; });
+        flush_matrix<MB, IMB, NP * 128, NP>(red, partial, 0, pair, n, h, [&](auto mo, auto ni) { return dw0[mo][ni]; });
 #pragma unroll
         for (uint32_t k = 0; k < (uint32_t)NH; k++)
-            flush_matrix<MB, MB, 512>(red, partial, 1 + k, pair, n, h, [&](auto mo, auto ni) { return dwh[k][mo][ni]; });
-        flush_matrix<1, MB, 512>(red, partial, NH + 1, pair, n, h, [&](auto mo, auto ni) { (void)mo; return dwl[ni]; });
+            flush_matrix<MB, MB, NP * 128, NP>(red, partial, 1 + k, pair, n, h, [&](auto mo, auto ni) { return dwh[k][mo][ni]; });
+        flush_matrix<1, MB, NP * 128, NP>(red, partial, NH + 1, pair, n, h, [&](auto mo, auto ni) { (void)mo; return dwl[ni]; });
         return;
     }
     // compute waves: the same barriers as the flushes above, and their share of the sums
     float* red = reinterpret_cast<float*>(smem_raw);
     const float16v none = zero16();
-    flush_matrix<MB, IMB, 512>(red, partial, 0, 4 + pair, n, h, [&](auto, auto) { return none; });
+    flush_matrix<MB, IMB, NP * 128, NP>(red, partial, 0, NP + pair, n, h, [&](auto, auto) { return none; });
 #pragma unroll
-    for (uint32_t k = 0; k < (uint32_t)NH; k++) flush_matrix<MB, MB, 512>(red, partial, 1 + k, 4 + pair, n, h, [&](auto, auto) { return none; });
-    flush_matrix<1, MB, 512>(red, partial, NH + 1, 4 + pair, n, h, [&](auto, auto) { return none; });
+    for (uint32_t k = 0; k < (uint32_t)NH; k++) flush_matrix<MB, MB, NP * 128, NP>(red, partial, 1 + k, NP + pair, n, h, [&](auto, auto) { return none; });
+    flush_matrix<1, MB, NP * 128, NP>(red, partial, NH + 1, NP + pair, n, h, [&](auto, auto) { return none; });
 }
 
 constexpr uint32_t kWgradBlocks = 256;
@@ -1669,25 +1675,33 @@ int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Floa
                             uint32_t out_dim, uint32_t act, _Float16* grad_inputs, _Float16* grad_weights, float* partial,
                             uint32_t in_layout, uint32_t accumulate, hipStream_t st) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
+#ifndef S3D_DUO_PAIRS_LIGHT
+#define S3D_DUO_PAIRS_LIGHT 6
+#endif
+    // (the density network of the BASELINE configs — 32 -> 64 -> 64 -> 16, ReLU — needs 150 registers: six pairs = three waves per SIMD)
+    constexpr uint32_t NP = (W == 64 && NH == 1 && IMB == 1 && KS0T == 2 && ACT == ACT_RELU) ? S3D_DUO_PAIRS_LIGHT : 4;
     const uint32_t nfrag = MB * (in_dim / 16) + NH * MB * KS + MB + NH * MB * KS + (grad_inputs ? IMB * KS : 0);
-    size_t smem = (size_t)nfrag * 64 * sizeof(half8) + (size_t)4 * 2 * kTRows * kTRow * sizeof(_Float16);
-    if (smem < 4 * kWgradPad * kWgradPad * sizeof(float)) smem = 4 * kWgradPad * kWgradPad * sizeof(float);  // epilogue planes
     static const bool duo = [] { const char* e = getenv("S3D_FFMLP_DUO"); return !(e && e[0] == '0'); }();  // A/B switch
-    if (duo) smem += (size_t)4 * 2 * kTRows * kTRow * sizeof(_Float16);  // second tile slot per pair
+    const uint32_t np = duo ? NP : 4u;  // tile owners per workgroup
+    size_t smem = (size_t)nfrag * 64 * sizeof(half8) + (size_t)np * 2 * kTRows * kTRow * sizeof(_Float16);
+    if (duo) smem += (size_t)np * 2 * kTRows * kTRow * sizeof(_Float16);  // second tile slot per pair
+    if (smem < np * kWgradPad * kWgradPad * sizeof(float)) smem = np * kWgradPad * kWgradPad * sizeof(float);  // epilogue planes
     static std::atomic<uint64_t> attr_devs{0};
     int dev;
     if (device_needs_setup(attr_devs, &dev)) {
         S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_backward_fused<W, NH, IMB, ACT, KS0T>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_backward_duo<W, NH, IMB, ACT, KS0T>),
+        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_backward_duo<W, NH, IMB, ACT, KS0T, NP>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         device_setup_done(attr_devs, dev);
     }
     const uint32_t ntiles = B / 32;
+    // (four tile owners per workgroup decide the partial count whatever the kernel: s3d_ffmlp_wgrad_reduce_pair derives the
+    //  layout of a deferred reduce from B alone; a six-pair workgroup of a small batch simply has idle pairs)
     uint32_t nblk = div_up<uint32_t>(ntiles, 4);
     if (nblk > kWgradBlocks) nblk = kWgradBlocks;
     if (duo)
-        hipLaunchKernelGGL((k_ffmlp_backward_duo<W, NH, IMB, ACT, KS0T>), dim3(nblk), dim3(512), smem, st, grad, X, Wt, B, in_dim,
+        hipLaunchKernelGGL((k_ffmlp_backward_duo<W, NH, IMB, ACT, KS0T, NP>), dim3(nblk), dim3(NP * 128), smem, st, grad, X, Wt, B, in_dim,
                            out_dim, act, grad_inputs, partial, in_layout, t_n_valid, t_d_rgb, t_rgb_in, t_mid_bwd);
     else
         hipLaunchKernelGGL((k_ffmlp_backward_fused<W, NH, IMB, ACT, KS0T>), dim3(nblk), dim3(256), smem, st, grad, X, Wt, B, in_dim,
