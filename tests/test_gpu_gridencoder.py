@@ -427,3 +427,34 @@ def test_grid_backward_plane_of_group_boundary_cells(oracle, hip, dtype, C, grid
         assert torch.equal(out[2].view(torch.int16), out["again"].view(torch.int16))  # exact sums: the same bits every time
     else:
         torch.testing.assert_close(out[2], ge_ref, rtol=1e-4, atol=1e-5 * float(ge_ref.abs().max()))
+
+
+@pytest.mark.parametrize("pair", [False, True])
+def test_forward_of_a_padded_batch_with_a_device_side_row_count(hip, pair):
+    """A padded batch (extent of more than 2,048 chunks, `n_valid` rows filled — the teacher's proxy render of the Seal step:
+    N x max_steps rows, 2e5 of them real) is walked by a fixed number of workgroups (k_grid_forward_pair<..., STRIDED>): the
+    filled rows equal, bit for bit, what a launch over exactly those rows writes; rows behind the count (rounded up to 128, as
+    everywhere: valid_rows()) are not touched."""
+    torch.manual_seed(7)
+    offsets, S, total = _enc_meta()
+    D, L, C, base = 3, 16, 2, 16
+    B, nv = 3 * 2048 * 256 + 1000, 200_000 + 77          # ragged extent, ragged count
+    G = hip.GridBackend
+    x = torch.rand(B, D, device="cuda")
+    x[5] = 1.5                                            # an out-of-range row inside the filled part
+    emb = [(torch.rand(total, C, device="cuda") * 2 - 1).half() for _ in range(2)]
+    offs = offsets.cuda()
+    n_valid = torch.tensor([nv], dtype=torch.int32, device="cuda")
+    rows = (nv + 255) // 256 * 256                        # a launch over the filled chunks only
+    out = [torch.full((L, B, C), 7.0, device="cuda", dtype=torch.half) for _ in range(2)]
+    ref = [torch.empty(L, rows, C, device="cuda", dtype=torch.half) for _ in range(2)]
+    if pair:
+        G.grid_encode_forward_pair(x, emb[0], emb[1], offs, out[0], out[1], B, D, C, L, S, base, 0, False, 0, 0.0, n_valid)
+        G.grid_encode_forward_pair(x[:rows].contiguous(), emb[0], emb[1], offs, ref[0], ref[1], rows, D, C, L, S, base, 0, False, 0)
+    else:
+        G.grid_encode_forward(x, emb[0], offs, out[0], B, D, C, L, S, base, None, 0, False, 0, 0.0, n_valid)
+        G.grid_encode_forward(x[:rows].contiguous(), emb[0], offs, ref[0], rows, D, C, L, S, base, None, 0, False, 0)
+    for k in range(2 if pair else 1):
+        assert torch.equal(out[k][:, :nv], ref[k][:, :nv])
+        assert float(out[k][:, :nv].abs().max()) > 0 and bool((out[k][:, 5] == 0).all())
+        assert bool((out[k][:, (nv + 127) // 128 * 128:] == 7.0).all())  # (the count is honoured in units of 128 rows: valid_rows())
