@@ -64,3 +64,26 @@ def test_oracle_edge_resolutions_and_border_points():
         c_ref = net._color_prod_torch(x, net.color_mat, net.color_vec).detach().numpy()
         np.testing.assert_allclose(vo.sigma_feat(x.numpy(), _np(net.sigma_mat), _np(net.sigma_vec)), s_ref, rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(vo.color_products(x.numpy(), _np(net.color_mat), _np(net.color_vec)), c_ref, rtol=1e-5, atol=1e-7)
+
+
+def test_tall_linear_chunked_weight_gradient_equals_autograd_on_cpu():
+    """tensoRF/network.py:_TallLinear (weight gradient of a bias-free Linear as a batched GEMM over 1,024-row chunks + a remainder
+    GEMM, summed in fp32) is the same function as F.linear under autograd: values, data gradient and weight gradient on CPU
+    tensors in fp32 (the GPU test compares it with the fp16 autocast nn.Linear), ragged row counts included; and `_linear` only
+    takes that route on the GPU under autocast."""
+    for N in (5 * 1024, 5 * 1024 + 333, 700):
+        torch.manual_seed(N)
+        layer = torch.nn.Linear(24, 7, bias=False)
+        x0, go = torch.randn(N, 24), torch.randn(N, 7)
+        res = []
+        for tall in (True, False):
+            layer.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            y = trf._TallLinear.apply(x, layer.weight) if tall else layer(x)
+            y.backward(go)
+            res.append((y.detach(), x.grad.clone(), layer.weight.grad.clone()))
+        torch.testing.assert_close(res[0][0], res[1][0], rtol=0, atol=0)
+        torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-5, atol=1e-4)
+    y = trf._linear(layer, x0)  # CPU tensors: the module itself
+    assert y.grad_fn is None or "TallLinear" not in type(y.grad_fn).__name__
