@@ -60,6 +60,11 @@ int s3d_near_far_from_aabb(const float* rays_o, const float* rays_d, const float
 int s3d_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
                      s3d_stream_t stream);
 
+/* Test hook (no reference entry point): the cascade selection of the marching kernels, `mip_from_pos` / `mip_from_dt`
+ * (raymarching.cu:42-54), on arrays: xyz [N,3] -> mip_pos [N], dt [N] -> mip_dt [N]; either output may be NULL. */
+int s3d_mip_levels(const float* xyz, const float* dt, uint32_t N, uint32_t H, uint32_t C, int32_t* mip_pos, int32_t* mip_dt,
+                   s3d_stream_t stream);
+
 /* raymarching.h:9  void morton3D(coords, N, indices) */
 int s3d_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, s3d_stream_t stream);
 

@@ -116,6 +116,249 @@ def gen_sh():
     print("sh_torch: wrote sh_torch_deg5.npz")
 
 
+# ----------------------------------------------------------------------------- integer kernels, evaluated from the reference text
+_C_TYPES = {"uint32_t": "U32", "int": "I32", "float": "F32", "bool": "BOOL"}
+
+
+def _c_function(src, name):
+    """Text of the C function `name` in `src` (signature + body), with its `template <...>` line if any."""
+    m = re.search(r"((?:template\s*<[^>]*>\s*)?(?:[\w]+\s+)+?)\b%s\s*\(([^)]*)\)\s*\{" % re.escape(name), src)
+    assert m, name
+    depth, i = 1, m.end()
+    while depth:
+        depth += {"{": 1, "}": -1}.get(src[i], 0)
+        i += 1
+    ret = [t for t in m.group(1).split() if t in _C_TYPES][-1]
+    params = [(p.split()[-1].split("[")[0].replace("&", ""), [t for t in p.split() if t in _C_TYPES][-1], "[" in p)
+              for p in m.group(2).split(",")]
+    return ret, params, src[m.end():i - 1]
+
+
+def _c_expr(e):
+    """C expression -> python expression over numpy values (uint32 wrap-around, float32 rounding per operator)."""
+    e = re.sub(r"<\s*\w+(?:\s*,\s*\w+)*\s*>\s*\(", "(", e)                     # template arguments of a call
+    e = re.sub(r"\b(0x[0-9a-fA-F]+|\d+)u\b", r"U32(\1)", e)                       # unsigned literals
+    e = re.sub(r"(?<![\w.])(\d+\.\d*)f\b", r"F32(\1)", e)                         # float literals
+    e = re.sub(r"(?<![\w.(])(\d+\.\d+)(?![\w.)])", r"F64(\1)", e)                 # double literals (`dt * H * 0.5`)
+    e = e.replace("&&", " and ").replace("||", " or ")
+    m = re.match(r"^(.*?)\?(.*?):(.*)$", e)                                       # one scalar ternary per expression
+    if m:
+        e = "((%s) if (%s) else (%s))" % (m.group(2).strip(), m.group(1).strip(), m.group(3).strip())
+    return e.strip()
+
+
+def _c_to_python(src, name):
+    """Transliterate one short C function of the reference to python source.  Handles exactly the constructs the pinned
+    functions use: typed declarations, compound assignments, counted `for` loops (with an extra `&&` condition), `if`,
+    `return`, `frexpf(x, &e)`.  Every assignment to a typed variable converts to that type (the C conversion)."""
+    ret, params, body = _c_function(src, name)
+    types_ = {p: t for p, t, arr in params if not arr}
+    out, ind = ["def %s(%s):" % (name, ", ".join(p for p, _, _ in params))], 1
+    for p, t, arr in params:
+        if not arr:
+            out.append("    %s = %s(%s)" % (p, _C_TYPES[t], p))
+    for raw in body.split("\n"):
+        line = raw.split("//")[0].strip()
+        if not line or line.startswith("#pragma"):
+            continue
+        pad = "    " * ind
+        if line == "}":
+            ind -= 1
+            continue
+        m = re.match(r"for\s*\(\s*uint32_t\s+(\w+)\s*=\s*(\w+)\s*;\s*\1\s*<\s*(\w+)\s*(?:&&\s*(.*?))?\s*;\s*(?:\+\+\1|\1\+\+)\s*\)\s*\{$", line)
+        if m:
+            out.append(pad + "for %s in range(%s, %s):" % (m.group(1), m.group(2), m.group(3)))
+            if m.group(4):
+                out.append(pad + "    if not (%s): break" % _c_expr(m.group(4)))
+            ind += 1
+            continue
+        m = re.match(r"if\s*\((.*)\)\s*\{$", line)
+        if m:
+            out.append(pad + "if %s:" % _c_expr(m.group(1)))
+            ind += 1
+            continue
+        m = re.match(r"frexpf\((\w+),\s*&(\w+)\);$", line)
+        if m:
+            out.append(pad + "%s = I32(frexp_exponent(%s))" % (m.group(2), m.group(1)))
+            continue
+        m = re.match(r"(?:const\s+|constexpr\s+)*(uint32_t|int|float|bool)\s+(\w+)\[(\d+)\]\s*=\s*\{(.*)\};$", line)
+        if m:
+            out.append(pad + "%s = [%s]" % (m.group(2), ", ".join("%s(%s)" % (_C_TYPES[m.group(1)], _c_expr(v)) for v in m.group(4).split(","))))
+            continue
+        m = re.match(r"(?:const\s+|constexpr\s+)*(uint32_t|int|float|bool)\s+(\w+)\s*(?:=\s*(.*))?;$", line)
+        if m:
+            types_[m.group(2)] = m.group(1)
+            if m.group(3) is not None:
+                out.append(pad + "%s = %s(%s)" % (m.group(2), _C_TYPES[m.group(1)], _c_expr(m.group(3))))
+            continue
+        m = re.match(r"return\s+(.*);$", line)
+        if m:
+            out.append(pad + "return %s(%s)" % (_C_TYPES[ret], _c_expr(m.group(1))))
+            continue
+        m = re.match(r"(\w+)\s*([\^+*|&-]?)=\s*(.*);$", line)
+        if m:
+            v, op, e = m.group(1), m.group(2), _c_expr(m.group(3))
+            rhs = "(%s) %s (%s)" % (v, op, e) if op else e
+            out.append(pad + "%s = %s(%s)" % (v, _C_TYPES[types_[v]], rhs))
+            continue
+        raise AssertionError("untranslated reference line in %s: %r" % (name, line))
+    return "\n".join(out)
+
+
+def _int_env(**consts):
+    def U32(v):
+        a = np.asarray(v)
+        if a.dtype.kind == "f":
+            a = a.astype(np.int64)
+        return (a.astype(np.int64) & 0xFFFFFFFF).astype(np.uint32) if a.dtype.kind in "iub" and a.dtype != np.uint32 else a.astype(np.uint32)
+
+    def I32(v):
+        a = np.asarray(v)
+        return np.trunc(a).astype(np.int32) if a.dtype.kind == "f" else a.astype(np.int32)
+    F32 = lambda v: np.asarray(v).astype(np.float32)
+    f1 = lambda fn: (lambda a: fn(F32(a)))
+    f2 = lambda fn: (lambda a, b: fn(F32(a), F32(b)))
+    env = dict(U32=U32, I32=I32, F32=F32, F64=np.float64, BOOL=bool, range=range,
+               fabsf=f1(np.abs), fabs=f1(np.abs), fmaxf=f2(np.maximum), fminf=f2(np.minimum),
+               frexp_exponent=lambda a: np.frexp(F32(a))[1])
+    env.update(consts)
+    return env
+
+
+def gen_int():
+    """raymarching.cu:42-81 (`mip_from_pos`, `mip_from_dt`, `__expand_bits`, `__morton3D`, `__morton3D_invert`), the kernel
+    lines :225 / :246-248 that call them, and gridencoder.cu:50-84 (`fast_hash`, `get_grid_index`): the reference TEXT is
+    transliterated statement by statement (`_c_to_python`) and evaluated on seeded inputs with numpy uint32 / int32 /
+    float32 semantics.  -> tests/golden/int_kernels.npz: the oracle (CPU test) and the HIP kernels (GPU test) must
+    reproduce every value bit for bit."""
+    rm_src = open(os.path.join(REF, "raymarching/src/raymarching.cu")).read()
+    ge_src = open(os.path.join(REF, "gridencoder/src/gridencoder.cu")).read()
+    out = {}
+    rng = np.random.default_rng(20260928)
+    with np.errstate(over="ignore"):
+        # ---- morton
+        env = _int_env()
+        for fn in ("__expand_bits", "__morton3D", "__morton3D_invert", "mip_from_pos", "mip_from_dt"):
+            exec(_c_to_python(rm_src, fn), env)
+        v = np.concatenate([np.arange(0, 1024, dtype=np.uint32), rng.integers(0, 2**32, 1024, dtype=np.uint32)])
+        out["expand_in"], out["expand_out"] = v, env["__expand_bits"](v)
+        coords = np.concatenate([rng.integers(0, 128, (8192, 3)), rng.integers(0, 1024, (8192, 3)),
+                                 np.array([[0, 0, 0], [127, 127, 127], [1023, 1023, 1023], [1, 0, 0], [0, 1, 0], [0, 0, 1]])]).astype(np.int32)
+        # kernel_morton3D (:225): `indices[n] = __morton3D(coords[0], coords[1], coords[2]);` int -> uint32_t -> int
+        call = re.search(r"indices\[n\]\s*=\s*(__morton3D\(.*?\));", rm_src).group(1)
+        morton = lambda c: eval(_c_expr(call), env, {"coords": [c[:, 0], c[:, 1], c[:, 2]]}).astype(np.int32)
+        out["morton_coords"], out["morton_indices"] = coords, morton(coords)
+        g = np.arange(128, dtype=np.int32)
+        sweep = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+        sw = morton(sweep)
+        assert np.array_equal(np.sort(sw), np.arange(128**3))      # a bijection of the 128^3 cells onto [0, 2^21)
+        out["morton_sweep128_crc"] = np.uint32(zlib.crc32(sw.tobytes()))
+        # kernel_morton3D_invert (:246-248): `coords[k] = __morton3D_invert(ind >> k);` with `const int ind` (arithmetic shift)
+        inv_lines = re.findall(r"coords\[(\d)\]\s*=\s*(__morton3D_invert\(.*?\));", rm_src)
+        assert [k for k, _ in inv_lines] == ["0", "1", "2"]
+        invert = lambda ind: np.stack([eval(_c_expr(e), env, {"ind": ind}).astype(np.int32) for _, e in inv_lines], -1)
+        ind = np.concatenate([rng.integers(0, 128**3, 8192), rng.integers(0, 2**30, 4096), rng.integers(-2**31, 0, 4096),
+                              np.array([0, 1, 2, 4, 128**3 - 1, 2**30 - 1, 2**31 - 1, -1, -2**31])]).astype(np.int32)
+        out["invert_indices"], out["invert_coords"] = ind, invert(ind)
+        assert np.array_equal(invert(sw), sweep)
+        out["invert_sweep128_crc"] = np.uint32(zlib.crc32(invert(np.arange(128**3, dtype=np.int32)).tobytes()))
+        # ---- cascade selection
+        e = rng.integers(-30, 8, 4096)
+        xyz = (rng.uniform(-1, 1, (4096, 3)) * np.exp2(e)[:, None]).astype(np.float32)
+        edge = np.array([[0, 0, 0], [0.5, 0, 0], [0, -0.5, 0], [0.49999997, 0, 0], [1, 1, 1], [0, 0, -1], [0.99999994, 0.2, 0.1],
+                         [2, 0, 0], [3.9999998, 0, 0], [-4, 0, 0], [64, 1, 1], [1e-45, 0, 0], [1e-38, 0, 0]], np.float32)
+        xyz = np.concatenate([xyz, edge])
+        dt = np.concatenate([np.exp2(rng.uniform(-14, 2, 4096)), np.array([2 * 3**0.5 / 1024, 1 / 128, 1 / 64, 1 / 256, 2 / 128, 0.0])]).astype(np.float32)
+        for C in (1, 2, 4, 8):
+            out[f"mip_pos_c{C}"] = env["mip_from_pos"](xyz[:, 0], xyz[:, 1], xyz[:, 2], np.float32(C))
+            out[f"mip_dt_c{C}"] = env["mip_from_dt"](dt, np.float32(128), np.float32(C))
+        out["mip_xyz"], out["mip_dt"] = xyz, dt
+        # ---- grid rows: gridencoder.cu:50-84 on raw cell coordinates (uint32 wrap-around included)
+        genv = _int_env(D=3, C=2)
+        for fn in ("fast_hash", "get_grid_index"):
+            exec(_c_to_python(ge_src, fn), genv)
+        raw = []
+        for D in (2, 3):
+            genv["D"] = D
+            pg = np.concatenate([rng.integers(0, 2**32, (256, D), dtype=np.uint32), rng.integers(0, 2100, (256, D)).astype(np.uint32)])
+            out[f"raw_d{D}_pos_grid"] = pg
+            out[f"raw_d{D}_fast_hash"] = genv["fast_hash"]([pg[:, d] for d in range(D)])
+            for gridtype in (0, 1):
+                for ac in (False, True):
+                    for hs, res in ((256, 8), (512, 7), (4920, 16), (32768, 31), (524288, 81), (524288, 2048), (1 << 24, 2048), (100, 3)):
+                        C = (1, 2, 4, 8)[len(raw) % 4]
+                        genv["C"] = C
+                        idx = genv["get_grid_index"](gridtype, ac, C - 1, hs, res, [pg[:, d] for d in range(D)])
+                        raw.append((D, C, gridtype, int(ac), C - 1, hs, res))
+                        out[f"raw_idx_{len(raw) - 1}"] = idx
+        out["raw_cases"] = np.array(raw, np.int64)
+        # ---- kernel_grid (:137-139, :148-149, :165-180): scale, resolution, cell coordinates and the 2^D corner rows of
+        # seeded points, per level, for the reference's own encoder configurations (offset tables from wrappers.npz, which
+        # the reference's GridEncoder.__init__ produced)
+        m = re.search(r"__global__ void kernel_grid\(.*?\n\}\n", ge_src, re.S)
+        ktext = m.group(0)
+        e_scale = re.search(r"const float scale = (.*);", ktext).group(1)                    # exp2f(level * S) * H - 1.0f
+        e_res = re.search(r"const uint32_t resolution = (.*);", ktext).group(1)              # (uint32_t)ceil(scale) + 1
+        e_hs = re.search(r"const uint32_t hashmap_size = (.*);", ktext).group(1)
+        e_pos = re.search(r"pos\[d\] = (inputs\[d\].*);", ktext).group(1)                 # inputs[d] * scale + (align_corners ? 0.0f : 0.5f)
+        e_pg = re.search(r"pos_grid\[d\] = (.*);", ktext).group(1)                          # floorf(pos[d])
+        e_call = re.search(r"uint32_t index = (get_grid_index.*);", ktext).group(1)
+        assert re.search(r"if \(\(idx & \(1 << d\)\) == 0\) \{\s*w \*= 1 - pos\[d\];\s*pos_grid_local\[d\] = pos_grid\[d\];\s*\} else \{"
+                         r"\s*w \*= pos\[d\];\s*pos_grid_local\[d\] = pos_grid\[d\] \+ 1;", ktext)     # corner idx: bit d set -> +1 along d
+        mm = re.match(r"^(\S+) \* (\S+) \+ \((.*)\)$", e_pos)
+        assert mm, e_pos          # `a * b + c`: one fused multiply-add under nvcc's default -fmad=true (DESIGN §2)
+        LD = np.longdouble
+
+        def fma(a, b, c):         # exact product and sum in 64-bit-mantissa arithmetic, one rounding to float32
+            return (LD(a) * LD(b) + LD(c)).astype(np.float32)
+        W = np.load(os.path.join(OUT, "wrappers.npz"))
+        cfgs = [("lego", 3, 2, 0, False, 16, np.exp2(np.log2(2048 / 16) / 15), 16, W["grid_lego_offsets"]),
+                ("hash", 3, 2, 0, False, 4, float(W["grid_hash_pls"]), 4, W["grid_hash_offsets"]),
+                ("smooth", 2, 4, 0, False, 3, float(W["grid_smooth_pls"]), 8, W["grid_smooth_offsets"]),
+                ("tiled_ac", 3, 1, 1, True, 3, float(W["grid_tiled_ac_pls"]), 8, W["grid_tiled_ac_offsets"])]
+        for tag, D, C, gridtype, ac, L, pls, H, offsets in cfgs:
+            S = np.float32(np.log2(pls))                                               # grid.py:154 -> `const float S`
+            n = 512
+            x = rng.uniform(0, 1, (n, D)).astype(np.float32)
+            x[:8] = np.array([0, 1, 0.5, 0.25, 1, 0, 0.99999994, 1e-8], np.float32)[:, None]
+            x[8:16, 0], x[8:16, 1] = 0, 1
+            scales, ress, pgs, rows = [], [], [], []
+            genv.update(D=D, C=C)
+            for level in range(L):
+                kenv = _int_env(level=np.uint32(level), S=S, H=np.uint32(H), offsets=offsets.astype(np.int32), align_corners=ac,
+                                exp2f=lambda a: np.exp2(np.float64(a)).astype(np.float32), ceil=np.ceil, floorf=np.floor)
+                lit = lambda e: re.sub(r"\(uint32_t\)(\w+\([^()]*\))", r"U32(\1)", _c_expr(e))
+                hashmap_size = int(eval(lit(e_hs), kenv))
+                # `level * S`: uint32 -> float, float product; `* H - 1.0f`: H -> float, exact for the power-of-two H used
+                scale = np.float32(eval(lit(e_scale).replace("level * S", "F32(F32(level) * S)").replace("* H", "* F32(H)"), kenv))
+                kenv["scale"] = scale
+                resolution = int(eval(lit(e_res), kenv))
+                pg = []
+                for d in range(D):
+                    kenv.update(d=d, inputs=[x[:, k] for k in range(D)])
+                    a, b, c = (eval(_c_expr(t), kenv) for t in mm.groups())
+                    kenv["pos"] = {d: fma(a, b, c)}
+                    pg.append(U32f(eval(_c_expr(e_pg), kenv)))
+                corner = []
+                for idx in range(1 << D):
+                    local = [pg[d] + np.uint32(1) if idx & (1 << d) else pg[d] for d in range(D)]
+                    kenv2 = dict(genv, gridtype=gridtype, align_corners=ac, hashmap_size=hashmap_size, resolution=resolution,
+                                 pos_grid_local=local)
+                    corner.append(eval(_c_expr(e_call), kenv2))
+                scales.append(scale), ress.append(resolution), pgs.append(np.stack(pg, -1)), rows.append(np.stack(corner, -1))
+            out.update({f"grid_{tag}_cfg": np.array([D, C, gridtype, int(ac), L, H], np.int64), f"grid_{tag}_S": S,
+                        f"grid_{tag}_offsets": offsets.astype(np.int32), f"grid_{tag}_x": x,
+                        f"grid_{tag}_scales": np.array(scales, np.float32), f"grid_{tag}_resolution": np.array(ress, np.int64),
+                        f"grid_{tag}_pos_grid": np.stack(pgs, 1), f"grid_{tag}_index": np.stack(rows, 1)})   # [n, L, D] / [n, L, 2^D]
+    np.savez_compressed(os.path.join(OUT, "int_kernels.npz"), **out)
+    print("int: wrote int_kernels.npz with", len(out), "arrays")
+
+
+def U32f(v):
+    """C conversion float -> uint32_t of a non-negative value (`pos_grid[d] = floorf(pos[d])`)."""
+    return np.asarray(v).astype(np.int64).astype(np.uint32)
+
+
 # ----------------------------------------------------------------------------- reference wrappers on the oracle
 def _install_reference_stack():
     """Make the reference's Python importable on CPU: its five `_backend` extension modules are replaced by the
@@ -587,7 +830,7 @@ def check_dropin():
     print("dropin: reference nerf/renderer.py + nerf/network.py on the build's packages reproduce wrappers.npz")
 
 
-SECTIONS = {"sh": gen_sh, "wrappers": gen_wrappers, "train": gen_train, "seal": gen_seal, "dropin": check_dropin}
+SECTIONS = {"sh": gen_sh, "int": gen_int, "wrappers": gen_wrappers, "train": gen_train, "seal": gen_seal, "dropin": check_dropin}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -96,6 +96,22 @@ def grid_index(D, Cc, gridtype, align_corners, ch, hashmap_size, resolution, pos
                                     _u(hashmap_size), _u(resolution), _p(pg)))
 
 
+def mip_from_pos(xyz, max_cascade):
+    """raymarching.cu:42-47 on an [N,3] float32 array (test hook)."""
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+    out = np.empty(xyz.shape[0], dtype=np.int32)
+    lib().s3o_mip_from_pos(_p(xyz), _u(xyz.shape[0]), _f(max_cascade), _p(out))
+    return out
+
+
+def mip_from_dt(dt, H, max_cascade):
+    """raymarching.cu:49-54 on an [N] float32 array (test hook)."""
+    dt = np.ascontiguousarray(dt, dtype=np.float32)
+    out = np.empty(dt.shape[0], dtype=np.int32)
+    lib().s3o_mip_from_dt(_p(dt), _u(dt.shape[0]), _f(H), _f(max_cascade), _p(out))
+    return out
+
+
 class RaymarchingBackend:
     """raymarching/src/raymarching.h:7-18"""
     device_type = "cpu"

@@ -78,6 +78,14 @@ static inline int mip_from_dt(float dt, float H, float max_cascade) {
     return (int)fminf(max_cascade - 1, fmaxf(0, (float)exponent));
 }
 
+/* exported so tests can pin the cascade selection against tests/golden/int_kernels.npz */
+S3O_API void s3o_mip_from_pos(const float* xyz, uint32_t N, float max_cascade, int32_t* out) {
+    for (uint32_t n = 0; n < N; n++) out[n] = mip_from_pos(xyz[n * 3], xyz[n * 3 + 1], xyz[n * 3 + 2], max_cascade);
+}
+S3O_API void s3o_mip_from_dt(const float* dt, uint32_t N, float H, float max_cascade, int32_t* out) {
+    for (uint32_t n = 0; n < N; n++) out[n] = mip_from_dt(dt[n], H, max_cascade);
+}
+
 /* ---- near/far: raymarching.cu:92-145 ---- */
 S3O_API void s3o_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb,
                                     uint32_t N, float min_near, float* nears, float* fars) {

@@ -279,13 +279,29 @@ __device__ __forceinline__ Ray load_ray(const float* __restrict__ rays_o, const 
     return r;
 }
 
+// Cascade of a position / of a step (raymarching.cu:42-54): the frexp exponent clamped to [0, C - 1].
+__device__ __forceinline__ int mip_from_pos(float x, float y, float z, float Cf) {
+    int e;
+    (void)frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e);
+    return (int)fminf(Cf - 1, fmaxf(0.0f, (float)e));
+}
+__device__ __forceinline__ int mip_from_dt(float dt, float Hf, float Cf) {
+    int e;
+    (void)frexpf((dt * Hf) * 0.5f, &e);  // (`dt * H * 0.5`: the float product halved in double — halving is exact in float too)
+    return (int)fminf(Cf - 1, fmaxf(0.0f, (float)e));
+}
 __device__ __forceinline__ int mip_level(float x, float y, float z, float dt, const MarchParams& p) {
-    int e1, e2;
-    (void)frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e1);
-    const int la = (int)fminf(p.Cf - 1, fmaxf(0.0f, (float)e1));
-    (void)frexpf((dt * p.Hf) * 0.5f, &e2);  // (`dt * H * 0.5`: the float product halved in double — halving is exact in float too)
-    const int lb = (int)fminf(p.Cf - 1, fmaxf(0.0f, (float)e2));
+    const int la = mip_from_pos(x, y, z, p.Cf), lb = mip_from_dt(dt, p.Hf, p.Cf);
     return la > lb ? la : lb;
+}
+
+// test hook: the marcher's cascade selection on arrays (pinned to the reference text by tests/golden/int_kernels.npz)
+__global__ void k_mip_levels(const float* __restrict__ xyz, const float* __restrict__ dt, uint32_t N, float Hf, float Cf,
+                             int32_t* __restrict__ mip_pos, int32_t* __restrict__ mip_dt) {
+    for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+        if (mip_pos) mip_pos[n] = mip_from_pos(xyz[n * 3], xyz[n * 3 + 1], xyz[n * 3 + 2], Cf);
+        if (mip_dt) mip_dt[n] = mip_from_dt(dt[n], Hf, Cf);
+    }
 }
 
 // Cell of the grid at parameter t (raymarching.cu:358-372): position, step, cascade, cell coordinates; returns the bit index.
@@ -1507,6 +1523,15 @@ S3D_EXPORT int s3d_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* 
     S3D_REQUIRE(coords && indices, "morton3D_invert: null pointer");
     hipLaunchKernelGGL(k_morton3d_invert, dim3(stream_grid(N, 256)), dim3(256), 0, as_stream(stream), indices, N, coords);
     return check_launch("morton3D_invert");
+}
+
+S3D_EXPORT int s3d_mip_levels(const float* xyz, const float* dt, uint32_t N, uint32_t H, uint32_t C, int32_t* mip_pos,
+                              int32_t* mip_dt, s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE((!mip_pos || xyz) && (!mip_dt || dt), "mip_levels: an output without its input");
+    hipLaunchKernelGGL(k_mip_levels, dim3(stream_grid(N, 256)), dim3(256), 0, as_stream(stream), xyz, dt, N, (float)H, (float)C,
+                       mip_pos, mip_dt);
+    return check_launch("mip_levels");
 }
 
 S3D_EXPORT int s3d_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield,

@@ -27,7 +27,7 @@ F32, F16 = 0, 1
 # every symbol include/seal3d_hip.h declares
 EXPORTS = [
     "s3d_last_error", "s3d_version",
-    "s3d_near_far_from_aabb", "s3d_sph_from_ray", "s3d_morton3D", "s3d_morton3D_invert", "s3d_packbits",
+    "s3d_near_far_from_aabb", "s3d_sph_from_ray", "s3d_morton3D", "s3d_morton3D_invert", "s3d_mip_levels", "s3d_packbits",
     "s3d_march_rays_train_workspace_size", "s3d_march_rays_train",
     "s3d_sweep_draw", "s3d_sweep_update_workspace_size", "s3d_sweep_update",
     "s3d_composite_rays_train_forward", "s3d_composite_rays_train_backward",
@@ -317,6 +317,18 @@ class RaymarchingBackend:
     def morton3D_invert(indices, N, coords):
         _need(indices, torch.int32, "indices")
         _check(lib().s3d_morton3D_invert(_p(indices), _u(N), _p(coords), _stream()), "morton3D_invert")
+
+    @staticmethod
+    def mip_levels(xyz, dt, H, Cc):
+        """Test hook: (mip_from_pos [N], mip_from_dt [N]) of the marching kernels' cascade selection (raymarching.cu:42-54)."""
+        _need(xyz, torch.float32, "xyz")
+        _need(dt, torch.float32, "dt")
+        N = xyz.shape[0]
+        assert dt.shape[0] == N
+        mp = torch.empty(N, dtype=torch.int32, device=xyz.device)
+        md = torch.empty(N, dtype=torch.int32, device=xyz.device)
+        _check(lib().s3d_mip_levels(_p(xyz), _p(dt), _u(N), _u(H), _u(Cc), _p(mp), _p(md), _stream()), "mip_levels")
+        return mp, md
 
     @staticmethod
     def packbits(grid, N, density_thresh, bitfield):

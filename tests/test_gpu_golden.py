@@ -365,3 +365,67 @@ def test_finetune_step_fp16_fused_path_vs_reference(hip, T, cpu_random):
     for k, p in net.named_parameters():
         ref = float(T[f"ts_grad_{k.replace('.', '_')}_norm"])
         assert abs(float(p.grad.double().norm()) - ref) <= 3e-2 * ref, (k, float(p.grad.double().norm()), ref)
+
+
+# ----------------------------------------------------------------------------- integer kernels vs the reference TEXT
+# tests/golden/int_kernels.npz: raymarching.cu:42-81 and gridencoder.cu:50-84 (+ the index lines of kernel_grid) evaluated
+# statement by statement by oracle/gen_golden.py `int` (CPU twin of these tests: tests/test_int_golden.py).
+@pytest.fixture(scope="module")
+def GI():
+    return np.load(os.path.join(GOLDEN, "int_kernels.npz"))
+
+
+def _hip_morton(hip, coords):
+    c = torch.from_numpy(np.ascontiguousarray(coords, dtype=np.int32)).cuda()
+    out = torch.empty(c.shape[0], dtype=torch.int32, device="cuda")
+    hip.RaymarchingBackend.morton3D(c, c.shape[0], out)
+    return out.cpu().numpy()
+
+
+def _hip_invert(hip, ind):
+    i = torch.from_numpy(np.ascontiguousarray(ind, dtype=np.int32)).cuda()
+    out = torch.empty(i.shape[0], 3, dtype=torch.int32, device="cuda")
+    hip.RaymarchingBackend.morton3D_invert(i, i.shape[0], out)
+    return out.cpu().numpy()
+
+
+def test_morton_kernels_reproduce_the_reference_text(hip, GI):
+    v = GI["expand_in"]
+    c = np.zeros((v.size, 3), np.int32)
+    c[:, 0] = v.view(np.int32)                      # `__morton3D(x, 0, 0) == __expand_bits(x)`, wrap-around above 10 bits included
+    assert np.array_equal(_hip_morton(hip, c).view(np.uint32), GI["expand_out"])
+    assert np.array_equal(_hip_morton(hip, GI["morton_coords"]), GI["morton_indices"])
+    g = np.arange(128, dtype=np.int32)
+    sweep = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    assert np.uint32(zlib.crc32(_hip_morton(hip, sweep).tobytes())) == GI["morton_sweep128_crc"]
+    assert np.array_equal(_hip_invert(hip, GI["invert_indices"]), GI["invert_coords"])   # negative int32 (arithmetic shift) included
+    assert np.uint32(zlib.crc32(_hip_invert(hip, np.arange(128 ** 3, dtype=np.int32)).tobytes())) == GI["invert_sweep128_crc"]
+
+
+@pytest.mark.parametrize("C", [1, 2, 4, 8])
+def test_cascade_selection_reproduces_the_reference_text(hip, GI, C):
+    xyz, dt = GI["mip_xyz"], GI["mip_dt"]
+    n = max(xyz.shape[0], dt.shape[0])
+    xyz_p = np.zeros((n, 3), np.float32)
+    xyz_p[:xyz.shape[0]] = xyz
+    dt_p = np.ones(n, np.float32)
+    dt_p[:dt.shape[0]] = dt
+    mp, md = hip.RaymarchingBackend.mip_levels(torch.from_numpy(xyz_p).cuda(), torch.from_numpy(dt_p).cuda(), 128, C)
+    assert np.array_equal(mp.cpu().numpy()[:xyz.shape[0]], GI[f"mip_pos_c{C}"])
+    assert np.array_equal(md.cpu().numpy()[:dt.shape[0]], GI[f"mip_dt_c{C}"])
+
+
+@pytest.mark.parametrize("tag", ["lego", "hash", "smooth", "tiled_ac"])
+def test_grid_corner_rows_reproduce_the_reference_text(hip, GI, tag):
+    """scale table (host), cell of a point and the table row of each of its 2^D corners, per level: `get_grid_index` /
+    `fast_hash` (gridencoder.cu:50-84) applied to the cells `kernel_grid` (:137-149) derives — hashed, dense and tiled levels."""
+    D, C, gridtype, ac, L, H = GI[f"grid_{tag}_cfg"].tolist()
+    S = float(GI[f"grid_{tag}_S"])
+    assert np.array_equal(np.asarray(hip.level_scales(L, S, H), dtype=np.float32), GI[f"grid_{tag}_scales"])
+    x = torch.from_numpy(GI[f"grid_{tag}_x"]).cuda()
+    offsets = torch.from_numpy(GI[f"grid_{tag}_offsets"]).cuda()
+    B = x.shape[0]
+    cidx = torch.empty(B, L, 1 << D, dtype=torch.int32, device="cuda")
+    hip.GridBackend.grid_corner_indices(x, offsets, cidx, B, D, C, L, S, H, gridtype, bool(ac))
+    rows = cidx.cpu().numpy().view(np.uint32).astype(np.int64)
+    assert np.array_equal(rows * C, GI[f"grid_{tag}_index"].astype(np.int64))
