@@ -424,7 +424,8 @@ def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m:
     """Does the native fp16 path (fp16 table gradients, exact fixed-point sums, native Adam + loss scaling, HIP-graph replay)
     CONVERGE like the reference arrangement (torch.optim.Adam on fp32 `.grad`s + torch GradScaler, eager)?  Both train
     configs[1]'s network from the same initial weights on the same batches for `steps` steps (lr 1e-2 decayed to 0.1x as
-    main_SealNeRF.py:283-288); PSNR (nerf/utils.py:226-233) on four HELD-OUT 200x200 views against the analytic scene.
+    main_SealNeRF.py:283-288, every step in both arrangements: the replayed graph reads the schedule's factor from a device
+    word, nerf/optim.py: follow_lr_schedule); PSNR (nerf/utils.py:226-233) on four HELD-OUT 200x200 views against the analytic scene.
     The two trajectories are chaotic twins (different rounding, different RNG consumption under capture), so ONE pair says
     little: the comparison is repeated for `seeds` initialisations and reported as mean +- sample standard deviation of
     each arrangement and of the paired difference."""
@@ -450,8 +451,6 @@ def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m:
                 lr = 1e-2 * 0.1 ** min(i / steps, 1.0)
                 for g in tr.optimizer.param_groups:
                     g["lr"] = lr
-                if native and tr.graph is not None and i % 100 == 0:
-                    tr.graph = None  # (the learning rate is a kernel argument of the captured step: re-capture on the decay schedule)
                 tr.train_step(*pool[(i + 257 * k) % len(pool)])
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0

@@ -442,11 +442,15 @@ int s3d_seal_bbox_map(const float* points, const float* dirs, uint32_t M, const 
  * s3d_grads_nonfinite sets *found_inf = 1 if any element is inf/NaN (never clears it).
  * s3d_adam_step updates param / exp_avg / exp_avg_sq (fp32) with grad / *grad_scale as step number *step + 1, and
  * does nothing when *found_inf != 0; param_half (optional) receives the fp16 copy of the updated parameters.
- * s3d_adam_advance increments *step unless *found_inf != 0 (call once per optimizer step, after the tensors). */
+ * s3d_adam_advance increments *step unless *found_inf != 0 (call once per optimizer step, after the tensors).
+ * lr_scale (optional, device): the update uses lr * *lr_scale — the factor of a learning-rate schedule
+ * (torch.optim.lr_scheduler.LambdaLR in main_SealNeRF.py:283-288), read at run time so that a step captured in a HIP graph
+ * follows the schedule without being re-captured. */
 int s3d_grads_nonfinite(const void* grad, size_t n, int dtype, float* found_inf, s3d_stream_t stream);
 int s3d_adam_step(float* param, const void* grad, int grad_dtype, float* exp_avg, float* exp_avg_sq,
                   uint16_t* param_half, size_t n, float lr, float beta1, float beta2, float eps,
-                  const float* step, const float* grad_scale, const float* found_inf, s3d_stream_t stream);
+                  const float* step, const float* grad_scale, const float* found_inf, const float* lr_scale,
+                  s3d_stream_t stream);
 int s3d_adam_advance(float* step, const float* found_inf, s3d_stream_t stream);
 /* s3d_adam_step for every tensor of the optimizer in one launch (same arithmetic per element).  consume_grads != 0: every
  * gradient is cleared behind the read — also on a skipped (*found_inf != 0) step — for producers that accumulate into it. */
@@ -466,7 +470,8 @@ typedef struct s3d_adam_tensor {
     uint32_t pack_cols, pack_stride;
 } s3d_adam_tensor;
 int s3d_adam_step_multi(const s3d_adam_tensor* tensors /* host array */, int32_t n_tensors, const float* step,
-                        const float* grad_scale, const float* found_inf, int consume_grads, s3d_stream_t stream);
+                        const float* grad_scale, const float* found_inf, const float* lr_scale, int consume_grads,
+                        s3d_stream_t stream);
 /* GradScaler.update(): scale *= backoff on overflow, *= growth after growth_interval clean steps; clears *found_inf.
  * adam_step (optional): s3d_adam_advance of that step count folded into the same launch (before the flag is cleared). */
 int s3d_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, float growth_factor,

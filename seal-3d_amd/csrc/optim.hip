@@ -137,14 +137,14 @@ __global__ void __launch_bounds__(256) k_adam_step(float* __restrict__ p, const 
                                                    float* __restrict__ v, __half* __restrict__ p_half, size_t n, float lr,
                                                    float beta1, float beta2, float eps, const float* __restrict__ step,
                                                    const float* __restrict__ grad_scale, const float* __restrict__ found_inf,
-                                                   uint32_t vec) {
+                                                   const float* __restrict__ lr_scale, uint32_t vec) {
     if (found_inf && *found_inf != 0.0f) return;  // the whole step is skipped (GradScaler.step)
     const float t = *step + 1.0f;                 // this update's step number; k_adam_advance stores it afterwards
     AdamCoef c;
     c.beta1 = beta1; c.beta2 = beta2; c.eps = eps;
     c.inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
     const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
-    c.step_size = lr / bc1;
+    c.step_size = (lr_scale ? lr * *lr_scale : lr) / bc1;  // (lr_scale: the schedule's factor, read at run time by a replayed graph)
     c.bc2_sqrt = sqrtf(bc2);
     adam_range<G>(c, p, const_cast<G*>(g), m, v, p_half, n, vec != 0, (size_t)blockIdx.x * 256 + threadIdx.x,
                   (size_t)gridDim.x * 256, false);
@@ -169,7 +169,8 @@ struct AdamBatch {
 
 __global__ void __launch_bounds__(256) k_adam_step_multi(AdamBatch b, const float* __restrict__ step,
                                                          const float* __restrict__ grad_scale,
-                                                         const float* __restrict__ found_inf) {
+                                                         const float* __restrict__ found_inf,
+                                                         const float* __restrict__ lr_scale) {
     int i = 0;
     while (i + 1 < b.count && blockIdx.x >= b.first_block[i + 1]) i++;
     const size_t tid = (size_t)(blockIdx.x - b.first_block[i]) * 256 + threadIdx.x;
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(256) k_adam_step_multi(AdamBatch b, const floa
     c.beta1 = b.beta1[i]; c.beta2 = b.beta2[i]; c.eps = b.eps[i];
     c.inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
     const float bc1 = 1.0f - powf(c.beta1, t), bc2 = 1.0f - powf(c.beta2, t);
-    c.step_size = b.lr[i] / bc1;
+    c.step_size = (lr_scale ? b.lr[i] * *lr_scale : b.lr[i]) / bc1;
     c.bc2_sqrt = sqrtf(bc2);
     if (b.stride[i]) {
         if (b.half_grad[i])
@@ -285,7 +286,8 @@ S3D_EXPORT int s3d_grads_nonfinite(const void* grad, size_t n, int dtype, float*
 
 S3D_EXPORT int s3d_adam_step(float* param, const void* grad, int grad_dtype, float* exp_avg, float* exp_avg_sq,
                              uint16_t* param_half, size_t n, float lr, float beta1, float beta2, float eps,
-                             const float* step, const float* grad_scale, const float* found_inf, s3d_stream_t stream) {
+                             const float* step, const float* grad_scale, const float* found_inf, const float* lr_scale,
+                             s3d_stream_t stream) {
     if (n == 0) return S3D_OK;
     S3D_REQUIRE(param && grad && exp_avg && exp_avg_sq && step, "adam_step: null pointer");
     S3D_REQUIRE(grad_dtype == S3D_F32 || grad_dtype == S3D_F16, "adam_step: grad dtype must be f32 or f16");
@@ -295,15 +297,15 @@ S3D_EXPORT int s3d_adam_step(float* param, const void* grad, int grad_dtype, flo
     const uint32_t vec = (bits & 15) == 0;
     if (grad_dtype == S3D_F16)
         hipLaunchKernelGGL(k_adam_step<__half>, dim3(grid), dim3(256), 0, as_stream(stream), param, (const __half*)grad, exp_avg,
-                           exp_avg_sq, (__half*)param_half, n, lr, beta1, beta2, eps, step, grad_scale, found_inf, vec);
+                           exp_avg_sq, (__half*)param_half, n, lr, beta1, beta2, eps, step, grad_scale, found_inf, lr_scale, vec);
     else
         hipLaunchKernelGGL(k_adam_step<float>, dim3(grid), dim3(256), 0, as_stream(stream), param, (const float*)grad, exp_avg,
-                           exp_avg_sq, (__half*)param_half, n, lr, beta1, beta2, eps, step, grad_scale, found_inf, vec);
+                           exp_avg_sq, (__half*)param_half, n, lr, beta1, beta2, eps, step, grad_scale, found_inf, lr_scale, vec);
     return check_launch("adam_step");
 }
 
 S3D_EXPORT int s3d_adam_step_multi(const s3d_adam_tensor* tensors, int32_t n_tensors, const float* step, const float* grad_scale,
-                                   const float* found_inf, int consume_grads, s3d_stream_t stream) {
+                                   const float* found_inf, const float* lr_scale, int consume_grads, s3d_stream_t stream) {
     S3D_REQUIRE(n_tensors >= 0 && (tensors || n_tensors == 0) && step, "adam_step_multi: null pointer");
     for (int32_t base = 0; base < n_tensors; base += kAdamMaxTensors) {
         AdamBatch b;
@@ -331,7 +333,7 @@ S3D_EXPORT int s3d_adam_step_multi(const s3d_adam_tensor* tensors, int32_t n_ten
             b.first_block[i + 1] = blocks;
         }
         if (b.count == 0) continue;
-        hipLaunchKernelGGL(k_adam_step_multi, dim3(blocks), dim3(256), 0, as_stream(stream), b, step, grad_scale, found_inf);
+        hipLaunchKernelGGL(k_adam_step_multi, dim3(blocks), dim3(256), 0, as_stream(stream), b, step, grad_scale, found_inf, lr_scale);
     }
     return check_launch("adam_step_multi");
 }

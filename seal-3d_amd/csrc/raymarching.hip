@@ -20,9 +20,20 @@ namespace {
 constexpr float kSqrt3 = 1.7320508075688772f;
 constexpr float kRPi = 0.3183098861837907f;
 
-// (raymarching.cu:56-63 spreads the bits with multiplies by 0x00010001, 0x101, 0x11, 5; after each mask the shifted copy
-//  never overlaps the original, so `v * (1 + 2^k)` == `v | v << k` bit for bit — and a 32-bit integer multiply is a
-//  quarter-rate instruction here while shift-or is one full-rate v_lshl_or_b32: 12 multiplies per occupancy probe gone)
+// raymarching.cu:56-63 as written: multiplies by 0x00010001, 0x101, 0x11, 5 with uint32 wrap-around — what the exported
+// morton3D kernel computes for ANY int32 input (tests/golden/int_kernels.npz holds inputs up to 2^32 - 1).
+__device__ __forceinline__ uint32_t expand_bits_any(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+// The marching kernels' form, for v < 2^16 (cell coordinates are clamped to [0, H - 1], H <= 1024): the shifted copy never
+// overlaps the original there — in the first step because v has no bit above 15, afterwards because of the masks — so
+// `v * (1 + 2^k)` == `v | v << k` bit for bit, and a 32-bit integer multiply is a quarter-rate instruction here while
+// shift-or is one full-rate v_lshl_or_b32: 12 multiplies per occupancy probe gone.  (v >= 2^16: the product carries where
+// the `or` does not — the exported kernel therefore uses expand_bits_any.)
 __device__ __forceinline__ uint32_t expand_bits(uint32_t v) {
     v = (v | (v << 16)) & 0xFF0000FFu;
     v = (v | (v << 8)) & 0x0F00F00Fu;
@@ -137,7 +148,8 @@ __global__ void k_sph_from_ray(const float* __restrict__ rays_o, const float* __
 
 __global__ void k_morton3d(const int32_t* __restrict__ coords, uint32_t N, int32_t* __restrict__ indices) {
     for (uint32_t n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x)
-        indices[n] = (int32_t)morton3d((uint32_t)coords[n * 3], (uint32_t)coords[n * 3 + 1], (uint32_t)coords[n * 3 + 2]);
+        indices[n] = (int32_t)(expand_bits_any((uint32_t)coords[n * 3]) | (expand_bits_any((uint32_t)coords[n * 3 + 1]) << 1) |
+                               (expand_bits_any((uint32_t)coords[n * 3 + 2]) << 2));
 }
 
 __global__ void k_morton3d_invert(const int32_t* __restrict__ indices, uint32_t N, int32_t* __restrict__ coords) {

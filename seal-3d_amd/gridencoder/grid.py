@@ -196,8 +196,8 @@ class _GridEncodePair(Function):
         inputs, ta, tb, offsets = ctx.saved_tensors
         B, D, C, L, S, H, gridtype, interpolation, align_corners = ctx.meta
         outs = []
-        for grad, table, param in ((ga, ta, ctx.params[0]), (gb, tb, ctx.params[1])):
-            if grad is None:
+        for k, (grad, table, param) in enumerate(((ga, ta, ctx.params[0]), (gb, tb, ctx.params[1]))):
+            if grad is None or not ctx.needs_input_grad[1 + k]:  # (a frozen table of the pair: no scatter, no hand-over mark)
                 outs.append(None)
                 continue
             grad = grad.contiguous()

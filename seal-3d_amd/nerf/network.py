@@ -129,7 +129,15 @@ class PackedWeights:
       * otherwise (teacher, evaluation, frozen MLPs): `refreshed()` re-copies the members when one of them has changed (tensor
         version or optimizer epoch), i.e. once per weight update instead of once per call."""
 
-    _s3d_overwrite = True  # the MLP backward REPLACES the gradient twin (constant blocks would pile up under accumulation)
+    @property
+    def _s3d_overwrite(self):
+        """What the MLP backward asks before it writes the gradient twin.  The twin is never cleared (Adam reads it through the
+        member views only, constant blocks would pile up under blind accumulation): the FIRST backward of a step replaces it,
+        any further backward before the step — the two `density()` calls of `NeRFRenderer.run`, gradient accumulation over
+        several batches — adds to it.  "Of a step": since the last zero_grad() / consuming step(), the same host-side flags
+        the optimizer's own clearing decision uses (nerf/optim.py: zero_grad, clear_unconsumed)."""
+        return not any(getattr(p, "_s3d_grad_touched", False) and not getattr(p, "_s3d_grad_consumed", False)
+                       for p, _, _ in self.members)
 
     def __init__(self, members, numel, constants=()):
         self.members, self.numel, self.constants = list(members), int(numel), list(constants)

@@ -32,6 +32,10 @@ class NativeAdam(torch.optim.Optimizer):
                                       foreach=None, capturable=False, differentiable=False, fused=None,
                                       decoupled_weight_decay=False))
         self.step_count = None
+        # device-side factor on every group's lr (None: none).  A trainer that replays the step from a HIP graph keeps the
+        # group's `lr` of the capture in the launch arguments and writes schedule / captured here (follow_lr_schedule)
+        self.lr_scale = None
+        self._lr_captured = None
         # the update launch clears every handed-over gradient behind its read: the next zero_grad() has nothing to fill
         self.consume_grads = consume_grads
         self.flat_half = None  # ONE fp16 buffer behind every handed-over gradient: one clear, one check, one all-reduce
@@ -160,6 +164,31 @@ class NativeAdam(torch.optim.Optimizer):
                     if k not in st:
                         st[k] = torch.zeros_like(p, memory_format=torch.contiguous_format)
 
+    def capture_lr(self):
+        """The step is about to be captured in a graph: remember each group's lr (it becomes a launch argument) and start
+        the device-side factor at 1."""
+        if self.lr_scale is None:
+            self.lr_scale = torch.ones(1, dtype=torch.float32, device=self.step_count.device)
+        self._lr_captured = [float(g["lr"]) for g in self.param_groups]
+        self._lr_factor = 1.0
+        self.lr_scale.fill_(1.0)
+
+    def follow_lr_schedule(self):
+        """Before a replay: `param_groups[i]["lr"]` may have been moved by a scheduler (LambdaLR, main_SealNeRF.py:283-288)
+        since the capture.  All groups moved by the same factor (the schedulers of the reference scale every group alike):
+        that factor goes to the device word the captured Adam launch reads — one 4-byte fill, and only when it changed.
+        Returns False when the groups moved by different factors: the caller re-captures."""
+        if self._lr_captured is None:
+            return True
+        now = [float(g["lr"]) for g in self.param_groups]
+        f = [n / c if c != 0 else (1.0 if n == 0 else float("inf")) for n, c in zip(now, self._lr_captured)]
+        if any(abs(x - f[0]) > 1e-12 * max(1.0, abs(f[0])) for x in f) or f[0] == float("inf"):
+            return False
+        if f[0] != self._lr_factor:
+            self.lr_scale.fill_(f[0])
+            self._lr_factor = f[0]
+        return True
+
     def mark_all_touched(self):
         """after a gradient all-reduce every stashed gradient is the replicas' mean on EVERY rank, also on a rank whose own
         batch never reached that table: all ranks must take the same update"""
@@ -174,6 +203,13 @@ class NativeAdam(torch.optim.Optimizer):
         cover p's gradient while later pieces are still on the wire); without it all tensors are updated by ONE launch.
         `advance=False`: the caller advances `step_count` itself (NativeGradScaler.update folds it into its own launch)."""
         batch, stale, consumed = [], [], []
+        lr_of = {}
+        if self._lr_captured is not None:
+            # launches carry the lr of the capture and the device-side factor carries the schedule — also for an eager step of
+            # an optimizer whose step has been captured once (same arithmetic on both routes)
+            if not torch.cuda.is_current_stream_capturing() and not self.follow_lr_schedule():
+                self.capture_lr()  # groups moved apart: rebase (a trainer holding a graph re-captures, trainer.py)
+            lr_of = {id(g): lr for g, lr in zip(self.param_groups, self._lr_captured)}
         for group, p, g in self.grads():
             if before_param is not None:
                 before_param(p)
@@ -185,14 +221,14 @@ class NativeAdam(torch.optim.Optimizer):
             packed = getattr(p, "_s3d_pack_spec", None) is not None and g is getattr(p, "_s3d_grad", None)
             if half is not None and not packed and not half.is_contiguous():
                 half = None  # a pack member updated from a plain `.grad` (nn.Linear route): its strided fp16 image is re-copied below
-            item = (p.data, g, st["exp_avg"], st["exp_avg_sq"], half, group["lr"], b1, b2, group["eps"])
+            item = (p.data, g, st["exp_avg"], st["exp_avg_sq"], half, lr_of.get(id(group), group["lr"]), b1, b2, group["eps"])
             if before_param is not None and packed:
                 # (row-strided views of the pack: the multi-tensor entry point knows the layout.  The MLP backward OVERWRITES
                 #  the pack's gradient twin, so nothing is cleared behind the read)
-                _backend.adam_step_multi([item + (False,)], self.step_count, grad_scale, found_inf)
+                _backend.adam_step_multi([item + (False,)], self.step_count, grad_scale, found_inf, lr_scale=self.lr_scale)
                 p._s3d_grad_consumed = True
             elif before_param is not None:
-                _backend.adam_step(*item, self.step_count, grad_scale, found_inf)
+                _backend.adam_step(*item, self.step_count, grad_scale, found_inf, self.lr_scale)
             elif packed:
                 batch.append(item + (False,))
                 consumed.append(p)  # (nothing to clear: the next backward overwrites the pack's gradient twin)
@@ -205,7 +241,7 @@ class NativeAdam(torch.optim.Optimizer):
             if half is None and hasattr(p, "_s3d_half"):
                 stale.append(p)
         if batch:
-            _backend.adam_step_multi(batch, self.step_count, grad_scale, found_inf)
+            _backend.adam_step_multi(batch, self.step_count, grad_scale, found_inf, lr_scale=self.lr_scale)
             for p in consumed:
                 p._s3d_grad_consumed = True
         for p in stale:

@@ -686,7 +686,7 @@ class OptimBackend:
                "grads_nonfinite")
 
     @staticmethod
-    def adam_step(param, grad, exp_avg, exp_avg_sq, param_half, lr, beta1, beta2, eps, step, grad_scale, found_inf):
+    def adam_step(param, grad, exp_avg, exp_avg_sq, param_half, lr, beta1, beta2, eps, step, grad_scale, found_inf, lr_scale=None):
         _need(param, torch.float32, "param")
         _need(exp_avg, torch.float32, "exp_avg")
         _need(exp_avg_sq, torch.float32, "exp_avg_sq")
@@ -696,10 +696,10 @@ class OptimBackend:
             _need(param_half, torch.float16, "param_half")
         _check(lib().s3d_adam_step(_p(param), _p(grad), C.c_int(_dt(grad)), _p(exp_avg), _p(exp_avg_sq), _p(param_half),
                                    C.c_size_t(param.numel()), _f(lr), _f(beta1), _f(beta2), _f(eps), _p(step),
-                                   _p(grad_scale), _p(found_inf), _stream()), "adam_step")
+                                   _p(grad_scale), _p(found_inf), _p(lr_scale), _stream()), "adam_step")
 
     @staticmethod
-    def adam_step_multi(items, step, grad_scale, found_inf, consume_grads=False):
+    def adam_step_multi(items, step, grad_scale, found_inf, consume_grads=False, lr_scale=None):
         """`items`: (param, grad, exp_avg, exp_avg_sq, param_half or None, lr, beta1, beta2, eps[, consume]) per tensor — adam_step
         for all of them in one launch; `consume_grads` (all tensors) / the optional tenth element (that tensor): the gradient
         is cleared behind the read (seal3d_hip.h)"""
@@ -728,7 +728,7 @@ class OptimBackend:
             a.n = param.numel()
             a.lr, a.beta1, a.beta2, a.eps = float(lr), float(beta1), float(beta2), float(eps)
             a.grad_dtype = _dt(grad)
-        _check(lib().s3d_adam_step_multi(arr, C.c_int32(len(items)), _p(step), _p(grad_scale), _p(found_inf),
+        _check(lib().s3d_adam_step_multi(arr, C.c_int32(len(items)), _p(step), _p(grad_scale), _p(found_inf), _p(lr_scale),
                                          C.c_int(int(bool(consume_grads))), _stream()), "adam_step_multi")
 
     @staticmethod
@@ -878,12 +878,18 @@ class NgpHeadBackend:
         if grad_loss is not None:
             for t, nm in ((grad_loss, "grad_loss"), (grad_sigma, "grad_sigma"), (grad_color, "grad_color")):
                 _need(t, torch.float32, nm)
-        key = sigma.device.index
+        # one workspace (partial sums + the last-block ticket) per (device, stream): two launches in flight on different
+        # streams — a pretraining graph on a side stream next to an eager call, two trainers — must not share a ticket
+        key = (sigma.device.index, torch.cuda.current_stream(sigma.device).cuda_stream)
         ws = NgpHeadBackend._l1_ws.get(key)
-        if ws is None:  # (zeroed once, outside any capture: the kernel leaves its ticket word zero)
+        if ws is None:  # (zeroed once: the kernel leaves its ticket word zero)
+            n_ws = lib().s3d_l1_pair_workspace_size() // 4
             if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError("l1_pair_loss: first call on this device must not be inside a graph capture (workspace)")
-            ws = NgpHeadBackend._l1_ws[key] = torch.zeros(lib().s3d_l1_pair_workspace_size() // 4, dtype=torch.float32, device=sigma.device)
+                # (torch captures every graph on its own stream: a buffer first asked for during a capture is allocated from
+                #  that graph's pool and zeroed by a fill the graph replays — it is not cached beyond the capture)
+                ws = torch.zeros(n_ws, dtype=torch.float32, device=sigma.device)
+            else:
+                ws = NgpHeadBackend._l1_ws[key] = torch.zeros(n_ws, dtype=torch.float32, device=sigma.device)
         _check(lib().s3d_l1_pair_loss(_p(sigma), _p(color), _p(gt_sigma), _p(gt_color), _u(n), _u(n_rows), _u(n_total), _p(loss), _p(grad_loss),
                                       _p(grad_sigma), _p(grad_color), _p(ws), _stream()), "l1_pair_loss")
 

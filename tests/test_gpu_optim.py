@@ -230,3 +230,58 @@ def test_optimizer_and_scaler_state_dicts_interchange_with_torch(hip):
     sc = NativeGradScaler("cuda")
     sc.load_state_dict(sb.state_dict())
     assert sc.get_scale() == 4096.0 and int(sc._growth_tracker) == 17
+
+
+def test_lr_schedule_reaches_a_captured_step_through_the_device_side_factor(hip):
+    """A learning-rate schedule (LambdaLR in main_SealNeRF.py:283-288) moves `param_groups[i]["lr"]` every step.  A step
+    captured in a HIP graph has the lr of the capture among its launch arguments; `NativeAdam.capture_lr` /
+    `follow_lr_schedule` route the later values through one device word (s3d_adam_step_multi: lr_scale).  The replayed
+    updates must equal torch.optim.Adam under the same schedule."""
+    from nerf.optim import NativeAdam
+    p0 = [_mk((3000, 2), 1), _mk((513,), 2)]
+    pa = [torch.nn.Parameter(t.clone().cuda()) for t in p0]
+    pb = [torch.nn.Parameter(t.clone().cuda()) for t in p0]
+    oa = NativeAdam([{"params": pa[:1]}, {"params": pa[1:], "lr": 3e-3}], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    ob = torch.optim.Adam([{"params": pb[:1]}, {"params": pb[1:], "lr": 3e-3}], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    base = [g["lr"] for g in oa.param_groups]
+    sg = [torch.zeros_like(p) for p in pa]  # static gradient buffers of the captured step
+    for p, g in zip(pa, sg):
+        p.grad = g
+    steps = 12
+    grads = [[_mk(p.shape, 100 * s + i).cuda() for i, p in enumerate(pa)] for s in range(steps)]
+    for g, src in zip(sg, grads[0]):
+        g.copy_(src)
+    oa.capture_lr()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        oa.step()  # warm-up = step 0 (eager, factor 1)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        oa.step()
+    for s in range(steps):
+        f = 0.1 ** (s / steps)
+        for grp, grb, b in zip(oa.param_groups, ob.param_groups, base):
+            grp["lr"] = grb["lr"] = b * f
+        for i, b in enumerate(pb):
+            b.grad = grads[s][i].clone()
+        ob.step()
+        if s > 0:
+            for g, src in zip(sg, grads[s]):
+                g.copy_(src)
+            assert oa.follow_lr_schedule()
+            graph.replay()
+    assert float(oa.step_count) == steps
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=3e-6, atol=2e-7)
+    # groups that move apart cannot share the factor: the caller is told to re-capture
+    oa.param_groups[0]["lr"] *= 0.5
+    assert not oa.follow_lr_schedule()
+    # ... and an eager step rebases by itself
+    for g, src in zip(sg, grads[0]):
+        g.copy_(src)
+    before = pa[0].detach().clone()
+    oa.step()
+    assert oa._lr_captured[0] == oa.param_groups[0]["lr"] and float(oa.lr_scale) == 1.0
+    assert not torch.equal(before, pa[0].detach())

@@ -423,6 +423,56 @@ def test_packed_linear_weights_in_the_native_optimizer_match_the_assembled_path(
         assert torch.equal(v, out[False][1][k]), k
 
 
+def test_two_backward_passes_of_one_step_add_up_in_the_packed_weight_gradient(hip):
+    """`NeRFRenderer.run` (cuda_ray off, nerf/renderer.py:168-214) queries `density()` twice with gradients before one
+    optimizer step, and gradient accumulation runs several backward passes per step.  The pack's gradient twin is never cleared,
+    so the FIRST backward since zero_grad() / step() replaces it and every further one adds to it (PackedWeights._s3d_overwrite):
+    the twin must hold the SUM of both passes — against the same model without packs, where autograd sums the fp32 `.grad`s —
+    and the next step must start from a replaced twin again."""
+    from nerf import network
+    from nerf.trainer import Trainer
+    g = torch.Generator().manual_seed(5)
+    xs = [((torch.rand(1024, 3, generator=g) * 2 - 1) * 0.9).cuda() for _ in range(3)]
+    res = {}
+    for packed in (True, False):
+        torch.manual_seed(0)
+        net = network.NeRFNetwork(bound=1, cuda_ray=True, log2_hashmap_size=15, density_scale=1, min_near=0.2, density_thresh=10).cuda()
+        with torch.no_grad():
+            net.encoder.embeddings.uniform_(-0.5, 0.5)
+        if not packed:
+            for pk in net._packs:
+                for p, _, _ in pk.members:
+                    del p._s3d_pack_spec
+            net._packs = None
+        tr = Trainer(net, lr=1e-2, fp16=True, update_extra_interval=10 ** 9)
+        assert tr.native_optim
+        net.train()
+        out = []
+        for batches in ((xs[0], xs[1]), (xs[2],)):       # step A: two passes; step B: one pass (must not see step A's sum)
+            tr.optimizer.zero_grad()
+            for x in batches:
+                with torch.autocast("cuda", dtype=torch.float16):
+                    sig = net.density(x)["sigma"]
+                (sig.float().sum() * 4.0).backward()
+            ws = [l.weight for l in net.sigma_net]
+            if packed:
+                assert all(w.grad is None and w._s3d_grad_touched for w in ws)
+                out.append([w._s3d_grad.float().clone() for w in ws])
+            else:
+                out.append([w.grad.float().clone() for w in ws])
+            if batches is not None and len(batches) == 2:
+                for w in ws:      # as a consuming step would leave the flags (the twin itself stays as it is: never cleared)
+                    if packed:
+                        w._s3d_grad_consumed = True
+        res[packed] = out
+    for step in range(2):
+        for a, b in zip(res[True][step], res[False][step]):
+            assert b.abs().max() > 0
+            torch.testing.assert_close(a, b, rtol=1e-2, atol=2e-3 * float(b.abs().max()))
+    # the two-pass sum really is larger than one pass (the bug this guards against kept only the second pass)
+    assert not torch.allclose(res[True][0][0], res[True][1][0], rtol=0.2, atol=0.0)
+
+
 def test_seal_loss_heads_match_the_torch_op_sequences(hip):
     """The Seal-3D loss glue as single launches (csrc/ngp_head.hip) against the reference's op sequences: fine-tuning criterion
     MSE + L1(nan_to_num(depth)) (nerf/utils.py:484-489; the depth term has a value and no gradient, raymarching.py:274),
