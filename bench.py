@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--long_run_steps", type=int, default=3000)
     ap.add_argument("--long_run_seeds", type=int, default=3)
     ap.add_argument("--seal_teacher_steps", type=int, default=256)
+    ap.add_argument("--seal_point_step", type=float, default=0.005, help="pretraining_local_point_step (readme.md:109)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="process-group backend (default: nccl = RCCL)")
     ap.add_argument("--rendezvous_only", action="store_true",
@@ -345,17 +346,29 @@ SEAL_BBOX = {"type": "bbox", "raw": [[x, y, z] for x in (-0.2, 0.2) for y in (0.
              "transform": [[1, 0, 0, 0.3], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], "scale": [1, 1, 1], "boundType": "both"}
 
 
-def seal_section(args, dev, batches, note=lambda m: None):
-    """BASELINE configs[2] on one GPU: teacher = the two-encoder NGP net trained on the synthetic scene,
-    student = its copy, bbox edit translate (0.3, 0, 0), pretraining_local_point_step 0.005 (~7.7e5 lattice points, one
-    chunk), then fine-tuning on 4,096-ray batches whose RGB + depth targets the teacher renders through the proxy."""
+def seal_section(args, dev, batches, note=lambda m: None, make_dp=None, reps=None, eager=False, net_kw=None):
+    """BASELINE configs[2] (1 GPU) / configs[3] (`--gpus N`: SURVEY §8e) — teacher = the two-encoder NGP net trained on the
+    synthetic scene, student = its copy, bbox edit translate (0.3, 0, 0), pretraining_local_point_step 0.005 (~7.7e5 lattice
+    points, one chunk), then fine-tuning on 4,096-ray batches per rank whose RGB + depth targets the teacher renders through
+    the proxy.  With N ranks (`make_dp()` -> a parallel.RayShardedDP per trainer): every chunk of pretraining points is
+    sharded over the ranks (SealNeRF/trainer.py:404-413; MLPs frozen: table gradients only), each rank renders the proxy
+    targets of and fine-tunes on its OWN rays (weak scaling), and both tables' and both MLPs' gradients travel in the one
+    all-reduce per step.  Every timing is bracketed by a barrier and is the MAX over the ranks; rates are whole-job.
+    `eager`: the eager trainers instead of the graph-replayed ones (the only choice without a GPU: tests/); `reps`, `net_kw`:
+    repetition counts / network arguments of a reduced run (tests/)."""
+    import torch.distributed as dist
     from nerf import network
-    from nerf.trainer import GraphedTrainer
-    from sealnerf import GraphedSealTrainer, SealBBoxMapper, make_student, make_teacher
-    kw = dict(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10)
+    from nerf.trainer import GraphedTrainer, Trainer
+    from sealnerf import GraphedSealTrainer, SealBBoxMapper, SealTrainer, make_student, make_teacher
+    reps = dict(dict(pretrain=8, proxy=8, warm=40, step=32, proxy_graph=16, allreduce=8), **(reps or {}))
+    dpt, dps = (make_dp(), make_dp()) if make_dp is not None else (None, None)
+    world = dps.world if dps is not None else 1
+    multi = world > 1 and dist.is_initialized()
+    kw = dict(dict(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10), **(net_kw or {}))
     torch.manual_seed(args.seed + 17)
     teacher = make_teacher(network.NeRFNetwork, **kw).to(dev)
-    ttr = GraphedTrainer(teacher, args.num_rays, lr=1e-2, fp16=True, update_extra_interval=16)
+    ttr = (Trainer(teacher, lr=1e-2, fp16=True, update_extra_interval=16, dist=dpt) if eager else
+           GraphedTrainer(teacher, args.num_rays, lr=1e-2, fp16=True, update_extra_interval=16, dist=dpt))
     for i in range(args.seal_teacher_steps):
         ttr.train_step(*batches[i % len(batches)])
     del ttr
@@ -366,57 +379,96 @@ def seal_section(args, dev, batches, note=lambda m: None):
     teacher.init_mapper(mapper)
     student.init_mapper(mapper)
     note("seal: teacher trained; pretraining")
-    tr = GraphedSealTrainer(student, teacher, args.num_rays, lr=1e-2, fp16=True, update_extra_interval=16)
-    n_local = tr.init_pretraining(batch_size=6144000, lr=0.05, local_point_step=0.005)
+    tr = (SealTrainer(student, teacher, lr=1e-2, fp16=True, update_extra_interval=16, dist=dps) if eager else
+          GraphedSealTrainer(student, teacher, args.num_rays, lr=1e-2, fp16=True, update_extra_interval=16, dist=dps))
+    n_local = tr.init_pretraining(batch_size=6144000, lr=0.05, local_point_step=args.seal_point_step)
 
-    def sync_time(fn, reps):
-        torch.cuda.synchronize()
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    def sync_time(fn, n):
+        sync()
+        if multi:
+            dist.barrier()
         t0 = time.perf_counter()
-        for i in range(reps):
+        for i in range(n):
             fn(i)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps
+        sync()
+        if multi:
+            dist.barrier()
+        dt = torch.tensor([(time.perf_counter() - t0) / n], dtype=torch.float64, device=dev)
+        if multi:
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        return float(dt.item())
+
+    def total(t):  # whole-job count: the sum over the ranks
+        t = t.to(torch.float64)
+        if multi:
+            dist.all_reduce(t)
+        return float(t.item())
     l0 = float(tr.pretrain_one_epoch())
     tr.pretrain_one_epoch()  # (second epoch: the chunk's graph is captured)
-    ep = sync_time(lambda i: tr.pretrain_one_epoch(), 8)
+    ep = sync_time(lambda i: tr.pretrain_one_epoch(), reps["pretrain"])
     l1 = float(tr.pretrain_one_epoch())
     note(f"seal: pretraining timed ({ep * 1e3:.2f} ms/epoch); proxy truth")
-    proxy = sync_time(lambda i: tr.proxy_truth(batches[i % len(batches)][0], batches[i % len(batches)][1]), 8)
+    proxy = sync_time(lambda i: tr.proxy_truth(batches[i % len(batches)][0], batches[i % len(batches)][1]), reps["proxy"])
     note("seal: fine-tuning")
-    for i in range(40):  # fine-tuning warm-up: 16 eager steps (sample statistics), capture, replays
+    for i in range(reps["warm"]):  # fine-tuning warm-up: 16 eager steps (sample statistics), capture, replays
         tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
     samples = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def ft(i):
         tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
         samples.add_(student.step_counter[(student.local_step - 1) % 16, 0].long())
-    step = sync_time(ft, 32)
-
-    def proxy_replay(i):  # the proxy render as the fine-tuning step runs it: rays staged, its own HIP graph replayed
-        b = batches[i % len(batches)]
-        torch._foreach_copy_([tr.s_ro, tr.s_rd], [b[0].reshape(-1, 3), b[1].reshape(-1, 3)])
-        tr._proxy_replay()
-    proxy_graph = sync_time(proxy_replay, 16) if tr.proxy_graph is not None else None
-    targets = [tr.proxy_truth(b[0], b[1]) for b in batches[:8]]
+    step = sync_time(ft, reps["step"])
+    proxy_graph = None
+    if getattr(tr, "proxy_graph", None) is not None:
+        def proxy_replay(i):  # the proxy render as the fine-tuning step runs it: rays staged, its own HIP graph replayed
+            b = batches[i % len(batches)]
+            torch._foreach_copy_([tr.s_ro, tr.s_rd], [b[0].reshape(-1, 3), b[1].reshape(-1, 3)])
+            tr._proxy_replay()
+        proxy_graph = sync_time(proxy_replay, reps["proxy_graph"])
+    nb = min(8, len(batches))
+    targets = [tr.proxy_truth(b[0], b[1]) for b in batches[:nb]]
     samples2 = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def ft_cached(i):
-        tr.train_step(batches[i % 8][0], batches[i % 8][1], *targets[i % 8])
+        tr.train_step(batches[i % nb][0], batches[i % nb][1], *targets[i % nb])
         samples2.add_(student.step_counter[(student.local_step - 1) % 16, 0].long())
-    step_cached = sync_time(ft_cached, 32)
-    return {"workload": "configs[2]: lego_bbox-shaped edit (bbox translate 0.3), teacher+student two-encoder NGP, "
-                        "pretraining_local_point_step=0.005, 4096 rays/step, 1 GPU, HIP-graph replay",
-            "local_points": int(n_local),
-            "seal_pretrain_points_per_s": n_local / ep, "pretrain_ms_per_epoch": ep * 1e3, "pretrain_loss_first_last": [l0, l1],
-            "proxy_truth_mrays_per_s": args.num_rays / proxy / 1e6, "proxy_truth_ms_per_batch": proxy * 1e3,
-            "proxy_truth_note": "eager call of SealSteps.proxy_truth (host launches); inside the fine-tuning step the render is "
-                                "replayed from its own graph: *_graph_replay",
-            "proxy_truth_ms_per_batch_graph_replay": None if proxy_graph is None else proxy_graph * 1e3,
-            "proxy_truth_mrays_per_s_graph_replay": None if proxy_graph is None else args.num_rays / proxy_graph / 1e6,
-            "seal_train_samples_per_s": float(samples.item()) / 32 / step, "seal_train_ms_per_step": step * 1e3,
-            "seal_train_samples_per_s_cached_targets": float(samples2.item()) / 32 / step_cached,
-            "seal_train_ms_per_step_cached_targets": step_cached * 1e3,
-            "graph_captures": tr.n_captures}
+    step_cached = sync_time(ft_cached, reps["step"])
+    n_samples, n_samples2 = total(samples), total(samples2)
+    out = {"workload": ("configs[2]: lego_bbox-shaped edit (bbox translate 0.3), teacher+student two-encoder NGP, "
+                        f"pretraining_local_point_step={args.seal_point_step:g}, {args.num_rays} rays/step, 1 GPU, HIP-graph replay") if world == 1 and not eager else
+                       ("configs[3]: lego_bbox-shaped edit, teacher+student two-encoder NGP distillation, pretraining points sharded "
+                        f"over {world} rank(s), {args.num_rays} rays/step/rank, one gradient all-reduce per step"),
+           "local_points": int(n_local),
+           "seal_pretrain_points_per_s": n_local / ep, "pretrain_ms_per_epoch": ep * 1e3, "pretrain_loss_first_last": [l0, l1],
+           "proxy_truth_mrays_per_s": world * args.num_rays / proxy / 1e6, "proxy_truth_ms_per_batch": proxy * 1e3,
+           "proxy_truth_note": "eager call of SealSteps.proxy_truth (host launches); inside the fine-tuning step the render is "
+                               "replayed from its own graph: *_graph_replay",
+           "proxy_truth_ms_per_batch_graph_replay": None if proxy_graph is None else proxy_graph * 1e3,
+           "proxy_truth_mrays_per_s_graph_replay": None if proxy_graph is None else world * args.num_rays / proxy_graph / 1e6,
+           "seal_train_samples_per_s": n_samples / reps["step"] / step, "seal_train_ms_per_step": step * 1e3,
+           "seal_train_samples_per_s_cached_targets": n_samples2 / reps["step"] / step_cached,
+           "seal_train_ms_per_step_cached_targets": step_cached * 1e3,
+           "graph_captures": getattr(tr, "n_captures", 0)}
+    if dps is not None:
+        # the step's one exchange, alone: both tables' + both MLPs' gradients (fp16 hand-over buffer + fp32 bucket)
+        ar = sync_time(lambda i: dps.allreduce_grads(tr.scaler), reps["allreduce"])
+        half = sum(b.numel() * b.element_size() for b in dps.half_grads)
+        flat = 0 if dps.flat is None else dps.flat.numel() * dps.flat.element_size()
+        seen = torch.ones(1, device=dev)
+        if multi:
+            dist.all_reduce(seen)
+        out["data_parallel"] = {
+            "ranks_seen": int(seen.item()), "backend": dist.get_backend() if dist.is_initialized() else None,
+            "allreduce_ms_per_step_alone": ar * 1e3, "allreduce_bytes_fp16_buffer": int(half), "allreduce_bytes_fp32_bucket": int(flat),
+            "allreduce_in_step_graph": bool(getattr(tr, "collectives_in_graph", False)),
+            "pretraining": f"each {'chunk'} of local points sharded over {world} rank(s), table gradients all-reduced, steps eager" if world > 1
+                           else "1 rank: the chunk's step replayed from its graph",
+            "finetune": f"{args.num_rays} rays per rank and step (weak scaling), proxy targets rendered by each rank for its own rays"}
+    return out
 
 
 # ----------------------------------------------------------------------------- quality over a long run
@@ -773,10 +825,12 @@ def main():
     if world == 1 and not args.no_long_run and args.net == "ff":
         lr_ = long_run_quality(args, dev, R, scene_bits, boxes, steps=args.long_run_steps, note=note, seeds=args.long_run_seeds)
         extra.setdefault("psnr", {})["long_run"] = lr_
-    if world == 1 and not args.no_seal and args.net == "ff":
+    if not args.no_seal and args.net == "ff":
+        # configs[2] on one GPU; under `--gpus N` (or --force_dp) configs[3]: the same section data-parallel over the ranks
         note("seal section")
         del trainer
-        extra["seal"] = seal_section(args, dev, batches, note)
+        extra["seal"] = seal_section(args, dev, batches, note if rank == 0 else (lambda m: None),
+                                     make_dp=(lambda: RayShardedDP(force_collective=args.force_dp)) if dp is not None else None)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         note("cpu baseline")

@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(REPO, "bench.py")
 
@@ -42,3 +44,74 @@ def test_rank_count_that_differs_from_the_flag_is_refused():
              env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
     assert r.returncode != 0
     assert "--gpus 4" in r.stderr and "1 rank" in r.stderr
+
+
+# ----------------------------------------------------------------------------- configs[3]: the Seal section under N ranks
+_SEAL_DP = r'''
+import json, os, sys, types
+sys.path[:0] = [os.environ["S3D_REPO"], os.path.join(os.environ["S3D_REPO"], "seal-3d_amd")]
+import torch, torch.distributed as dist
+torch.set_num_threads(2)
+world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+if world > 1: dist.init_process_group("gloo", rank=rank, world_size=world)
+# the drop-in packages on the CPU oracle (test infrastructure; the product path has no CPU fallback)
+from oracle import oracle_backend as ob
+ob.build(); ob.set_threads(2)
+import raymarching.raymarching as rm, gridencoder.grid as gg, shencoder.sphere_harmonics as sh, freqencoder.freq as fq, ffmlp.ffmlp as ff
+rm._backend, gg._backend, sh._backend, fq._backend, ff._backend = (ob.RaymarchingBackend, ob.GridBackend, ob.SHBackend,
+                                                                   ob.FreqBackend, ob.FFMLPBackend)
+import bench
+from nerf import synthetic as syn
+from parallel import RayShardedDP
+sys.argv = ["bench.py", "--num_rays", "192", "--seal_teacher_steps", "18", "--seal_point_step", "0.06"]
+args = bench.parse()
+dev = torch.device("cpu")
+_, bits = syn.lego_like_density_grid(seed=0)
+batches, _ = bench.make_batches(3, args.num_rays, args.seed + rank, dev, ob.RaymarchingBackend, torch.from_numpy(bits), syn.lego_like_boxes(0))
+out = bench.seal_section(args, dev, batches, make_dp=(lambda: RayShardedDP()) if world > 1 else None, eager=True,
+                         reps=dict(pretrain=1, proxy=1, warm=2, step=2, allreduce=1), net_kw=dict(log2_hashmap_size=12))
+if rank == 0: print(json.dumps({"seal": out, "n_gpus": world}), flush=True)
+if world > 1: dist.destroy_process_group()
+'''
+
+
+def test_seal_section_runs_data_parallel_over_two_gloo_ranks(tmp_path):
+    """bench.seal_section — what `bench.py --gpus N` times as configs[3] — over 2 ranks (gloo, CPU oracle under the drop-in
+    packages, eager trainers, reduced sizes): pretraining points sharded, per-rank proxy targets and fine-tuning rays, one
+    gradient all-reduce per step, whole-job rates, and the `data_parallel` record of the bench line."""
+    script = tmp_path / "seal_dp.py"
+    script.write_text(_SEAL_DP)
+    env = dict(os.environ, S3D_REPO=REPO, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    seal, dp = line["seal"], line["seal"]["data_parallel"]
+    assert line["n_gpus"] == 2 and dp["ranks_seen"] == 2 and dp["backend"] == "gloo"
+    assert seal["workload"].startswith("configs[3]") and "2 rank(s)" in seal["workload"]
+    assert dp["allreduce_bytes_fp32_bucket"] > 0 and dp["allreduce_ms_per_step_alone"] > 0
+    assert seal["local_points"] > 100 and seal["seal_pretrain_points_per_s"] > 0
+    assert seal["seal_train_samples_per_s"] > 0 and seal["proxy_truth_mrays_per_s"] > 0
+    l0, l1 = seal["pretrain_loss_first_last"]
+    assert l1 < l0, "sharded pretraining does not reduce the distillation loss"
+
+
+@pytest.mark.gpu
+def test_force_dp_runs_the_seal_section_through_a_one_rank_rccl_group():
+    """`bench.py --force_dp` on one GPU: the plain step AND the Seal section (configs[3]'s code path: sharded pretraining,
+    per-rank proxy targets, fine-tuning with both tables' gradients in the all-reduce) run through a 1-rank RCCL process
+    group, collectives issued for real."""
+    r = _run(["--force_dp", "--steps", "4", "--warmup", "2", "--pretrain", "64", "--no_cpu_baseline", "--no_render",
+              "--no_long_run", "--seal_teacher_steps", "48"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["data_parallel"]["n_ranks_seen"] == 1
+    seal, dp = line["seal"], line["seal"]["data_parallel"]
+    assert dp["ranks_seen"] == 1 and dp["backend"] == "nccl"
+    assert dp["allreduce_bytes_fp16_buffer"] >= 2 * 12_239_728 * 2      # both tables' fp16 gradients travel
+    assert seal["seal_train_samples_per_s"] > 0 and seal["seal_pretrain_points_per_s"] > 0
+    l0, l1 = seal["pretrain_loss_first_last"]
+    assert l1 < l0
