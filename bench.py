@@ -850,6 +850,12 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu,
     }
     line.update(extra)
+    # the second half of BASELINE.json's metric ("render Mrays/s"), also inside `config` (a field the driver parses)
+    for k in ("render_mrays_per_s", "render_ms_per_frame"):
+        if k in extra:
+            line["config"][k] = extra[k]
+            if "roofline_render" in extra:
+                line["roofline_render"][k] = extra[k]
     if dp_info is not None:
         line["data_parallel"] = dp_info
     if dist.is_initialized():

@@ -1122,17 +1122,8 @@ __global__ void __launch_bounds__(1024) k_bin_amax(const T* __restrict__ grad, c
 #ifndef S3D_BIN3_NSUB   // XCD-private sub-buckets per (level, slice): 8x fewer same-word cursor atomics (r08: 152 -> 131 us), 1 = off
 #define S3D_BIN3_NSUB 8
 #endif
-#ifndef S3D_BIN3_MERGE   // 0: no wave-wide merge (A/B)
-#define S3D_BIN3_MERGE 1
-#endif
 #ifndef S3D_BIN3_MIN_MERGES  // fewer continuing lanes than this in a wave: no merge there (the scan costs more than it saves)
 #define S3D_BIN3_MIN_MERGES 6
-#endif
-#ifndef S3D_BIN3_LDSBAR  // 0: plain __syncthreads() (A/B)
-#define S3D_BIN3_LDSBAR 1
-#endif
-#ifndef S3D_BIN3_LEVEL_FAST  // 1: consecutive workgroups of the scatter serve different LEVELS of one chunk (cursor words of 16 levels in play)
-#define S3D_BIN3_LEVEL_FAST 0
 #endif
 #ifndef S3D_BIN3_CURSOR_STRIDE  // words between two cursors (16 = one cursor per 64-byte line)
 #define S3D_BIN3_CURSOR_STRIDE 16
@@ -1144,22 +1135,15 @@ __device__ unsigned long long s3d_prof_buf[2][16384][8];
 #else
 #define S3D_STAMP(kern, wg, k) do { } while (0)
 #endif
-#ifndef S3D_BIN3_LEAN  // 0: round 3's instruction sequences in the scatter (A/B)
-#define S3D_BIN3_LEAN 1
-#endif
 static_assert(kBinGroup == 32, "the scatter's key arithmetic shifts by 5");
 constexpr uint32_t kBin3Sub = S3D_BIN3_NSUB;
 static_assert(kBin3Sub == 1 || kBin3Sub == 2 || kBin3Sub == 4 || kBin3Sub == 8, "sub-buckets follow the XCD id");
 
 // workgroup barrier that waits for this wave's LDS traffic only (a __syncthreads() also drains the vector-memory queue)
 __device__ __forceinline__ void lds_barrier() {
-#if S3D_BIN3_LDSBAR
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-#else
-    __syncthreads();
-#endif
 }
 __device__ __forceinline__ uint32_t xcc_id() {
     uint32_t x;
@@ -1274,8 +1258,8 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
     uint2* stage = tab + smax;                                        // [P * K] {value, slice << 16 | row-in-slice}
     __shared__ uint32_t total_s, arrived, spilled_s;
 
-    const uint32_t lip = S3D_BIN3_LEVEL_FAST ? blockIdx.x : blockIdx.y;  // level inside the pass
-    const uint32_t level = level0 + lip, chunk = S3D_BIN3_LEVEL_FAST ? blockIdx.y : blockIdx.x;
+    const uint32_t lip = blockIdx.y;  // level inside the pass
+    const uint32_t level = level0 + lip, chunk = blockIdx.x;
     const uint32_t wg_lin = blockIdx.y * gridDim.x + blockIdx.x;
     (void)wg_lin;
     S3D_STAMP(0, wg_lin, 0);
@@ -1350,7 +1334,7 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
     bool cells_equal = active && pa != 0u && lane > 0;
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) cells_equal &= (dpp_take<0x138, 0xF>(pg[d]) == pg[d]);
-    bool same = S3D_BIN3_MERGE ? cells_equal : false;  // continues the run of lane - 1
+    bool same = cells_equal;  // continues the run of lane - 1
     // a wave in which (almost) nothing merges skips the scan: every active lane is its own run
     const unsigned long long smask = __ballot(same);
     if (__popcll(smask) < S3D_BIN3_MIN_MERGES) same = false;
@@ -1367,7 +1351,7 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
         // One maximum per lane instead of a test per record; at most one atomic per wave.
         // (|w| <= 1 and a run has at most 64 lanes: a wave whose gradients all lie below 1 in magnitude cannot hold a record of
         //  64 or more — one maximum and one ballot instead of 2^D x C maxima; NaN fails the comparison and takes the full test)
-        if (S3D_BIN3_LEAN == 0 || __ballot(!(gmax < 1.0f)) != 0ull) {
+        if (__ballot(!(gmax < 1.0f)) != 0ull) {
             float m = 0.0f;
 #pragma unroll
             for (uint32_t i = 0; i < K * C; i++) m = fmaxf(m, fabsf(v[i]));
@@ -1379,7 +1363,7 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
     }
     if (tail) {
         uint32_t row[K];
-        if (S3D_BIN3_LEAN && li.hashed && li.pow2) {
+        if (li.hashed && li.pow2) {
             // (level-uniform branch) hashed level of power-of-two size: the 2^D rows are XORs of 2 D terms, one mask each —
             // no select between the dense and the hashed rule, no division path
             uint32_t t0[D], t1[D];
@@ -1478,7 +1462,7 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
     uint16_t* const sk = skeys + ((size_t)lip * nchunks + chunk) * (P * K);
     uint32_t* const sv = svals + ((size_t)lip * nchunks + chunk) * (P * K);
     constexpr uint32_t UC = 4;
-    if (S3D_BIN3_LEAN && !spilled_s) {
+    if (!spilled_s) {
         // every run fits its bucket (the rule; tested once per workgroup, not per record): position = sorted index + the
         // run's bucket offset.  Whole trips of UC x P records carry no per-record range test (the trip count is uniform);
         // the remainder goes one record per lane and trip.
@@ -1502,27 +1486,6 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
             const uint32_t p = i + tab[r.y >> 16].x;
             gk[p] = (uint16_t)r.y;
             gv[p] = r.x;
-        }
-    } else if (!spilled_s) {
-        for (uint32_t i0 = threadIdx.x; i0 < total; i0 += UC * P) {
-            uint2 r[UC];
-            uint32_t gd[UC];
-#pragma unroll
-            for (uint32_t u = 0; u < UC; u++) {
-                const uint32_t i = i0 + u * P;
-                r[u] = stage[i < total ? i : 0];
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < UC; u++) gd[u] = tab[r[u].y >> 16].x;
-#pragma unroll
-            for (uint32_t u = 0; u < UC; u++) {
-                const uint32_t i = i0 + u * P;
-                if (i < total) {
-                    const uint32_t p = i + gd[u];  // (mod 2^32: gd = bucket position - run start)
-                    gk[p] = (uint16_t)r[u].y;
-                    gv[p] = r[u].x;
-                }
-            }
         }
     } else {
         for (uint32_t i0 = threadIdx.x; i0 < total; i0 += UC * P) {
@@ -1931,9 +1894,6 @@ inline uint32_t xcd_grid(uint32_t B) { return kXcds * div_up<uint32_t>(B, kFwdBl
 // points cost ~39 us on every level from 3 on, i.e. the home mapping is balanced for them and this plan costs them ~10 %; every
 // product caller presents ray-, Morton- or lattice-ordered points.)  Placement only: every point is computed by the same
 // instructions as before — results are bit-identical (tests/test_gpu_gridencoder.py runs against the oracle unchanged).
-#ifndef S3D_FWD_BALANCE  // 0: the round-1 mapping (A/B)
-#define S3D_FWD_BALANCE 1
-#endif
 inline FwdPlan balance_forward_plan(uint32_t L, const LevelScales& sc, bool balance) {
     FwdPlan p;
     memset(&p, 0, sizeof(p));
@@ -1952,7 +1912,7 @@ inline FwdPlan balance_forward_plan(uint32_t L, const LevelScales& sc, bool bala
         for (uint32_t k = 0; k < kFwdResidues; k++) if (owner[l][k] == x) return true;
         return false;
     };
-    for (int it = 0; S3D_FWD_BALANCE && balance && it < 1024; it++) {
+    for (int it = 0; balance && it < 1024; it++) {
         uint32_t hi = 0;
         for (uint32_t x = 1; x < kXcds; x++) if (load[x] > load[hi]) hi = x;
         uint32_t order[kXcds];
@@ -2170,7 +2130,7 @@ int launch_binned3(const T* grad, const float* inputs, const int32_t* offsets, T
     const uint32_t cus = device_cus();
     for (uint32_t l0 = 0; l0 < L; l0 += lay.levels_per_pass) {
         const uint32_t nl = (L - l0 < lay.levels_per_pass) ? L - l0 : lay.levels_per_pass;
-        hipLaunchKernelGGL((k_bin_scatter6<T, D, C, FIXED24, P>), S3D_BIN3_LEVEL_FAST ? dim3(nl, lay.chunks) : dim3(lay.chunks, nl), dim3(P), stage, st, grad, inputs, offsets, B, l0,
+        hipLaunchKernelGGL((k_bin_scatter6<T, D, C, FIXED24, P>), dim3(lay.chunks, nl), dim3(P), stage, st, grad, inputs, offsets, B, l0,
                            sc, hdr, cursor, ovn, ovl, lay.smax, lay.chunks, lay.cap, keys, vals, skeys, svals, gridtype, ac, interp);
         const uint32_t items = lay.smax * nl;
         hipLaunchKernelGGL((k_bin_accumulate6<T, D, C, FIXED24, P>), dim3(std::min(items, cus)), dim3(kBinAccThreads), kBinAccBytes, st,

@@ -470,9 +470,6 @@ constexpr uint32_t kWin = 1024;
 constexpr uint16_t kOcc = 0xFFFF;
 // workspace (wave path): u32 base | u32 pad[3] | u32 counts[N] | float tsamples[N * max_steps]
 
-#ifndef S3D_MARCH_SHORTCUT  // 0: always pointer doubling (A/B)
-#define S3D_MARCH_SHORTCUT 1
-#endif
 template <bool CONST_DT, bool FAST>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) k_march_count_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                          const uint8_t* __restrict__ grid, float bound, float dt_gamma,
@@ -695,7 +692,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #ifdef S3D_MARCH_PROFILE
         uint32_t dbg_vm0 = 0;
 #endif
-        if constexpr (FAST && S3D_MARCH_SHORTCUT) {
+        if constexpr (FAST) {
             uint32_t vm = 0;
 #pragma unroll
             for (uint32_t i = 0; i < kWin / 64; i++) {
@@ -1073,66 +1070,6 @@ __device__ __forceinline__ uint32_t alive_count(uint32_t bound, const int32_t* _
     if (!dev) return bound;
     const int32_t v = *dev;
     return v <= 0 ? 0u : ((uint32_t)v < bound ? (uint32_t)v : bound);
-}
-
-__global__ void __launch_bounds__(64) k_march_rays_v1(uint32_t n_alive, uint32_t n_step, const int32_t* __restrict__ rays_alive,
-                                                   const float* __restrict__ rays_t, const float* __restrict__ rays_o,
-                                                   const float* __restrict__ rays_d, float bound, float dt_gamma,
-                                                   uint32_t max_steps, uint32_t C, uint32_t H, const uint8_t* __restrict__ grid,
-                                                   const float* __restrict__ fars, float* __restrict__ xyzs,
-                                                   float* __restrict__ dirs, float* __restrict__ deltas,
-                                                   const float* __restrict__ noises, const int32_t* __restrict__ n_alive_dev,
-                                                   int32_t* __restrict__ n_rows_out, uint32_t rows_total, bool zero_unfilled) {
-    // sync-free loop: `n_alive` is the host's upper bound (launch geometry, buffer extents), *n_alive_dev the real count
-    const uint32_t n = blockIdx.x * 64 + threadIdx.x;
-    const uint32_t live = alive_count(n_alive, n_alive_dev);
-    if (n == 0 && n_rows_out) *n_rows_out = (int32_t)(live * n_step);
-    if (n >= live) {
-        // zero_unfilled: the caller's buffers are NOT pre-filled; rows behind the live rays that a consumer may read — up to the
-        // next multiple of 128 of the live rows when the count is on the device (n_valid), the whole buffer otherwise — are
-        // zeroed here (the slots a live ray does not fill are zeroed by its own lane below)
-        if (!zero_unfilled) return;
-        const uint32_t live_rows = live * n_step;
-        const uint32_t end = n_alive_dev ? min(rows_total, (live_rows + 127u) & ~127u) : rows_total;
-        for (uint32_t s = 0; s < n_step; s++) {
-            const size_t row = (size_t)n * n_step + s;
-            if (row >= end) break;
-            xyzs[row * 3] = 0.0f; xyzs[row * 3 + 1] = 0.0f; xyzs[row * 3 + 2] = 0.0f;
-            dirs[row * 3] = 0.0f; dirs[row * 3 + 1] = 0.0f; dirs[row * 3 + 2] = 0.0f;
-            deltas[row * 2] = 0.0f; deltas[row * 2 + 1] = 0.0f;
-        }
-        return;
-    }
-    const uint32_t index = (uint32_t)rays_alive[n];
-    const MarchParams p = make_params(bound, dt_gamma, max_steps, C, H, grid);
-    const Ray r = load_ray(rays_o, rays_d, index);
-    float* px = xyzs + (size_t)n * n_step * 3;
-    float* pd = dirs + (size_t)n * n_step * 3;
-    float* pl = deltas + (size_t)n * n_step * 2;
-    float t = rays_t[index];
-    const float far = fars[index];
-    t = __builtin_fmaf(clampf(t * dt_gamma, p.dt_min, p.dt_max), noises ? noises[n] : 0.0f, t);  // (no noise: t + x * 0 = t)
-    float last_t = t;
-    uint32_t step = 0;
-    while (t < far && step < n_step) {
-        float x, y, z, dt, tt;
-        if (probe(r, p, t, x, y, z, dt, tt)) {
-            px[0] = x; px[1] = y; px[2] = z;
-            pd[0] = r.dx; pd[1] = r.dy; pd[2] = r.dz;
-            t += dt;
-            pl[0] = dt; pl[1] = t - last_t;
-            last_t = t;
-            px += 3; pd += 3; pl += 2; step++;
-        } else t = skip_to(p, t, tt);
-    }
-    if (zero_unfilled) {
-        for (; step < n_step; step++) {
-            px[0] = 0.0f; px[1] = 0.0f; px[2] = 0.0f;
-            pd[0] = 0.0f; pd[1] = 0.0f; pd[2] = 0.0f;
-            pl[0] = 0.0f; pl[1] = 0.0f;
-            px += 3; pd += 3; pl += 2;
-        }
-    }
 }
 
 // ---- march_rays, second generation: two launches ----
@@ -1657,13 +1594,6 @@ S3D_EXPORT int s3d_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* 
     S3D_REQUIRE(C >= 1 && C <= 8 && H >= 1 && H <= 1024, "march_rays: unsupported cascade/grid size C=%u H=%u", C, H);
     S3D_REQUIRE(!zero_unfilled || rows_total >= n_alive * n_step, "march_rays: rows_total (the extent of xyzs / dirs / deltas) is "
                 "smaller than n_alive * n_step");
-#ifdef S3D_MARCH_RAYS_V1  // first generation (one launch, lane per ray): variant builds for A/B runs only
-    // with zero_unfilled the launch also covers the padding rows behind the last ray's chunk
-    const uint32_t lanes = zero_unfilled ? std::max(n_alive, div_up<uint32_t>(rows_total, n_step)) : n_alive;
-    hipLaunchKernelGGL(k_march_rays_v1, dim3(div_up<uint32_t>(lanes, 64)), dim3(64), 0, as_stream(stream), n_alive, n_step,
-                       rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs,
-                       deltas, noises, n_alive_dev, n_rows_out, rows_total, zero_unfilled != 0);
-#else
     S3D_REQUIRE((uint64_t)n_alive * n_step < (1ull << 32) && (zero_unfilled || rows_total >= n_alive * n_step || rows_total == 0),
                 "march_rays: n_alive * n_step does not fit the sample buffers");
     // ray slots per wave: enough waves to fill the chip (>= 4 per SIMD while the rays last), pools no larger than 256
@@ -1690,7 +1620,6 @@ S3D_EXPORT int s3d_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* 
     hipLaunchKernelGGL(k_march_rays_expand, dim3(div_up<uint32_t>(rows, 256)), b, 0, as_stream(stream), n_alive, n_step, rays_alive,
                        rays_o, rays_d, bound, dt_gamma, max_steps, C, H, xyzs, dirs, tl, n_alive_dev, rows_total,
                        zero_unfilled != 0);
-#endif
     return check_launch("march_rays");
 }
 
