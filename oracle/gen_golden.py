@@ -681,6 +681,118 @@ def gen_train():
           "samples", net.step_counter[0].tolist(), "psnr", meter.measure())
 
 
+def _grad_record_flat(module, prefix, out, n=2048):
+    """per-tensor gradient record: norm, sum, small tensors whole, larger ones at `n` seeded flat positions"""
+    for k, p in module.named_parameters():
+        g = p.grad
+        key = f"{prefix}_{k.replace('.', '_')}"
+        if g is None:
+            out[key + "_none"] = np.int64(1)
+            continue
+        g = g.detach().reshape(-1)
+        out[key + "_norm"] = np.float64(g.double().norm())
+        out[key + "_sum"] = np.float64(g.double().sum())
+        if g.numel() <= 8192:
+            out[key] = g.numpy().copy()
+        else:
+            at = torch.randint(0, g.numel(), (n,), generator=torch.Generator().manual_seed(zlib.crc32(k.encode()) % 1000))
+            out[key + "_at"] = at.numpy()
+            out[key + "_at_values"] = g[at].numpy().copy()
+
+
+TENSORF_NET = dict(resolution=[24, 28, 32], sigma_rank=[4, 5, 6], color_rank=[6, 7, 8], bound=1, cuda_ray=True, density_scale=1,
+                   min_near=0.2, density_thresh=10)
+
+
+def gen_tensorf():
+    """BASELINE configs[4]: the reference's TensoRF backbone and its trainer, EXECUTED on the CPU oracle stack.
+    tensoRF/network.py `NeRFNetwork` (VM decomposition, :13-199) with seeded factors: forward / density on seeded points,
+    `density_loss()` (:259-263), `get_params` group layout (:322-331), `upsample_model` (:266-281) and `shrink_model` (:283-318);
+    tensoRF/utils.py `Trainer.train_step` (:42-49: nerf/utils.py's step + `density_loss() * l1_reg_weight`) with every
+    parameter gradient; SealNeRF/trainer.py `freeze_mlp` (:472-488) and `pretrain_step` (:455-469) on the TensoRF backbone
+    (nothing is frozen there).  -> tests/golden/tensorf.npz"""
+    _install_reference_stack()
+    _stub_training_imports()
+    import importlib
+    trf = importlib.import_module("tensoRF.network")
+    tu = importlib.import_module("tensoRF.utils")
+    strainer = importlib.import_module("SealNeRF.trainer")
+    for m_ in (trf, tu, strainer):
+        _assert_reference(m_)
+    syn = _load_synthetic()
+    out = {}
+    trf.NeRFNetwork._self = trf.NeRFNetwork
+    torch.manual_seed(3)
+    net = trf.NeRFNetwork(**TENSORF_NET)
+    _seed_params(net)
+    out.update(param_names=np.array([k for k, _ in net.named_parameters()]),
+               param_shapes=np.array([str(tuple(p.shape)) for _, p in net.named_parameters()]))
+    groups = net.get_params(2e-2, 1e-3)
+    names = {id(p): k for k, p in net.named_parameters()}
+    out["group_lrs"] = np.array([g["lr"] for g in groups])
+    out["group_members"] = np.array([",".join(names[id(p)] for p in g["params"]) for g in groups])
+    x = _seeded((300, 3), 71, -1, 1)
+    d = torch.nn.functional.normalize(_seeded((300, 3), 72, -1, 1), dim=-1)
+    sg, cl = net(x, d)
+    dl = net.density_loss()
+    out.update(fw_x=x.numpy(), fw_d=d.numpy(), fw_sigma=sg.detach().numpy(), fw_color=cl.detach().numpy(),
+               fw_density=net.density(x)["sigma"].detach().numpy(), density_loss=np.float64(dl.item()))
+    # -- Trainer.train_step (tensoRF/utils.py:42-49) on an instance made without __init__
+    dens, bits = syn.lego_like_density_grid(seed=0)
+    net.density_grid.copy_(torch.from_numpy(dens))
+    net.density_bitfield.copy_(torch.from_numpy(bits))
+    net.mean_count = 32768
+    poses = syn.orbit_poses(1, seed=0)
+    g = torch.Generator().manual_seed(81)
+    r = syn.get_rays(poses[:1], syn.lego_intrinsics(), 800, 800, N=256, generator=g)
+    ro, rd = r["rays_o"].contiguous(), r["rays_d"].contiguous()
+    images = _seeded((1, 256, 3), 82)
+    opt = types.SimpleNamespace(color_space="srgb", patch_size=1, dt_gamma=0, max_steps=1024, T_thresh=1e-4, l1_reg_weight=1e-4)
+    me = object.__new__(tu.Trainer)
+    me.model, me.opt, me.criterion, me.error_map = net, opt, torch.nn.MSELoss(reduction="none"), None
+    me._backbone, me.log_ptr = strainer.BackBoneTypes.TensoRF, None
+    net.train()
+    torch.manual_seed(5)
+    noises = torch.rand(256)
+    torch.manual_seed(5)
+    pred, gt, loss = tu.Trainer.train_step(me, {"rays_o": ro, "rays_d": rd, "images": images.clone()})
+    net.zero_grad()
+    loss.backward()
+    out.update(ts_rays_o=ro.numpy(), ts_rays_d=rd.numpy(), ts_images=images.numpy(), ts_noises=noises.numpy(),
+               ts_loss=np.float64(loss.item()), ts_pred=pred.detach().numpy(), ts_counter=net.step_counter[0].numpy().copy(),
+               ts_l1_weight=np.float64(opt.l1_reg_weight))
+    _grad_record_flat(net, "ts_grad", out)
+    # -- Seal distillation on the TensoRF backbone: freeze_mlp freezes nothing, pretrain_step is the L1 pair
+    strainer.freeze_mlp(me, True)
+    out["pt_frozen"] = np.array([k for k, p in net.named_parameters() if not p.requires_grad])
+    P = 1024
+    pts = _seeded((P, 3), 91, -0.6, 0.6)
+    pdirs = torch.nn.functional.normalize(_seeded((P, 3), 92, -1, 1), dim=-1)
+    gsig, gcol = _seeded((P,), 93, 0, 30), _seeded((P, 3), 94)
+    me.pretraining_data = {"local": {"sigma": gsig, "color": gcol}}
+    me.pretraining_criterion = torch.nn.L1Loss()
+    net.zero_grad()
+    ploss = strainer.pretrain_step(me, {"points": pts, "dirs": pdirs, "indices": [0, P], "source_type": "local"})
+    ploss.backward()
+    out.update(pt_points=pts.numpy(), pt_dirs=pdirs.numpy(), pt_sigma=gsig.numpy(), pt_color=gcol.numpy(), pt_loss=np.float64(ploss.item()))
+    _grad_record_flat(net, "pt_grad", out)
+    strainer.freeze_mlp(me, False)
+    # -- shrink_model + upsample_model (parameter shapes, aabb, a forward on the re-sampled factors)
+    net.mean_density = 5.0
+    net.density_grid.copy_(torch.from_numpy(dens))
+    with torch.no_grad():
+        net.shrink_model()
+        out.update(shrink_aabb=net.aabb_train.numpy().copy(),
+                   shrink_shapes=np.array([str(tuple(p.shape)) for _, p in net.named_parameters()]))
+        net.upsample_model([30, 26, 22])
+        out["up_shapes"] = np.array([str(tuple(p.shape)) for _, p in net.named_parameters()])
+        xs = _seeded((200, 3), 95, -0.5, 0.5)
+        sg2, cl2 = net(xs, d[:200])
+        out.update(up_x=xs.numpy(), up_sigma=sg2.numpy(), up_color=cl2.numpy())
+    np.savez_compressed(os.path.join(OUT, "tensorf.npz"), **out)
+    print("tensorf: wrote tensorf.npz with", len(out), "arrays; train loss", loss.item(), "density_loss", dl.item(), "pretrain loss", ploss.item())
+
+
 SEAL_CASES = {
     "both": dict(boundType="both", scale=[1.2, 0.8, 1.0], transform=[[0.8, -0.6, 0, 0.3], [0.6, 0.8, 0, 0.05], [0, 0, 1, -0.1], [0, 0, 0, 1]],
                  mapSource=[0.9, 0.9, 0.9]),
@@ -830,7 +942,7 @@ def check_dropin():
     print("dropin: reference nerf/renderer.py + nerf/network.py on the build's packages reproduce wrappers.npz")
 
 
-SECTIONS = {"sh": gen_sh, "int": gen_int, "wrappers": gen_wrappers, "train": gen_train, "seal": gen_seal, "dropin": check_dropin}
+SECTIONS = {"sh": gen_sh, "int": gen_int, "wrappers": gen_wrappers, "train": gen_train, "tensorf": gen_tensorf, "seal": gen_seal, "dropin": check_dropin}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -98,6 +98,10 @@ class Trainer:
                 resync()  # ... so the optimizer's fp16 copies are re-made from the adopted values
             bump_weights_epoch()
 
+    def _param_groups(self):
+        """the optimizer's parameter groups (a backbone's trainer may use several learning rates: tensoRF/utils.py)"""
+        return self.model.get_params(self.lr)
+
     def rebuild_optimizer(self):
         """(re-)create optimizer (and, the first time, the loss scaler) over the model's CURRENT parameters — needed after
         the parameter set changes (TensoRF upsample_model, tensoRF/utils.py:137-140 / :347-352)"""
@@ -105,13 +109,13 @@ class Trainer:
         on_gpu = next(model.parameters()).is_cuda
         if self.native_optim:
             from .optim import NativeAdam, NativeGradScaler
-            self.optimizer = NativeAdam(model.get_params(lr), lr=lr, betas=(0.9, 0.99), eps=1e-15)
+            self.optimizer = NativeAdam(self._param_groups(), lr=lr, betas=(0.9, 0.99), eps=1e-15)
             if self.scaler is None:
                 self.scaler = NativeGradScaler(next(model.parameters()).device, enabled=fp16)
             if self.dist is None:
                 self.scaler.attach(self.optimizer)
         else:
-            self.optimizer = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15, fused=on_gpu,
+            self.optimizer = torch.optim.Adam(self._param_groups(), betas=(0.9, 0.99), eps=1e-15, fused=on_gpu,
                                               capturable=self._capturable)
             if self.scaler is None:
                 self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
@@ -146,10 +150,18 @@ class Trainer:
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             out = model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False,
                                defer_background=self.native_optim, **self.render_kwargs)
-            loss = render_loss(out, gt_rgb, self._expected_grad())
+            loss = self._regularized(render_loss(out, gt_rgb, self._expected_grad()))
         self._backward(loss)
         self._reduce_and_step()
         return loss.detach()
+
+    def _regularizer(self):
+        """extra loss term of a backbone's trainer (TensoRF: `density_loss() * l1_reg_weight`, tensoRF/utils.py:42-49); None: none"""
+        return None
+
+    def _regularized(self, loss):
+        reg = self._regularizer()
+        return loss if reg is None else loss + reg.to(loss.dtype)
 
     def _reduce_and_step(self):
         """gradient all-reduce (data parallelism) + optimizer step.  Native optimizer: the reduction is issued in pieces and
@@ -241,7 +253,7 @@ class GraphedTrainer(Trainer):
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             out = self.model.render(self.s_ro, self.s_rd, bg_color=1, perturb=True, force_all_rays=False,
                                     defer_background=self.native_optim, **self.render_kwargs)
-            return render_loss(out, self.s_gt, self._expected_grad())
+            return self._regularized(render_loss(out, self.s_gt, self._expected_grad()))
 
     def _body_fb(self):
         """zero grads -> render -> loss -> scaled backward"""

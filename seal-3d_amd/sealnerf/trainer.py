@@ -139,6 +139,10 @@ class SealSteps:
         return out
 
     def freeze_mlp(self, freeze=True):
+        """SealNeRF/trainer.py:472-488: the NGP backbone freezes its MLPs during local pretraining; the TensoRF backbone
+        (recognised by its factor lists) freezes NOTHING — its branch returns before touching a module"""
+        if hasattr(self.model, "sigma_mat"):
+            return
         for name in ("sigma_net", "color_net", "bg_net"):
             m = getattr(self.model, name, None)
             if m is not None:
@@ -175,7 +179,9 @@ class SealSteps:
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             out = self.model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False,
                                     defer_background=self.native_optim and not torch.is_tensor(bg_color), **self.render_kwargs)
-            loss = render_loss(out, gt_rgb, self._expected_grad(), gt_depth, self.depth_weight)
+            # (+ the backbone trainer's own term: TensoRF's L1 penalty, tensoRF/utils.py:42-49 — the student's train_step of
+            #  the reference is the backbone trainer's, SealNeRF/trainer.py:589-594)
+            loss = self._regularized(render_loss(out, gt_rgb, self._expected_grad(), gt_depth, self.depth_weight))
         return loss, out
 
     def pretrain_step(self, points, dirs, gt_sigma, gt_color, n_total=None):
@@ -317,6 +323,38 @@ class SealTrainer(SealSteps, Trainer):
         self._maybe_update_extra_state()  # (with data parallelism: occupancy state re-synchronised over the ranks)
         self.global_step += 1
         return self._seal_step(rays_o, rays_d, gt_rgb, gt_depth, bg_color)
+
+
+def _tensorf_seal_trainer():
+    from tensoRF.utils import TensoRFSteps
+
+    class SealTensoRFTrainer(SealSteps, TensoRFSteps, Trainer):
+        """the student trainer of main_SealTensoRF.py (`get_trainer(BackBoneTypes.TensoRF, CharacterTypes.Student)`,
+        SealNeRF/trainer.py:56-104): Seal's steps on top of the TensoRF trainer — two learning rates, the L1 penalty on the
+        density factors inside every fine-tuning step, nothing frozen during local pretraining (freeze_mlp)"""
+
+        def __init__(self, student, teacher, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, fp16=True, dist=None, depth_weight=1.0, **kw):
+            self._init_tensorf(lr0, lr1, l1_reg_weight, kw.pop("upsample_model_steps", ()), kw.pop("upsample_resolutions", ()))
+            Trainer.__init__(self, student, lr=lr0, fp16=fp16, dist=dist, **kw)
+            self._init_seal(teacher, lr0, depth_weight)
+
+        def train_step(self, rays_o, rays_d, gt_rgb=None, gt_depth=None, bg_color=1):
+            loss = SealTrainer.train_step(self, rays_o, rays_d, gt_rgb, gt_depth, bg_color)
+            self._maybe_upsample()
+            return loss
+    return SealTensoRFTrainer
+
+
+def get_trainer(backbone="ngp", graphed=False):
+    """SealNeRF/trainer.py:56-104 `get_trainer(backbone, CharacterTypes.Student)`: the student trainer class of a backbone
+    ("ngp": nerf/network.py or network_ff.py, "tensorf": tensoRF/network.py)"""
+    if backbone == "tensorf":
+        if graphed:
+            raise NotImplementedError("the TensoRF distillation step is launched eagerly")
+        return _tensorf_seal_trainer()
+    if backbone != "ngp":
+        raise ValueError(f"unknown backbone {backbone!r}")
+    return GraphedSealTrainer if graphed else SealTrainer
 
 
 class GraphedSealTrainer(SealSteps, GraphedTrainer):

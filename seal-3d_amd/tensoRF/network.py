@@ -234,6 +234,14 @@ class NeRFNetwork(NeRFRenderer):
     def density(self, x):
         return {"sigma": trunc_exp(self.get_sigma_feat(self._normalize(x)))}
 
+    def density_loss(self):
+        """L1 penalty on the density factors (tensoRF/network.py:259-263): sum over the three plane / line pairs of
+        mean|sigma_mat| + mean|sigma_vec|; the trainer adds it times `l1_reg_weight` (tensoRF/utils.py:42-49)"""
+        loss = 0
+        for m, v in zip(self.sigma_mat, self.sigma_vec):
+            loss = loss + torch.mean(torch.abs(m)) + torch.mean(torch.abs(v))
+        return loss
+
     def get_params(self, lr1, lr2=None):
         lr2 = lr1 if lr2 is None else lr2
         return [{"params": self.sigma_mat, "lr": lr1}, {"params": self.sigma_vec, "lr": lr1},

@@ -138,6 +138,110 @@ def test_tensorf_vm48_step_on_gpu(hip):
     assert out["image"].shape == (1, 1000, 3) and torch.isfinite(out["image"]).all()
 
 
+def _tensorf_fixture_net():
+    import os
+    import zlib
+    from conftest import GOLDEN
+    from tensoRF import network as trf
+    T = np.load(os.path.join(GOLDEN, "tensorf.npz"))
+    net = trf.NeRFNetwork(resolution=[24, 28, 32], sigma_rank=[4, 5, 6], color_rank=[6, 7, 8], bound=1, cuda_ray=True, density_scale=1,
+                          min_near=0.2, density_thresh=10)
+    for k, p in net.named_parameters():
+        g = torch.Generator().manual_seed(zlib.crc32(k.encode()) % 1000)
+        p.data.copy_(torch.rand(*p.shape, generator=g) - 0.5)
+    dens, bits = syn.lego_like_density_grid(seed=0)
+    net.density_grid.copy_(torch.from_numpy(dens))
+    net.density_bitfield.copy_(torch.from_numpy(bits))
+    return net.cuda(), T
+
+
+def test_tensorf_train_step_with_l1_term_vs_the_reference_trainer(hip, monkeypatch):
+    """tests/golden/tensorf.npz: tensoRF/utils.py `Trainer.train_step` (NGP step + `density_loss() * l1_reg_weight`) EXECUTED
+    on the reference's TensoRF network; here the build's trainer on the HIP path in fp32 (fused VM feature kernels, HIP
+    marcher / compositing / freq encoder): forward values 1e-5, loss 1e-5, every parameter gradient within 2e-4 of its
+    largest element."""
+    import raymarching.raymarching as rm
+    from tensoRF.utils import Trainer
+    net, T = _tensorf_fixture_net()
+    with torch.no_grad():
+        sg, cl = net(torch.from_numpy(T["fw_x"]).cuda(), torch.from_numpy(T["fw_d"]).cuda())
+    np.testing.assert_allclose(sg.cpu().numpy(), T["fw_sigma"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(cl.cpu().numpy(), T["fw_color"], rtol=2e-5, atol=1e-6)
+    assert abs(float(net.density_loss()) - float(T["density_loss"])) <= 1e-6 * float(T["density_loss"])
+    net.mean_count = 32768
+    tr = Trainer(net, lr0=2e-2, lr1=1e-3, l1_reg_weight=float(T["ts_l1_weight"]), fp16=False, update_extra_interval=10 ** 9)
+    tr.global_step = 1
+    net.train()
+    import nerf.renderer as rend
+    from test_gpu_golden import _CpuRandom   # the marcher's jitter drawn from the CPU generator, as the fixture's was
+    proxy = _CpuRandom()
+    monkeypatch.setattr(rm, "torch", proxy)
+    monkeypatch.setattr(rend, "torch", proxy)
+    torch.manual_seed(5)
+    seen = {}
+    monkeypatch.setattr(tr, "_reduce_and_step", lambda: seen.update(
+        {k: (p.grad if p.grad is not None else getattr(p, "_s3d_grad", None)).detach().float().clone() for k, p in net.named_parameters()}))
+    ro, rd, gt = (torch.from_numpy(T[k]).cuda() for k in ("ts_rays_o", "ts_rays_d", "ts_images"))
+    loss = tr.train_step(ro[0].contiguous(), rd[0].contiguous(), gt[0].contiguous())
+    assert np.array_equal(net.step_counter[0].cpu().numpy(), T["ts_counter"])
+    assert abs(float(loss) - float(T["ts_loss"])) <= 1e-5 * float(T["ts_loss"])
+    scale = float(tr.scaler.get_scale()) if hasattr(tr.scaler, "get_scale") else 1.0
+    for k, g in seen.items():
+        key = "ts_grad_" + k.replace(".", "_")
+        g = (g / scale).reshape(-1).cpu()
+        if key in T.files:
+            want = torch.from_numpy(T[key])
+        else:
+            want, g = torch.from_numpy(T[key + "_at_values"]), g[torch.from_numpy(T[key + "_at"])]
+        assert float((g - want).abs().max()) <= 2e-4 * float(want.abs().max()) + 1e-9, k
+
+
+def test_seal_tensorf_teacher_student_pair(hip):
+    """BASELINE configs[4] as main_SealTensoRF.py:14-17 builds it: a TensoRF teacher viewed through the bbox proxy and a
+    TensoRF student (`make_teacher` / `make_student`), the student trainer of `get_trainer("tensorf")`: local pretraining
+    (L1(sigma) + L1(colour) on the lattice points, nothing frozen on this backbone) and fine-tuning steps against the teacher's
+    proxy targets, with the L1 penalty on the density factors inside every step."""
+    from sealnerf import SealBBoxMapper, get_trainer, make_student, make_teacher
+    from tensoRF import network as trf
+    torch.manual_seed(0)
+    kw = dict(resolution=[128] * 3, bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10)
+    teacher = make_teacher(trf.NeRFNetwork, **kw).cuda()
+    student = make_student(trf.NeRFNetwork, **kw).cuda()
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    teacher.density_grid.copy_(torch.from_numpy(grid))
+    teacher.density_bitfield.copy_(torch.from_numpy(bits))
+    teacher.iter_density = 100
+    student.load_state_dict(teacher.state_dict())
+    student.iter_density = 100
+    mapper = SealBBoxMapper(BBOX)
+    teacher.init_mapper(mapper)
+    student.init_mapper(mapper)
+    tr = get_trainer("tensorf")(student, teacher, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, fp16=True, update_extra_interval=10 ** 9)
+    assert [g["lr"] for g in tr.optimizer.param_groups] == [2e-2] * 4 + [1e-3] * 2
+    n = tr.init_pretraining(batch_size=6144000, lr=0.02, local_point_step=0.01)
+    assert 80000 < n < 120000, n
+    before = {k: p.detach().clone() for k, p in student.named_parameters()}
+    tbefore = {k: p.detach().clone() for k, p in teacher.named_parameters()}
+    losses = [float(tr.pretrain_one_epoch()) for _ in range(8)]
+    assert np.isfinite(losses).all() and losses[-1] < 0.9 * losses[0], losses
+    assert all(p.requires_grad for p in student.parameters())                 # nothing frozen on the TensoRF backbone
+    assert not torch.equal(before["color_net.0.weight"], student.color_net[0].weight)   # ... so its MLP trains too
+    # the reference restores group 0's learning rate into EVERY group after pretraining (SealNeRF/trainer.py:491-504)
+    assert [g["lr"] for g in tr.optimizer.param_groups] == [2e-2] * 6
+    tr.global_step = 1
+    poses = syn.orbit_poses(1, seed=0).cuda()
+    r = syn.get_rays(poses, syn.lego_intrinsics(), 800, 800, N=4096, generator=torch.Generator().manual_seed(3))
+    ro, rd = r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous()
+    gt = tr.proxy_truth(ro, rd)
+    assert gt[0].shape == (4096, 3) and torch.isfinite(gt[0]).all() and torch.isfinite(gt[1]).all()
+    reg = float(student.density_loss()) * 1e-4
+    hist = [float(tr.train_step(ro, rd, *gt)) for _ in range(12)]
+    assert np.isfinite(hist).all() and hist[-1] < hist[0], hist
+    assert hist[0] > 0.5 * reg > 0          # the penalty is part of the step's loss
+    for k, p in teacher.named_parameters():
+        assert torch.equal(p, tbefore[k]), k
+
+
 @pytest.mark.parametrize("N,shape", [(100_000 + 37, (27, 144)), (16 * 1024, (128, 150)), (9000, (3, 128))])
 def test_tensorf_tall_linear_matches_nn_linear_under_autocast(hip, N, shape):
     """tensoRF/network.py:_TallLinear (weight gradient as a batched GEMM over 1,024-row chunks, summed in fp32) vs nn.Linear
