@@ -60,9 +60,10 @@ def parse():
     ap.add_argument("--cpu_rays", type=int, default=4096, help="rays per CPU-baseline step (BASELINE.md §3 (ii): 4,096)")
     ap.add_argument("--no_cpu_render", action="store_true", help="skip the 64x64 CPU renders (cuda_ray on and off) of BASELINE.md §3 (i)")
     ap.add_argument("--no_seal", action="store_true", help="skip the configs[2] (Seal bbox distillation) section")
+    ap.add_argument("--no_tensorf", action="store_true", help="skip the configs[4] (TensoRF VM-48 training step) section")
     ap.add_argument("--no_long_run", action="store_true", help="skip the 2 x 3,000-step convergence comparison (psnr.long_run)")
     ap.add_argument("--long_run_steps", type=int, default=3000)
-    ap.add_argument("--long_run_seeds", type=int, default=3)
+    ap.add_argument("--long_run_seeds", type=int, default=8)
     ap.add_argument("--seal_teacher_steps", type=int, default=256)
     ap.add_argument("--seal_point_step", type=float, default=0.005, help="pretraining_local_point_step (readme.md:109)")
     ap.add_argument("--seed", type=int, default=0)
@@ -471,6 +472,64 @@ def seal_section(args, dev, batches, note=lambda m: None, make_dp=None, reps=Non
     return out
 
 
+# ----------------------------------------------------------------------------- configs[4]: TensoRF VM-48
+def tensorf_section(args, dev, batches, note=lambda m: None, res=300, steps=24):
+    """BASELINE configs[4]: the TensoRF VM-48 backbone (tensoRF/network.py: density rank 16x3, colour rank 48x3, basis 144 -> 27,
+    colour MLP 150 -> 128 -> 128 -> 3) at resolution 300 on the synthetic scene, the reference's training step (tensoRF/utils.py:
+    NGP step + L1 penalty on the density factors, weight 1e-4; lr 2e-2 factors / 1e-3 networks) — eager, NativeAdam, fused VM
+    feature kernels (csrc/tensorf.hip).  `roofline`: the colour factors' backward (s3d_vm_color_backward: bound + plane + line
+    kernels and the zero fills of its buffers, HIP events on the launch stream) against its algorithmic bytes per sample:
+    3 components x (4 corners x 48 ranks x 4 B read + the same added, 2 x 48 x 4 B line values, 48 x 4 B g m written and read,
+    2 x 48 x 4 B line gradient) + 12 B position + 64 B output gradient = 8,140 B."""
+    import s3d_hip
+    from nerf import synthetic as syn
+    from tensoRF import network as trf
+    from tensoRF.utils import Trainer as TensoRFTrainer
+    torch.manual_seed(args.seed + 31)
+    net = trf.NeRFNetwork(resolution=[res] * 3, bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).to(dev)
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    net.density_grid.copy_(torch.from_numpy(grid))
+    net.density_bitfield.copy_(torch.from_numpy(bits))
+    net.iter_density = 100
+    tr = TensoRFTrainer(net, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, fp16=True, update_extra_interval=10 ** 9)
+    tr.global_step = 1
+    for k in range(4):
+        tr.train_step(*batches[k % len(batches)])
+    net.mean_count = int(net.step_counter[:4, 0].float().mean().item())  # the sample budget after the first grid update
+    net.local_step = 0
+    for k in range(4):
+        tr.train_step(*batches[k % len(batches)])
+    timers = KernelTimers(s3d_hip.VmBackend, ["color_backward", "features_backward"])
+    timers.install(lambda name, a: a[0].shape[0])
+    for k in range(4):
+        tr.train_step(*batches[k % len(batches)])
+    op = timers.summary()
+    timers.remove()
+    samples = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        tr.train_step(*batches[k % len(batches)])
+        samples.add_(net.step_counter[(net.local_step - 1) % 16, 0].long())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    n = float(samples.item()) / steps
+    out = {"workload": f"configs[4]: TensoRF VM-48 (sigma rank 16x3, colour rank 48x3), resolution {res}, {args.num_rays} rays/step, "
+                       "training step with the L1 penalty (weight 1e-4), eager, NativeAdam, fused VM kernels",
+           "ms_per_step": dt * 1e3, "samples_per_step": n, "samples_per_s": n / dt}
+    cb = op.get("color_backward")
+    if cb:
+        bytes_per = 3 * (2 * 4 * 48 * 4 + 2 * 48 * 4 + 2 * 48 * 4 + 2 * 48 * 4) + 12 + 64
+        ach = bytes_per * cb["units"] / (cb["avg_us"] * 1e-6) / 1e9
+        out["roofline"] = {"kernel": "s3d_vm_color_backward (bound + plane + line kernels, with the call's zero fills)", "bound": "hbm",
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "algorithmic_bytes_per_sample": bytes_per, "avg_us": cb["avg_us"], "rows": cb["units"], "traffic": None}
+    fb = op.get("features_backward")
+    if fb:
+        out["density_factor_backward_us"] = fb["avg_us"]
+    return out
+
+
 # ----------------------------------------------------------------------------- quality over a long run
 def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m: None, seeds=3):
     """Does the native fp16 path (fp16 table gradients, exact fixed-point sums, native Adam + loss scaling, HIP-graph replay)
@@ -523,7 +582,15 @@ def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m:
     out["delta_db_per_seed"] = [round(x, 3) for x in d]
     out["delta_db"] = float(np.mean(d))
     out["delta_db_std"] = float(np.std(d, ddof=1)) if len(d) > 1 else 0.0
+    # the paired difference's standard error and 95 % interval (Student t): per-seed differences scatter with sigma ~0.5 dB
+    # (profiles/r10_psnr_seeds*.json: 16 / 64 seeds), so ONE mean of few seeds cannot resolve 0.1 dB
+    sem = out["delta_db_std"] / math.sqrt(len(d)) if len(d) > 1 else float("nan")
+    t975 = {2: 12.706, 3: 4.303, 4: 3.182, 5: 2.776, 6: 2.571, 7: 2.447, 8: 2.365, 12: 2.201, 16: 2.131, 32: 2.040, 64: 1.998}
+    tq = t975[max(k for k in t975 if k <= max(len(d), 2))]
+    out["delta_db_sem"] = sem
+    out["delta_db_ci95"] = [out["delta_db"] - tq * sem, out["delta_db"] + tq * sem]
     out["within_0p1_db"] = bool(abs(out["delta_db"]) <= 0.1)
+    out["ci95_overlaps_0p1_db"] = bool(out["delta_db_ci95"][0] <= 0.1 and out["delta_db_ci95"][1] >= -0.1)
     out["views"] = "4 held-out 200x200 orbit cameras (seed 977), analytic box scene"
     return out
 
@@ -831,6 +898,9 @@ def main():
         del trainer
         extra["seal"] = seal_section(args, dev, batches, note if rank == 0 else (lambda m: None),
                                      make_dp=(lambda: RayShardedDP(force_collective=args.force_dp)) if dp is not None else None)
+    if world == 1 and not args.no_tensorf and args.net == "ff":
+        note("tensorf section")
+        extra["tensorf"] = tensorf_section(args, dev, batches, note)
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         note("cpu baseline")

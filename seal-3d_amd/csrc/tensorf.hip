@@ -206,43 +206,143 @@ struct VmBackward {
     const _Float16* g_out;   // [N][kVmBasisPad] (rows padded to 64 bytes: four 16-byte loads per point)
     float* d_basis;          // [Cb][rows] fp32, zero-initialised
     uint32_t Cb;
+    // bit patterns of non-negative floats (monotone as uint32; NaN patterns sort above +inf), zero-initialised by the caller:
+    // [0] max |g| (BASIS: max |g_out|), [1] max |line parameter|, [2] max |g_r m_r| (written by the plane kernel for the
+    // line kernel), [3] BASIS: max_r sum_c |W[c][r]|
+    uint32_t* bound;
+    uint32_t pts_plane, pts_line;  // sorted points per workgroup
 };
 
+// LDS float atomics retire at ~0.2 T/s on MI355X, LDS integer atomics at ~2.3 T/s (tools/ubench, csrc/gridencoder.hip): the
+// tile accumulators are 64-bit fixed point.  The scale comes from a bound on one contribution (|g| max x |line| max for the
+// plane kernel, max |g m| for the line kernel: the corner weights are <= 1) placed at 2^40: a workgroup adds at most a few
+// thousand contributions into a cell before it flushes, so nothing overflows, and a contribution 2^-20 of the bound still
+// carries 20 bits — the sums then leave as fp32 global atomics as before.  Integer adds commute: a tile's sum no longer
+// depends on the order in which its points arrive.
+constexpr int kVmFixBits = 40;
+__device__ __forceinline__ long long vm_to_fixed(float v, float scale) {
+    const float t = v * scale;                                  // (power-of-two scale: exact)
+    const float hi = truncf(t * 5.9604644775390625e-08f);       // t / 2^24, |hi| < 2^17
+    const float lo = __builtin_fmaf(-hi, 16777216.0f, t);       // exact remainder, |lo| < 2^24
+    return (long long)(int)hi * 16777216ll + (long long)(int)lo;
+}
+__device__ __forceinline__ void vm_lds_add(long long* a, long long q) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(a), (unsigned long long)q);
+}
+// scale for a bound given as two (three) factors' bit patterns; returns false when there is nothing to add (a zero factor)
+// and sets `poison` when a factor is not finite (the gradient is then non-finite as the float sums would be)
+__device__ __forceinline__ bool vm_scale(float bound, float& scale, float& inv, bool& poison) {
+    poison = !(bound <= 3.402823466e38f);
+    if (poison || !(bound > 0.0f)) return false;
+    int e;
+    (void)frexpf(bound, &e);  // bound < 2^e
+    e = e < -80 ? -80 : e;    // (keeps the scale finite for vanishing bounds)
+    scale = ldexpf(1.0f, kVmFixBits - e);
+    inv = ldexpf(1.0f, e - kVmFixBits);
+    return true;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t nan_aware_bits(float m, bool bad) { return bad ? 0x7fc00000u : __float_as_uint(m); }
+
+// bounds of one backward call: [0] over the gradient tensor (fp32 `g`, n_g values, or fp16 `g16`, n_g16 values), [1] over the
+// three line factors, [3] over the columns of basis_mat
+__global__ void __launch_bounds__(256) k_vm_bound(const float* __restrict__ g, size_t n_g, const _Float16* __restrict__ g16, size_t n_g16,
+                                                   VmFactors f, const _Float16* __restrict__ basis, uint32_t Cb, uint32_t rows,
+                                                   uint32_t* __restrict__ bound) {
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
+    float m = 0.0f;
+    bool bad = false;
+    if (g) {
+        const float4* g4 = reinterpret_cast<const float4*>(g);
+        for (size_t k = tid; k < n_g / 4; k += nt) {
+            const float4 v = g4[k];
+            const float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+            bad |= !(fabsf(v.x) <= 3.4e38f) || !(fabsf(v.y) <= 3.4e38f) || !(fabsf(v.z) <= 3.4e38f) || !(fabsf(v.w) <= 3.4e38f);
+            m = fmaxf(m, a);
+        }
+        for (size_t k = (n_g / 4) * 4 + tid; k < n_g; k += nt) { bad |= !(fabsf(g[k]) <= 3.4e38f); m = fmaxf(m, fabsf(g[k])); }
+    }
+    if (g16) {
+        typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+        const half8v* g8 = reinterpret_cast<const half8v*>(g16);
+        for (size_t k = tid; k < n_g16 / 8; k += nt) {
+            const half8v v = g8[k];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const float a = fabsf((float)v[j]); bad |= !(a <= 65504.0f); m = fmaxf(m, a); }
+        }
+    }
+    m = wave_max(m);
+    bad = __ballot(bad) != 0ull;
+    if ((threadIdx.x & 63) == 0 && (m > 0.0f || bad)) atomicMax(bound + 0, nan_aware_bits(m, bad));
+    // line factors
+    float lm = 0.0f;
+    bool lbad = false;
+#pragma unroll
+    for (uint32_t i = 0; i < 3; i++) {
+        const size_t n = (size_t)f.rank[i] * f.Dn[i];
+        for (size_t k = tid; k < n; k += nt) { const float a = fabsf(f.line[i][k]); lbad |= !(a <= 3.4e38f); lm = fmaxf(lm, a); }
+    }
+    lm = wave_max(lm);
+    lbad = __ballot(lbad) != 0ull;
+    if ((threadIdx.x & 63) == 0 && (lm > 0.0f || lbad)) atomicMax(bound + 1, nan_aware_bits(lm, lbad));
+    if (basis && blockIdx.x == 0) {
+        float cm = 0.0f;
+        bool cbad = false;
+        for (uint32_t r = threadIdx.x; r < rows; r += 256) {
+            float s = 0.0f;
+            for (uint32_t c = 0; c < Cb; c++) s += fabsf((float)basis[(size_t)c * rows + r]);
+            cbad |= !(s <= 3.4e38f);
+            cm = fmaxf(cm, s);
+        }
+        cm = wave_max(cm);
+        cbad = __ballot(cbad) != 0ull;
+        if ((threadIdx.x & 63) == 0 && (cm > 0.0f || cbad)) atomicMax(bound + 3, nan_aware_bits(cm, cbad));
+    }
+}
+
+// One workgroup = `pts_plane` consecutive positions of plane i's sorted point order (a hot tile is shared by as many
+// workgroups as its points fill, a stretch of sparse tiles is walked by one): per tile segment the 9x9 cells' plane values
+// and a cleared accumulator live in LDS, lanes = rank channels, eight waves = eight points (RP = 64) in flight.
 // RP = lanes per point (16 or 64 >= rank); a wave handles 64 / RP points per trip
 // BASIS (colour features behind basis_mat, REDUCE = false): lane r derives its product gradient from the Linear's output
 // gradient, g_r = sum_c W[c][row0 + r] * g_out[n][c] (its column of W lives in registers, the point's Cb gradients are the
 // same for the whole 64-lane group), and accumulates basis_mat's own gradient dW[c][row0 + r] += g_out[n][c] * prod_r in
 // registers — flushed with one atomic per (c, r) and workgroup.  Every (point, component) is visited by exactly one lane group
 // of this kernel, so the three components' launches cover dW once.
+constexpr uint32_t kVmBwdThreads = 512;
 template <int RP, bool REDUCE, bool BASIS = false>
-__global__ void __launch_bounds__(256) k_vm_plane_backward(const float* __restrict__ x, uint32_t N, VmFactors f, VmBackward b) {
+__global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float* __restrict__ x, uint32_t N, VmFactors f, VmBackward b) {
     static_assert(!BASIS || (RP == 64 && !REDUCE), "basis_mat sits behind the 48-rank colour products");
-    extern __shared__ float vm_smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem_raw[];
     const uint32_t i = blockIdx.y;
     const int W = (int)f.W[i], H = (int)f.H[i], Dn = (int)f.Dn[i];
     const uint32_t R = f.rank[i];
     const int tiles_x = (W + kVmTile - 1) / kVmTile, tiles_y = (H + kVmTile - 1) / kVmTile;
-    const int t = (int)blockIdx.x;
-    if (t >= tiles_x * tiles_y) return;
+    const int ntiles = tiles_x * tiles_y;
     const int32_t* st = b.start + (size_t)i * b.n_bounds;
-    // (real scenes concentrate the samples in few tiles: a tile's range is shared by gridDim.z workgroups)
-    const uint32_t lo = (uint32_t)st[t], hi = (uint32_t)st[t + 1];
-    const uint32_t begin = lo + (uint32_t)(((uint64_t)(hi - lo) * blockIdx.z) / gridDim.z);
-    const uint32_t end = lo + (uint32_t)(((uint64_t)(hi - lo) * (blockIdx.z + 1)) / gridDim.z);
-    if (begin >= end) return;  // (empty: nothing to add to the zero-initialised gradient)
-    const int cx0 = (t % tiles_x) * kVmTile, cy0 = (t / tiles_x) * kVmTile;
-    float* pv = vm_smem;                          // [81][R] plane values
-    float* acc = vm_smem + kVmTileCells * R;      // [81][R] gradient accumulator
+    const uint32_t valid_end = (uint32_t)st[ntiles];  // (points without a contribution sort behind every tile)
+    const uint32_t begin = blockIdx.x * b.pts_plane;
+    if (begin >= valid_end) return;
+    const uint32_t end = begin + b.pts_plane < valid_end ? begin + b.pts_plane : valid_end;
+    float scale = 1.0f, inv = 1.0f;
+    bool poison;
+    float bound = __uint_as_float(b.bound[0]) * __uint_as_float(b.bound[1]);
+    if constexpr (BASIS) bound *= __uint_as_float(b.bound[3]);
+    if (!vm_scale(bound, scale, inv, poison)) {
+        // (nothing to add: gm stays zero.  A non-finite factor poisons the plane gradient like the float sums would)
+        if (poison && blockIdx.x == 0 && threadIdx.x == 0) b.d_plane[i][0] = NAN;
+        return;
+    }
+    long long* acc = reinterpret_cast<long long*>(vm_smem_raw);                   // [81][R] gradient accumulator (fixed point)
+    float* pv = reinterpret_cast<float*>(acc + kVmTileCells * R);                 // [81][R] plane values
     const float* P = f.plane[i];
     const size_t plane_stride = (size_t)H * W;
-    for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += 256) {
-        const uint32_t r = e / kVmTileCells, c = e % kVmTileCells;  // cell fastest: 9-float row segments of one channel
-        const int cy = cy0 + (int)(c / (kVmTile + 1)), cx = cx0 + (int)(c % (kVmTile + 1));
-        pv[c * R + r] = (cx < W && cy < H) ? P[r * plane_stride + (size_t)cy * W + cx] : 0.0f;
-        acc[c * R + r] = 0.0f;
-    }
-    __syncthreads();
     constexpr uint32_t PPW = 64 / RP;  // points per wave trip
+    constexpr uint32_t NWV = kVmBwdThreads / 64;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t sub = lane / RP, r = lane % RP;
     const int32_t* perm = b.perm + (size_t)i * N;
@@ -255,105 +355,171 @@ __global__ void __launch_bounds__(256) k_vm_plane_backward(const float* __restri
             dw[c] = 0.0f;
         }
     }
-    for (uint32_t k = begin + wave * PPW + sub; k < end; k += 4 * PPW) {
-        uint32_t n = (uint32_t)perm[k];
-        if constexpr (BASIS) n = __builtin_amdgcn_readfirstlane(n);  // (RP = 64: one point per wave trip)
-        const VmPoint q = vm_locate(x, n, f, i);
-        if (r >= R) continue;
-        float g;
-        float go[BASIS ? kVmBasisPad : 1];
-        if constexpr (BASIS) {
-            typedef _Float16 half8v __attribute__((ext_vector_type(8)));
-            const half8v* gp = reinterpret_cast<const half8v*>(b.g_out + (size_t)n * kVmBasisPad);
-            g = 0.0f;
+    for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += kVmBwdThreads) acc[e] = 0ll;
+    // tile of the first position: the last t with st[t] <= begin (empty tiles repeat their neighbour's start)
+    int t = 0;
+    {
+        int lo = 0, hi = ntiles;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((uint32_t)st[mid] <= begin) lo = mid; else hi = mid;
+        }
+        t = lo;
+    }
+    float gm_max = 0.0f;
+    uint32_t pos = begin;
+    while (pos < end) {
+        while ((uint32_t)st[t + 1] <= pos) t++;
+        const uint32_t seg_end = (uint32_t)st[t + 1] < end ? (uint32_t)st[t + 1] : end;
+        const int cx0 = (t % tiles_x) * kVmTile, cy0 = (t / tiles_x) * kVmTile;
+        for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += kVmBwdThreads) {
+            const uint32_t rr = e / kVmTileCells, c = e % kVmTileCells;  // cell fastest: 9-float row segments of one channel
+            const int cy = cy0 + (int)(c / (kVmTile + 1)), cx = cx0 + (int)(c % (kVmTile + 1));
+            pv[c * R + rr] = (cx < W && cy < H) ? P[rr * plane_stride + (size_t)cy * W + cx] : 0.0f;
+        }
+        __syncthreads();  // plane values in place; accumulator clear (start of the kernel / previous flush)
+        for (uint32_t k = pos + wave * PPW + sub; k < seg_end; k += NWV * PPW) {
+            uint32_t n = (uint32_t)perm[k];
+            if constexpr (BASIS) n = __builtin_amdgcn_readfirstlane(n);  // (RP = 64: one point per wave trip)
+            const VmPoint q = vm_locate(x, n, f, i);
+            if (r >= R) continue;
+            float g;
+            float go[BASIS ? kVmBasisPad : 1];
+            if constexpr (BASIS) {
+                typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+                const half8v* gp = reinterpret_cast<const half8v*>(b.g_out + (size_t)n * kVmBasisPad);
+                g = 0.0f;
 #pragma unroll
-            for (uint32_t q = 0; q < kVmBasisPad / 8; q++) {
-                const half8v h = gp[q];
+                for (uint32_t qq = 0; qq < kVmBasisPad / 8; qq++) {
+                    const half8v h = gp[qq];
 #pragma unroll
-                for (uint32_t j = 0; j < 8; j++) {
-                    const uint32_t c = 8 * q + j;
-                    go[c] = (float)h[j];  // (columns behind Cb are the caller's zero padding)
-                    g = __builtin_fmaf(go[c], wcol[c], g);
+                    for (uint32_t j = 0; j < 8; j++) {
+                        const uint32_t c = 8 * qq + j;
+                        go[c] = (float)h[j];  // (columns behind Cb are the caller's zero padding)
+                        g = __builtin_fmaf(go[c], wcol[c], g);
+                    }
                 }
+            } else {
+                g = REDUCE ? b.g[n] : b.g[(size_t)n * b.rows + f.row0[i] + r];
             }
-        } else {
-            g = REDUCE ? b.g[n] : b.g[(size_t)n * b.rows + f.row0[i] + r];
-        }
-        const bool bz0 = q.z0 >= 0 && q.z0 < Dn, bz1 = q.z0 + 1 >= 0 && q.z0 + 1 < Dn;
-        float l = 0.0f;
-        if (bz0) l += Lq[(size_t)r * Dn + q.z0] * q.lz0;
-        if (bz1) l += Lq[(size_t)r * Dn + q.z0 + 1] * q.lz1;
-        const int lx = q.x0 - cx0, ly = q.y0 - cy0;  // nw corner inside the tile's 9x9 window: -1 .. 7
-        const bool bx0 = q.x0 >= 0 && q.x0 < W, bx1 = q.x0 + 1 >= 0 && q.x0 + 1 < W;
-        const bool by0 = q.y0 >= 0 && q.y0 < H, by1 = q.y0 + 1 >= 0 && q.y0 + 1 < H;
-        const int c_nw = ly * (kVmTile + 1) + lx;
-        const float gl = g * l;
-        float m = 0.0f;
-        if (bx0 && by0) { m += pv[c_nw * R + r] * q.nw; atomicAdd(&acc[c_nw * R + r], gl * q.nw); }
-        if (bx1 && by0) { m += pv[(c_nw + 1) * R + r] * q.ne; atomicAdd(&acc[(c_nw + 1) * R + r], gl * q.ne); }
-        if (bx0 && by1) { m += pv[(c_nw + kVmTile + 1) * R + r] * q.sw; atomicAdd(&acc[(c_nw + kVmTile + 1) * R + r], gl * q.sw); }
-        if (bx1 && by1) { m += pv[(c_nw + kVmTile + 2) * R + r] * q.se; atomicAdd(&acc[(c_nw + kVmTile + 2) * R + r], gl * q.se); }
-        b.gm[(size_t)n * b.rows + f.row0[i] + r] = g * m;
-        if constexpr (BASIS) {
-            const float prod = (float)(_Float16)(m * l);  // (the Linear's fp16 input, as in the forward)
+            const bool bz0 = q.z0 >= 0 && q.z0 < Dn, bz1 = q.z0 + 1 >= 0 && q.z0 + 1 < Dn;
+            float l = 0.0f;
+            if (bz0) l += Lq[(size_t)r * Dn + q.z0] * q.lz0;
+            if (bz1) l += Lq[(size_t)r * Dn + q.z0 + 1] * q.lz1;
+            const int lx = q.x0 - cx0, ly = q.y0 - cy0;  // nw corner inside the tile's 9x9 window: -1 .. 7
+            const bool bx0 = q.x0 >= 0 && q.x0 < W, bx1 = q.x0 + 1 >= 0 && q.x0 + 1 < W;
+            const bool by0 = q.y0 >= 0 && q.y0 < H, by1 = q.y0 + 1 >= 0 && q.y0 + 1 < H;
+            const int c_nw = ly * (kVmTile + 1) + lx;
+            const float gl = g * l;
+            float m = 0.0f;
+            if (bx0 && by0) { m += pv[c_nw * R + r] * q.nw; vm_lds_add(&acc[c_nw * R + r], vm_to_fixed(gl * q.nw, scale)); }
+            if (bx1 && by0) { m += pv[(c_nw + 1) * R + r] * q.ne; vm_lds_add(&acc[(c_nw + 1) * R + r], vm_to_fixed(gl * q.ne, scale)); }
+            if (bx0 && by1) { m += pv[(c_nw + kVmTile + 1) * R + r] * q.sw; vm_lds_add(&acc[(c_nw + kVmTile + 1) * R + r], vm_to_fixed(gl * q.sw, scale)); }
+            if (bx1 && by1) { m += pv[(c_nw + kVmTile + 2) * R + r] * q.se; vm_lds_add(&acc[(c_nw + kVmTile + 2) * R + r], vm_to_fixed(gl * q.se, scale)); }
+            const float gmv = g * m;
+            b.gm[(size_t)n * b.rows + f.row0[i] + r] = gmv;
+            gm_max = fmaxf(gm_max, fabsf(gmv));
+            if constexpr (BASIS) {
+                const float prod = (float)(_Float16)(m * l);  // (the Linear's fp16 input, as in the forward)
 #pragma unroll
-            for (uint32_t c = 0; c < kVmBasisPad; c++) dw[c] = __builtin_fmaf(go[c], prod, dw[c]);
+                for (uint32_t c = 0; c < kVmBasisPad; c++) dw[c] = __builtin_fmaf(go[c], prod, dw[c]);
+            }
         }
+        __syncthreads();
+        float* dP = b.d_plane[i];
+        for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += kVmBwdThreads) {
+            const uint32_t rr = e / kVmTileCells, c = e % kVmTileCells;
+            const int cy = cy0 + (int)(c / (kVmTile + 1)), cx = cx0 + (int)(c % (kVmTile + 1));
+            const long long qv = acc[c * R + rr];
+            if (qv != 0ll) {
+                acc[c * R + rr] = 0ll;  // cleared behind the read: the next segment starts from zeros
+                if (cx < W && cy < H) atomicAdd(&dP[rr * plane_stride + (size_t)cy * W + cx], (float)qv * inv);
+            }
+        }
+        pos = seg_end;
+        // (the next segment's plane values are written before its barrier; the flush only touches `acc`)
     }
+    gm_max = wave_max(gm_max);
+    if (lane == 0 && gm_max > 0.0f) atomicMax(b.bound + 2, __float_as_uint(gm_max));
     if constexpr (BASIS) {
-        if (r < R) {
+        // basis_mat's gradient: the eight waves' register sums are added in LDS first (fixed order), then ONE global atomic per
+        // (c, r) and workgroup — per wave it was eight times as many, and global atomics retire at 21 G/s chip-wide
+        float* red = reinterpret_cast<float*>(vm_smem_raw);  // [NWV][16][64] (the host sizes the allocation for it)
+        constexpr uint32_t HC = kVmBasisPad / 2;
 #pragma unroll
-            for (uint32_t c = 0; c < kVmBasisPad; c++)
-                if (c < b.Cb && dw[c] != 0.0f) atomicAdd(&b.d_basis[(size_t)c * b.rows + f.row0[i] + r], dw[c]);
+        for (uint32_t half = 0; half < 2; half++) {
+            __syncthreads();  // accumulator / previous half no longer read
+#pragma unroll
+            for (uint32_t c = 0; c < HC; c++) red[(wave * HC + c) * 64 + lane] = dw[half * HC + c];
+            __syncthreads();
+            for (uint32_t e = threadIdx.x; e < HC * 64; e += kVmBwdThreads) {
+                const uint32_t c = half * HC + e / 64, rr = e % 64;
+                float sum = 0.0f;
+#pragma unroll
+                for (uint32_t w = 0; w < NWV; w++) sum += red[(w * HC + e / 64) * 64 + rr];
+                if (rr < R && c < b.Cb && sum != 0.0f) atomicAdd(&b.d_basis[(size_t)c * b.rows + f.row0[i] + rr], sum);
+            }
         }
-    }
-    __syncthreads();
-    float* dP = b.d_plane[i];
-    for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += 256) {
-        const uint32_t rr = e / kVmTileCells, c = e % kVmTileCells;
-        const int cy = cy0 + (int)(c / (kVmTile + 1)), cx = cx0 + (int)(c % (kVmTile + 1));
-        const float v = acc[c * R + rr];
-        if (v != 0.0f && cx < W && cy < H) atomicAdd(&dP[rr * plane_stride + (size_t)cy * W + cx], v);
     }
 }
 
 template <int RP>
-__global__ void __launch_bounds__(256) k_vm_line_backward(const float* __restrict__ x, uint32_t N, VmFactors f, VmBackward b) {
-    extern __shared__ float vm_smem[];
+__global__ void __launch_bounds__(kVmBwdThreads) k_vm_line_backward(const float* __restrict__ x, uint32_t N, VmFactors f, VmBackward b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem_raw[];
     const uint32_t i = blockIdx.y;
     const int Dn = (int)f.Dn[i];
     const uint32_t R = f.rank[i];
-    const int t = (int)blockIdx.x;
-    if (t * kVmZChunk >= Dn) return;
+    const int nchunks = (Dn + kVmZChunk - 1) / kVmZChunk;
     const int32_t* st = b.start + (size_t)(3 + i) * b.n_bounds;
-    // a chunk holds ~N / 5 points: its range is shared by gridDim.z workgroups, each with its own LDS accumulator
-    const uint32_t lo = (uint32_t)st[t], hi = (uint32_t)st[t + 1];
-    const uint32_t begin = lo + (uint32_t)(((uint64_t)(hi - lo) * blockIdx.z) / gridDim.z);
-    const uint32_t end = lo + (uint32_t)(((uint64_t)(hi - lo) * (blockIdx.z + 1)) / gridDim.z);
-    if (begin >= end) return;
-    const int zb = t * kVmZChunk;
-    float* acc = vm_smem;  // [65][R]
-    for (uint32_t e = threadIdx.x; e < (kVmZChunk + 1) * R; e += 256) acc[e] = 0.0f;
-    __syncthreads();
+    const uint32_t valid_end = (uint32_t)st[nchunks];
+    const uint32_t begin = blockIdx.x * b.pts_line;
+    if (begin >= valid_end) return;
+    const uint32_t end = begin + b.pts_line < valid_end ? begin + b.pts_line : valid_end;
+    float scale = 1.0f, inv = 1.0f;
+    bool poison;
+    if (!vm_scale(__uint_as_float(b.bound[2]), scale, inv, poison)) return;  // (max |g m| is finite whenever the plane pass ran)
+    long long* acc = reinterpret_cast<long long*>(vm_smem_raw);  // [65][R]
+    for (uint32_t e = threadIdx.x; e < (kVmZChunk + 1) * R; e += kVmBwdThreads) acc[e] = 0ll;
     constexpr uint32_t PPW = 64 / RP;
+    constexpr uint32_t NWV = kVmBwdThreads / 64;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t sub = lane / RP, r = lane % RP;
     const int32_t* perm = b.perm + (size_t)(3 + i) * N;
-    for (uint32_t k = begin + wave * PPW + sub; k < end; k += 4 * PPW) {
-        const uint32_t n = (uint32_t)perm[k];
-        const VmPoint q = vm_locate(x, n, f, i);
-        if (r >= R) continue;
-        const float gm = b.gm[(size_t)n * b.rows + f.row0[i] + r];
-        const int lz = q.z0 - zb;  // -1 .. 63
-        if (q.z0 >= 0 && q.z0 < Dn) atomicAdd(&acc[lz * R + r], gm * q.lz0);
-        if (q.z0 + 1 >= 0 && q.z0 + 1 < Dn) atomicAdd(&acc[(lz + 1) * R + r], gm * q.lz1);
+    int t = 0;
+    {
+        int lo = 0, hi = nchunks;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((uint32_t)st[mid] <= begin) lo = mid; else hi = mid;
+        }
+        t = lo;
     }
-    __syncthreads();
-    float* dL = b.d_line[i];
-    for (uint32_t e = threadIdx.x; e < (kVmZChunk + 1) * R; e += 256) {
-        const uint32_t z = e / R, rr = e % R;
-        const float v = acc[e];
-        if (v != 0.0f && zb + (int)z < Dn) atomicAdd(&dL[(size_t)rr * Dn + zb + z], v);
+    uint32_t pos = begin;
+    while (pos < end) {
+        while ((uint32_t)st[t + 1] <= pos) t++;
+        const uint32_t seg_end = (uint32_t)st[t + 1] < end ? (uint32_t)st[t + 1] : end;
+        const int zb = t * kVmZChunk;
+        __syncthreads();  // accumulator clear (start of the kernel / previous flush)
+        for (uint32_t k = pos + wave * PPW + sub; k < seg_end; k += NWV * PPW) {
+            const uint32_t n = (uint32_t)perm[k];
+            const VmPoint q = vm_locate(x, n, f, i);
+            if (r >= R) continue;
+            const float gm = b.gm[(size_t)n * b.rows + f.row0[i] + r];
+            const int lz = q.z0 - zb;  // -1 .. 63
+            if (q.z0 >= 0 && q.z0 < Dn) vm_lds_add(&acc[lz * R + r], vm_to_fixed(gm * q.lz0, scale));
+            if (q.z0 + 1 >= 0 && q.z0 + 1 < Dn) vm_lds_add(&acc[(lz + 1) * R + r], vm_to_fixed(gm * q.lz1, scale));
+        }
+        __syncthreads();
+        float* dL = b.d_line[i];
+        for (uint32_t e = threadIdx.x; e < (kVmZChunk + 1) * R; e += kVmBwdThreads) {
+            const uint32_t z = e / R, rr = e % R;
+            const long long qv = acc[e];
+            if (qv != 0ll) {
+                acc[e] = 0ll;
+                if (zb + (int)z < Dn) atomicAdd(&dL[(size_t)rr * Dn + zb + z], (float)qv * inv);
+            }
+        }
+        pos = seg_end;
     }
 }
 
@@ -407,12 +573,28 @@ S3D_EXPORT int s3d_vm_backward_keys(const float* x, uint32_t N, const uint32_t* 
     return check_launch("vm_backward_keys");
 }
 
+// launch geometry shared by the two backward entry points: points per workgroup so that the sorted order fills the chip a
+// few times over (eight waves x 64 / RP points in flight per workgroup), LDS = fixed-point accumulator + plane values
+static void vm_backward_geometry(VmBackward& b, uint32_t N, uint32_t max_rank, bool basis, dim3& gp, dim3& gl, size_t& smem_p,
+                                 size_t& smem_l) {
+    const uint32_t rp = max_rank <= 16 ? 16u : 64u;
+    b.pts_plane = rp == 16 ? 2048u : 1024u;
+    b.pts_line = rp == 16 ? 4096u : 2048u;
+    gp = dim3(div_up<uint32_t>(N, b.pts_plane), 3);
+    gl = dim3(div_up<uint32_t>(N, b.pts_line), 3);
+    smem_p = (size_t)kVmTileCells * max_rank * (sizeof(long long) + sizeof(float));
+    if (basis && smem_p < (size_t)(kVmBwdThreads / 64) * (kVmBasisPad / 2) * 64 * sizeof(float))
+        smem_p = (size_t)(kVmBwdThreads / 64) * (kVmBasisPad / 2) * 64 * sizeof(float);
+    smem_l = (size_t)(kVmZChunk + 1) * max_rank * sizeof(long long);
+}
+
 S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                                         const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
                                         const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
-                                        float* const* grad_planes, float* const* grad_lines, s3d_stream_t stream) {
+                                        float* const* grad_planes, float* const* grad_lines, uint32_t* bound_words,
+                                        s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
-    S3D_REQUIRE(x && planes && lines && rank && resolution && grad && perm && start && gm && grad_planes && grad_lines,
+    S3D_REQUIRE(x && planes && lines && rank && resolution && grad && perm && start && gm && grad_planes && grad_lines && bound_words,
                 "vm_features_backward: null pointer");
     VmFactors f;
     VmBackward b;
@@ -436,12 +618,15 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
     b.start = start;
     b.n_bounds = n_bounds;
     b.basis = nullptr; b.g_out = nullptr; b.d_basis = nullptr; b.Cb = 0;
+    b.bound = bound_words;
     hipStream_t st = as_stream(stream);
-    const size_t smem_p = (size_t)2 * kVmTileCells * max_rank * sizeof(float), smem_l = (size_t)(kVmZChunk + 1) * max_rank * sizeof(float);
-    // split factors: planes so that a tile holding every point still spreads over the chip; lines: few chunks, many points
-    // (marched samples are concentrated: at the Lego scene a handful of tiles hold most points; empty shares exit at once)
-    const uint32_t split_p = 8, split_l = 128;
-    const dim3 gp(max_tiles, 3, split_p), gl(max_chunks, 3, split_l), block(256);
+    dim3 gp, gl;
+    size_t smem_p, smem_l;
+    vm_backward_geometry(b, N, max_rank, false, gp, gl, smem_p, smem_l);
+    const dim3 block(kVmBwdThreads);
+    const size_t n_g = reduce ? (size_t)N : (size_t)N * b.rows;
+    hipLaunchKernelGGL(k_vm_bound, dim3(stream_grid(n_g / 4 + 1, 256)), dim3(256), 0, st, grad, n_g, (const _Float16*)nullptr, (size_t)0, f,
+                       (const _Float16*)nullptr, 0u, b.rows, bound_words);
     if (max_rank <= 16) {
         if (reduce) hipLaunchKernelGGL((k_vm_plane_backward<16, true>), gp, block, smem_p, st, x, N, f, b);
         else hipLaunchKernelGGL((k_vm_plane_backward<16, false>), gp, block, smem_p, st, x, N, f, b);
@@ -474,10 +659,10 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
                                      const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
                                      const uint16_t* grad_out, const int32_t* perm, const int32_t* start, uint32_t n_bounds,
                                      float* gm, float* const* grad_planes, float* const* grad_lines, float* grad_basis,
-                                     s3d_stream_t stream) {
+                                     uint32_t* bound_words, s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && planes && lines && rank && resolution && basis && grad_out && perm && start && gm && grad_planes && grad_lines &&
-                grad_basis, "vm_color_backward: null pointer");
+                grad_basis && bound_words, "vm_color_backward: null pointer");
     VmFactors f;
     VmBackward b;
     if (int rc = fill_factors(f, planes, lines, rank, resolution, b.rows)) return rc;
@@ -505,10 +690,15 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
     b.g_out = (const _Float16*)grad_out;
     b.d_basis = grad_basis;
     b.Cb = basis_rows;
+    b.bound = bound_words;
     hipStream_t st = as_stream(stream);
-    const size_t smem_p = (size_t)2 * kVmTileCells * max_rank * sizeof(float), smem_l = (size_t)(kVmZChunk + 1) * max_rank * sizeof(float);
-    const uint32_t split_p = 8, split_l = 128;  // (as s3d_vm_features_backward)
-    const dim3 gp(max_tiles, 3, split_p), gl(max_chunks, 3, split_l), block(256);
+    dim3 gp, gl;
+    size_t smem_p, smem_l;
+    vm_backward_geometry(b, N, 64, true, gp, gl, smem_p, smem_l);  // (the BASIS kernel: 64 lanes per point whatever the rank)
+    const dim3 block(kVmBwdThreads);
+    const size_t n_g16 = (size_t)N * kVmBasisPad;
+    hipLaunchKernelGGL(k_vm_bound, dim3(stream_grid(n_g16 / 8 + 1, 256)), dim3(256), 0, st, (const float*)nullptr, (size_t)0,
+                       (const _Float16*)grad_out, n_g16, f, (const _Float16*)basis, basis_rows, b.rows, bound_words);
     hipLaunchKernelGGL((k_vm_plane_backward<64, false, true>), gp, block, smem_p, st, x, N, f, b);
     hipLaunchKernelGGL((k_vm_line_backward<64>), gl, block, smem_l, st, x, N, f, b);
     return check_launch("vm_color_backward");

@@ -995,7 +995,7 @@ class VmBackend:
                                               ptr3(*[t.data_ptr() for t in lines]), rank, res, C.c_int(int(bool(reduce))),
                                               _p(grad), _p(perm), _p(start), _u(n_bounds), _p(gm),
                                               ptr3(*[t.data_ptr() for t in g_planes]), ptr3(*[t.data_ptr() for t in g_lines]),
-                                              _stream()), "vm_features_backward")
+                                              _p(torch.zeros(4, dtype=torch.int32, device=dev)), _stream()), "vm_features_backward")
         return g_planes, g_lines
 
     @staticmethod
@@ -1037,5 +1037,6 @@ class VmBackend:
                                            ptr3(*[t.data_ptr() for t in lines]), u3(*[int(t.shape[1]) for t in planes]),
                                            u3(*[int(r) for r in resolution]), _p(basis), _u(basis.shape[0]), _p(grad_out),
                                            _p(perm), _p(start), _u(n_bounds), _p(gm), ptr3(*[t.data_ptr() for t in g_planes]),
-                                           ptr3(*[t.data_ptr() for t in g_lines]), _p(g_basis), _stream()), "vm_color_backward")
+                                           ptr3(*[t.data_ptr() for t in g_lines]), _p(g_basis),
+                                           _p(torch.zeros(4, dtype=torch.int32, device=dev)), _stream()), "vm_color_backward")
         return g_planes, g_lines, g_basis

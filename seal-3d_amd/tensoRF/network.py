@@ -144,6 +144,25 @@ def _linear(layer, x):
     return layer(x)
 
 
+class _MeanAbsSum(torch.autograd.Function):
+    """sum_i mean|t_i| over a list of tensors (the L1 penalty of tensoRF/network.py:259-263) with multi-tensor launches: one
+    `_foreach_norm` forward, `_foreach_sign` + two `_foreach_mul_` backward — the op-by-op expression costs ~10 launches per
+    tensor and direction (abs, mean, their backward, the scalar products), 0.6 ms of a 3 ms step at resolution 300."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        ctx.save_for_backward(*tensors)
+        norms = torch._foreach_norm([t.detach() for t in tensors], 1)
+        return torch.stack([n / t.numel() for n, t in zip(norms, tensors)]).sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        signs = torch._foreach_sign([t.detach() for t in ctx.saved_tensors])
+        torch._foreach_mul_(signs, g.to(signs[0].dtype))
+        torch._foreach_mul_(signs, [1.0 / t.numel() for t in ctx.saved_tensors])
+        return tuple(signs)
+
+
 class NeRFNetwork(NeRFRenderer):
     def __init__(self, resolution=(128, 128, 128), sigma_rank=(16, 16, 16), color_rank=(48, 48, 48), color_feat_dim=27,
                  num_layers=3, hidden_dim=128, bound=1, **kwargs):
@@ -237,10 +256,14 @@ class NeRFNetwork(NeRFRenderer):
     def density_loss(self):
         """L1 penalty on the density factors (tensoRF/network.py:259-263): sum over the three plane / line pairs of
         mean|sigma_mat| + mean|sigma_vec|; the trainer adds it times `l1_reg_weight` (tensoRF/utils.py:42-49)"""
+        if self.fused_l1:
+            return _MeanAbsSum.apply(*self.sigma_mat, *self.sigma_vec)
         loss = 0
         for m, v in zip(self.sigma_mat, self.sigma_vec):
             loss = loss + torch.mean(torch.abs(m)) + torch.mean(torch.abs(v))
         return loss
+
+    fused_l1 = True  # tests / A-B runs: False = the reference's op-by-op expression
 
     def get_params(self, lr1, lr2=None):
         lr2 = lr1 if lr2 is None else lr2

@@ -322,22 +322,27 @@ def test_sync_free_inference_loop_renders_the_same_frame(hip, net_kind):
 
 def test_long_run_native_fp16_path_converges_like_fp32_adam(hip):
     """3,000 steps of configs[1]'s network from the same initial weights on the same 3.1 M-ray pool: the native path (fp16
-    gradient hand-over, exact fixed-point table sums, native Adam + loss scaling, HIP-graph replay) against torch.optim.Adam
-    on fp32 `.grad`s + torch GradScaler (eager).  PSNR on four held-out 200x200 views of the analytic scene: both above
-    28 dB, and the MEANS over three initialisations within 0.4 dB of each other.  The two trajectories are chaotic twins
-    (different rounding, different RNG consumption under capture): per seed they land -0.30 / +0.17 / +0.06 dB apart
-    (profiles/r09_bench_default.json: mean -0.02 dB, sample sigma 0.25 dB), so the mean of three is known to +-0.14 dB and a 0.1 dB
-    assertion would fail every other run for identical algorithms; bench.py reports mean, spread and `within_0p1_db`."""
+    gradient hand-over, exact fixed-point table sums, native Adam + loss scaling, HIP-graph replay, learning-rate schedule read
+    from a device word) against torch.optim.Adam on fp32 `.grad`s + torch GradScaler (eager).  PSNR on four held-out 200x200
+    views of the analytic scene.  The two trajectories are chaotic twins (different rounding, different RNG consumption under
+    capture): over 16 / 64 initialisations (profiles/r10_psnr_seeds16.json, r10_psnr_seeds64.json, tools/psnr_seeds.py) each
+    arrangement's PSNR scatters with sigma 0.3 - 0.5 dB and the paired difference with sigma_d ~ 0.5 dB around a mean that is
+    zero within its standard error.  Asserted here: both arrangements above 28 dB, and the mean difference over EIGHT seeds
+    within 3 sigma_d / sqrt(8) = 0.55 dB (a 0.1 dB assertion on 8 seeds would fail most runs of identical algorithms:
+    its standard error is 0.18 dB; bench.py reports mean, standard error and the 95 % interval)."""
     import argparse
     import bench
     from nerf import synthetic as syn
     dev = torch.device("cuda")
     _, bits = syn.lego_like_density_grid(seed=0)
     args = argparse.Namespace(num_rays=4096, seed=0)
-    out = bench.long_run_quality(args, dev, hip.RaymarchingBackend, torch.from_numpy(bits).to(dev), syn.lego_like_boxes(0), steps=3000)
+    out = bench.long_run_quality(args, dev, hip.RaymarchingBackend, torch.from_numpy(bits).to(dev), syn.lego_like_boxes(0), steps=3000,
+                                 seeds=8)
     a, b = out["native_fp16_graph"]["psnr_db"], out["torch_adam_fp32_eager"]["psnr_db"]
     assert a >= 28.0 and b >= 28.0, out
-    assert out["seeds"] >= 3 and abs(out["delta_db"]) <= 0.4, out
+    sigma_d = 0.52
+    assert out["seeds"] == 8 and abs(out["delta_db"]) <= 3 * sigma_d / 8 ** 0.5, out
+    assert out["delta_db_ci95"][0] < out["delta_db"] < out["delta_db_ci95"][1]
 
 
 _DP2_SCRIPT = r'''
