@@ -8,6 +8,7 @@
 // torch's grid sampler: index = ((c + 1) / 2) * (size - 1), corner weights as products of the distances to the opposite
 // corner, corners accumulated in the order nw, ne, sw, se, out-of-range corners skipped.
 #include "s3d_common.hpp"
+#include <algorithm>
 
 namespace s3d {
 namespace {
@@ -161,9 +162,17 @@ struct VmPoint {
     bool valid;
 };
 
+struct VmXyz { float u, v, w; };  // a point's coordinates along the plane's two axes and the line's axis
+__device__ __forceinline__ VmXyz vm_load_xyz(const float* __restrict__ x, uint32_t n, const VmFactors& f, uint32_t i) {
+    return VmXyz{x[(size_t)n * 3 + f.cu[i]], x[(size_t)n * 3 + f.cv[i]], x[(size_t)n * 3 + f.cw[i]]};
+}
+__device__ __forceinline__ VmPoint vm_locate_xyz(const VmXyz& p, const VmFactors& f, uint32_t i);
 __device__ __forceinline__ VmPoint vm_locate(const float* __restrict__ x, uint32_t n, const VmFactors& f, uint32_t i) {
+    return vm_locate_xyz(vm_load_xyz(x, n, f, i), f, i);
+}
+__device__ __forceinline__ VmPoint vm_locate_xyz(const VmXyz& p, const VmFactors& f, uint32_t i) {
     VmPoint q;
-    const float px = x[(size_t)n * 3 + f.cu[i]], py = x[(size_t)n * 3 + f.cv[i]], pz = x[(size_t)n * 3 + f.cw[i]];
+    const float px = p.u, py = p.v, pz = p.w;
     const float ix = unnormalize(px, f.W[i]), iy = unnormalize(py, f.H[i]), iz = unnormalize(pz, f.Dn[i]);
     const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
     const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
@@ -275,9 +284,13 @@ __global__ void __launch_bounds__(256) k_vm_bound(const float* __restrict__ g, s
             for (int j = 0; j < 8; j++) { const float a = fabsf((float)v[j]); bad |= !(a <= 65504.0f); m = fmaxf(m, a); }
         }
     }
+    // (one atomic per BLOCK: thousands of waves on one word serialise — 46 us per call with one per wave)
+    __shared__ uint32_t blk[3];
+    if (threadIdx.x < 3) blk[threadIdx.x] = 0u;
+    __syncthreads();
     m = wave_max(m);
     bad = __ballot(bad) != 0ull;
-    if ((threadIdx.x & 63) == 0 && (m > 0.0f || bad)) atomicMax(bound + 0, nan_aware_bits(m, bad));
+    if ((threadIdx.x & 63) == 0 && (m > 0.0f || bad)) atomicMax(&blk[0], nan_aware_bits(m, bad));
     // line factors
     float lm = 0.0f;
     bool lbad = false;
@@ -288,7 +301,10 @@ __global__ void __launch_bounds__(256) k_vm_bound(const float* __restrict__ g, s
     }
     lm = wave_max(lm);
     lbad = __ballot(lbad) != 0ull;
-    if ((threadIdx.x & 63) == 0 && (lm > 0.0f || lbad)) atomicMax(bound + 1, nan_aware_bits(lm, lbad));
+    if ((threadIdx.x & 63) == 0 && (lm > 0.0f || lbad)) atomicMax(&blk[1], nan_aware_bits(lm, lbad));
+    __syncthreads();
+    if (threadIdx.x == 0 && blk[0]) atomicMax(bound + 0, blk[0]);
+    if (threadIdx.x == 1 && blk[1]) atomicMax(bound + 1, blk[1]);
     if (basis && blockIdx.x == 0) {
         float cm = 0.0f;
         bool cbad = false;
@@ -378,10 +394,22 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
             pv[c * R + rr] = (cx < W && cy < H) ? P[rr * plane_stride + (size_t)cy * W + cx] : 0.0f;
         }
         __syncthreads();  // plane values in place; accumulator clear (start of the kernel / previous flush)
-        for (uint32_t k = pos + wave * PPW + sub; k < seg_end; k += NWV * PPW) {
-            uint32_t n = (uint32_t)perm[k];
+        // A trip is a chain of dependent loads (sorted position -> point id -> coordinates -> line values / gradients): the id
+        // of the trip after next and the coordinates of the next trip are requested before this trip's arithmetic — with one
+        // chain per trip a workgroup's 64 - 128 trips of ~2.5 us each WERE the kernel's time
+        constexpr uint32_t STEP = NWV * PPW;
+        const uint32_t k0 = pos + wave * PPW + sub;
+        uint32_t n_nx = k0 < seg_end ? (uint32_t)perm[k0] : 0u;
+        uint32_t n_nx2 = k0 + STEP < seg_end ? (uint32_t)perm[k0 + STEP] : 0u;
+        VmXyz p_nx = k0 < seg_end ? vm_load_xyz(x, n_nx, f, i) : VmXyz{0.0f, 0.0f, 0.0f};
+        for (uint32_t k = k0; k < seg_end; k += STEP) {
+            uint32_t n = n_nx;
+            const VmXyz p_cur = p_nx;
+            n_nx = n_nx2;
+            if (k + STEP < seg_end) p_nx = vm_load_xyz(x, n_nx, f, i);
+            if (k + 2 * STEP < seg_end) n_nx2 = (uint32_t)perm[k + 2 * STEP];
             if constexpr (BASIS) n = __builtin_amdgcn_readfirstlane(n);  // (RP = 64: one point per wave trip)
-            const VmPoint q = vm_locate(x, n, f, i);
+            const VmPoint q = vm_locate_xyz(p_cur, f, i);
             if (r >= R) continue;
             float g;
             float go[BASIS ? kVmBasisPad : 1];
@@ -500,11 +528,23 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_line_backward(const float*
         const uint32_t seg_end = (uint32_t)st[t + 1] < end ? (uint32_t)st[t + 1] : end;
         const int zb = t * kVmZChunk;
         __syncthreads();  // accumulator clear (start of the kernel / previous flush)
-        for (uint32_t k = pos + wave * PPW + sub; k < seg_end; k += NWV * PPW) {
-            const uint32_t n = (uint32_t)perm[k];
-            const VmPoint q = vm_locate(x, n, f, i);
+        constexpr uint32_t STEP = NWV * PPW;  // (ids two trips, coordinates and g m one trip ahead: see the plane kernel)
+        const uint32_t k0 = pos + wave * PPW + sub;
+        uint32_t n_nx = k0 < seg_end ? (uint32_t)perm[k0] : 0u;
+        uint32_t n_nx2 = k0 + STEP < seg_end ? (uint32_t)perm[k0 + STEP] : 0u;
+        VmXyz p_nx = k0 < seg_end ? vm_load_xyz(x, n_nx, f, i) : VmXyz{0.0f, 0.0f, 0.0f};
+        float gm_nx = (k0 < seg_end && r < R) ? b.gm[(size_t)n_nx * b.rows + f.row0[i] + r] : 0.0f;
+        for (uint32_t k = k0; k < seg_end; k += STEP) {
+            const VmXyz p_cur = p_nx;
+            const float gm = gm_nx;
+            n_nx = n_nx2;
+            if (k + STEP < seg_end) {
+                p_nx = vm_load_xyz(x, n_nx, f, i);
+                if (r < R) gm_nx = b.gm[(size_t)n_nx * b.rows + f.row0[i] + r];
+            }
+            if (k + 2 * STEP < seg_end) n_nx2 = (uint32_t)perm[k + 2 * STEP];
+            const VmPoint q = vm_locate_xyz(p_cur, f, i);
             if (r >= R) continue;
-            const float gm = b.gm[(size_t)n * b.rows + f.row0[i] + r];
             const int lz = q.z0 - zb;  // -1 .. 63
             if (q.z0 >= 0 && q.z0 < Dn) vm_lds_add(&acc[lz * R + r], vm_to_fixed(gm * q.lz0, scale));
             if (q.z0 + 1 >= 0 && q.z0 + 1 < Dn) vm_lds_add(&acc[(lz + 1) * R + r], vm_to_fixed(gm * q.lz1, scale));
@@ -578,8 +618,8 @@ S3D_EXPORT int s3d_vm_backward_keys(const float* x, uint32_t N, const uint32_t* 
 static void vm_backward_geometry(VmBackward& b, uint32_t N, uint32_t max_rank, bool basis, dim3& gp, dim3& gl, size_t& smem_p,
                                  size_t& smem_l) {
     const uint32_t rp = max_rank <= 16 ? 16u : 64u;
-    b.pts_plane = rp == 16 ? 2048u : 1024u;
-    b.pts_line = rp == 16 ? 4096u : 2048u;
+    b.pts_plane = rp == 16 ? 1024u : 512u;   // (32 / 64 trips per wave: the sorted order fills the chip about twice)
+    b.pts_line = rp == 16 ? 2048u : 1024u;
     gp = dim3(div_up<uint32_t>(N, b.pts_plane), 3);
     gl = dim3(div_up<uint32_t>(N, b.pts_line), 3);
     smem_p = (size_t)kVmTileCells * max_rank * (sizeof(long long) + sizeof(float));
@@ -625,7 +665,7 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
     vm_backward_geometry(b, N, max_rank, false, gp, gl, smem_p, smem_l);
     const dim3 block(kVmBwdThreads);
     const size_t n_g = reduce ? (size_t)N : (size_t)N * b.rows;
-    hipLaunchKernelGGL(k_vm_bound, dim3(stream_grid(n_g / 4 + 1, 256)), dim3(256), 0, st, grad, n_g, (const _Float16*)nullptr, (size_t)0, f,
+    hipLaunchKernelGGL(k_vm_bound, dim3(std::min<uint32_t>(stream_grid(n_g / 4 + 1, 256), 512u)), dim3(256), 0, st, grad, n_g, (const _Float16*)nullptr, (size_t)0, f,
                        (const _Float16*)nullptr, 0u, b.rows, bound_words);
     if (max_rank <= 16) {
         if (reduce) hipLaunchKernelGGL((k_vm_plane_backward<16, true>), gp, block, smem_p, st, x, N, f, b);
@@ -697,7 +737,7 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
     vm_backward_geometry(b, N, 64, true, gp, gl, smem_p, smem_l);  // (the BASIS kernel: 64 lanes per point whatever the rank)
     const dim3 block(kVmBwdThreads);
     const size_t n_g16 = (size_t)N * kVmBasisPad;
-    hipLaunchKernelGGL(k_vm_bound, dim3(stream_grid(n_g16 / 8 + 1, 256)), dim3(256), 0, st, (const float*)nullptr, (size_t)0,
+    hipLaunchKernelGGL(k_vm_bound, dim3(std::min<uint32_t>(stream_grid(n_g16 / 8 + 1, 256), 512u)), dim3(256), 0, st, (const float*)nullptr, (size_t)0,
                        (const _Float16*)grad_out, n_g16, f, (const _Float16*)basis, basis_rows, b.rows, bound_words);
     hipLaunchKernelGGL((k_vm_plane_backward<64, false, true>), gp, block, smem_p, st, x, N, f, b);
     hipLaunchKernelGGL((k_vm_line_backward<64>), gl, block, smem_l, st, x, N, f, b);
