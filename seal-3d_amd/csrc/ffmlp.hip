@@ -751,12 +751,21 @@ __device__ __forceinline__ uint32_t tile_elem(uint32_t native, uint32_t F, uint3
 }
 
 
+// partial weight-gradient matrices of the stored-activation path: [PAD][PAD] fp32 per (layer, workgroup)
+template <int W> struct WgradGeom { static constexpr uint32_t PAD = W > 64 ? 128u : kWgradPad; };
+inline uint32_t wgrad_pad(uint32_t W) { return W > 64 ? 128u : kWgradPad; }
+inline uint32_t wgrad_blocks(uint32_t W);
+
 template <int W>
 __global__ void __launch_bounds__(256) k_ffmlp_wgrad(WgradPlan plan, uint32_t B, float* __restrict__ partial,
                                                      const int32_t* __restrict__ n_valid) {
     constexpr uint32_t MAXB = (W + 31) / 32;  // 32-blocks per side
-    __shared__ __attribute__((aligned(16))) _Float16 tiles[4][2][32 * W];
-    __shared__ float red[kWgradPad * kWgradPad];
+    constexpr uint32_t PAD = WgradGeom<W>::PAD;
+    // the four waves' operand tiles; the workgroup's reduction plane takes their place after the last tile (W = 128: 64 KiB each)
+    constexpr uint32_t kTileBytes = 4 * 2 * 32 * W * sizeof(_Float16), kRedBytes = PAD * PAD * sizeof(float);
+    __shared__ __attribute__((aligned(16))) unsigned char wg_smem[kTileBytes > kRedBytes ? kTileBytes : kRedBytes];
+    _Float16 (*tiles)[2][32 * W] = reinterpret_cast<_Float16 (*)[2][32 * W]>(wg_smem);
+    float* red = reinterpret_cast<float*>(wg_smem);
 
     const WgradLayer L = plan.layer[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -806,7 +815,8 @@ __global__ void __launch_bounds__(256) k_ffmlp_wgrad(WgradPlan plan, uint32_t B,
         __syncthreads();
     }
     // reduce the four waves through LDS, then one coalesced partial per block
-    for (uint32_t i = threadIdx.x; i < kWgradPad * kWgradPad; i += 256) red[i] = 0.0f;
+    // (the loop above ends with a barrier — or never ran: the tiles are dead)
+    for (uint32_t i = threadIdx.x; i < PAD * PAD; i += 256) red[i] = 0.0f;
     __syncthreads();
     for (uint32_t w = 0; w < 4; w++) {
         if (wave == w) {
@@ -817,13 +827,13 @@ __global__ void __launch_bounds__(256) k_ffmlp_wgrad(WgradPlan plan, uint32_t B,
 #pragma unroll
                     for (uint32_t r = 0; r < 16; r++) {
                         const uint32_t o = mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, i = ni * 32 + fl;
-                        red[o * kWgradPad + i] += acc[mo][ni][r];
+                        red[o * PAD + i] += acc[mo][ni][r];
                     }
         }
         __syncthreads();
     }
-    float* dst = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kWgradPad * kWgradPad;
-    for (uint32_t i = threadIdx.x; i < kWgradPad * kWgradPad; i += 256) dst[i] = red[i];
+    float* dst = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * PAD * PAD;
+    for (uint32_t i = threadIdx.x; i < PAD * PAD; i += 256) dst[i] = red[i];
 }
 
 // Eight lanes per matrix element: each sums every 8th workgroup partial with independent accumulators (a single chain over
@@ -845,14 +855,15 @@ struct ReduceJobs {
 __global__ void k_ffmlp_wgrad_reduce_jobs(ReduceJobs jobs);
 
 __global__ void k_ffmlp_wgrad_reduce(WgradPlan plan, uint32_t nblk, const float* __restrict__ partial,
-                                     _Float16* __restrict__ grad_weights, uint32_t accumulate, float* __restrict__ found_inf) {
+                                     _Float16* __restrict__ grad_weights, uint32_t accumulate, float* __restrict__ found_inf,
+                                     uint32_t pad) {
     const WgradLayer L = plan.layer[blockIdx.y];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t e = t / kReduceSplit, part = t % kReduceSplit;
     const bool live = e < L.Fo * L.Fi;
     const uint32_t o = live ? e / L.Fi : 0, i = live ? e - o * L.Fi : 0;
-    const float* p = partial + (size_t)blockIdx.y * nblk * kWgradPad * kWgradPad + o * kWgradPad + i;
-    constexpr size_t kPlane = (size_t)kWgradPad * kWgradPad;
+    const size_t kPlane = (size_t)pad * pad;
+    const float* p = partial + (size_t)blockIdx.y * nblk * kPlane + o * pad + i;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     if (live) {
         uint32_t b = part;
@@ -1566,9 +1577,10 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
 }
 
 constexpr uint32_t kWgradBlocks = 256;
+inline uint32_t wgrad_blocks(uint32_t W) { return W > 64 ? 64u : kWgradBlocks; }  // (W = 128: 64 KiB partial planes)
 }  // namespace
 // csrc/ffmlp_generic.hip: the shapes the register-resident kernels do not cover (hidden 16 / 128 / 256, input_dim > 64)
-bool ffmlp_native_shape(uint32_t in_dim, uint32_t W);
+bool ffmlp_native_shape(uint32_t in_dim, uint32_t W, uint32_t n_layers = 2);
 int ffmlp_generic_forward(const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t in_dim, uint32_t W, uint32_t n_layers, uint32_t act,
                           uint32_t out_act, _Float16* acts, bool training, _Float16* out, hipStream_t st);
 int ffmlp_generic_backward(const _Float16* grad, const _Float16* X, const _Float16* Wt, const _Float16* fwd, uint32_t B, uint32_t in_dim,
@@ -1611,7 +1623,11 @@ int launch_forward(const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t i
     // (measured at 2.6e5 points: 768 workgroups 11.8 / 14.6 us for the 2- / 3-matrix net, 1024: 12.7 / 16.2, 2048: 16.9 / 21.6,
     //  512: 12.2 / 14.7 — every workgroup stages all weights once, three per CU still hide the tile latencies)
     if (grid > 768) grid = 768;
-#define S3D_FWD_K(TRAIN, A, O, K0) hipLaunchKernelGGL((k_ffmlp_forward<W, TRAIN, A, O, K0>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out, in_layout, t_n_valid, t_rgb_out, t_mid_fwd)
+    const bool big = smem > 64 * 1024;  // (W = 128: the dynamic allocation has to be announced; one workgroup per CU)
+    if (big && grid > 256) grid = 256;
+#define S3D_FWD_K(TRAIN, A, O, K0) do { \
+        if (big) S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_forward<W, TRAIN, A, O, K0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((k_ffmlp_forward<W, TRAIN, A, O, K0>), dim3(grid), dim3(256), smem, st, X, Wt, B, in_dim, out_dim, n_layers, act, out_act, fwd, out, in_layout, t_n_valid, t_rgb_out, t_mid_fwd); } while (0)
 #define S3D_FWD(TRAIN, A, O) do { if (in_dim == 32) S3D_FWD_K(TRAIN, A, O, 2); else if (in_dim == 64) S3D_FWD_K(TRAIN, A, O, 4); else S3D_FWD_K(TRAIN, A, O, 0); } while (0)
     const bool fast = act == ACT_RELU && out_act == ACT_NONE;  // the networks of the hot path; anything else: run-time switch
     if (fwd) { if (fast) S3D_FWD(true, ACT_RELU, ACT_NONE); else S3D_FWD(true, -1, -1); }
@@ -1632,6 +1648,11 @@ int launch_backward(const _Float16* grad, const _Float16* X, const _Float16* Wt,
     const uint32_t ntiles = B / 32;
     uint32_t grid = div_up<uint32_t>(ntiles, 4);
     if (grid > 1024) grid = 1024;
+    if (smem > 64 * 1024) {  // (W = 128: one workgroup per CU holds every matrix's fragments)
+        if (grid > 256) grid = 256;
+        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_dgrad<W, ACT_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_dgrad<W, -1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    }
     if (act == ACT_RELU)
         hipLaunchKernelGGL((k_ffmlp_dgrad<W, ACT_RELU>), dim3(grid), dim3(256), smem, st, grad, Wt, fwd, B, in_dim, out_dim, n_layers,
                            act, bwd, grad_inputs, t_n_valid);
@@ -1653,10 +1674,11 @@ int launch_backward(const _Float16* grad, const _Float16* X, const _Float16* Wt,
                                       (uint32_t)(W * in_dim + NH * W * W)};
     // the last layer's matrix is [out_pad=16, W]; rows >= out_dim receive the (zero) gradient of the padding
     uint32_t nblk = div_up<uint32_t>(ntiles, 4);
-    if (nblk > kWgradBlocks) nblk = kWgradBlocks;
+    if (nblk > wgrad_blocks(W)) nblk = wgrad_blocks(W);
     hipLaunchKernelGGL((k_ffmlp_wgrad<W>), dim3(nblk, plan.n), dim3(256), 0, st, plan, B, partial, t_n_valid);
-    hipLaunchKernelGGL(k_ffmlp_wgrad_reduce, dim3(div_up<uint32_t>(W * W * kReduceSplit, 256), plan.n), dim3(256), 0, st, plan, nblk,
-                       (const float*)partial, grad_weights, accumulate, t_found_inf);
+    const uint32_t widest = (uint32_t)W > in_dim ? (uint32_t)W : in_dim;
+    hipLaunchKernelGGL(k_ffmlp_wgrad_reduce, dim3(div_up<uint32_t>(W * widest * kReduceSplit, 256), plan.n), dim3(256), 0, st, plan, nblk,
+                       (const float*)partial, grad_weights, accumulate, t_found_inf, wgrad_pad(W));
     return check_launch("ffmlp_backward");
 }
 
@@ -1715,7 +1737,7 @@ int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Floa
     plan.layer[NH + 1] = WgradLayer{nullptr, nullptr, 0u, 0u, 16u, (uint32_t)W, (uint32_t)(W * in_dim + NH * W * W)};
     if (accumulate != 2u)  // (2: the caller finishes several networks with one s3d_ffmlp_wgrad_reduce_pair)
         hipLaunchKernelGGL(k_ffmlp_wgrad_reduce, dim3(div_up<uint32_t>(W * W * kReduceSplit, 256), plan.n), dim3(256), 0, st, plan, nblk,
-                           (const float*)partial, grad_weights, accumulate, t_found_inf);
+                           (const float*)partial, grad_weights, accumulate, t_found_inf, kWgradPad);
     return check_launch("ffmlp_backward (fused)");
 }
 
@@ -1777,7 +1799,7 @@ S3D_EXPORT int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights
     S3D_REQUIRE(output_dim == 16, "ffmlp_forward: the output must be padded to 16 columns (ffmlp.py:117)");
     const _Float16* X = (const _Float16*)inputs; const _Float16* Wt = (const _Float16*)weights;
     _Float16* fb = (_Float16*)forward_buffer; _Float16* o = (_Float16*)outputs;
-    if (!ffmlp_native_shape(input_dim, hidden_dim)) {
+    if (!ffmlp_native_shape(input_dim, hidden_dim, num_layers)) {
         S3D_REQUIRE(input_layout == 0 && !n_valid && !rgb_head && !mid_color_in && outputs,
                     "ffmlp_forward: hidden_dim %u / input_dim %u take the layer-by-layer path, which implements the reference's "
                     "interface only (row-major inputs, no heads, no n_valid)", hidden_dim, input_dim);
@@ -1787,6 +1809,10 @@ S3D_EXPORT int s3d_ffmlp_forward(const uint16_t* inputs, const uint16_t* weights
                                      fb ? fb : t_generic_scratch, fb != nullptr, o, as_stream(stream));
     }
     if (hidden_dim == 64) return launch_forward<64>(X, Wt, B, input_dim, output_dim, num_layers, activation, output_activation, fb, o, (uint32_t)input_layout, as_stream(stream));
+    if (hidden_dim == 128) {
+        S3D_REQUIRE(!rgb_head && !mid_color_in, "ffmlp_forward: the NGP heads belong to the 64-wide networks");
+        return launch_forward<128>(X, Wt, B, input_dim, output_dim, num_layers, activation, output_activation, fb, o, (uint32_t)input_layout, as_stream(stream));
+    }
     return launch_forward<32>(X, Wt, B, input_dim, output_dim, num_layers, activation, output_activation, fb, o, (uint32_t)input_layout, as_stream(stream));
 }
 
@@ -1898,8 +1924,8 @@ S3D_EXPORT int s3d_ffmlp_wgrad_reduce_pair(const void* workspace_a, uint32_t B_a
 
 S3D_EXPORT size_t s3d_ffmlp_backward_workspace_size(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                                                     uint32_t num_layers) {
-    (void)input_dim; (void)output_dim; (void)hidden_dim;
-    return (size_t)(num_layers + 1) * kWgradBlocks * kWgradPad * kWgradPad * sizeof(float);
+    (void)input_dim; (void)output_dim;
+    return (size_t)(num_layers + 1) * wgrad_blocks(hidden_dim) * wgrad_pad(hidden_dim) * wgrad_pad(hidden_dim) * sizeof(float);
 }
 
 S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights,
@@ -1940,7 +1966,7 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
     S3D_REQUIRE(workspace && workspace_bytes >= s3d_ffmlp_backward_workspace_size(input_dim, output_dim, hidden_dim, num_layers),
                 "ffmlp_backward: workspace too small");
     _Float16* gi = calc_grad_inputs ? (_Float16*)grad_inputs : nullptr;
-    if (!ffmlp_native_shape(input_dim, hidden_dim)) {
+    if (!ffmlp_native_shape(input_dim, hidden_dim, num_layers)) {
         S3D_REQUIRE(forward_buffer && backward_buffer && grad && input_layout == 0 && !n_valid && !grad_rgb && !mid_grad_color_in,
                     "ffmlp_backward: hidden_dim %u / input_dim %u take the layer-by-layer path: forward_buffer and backward_buffer "
                     "[n, B, W], row-major inputs, no heads, no n_valid", hidden_dim, input_dim);
@@ -1963,6 +1989,10 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
         return launch_backward<64>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights,
                                    (const _Float16*)forward_buffer, B, input_dim, output_dim, num_layers, activation,
                                    (_Float16*)backward_buffer, gi, (_Float16*)grad_weights, (float*)workspace, accumulate, as_stream(stream));
+    if (hidden_dim == 128)
+        return launch_backward<128>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights,
+                                    (const _Float16*)forward_buffer, B, input_dim, output_dim, num_layers, activation,
+                                    (_Float16*)backward_buffer, gi, (_Float16*)grad_weights, (float*)workspace, accumulate, as_stream(stream));
     return launch_backward<32>((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights,
                                (const _Float16*)forward_buffer, B, input_dim, output_dim, num_layers, activation,
                                (_Float16*)backward_buffer, gi, (_Float16*)grad_weights, (float*)workspace, accumulate, as_stream(stream));

@@ -82,7 +82,16 @@ inline uint32_t ew_grid(size_t n) { return stream_grid(n, 256); }
 
 }  // namespace
 
-bool ffmlp_native_shape(uint32_t in_dim, uint32_t W) { return (W == 32 || W == 64) && in_dim <= 64; }
+// Shapes of the register-resident MFMA kernels (csrc/ffmlp.hip).  W = 128: forward / data-gradient / weight-gradient kernels of
+// the stored-activation path (its three weight matrices' fragments need 136 KB of the CU's 160 KB of LDS at most); the
+// re-computing fused backward stays at W <= 64 (a 128 x 128 fp32 weight-gradient accumulator is 256 registers per lane).
+bool ffmlp_native_shape(uint32_t in_dim, uint32_t W, uint32_t n_layers) {
+    if (W == 32 || W == 64) return in_dim <= 64;
+    if (W != 128 || in_dim > 128 || n_layers < 2) return false;
+    const uint32_t NH = n_layers - 1;
+    const uint32_t fwd_frags = 4 * (in_dim / 16) + NH * 32 + 8, bwd_frags = 4 + NH * 32 + ((in_dim + 31) / 32) * 8;
+    return fwd_frags <= 144 && bwd_frags <= 144;  // 1 KiB each
+}
 
 // forward: X [B, in] -> out [B, 16]; `acts` = forward_buffer [n, B, W] (training) or inference_buffer [2, B, W]
 int ffmlp_generic_forward(const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t in_dim, uint32_t W, uint32_t n_layers,

@@ -15,12 +15,16 @@ NETS = [  # in, W, n_layers, out(real), activation
     (64, 64, 2, 8, 0),    # in == W
     (32, 32, 4, 16, 0),   # W = 32, deeper
     (48, 64, 2, 16, 3),   # sigmoid, in = 48
-    # the widths ffmlp.cu:40-44 dispatches beside 32 / 64, and an input wider than 64: layer-by-layer path (csrc/ffmlp_generic.hip)
-    (32, 16, 2, 16, 0),
+    # W = 128: the MFMA kernels of the stored-activation path (forward / dgrad / wgrad with 64 KiB partial planes, round 5)
     (32, 128, 3, 16, 0),
+    (32, 128, 2, 16, 3),  # sigmoid
+    (128, 128, 2, 16, 0),  # in == W = 128
+    (64, 128, 4, 5, 0),   # three hidden matrices: 136 KiB of weight fragments per workgroup
+    # the other widths ffmlp.cu:40-44 dispatches, and a 64-wide network with an input wider than 64: layer-by-layer path
+    # (csrc/ffmlp_generic.hip)
+    (32, 16, 2, 16, 0),
     (64, 256, 2, 3, 0),
     (128, 64, 2, 16, 0),
-    (32, 128, 2, 16, 3),  # sigmoid
 ]
 
 
