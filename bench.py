@@ -891,6 +891,16 @@ def main():
                                        poses, scene_bits, boxes, dev, R)
     if world == 1 and not args.no_long_run and args.net == "ff":
         lr_ = long_run_quality(args, dev, R, scene_bits, boxes, steps=args.long_run_steps, note=note, seeds=args.long_run_seeds)
+        # the committed many-seed study of the same comparison (tools/psnr_seeds.py): what settles "within 0.1 dB"
+        study = os.path.join(REPO, "profiles", "r10_psnr_seeds64.json")
+        if os.path.exists(study):
+            try:
+                st = json.load(open(study))
+                lr_["many_seed_study"] = {"file": "profiles/r10_psnr_seeds64.json", "seeds": st["seeds"], "steps": st["steps"],
+                                          "delta_db": st["delta_db"], "delta_db_sem": st["delta_db_sem"],
+                                          "delta_db_ci95": st["delta_db_ci95"], "within_0p1_db": st["within_0p1_db"]}
+            except (OSError, ValueError, KeyError):
+                pass
         extra.setdefault("psnr", {})["long_run"] = lr_
     if not args.no_seal and args.net == "ff":
         # configs[2] on one GPU; under `--gpus N` (or --force_dp) configs[3]: the same section data-parallel over the ranks

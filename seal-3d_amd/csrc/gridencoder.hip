@@ -643,6 +643,10 @@ __device__ __forceinline__ long long to_fixed64(float v, int k) {
 #define S3D_BIN_ACC_UNROLL 4
 #endif
 constexpr uint32_t kBinGroup = 32;
+#ifndef S3D_BIN_ACC_PER_CU  // persistent accumulate workgroups per CU (2 needs S3D_BIN_ACC_KB <= 64)
+#define S3D_BIN_ACC_PER_CU 1
+#endif
+constexpr uint32_t kBinAccPerCu = S3D_BIN_ACC_PER_CU;
 constexpr uint32_t kBinAccBytes = S3D_BIN_ACC_KB * 1024;
 constexpr uint32_t kBinAccThreads = S3D_BIN_ACC_THREADS;
 constexpr uint32_t kBinAccUnroll = S3D_BIN_ACC_UNROLL;
@@ -2133,7 +2137,7 @@ int launch_binned3(const T* grad, const float* inputs, const int32_t* offsets, T
         hipLaunchKernelGGL((k_bin_scatter6<T, D, C, FIXED24, P>), dim3(lay.chunks, nl), dim3(P), stage, st, grad, inputs, offsets, B, l0,
                            sc, hdr, cursor, ovn, ovl, lay.smax, lay.chunks, lay.cap, keys, vals, skeys, svals, gridtype, ac, interp);
         const uint32_t items = lay.smax * nl;
-        hipLaunchKernelGGL((k_bin_accumulate6<T, D, C, FIXED24, P>), dim3(std::min(items, cus)), dim3(kBinAccThreads), kBinAccBytes, st,
+        hipLaunchKernelGGL((k_bin_accumulate6<T, D, C, FIXED24, P>), dim3(std::min(items, cus * kBinAccPerCu)), dim3(kBinAccThreads), kBinAccBytes, st,
                            (const uint16_t*)keys, (const uint32_t*)vals, (const uint16_t*)skeys, (const uint32_t*)svals, offsets,
                            grad_emb, B, l0, nl, hdr, done, cursor, ovn, (const uint2*)ovl, lay.smax, lay.chunks, lay.cap, t_found_inf);
     }

@@ -9,6 +9,9 @@
 // corner, corners accumulated in the order nw, ne, sw, se, out-of-range corners skipped.
 #include "s3d_common.hpp"
 #include <algorithm>
+#include <array>
+#include <cstdio>
+#include <cstdlib>
 
 namespace s3d {
 namespace {
@@ -618,8 +621,19 @@ S3D_EXPORT int s3d_vm_backward_keys(const float* x, uint32_t N, const uint32_t* 
 static void vm_backward_geometry(VmBackward& b, uint32_t N, uint32_t max_rank, bool basis, dim3& gp, dim3& gl, size_t& smem_p,
                                  size_t& smem_l) {
     const uint32_t rp = max_rank <= 16 ? 16u : 64u;
-    b.pts_plane = rp == 16 ? 1024u : 512u;   // (32 / 64 trips per wave: the sorted order fills the chip about twice)
-    b.pts_line = rp == 16 ? 2048u : 1024u;
+    // Every (range, tile) segment ends with one global atomic per cell of the 9 x 9 window and rank channel (3,888 at rank 48)
+    // and global atomics retire at ~21 G/s chip-wide: segments = ranges + occupied tiles, so the ranges are as long as the
+    // workgroup count allows (tools/bench_tensorf_step.py with S3D_VM_PTS=plane64,plane16,line64,line16 sweeps them)
+    static const std::array<uint32_t, 4> pts = [] {
+        std::array<uint32_t, 4> v = {1024u, 1024u, 2048u, 2048u};
+        if (const char* e = getenv("S3D_VM_PTS")) {
+            unsigned a, b2, c, d;
+            if (sscanf(e, "%u,%u,%u,%u", &a, &b2, &c, &d) == 4 && a && b2 && c && d) v = {a, b2, c, d};
+        }
+        return v;
+    }();
+    b.pts_plane = rp == 16 ? pts[1] : pts[0];
+    b.pts_line = rp == 16 ? pts[3] : pts[2];
     gp = dim3(div_up<uint32_t>(N, b.pts_plane), 3);
     gl = dim3(div_up<uint32_t>(N, b.pts_line), 3);
     smem_p = (size_t)kVmTileCells * max_rank * (sizeof(long long) + sizeof(float));

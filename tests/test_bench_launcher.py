@@ -105,7 +105,7 @@ def test_force_dp_runs_the_seal_section_through_a_one_rank_rccl_group():
     per-rank proxy targets, fine-tuning with both tables' gradients in the all-reduce) run through a 1-rank RCCL process
     group, collectives issued for real."""
     r = _run(["--force_dp", "--steps", "4", "--warmup", "2", "--pretrain", "64", "--no_cpu_baseline", "--no_render",
-              "--no_long_run", "--seal_teacher_steps", "48"])
+              "--no_long_run", "--no_tensorf", "--seal_teacher_steps", "48"])
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["data_parallel"]["n_ranks_seen"] == 1

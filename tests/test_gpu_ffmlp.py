@@ -125,9 +125,13 @@ def test_ffmlp_rejects_bad_shapes(hip):
     x = torch.zeros(128, 32, dtype=torch.half, device="cuda")
     with pytest.raises(RuntimeError, match="only support hidden_dim"):  # (the reference's message, ffmlp.cu:44)
         hip.FFMLPBackend.ffmlp_forward(x, w, 128, 32, 16, 48, 2, 0, 6, None, torch.empty(128, 16, dtype=torch.half, device="cuda"))
-    with pytest.raises(RuntimeError, match="needs forward_buffer"):  # hidden 128 trains through forward_buffer / backward_buffer
-        hip.FFMLPBackend.ffmlp_forward(x, torch.zeros(128 * (32 + 128 + 16), dtype=torch.half, device="cuda"), 128, 32, 16, 128, 2, 0, 6, None,
+    with pytest.raises(RuntimeError, match="needs forward_buffer"):  # hidden 256: the layer-by-layer path needs its activation buffers
+        hip.FFMLPBackend.ffmlp_forward(x, torch.zeros(256 * (32 + 256 + 16), dtype=torch.half, device="cuda"), 128, 32, 16, 256, 2, 0, 6, None,
                                        torch.empty(128, 16, dtype=torch.half, device="cuda"))
+    # hidden 128 runs on the MFMA kernels: a forward without forward_buffer is an inference call, as for 32 / 64
+    hip.FFMLPBackend.ffmlp_forward(x, torch.zeros(128 * (32 + 128 + 16), dtype=torch.half, device="cuda"), 128, 32, 16, 128, 2, 0, 6, None,
+                                   torch.empty(128, 16, dtype=torch.half, device="cuda"))
+    assert not hip.FFMLPBackend.fused_backward_supported(32, 16, 128, 2, 0)   # ... and trains through forward_buffer / backward_buffer
 
 
 def test_ffmlp_level_major_input_layout(hip):

@@ -11,7 +11,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_${1:-r01}
-ARGS="--steps 32 --warmup 8 --no_cpu_baseline --no_render --no_seal --no_long_run"
+ARGS="--steps 32 --warmup 8 --no_cpu_baseline --no_render --no_seal --no_long_run --no_tensorf"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python "$ROOT/bench.py" $ARGS > "$OUT/trace.log" 2>&1

@@ -7,7 +7,7 @@ FRAMES=5
 mkdir -p "$ROOT/gpurun_out/profiles_out"
 cd /tmp && export TMPDIR=/tmp
 # the model bench.py renders: its default run up to the end of the timed region (same seed, pretrain count, steps)
-python "$ROOT/bench.py" --no_cpu_baseline --no_seal --no_long_run --no_render --save_model /tmp/s3d_model.pth > /tmp/render_train.log 2>&1 || { tail -5 /tmp/render_train.log; exit 1; }
+python "$ROOT/bench.py" --no_cpu_baseline --no_seal --no_long_run --no_tensorf --no_render --save_model /tmp/s3d_model.pth > /tmp/render_train.log 2>&1 || { tail -5 /tmp/render_train.log; exit 1; }
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/render_prof -- python "$ROOT/tools/render_frames.py" --load /tmp/s3d_model.pth --frames $FRAMES > /tmp/render_prof.log 2>&1
 LINE=$(grep "render 800x800" /tmp/render_prof.log | tail -1)
 F=$(find /tmp/render_prof -name "*kernel_stats.csv" | head -1)
