@@ -906,8 +906,15 @@ def main():
         # configs[2] on one GPU; under `--gpus N` (or --force_dp) configs[3]: the same section data-parallel over the ranks
         note("seal section")
         del trainer
-        extra["seal"] = seal_section(args, dev, batches, note if rank == 0 else (lambda m: None),
-                                     make_dp=(lambda: RayShardedDP(force_collective=args.force_dp)) if dp is not None else None)
+        try:
+            extra["seal"] = seal_section(args, dev, batches, note if rank == 0 else (lambda m: None),
+                                         make_dp=(lambda: RayShardedDP(force_collective=args.force_dp)) if dp is not None else None)
+        except Exception as e:  # noqa: BLE001
+            if world == 1:
+                raise
+            # the headline line of an N-rank run must not be lost to a failure of this optional section (every rank runs the
+            # same code on the same shapes: a Python-level failure is raised on all of them)
+            extra["seal"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     if world == 1 and not args.no_tensorf and args.net == "ff":
         note("tensorf section")
         extra["tensorf"] = tensorf_section(args, dev, batches, note)

@@ -350,6 +350,78 @@ def gen_int():
                         f"grid_{tag}_offsets": offsets.astype(np.int32), f"grid_{tag}_x": x,
                         f"grid_{tag}_scales": np.array(scales, np.float32), f"grid_{tag}_resolution": np.array(ress, np.int64),
                         f"grid_{tag}_pos_grid": np.stack(pgs, 1), f"grid_{tag}_index": np.stack(rows, 1)})   # [n, L, D] / [n, L, 2^D]
+    # ---- kernel_packbits (:262-289): the one expression line, vectorised over the 8 cells of a byte
+    e_bits = re.search(r"bits \|= (.*);", rm_src).group(1)          # (grid[i] > density_thresh) ? ((uint8_t)1 << i) : 0
+    mb = re.match(r"^\((.*?)\)\s*\?\s*\(\(uint8_t\)(\d+) << i\)\s*:\s*(\d+)$", e_bits)
+    assert mb, e_bits
+    cells = rng.uniform(-1, 30, (4096, 8)).astype(np.float32)
+    cells[:16] = np.array([10.0, 9.999999, 10.000001, 0, -0.0, np.inf, -np.inf, np.nan], np.float32)
+    for th in (10.0, 0.0, 0.01):
+        bits = np.zeros(cells.shape[0], np.uint8)
+        for i in range(8):
+            cond = eval(mb.group(1), {"__builtins__": {}}, {"grid": {i: cells[:, i]}, "i": i, "density_thresh": np.float32(th)})
+            bits |= np.where(cond, np.uint8(int(mb.group(2)) << i), np.uint8(int(mb.group(3)))).astype(np.uint8)
+        out[f"packbits_thresh{th:g}"] = bits
+    out["packbits_grid"] = cells
+    # ---- kernel_near_far_from_aabb (:92-145): subtract / multiply / divide / compare / swap only — nothing nvcc could contract,
+    # IEEE division (-prec-div is nvcc's default) — evaluated ray by ray with numpy float32 scalars
+    body = re.search(r"const float ox = rays_o\[0\].*?fars\[n\] = far;", rm_src, re.S).group(0)
+    src_py, ind = ["def near_far(rays_o, rays_d, aabb, min_near):"], 1
+    for raw in body.split("\n"):
+        line = raw.split("//")[0].strip()
+        if not line:
+            continue
+        pad = "    " * ind
+        if line == "}":
+            ind -= 1
+            continue
+        m1 = re.match(r"(?:const )?float (.*);$", line)
+        if m1:
+            for part in m1.group(1).split(","):
+                name, expr = part.split("=", 1)
+                src_py.append(pad + f"{name.strip()} = F32({expr.strip()})")
+            continue
+        m1 = re.match(r"if \((.*)\) swapf\((\w+), (\w+)\);$", line)
+        if m1:
+            src_py.append(pad + f"if {m1.group(1)}: {m1.group(2)}, {m1.group(3)} = {m1.group(3)}, {m1.group(2)}")   # swapf (:38-40)
+            continue
+        m1 = re.match(r"if \((.*)\) (\w+) = (\w+);$", line)
+        if m1:
+            src_py.append(pad + f"if {m1.group(1)}: {m1.group(2)} = {m1.group(3)}")
+            continue
+        m1 = re.match(r"if \((.*)\) \{$", line)
+        if m1:
+            src_py.append(pad + "if %s:" % m1.group(1).replace("||", " or "))
+            ind += 1
+            continue
+        if line == "nears[n] = fars[n] = std::numeric_limits<scalar_t>::max();":
+            src_py.append(pad + "near = far = FLT_MAX")
+            continue
+        if line == "return;":
+            src_py.append(pad + "return near, far")
+            continue
+        if line in ("nears[n] = near;", "fars[n] = far;"):
+            continue
+        raise AssertionError("untranslated reference line in kernel_near_far_from_aabb: %r" % line)
+    src_py.append("    return near, far")
+    nf_env = {"F32": np.float32, "FLT_MAX": np.float32(np.finfo(np.float32).max)}
+    exec("\n".join(src_py), nf_env)
+    syn = _load_synthetic()
+    poses = syn.orbit_poses(3, seed=5)
+    r = syn.get_rays(poses, syn.lego_intrinsics(64, 64), 64, 64, N=600, generator=torch.Generator().manual_seed(9))
+    ro = r["rays_o"].reshape(-1, 3).numpy().astype(np.float32)
+    rd = r["rays_d"].reshape(-1, 3).numpy().astype(np.float32)
+    extra_o = np.array([[0, 0, 3], [0.5, 0.5, 3], [3, 0, 0], [0, -3, 0], [1, 0, 3], [1, 1, 3], [0, 0, 0], [0.2, 0.1, 0.3], [5, 5, 5],
+                        [-1, 0, 2], [0, 0, -1], [2, 2, 2]], np.float32)
+    extra_d = np.array([[0, 0, -1], [0, 0, -1], [-1, 0, 0], [0, 1, 0], [0, 0, -1], [0, 0, -1], [0, 0, 1], [0.6, 0, 0.8], [1, 0, 0],
+                        [0, 0, -1], [0, 0, 1], [-0.57735026, -0.57735026, -0.57735026]], np.float32)
+    ro, rd = np.concatenate([ro, extra_o]), np.concatenate([rd, extra_d])
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    with np.errstate(all="ignore"):
+        for mn in (0.2, 0.05):
+            nf = np.array([nf_env["near_far"](ro[k], rd[k], aabb, np.float32(mn)) for k in range(ro.shape[0])], np.float32)
+            out[f"nearfar_min{mn:g}"] = nf
+    out.update(nearfar_rays_o=ro, nearfar_rays_d=rd, nearfar_aabb=aabb)
     np.savez_compressed(os.path.join(OUT, "int_kernels.npz"), **out)
     print("int: wrote int_kernels.npz with", len(out), "arrays")
 

@@ -4,8 +4,14 @@
  * TEST INFRASTRUCTURE ONLY (see s3o_common.h).  Scalar restatement of
  * gridencoder/src/gridencoder.cu: grid_encode_forward (:87-242),
  * grid_encode_backward (:245-366) and grad_total_variation (:503-607), D in
- * {2..5}, C in {1,2,4,8}, fp32 and fp16 tables.  PARITY UNPINNED by reference
- * fixtures (none exist); checked against hand-derived known answers,
+ * {2..5}, C in {1,2,4,8}, fp32 and fp16 tables.  PINNED for the integer half:
+ * fast_hash / get_grid_index (:50-84) and the cell / corner-row lines of
+ * kernel_grid (:137-149, 165-180) are evaluated from the reference TEXT by
+ * oracle/gen_golden.py `int` (tests/golden/int_kernels.npz) and reproduced here
+ * bit for bit (tests/test_int_golden.py).  The floating-point interpolation stays
+ * PARITY UNPINNED by reference fixtures (none exist; nvcc's
+ * contraction choices and CUDA's exp2f cannot be observed here): checked against
+ * hand-derived known answers,
  * finite differences with the reference's own gradcheck tolerances
  * (testing/test_hashgrid_grad.py:58) and the reference's Python wrapper run on
  * top of it (oracle/gen_golden.py).

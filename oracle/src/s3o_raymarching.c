@@ -4,7 +4,12 @@
  * TEST INFRASTRUCTURE ONLY (see s3o_common.h).  Scalar restatement of the ten
  * native entry points of the reference's raymarching extension, one C function
  * per `_backend` function, following raymarching/src/raymarching.cu (cited per
- * function).  PARITY UNPINNED: the reference ships no golden vectors or
+ * function).  PINNED for the integer helpers: __expand_bits / __morton3D /
+ * __morton3D_invert and mip_from_pos / mip_from_dt (raymarching.cu:42-81) and the
+ * two morton kernels' call lines are evaluated from the reference TEXT by
+ * oracle/gen_golden.py `int` (tests/golden/int_kernels.npz) and reproduced here
+ * bit for bit (tests/test_int_golden.py).  The rest (DDA stepping, compositing
+ * arithmetic) stays PARITY UNPINNED: the reference ships no golden vectors or
  * asserting tests for these functions and its CUDA sources cannot be built in
  * this image; the restatement is checked against hand-derived known answers
  * (tests/test_oracle_raymarching.py) and against the reference's own Python

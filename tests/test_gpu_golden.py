@@ -429,3 +429,24 @@ def test_grid_corner_rows_reproduce_the_reference_text(hip, GI, tag):
     hip.GridBackend.grid_corner_indices(x, offsets, cidx, B, D, C, L, S, H, gridtype, bool(ac))
     rows = cidx.cpu().numpy().view(np.uint32).astype(np.int64)
     assert np.array_equal(rows * C, GI[f"grid_{tag}_index"].astype(np.int64))
+
+
+def test_packbits_and_near_far_reproduce_the_reference_text(hip, GI):
+    """kernel_packbits (raymarching.cu:262-289) and kernel_near_far_from_aabb (:92-145) evaluated from the reference text
+    (oracle/gen_golden.py `int`): the HIP kernels bit for bit — threshold neighbours, +-0 / +-inf / NaN cells; hits, misses
+    (FLT_MAX), axis-parallel rays, origins on a slab plane, both min_near values"""
+    cells = GI["packbits_grid"]
+    grid = torch.from_numpy(np.ascontiguousarray(cells.reshape(-1))).cuda()
+    for th in (10.0, 0.0, 0.01):
+        bf = torch.zeros(cells.shape[0], dtype=torch.uint8, device="cuda")
+        hip.RaymarchingBackend.packbits(grid, cells.shape[0], th, bf)
+        assert np.array_equal(bf.cpu().numpy(), GI[f"packbits_thresh{th:g}"]), th
+    ro, rd = torch.from_numpy(GI["nearfar_rays_o"]).cuda(), torch.from_numpy(GI["nearfar_rays_d"]).cuda()
+    aabb = torch.from_numpy(GI["nearfar_aabb"]).cuda()
+    N = ro.shape[0]
+    for mn in (0.2, 0.05):
+        nears, fars = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+        hip.RaymarchingBackend.near_far_from_aabb(ro, rd, aabb, N, mn, nears, fars)
+        got = np.stack([nears.cpu().numpy(), fars.cpu().numpy()], -1)
+        want = GI[f"nearfar_min{mn:g}"]
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.argwhere(got.view(np.uint32) != want.view(np.uint32))[:5]

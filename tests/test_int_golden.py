@@ -117,3 +117,30 @@ def test_level_table_cells_and_corner_rows(oracle, G, tag):
                 r0 = rows[:, l, 0].astype(np.int64)
                 cell = np.stack([(r0 // (res[l] + 1) ** d) % (res[l] + 1) for d in range(D)], -1)
                 assert np.array_equal(cell, G[f"grid_{tag}_pos_grid"][:, l].astype(np.int64)), l
+
+
+def test_packbits_from_the_reference_expression(oracle, G):
+    """kernel_packbits (raymarching.cu:262-289): `bits |= (grid[i] > density_thresh) ? ((uint8_t)1 << i) : 0` — the comparison
+    incl. the threshold itself, its neighbours, +-0, +-inf and NaN"""
+    cells = G["packbits_grid"]
+    grid = torch.from_numpy(np.ascontiguousarray(cells.reshape(-1)))
+    for th in (10.0, 0.0, 0.01):
+        bf = torch.zeros(cells.shape[0], dtype=torch.uint8)
+        oracle.RaymarchingBackend.packbits(grid, cells.shape[0], th, bf)
+        assert np.array_equal(bf.numpy(), G[f"packbits_thresh{th:g}"]), th
+
+
+def test_near_far_from_the_reference_statements(oracle, G):
+    """kernel_near_far_from_aabb (raymarching.cu:92-145) evaluated ray by ray: hits, misses (FLT_MAX), axis-parallel rays
+    (reciprocal +-inf), origins on a slab plane (0 x inf = NaN in a comparison), min_near clamp — bit for bit"""
+    ro, rd = torch.from_numpy(G["nearfar_rays_o"]), torch.from_numpy(G["nearfar_rays_d"])
+    aabb = torch.from_numpy(G["nearfar_aabb"])
+    N = ro.shape[0]
+    for mn in (0.2, 0.05):
+        nears, fars = torch.empty(N), torch.empty(N)
+        oracle.RaymarchingBackend.near_far_from_aabb(ro, rd, aabb, N, mn, nears, fars)
+        want = G[f"nearfar_min{mn:g}"]
+        got = np.stack([nears.numpy(), fars.numpy()], -1)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.argwhere(got.view(np.uint32) != want.view(np.uint32))[:5]
+    miss = want[:, 0] == np.finfo(np.float32).max
+    assert 0 < miss.sum() < N
