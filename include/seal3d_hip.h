@@ -345,7 +345,7 @@ int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* plan
  * scatter-adds every corner with a global atomic).  Binned instead: s3d_vm_backward_keys writes keys [6,N] i32 (rows 0-2
  * the 8x8-cell plane tile of component i, rows 3-5 its 64-row line chunk; 0x7fffffff = contributes nothing); the caller
  * sorts each row, passes perm [6,N] i32 (point ids in key order) and start [6,n_bounds] i32 (first sorted position with
- * key >= t, n_bounds > s3d_vm_backward_max_bins(resolution) + 1), a zero-initialised scratch gm [N, sum rank] and
+ * key >= t, n_bounds > s3d_vm_backward_max_bins(resolution) + 1), a scratch gm [N, sum rank] (no initialisation needed) and
  * zero-initialised gradient buffers shaped like the factors.  grad: [N] (reduce = 1) or [N, sum rank] (reduce = 0: the
  * gradient of the products, point-major — the memory layout autograd hands back through the reference's `.T`).
  * bound_words: four zero-initialised device words per call — the kernels sum a tile's contributions in LDS as 64-bit fixed

@@ -404,6 +404,12 @@ class GraphedTrainer(Trainer):
         if self.graph_opt is not None:
             self.dist.allreduce_grads(self.scaler)
             self.graph_opt.replay()
+        # the replay files its loss at slot s_cursor[1] % loss_slots and advances the device cursor: the host count moves HERE,
+        # next to the launch, so that any caller of _replay() keeps the two in step
+        slot = self._pushes % self.loss_ring.numel()
+        if self._counter_ring is not None:
+            self._pushes += 1
+        return slot
 
     def train_step(self, rays_o, rays_d, gt_rgb, bg_color=1):
         model = self.model
@@ -428,12 +434,12 @@ class GraphedTrainer(Trainer):
             filed = self._counter_ring is not None
             self._pushes += 1 if filed else 0  # (the warm-up step filed its loss too)
         else:
-            self._replay()
+            slot = self._replay()
             filed = self._counter_ring is not None
             # the static loss buffer is overwritten by the next replay; the graph files each step's loss in a 1,024-slot
-            # history (no extra launch per step): the caller gets the view of this step's slot, untouched for 1,023 more steps
-            loss = self.loss_ring[self._pushes % self.loss_ring.numel()] if filed else self.s_loss.clone()
-            self._pushes += 1 if filed else 0
+            # history (no extra launch per step): the caller gets the VIEW of this step's slot, untouched for 1,023 more steps
+            # — a caller that keeps loss tensors longer than that (statistics over an epoch) clones or reads them
+            loss = self.loss_ring[slot] if filed else self.s_loss.clone()
         bump_weights_epoch()  # replays update the parameters without touching Tensor._version
         if not filed:
             model.step_counter[model.local_step % 16].copy_(self.s_counter)

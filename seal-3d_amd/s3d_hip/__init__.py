@@ -988,7 +988,7 @@ class VmBackend:
         if not grad.is_contiguous() or grad.numel() != (N if reduce else N * rows):
             raise RuntimeError("vm features backward: grad must be contiguous [N] / [N, sum rank]")
         perm, start, n_bounds = bins if bins is not None else VmBackend.backward_bins(x, planes, resolution)
-        gm = torch.zeros(N, rows, dtype=torch.float32, device=dev)
+        gm = torch.empty(N, rows, dtype=torch.float32, device=dev)  # (written by the plane pass for every point the line pass reads)
         g_planes = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in planes]
         g_lines = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in lines]
         _check(lib().s3d_vm_features_backward(_p(x), _u(N), ptr3(*[t.data_ptr() for t in planes]),
@@ -1029,7 +1029,7 @@ class VmBackend:
         # the kernel reads a point's gradients as four 16-byte words: rows padded to 32 columns
         grad_out = torch.nn.functional.pad(grad_out, (0, 32 - basis.shape[0])).contiguous()
         perm, start, n_bounds = bins if bins is not None else VmBackend.backward_bins(x, planes, resolution)
-        gm = torch.zeros(N, rows, dtype=torch.float32, device=dev)
+        gm = torch.empty(N, rows, dtype=torch.float32, device=dev)  # (written by the plane pass for every point the line pass reads)
         g_planes = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in planes]
         g_lines = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in lines]
         g_basis = torch.zeros(basis.shape, dtype=torch.float32, device=dev)

@@ -68,9 +68,14 @@ def _bins(net, x, mats):
     if key not in cache:
         if len(cache) >= 4:
             cache.clear()
-        # (the entry keeps x itself: while it is cached no other tensor can live at its address)
-        cache[key] = (x, s3d_hip.VmBackend.backward_bins(x, [m.contiguous() for m in mats], net.resolution))
-    return cache[key][1]
+        # (the entry keeps x itself: while it is cached no other tensor can live at its address; two consumers — the density
+        #  and the colour features' backward — then the points and their six sorted index rows are let go)
+        cache[key] = [x, s3d_hip.VmBackend.backward_bins(x, [m.contiguous() for m in mats], net.resolution), 2]
+    ent = cache[key]
+    ent[2] -= 1
+    if ent[2] <= 0:
+        del cache[key]
+    return ent[1]
 
 
 class _VmColorBasis(torch.autograd.Function):
@@ -182,6 +187,12 @@ class NeRFNetwork(NeRFRenderer):
         self.color_net = nn.ModuleList([nn.Linear(i, o, bias=False) for i, o in zip(dims[:-1], dims[1:])])
         if self.bg_radius > 0:
             raise NotImplementedError("background model is outside the BASELINE configs")
+
+    def __getstate__(self):
+        """copy.deepcopy (teacher creation, EMA) and pickling leave the backward's sorted-point cache behind"""
+        state = self.__dict__.copy()
+        state.pop("_vm_bins", None)
+        return state
 
     def init_one_svd(self, n_component, resolution, scale=0.1):
         mat, vec = [], []
