@@ -350,14 +350,17 @@ int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* plan
  * gradient of the products, point-major — the memory layout autograd hands back through the reference's `.T`).
  * bound_words: four zero-initialised device words per call — the kernels sum a tile's contributions in LDS as 64-bit fixed
  * point (integer LDS atomics retire ~10x faster than float ones on MI355X) and keep the bounds that fix its scale there
- * (max |grad|, max |line parameter|, max |g m|, max column sum of |basis|); a non-finite bound poisons the gradients. */
+ * (max |grad|, max |line parameter|, max |g m|, max column sum of |basis|); a non-finite bound poisons the gradients.
+ * line_scratch: sum_i rank_i * resolution[vec_ids[i]] floats, no initialisation: the bound pass leaves the line factors there
+ * transposed ([Dn][rank]) for the plane pass, whose lanes are rank channels. */
 uint32_t s3d_vm_backward_max_bins(const uint32_t* resolution);
 int s3d_vm_backward_keys(const float* x, uint32_t N, const uint32_t* rank, const uint32_t* resolution, int32_t* keys,
                          s3d_stream_t stream);
 int s3d_vm_features_backward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                              const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
                              const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
-                             float* const* grad_planes, float* const* grad_lines, uint32_t* bound_words, s3d_stream_t stream);
+                             float* const* grad_planes, float* const* grad_lines, uint32_t* bound_words, float* line_scratch,
+                             s3d_stream_t stream);
 
 /* The colour features with basis_mat applied inside the kernel (tensoRF/network.py:149-153: `basis_mat((mat * vec).T)`, an
  * nn.Linear(sum rank, basis_rows, bias=False) that runs under fp16 autocast): out [N, basis_rows] fp16 =
@@ -374,7 +377,7 @@ int s3d_vm_color_backward(const float* x, uint32_t N, const float* const* planes
                           const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
                           const uint16_t* grad_out, const int32_t* perm, const int32_t* start, uint32_t n_bounds,
                           float* gm, float* const* grad_planes, float* const* grad_lines, float* grad_basis,
-                          uint32_t* bound_words, s3d_stream_t stream);
+                          uint32_t* bound_words, float* line_scratch, s3d_stream_t stream);
 
 /* ------------------------------------------------------------------ NGP head glue
  * The elementwise steps between the two MLPs of nerf/network_ff.py:55-96 (slice / trunc_exp / SH / cat / cast /

@@ -222,6 +222,11 @@ struct VmBackward {
     // [0] max |g| (BASIS: max |g_out|), [1] max |line parameter|, [2] max |g_r m_r| (written by the plane kernel for the
     // line kernel), [3] BASIS: max_r sum_c |W[c][r]|
     uint32_t* bound;
+    // the three line factors TRANSPOSED, [Dn][rank] each (component i at line_t_off[i]): the plane pass has one lane per rank
+    // channel read a point's line value — in the parameters' [rank][Dn] layout that is one cache line per lane and load
+    // (96 line requests per point, which kept the L1 busy ~4 us per round of trips); transposed it is 192 contiguous bytes
+    float* line_t;
+    uint32_t line_t_off[3];
     uint32_t pts_plane, pts_line;  // sorted points per workgroup
 };
 
@@ -264,7 +269,7 @@ __device__ __forceinline__ uint32_t nan_aware_bits(float m, bool bad) { return b
 // three line factors, [3] over the columns of basis_mat
 __global__ void __launch_bounds__(256) k_vm_bound(const float* __restrict__ g, size_t n_g, const _Float16* __restrict__ g16, size_t n_g16,
                                                    VmFactors f, const _Float16* __restrict__ basis, uint32_t Cb, uint32_t rows,
-                                                   uint32_t* __restrict__ bound) {
+                                                   uint32_t* __restrict__ bound, float* __restrict__ line_t) {
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
     float m = 0.0f;
     bool bad = false;
@@ -297,10 +302,18 @@ __global__ void __launch_bounds__(256) k_vm_bound(const float* __restrict__ g, s
     // line factors
     float lm = 0.0f;
     bool lbad = false;
+    size_t base = 0;
 #pragma unroll
     for (uint32_t i = 0; i < 3; i++) {
         const size_t n = (size_t)f.rank[i] * f.Dn[i];
-        for (size_t k = tid; k < n; k += nt) { const float a = fabsf(f.line[i][k]); lbad |= !(a <= 3.4e38f); lm = fmaxf(lm, a); }
+        for (size_t k = tid; k < n; k += nt) {
+            const float v = f.line[i][k], a = fabsf(v);
+            lbad |= !(a <= 3.4e38f);
+            lm = fmaxf(lm, a);
+            const size_t r = k / f.Dn[i], z = k - r * f.Dn[i];
+            line_t[base + z * f.rank[i] + r] = v;  // (the transposed copy the plane pass reads)
+        }
+        base += n;
     }
     lm = wave_max(lm);
     lbad = __ballot(lbad) != 0ull;
@@ -365,7 +378,7 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t sub = lane / RP, r = lane % RP;
     const int32_t* perm = b.perm + (size_t)i * N;
-    const float* Lq = f.line[i];
+    const float* Lt = b.line_t + b.line_t_off[i];  // [Dn][R]
     float wcol[BASIS ? kVmBasisPad : 1], dw[BASIS ? kVmBasisPad : 1];
     if constexpr (BASIS) {
 #pragma unroll
@@ -435,8 +448,8 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
             }
             const bool bz0 = q.z0 >= 0 && q.z0 < Dn, bz1 = q.z0 + 1 >= 0 && q.z0 + 1 < Dn;
             float l = 0.0f;
-            if (bz0) l += Lq[(size_t)r * Dn + q.z0] * q.lz0;
-            if (bz1) l += Lq[(size_t)r * Dn + q.z0 + 1] * q.lz1;
+            if (bz0) l += Lt[(size_t)q.z0 * R + r] * q.lz0;
+            if (bz1) l += Lt[(size_t)(q.z0 + 1) * R + r] * q.lz1;
             const int lx = q.x0 - cx0, ly = q.y0 - cy0;  // nw corner inside the tile's 9x9 window: -1 .. 7
             const bool bx0 = q.x0 >= 0 && q.x0 < W, bx1 = q.x0 + 1 >= 0 && q.x0 + 1 < W;
             const bool by0 = q.y0 >= 0 && q.y0 < H, by1 = q.y0 + 1 >= 0 && q.y0 + 1 < H;
@@ -458,13 +471,23 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
         }
         __syncthreads();
         float* dP = b.d_plane[i];
+        // A segment that holds ALL points of its tile is the only writer of the tile's inner 7 x 7 cells (the window's first
+        // row / column are the left / upper neighbours' border, its last row / column the right / lower neighbours' first):
+        // those leave as plain stores into the zero-initialised gradient — 1,536 instead of 3,888 global atomics per tile at
+        // rank 48, and global atomics (~21 G/s chip-wide) are what this kernel waits for
+        const bool whole = pos == (uint32_t)st[t] && seg_end == (uint32_t)st[t + 1];
         for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += kVmBwdThreads) {
             const uint32_t rr = e / kVmTileCells, c = e % kVmTileCells;
-            const int cy = cy0 + (int)(c / (kVmTile + 1)), cx = cx0 + (int)(c % (kVmTile + 1));
+            const int ly = (int)(c / (kVmTile + 1)), lx = (int)(c % (kVmTile + 1));
+            const int cy = cy0 + ly, cx = cx0 + lx;
             const long long qv = acc[c * R + rr];
             if (qv != 0ll) {
                 acc[c * R + rr] = 0ll;  // cleared behind the read: the next segment starts from zeros
-                if (cx < W && cy < H) atomicAdd(&dP[rr * plane_stride + (size_t)cy * W + cx], (float)qv * inv);
+                if (cx < W && cy < H) {
+                    float* dst = &dP[rr * plane_stride + (size_t)cy * W + cx];
+                    if (whole && lx >= 1 && lx < kVmTile && ly >= 1 && ly < kVmTile) *dst = (float)qv * inv;
+                    else atomicAdd(dst, (float)qv * inv);
+                }
             }
         }
         pos = seg_end;
@@ -625,7 +648,7 @@ static void vm_backward_geometry(VmBackward& b, uint32_t N, uint32_t max_rank, b
     // and global atomics retire at ~21 G/s chip-wide: segments = ranges + occupied tiles, so the ranges are as long as the
     // workgroup count allows (tools/bench_tensorf_step.py with S3D_VM_PTS=plane64,plane16,line64,line16 sweeps them)
     static const std::array<uint32_t, 4> pts = [] {
-        std::array<uint32_t, 4> v = {1024u, 1024u, 2048u, 2048u};
+        std::array<uint32_t, 4> v = {256u, 512u, 1024u, 1024u};  // (same-box sweep, tools/vm_pts_sweep.sh)
         if (const char* e = getenv("S3D_VM_PTS")) {
             unsigned a, b2, c, d;
             if (sscanf(e, "%u,%u,%u,%u", &a, &b2, &c, &d) == 4 && a && b2 && c && d) v = {a, b2, c, d};
@@ -646,10 +669,10 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
                                         const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
                                         const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
                                         float* const* grad_planes, float* const* grad_lines, uint32_t* bound_words,
-                                        s3d_stream_t stream) {
+                                        float* line_scratch, s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
-    S3D_REQUIRE(x && planes && lines && rank && resolution && grad && perm && start && gm && grad_planes && grad_lines && bound_words,
-                "vm_features_backward: null pointer");
+    S3D_REQUIRE(x && planes && lines && rank && resolution && grad && perm && start && gm && grad_planes && grad_lines && bound_words &&
+                line_scratch, "vm_features_backward: null pointer");
     VmFactors f;
     VmBackward b;
     if (int rc = fill_factors(f, planes, lines, rank, resolution, b.rows)) return rc;
@@ -673,6 +696,8 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
     b.n_bounds = n_bounds;
     b.basis = nullptr; b.g_out = nullptr; b.d_basis = nullptr; b.Cb = 0;
     b.bound = bound_words;
+    b.line_t = line_scratch;
+    for (uint32_t i = 0, off = 0; i < 3; off += f.rank[i] * f.Dn[i], i++) b.line_t_off[i] = off;
     hipStream_t st = as_stream(stream);
     dim3 gp, gl;
     size_t smem_p, smem_l;
@@ -680,7 +705,7 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
     const dim3 block(kVmBwdThreads);
     const size_t n_g = reduce ? (size_t)N : (size_t)N * b.rows;
     hipLaunchKernelGGL(k_vm_bound, dim3(std::min<uint32_t>(stream_grid(n_g / 4 + 1, 256), 512u)), dim3(256), 0, st, grad, n_g, (const _Float16*)nullptr, (size_t)0, f,
-                       (const _Float16*)nullptr, 0u, b.rows, bound_words);
+                       (const _Float16*)nullptr, 0u, b.rows, bound_words, line_scratch);
     if (max_rank <= 16) {
         if (reduce) hipLaunchKernelGGL((k_vm_plane_backward<16, true>), gp, block, smem_p, st, x, N, f, b);
         else hipLaunchKernelGGL((k_vm_plane_backward<16, false>), gp, block, smem_p, st, x, N, f, b);
@@ -713,10 +738,10 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
                                      const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
                                      const uint16_t* grad_out, const int32_t* perm, const int32_t* start, uint32_t n_bounds,
                                      float* gm, float* const* grad_planes, float* const* grad_lines, float* grad_basis,
-                                     uint32_t* bound_words, s3d_stream_t stream) {
+                                     uint32_t* bound_words, float* line_scratch, s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && planes && lines && rank && resolution && basis && grad_out && perm && start && gm && grad_planes && grad_lines &&
-                grad_basis && bound_words, "vm_color_backward: null pointer");
+                grad_basis && bound_words && line_scratch, "vm_color_backward: null pointer");
     VmFactors f;
     VmBackward b;
     if (int rc = fill_factors(f, planes, lines, rank, resolution, b.rows)) return rc;
@@ -745,6 +770,8 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
     b.d_basis = grad_basis;
     b.Cb = basis_rows;
     b.bound = bound_words;
+    b.line_t = line_scratch;
+    for (uint32_t i = 0, off = 0; i < 3; off += f.rank[i] * f.Dn[i], i++) b.line_t_off[i] = off;
     hipStream_t st = as_stream(stream);
     dim3 gp, gl;
     size_t smem_p, smem_l;
@@ -752,7 +779,7 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
     const dim3 block(kVmBwdThreads);
     const size_t n_g16 = (size_t)N * kVmBasisPad;
     hipLaunchKernelGGL(k_vm_bound, dim3(std::min<uint32_t>(stream_grid(n_g16 / 8 + 1, 256), 512u)), dim3(256), 0, st, (const float*)nullptr, (size_t)0,
-                       (const _Float16*)grad_out, n_g16, f, (const _Float16*)basis, basis_rows, b.rows, bound_words);
+                       (const _Float16*)grad_out, n_g16, f, (const _Float16*)basis, basis_rows, b.rows, bound_words, line_scratch);
     hipLaunchKernelGGL((k_vm_plane_backward<64, false, true>), gp, block, smem_p, st, x, N, f, b);
     hipLaunchKernelGGL((k_vm_line_backward<64>), gl, block, smem_l, st, x, N, f, b);
     return check_launch("vm_color_backward");

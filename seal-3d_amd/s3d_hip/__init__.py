@@ -991,11 +991,14 @@ class VmBackend:
         gm = torch.empty(N, rows, dtype=torch.float32, device=dev)  # (written by the plane pass for every point the line pass reads)
         g_planes = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in planes]
         g_lines = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in lines]
+        # (named locals: temporaries created inside the argument list would be freed one by one and handed the SAME block)
+        bound_words = torch.zeros(4, dtype=torch.int32, device=dev)
+        line_scratch = torch.empty(sum(t.numel() for t in lines), dtype=torch.float32, device=dev)
         _check(lib().s3d_vm_features_backward(_p(x), _u(N), ptr3(*[t.data_ptr() for t in planes]),
                                               ptr3(*[t.data_ptr() for t in lines]), rank, res, C.c_int(int(bool(reduce))),
                                               _p(grad), _p(perm), _p(start), _u(n_bounds), _p(gm),
                                               ptr3(*[t.data_ptr() for t in g_planes]), ptr3(*[t.data_ptr() for t in g_lines]),
-                                              _p(torch.zeros(4, dtype=torch.int32, device=dev)), _stream()), "vm_features_backward")
+                                              _p(bound_words), _p(line_scratch), _stream()), "vm_features_backward")
         return g_planes, g_lines
 
     @staticmethod
@@ -1033,10 +1036,12 @@ class VmBackend:
         g_planes = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in planes]
         g_lines = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in lines]
         g_basis = torch.zeros(basis.shape, dtype=torch.float32, device=dev)
+        bound_words = torch.zeros(4, dtype=torch.int32, device=dev)
+        line_scratch = torch.empty(sum(t.numel() for t in lines), dtype=torch.float32, device=dev)
         _check(lib().s3d_vm_color_backward(_p(x), _u(N), ptr3(*[t.data_ptr() for t in planes]),
                                            ptr3(*[t.data_ptr() for t in lines]), u3(*[int(t.shape[1]) for t in planes]),
                                            u3(*[int(r) for r in resolution]), _p(basis), _u(basis.shape[0]), _p(grad_out),
                                            _p(perm), _p(start), _u(n_bounds), _p(gm), ptr3(*[t.data_ptr() for t in g_planes]),
                                            ptr3(*[t.data_ptr() for t in g_lines]), _p(g_basis),
-                                           _p(torch.zeros(4, dtype=torch.int32, device=dev)), _stream()), "vm_color_backward")
+                                           _p(bound_words), _p(line_scratch), _stream()), "vm_color_backward")
         return g_planes, g_lines, g_basis
