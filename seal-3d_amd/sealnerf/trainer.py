@@ -151,6 +151,16 @@ class SealSteps:
     def set_lr(self, lr):
         for g in self.optimizer.param_groups:
             g["lr"] = lr
+        # an optimizer whose step has been captured once applies lr changes through a device-side factor (nerf/optim.py:
+        # capture_lr): bring it up to date HERE, so that a graph replayed next — a pretraining chunk, the fine-tuning step —
+        # runs at this lr and not at the factor some other phase left behind
+        follow = getattr(self.optimizer, "follow_lr_schedule", None)
+        if follow is not None and getattr(self.optimizer, "_lr_captured", None) is not None \
+                and not torch.cuda.is_current_stream_capturing() and not follow():
+            self.optimizer.capture_lr()   # groups moved by different factors: rebase, and drop every graph that baked the old lrs in
+            self._pt_graphs = {}
+            if getattr(self, "graph", None) is not None:
+                self.graph = self.graph_opt = None
 
     def pretrain_loss(self, points, dirs, gt_sigma, gt_color, n_total=None):
         """SealNeRF/trainer.py:455-469: L1Loss(sigma) + L1Loss(colour) (means) of the student on one point chunk.  With a

@@ -111,6 +111,54 @@ def test_seal_distillation_graph_replay_matches_eager(hip):
     np.testing.assert_allclose(hist, hist_e, rtol=0.5)  # (different noise streams: same trajectory, not the same numbers)
 
 
+def test_seal_lr_changes_reach_replayed_graphs_through_the_device_factor(hip):
+    """Seal-3D switches learning rates between its phases (`set_lr`, SealNeRF/trainer.py:491-504: pretraining lr, then back).
+    Once the fine-tuning step has been captured, lr changes travel through NativeAdam's device-side factor: `set_lr` has to
+    leave that factor at new lr / captured lr — a pretraining chunk captured AFTER the fine-tuning graph would otherwise be
+    replayed at whatever factor the last phase left behind."""
+    from nerf import network
+    from sealnerf import GraphedSealTrainer, SealBBoxMapper, make_student, make_teacher
+    torch.manual_seed(0)
+    kw = dict(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, log2_hashmap_size=15)
+    teacher = make_teacher(network.NeRFNetwork, **kw).cuda()
+    student = make_student(network.NeRFNetwork, **kw).cuda()
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    for m in (teacher, student):
+        m.density_grid.copy_(torch.from_numpy(grid))
+        m.density_bitfield.copy_(torch.from_numpy(bits))
+        m.iter_density = 100
+    student.load_state_dict(teacher.state_dict())
+    mapper = SealBBoxMapper(BBOX)
+    teacher.init_mapper(mapper)
+    student.init_mapper(mapper)
+    tr = GraphedSealTrainer(student, teacher, 1024, lr=1e-2, fp16=True, update_extra_interval=10 ** 9)
+    poses = syn.orbit_poses(1, seed=0).cuda()
+    r = syn.get_rays(poses, syn.lego_intrinsics(), 800, 800, N=1024, generator=torch.Generator().manual_seed(0))
+    ro, rd = r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous()
+    tr.global_step = 1
+    for _ in range(24):                       # 16 eager steps (sample statistics), capture, replays
+        tr.train_step(ro, rd)
+    opt = tr.optimizer
+    assert tr.n_captures >= 1 and opt._lr_captured is not None and float(opt.lr_scale) == 1.0
+    tr.init_pretraining(batch_size=6144000, lr=0.05, local_point_step=0.02)
+    l0 = float(tr.pretrain_one_epoch())       # eager warm-up step + capture of the chunk's graph, at the pretraining lr
+    assert float(opt.lr_scale) == 1.0 and all(g["lr"] == 1e-2 for g in opt.param_groups)   # restored behind the epoch
+    seen = []
+    real = type(tr)._pretrain_chunk
+
+    def spy(self, key, sl, n_total):
+        seen.append(float(opt.lr_scale))      # the factor a replayed chunk graph will read
+        return real(self, key, sl, n_total)
+    type(tr)._pretrain_chunk = spy
+    try:
+        tr.train_step(ro, rd)                 # a fine-tuning replay in between
+        l1 = float(tr.pretrain_one_epoch())   # replays the chunk graph
+    finally:
+        type(tr)._pretrain_chunk = real
+    assert seen and all(abs(f - 0.05 / 1e-2) < 1e-6 for f in seen), seen
+    assert float(opt.lr_scale) == 1.0 and np.isfinite([l0, l1]).all()
+
+
 def test_tensorf_vm48_step_on_gpu(hip):
     from tensoRF import network as trf
     from nerf.trainer import Trainer
