@@ -131,12 +131,11 @@ def test_seal_lr_changes_reach_replayed_graphs_through_the_device_factor(hip):
     mapper = SealBBoxMapper(BBOX)
     teacher.init_mapper(mapper)
     student.init_mapper(mapper)
-    tr = GraphedSealTrainer(student, teacher, 1024, lr=1e-2, fp16=True, update_extra_interval=10 ** 9)
+    tr = GraphedSealTrainer(student, teacher, 1024, lr=1e-2, fp16=True, update_extra_interval=16)
     poses = syn.orbit_poses(1, seed=0).cuda()
     r = syn.get_rays(poses, syn.lego_intrinsics(), 800, 800, N=1024, generator=torch.Generator().manual_seed(0))
     ro, rd = r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous()
-    tr.global_step = 1
-    for _ in range(24):                       # 16 eager steps (sample statistics), capture, replays
+    for _ in range(40):                       # 16 eager steps (sample statistics), capture, replays
         tr.train_step(ro, rd)
     opt = tr.optimizer
     assert tr.n_captures >= 1 and opt._lr_captured is not None and float(opt.lr_scale) == 1.0
