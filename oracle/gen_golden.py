@@ -753,6 +753,447 @@ def gen_train():
           "samples", net.step_counter[0].tolist(), "psnr", meter.measure())
 
 
+# ----------------------------------------------------------------------------- float kernels, evaluated from the reference text
+class _Ptr:
+    """a C pointer into a numpy array: `p[i]`, `p[i] = v`, `p += k` (returns a new pointer), element type preserved"""
+
+    def __init__(self, a, off=0):
+        self.a, self.off = a, int(off)
+
+    def __getitem__(self, i):
+        return self.a[self.off + int(i)]
+
+    def __setitem__(self, i, v):
+        self.a[self.off + int(i)] = v
+
+    def __add__(self, k):
+        return _Ptr(self.a, self.off + int(k))
+
+    __iadd__ = __add__
+
+
+def _c_expr_ast(e, contract):
+    """C arithmetic expression -> python source through python's own parser (the operator grammar is the same), with C's
+    typing made explicit: `1.0f` float32, `0.5` double, `/` = C division (integer for integers), `(float)x` casts; and —
+    `contract` — every `a * b + c`, `c + a * b`, `a * b - c`, `c - a * b` outside an index evaluated as ONE fused multiply-add,
+    which is what nvcc's default -fmad=true makes of a float product feeding an add."""
+    import ast
+    e = re.sub(r"(?<![\w.])(\d+\.\d*(?:e[+-]?\d+)?)f\b", r"F32(\1)", e)
+    e = re.sub(r"(?<![\w.(])(\d+\.\d+)(?![\w.)])", r"F64(\1)", e)
+    e = re.sub(r"\(float\)\s*(\w+(?:\([^()]*\))?|\([^()]*\))", r"F32(\1)", e)
+    e = re.sub(r"\(uint32_t\)\s*(\w+(?:\[[^\]]*\])?|\([^()]*\))", r"U32s(\1)", e)
+    e = re.sub(r"\b(0x[0-9a-fA-F]+|\d+)u\b", r"\1", e)
+    e = e.replace("&&", " and ").replace("||", " or ")
+    tree = ast.parse(e.strip(), mode="eval")
+
+    class IntOnly(ast.NodeTransformer):
+        def visit_BinOp(self, node):
+            node = self.generic_visit(node)
+            if isinstance(node.op, ast.Div):
+                node.op = ast.FloorDiv()
+            return node
+
+    class T(ast.NodeTransformer):
+        def visit_Subscript(self, node):       # indices are integer arithmetic: no contraction, C division stays integer
+            node.value = self.visit(node.value)
+            node.slice = IntOnly().visit(node.slice)
+            return node
+
+        def visit_BinOp(self, node):
+            node = self.generic_visit(node)
+            call = lambda f, *a: ast.Call(ast.Name(f, ast.Load()), list(a), [])
+            neg = lambda x: ast.UnaryOp(ast.USub(), x)
+            ismul = lambda x: isinstance(x, ast.BinOp) and isinstance(x.op, ast.Mult)
+            if isinstance(node.op, ast.Div):
+                return call("cdiv", node.left, node.right)
+            if contract and isinstance(node.op, (ast.Add, ast.Sub)):
+                L, R_ = node.left, node.right
+                if ismul(L):
+                    return call("fma", L.left, L.right, R_ if isinstance(node.op, ast.Add) else neg(R_))
+                if ismul(R_):
+                    return call("fma", R_.left if isinstance(node.op, ast.Add) else neg(R_.left), R_.right, L)
+            return node
+    return ast.unparse(ast.fix_missing_locations(T().visit(tree)))
+
+
+def _split_top(text):
+    """split at the commas outside every bracket (`a = f(x, y), b = g[1]` -> two declarators)"""
+    parts, depth, cur = [], 0, ""
+    for ch in text:
+        depth += ch in "([" 
+        depth -= ch in ")]"
+        if ch == "," and depth == 0:
+            parts.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    return parts + [cur]
+
+
+def _c_runtime():
+    """what the transliterated kernels call: C's typing rules on numpy scalars"""
+    F32, F64, LD = np.float32, np.float64, np.longdouble
+    isf = lambda v: isinstance(v, (np.floating, float))
+    isd = lambda v: isinstance(v, (np.float64, float))
+
+    def fma(a, b, c):
+        if not (isf(a) or isf(b) or isf(c)):
+            return a * b + c
+        r = LD(a) * LD(b) + LD(c)              # exact product of two float32, one rounding at the end
+        return F64(r) if (isd(a) or isd(b) or isd(c)) else F32(r)
+
+    def cdiv(a, b):
+        if isf(a) or isf(b):
+            return (F64(a) / F64(b)) if (isd(a) or isd(b)) else F32(F32(a) / F32(b))
+        return int(a) // int(b)                # (operands are non-negative wherever the kernels divide integers)
+
+    def atomicAdd(ptr, v):
+        old = int(ptr[0])
+        ptr[0] = old + int(v)
+        return old
+    return dict(F32=F32, F64=F64, U32s=lambda v: int(v) & 0xFFFFFFFF, fma=fma, cdiv=cdiv, atomicAdd=atomicAdd, int=int, bool=bool,
+                fminf=lambda a, b: F32(min(F32(a), F32(b))), fmaxf=lambda a, b: F32(max(F32(a), F32(b))), max=max, min=min,
+                scalbnf=lambda x, n: F32(np.ldexp(F32(x), int(n))), copysignf=lambda m, x: F32(np.copysign(F32(m), F32(x))),
+                __expf=lambda x: np.exp(F32(x)))
+
+
+def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="__global__ void", thread_arg=True):
+    """Transliterate the body of a reference CUDA kernel to a python function `name(n, <parameters>)` that does the work
+    of ONE thread (index n).  Handles what the pinned kernels are written in: typed declarations (several per statement),
+    assignments / compound assignments, `x++`, pointer bumps, `while (...) {`, `if (...) {` / `} else {`, one-line
+    `if (...) break|return;`, `break;`, `return;`, statements continued over several lines.  Scalars are numpy float32 / python
+    ints: every binary operation rounds to float32 once — NO multiply-add is fused (nvcc's -fmad contraction is not modelled;
+    the fixtures made this way are compared at the tolerance north_star states, not bit for bit)."""
+    m = re.search(r"%s %s\s*\((.*?)\)\s*\{" % (qualifier, re.escape(name)), src, re.S)
+    assert m, name
+    params = [p.split()[-1].replace("*", "").strip() for p in m.group(1).split(",") if p.strip()]
+    depth, i = 1, m.end()
+    while depth:
+        depth += {"{": 1, "}": -1}.get(src[i], 0)
+        i += 1
+    body = re.sub(r"/\*.*?\*/", "", src[m.end():i - 1], flags=re.S)
+    lines, cur = [], ""
+    for raw in body.split("\n"):
+        t = raw.split("//")[0].strip()
+        if not t:
+            continue
+        cur = (cur + " " + t).strip()
+        if cur.endswith((";", "{", "}")) and cur.count("(") == cur.count(")"):
+            lines.append(cur)
+            cur = ""
+    assert not cur, cur
+
+    def ex(e):
+        if contract is not None:   # (the AST route: C typing explicit, optional multiply-add contraction)
+            return _c_expr_ast(e, contract)
+        e = re.sub(r"(?<![\w.])(\d+\.\d*)f\b", r"F32(\1)", e)
+        return e.replace("&&", " and ").replace("||", " or ").strip()
+    out, ind = ["def %s(%s%s):" % (name, "n, " if thread_arg else "", ", ".join(params))], 1
+    ftypes = set()
+    for line in lines:
+        pad = "    " * ind
+        if any(k in line for k in skip):
+            continue
+        if line == "}":
+            ind -= 1
+            continue
+        if line == "} else {":
+            out.append("    " * (ind - 1) + "else:")
+            continue
+        if line == "do {":
+            out.append(pad + "while True:")
+            ind += 1
+            continue
+        mm = re.match(r"\} while \((.*)\);$", line)
+        if mm:
+            out.append(pad + "if not (%s): break" % ex(mm.group(1)))
+            ind -= 1
+            continue
+        mm = re.match(r"return (.*);$", line)
+        if mm:
+            out.append(pad + "return %s" % ex(mm.group(1)))
+            continue
+        mm = re.match(r"(while|if) \((.*)\) \{$", line)
+        if mm:
+            out.append(pad + "%s %s:" % (mm.group(1), ex(mm.group(2))))
+            ind += 1
+            continue
+        mm = re.match(r"if \((.*)\) (break|return);$", line)
+        if mm:
+            out.append(pad + "if %s: %s" % (ex(mm.group(1)), mm.group(2)))
+            continue
+        if line in ("break;", "return;"):
+            out.append(pad + line[:-1])
+            continue
+        mm = re.match(r"(?:const )?(uint32_t|int|float|scalar_t|bool) (.*);$", line)
+        if mm:
+            isf = mm.group(1) in ("float", "scalar_t")
+            conv = {"float": "F32", "scalar_t": "F32", "bool": "bool", "uint32_t": "U32s" if contract is not None else "int"}.get(mm.group(1), "int")
+            for part in _split_top(mm.group(2)):
+                if "=" not in part:          # `int exponent;`
+                    continue
+                nm, e = part.split("=", 1)
+                nm = nm.strip()
+                if isf:
+                    ftypes.add(nm)
+                out.append(pad + "%s = %s(%s)" % (nm, conv, ex(e)))
+            continue
+        mm = re.match(r"(\w+)\+\+;$", line)
+        if mm:
+            out.append(pad + "%s += 1" % mm.group(1))
+            continue
+        mm = re.match(r"(\w+(?:\[[^\]]*\])?) ([+*-]?)= (.*);$", line)
+        if mm:
+            lhs, op, e = mm.group(1), mm.group(2), ex(mm.group(3))
+            if lhs in pointers and op == "+":
+                out.append(pad + "%s = %s + (%s)" % (lhs, lhs, e))
+            elif "[" in lhs or lhs in ftypes:
+                rhs = ex("%s %s (%s)" % (lhs, op, mm.group(3))) if op else e
+                out.append(pad + "%s = F32(%s)" % (ex(lhs) if "[" in lhs else lhs, rhs))
+            else:
+                out.append(pad + "%s %s= %s" % (lhs, op, e))
+            continue
+        raise AssertionError("untranslated reference line in %s: %r" % (name, line))
+    return "\n".join(out)
+
+
+def gen_float():
+    """The float half of north_star's parity statement ("within 1e-4 rel on composited RGB / sigma"), anchored on the reference
+    TEXT: `kernel_composite_rays_train_forward` (raymarching.cu:501-578), `kernel_composite_rays_train_backward` (:603-684) and
+    `kernel_composite_rays` (:821-900) are transliterated statement by statement (`_c_kernel_to_python`) and run thread by
+    thread with numpy float32 scalars — `__expf` as float32 exp, no fused multiply-adds (what nvcc contracts is not observable
+    here, and is far below the tolerance).  -> tests/golden/float_kernels.npz; oracle (CPU) and HIP (GPU) within 1e-4 relative
+    of the largest value per output, integers (kill pattern, untouched entries) exact."""
+    rm_src = open(os.path.join(REF, "raymarching/src/raymarching.cu")).read()
+    F32 = np.float32
+    env = {"F32": F32, "int": int, "__expf": lambda x: np.exp(F32(x))}
+    thread_line = ("threadIdx.x",)
+    for k, ptrs in (("kernel_composite_rays_train_forward", ("sigmas", "rgbs", "deltas")),
+                    ("kernel_composite_rays_train_backward", ("grad_weights_sum", "grad_image", "weights_sum", "image", "sigmas", "rgbs",
+                                                              "deltas", "grad_sigmas", "grad_rgbs")),
+                    ("kernel_composite_rays", ("sigmas", "rgbs", "deltas", "rays_t", "weights_sum", "depth", "image"))):
+        exec(_c_kernel_to_python(rm_src, k, ptrs, skip=thread_line), env)
+    rng = np.random.default_rng(777)
+    out = {}
+    # ---- training compositing: 300 rays, spans in ray order with gaps, empty rays, one ray past the buffer's end
+    N, T_thresh = 300, F32(1e-4)
+    steps = rng.integers(0, 48, N)
+    steps[rng.random(N) < 0.1] = 0
+    offs = np.concatenate([[0], np.cumsum(steps + rng.integers(0, 3, N))[:-1]])
+    M = int(offs[-1] + steps[-1]) - 5                       # the last ray exceeds M: `offset + num_steps > M`
+    perm = rng.permutation(N)                                # ray index != thread index
+    rays = np.stack([perm, offs, steps], -1).astype(np.int32)
+    Mbuf = int(offs.max() + steps.max() + 8)
+    sig = (rng.gamma(0.6, 20.0, Mbuf)).astype(np.float32)
+    sig[rng.random(Mbuf) < 0.2] = 0
+    sig[rng.random(Mbuf) < 0.02] = 3000.0                   # opaque samples: early termination
+    rgb = rng.random((Mbuf, 3)).astype(np.float32)
+    dl = np.stack([np.full(Mbuf, 2 * 3 ** 0.5 / 1024), rng.uniform(0.003, 0.02, Mbuf)], -1).astype(np.float32)
+    ws, dp, im = (np.full(N, -7, np.float32), np.full(N, -7, np.float32), np.full((N, 3), -7, np.float32))
+    with np.errstate(all="ignore"):
+        for n in range(N):
+            env["kernel_composite_rays_train_forward"](n, _Ptr(sig), _Ptr(rgb.reshape(-1)), _Ptr(dl.reshape(-1)), _Ptr(rays.reshape(-1)),
+                                                       M, N, T_thresh, _Ptr(ws), _Ptr(dp), _Ptr(im.reshape(-1)))
+        g_ws = rng.standard_normal(N).astype(np.float32)
+        g_im = rng.standard_normal((N, 3)).astype(np.float32)
+        g_sig, g_rgb = np.zeros(Mbuf, np.float32), np.zeros((Mbuf, 3), np.float32)
+        for n in range(N):
+            env["kernel_composite_rays_train_backward"](n, _Ptr(g_ws), _Ptr(g_im.reshape(-1)), _Ptr(sig), _Ptr(rgb.reshape(-1)),
+                                                        _Ptr(dl.reshape(-1)), _Ptr(rays.reshape(-1)), _Ptr(ws), _Ptr(im.reshape(-1)), M, N,
+                                                        T_thresh, _Ptr(g_sig), _Ptr(g_rgb.reshape(-1)))
+    out.update(ct_sigmas=sig, ct_rgbs=rgb, ct_deltas=dl, ct_rays=rays, ct_M=np.int64(M), ct_T_thresh=T_thresh, ct_weights_sum=ws,
+               ct_depth=dp, ct_image=im, ct_grad_weights_sum=g_ws, ct_grad_image=g_im, ct_grad_sigmas=g_sig, ct_grad_rgbs=g_rgb)
+    # ---- inference compositing: 3 iterations on 400 alive rays, 6 slots each, unfilled slots (delta 0), kills
+    n_alive, n_step, NR, Tt = 400, 6, 640, F32(1e-2)
+    alive = rng.permutation(NR)[:n_alive].astype(np.int32)
+    rays_t = rng.uniform(0.3, 2.0, NR).astype(np.float32)
+    wsum, dep, img = np.zeros(NR, np.float32), np.zeros(NR, np.float32), np.zeros((NR, 3), np.float32)
+    out["ci_rays_t_init"] = rays_t.copy()
+    trace = []
+    with np.errstate(all="ignore"):
+        for it in range(3):
+            rows = n_alive * n_step
+            s_i = rng.gamma(0.5, 12.0, rows).astype(np.float32)
+            c_i = rng.random((rows, 3)).astype(np.float32)
+            d_i = np.stack([np.full(rows, 2 * 3 ** 0.5 / 1024), rng.uniform(0.003, 0.02, rows)], -1).astype(np.float32)
+            fill = np.where(rng.random(n_alive) < 0.75, n_step, rng.integers(0, n_step + 1, n_alive))
+            for a in range(n_alive):
+                d_i[a * n_step + fill[a]:(a + 1) * n_step] = 0       # slots a ray did not fill
+            before = alive.copy()
+            for n in range(n_alive):
+                env["kernel_composite_rays"](n, n_alive, n_step, Tt, _Ptr(alive), _Ptr(rays_t), _Ptr(s_i), _Ptr(c_i.reshape(-1)),
+                                             _Ptr(d_i.reshape(-1)), _Ptr(wsum), _Ptr(dep), _Ptr(img.reshape(-1)))
+            trace.append(dict(alive_in=before, sigmas=s_i, rgbs=c_i, deltas=d_i, alive_out=alive.copy(), rays_t=rays_t.copy(),
+                              weights_sum=wsum.copy(), depth=dep.copy(), image=img.copy()))
+            alive = alive[alive >= 0]
+            n_alive = alive.shape[0]
+    for it, tr in enumerate(trace):
+        for k, v in tr.items():
+            out[f"ci{it}_{k}"] = v
+    out.update(ci_n_step=np.int64(n_step), ci_T_thresh=Tt, ci_NR=np.int64(NR))
+    np.savez_compressed(os.path.join(OUT, "float_kernels.npz"), **out)
+    print("float: wrote float_kernels.npz with", len(out), "arrays; rays terminated early:",
+          int((trace[0]["alive_out"] < 0).sum()), "of", trace[0]["alive_in"].shape[0])
+
+
+def gen_march():
+    """`kernel_march_rays_train` (raymarching.cu:311-478: both passes, the span reservation, the voxel skip) transliterated
+    statement by statement and run ray by ray in thread order — with C's typing made explicit (float32 / double literals,
+    integer division, truncating conversions) and every float product that feeds an add evaluated as ONE fused multiply-add,
+    nvcc's default (-fmad=true): `ox + t * dx`, `x * mip_rbound + 1`, `t0 += clamp(..) * noise`, the three nested ones of the
+    voxel-exit distance, `level * H3 + morton`.  `signf`, `clamp`, `SQRT3` are transliterated from the text too;
+    `mip_from_pos`, `mip_from_dt`, `__morton3D` are the translations gen_int pins.  -> tests/golden/march_kernels.npz: ray
+    table, counter and every sample (position, direction, both deltas) — the oracle and the HIP marcher must reproduce them
+    BIT FOR BIT.  What this pins: that the build's restatement IS the reference's text under that contraction model (the model
+    itself — which products nvcc fuses — stays the one assumption that cannot be observed without nvcc)."""
+    rm_src = open(os.path.join(REF, "raymarching/src/raymarching.cu")).read()
+    env = _c_runtime()
+    env.update(fabsf=lambda a: np.abs(np.float32(a)), fabs=lambda a: np.abs(np.float32(a)))
+    ienv = _int_env()
+    for fn in ("__expand_bits", "__morton3D", "mip_from_pos", "mip_from_dt"):
+        exec(_c_to_python(rm_src, fn), ienv)
+    env["__morton3D"] = lambda x, y, z: int(ienv["__morton3D"](x, y, z))
+    env["mip_from_pos"] = lambda x, y, z, C: int(ienv["mip_from_pos"](x, y, z, np.float32(C)))
+    env["mip_from_dt"] = lambda dt, H, C: int(ienv["mip_from_dt"](dt, np.float32(H), np.float32(C)))
+    for fn, q in (("SQRT3", "inline constexpr __device__ float"), ("signf", "inline __host__ __device__ float"),
+                  ("clamp", "inline __host__ __device__ float")):
+        exec(_c_kernel_to_python(rm_src, fn, (), contract=True, qualifier=q, thread_arg=False), env)
+    code = _c_kernel_to_python(rm_src, "kernel_march_rays_train", ("rays_o", "rays_d", "xyzs", "dirs", "deltas"), skip=("threadIdx.x",),
+                               contract=True)
+    assert code.count("fma(") >= 2 * 13, code       # both passes: 3 positions, 3 cell coordinates, 6 + ... of the exit distance, index
+    exec(code, env)
+    syn = _load_synthetic()
+    out = {}
+    cases = (("c1", 1, 1.0, 0.0, 96, True), ("c2", 2, 2.0, 1 / 128, 64, True), ("c1_noperturb", 1, 1.0, 0.0, 64, False))
+    for tag, C, bound, dt_gamma, N, perturb in cases:
+        H = 128
+        rng = np.random.default_rng(zlib.crc32(tag.encode()))
+        if C == 1:
+            _, bits = syn.lego_like_density_grid(seed=0)
+        else:
+            bits = (rng.random(C * H ** 3 // 8) < 0.06).astype(np.uint8) * rng.integers(1, 256, C * H ** 3 // 8).astype(np.uint8)
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        poses = syn.orbit_poses(2, seed=11)
+        r = syn.get_rays(poses[:1], syn.lego_intrinsics(), 800, 800, N=N, generator=torch.Generator().manual_seed(3))
+        ro = r["rays_o"][0].numpy().astype(np.float32) * np.float32(1.0 if C == 1 else 0.9)
+        rd = r["rays_d"][0].numpy().astype(np.float32)
+        # near / far: the reference's own kernel text (gen_int's transliteration restated inline would be circular here): slab test
+        # in float32 through the oracle-free numpy expression of raymarching.cu:113-140
+        aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+        nears, fars = np.empty(N, np.float32), np.empty(N, np.float32)
+        nf = _near_far_env(rm_src)
+        with np.errstate(all="ignore"):
+            for k in range(N):
+                nears[k], fars[k] = nf(ro[k], rd[k], aabb, np.float32(0.2))
+        noises = rng.random(N).astype(np.float32) if perturb else np.zeros(N, np.float32)
+        max_steps = 1024
+        # first run with an unbounded buffer to learn the sample count, then the real one with M below it for one case
+        def run(M):
+            xyzs, dirs, deltas = np.zeros((M, 3), np.float32), np.zeros((M, 3), np.float32), np.zeros((M, 2), np.float32)
+            rays, counter = np.zeros((N, 3), np.int32), np.zeros(2, np.int32)
+            with np.errstate(all="ignore"):
+                for n in range(N):
+                    env["kernel_march_rays_train"](n, _Ptr(ro.reshape(-1)), _Ptr(rd.reshape(-1)), _Ptr(bits), np.float32(bound),
+                                                   np.float32(dt_gamma), max_steps, N, C, H, M, _Ptr(nears), _Ptr(fars),
+                                                   _Ptr(xyzs.reshape(-1)), _Ptr(dirs.reshape(-1)), _Ptr(deltas.reshape(-1)),
+                                                   _Ptr(rays.reshape(-1)), _Ptr(counter), _Ptr(noises))
+            return xyzs, dirs, deltas, rays, counter
+        total = int(run(N * max_steps)[4][0])
+        M = total - 7 if tag == "c2" else total + 64     # c2: the last rays do not fit (`point_index + num_steps > M`)
+        xyzs, dirs, deltas, rays, counter = run(M)
+        out.update({f"{tag}_cfg": np.array([C, H, max_steps, M, N], np.int64), f"{tag}_bound": np.float32(bound),
+                    f"{tag}_dt_gamma": np.float32(dt_gamma), f"{tag}_bits": bits if C > 1 else np.zeros(0, np.uint8),
+                    f"{tag}_rays_o": ro, f"{tag}_rays_d": rd, f"{tag}_nears": nears, f"{tag}_fars": fars, f"{tag}_noises": noises,
+                    f"{tag}_xyzs": xyzs, f"{tag}_dirs": dirs, f"{tag}_deltas": deltas, f"{tag}_rays": rays, f"{tag}_counter": counter})
+        print(f"march[{tag}]: {total} samples from {N} rays, {int((rays[:, 2] > 0).sum())} rays with samples, M = {M}")
+    # ---- kernel_march_rays (:701-800): the inference loop's marcher, two iterations on the rays that hit the box
+    code = _c_kernel_to_python(rm_src, "kernel_march_rays", ("rays_o", "rays_d", "xyzs", "dirs", "deltas"), skip=("threadIdx.x",),
+                               contract=True)
+    exec(code, env)
+    _, bits = syn.lego_like_density_grid(seed=0)
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    poses = syn.orbit_poses(2, seed=11)
+    r = syn.get_rays(poses[1:2], syn.lego_intrinsics(64, 64), 64, 64)
+    ro = r["rays_o"][0].numpy().astype(np.float32)[1200:2900]
+    rd = r["rays_d"][0].numpy().astype(np.float32)[1200:2900]
+    NR = ro.shape[0]
+    aabb = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    nf = _near_far_env(rm_src)
+    nears, fars = np.empty(NR, np.float32), np.empty(NR, np.float32)
+    with np.errstate(all="ignore"):
+        for k in range(NR):
+            nears[k], fars[k] = nf(ro[k], rd[k], aabb, np.float32(0.2))
+    rng = np.random.default_rng(4242)
+    alive = np.nonzero(nears < fars)[0].astype(np.int32)[::3][:220]
+    rays_t = nears.copy()
+    out.update(mi_rays_o=ro, mi_rays_d=rd, mi_nears=nears, mi_fars=fars, mi_cfg=np.array([1, 128, 1024], np.int64))
+    for it, (n_step, perturb) in enumerate(((8, False), (12, True))):
+        n_alive = alive.shape[0]
+        noises = rng.random(n_alive).astype(np.float32) if perturb else np.zeros(n_alive, np.float32)
+        rows = n_alive * n_step
+        xyzs, dirs, deltas = np.zeros((rows, 3), np.float32), np.zeros((rows, 3), np.float32), np.zeros((rows, 2), np.float32)
+        with np.errstate(all="ignore"):
+            for n in range(n_alive):
+                env["kernel_march_rays"](n, n_alive, n_step, _Ptr(alive), _Ptr(rays_t), _Ptr(ro.reshape(-1)), _Ptr(rd.reshape(-1)),
+                                         np.float32(1.0), np.float32(0.0), 1024, 1, 128, _Ptr(bits), _Ptr(nears), _Ptr(fars),
+                                         _Ptr(xyzs.reshape(-1)), _Ptr(dirs.reshape(-1)), _Ptr(deltas.reshape(-1)), _Ptr(noises))
+        out.update({f"mi{it}_alive": alive.copy(), f"mi{it}_rays_t": rays_t.copy(), f"mi{it}_noises": noises, f"mi{it}_n_step": np.int64(n_step),
+                    f"mi{it}_xyzs": xyzs, f"mi{it}_dirs": dirs, f"mi{it}_deltas": deltas})
+        # what composite_rays would leave behind for the next iteration: t advanced by the real deltas of the filled slots
+        filled = deltas[:, 0].reshape(n_alive, n_step) > 0
+        rays_t[alive] = rays_t[alive] + deltas[:, 1].reshape(n_alive, n_step).sum(1).astype(np.float32)
+        alive = alive[filled.all(1)]
+        print(f"march_rays[{it}]: {int(filled.sum())} filled slots of {rows}, {alive.shape[0]} rays go on")
+    np.savez_compressed(os.path.join(OUT, "march_kernels.npz"), **out)
+    print("march: wrote march_kernels.npz with", len(out), "arrays")
+
+
+def _near_far_env(rm_src):
+    """kernel_near_far_from_aabb as gen_int transliterates it (one ray per call) — shared by gen_march"""
+    body = re.search(r"const float ox = rays_o\[0\].*?fars\[n\] = far;", rm_src, re.S).group(0)
+    src_py, ind = ["def near_far(rays_o, rays_d, aabb, min_near):"], 1
+    for raw in body.split("\n"):
+        line = raw.split("//")[0].strip()
+        if not line:
+            continue
+        pad = "    " * ind
+        if line == "}":
+            ind -= 1
+            continue
+        m1 = re.match(r"(?:const )?float (.*);$", line)
+        if m1:
+            for part in m1.group(1).split(","):
+                name, expr = part.split("=", 1)
+                src_py.append(pad + f"{name.strip()} = F32({expr.strip()})")
+            continue
+        m1 = re.match(r"if \((.*)\) swapf\((\w+), (\w+)\);$", line)
+        if m1:
+            src_py.append(pad + f"if {m1.group(1)}: {m1.group(2)}, {m1.group(3)} = {m1.group(3)}, {m1.group(2)}")
+            continue
+        m1 = re.match(r"if \((.*)\) (\w+) = (\w+);$", line)
+        if m1:
+            src_py.append(pad + f"if {m1.group(1)}: {m1.group(2)} = {m1.group(3)}")
+            continue
+        m1 = re.match(r"if \((.*)\) \{$", line)
+        if m1:
+            src_py.append(pad + "if %s:" % m1.group(1).replace("||", " or "))
+            ind += 1
+            continue
+        if line == "nears[n] = fars[n] = std::numeric_limits<scalar_t>::max();":
+            src_py.append(pad + "near = far = FLT_MAX")
+            continue
+        if line == "return;":
+            src_py.append(pad + "return near, far")
+            continue
+        if line in ("nears[n] = near;", "fars[n] = far;"):
+            continue
+        raise AssertionError("untranslated reference line in kernel_near_far_from_aabb: %r" % line)
+    src_py.append("    return near, far")
+    nf_env = {"F32": np.float32, "FLT_MAX": np.float32(np.finfo(np.float32).max)}
+    exec("\n".join(src_py), nf_env)
+    return nf_env["near_far"]
+
+
 def _grad_record_flat(module, prefix, out, n=2048):
     """per-tensor gradient record: norm, sum, small tensors whole, larger ones at `n` seeded flat positions"""
     for k, p in module.named_parameters():
@@ -1014,7 +1455,7 @@ def check_dropin():
     print("dropin: reference nerf/renderer.py + nerf/network.py on the build's packages reproduce wrappers.npz")
 
 
-SECTIONS = {"sh": gen_sh, "int": gen_int, "wrappers": gen_wrappers, "train": gen_train, "tensorf": gen_tensorf, "seal": gen_seal, "dropin": check_dropin}
+SECTIONS = {"sh": gen_sh, "int": gen_int, "float": gen_float, "march": gen_march, "wrappers": gen_wrappers, "train": gen_train, "tensorf": gen_tensorf, "seal": gen_seal, "dropin": check_dropin}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -450,3 +450,44 @@ def test_packbits_and_near_far_reproduce_the_reference_text(hip, GI):
         got = np.stack([nears.cpu().numpy(), fars.cpu().numpy()], -1)
         want = GI[f"nearfar_min{mn:g}"]
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.argwhere(got.view(np.uint32) != want.view(np.uint32))[:5]
+
+
+# ----------------------------------------------------------------------------- compositing vs the reference TEXT (1e-4)
+# tests/golden/float_kernels.npz: kernel_composite_rays_train_forward / _backward and kernel_composite_rays run statement by
+# statement in float32 (oracle/gen_golden.py `float`; CPU twin: tests/test_float_golden.py, whose helpers are used here).
+def test_training_compositing_within_1e4_of_the_reference_text(hip):
+    import test_float_golden as fg
+    G = np.load(os.path.join(GOLDEN, "float_kernels.npz"))
+    fg.check_train(fg.train_compositing(hip.RaymarchingBackend, G, dev="cuda"), G)
+
+
+def test_inference_compositing_within_1e4_of_the_reference_text(hip):
+    import test_float_golden as fg
+    G = np.load(os.path.join(GOLDEN, "float_kernels.npz"))
+    fg.check_inference(fg.inference_compositing(hip.RaymarchingBackend, G, dev="cuda"), G)
+
+
+# ----------------------------------------------------------------------------- the marchers vs the reference TEXT, bit for bit
+# tests/golden/march_kernels.npz: kernel_march_rays_train and kernel_march_rays run statement by statement with nvcc's
+# multiply-add contraction modelled (oracle/gen_golden.py `march`; CPU twin and helpers: tests/test_march_golden.py).
+@pytest.mark.parametrize("tag", ["c1", "c2", "c1_noperturb"])
+@pytest.mark.parametrize("path", [1, 2, 3], ids=["lane-per-ray", "wave-per-ray", "wave-per-ray-general"])
+def test_training_marcher_reproduces_the_reference_text(hip, tag, path):
+    """ray table (ray-ordered spans), counter, every sample's position / direction / deltas — all three marching kernels (lane
+    per ray, wave per ray with the single-cascade voxel-run fast path, wave per ray general); one cascade and two, dt_gamma 0
+    and 1/128, perturbed and unperturbed starts, a sample buffer the last rays do not fit"""
+    import test_march_golden as mg
+    G = np.load(os.path.join(GOLDEN, "march_kernels.npz"))
+    R = hip.RaymarchingBackend
+    old = R._march_path
+    R._march_path = path
+    try:
+        mg.check_march(mg.run_march(R, G, tag, dev="cuda"), G, tag)
+    finally:
+        R._march_path = old
+
+
+def test_inference_marcher_reproduces_the_reference_text(hip):
+    import test_march_golden as mg
+    G = np.load(os.path.join(GOLDEN, "march_kernels.npz"))
+    mg.check_march_infer(mg.run_march_infer(hip.RaymarchingBackend, G, dev="cuda"), G)
