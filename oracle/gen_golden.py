@@ -780,9 +780,17 @@ def _c_expr_ast(e, contract):
     import ast
     e = re.sub(r"(?<![\w.])(\d+\.\d*(?:e[+-]?\d+)?)f\b", r"F32(\1)", e)
     e = re.sub(r"(?<![\w.(])(\d+\.\d+)(?![\w.)])", r"F64(\1)", e)
-    e = re.sub(r"\(float\)\s*(\w+(?:\([^()]*\))?|\([^()]*\))", r"F32(\1)", e)
-    e = re.sub(r"\(uint32_t\)\s*(\w+(?:\[[^\]]*\])?|\([^()]*\))", r"U32s(\1)", e)
+    e = re.sub(r"\(float\)\s*(\w+(?:\([^()]*\)|\[[^\]]*\])?|\([^()]*\))", r"F32(\1)", e)
+    e = re.sub(r"\(uint32_t\)\s*(\w+(?:\([^()]*\)|\[[^\]]*\])?|\([^()]*\))", r"U32s(\1)", e)
     e = re.sub(r"\b(0x[0-9a-fA-F]+|\d+)u\b", r"\1", e)
+    e = re.sub(r"(\w+)<\s*\w+(?:\s*,\s*\w+)*\s*>\s*\(", r"\1(", e)          # template arguments of a call
+    e = re.sub(r"\btrue\b", "True", re.sub(r"\bfalse\b", "False", e))
+    for _ in range(4):                                                          # `(c ? a : b)` and a whole-expression ternary
+        e = re.sub(r"\(([^()?:]+(?:\([^()]*\))?[^()?:]*)\?([^()?:]+(?:\([^()]*\))?[^()?:]*):([^()?:]+(?:\([^()]*\))?[^()?:]*)\)",
+                   r"((\2) if (\1) else (\3))", e)
+    mt = re.match(r"^([^?]+)\?([^:]+):(.+)$", e)
+    if mt and "if" not in e:
+        e = "((%s) if (%s) else (%s))" % (mt.group(2).strip(), mt.group(1).strip(), mt.group(3).strip())
     e = e.replace("&&", " and ").replace("||", " or ")
     tree = ast.parse(e.strip(), mode="eval")
 
@@ -857,7 +865,8 @@ def _c_runtime():
                 __expf=lambda x: np.exp(F32(x)))
 
 
-def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="__global__ void", thread_arg=True):
+def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="__global__ void", thread_arg=True, lead="n",
+                        int_arrays=()):
     """Transliterate the body of a reference CUDA kernel to a python function `name(n, <parameters>)` that does the work
     of ONE thread (index n).  Handles what the pinned kernels are written in: typed declarations (several per statement),
     assignments / compound assignments, `x++`, pointer bumps, `while (...) {`, `if (...) {` / `} else {`, one-line
@@ -875,11 +884,11 @@ def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="
     lines, cur = [], ""
     for raw in body.split("\n"):
         t = raw.split("//")[0].strip()
-        if not t:
+        if not t or t.startswith("#pragma"):
             continue
         cur = (cur + " " + t).strip()
         if cur.endswith((";", "{", "}")) and cur.count("(") == cur.count(")"):
-            lines.append(cur)
+            lines.append(re.sub(r"(\w+)<\s*\w+(?:\s*,\s*\w+)*\s*>\s*\(", r"\1(", cur))   # (template arguments of calls)
             cur = ""
     assert not cur, cur
 
@@ -888,8 +897,8 @@ def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="
             return _c_expr_ast(e, contract)
         e = re.sub(r"(?<![\w.])(\d+\.\d*)f\b", r"F32(\1)", e)
         return e.replace("&&", " and ").replace("||", " or ").strip()
-    out, ind = ["def %s(%s%s):" % (name, "n, " if thread_arg else "", ", ".join(params))], 1
-    ftypes = set()
+    out, ind = ["def %s(%s%s):" % (name, (lead + ", ") if thread_arg else "", ", ".join(params))], 1
+    ftypes, farrays = set(), set()
     for line in lines:
         pad = "    " * ind
         if any(k in line for k in skip):
@@ -899,6 +908,20 @@ def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="
             continue
         if line == "} else {":
             out.append("    " * (ind - 1) + "else:")
+            continue
+        mm = re.match(r"for \(uint(?:32|8)_t (\w+) = (\w+); \1 < (.*?); \1\+\+\) \{$", line)
+        if mm:
+            out.append(pad + "for %s in range(%s, %s):" % (mm.group(1), mm.group(2), ex(mm.group(3))))
+            ind += 1
+            continue
+        mm = re.match(r"(?:const )?(uint32_t|int|float|scalar_t) (\w+)\[(\w+)\](?: = \{(.*)\})?;$", line)
+        if mm:      # local array: `float pos[D];`, `float pos_deriv[D] = {1.0f};` (remaining elements zero, as in C)
+            isf = mm.group(1) in ("float", "scalar_t")
+            zero = "F32(0)" if isf else "0"
+            first = [("F32(%s)" % ex(v) if isf else ex(v)) for v in (mm.group(4).split(",") if mm.group(4) else [])]
+            out.append(pad + "%s = [%s] + [%s] * (%s - %d)" % (mm.group(2), ", ".join(first), zero, mm.group(3), len(first)))
+            if isf:
+                farrays.add(mm.group(2))
             continue
         if line == "do {":
             out.append(pad + "while True:")
@@ -949,7 +972,9 @@ def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="
                 out.append(pad + "%s = %s + (%s)" % (lhs, lhs, e))
             elif "[" in lhs or lhs in ftypes:
                 rhs = ex("%s %s (%s)" % (lhs, op, mm.group(3))) if op else e
-                out.append(pad + "%s = F32(%s)" % (ex(lhs) if "[" in lhs else lhs, rhs))
+                base = lhs.split("[")[0]
+                conv = "int" if ("[" in lhs and base in int_arrays) else "F32"
+                out.append(pad + "%s = %s(%s)" % (ex(lhs) if "[" in lhs else lhs, conv, rhs))
             else:
                 out.append(pad + "%s %s= %s" % (lhs, op, e))
             continue
@@ -1146,6 +1171,56 @@ def gen_march():
         print(f"march_rays[{it}]: {int(filled.sum())} filled slots of {rows}, {alive.shape[0]} rays go on")
     np.savez_compressed(os.path.join(OUT, "march_kernels.npz"), **out)
     print("march: wrote march_kernels.npz with", len(out), "arrays")
+
+
+def gen_grid():
+    """`kernel_grid` (gridencoder.cu:87-242: oob test, scale / resolution, cell + fractional position, smoothstep, the 2^D corner
+    gathers with their trilinear weights, dy_dx) transliterated statement by statement — C typing explicit, multiply-add
+    contraction modelled (`exp2f(level * S) * H - 1`, `inputs[d] * scale + 0.5`, `results[ch] += w * grid[..]`,
+    `results_grad[ch] += w * (..) * pos_deriv[gd]`, `3 - 2 val` of smoothstep), `exp2f` correctly rounded — and run thread by thread
+    for fp32 tables on the reference's own encoder configurations (offset tables from wrappers.npz).  `get_grid_index` /
+    `fast_hash` are the translations gen_int pins; `smoothstep` / `smoothstep_derivative` are transliterated here.
+    -> tests/golden/grid_kernels.npz: outputs [L,B,C] and dy_dx [B,L*D*C], which the oracle and the HIP forward must reproduce BIT
+    FOR BIT (the Jacobian within 1e-6: its corner differences cancel)."""
+    ge_src = open(os.path.join(REF, "gridencoder/src/gridencoder.cu")).read()
+    W = np.load(os.path.join(OUT, "wrappers.npz"))
+    out = {}
+    cfgs = [("hash", 3, 2, 0, False, 0, 4, float(W["grid_hash_pls"]), 4, W["grid_hash_offsets"]),
+            ("smooth", 2, 4, 0, False, 1, 3, float(W["grid_smooth_pls"]), 8, W["grid_smooth_offsets"]),
+            ("tiled_ac", 3, 1, 1, True, 0, 3, float(W["grid_tiled_ac_pls"]), 8, W["grid_tiled_ac_offsets"]),
+            ("lego", 3, 2, 0, False, 0, 16, np.exp2(np.log2(2048 / 16) / 15), 16, W["grid_lego_offsets"])]
+    for tag, D, C, gridtype, ac, interp, L, pls, H, offsets in cfgs:
+        env = _c_runtime()
+        genv = _int_env(D=D, C=C)
+        for fn in ("fast_hash", "get_grid_index"):
+            exec(_c_to_python(ge_src, fn), genv)
+        U32 = genv["U32"]
+        env.update(D=D, C=C, exp2f=lambda a: np.float32(np.exp2(np.float64(a))), ceil=np.ceil, floorf=np.floor,
+                   get_grid_index=lambda gt, a, ch, hs, res, pg: int(genv["get_grid_index"](gt, a, ch, hs, res, [U32(v) for v in pg])))
+        for fn in ("smoothstep", "smoothstep_derivative"):
+            exec(_c_kernel_to_python(ge_src, fn, (), contract=True, qualifier="__device__ inline T", thread_arg=False), env)
+        exec(_c_kernel_to_python(ge_src, "kernel_grid", ("grid", "inputs", "outputs", "dy_dx"), skip=("blockIdx",), contract=True,
+                                 lead="b, level", int_arrays=("pos_grid", "pos_grid_local")), env)
+        rng = np.random.default_rng(zlib.crc32(tag.encode()) + 5)
+        B = 96 if tag == "lego" else 160
+        x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+        x[:6] = np.array([0, 1, 0.5, 0.25, 0.99999994, 1e-8], np.float32)[:, None]
+        x[6], x[7] = -0.01, 1.01                                   # out of range: zero outputs
+        emb = rng.uniform(-1, 1, (int(offsets[-1]), C)).astype(np.float32)
+        S = np.float32(np.log2(pls))
+        outputs = np.full((L, B, C), 7, np.float32)
+        dy_dx = np.full((B, L * D * C), 7, np.float32)
+        with np.errstate(all="ignore"):
+            for level in range(L):
+                for b in range(B):
+                    env["kernel_grid"](b, level, _Ptr(x.reshape(-1)), _Ptr(emb.reshape(-1)), offsets.astype(np.int64), _Ptr(outputs.reshape(-1)),
+                                       B, L, S, H, _Ptr(dy_dx.reshape(-1)), gridtype, ac, interp)
+        out.update({f"{tag}_cfg": np.array([D, C, gridtype, int(ac), interp, L, H], np.int64), f"{tag}_S": S,
+                    f"{tag}_offsets": offsets.astype(np.int32), f"{tag}_x": x, f"{tag}_emb": emb if tag != "lego" else np.zeros(0, np.float32),
+                    f"{tag}_emb_seed": np.int64(zlib.crc32(tag.encode()) + 5), f"{tag}_outputs": outputs, f"{tag}_dy_dx": dy_dx})
+        print(f"grid[{tag}]: {L} levels x {B} points, |out| max {np.abs(outputs).max():.3f}")
+    np.savez_compressed(os.path.join(OUT, "grid_kernels.npz"), **out)
+    print("grid: wrote grid_kernels.npz with", len(out), "arrays")
 
 
 def _near_far_env(rm_src):
@@ -1455,7 +1530,7 @@ def check_dropin():
     print("dropin: reference nerf/renderer.py + nerf/network.py on the build's packages reproduce wrappers.npz")
 
 
-SECTIONS = {"sh": gen_sh, "int": gen_int, "float": gen_float, "march": gen_march, "wrappers": gen_wrappers, "train": gen_train, "tensorf": gen_tensorf, "seal": gen_seal, "dropin": check_dropin}
+SECTIONS = {"sh": gen_sh, "int": gen_int, "float": gen_float, "march": gen_march, "grid": gen_grid, "wrappers": gen_wrappers, "train": gen_train, "tensorf": gen_tensorf, "seal": gen_seal, "dropin": check_dropin}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -491,3 +491,12 @@ def test_inference_marcher_reproduces_the_reference_text(hip):
     import test_march_golden as mg
     G = np.load(os.path.join(GOLDEN, "march_kernels.npz"))
     mg.check_march_infer(mg.run_march_infer(hip.RaymarchingBackend, G, dev="cuda"), G)
+
+
+@pytest.mark.parametrize("tag", ["hash", "smooth", "tiled_ac", "lego"])
+def test_grid_forward_reproduces_the_reference_text(hip, tag):
+    """tests/golden/grid_kernels.npz: `kernel_grid` (gridencoder.cu:87-242) run statement by statement with nvcc's contraction
+    modelled (oracle/gen_golden.py `grid`; CPU twin: tests/test_grid_golden.py): fp32 outputs bit for bit, dy_dx to 1e-6"""
+    import test_grid_golden as gg
+    G = np.load(os.path.join(GOLDEN, "grid_kernels.npz"))
+    gg.check_forward(gg.run_forward(hip.GridBackend, G, tag, dev="cuda"), G, tag)
