@@ -866,7 +866,7 @@ def _c_runtime():
 
 
 def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="__global__ void", thread_arg=True, lead="n",
-                        int_arrays=()):
+                        int_arrays=(), calls=(), pre=None):
     """Transliterate the body of a reference CUDA kernel to a python function `name(n, <parameters>)` that does the work
     of ONE thread (index n).  Handles what the pinned kernels are written in: typed declarations (several per statement),
     assignments / compound assignments, `x++`, pointer bumps, `while (...) {`, `if (...) {` / `} else {`, one-line
@@ -881,10 +881,12 @@ def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="
         depth += {"{": 1, "}": -1}.get(src[i], 0)
         i += 1
     body = re.sub(r"/\*.*?\*/", "", src[m.end():i - 1], flags=re.S)
+    if pre is not None:
+        body = pre(body)
     lines, cur = [], ""
     for raw in body.split("\n"):
         t = raw.split("//")[0].strip()
-        if not t or t.startswith("#pragma"):
+        if not t or t.startswith("#"):
             continue
         cur = (cur + " " + t).strip()
         if cur.endswith((";", "{", "}")) and cur.count("(") == cur.count(")"):
@@ -909,10 +911,15 @@ def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="
         if line == "} else {":
             out.append("    " * (ind - 1) + "else:")
             continue
-        mm = re.match(r"for \(uint(?:32|8)_t (\w+) = (\w+); \1 < (.*?); \1\+\+\) \{$", line)
+        mm = re.match(r"for \((?:uint32_t|uint8_t|int) (\w+) = (\w+); \1 < (.*?); \1(?:\+\+| \+= (\w+))\) \{$", line)
         if mm:
-            out.append(pad + "for %s in range(%s, %s):" % (mm.group(1), mm.group(2), ex(mm.group(3))))
+            out.append(pad + "for %s in range(%s, %s%s):" % (mm.group(1), mm.group(2), ex(mm.group(3)),
+                                                              (", " + mm.group(4)) if mm.group(4) else ""))
             ind += 1
+            continue
+        mm = re.match(r"(\w+)\((.*)\);$", line)
+        if mm and mm.group(1) in calls:      # a call as a statement (atomics rewritten by the caller's pre-pass)
+            out.append(pad + ex(line[:-1]))
             continue
         mm = re.match(r"(?:const )?(uint32_t|int|float|scalar_t) (\w+)\[(\w+)\](?: = \{(.*)\})?;$", line)
         if mm:      # local array: `float pos[D];`, `float pos_deriv[D] = {1.0f};` (remaining elements zero, as in C)
@@ -1219,6 +1226,36 @@ def gen_grid():
                     f"{tag}_offsets": offsets.astype(np.int32), f"{tag}_x": x, f"{tag}_emb": emb if tag != "lego" else np.zeros(0, np.float32),
                     f"{tag}_emb_seed": np.int64(zlib.crc32(tag.encode()) + 5), f"{tag}_outputs": outputs, f"{tag}_dy_dx": dy_dx})
         print(f"grid[{tag}]: {L} levels x {B} points, |out| max {np.abs(outputs).max():.3f}")
+        if tag == "lego":
+            continue
+        # ---- kernel_grid_backward (:245-337, the float branch) and kernel_input_backward (:340-366) on the same points
+        def float_branch(body):
+            """keep the `else` branch of the `std::is_same<scalar_t, at::Half>` test (fp32 tables) and turn the atomics on
+            `&grad_grid[i]` into calls the translator can emit"""
+            m = re.search(r"if \(std::is_same<scalar_t, at::Half>::value && N_C % 2 == 0\) \{.*?\} else \{(.*?)\n        \}", body, re.S)
+            assert m
+            body = body[:m.start()] + m.group(1) + body[m.end():]
+            return re.sub(r"atomicAdd\(&(\w+)\[(.*?)\], (.*?)\);", r"atomic_add_f(\1, \2, \3);", body)
+        N_C = 2 if C % 2 == 0 else 1
+
+        def atomic_add_f(ptr, idx, v):     # fp32 atomics applied in thread order (one of the orders the hardware may take)
+            ptr[idx] = np.float32(ptr[idx] + np.float32(v))
+        env.update(N_C=N_C, atomic_add_f=atomic_add_f)
+        exec(_c_kernel_to_python(ge_src, "kernel_grid_backward", ("grad", "inputs", "grad_grid"), skip=("blockIdx",), contract=True,
+                                 lead="b, level, ch", int_arrays=("pos_grid", "pos_grid_local"), calls=("atomic_add_f",), pre=float_branch), env)
+        exec(_c_kernel_to_python(ge_src, "kernel_input_backward", ("dy_dx",), skip=("threadIdx",), contract=True, lead="t"), env)
+        grad = rng.standard_normal((L, B, C)).astype(np.float32)
+        g_emb = np.zeros_like(emb)
+        g_in = np.zeros((B, D), np.float32)
+        with np.errstate(all="ignore"):
+            for level in range(L):
+                for b in range(B):
+                    for ch in range(0, C, N_C):
+                        env["kernel_grid_backward"](b, level, ch, _Ptr(grad.reshape(-1)), _Ptr(x.reshape(-1)), _Ptr(emb.reshape(-1)),
+                                                    offsets.astype(np.int64), _Ptr(g_emb.reshape(-1)), B, L, S, H, gridtype, ac, interp)
+            for t in range(B * D):
+                env["kernel_input_backward"](t, _Ptr(grad.reshape(-1)), _Ptr(dy_dx.reshape(-1)), _Ptr(g_in.reshape(-1)), B, L)
+        out.update({f"{tag}_grad": grad, f"{tag}_grad_emb": g_emb, f"{tag}_grad_inputs": g_in})
     np.savez_compressed(os.path.join(OUT, "grid_kernels.npz"), **out)
     print("grid: wrote grid_kernels.npz with", len(out), "arrays")
 

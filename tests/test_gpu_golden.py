@@ -500,3 +500,12 @@ def test_grid_forward_reproduces_the_reference_text(hip, tag):
     import test_grid_golden as gg
     G = np.load(os.path.join(GOLDEN, "grid_kernels.npz"))
     gg.check_forward(gg.run_forward(hip.GridBackend, G, tag, dev="cuda"), G, tag)
+
+
+@pytest.mark.parametrize("tag", ["hash", "smooth", "tiled_ac"])
+def test_grid_backward_within_summation_order_of_the_reference_text(hip, tag):
+    """kernel_grid_backward / kernel_input_backward (gridencoder.cu:245-366) run statement by statement: the same rows touched,
+    sums within fp32 summation order (2e-6 of the largest entry), input gradient from the forward's dy_dx"""
+    import test_grid_golden as gg
+    G = np.load(os.path.join(GOLDEN, "grid_kernels.npz"))
+    gg.check_backward(gg.run_backward(hip.GridBackend, G, tag, dev="cuda"), G, tag)

@@ -55,3 +55,33 @@ def check_forward(got, G, tag):
 @pytest.mark.parametrize("tag", TAGS)
 def test_grid_forward_reproduces_the_reference_text(oracle, G, tag):
     check_forward(run_forward(oracle.GridBackend, G, tag), G, tag)
+
+
+def run_backward(Gb, G, tag, dev="cpu"):
+    D, C, gridtype, ac, interp, L, H = G[f"{tag}_cfg"].tolist()
+    x = torch.from_numpy(G[f"{tag}_x"]).to(dev)
+    emb = torch.from_numpy(table(G, tag)).to(dev)
+    offsets = torch.from_numpy(G[f"{tag}_offsets"]).to(dev)
+    grad = torch.from_numpy(G[f"{tag}_grad"]).to(dev)
+    jac = torch.from_numpy(G[f"{tag}_dy_dx"]).to(dev)
+    B = x.shape[0]
+    g_emb = torch.zeros_like(emb)
+    g_in = torch.zeros(B, D, device=dev)
+    Gb.grid_encode_backward(grad, x, emb, offsets, g_emb, B, D, C, L, float(G[f"{tag}_S"]), H, jac, g_in, gridtype, bool(ac), interp)
+    return g_emb.cpu().numpy(), g_in.cpu().numpy()
+
+
+def check_backward(got, G, tag):
+    g_emb, g_in = got
+    want, win = G[f"{tag}_grad_emb"], G[f"{tag}_grad_inputs"]
+    assert np.array_equal(g_emb == 0, want == 0)          # exactly the rows some in-range point touches
+    # (the reference adds with fp32 atomics in arrival order; the fixture applied them in thread order: rounding of the sums differs)
+    np.testing.assert_allclose(g_emb, want, rtol=0, atol=2e-6 * float(np.abs(want).max()))
+    np.testing.assert_allclose(g_in, win, rtol=0, atol=2e-6 * float(np.abs(win).max()))
+
+
+@pytest.mark.parametrize("tag", ["hash", "smooth", "tiled_ac"])
+def test_grid_backward_within_fp32_summation_order_of_the_reference_text(oracle, G, tag):
+    """kernel_grid_backward (gridencoder.cu:245-337, fp32 branch) and kernel_input_backward (:340-366): the same set of
+    `w * grad` contributions on the same rows, the input gradient from the forward's own dy_dx"""
+    check_backward(run_backward(oracle.GridBackend, G, tag), G, tag)
