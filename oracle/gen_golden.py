@@ -25,8 +25,22 @@ Sections
             `_backend` replaced by the CPU oracle: pins the HOST logic (offset
             tables, padding, counters, zero-init contracts, control flow) that
             the build's wrappers must reproduce.  The native arithmetic under
-            them is the oracle's — for raymarching/gridencoder parity with the
-            CUDA build stays UNPINNED (no reference fixtures exist).
+            them is the oracle's — which the sections int / float / march / grid
+            below anchor on the reference's kernel TEXT.
+  int       raymarching.cu:42-81, gridencoder.cu:50-84 (+ kernel_grid's index
+            lines, kernel_packbits, kernel_near_far_from_aabb) transliterated
+            statement by statement, uint32 / int32 / float32 numpy semantics
+            -> int_kernels.npz (oracle and HIP: bit for bit).
+  float     the three compositing kernels (raymarching.cu:501-684, 821-900) run
+            thread by thread in plain float32 -> float_kernels.npz (1e-4).
+  march     kernel_march_rays_train / kernel_march_rays (:311-478, 701-800) run
+            thread by thread, C typing explicit, nvcc's multiply-add contraction
+            modelled -> march_kernels.npz (oracle and HIP: bit for bit).
+  grid      kernel_grid (gridencoder.cu:87-242) the same way, plus the fp32 branch
+            of the backward kernels (:245-366) -> grid_kernels.npz (forward bit
+            for bit, dy_dx 1e-6, backward within fp32 summation order).
+  tensorf   tensoRF/network.py + tensoRF/utils.py + the Seal steps on the TensoRF
+            backbone, executed -> tensorf.npz.
   train     SURVEY §8(c) golden (11): the reference's own `Trainer.train_step`
             (nerf/utils.py:436-537), `pretrain_step` + `freeze_mlp`
             (SealNeRF/trainer.py:455-488) and `NeRFNetwork.render` (eval,

@@ -8,10 +8,16 @@
  * fast_hash / get_grid_index (:50-84) and the cell / corner-row lines of
  * kernel_grid (:137-149, 165-180) are evaluated from the reference TEXT by
  * oracle/gen_golden.py `int` (tests/golden/int_kernels.npz) and reproduced here
- * bit for bit (tests/test_int_golden.py).  The floating-point interpolation stays
- * PARITY UNPINNED by reference fixtures (none exist; nvcc's
- * contraction choices and CUDA's exp2f cannot be observed here): checked against
- * hand-derived known answers,
+ * bit for bit (tests/test_int_golden.py).  The floating-point half is PINNED TO
+ * THE TEXT UNDER A STATED MODEL: kernel_grid (:87-242, incl. smoothstep and dy_dx)
+ * is run statement by statement with C's typing explicit, exp2f correctly rounded
+ * and every float product that feeds an add fused (nvcc's default -fmad=true;
+ * oracle/gen_golden.py `grid`, tests/golden/grid_kernels.npz) and the fp32 forward
+ * here reproduces it bit for bit on four encoder configurations; the backward
+ * kernels (:245-366) agree in the rows touched and within fp32 summation order
+ * (tests/test_grid_golden.py).  What stays unobservable without nvcc is the
+ * contraction model itself, CUDA's exp2f and the at::Half arithmetic of fp16
+ * tables.  Also checked against hand-derived known answers,
  * finite differences with the reference's own gradcheck tolerances
  * (testing/test_hashgrid_grad.py:58) and the reference's Python wrapper run on
  * top of it (oracle/gen_golden.py).

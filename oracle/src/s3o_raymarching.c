@@ -8,10 +8,19 @@
  * __morton3D_invert and mip_from_pos / mip_from_dt (raymarching.cu:42-81) and the
  * two morton kernels' call lines are evaluated from the reference TEXT by
  * oracle/gen_golden.py `int` (tests/golden/int_kernels.npz) and reproduced here
- * bit for bit (tests/test_int_golden.py).  The rest (DDA stepping, compositing
- * arithmetic) stays PARITY UNPINNED: the reference ships no golden vectors or
- * asserting tests for these functions and its CUDA sources cannot be built in
- * this image; the restatement is checked against hand-derived known answers
+ * bit for bit (tests/test_int_golden.py); so are kernel_packbits and
+ * kernel_near_far_from_aabb.  PINNED TO THE TEXT UNDER A STATED MODEL: both
+ * marchers — kernel_march_rays_train (:311-478) and kernel_march_rays (:701-800) —
+ * are run statement by statement with C's typing explicit and every float product
+ * that feeds an add fused (nvcc's default -fmad=true; oracle/gen_golden.py `march`,
+ * tests/golden/march_kernels.npz), and this file reproduces ray table, counter and
+ * every sample bit for bit (tests/test_march_golden.py); the three compositing
+ * kernels are run in plain float32 (`float`, float_kernels.npz) and reproduced
+ * within 1e-4 relative, integers exact (tests/test_float_golden.py).  What stays
+ * unobservable without nvcc is the contraction model itself and __expf's rounding.
+ * The reference ships no golden vectors or asserting tests for these functions and
+ * its CUDA sources cannot be built in this image; besides the text fixtures the
+ * restatement is checked against hand-derived known answers
  * (tests/test_oracle_raymarching.py) and against the reference's own Python
  * control flow run on top of it (oracle/gen_golden.py).
  *
