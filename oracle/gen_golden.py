@@ -873,20 +873,25 @@ def _c_runtime():
         old = int(ptr[0])
         ptr[0] = old + int(v)
         return old
-    return dict(F32=F32, F64=F64, U32s=lambda v: int(v) & 0xFFFFFFFF, fma=fma, cdiv=cdiv, atomicAdd=atomicAdd, int=int, bool=bool,
+    return dict(F32=F32, F64=F64, H16=np.float16, U32s=lambda v: int(v) & 0xFFFFFFFF, fma=fma, cdiv=cdiv, atomicAdd=atomicAdd, int=int, bool=bool,
                 fminf=lambda a, b: F32(min(F32(a), F32(b))), fmaxf=lambda a, b: F32(max(F32(a), F32(b))), max=max, min=min,
                 scalbnf=lambda x, n: F32(np.ldexp(F32(x), int(n))), copysignf=lambda m, x: F32(np.copysign(F32(m), F32(x))),
                 __expf=lambda x: np.exp(F32(x)))
 
 
 def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="__global__ void", thread_arg=True, lead="n",
-                        int_arrays=(), calls=(), pre=None):
+                        int_arrays=(), calls=(), pre=None, half=False):
     """Transliterate the body of a reference CUDA kernel to a python function `name(n, <parameters>)` that does the work
     of ONE thread (index n).  Handles what the pinned kernels are written in: typed declarations (several per statement),
     assignments / compound assignments, `x++`, pointer bumps, `while (...) {`, `if (...) {` / `} else {`, one-line
     `if (...) break|return;`, `break;`, `return;`, statements continued over several lines.  Scalars are numpy float32 / python
     ints: every binary operation rounds to float32 once — NO multiply-add is fused (nvcc's -fmad contraction is not modelled;
-    the fixtures made this way are compared at the tolerance north_star states, not bit for bit)."""
+    the fixtures made this way are compared at the tolerance north_star states, not bit for bit).
+    `half`: the `scalar_t = at::Half` instantiation.  numpy's float16 scalars already behave like c10::Half (Half op Half: the
+    float32 result rounded to half; Half op float: float32); what C++ adds is `Half += float`, which has no overload of its own
+    and resolves to `operator+=(Half&, const Half&)` through Half's implicit constructor — the right-hand side is ROUNDED TO HALF
+    FIRST, then added and rounded again (c10/util/Half-inl.h) — so a compound assignment to a `scalar_t` variable is emitted as
+    exactly that, and no multiply-add is fused across it."""
     m = re.search(r"%s %s\s*\((.*?)\)\s*\{" % (qualifier, re.escape(name)), src, re.S)
     assert m, name
     params = [p.split()[-1].replace("*", "").strip() for p in m.group(1).split(",") if p.strip()]
@@ -914,7 +919,7 @@ def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="
         e = re.sub(r"(?<![\w.])(\d+\.\d*)f\b", r"F32(\1)", e)
         return e.replace("&&", " and ").replace("||", " or ").strip()
     out, ind = ["def %s(%s%s):" % (name, (lead + ", ") if thread_arg else "", ", ".join(params))], 1
-    ftypes, farrays = set(), set()
+    ftypes, farrays, stypes = set(), set(), set()     # float-typed scalars / arrays; names declared `scalar_t` (half mode)
     for line in lines:
         pad = "    " * ind
         if any(k in line for k in skip):
@@ -938,8 +943,11 @@ def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="
         mm = re.match(r"(?:const )?(uint32_t|int|float|scalar_t) (\w+)\[(\w+)\](?: = \{(.*)\})?;$", line)
         if mm:      # local array: `float pos[D];`, `float pos_deriv[D] = {1.0f};` (remaining elements zero, as in C)
             isf = mm.group(1) in ("float", "scalar_t")
-            zero = "F32(0)" if isf else "0"
-            first = [("F32(%s)" % ex(v) if isf else ex(v)) for v in (mm.group(4).split(",") if mm.group(4) else [])]
+            cv = "H16" if (half and mm.group(1) == "scalar_t") else "F32"
+            if cv == "H16":
+                stypes.add(mm.group(2))
+            zero = (cv + "(0)") if isf else "0"
+            first = [("%s(%s)" % (cv, ex(v)) if isf else ex(v)) for v in (mm.group(4).split(",") if mm.group(4) else [])]
             out.append(pad + "%s = [%s] + [%s] * (%s - %d)" % (mm.group(2), ", ".join(first), zero, mm.group(3), len(first)))
             if isf:
                 farrays.add(mm.group(2))
@@ -972,7 +980,8 @@ def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="
         mm = re.match(r"(?:const )?(uint32_t|int|float|scalar_t|bool) (.*);$", line)
         if mm:
             isf = mm.group(1) in ("float", "scalar_t")
-            conv = {"float": "F32", "scalar_t": "F32", "bool": "bool", "uint32_t": "U32s" if contract is not None else "int"}.get(mm.group(1), "int")
+            conv = {"float": "F32", "scalar_t": "H16" if half else "F32", "bool": "bool",
+                    "uint32_t": "U32s" if contract is not None else "int"}.get(mm.group(1), "int")
             for part in _split_top(mm.group(2)):
                 if "=" not in part:          # `int exponent;`
                     continue
@@ -980,6 +989,8 @@ def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="
                 nm = nm.strip()
                 if isf:
                     ftypes.add(nm)
+                if conv == "H16":
+                    stypes.add(nm)
                 out.append(pad + "%s = %s(%s)" % (nm, conv, ex(e)))
             continue
         mm = re.match(r"(\w+)\+\+;$", line)
@@ -992,10 +1003,14 @@ def _c_kernel_to_python(src, name, pointers, skip=(), contract=None, qualifier="
             if lhs in pointers and op == "+":
                 out.append(pad + "%s = %s + (%s)" % (lhs, lhs, e))
             elif "[" in lhs or lhs in ftypes:
-                rhs = ex("%s %s (%s)" % (lhs, op, mm.group(3))) if op else e
                 base = lhs.split("[")[0]
+                tgt = ex(lhs) if "[" in lhs else lhs
+                if base in stypes:      # at::Half target: `a op= b` is `a = a op Half(b)`, a plain store rounds to half
+                    out.append(pad + ("%s = H16(%s %s H16(%s))" % (tgt, tgt, op, e) if op else "%s = H16(%s)" % (tgt, e)))
+                    continue
+                rhs = ex("%s %s (%s)" % (lhs, op, mm.group(3))) if op else e
                 conv = "int" if ("[" in lhs and base in int_arrays) else "F32"
-                out.append(pad + "%s = %s(%s)" % (ex(lhs) if "[" in lhs else lhs, conv, rhs))
+                out.append(pad + "%s = %s(%s)" % (tgt, conv, rhs))
             else:
                 out.append(pad + "%s %s= %s" % (lhs, op, e))
             continue
@@ -1240,6 +1255,20 @@ def gen_grid():
                     f"{tag}_offsets": offsets.astype(np.int32), f"{tag}_x": x, f"{tag}_emb": emb if tag != "lego" else np.zeros(0, np.float32),
                     f"{tag}_emb_seed": np.int64(zlib.crc32(tag.encode()) + 5), f"{tag}_outputs": outputs, f"{tag}_dy_dx": dy_dx})
         print(f"grid[{tag}]: {L} levels x {B} points, |out| max {np.abs(outputs).max():.3f}")
+        if tag in ("hash", "lego"):
+            # ---- the `-O` instantiation: scalar_t = at::Half (fp16 table, outputs and Jacobian), same points
+            henv = dict(env)
+            exec(_c_kernel_to_python(ge_src, "kernel_grid", ("grid", "inputs", "outputs", "dy_dx"), skip=("blockIdx",), contract=True,
+                                     lead="b, level", int_arrays=("pos_grid", "pos_grid_local"), half=True), henv)
+            emb16 = (emb * np.float32(0.5)).astype(np.float16)
+            out16 = np.full((L, B, C), 7, np.float16)
+            jac16 = np.full((B, L * D * C), 7, np.float16)
+            with np.errstate(all="ignore"):
+                for level in range(L):
+                    for b in range(B):
+                        henv["kernel_grid"](b, level, _Ptr(x.reshape(-1)), _Ptr(emb16.reshape(-1)), offsets.astype(np.int64),
+                                            _Ptr(out16.reshape(-1)), B, L, S, H, _Ptr(jac16.reshape(-1)), gridtype, ac, interp)
+            out.update({f"{tag}_outputs_f16": out16, f"{tag}_dy_dx_f16": jac16})
         if tag == "lego":
             continue
         # ---- kernel_grid_backward (:245-337, the float branch) and kernel_input_backward (:340-366) on the same points

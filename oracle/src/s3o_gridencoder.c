@@ -16,8 +16,9 @@
  * here reproduces it bit for bit on four encoder configurations; the backward
  * kernels (:245-366) agree in the rows touched and within fp32 summation order
  * (tests/test_grid_golden.py).  What stays unobservable without nvcc is the
- * contraction model itself, CUDA's exp2f and the at::Half arithmetic of fp16
- * tables.  Also checked against hand-derived known answers,
+ * contraction model itself and CUDA's exp2f; the at::Half instantiation (fp16
+ * tables, `-O`) is modelled with c10::Half's operator semantics and reproduced
+ * bit for bit as well.  Also checked against hand-derived known answers,
  * finite differences with the reference's own gradcheck tolerances
  * (testing/test_hashgrid_grad.py:58) and the reference's Python wrapper run on
  * top of it (oracle/gen_golden.py).

@@ -509,3 +509,12 @@ def test_grid_backward_within_summation_order_of_the_reference_text(hip, tag):
     import test_grid_golden as gg
     G = np.load(os.path.join(GOLDEN, "grid_kernels.npz"))
     gg.check_backward(gg.run_backward(hip.GridBackend, G, tag, dev="cuda"), G, tag)
+
+
+@pytest.mark.parametrize("tag", ["hash", "lego"])
+def test_grid_forward_fp16_tables_reproduce_the_reference_text(hip, tag):
+    """the `-O` instantiation of kernel_grid (scalar_t = at::Half, c10::Half's operator semantics modelled): fp16 outputs of the HIP
+    forward bit for bit, on the small hash configuration and on the Lego table"""
+    import test_grid_golden as gg
+    G = np.load(os.path.join(GOLDEN, "grid_kernels.npz"))
+    gg.check_forward_f16(gg.run_forward_f16(hip.GridBackend, G, tag, dev="cuda"), G, tag)

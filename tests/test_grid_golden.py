@@ -85,3 +85,31 @@ def test_grid_backward_within_fp32_summation_order_of_the_reference_text(oracle,
     """kernel_grid_backward (gridencoder.cu:245-337, fp32 branch) and kernel_input_backward (:340-366): the same set of
     `w * grad` contributions on the same rows, the input gradient from the forward's own dy_dx"""
     check_backward(run_backward(oracle.GridBackend, G, tag), G, tag)
+
+
+def run_forward_f16(Gb, G, tag, dev="cpu"):
+    D, C, gridtype, ac, interp, L, H = G[f"{tag}_cfg"].tolist()
+    x = torch.from_numpy(G[f"{tag}_x"]).to(dev)
+    emb = torch.from_numpy((table(G, tag) * np.float32(0.5)).astype(np.float16)).to(dev)   # (as the generator made the fp16 table)
+    offsets = torch.from_numpy(G[f"{tag}_offsets"]).to(dev)
+    B = x.shape[0]
+    out = torch.full((L, B, C), 7.0, dtype=torch.float16, device=dev)
+    jac = torch.full((B, L * D * C), 7.0, dtype=torch.float16, device=dev)
+    Gb.grid_encode_forward(x, emb, offsets, out, B, D, C, L, float(G[f"{tag}_S"]), H, jac, gridtype, bool(ac), interp)
+    return out.cpu().numpy(), jac.cpu().numpy()
+
+
+def check_forward_f16(got, G, tag):
+    out, jac = got
+    want, wjac = G[f"{tag}_outputs_f16"], G[f"{tag}_dy_dx_f16"]
+    bad = np.argwhere(out.view(np.uint16) != want.view(np.uint16))
+    assert bad.size == 0, (tag, len(bad), bad[:5], out[tuple(bad[0])], want[tuple(bad[0])])
+    assert np.abs(want.astype(np.float32)).max() > 0.2
+    np.testing.assert_allclose(jac.astype(np.float32), wjac.astype(np.float32), rtol=0, atol=2e-3 * float(np.abs(wjac.astype(np.float32)).max()))
+
+
+@pytest.mark.parametrize("tag", ["hash", "lego"])
+def test_grid_forward_fp16_tables_reproduce_the_reference_text(oracle, G, tag):
+    """the `-O` instantiation (scalar_t = at::Half): every `results[ch] += w * grid[..]` rounds the product to half and the sum
+    to half (c10::Half has no `Half += float`: the right-hand side goes through Half's constructor) — outputs bit for bit"""
+    check_forward_f16(run_forward_f16(oracle.GridBackend, G, tag), G, tag)
