@@ -171,7 +171,7 @@ class _FFMLPNgpMid(Function):
         if not inference:
             ctx.save_for_backward(inputs, weights, h0)
             ctx.dims, ctx.extra, ctx.param_ref = dims, extra, param_ref
-            ctx.calc_grad_inputs = inputs.requires_grad
+            ctx.calc_grad_inputs = ctx.needs_input_grad[0]  # (not `inputs.requires_grad`: a cast above would hide it)
             ctx.set_materialize_grads(False)
         return sigma, cin
 
@@ -223,7 +223,7 @@ class _FFMLPNgpPair(Function):
         ctx.save_for_backward(inputs, w_sigma, w_color, h0, cin, rgb)
         ctx.dims_s, ctx.dims_c, ctx.refs = dims_s, dims_c, refs
         ctx.extra = dict(({"input_layout": input_layout} if input_layout else {}), **({"n_valid": n_valid} if n_valid is not None else {}))
-        ctx.calc_grad_inputs = inputs.requires_grad
+        ctx.calc_grad_inputs = ctx.needs_input_grad[0]  # (not `inputs.requires_grad`: a cast above would hide it)
         ctx.set_materialize_grads(False)
         return sigma, rgb
 

@@ -33,7 +33,7 @@ class _SealMid(Function):
         _head.mid2_forward(h, dirs, enc_color, sigma, cin, n_valid)
         ctx.save_for_backward(h)
         ctx.n_valid = n_valid
-        ctx.enc_grad = enc_color.requires_grad
+        ctx.enc_grad = ctx.needs_input_grad[2]
         return sigma, cin
 
     @staticmethod
@@ -71,7 +71,8 @@ class _SealPair(Function):
         if keep:
             ctx.save_for_backward(e0, w_sigma, w_color, h0, cin, rgb)
             ctx.refs, ctx.n_valid = refs, n_valid
-            ctx.need = (e0.requires_grad, e1.requires_grad)
+            # (asked of autograd, not of the tensors: a cast made above under no-grad would hide an fp32 input's flag)
+            ctx.need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
             ctx.set_materialize_grads(False)
         return sigma, rgb
 
