@@ -1272,6 +1272,15 @@ __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<uin
 template <uint32_t N, typename F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<uint32_t, N>{}); }
 
+#ifdef S3D_FFMLP_PROF  // shader-clock stamps of one pair of one workgroup of k_ffmlp_backward_duo: tools/prof_duo.py only
+#ifndef S3D_FFMLP_PROF_BLOCK
+#define S3D_FFMLP_PROF_BLOCK 7
+#endif
+__device__ unsigned long long s3d_ffmlp_prof[2][1024];
+#define DUO_STAMP() do { if (prof_on && prof_k < 1024) s3d_ffmlp_prof[role][prof_k++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DUO_STAMP() do { } while (0)
+#endif
 // ------------------------------------------------------------------------------------ backward: fused, two roles
 // The fused kernel above runs ONE 456-register wave per SIMD: nothing hides the latencies of its MFMA chains, conversions and
 // LDS round trips, and it spends ~70 % of a launch in the re-computation + data-gradient chain and ~30 % in the weight-gradient
@@ -1299,6 +1308,10 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
     const uint32_t KS0 = KS0T ? (uint32_t)KS0T : in_dim / 16;
     const uint32_t nf_f0 = MB * KS0, nf_fh = NH * MB * KS;
     const uint32_t nf_bl = MB, nf_bh = NH * MB * KS, nf_b0 = grad_inputs ? IMB * KS : 0;
+#ifdef S3D_FFMLP_PROF
+    uint32_t prof_k = 0;
+    const bool prof_on = NH == S3D_FFMLP_PROF && blockIdx.x == S3D_FFMLP_PROF_BLOCK && pair == 0 && lane == 0;  // -DS3D_FFMLP_PROF=<hidden matrices of the network to stamp>
+#endif
     const uint32_t nfrag = nf_f0 + nf_fh + nf_bl + nf_bh + nf_b0;
     half8* frags = reinterpret_cast<half8*>(smem_raw);
     half8* ff0 = frags;
@@ -1366,6 +1379,7 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
             half8 a[NH + 1][KS];
             float16v acc[MB];
             half8 G[KS];
+            DUO_STAMP();  // 0: top of the tile
             if (live) {
 #pragma unroll
                 for (uint32_t s = 0; s < 4; s++)
@@ -1394,6 +1408,7 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
 #pragma unroll
                         for (uint32_t m = 0; m < MB; m++) acc[m] = mfma(ff0[(m * KS0 + s) * 64 + lane], xf[s], acc[m]);
                     }
+                DUO_STAMP();  // 1: inputs arrived, layer 0 issued
 #pragma unroll
                 for (uint32_t layer = 0; layer <= (uint32_t)NH; layer++) {
 #pragma unroll
@@ -1422,6 +1437,7 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
                         }
                     }
                 }
+                DUO_STAMP();  // 2: forward re-computed
                 // stage 0: tiles of the last layer, then through it
                 _Float16* T = slot_of(i, 0);
                 const half8 gtmp[1] = {gf};
@@ -1430,7 +1446,9 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
 #pragma unroll
                 for (uint32_t m = 0; m < MB; m++) acc[m] = mfma(fbl[m * 64 + lane], gf, zero16());
             }
+            DUO_STAMP();  // 3: stage 0 produced
             __syncthreads();
+            DUO_STAMP();  // 4: past the barrier
 #pragma unroll
             for (int k = NH; k >= 0; k--) {
                 const uint32_t st = (uint32_t)(NH - k) + 1;
@@ -1487,7 +1505,9 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
                         }
                     }
                 }
+                DUO_STAMP();  // 5 + 2j: stage produced
                 __syncthreads();
+                DUO_STAMP();  // 6 + 2j: past the barrier
             }
         }
         if (nit) __syncthreads();  // the partner's draining stage
@@ -1547,10 +1567,14 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
             }
         };
         for (uint32_t i = 0; i < nit; i++) {
+            DUO_STAMP();
             if (i > 0) consume(i - 1, std::integral_constant<uint32_t, NS - 1>{});
+            DUO_STAMP();
             __syncthreads();
             static_for<NS - 1>([&](auto stc) {
+                DUO_STAMP();
                 consume(i, stc);
+                DUO_STAMP();
                 __syncthreads();
             });
         }
@@ -2005,3 +2029,16 @@ S3D_EXPORT int s3d_ffmlp_fused_backward_supported(uint32_t input_dim, uint32_t o
 
 S3D_EXPORT int s3d_ffmlp_allocate_splitk(size_t n) { (void)n; return S3D_OK; }
 S3D_EXPORT int s3d_ffmlp_free_splitk(void) { return S3D_OK; }
+
+#ifdef S3D_FFMLP_PROF
+S3D_EXPORT int s3d_debug_ffmlp_prof_read(unsigned long long* dst, int clear) {
+    if (hipDeviceSynchronize() != hipSuccess) return S3D_ERR_HIP;
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(s3d_ffmlp_prof), sizeof(unsigned long long) * 2 * 1024) != hipSuccess) return S3D_ERR_HIP;
+    if (clear) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(s3d_ffmlp_prof)) != hipSuccess) return S3D_ERR_HIP;
+        if (hipMemset(p, 0, sizeof(unsigned long long) * 2 * 1024) != hipSuccess) return S3D_ERR_HIP;
+    }
+    return S3D_OK;
+}
+#endif
