@@ -129,6 +129,20 @@ int s3d_composite_rays_train_backward(const float* grad_weights_sum, const float
                                       uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas,
                                       float* grad_rgbs, int path, s3d_stream_t stream);
 
+/* Build extension — s3d_composite_rays_train_forward, s3d_bg_mse_forward(grad_loss) and s3d_composite_rays_train_backward of
+ * one training ray batch as ONE launch (raymarching.py:238-291 + nerf/renderer.py:316 + nerf/utils.py:484-489): the wave that
+ * composites a ray forms that ray's loss gradient (k = *grad_loss * 2 / (3N), the announced upstream gradient of the loss) and
+ * walks its samples again for grad_sigmas / grad_rgbs; the loss value is summed by a one-workgroup launch behind it in
+ * s3d_bg_mse_forward's order (two launches instead of three, the second off the backward's critical data).  Every output equals
+ * the three-call sequence (wave-per-ray paths) bit for bit.  gt [N,3], bg_rgb = 3 HOST floats, gt_depth [N] or NULL (value-only
+ * depth term), grad_image [N,3] / grad_weights_sum [N]: optional outputs (both or neither), workspace: 4N floats (scratch). */
+int s3d_composite_rays_train_loss(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                  uint32_t M, uint32_t N, float T_thresh, const float* gt, const float* bg_rgb,
+                                  const float* grad_loss, const float* gt_depth, float depth_weight,
+                                  float* weights_sum, float* depth, float* image, float* grad_sigmas, float* grad_rgbs,
+                                  float* grad_image, float* grad_weights_sum, float* loss, float* workspace,
+                                  s3d_stream_t stream);
+
 /* raymarching.h:17 void march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma,
  *                       max_steps, C, H, grid, nears, fars, xyzs, dirs, deltas, noises)
  * noises may be NULL (= all zero: no perturbation).  zero_unfilled (build extension): the reference's wrapper zero-fills

@@ -970,15 +970,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__global__ void __launch_bounds__(256) k_composite_train_fwd_wave(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
-                                                                 const float* __restrict__ deltas, const int32_t* __restrict__ rays,
-                                                                 uint32_t M, uint32_t N, float T_thresh,
-                                                                 float* __restrict__ weights_sum, float* __restrict__ depth,
-                                                                 float* __restrict__ image) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
-    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+struct RayPixel { float r, g, b, ws, depth; };
+// forward of one ray by one wave; every lane returns the same (butterfly-summed) pixel
+__device__ __forceinline__ RayPixel composite_ray_fwd_wave(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                          const float* __restrict__ deltas, uint32_t offset, uint32_t num_steps,
+                                                          uint32_t M, float T_thresh, uint32_t lane) {
     float r = 0, g = 0, b = 0, ws = 0, dsum = 0;
     if (num_steps != 0 && offset + num_steps <= M) {
         float T_carry = 1.0f, t_carry = 0.0f;
@@ -1004,30 +1000,35 @@ __global__ void __launch_bounds__(256) k_composite_train_fwd_wave(const float* _
         }
         r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); ws = wave_sum(ws); dsum = wave_sum(dsum);
     }
-    if (lane == 0) {
-        weights_sum[index] = ws; depth[index] = dsum;
-        image[index * 3] = r; image[index * 3 + 1] = g; image[index * 3 + 2] = b;
-    }
+    return RayPixel{r, g, b, ws, dsum};
 }
 
-__global__ void __launch_bounds__(256) k_composite_train_bwd_wave(const float* __restrict__ grad_weights_sum,
-                                                                 const float* __restrict__ grad_image,
-                                                                 const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+__global__ void __launch_bounds__(256) k_composite_train_fwd_wave(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
                                                                  const float* __restrict__ deltas, const int32_t* __restrict__ rays,
-                                                                 const float* __restrict__ weights_sum,
-                                                                 const float* __restrict__ image, uint32_t M, uint32_t N,
-                                                                 float T_thresh, float* __restrict__ grad_sigmas,
-                                                                 float* __restrict__ grad_rgbs) {
+                                                                 uint32_t M, uint32_t N, float T_thresh,
+                                                                 float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                                 float* __restrict__ image) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    const RayPixel px = composite_ray_fwd_wave(sigmas, rgbs, deltas, offset, num_steps, M, T_thresh, lane);
+    if (lane == 0) {
+        weights_sum[index] = px.ws; depth[index] = px.depth;
+        image[index * 3] = px.r; image[index * 3 + 1] = px.g; image[index * 3 + 2] = px.b;
+    }
+}
+
+// backward of ray n by one wave (gws, gi*: the gradient of its pixel; rf, gf, bf, wsf: the pixel)
+__device__ __forceinline__ void composite_ray_bwd_wave(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                       const float* __restrict__ deltas, uint32_t n, uint32_t offset,
+                                                       uint32_t num_steps, uint32_t M, uint32_t N, float T_thresh, float gws,
+                                                       float gi0, float gi1, float gi2, float rf, float gf, float bf, float wsf,
+                                                       float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs,
+                                                       uint32_t lane) {
     if (n == N - 1 && offset + num_steps < M) zero_grad_rows(grad_sigmas, grad_rgbs, offset + num_steps, pad_end(offset + num_steps, M), lane, 64);
     if (num_steps != 0 && offset < M && offset + num_steps > M) zero_grad_rows(grad_sigmas, grad_rgbs, offset, M, lane, 64);
     if (num_steps == 0 || offset + num_steps > M) return;
-    const float gws = grad_weights_sum[index];
-    const float gi0 = grad_image[index * 3], gi1 = grad_image[index * 3 + 1], gi2 = grad_image[index * 3 + 2];
-    const float rf = image[index * 3], gf = image[index * 3 + 1], bf = image[index * 3 + 2], wsf = weights_sum[index];
     float T_carry = 1.0f, rc = 0, gc = 0, bc = 0;  // running composites up to the previous chunk
     for (uint32_t base = 0; base < num_steps; base += 64) {
         const uint32_t i = base + lane;
@@ -1062,6 +1063,104 @@ __global__ void __launch_bounds__(256) k_composite_train_bwd_wave(const float* _
             zero_grad_rows(grad_sigmas, grad_rgbs, offset + base + 64, offset + num_steps, lane, 64);
             break;
         }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_composite_train_bwd_wave(const float* __restrict__ grad_weights_sum,
+                                                                 const float* __restrict__ grad_image,
+                                                                 const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                 const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+                                                                 const float* __restrict__ weights_sum,
+                                                                 const float* __restrict__ image, uint32_t M, uint32_t N,
+                                                                 float T_thresh, float* __restrict__ grad_sigmas,
+                                                                 float* __restrict__ grad_rgbs) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+    composite_ray_bwd_wave(sigmas, rgbs, deltas, n, offset, num_steps, M, N, T_thresh, grad_weights_sum[index], grad_image[index * 3],
+                           grad_image[index * 3 + 1], grad_image[index * 3 + 2], image[index * 3], image[index * 3 + 1],
+                           image[index * 3 + 2], weights_sum[index], grad_sigmas, grad_rgbs, lane);
+}
+
+// ---- compositing, background + MSE criterion and the compositing backward of one training ray batch in ONE launch
+// (k_composite_train_fwd_wave -> ngp_head.hip:k_bg_mse_forward with its announced upstream gradient -> k_composite_train_bwd_wave:
+// three launches of ~8 us each for 4,096 rays, all three bound by their launch and one pass of latencies).  The gradient of a mean
+// of squared errors w.r.t. a ray's pixel needs that ray alone, so the wave that composited a ray goes straight on to its
+// backward (its samples are in L2); only the loss VALUE needs every ray: each wave files its three squared errors (and the depth
+// term) and a one-workgroup launch behind this one adds them in k_bg_mse_forward's order — thread t of 1,024 takes rays t,
+// t + 1,024, ..., butterfly per 64, sixteen partials in sequence — so loss, pixel and gradients equal the three-launch sequence
+// bit for bit.  (Measured first with the sum inside this kernel, by the last workgroup to take a ticket: 80 us instead of ~12 —
+// 1,024 workgroups each paying an agent-scope release, i.e. an L2 write-back, and queueing on one ticket word.)
+// work: [3N squared errors | N depth terms]
+__global__ void __launch_bounds__(256) k_composite_train_loss_wave(
+    const float* __restrict__ sigmas, const float* __restrict__ rgbs, const float* __restrict__ deltas, const int32_t* __restrict__ rays,
+    uint32_t M, uint32_t N, float T_thresh, const float* __restrict__ gt, float bg0, float bg1, float bg2,
+    const float* __restrict__ grad_loss, const float* __restrict__ gt_depth, float depth_weight, float* __restrict__ weights_sum,
+    float* __restrict__ depth, float* __restrict__ image, float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs,
+    float* __restrict__ grad_image, float* __restrict__ grad_ws, float* __restrict__ work) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    float* sq = work;
+    float* dabs = work + (size_t)3 * N;
+    if (n >= N) return;
+    {
+        const uint32_t index = (uint32_t)rays[n * 3], offset = (uint32_t)rays[n * 3 + 1], num_steps = (uint32_t)rays[n * 3 + 2];
+        const RayPixel px = composite_ray_fwd_wave(sigmas, rgbs, deltas, offset, num_steps, M, T_thresh, lane);
+        // ngp_head.hip:k_bg_mse_forward for this ray
+        const float bg[3] = {bg0, bg1, bg2};
+        const float pix[3] = {px.r, px.g, px.b};
+        const float k = *grad_loss * (2.0f / (3.0f * (float)N));
+        const float w = 1.0f - px.ws;
+        float gd[3], gw = 0.0f, dd[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float d = (pix[c] + w * bg[c]) - gt[(size_t)index * 3 + c];
+            dd[c] = d * d;
+            gd[c] = k * d;
+            gw -= gd[c] * bg[c];
+        }
+        if (lane == 0) {
+            weights_sum[index] = px.ws; depth[index] = px.depth;
+            image[index * 3] = px.r; image[index * 3 + 1] = px.g; image[index * 3 + 2] = px.b;
+            sq[(size_t)index * 3] = dd[0]; sq[(size_t)index * 3 + 1] = dd[1]; sq[(size_t)index * 3 + 2] = dd[2];
+            if (gt_depth) {
+                float dv = px.depth;
+                dv = dv != dv ? 0.0f : fminf(fmaxf(dv, -3.402823466e38f), 3.402823466e38f);  // torch.nan_to_num(nan=0.)
+                dabs[index] = fabsf(dv - gt_depth[index]);
+            }
+            if (grad_image) {
+                grad_image[(size_t)index * 3] = gd[0]; grad_image[(size_t)index * 3 + 1] = gd[1]; grad_image[(size_t)index * 3 + 2] = gd[2];
+                grad_ws[index] = gw;
+            }
+        }
+        composite_ray_bwd_wave(sigmas, rgbs, deltas, n, offset, num_steps, M, N, T_thresh, gw, gd[0], gd[1], gd[2], px.r, px.g, px.b,
+                               px.ws, grad_sigmas, grad_rgbs, lane);
+    }
+}
+
+// the value of the criterion from the terms k_composite_train_loss_wave filed, in k_bg_mse_forward's order of additions (one
+// workgroup, thread t takes rays t, t + 1,024, ...)
+__global__ void __launch_bounds__(1024) k_bg_mse_reduce(const float* __restrict__ sq, const float* __restrict__ dabs, uint32_t N,
+                                                        float depth_weight, float* __restrict__ loss) {
+    __shared__ float part[16], dpart[16];
+    float acc = 0.0f, dacc = 0.0f;
+    for (uint32_t m = threadIdx.x; m < N; m += 1024) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc += sq[(size_t)m * 3 + c];
+    }
+    if (dabs)
+        for (uint32_t m = threadIdx.x; m < N; m += 1024) dacc += dabs[m];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { acc += __shfl_xor(acc, d, 64); dacc += __shfl_xor(dacc, d, 64); }
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = acc; dpart[threadIdx.x >> 6] = dacc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f, td = 0.0f;
+        for (int w = 0; w < 16; w++) { t += part[w]; td += dpart[w]; }
+        t = t / (3.0f * (float)N);
+        if (dabs) t = t + depth_weight * (td / (float)N);
+        *loss = t;
     }
 }
 
@@ -1581,6 +1680,26 @@ S3D_EXPORT int s3d_composite_rays_train_backward(const float* grad_weights_sum, 
                            grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh,
                            grad_sigmas, grad_rgbs);
     return check_launch("composite_rays_train_backward");
+}
+
+S3D_EXPORT int s3d_composite_rays_train_loss(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                             uint32_t M, uint32_t N, float T_thresh, const float* gt, const float* bg_rgb,
+                                             const float* grad_loss, const float* gt_depth, float depth_weight,
+                                             float* weights_sum, float* depth, float* image, float* grad_sigmas, float* grad_rgbs,
+                                             float* grad_image, float* grad_weights_sum, float* loss, float* workspace,
+                                             s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(rays && weights_sum && depth && image && gt && bg_rgb && grad_loss && loss && workspace,
+                "composite_rays_train_loss: null pointer");
+    S3D_REQUIRE(M == 0 || (sigmas && rgbs && deltas && grad_sigmas && grad_rgbs), "composite_rays_train_loss: null sample buffer");
+    S3D_REQUIRE((grad_image == nullptr) == (grad_weights_sum == nullptr), "composite_rays_train_loss: grad_image and grad_weights_sum "
+                "come together");
+    hipLaunchKernelGGL(k_composite_train_loss_wave, dim3(div_up<uint32_t>(N, 4)), dim3(256), 0, as_stream(stream), sigmas, rgbs, deltas,
+                       rays, M, N, T_thresh, gt, bg_rgb[0], bg_rgb[1], bg_rgb[2], grad_loss, gt_depth, depth_weight, weights_sum, depth,
+                       image, grad_sigmas, grad_rgbs, grad_image, grad_weights_sum, workspace);
+    hipLaunchKernelGGL(k_bg_mse_reduce, dim3(1), dim3(1024), 0, as_stream(stream), (const float*)workspace,
+                       gt_depth ? (const float*)(workspace + (size_t)3 * N) : nullptr, N, depth_weight, loss);
+    return check_launch("composite_rays_train_loss");
 }
 
 S3D_EXPORT int s3d_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,

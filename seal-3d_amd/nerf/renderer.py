@@ -191,8 +191,16 @@ class NeRFRenderer(nn.Module):
             if self.density_scale != 1:  # (x1 is the identity: skip the pass over [M])
                 sigmas = self.density_scale * sigmas
             rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)
-            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh,
-                                                                         *(() if not lean else (False,)))
+            fused = kwargs.get("fused_loss")  # (nerf/trainer.py: the criterion and its gradient inside the compositing launch)
+            if (fused is not None and kwargs.get("defer_background", False) and not torch.is_tensor(bg_color)
+                    and sigmas.is_cuda and fused.get("expected_grad") is not None):
+                bg3 = (float(bg_color),) * 3 if not isinstance(bg_color, (tuple, list)) else tuple(float(v) for v in bg_color)
+                results["loss"], weights_sum, depth, image = raymarching.composite_rays_train_loss(
+                    sigmas, rgbs, deltas, rays, T_thresh, fused["gt"], bg3, fused["expected_grad"], fused.get("workspace"),
+                    fused.get("gt_depth"), fused.get("depth_weight", 1.0), not lean)
+            else:
+                weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh,
+                                                                             *(() if not lean else (False,)))
             if kwargs.get("defer_background", False) and not torch.is_tensor(bg_color):
                 # the caller composites the background inside its fused loss kernel (nerf/trainer.py:bg_mse_loss)
                 results["premultiplied"] = True

@@ -56,6 +56,8 @@ class _BgMse(torch.autograd.Function):
 def render_loss(out, gt_rgb, expected_grad=None, gt_depth=None, depth_weight=1.0):
     """MSE between the rendered batch and the targets (+ Seal-3D's L1 depth term when `gt_depth` is given); uses the fused
     kernel when the renderer deferred the background (`expected_grad`: see _BgMse.forward)"""
+    if "loss" in out:  # the renderer's compositing launch formed the criterion itself (Trainer._fused_loss -> render(fused_loss=...))
+        return out["loss"]
     if out.get("premultiplied", False):
         bg = out["bg_color"]
         bg = (float(bg),) * 3 if not isinstance(bg, (tuple, list)) else tuple(float(v) for v in bg)
@@ -149,11 +151,22 @@ class Trainer:
         self.optimizer.zero_grad(set_to_none=self.dist is None)
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             out = model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False,
-                               defer_background=self.native_optim, **self.render_kwargs)
+                               defer_background=self.native_optim, fused_loss=self._fused_loss(gt_rgb), **self.render_kwargs)
             loss = self._regularized(render_loss(out, gt_rgb, self._expected_grad()))
         self._backward(loss)
         self._reduce_and_step()
         return loss.detach()
+
+    fused_losses = True  # GPU + native optimizer: one-launch criteria (False: the unfused sequences, A/B runs and parity tests)
+
+    def _fused_loss(self, gt_rgb, gt_depth=None, depth_weight=1.0):
+        """`fused_loss=` of NeRFRenderer.run_cuda: targets and the loss's announced upstream gradient for
+        raymarching.composite_rays_train_loss — compositing, criterion and compositing backward as one launch.
+        None where the step has no announced gradient (torch's GradScaler) or the fusion is switched off."""
+        g = self._expected_grad()
+        if g is None or not self.fused_losses or not self.native_optim or not gt_rgb.is_cuda:
+            return None
+        return dict(gt=gt_rgb, expected_grad=g, gt_depth=gt_depth, depth_weight=depth_weight)
 
     def _regularizer(self):
         """extra loss term of a backbone's trainer (TensoRF: `density_loss() * l1_reg_weight`, tensoRF/utils.py:42-49); None: none"""
@@ -252,7 +265,7 @@ class GraphedTrainer(Trainer):
         """the step's loss on the static input buffers (subclasses: other criteria, e.g. Seal's depth term)"""
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             out = self.model.render(self.s_ro, self.s_rd, bg_color=1, perturb=True, force_all_rays=False,
-                                    defer_background=self.native_optim, **self.render_kwargs)
+                                    defer_background=self.native_optim, fused_loss=self._fused_loss(self.s_gt), **self.render_kwargs)
             return self._regularized(render_loss(out, self.s_gt, self._expected_grad()))
 
     def _body_fb(self):

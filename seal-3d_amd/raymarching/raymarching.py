@@ -27,7 +27,7 @@ def _zeros_332(M, dtype, device):
     return flat[:3 * M].view(M, 3), flat[3 * M:6 * M].view(M, 3), flat[6 * M:].view(M, 2)
 
 __all__ = ["near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
-           "composite_rays_train", "march_rays", "composite_rays", "compact_rays_alive"]
+           "composite_rays_train", "composite_rays_train_loss", "march_rays", "composite_rays", "compact_rays_alive"]
 
 
 def _on_device(t):
@@ -241,6 +241,80 @@ class _CompositeRaysTrain(Function):
 
 
 composite_rays_train = _CompositeRaysTrain.apply
+
+
+class _CompositeRaysTrainLoss(Function):
+    """Build extension (HIP backend): composite_rays_train, the background + MSE criterion of the training step
+    (nerf/renderer.py:316 `image + (1 - weights_sum) * bg_color`, nerf/utils.py:484-489) and composite_rays_train's backward for
+    the loss's ANNOUNCED upstream gradient `expected_grad` (the loss scale under GradScaler) in one launch, plus a one-workgroup
+    sum of the loss terms (seal3d_hip.h: s3d_composite_rays_train_loss).  Returns (loss, weights_sum, depth, image).  backward() hands out the
+    gradients the forward launch wrote when it receives exactly that tensor as the loss's gradient and nothing else; any other
+    use takes the unfused kernels."""
+
+    @staticmethod
+    @custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+    def forward(ctx, sigmas, rgbs, deltas, rays, T_thresh, gt, bg, expected_grad, workspace=None, gt_depth=None, depth_weight=1.0,
+                zero_grads=True):
+        sigmas, rgbs, deltas = sigmas.float().contiguous(), rgbs.float().contiguous(), deltas.contiguous()
+        gt = gt.float().contiguous().view(-1, 3)
+        M, N = sigmas.shape[0], rays.shape[0]
+        dev = sigmas.device
+        weights_sum = torch.empty(N, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        image = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        # zero_grads=False: as for composite_rays_train — the kernel zeroes the rows a count-bounded consumer still reads itself
+        flat = (torch.zeros if zero_grads else torch.empty)(4 * M, dtype=torch.float32, device=dev)
+        grad_sigmas, grad_rgbs = flat[:M], flat[M:].view(M, 3)
+        if workspace is None:
+            workspace = torch.empty(4 * N, dtype=torch.float32, device=dev)
+        if gt_depth is not None:
+            gt_depth = gt_depth.float().contiguous().view(-1)
+        _backend.composite_rays_train_loss(sigmas, rgbs, deltas, rays, M, N, T_thresh, gt, bg, expected_grad, weights_sum, depth,
+                                           image, grad_sigmas, grad_rgbs, loss, workspace, gt_depth=gt_depth,
+                                           depth_weight=float(depth_weight))
+        ctx.pre = (grad_sigmas, grad_rgbs, expected_grad.data_ptr(), expected_grad._version)
+        ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, image, gt)
+        ctx.dims = (M, N, T_thresh, bg)
+        ctx.set_materialize_grads(False)
+        return loss, weights_sum, depth, image
+
+    @staticmethod
+    @custom_bwd(device_type="cuda")
+    def backward(ctx, g_loss, g_ws, g_depth, g_image):
+        none = (None,) * 10
+        if g_loss is None and g_ws is None and g_image is None:
+            return (None, None) + none
+        if (g_ws is None and g_image is None and g_loss is not None and g_loss.dtype == torch.float32
+                and g_loss.data_ptr() == ctx.pre[2] and g_loss._version == ctx.pre[3]):
+            return (ctx.pre[0], ctx.pre[1]) + none  # (the announced upstream gradient: already computed)
+        sigmas, rgbs, deltas, rays, weights_sum, image, gt = ctx.saved_tensors
+        M, N, T_thresh, bg = ctx.dims
+        gi, gw = torch.zeros_like(image), torch.zeros_like(weights_sum)
+        if g_loss is not None:
+            _head().bg_mse_backward(image, weights_sum, gt, bg, g_loss.float().contiguous(), gi, gw)
+        if g_image is not None:
+            gi = gi + g_image
+        if g_ws is not None:
+            gw = gw + g_ws
+        flat = torch.zeros(4 * M, dtype=torch.float32, device=sigmas.device)
+        grad_sigmas, grad_rgbs = flat[:M], flat[M:].view(M, 3)
+        _backend.composite_rays_train_backward(gw.contiguous(), gi.contiguous(), sigmas, rgbs, deltas, rays, weights_sum, image, M, N,
+                                               T_thresh, grad_sigmas, grad_rgbs)
+        return (grad_sigmas, grad_rgbs) + none
+
+
+def _head():
+    import s3d_hip
+    return s3d_hip.NgpHeadBackend
+
+
+def composite_rays_train_loss(sigmas, rgbs, deltas, rays, T_thresh, gt, bg, expected_grad, workspace=None, gt_depth=None,
+                              depth_weight=1.0, zero_grads=True):
+    if not hasattr(_backend, "composite_rays_train_loss"):
+        raise RuntimeError("composite_rays_train_loss: the active raymarching backend has no fused loss launch")
+    return _CompositeRaysTrainLoss.apply(sigmas, rgbs, deltas, rays, T_thresh, gt, bg, expected_grad, workspace, gt_depth, depth_weight,
+                                         zero_grads)
 
 
 class _MarchRays(Function):

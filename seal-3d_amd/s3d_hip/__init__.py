@@ -30,7 +30,7 @@ EXPORTS = [
     "s3d_near_far_from_aabb", "s3d_sph_from_ray", "s3d_morton3D", "s3d_morton3D_invert", "s3d_mip_levels", "s3d_packbits",
     "s3d_march_rays_train_workspace_size", "s3d_march_rays_train",
     "s3d_sweep_draw", "s3d_sweep_update_workspace_size", "s3d_sweep_update",
-    "s3d_composite_rays_train_forward", "s3d_composite_rays_train_backward",
+    "s3d_composite_rays_train_forward", "s3d_composite_rays_train_backward", "s3d_composite_rays_train_loss",
     "s3d_march_rays", "s3d_composite_rays", "s3d_compact_alive_workspace_size", "s3d_compact_alive",
     "s3d_grid_level_scales", "s3d_grid_encode_forward", "s3d_grid_encode_forward_pair", "s3d_grid_corner_indices", "s3d_grid_encode_backward",
     "s3d_grid_encode_backward_workspace_size", "s3d_grid_encode_backward_control_size",
@@ -374,6 +374,31 @@ class RaymarchingBackend:
                                                        _u(N), _f(T_thresh), _p(grad_sigmas), _p(grad_rgbs),
                                                        C.c_int(RaymarchingBackend._composite_path), _stream()),
                "composite_rays_train_backward")
+
+    @staticmethod
+    def composite_rays_train_loss(sigmas, rgbs, deltas, rays, M, N, T_thresh, gt, bg_rgb, grad_loss, weights_sum, depth, image,
+                                  grad_sigmas, grad_rgbs, loss, workspace, gt_depth=None, depth_weight=1.0, grad_image=None,
+                                  grad_weights_sum=None):
+        """composite forward + background / MSE loss (announced upstream gradient `grad_loss`) + composite backward of one ray batch
+        in one launch + a one-workgroup sum of the loss terms (seal3d_hip.h); workspace: 4N floats of scratch"""
+        for t, n in ((sigmas, "sigmas"), (rgbs, "rgbs"), (deltas, "deltas"), (gt, "gt"), (grad_loss, "grad_loss"), (loss, "loss"),
+                     (workspace, "workspace"), (grad_sigmas, "grad_sigmas"), (grad_rgbs, "grad_rgbs")):
+            _need(t, torch.float32, n)
+        if gt.numel() != 3 * N or workspace.numel() < 4 * N or grad_sigmas.numel() < M or grad_rgbs.numel() < 3 * M:
+            raise RuntimeError("composite_rays_train_loss: gt [N,3], workspace >= 4N floats, grad_sigmas [M], grad_rgbs [M,3]")
+        if gt_depth is not None:
+            _need(gt_depth, torch.float32, "gt_depth")
+            if gt_depth.numel() != N:
+                raise RuntimeError("composite_rays_train_loss: gt_depth holds one value per ray")
+        if (grad_image is None) != (grad_weights_sum is None):
+            raise RuntimeError("composite_rays_train_loss: grad_image and grad_weights_sum come together")
+        if RaymarchingBackend._composite_path != 0:
+            raise RuntimeError("composite_rays_train_loss: the fused launch exists for the wave-per-ray path only")
+        bg = (C.c_float * 3)(*[float(v) for v in bg_rgb])
+        _check(lib().s3d_composite_rays_train_loss(_p(sigmas), _p(rgbs), _p(deltas), _p(rays), _u(M), _u(N), _f(T_thresh), _p(gt), bg,
+                                                   _p(grad_loss), _p(gt_depth), _f(depth_weight), _p(weights_sum), _p(depth), _p(image),
+                                                   _p(grad_sigmas), _p(grad_rgbs), _p(grad_image), _p(grad_weights_sum), _p(loss),
+                                                   _p(workspace), _stream()), "composite_rays_train_loss")
 
     zero_fills_march_rays = True  # march_rays(zero_unfilled=True): the kernel writes the zeros of the unfilled slots itself
 

@@ -188,7 +188,8 @@ class SealSteps:
         from nerf.trainer import render_loss
         with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
             out = self.model.render(rays_o, rays_d, bg_color=bg_color, perturb=True, force_all_rays=False,
-                                    defer_background=self.native_optim and not torch.is_tensor(bg_color), **self.render_kwargs)
+                                    defer_background=self.native_optim and not torch.is_tensor(bg_color),
+                                    fused_loss=self._fused_loss(gt_rgb, gt_depth, self.depth_weight), **self.render_kwargs)
             # (+ the backbone trainer's own term: TensoRF's L1 penalty, tensoRF/utils.py:42-49 — the student's train_step of
             #  the reference is the backbone trainer's, SealNeRF/trainer.py:589-594)
             loss = self._regularized(render_loss(out, gt_rgb, self._expected_grad(), gt_depth, self.depth_weight))

@@ -518,3 +518,88 @@ def test_full_size_properties(hip):
     assert float(xyzs[total:].abs().sum()) == 0.0
     # deltas: dt == dt_min everywhere (dt_gamma = 0)
     assert bool((deltas[:total, 0] == deltas[0, 0]).all())
+
+
+@pytest.mark.parametrize("with_depth", [False, True], ids=["mse", "mse+depth"])
+@pytest.mark.parametrize("budget", ["fits", "short"], ids=["all-rays-fit", "budget-cuts-rays"])
+def test_composite_loss_one_launch_is_the_three_launch_sequence_bit_for_bit(oracle, hip, with_depth, budget):
+    """s3d_composite_rays_train_loss = composite forward -> bg_mse_forward(announced gradient) -> composite backward: pixel, loss,
+    loss gradients and sample gradients, incl. empty rays, early terminations, rays behind a too small budget M and NaN-filled
+    gradient buffers (the rows a count-bounded consumer reads are written by the kernel itself)"""
+    R, H = hip.RaymarchingBackend, hip.NgpHeadBackend
+    sigmas, rgbs, deltas, rays, m, N = _composite_inputs(oracle, seed=3)
+    M = m if budget == "fits" else (m * 3 // 4) // 128 * 128  # rays whose span ends behind M are dropped (raymarching.cu:416)
+    end = M
+    sigmas, rgbs, deltas = sigmas[:M].contiguous().cuda(), rgbs[:M].contiguous().cuda(), deltas[:M].contiguous().cuda()
+    rays = rays.cuda()
+    g = torch.Generator().manual_seed(11)
+    gt = torch.rand(N, 3, generator=g).cuda()
+    gt_depth = (torch.rand(N, generator=g) * 3).cuda() if with_depth else None
+    scale = torch.tensor(1024.0, device="cuda")
+    bg = (1.0, 0.5, 0.25)
+    # the three launches
+    ws, dp, im = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, 3, device="cuda")
+    R.set_composite_path(0)
+    R.composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, 1e-4, ws, dp, im)
+    loss, gi, gw = torch.empty((), device="cuda"), torch.empty(N, 3, device="cuda"), torch.empty(N, device="cuda")
+    H.bg_mse_forward(im, ws, gt, bg, loss, scale, gi, gw, **(dict(depth=dp, gt_depth=gt_depth, depth_weight=0.7) if with_depth else {}))
+    rows = sigmas.shape[0]
+    gs, gc = torch.full((rows,), float("nan"), device="cuda"), torch.full((rows, 3), float("nan"), device="cuda")
+    R.composite_rays_train_backward(gw, gi, sigmas, rgbs, deltas, rays, ws, im, M, N, 1e-4, gs, gc)
+    # the one launch (twice through the same scratch)
+    work = torch.full((4 * N,), float("nan"), device="cuda")
+    for _ in range(2):
+        ws2, dp2, im2 = torch.empty(N, device="cuda"), torch.empty(N, device="cuda"), torch.empty(N, 3, device="cuda")
+        loss2, gi2, gw2 = torch.empty((), device="cuda"), torch.empty(N, 3, device="cuda"), torch.empty(N, device="cuda")
+        gs2, gc2 = torch.full((rows,), float("nan"), device="cuda"), torch.full((rows, 3), float("nan"), device="cuda")
+        R.composite_rays_train_loss(sigmas, rgbs, deltas, rays, M, N, 1e-4, gt, bg, scale, ws2, dp2, im2, gs2, gc2, loss2, work,
+                                    gt_depth=gt_depth, depth_weight=0.7, grad_image=gi2, grad_weights_sum=gw2)
+        for a, b, name in ((ws, ws2, "weights_sum"), (dp, dp2, "depth"), (im, im2, "image"), (loss, loss2, "loss"), (gi, gi2, "grad_image"),
+                           (gw, gw2, "grad_weights_sum"), (gs, gs2, "grad_sigmas"), (gc, gc2, "grad_rgbs")):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), name
+    assert torch.isfinite(gs[:end]).all() and (gs[:end] != 0).any() and (ws == 0).any()
+    if budget == "short":
+        assert int(((rays[:, 1] + rays[:, 2]) > M).sum()) > 0, "expect rays behind the budget"
+
+
+def test_composite_loss_function_backward_with_any_other_gradient_is_the_unfused_autograd(hip, oracle):
+    """raymarching.composite_rays_train_loss hands out its precomputed gradients only for the announced upstream gradient; another
+    gradient of the loss, or a gradient of the pixel, goes through the unfused kernels — and equals composite_rays_train + _BgMse"""
+    import raymarching
+    from nerf.trainer import _BgMse
+    sigmas, rgbs, deltas, rays, M, N = _composite_inputs(oracle, seed=5, n_rays=1024)
+    sigmas, rgbs, deltas, rays = sigmas.cuda(), rgbs.cuda(), deltas.cuda(), rays.cuda()
+    gt = torch.rand(N, 3, generator=torch.Generator().manual_seed(2)).cuda()
+    bg = (1.0, 1.0, 1.0)
+    scale = torch.tensor(512.0, device="cuda")
+    from raymarching import raymarching as rm
+    prev = rm._backend
+    rm._backend = hip.RaymarchingBackend
+    try:
+        def grads(fused, root, extra):
+            s, c = sigmas.clone().requires_grad_(True), rgbs.clone().requires_grad_(True)
+            if fused:
+                loss, ws, dp, im = raymarching.composite_rays_train_loss(s, c, deltas, rays, 1e-4, gt, bg, scale)
+            else:
+                ws, dp, im = raymarching.composite_rays_train(s, c, deltas, rays, 1e-4)
+                loss = _BgMse.apply(im, ws, gt, bg, scale)
+            total = loss * 1.0 if not extra else loss + (im * 0.25).sum() + ws.sum() * 0.5
+            total.backward(gradient=root)
+            return loss.detach(), s.grad, c.grad
+        for root, extra in ((scale, False), (torch.tensor(3.0, device="cuda"), False), (scale, True)):
+            a, b = grads(True, root, extra), grads(False, root, extra)
+            assert torch.equal(a[0], b[0])
+            if root is scale and not extra:  # (loss * 1.0 hands the root gradient on as a new tensor: the general path on both sides)
+                pass
+            torch.testing.assert_close(a[1], b[1], rtol=1e-5, atol=1e-6 * float(b[1].abs().max()))
+            torch.testing.assert_close(a[2], b[2], rtol=1e-5, atol=1e-6 * float(b[2].abs().max()))
+        # the announced gradient itself: bit for bit
+        s, c = sigmas.clone().requires_grad_(True), rgbs.clone().requires_grad_(True)
+        loss, *_ = raymarching.composite_rays_train_loss(s, c, deltas, rays, 1e-4, gt, bg, scale)
+        loss.backward(gradient=scale)
+        s2, c2 = sigmas.clone().requires_grad_(True), rgbs.clone().requires_grad_(True)
+        ws, dp, im = raymarching.composite_rays_train(s2, c2, deltas, rays, 1e-4)
+        _BgMse.apply(im, ws, gt, bg, scale).backward(gradient=scale)
+        assert torch.equal(s.grad, s2.grad) and torch.equal(c.grad, c2.grad)
+    finally:
+        rm._backend = prev

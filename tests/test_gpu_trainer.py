@@ -418,3 +418,37 @@ def test_network_with_library_path_widths_trains_and_renders(hip, hidden):
     r = syn.get_rays(poses[:1].cuda(), syn.lego_intrinsics(32, 32), 32, 32)
     img = tr.render_image(r["rays_o"].contiguous(), r["rays_d"].contiguous())["image"]
     assert img.shape[-1] == 3 and torch.isfinite(img).all()
+
+
+@pytest.mark.parametrize("graphed", [False, True], ids=["eager", "graph"])
+def test_step_with_the_one_launch_criterion_equals_the_three_launch_step_bit_for_bit(hip, graphed):
+    """Trainer.fused_losses: compositing, background + MSE and the compositing backward as one launch
+    (raymarching.composite_rays_train_loss) against composite_rays_train -> _BgMse -> backward — same steps, same RNG, every
+    loss and every parameter afterwards identical; the graph holds two launches fewer"""
+    from nerf.trainer import GraphedTrainer, Trainer
+    res, calls = {}, {True: 0, False: 0}
+    R = hip.RaymarchingBackend
+    inner = R.composite_rays_train_loss
+    for fused in (True, False):
+        model, batches = _setup()
+        model.iter_density = 100
+        tr = (GraphedTrainer(model, 2048, lr=1e-2, fp16=True, update_extra_interval=10 ** 9) if graphed
+              else Trainer(model, lr=1e-2, fp16=True, update_extra_interval=10 ** 9))
+        tr.fused_losses = fused
+        tr.global_step = 1
+        torch.manual_seed(7)
+
+        def counted(*a, **k):
+            calls[fused] += 1
+            return inner(*a, **k)
+        R.composite_rays_train_loss = staticmethod(counted)
+        try:
+            losses = _run(tr, batches, 6)
+        finally:
+            R.composite_rays_train_loss = staticmethod(inner)
+        assert torch.isfinite(losses).all()
+        res[fused] = (losses, [p.detach().clone() for p in model.parameters()])
+    assert calls[True] > 0 and calls[False] == 0, calls
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)
