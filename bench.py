@@ -476,15 +476,15 @@ def seal_section(args, dev, batches, note=lambda m: None, make_dp=None, reps=Non
 def tensorf_section(args, dev, batches, note=lambda m: None, res=300, steps=24):
     """BASELINE configs[4]: the TensoRF VM-48 backbone (tensoRF/network.py: density rank 16x3, colour rank 48x3, basis 144 -> 27,
     colour MLP 150 -> 128 -> 128 -> 3) at resolution 300 on the synthetic scene, the reference's training step (tensoRF/utils.py:
-    NGP step + L1 penalty on the density factors, weight 1e-4; lr 2e-2 factors / 1e-3 networks) — eager, NativeAdam, fused VM
-    feature kernels (csrc/tensorf.hip).  `roofline`: the colour factors' backward (s3d_vm_color_backward: bound + plane + line
+    NGP step + L1 penalty on the density factors, weight 1e-4; lr 2e-2 factors / 1e-3 networks) — NativeAdam, fused VM feature
+    kernels (csrc/tensorf.hip), timed eagerly and replayed from a HIP graph (`ms_per_step`).  `roofline`: the colour factors' backward (s3d_vm_color_backward: bound + plane + line
     kernels and the zero fills of its buffers, HIP events on the launch stream) against its algorithmic bytes per sample:
     3 components x (4 corners x 48 ranks x 4 B read + the same added, 2 x 48 x 4 B line values, 48 x 4 B g m written and read,
     2 x 48 x 4 B line gradient) + 12 B position + 64 B output gradient = 8,140 B."""
     import s3d_hip
     from nerf import synthetic as syn
     from tensoRF import network as trf
-    from tensoRF.utils import Trainer as TensoRFTrainer
+    from tensoRF.utils import GraphedTrainer as TensoRFGraphedTrainer, Trainer as TensoRFTrainer
     torch.manual_seed(args.seed + 31)
     net = trf.NeRFNetwork(resolution=[res] * 3, bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).to(dev)
     grid, bits = syn.lego_like_density_grid(seed=0)
@@ -503,20 +503,33 @@ def tensorf_section(args, dev, batches, note=lambda m: None, res=300, steps=24):
     timers.install(lambda name, a: a[0].shape[0])
     for k in range(4):
         tr.train_step(*batches[k % len(batches)])
+    torch.cuda.synchronize()
     op = timers.summary()
     timers.remove()
-    samples = torch.zeros(1, dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(steps):
+
+    def timed(trainer, n_steps):
+        samples = torch.zeros(1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            trainer.train_step(*batches[k % len(batches)])
+            samples.add_(net.step_counter[(net.local_step - 1) % 16, 0].long())
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n_steps, float(samples.item()) / n_steps
+
+    for k in range(2):
         tr.train_step(*batches[k % len(batches)])
-        samples.add_(net.step_counter[(net.local_step - 1) % 16, 0].long())
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    n = float(samples.item()) / steps
+    dt_eager, _ = timed(tr, max(steps // 2, 4))
+    # the same step replayed from a HIP graph (tensoRF/utils.py: GraphedTrainer) — the eager step is bound by its ~150 launches
+    gtr = TensoRFGraphedTrainer(net, args.num_rays, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, fp16=True, update_extra_interval=10 ** 9)
+    gtr.global_step = 1
+    for k in range(6):
+        gtr.train_step(*batches[k % len(batches)])
+    dt, n = timed(gtr, steps)
     out = {"workload": f"configs[4]: TensoRF VM-48 (sigma rank 16x3, colour rank 48x3), resolution {res}, {args.num_rays} rays/step, "
-                       "training step with the L1 penalty (weight 1e-4), eager, NativeAdam, fused VM kernels",
-           "ms_per_step": dt * 1e3, "samples_per_step": n, "samples_per_s": n / dt}
+                       "training step with the L1 penalty (weight 1e-4), HIP-graph replay, NativeAdam, fused VM kernels",
+           "ms_per_step": dt * 1e3, "ms_per_step_eager": dt_eager * 1e3, "graph_captures": gtr.n_captures, "samples_per_step": n,
+           "samples_per_s": n / dt}
     cb = op.get("color_backward")
     if cb:
         bytes_per = 3 * (2 * 4 * 48 * 4 + 2 * 48 * 4 + 2 * 48 * 4 + 2 * 48 * 4) + 12 + 64

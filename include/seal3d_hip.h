@@ -370,6 +370,12 @@ int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* plan
 uint32_t s3d_vm_backward_max_bins(const uint32_t* resolution);
 int s3d_vm_backward_keys(const float* x, uint32_t N, const uint32_t* rank, const uint32_t* resolution, int32_t* keys,
                          s3d_stream_t stream);
+/* The whole binning in one call: perm [6,N] i32 and start [6,n_bounds] i32 (n_bounds >= max_bins + 2) as described above, by a
+ * counting sort (keys + wave-aggregated bin counts, scan, scatter); the order of the points inside a bin is unspecified (the
+ * backward kernels sum a bin exactly, in fixed point).  workspace: s3d_vm_backward_bins_workspace_size(N, n_bounds) bytes. */
+size_t s3d_vm_backward_bins_workspace_size(uint32_t N, uint32_t n_bounds);
+int s3d_vm_backward_bins(const float* x, uint32_t N, const uint32_t* rank, const uint32_t* resolution, int32_t* perm,
+                         int32_t* start, uint32_t n_bounds, void* workspace, size_t workspace_bytes, s3d_stream_t stream);
 int s3d_vm_features_backward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                              const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
                              const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,

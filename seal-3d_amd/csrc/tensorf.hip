@@ -205,6 +205,76 @@ __global__ void __launch_bounds__(256) k_vm_keys(const float* __restrict__ x, ui
     }
 }
 
+// Counting sort of the points by (row, bin): the bins of a row are few (1,444 plane tiles, 5 line chunks at resolution 300)
+// and points arrive ray by ray, so the lanes of a wave share a handful of bins — one atomic per distinct bin and wave, in
+// both passes.  A point without contribution goes to the row's last bin (n_bounds - 1, behind every bin a kernel asks for).
+// The order of the points INSIDE a bin is whatever the atomics make it (the backward sums a bin's points exactly, in fixed
+// point: the order does not reach the result).
+__device__ __forceinline__ uint32_t wave_bin_add(uint32_t* __restrict__ counters, uint32_t key, uint32_t lane) {
+    uint32_t pos = 0;
+    unsigned long long todo = __ballot(1);
+    while (todo) {
+        const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
+        const uint32_t k = (uint32_t)__shfl((int)key, (int)leader, 64);
+        const unsigned long long same = __ballot(key == k) & todo;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&counters[k], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, (int)leader, 64);
+        if (key == k) pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return pos;
+}
+__global__ void __launch_bounds__(256) k_vm_zero_words(uint32_t* __restrict__ p, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+__global__ void __launch_bounds__(256) k_vm_bin_count(const float* __restrict__ x, uint32_t N, VmFactors f, uint32_t n_bounds,
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ counts) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;  // (whole waves leave together except in the last block: __ballot(1) counts the lanes still here)
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (uint32_t i = 0; i < 3; i++) {
+        const VmPoint q = vm_locate(x, n, f, i);
+        const int tiles_x = ((int)f.W[i] + kVmTile - 1) / kVmTile;
+        const uint32_t tk = (uint32_t)((clampi(q.y0, 0, (int)f.H[i] - 1) / kVmTile) * tiles_x + clampi(q.x0, 0, (int)f.W[i] - 1) / kVmTile);
+        const uint32_t zk = (uint32_t)(clampi(q.z0, 0, (int)f.Dn[i] - 1) / kVmZChunk);
+        const uint32_t kp = q.valid ? tk : n_bounds - 1u, kl = q.valid ? zk : n_bounds - 1u;
+        keys[(size_t)i * N + n] = kp;
+        keys[(size_t)(3 + i) * N + n] = kl;
+        (void)wave_bin_add(counts + i * n_bounds, kp, lane);
+        (void)wave_bin_add(counts + (3 + i) * n_bounds, kl, lane);
+    }
+}
+// start[r][t] = points of row r in bins < t (one wave per row)
+__global__ void __launch_bounds__(384) k_vm_bin_scan(const uint32_t* __restrict__ counts, uint32_t n_bounds, int32_t* __restrict__ start) {
+    const uint32_t r = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < n_bounds; t0 += 64) {
+        const uint32_t t = t0 + lane;
+        const uint32_t c = t < n_bounds ? counts[r * n_bounds + t] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
+        if (t < n_bounds) start[r * n_bounds + t] = (int32_t)(carry + incl - c);
+        carry += (uint32_t)__shfl((int)incl, 63, 64);
+    }
+}
+__global__ void __launch_bounds__(256) k_vm_bin_scatter(const uint32_t* __restrict__ keys, uint32_t N, uint32_t n_bounds,
+                                                        const int32_t* __restrict__ start, uint32_t* __restrict__ cursors,
+                                                        int32_t* __restrict__ perm) {
+    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (uint32_t r = 0; r < 6; r++) {
+        const uint32_t k = keys[(size_t)r * N + n];
+        const uint32_t pos = (uint32_t)start[r * n_bounds + k] + wave_bin_add(cursors + r * n_bounds, k, lane);
+        perm[(size_t)r * N + pos] = (int32_t)n;
+    }
+}
+
 struct VmBackward {
     float* d_plane[3];
     float* d_line[3];
@@ -637,6 +707,36 @@ S3D_EXPORT int s3d_vm_backward_keys(const float* x, uint32_t N, const uint32_t* 
     if (int rc = fill_factors(f, dummy, dummy, rank, resolution, rows)) return rc;
     hipLaunchKernelGGL(k_vm_keys, dim3(div_up<uint32_t>(N, 256)), dim3(256), 0, as_stream(stream), x, N, f, keys);
     return check_launch("vm_backward_keys");
+}
+
+S3D_EXPORT size_t s3d_vm_backward_bins_workspace_size(uint32_t N, uint32_t n_bounds) {
+    return ((size_t)6 * N + (size_t)12 * n_bounds) * sizeof(uint32_t);  // keys [6,N] | counts [6,n_bounds] | cursors [6,n_bounds]
+}
+// keys + counts, scan, scatter: four launches (with the clearing of the counters) instead of torch.sort's ~20 merge passes over
+// 6N words and a dozen small tensor ops around it
+S3D_EXPORT int s3d_vm_backward_bins(const float* x, uint32_t N, const uint32_t* rank, const uint32_t* resolution, int32_t* perm,
+                                    int32_t* start, uint32_t n_bounds, void* workspace, size_t workspace_bytes, s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(x && rank && resolution && perm && start && workspace, "vm_backward_bins: null pointer");
+    S3D_REQUIRE(n_bounds >= s3d_vm_backward_max_bins(resolution) + 2, "vm_backward_bins: n_bounds must exceed max_bins + 1");
+    S3D_REQUIRE((uint64_t)6 * N < (1ull << 31), "vm_backward_bins: batch too large");
+    S3D_REQUIRE(workspace_bytes >= s3d_vm_backward_bins_workspace_size(N, n_bounds), "vm_backward_bins: workspace too small");
+    VmFactors f;
+    uint32_t rows;
+    const float* dummy[3] = {x, x, x};  // (only the geometry is used)
+    if (int rc = fill_factors(f, dummy, dummy, rank, resolution, rows)) return rc;
+    uint32_t* keys = reinterpret_cast<uint32_t*>(workspace);
+    uint32_t* counts = keys + (size_t)6 * N;
+    uint32_t* cursors = counts + (size_t)6 * n_bounds;
+    hipStream_t st = as_stream(stream);
+    // (a kernel, not hipMemsetAsync: the call is also captured into HIP graphs, where a memset node did not clear the counters on
+    //  replay — ROCm 7.2, memory access fault in the scatter of the first replayed step)
+    hipLaunchKernelGGL(k_vm_zero_words, dim3(div_up<uint32_t>(12u * n_bounds, 256)), dim3(256), 0, st, counts, 12u * n_bounds);
+    hipLaunchKernelGGL(k_vm_bin_count, dim3(div_up<uint32_t>(N, 256)), dim3(256), 0, st, x, N, f, n_bounds, keys, counts);
+    hipLaunchKernelGGL(k_vm_bin_scan, dim3(1), dim3(384), 0, st, (const uint32_t*)counts, n_bounds, start);
+    hipLaunchKernelGGL(k_vm_bin_scatter, dim3(div_up<uint32_t>(N, 256)), dim3(256), 0, st, (const uint32_t*)keys, N, n_bounds,
+                       (const int32_t*)start, cursors, perm);
+    return check_launch("vm_backward_bins");
 }
 
 // launch geometry shared by the two backward entry points: points per workgroup so that the sorted order fills the chip a

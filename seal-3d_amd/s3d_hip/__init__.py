@@ -43,7 +43,8 @@ EXPORTS = [
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_mid2_forward", "s3d_ngp_mid2_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
     "s3d_bg_mse_forward", "s3d_bg_mse_backward", "s3d_bg_targets", "s3d_l1_pair_workspace_size", "s3d_l1_pair_loss",
     "s3d_seal_bbox_map", "s3d_vm_features_forward",
-    "s3d_vm_backward_max_bins", "s3d_vm_backward_keys", "s3d_vm_features_backward", "s3d_vm_color_forward", "s3d_vm_color_backward",
+    "s3d_vm_backward_max_bins", "s3d_vm_backward_keys", "s3d_vm_backward_bins_workspace_size", "s3d_vm_backward_bins",
+    "s3d_vm_features_backward", "s3d_vm_color_forward", "s3d_vm_color_backward",
 ]
 
 
@@ -72,7 +73,7 @@ def lib():
         for name in ("s3d_march_rays_train_workspace_size", "s3d_compact_alive_workspace_size",
                      "s3d_ffmlp_backward_workspace_size", "s3d_grid_encode_backward_workspace_size",
                      "s3d_grid_encode_backward_control_size", "s3d_l1_pair_workspace_size",
-                     "s3d_sweep_update_workspace_size"):
+                     "s3d_sweep_update_workspace_size", "s3d_vm_backward_bins_workspace_size"):
             getattr(l, name).restype = C.c_size_t
         l.s3d_vm_backward_max_bins.restype = C.c_uint32
         l.s3d_grid_level_scales.restype = None
@@ -975,6 +976,9 @@ class VmBackend:
         _check(lib().s3d_vm_features_forward(_p(x), _u(x.shape[0]), pl, ln, rank, res, C.c_int(int(bool(reduce))), _p(out),
                                              _stream()), "vm_features_forward")
 
+    # False (S3D_VM_BINS=torch): keys + torch.sort + searchsorted, the A/B twin of s3d_vm_backward_bins
+    native_bins = os.environ.get("S3D_VM_BINS", "native") != "torch"
+
     @staticmethod
     def backward_bins(x, planes, resolution):
         """(perm [6,N] i32, start [6,n_bounds] i32, n_bounds): the points sorted by plane tile / line chunk, as the backward
@@ -983,18 +987,23 @@ class VmBackend:
         u3 = C.c_uint32 * 3
         rank = u3(*[int(t.shape[1]) for t in planes])
         res = u3(*[int(r) for r in resolution])
+        n_bounds = int(lib().s3d_vm_backward_max_bins(res)) + 2
+        if VmBackend.native_bins:
+            perm = torch.empty(6, N, dtype=torch.int32, device=dev)
+            start = torch.empty(6, n_bounds, dtype=torch.int32, device=dev)
+            nbytes = int(lib().s3d_vm_backward_bins_workspace_size(_u(N), _u(n_bounds)))
+            work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _check(lib().s3d_vm_backward_bins(_p(x), _u(N), rank, res, _p(perm), _p(start), _u(n_bounds), _p(work), C.c_size_t(nbytes),
+                                              _stream()), "vm_backward_bins")
+            return perm, start, n_bounds
         keys = torch.empty(6, N, dtype=torch.int32, device=dev)
         _check(lib().s3d_vm_backward_keys(_p(x), _u(N), rank, res, _p(keys), _stream()), "vm_backward_keys")
-        # one sort over all six rows (row number above the key bits) instead of six segment sorts: torch sorts a [6, N] int32
-        # tensor along dim 1 with ~20 merge passes per call.  Keys stay 32 bits wide (row: 3 bits, bin: `bits`; a point that
-        # contributes nothing — 0x7fffffff — takes the largest bin number, behind every real one): half the radix passes and
-        # half the bytes of a 64-bit sort
-        n_bounds = int(lib().s3d_vm_backward_max_bins(res)) + 2
+        # (A/B path: the same list through torch.sort — one sort over all six rows, row number above the key bits)
         bits = max(int(n_bounds).bit_length(), 1)
         if bits > 27:
             raise RuntimeError("vm features backward: resolution too large for 32-bit sort keys")
         rows6 = torch.arange(6, dtype=torch.int32, device=dev).unsqueeze(1)
-        skeys, order = torch.sort(((rows6 << bits) | keys.clamp_(max=(1 << bits) - 1)).view(-1))
+        skeys, order = torch.sort(((rows6 << bits) | keys.clamp_(max=(1 << bits) - 1)).view(-1), stable=True)
         bounds = (rows6 << bits) | torch.arange(n_bounds, dtype=torch.int32, device=dev).unsqueeze(0)
         start = (torch.searchsorted(skeys, bounds.view(-1)).view(6, n_bounds) - rows6 * N).to(torch.int32).contiguous()
         perm = (order.view(6, N) - rows6.long() * N).to(torch.int32).contiguous()

@@ -488,3 +488,33 @@ def test_tensorf_vm_kernels_edge_resolutions(hip):
         rp, rl = vo.factor_grads(x.numpy(), pn, ln, gc.numpy().T)
         for a, b in zip(gp + gl, rp + rl):
             np.testing.assert_allclose(a.cpu().numpy().reshape(b.shape), b, rtol=1e-4, atol=2e-5 * float(np.abs(b).max()))
+
+
+@pytest.mark.parametrize("res", [[300, 300, 300], [24, 17, 33], [2, 5, 3]], ids=["300", "24x17x33", "2x5x3"])
+def test_tensorf_backward_bins_native_sort_equals_the_torch_sort_twin(hip, res):
+    """s3d_vm_backward_bins (keys + wave-aggregated counts, scan, scatter) against the same list through torch.sort + searchsorted:
+    every bin boundary and every bin's set of points (the order inside a bin is free), incl. points without contribution"""
+    import s3d_hip
+    V = s3d_hip.VmBackend
+    g = torch.Generator().manual_seed(4)
+    N = 50021
+    x = torch.cat([torch.rand(N - 21, 3, generator=g) * 2.3 - 1.15, torch.full((21, 3), 7.0)]).cuda().contiguous()
+    planes = [torch.zeros(1, 2, 2, 2, device="cuda") for _ in range(3)]  # (only the ranks are read)
+    try:
+        V.native_bins = True
+        perm, start, nb = V.backward_bins(x, planes, res)
+        V.native_bins = False
+        perm_t, start_t, nb_t = V.backward_bins(x, planes, res)
+    finally:
+        V.native_bins = True
+    assert nb == nb_t and torch.equal(start, start_t)
+    # the same points in every bin: sort each row's (bin of position, point) pairs
+    pos = torch.arange(N, device="cuda")
+    for r in range(6):
+        bin_of_pos = torch.searchsorted(start[r].long().contiguous(), pos, right=True)
+        for p in (perm, perm_t):
+            assert int(p[r].min()) == 0 and int(p[r].max()) == N - 1 and p[r].unique().numel() == N
+        a = torch.sort(bin_of_pos * N + perm[r].long()).values
+        b = torch.sort(bin_of_pos * N + perm_t[r].long()).values
+        assert torch.equal(a, b), r
+    assert int(start[:, -1].min()) <= N - 21 and int(start[:, 0].max()) == 0
