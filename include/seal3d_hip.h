@@ -494,6 +494,10 @@ typedef struct s3d_adam_tensor {
      * pack_cols] parameter lives at r * pack_stride + c (the nn.Linear weights of nerf/network.py inside the fused MLP
      * kernels' padded [out, in] layout); param / exp_avg / exp_avg_sq stay contiguous.  0: contiguous (the reference case). */
     uint32_t pack_cols, pack_stride;
+    /* Build extension: != 0 adds the gradient of the penalty l1 * sum|param| to the (unscaled) gradient inside the update,
+     * l1 * sign(param) with sign(0) = 0 — TensoRF's L1 term on the density factors (tensoRF/network.py:259-263, tensoRF/utils.py:
+     * 42-49: l1 = l1_reg_weight / numel) without the sign / scale / accumulate passes over the factors. */
+    float l1;
 } s3d_adam_tensor;
 int s3d_adam_step_multi(const s3d_adam_tensor* tensors /* host array */, int32_t n_tensors, const float* step,
                         const float* grad_scale, const float* found_inf, const float* lr_scale, int consume_grads,

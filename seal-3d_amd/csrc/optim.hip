@@ -32,9 +32,11 @@ __global__ void __launch_bounds__(256) k_grads_nonfinite(const G* __restrict__ g
 
 struct AdamCoef {
     float beta1, beta2, eps, inv_scale, step_size, bc2_sqrt;
+    float l1;  // gradient of an L1 penalty l1 * sum|p| formed here (s3d_adam_tensor.l1): + l1 * sign(p), sign(0) = 0 like torch.sign
 };
 __device__ __forceinline__ void adam_update(const AdamCoef& c, float g, float& m, float& v, float& p) {
-    const float gi = g * c.inv_scale;
+    float gi = g * c.inv_scale;
+    if (c.l1 != 0.0f) gi = gi + (p > 0.0f ? c.l1 : (p < 0.0f ? -c.l1 : 0.0f));
     m = m + (1.0f - c.beta1) * (gi - m);
     v = c.beta2 * v + (1.0f - c.beta2) * gi * gi;
     const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(256) k_adam_step(float* __restrict__ p, const 
     if (found_inf && *found_inf != 0.0f) return;  // the whole step is skipped (GradScaler.step)
     const float t = *step + 1.0f;                 // this update's step number; k_adam_advance stores it afterwards
     AdamCoef c;
-    c.beta1 = beta1; c.beta2 = beta2; c.eps = eps;
+    c.beta1 = beta1; c.beta2 = beta2; c.eps = eps; c.l1 = 0.0f;
     c.inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
     const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
     c.step_size = (lr_scale ? lr * *lr_scale : lr) / bc1;  // (lr_scale: the schedule's factor, read at run time by a replayed graph)
@@ -160,7 +162,7 @@ struct AdamBatch {
     float* v[kAdamMaxTensors];
     __half* h[kAdamMaxTensors];
     size_t n[kAdamMaxTensors];
-    float lr[kAdamMaxTensors], beta1[kAdamMaxTensors], beta2[kAdamMaxTensors], eps[kAdamMaxTensors];
+    float lr[kAdamMaxTensors], beta1[kAdamMaxTensors], beta2[kAdamMaxTensors], eps[kAdamMaxTensors], l1[kAdamMaxTensors];
     uint32_t first_block[kAdamMaxTensors + 1];
     uint32_t cols[kAdamMaxTensors], stride[kAdamMaxTensors];  // stride != 0: packed layout of g / h (adam_range_packed)
     uint8_t half_grad[kAdamMaxTensors], vec[kAdamMaxTensors], consume[kAdamMaxTensors];
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(256) k_adam_step_multi(AdamBatch b, const floa
     }
     const float t = *step + 1.0f;
     AdamCoef c;
-    c.beta1 = b.beta1[i]; c.beta2 = b.beta2[i]; c.eps = b.eps[i];
+    c.beta1 = b.beta1[i]; c.beta2 = b.beta2[i]; c.eps = b.eps[i]; c.l1 = b.l1[i];
     c.inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
     const float bc1 = 1.0f - powf(c.beta1, t), bc2 = 1.0f - powf(c.beta2, t);
     c.step_size = (lr_scale ? b.lr[i] * *lr_scale : b.lr[i]) / bc1;
@@ -318,7 +320,7 @@ S3D_EXPORT int s3d_adam_step_multi(const s3d_adam_tensor* tensors, int32_t n_ten
             S3D_REQUIRE(t.grad_dtype == S3D_F32 || t.grad_dtype == S3D_F16, "adam_step_multi: grad dtype must be f32 or f16");
             const int i = b.count++;
             b.p[i] = t.param; b.g[i] = const_cast<void*>(t.grad); b.m[i] = t.exp_avg; b.v[i] = t.exp_avg_sq; b.h[i] = (__half*)t.param_half;
-            b.n[i] = t.n; b.lr[i] = t.lr; b.beta1[i] = t.beta1; b.beta2[i] = t.beta2; b.eps[i] = t.eps;
+            b.n[i] = t.n; b.lr[i] = t.lr; b.beta1[i] = t.beta1; b.beta2[i] = t.beta2; b.eps[i] = t.eps; b.l1[i] = t.l1;
             b.half_grad[i] = t.grad_dtype == S3D_F16;
             b.consume[i] = (consume_grads || t.consume) ? 1 : 0;
             S3D_REQUIRE((t.pack_stride == 0) || (t.pack_cols > 0 && t.pack_cols <= t.pack_stride && t.n % t.pack_cols == 0),

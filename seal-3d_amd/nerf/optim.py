@@ -222,6 +222,10 @@ class NativeAdam(torch.optim.Optimizer):
             if half is not None and not packed and not half.is_contiguous():
                 half = None  # a pack member updated from a plain `.grad` (nn.Linear route): its strided fp16 image is re-copied below
             item = (p.data, g, st["exp_avg"], st["exp_avg_sq"], half, lr_of.get(id(group), group["lr"]), b1, b2, group["eps"])
+            # an L1 penalty whose gradient this update forms itself (tensoRF/utils.py announces it per step: read once, then cleared)
+            l1 = float(p.__dict__.pop("_s3d_l1", 0.0))
+            if l1 != 0.0 and (before_param is not None or packed):
+                raise RuntimeError("NativeAdam: an in-update L1 term needs the one-launch route (no packed weights, no piecewise reduction)")
             if before_param is not None and packed:
                 # (row-strided views of the pack: the multi-tensor entry point knows the layout.  The MLP backward OVERWRITES
                 #  the pack's gradient twin, so nothing is cleared behind the read)
@@ -235,7 +239,7 @@ class NativeAdam(torch.optim.Optimizer):
             else:
                 # (a hand-over buffer is cleared behind the read; a `.grad` stays readable after the step)
                 mine = self.consume_grads and g is getattr(p, "_s3d_grad", None)
-                batch.append(item + (mine,))
+                batch.append(item + (mine, l1))
                 if mine:
                     consumed.append(p)
             if half is None and hasattr(p, "_s3d_half"):

@@ -699,7 +699,7 @@ class _AdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
                 ("param_half", C.c_void_p), ("n", C.c_size_t), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
                 ("eps", C.c_float), ("grad_dtype", C.c_int), ("consume", C.c_int), ("pack_cols", C.c_uint32),
-                ("pack_stride", C.c_uint32)]
+                ("pack_stride", C.c_uint32), ("l1", C.c_float)]
 
 
 class OptimBackend:
@@ -726,13 +726,15 @@ class OptimBackend:
 
     @staticmethod
     def adam_step_multi(items, step, grad_scale, found_inf, consume_grads=False, lr_scale=None):
-        """`items`: (param, grad, exp_avg, exp_avg_sq, param_half or None, lr, beta1, beta2, eps[, consume]) per tensor — adam_step
-        for all of them in one launch; `consume_grads` (all tensors) / the optional tenth element (that tensor): the gradient
-        is cleared behind the read (seal3d_hip.h)"""
+        """`items`: (param, grad, exp_avg, exp_avg_sq, param_half or None, lr, beta1, beta2, eps[, consume[, l1]]) per tensor —
+        adam_step for all of them in one launch; `consume_grads` (all tensors) / the optional tenth element (that tensor): the
+        gradient is cleared behind the read; eleventh element: coefficient of an L1 penalty whose gradient the update adds
+        (seal3d_hip.h)"""
         arr = (_AdamTensor * len(items))()
         for a, item in zip(arr, items):
             param, grad, exp_avg, exp_avg_sq, param_half, lr, beta1, beta2, eps = item[:9]
             a.consume = int(bool(item[9])) if len(item) > 9 else 0
+            a.l1 = float(item[10]) if len(item) > 10 else 0.0
             _need(param, torch.float32, "param"); _need(exp_avg, torch.float32, "exp_avg"); _need(exp_avg_sq, torch.float32, "exp_avg_sq")
             packed = grad.dim() == 2 and not grad.is_contiguous()
             if packed:

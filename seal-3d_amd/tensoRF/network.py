@@ -192,6 +192,7 @@ class NeRFNetwork(NeRFRenderer):
         """copy.deepcopy (teacher creation, EMA) and pickling leave the backward's sorted-point cache behind"""
         state = self.__dict__.copy()
         state.pop("_vm_bins", None)
+        state.pop("_l1_inv", None)
         return state
 
     def init_one_svd(self, n_component, resolution, scale=0.1):
@@ -275,6 +276,16 @@ class NeRFNetwork(NeRFRenderer):
         return loss
 
     fused_l1 = True  # tests / A-B runs: False = the reference's op-by-op expression
+
+    @torch.no_grad()
+    def density_loss_value(self):
+        """the value of density_loss() without a graph (tensoRF/utils.py: the trainer whose optimizer forms the gradient itself)"""
+        ts = [t.detach() for t in list(self.sigma_mat) + list(self.sigma_vec)]
+        key = tuple(t.numel() for t in ts)
+        inv = self.__dict__.get("_l1_inv")
+        if inv is None or inv[0] != key or inv[1].device != ts[0].device:
+            inv = self.__dict__["_l1_inv"] = (key, torch.tensor([1.0 / n for n in key], dtype=torch.float32, device=ts[0].device))
+        return (torch.stack(torch._foreach_norm(ts, 1)) * inv[1]).sum()
 
     def get_params(self, lr1, lr2=None):
         lr2 = lr1 if lr2 is None else lr2

@@ -518,3 +518,39 @@ def test_tensorf_backward_bins_native_sort_equals_the_torch_sort_twin(hip, res):
         b = torch.sort(bin_of_pos * N + perm_t[r].long()).values
         assert torch.equal(a, b), r
     assert int(start[:, -1].min()) <= N - 21 and int(start[:, 0].max()) == 0
+
+
+def test_tensorf_l1_penalty_inside_the_adam_launch_trains_like_the_autograd_route(hip):
+    """tensoRF/utils.py `l1_in_update`: the L1 term as a value + its gradient formed inside NativeAdam's launch, against the term
+    through autograd (sign / scale / accumulate passes) — same steps, same RNG: the losses agree and after three steps all but a
+    vanishing share of the density factors' elements are equal to rounding (an element whose total gradient is ~0 may take its
+    Adam-normalised step in the other direction)"""
+    from tensoRF import network as trf
+    from tensoRF.utils import Trainer
+    from nerf import synthetic as syn
+    poses = syn.orbit_poses(2, seed=0).cuda()
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    res = {}
+    for in_update in (True, False):
+        torch.manual_seed(3)
+        net = trf.NeRFNetwork(resolution=[64] * 3, bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).cuda()
+        net.density_grid.copy_(torch.from_numpy(grid)); net.density_bitfield.copy_(torch.from_numpy(bits))
+        net.iter_density = 100
+        tr = Trainer(net, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-2, fp16=True, update_extra_interval=10 ** 9, native_optim=True)
+        tr.l1_in_update = in_update
+        tr.global_step = 1
+        losses = []
+        for k in range(3):
+            r = syn.get_rays(poses[k % 2:k % 2 + 1], syn.lego_intrinsics(), 800, 800, N=1024, generator=torch.Generator().manual_seed(k))
+            torch.manual_seed(100 + k)
+            losses.append(float(tr.train_step(r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous(),
+                                              torch.rand(1024, 3, generator=torch.Generator().manual_seed(50 + k)).cuda())))
+        res[in_update] = (losses, [p.detach().clone() for p in list(net.sigma_mat) + list(net.sigma_vec)])
+    for a, b in zip(res[True][0], res[False][0]):
+        assert abs(a - b) <= 1e-4 * abs(b), (res[True][0], res[False][0])
+    moved = False
+    for a, b in zip(res[True][1], res[False][1]):
+        off = ((a - b).abs() > 1e-5 + 1e-4 * b.abs()).float().mean()
+        assert float(off) < 2e-3, float(off)
+        moved |= bool((a != 0).any())
+    assert moved

@@ -285,3 +285,36 @@ def test_lr_schedule_reaches_a_captured_step_through_the_device_side_factor(hip)
     oa.step()
     assert oa._lr_captured[0] == oa.param_groups[0]["lr"] and float(oa.lr_scale) == 1.0
     assert not torch.equal(before, pa[0].detach())
+
+
+def test_native_adam_forms_an_announced_l1_gradient_inside_the_update(hip):
+    """s3d_adam_tensor.l1 (tensoRF/utils.py: TensoRF's L1 penalty on the density factors): p._s3d_l1 = c announced for ONE step
+    adds c * sign(p) to the unscaled gradient — against torch.optim.Adam on grad + c * torch.sign(p); the announcement is consumed
+    by the step, exact zeros of the parameter take no penalty gradient, an overflow step applies nothing"""
+    from nerf.optim import NativeAdam
+    p0 = [_mk((600, 5), 1), _mk((4097,), 2)]
+    p0[1][::11] = 0.0
+    pa = [torch.nn.Parameter(t.clone().cuda()) for t in p0]
+    pb = [torch.nn.Parameter(t.clone().cuda()) for t in p0]
+    oa = NativeAdam([{"params": pa}], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    ob = torch.optim.Adam(pb, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    scale = torch.full((1,), 256.0, device="cuda")
+    flag = torch.zeros(1, device="cuda")
+    coef = [1e-4 / p0[0].numel(), 3e-2]
+    for step in range(5):
+        announced = step != 2  # (step 2: no announcement -> a plain update)
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            g = _mk(a.shape, 10 * step + i).cuda() * 1e-3
+            g[::5] = 0
+            a.grad = g * 256.0
+            b.grad = g + (coef[i] * torch.sign(b.detach()) if announced and step != 3 else 0)
+            if announced:
+                a._s3d_l1 = coef[i]
+        flag.fill_(1.0 if step == 3 else 0.0)
+        oa.step(grad_scale=scale, found_inf=flag)
+        assert all("_s3d_l1" not in a.__dict__ for a in pa)
+        if step != 3:
+            ob.step()
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-6, atol=2e-7)
+    assert torch.equal(pa[1].detach()[::11][:1] == 0, pb[1].detach()[::11][:1] == 0)
