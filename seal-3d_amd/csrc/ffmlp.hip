@@ -739,6 +739,9 @@ struct WgradLayer {
     uint32_t g_native, x_native;  // fragment-ordered (W wide) or row-major
     uint32_t Fo, Fi;              // real feature counts
     uint32_t w_off;               // offset of this layer's matrix in the flat weight vector
+    // a column block of a wider layer (W = 128 with 128 < input_dim <= 160: the first matrix's gradient as two plan entries):
+    uint32_t x_ld, x_col0;        // row-major X: row stride and first column of the block (x_ld = 0: the block is all of X)
+    uint32_t w_ld;                // row stride of the matrix in the flat weight vector (0: Fi); w_off points at the block's first column
 };
 struct WgradPlan {
     WgradLayer layer[kMaxMlpLayers];
@@ -789,7 +792,16 @@ __global__ void __launch_bounds__(256) k_ffmlp_wgrad(WgradPlan plan, uint32_t B,
             const uint4* sg = reinterpret_cast<const uint4*>(L.G + (size_t)tile * 32 * gF);
             const uint4* sx = reinterpret_cast<const uint4*>(L.X + (size_t)tile * 32 * xF);
             for (uint32_t i = lane; i < 32 * gF / 8; i += 64) reinterpret_cast<uint4*>(tg)[i] = sg[i];
-            for (uint32_t i = lane; i < 32 * xF / 8; i += 64) reinterpret_cast<uint4*>(tx)[i] = sx[i];
+            if (L.x_ld == 0) {
+                for (uint32_t i = lane; i < 32 * xF / 8; i += 64) reinterpret_cast<uint4*>(tx)[i] = sx[i];
+            } else {  // a column block of a wider row-major matrix: xF of x_ld columns, row by row (8-half chunks)
+                const uint32_t per_row = xF / 8;
+                for (uint32_t i = lane; i < 32 * per_row; i += 64) {
+                    const uint32_t b = i / per_row, c = i - b * per_row;
+                    reinterpret_cast<uint4*>(tx)[i] =
+                        *reinterpret_cast<const uint4*>(L.X + ((size_t)tile * 32 + b) * L.x_ld + L.x_col0 + 8 * c);
+                }
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -879,9 +891,10 @@ __global__ void k_ffmlp_wgrad_reduce(WgradPlan plan, uint32_t nblk, const float*
 #pragma unroll
     for (int d = 1; d < (int)kReduceSplit; d <<= 1) v += __shfl_xor(v, d, 64);
     if (live && part == 0) {
-        if (accumulate) v += (float)grad_weights[L.w_off + e];  // add to the caller's running gradient (fp16 hand-over buffer)
+        const size_t at = (size_t)L.w_off + (L.w_ld ? (size_t)o * L.w_ld + i : (size_t)e);
+        if (accumulate) v += (float)grad_weights[at];  // add to the caller's running gradient (fp16 hand-over buffer)
         const _Float16 h = (_Float16)v;
-        grad_weights[L.w_off + e] = h;
+        grad_weights[at] = h;
         // GradScaler's non-finite check made where the gradient is written (benign race: everyone writes 1)
         if (found_inf && !(fabsf((float)h) <= 65504.0f)) *found_inf = 1.0f;
     }
@@ -1697,6 +1710,13 @@ int launch_backward(const _Float16* grad, const _Float16* X, const _Float16* Wt,
     plan.layer[n_layers] = WgradLayer{grad, fwd + (size_t)NH * BW, 0u, 1u, 16u, (uint32_t)W,
                                       (uint32_t)(W * in_dim + NH * W * W)};
     // the last layer's matrix is [out_pad=16, W]; rows >= out_dim receive the (zero) gradient of the padding
+    if (in_dim > (uint32_t)W) {
+        // the operand tiles hold W columns: the first matrix's gradient as two column blocks, [0, W) and [W, in_dim)
+        S3D_REQUIRE(plan.n < kMaxMlpLayers, "ffmlp_backward: too many layers for an input wider than the hidden width");
+        plan.layer[0].Fi = (uint32_t)W; plan.layer[0].x_ld = in_dim; plan.layer[0].x_col0 = 0u; plan.layer[0].w_ld = in_dim;
+        plan.layer[plan.n] = WgradLayer{bwd + NH * BW, X, 1u, 0u, (uint32_t)W, in_dim - (uint32_t)W, (uint32_t)W, in_dim, (uint32_t)W, in_dim};
+        plan.n++;
+    }
     uint32_t nblk = div_up<uint32_t>(ntiles, 4);
     if (nblk > wgrad_blocks(W)) nblk = wgrad_blocks(W);
     hipLaunchKernelGGL((k_ffmlp_wgrad<W>), dim3(nblk, plan.n), dim3(256), 0, st, plan, B, partial, t_n_valid);
@@ -1948,8 +1968,9 @@ S3D_EXPORT int s3d_ffmlp_wgrad_reduce_pair(const void* workspace_a, uint32_t B_a
 
 S3D_EXPORT size_t s3d_ffmlp_backward_workspace_size(uint32_t input_dim, uint32_t output_dim, uint32_t hidden_dim,
                                                     uint32_t num_layers) {
-    (void)input_dim; (void)output_dim;
-    return (size_t)(num_layers + 1) * wgrad_blocks(hidden_dim) * wgrad_pad(hidden_dim) * wgrad_pad(hidden_dim) * sizeof(float);
+    (void)output_dim;
+    const size_t planes = (size_t)num_layers + 1 + (input_dim > hidden_dim && hidden_dim == 128 ? 1 : 0);  // (launch_backward: two column blocks)
+    return planes * wgrad_blocks(hidden_dim) * wgrad_pad(hidden_dim) * wgrad_pad(hidden_dim) * sizeof(float);
 }
 
 S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights,

@@ -87,7 +87,7 @@ inline uint32_t ew_grid(size_t n) { return stream_grid(n, 256); }
 // re-computing fused backward stays at W <= 64 (a 128 x 128 fp32 weight-gradient accumulator is 256 registers per lane).
 bool ffmlp_native_shape(uint32_t in_dim, uint32_t W, uint32_t n_layers) {
     if (W == 32 || W == 64) return in_dim <= 64;
-    if (W != 128 || in_dim > 128 || n_layers < 2) return false;
+    if (W != 128 || in_dim > 160 || n_layers < 2) return false;  // (128 < in_dim <= 160: the first weight gradient in two column blocks)
     const uint32_t NH = n_layers - 1;
     const uint32_t fwd_frags = 4 * (in_dim / 16) + NH * 32 + 8, bwd_frags = 4 + NH * 32 + ((in_dim + 31) / 32) * 8;
     return fwd_frags <= 144 && bwd_frags <= 144;  // 1 KiB each

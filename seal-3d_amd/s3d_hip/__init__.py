@@ -955,6 +955,18 @@ class SealBackend:
                                        _p(out_dirs), _p(mask), _nv(n_valid), _stream()), "seal_bbox_map")
 
 
+def _zeros_like_many(tensors, words=0):
+    """zero tensors shaped like `tensors` (fp32, contiguous) + `words` zero int32 words, carved out of ONE filled buffer: one fill
+    launch instead of one per tensor (seven to eight ~5 us launches per factor backward otherwise); segments start on 16 bytes"""
+    sizes = [(t.numel() + 3) // 4 * 4 for t in tensors]
+    flat = torch.zeros(sum(sizes) + (words + 3) // 4 * 4, dtype=torch.float32, device=tensors[0].device)
+    out, off = [], 0
+    for t, n in zip(tensors, sizes):
+        out.append(flat[off:off + t.numel()].view(t.shape))
+        off += n
+    return out, (flat[off:off + words].view(torch.int32) if words else None)
+
+
 class VmBackend:
     """csrc/tensorf.hip — TensoRF vector-matrix features (tensoRF/network.py:112-153 of the reference)"""
 
@@ -1025,10 +1037,9 @@ class VmBackend:
             raise RuntimeError("vm features backward: grad must be contiguous [N] / [N, sum rank]")
         perm, start, n_bounds = bins if bins is not None else VmBackend.backward_bins(x, planes, resolution)
         gm = torch.empty(N, rows, dtype=torch.float32, device=dev)  # (written by the plane pass for every point the line pass reads)
-        g_planes = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in planes]
-        g_lines = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in lines]
         # (named locals: temporaries created inside the argument list would be freed one by one and handed the SAME block)
-        bound_words = torch.zeros(4, dtype=torch.int32, device=dev)
+        gs, bound_words = _zeros_like_many(list(planes) + list(lines), 4)
+        g_planes, g_lines = gs[:3], gs[3:]
         line_scratch = torch.empty(sum(t.numel() for t in lines), dtype=torch.float32, device=dev)
         _check(lib().s3d_vm_features_backward(_p(x), _u(N), ptr3(*[t.data_ptr() for t in planes]),
                                               ptr3(*[t.data_ptr() for t in lines]), rank, res, C.c_int(int(bool(reduce))),
@@ -1069,10 +1080,8 @@ class VmBackend:
         grad_out = torch.nn.functional.pad(grad_out, (0, 32 - basis.shape[0])).contiguous()
         perm, start, n_bounds = bins if bins is not None else VmBackend.backward_bins(x, planes, resolution)
         gm = torch.empty(N, rows, dtype=torch.float32, device=dev)  # (written by the plane pass for every point the line pass reads)
-        g_planes = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in planes]
-        g_lines = [torch.zeros_like(t, memory_format=torch.contiguous_format) for t in lines]
-        g_basis = torch.zeros(basis.shape, dtype=torch.float32, device=dev)
-        bound_words = torch.zeros(4, dtype=torch.int32, device=dev)
+        gs, bound_words = _zeros_like_many(list(planes) + list(lines) + [basis], 4)
+        g_planes, g_lines, g_basis = gs[:3], gs[3:6], gs[6]
         line_scratch = torch.empty(sum(t.numel() for t in lines), dtype=torch.float32, device=dev)
         _check(lib().s3d_vm_color_backward(_p(x), _u(N), ptr3(*[t.data_ptr() for t in planes]),
                                            ptr3(*[t.data_ptr() for t in lines]), u3(*[int(t.shape[1]) for t in planes]),

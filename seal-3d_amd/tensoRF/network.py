@@ -255,12 +255,42 @@ class NeRFNetwork(NeRFRenderer):
         x = self._normalize(x)
         self.__dict__["_vm_bins"] = {}  # (the previous forward's sorted points)
         sigma = trunc_exp(self.get_sigma_feat(x))
-        h = torch.cat([self.encoder(self.get_color_feat(x)), self.encoder_dir(d)], dim=-1)
+        feat, dirs = self.encoder(self.get_color_feat(x)), self.encoder_dir(d)
+        if self._fused_mlp_ok(feat):
+            return sigma, torch.sigmoid(self._color_mlp_fused(feat, dirs))
+        h = torch.cat([feat, dirs], dim=-1)
         for k, layer in enumerate(self.color_net):
             h = _linear(layer, h)
             if k != self.num_layers - 1:
                 h = F.relu(h, inplace=True)
         return sigma, torch.sigmoid(h)
+
+    fused_mlp = True  # A-B runs / tests: False = the nn.Linear chain (library GEMMs + elementwise launches)
+
+    def _fused_mlp_ok(self, feat):
+        """the colour MLP (tensoRF/network.py:71-83: bias-free Linear -> ReLU chain, 150 -> 128 -> 128 -> 3) on the MFMA kernels
+        of the ffmlp package: hidden width 128, input padded to a multiple of 16 (<= 160), whole 128-row tiles, fp16 autocast"""
+        net = self.color_net
+        return (self.fused_mlp and feat.is_cuda and feat.dim() == 2 and feat.shape[0] > 0 and feat.shape[0] % 128 == 0
+                and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16
+                and len(net) >= 2 and all(l.bias is None for l in net) and self.hidden_dim == 128
+                and net[-1].out_features <= 16 and (self.in_dim + 15) // 16 * 16 <= 160)
+
+    def _color_mlp_fused(self, feat, dirs):
+        """same arithmetic as the Linear chain under autocast (fp16 operands, fp32 accumulation, fp16 activations); the weights
+        travel as the ffmlp layout [W, in_pad] | (n - 1) x [W, W] | [16, W] built from the nn.Linear parameters each step
+        (~55 K elements: autograd splits the flat fp16 gradient back)"""
+        from ffmlp.ffmlp import _FFMLPForward
+        net = self.color_net
+        N, in_pad, out = feat.shape[0], (self.in_dim + 15) // 16 * 16, net[-1].out_features
+        parts = [feat.half(), dirs.half()]
+        if in_pad > self.in_dim:
+            parts.append(torch.zeros(N, in_pad - self.in_dim, dtype=torch.half, device=feat.device))
+        h = torch.cat(parts, dim=-1)
+        flat = torch.cat([F.pad(net[0].weight, (0, in_pad - self.in_dim)).reshape(-1)] + [l.weight.reshape(-1) for l in net[1:-1]]
+                         + [F.pad(net[-1].weight, (0, 0, 0, 16 - out)).reshape(-1)])
+        # (the kernels write the output padded to 16 columns, ffmlp.py:117-118, 162-163: the real ones are sliced out)
+        return _FFMLPForward.apply(h, flat, in_pad, 16, self.hidden_dim, len(net) - 1, 0, 6, False, True)[:, :out]
 
     def density(self, x):
         return {"sigma": trunc_exp(self.get_sigma_feat(self._normalize(x)))}

@@ -554,3 +554,39 @@ def test_tensorf_l1_penalty_inside_the_adam_launch_trains_like_the_autograd_rout
         assert float(off) < 2e-3, float(off)
         moved |= bool((a != 0).any())
     assert moved
+
+
+def test_tensorf_colour_mlp_on_the_ffmlp_kernels_matches_the_linear_chain(hip):
+    """tensoRF/network.py `fused_mlp`: the colour MLP 150 -> 128 -> 128 -> 3 (input padded to 160) through the W = 128 MFMA kernels of
+    the ffmlp package against the nn.Linear chain under fp16 autocast — colours, and the gradients of every MLP weight, of
+    basis_mat and of the colour factors (the data gradient travels on through the encoders and the VM kernels)"""
+    from tensoRF import network as trf
+    torch.manual_seed(1)
+    net = trf.NeRFNetwork(resolution=[48] * 3, bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).cuda()
+    with torch.no_grad():
+        for l in net.color_net:
+            l.weight.mul_(3.0)  # (default init leaves the colours near 0.5: make the network matter)
+    g = torch.Generator().manual_seed(2)
+    N = 128 * 40
+    x = (torch.rand(N, 3, generator=g) * 1.8 - 0.9).cuda()
+    d = torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1).cuda()
+    go = torch.randn(N, 3, generator=g).cuda()
+    out = {}
+    for fused in (True, False):
+        net.fused_mlp = fused
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            sigma, rgb = net(x, d)
+        assert rgb.shape == (N, 3)
+        (rgb.float() * go).sum().backward()
+        out[fused] = (rgb.detach().float(), {k: p.grad.detach().float().clone() for k, p in net.named_parameters() if p.grad is not None})
+    net.fused_mlp = True
+    torch.testing.assert_close(out[True][0], out[False][0], rtol=0, atol=2e-3)
+    assert float((out[True][0] - 0.5).abs().max()) > 0.2
+    keys = set(out[True][1]) & set(out[False][1])
+    assert any(k.startswith("color_net.0") for k in keys) and any(k.startswith("color_mat") for k in keys) and "basis_mat.weight" in keys
+    for k in keys:
+        if k.startswith("sigma"):
+            continue
+        a, b = out[True][1][k], out[False][1][k]
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-6, (k, float((a - b).abs().max()), float(b.abs().max()))

@@ -20,6 +20,8 @@ NETS = [  # in, W, n_layers, out(real), activation
     (32, 128, 2, 16, 3),  # sigmoid
     (128, 128, 2, 16, 0),  # in == W = 128
     (64, 128, 4, 5, 0),   # three hidden matrices: 136 KiB of weight fragments per workgroup
+    (160, 128, 3, 3, 0),  # input wider than the hidden width (TensoRF's colour MLP, 150 padded to 160): first weight gradient in two column blocks
+    (144, 128, 2, 16, 0),
     # the other widths ffmlp.cu:40-44 dispatches, and a 64-wide network with an input wider than 64: layer-by-layer path
     # (csrc/ffmlp_generic.hip)
     (32, 16, 2, 16, 0),
