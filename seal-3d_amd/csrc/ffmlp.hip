@@ -748,10 +748,6 @@ struct WgradPlan {
     uint32_t n;
 };
 
-__device__ __forceinline__ uint32_t tile_elem(uint32_t native, uint32_t F, uint32_t b, uint32_t f) {
-    if (native) return (((f >> 5) * 4 + ((f >> 3) & 3)) * 32 + b) * 8 + ((f >> 2) & 1) * 4 + (f & 3);
-    return b * F + f;
-}
 
 
 // partial weight-gradient matrices of the stored-activation path: [PAD][PAD] fp32 per (layer, workgroup)
@@ -759,93 +755,130 @@ template <int W> struct WgradGeom { static constexpr uint32_t PAD = W > 64 ? 128
 inline uint32_t wgrad_pad(uint32_t W) { return W > 64 ? 128u : kWgradPad; }
 inline uint32_t wgrad_blocks(uint32_t W);
 
+// fragment of a row-major [32 points][features] LDS tile with `stride` halfs per row (see transpose_load below: the same
+// ds_read_b64_tr_b16 pair, any row stride that keeps the 8-byte segments aligned)
+__device__ __forceinline__ half8 tile_fragment(const _Float16* __restrict__ T, uint32_t stride, uint32_t blk, uint32_t s, uint32_t fl,
+                                               uint32_t h, uint32_t nfeat) {
+    typedef __fp16 f16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    typedef __attribute__((address_space(3))) f16x4 lds_f16x4;
+    const uint32_t i = fl & 15, g1 = fl >> 4;  // lane = 32 h + fl: 16-lane group 2 h + g1
+    const _Float16* p = T + (16 * s + 8 * h + i / 4) * stride + 32 * blk + 16 * g1 + 4 * (i % 4);
+    const f16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4*)p);
+    const f16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4*)(p + 4 * stride));
+    half8 v;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; j++) { v[j] = (_Float16)a[j]; v[4 + j] = (_Float16)b[j]; }
+    if (blk * 32 + fl >= nfeat) {
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) v[j] = (_Float16)0.0f;
+    }
+    return v;
+}
+
+// Both operands of dW = G^T X have the batch as the MFMA K dimension: a 32-row tile of each goes to LDS as a row-major image (row =
+// point, W + 8 halfs per row) — a fragment-ordered buffer is re-ordered by the 16-byte chunk on the way in — and every lane reads
+// its 8 consecutive points of one feature with two transposing 8-byte loads.  The four waves of a workgroup SHARE the tile pair and
+// split the 32 x 32 output blocks between them (block j of the layer goes to wave j % 4): 64 accumulator registers per wave
+// instead of 256, so four workgroups fit a CU and their waves cover each other's loads; the next pair is requested into registers
+// before the current one is multiplied and parked in the other half of a double buffer (one barrier per tile), and every wave
+// writes its own blocks of the workgroup's partial plane (no cross-wave sum).  What is left is traffic: 16 KiB per 32-row tile and
+// layer for 8 MFMAs per wave (263 MB per launch for TensoRF's network, 80 - 110 us); a second tile in flight per workgroup changed
+// nothing.
+// [First version: one tile per wave, linear copies, sixteen 2-byte LDS reads per fragment, 256 accumulator registers: 129.7 us for
+//  TensoRF's 160 -> 128 -> 128 -> 3 network at 1.05e5 rows; with transposing loads alone 131 -> 95-130 us, still one wave per SIMD
+//  waiting for every tile.]
 template <int W>
 __global__ void __launch_bounds__(256) k_ffmlp_wgrad(WgradPlan plan, uint32_t B, float* __restrict__ partial,
                                                      const int32_t* __restrict__ n_valid) {
     constexpr uint32_t MAXB = (W + 31) / 32;  // 32-blocks per side
     constexpr uint32_t PAD = WgradGeom<W>::PAD;
-    // the four waves' operand tiles; the workgroup's reduction plane takes their place after the last tile (W = 128: 64 KiB each)
-    constexpr uint32_t kTileBytes = 4 * 2 * 32 * W * sizeof(_Float16), kRedBytes = PAD * PAD * sizeof(float);
-    __shared__ __attribute__((aligned(16))) unsigned char wg_smem[kTileBytes > kRedBytes ? kTileBytes : kRedBytes];
-    _Float16 (*tiles)[2][32 * W] = reinterpret_cast<_Float16 (*)[2][32 * W]>(wg_smem);
-    float* red = reinterpret_cast<float*>(wg_smem);
+    constexpr uint32_t TS = W + 8;            // halfs per tile row (8 pad: the transposing loads' 16-lane groups spread over the banks)
+    constexpr uint32_t kTile = 32 * TS;       // halfs per tile image
+    constexpr uint32_t NBLK = (MAXB * MAXB + 3) / 4;  // output blocks per wave
+    constexpr uint32_t NCH = (32 * W / 8 + 255) / 256;  // 16-byte chunks of a W-wide tile per thread
+    __shared__ __attribute__((aligned(16))) _Float16 tiles[2][2][kTile];  // [buffer][G | X]
 
     const WgradLayer L = plan.layer[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t fl = lane & 31, h = lane >> 5;
     const uint32_t gF = L.g_native ? W : L.Fo, xF = L.x_native ? W : L.Fi;  // storage widths
     const uint32_t MBo = (L.Fo + 31) / 32, NBi = (L.Fi + 31) / 32;
+    const uint32_t x_ld = L.x_ld ? L.x_ld : xF;
 
-    float16v acc[MAXB][MAXB];
+    float16v acc[NBLK];
 #pragma unroll
-    for (uint32_t a = 0; a < MAXB; a++)
-#pragma unroll
-        for (uint32_t b = 0; b < MAXB; b++) acc[a][b] = zero16();
+    for (uint32_t t = 0; t < NBLK; t++) acc[t] = zero16();
 
-    _Float16* tg = tiles[wave][0];
-    _Float16* tx = tiles[wave][1];
-    const uint32_t ntiles = valid_rows(B, n_valid) / 32;  // B % 128 == 0: the four waves of a block always have a tile together
-    for (uint32_t base = blockIdx.x * 4; base < ntiles; base += gridDim.x * 4) {
-        const uint32_t tile = base + wave;
-        // linear 16-byte copies of the two 32-row tiles into LDS
-        {
-            const uint4* sg = reinterpret_cast<const uint4*>(L.G + (size_t)tile * 32 * gF);
-            const uint4* sx = reinterpret_cast<const uint4*>(L.X + (size_t)tile * 32 * xF);
-            for (uint32_t i = lane; i < 32 * gF / 8; i += 64) reinterpret_cast<uint4*>(tg)[i] = sg[i];
-            if (L.x_ld == 0) {
-                for (uint32_t i = lane; i < 32 * xF / 8; i += 64) reinterpret_cast<uint4*>(tx)[i] = sx[i];
-            } else {  // a column block of a wider row-major matrix: xF of x_ld columns, row by row (8-half chunks)
-                const uint32_t per_row = xF / 8;
-                for (uint32_t i = lane; i < 32 * per_row; i += 64) {
-                    const uint32_t b = i / per_row, c = i - b * per_row;
-                    reinterpret_cast<uint4*>(tx)[i] =
-                        *reinterpret_cast<const uint4*>(L.X + ((size_t)tile * 32 + b) * L.x_ld + L.x_col0 + 8 * c);
+    // 16-byte chunk i (= thread + 256 k) of a tile's global image, and its place in the row-major LDS image
+    auto request = [&](uint4 (&r)[NCH], const _Float16* src, uint32_t native, uint32_t F, uint32_t ld, uint32_t col0, uint32_t tile) {
+        const uint32_t per_row = F / 8;
+#pragma unroll
+        for (uint32_t k = 0; k < NCH; k++) {
+            const uint32_t i = threadIdx.x + 256 * k;
+            if (i >= 32 * per_row) continue;
+            if (native) {  // [F / 8 feature groups][32 points][8 features]
+                r[k] = reinterpret_cast<const uint4*>(src + (size_t)tile * 32 * F)[i];
+            } else {       // [32 points][ld features], F of them from column col0
+                const uint32_t b = i / per_row, c = i - b * per_row;
+                r[k] = *reinterpret_cast<const uint4*>(src + ((size_t)tile * 32 + b) * ld + col0 + 8 * c);
+            }
+        }
+    };
+    auto park = [&](_Float16* t, const uint4 (&r)[NCH], uint32_t native, uint32_t F) {
+        const uint32_t per_row = F / 8;
+#pragma unroll
+        for (uint32_t k = 0; k < NCH; k++) {
+            const uint32_t i = threadIdx.x + 256 * k;
+            if (i >= 32 * per_row) continue;
+            const uint32_t at = native ? (i & 31u) * (TS / 8) + (i >> 5) : (i / per_row) * (TS / 8) + i % per_row;
+            reinterpret_cast<uint4*>(t)[at] = r[k];
+        }
+    };
+    const uint32_t ntiles = valid_rows(B, n_valid) / 32;
+    uint4 rg[NCH], rx[NCH];
+    if (blockIdx.x < ntiles) {
+        request(rg, L.G, L.g_native, gF, gF, 0u, blockIdx.x);
+        request(rx, L.X, L.x_native, xF, x_ld, L.x_col0, blockIdx.x);
+    }
+    uint32_t buf = 0;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1u) {
+        _Float16* tg = tiles[buf][0];
+        _Float16* tx = tiles[buf][1];
+        park(tg, rg, L.g_native, gF);
+        park(tx, rx, L.x_native, xF);
+        __syncthreads();  // (also: every wave is done with the other buffer, which the next round parks into)
+        if (tile + gridDim.x < ntiles) {
+            request(rg, L.G, L.g_native, gF, gF, 0u, tile + gridDim.x);
+            request(rx, L.X, L.x_native, xF, x_ld, L.x_col0, tile + gridDim.x);
+        }
+#pragma unroll
+        for (uint32_t s = 0; s < 2; s++) {
+#pragma unroll
+            for (uint32_t t = 0; t < NBLK; t++) {
+                const uint32_t j = wave + 4 * t;  // block j = (mo, ni) of this layer
+                if (j < MBo * NBi) {
+                    const uint32_t mo = j / NBi, ni = j - mo * NBi;
+                    acc[t] = mfma(tile_fragment(tg, TS, mo, s, fl, h, L.Fo), tile_fragment(tx, TS, ni, s, fl, h, L.Fi), acc[t]);
                 }
             }
         }
-        __syncthreads();
-#pragma unroll
-        for (uint32_t s = 0; s < 2; s++) {
-            half8 af[MAXB], bfr[MAXB];
-#pragma unroll
-            for (uint32_t m = 0; m < MAXB; m++) {
-                const uint32_t o = m * 32 + fl;
-#pragma unroll
-                for (uint32_t j = 0; j < 8; j++)
-                    af[m][j] = (m < MBo && o < L.Fo) ? tg[tile_elem(L.g_native, gF, 16 * s + 8 * h + j, o)] : (_Float16)0.0f;
-                const uint32_t i = m * 32 + fl;
-#pragma unroll
-                for (uint32_t j = 0; j < 8; j++)
-                    bfr[m][j] = (m < NBi && i < L.Fi) ? tx[tile_elem(L.x_native, xF, 16 * s + 8 * h + j, i)] : (_Float16)0.0f;
-            }
-#pragma unroll
-            for (uint32_t mo = 0; mo < MAXB; mo++)
-#pragma unroll
-                for (uint32_t ni = 0; ni < MAXB; ni++)
-                    if (mo < MBo && ni < NBi) acc[mo][ni] = mfma(af[mo], bfr[ni], acc[mo][ni]);
-        }
-        __syncthreads();
     }
-    // reduce the four waves through LDS, then one coalesced partial per block
-    // (the loop above ends with a barrier — or never ran: the tiles are dead)
-    for (uint32_t i = threadIdx.x; i < PAD * PAD; i += 256) red[i] = 0.0f;
-    __syncthreads();
-    for (uint32_t w = 0; w < 4; w++) {
-        if (wave == w) {
-#pragma unroll
-            for (uint32_t mo = 0; mo < MAXB; mo++)
-#pragma unroll
-                for (uint32_t ni = 0; ni < MAXB; ni++)
-#pragma unroll
-                    for (uint32_t r = 0; r < 16; r++) {
-                        const uint32_t o = mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, i = ni * 32 + fl;
-                        red[o * PAD + i] += acc[mo][ni][r];
-                    }
-        }
-        __syncthreads();
-    }
+    // every wave's blocks straight into the workgroup's partial plane; the blocks no wave owns (layers narrower than W) are zero
     float* dst = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * PAD * PAD;
-    for (uint32_t i = threadIdx.x; i < PAD * PAD; i += 256) dst[i] = red[i];
+#pragma unroll
+    for (uint32_t t = 0; t < NBLK; t++) {
+        const uint32_t j = wave + 4 * t;
+        if (j >= MAXB * MAXB) continue;
+        const bool mine = j < MBo * NBi;
+        // (unused blocks: position j of the MAXB x MAXB grid that no (mo, ni) of this layer maps to)
+        const uint32_t mo = mine ? j / NBi : 0, ni = mine ? j - mo * NBi : 0;
+        if (!mine) continue;
+#pragma unroll
+        for (uint32_t r = 0; r < 16; r++) {
+            const uint32_t o = mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, i = ni * 32 + fl;
+            dst[o * PAD + i] = acc[t][r];
+        }
+    }
 }
 
 // Eight lanes per matrix element: each sums every 8th workgroup partial with independent accumulators (a single chain over
@@ -1614,7 +1647,7 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
 }
 
 constexpr uint32_t kWgradBlocks = 256;
-inline uint32_t wgrad_blocks(uint32_t W) { return W > 64 ? 64u : kWgradBlocks; }  // (W = 128: 64 KiB partial planes)
+inline uint32_t wgrad_blocks(uint32_t W) { return W > 64 ? 128u : kWgradBlocks; }  // (W = 128: 64 KiB partial planes)
 }  // namespace
 // csrc/ffmlp_generic.hip: the shapes the register-resident kernels do not cover (hidden 16 / 128 / 256, input_dim > 64)
 bool ffmlp_native_shape(uint32_t in_dim, uint32_t W, uint32_t n_layers = 2);

@@ -210,20 +210,24 @@ __global__ void __launch_bounds__(256) k_vm_keys(const float* __restrict__ x, ui
 // both passes.  A point without contribution goes to the row's last bin (n_bounds - 1, behind every bin a kernel asks for).
 // The order of the points INSIDE a bin is whatever the atomics make it (the backward sums a bin's points exactly, in fixed
 // point: the order does not reach the result).
-__device__ __forceinline__ uint32_t wave_bin_add(uint32_t* __restrict__ counters, uint32_t key, uint32_t lane) {
-    uint32_t pos = 0;
+// the lanes of a wave that share `key`: the group's first lane (leader), the lane's rank inside the group and the group's size —
+// a loop over the wave's DISTINCT keys (a handful for ray-ordered points), no memory traffic
+struct BinGroup { uint32_t leader, rank, size; };
+__device__ __forceinline__ BinGroup wave_bin_group(uint32_t key, uint32_t lane) {
+    BinGroup g{0u, 0u, 0u};
     unsigned long long todo = __ballot(1);
     while (todo) {
-        const uint32_t leader = (uint32_t)__ffsll((long long)todo) - 1u;
-        const uint32_t k = (uint32_t)__shfl((int)key, (int)leader, 64);
+        const uint32_t first = (uint32_t)__ffsll((long long)todo) - 1u;
+        const uint32_t k = (uint32_t)__shfl((int)key, (int)first, 64);
         const unsigned long long same = __ballot(key == k) & todo;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&counters[k], (uint32_t)__popcll(same));
-        base = (uint32_t)__shfl((int)base, (int)leader, 64);
-        if (key == k) pos = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (key == k) {
+            g.leader = first;
+            g.rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            g.size = (uint32_t)__popcll(same);
+        }
         todo &= ~same;
     }
-    return pos;
+    return g;
 }
 __global__ void __launch_bounds__(256) k_vm_zero_words(uint32_t* __restrict__ p, uint32_t n) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -243,22 +247,26 @@ __global__ void __launch_bounds__(256) k_vm_bin_count(const float* __restrict__ 
         const uint32_t kp = q.valid ? tk : n_bounds - 1u, kl = q.valid ? zk : n_bounds - 1u;
         keys[(size_t)i * N + n] = kp;
         keys[(size_t)(3 + i) * N + n] = kl;
-        (void)wave_bin_add(counts + i * n_bounds, kp, lane);
-        (void)wave_bin_add(counts + (3 + i) * n_bounds, kl, lane);
+        const BinGroup gp = wave_bin_group(kp, lane), gl = wave_bin_group(kl, lane);
+        if (lane == gp.leader) atomicAdd(&counts[i * n_bounds + kp], gp.size);  // (no value returned: nothing waits for it)
+        if (lane == gl.leader) atomicAdd(&counts[(3 + i) * n_bounds + kl], gl.size);
     }
 }
-// start[r][t] = points of row r in bins < t (one wave per row)
+// start[r][t] = points of row r in bins < t: one wave per row, lane l sums bins [l * per, (l + 1) * per) on its own (all its
+// loads in flight together), one wave scan over the 64 run totals
 __global__ void __launch_bounds__(384) k_vm_bin_scan(const uint32_t* __restrict__ counts, uint32_t n_bounds, int32_t* __restrict__ start) {
     const uint32_t r = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    uint32_t carry = 0;
-    for (uint32_t t0 = 0; t0 < n_bounds; t0 += 64) {
-        const uint32_t t = t0 + lane;
-        const uint32_t c = t < n_bounds ? counts[r * n_bounds + t] : 0u;
-        uint32_t incl = c;
+    const uint32_t per = (n_bounds + 63u) / 64u;
+    const uint32_t t0 = lane * per;
+    uint32_t total = 0;
+    for (uint32_t j = 0; j < per; j++) total += t0 + j < n_bounds ? counts[r * n_bounds + t0 + j] : 0u;
+    uint32_t incl = total;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
-        if (t < n_bounds) start[r * n_bounds + t] = (int32_t)(carry + incl - c);
-        carry += (uint32_t)__shfl((int)incl, 63, 64);
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
+    uint32_t run = incl - total;
+    for (uint32_t j = 0; j < per && t0 + j < n_bounds; j++) {
+        start[r * n_bounds + t0 + j] = (int32_t)run;
+        run += counts[r * n_bounds + t0 + j];
     }
 }
 __global__ void __launch_bounds__(256) k_vm_bin_scatter(const uint32_t* __restrict__ keys, uint32_t N, uint32_t n_bounds,
@@ -267,11 +275,21 @@ __global__ void __launch_bounds__(256) k_vm_bin_scatter(const uint32_t* __restri
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     const uint32_t lane = threadIdx.x & 63u;
+    uint32_t k[6], base[6], first[6];
+    BinGroup g[6];
 #pragma unroll
     for (uint32_t r = 0; r < 6; r++) {
-        const uint32_t k = keys[(size_t)r * N + n];
-        const uint32_t pos = (uint32_t)start[r * n_bounds + k] + wave_bin_add(cursors + r * n_bounds, k, lane);
-        perm[(size_t)r * N + pos] = (int32_t)n;
+        k[r] = keys[(size_t)r * N + n];
+        first[r] = (uint32_t)start[r * n_bounds + k[r]];
+        g[r] = wave_bin_group(k[r], lane);
+    }
+    // one reservation per distinct (row, bin) of the wave, all six rows' requests in flight before the first answer is used
+#pragma unroll
+    for (uint32_t r = 0; r < 6; r++) base[r] = lane == g[r].leader ? atomicAdd(&cursors[r * n_bounds + k[r]], g[r].size) : 0u;
+#pragma unroll
+    for (uint32_t r = 0; r < 6; r++) {
+        const uint32_t b = (uint32_t)__shfl((int)base[r], (int)g[r].leader, 64);
+        perm[(size_t)r * N + first[r] + b + g[r].rank] = (int32_t)n;
     }
 }
 
