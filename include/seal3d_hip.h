@@ -261,6 +261,16 @@ int s3d_freq_encode_forward(const float* inputs, uint32_t B, uint32_t D, uint32_
                             float* outputs, s3d_stream_t stream);
 int s3d_freq_encode_backward(const float* grad, const float* outputs, uint32_t B, uint32_t D, uint32_t deg,
                              uint32_t C, float* grad_inputs, s3d_stream_t stream);
+/* Build extension — two frequency encodings side by side in one fp16 row: out[b] = [freq(a[b]) (D1 + 2 D1 deg1 columns) |
+ * freq(d[b]) (D2 + 2 D2 deg2) | zeros up to ld] — TensoRF's colour MLP input cat([encoder(feat), encoder_dir(d)]) as the fp16
+ * autocast Linear sees it (tensoRF/network.py:48-51, 160-166): s3d_freq_encode_forward's fp32 values of float(a) and d, rounded
+ * to binary16 once.  a: fp16 [B, D1], d: fp32 [B, D2], out: fp16 [B, ld], ld even.  _backward: the gradient w.r.t. a from the
+ * row's fp16 gradient (s3d_freq_encode_backward's expression, sin / cos re-computed), fp16 [B, ldg] with the columns behind D1
+ * zero (ldg = 32: the row layout s3d_vm_color_backward reads); d takes no gradient (view directions). */
+int s3d_freq_encode_pack_forward(const uint16_t* a, const float* d, uint32_t B, uint32_t D1, uint32_t deg1, uint32_t D2,
+                                 uint32_t deg2, uint32_t ld, uint16_t* out, s3d_stream_t stream);
+int s3d_freq_encode_pack_backward(const uint16_t* grad, const uint16_t* a, uint32_t B, uint32_t D1, uint32_t deg1, uint32_t ld,
+                                  uint32_t ldg, uint16_t* grad_a, s3d_stream_t stream);
 
 /* ------------------------------------------------------------------ ffmlp
  * ffmlp/src/ffmlp.h:8-14.  All tensors fp16 (uint16_t bit patterns).

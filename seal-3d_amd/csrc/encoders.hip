@@ -81,6 +81,71 @@ __global__ void k_freq_backward(const float* __restrict__ grad, const float* __r
     grad_inputs[t] = result;
 }
 
+// Two frequency encodings side by side in ONE fp16 row (TensoRF's colour MLP input, tensoRF/network.py:48-51, 160-166:
+// cat([freq(feat), freq(dirs)]) under fp16 autocast): out[b] = [freq_1(a[b]) | freq_2(d[b]) | 0 ...] with the values of
+// k_freq_forward (fp32 arithmetic on float(a), rounded to binary16 once — what the autocast Linear's cast makes of the fp32
+// encodings).  One lane per PAIR of output columns (one 4-byte store).
+__device__ __forceinline__ float freq_value(const float* __restrict__ x, uint32_t D, uint32_t c) {
+    const float half_pi = 3.141592653589793f / 2;
+    if (c < D) return x[c];
+    const uint32_t col = c / D - 1, d = c % D, freq = col / 2;
+    return sinf(ldexpf(x[d], (int)freq) + (float)(col % 2) * half_pi);
+}
+__global__ void __launch_bounds__(256) k_freq_pack_forward(const _Float16* __restrict__ a, const float* __restrict__ d, uint32_t B,
+                                                            uint32_t D1, uint32_t C1, uint32_t D2, uint32_t C2, uint32_t ld,
+                                                            _Float16* __restrict__ out) {
+    const float half_pi = 3.141592653589793f / 2;
+    const uint32_t pairs = ld / 2;
+    const uint64_t total = (uint64_t)B * pairs;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256) {
+        const uint32_t b = (uint32_t)(t / pairs), c0 = 2u * (uint32_t)(t - (uint64_t)b * pairs);
+        _Float16 v[2];
+#pragma unroll
+        for (uint32_t e = 0; e < 2; e++) {
+            const uint32_t c = c0 + e;
+            float r = 0.0f;
+            if (c < C1) {
+                const float x = (float)a[(size_t)b * D1 + c % D1];  // (neighbouring lanes share the row's D1 inputs)
+                if (c < D1) r = x;
+                else {
+                    const uint32_t col = c / D1 - 1u;
+                    r = sinf(ldexpf(x, (int)(col / 2)) + (float)(col % 2) * half_pi);
+                }
+            } else if (c < C1 + C2) {
+                r = freq_value(d + (size_t)b * D2, D2, c - C1);
+            }
+            v[e] = (_Float16)r;
+        }
+        *reinterpret_cast<uint32_t*>(out + (size_t)b * ld + c0) = (uint32_t)__builtin_bit_cast(uint16_t, v[0]) |
+                                                                   ((uint32_t)__builtin_bit_cast(uint16_t, v[1]) << 16);
+    }
+}
+// gradient w.r.t. the FIRST input from the packed row's fp16 gradient (k_freq_backward's expression with sin / cos re-computed
+// from the input instead of read from the stored fp32 outputs: the same values), written as binary16 rows of `ldg` columns with
+// the columns behind D1 zero (the layout s3d_vm_color_backward reads: four 16-byte words per point)
+__global__ void __launch_bounds__(256) k_freq_pack_backward(const _Float16* __restrict__ grad, const _Float16* __restrict__ a, uint32_t B,
+                                                             uint32_t D1, uint32_t deg1, uint32_t ld, uint32_t ldg,
+                                                             _Float16* __restrict__ grad_a) {
+    const float half_pi = 3.141592653589793f / 2;
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= B * ldg) return;
+    const uint32_t b = t / ldg, dd = t - b * ldg;
+    float result = 0.0f;
+    if (dd < D1) {
+        const _Float16* g = grad + (size_t)b * ld;
+        const float x = (float)a[(size_t)b * D1 + dd];
+        result = (float)g[dd];
+        g += D1;
+        for (uint32_t f = 0; f < deg1; f++) {
+            const float arg = ldexpf(x, (int)f);
+            const float sv = sinf(arg), cv = sinf(arg + half_pi);
+            result = __builtin_fmaf(ldexpf(1.0f, (int)f), __builtin_fmaf((float)g[dd], cv, -((float)g[D1 + dd] * sv)), result);
+            g += 2 * D1;
+        }
+    }
+    grad_a[t] = (_Float16)result;
+}
+
 template <uint32_t DEG>
 int launch_sh(const float* inputs, float* outputs, uint32_t B, uint32_t D, const ShNorm& K, float* dy_dx, hipStream_t st) {
     const dim3 grid(div_up<uint32_t>(B, 256)), block(256);
@@ -143,4 +208,25 @@ S3D_EXPORT int s3d_freq_encode_backward(const float* grad, const float* outputs,
     hipLaunchKernelGGL(k_freq_backward, dim3(div_up<uint32_t>(B * D, 256)), dim3(256), 0, as_stream(stream), grad,
                        outputs, B, D, deg, C, grad_inputs);
     return check_launch("freq_encode_backward");
+}
+
+S3D_EXPORT int s3d_freq_encode_pack_forward(const uint16_t* a, const float* d, uint32_t B, uint32_t D1, uint32_t deg1, uint32_t D2,
+                                            uint32_t deg2, uint32_t ld, uint16_t* out, s3d_stream_t stream) {
+    if (B == 0) return S3D_OK;
+    S3D_REQUIRE(a && d && out, "freq_encode_pack_forward: null pointer");
+    const uint32_t C1 = D1 + 2 * D1 * deg1, C2 = D2 + 2 * D2 * deg2;
+    S3D_REQUIRE(D1 >= 1 && D2 >= 1 && ld % 2 == 0 && ld >= C1 + C2, "freq_encode_pack_forward: ld must be even and >= %u", C1 + C2);
+    hipLaunchKernelGGL(k_freq_pack_forward, dim3(stream_grid((uint64_t)B * (ld / 2), 256)), dim3(256), 0, as_stream(stream),
+                       (const _Float16*)a, d, B, D1, C1, D2, C2, ld, (_Float16*)out);
+    return check_launch("freq_encode_pack_forward");
+}
+
+S3D_EXPORT int s3d_freq_encode_pack_backward(const uint16_t* grad, const uint16_t* a, uint32_t B, uint32_t D1, uint32_t deg1,
+                                             uint32_t ld, uint32_t ldg, uint16_t* grad_a, s3d_stream_t stream) {
+    if (B == 0) return S3D_OK;
+    S3D_REQUIRE(grad && a && grad_a, "freq_encode_pack_backward: null pointer");
+    S3D_REQUIRE(D1 >= 1 && ld >= D1 + 2 * D1 * deg1 && ldg >= D1 && (uint64_t)B * ldg < (1ull << 32), "freq_encode_pack_backward: bad shape");
+    hipLaunchKernelGGL(k_freq_pack_backward, dim3(div_up<uint32_t>(B * ldg, 256)), dim3(256), 0, as_stream(stream),
+                       (const _Float16*)grad, (const _Float16*)a, B, D1, deg1, ld, ldg, (_Float16*)grad_a);
+    return check_launch("freq_encode_pack_backward");
 }

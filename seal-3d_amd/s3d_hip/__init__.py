@@ -35,7 +35,7 @@ EXPORTS = [
     "s3d_grid_level_scales", "s3d_grid_encode_forward", "s3d_grid_encode_forward_pair", "s3d_grid_corner_indices", "s3d_grid_encode_backward",
     "s3d_grid_encode_backward_workspace_size", "s3d_grid_encode_backward_control_size",
     "s3d_grad_total_variation",
-    "s3d_sh_encode_forward", "s3d_sh_encode_backward", "s3d_freq_encode_forward", "s3d_freq_encode_backward",
+    "s3d_sh_encode_forward", "s3d_sh_encode_backward", "s3d_freq_encode_forward", "s3d_freq_encode_backward", "s3d_freq_encode_pack_forward", "s3d_freq_encode_pack_backward",
     "s3d_ffmlp_forward", "s3d_ffmlp_inference", "s3d_ffmlp_ngp_pair_inference", "s3d_ffmlp_wgrad_reduce_pair", "s3d_ffmlp_backward_workspace_size", "s3d_ffmlp_backward",
     "s3d_ffmlp_fused_backward_supported",
     "s3d_ffmlp_allocate_splitk", "s3d_ffmlp_free_splitk",
@@ -567,6 +567,26 @@ class FreqBackend:
                "freq_encode_forward")
 
     @staticmethod
+    def freq_encode_pack_forward(a, d, deg1, deg2, out):
+        """out fp16 [B, ld] = [freq(a) | freq(d) | 0]: a fp16 [B, D1], d fp32 [B, D2] (seal3d_hip.h)"""
+        _need(a, torch.float16, "a"); _need(d, torch.float32, "d"); _need(out, torch.float16, "out")
+        B = a.shape[0]
+        if not (a.is_contiguous() and d.is_contiguous() and out.is_contiguous()) or d.shape[0] != B or out.shape[0] != B:
+            raise RuntimeError("freq_encode_pack_forward: contiguous a [B, D1], d [B, D2], out [B, ld]")
+        _check(lib().s3d_freq_encode_pack_forward(_p(a), _p(d), _u(B), _u(a.shape[1]), _u(deg1), _u(d.shape[1]), _u(deg2), _u(out.shape[1]),
+                                                  _p(out), _stream()), "freq_encode_pack_forward")
+
+    @staticmethod
+    def freq_encode_pack_backward(grad, a, deg1, grad_a):
+        """grad_a fp16 [B, ldg] (columns behind D1 zero) from the packed row's gradient fp16 [B, ld]"""
+        _need(grad, torch.float16, "grad"); _need(a, torch.float16, "a"); _need(grad_a, torch.float16, "grad_a")
+        B = a.shape[0]
+        if not (grad.is_contiguous() and a.is_contiguous() and grad_a.is_contiguous()) or grad.shape[0] != B or grad_a.shape[0] != B:
+            raise RuntimeError("freq_encode_pack_backward: contiguous grad [B, ld], a [B, D1], grad_a [B, ldg]")
+        _check(lib().s3d_freq_encode_pack_backward(_p(grad), _p(a), _u(B), _u(a.shape[1]), _u(deg1), _u(grad.shape[1]), _u(grad_a.shape[1]),
+                                                   _p(grad_a), _stream()), "freq_encode_pack_backward")
+
+    @staticmethod
     def freq_encode_backward(grad, outputs, B, D, deg, Cc, grad_inputs):
         _need(grad, torch.float32, "grad")
         _check(lib().s3d_freq_encode_backward(_p(grad), _p(outputs), _u(B), _u(D), _u(deg), _u(Cc), _p(grad_inputs),
@@ -1076,8 +1096,14 @@ class VmBackend:
         rows = sum(int(t.shape[1]) for t in planes)
         if grad_out.shape != (N, basis.shape[0]) or not basis.is_contiguous() or basis.shape[1] != rows or basis.shape[0] > 32:
             raise RuntimeError("vm color backward: grad_out must be [N, Cb <= 32], basis contiguous [Cb, sum rank]")
-        # the kernel reads a point's gradients as four 16-byte words: rows padded to 32 columns
-        grad_out = torch.nn.functional.pad(grad_out, (0, 32 - basis.shape[0])).contiguous()
+        # the kernel reads a point's gradients as four 16-byte words: rows padded to 32 columns (a [:, :Cb] view of a zero-padded
+        # [N, 32] buffer — FreqBackend.freq_encode_pack_backward marks what it wrote — is taken as it is)
+        base = grad_out._base
+        if (base is not None and getattr(base, "_s3d_zero_padded", False) and base.shape == (N, 32) and base.is_contiguous()
+                and grad_out.data_ptr() == base.data_ptr() and grad_out.stride() == (32, 1)):
+            grad_out = base
+        else:
+            grad_out = torch.nn.functional.pad(grad_out, (0, 32 - basis.shape[0])).contiguous()
         perm, start, n_bounds = bins if bins is not None else VmBackend.backward_bins(x, planes, resolution)
         gm = torch.empty(N, rows, dtype=torch.float32, device=dev)  # (written by the plane pass for every point the line pass reads)
         gs, bound_words = _zeros_like_many(list(planes) + list(lines) + [basis], 4)

@@ -99,9 +99,35 @@ class _VmColorBasis(torch.autograd.Function):
     def backward(ctx, g):
         x, w16, *factors = ctx.saved_tensors
         mats, vecs = [f.float().contiguous() for f in factors[:3]], [f.float().contiguous() for f in factors[3:]]
-        gp, gl, gw = s3d_hip.VmBackend.color_backward(x, mats, vecs, ctx.net.resolution, w16, g.to(torch.float16).contiguous(),
+        # (g as it arrives: a [:, :27] view of _MlpInput's zero-padded [N, 32] gradient is used in place, anything else is padded)
+        gp, gl, gw = s3d_hip.VmBackend.color_backward(x, mats, vecs, ctx.net.resolution, w16, g.to(torch.float16),
                                                       _bins(ctx.net, x, mats))
         return (None, None, gw) + tuple(gp) + tuple(gl)
+
+
+class _MlpInput(torch.autograd.Function):
+    """cat([encoder(feat), encoder_dir(d)]) of tensoRF/network.py:160-166 as the fp16 autocast Linear sees it, in one launch per
+    direction (s3d_freq_encode_pack_forward / _backward): fp16 features in, one fp16 [N, ld] row out (ld = the MLP kernels' padded
+    input width), instead of a cast, two encoder launches, two casts, a fill and a cat forward and five launches backward.  The
+    feature gradient leaves as a [:, :D] view of a zero-padded [N, 32] fp16 buffer — the row layout the factor backward reads."""
+
+    @staticmethod
+    def forward(ctx, feat, dirs, deg1, deg2, ld):
+        feat = feat.to(torch.float16).contiguous()
+        dirs = dirs.float().contiguous()
+        out = torch.empty(feat.shape[0], ld, dtype=torch.float16, device=feat.device)
+        s3d_hip.FreqBackend.freq_encode_pack_forward(feat, dirs, deg1, deg2, out)
+        ctx.save_for_backward(feat)
+        ctx.deg1 = deg1
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, = ctx.saved_tensors
+        ga = torch.empty(feat.shape[0], max(32, feat.shape[1]), dtype=torch.float16, device=feat.device)
+        s3d_hip.FreqBackend.freq_encode_pack_backward(g.to(torch.float16).contiguous(), feat, ctx.deg1, ga)
+        ga._s3d_zero_padded = True  # (VmBackend.color_backward takes the buffer behind the view)
+        return ga[:, :feat.shape[1]], None, None, None, None
 
 
 class _TallLinear(torch.autograd.Function):
@@ -255,9 +281,10 @@ class NeRFNetwork(NeRFRenderer):
         x = self._normalize(x)
         self.__dict__["_vm_bins"] = {}  # (the previous forward's sorted points)
         sigma = trunc_exp(self.get_sigma_feat(x))
-        feat, dirs = self.encoder(self.get_color_feat(x)), self.encoder_dir(d)
-        if self._fused_mlp_ok(feat):
-            return sigma, torch.sigmoid(self._color_mlp_fused(feat, dirs))
+        cf = self.get_color_feat(x)
+        if self._fused_mlp_ok(cf, d.requires_grad):
+            return sigma, torch.sigmoid(self._color_mlp_fused(cf, d))
+        feat, dirs = self.encoder(cf), self.encoder_dir(d)
         h = torch.cat([feat, dirs], dim=-1)
         for k, layer in enumerate(self.color_net):
             h = _linear(layer, h)
@@ -267,26 +294,24 @@ class NeRFNetwork(NeRFRenderer):
 
     fused_mlp = True  # A-B runs / tests: False = the nn.Linear chain (library GEMMs + elementwise launches)
 
-    def _fused_mlp_ok(self, feat):
+    def _fused_mlp_ok(self, feat, d_requires_grad=False):
         """the colour MLP (tensoRF/network.py:71-83: bias-free Linear -> ReLU chain, 150 -> 128 -> 128 -> 3) on the MFMA kernels
         of the ffmlp package: hidden width 128, input padded to a multiple of 16 (<= 160), whole 128-row tiles, fp16 autocast"""
         net = self.color_net
         return (self.fused_mlp and feat.is_cuda and feat.dim() == 2 and feat.shape[0] > 0 and feat.shape[0] % 128 == 0
                 and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16
                 and len(net) >= 2 and all(l.bias is None for l in net) and self.hidden_dim == 128
-                and net[-1].out_features <= 16 and (self.in_dim + 15) // 16 * 16 <= 160)
+                and net[-1].out_features <= 16 and (self.in_dim + 15) // 16 * 16 <= 160
+                and hasattr(self.encoder, "degree") and hasattr(self.encoder_dir, "degree") and not d_requires_grad)
 
-    def _color_mlp_fused(self, feat, dirs):
-        """same arithmetic as the Linear chain under autocast (fp16 operands, fp32 accumulation, fp16 activations); the weights
-        travel as the ffmlp layout [W, in_pad] | (n - 1) x [W, W] | [16, W] built from the nn.Linear parameters each step
-        (~55 K elements: autograd splits the flat fp16 gradient back)"""
+    def _color_mlp_fused(self, cf, d):
+        """same arithmetic as the encoders + Linear chain under autocast (fp32 encodings rounded to fp16 once, fp16 operands, fp32
+        accumulation, fp16 activations); the weights travel as the ffmlp layout [W, in_pad] | (n - 1) x [W, W] | [16, W] built from
+        the nn.Linear parameters each step (~55 K elements: autograd splits the flat fp16 gradient back)"""
         from ffmlp.ffmlp import _FFMLPForward
         net = self.color_net
-        N, in_pad, out = feat.shape[0], (self.in_dim + 15) // 16 * 16, net[-1].out_features
-        parts = [feat.half(), dirs.half()]
-        if in_pad > self.in_dim:
-            parts.append(torch.zeros(N, in_pad - self.in_dim, dtype=torch.half, device=feat.device))
-        h = torch.cat(parts, dim=-1)
+        in_pad, out = (self.in_dim + 15) // 16 * 16, net[-1].out_features
+        h = _MlpInput.apply(cf, d, self.encoder.degree, self.encoder_dir.degree, in_pad)
         flat = torch.cat([F.pad(net[0].weight, (0, in_pad - self.in_dim)).reshape(-1)] + [l.weight.reshape(-1) for l in net[1:-1]]
                          + [F.pad(net[-1].weight, (0, 0, 0, 16 - out)).reshape(-1)])
         # (the kernels write the output padded to 16 columns, ffmlp.py:117-118, 162-163: the real ones are sliced out)
