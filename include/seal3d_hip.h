@@ -376,7 +376,9 @@ int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* plan
  * point (integer LDS atomics retire ~10x faster than float ones on MI355X) and keep the bounds that fix its scale there
  * (max |grad|, max |line parameter|, max |g m|, max column sum of |basis|); a non-finite bound poisons the gradients.
  * line_scratch: sum_i rank_i * resolution[vec_ids[i]] floats, no initialisation: the bound pass leaves the line factors there
- * transposed ([Dn][rank]) for the plane pass, whose lanes are rank channels. */
+ * transposed ([Dn][rank]) for the plane pass, whose lanes are rank channels.
+ * found_inf (optional device float): set to 1 when a bound is not finite — the condition under which these kernels write a
+ * non-finite gradient — so a GradScaler need not read the 69 MB of factor gradients again to find out. */
 uint32_t s3d_vm_backward_max_bins(const uint32_t* resolution);
 int s3d_vm_backward_keys(const float* x, uint32_t N, const uint32_t* rank, const uint32_t* resolution, int32_t* keys,
                          s3d_stream_t stream);
@@ -390,7 +392,7 @@ int s3d_vm_features_backward(const float* x, uint32_t N, const float* const* pla
                              const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
                              const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
                              float* const* grad_planes, float* const* grad_lines, uint32_t* bound_words, float* line_scratch,
-                             s3d_stream_t stream);
+                             float* found_inf, s3d_stream_t stream);
 
 /* The colour features with basis_mat applied inside the kernel (tensoRF/network.py:149-153: `basis_mat((mat * vec).T)`, an
  * nn.Linear(sum rank, basis_rows, bias=False) that runs under fp16 autocast): out [N, basis_rows] fp16 =
@@ -407,7 +409,7 @@ int s3d_vm_color_backward(const float* x, uint32_t N, const float* const* planes
                           const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
                           const uint16_t* grad_out, const int32_t* perm, const int32_t* start, uint32_t n_bounds,
                           float* gm, float* const* grad_planes, float* const* grad_lines, float* grad_basis,
-                          uint32_t* bound_words, float* line_scratch, s3d_stream_t stream);
+                          uint32_t* bound_words, float* line_scratch, float* found_inf, s3d_stream_t stream);
 
 /* ------------------------------------------------------------------ NGP head glue
  * The elementwise steps between the two MLPs of nerf/network_ff.py:55-96 (slice / trunc_exp / SH / cat / cast /

@@ -316,6 +316,7 @@ struct VmBackward {
     float* line_t;
     uint32_t line_t_off[3];
     uint32_t pts_plane, pts_line;  // sorted points per workgroup
+    float* found_inf;              // optional: raised when a bound is not finite (GradScaler's check made where the gradient is written)
 };
 
 // LDS float atomics retire at ~0.2 T/s on MI355X, LDS integer atomics at ~2.3 T/s (tools/ubench, csrc/gridencoder.hip): the
@@ -454,7 +455,10 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
     if constexpr (BASIS) bound *= __uint_as_float(b.bound[3]);
     if (!vm_scale(bound, scale, inv, poison)) {
         // (nothing to add: gm stays zero.  A non-finite factor poisons the plane gradient like the float sums would)
-        if (poison && blockIdx.x == 0 && threadIdx.x == 0) b.d_plane[i][0] = NAN;
+        if (poison && blockIdx.x == 0 && threadIdx.x == 0) {
+            b.d_plane[i][0] = NAN;
+            if (b.found_inf) *b.found_inf = 1.0f;
+        }
         return;
     }
     long long* acc = reinterpret_cast<long long*>(vm_smem_raw);                   // [81][R] gradient accumulator (fixed point)
@@ -619,7 +623,10 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_line_backward(const float*
     const uint32_t end = begin + b.pts_line < valid_end ? begin + b.pts_line : valid_end;
     float scale = 1.0f, inv = 1.0f;
     bool poison;
-    if (!vm_scale(__uint_as_float(b.bound[2]), scale, inv, poison)) return;  // (max |g m| is finite whenever the plane pass ran)
+    if (!vm_scale(__uint_as_float(b.bound[2]), scale, inv, poison)) {  // (max |g m| is finite whenever the plane pass ran)
+        if (poison && b.found_inf && blockIdx.x == 0 && threadIdx.x == 0) *b.found_inf = 1.0f;
+        return;
+    }
     long long* acc = reinterpret_cast<long long*>(vm_smem_raw);  // [65][R]
     for (uint32_t e = threadIdx.x; e < (kVmZChunk + 1) * R; e += kVmBwdThreads) acc[e] = 0ll;
     constexpr uint32_t PPW = 64 / RP;
@@ -787,7 +794,7 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
                                         const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
                                         const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
                                         float* const* grad_planes, float* const* grad_lines, uint32_t* bound_words,
-                                        float* line_scratch, s3d_stream_t stream) {
+                                        float* line_scratch, float* found_inf, s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && planes && lines && rank && resolution && grad && perm && start && gm && grad_planes && grad_lines && bound_words &&
                 line_scratch, "vm_features_backward: null pointer");
@@ -814,6 +821,7 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
     b.n_bounds = n_bounds;
     b.basis = nullptr; b.g_out = nullptr; b.d_basis = nullptr; b.Cb = 0;
     b.bound = bound_words;
+    b.found_inf = found_inf;
     b.line_t = line_scratch;
     for (uint32_t i = 0, off = 0; i < 3; off += f.rank[i] * f.Dn[i], i++) b.line_t_off[i] = off;
     hipStream_t st = as_stream(stream);
@@ -856,7 +864,7 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
                                      const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
                                      const uint16_t* grad_out, const int32_t* perm, const int32_t* start, uint32_t n_bounds,
                                      float* gm, float* const* grad_planes, float* const* grad_lines, float* grad_basis,
-                                     uint32_t* bound_words, float* line_scratch, s3d_stream_t stream) {
+                                     uint32_t* bound_words, float* line_scratch, float* found_inf, s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && planes && lines && rank && resolution && basis && grad_out && perm && start && gm && grad_planes && grad_lines &&
                 grad_basis && bound_words && line_scratch, "vm_color_backward: null pointer");
@@ -888,6 +896,7 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
     b.d_basis = grad_basis;
     b.Cb = basis_rows;
     b.bound = bound_words;
+    b.found_inf = found_inf;
     b.line_t = line_scratch;
     for (uint32_t i = 0, off = 0; i < 3; off += f.rank[i] * f.Dn[i], i++) b.line_t_off[i] = off;
     hipStream_t st = as_stream(stream);

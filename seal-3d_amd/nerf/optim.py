@@ -321,7 +321,10 @@ class NativeGradScaler:
         """the gradients that are NOT hand-over buffers (`.grad` of the nn.Linear weights of the Seal net, ...): one
         multi-tensor launch for all of them (aten's check-and-unscale with a unit scale raises the same flag; one launch per
         tensor was 5 x 5 us of a 0.9 ms Seal step, profiles/r08_seal.md), the native per-tensor kernel for a single one"""
-        rest = [g for _, p, g in optimizer.grads() if flat is None or g is not getattr(p, "_s3d_grad", None)]
+        # (a gradient whose producer raised THIS flag itself — tensoRF/network.py: the factor backward — is not read again;
+        #  the mark is the producer's, per backward pass, and is consumed here)
+        rest = [g for _, p, g in optimizer.grads() if (flat is None or g is not getattr(p, "_s3d_grad", None))
+                and p.__dict__.pop("_s3d_grad_checked", None) is not self._found_inf]
         if len(rest) > 1 and all(g.is_cuda and g.dtype == rest[0].dtype and g.layout == torch.strided for g in rest):
             torch._amp_foreach_non_finite_check_and_unscale_(rest, self._found_inf, self._one)
         else:

@@ -1044,7 +1044,7 @@ class VmBackend:
         return perm, start, n_bounds
 
     @staticmethod
-    def features_backward(x, planes, lines, resolution, reduce, grad, bins=None):
+    def features_backward(x, planes, lines, resolution, reduce, grad, bins=None, found_inf=None):
         """gradients of features_forward w.r.t. planes / lines (lists shaped like the factors).  grad: [N] (reduce) or
         [N, sum R_i] point-major.  `bins`: a backward_bins() result for the same x / resolution."""
         _need(x, torch.float32, "x"); _need(grad, torch.float32, "grad")
@@ -1065,7 +1065,7 @@ class VmBackend:
                                               ptr3(*[t.data_ptr() for t in lines]), rank, res, C.c_int(int(bool(reduce))),
                                               _p(grad), _p(perm), _p(start), _u(n_bounds), _p(gm),
                                               ptr3(*[t.data_ptr() for t in g_planes]), ptr3(*[t.data_ptr() for t in g_lines]),
-                                              _p(bound_words), _p(line_scratch), _stream()), "vm_features_backward")
+                                              _p(bound_words), _p(line_scratch), _p(found_inf), _stream()), "vm_features_backward")
         return g_planes, g_lines
 
     @staticmethod
@@ -1088,7 +1088,7 @@ class VmBackend:
                "vm_color_forward")
 
     @staticmethod
-    def color_backward(x, planes, lines, resolution, basis, grad_out, bins=None):
+    def color_backward(x, planes, lines, resolution, basis, grad_out, bins=None, found_inf=None):
         """gradients of color_forward w.r.t. planes / lines / basis from grad_out fp16 [N, Cb]: (g_planes, g_lines, g_basis fp32)"""
         _need(x, torch.float32, "x"); _need(basis, torch.float16, "basis"); _need(grad_out, torch.float16, "grad_out")
         N, dev = x.shape[0], x.device
@@ -1114,5 +1114,5 @@ class VmBackend:
                                            u3(*[int(r) for r in resolution]), _p(basis), _u(basis.shape[0]), _p(grad_out),
                                            _p(perm), _p(start), _u(n_bounds), _p(gm), ptr3(*[t.data_ptr() for t in g_planes]),
                                            ptr3(*[t.data_ptr() for t in g_lines]), _p(g_basis),
-                                           _p(bound_words), _p(line_scratch), _stream()), "vm_color_backward")
+                                           _p(bound_words), _p(line_scratch), _p(found_inf), _stream()), "vm_color_backward")
         return g_planes, g_lines, g_basis

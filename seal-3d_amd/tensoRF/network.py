@@ -21,6 +21,23 @@ from encoding import get_encoder
 from nerf.renderer import NeRFRenderer
 
 
+def _source_check(net, factors, *more):
+    """`net._s3d_found_inf` (set by a trainer whose GradScaler owns that flag, tensoRF/utils.py): the factor backward raises it
+    itself when a bound is not finite, and the parameters it writes are marked so that the scaler's pass over the remaining
+    gradients skips them for this step (nerf/optim.py: NativeGradScaler._check_plain)"""
+    flag = getattr(net, "_s3d_found_inf", None)
+    if flag is None:
+        return None
+    owners = {id(p): p for p in list(net.sigma_mat) + list(net.sigma_vec) + list(net.color_mat) + list(net.color_vec) + [net.basis_mat.weight]}
+    for f in list(factors) + list(more):
+        p = owners.get(id(f))
+        if p is None:  # (not the network's own parameter objects: leave the gradient to the scaler's pass)
+            return None
+    for f in list(factors) + list(more):
+        owners[id(f)]._s3d_grad_checked = flag
+    return flag
+
+
 class _VmFeatures(torch.autograd.Function):
     """forward: one HIP kernel; backward: binned HIP kernels for the factor gradients (coordinates' gradient, if ever
     asked for: the reference's grid_sample sequence re-run under autograd)"""
@@ -46,7 +63,8 @@ class _VmFeatures(torch.autograd.Function):
             g = g if ctx.reduce else g.t()  # [rows, N] gradient of the `.T` consumer: point-major underneath
             gp, gl = s3d_hip.VmBackend.features_backward(x, [f.contiguous() for f in factors[:3]],
                                                          [f.contiguous() for f in factors[3:]], ctx.net.resolution, ctx.reduce,
-                                                         g.float().contiguous(), _bins(ctx.net, x, factors[:3]))
+                                                         g.float().contiguous(), _bins(ctx.net, x, factors[:3]),
+                                                         _source_check(ctx.net, factors))
             return (None, None, None) + tuple(gp) + tuple(gl)
         with torch.enable_grad():
             leaves = [f.detach().requires_grad_(True) for f in factors]
@@ -101,7 +119,7 @@ class _VmColorBasis(torch.autograd.Function):
         mats, vecs = [f.float().contiguous() for f in factors[:3]], [f.float().contiguous() for f in factors[3:]]
         # (g as it arrives: a [:, :27] view of _MlpInput's zero-padded [N, 32] gradient is used in place, anything else is padded)
         gp, gl, gw = s3d_hip.VmBackend.color_backward(x, mats, vecs, ctx.net.resolution, w16, g.to(torch.float16),
-                                                      _bins(ctx.net, x, mats))
+                                                      _bins(ctx.net, x, mats), _source_check(ctx.net, factors, ctx.net.basis_mat.weight))
         return (None, None, gw) + tuple(gp) + tuple(gl)
 
 
@@ -219,6 +237,7 @@ class NeRFNetwork(NeRFRenderer):
         state = self.__dict__.copy()
         state.pop("_vm_bins", None)
         state.pop("_l1_inv", None)
+        state.pop("_s3d_found_inf", None)  # (a trainer's scaler flag: re-attached by the trainer that owns the copy)
         return state
 
     def init_one_svd(self, n_component, resolution, scale=0.1):

@@ -22,6 +22,14 @@ class TensoRFSteps:
     def _param_groups(self):
         return self.model.get_params(self.lr0, self.lr1)
 
+    def _attach_source_checks(self):
+        """single replica + native GradScaler: the factor backward raises the scaler's flag itself (s3d_vm_*_backward(found_inf))
+        and the scaler's check pass skips the 69 MB of factor gradients; with a data-parallel layer the REDUCED gradient is what
+        has to be checked, so nothing is attached"""
+        flag = getattr(self.scaler, "_found_inf", None)
+        ok = flag is not None and getattr(self.scaler, "enabled", False) and self.dist is None and self.native_optim
+        self.model.__dict__["_s3d_found_inf"] = flag if ok else None
+
     l1_in_update = True  # native optimizer: the penalty's gradient is formed inside the Adam launch (False: autograd, A/B + tests)
 
     def _regularizer(self):
@@ -62,6 +70,7 @@ class Trainer(TensoRFSteps, _Trainer):
     def __init__(self, model, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, upsample_model_steps=(), upsample_resolutions=(), **kw):
         self._init_tensorf(lr0, lr1, l1_reg_weight, upsample_model_steps, upsample_resolutions)
         _Trainer.__init__(self, model, lr=lr0, **kw)
+        self._attach_source_checks()
 
     def train_step(self, rays_o, rays_d, gt_rgb, bg_color=1):
         loss = _Trainer.train_step(self, rays_o, rays_d, gt_rgb, bg_color)
@@ -75,6 +84,7 @@ class GraphedTrainer(TensoRFSteps, _GraphedTrainer):
     def __init__(self, model, num_rays, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, upsample_model_steps=(), upsample_resolutions=(), **kw):
         self._init_tensorf(lr0, lr1, l1_reg_weight, upsample_model_steps, upsample_resolutions)
         _GraphedTrainer.__init__(self, model, num_rays, lr=lr0, **kw)
+        self._attach_source_checks()
 
     def train_step(self, rays_o, rays_d, gt_rgb, bg_color=1):
         loss = _GraphedTrainer.train_step(self, rays_o, rays_d, gt_rgb, bg_color)

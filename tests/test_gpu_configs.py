@@ -590,3 +590,48 @@ def test_tensorf_colour_mlp_on_the_ffmlp_kernels_matches_the_linear_chain(hip):
             continue
         a, b = out[True][1][k], out[False][1][k]
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-6, (k, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_tensorf_factor_backward_raises_the_scalers_flag_itself(hip):
+    """tensoRF/utils.py `_attach_source_checks`: with the native GradScaler on one replica the factor backward marks the gradients
+    it wrote and raises found_inf for a non-finite bound, so the scaler's check pass reads only the MLP weights; a non-finite
+    factor then skips the whole step (no parameter moves, the scale backs off) exactly like the scaler's own pass would"""
+    from tensoRF import network as trf
+    from tensoRF.utils import Trainer
+    from nerf import synthetic as syn
+    import nerf.optim as optim
+    poses = syn.orbit_poses(1, seed=0).cuda()
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    torch.manual_seed(3)
+    net = trf.NeRFNetwork(resolution=[64] * 3, bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10).cuda()
+    net.density_grid.copy_(torch.from_numpy(grid)); net.density_bitfield.copy_(torch.from_numpy(bits))
+    net.iter_density = 100
+    tr = Trainer(net, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, fp16=True, update_extra_interval=10 ** 9, native_optim=True)
+    assert net._s3d_found_inf is tr.scaler._found_inf
+    tr.global_step = 1
+    r = syn.get_rays(poses[:1], syn.lego_intrinsics(), 800, 800, N=1024, generator=torch.Generator().manual_seed(0))
+    batch = (r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous(), torch.rand(1024, 3).cuda())
+    seen = []
+    inner = torch._amp_foreach_non_finite_check_and_unscale_
+
+    def spy(grads, found_inf, inv_scale):
+        seen.append(sum(g.numel() for g in grads))
+        return inner(grads, found_inf, inv_scale)
+    torch._amp_foreach_non_finite_check_and_unscale_ = spy
+    try:
+        tr.train_step(*batch)
+        factors = sum(p.numel() for p in list(net.sigma_mat) + list(net.sigma_vec) + list(net.color_mat) + list(net.color_vec))
+        assert seen and max(seen) < factors, (seen, factors)  # the pass no longer covers the factors
+        assert all("_s3d_grad_checked" not in p.__dict__ for p in net.parameters())
+        # a non-finite colour line factor: found_inf from the kernels, the step is skipped
+        before = [p.detach().clone() for p in net.parameters()]
+        scale0 = float(tr.scaler.get_scale())
+        with torch.no_grad():
+            net.color_vec[1][0, 3, 7, 0] = float("inf")
+            before[[id(p) for p in net.parameters()].index(id(net.color_vec[1]))][0, 3, 7, 0] = float("inf")
+        tr.train_step(*batch)
+        for a, b in zip(net.parameters(), before):
+            assert torch.equal(a.detach(), b)
+        assert float(tr.scaler.get_scale()) < scale0
+    finally:
+        torch._amp_foreach_non_finite_check_and_unscale_ = inner
