@@ -213,14 +213,14 @@ __global__ void __launch_bounds__(256) k_vm_keys(const float* __restrict__ x, ui
 // the lanes of a wave that share `key`: the group's first lane (leader), the lane's rank inside the group and the group's size —
 // a loop over the wave's DISTINCT keys (a handful for ray-ordered points), no memory traffic
 struct BinGroup { uint32_t leader, rank, size; };
-__device__ __forceinline__ BinGroup wave_bin_group(uint32_t key, uint32_t lane) {
+__device__ __forceinline__ BinGroup wave_bin_group(uint32_t key, uint32_t lane, bool active = true) {
     BinGroup g{0u, 0u, 0u};
-    unsigned long long todo = __ballot(1);
+    unsigned long long todo = __ballot(active);
     while (todo) {
         const uint32_t first = (uint32_t)__ffsll((long long)todo) - 1u;
         const uint32_t k = (uint32_t)__shfl((int)key, (int)first, 64);
-        const unsigned long long same = __ballot(key == k) & todo;
-        if (key == k) {
+        const unsigned long long same = __ballot(active && key == k) & todo;
+        if (active && key == k) {
             g.leader = first;
             g.rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
             g.size = (uint32_t)__popcll(same);
@@ -229,27 +229,45 @@ __device__ __forceinline__ BinGroup wave_bin_group(uint32_t key, uint32_t lane) 
     }
     return g;
 }
+// The three line rows have a handful of bins (resolution / 64 chunks + the bin of points without contribution): every wave of the
+// launch would add to the same ~5 words per row — a thousand same-address atomics each, 25 us of a 30 us kernel.  A workgroup of
+// sixteen waves sums them in LDS first (slot = chunk, last slot = no contribution) and sends one atomic per slot.
+constexpr uint32_t kVmLineSlots = 33;  // chunks 0..31 + "no contribution"
+constexpr uint32_t kVmBinThreads = 1024;
 __global__ void __launch_bounds__(256) k_vm_zero_words(uint32_t* __restrict__ p, uint32_t n) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0u;
 }
-__global__ void __launch_bounds__(256) k_vm_bin_count(const float* __restrict__ x, uint32_t N, VmFactors f, uint32_t n_bounds,
-                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ counts) {
-    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;  // (whole waves leave together except in the last block: __ballot(1) counts the lanes still here)
+__global__ void __launch_bounds__(kVmBinThreads) k_vm_bin_count(const float* __restrict__ x, uint32_t N, VmFactors f, uint32_t n_bounds,
+                                                                uint32_t nlb, uint32_t* __restrict__ keys, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t lc[3][kVmLineSlots];
+    if (threadIdx.x < 3 * kVmLineSlots) (&lc[0][0])[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t n = blockIdx.x * kVmBinThreads + threadIdx.x;
+    const bool live = n < N;
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
     for (uint32_t i = 0; i < 3; i++) {
-        const VmPoint q = vm_locate(x, n, f, i);
+        const VmPoint q = vm_locate(x, live ? n : 0u, f, i);
         const int tiles_x = ((int)f.W[i] + kVmTile - 1) / kVmTile;
         const uint32_t tk = (uint32_t)((clampi(q.y0, 0, (int)f.H[i] - 1) / kVmTile) * tiles_x + clampi(q.x0, 0, (int)f.W[i] - 1) / kVmTile);
         const uint32_t zk = (uint32_t)(clampi(q.z0, 0, (int)f.Dn[i] - 1) / kVmZChunk);
         const uint32_t kp = q.valid ? tk : n_bounds - 1u, kl = q.valid ? zk : n_bounds - 1u;
-        keys[(size_t)i * N + n] = kp;
-        keys[(size_t)(3 + i) * N + n] = kl;
-        const BinGroup gp = wave_bin_group(kp, lane), gl = wave_bin_group(kl, lane);
-        if (lane == gp.leader) atomicAdd(&counts[i * n_bounds + kp], gp.size);  // (no value returned: nothing waits for it)
-        if (lane == gl.leader) atomicAdd(&counts[(3 + i) * n_bounds + kl], gl.size);
+        if (live) {
+            keys[(size_t)i * N + n] = kp;
+            keys[(size_t)(3 + i) * N + n] = kl;
+        }
+        const BinGroup gp = wave_bin_group(kp, lane, live);
+        if (live && lane == gp.leader) atomicAdd(&counts[i * n_bounds + kp], gp.size);  // (no value returned: nothing waits for it)
+        const uint32_t slot = q.valid ? zk : nlb;
+        const BinGroup gl = wave_bin_group(slot, lane, live);
+        if (live && lane == gl.leader) atomicAdd(&lc[i][slot], gl.size);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * kVmLineSlots) {
+        const uint32_t i = threadIdx.x / kVmLineSlots, slot = threadIdx.x % kVmLineSlots;
+        const uint32_t c = lc[i][slot];
+        if (c && slot <= nlb) atomicAdd(&counts[(3 + i) * n_bounds + (slot == nlb ? n_bounds - 1u : slot)], c);
     }
 }
 // start[r][t] = points of row r in bins < t: one wave per row, lane l sums bins [l * per, (l + 1) * per) on its own (all its
@@ -258,38 +276,78 @@ __global__ void __launch_bounds__(384) k_vm_bin_scan(const uint32_t* __restrict_
     const uint32_t r = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t per = (n_bounds + 63u) / 64u;
     const uint32_t t0 = lane * per;
+    constexpr uint32_t kKeep = 32;  // a lane's counts stay in registers up to this run length (n_bounds <= 2,048: resolution <= 360)
+    uint32_t c[kKeep];
     uint32_t total = 0;
-    for (uint32_t j = 0; j < per; j++) total += t0 + j < n_bounds ? counts[r * n_bounds + t0 + j] : 0u;
+    if (per <= kKeep) {
+#pragma unroll
+        for (uint32_t j = 0; j < kKeep; j++) c[j] = (j < per && t0 + j < n_bounds) ? counts[r * n_bounds + t0 + j] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < kKeep; j++) total += c[j];
+    } else {
+        for (uint32_t j = 0; j < per; j++) total += t0 + j < n_bounds ? counts[r * n_bounds + t0 + j] : 0u;
+    }
     uint32_t incl = total;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= (uint32_t)d) incl += o; }
     uint32_t run = incl - total;
-    for (uint32_t j = 0; j < per && t0 + j < n_bounds; j++) {
-        start[r * n_bounds + t0 + j] = (int32_t)run;
-        run += counts[r * n_bounds + t0 + j];
+    if (per <= kKeep) {
+#pragma unroll
+        for (uint32_t j = 0; j < kKeep; j++) {
+            if (j < per && t0 + j < n_bounds) start[r * n_bounds + t0 + j] = (int32_t)run;
+            run += c[j];
+        }
+    } else {
+        for (uint32_t j = 0; j < per && t0 + j < n_bounds; j++) {
+            start[r * n_bounds + t0 + j] = (int32_t)run;
+            run += counts[r * n_bounds + t0 + j];
+        }
     }
 }
-__global__ void __launch_bounds__(256) k_vm_bin_scatter(const uint32_t* __restrict__ keys, uint32_t N, uint32_t n_bounds,
-                                                        const int32_t* __restrict__ start, uint32_t* __restrict__ cursors,
-                                                        int32_t* __restrict__ perm) {
-    const uint32_t n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+__global__ void __launch_bounds__(kVmBinThreads) k_vm_bin_scatter(const uint32_t* __restrict__ keys, uint32_t N, uint32_t n_bounds,
+                                                                  uint32_t nlb, const int32_t* __restrict__ start,
+                                                                  uint32_t* __restrict__ cursors, int32_t* __restrict__ perm) {
+    __shared__ uint32_t lc[3][kVmLineSlots], lbase[3][kVmLineSlots];
+    if (threadIdx.x < 3 * kVmLineSlots) (&lc[0][0])[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t n = blockIdx.x * kVmBinThreads + threadIdx.x;
+    const bool live = n < N;
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t k[6], base[6], first[6];
+    uint32_t k[6], base[3], first[6], slot[3], woff[3];
     BinGroup g[6];
 #pragma unroll
     for (uint32_t r = 0; r < 6; r++) {
-        k[r] = keys[(size_t)r * N + n];
+        k[r] = live ? keys[(size_t)r * N + n] : 0u;
         first[r] = (uint32_t)start[r * n_bounds + k[r]];
-        g[r] = wave_bin_group(k[r], lane);
     }
-    // one reservation per distinct (row, bin) of the wave, all six rows' requests in flight before the first answer is used
+    // plane rows: one reservation per distinct bin of the wave, the three rows' requests in flight together
 #pragma unroll
-    for (uint32_t r = 0; r < 6; r++) base[r] = lane == g[r].leader ? atomicAdd(&cursors[r * n_bounds + k[r]], g[r].size) : 0u;
+    for (uint32_t r = 0; r < 3; r++) {
+        g[r] = wave_bin_group(k[r], lane, live);
+        base[r] = (live && lane == g[r].leader) ? atomicAdd(&cursors[r * n_bounds + k[r]], g[r].size) : 0u;
+    }
+    // line rows: the wave's offset inside the workgroup from LDS, the workgroup's reservation by one thread per slot
 #pragma unroll
-    for (uint32_t r = 0; r < 6; r++) {
+    for (uint32_t r = 0; r < 3; r++) {
+        slot[r] = k[3 + r] == n_bounds - 1u ? nlb : k[3 + r];
+        g[3 + r] = wave_bin_group(slot[r], lane, live);
+        woff[r] = (live && lane == g[3 + r].leader) ? atomicAdd(&lc[r][slot[r]], g[3 + r].size) : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * kVmLineSlots) {
+        const uint32_t i = threadIdx.x / kVmLineSlots, sl = threadIdx.x % kVmLineSlots;
+        const uint32_t c = lc[i][sl];
+        lbase[i][sl] = (c && sl <= nlb) ? atomicAdd(&cursors[(3 + i) * n_bounds + (sl == nlb ? n_bounds - 1u : sl)], c) : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < 3; r++) {
         const uint32_t b = (uint32_t)__shfl((int)base[r], (int)g[r].leader, 64);
-        perm[(size_t)r * N + first[r] + b + g[r].rank] = (int32_t)n;
+        const uint32_t w = (uint32_t)__shfl((int)woff[r], (int)g[3 + r].leader, 64);
+        if (live) {
+            perm[(size_t)r * N + first[r] + b + g[r].rank] = (int32_t)n;
+            perm[(size_t)(3 + r) * N + first[3 + r] + lbase[r][slot[r]] + w + g[3 + r].rank] = (int32_t)n;
+        }
     }
 }
 
@@ -757,10 +815,13 @@ S3D_EXPORT int s3d_vm_backward_bins(const float* x, uint32_t N, const uint32_t* 
     // (a kernel, not hipMemsetAsync: the call is also captured into HIP graphs, where a memset node did not clear the counters on
     //  replay — ROCm 7.2, memory access fault in the scatter of the first replayed step)
     hipLaunchKernelGGL(k_vm_zero_words, dim3(div_up<uint32_t>(12u * n_bounds, 256)), dim3(256), 0, st, counts, 12u * n_bounds);
-    hipLaunchKernelGGL(k_vm_bin_count, dim3(div_up<uint32_t>(N, 256)), dim3(256), 0, st, x, N, f, n_bounds, keys, counts);
+    uint32_t nlb = 0;  // line chunks of the longest axis
+    for (uint32_t i = 0; i < 3; i++) nlb = std::max(nlb, div_up<uint32_t>(resolution[i], (uint32_t)kVmZChunk));
+    S3D_REQUIRE(nlb < kVmLineSlots, "vm_backward_bins: resolution %u has more than %u line chunks", nlb * kVmZChunk, kVmLineSlots - 1);
+    hipLaunchKernelGGL(k_vm_bin_count, dim3(div_up<uint32_t>(N, kVmBinThreads)), dim3(kVmBinThreads), 0, st, x, N, f, n_bounds, nlb, keys, counts);
     hipLaunchKernelGGL(k_vm_bin_scan, dim3(1), dim3(384), 0, st, (const uint32_t*)counts, n_bounds, start);
-    hipLaunchKernelGGL(k_vm_bin_scatter, dim3(div_up<uint32_t>(N, 256)), dim3(256), 0, st, (const uint32_t*)keys, N, n_bounds,
-                       (const int32_t*)start, cursors, perm);
+    hipLaunchKernelGGL(k_vm_bin_scatter, dim3(div_up<uint32_t>(N, kVmBinThreads)), dim3(kVmBinThreads), 0, st, (const uint32_t*)keys, N,
+                       n_bounds, nlb, (const int32_t*)start, cursors, perm);
     return check_launch("vm_backward_bins");
 }
 
