@@ -411,6 +411,17 @@ int s3d_vm_color_backward(const float* x, uint32_t N, const float* const* planes
                           float* gm, float* const* grad_planes, float* const* grad_lines, float* grad_basis,
                           uint32_t* bound_words, float* line_scratch, float* found_inf, s3d_stream_t stream);
 
+/* Build extensions for the TensoRF step (chains of tiny launches otherwise):
+ * s3d_aabb_normalize: out[n][a] = 2 (x[n][a] - aabb[a]) / (aabb[3 + a] - aabb[a]) - 1 (tensoRF/network.py:155-157, the reference's
+ *   operation order; aabb = 6 DEVICE floats);
+ * s3d_weighted_abs_sum: *out = sum_i weights[i] * sum |tensors[i]| over up to 8 fp32 tensors (host arrays of device pointers /
+ *   element counts / weights) — density_loss() of tensoRF/network.py:259-263 with weights 1 / numel; workspace:
+ *   s3d_weighted_abs_sum_workspace_size() bytes of scratch; fixed summation order. */
+int s3d_aabb_normalize(const float* x, const float* aabb, uint32_t N, float* out, s3d_stream_t stream);
+size_t s3d_weighted_abs_sum_workspace_size(void);
+int s3d_weighted_abs_sum(const float* const* tensors, const uint64_t* numel, const float* weights, int32_t count, float* out,
+                         float* workspace, s3d_stream_t stream);
+
 /* ------------------------------------------------------------------ NGP head glue
  * The elementwise steps between the two MLPs of nerf/network_ff.py:55-96 (slice / trunc_exp / SH / cat / cast /
  * sigmoid and their backward nodes) as two streaming kernels per direction, csrc/ngp_head.hip.

@@ -764,6 +764,49 @@ int fill_factors(VmFactors& f, const float* const* planes, const float* const* l
     return S3D_OK;
 }
 
+// ---- two small pieces of the TensoRF step that were chains of tiny torch launches
+// x -> 2 (x - lo) / (hi - lo) - 1 per axis (tensoRF/network.py:155-157 `_normalize`, the reference's operation order)
+__global__ void __launch_bounds__(256) k_aabb_normalize(const float* __restrict__ x, const float* __restrict__ aabb, uint32_t n3,
+                                                        float* __restrict__ out) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n3) return;
+    const uint32_t a = t % 3u;
+    out[t] = (2.0f * (x[t] - aabb[a])) / (aabb[3 + a] - aabb[a]) - 1.0f;
+}
+// sum_i w_i * sum |t_i| over up to 8 tensors (density_loss(): w_i = 1 / numel_i): block partials, then one block adds them in a
+// fixed order
+constexpr int kAbsMaxTensors = 8;
+constexpr uint32_t kAbsBlocks = 256;
+struct AbsJobs {
+    const float* p[kAbsMaxTensors];
+    uint64_t n[kAbsMaxTensors];
+    float w[kAbsMaxTensors];
+    int32_t count;
+};
+__global__ void __launch_bounds__(256) k_weighted_abs_partial(AbsJobs j, float* __restrict__ partial) {
+    __shared__ float part[4];
+    float acc = 0.0f;
+    for (int i = 0; i < j.count; i++) {
+        float a = 0.0f;
+        for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < j.n[i]; k += (uint64_t)kAbsBlocks * 256) a += fabsf(j.p[i][k]);
+        acc += j.w[i] * a;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+__global__ void __launch_bounds__(256) k_weighted_abs_final(const float* __restrict__ partial, float* __restrict__ out) {
+    __shared__ float part[4];
+    float acc = partial[threadIdx.x];  // kAbsBlocks == 256 threads
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
 }  // namespace
 }  // namespace s3d
 
@@ -985,4 +1028,25 @@ S3D_EXPORT int s3d_vm_features_forward(const float* x, uint32_t N, const float* 
     if (reduce) hipLaunchKernelGGL((k_vm_features<true>), grid, block, 0, as_stream(stream), x, N, f, out);
     else hipLaunchKernelGGL((k_vm_features<false>), grid, block, 0, as_stream(stream), x, N, f, out);
     return check_launch("vm_features_forward");
+}
+
+S3D_EXPORT int s3d_aabb_normalize(const float* x, const float* aabb, uint32_t N, float* out, s3d_stream_t stream) {
+    if (N == 0) return S3D_OK;
+    S3D_REQUIRE(x && aabb && out && (uint64_t)N * 3 < (1ull << 32), "aabb_normalize: null pointer or too many points");
+    hipLaunchKernelGGL(k_aabb_normalize, dim3(div_up<uint32_t>(N * 3, 256)), dim3(256), 0, as_stream(stream), x, aabb, N * 3, out);
+    return check_launch("aabb_normalize");
+}
+
+S3D_EXPORT size_t s3d_weighted_abs_sum_workspace_size(void) { return kAbsBlocks * sizeof(float); }
+S3D_EXPORT int s3d_weighted_abs_sum(const float* const* tensors, const uint64_t* numel, const float* weights, int32_t count, float* out,
+                                    float* workspace, s3d_stream_t stream) {
+    S3D_REQUIRE(tensors && numel && weights && out && workspace && count >= 1 && count <= kAbsMaxTensors,
+                "weighted_abs_sum: null pointer or more than %d tensors", kAbsMaxTensors);
+    AbsJobs j;
+    memset(&j, 0, sizeof(j));
+    j.count = count;
+    for (int i = 0; i < count; i++) { j.p[i] = tensors[i]; j.n[i] = numel[i]; j.w[i] = weights[i]; }
+    hipLaunchKernelGGL(k_weighted_abs_partial, dim3(kAbsBlocks), dim3(256), 0, as_stream(stream), j, workspace);
+    hipLaunchKernelGGL(k_weighted_abs_final, dim3(1), dim3(256), 0, as_stream(stream), (const float*)workspace, out);
+    return check_launch("weighted_abs_sum");
 }

@@ -43,6 +43,7 @@ EXPORTS = [
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_mid2_forward", "s3d_ngp_mid2_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
     "s3d_bg_mse_forward", "s3d_bg_mse_backward", "s3d_bg_targets", "s3d_l1_pair_workspace_size", "s3d_l1_pair_loss",
     "s3d_seal_bbox_map", "s3d_vm_features_forward",
+    "s3d_aabb_normalize", "s3d_weighted_abs_sum_workspace_size", "s3d_weighted_abs_sum",
     "s3d_vm_backward_max_bins", "s3d_vm_backward_keys", "s3d_vm_backward_bins_workspace_size", "s3d_vm_backward_bins",
     "s3d_vm_features_backward", "s3d_vm_color_forward", "s3d_vm_color_backward",
 ]
@@ -73,7 +74,8 @@ def lib():
         for name in ("s3d_march_rays_train_workspace_size", "s3d_compact_alive_workspace_size",
                      "s3d_ffmlp_backward_workspace_size", "s3d_grid_encode_backward_workspace_size",
                      "s3d_grid_encode_backward_control_size", "s3d_l1_pair_workspace_size",
-                     "s3d_sweep_update_workspace_size", "s3d_vm_backward_bins_workspace_size"):
+                     "s3d_sweep_update_workspace_size", "s3d_vm_backward_bins_workspace_size",
+                     "s3d_weighted_abs_sum_workspace_size"):
             getattr(l, name).restype = C.c_size_t
         l.s3d_vm_backward_max_bins.restype = C.c_uint32
         l.s3d_grid_level_scales.restype = None
@@ -1009,6 +1011,29 @@ class VmBackend:
         res = u3(*[int(r) for r in resolution])
         _check(lib().s3d_vm_features_forward(_p(x), _u(x.shape[0]), pl, ln, rank, res, C.c_int(int(bool(reduce))), _p(out),
                                              _stream()), "vm_features_forward")
+
+    @staticmethod
+    def aabb_normalize(x, aabb, out):
+        """out = 2 (x - aabb[:3]) / (aabb[3:] - aabb[:3]) - 1 per row of x [N, 3] (seal3d_hip.h)"""
+        _need(x, torch.float32, "x"); _need(aabb, torch.float32, "aabb"); _need(out, torch.float32, "out")
+        if not (x.is_contiguous() and out.is_contiguous() and aabb.is_contiguous()) or x.shape[-1] != 3 or aabb.numel() != 6 or out.shape != x.shape:
+            raise RuntimeError("aabb_normalize: contiguous x / out [N, 3], aabb [6]")
+        _check(lib().s3d_aabb_normalize(_p(x), _p(aabb), _u(x.shape[0]), _p(out), _stream()), "aabb_normalize")
+
+    @staticmethod
+    def weighted_abs_sum(tensors, weights, out):
+        """out (fp32 scalar tensor) = sum_i weights[i] * sum |tensors[i]| (seal3d_hip.h)"""
+        _need(out, torch.float32, "out")
+        n = len(tensors)
+        for t in tensors:
+            _need(t, torch.float32, "tensor")
+            if not t.is_contiguous() or not t.is_cuda:
+                raise RuntimeError("weighted_abs_sum: contiguous GPU tensors")
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+        numel = (C.c_uint64 * n)(*[t.numel() for t in tensors])
+        ws = (C.c_float * n)(*[float(w) for w in weights])
+        work = torch.empty(int(lib().s3d_weighted_abs_sum_workspace_size()) // 4, dtype=torch.float32, device=out.device)
+        _check(lib().s3d_weighted_abs_sum(ptrs, numel, ws, C.c_int32(n), _p(out), _p(work), _stream()), "weighted_abs_sum")
 
     # False (S3D_VM_BINS=torch): keys + torch.sort + searchsorted, the A/B twin of s3d_vm_backward_bins
     native_bins = os.environ.get("S3D_VM_BINS", "native") != "torch"

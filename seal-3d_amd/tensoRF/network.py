@@ -294,6 +294,11 @@ class NeRFNetwork(NeRFRenderer):
         return _linear(self.basis_mat, self._color_prod_torch(x, self.color_mat, self.color_vec).T)
 
     def _normalize(self, x):
+        if (self.fused_vm and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and not x.requires_grad
+                and self.aabb_train.is_cuda and self.aabb_train.dtype == torch.float32):
+            out = torch.empty_like(x)  # (one launch instead of five, the same operations in the same order)
+            s3d_hip.VmBackend.aabb_normalize(x, self.aabb_train.contiguous(), out)
+            return out
         return 2 * (x - self.aabb_train[:3]) / (self.aabb_train[3:] - self.aabb_train[:3]) - 1
 
     def forward(self, x, d):
@@ -302,7 +307,7 @@ class NeRFNetwork(NeRFRenderer):
         sigma = trunc_exp(self.get_sigma_feat(x))
         cf = self.get_color_feat(x)
         if self._fused_mlp_ok(cf, d.requires_grad):
-            return sigma, torch.sigmoid(self._color_mlp_fused(cf, d))
+            return sigma, self._color_mlp_fused(cf, d)
         feat, dirs = self.encoder(cf), self.encoder_dir(d)
         h = torch.cat([feat, dirs], dim=-1)
         for k, layer in enumerate(self.color_net):
@@ -324,8 +329,8 @@ class NeRFNetwork(NeRFRenderer):
                 and hasattr(self.encoder, "degree") and hasattr(self.encoder_dir, "degree") and not d_requires_grad)
 
     def _color_mlp_fused(self, cf, d):
-        """same arithmetic as the encoders + Linear chain under autocast (fp32 encodings rounded to fp16 once, fp16 operands, fp32
-        accumulation, fp16 activations); the weights travel as the ffmlp layout [W, in_pad] | (n - 1) x [W, W] | [16, W] built from
+        """the colours: same arithmetic as the encoders + Linear chain + sigmoid under autocast (fp32 encodings rounded to fp16 once,
+        fp16 operands, fp32 accumulation, fp16 activations); the weights travel as the ffmlp layout [W, in_pad] | (n - 1) x [W, W] | [16, W] built from
         the nn.Linear parameters each step (~55 K elements: autograd splits the flat fp16 gradient back)"""
         from ffmlp.ffmlp import _FFMLPForward
         net = self.color_net
@@ -333,8 +338,14 @@ class NeRFNetwork(NeRFRenderer):
         h = _MlpInput.apply(cf, d, self.encoder.degree, self.encoder_dir.degree, in_pad)
         flat = torch.cat([F.pad(net[0].weight, (0, in_pad - self.in_dim)).reshape(-1)] + [l.weight.reshape(-1) for l in net[1:-1]]
                          + [F.pad(net[-1].weight, (0, 0, 0, 16 - out)).reshape(-1)])
-        # (the kernels write the output padded to 16 columns, ffmlp.py:117-118, 162-163: the real ones are sliced out)
-        return _FFMLPForward.apply(h, flat, in_pad, 16, self.hidden_dim, len(net) - 1, 0, 6, False, True)[:, :out]
+        # (the kernels write the output padded to 16 columns, ffmlp.py:117-118, 162-163)
+        out16 = _FFMLPForward.apply(h, flat, in_pad, 16, self.hidden_dim, len(net) - 1, 0, 6, False, True)
+        if out == 3:
+            # sigmoid of the three real columns as fp32 with torch.sigmoid's fp16 rounding, one launch per direction
+            # (nerf/network_ff.py: _NgpRgb — instead of slice, sigmoid, cast and their four backward launches)
+            from nerf.network_ff import _NgpRgb
+            return _NgpRgb.apply(out16)
+        return torch.sigmoid(out16[:, :out])
 
     def density(self, x):
         return {"sigma": trunc_exp(self.get_sigma_feat(self._normalize(x)))}
@@ -355,6 +366,10 @@ class NeRFNetwork(NeRFRenderer):
     def density_loss_value(self):
         """the value of density_loss() without a graph (tensoRF/utils.py: the trainer whose optimizer forms the gradient itself)"""
         ts = [t.detach() for t in list(self.sigma_mat) + list(self.sigma_vec)]
+        if self.fused_l1 and all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts) and len(ts) <= 8:
+            out = torch.empty((), dtype=torch.float32, device=ts[0].device)  # (two launches instead of eight)
+            s3d_hip.VmBackend.weighted_abs_sum(ts, [1.0 / t.numel() for t in ts], out)
+            return out
         key = tuple(t.numel() for t in ts)
         inv = self.__dict__.get("_l1_inv")
         if inv is None or inv[0] != key or inv[1].device != ts[0].device:

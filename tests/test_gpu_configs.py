@@ -635,3 +635,25 @@ def test_tensorf_factor_backward_raises_the_scalers_flag_itself(hip):
         assert float(tr.scaler.get_scale()) < scale0
     finally:
         torch._amp_foreach_non_finite_check_and_unscale_ = inner
+
+
+def test_tensorf_small_fused_launches_match_their_torch_expressions(hip):
+    """s3d_aabb_normalize == 2 (x - lo) / (hi - lo) - 1 bit for bit (same operations, same order); s3d_weighted_abs_sum == the sum of
+    mean|t| over the density factors to fp32 rounding; the colour head through _NgpRgb == torch.sigmoid on the fp16 output"""
+    import s3d_hip
+    from tensoRF import network as trf
+    g = torch.Generator().manual_seed(8)
+    x = (torch.rand(5000, 3, generator=g) * 3 - 1.5).cuda()
+    aabb = torch.tensor([-1.0, -0.7, -1.3, 0.9, 1.1, 0.8], device="cuda")
+    out = torch.empty_like(x)
+    s3d_hip.VmBackend.aabb_normalize(x, aabb, out)
+    assert torch.equal(out, 2 * (x - aabb[:3]) / (aabb[3:] - aabb[:3]) - 1)
+    torch.manual_seed(2)
+    net = trf.NeRFNetwork(resolution=[40, 33, 28], bound=1, cuda_ray=True).cuda()
+    a = float(net.density_loss_value())
+    net.fused_l1 = False
+    b = float(net.density_loss())
+    assert abs(a - b) <= 2e-6 * abs(b), (a, b)
+    h = torch.randn(4096, 16, generator=g).half().cuda()
+    from nerf.network_ff import _NgpRgb
+    assert torch.equal(_NgpRgb.apply(h), torch.sigmoid(h[:, :3]).float())
