@@ -422,6 +422,15 @@ size_t s3d_weighted_abs_sum_workspace_size(void);
 int s3d_weighted_abs_sum(const float* const* tensors, const uint64_t* numel, const float* weights, int32_t count, float* out,
                          float* workspace, s3d_stream_t stream);
 
+/* s3d_pack_linear_chain: the fp32 [rows_i, cols_i] weights of a bias-free nn.Linear chain into the flat fp16 vector s3d_ffmlp_*
+ * take ([W, in_pad] | (n - 1) x [W, W] | [16, W]: matrix i at its running offset, row stride ld[i] >= cols[i], padded_rows[i] >=
+ * rows[i] rows, padding zero) in one launch; s3d_unpack_linear_chain: the flat fp16 gradient back into fp32 matrices of the
+ * parameters' shapes.  Host arrays of `count` <= 8 entries. */
+int s3d_pack_linear_chain(const float* const* mats, const uint32_t* rows, const uint32_t* cols, const uint32_t* padded_rows,
+                          const uint32_t* ld, int32_t count, uint16_t* flat, s3d_stream_t stream);
+int s3d_unpack_linear_chain(const uint16_t* flat, float* const* mats, const uint32_t* rows, const uint32_t* cols,
+                            const uint32_t* padded_rows, const uint32_t* ld, int32_t count, s3d_stream_t stream);
+
 /* ------------------------------------------------------------------ NGP head glue
  * The elementwise steps between the two MLPs of nerf/network_ff.py:55-96 (slice / trunc_exp / SH / cat / cast /
  * sigmoid and their backward nodes) as two streaming kernels per direction, csrc/ngp_head.hip.

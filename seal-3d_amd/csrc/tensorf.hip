@@ -764,6 +764,32 @@ int fill_factors(VmFactors& f, const float* const* planes, const float* const* l
     return S3D_OK;
 }
 
+// ---- the weights of a bias-free Linear chain in the ffmlp package's flat fp16 layout (and the flat fp16 gradient back into
+// fp32 matrices): matrix i is [rows_i, cols_i] fp32 row-major and lands at flat[off_i + r * ld_i + c], the padding (columns
+// cols_i..ld_i, rows behind rows_i up to prows_i) is written as zeros
+constexpr int kPackMaxMats = 8;
+struct PackJobs {
+    float* m[kPackMaxMats];
+    uint32_t rows[kPackMaxMats], cols[kPackMaxMats], prows[kPackMaxMats], ld[kPackMaxMats], off[kPackMaxMats + 1];
+    int32_t count;
+};
+__global__ void __launch_bounds__(256) k_pack_linear_chain(PackJobs j, _Float16* __restrict__ flat) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= j.off[j.count]) return;
+    int i = 0;
+    while (i + 1 < j.count && t >= j.off[i + 1]) i++;
+    const uint32_t e = t - j.off[i], r = e / j.ld[i], c = e - r * j.ld[i];
+    flat[t] = (r < j.rows[i] && c < j.cols[i]) ? (_Float16)j.m[i][(size_t)r * j.cols[i] + c] : (_Float16)0.0f;
+}
+__global__ void __launch_bounds__(256) k_unpack_linear_chain(PackJobs j, const _Float16* __restrict__ flat) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= j.off[j.count]) return;
+    int i = 0;
+    while (i + 1 < j.count && t >= j.off[i + 1]) i++;
+    const uint32_t e = t - j.off[i], r = e / j.ld[i], c = e - r * j.ld[i];
+    if (r < j.rows[i] && c < j.cols[i]) j.m[i][(size_t)r * j.cols[i] + c] = (float)flat[t];
+}
+
 // ---- two small pieces of the TensoRF step that were chains of tiny torch launches
 // x -> 2 (x - lo) / (hi - lo) - 1 per axis (tensoRF/network.py:155-157 `_normalize`, the reference's operation order)
 __global__ void __launch_bounds__(256) k_aabb_normalize(const float* __restrict__ x, const float* __restrict__ aabb, uint32_t n3,
@@ -1049,4 +1075,37 @@ S3D_EXPORT int s3d_weighted_abs_sum(const float* const* tensors, const uint64_t*
     hipLaunchKernelGGL(k_weighted_abs_partial, dim3(kAbsBlocks), dim3(256), 0, as_stream(stream), j, workspace);
     hipLaunchKernelGGL(k_weighted_abs_final, dim3(1), dim3(256), 0, as_stream(stream), (const float*)workspace, out);
     return check_launch("weighted_abs_sum");
+}
+
+static int fill_pack_jobs(PackJobs& j, float* const* mats, const uint32_t* rows, const uint32_t* cols, const uint32_t* padded_rows,
+                          const uint32_t* ld, int32_t count) {
+    S3D_REQUIRE(mats && rows && cols && padded_rows && ld && count >= 1 && count <= kPackMaxMats, "linear_chain pack: null pointer or more than %d matrices",
+                kPackMaxMats);
+    memset(&j, 0, sizeof(j));
+    j.count = count;
+    uint32_t off = 0;
+    for (int i = 0; i < count; i++) {
+        S3D_REQUIRE(mats[i] && ld[i] >= cols[i] && padded_rows[i] >= rows[i], "linear_chain pack: matrix %d: ld >= cols, padded_rows >= rows", i);
+        j.m[i] = mats[i]; j.rows[i] = rows[i]; j.cols[i] = cols[i]; j.prows[i] = padded_rows[i]; j.ld[i] = ld[i];
+        j.off[i] = off;
+        off += padded_rows[i] * ld[i];
+    }
+    j.off[count] = off;
+    return S3D_OK;
+}
+S3D_EXPORT int s3d_pack_linear_chain(const float* const* mats, const uint32_t* rows, const uint32_t* cols, const uint32_t* padded_rows,
+                                     const uint32_t* ld, int32_t count, uint16_t* flat, s3d_stream_t stream) {
+    PackJobs j;
+    if (int rc = fill_pack_jobs(j, const_cast<float* const*>(mats), rows, cols, padded_rows, ld, count)) return rc;
+    S3D_REQUIRE(flat, "pack_linear_chain: null pointer");
+    hipLaunchKernelGGL(k_pack_linear_chain, dim3(div_up<uint32_t>(j.off[count], 256)), dim3(256), 0, as_stream(stream), j, (_Float16*)flat);
+    return check_launch("pack_linear_chain");
+}
+S3D_EXPORT int s3d_unpack_linear_chain(const uint16_t* flat, float* const* mats, const uint32_t* rows, const uint32_t* cols,
+                                       const uint32_t* padded_rows, const uint32_t* ld, int32_t count, s3d_stream_t stream) {
+    PackJobs j;
+    if (int rc = fill_pack_jobs(j, mats, rows, cols, padded_rows, ld, count)) return rc;
+    S3D_REQUIRE(flat, "unpack_linear_chain: null pointer");
+    hipLaunchKernelGGL(k_unpack_linear_chain, dim3(div_up<uint32_t>(j.off[count], 256)), dim3(256), 0, as_stream(stream), j, (const _Float16*)flat);
+    return check_launch("unpack_linear_chain");
 }

@@ -43,7 +43,7 @@ EXPORTS = [
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_mid2_forward", "s3d_ngp_mid2_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
     "s3d_bg_mse_forward", "s3d_bg_mse_backward", "s3d_bg_targets", "s3d_l1_pair_workspace_size", "s3d_l1_pair_loss",
     "s3d_seal_bbox_map", "s3d_vm_features_forward",
-    "s3d_aabb_normalize", "s3d_weighted_abs_sum_workspace_size", "s3d_weighted_abs_sum",
+    "s3d_aabb_normalize", "s3d_weighted_abs_sum_workspace_size", "s3d_weighted_abs_sum", "s3d_pack_linear_chain", "s3d_unpack_linear_chain",
     "s3d_vm_backward_max_bins", "s3d_vm_backward_keys", "s3d_vm_backward_bins_workspace_size", "s3d_vm_backward_bins",
     "s3d_vm_features_backward", "s3d_vm_color_forward", "s3d_vm_color_backward",
 ]
@@ -1034,6 +1034,35 @@ class VmBackend:
         ws = (C.c_float * n)(*[float(w) for w in weights])
         work = torch.empty(int(lib().s3d_weighted_abs_sum_workspace_size()) // 4, dtype=torch.float32, device=out.device)
         _check(lib().s3d_weighted_abs_sum(ptrs, numel, ws, C.c_int32(n), _p(out), _p(work), _stream()), "weighted_abs_sum")
+
+    @staticmethod
+    def _chain_args(mats, padded_rows, ld):
+        n = len(mats)
+        for m in mats:
+            _need(m, torch.float32, "matrix")
+            if m.dim() != 2 or not m.is_contiguous() or not m.is_cuda:
+                raise RuntimeError("linear chain pack: contiguous fp32 GPU matrices")
+        u = C.c_uint32 * n
+        return ((C.c_void_p * n)(*[m.data_ptr() for m in mats]), u(*[m.shape[0] for m in mats]), u(*[m.shape[1] for m in mats]),
+                u(*[int(r) for r in padded_rows]), u(*[int(v) for v in ld]), C.c_int32(n))
+
+    @staticmethod
+    def pack_linear_chain(mats, padded_rows, ld, flat):
+        """flat fp16 = the matrices in the ffmlp layout, zero padded (seal3d_hip.h)"""
+        _need(flat, torch.float16, "flat")
+        if flat.numel() != sum(int(r) * int(v) for r, v in zip(padded_rows, ld)) or not flat.is_contiguous():
+            raise RuntimeError("pack_linear_chain: flat holds sum(padded_rows * ld) elements")
+        a = VmBackend._chain_args(mats, padded_rows, ld)
+        _check(lib().s3d_pack_linear_chain(a[0], a[1], a[2], a[3], a[4], a[5], _p(flat), _stream()), "pack_linear_chain")
+
+    @staticmethod
+    def unpack_linear_chain(flat, mats, padded_rows, ld):
+        """the matrices (fp32, the parameters' shapes) out of a flat fp16 vector in the ffmlp layout"""
+        _need(flat, torch.float16, "flat")
+        if flat.numel() != sum(int(r) * int(v) for r, v in zip(padded_rows, ld)) or not flat.is_contiguous():
+            raise RuntimeError("unpack_linear_chain: flat holds sum(padded_rows * ld) elements")
+        a = VmBackend._chain_args(mats, padded_rows, ld)
+        _check(lib().s3d_unpack_linear_chain(_p(flat), a[0], a[1], a[2], a[3], a[4], a[5], _stream()), "unpack_linear_chain")
 
     # False (S3D_VM_BINS=torch): keys + torch.sort + searchsorted, the A/B twin of s3d_vm_backward_bins
     native_bins = os.environ.get("S3D_VM_BINS", "native") != "torch"

@@ -148,6 +148,28 @@ class _MlpInput(torch.autograd.Function):
         return ga[:, :feat.shape[1]], None, None, None, None
 
 
+class _PackChain(torch.autograd.Function):
+    """the weights of the colour MLP's bias-free Linears as the flat fp16 vector of the ffmlp kernels ([W, in_pad] | ... | [16, W]),
+    one launch per direction (s3d_pack_linear_chain / s3d_unpack_linear_chain) instead of pad / cat / cast and their backward"""
+
+    @staticmethod
+    def forward(ctx, in_pad, *weights):
+        ws = [w.detach().float().contiguous() for w in weights]
+        padded_rows = [w.shape[0] for w in ws[:-1]] + [16]
+        ld = [in_pad] + [w.shape[1] for w in ws[1:]]
+        flat = torch.empty(sum(r * v for r, v in zip(padded_rows, ld)), dtype=torch.float16, device=ws[0].device)
+        s3d_hip.VmBackend.pack_linear_chain(ws, padded_rows, ld, flat)
+        ctx.geom = (padded_rows, ld, [tuple(w.shape) for w in ws])
+        return flat
+
+    @staticmethod
+    def backward(ctx, g):
+        padded_rows, ld, shapes = ctx.geom
+        gs = [torch.empty(s, dtype=torch.float32, device=g.device) for s in shapes]
+        s3d_hip.VmBackend.unpack_linear_chain(g.to(torch.float16).contiguous(), gs, padded_rows, ld)
+        return (None,) + tuple(gs)
+
+
 class _TallLinear(torch.autograd.Function):
     """y = x W^T of a bias-free nn.Linear on [N, in] rows with N >> out * in (basis_mat 144 -> 27 and the colour MLP of
     tensoRF/network.py:71-83 at ~1e5 samples per step).  Forward and data gradient are the library GEMMs nn.Linear runs under
@@ -331,13 +353,12 @@ class NeRFNetwork(NeRFRenderer):
     def _color_mlp_fused(self, cf, d):
         """the colours: same arithmetic as the encoders + Linear chain + sigmoid under autocast (fp32 encodings rounded to fp16 once,
         fp16 operands, fp32 accumulation, fp16 activations); the weights travel as the ffmlp layout [W, in_pad] | (n - 1) x [W, W] | [16, W] built from
-        the nn.Linear parameters each step (~55 K elements: autograd splits the flat fp16 gradient back)"""
+        the nn.Linear parameters each step (_PackChain: ~39 K elements, one launch per direction)"""
         from ffmlp.ffmlp import _FFMLPForward
         net = self.color_net
         in_pad, out = (self.in_dim + 15) // 16 * 16, net[-1].out_features
         h = _MlpInput.apply(cf, d, self.encoder.degree, self.encoder_dir.degree, in_pad)
-        flat = torch.cat([F.pad(net[0].weight, (0, in_pad - self.in_dim)).reshape(-1)] + [l.weight.reshape(-1) for l in net[1:-1]]
-                         + [F.pad(net[-1].weight, (0, 0, 0, 16 - out)).reshape(-1)])
+        flat = _PackChain.apply(in_pad, *[l.weight for l in net])
         # (the kernels write the output padded to 16 columns, ffmlp.py:117-118, 162-163)
         out16 = _FFMLPForward.apply(h, flat, in_pad, 16, self.hidden_dim, len(net) - 1, 0, 6, False, True)
         if out == 3:
