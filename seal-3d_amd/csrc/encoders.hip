@@ -85,39 +85,32 @@ __global__ void k_freq_backward(const float* __restrict__ grad, const float* __r
 // cat([freq(feat), freq(dirs)]) under fp16 autocast): out[b] = [freq_1(a[b]) | freq_2(d[b]) | 0 ...] with the values of
 // k_freq_forward (fp32 arithmetic on float(a), rounded to binary16 once — what the autocast Linear's cast makes of the fp32
 // encodings).  One lane per PAIR of output columns (one 4-byte store).
-__device__ __forceinline__ float freq_value(const float* __restrict__ x, uint32_t D, uint32_t c) {
-    const float half_pi = 3.141592653589793f / 2;
-    if (c < D) return x[c];
-    const uint32_t col = c / D - 1, d = c % D, freq = col / 2;
-    return sinf(ldexpf(x[d], (int)freq) + (float)(col % 2) * half_pi);
-}
+// One lane per INPUT element: it loads x once and writes the identity column and the 2 deg sines of its feature (columns D apart;
+// neighbouring lanes are neighbouring features: 2-byte stores side by side).  [One lane per output pair — two divisions and two
+// branches per value around the same sinf — took 61 us for 1.05e5 rows; the sines themselves are ~35 us of vector issue.]
 __global__ void __launch_bounds__(256) k_freq_pack_forward(const _Float16* __restrict__ a, const float* __restrict__ d, uint32_t B,
-                                                            uint32_t D1, uint32_t C1, uint32_t D2, uint32_t C2, uint32_t ld,
-                                                            _Float16* __restrict__ out) {
+                                                            uint32_t D1, uint32_t deg1, uint32_t D2, uint32_t deg2, uint32_t ld,
+                                                            uint32_t lanes_per_row, _Float16* __restrict__ out) {
     const float half_pi = 3.141592653589793f / 2;
-    const uint32_t pairs = ld / 2;
-    const uint64_t total = (uint64_t)B * pairs;
-    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (uint64_t)gridDim.x * 256) {
-        const uint32_t b = (uint32_t)(t / pairs), c0 = 2u * (uint32_t)(t - (uint64_t)b * pairs);
-        _Float16 v[2];
-#pragma unroll
-        for (uint32_t e = 0; e < 2; e++) {
-            const uint32_t c = c0 + e;
-            float r = 0.0f;
-            if (c < C1) {
-                const float x = (float)a[(size_t)b * D1 + c % D1];  // (neighbouring lanes share the row's D1 inputs)
-                if (c < D1) r = x;
-                else {
-                    const uint32_t col = c / D1 - 1u;
-                    r = sinf(ldexpf(x, (int)(col / 2)) + (float)(col % 2) * half_pi);
-                }
-            } else if (c < C1 + C2) {
-                r = freq_value(d + (size_t)b * D2, D2, c - C1);
-            }
-            v[e] = (_Float16)r;
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t b = t / lanes_per_row, e = t - b * lanes_per_row;
+    if (b >= B) return;
+    const uint32_t C1 = D1 + 2 * D1 * deg1, C2 = D2 + 2 * D2 * deg2;
+    _Float16* row = out + (size_t)b * ld;
+    if (e < D1 + D2) {
+        const bool first = e < D1;
+        const uint32_t dd = first ? e : e - D1, D = first ? D1 : D2, deg = first ? deg1 : deg2;
+        const float x = first ? (float)a[(size_t)b * D1 + dd] : d[(size_t)b * D2 + dd];
+        _Float16* o = row + (first ? 0u : C1);
+        o[dd] = (_Float16)x;
+        for (uint32_t f = 0; f < deg; f++) {
+            const float arg = ldexpf(x, (int)f);
+            o[D + (2 * f) * D + dd] = (_Float16)sinf(arg + 0.0f * half_pi);
+            o[D + (2 * f + 1) * D + dd] = (_Float16)sinf(arg + 1.0f * half_pi);
         }
-        *reinterpret_cast<uint32_t*>(out + (size_t)b * ld + c0) = (uint32_t)__builtin_bit_cast(uint16_t, v[0]) |
-                                                                   ((uint32_t)__builtin_bit_cast(uint16_t, v[1]) << 16);
+    } else {  // the spare lanes of a row clear the padding columns
+        const uint32_t spare = lanes_per_row - (D1 + D2);
+        for (uint32_t c = C1 + C2 + (e - (D1 + D2)); c < ld; c += spare) row[c] = (_Float16)0.0f;
     }
 }
 // gradient w.r.t. the FIRST input from the packed row's fp16 gradient (k_freq_backward's expression with sin / cos re-computed
@@ -216,8 +209,11 @@ S3D_EXPORT int s3d_freq_encode_pack_forward(const uint16_t* a, const float* d, u
     S3D_REQUIRE(a && d && out, "freq_encode_pack_forward: null pointer");
     const uint32_t C1 = D1 + 2 * D1 * deg1, C2 = D2 + 2 * D2 * deg2;
     S3D_REQUIRE(D1 >= 1 && D2 >= 1 && ld % 2 == 0 && ld >= C1 + C2, "freq_encode_pack_forward: ld must be even and >= %u", C1 + C2);
-    hipLaunchKernelGGL(k_freq_pack_forward, dim3(stream_grid((uint64_t)B * (ld / 2), 256)), dim3(256), 0, as_stream(stream),
-                       (const _Float16*)a, d, B, D1, C1, D2, C2, ld, (_Float16*)out);
+    uint32_t lanes = 1;
+    while (lanes < D1 + D2 + 1) lanes <<= 1;  // (a power of two >= D1 + D2 + 1: at least one spare lane per row for the padding)
+    S3D_REQUIRE((uint64_t)B * lanes < (1ull << 32), "freq_encode_pack_forward: too many rows");
+    hipLaunchKernelGGL(k_freq_pack_forward, dim3(div_up<uint32_t>(B * lanes, 256)), dim3(256), 0, as_stream(stream),
+                       (const _Float16*)a, d, B, D1, deg1, D2, deg2, ld, lanes, (_Float16*)out);
     return check_launch("freq_encode_pack_forward");
 }
 
