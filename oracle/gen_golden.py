@@ -39,6 +39,10 @@ Sections
   grid      kernel_grid (gridencoder.cu:87-242) the same way, plus the fp32 branch
             of the backward kernels (:245-366) -> grid_kernels.npz (forward bit
             for bit, dy_dx 1e-6, backward within fp32 summation order).
+  enc       kernel_freq / kernel_freq_backward (freqencoder.cu:30-94),
+            kernel_sph_from_ray (raymarching.cu:163-198), kernel_grad_tv
+            (gridencoder.cu:503-607) from their text -> encoder_kernels.npz (2e-6:
+            `__sinf` is an approximate intrinsic).
   tensorf   tensoRF/network.py + tensoRF/utils.py + the Seal steps on the TensoRF
             backbone, executed -> tensorf.npz.
   train     SURVEY §8(c) golden (11): the reference's own `Trainer.train_step`
@@ -793,6 +797,7 @@ def _c_expr_ast(e, contract):
     which is what nvcc's default -fmad=true makes of a float product feeding an add."""
     import ast
     e = re.sub(r"(?<![\w.])(\d+\.\d*(?:e[+-]?\d+)?)f\b", r"F32(\1)", e)
+    e = re.sub(r"(?<![\w.])(\d+e[+-]?\d+)f\b", r"F32(\1)", e)              # `1e-9f`
     e = re.sub(r"(?<![\w.(])(\d+\.\d+)(?![\w.)])", r"F64(\1)", e)
     e = re.sub(r"\(float\)\s*(\w+(?:\([^()]*\)|\[[^\]]*\])?|\([^()]*\))", r"F32(\1)", e)
     e = re.sub(r"\(uint32_t\)\s*(\w+(?:\([^()]*\)|\[[^\]]*\])?|\([^()]*\))", r"U32s(\1)", e)
@@ -1303,6 +1308,92 @@ def gen_grid():
     print("grid: wrote grid_kernels.npz with", len(out), "arrays")
 
 
+def gen_enc():
+    """The remaining native kernels of the five extension packages, from their TEXT: `kernel_freq` / `kernel_freq_backward`
+    (freqencoder.cu:30-94; `__sinf` as float32 sin — CUDA's intrinsic is an approximation with 2^-21.4 absolute error on
+    [-pi, pi], so these are compared at 2e-6, not bit for bit; the backward's `result += scalbnf(1, f) * (g * cos - g * sin)`
+    with nvcc's contraction modelled), `kernel_sph_from_ray` (raymarching.cu:163-198) and `kernel_grad_tv`
+    (gridencoder.cu:503-607, fp32 tables: the neighbour rows through the pinned `get_grid_index`, the normalised sum, the atomics
+    applied in thread order).  -> tests/golden/encoder_kernels.npz"""
+    out = {}
+    F32 = np.float32
+    # ---- frequency encoder
+    fq_src = open(os.path.join(REF, "freqencoder/src/freqencoder.cu")).read()
+    env = _c_runtime()
+    env.update(__sinf=lambda x: np.sin(F32(x)), scalbnf=lambda x, n: F32(np.ldexp(F32(x), int(n))))
+    exec(_c_kernel_to_python(fq_src, "PI", (), contract=True, qualifier="inline constexpr __device__ float", thread_arg=False), env)
+    exec(_c_kernel_to_python(fq_src, "kernel_freq", ("inputs", "outputs"), skip=("threadIdx",), contract=True, lead="t"), env)
+    exec(_c_kernel_to_python(fq_src, "kernel_freq_backward", ("grad", "outputs", "grad_inputs"), skip=("threadIdx",), contract=True, lead="t"), env)
+    rng = np.random.default_rng(2024)
+    for tag, B, D, deg in (("tensorf", 48, 27, 2), ("dirs", 64, 3, 4)):
+        C = D + 2 * D * deg
+        x = rng.uniform(-1.5, 1.5, (B, D)).astype(np.float32)
+        x[0, :3] = np.array([0.0, -0.0, 1.0], np.float32)
+        y = np.full((B, C), 9, np.float32)
+        with np.errstate(all="ignore"):
+            for t in range(B * C):
+                env["kernel_freq"](t, _Ptr(x.reshape(-1)), B, D, deg, C, _Ptr(y.reshape(-1)))
+            g = rng.standard_normal((B, C)).astype(np.float32)
+            gx = np.full((B, D), 9, np.float32)
+            for t in range(B * D):
+                env["kernel_freq_backward"](t, _Ptr(g.reshape(-1)), _Ptr(y.reshape(-1)), B, D, deg, C, _Ptr(gx.reshape(-1)))
+        out.update({f"freq_{tag}_x": x, f"freq_{tag}_deg": np.int64(deg), f"freq_{tag}_y": y, f"freq_{tag}_grad": g, f"freq_{tag}_grad_x": gx})
+    # ---- sph_from_ray
+    rm_src = open(os.path.join(REF, "raymarching/src/raymarching.cu")).read()
+    env = _c_runtime()
+    env.update(sqrtf=lambda a: np.sqrt(F32(a)), atan2=lambda a, b: F32(np.arctan2(F32(a), F32(b))))
+    exec(_c_kernel_to_python(rm_src, "RPI", (), contract=True, qualifier="inline constexpr __device__ float", thread_arg=False), env)
+    exec(_c_kernel_to_python(rm_src, "kernel_sph_from_ray", ("rays_o", "rays_d", "coords"), skip=("threadIdx",), contract=True), env)
+    N, radius = 160, F32(2.5)
+    ro = rng.uniform(-1.2, 1.2, (N, 3)).astype(np.float32)
+    rd = rng.standard_normal((N, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    rd = rd.astype(np.float32)
+    rd[:3] = np.eye(3, dtype=np.float32)                     # axis-parallel directions (1 / 0 of the unused reciprocals)
+    coords = np.full((N, 2), 9, np.float32)
+    with np.errstate(all="ignore"):
+        for n in range(N):
+            env["kernel_sph_from_ray"](n, _Ptr(ro.reshape(-1)), _Ptr(rd.reshape(-1)), radius, N, _Ptr(coords.reshape(-1)))
+    out.update(sph_rays_o=ro, sph_rays_d=rd, sph_radius=radius, sph_coords=coords)
+    # ---- grad_total_variation (fp32 tables)
+    ge_src = open(os.path.join(REF, "gridencoder/src/gridencoder.cu")).read()
+    W = np.load(os.path.join(OUT, "wrappers.npz"))
+    for tag, D, C, gridtype, ac, L, pls, H, offsets in (("hash", 3, 2, 0, False, 4, float(W["grid_hash_pls"]), 4, W["grid_hash_offsets"]),
+                                                         ("tiled_ac", 3, 1, 1, True, 3, float(W["grid_tiled_ac_pls"]), 8, W["grid_tiled_ac_offsets"])):
+        env = _c_runtime()
+        genv = _int_env(D=D, C=C)
+        for fn in ("fast_hash", "get_grid_index"):
+            exec(_c_to_python(ge_src, fn), genv)
+        U32 = genv["U32"]
+
+        def atomic_add_f(ptr, idx, v):
+            ptr[idx] = np.float32(ptr[idx] + np.float32(v))
+        env.update(D=D, C=C, exp2f=lambda a: np.float32(np.exp2(np.float64(a))), ceil=np.ceil, floorf=np.floor,
+                   rsqrtf=lambda a: F32(F32(1.0) / np.sqrt(F32(a))), atomic_add_f=atomic_add_f,
+                   get_grid_index=lambda gt, a, ch, hs, res, pg: int(genv["get_grid_index"](gt, a, ch, hs, res, [U32(v) for v in pg])))
+        pre = lambda body: re.sub(r"atomicAdd\(&(\w+)\[(.*?)\], (.*?)\);", r"atomic_add_f(\1, \2, \3);", body)
+        exec(_c_kernel_to_python(ge_src, "kernel_grad_tv", ("inputs", "grid", "grad"), skip=("blockIdx",), contract=True, lead="b, level",
+                                 int_arrays=("pos_grid",), calls=("atomic_add_f",), pre=pre), env)
+        rng = np.random.default_rng(zlib.crc32(tag.encode()) + 77)
+        B = 120
+        x = rng.uniform(0, 1, (B, D)).astype(np.float32)
+        x[:4] = np.array([0, 1, 0.5, 0.99999994], np.float32)[:, None]
+        x[4], x[5] = -0.01, 1.01
+        emb = rng.uniform(-1, 1, (int(offsets[-1]), C)).astype(np.float32)
+        S, weight = np.float32(np.log2(pls)), np.float32(0.37)
+        g = np.zeros_like(emb)
+        with np.errstate(all="ignore"):
+            for level in range(L):
+                for b in range(B):
+                    env["kernel_grad_tv"](b, level, _Ptr(x.reshape(-1)), _Ptr(emb.reshape(-1)), _Ptr(g.reshape(-1)), offsets.astype(np.int64),
+                                          weight, B, L, S, H, gridtype, ac)
+        out.update({f"tv_{tag}_cfg": np.array([D, C, gridtype, int(ac), L, H], np.int64), f"tv_{tag}_S": S, f"tv_{tag}_weight": weight,
+                    f"tv_{tag}_offsets": offsets.astype(np.int32), f"tv_{tag}_x": x, f"tv_{tag}_emb": emb, f"tv_{tag}_grad": g})
+        print(f"enc[tv {tag}]: rows touched {int((np.abs(g).sum(1) > 0).sum())} of {g.shape[0]}")
+    np.savez_compressed(os.path.join(OUT, "encoder_kernels.npz"), **out)
+    print("enc: wrote encoder_kernels.npz with", len(out), "arrays")
+
+
 def _near_far_env(rm_src):
     """kernel_near_far_from_aabb as gen_int transliterates it (one ray per call) — shared by gen_march"""
     body = re.search(r"const float ox = rays_o\[0\].*?fars\[n\] = far;", rm_src, re.S).group(0)
@@ -1610,7 +1701,7 @@ def check_dropin():
     print("dropin: reference nerf/renderer.py + nerf/network.py on the build's packages reproduce wrappers.npz")
 
 
-SECTIONS = {"sh": gen_sh, "int": gen_int, "float": gen_float, "march": gen_march, "grid": gen_grid, "wrappers": gen_wrappers, "train": gen_train, "tensorf": gen_tensorf, "seal": gen_seal, "dropin": check_dropin}
+SECTIONS = {"sh": gen_sh, "int": gen_int, "float": gen_float, "march": gen_march, "grid": gen_grid, "enc": gen_enc, "wrappers": gen_wrappers, "train": gen_train, "tensorf": gen_tensorf, "seal": gen_seal, "dropin": check_dropin}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

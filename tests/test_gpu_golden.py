@@ -518,3 +518,25 @@ def test_grid_forward_fp16_tables_reproduce_the_reference_text(hip, tag):
     import test_grid_golden as gg
     G = np.load(os.path.join(GOLDEN, "grid_kernels.npz"))
     gg.check_forward_f16(gg.run_forward_f16(hip.GridBackend, G, tag, dev="cuda"), G, tag)
+
+
+# ---- the remaining native kernels against the reference TEXT: frequency encoder, sph_from_ray, grad_total_variation
+# (oracle/gen_golden.py `enc`; CPU twin and tolerances: tests/test_enc_golden.py, whose helpers are used here)
+@pytest.mark.parametrize("tag", ["tensorf", "dirs"])
+def test_hip_freq_encoder_vs_reference_text(hip, tag):
+    import test_enc_golden as eg
+    G = np.load(os.path.join(GOLDEN, "encoder_kernels.npz"))
+    eg.check_freq(eg.run_freq(hip.FreqBackend, G, tag, dev="cuda"), G, tag)
+
+
+def test_hip_sph_from_ray_vs_reference_text(hip):
+    import test_enc_golden as eg
+    G = np.load(os.path.join(GOLDEN, "encoder_kernels.npz"))
+    eg.check_sph(eg.run_sph(hip.RaymarchingBackend, G, dev="cuda"), G)
+
+
+@pytest.mark.parametrize("tag", ["hash", "tiled_ac"])
+def test_hip_grad_total_variation_vs_reference_text(hip, tag):
+    import test_enc_golden as eg
+    G = np.load(os.path.join(GOLDEN, "encoder_kernels.npz"))
+    eg.check_tv(eg.run_tv(hip.GridBackend, G, tag, dev="cuda"), G, tag)
