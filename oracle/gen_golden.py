@@ -1304,6 +1304,43 @@ def gen_grid():
             for t in range(B * D):
                 env["kernel_input_backward"](t, _Ptr(grad.reshape(-1)), _Ptr(dy_dx.reshape(-1)), _Ptr(g_in.reshape(-1)), B, L)
         out.update({f"{tag}_grad": grad, f"{tag}_grad_emb": g_emb, f"{tag}_grad_inputs": g_in})
+        if tag == "hash":
+            # ---- the `-O` instantiation of kernel_grid_backward: scalar_t = at::Half, the `__half2` branch (:321-327).  Each
+            # contribution is `(__half)(w * grad_cur[c])` — float product, ONE rounding to half — added with half atomics whose
+            # order the hardware picks.  Recorded: the result of thread order (one of the possible outcomes) and the EXACT sum of
+            # those half values rounded to half once — what an order-independent implementation produces.
+            def half_branch(body):
+                m = re.search(r"if \(std::is_same<scalar_t, at::Half>::value && N_C % 2 == 0\) \{(.*?)\n        \} else \{.*?\n        \}", body, re.S)
+                assert m
+                body = body[:m.start()] + m.group(1) + body[m.end():]
+                body, k = re.subn(r"__half2 v = \{\(__half\)\((.*?)\), \(__half\)\((.*?)\)\};\s*atomicAdd\(\(__half2\*\)&(\w+)\[(.*?)\], v\);",
+                                  r"atomic_add_h2(\3, \4, \1, \2);", body, flags=re.S)
+                assert k == 1, k
+                return body
+            exact = np.zeros(emb.size, np.float64)
+
+            def atomic_add_h2(ptr, idx, a, b):
+                for j, v in enumerate((a, b)):
+                    hv = np.float16(np.float32(v))                   # (__half)(float): one rounding
+                    ptr[idx + j] = np.float16(ptr[idx + j] + hv)     # half + half: float32 sum rounded to half
+                    exact[ptr.off + idx + j] += np.float64(hv)
+            henv = dict(env)
+            henv.update(atomic_add_h2=atomic_add_h2)
+            exec(_c_kernel_to_python(ge_src, "kernel_grid_backward", ("grad", "inputs", "grad_grid"), skip=("blockIdx",), contract=True,
+                                     lead="b, level, ch", int_arrays=("pos_grid", "pos_grid_local"), calls=("atomic_add_h2",), pre=half_branch,
+                                     half=True), henv)
+            grad16 = (grad * np.float32(0.25)).astype(np.float16)
+            g16 = np.zeros(emb.shape, np.float16)
+            with np.errstate(all="ignore"):
+                for level in range(L):
+                    for b in range(B):
+                        for ch in range(0, C, N_C):
+                            henv["kernel_grid_backward"](b, level, ch, _Ptr(grad16.reshape(-1)), _Ptr(x.reshape(-1)), _Ptr(emb16.reshape(-1)),
+                                                         offsets.astype(np.int64), _Ptr(g16.reshape(-1)), B, L, S, H, gridtype, ac, interp)
+            out.update({f"{tag}_grad_f16": grad16, f"{tag}_grad_emb_f16_thread_order": g16,
+                        f"{tag}_grad_emb_f16_exact": exact.reshape(emb.shape), f"{tag}_grad_emb_f16_exact_rounded": exact.reshape(emb.shape).astype(np.float16)})
+            print(f"grid[{tag}] fp16 backward: rows touched {int((np.abs(exact.reshape(emb.shape)).sum(1) > 0).sum())}, thread order vs exact: "
+                  f"{int((g16 != exact.reshape(emb.shape).astype(np.float16)).sum())} of {g16.size} entries differ")
     np.savez_compressed(os.path.join(OUT, "grid_kernels.npz"), **out)
     print("grid: wrote grid_kernels.npz with", len(out), "arrays")
 

@@ -540,3 +540,26 @@ def test_hip_grad_total_variation_vs_reference_text(hip, tag):
     import test_enc_golden as eg
     G = np.load(os.path.join(GOLDEN, "encoder_kernels.npz"))
     eg.check_tv(eg.run_tv(hip.GridBackend, G, tag, dev="cuda"), G, tag)
+
+
+@pytest.mark.parametrize("path", [1, 2], ids=["atomics", "binned"])
+def test_hip_grid_backward_fp16_contributions_of_the_reference_text(hip, path):
+    """the `-O` branch of kernel_grid_backward (`(__half)(w * grad)` per contribution, `__half2` atomics): the binned path sums the
+    contributions exactly (64-bit fixed point) and must reproduce the correctly rounded exact sum of the reference's half values
+    (consecutive points of one cell are merged in fp32 before the rounding: at most an ulp on the few rows where that happens);
+    the atomics path adds in fp16 in the hardware's order and stays within the drift thread order shows"""
+    import test_grid_golden as gg
+    G = np.load(os.path.join(GOLDEN, "grid_kernels.npz"))
+    hip.GridBackend.set_backward_path(path)
+    try:
+        got = gg.run_backward_f16(hip.GridBackend, G, "hash", dev="cuda")
+    finally:
+        hip.GridBackend.set_backward_path(0)
+    if path == 2:
+        exact, rounded = G["hash_grad_emb_f16_exact"], G["hash_grad_emb_f16_exact_rounded"]
+        assert np.array_equal(got == 0, rounded == 0)
+        bad = got.view(np.uint16) != rounded.view(np.uint16)
+        one_ulp = np.abs(got.astype(np.float64) - exact) <= np.abs(np.spacing(rounded)).astype(np.float64)
+        assert one_ulp.all() and bad.mean() < 0.02, (int(bad.sum()), got.size)
+    else:
+        gg.check_backward_f16(got, G, "hash", exact_sum=False)

@@ -113,3 +113,39 @@ def test_grid_forward_fp16_tables_reproduce_the_reference_text(oracle, G, tag):
     """the `-O` instantiation (scalar_t = at::Half): every `results[ch] += w * grid[..]` rounds the product to half and the sum
     to half (c10::Half has no `Half += float`: the right-hand side goes through Half's constructor) — outputs bit for bit"""
     check_forward_f16(run_forward_f16(oracle.GridBackend, G, tag), G, tag)
+
+
+def run_backward_f16(Gb, G, tag, dev="cpu", **extra):
+    D, C, gridtype, ac, interp, L, H = G[f"{tag}_cfg"].tolist()
+    x = torch.from_numpy(G[f"{tag}_x"]).to(dev)
+    emb = torch.from_numpy((table(G, tag) * np.float32(0.5)).astype(np.float16)).to(dev)
+    offsets = torch.from_numpy(G[f"{tag}_offsets"]).to(dev)
+    grad = torch.from_numpy(G[f"{tag}_grad_f16"]).to(dev)
+    B = x.shape[0]
+    g_emb = torch.zeros_like(emb)
+    Gb.grid_encode_backward(grad, x, emb, offsets, g_emb, B, D, C, L, float(G[f"{tag}_S"]), H, None, None, gridtype, bool(ac), interp, **extra)
+    return g_emb.cpu().numpy()
+
+
+def check_backward_f16(got, G, tag, exact_sum):
+    """`exact_sum`: the implementation adds the reference's per-contribution half values `(__half)(w * grad)` WITHOUT rounding in
+    between (the HIP kernels' fixed-point sums): it must reproduce the correctly rounded exact sum — a conversion through fp32 on
+    the way may double-round a near-tie, one ulp on a vanishing share of the entries.  Otherwise (an implementation that adds in
+    fp16 like the reference's `__half2` atomics, in some order): within the drift thread order itself shows against the exact sum."""
+    exact, rounded, thread = G[f"{tag}_grad_emb_f16_exact"], G[f"{tag}_grad_emb_f16_exact_rounded"], G[f"{tag}_grad_emb_f16_thread_order"]
+    assert np.array_equal(got == 0, rounded == 0), "rows touched"
+    if exact_sum:
+        bad = got.view(np.uint16) != rounded.view(np.uint16)
+        assert bad.mean() < 2e-3, int(bad.sum())
+        ulp = np.abs(got.astype(np.float64) - exact) <= np.abs(np.spacing(rounded.astype(np.float32).astype(np.float16)).astype(np.float64))
+        assert ulp.all()
+    else:
+        drift = np.abs(thread.astype(np.float64) - exact).max()
+        assert np.abs(got.astype(np.float64) - exact).max() <= 2.0 * drift + 1e-12
+
+
+def test_grid_backward_fp16_contributions_of_the_reference_text(oracle, G):
+    """the `-O` branch of kernel_grid_backward (gridencoder.cu:321-327): per contribution `(__half)(w * grad)`, summed by `__half2`
+    atomics in an order the hardware picks.  The fixture holds the exact sum of those half values and the outcome of thread order;
+    the oracle (fp32 accumulation of the rounded contributions) stays within the drift thread order shows"""
+    check_backward_f16(run_backward_f16(oracle.GridBackend, G, "hash"), G, "hash", exact_sum=False)
