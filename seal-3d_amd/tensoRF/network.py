@@ -360,7 +360,8 @@ class NeRFNetwork(NeRFRenderer):
         h = _MlpInput.apply(cf, d, self.encoder.degree, self.encoder_dir.degree, in_pad)
         flat = _PackChain.apply(in_pad, *[l.weight for l in net])
         # (the kernels write the output padded to 16 columns, ffmlp.py:117-118, 162-163)
-        out16 = _FFMLPForward.apply(h, flat, in_pad, 16, self.hidden_dim, len(net) - 1, 0, 6, False, True)
+        # (no graph being recorded — rendering: the inference entry point, no activation buffers)
+        out16 = _FFMLPForward.apply(h, flat, in_pad, 16, self.hidden_dim, len(net) - 1, 0, 6, not torch.is_grad_enabled(), True)
         if out == 3:
             # sigmoid of the three real columns as fp32 with torch.sigmoid's fp16 rounding, one launch per direction
             # (nerf/network_ff.py: _NgpRgb — instead of slice, sigmoid, cast and their four backward launches)

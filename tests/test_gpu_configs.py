@@ -581,6 +581,9 @@ def test_tensorf_colour_mlp_on_the_ffmlp_kernels_matches_the_linear_chain(hip):
         (rgb.float() * go).sum().backward()
         out[fused] = (rgb.detach().float(), {k: p.grad.detach().float().clone() for k, p in net.named_parameters() if p.grad is not None})
     net.fused_mlp = True
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        _, rgb_eval = net(x, d)  # (rendering: the MLP's inference entry point, no activation buffers)
+    assert torch.equal(rgb_eval.float(), out[True][0])
     torch.testing.assert_close(out[True][0], out[False][0], rtol=0, atol=2e-3)
     assert float((out[True][0] - 0.5).abs().max()) > 0.2
     keys = set(out[True][1]) & set(out[False][1])
