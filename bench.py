@@ -547,6 +547,71 @@ def tensorf_section(args, dev, batches, note=lambda m: None, res=300, steps=24):
     return out
 
 
+def seal_tensorf_section(args, dev, batches, note=lambda m: None, res=300):
+    """BASELINE configs[4] as `main_SealTensoRF.py:14-17` runs it: a TensoRF VM-48 teacher behind the bbox proxy and a TensoRF student
+    (`sealnerf.get_trainer("tensorf")`: Seal's steps on the TensoRF trainer — nothing frozen during local pretraining, the L1 penalty
+    inside every fine-tuning step), same edit and lattice step as the NGP Seal section.  Eager launches (the distillation step of
+    this backbone is not captured)."""
+    from nerf import synthetic as syn
+    from sealnerf import SealBBoxMapper, get_trainer, make_student, make_teacher
+    from tensoRF import network as trf
+    from tensoRF.utils import Trainer as TensoRFTrainer
+    torch.manual_seed(args.seed + 47)
+    kw = dict(resolution=[res] * 3, bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10)
+    teacher = make_teacher(trf.NeRFNetwork, **kw).to(dev)
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    teacher.density_grid.copy_(torch.from_numpy(grid))
+    teacher.density_bitfield.copy_(torch.from_numpy(bits))
+    teacher.iter_density = 100
+    ttr = TensoRFTrainer(teacher, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, fp16=True, update_extra_interval=10 ** 9)
+    ttr.global_step = 1
+    for i in range(48):  # a teacher that shows the scene: a few dozen steps on the training rays
+        ttr.train_step(*batches[i % len(batches)])
+    del ttr
+    student = make_student(trf.NeRFNetwork, **kw).to(dev)
+    student.load_state_dict(teacher.state_dict())
+    student.mean_count, student.mean_density, student.iter_density = teacher.mean_count, teacher.mean_density, teacher.iter_density
+    mapper = SealBBoxMapper(SEAL_BBOX)
+    teacher.init_mapper(mapper)
+    student.init_mapper(mapper)
+    tr = get_trainer("tensorf")(student, teacher, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, fp16=True, update_extra_interval=10 ** 9)
+    n_local = tr.init_pretraining(batch_size=6144000, lr=0.02, local_point_step=args.seal_point_step)
+
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    l0 = float(tr.pretrain_one_epoch())
+    tr.pretrain_one_epoch()
+    ep = timed(lambda i: tr.pretrain_one_epoch(), 4)
+    l1 = float(tr.pretrain_one_epoch())
+    note(f"seal tensorf: pretraining timed ({ep * 1e3:.2f} ms/epoch)")
+    tr.global_step = 1
+    proxy = timed(lambda i: tr.proxy_truth(batches[i % len(batches)][0], batches[i % len(batches)][1]), 4)
+    for i in range(8):
+        tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
+    student.mean_count = int(student.step_counter[:8, 0].float().mean().item())  # the sample budget after the first grid update
+    student.local_step = 0
+    for i in range(4):
+        tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
+    samples = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def ft(i):
+        tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
+        samples.add_(student.step_counter[(student.local_step - 1) % 16, 0].long())
+    step = timed(ft, 16)
+    n = float(samples.item()) / 16
+    return {"workload": f"configs[4] (main_SealTensoRF.py): lego_bbox-shaped edit, TensoRF VM-48 teacher + student at resolution {res}, "
+                        f"pretraining_local_point_step={args.seal_point_step:g}, {args.num_rays} rays/step, eager",
+            "local_points": int(n_local), "pretrain_ms_per_epoch": ep * 1e3, "seal_pretrain_points_per_s": n_local / ep,
+            "pretrain_loss_first_last": [l0, l1], "proxy_truth_ms_per_batch": proxy * 1e3,
+            "seal_train_ms_per_step": step * 1e3, "seal_train_samples_per_s": n / step, "samples_per_step": n,
+            "note": "a fine-tuning step = the teacher's proxy render of the batch's rays (targets) + the student's training step"}
+
+
 # ----------------------------------------------------------------------------- quality over a long run
 def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m: None, seeds=3):
     """Does the native fp16 path (fp16 table gradients, exact fixed-point sums, native Adam + loss scaling, HIP-graph replay)
@@ -935,6 +1000,11 @@ def main():
     if world == 1 and not args.no_tensorf and args.net == "ff":
         note("tensorf section")
         extra["tensorf"] = tensorf_section(args, dev, batches, note)
+        if not args.no_seal:
+            try:
+                extra["tensorf"]["seal"] = seal_tensorf_section(args, dev, batches, note)
+            except Exception as e:  # (a reported gap, not a lost bench line)
+                extra["tensorf"]["seal"] = {"error": f"{type(e).__name__}: {e}"[:400]}
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         note("cpu baseline")
