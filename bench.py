@@ -550,8 +550,8 @@ def tensorf_section(args, dev, batches, note=lambda m: None, res=300, steps=24):
 def seal_tensorf_section(args, dev, batches, note=lambda m: None, res=300):
     """BASELINE configs[4] as `main_SealTensoRF.py:14-17` runs it: a TensoRF VM-48 teacher behind the bbox proxy and a TensoRF student
     (`sealnerf.get_trainer("tensorf")`: Seal's steps on the TensoRF trainer — nothing frozen during local pretraining, the L1 penalty
-    inside every fine-tuning step), same edit and lattice step as the NGP Seal section.  Eager launches (the distillation step of
-    this backbone is not captured)."""
+    inside every fine-tuning step), same edit and lattice step as the NGP Seal section; the student's step is replayed from a HIP graph,
+    the teacher's proxy render is launched eagerly (its kernels take no device-side row count)."""
     from nerf import synthetic as syn
     from sealnerf import SealBBoxMapper, get_trainer, make_student, make_teacher
     from tensoRF import network as trf
@@ -574,7 +574,8 @@ def seal_tensorf_section(args, dev, batches, note=lambda m: None, res=300):
     mapper = SealBBoxMapper(SEAL_BBOX)
     teacher.init_mapper(mapper)
     student.init_mapper(mapper)
-    tr = get_trainer("tensorf")(student, teacher, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, fp16=True, update_extra_interval=10 ** 9)
+    tr = get_trainer("tensorf", graphed=True)(student, teacher, args.num_rays, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, fp16=True,
+                                              update_extra_interval=10 ** 9)
     n_local = tr.init_pretraining(batch_size=6144000, lr=0.02, local_point_step=args.seal_point_step)
 
     def timed(fn, n):
@@ -595,7 +596,7 @@ def seal_tensorf_section(args, dev, batches, note=lambda m: None, res=300):
         tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
     student.mean_count = int(student.step_counter[:8, 0].float().mean().item())  # the sample budget after the first grid update
     student.local_step = 0
-    for i in range(4):
+    for i in range(16):  # (capture of the student's step, replays)
         tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
     samples = torch.zeros(1, dtype=torch.int64, device=dev)
 
@@ -605,7 +606,8 @@ def seal_tensorf_section(args, dev, batches, note=lambda m: None, res=300):
     step = timed(ft, 16)
     n = float(samples.item()) / 16
     return {"workload": f"configs[4] (main_SealTensoRF.py): lego_bbox-shaped edit, TensoRF VM-48 teacher + student at resolution {res}, "
-                        f"pretraining_local_point_step={args.seal_point_step:g}, {args.num_rays} rays/step, eager",
+                        f"pretraining_local_point_step={args.seal_point_step:g}, {args.num_rays} rays/step, student step replayed from a HIP graph, proxy render eager",
+            "graph_captures": getattr(tr, "n_captures", 0),
             "local_points": int(n_local), "pretrain_ms_per_epoch": ep * 1e3, "seal_pretrain_points_per_s": n_local / ep,
             "pretrain_loss_first_last": [l0, l1], "proxy_truth_ms_per_batch": proxy * 1e3,
             "seal_train_ms_per_step": step * 1e3, "seal_train_samples_per_s": n / step, "samples_per_step": n,

@@ -348,6 +348,7 @@ def _tensorf_seal_trainer():
             self._init_tensorf(lr0, lr1, l1_reg_weight, kw.pop("upsample_model_steps", ()), kw.pop("upsample_resolutions", ()))
             Trainer.__init__(self, student, lr=lr0, fp16=fp16, dist=dist, **kw)
             self._init_seal(teacher, lr0, depth_weight)
+            self._attach_source_checks()
 
         def train_step(self, rays_o, rays_d, gt_rgb=None, gt_depth=None, bg_color=1):
             loss = SealTrainer.train_step(self, rays_o, rays_d, gt_rgb, gt_depth, bg_color)
@@ -356,13 +357,32 @@ def _tensorf_seal_trainer():
     return SealTensoRFTrainer
 
 
+def _tensorf_seal_graphed_trainer():
+    from tensoRF.utils import TensoRFSteps
+
+    class SealTensoRFGraphedTrainer(TensoRFSteps, GraphedSealTrainer):
+        """the same student trainer with the fine-tuning step replayed from a HIP graph (GraphedSealTrainer); the teacher's proxy
+        render stays eager on this backbone (its kernels take no device-side row count: `honours_row_limit_under_autocast`), and a
+        captured step is dropped when the resolution schedule changes the factors"""
+
+        def __init__(self, student, teacher, num_rays, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, fp16=True, dist=None, depth_weight=1.0, **kw):
+            self._init_tensorf(lr0, lr1, l1_reg_weight, kw.pop("upsample_model_steps", ()), kw.pop("upsample_resolutions", ()))
+            kw.setdefault("budget_factor", 1.1)  # (tensoRF/utils.py: GraphedTrainer)
+            GraphedSealTrainer.__init__(self, student, teacher, num_rays, lr=lr0, fp16=fp16, dist=dist, depth_weight=depth_weight, **kw)
+            self._attach_source_checks()
+
+        def train_step(self, rays_o, rays_d, gt_rgb=None, gt_depth=None, bg_color=1):
+            loss = GraphedSealTrainer.train_step(self, rays_o, rays_d, gt_rgb, gt_depth, bg_color)
+            self._maybe_upsample()
+            return loss
+    return SealTensoRFGraphedTrainer
+
+
 def get_trainer(backbone="ngp", graphed=False):
     """SealNeRF/trainer.py:56-104 `get_trainer(backbone, CharacterTypes.Student)`: the student trainer class of a backbone
     ("ngp": nerf/network.py or network_ff.py, "tensorf": tensoRF/network.py)"""
     if backbone == "tensorf":
-        if graphed:
-            raise NotImplementedError("the TensoRF distillation step is launched eagerly")
-        return _tensorf_seal_trainer()
+        return _tensorf_seal_graphed_trainer() if graphed else _tensorf_seal_trainer()
     if backbone != "ngp":
         raise ValueError(f"unknown backbone {backbone!r}")
     return GraphedSealTrainer if graphed else SealTrainer

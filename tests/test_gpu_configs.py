@@ -243,7 +243,8 @@ def test_tensorf_train_step_with_l1_term_vs_the_reference_trainer(hip, monkeypat
         assert float((g - want).abs().max()) <= 2e-4 * float(want.abs().max()) + 1e-9, k
 
 
-def test_seal_tensorf_teacher_student_pair(hip):
+@pytest.mark.parametrize("graphed", [False, True], ids=["eager", "graph"])
+def test_seal_tensorf_teacher_student_pair(hip, graphed):
     """BASELINE configs[4] as main_SealTensoRF.py:14-17 builds it: a TensoRF teacher viewed through the bbox proxy and a
     TensoRF student (`make_teacher` / `make_student`), the student trainer of `get_trainer("tensorf")`: local pretraining
     (L1(sigma) + L1(colour) on the lattice points, nothing frozen on this backbone) and fine-tuning steps against the teacher's
@@ -263,7 +264,8 @@ def test_seal_tensorf_teacher_student_pair(hip):
     mapper = SealBBoxMapper(BBOX)
     teacher.init_mapper(mapper)
     student.init_mapper(mapper)
-    tr = get_trainer("tensorf")(student, teacher, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, fp16=True, update_extra_interval=10 ** 9)
+    cls = get_trainer("tensorf", graphed=graphed)
+    tr = cls(student, teacher, *((4096,) if graphed else ()), lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, fp16=True, update_extra_interval=10 ** 9)
     assert [g["lr"] for g in tr.optimizer.param_groups] == [2e-2] * 4 + [1e-3] * 2
     n = tr.init_pretraining(batch_size=6144000, lr=0.02, local_point_step=0.01)
     assert 80000 < n < 120000, n
@@ -282,7 +284,13 @@ def test_seal_tensorf_teacher_student_pair(hip):
     gt = tr.proxy_truth(ro, rd)
     assert gt[0].shape == (4096, 3) and torch.isfinite(gt[0]).all() and torch.isfinite(gt[1]).all()
     reg = float(student.density_loss()) * 1e-4
-    hist = [float(tr.train_step(ro, rd, *gt)) for _ in range(12)]
+    hist = [float(tr.train_step(ro, rd, *gt)) for _ in range(8)]
+    if graphed:  # the sample budget a grid update would set: from here on the student's step is captured and replayed
+        student.mean_count = int(student.step_counter[:8, 0].float().mean().item())
+        student.local_step = 0
+    hist += [float(tr.train_step(ro, rd, *gt)) for _ in range(12 if graphed else 4)]
+    if graphed:
+        assert tr.graph is not None and tr.n_captures >= 1  # (the student's step was captured and replayed)
     # the student starts as the teacher's copy fitted to the edit: the loss against the proxy targets is small from the first
     # step on and stays there; the penalty is part of it
     assert np.isfinite(hist).all() and max(hist) < 2e-2, hist
