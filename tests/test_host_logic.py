@@ -321,3 +321,63 @@ def test_any_torch_optimizer_step_advances_the_weights_epoch(oracle_wrappers):
     before = gg._weights_epoch
     opt.step()
     assert gg._weights_epoch == before + 1
+
+
+def test_round5_host_logic_of_the_tensorf_step_on_cpu(oracle_wrappers):
+    """host-side pieces of the second half of round 5 that need no GPU: the gradient buffers of a factor backward carved out of ONE
+    zero fill (16-byte aligned segments, trailing int32 words), the scaler's check pass skipping exactly the gradients whose producer
+    raised THIS scaler's flag (and consuming the mark), density_loss_value() == density_loss() without a graph, and the trainers'
+    fallbacks on a device without the HIP path (no announced gradient -> autograd L1 term, no fused criterion)"""
+    import types
+    import torch
+    import s3d_hip
+    from nerf.optim import NativeGradScaler
+    from tensoRF import network as trf
+    ts = [torch.empty(1, 3, 5, 5), torch.empty(2, 7), torch.empty(27, 144, dtype=torch.float16)]
+    views, words = s3d_hip._zeros_like_many(ts, 4)
+    assert [tuple(v.shape) for v in views] == [tuple(t.shape) for t in ts] and all(v.dtype == torch.float32 for v in views)
+    assert all(float(v.abs().sum()) == 0 for v in views) and words.dtype == torch.int32 and words.tolist() == [0, 0, 0, 0]
+    base = views[0].untyped_storage().data_ptr()
+    assert all((v.data_ptr() - base) % 16 == 0 for v in views) and (words.data_ptr() - base) % 16 == 0
+    assert len({v.untyped_storage().data_ptr() for v in views}) == 1
+    # the scaler's pass over the plain gradients
+    sc, other = NativeGradScaler("cpu"), NativeGradScaler("cpu")
+    ps = [torch.nn.Parameter(torch.ones(3)) for _ in range(4)]
+    for p in ps:
+        p.grad = torch.ones(3)
+    ps[3].grad[1] = float("inf")
+    ps[0]._s3d_grad_checked = sc._found_inf      # its producer reported into this scaler: skipped
+    ps[1]._s3d_grad_checked = other._found_inf   # ... into another one: still read
+    ps[3]._s3d_grad_checked = sc._found_inf      # a non-finite gradient behind a mark is the producer's to report
+    opt = types.SimpleNamespace(grads=lambda: [(None, p, p.grad) for p in ps])
+    import nerf.optim as optim_mod
+    seen = []
+
+    def cpu_check(g, flag):  # (a stand-in for the HIP per-tensor check: which gradients the pass reads is what is tested)
+        seen.append(g)
+        if not bool(torch.isfinite(g).all()):
+            flag.fill_(1.0)
+    real = optim_mod._backend
+    optim_mod._backend = types.SimpleNamespace(grads_nonfinite=cpu_check)
+    try:
+        sc._check_plain(opt, None)
+        assert [id(g) for g in seen] == [id(ps[1].grad), id(ps[2].grad)]
+        assert float(sc._found_inf) == 0.0 and all("_s3d_grad_checked" not in p.__dict__ for p in ps)
+        seen.clear()
+        sc._check_plain(opt, None)               # marks are consumed: the next pass reads everything
+        assert len(seen) == 4 and float(sc._found_inf) == 1.0
+    finally:
+        optim_mod._backend = real
+    # the L1 term's value
+    torch.manual_seed(0)
+    net = trf.NeRFNetwork(resolution=[9, 8, 7], sigma_rank=[2, 3, 2], color_rank=[3, 3, 3], bound=1, cuda_ray=True)
+    assert abs(float(net.density_loss_value()) - float(net.density_loss())) <= 1e-6 * float(net.density_loss())
+    assert not net.density_loss_value().requires_grad and net.density_loss().requires_grad
+    st = net.__getstate__()
+    assert "_l1_inv" not in st and "_vm_bins" not in st and "_s3d_found_inf" not in st
+    # trainers on a device without the HIP path
+    from tensoRF.utils import Trainer
+    tr = Trainer(net, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-3, fp16=False, update_extra_interval=10 ** 9, native_optim=False)
+    assert tr._fused_loss(torch.zeros(8, 3)) is None and net.__dict__.get("_s3d_found_inf") is None
+    reg = tr._regularizer()
+    assert reg.requires_grad and all("_s3d_l1" not in p.__dict__ for p in net.parameters())
