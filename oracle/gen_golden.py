@@ -1670,6 +1670,233 @@ def gen_seal():
     print("seal: wrote seal_bbox.npz with", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------- the Seal CALLER side, executed
+SEAL_LOOP_NET = dict(encoding="hashgrid", bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10, bg_radius=-1,
+                     log2_hashmap_size=14)
+SEAL_LOOP_OPT = dict(color_space="srgb", patch_size=1, dt_gamma=0, max_steps=1024, T_thresh=1e-4)
+SEAL_LOOP_COLOR = {"hsv": [0.12, -0.05, 0.03], "rgb": [0.8, 0.2, 0.1], "rgbLightOffset": 0.05}
+
+
+def _reference_mapper(su, mine, cfg):
+    """a reference SealBBoxMapper without its trimesh / pytorch3d constructor: constants (triangles, bounds, transforms,
+    colour options) from the build's mapper, every METHOD the reference's"""
+    mb = mine.SealBBoxMapper(cfg)
+    ref = su.SealBBoxMapper.__new__(su.SealBBoxMapper)
+    su.SealMapper.__init__(ref, cfg)
+    ref.map_data = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in mb.map_data.items()}
+    ref.map_triangles = mb.map_triangles.clone()
+    return ref, mb
+
+
+def gen_seal_loop():
+    """SURVEY §8 a14 / a15, the halves gen_seal / gen_train leave open: the reference's Seal CALLERS, executed on the CPU oracle.
+      SealNeRF/network.py `get_network(NGP, Teacher | Student)` (the dynamically built classes main_SealNeRF.py uses),
+      SealNeRF/renderer.py `init_mapper` (:22-47), `hack_bitfield` / `restore_bitfield` (:58-72),
+        `SealNeRFTeacherRenderer.run_cuda` (:254-418) — training branch (force_all_rays) and the inference loop, the proxy
+        mapping of positions, directions and colours in both — for three bound types and one colour edit,
+      SealNeRF/trainer.py `sample_points` (:609-635), `init_pretraining` (:88-263; local + surrounding + global parts),
+        `pretrain_one_epoch` / `pretrain_part` / `pretrain_step` / `freeze_mlp` / `set_lr` (:363-503) for two epochs of Adam,
+        `proxy_truth` (:506-586; teacher in eval mode as main_SealNeRF.py:210 leaves it, and in training mode; n_batch 1 and
+        3; the pixel cache),
+      SealNeRF/provider.py `SealDataset.proxy_dataset` (:19-70) and `collate` (:72-128) on two 24x24 poses.
+    -> tests/golden/seal_loop.npz"""
+    _install_reference_stack()
+    _stub_training_imports()
+    import importlib
+    for name, attrs in (("dearpygui", {}), ("dearpygui.dearpygui", {}), ("cv2", {"transform": None})):
+        m = sys.modules.get(name) or types.ModuleType(name)
+        for k, v in attrs.items():
+            if not hasattr(m, k):
+                setattr(m, k, v)
+        sys.modules[name] = m
+    os.environ.pop("DISPLAY", None)
+    stypes = importlib.import_module("SealNeRF.types")
+    snet = importlib.import_module("SealNeRF.network")
+    srend = importlib.import_module("SealNeRF.renderer")
+    strainer = importlib.import_module("SealNeRF.trainer")
+    sprov = importlib.import_module("SealNeRF.provider")
+    su = importlib.import_module("SealNeRF.seal_utils")
+    rm = importlib.import_module("raymarching.raymarching")
+    for m_ in (stypes, snet, srend, strainer, sprov, su, rm):
+        _assert_reference(m_)
+    spec = importlib.util.spec_from_file_location("s3d_seal_utils", os.path.join(REPO, "seal-3d_amd", "sealnerf", "seal_utils.py"))
+    mine = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mine)
+    syn = _load_synthetic()
+    Teacher = snet.get_network(stypes.BackBoneTypes.NGP, stypes.CharacterTypes.Teacher)
+    Student = snet.get_network(stypes.BackBoneTypes.NGP, stypes.CharacterTypes.Student)
+    dens, bits = syn.lego_like_density_grid(seed=0)
+    opt = types.SimpleNamespace(**SEAL_LOOP_OPT)
+    poses = syn.orbit_poses(3, seed=0)
+    g = torch.Generator().manual_seed(41)
+    r = syn.get_rays(poses[:1], syn.lego_intrinsics(), 800, 800, N=384, generator=g)
+    ro, rd = r["rays_o"].contiguous(), r["rays_d"].contiguous()
+    out = {"rays_o": ro.numpy(), "rays_d": rd.numpy(), "poses": poses.numpy()}
+
+    def network(cls, mapper=None, **init):
+        torch.manual_seed(3)
+        net = cls(**SEAL_LOOP_NET)
+        _seed_params(net)
+        net.density_grid.copy_(torch.from_numpy(dens))
+        net.density_bitfield.copy_(torch.from_numpy(bits))
+        net.init_mapper(mapper=mapper, **init)
+        return net
+
+    trace = []
+    real_march = rm.march_rays
+
+    def traced_march(n_alive, n_step, *a, **k):
+        trace.append((n_alive, n_step))
+        return real_march(n_alive, n_step, *a, **k)
+    srend.raymarching.march_rays = traced_march
+
+    cases = {tag: seal_case_config(tag) for tag in SEAL_CASES}
+    cases["both_color"] = dict(seal_case_config("both"), **SEAL_LOOP_COLOR)
+    for tag, cfg in cases.items():
+        ref, mb = _reference_mapper(su, mine, cfg)
+        out[f"{tag}_fill_bound_in"] = ref.map_data["force_fill_bound"].numpy().copy()
+        teacher = network(Teacher, ref)
+        out[f"{tag}_fill_bound_clamped"] = ref.map_data["force_fill_bound"].numpy().copy()  # (init_mapper clamps IN PLACE, :31-32)
+        out[f"{tag}_grid_indices"] = teacher.force_fill_grid_indices.numpy().copy()
+        out[f"{tag}_bitfield_indices"] = teacher.force_fill_bitfield_indices.numpy().copy()
+        teacher.hack_bitfield()
+        out[f"{tag}_bitfield_hacked"] = teacher.density_bitfield.numpy().copy()
+        teacher.restore_bitfield()
+        assert np.array_equal(teacher.density_bitfield.numpy(), bits) and not teacher.density_bitfield_hacked
+        teacher.hack_bitfield()
+        # run_cuda, training branch: what `render(..., force_all_rays=True)` takes when the teacher is in training mode
+        teacher.train()
+        with torch.no_grad():
+            tr = teacher.render(ro, rd, staged=True, bg_color=None, perturb=False, force_all_rays=True, **vars(opt))
+        out.update({f"{tag}_train_image": tr["image"].numpy(), f"{tag}_train_depth": tr["depth"].numpy(),
+                    f"{tag}_train_weights_sum": tr["weights_sum"].numpy(), f"{tag}_train_counter": teacher.step_counter[0].numpy().copy()})
+        # run_cuda, inference loop: main_SealNeRF.py:210 leaves the teacher in eval mode
+        teacher.train(False)
+        trace.clear()
+        with torch.no_grad():
+            ev = teacher.render(ro, rd, staged=True, bg_color=None, perturb=False, force_all_rays=True, **vars(opt))
+        out.update({f"{tag}_eval_image": ev["image"].numpy(), f"{tag}_eval_depth": ev["depth"].numpy(),
+                    f"{tag}_eval_trace": np.array(trace, dtype=np.int64)})
+        print(f"seal_loop[{tag}]: {teacher.force_fill_grid_indices.numel()} forced cells, train samples {teacher.step_counter[0].tolist()}, "
+              f"eval iterations {len(trace)}, image mean {tr['image'].mean().item():.4f} / {ev['image'].mean().item():.4f}")
+
+    # ---- the distillation loop on the `both_color` edit (every hook active: map_source, colour edit, two boxes)
+    cfg = cases["both_color"]
+    ref, mb = _reference_mapper(su, mine, cfg)
+    teacher = network(Teacher, ref)
+    teacher.train(False)
+    student = network(Student, teacher.seal_mapper)
+    assert torch.equal(student.force_fill_grid_indices, teacher.force_fill_grid_indices)
+    spts, sdirs = strainer.sample_points(ref.map_data["force_fill_bound"], 0.05, 90)
+    out.update(sp_points=spts.numpy(), sp_dirs=sdirs.numpy())
+
+    Steps = type("RefSealSteps", (), {k: getattr(strainer, k) for k in (
+        "init_pretraining", "pretrain_one_epoch", "pretrain_part", "pretrain_step", "freeze_mlp", "set_lr", "proxy_truth")})
+    me = Steps()
+    me._backbone = stypes.BackBoneTypes.NGP
+    me.teacher_model, me.model, me.device, me.workspace, me.opt = teacher, student, torch.device("cpu"), None, opt
+    me.fp16, me.local_rank, me.report_metric_at_train, me.use_tensorboardX, me.ema = False, 0, False, False, None
+    me.scheduler_update_every_step, me.metrics, me.epoch, me.global_step, me.local_step = False, [], 0, 0, 0
+    me.log = lambda *a, **k: None
+    torch.manual_seed(11)
+    me.init_pretraining(epochs=2, batch_size=3000, lr=0.02, local_point_step=0.02, local_angle_step=45,
+                        surrounding_point_step=0.04, surrounding_angle_step=45, surrounding_bounds_extend=0.1,
+                        global_point_step=0.25, global_angle_step=90, no_debug=True)
+    out["ip_fill_bound_after"] = ref.map_data["force_fill_bound"].numpy().copy()  # (the surrounding part extends it IN PLACE, :166-180)
+    out["ip_parts"] = np.array(list(me.pretraining_data.keys()))
+    for part, src in me.pretraining_data.items():
+        out.update({f"ip_{part}_points": src["points"].numpy(), f"ip_{part}_dirs": src["dirs"].numpy(),
+                    f"ip_{part}_sigma": src["sigma"].numpy(), f"ip_{part}_color": src["color"].numpy(),
+                    f"ip_{part}_steps": np.array(src["steps"], dtype=np.int64)})
+        print(f"seal_loop[init_pretraining {part}]: {src['points'].shape[0]} points, steps {src['steps']}")
+    me.optimizer = torch.optim.Adam(student.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    me.scaler = torch.cuda.amp.GradScaler(enabled=False)
+    losses = []
+    real_step = Steps.pretrain_step
+
+    def recording_step(self, data):
+        loss = real_step(self, data)
+        losses.append(float(loss.item()))
+        return loss
+    Steps.pretrain_step = recording_step
+    for _ in range(2):
+        me.pretrain_one_epoch(silent=True)
+    Steps.pretrain_step = real_step
+    me.freeze_mlp(False)
+    me.set_lr(-1)
+    out["pe_losses"] = np.array(losses, dtype=np.float64)
+    out["pe_lr_after"] = np.float64(me.optimizer.param_groups[0]["lr"])
+    out["pe_bitfield_hacked"] = np.int64(student.density_bitfield_hacked)
+    for k, p in student.named_parameters():
+        key = f"pe_param_{k.replace('.', '_')}"
+        v = p.detach()
+        out[key + "_norm"] = np.float64(v.double().norm())
+        if v.numel() <= 8192:
+            out[key] = v.numpy().copy()
+        else:
+            rows = torch.randint(0, v.shape[0], (2048,), generator=torch.Generator().manual_seed(zlib.crc32(k.encode()) % 1000))
+            out[key + "_rows"] = rows.numpy()
+            out[key + "_at_rows"] = v[rows].numpy().copy()
+    print(f"seal_loop[pretrain]: {len(losses)} steps, loss {losses[0]:.5f} -> {losses[-1]:.5f}")
+
+    # ---- proxy_truth (:506-586)
+    teacher.density_bitfield_hacked and teacher.restore_bitfield()
+    data = {"rays_o": ro, "rays_d": rd, "images": torch.zeros(1, ro.shape[1], 3)}
+    me.proxy_truth(data)  # hacks the teacher's bitfield itself (:517-518), eval-mode teacher
+    assert teacher.density_bitfield_hacked
+    out.update(pt_eval_images=data["images"].numpy().copy(), pt_eval_depths=data["depths"].numpy().copy())
+    data3 = {"rays_o": ro, "rays_d": rd, "images": torch.zeros(1, ro.shape[1], 3)}
+    me.proxy_truth(data3, n_batch=5)  # 384 = 5 * 76 + 4: a sixth batch of the remainder (:551-554)
+    out.update(pt_eval_images_nb5=data3["images"].numpy().copy(), pt_eval_depths_nb5=data3["depths"].numpy().copy())
+    skipped = {"rays_o": ro, "rays_d": rd, "images": torch.full((1, ro.shape[1], 3), 0.25), "skip_proxy": True}
+    me.proxy_truth(skipped)
+    assert "depths" not in skipped and float(skipped["images"].mean()) == 0.25
+    full = {"rays_o": ro[:, :64], "rays_d": rd[:, :64], "images_shape": [1, 8, 8, 3]}
+    me.proxy_truth(full)
+    out.update(pt_full_images=full["images"].numpy().copy(), pt_full_depths=full["depths"].numpy().copy())
+    teacher.train()
+    datat = {"rays_o": ro, "rays_d": rd, "images": torch.zeros(1, ro.shape[1], 3)}
+    me.proxy_truth(datat)
+    teacher.train(False)
+    out.update(pt_train_images=datat["images"].numpy().copy(), pt_train_depths=datat["depths"].numpy().copy())
+    # the pixel cache (cache_gt, :300-311 + :530-576): two poses, 16x16 pixels; second call overlaps the first
+    me.cache_gt = True
+    me.proxy_cache_mask = torch.zeros(2, 256, dtype=torch.bool)
+    me.proxy_cache_image = torch.zeros(2, 256, 3)
+    me.proxy_cache_depth = torch.zeros(2, 256)
+    r16 = syn.get_rays(poses[1:2], syn.lego_intrinsics(16, 16), 16, 16)
+    pix_a = torch.arange(0, 160)[None]
+    pix_b = torch.arange(96, 256)[None]
+    for name, pix in (("a", pix_a), ("b", pix_b)):
+        d_ = {"rays_o": r16["rays_o"][:, pix[0]].contiguous(), "rays_d": r16["rays_d"][:, pix[0]].contiguous(),
+              "images": torch.zeros(1, pix.shape[1], 3), "data_index": torch.tensor([1]), "pixel_index": pix}
+        trace.clear()
+        me.proxy_truth(d_, use_cache=True)
+        out.update({f"pc_{name}_pixels": pix.numpy(), f"pc_{name}_images": d_["images"].numpy().copy(),
+                    f"pc_{name}_depths": d_["depths"].numpy().copy(), f"pc_{name}_first_alive": np.int64(trace[0][0] if trace else 0)})
+    out.update(pc_rays_o=r16["rays_o"].numpy(), pc_rays_d=r16["rays_d"].numpy(), pc_mask=me.proxy_cache_mask.numpy().copy(),
+               pc_image=me.proxy_cache_image.numpy().copy(), pc_depth=me.proxy_cache_depth.numpy().copy())
+    print("seal_loop[proxy_truth]: eval image mean", data["images"].mean().item(), "train image mean", datat["images"].mean().item(),
+          "cache rays computed", int(out["pc_a_first_alive"]), int(out["pc_b_first_alive"]))
+
+    # ---- SealDataset.proxy_dataset + collate (SealNeRF/provider.py:19-128) on an instance made without the disk loader
+    ds = sprov.SealDataset.__new__(sprov.SealDataset)
+    H = W = 24
+    ds.opt, ds.device, ds.type, ds.training, ds.fp16 = types.SimpleNamespace(**SEAL_LOOP_OPT), torch.device("cpu"), "train", True, False
+    ds.H, ds.W, ds.intrinsics, ds.error_map, ds.rand_pose, ds.num_rays = H, W, syn.lego_intrinsics(H, W), None, -1, 96
+    ds.poses, ds.images, ds.depths, ds.proxy_flag = poses[1:3].clone(), torch.zeros(2, H, W, 3), None, False
+    ds.proxy_dataset(teacher, n_batch=1)
+    out.update(pd_poses=ds.poses.numpy(), pd_images=ds.images.numpy().copy(), pd_depths=ds.depths.numpy().copy(), pd_flag=np.int64(ds.proxy_flag))
+    torch.manual_seed(21)
+    batch = ds.collate([1])
+    out.update(pd_collate_inds=batch["pixel_index"].numpy(), pd_collate_images=batch["images"].numpy(), pd_collate_depths=batch["depths"].numpy(),
+               pd_collate_rays_o=batch["rays_o"].numpy(), pd_collate_rays_d=batch["rays_d"].numpy(), pd_collate_skip=np.int64(batch["skip_proxy"]))
+    print("seal_loop[proxy_dataset]: images", tuple(ds.images.shape), "depths", tuple(ds.depths.shape), "mean", ds.images.mean().item())
+    srend.raymarching.march_rays = real_march
+    np.savez_compressed(os.path.join(OUT, "seal_loop.npz"), **out)
+    print("seal_loop: wrote seal_loop.npz with", len(out), "arrays,", os.path.getsize(os.path.join(OUT, "seal_loop.npz")) // 1024, "KiB")
+
+
 def check_dropin():
     """The reference's callers on the BUILD's drop-in packages (oracle backend): must reproduce wrappers.npz."""
     from oracle import oracle_backend as ob
@@ -1738,7 +1965,7 @@ def check_dropin():
     print("dropin: reference nerf/renderer.py + nerf/network.py on the build's packages reproduce wrappers.npz")
 
 
-SECTIONS = {"sh": gen_sh, "int": gen_int, "float": gen_float, "march": gen_march, "grid": gen_grid, "enc": gen_enc, "wrappers": gen_wrappers, "train": gen_train, "tensorf": gen_tensorf, "seal": gen_seal, "dropin": check_dropin}
+SECTIONS = {"sh": gen_sh, "int": gen_int, "float": gen_float, "march": gen_march, "grid": gen_grid, "enc": gen_enc, "wrappers": gen_wrappers, "train": gen_train, "tensorf": gen_tensorf, "seal": gen_seal, "seal_loop": gen_seal_loop, "dropin": check_dropin}
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

@@ -36,6 +36,7 @@ class NativeAdam(torch.optim.Optimizer):
         # group's `lr` of the capture in the launch arguments and writes schedule / captured here (follow_lr_schedule)
         self.lr_scale = None
         self._lr_captured = None
+        self.lr_epoch = 0  # bumped by every capture_lr(): a graph stores the epoch it baked its lr arguments in
         # the update launch clears every handed-over gradient behind its read: the next zero_grad() has nothing to fill
         self.consume_grads = consume_grads
         self.flat_half = None  # ONE fp16 buffer behind every handed-over gradient: one clear, one check, one all-reduce
@@ -166,7 +167,10 @@ class NativeAdam(torch.optim.Optimizer):
 
     def capture_lr(self):
         """The step is about to be captured in a graph: remember each group's lr (it becomes a launch argument) and start
-        the device-side factor at 1."""
+        the device-side factor at 1.  Every call is a new `lr_epoch`: a graph captured against an earlier base would run at
+        old_base x new_factor, so whoever holds one compares the epoch it stored and re-captures (nerf/trainer.py,
+        sealnerf/trainer.py)."""
+        self.lr_epoch += 1
         if self.lr_scale is None:
             self.lr_scale = torch.ones(1, dtype=torch.float32, device=self.step_count.device)
         self._lr_captured = [float(g["lr"]) for g in self.param_groups]
@@ -208,7 +212,7 @@ class NativeAdam(torch.optim.Optimizer):
             # launches carry the lr of the capture and the device-side factor carries the schedule — also for an eager step of
             # an optimizer whose step has been captured once (same arithmetic on both routes)
             if not torch.cuda.is_current_stream_capturing() and not self.follow_lr_schedule():
-                self.capture_lr()  # groups moved apart: rebase (a trainer holding a graph re-captures, trainer.py)
+                self.capture_lr()  # groups moved apart: rebase — a new lr_epoch, so every trainer holding a graph re-captures
             lr_of = {id(g): lr for g, lr in zip(self.param_groups, self._lr_captured)}
         for group, p, g in self.grads():
             if before_param is not None:

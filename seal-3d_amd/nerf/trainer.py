@@ -304,6 +304,7 @@ class GraphedTrainer(Trainer):
         self.n_captures += 1
         if hasattr(self.optimizer, "capture_lr"):
             self.optimizer.capture_lr()  # (this lr becomes a launch argument; later values reach the replay through lr_scale)
+        self._graph_lr_epoch = getattr(self.optimizer, "lr_epoch", 0)
         self.budget = int(max(model.mean_count, 1) * self.budget_factor)
         saved = (model.mean_count, model.local_step)
         model.mean_count = self.budget
@@ -441,6 +442,8 @@ class GraphedTrainer(Trainer):
         self._stage_inputs(rays_o, rays_d, gt_rgb)
         if self.graph is not None and hasattr(self.optimizer, "follow_lr_schedule") and not self.optimizer.follow_lr_schedule():
             self.graph = None  # (parameter groups moved by different factors: the captured lr arguments no longer fit)
+        if self.graph is not None and getattr(self.optimizer, "lr_epoch", 0) != getattr(self, "_graph_lr_epoch", 0):
+            self.graph = None  # (somebody rebased the captured lrs since — another graph's capture, an eager step: re-capture)
         if self.graph is None:
             self._capture()  # runs this step eagerly (one optimizer update), then records the graph
             loss = self.s_warm_loss

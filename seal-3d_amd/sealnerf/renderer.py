@@ -16,17 +16,20 @@ class SealTeacherMixin:
     proxy_enabled = True
 
     def init_mapper(self, mapper):
-        """SealNeRF/renderer.py:22-47: cells of the force-fill bounds -> bitfield byte indices"""
+        """SealNeRF/renderer.py:22-47: cells of the force-fill bounds -> bitfield byte indices.  As there, the mapper's
+        `force_fill_bound` is clamped to the inference box IN PLACE: the pretraining lattice (trainer.py: init_pretraining)
+        and every later init_mapper of the same mapper (the student's) see the clamped bounds."""
         self.seal_mapper = mapper
         dev = self.density_bitfield.device
-        bounds = mapper.map_data["force_fill_bound"].clone().to(dev)
+        bounds = mapper.map_data["force_fill_bound"]
         if bounds.ndim == 2:
-            bounds = bounds[None]
-        bounds[:, 0, :] = torch.max(bounds[:, 0, :], self.aabb_infer[:3])
-        bounds[:, 1, :] = torch.min(bounds[:, 1, :], self.aabb_infer[-3:])
+            bounds = bounds[None]  # (a view: the clamp below still lands in map_data)
+        aabb = self.aabb_infer.to(bounds.device)
+        bounds[:, 0, :] = torch.max(bounds[:, 0, :], aabb[:3])
+        bounds[:, 1, :] = torch.min(bounds[:, 1, :], aabb[-3:])
         idx = []
         for i in range(bounds.shape[0]):
-            cmin, cmax = torch.floor(((bounds[i] + self.bound) / self.bound / 2) * self.grid_size)
+            cmin, cmax = torch.floor(((bounds[i] + self.bound) / self.bound / 2) * self.grid_size).to(dev)
             X, Y, Z = torch.meshgrid(torch.arange(cmin[0], cmax[0], device=dev), torch.arange(cmin[1], cmax[1], device=dev),
                                      torch.arange(cmin[2], cmax[2], device=dev), indexing="ij")
             coords = torch.stack([X, Y, Z], dim=-1).reshape(-1, 3)
@@ -74,9 +77,15 @@ class SealTeacherMixin:
         return self.seal_mapper.map_to_origin(xyzs.view(-1, 3), dirs.view(-1, 3))
 
     def map_colors(self, xyzs, dirs, rgbs, mask):
+        """`rgbs[mapped_mask] = map_color(mapped_xyzs[mapped_mask], mapped_dirs[mapped_mask], rgbs[mapped_mask])`
+        (SealNeRF/renderer.py:316, 396-399): only the samples the proxy moved are re-coloured, and the batch statistics of a
+        colour edit (modify_rgb's mean brightness, seal_utils.py:753-769) are those of the moved samples alone."""
         if mask is None or self.seal_mapper is None:
             return rgbs
-        return self.seal_mapper.map_color(xyzs, dirs, rgbs)
+        md = self.seal_mapper.map_data
+        if "hsv" not in md and "rgb" not in md:
+            return rgbs
+        return self.seal_mapper.map_color_masked(xyzs, dirs, rgbs, mask)
 
 
 def _mix(net_cls, name, proxy):

@@ -293,6 +293,18 @@ class SealBBoxMapper:
         return colors
 
 
+    def map_color_masked(self, points, dirs, colors, mask):
+        """the renderers' use of map_color (SealNeRF/renderer.py:316, 396-399): `colors[mask] = map_color(points[mask],
+        dirs[mask], colors[mask])` — returns a new tensor, `colors` is left alone"""
+        out = colors.clone()
+        if mask is None:
+            return self.map_color(points, dirs, out)
+        sel = colors[mask]
+        if sel.shape[0]:
+            out[mask] = self.map_color(points[mask], dirs[mask] if dirs is not None else None, sel.float()).to(colors.dtype)
+        return out
+
+
 def get_seal_mapper(config_dict=None, config_file=None):
     """seal_utils.py:573-584 (plain JSON instead of json5)"""
     if config_dict is None:

@@ -89,34 +89,86 @@ class SealSteps:
         self.depth_weight = depth_weight
         self.pretraining_data = {}
         self.base_lr = lr
+        self._pt_graphs, self._pt_padded = {}, {}
+        self._cached_lr, self._pretraining_open, self.is_pretraining = None, False, False
+        self.cache_gt = False
 
     # ------------------------------------------------------------------ local pretraining
+    def _teacher_query(self, points, dirs):
+        dev = points.device
+        with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16 and dev.type == "cuda"):
+            chunks = [self.teacher(points[i:i + (1 << 20)], dirs[i:i + (1 << 20)]) for i in range(0, points.shape[0], 1 << 20)]
+        if not chunks:
+            return torch.zeros(0, device=dev), torch.zeros(0, 3, device=dev)
+        return torch.cat([c[0].float() for c in chunks]), torch.cat([c[1].float() for c in chunks])
+
     @torch.no_grad()
-    def init_pretraining(self, batch_size=6144000, lr=0.05, local_point_step=0.005, local_angle_step=45, seed=0):
+    def init_pretraining(self, epochs=0, batch_size=6144000, lr=0.05, local_point_step=0.005, local_angle_step=45,
+                         surrounding_point_step=-1, surrounding_angle_step=45, surrounding_bounds_extend=0.2,
+                         global_point_step=-1, global_angle_step=45, seed=0):
+        """SealNeRF/trainer.py:88-263: the three point sets of the distillation pretraining, each with teacher targets —
+          local        lattice inside the force-fill bounds, kept where the proxy maps (everywhere with `mapSource`);
+                       targets = teacher at the MAPPED points for the mapped constant direction (1,0,0), colours through the edit
+          surrounding  lattice inside the bounds grown by `surrounding_bounds_extend` (clamped to the training box; as in the
+                       reference the mapper's `force_fill_bound` is grown IN PLACE, :166-180), kept where the proxy does NOT map
+          global       lattice over the training box, kept where the proxy does not map
+        A part is skipped when its step is <= 0 (main_SealNeRF.py:93-108 defaults: local 0.001, surrounding 0.01 / extend 0.1,
+        global off).  The training directions are drawn per kept point from the Euler grid; `seed=None` draws them from torch's
+        global generator exactly where the reference does (one randint per part), an int seeds a private generator (every
+        data-parallel rank holds the same set).  Returns the number of local points."""
         mapper = self.teacher.seal_mapper
         dev = next(self.model.parameters()).device
-        pts, dirs = sample_points(mapper.map_data["force_fill_bound"], local_point_step, local_angle_step)
-        pts, dirs = pts.to(dev, torch.float32), dirs.to(dev, torch.float32)
-        ones = torch.zeros_like(pts) + torch.tensor([1.0, 0, 0], device=dev)
-        mapped_p, mapped_d, mask = mapper.map_to_origin(pts, ones)
-        if "map_source" in mapper.map_data:
-            mask[:] = True
-        pts = pts[mask]
-        g = torch.Generator(device="cpu").manual_seed(seed)
-        dirs = dirs[torch.randint(dirs.shape[0], (pts.shape[0],), generator=g).to(dev)]
-        mapped_p, mapped_d = mapped_p[mask], mapped_d[mask]
-        with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16 and dev.type == "cuda"):
-            chunks = [self.teacher(mapped_p[i:i + (1 << 20)], mapped_d[i:i + (1 << 20)]) for i in range(0, pts.shape[0], 1 << 20)]
-        gt_sigma = torch.cat([c[0].float() for c in chunks])
-        gt_color = mapper.map_color(mapped_p, mapped_d, torch.cat([c[1].float() for c in chunks]))
-        steps = list(range(0, pts.shape[0], batch_size))
-        if steps[-1] != pts.shape[0]:
-            steps.append(pts.shape[0])
-        self.pretraining_data["local"] = {"points": pts, "dirs": dirs, "sigma": gt_sigma, "color": gt_color, "steps": steps}
-        self.pretraining_data.pop("_padded", None)
-        self.pretraining_lr = lr
+        self.pretraining_epochs, self.pretraining_batch_size, self.pretraining_lr = epochs, batch_size, lr
+        self.pretraining_data = {}
+        gen = None if seed is None else torch.Generator(device="cpu").manual_seed(seed)
+        axis = torch.tensor([1.0, 0, 0], device=dev)
+
+        def lattice(bounds, point_step, angle_step):
+            pts, dirs = sample_points(bounds, point_step, angle_step)
+            pts, dirs = pts.to(dev, torch.float32), dirs.to(dev, torch.float32)
+            return (pts, dirs) + tuple(mapper.map_to_origin(pts, torch.zeros_like(pts) + axis))
+
+        def draw(dirs, n):
+            return dirs[torch.randint(dirs.shape[0], (n,), generator=gen).to(dev)]
+
+        def file(part, pts, dirs, sigma, color):
+            steps = list(range(0, pts.shape[0], batch_size))
+            if not steps or steps[-1] != pts.shape[0]:
+                steps.append(pts.shape[0])
+            self.pretraining_data[part] = {"points": pts.contiguous(), "dirs": dirs.contiguous(), "sigma": sigma.detach().contiguous(),
+                                           "color": color.detach().contiguous(), "steps": steps}
+
+        n_local = 0
+        if local_point_step > 0:
+            pts, dirs, mapped_p, mapped_d, mask = lattice(mapper.map_data["force_fill_bound"], local_point_step, local_angle_step)
+            if "map_source" in mapper.map_data:
+                mask = torch.ones_like(mask)
+            pts = pts[mask]
+            dirs = draw(dirs, pts.shape[0])
+            mapped_p, mapped_d = mapped_p[mask], mapped_d[mask]
+            gt_sigma, gt_color = self._teacher_query(mapped_p, mapped_d)
+            file("local", pts, dirs, gt_sigma, mapper.map_color(mapped_p, mapped_d, gt_color))
+            n_local = pts.shape[0]
+            self.is_pretraining = True
+        if surrounding_point_step > 0:
+            sb = mapper.map_data["force_fill_bound"]
+            aabb = self.model.aabb_train.to(sb.device)
+            lo, hi = (sb[0], sb[1]) if sb.ndim == 2 else (sb[:, 0], sb[:, 1])  # (views: the growth lands in map_data)
+            lo -= surrounding_bounds_extend
+            lo.copy_(torch.max(lo, aabb[:3]))
+            hi += surrounding_bounds_extend
+            hi.copy_(torch.min(hi, aabb[3:]))
+            pts, dirs, _, _, mask = lattice(sb, surrounding_point_step, surrounding_angle_step)
+            pts = pts[~mask]
+            dirs = draw(dirs, pts.shape[0])
+            file("surrounding", pts, dirs, *self._teacher_query(pts, dirs))
+        if global_point_step > 0:
+            pts, dirs, _, _, mask = lattice(self.model.aabb_train.view(2, 3).cpu(), global_point_step, global_angle_step)
+            pts = pts[~mask]
+            dirs = draw(dirs, pts.shape[0])
+            file("global", pts, dirs, *self._teacher_query(pts, dirs))
         self.invalidate_graphs()  # (the per-chunk graphs hold raw pointers into the previous point / target tensors)
-        return pts.shape[0]
+        return n_local
 
     def invalidate_graphs(self):
         """Drop every captured graph that bakes in state this trainer can replace: the per-chunk pretraining graphs (slices
@@ -124,7 +176,7 @@ class SealSteps:
         mapper's parameters are kernel arguments, the teacher's bitfield / tables are raw pointers).  Called by
         init_pretraining(), load_checkpoint() and set_teacher(); call it after changing the teacher's mapper or occupancy
         state in place."""
-        self._pt_graphs = {}
+        self._pt_graphs, self._pt_padded = {}, {}
         if hasattr(self, "proxy_graph"):
             self.proxy_graph = None
 
@@ -149,6 +201,16 @@ class SealSteps:
                 freeze_module(m, freeze)
 
     def set_lr(self, lr):
+        """SealNeRF/trainer.py:491-503: set every group's lr; the lr of the FIRST group at that moment is remembered and a
+        negative `lr` restores it (once).  As in the reference, a second set_lr(x) before the restore remembers x, not the
+        original value: after two pretraining epochs `set_lr(-1)` leaves the pretraining lr in place until the scheduler's
+        next step recomputes the groups from their initial lrs."""
+        if lr < 0:
+            if getattr(self, "_cached_lr", None) is None:
+                return
+            lr, self._cached_lr = self._cached_lr, None
+        else:
+            self._cached_lr = self.optimizer.param_groups[0]["lr"]
         for g in self.optimizer.param_groups:
             g["lr"] = lr
         # an optimizer whose step has been captured once applies lr changes through a device-side factor (nerf/optim.py:
@@ -157,10 +219,7 @@ class SealSteps:
         follow = getattr(self.optimizer, "follow_lr_schedule", None)
         if follow is not None and getattr(self.optimizer, "_lr_captured", None) is not None \
                 and not torch.cuda.is_current_stream_capturing() and not follow():
-            self.optimizer.capture_lr()   # groups moved by different factors: rebase, and drop every graph that baked the old lrs in
-            self._pt_graphs = {}
-            if getattr(self, "graph", None) is not None:
-                self.graph = self.graph_opt = None
+            self.optimizer.capture_lr()   # groups moved by different factors: rebase = a new lr_epoch, every graph re-captures
 
     def pretrain_loss(self, points, dirs, gt_sigma, gt_color, n_total=None):
         """SealNeRF/trainer.py:455-469: L1Loss(sigma) + L1Loss(colour) (means) of the student on one point chunk.  With a
@@ -211,16 +270,17 @@ class SealSteps:
     graph_pretraining = True  # GPU: every point chunk's step is replayed from its own HIP graph (static chunk tensors)
     fused_losses = True       # GPU + native optimizer: one-launch criteria (False: the reference's torch op sequences, A/B runs)
 
-    def _pretrain_chunk(self, key, sl, n_total):
-        """one optimizer step on the (static) chunk `sl` of the local points; GPU + native optimizer: captured once per chunk
+    def _pretrain_chunk(self, part, k, sl, n_total):
+        """one optimizer step on the (static) chunk `sl` of part `part`; GPU + native optimizer: captured once per chunk
         and replayed — the chunk's tensors never move, the learning rate and the frozen MLPs are part of the capture"""
-        src = self.pretraining_data["local"]
+        src = self.pretraining_data[part]
+        key = (part, k)
         args = (src["points"][sl], src["dirs"][sl], src["sigma"][sl], src["color"][sl])
         on_gpu = args[0].is_cuda
         if on_gpu and args[0].shape[0] % 128:
             # the chunk's points and directions padded to whole 128-row tiles ONCE (they are static): pretrain_loss would pad
             # them again on every step otherwise (two fills + two copies per replay)
-            cache = self.pretraining_data.setdefault("_padded", {})
+            cache = self._pt_padded
             ent = cache.get(key)
             if ent is None or ent[0] != (args[0].data_ptr(), args[0].shape[0]):
                 pad = 128 - args[0].shape[0] % 128
@@ -229,11 +289,12 @@ class SealSteps:
             args = (ent[1], ent[2], args[2], args[3])
         if not (self.graph_pretraining and on_gpu and self.native_optim):
             return self.pretrain_step(*args, n_total=n_total)
-        if not hasattr(self, "_pt_graphs"):
-            self._pt_graphs = {}
         # the entry is valid for exactly the tensors it was captured on (a replaced chunk tensor or optimizer moment = re-capture)
+        # and for the lr base it baked in (nerf/optim.py: every capture_lr() — this trainer's or the fine-tuning graph's — is a
+        # new lr_epoch; an entry of an older epoch would run at old_base x new_factor)
         sig = (key, args[0].data_ptr(), args[2].data_ptr(), tuple(st["exp_avg"].data_ptr() for st in self.optimizer.state.values()
-                                                                   if "exp_avg" in st), float(self.pretraining_lr))
+                                                                   if "exp_avg" in st), float(self.pretraining_lr),
+               getattr(self.optimizer, "lr_epoch", 0))
         ent = self._pt_graphs.get(key)
         if ent is not None and ent[2] != sig:
             ent = None
@@ -246,6 +307,7 @@ class SealSteps:
             world = self.dist.world if self.dist is not None else 1
             if world > 1:
                 return warm  # (collective between backward and step: the steps stay eager; no entry is cached)
+            sig = sig[:-1] + (getattr(self.optimizer, "lr_epoch", 0),)  # (the eager step may have rebased: store what the capture sees)
             g = torch.cuda.CUDAGraph()
             pool = next(iter(self._pt_graphs.values()))[0].pool() if self._pt_graphs else None
             with torch.cuda.graph(g, pool=pool, capture_error_mode=_CAPTURE_MODE):
@@ -258,37 +320,71 @@ class SealSteps:
         return ent[1]
 
     def pretrain_one_epoch(self):
-        """one pass over the local points (trainer.py:363-452); every rank processes its shard of each chunk"""
+        """one pass over every part of the pretraining set (SealNeRF/trainer.py:363-452: `set_lr(pretraining_lr)`, force-fill
+        the bitfield, training mode, frozen MLPs, then local -> surrounding -> global in steps of the batch size); every rank
+        processes its shard of each chunk.  As in the reference the epoch leaves the MLPs frozen and the pretraining lr set:
+        `end_pretraining()` — called by the next fine-tuning step, as `train()` does before every training epoch (:338-339) —
+        unfreezes and restores.  Returns the mean of the step losses."""
         from parallel import shard_slice
+        self.set_lr(self.pretraining_lr)
         if not self.model.density_bitfield_hacked:
             self.model.hack_bitfield()
-        self.set_lr(self.pretraining_lr)
+        self.model.train()
         self.freeze_mlp(True)
-        src = self.pretraining_data["local"]
+        self._pretraining_open = True
         rank, world = (self.dist.rank, self.dist.world) if self.dist is not None else (0, 1)
         losses = []
-        for k, (a, b) in enumerate(zip(src["steps"][:-1], src["steps"][1:])):
-            lo, hi = shard_slice(b - a, rank, world)
-            losses.append(self._pretrain_chunk(k, slice(a + lo, a + hi), b - a))
-        self.freeze_mlp(False)
-        self.set_lr(self.base_lr)
+        for part, src in self.pretraining_data.items():
+            for k, (a, b) in enumerate(zip(src["steps"][:-1], src["steps"][1:])):
+                if b <= a:
+                    continue
+                lo, hi = shard_slice(b - a, rank, world)
+                losses.append(self._pretrain_chunk(part, k, slice(a + lo, a + hi), b - a))
+        self.last_pretrain_losses = losses
+        if not losses:
+            return torch.zeros(())
         return losses[0] if len(losses) == 1 else torch.stack([l.reshape(()) for l in losses]).mean()
 
+    def end_pretraining(self):
+        """`self.freeze_mlp(False); self.set_lr(-1)` (SealNeRF/trainer.py:338-339)"""
+        if getattr(self, "_pretraining_open", False):
+            self._pretraining_open = False
+            self.freeze_mlp(False)
+            self.set_lr(-1)
+
     # ------------------------------------------------------------------ global fine-tuning
+    online_proxy_mode = None  # None: the teacher renders in the mode it is in (the reference); "train" / "eval": forced
+
     @torch.no_grad()
-    def proxy_truth(self, rays_o, rays_d, out_rgb=None, out_depth=None):
-        """teacher-rendered RGB + depth targets for a ray batch (force_all_rays, no perturbation) — trainer.py:506-586;
-        `out_rgb` [N,3] / `out_depth` [N]: write them there (fp32, contiguous)"""
+    def proxy_truth(self, rays_o, rays_d, out_rgb=None, out_depth=None, n_batch=1, teacher_mode=None):
+        """teacher-rendered RGB + depth targets for a ray batch — the render call of SealNeRF/trainer.py:506-586
+        (`teacher_model.render(..., staged=True, bg_color=None, perturb=False, force_all_rays=True)`, both outputs through
+        nan_to_num).  `out_rgb` [N,3] / `out_depth` [N]: write them there (fp32, contiguous).
+
+        The teacher renders in the mode it is in, as in the reference: main_SealNeRF.py:210 leaves it in eval mode, so the
+        targets come from run_cuda's inference loop (depth measured from the camera, raymarching.cu:844-872).  In training
+        mode the render takes the training branch — one march over every ray (`force_all_rays` is an argument of that branch
+        only), depth measured from the first sample like the student's (:536-552).  `teacher_mode` ("train" | "eval") forces
+        one of the two for this call.  `n_batch` > 1 renders the rays in pieces (:551-563, `proxy_batch`)."""
         if not self.teacher.density_bitfield_hacked:
             self.teacher.hack_bitfield()
-        # The reference never puts the teacher in eval mode: its render takes run_cuda's TRAINING branch (`force_all_rays` is
-        # an argument of that branch only) — one march over every ray, depth accumulated from the first sample like the
-        # student's (raymarching.cu:536-552), not from the camera like the inference loop's (:844-872).  The two depth
-        # conventions differ by the ray's entry distance, so targets from the inference loop would put a constant floor
-        # under the L1 depth term.
+        mode = teacher_mode or self.online_proxy_mode
         was_training = self.teacher.training
-        self.teacher.train()
-        native = rays_o.is_cuda and (out_rgb is not None or self.native_optim)
+        if mode is not None:
+            self.teacher.train(mode == "train")
+        total = rays_o.shape[-2]
+        if n_batch > 1 and rays_o.ndim == 3:
+            size = total // n_batch
+            pieces = n_batch + (1 if total % n_batch else 0)
+            parts = [self.proxy_truth(rays_o[:, i * size:(i + 1) * size], rays_d[:, i * size:(i + 1) * size], teacher_mode=mode)
+                     for i in range(pieces)]
+            self.teacher.train(was_training)
+            rgb, dep = torch.cat([p[0] for p in parts], 1), torch.cat([p[1] for p in parts], 1)
+            if out_rgb is not None:
+                torch._foreach_copy_([out_rgb, out_depth], [rgb.reshape(-1, 3), dep.reshape(-1)])
+                return out_rgb.view(rgb.shape), out_depth.view(dep.shape)
+            return rgb, dep
+        native = rays_o.is_cuda and (out_rgb is not None or self.native_optim) and self.teacher.training
         try:
             with torch.autocast("cuda", dtype=torch.float16, enabled=self.fp16):
                 out = self.teacher.render(rays_o, rays_d, bg_color=None, perturb=False, force_all_rays=True,
@@ -313,6 +409,47 @@ class SealSteps:
             return out_rgb.view(rgb.shape), out_depth.view(dep.shape)
         return rgb, dep
 
+    def init_proxy_cache(self, n_poses, n_pixels):
+        """`cache_gt` (SealNeRF/trainer.py:300-311): per (pose, pixel) memo of the proxied targets"""
+        dev = next(self.model.parameters()).device
+        self.cache_gt = True
+        self.proxy_cache_mask = torch.zeros(n_poses, n_pixels, dtype=torch.bool, device=dev)
+        self.proxy_cache_image = torch.zeros(n_poses, n_pixels, 3, dtype=torch.float, device=dev)
+        self.proxy_cache_depth = torch.zeros(n_poses, n_pixels, dtype=torch.float, device=dev)
+
+    @torch.no_grad()
+    def proxy_truth_data(self, data, all_ray=True, use_cache=False, n_batch=1):
+        """SealNeRF/trainer.py:506-586 on a data-loader dict, in place: `images` / `depths` become the teacher's targets.
+        `skip_proxy` (the provider already proxied its dataset, SealNeRF/provider.py:101): nothing happens.  A full frame
+        (`images` or `images_shape` of 4 dims) comes back as [B, H, W, C].  With the pixel cache only the rays whose
+        (data_index, pixel_index) entry is still empty are rendered."""
+        if data.get("skip_proxy"):
+            return
+        is_full, shape = False, None
+        if "images" in data:
+            shape = data["images"].shape
+            is_full = data["images"].ndim == 4
+        elif "images_shape" in data:
+            shape = data["images_shape"]
+            is_full = len(shape) == 4
+        use_cache = bool(use_cache and data.get("pixel_index") is not None and not is_full)
+        rays_o, rays_d = data["rays_o"], data["rays_d"]
+        if use_cache:
+            di, pi = data["data_index"], data["pixel_index"]
+            di = di.to(self.proxy_cache_mask.device) if torch.is_tensor(di) else di
+            todo = ~self.proxy_cache_mask[di, pi]
+            if todo.any():
+                rgb, dep = self.proxy_truth(rays_o[todo][None], rays_d[todo][None], n_batch=n_batch)
+                self.proxy_cache_image[di, pi[todo]] = rgb
+                self.proxy_cache_depth[di, pi[todo]] = dep
+                self.proxy_cache_mask[di, pi[todo]] = True
+            data["images"], data["depths"] = self.proxy_cache_image[di, pi], self.proxy_cache_depth[di, pi]
+        else:
+            data["images"], data["depths"] = self.proxy_truth(rays_o, rays_d, n_batch=n_batch)
+        if is_full:
+            data["images"] = data["images"].reshape(*shape[:-1], -1)
+            data["depths"] = data["depths"].reshape(*shape[:-1], -1)
+
     def _seal_step(self, rays_o, rays_d, gt_rgb, gt_depth, bg_color=1):
         """zero grads -> fine-tuning loss -> backward -> (all-reduce) -> loss-scaled Adam, launched eagerly"""
         self.optimizer.zero_grad(set_to_none=False)
@@ -328,6 +465,7 @@ class SealTrainer(SealSteps, Trainer):
         self._init_seal(teacher, lr, depth_weight)
 
     def train_step(self, rays_o, rays_d, gt_rgb=None, gt_depth=None, bg_color=1):
+        self.end_pretraining()
         if gt_rgb is None:
             gt_rgb, gt_depth = self.proxy_truth(rays_o, rays_d)
         self.model.train()
@@ -407,7 +545,7 @@ class GraphedSealTrainer(SealSteps, GraphedTrainer):
         training branch (force_all_rays): N * max_steps sample rows of static extent, the real count on the device (every
         kernel of the two-encoder network takes it as n_valid) — no host read-back, so it can be captured."""
         def body():
-            self.proxy_truth(self.s_ro, self.s_rd, self.s_gt, self.s_depth)
+            self.proxy_truth(self.s_ro, self.s_rd, self.s_gt, self.s_depth, teacher_mode="train")
         if self.proxy_graph is None:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -435,8 +573,11 @@ class GraphedSealTrainer(SealSteps, GraphedTrainer):
         return self._seal_step(rays_o, rays_d, gt[0], gt[1], bg_color)
 
     def train_step(self, rays_o, rays_d, gt_rgb=None, gt_depth=None, bg_color=1):
+        self.end_pretraining()
         if gt_rgb is None:
+            mode = self.online_proxy_mode
             ok = (self.graph_proxy and self.fp16 and rays_o.is_cuda and rays_o.numel() == self.s_ro.numel()
+                  and (mode == "train" or (mode is None and self.teacher.training))  # (the one-march branch has static extents)
                   and self.teacher.honours_row_limit_under_autocast(rays_o.numel() // 3 * self.render_kwargs["max_steps"]))
             if ok:
                 torch._foreach_copy_([self.s_ro, self.s_rd], [rays_o.reshape(-1, 3), rays_d.reshape(-1, 3)])

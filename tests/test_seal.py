@@ -91,8 +91,11 @@ def test_teacher_proxy_and_pretrain_step(oracle_wrappers):
     for _ in range(3):
         l1 = float(tr.pretrain_one_epoch())
     assert l1 < l0
-    # MLPs were frozen during pretraining and are trainable again afterwards
-    assert all(p.requires_grad for p in student.sigma_net.parameters())
+    # MLPs were frozen during pretraining (an epoch leaves them frozen, SealNeRF/trainer.py:383) and are trainable again once
+    # the phase is closed — train() does that before every fine-tuning epoch (:338-339), here the next train_step would
+    assert not any(p.requires_grad for p in student.sigma_net.parameters())
+    tr.end_pretraining()
+    assert all(p.requires_grad for p in student.sigma_net.parameters()) and tr.optimizer.param_groups[0]["lr"] == 0.05
     w0 = teacher.sigma_net[0].weight
     assert torch.equal(student.sigma_net[0].weight, w0), "frozen MLP weights must not move during local pretraining"
     assert not torch.equal(student.encoder.embeddings, teacher.encoder.embeddings)
