@@ -126,6 +126,9 @@ class NeRFRenderer(nn.Module):
     def color(self, x, d, mask=None, **kwargs):
         raise NotImplementedError()
 
+    def _batch_dependent_colors(self):
+        return False
+
     def reset_extra_state(self):
         if not self.cuda_ray:
             return
@@ -217,14 +220,19 @@ class NeRFRenderer(nn.Module):
             rays_alive = torch.arange(n_alive, dtype=torch.int32, device=device)
             rays_t = nears.clone()
             use_dev_compaction = self.device_compaction and device.type == "cuda"
-            sync_free = use_dev_compaction and self.sync_every > 1
+            # a proxy colour edit whose result depends on WHICH samples share a network batch (Seal's `rgb` edit keeps each
+            # sample's brightness offset from the batch mean, seal_utils.py:753-769) pins the loop to the reference's shape:
+            # exact alive count every iteration, n_step = max(min(N // n_alive, 8), 1)
+            exact_batches = self._batch_dependent_colors()
+            batch_scale = 1 if exact_batches else self.infer_batch_scale
+            sync_free = use_dev_compaction and self.sync_every > 1 and not exact_batches
             # sync-free variant: `n_alive` is the host's upper bound, `cnt` (device) the real count; every kernel of the
             # iteration takes the count from the device, the bound is refreshed every `sync_every` iterations
             cnt = torch.full((1,), N, dtype=torch.int32, device=device) if sync_free else None
             rows = torch.zeros(1, dtype=torch.int32, device=device) if sync_free else None
             step = it = 0
             while step < max_steps and n_alive > 0:
-                n_step = max(min(self.infer_batch_scale * N // n_alive, 8 * self.infer_batch_scale), 1)
+                n_step = max(min(batch_scale * N // n_alive, 8 * batch_scale), 1)
                 if sync_free:
                     xyzs, dirs, deltas = raymarching.march_rays(
                         n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,

@@ -73,8 +73,13 @@ def render_loss(out, gt_rgb, expected_grad=None, gt_depth=None, depth_weight=1.0
 
 class Trainer:
     def __init__(self, model, lr=1e-2, fp16=True, update_extra_interval=16, dist=None, max_steps=1024, dt_gamma=0,
-                 T_thresh=1e-4, capturable=False, native_optim=None, optimizer=None, scaler=None):
+                 T_thresh=1e-4, capturable=False, native_optim=None, optimizer=None, scaler=None, lr_scheduler=None):
         self.model = model
+        # `lr_scheduler(optimizer)` -> a torch scheduler, stepped after every optimizer step (nerf/utils.py:411-414 with
+        # `scheduler_update_every_step=True`, main_SealNeRF.py:283-300: LambdaLR 0.1 ** min(iter / iters, 1)); a replayed step
+        # follows it through the optimizer's device-side lr factor (nerf/optim.py: follow_lr_schedule)
+        self._lr_scheduler_factory = lr_scheduler
+        self.lr_scheduler = None
         self.lr = lr
         self.fp16 = fp16
         self.update_extra_interval = update_extra_interval
@@ -87,6 +92,8 @@ class Trainer:
         self._capturable = capturable and on_gpu
         if optimizer is not None:  # share an existing optimizer / scaler (e.g. an eager twin of a graphed trainer)
             self.optimizer, self.scaler = optimizer, scaler
+            if lr_scheduler is not None:
+                self.lr_scheduler = lr_scheduler(self.optimizer)
         else:
             self.scaler = None
             self.rebuild_optimizer()
@@ -121,6 +128,12 @@ class Trainer:
                                               capturable=self._capturable)
             if self.scaler is None:
                 self.scaler = torch.amp.GradScaler("cuda", enabled=fp16)
+        if self._lr_scheduler_factory is not None:
+            self.lr_scheduler = self._lr_scheduler_factory(self.optimizer)
+
+    def _sched_step(self):
+        if self.lr_scheduler is not None:
+            self.lr_scheduler.step()
 
     def save_checkpoint(self, workspace, name="ngp", full=False, best=False, remove_old=True, max_keep_ckpt=2):
         """reference on-disk format (nerf/utils.py:1015-1076); see nerf/checkpoint.py"""
@@ -203,7 +216,9 @@ class Trainer:
         self.model.train()
         self._maybe_update_extra_state()
         self.global_step += 1
-        return self._eager_step(rays_o, rays_d, gt_rgb, bg_color)
+        loss = self._eager_step(rays_o, rays_d, gt_rgb, bg_color)
+        self._sched_step()
+        return loss
 
     @torch.no_grad()
     def render_image(self, rays_o, rays_d, bg_color=1):
@@ -435,7 +450,9 @@ class GraphedTrainer(Trainer):
         self.global_step += 1
         if self.graph is None and model.mean_count <= 0:
             # no sample statistics yet (first 16 steps): eager step with the wrapper's host sync
-            return self._eager_step(rays_o, rays_d, gt_rgb, bg_color)
+            loss = self._eager_step(rays_o, rays_d, gt_rgb, bg_color)
+            self._sched_step()
+            return loss
         if bg_color != 1:
             raise ValueError("GraphedTrainer: the captured step composites on the white background (bg_color=1) of the "
                              "BASELINE configs; use Trainer for per-batch background colours")
@@ -460,4 +477,5 @@ class GraphedTrainer(Trainer):
         if not filed:
             model.step_counter[model.local_step % 16].copy_(self.s_counter)
         model.local_step += 1
+        self._sched_step()
         return loss

@@ -70,6 +70,9 @@ class SealTeacherMixin:
         m = self.seal_mapper
         return bool(getattr(m, "native", False)) and "hsv" not in m.map_data and "rgb" not in m.map_data
 
+    def _batch_dependent_colors(self):
+        return self.seal_mapper is not None and self.proxy_enabled and "rgb" in self.seal_mapper.map_data
+
     # teacher only: proxy the samples
     def map_samples(self, xyzs, dirs):
         if self.seal_mapper is None or not self.proxy_enabled:

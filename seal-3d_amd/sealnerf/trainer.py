@@ -471,7 +471,9 @@ class SealTrainer(SealSteps, Trainer):
         self.model.train()
         self._maybe_update_extra_state()  # (with data parallelism: occupancy state re-synchronised over the ranks)
         self.global_step += 1
-        return self._seal_step(rays_o, rays_d, gt_rgb, gt_depth, bg_color)
+        loss = self._seal_step(rays_o, rays_d, gt_rgb, gt_depth, bg_color)
+        self._sched_step()
+        return loss
 
 
 def _tensorf_seal_trainer():

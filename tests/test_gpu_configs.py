@@ -77,13 +77,16 @@ def test_seal_distillation_graph_replay_matches_eager(hip):
     teacher's proxy render, MSE + L1 depth)."""
     from sealnerf import GraphedSealTrainer, SealTrainer
     res = {}
+
+    def sched(opt):  # main_SealNeRF.py:283-300 steps a LambdaLR after every step: it is what brings the lr back from the
+        return torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 1.0)  # pretraining value after `set_lr(-1)`'s cache quirk
     for mode in ("eager", "graph"):
         teacher, student = _seal_pair(0)
         if mode == "eager":
-            tr = SealTrainer(student, teacher, lr=1e-2, fp16=True)
+            tr = SealTrainer(student, teacher, lr=1e-2, fp16=True, lr_scheduler=sched)
             tr.graph_pretraining = False
         else:
-            tr = GraphedSealTrainer(student, teacher, 4096, lr=1e-2, fp16=True)
+            tr = GraphedSealTrainer(student, teacher, 4096, lr=1e-2, fp16=True, lr_scheduler=sched)
         n = tr.init_pretraining(batch_size=6144000, lr=0.05, local_point_step=0.005)
         losses = [float(tr.pretrain_one_epoch()) for _ in range(5)]
         res[mode] = (n, losses, student.encoder.embeddings.detach().clone(), student.encoder_color.embeddings.detach().clone(), tr, student)
@@ -141,20 +144,23 @@ def test_seal_lr_changes_reach_replayed_graphs_through_the_device_factor(hip):
     assert tr.n_captures >= 1 and opt._lr_captured is not None and float(opt.lr_scale) == 1.0
     tr.init_pretraining(batch_size=6144000, lr=0.05, local_point_step=0.02)
     l0 = float(tr.pretrain_one_epoch())       # eager warm-up step + capture of the chunk's graph, at the pretraining lr
-    assert float(opt.lr_scale) == 1.0 and all(g["lr"] == 1e-2 for g in opt.param_groups)   # restored behind the epoch
+    # (an epoch leaves the pretraining lr set, SealNeRF/trainer.py:363-395; the next fine-tuning step restores it)
+    assert abs(float(opt.lr_scale) - 5.0) < 1e-6 and all(g["lr"] == 0.05 for g in opt.param_groups)
     seen = []
     real = type(tr)._pretrain_chunk
 
-    def spy(self, key, sl, n_total):
+    def spy(self, part, k, sl, n_total):
         seen.append(float(opt.lr_scale))      # the factor a replayed chunk graph will read
-        return real(self, key, sl, n_total)
+        return real(self, part, k, sl, n_total)
     type(tr)._pretrain_chunk = spy
     try:
-        tr.train_step(ro, rd)                 # a fine-tuning replay in between
+        tr.train_step(ro, rd)                 # a fine-tuning replay in between (closes the pretraining phase: lr back to 1e-2)
+        assert float(opt.lr_scale) == 1.0 and all(g["lr"] == 1e-2 for g in opt.param_groups)
         l1 = float(tr.pretrain_one_epoch())   # replays the chunk graph
     finally:
         type(tr)._pretrain_chunk = real
     assert seen and all(abs(f - 0.05 / 1e-2) < 1e-6 for f in seen), seen
+    tr.end_pretraining()
     assert float(opt.lr_scale) == 1.0 and np.isfinite([l0, l1]).all()
 
 

@@ -55,15 +55,10 @@ def test_init_pretraining_and_two_epochs_vs_reference(hip, G, native_optim):
     """SealNeRF/trainer.py:88-263, 363-503: lattices exact, teacher targets 1e-4, per-step losses of two epochs of frozen-MLP
     Adam and the student's tables afterwards (torch.optim.Adam and the HIP multi-tensor Adam)"""
     teacher, student, tr, mapper = _distillation(G, "cuda", native_optim=native_optim)
-    g = torch.Generator().manual_seed(11)  # the reference drew from the CPU generator seeded with 11: one randint per part
-    real = torch.randint
-    torch.randint = lambda *a, **k: real(*a, **dict(k, generator=g)) if "generator" in k or not k.get("device") else real(*a, **k)
-    try:
-        n = tr.init_pretraining(epochs=2, batch_size=3000, lr=0.02, local_point_step=0.02, local_angle_step=45,
-                                surrounding_point_step=0.04, surrounding_angle_step=45, surrounding_bounds_extend=0.1,
-                                global_point_step=0.25, global_angle_step=90, seed=None)
-    finally:
-        torch.randint = real
+    torch.manual_seed(11)  # (seed=None: the directions are drawn on the CPU generator, one randint per part, like the reference's)
+    n = tr.init_pretraining(epochs=2, batch_size=3000, lr=0.02, local_point_step=0.02, local_angle_step=45,
+                            surrounding_point_step=0.04, surrounding_angle_step=45, surrounding_bounds_extend=0.1,
+                            global_point_step=0.25, global_angle_step=90, seed=None)
     assert list(tr.pretraining_data) == G["ip_parts"].tolist() and n == G["ip_local_points"].shape[0]
     assert np.array_equal(mapper.map_data["force_fill_bound"].cpu().numpy(), G["ip_fill_bound_after"])
     for part, src in tr.pretraining_data.items():
