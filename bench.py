@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--long_run_seeds", type=int, default=8)
     ap.add_argument("--seal_teacher_steps", type=int, default=256)
     ap.add_argument("--seal_point_step", type=float, default=0.005, help="pretraining_local_point_step (readme.md:109)")
+    ap.add_argument("--seal_surrounding_step", type=float, default=0.01, help="pretraining_surrounding_point_step (main_SealNeRF.py:98; <= 0: off)")
+    ap.add_argument("--seal_proxy_poses", type=int, default=4, help="poses per rank whose frames proxy_dataset renders")
+    ap.add_argument("--seal_frame", type=int, default=800, help="frame size of the proxied dataset")
+    ap.add_argument("--seal_iters", type=int, default=30000, help="--iters of main_SealNeRF.py (LambdaLR horizon)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=None, help="process-group backend (default: nccl = RCCL)")
     ap.add_argument("--rendezvous_only", action="store_true",
@@ -348,22 +352,32 @@ SEAL_BBOX = {"type": "bbox", "raw": [[x, y, z] for x in (-0.2, 0.2) for y in (0.
 
 
 def seal_section(args, dev, batches, note=lambda m: None, make_dp=None, reps=None, eager=False, net_kw=None):
-    """BASELINE configs[2] (1 GPU) / configs[3] (`--gpus N`: SURVEY §8e) — teacher = the two-encoder NGP net trained on the
-    synthetic scene, student = its copy, bbox edit translate (0.3, 0, 0), pretraining_local_point_step 0.005 (~7.7e5 lattice
-    points, one chunk), then fine-tuning on 4,096-ray batches per rank whose RGB + depth targets the teacher renders through
-    the proxy.  With N ranks (`make_dp()` -> a parallel.RayShardedDP per trainer): every chunk of pretraining points is
-    sharded over the ranks (SealNeRF/trainer.py:404-413; MLPs frozen: table gradients only), each rank renders the proxy
-    targets of and fine-tunes on its OWN rays (weak scaling), and both tables' and both MLPs' gradients travel in the one
-    all-reduce per step.  Every timing is bracketed by a barrier and is the MAX over the ranks; rates are whole-job.
+    """BASELINE configs[2] (1 GPU) / configs[3] (`--gpus N`: SURVEY §8e), in the order main_SealNeRF.py runs them — teacher = the
+    two-encoder NGP net trained on the synthetic scene and left in eval mode (:210), student = its copy, bbox edit translate
+    (0.3, 0, 0), LambdaLR 0.1 ** (iter / iters) stepped every step (:283-300);
+      init_pretraining  local lattice at pretraining_local_point_step 0.005 (~7.7e5 points) + the surrounding lattice at the
+                        CLI defaults (step 0.01, bounds grown by 0.1; :98-103), one chunk each (batch 6,144,000);
+      pretraining       epochs over both parts, MLPs frozen;
+      proxy_dataset     every training pose's 800x800 frame rendered ONCE by the eval-mode teacher through the proxy
+                        (SealNeRF/provider.py:19-70, called by train() :270-273) -> colour + depth targets;
+      fine-tuning       4,096-ray batches per rank whose targets are gathered from those frames (`skip_proxy`): the student's
+                        step alone — `seal_train_ms_per_step`.  Also timed: the step with the per-step teacher render the
+                        reference's GUI loop does (train_gui -> proxy_truth, eval-mode teacher: `*_online_proxy`), and this
+                        build's one-march variant of it (teacher's training branch replayed from a HIP graph: `*_one_march`).
+    With N ranks (`make_dp()` -> a parallel.RayShardedDP per trainer): every chunk of pretraining points is sharded over the
+    ranks (SealNeRF/trainer.py:404-413; MLPs frozen: table gradients only), each rank proxies its own poses and fine-tunes on
+    its OWN rays (weak scaling), and both tables' and both MLPs' gradients travel in the one all-reduce per step.  Every timing
+    is bracketed by a barrier and is the MAX over the ranks; rates are whole-job.
     `eager`: the eager trainers instead of the graph-replayed ones (the only choice without a GPU: tests/); `reps`, `net_kw`:
     repetition counts / network arguments of a reduced run (tests/)."""
     import torch.distributed as dist
-    from nerf import network
+    from nerf import network, synthetic as syn
     from nerf.trainer import GraphedTrainer, Trainer
-    from sealnerf import GraphedSealTrainer, SealBBoxMapper, SealTrainer, make_student, make_teacher
-    reps = dict(dict(pretrain=8, proxy=8, warm=40, step=32, proxy_graph=16, allreduce=8), **(reps or {}))
+    from sealnerf import GraphedSealTrainer, SealBBoxMapper, SealDataset, SealTrainer, make_student, make_teacher
+    reps = dict(dict(pretrain=8, proxy=8, warm=40, step=32, proxy_graph=16, allreduce=8, online=8), **(reps or {}))
     dpt, dps = (make_dp(), make_dp()) if make_dp is not None else (None, None)
     world = dps.world if dps is not None else 1
+    rank = dps.rank if dps is not None else 0
     multi = world > 1 and dist.is_initialized()
     kw = dict(dict(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10), **(net_kw or {}))
     torch.manual_seed(args.seed + 17)
@@ -373,6 +387,7 @@ def seal_section(args, dev, batches, note=lambda m: None, make_dp=None, reps=Non
     for i in range(args.seal_teacher_steps):
         ttr.train_step(*batches[i % len(batches)])
     del ttr
+    teacher.train(False)  # main_SealNeRF.py:210: every teacher render below takes run_cuda's inference loop
     student = make_student(network.NeRFNetwork, **kw).to(dev)
     student.load_state_dict(teacher.state_dict())
     student.mean_count, student.mean_density, student.iter_density = teacher.mean_count, teacher.mean_density, teacher.iter_density
@@ -380,9 +395,14 @@ def seal_section(args, dev, batches, note=lambda m: None, make_dp=None, reps=Non
     teacher.init_mapper(mapper)
     student.init_mapper(mapper)
     note("seal: teacher trained; pretraining")
-    tr = (SealTrainer(student, teacher, lr=1e-2, fp16=True, update_extra_interval=16, dist=dps) if eager else
-          GraphedSealTrainer(student, teacher, args.num_rays, lr=1e-2, fp16=True, update_extra_interval=16, dist=dps))
-    n_local = tr.init_pretraining(batch_size=6144000, lr=0.05, local_point_step=args.seal_point_step)
+
+    def scheduler(opt):
+        return torch.optim.lr_scheduler.LambdaLR(opt, lambda it: 0.1 ** min(it / args.seal_iters, 1))
+    tr = (SealTrainer(student, teacher, lr=1e-2, fp16=True, update_extra_interval=16, dist=dps, lr_scheduler=scheduler) if eager else
+          GraphedSealTrainer(student, teacher, args.num_rays, lr=1e-2, fp16=True, update_extra_interval=16, dist=dps, lr_scheduler=scheduler))
+    n_local = tr.init_pretraining(batch_size=6144000, lr=0.05, local_point_step=args.seal_point_step,
+                                  surrounding_point_step=args.seal_surrounding_step, surrounding_bounds_extend=0.1, global_point_step=-1)
+    n_points = {k: int(v["points"].shape[0]) for k, v in tr.pretraining_data.items()}
 
     def sync():
         if dev.type == "cuda":
@@ -408,52 +428,89 @@ def seal_section(args, dev, batches, note=lambda m: None, make_dp=None, reps=Non
         if multi:
             dist.all_reduce(t)
         return float(t.item())
-    l0 = float(tr.pretrain_one_epoch())
-    tr.pretrain_one_epoch()  # (second epoch: the chunk's graph is captured)
+    tr.pretrain_one_epoch()
+    l0 = float(tr.last_pretrain_losses[0])  # (the local part's first chunk: the edit region, where student != teacher's proxy)
+    tr.pretrain_one_epoch()  # (second epoch: the chunks' graphs are captured)
     ep = sync_time(lambda i: tr.pretrain_one_epoch(), reps["pretrain"])
-    l1 = float(tr.pretrain_one_epoch())
-    note(f"seal: pretraining timed ({ep * 1e3:.2f} ms/epoch); proxy truth")
+    tr.pretrain_one_epoch()
+    l1 = float(tr.last_pretrain_losses[0])
+    note(f"seal: pretraining timed ({ep * 1e3:.2f} ms/epoch); proxy dataset")
+    # ---- proxy_dataset: this rank's poses, whole frames, eval-mode teacher through the proxy
+    F_ = args.seal_frame
+    n_frames = max(1, args.seal_proxy_poses)
+    poses = syn.orbit_poses(100, seed=0)[rank * n_frames:(rank + 1) * n_frames].to(dev)
+    ds = SealDataset(poses, syn.lego_intrinsics(F_, F_), F_, F_, num_rays=args.num_rays, device=dev, render_kwargs=tr.render_kwargs, fp16=True)
+    ds.proxy_dataset(teacher)  # (warm-up: allocator pools, lazy initialisations)
+    pd = sync_time(lambda i: ds.proxy_dataset(teacher), 1)
     proxy = sync_time(lambda i: tr.proxy_truth(batches[i % len(batches)][0], batches[i % len(batches)][1]), reps["proxy"])
-    note("seal: fine-tuning")
+    note(f"seal: proxy dataset {n_frames} frame(s) in {pd * 1e3:.1f} ms; fine-tuning")
+    g = torch.Generator().manual_seed(args.seed + 23 + rank)
+    nb = min(16, max(len(batches), 2))
+    coll = []
+    for i in range(nb):
+        b = ds.collate([i % n_frames], generator=g)
+        coll.append((b["rays_o"][0].contiguous(), b["rays_d"][0].contiguous(), b["images"][0].contiguous(), b["depths"][0, :, 0].contiguous()))
     for i in range(reps["warm"]):  # fine-tuning warm-up: 16 eager steps (sample statistics), capture, replays
-        tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
+        tr.train_step(*coll[i % nb])
     samples = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def ft(i):
-        tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
+        tr.train_step(*coll[i % nb])
         samples.add_(student.step_counter[(student.local_step - 1) % 16, 0].long())
     step = sync_time(ft, reps["step"])
+
+    def ft_collate(i):
+        b = ds.collate([i % n_frames], generator=g)
+        tr.train_step(b["rays_o"][0], b["rays_d"][0], b["images"][0], b["depths"][0, :, 0])
+    step_collate = sync_time(ft_collate, reps["step"])
+    # ---- the GUI loop's per-step teacher render (train_gui -> train_step -> proxy_truth), eval-mode teacher
+    samples_on = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def ft_online(i):
+        tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
+        samples_on.add_(student.step_counter[(student.local_step - 1) % 16, 0].long())
+    ft_online(0)
+    step_online = sync_time(ft_online, reps["online"])
+    # ---- this build's one-march variant: the teacher's training branch (force_all_rays), replayed from its own graph
+    tr.online_proxy_mode = "train"
+    for i in range(3):
+        tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
+    samples_om = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def ft_one_march(i):
+        tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
+        samples_om.add_(student.step_counter[(student.local_step - 1) % 16, 0].long())
+    step_one_march = sync_time(ft_one_march, reps["step"])
     proxy_graph = None
     if getattr(tr, "proxy_graph", None) is not None:
-        def proxy_replay(i):  # the proxy render as the fine-tuning step runs it: rays staged, its own HIP graph replayed
+        def proxy_replay(i):  # the proxy render as that step runs it: rays staged, its own HIP graph replayed
             b = batches[i % len(batches)]
             torch._foreach_copy_([tr.s_ro, tr.s_rd], [b[0].reshape(-1, 3), b[1].reshape(-1, 3)])
             tr._proxy_replay()
         proxy_graph = sync_time(proxy_replay, reps["proxy_graph"])
-    nb = min(8, len(batches))
-    targets = [tr.proxy_truth(b[0], b[1]) for b in batches[:nb]]
-    samples2 = torch.zeros(1, dtype=torch.int64, device=dev)
-
-    def ft_cached(i):
-        tr.train_step(batches[i % nb][0], batches[i % nb][1], *targets[i % nb])
-        samples2.add_(student.step_counter[(student.local_step - 1) % 16, 0].long())
-    step_cached = sync_time(ft_cached, reps["step"])
-    n_samples, n_samples2 = total(samples), total(samples2)
+    tr.online_proxy_mode = None
+    n_samples, n_on, n_om = total(samples), total(samples_on), total(samples_om)
+    n_epoch = sum(n_points.values())
     out = {"workload": ("configs[2]: lego_bbox-shaped edit (bbox translate 0.3), teacher+student two-encoder NGP, "
-                        f"pretraining_local_point_step={args.seal_point_step:g}, {args.num_rays} rays/step, 1 GPU, HIP-graph replay") if world == 1 and not eager else
+                        f"pretraining_local_point_step={args.seal_point_step:g} + surrounding {args.seal_surrounding_step:g}, "
+                        f"{args.num_rays} rays/step, targets from the proxied dataset, 1 GPU, HIP-graph replay") if world == 1 and not eager else
                        ("configs[3]: lego_bbox-shaped edit, teacher+student two-encoder NGP distillation, pretraining points sharded "
                         f"over {world} rank(s), {args.num_rays} rays/step/rank, one gradient all-reduce per step"),
-           "local_points": int(n_local),
-           "seal_pretrain_points_per_s": n_local / ep, "pretrain_ms_per_epoch": ep * 1e3, "pretrain_loss_first_last": [l0, l1],
+           "local_points": int(n_local), "pretrain_points": n_points,
+           "seal_pretrain_points_per_s": n_epoch / ep, "pretrain_ms_per_epoch": ep * 1e3, "pretrain_loss_first_last": [l0, l1],
+           "proxy_dataset_frames_per_rank": n_frames, "proxy_dataset_ms_per_frame": pd / n_frames * 1e3,
+           "proxy_dataset_mrays_per_s": world * n_frames * F_ * F_ / pd / 1e6,
            "proxy_truth_mrays_per_s": world * args.num_rays / proxy / 1e6, "proxy_truth_ms_per_batch": proxy * 1e3,
-           "proxy_truth_note": "eager call of SealSteps.proxy_truth (host launches); inside the fine-tuning step the render is "
-                               "replayed from its own graph: *_graph_replay",
+           "proxy_truth_note": "SealSteps.proxy_truth on one ray batch, teacher in eval mode (inference loop, eager launches)",
+           "seal_train_samples_per_s": n_samples / reps["step"] / step, "seal_train_ms_per_step": step * 1e3,
+           "seal_train_ms_per_step_with_collate": step_collate * 1e3,
+           "seal_train_ms_per_step_online_proxy": step_online * 1e3,
+           "seal_train_samples_per_s_online_proxy": n_on / reps["online"] / step_online,
+           "seal_train_ms_per_step_one_march": step_one_march * 1e3,
+           "seal_train_samples_per_s_one_march": n_om / reps["step"] / step_one_march,
            "proxy_truth_ms_per_batch_graph_replay": None if proxy_graph is None else proxy_graph * 1e3,
            "proxy_truth_mrays_per_s_graph_replay": None if proxy_graph is None else world * args.num_rays / proxy_graph / 1e6,
-           "seal_train_samples_per_s": n_samples / reps["step"] / step, "seal_train_ms_per_step": step * 1e3,
-           "seal_train_samples_per_s_cached_targets": n_samples2 / reps["step"] / step_cached,
-           "seal_train_ms_per_step_cached_targets": step_cached * 1e3,
-           "graph_captures": getattr(tr, "n_captures", 0)}
+           "graph_captures": getattr(tr, "n_captures", 0), "lr_after": [float(g_["lr"]) for g_ in tr.optimizer.param_groups][:1]}
     if dps is not None:
         # the step's one exchange, alone: both tables' + both MLPs' gradients (fp16 hand-over buffer + fp32 bucket)
         ar = sync_time(lambda i: dps.allreduce_grads(tr.scaler), reps["allreduce"])
@@ -519,21 +576,23 @@ def tensorf_section(args, dev, batches, note=lambda m: None, res=300, steps=24):
 
     for k in range(2):
         tr.train_step(*batches[k % len(batches)])
-    dt_eager, _ = timed(tr, max(steps // 2, 4))
+    dt_eager, n_eager = timed(tr, max(steps // 2, 4))
     # the same step replayed from a HIP graph (tensoRF/utils.py: GraphedTrainer) — the eager step is bound by its ~150 launches
     gtr = TensoRFGraphedTrainer(net, args.num_rays, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, fp16=True, update_extra_interval=10 ** 9)
     gtr.global_step = 1
     for k in range(6):
         gtr.train_step(*batches[k % len(batches)])
-    dt_graph, n = timed(gtr, steps)
+    dt_graph, n_graph = timed(gtr, steps)
     # (both are product routes: the replayed step carries a static sample budget 1.3x the marched count, and the kernels without a
     #  device-side row count — the W = 128 MLP — process the padding; since the step is down to ~60 launches the eager one, with the
     #  exact budget, can be the faster of the two)
     dt = min(dt_graph, dt_eager)
+    n = n_graph if dt_graph <= dt_eager else n_eager  # (the sample count of the SAME run the reported time comes from)
     out = {"workload": f"configs[4]: TensoRF VM-48 (sigma rank 16x3, colour rank 48x3), resolution {res}, {args.num_rays} rays/step, "
                        "training step with the L1 penalty (weight 1e-4), NativeAdam, fused VM kernels; the faster of eager and HIP-graph replay",
            "ms_per_step": dt * 1e3, "trainer": "graph" if dt_graph <= dt_eager else "eager", "ms_per_step_graph": dt_graph * 1e3,
-           "ms_per_step_eager": dt_eager * 1e3, "graph_captures": gtr.n_captures, "samples_per_step": n, "samples_per_s": n / dt}
+           "ms_per_step_eager": dt_eager * 1e3, "graph_captures": gtr.n_captures, "samples_per_step": n, "samples_per_s": n / dt,
+           "samples_per_s_graph": n_graph / dt_graph, "samples_per_s_eager": n_eager / dt_eager}
     cb = op.get("color_backward")
     if cb:
         bytes_per = 3 * (2 * 4 * 48 * 4 + 2 * 48 * 4 + 2 * 48 * 4 + 2 * 48 * 4) + 12 + 64
@@ -591,27 +650,37 @@ def seal_tensorf_section(args, dev, batches, note=lambda m: None, res=300):
     l1 = float(tr.pretrain_one_epoch())
     note(f"seal tensorf: pretraining timed ({ep * 1e3:.2f} ms/epoch)")
     tr.global_step = 1
+    teacher.train(False)  # main_SealTensoRF.py:184
     proxy = timed(lambda i: tr.proxy_truth(batches[i % len(batches)][0], batches[i % len(batches)][1]), 4)
+    nb = min(8, len(batches))
+    # the targets the proxied dataset would hold for these rays (SealNeRF/provider.py:19-70: rendered once, before training)
+    targets = [tuple(t.reshape(-1, t.shape[-1]) if t.ndim == 3 else t.reshape(-1) for t in tr.proxy_truth(batches[i][0], batches[i][1]))
+               for i in range(nb)]
     for i in range(8):
-        tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
+        tr.train_step(batches[i % nb][0], batches[i % nb][1], *targets[i % nb])
     student.mean_count = int(student.step_counter[:8, 0].float().mean().item())  # the sample budget after the first grid update
     student.local_step = 0
     for i in range(16):  # (capture of the student's step, replays)
-        tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
+        tr.train_step(batches[i % nb][0], batches[i % nb][1], *targets[i % nb])
     samples = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def ft(i):
-        tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1])
+        tr.train_step(batches[i % nb][0], batches[i % nb][1], *targets[i % nb])
         samples.add_(student.step_counter[(student.local_step - 1) % 16, 0].long())
     step = timed(ft, 16)
     n = float(samples.item()) / 16
+    step_online = timed(lambda i: tr.train_step(batches[i % len(batches)][0], batches[i % len(batches)][1]), 8)
     return {"workload": f"configs[4] (main_SealTensoRF.py): lego_bbox-shaped edit, TensoRF VM-48 teacher + student at resolution {res}, "
-                        f"pretraining_local_point_step={args.seal_point_step:g}, {args.num_rays} rays/step, student step replayed from a HIP graph, proxy render eager",
+                        f"pretraining_local_point_step={args.seal_point_step:g}, {args.num_rays} rays/step, targets proxied before training, "
+                        "student step replayed from a HIP graph",
             "graph_captures": getattr(tr, "n_captures", 0),
             "local_points": int(n_local), "pretrain_ms_per_epoch": ep * 1e3, "seal_pretrain_points_per_s": n_local / ep,
             "pretrain_loss_first_last": [l0, l1], "proxy_truth_ms_per_batch": proxy * 1e3,
             "seal_train_ms_per_step": step * 1e3, "seal_train_samples_per_s": n / step, "samples_per_step": n,
-            "note": "a fine-tuning step = the teacher's proxy render of the batch's rays (targets) + the student's training step"}
+            "seal_train_ms_per_step_online_proxy": step_online * 1e3,
+            "note": "a fine-tuning step = the student's training step on targets the eval-mode teacher rendered beforehand "
+                    "(main_SealTensoRF.py's flow: proxy_dataset, then skip_proxy batches); *_online_proxy adds the GUI loop's "
+                    "per-step teacher render (inference loop, eager)"}
 
 
 # ----------------------------------------------------------------------------- quality over a long run
@@ -1032,6 +1101,16 @@ def main():
             line["config"][k] = extra[k]
             if "roofline_render" in extra:
                 line["roofline_render"][k] = extra[k]
+    # configs[2] / configs[4]: the figures of the optional sections, where the driver's parser looks (`config`)
+    seal_, tf_ = extra.get("seal") or {}, extra.get("tensorf") or {}
+    for key, src, name in (("seal_train_ms_per_step", seal_, "seal_train_ms_per_step"),
+                           ("seal_pretrain_ms_per_epoch", seal_, "pretrain_ms_per_epoch"),
+                           ("seal_proxy_dataset_mrays_per_s", seal_, "proxy_dataset_mrays_per_s"),
+                           ("tensorf_ms_per_step", tf_, "ms_per_step"),
+                           ("seal_tensorf_ms_per_step", tf_.get("seal") or {}, "seal_train_ms_per_step"),
+                           ("seal_tensorf_pretrain_ms_per_epoch", tf_.get("seal") or {}, "pretrain_ms_per_epoch")):
+        if isinstance(src.get(name), (int, float)):
+            line["config"][key] = src[name]
     if dp_info is not None:
         line["data_parallel"] = dp_info
     if dist.is_initialized():

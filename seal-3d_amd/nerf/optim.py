@@ -110,6 +110,7 @@ class NativeAdam(torch.optim.Optimizer):
                     p._s3d_grad_touched = False
                     p._s3d_grad_consumed = False
                     p._s3d_unchecked = False
+                p.__dict__.pop("_s3d_grad_checked", None)  # (a producer's "checked at the source" mark never outlives its step)
                 if p.grad is not None:
                     if set_to_none:
                         p.grad = None
@@ -327,8 +328,11 @@ class NativeGradScaler:
         tensor was 5 x 5 us of a 0.9 ms Seal step, profiles/r08_seal.md), the native per-tensor kernel for a single one"""
         # (a gradient whose producer raised THIS flag itself — tensoRF/network.py: the factor backward — is not read again;
         #  the mark is the producer's, per backward pass, and is consumed here)
+        # (the mark is popped from EVERY parameter first: a mark whose backward was not followed by this scaler's step — a loss
+        #  evaluated without a step, an exception, another scaler — must not excuse a later gradient made by another route)
+        marks = {id(p): p.__dict__.pop("_s3d_grad_checked", None) for _, p, _ in optimizer.grads()}
         rest = [g for _, p, g in optimizer.grads() if (flat is None or g is not getattr(p, "_s3d_grad", None))
-                and p.__dict__.pop("_s3d_grad_checked", None) is not self._found_inf]
+                and marks.get(id(p)) is not self._found_inf]
         if len(rest) > 1 and all(g.is_cuda and g.dtype == rest[0].dtype and g.layout == torch.strided for g in rest):
             torch._amp_foreach_non_finite_check_and_unscale_(rest, self._found_inf, self._one)
         else:

@@ -196,7 +196,11 @@ class NeRFRenderer(nn.Module):
             rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)
             fused = kwargs.get("fused_loss")  # (nerf/trainer.py: the criterion and its gradient inside the compositing launch)
             if (fused is not None and kwargs.get("defer_background", False) and not torch.is_tensor(bg_color)
-                    and sigmas.is_cuda and fused.get("expected_grad") is not None):
+                    and sigmas.is_cuda and fused.get("expected_grad") is not None
+                    # (the one-launch composite + criterion exists on the product's composite path only: an A/B run on
+                    #  another path takes the unfused sequence below instead of failing)
+                    and hasattr(raymarching.raymarching._backend, "composite_rays_train_loss")
+                    and getattr(raymarching.raymarching._backend, "_composite_path", 0) == 0):
                 bg3 = (float(bg_color),) * 3 if not isinstance(bg_color, (tuple, list)) else tuple(float(v) for v in bg_color)
                 results["loss"], weights_sum, depth, image = raymarching.composite_rays_train_loss(
                     sigmas, rgbs, deltas, rays, T_thresh, fused["gt"], bg3, fused["expected_grad"], fused.get("workspace"),

@@ -63,13 +63,14 @@ rm._backend, gg._backend, sh._backend, fq._backend, ff._backend = (ob.Raymarchin
 import bench
 from nerf import synthetic as syn
 from parallel import RayShardedDP
-sys.argv = ["bench.py", "--num_rays", "192", "--seal_teacher_steps", "18", "--seal_point_step", "0.06"]
+sys.argv = ["bench.py", "--num_rays", "192", "--seal_teacher_steps", "18", "--seal_point_step", "0.06", "--seal_surrounding_step", "0.09",
+            "--seal_proxy_poses", "1", "--seal_frame", "16"]
 args = bench.parse()
 dev = torch.device("cpu")
 _, bits = syn.lego_like_density_grid(seed=0)
 batches, _ = bench.make_batches(3, args.num_rays, args.seed + rank, dev, ob.RaymarchingBackend, torch.from_numpy(bits), syn.lego_like_boxes(0))
 out = bench.seal_section(args, dev, batches, make_dp=(lambda: RayShardedDP()) if world > 1 else None, eager=True,
-                         reps=dict(pretrain=1, proxy=1, warm=2, step=2, allreduce=1), net_kw=dict(log2_hashmap_size=12))
+                         reps=dict(pretrain=1, proxy=1, warm=2, step=2, allreduce=1, online=1), net_kw=dict(log2_hashmap_size=12))
 if rank == 0: print(json.dumps({"seal": out, "n_gpus": world}), flush=True)
 if world > 1: dist.destroy_process_group()
 '''
@@ -94,7 +95,8 @@ def test_seal_section_runs_data_parallel_over_two_gloo_ranks(tmp_path):
     assert seal["workload"].startswith("configs[3]") and "2 rank(s)" in seal["workload"]
     assert dp["allreduce_bytes_fp32_bucket"] > 0 and dp["allreduce_ms_per_step_alone"] > 0
     assert seal["local_points"] > 100 and seal["seal_pretrain_points_per_s"] > 0
-    assert seal["seal_train_samples_per_s"] > 0 and seal["proxy_truth_mrays_per_s"] > 0
+    assert seal["seal_train_samples_per_s"] > 0 and seal["proxy_truth_mrays_per_s"] > 0 and seal["proxy_dataset_mrays_per_s"] > 0
+    assert set(seal["pretrain_points"]) == {"local", "surrounding"} and seal["seal_train_ms_per_step_online_proxy"] > 0
     l0, l1 = seal["pretrain_loss_first_last"]
     assert l1 < l0, "sharded pretraining does not reduce the distillation loss"
 
