@@ -674,3 +674,165 @@ def test_tensorf_small_fused_launches_match_their_torch_expressions(hip):
     h = torch.randn(4096, 16, generator=g).half().cuda()
     from nerf.network_ff import _NgpRgb
     assert torch.equal(_NgpRgb.apply(h), torch.sigmoid(h[:, :3]).float())
+
+
+# ------------------------------------------------------------------------------------------------ configs[4] at its real shape
+def _vm48_marched_samples(n_rays=6144, seed=0):
+    """ray-ordered marched samples of the synthetic scene (what the training step hands the VM kernels): > 1e5 points"""
+    import raymarching
+    grid, bits = syn.lego_like_density_grid(seed=0)
+    poses = syn.orbit_poses(2, seed=seed).cuda()
+    r = syn.get_rays(poses[:1], syn.lego_intrinsics(), 800, 800, N=n_rays, generator=torch.Generator().manual_seed(seed))
+    ro, rd = r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous()
+    aabb = torch.tensor([-1.0, -1, -1, 1, 1, 1], device="cuda")
+    nears, fars = raymarching.near_far_from_aabb(ro, rd, aabb, 0.2)
+    counter = torch.zeros(2, dtype=torch.int32, device="cuda")
+    xyzs, dirs, deltas, rays = raymarching.march_rays_train(ro, rd, 1.0, torch.from_numpy(bits).cuda(), 1, 128, nears, fars, counter, 0,
+                                                            False, 128, True, 0, 1024)
+    m = int(counter[0])
+    return xyzs[:m].contiguous(), m
+
+
+def _vm48(res=300, seed=3):
+    from tensoRF import network as trf
+    torch.manual_seed(seed)
+    net = trf.NeRFNetwork(resolution=[res] * 3, bound=1, cuda_ray=True).cuda()   # the defaults ARE VM-48: sigma 16x3, colour 48x3
+    assert [p.shape[1] for p in net.sigma_mat] == [16] * 3 and [p.shape[1] for p in net.color_mat] == [48] * 3
+    return net
+
+
+def _factor_grads(net):
+    return [p.grad.float().clone() for p in list(net.sigma_mat) + list(net.sigma_vec) + list(net.color_mat) + list(net.color_vec) + [net.basis_mat.weight]]
+
+
+def _abs_sum_bound(net, x, g_abs_s, g_abs_c):
+    """per-element sum of |terms| of each factor gradient: the torch sequence run on |parameters| with |upstream gradients| —
+    the scale rounding errors of ANY summation order are proportional to"""
+    import copy
+    a = copy.deepcopy(net)
+    a.fused_vm = False
+    with torch.no_grad():
+        for p in a.parameters():
+            p.abs_()
+    a.zero_grad(set_to_none=True)
+    (a.get_sigma_feat(x) * g_abs_s).sum().backward()
+    cf = a.get_color_feat(x)
+    (cf * g_abs_c).sum().backward()
+    return _factor_grads(a)
+
+
+@pytest.mark.parametrize("case", ["marched", "hot_tile"])
+def test_vm48_resolution300_backward_vs_grid_sample_autograd(hip, case):
+    """configs[4]'s real shape — sigma rank 16x3, colour rank 48x3 + basis_mat, resolution 300, > 1e5 ray-ordered marched
+    samples — s3d_vm_features_backward / s3d_vm_color_backward against F.grid_sample's autograd in fp32 on the same parameters
+    (tensoRF/network.py:112-153).  `hot_tile`: every point inside ONE 8x8 plane tile (a cell takes ~1e5 / 64 contributions per
+    range: the fixed-point accumulators' worst case).
+    Tolerance: both sides sum ~1e3 - 1e5 fp32 terms per cell in different orders; the error of either is bounded by
+    (terms) x 2^-24 x sum|terms|, measured here as 2e-6 x the per-element sum of |terms| (the fixed-point path itself rounds each
+    term at 2^-50 of the batch bound: far below)."""
+    net = _vm48()
+    if case == "marched":
+        x, m = _vm48_marched_samples()
+        assert m >= 100000, m
+    else:
+        g = torch.Generator().manual_seed(5)
+        cell = 2.0 / 299
+        x = (torch.rand(120000, 3, generator=g) * (6 * cell) + (-1.0 + (12 * 8 + 1) * cell)).cuda()  # cells 97..103 on every axis: tile (12, 12)
+        m = x.shape[0]
+    g = torch.Generator().manual_seed(7)
+    gs = torch.randn(m, generator=g).cuda()
+    gc = (torch.randn(m, 27, generator=g) * 0.1).cuda()
+    res = {}
+    for fused in (True, False):
+        net.fused_vm = net.fused_basis = fused
+        net.zero_grad(set_to_none=True)
+        s = net.get_sigma_feat(x)
+        (s * gs).sum().backward()
+        c = net.get_color_feat(x)
+        if fused:
+            assert s.grad_fn.name().startswith("_VmFeatures")
+        (c.float() * gc).sum().backward()
+        res[fused] = (s.detach(), c.detach().float(), _factor_grads(net))
+    net.fused_vm = net.fused_basis = True
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(res[True][1], res[False][1], rtol=1e-4, atol=1e-5)
+    bound = _abs_sum_bound(net, x, gs.abs(), gc.abs())
+    names = [f"sigma_mat{i}" for i in range(3)] + [f"sigma_vec{i}" for i in range(3)] + [f"color_mat{i}" for i in range(3)] + \
+            [f"color_vec{i}" for i in range(3)] + ["basis_mat"]
+    for name, a, b, bd in zip(names, res[True][2], res[False][2], bound):
+        assert float(b.abs().max()) > 0, name
+        err = (a - b).abs()
+        tol = 2e-6 * bd + 1e-6 * float(b.abs().max())
+        assert bool((err <= tol).all()), (name, float((err / tol).max()), float(err.max()), float(b.abs().max()))
+        assert bool(((a != 0) == (b != 0)).all() or (err[(a != 0) != (b != 0)] <= tol[(a != 0) != (b != 0)]).all()), name
+
+
+def test_vm_backward_keeps_gradients_far_below_the_batch_maximum(hip):
+    """the fixed-point accumulators are scaled by ONE bound per call.  A region whose gradients lie 2^60 below the
+    batch maximum still receives them (vanishing contributions bypass the accumulator as exact fp32 atomics): compared with the
+    grid_sample autograd on the same inputs, cell by cell, relative to each cell's own magnitude."""
+    net = _vm48(res=64)
+    g = torch.Generator().manual_seed(11)
+    m = 40000
+    x = (torch.rand(m, 3, generator=g) * 1.9 - 0.95).cuda()
+    gs = torch.randn(m, generator=g).cuda()
+    tiny = x[:, 0] < 0  # the left half of space: gradients 2^-60 of the right half's
+    gs = torch.where(tiny, gs * 2.0 ** -60, gs)
+    res = {}
+    for fused in (True, False):
+        net.fused_vm = fused
+        net.zero_grad(set_to_none=True)
+        (net.get_sigma_feat(x) * gs).sum().backward()
+        res[fused] = [p.grad.clone() for p in list(net.sigma_mat) + list(net.sigma_vec)]
+    net.fused_vm = True
+    # plane 0 spans (x, y): its columns at x < 0 see only the tiny gradients
+    a, b = res[True][0][0], res[False][0][0]            # [16, H(y), W(x)]
+    left = slice(0, 28)
+    assert float(b[:, :, left].abs().max()) < 2.0 ** -40 and float(b[:, :, left].abs().max()) > 0
+    nz = b[:, :, left] != 0
+    assert bool(((a[:, :, left] != 0) == nz).all()), "a cell that receives only vanishing gradients must still receive them"
+    # error relative to each cell's OWN sum of |terms| (a cell's value may cancel; its terms do not): the torch sequence on
+    # |parameters| with |gradients|
+    import copy
+    ab = copy.deepcopy(net)
+    ab.fused_vm = False
+    with torch.no_grad():
+        for p in ab.parameters():
+            p.abs_()
+    ab.zero_grad(set_to_none=True)
+    (ab.get_sigma_feat(x) * gs.abs()).sum().backward()
+    bd = ab.sigma_mat[0].grad[0][:, :, left]
+    rel = ((a[:, :, left] - b[:, :, left]).abs() / bd.clamp_min(1e-45))[nz]
+    assert float(rel.max()) < 1e-5, float(rel.max())
+    for a, b in zip(res[True], res[False]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-5 * float(b.abs().max()))
+
+
+def test_vm_backward_non_finite_inputs_raise_the_scaler_flag(hip):
+    """a non-finite upstream gradient / line factor: the bound words catch it where the gradient is written — `found_inf` is
+    raised (GradScaler skips the step, like the reference's unscale pass over the .grad tensors) and nothing hangs"""
+    import s3d_hip
+    net = _vm48(res=48)
+    g = torch.Generator().manual_seed(13)
+    m = 20000
+    x = (torch.rand(m, 3, generator=g) * 2 - 1).cuda()
+    for poison in ("grad", "line"):
+        flag = torch.zeros(1, device="cuda")
+        net._s3d_found_inf = flag
+        net.zero_grad(set_to_none=True)
+        gs = torch.randn(m, generator=g).cuda()
+        saved = net.sigma_vec[1].data[0, 3, 5, 0].clone()
+        if poison == "grad":
+            gs[777] = float("inf")
+        else:
+            net.sigma_vec[1].data[0, 3, 5, 0] = float("nan")
+        (net.get_sigma_feat(x) * gs).sum().backward()
+        torch.cuda.synchronize()
+        net.sigma_vec[1].data[0, 3, 5, 0] = saved
+        assert float(flag) == 1.0, poison
+    net._s3d_found_inf = None
+    flag = torch.zeros(1, device="cuda")
+    net._s3d_found_inf = flag
+    net.zero_grad(set_to_none=True)
+    (net.get_sigma_feat(x) * torch.randn(m, generator=g).cuda()).sum().backward()
+    assert float(flag) == 0.0 and all(torch.isfinite(p.grad).all() for p in list(net.sigma_mat) + list(net.sigma_vec))
