@@ -492,6 +492,18 @@ int s3d_seal_bbox_map(const float* points, const float* dirs, uint32_t M, const 
                       float* out_points, float* out_dirs, uint8_t* mask, const int32_t* n_valid /* padded sample batch: rows past it are skipped, or NULL */,
                       s3d_stream_t stream);
 
+/* Colour edit of the bbox tool applied to the samples the proxy moved — `rgbs[mask] = map_color(.., rgbs[mask])` of
+ * SealNeRF/renderer.py:316, 396-399 with seal_utils.py:48-58 (map_color), :739-769 (modify_hsv, modify_rgb) and
+ * color_utils.py:33-66 (rgb2hsv_torch / hsv2rgb_torch).  rgbs / out DEVICE [M,3] f32 or f16 (`dtype`; out may alias rgbs),
+ * mask DEVICE [M] u8 (s3d_seal_bbox_map's).  hsv: HOST [3] offsets added to (h, s, v), or NULL.  rgb_target: HOST [3] target
+ * colour or NULL — every moved sample takes the target's hue and saturation and the value
+ * clamp(target_v + (v_i - mean_moved(v)) + light_offset, 0, 1); the mean is taken over the moved rows of THIS call (a batch
+ * statistic, as in the reference) in `stats`, DEVICE 16 bytes (order-independent fixed-point sum + count; cleared by the call).
+ * With both, hsv is applied first and its RGB result converted again (the reference's two steps).  Rows where mask == 0 are
+ * copied. */
+int s3d_seal_map_color(const void* rgbs, const uint8_t* mask, uint32_t M, int dtype, const float* hsv, const float* rgb_target,
+                       float light_offset, void* out, void* stats, const int32_t* n_valid /* or NULL */, s3d_stream_t stream);
+
 /* ------------------------------------------------------------------ parameter update
  * The reference's update is torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15) under torch.cuda.amp.GradScaler
  * (nerf/utils.py:356-361, 495-537; main_SealNeRF.py:283-288).  These three calls are that update taken directly

@@ -96,6 +96,108 @@ __global__ void __launch_bounds__(256) k_seal_map(const float* __restrict__ poin
     }
 }
 
+
+// ---- colour edit of the bbox tool (seal_utils.py:48-58 map_color, :739-769 modify_hsv / modify_rgb, color_utils.py:33-66) ----
+// The renderers re-colour only the samples the proxy moved: `rgbs[mask] = map_color(.., rgbs[mask])` (SealNeRF/renderer.py:316,
+// 396-399) — in torch a boolean gather (host sync), ~40 elementwise launches with masked scatters, and a scatter back.  Here:
+// one pass for the `hsv` offsets alone; with an `rgb` target two passes, because each sample keeps its brightness offset from
+// the MEAN brightness of the moved samples of the batch (a batch statistic): k_seal_color_stats sums the (hsv-shifted) value
+// channel of the masked rows — as 64-bit fixed point 2^-32, so the sum does not depend on the order — then k_seal_color_apply.
+struct SealColor {
+    float hsv[3], target_hs[2], target_v, light;
+    uint32_t has_hsv, has_rgb;
+};
+__device__ __forceinline__ float floor_mod(float a, float m) { return a - m * floorf(a / m); }  // torch's `%` (remainder)
+__device__ __forceinline__ void rgb2hsv(float r, float g, float b, float& h, float& s, float& v) {
+    // color_utils.py:33-46: hue from the FIRST maximal channel (torch.max's tie rule), grey -> 0
+    const float cmax = fmaxf(r, fmaxf(g, b)), cmin = fminf(r, fminf(g, b)), delta = cmax - cmin;
+    const int idx = (r >= g && r >= b) ? 0 : (g >= b ? 1 : 2);
+    if (delta == 0.0f) h = 0.0f;
+    else if (idx == 0) h = floor_mod((g - b) / delta, 6.0f);
+    else if (idx == 1) h = (b - r) / delta + 2.0f;
+    else h = (r - g) / delta + 4.0f;
+    h = h / 6.0f;
+    s = cmax == 0.0f ? 0.0f : delta / cmax;
+    v = cmax;
+}
+__device__ __forceinline__ void hsv2rgb(float h, float s, float v, float& r, float& g, float& b) {
+    // color_utils.py:49-66: sextant = (h * 6) converted to uint8 (truncation, modulo 256), modulo 6
+    const float c = v * s;
+    const float x = c * (-fabsf(floor_mod(h * 6.0f, 2.0f) - 1.0f) + 1.0f);
+    const float m = v - c;
+    const uint32_t k = ((uint32_t)(int)truncf(fminf(fmaxf(h * 6.0f, -2.0e9f), 2.0e9f)) & 0xffu) % 6u;
+    r = k == 0 || k == 5 ? c : (k == 1 || k == 4 ? x : 0.0f);
+    g = k == 1 || k == 2 ? c : (k == 0 || k == 3 ? x : 0.0f);
+    b = k == 3 || k == 4 ? c : (k == 2 || k == 5 ? x : 0.0f);
+    r += m; g += m; b += m;
+}
+__global__ void k_seal_zero2(unsigned long long* w) { if (threadIdx.x < 2) w[threadIdx.x] = 0ull; }
+template <typename T> __device__ __forceinline__ float color_ld(const T* p) { return (float)*p; }
+template <typename T>
+__device__ __forceinline__ void shifted_hsv(const T* __restrict__ rgb, size_t i, const SealColor& c, float& h, float& s, float& v) {
+    float r = color_ld(rgb + i * 3), g = color_ld(rgb + i * 3 + 1), b = color_ld(rgb + i * 3 + 2);
+    rgb2hsv(r, g, b, h, s, v);
+    if (c.has_hsv) {
+        if (c.has_rgb) {  // the `rgb` step converts the hsv step's RGB result again
+            hsv2rgb(h + c.hsv[0], s + c.hsv[1], v + c.hsv[2], r, g, b);
+            rgb2hsv(r, g, b, h, s, v);
+        } else {
+            h += c.hsv[0]; s += c.hsv[1]; v += c.hsv[2];
+        }
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_seal_color_stats(const T* __restrict__ rgb, const uint8_t* __restrict__ mask, uint32_t M,
+                                                          SealColor c, const int32_t* __restrict__ n_valid,
+                                                          unsigned long long* __restrict__ stats) {
+    const uint32_t Mv = valid_rows(M, n_valid);
+    long long sum = 0;
+    uint32_t cnt = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < Mv; i += gridDim.x * 256) {
+        if (!mask[i]) continue;
+        float h, s, v;
+        shifted_hsv(rgb, i, c, h, s, v);
+        sum += (long long)rintf(fminf(fmaxf(v, -1.0e6f), 1.0e6f) * 1048576.0f);  // v * 2^20 (|v| <= 1e6: 2^40 per term, 2^32 terms fit)
+        cnt++;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_xor(sum, o, 64);
+        cnt += __shfl_xor(cnt, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicAdd(stats, (unsigned long long)sum);
+        atomicAdd(stats + 1, (unsigned long long)cnt);
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) k_seal_color_apply(const T* __restrict__ rgb, const uint8_t* __restrict__ mask, uint32_t M,
+                                                          SealColor c, const int32_t* __restrict__ n_valid,
+                                                          const unsigned long long* __restrict__ stats, T* __restrict__ out) {
+    const uint32_t Mv = valid_rows(M, n_valid);
+    float mean = 0.0f;
+    if (c.has_rgb) {
+        const long long sum = (long long)stats[0];
+        const unsigned long long cnt = stats[1];
+        mean = cnt ? (float)((double)sum / 1048576.0 / (double)cnt) : 0.0f;
+    }
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < Mv; i += gridDim.x * 256) {
+        if (!mask[i]) {
+            if (out != rgb) { out[(size_t)i * 3] = rgb[(size_t)i * 3]; out[(size_t)i * 3 + 1] = rgb[(size_t)i * 3 + 1]; out[(size_t)i * 3 + 2] = rgb[(size_t)i * 3 + 2]; }
+            continue;
+        }
+        float h, s, v, r, g, b;
+        shifted_hsv(rgb, i, c, h, s, v);
+        if (c.has_rgb) {
+            const float val = fminf(1.0f, fmaxf(0.0f, c.target_v + (v - mean) + c.light));
+            hsv2rgb(c.target_hs[0], c.target_hs[1], val, r, g, b);
+        } else {
+            hsv2rgb(h, s, v, r, g, b);
+        }
+        out[(size_t)i * 3] = (T)r; out[(size_t)i * 3 + 1] = (T)g; out[(size_t)i * 3 + 2] = (T)b;
+    }
+}
+
 }  // namespace
 }  // namespace s3d
 
@@ -132,4 +234,42 @@ S3D_EXPORT int s3d_seal_bbox_map(const float* points, const float* dirs, uint32_
     hipLaunchKernelGGL(k_seal_map, dim3(std::min<uint32_t>(div_up<uint32_t>(M, 256), 2048u)), dim3(256), 0, as_stream(stream), points, dirs, M, m, out_points,
                        out_dirs, mask, n_valid);
     return check_launch("seal_bbox_map");
+}
+
+S3D_EXPORT int s3d_seal_map_color(const void* rgbs, const uint8_t* mask, uint32_t M, int dtype, const float* hsv, const float* rgb_target,
+                                  float light_offset, void* out, void* stats, const int32_t* n_valid, s3d_stream_t stream) {
+    if (M == 0) return S3D_OK;
+    S3D_REQUIRE(rgbs && mask && out, "seal_map_color: null pointer");
+    S3D_REQUIRE(dtype == S3D_F32 || dtype == S3D_F16, "seal_map_color: dtype must be f32 or f16");
+    S3D_REQUIRE(hsv || rgb_target, "seal_map_color: neither an hsv offset nor an rgb target");
+    S3D_REQUIRE(!rgb_target || stats, "seal_map_color: the rgb edit needs the 16-byte statistics buffer");
+    SealColor c;
+    memset(&c, 0, sizeof(c));
+    if (hsv) { c.has_hsv = 1; for (int k = 0; k < 3; k++) c.hsv[k] = hsv[k]; }
+    if (rgb_target) {
+        // hue / saturation / value of the target colour (host: rgb2hsv of one triple, the device function's arithmetic)
+        const float r = rgb_target[0], g = rgb_target[1], b = rgb_target[2];
+        const float cmax = std::max(r, std::max(g, b)), cmin = std::min(r, std::min(g, b)), delta = cmax - cmin;
+        float h;
+        if (delta == 0.0f) h = 0.0f;
+        else if (r >= g && r >= b) { const float a = (g - b) / delta; h = a - 6.0f * floorf(a / 6.0f); }
+        else if (g >= b) h = (b - r) / delta + 2.0f;
+        else h = (r - g) / delta + 4.0f;
+        c.has_rgb = 1;
+        c.target_hs[0] = h / 6.0f;
+        c.target_hs[1] = cmax == 0.0f ? 0.0f : delta / cmax;
+        c.target_v = cmax;
+        c.light = light_offset;
+    }
+    hipStream_t st = as_stream(stream);
+    const dim3 grid(std::min<uint32_t>(div_up<uint32_t>(M, 256), 2048u)), block(256);
+    auto* sw = reinterpret_cast<unsigned long long*>(stats);
+    if (c.has_rgb) {
+        hipLaunchKernelGGL(k_seal_zero2, dim3(1), dim3(64), 0, st, sw);  // (a kernel, not a memset node: see tensorf.hip's bins)
+        if (dtype == S3D_F32) hipLaunchKernelGGL(k_seal_color_stats<float>, grid, block, 0, st, (const float*)rgbs, mask, M, c, n_valid, sw);
+        else hipLaunchKernelGGL(k_seal_color_stats<_Float16>, grid, block, 0, st, (const _Float16*)rgbs, mask, M, c, n_valid, sw);
+    }
+    if (dtype == S3D_F32) hipLaunchKernelGGL(k_seal_color_apply<float>, grid, block, 0, st, (const float*)rgbs, mask, M, c, n_valid, sw, (float*)out);
+    else hipLaunchKernelGGL(k_seal_color_apply<_Float16>, grid, block, 0, st, (const _Float16*)rgbs, mask, M, c, n_valid, sw, (_Float16*)out);
+    return check_launch("seal_map_color");
 }

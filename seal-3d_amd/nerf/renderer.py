@@ -187,13 +187,14 @@ class NeRFRenderer(nn.Module):
                 with s3d_hip.row_limit(counter, xyzs.shape[0]):
                     mxyzs, mdirs, mmask = self.map_samples(xyzs, dirs)
                     sigmas, rgbs = self(mxyzs, mdirs)
+                    rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)  # (the mask's rows behind the count were never written)
             else:
                 mxyzs, mdirs, mmask = self.map_samples(xyzs, dirs)
                 with s3d_hip.row_limit(counter, xyzs.shape[0]):
                     sigmas, rgbs = self(mxyzs, mdirs)
+                rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)
             if self.density_scale != 1:  # (x1 is the identity: skip the pass over [M])
                 sigmas = self.density_scale * sigmas
-            rgbs = self.map_colors(mxyzs, mdirs, rgbs, mmask)
             fused = kwargs.get("fused_loss")  # (nerf/trainer.py: the criterion and its gradient inside the compositing launch)
             if (fused is not None and kwargs.get("defer_background", False) and not torch.is_tensor(bg_color)
                     and sigmas.is_cuda and fused.get("expected_grad") is not None

@@ -42,7 +42,7 @@ EXPORTS = [
     "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_step_multi", "s3d_adam_advance", "s3d_scaler_update", "s3d_step_ring_push", "s3d_step_epilogue",
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_mid2_forward", "s3d_ngp_mid2_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
     "s3d_bg_mse_forward", "s3d_bg_mse_backward", "s3d_bg_targets", "s3d_l1_pair_workspace_size", "s3d_l1_pair_loss",
-    "s3d_seal_bbox_map", "s3d_vm_features_forward",
+    "s3d_seal_bbox_map", "s3d_seal_map_color", "s3d_vm_features_forward",
     "s3d_aabb_normalize", "s3d_weighted_abs_sum_workspace_size", "s3d_weighted_abs_sum", "s3d_pack_linear_chain", "s3d_unpack_linear_chain",
     "s3d_vm_backward_max_bins", "s3d_vm_backward_keys", "s3d_vm_backward_bins_workspace_size", "s3d_vm_backward_bins",
     "s3d_vm_features_backward", "s3d_vm_color_forward", "s3d_vm_color_backward",
@@ -975,6 +975,21 @@ class SealBackend:
         _check(lib().s3d_seal_bbox_map(_p(points), _p(dirs), _u(points.shape[0]), ptr[0], _u(keep[0][0].shape[0]), ptr[1],
                                        _u(keep[1][0].shape[0]), ptr[2], ptr[3], ptr[4], ptr[5], ptr[6], ptr[7], _p(out_points),
                                        _p(out_dirs), _p(mask), _nv(n_valid), _stream()), "seal_bbox_map")
+
+
+    @staticmethod
+    def map_color(rgbs, mask, hsv, rgb_target, light_offset, out, stats=None, n_valid=None):
+        """colour edit of the moved samples (include/seal3d_hip.h: s3d_seal_map_color); `hsv` / `rgb_target`: 3 floats or None"""
+        if rgbs.dtype not in (torch.float32, torch.float16) or out.dtype != rgbs.dtype or not rgbs.is_contiguous() or not out.is_contiguous():
+            raise RuntimeError("map_color: contiguous f32 / f16 colours")
+        if mask.dtype != torch.uint8:
+            raise RuntimeError("mask must be uint8")
+        h = (C.c_float * 3)(*[float(v) for v in hsv]) if hsv is not None else None
+        t = (C.c_float * 3)(*[float(v) for v in rgb_target]) if rgb_target is not None else None
+        if t is not None and stats is None:
+            stats = torch.empty(2, dtype=torch.int64, device=rgbs.device)
+        _check(lib().s3d_seal_map_color(_p(rgbs), _p(mask), _u(rgbs.shape[0]), C.c_int(_dt(rgbs)), h, t, C.c_float(float(light_offset)),
+                                        _p(out), _p(stats), _nv(n_valid), _stream()), "seal_map_color")
 
 
 def _zeros_like_many(tensors, words=0):

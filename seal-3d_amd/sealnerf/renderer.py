@@ -64,11 +64,12 @@ class SealTeacherMixin:
         """nerf/renderer.py: may run_cuda skip the zero fills of the sample buffers?  Yes without a proxy (student), and with
         the native bbox mapper too: it takes the device-side sample count like every other per-sample kernel (rows behind
         the count are neither read nor written; the marcher keeps the pad rows up to the next 128 zero, the mapper maps them).
-        A colour edit (`map_color`: torch ops over whole tensors) keeps the conservative path."""
+        The bbox tool's colour edit runs on the device with the same count (csrc/seal.hip: s3d_seal_map_color); the brush
+        tool's image remap (torch ops over whole tensors) would keep the conservative path."""
         if self.seal_mapper is None or not self.proxy_enabled:
             return True
         m = self.seal_mapper
-        return bool(getattr(m, "native", False)) and "hsv" not in m.map_data and "rgb" not in m.map_data
+        return bool(getattr(m, "native", False)) and "image" not in m.map_data
 
     def _batch_dependent_colors(self):
         return self.seal_mapper is not None and self.proxy_enabled and "rgb" in self.seal_mapper.map_data

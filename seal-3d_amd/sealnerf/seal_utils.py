@@ -296,12 +296,26 @@ class SealBBoxMapper:
     def map_color_masked(self, points, dirs, colors, mask):
         """the renderers' use of map_color (SealNeRF/renderer.py:316, 396-399): `colors[mask] = map_color(points[mask],
         dirs[mask], colors[mask])` — returns a new tensor, `colors` is left alone"""
+        md = self.map_data
+        if (self.native and colors.is_cuda and mask is not None and colors.dtype in (torch.float32, torch.float16) and colors.dim() == 2
+                and colors.shape[1] == 3 and "image" not in md and ("hsv" in md or "rgb" in md)):
+            # one or two passes on the device (csrc/seal.hip: s3d_seal_map_color) instead of a boolean gather (host sync), ~40
+            # masked elementwise launches and a scatter back; the batch mean of the `rgb` edit is an order-independent sum
+            import s3d_hip
+            src = colors.contiguous()
+            out = torch.empty_like(src)
+            hsv = md["hsv"].tolist() if "hsv" in md else None
+            tgt = md["rgb"].tolist() if "rgb" in md else None
+            s3d_hip.SealBackend.map_color(src, mask.view(torch.uint8), hsv, tgt, md.get("rgb_light_offset", 0) if tgt is not None else 0.0,
+                                          out, n_valid=s3d_hip.active_row_limit(src.shape[0]))
+            return out
         out = colors.clone()
         if mask is None:
             return self.map_color(points, dirs, out)
         sel = colors[mask]
         if sel.shape[0]:
-            out[mask] = self.map_color(points[mask], dirs[mask] if dirs is not None else None, sel.float()).to(colors.dtype)
+            out[mask] = self.map_color(points[mask] if points is not None else None, dirs[mask] if dirs is not None else None,
+                                       sel.float()).to(colors.dtype)
         return out
 
 

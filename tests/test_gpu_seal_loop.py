@@ -120,3 +120,37 @@ def test_proxy_truth_and_provider_vs_reference(hip, G):
     assert np.array_equal(batch["pixel_index"].cpu().numpy(), G["pd_collate_inds"])
     for k in ("images", "depths", "rays_o", "rays_d"):
         assert relmax(batch[k].cpu(), G[f"pd_collate_{k}"]) < 1e-4, k
+
+
+@pytest.mark.parametrize("name", ["hsv", "rgb", "both"])
+def test_map_color_kernel_vs_reference_map_color(hip, name):
+    """csrc/seal.hip s3d_seal_map_color vs the reference's `map_color` EXECUTED on seeded colours (tests/golden/seal_bbox.npz:
+    greys, pure channels, channel ties, hue wrap-around) — all rows moved; then a partial mask against the torch route
+    (`colors[mask] = map_color(colors[mask])`: the batch mean of the `rgb` edit is the moved rows' alone), fp32 and fp16"""
+    import os
+    from conftest import GOLDEN
+    from sealnerf import SealBBoxMapper
+    from test_seal import BBOX
+    S = np.load(os.path.join(GOLDEN, "seal_bbox.npz"))
+    opts = S[f"color_{name}_opts"]
+    cfg = dict(BBOX)
+    if not np.isnan(opts[0]).any():
+        cfg["hsv"] = opts[0].tolist()
+    if not np.isnan(opts[1]).any():
+        cfg["rgb"], cfg["rgbLightOffset"] = opts[1].tolist(), float(opts[2][0])
+    mapper = SealBBoxMapper(cfg)
+    cols = torch.from_numpy(S["color_in"]).cuda()
+    every = torch.ones(cols.shape[0], dtype=torch.bool, device="cuda")
+    mapper.native = True
+    out = mapper.map_color_masked(None, None, cols, every)
+    ref = S[f"color_{name}"]
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-6, float(np.abs(out.cpu().numpy() - ref).max())
+    g = torch.Generator().manual_seed(3)
+    part = (torch.rand(cols.shape[0], generator=g) < 0.4).cuda()
+    a = mapper.map_color_masked(None, None, cols, part)
+    mapper.native = False
+    b = mapper.map_color_masked(None, None, cols, part)
+    mapper.native = True
+    assert torch.equal(a[~part], cols[~part]) and float((a - b).abs().max()) < 2e-6
+    h = mapper.map_color_masked(None, None, cols.half(), part)
+    assert h.dtype == torch.float16 and float((h.float() - b).abs().max()) < 4e-3
