@@ -241,6 +241,34 @@ int s3d_grid_encode_backward(const void* grad, const float* inputs, const void* 
                              float bound, const int32_t* n_valid, int path, float* found_inf,
                              void* control, size_t control_bytes, s3d_stream_t stream);
 
+/* Build extension: the backward of a table WITH its parameter update (single replica, fp16 C = 2 tables).  The binned path's
+ * accumulate kernel holds every row's gradient sum in registers at its write-out; given the optimizer's state it applies
+ * torch.optim.Adam's update (betas, eps as passed; the reference: main_SealNeRF.py:283-288) there — fp32 master row, both
+ * moments and the fp16 copy the next forward reads — for EVERY row of the table (rows without records take g = 0), and the
+ * gradient table is neither written nor read: the separate update's 30 B per parameter become 26 B, overlapped with the
+ * records' streaming.  The row's gradient is the exact sum rounded to binary16 (what the unfused path stores), so both routes
+ * update to the same bits; where that rounding would overflow the fp32 sum is used.  GradScaler: `found_inf` must hold the
+ * step's decision so far when the call is issued (every other gradient producer of the step has run: the table's backward is
+ * the last node of the graph); a non-finite dL/dy seen by this call's scatter raises it and skips the update as a whole.
+ * step / grad_scale / lr_scale: device floats (step count BEFORE this update; loss scale or NULL; schedule factor or NULL).
+ * *applied (host) = 1 when the update was made here; 0 when the call fell back to the plain backward (direct-atomics sizes,
+ * more than one level pass, other dtypes): grad_embeddings then holds the gradient and the caller's optimizer applies it. */
+typedef struct s3d_grid_adam {
+    float* param;
+    float* exp_avg;
+    float* exp_avg_sq;
+    void* param_half; /* fp16 [rows, C] or NULL */
+    float lr, beta1, beta2, eps;
+    const float* step;
+    const float* grad_scale;
+    const float* lr_scale;
+} s3d_grid_adam;
+int s3d_grid_encode_backward_adam(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                  void* grad_embeddings, uint32_t max_level_rows, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                  float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                  void* workspace, size_t workspace_bytes, float bound, const int32_t* n_valid, float* found_inf,
+                                  void* control, size_t control_bytes, const s3d_grid_adam* adam, int* applied, s3d_stream_t stream);
+
 /* gridencoder.h:15 void grad_total_variation(inputs, embeddings, grad, offsets, weight, B, D, C, L, S, H,
  *                        gridtype, align_corners) — fp32 only (grid.py:162 disables autocast) */
 int s3d_grad_total_variation(const float* inputs, const float* embeddings, float* grad,

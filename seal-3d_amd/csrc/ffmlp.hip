@@ -1335,10 +1335,23 @@ __device__ unsigned long long s3d_ffmlp_prof[2][1024];
 // LDS; its partner keeps the weight-gradient accumulators (192 registers) and consumes the tiles one stage behind, through a
 // double-buffered slot and one workgroup barrier per stage.  Two waves of <= 256 registers per SIMD: the matrix pipe, the VALU
 // and the LDS overlap across the pair.  Same per-wave tile sequence, same MFMA order per accumulator: bit-identical results.
-// NP = pairs per workgroup: 4, or 6 where the registers allow three waves per SIMD (the density network: 150 registers) — a third
-// more waves in flight behind the same weights in LDS.
-template <int W, int NH, int IMB, int ACT, int KS0T, int NP = 4>
-__global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16* __restrict__ grad, const _Float16* __restrict__ X,
+// NC compute waves and NG weight-gradient waves per workgroup (NC a multiple of NG): weight-gradient wave g consumes the tiles
+// of the compute waves g, g + NG, ... in that order, one stage behind each.  Deterministic; the sums differ from the (NC = NG)
+// arrangement only in the order the tiles of a workgroup enter an accumulator.
+// The stage barriers of the two-role kernel order LDS traffic only (tile slots): a __syncthreads() would also drain every wave's
+// vector-memory queue — the input-gradient stores of a tile's last stage and the next tile's input loads — at each of the NS + 1
+// barriers of a round.  S3D_DUO_FULL_BARRIER: the old behaviour (A/B).
+__device__ __forceinline__ void duo_barrier() {
+#ifdef S3D_DUO_FULL_BARRIER
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#endif
+}
+template <int W, int NH, int IMB, int ACT, int KS0T, int NC = 4, int NG = 4>
+__global__ void __launch_bounds__((NC + NG) * 64) k_ffmlp_backward_duo(const _Float16* __restrict__ grad, const _Float16* __restrict__ X,
                                                             const _Float16* __restrict__ Wt, uint32_t B, uint32_t in_dim,
                                                             uint32_t out_dim, uint32_t act, _Float16* __restrict__ grad_inputs,
                                                             float* __restrict__ partial, uint32_t in_layout,
@@ -1349,7 +1362,10 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t role = wave / NP, pair = wave % NP;  // role 0: compute, 1: weight gradient
+    static_assert(NC % NG == 0, "every weight-gradient wave serves the same number of compute waves");
+    constexpr uint32_t NR = NC / NG;  // compute waves (tile streams) per weight-gradient wave
+    const uint32_t role = wave < (uint32_t)NC ? 0u : 1u;  // 0: compute, 1: weight gradient
+    const uint32_t pair = role == 0 ? wave : wave - (uint32_t)NC;  // compute wave c / weight-gradient wave g (serves c = g + j NG)
     const uint32_t n = lane & 31, h = lane >> 5;
     const uint32_t KS0 = KS0T ? (uint32_t)KS0T : in_dim / 16;
     const uint32_t nf_f0 = MB * KS0, nf_fh = NH * MB * KS;
@@ -1367,11 +1383,11 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
     half8* fb0 = fbh + (size_t)nf_bh * 64;
     _Float16* tiles = reinterpret_cast<_Float16*>(frags + (size_t)nfrag * 64);
     constexpr uint32_t kTile = kTRows * kTRow;
-    _Float16* slots = tiles + (size_t)pair * 4 * kTile;  // [slot 0: TG | TX][slot 1: TG | TX]
+    // per COMPUTE wave: [slot 0: TG | TX][slot 1: TG | TX]
     const _Float16* w_hid = Wt + (size_t)W * in_dim;
     const _Float16* w_last = w_hid + (size_t)NH * W * W;
 
-    for (uint32_t f = wave; f < nfrag; f += 2 * NP) {
+    for (uint32_t f = wave; f < nfrag; f += NC + NG) {
         half8 v;
         if (f < nf_f0) {  // forward, layer 0: A[row = hidden feature][k = input]
             const uint32_t mblk = f / KS0, s = f % KS0;
@@ -1409,15 +1425,15 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
     // tiles of this pair: blockIdx.x * 4 + pair + i * gridDim.x * 4; every wave of the workgroup runs `nit` rounds of NS
     // stages plus one draining stage, whatever its own tile count (the barriers are workgroup-wide)
     const uint32_t ntiles = valid_rows(B, n_valid) / 32;
-    const uint32_t first = blockIdx.x * NP, stride = gridDim.x * NP;
-    const uint32_t nit = ntiles > first ? (ntiles - first - 1) / stride + 1 : 0;  // rounds of pair 0 (the most)
-    auto tile_of = [&](uint32_t i) { return first + pair + i * stride; };
-    auto slot_of = [&](uint32_t i, uint32_t st) { return slots + (size_t)((i * NS + st) & 1u) * 2 * kTile; };
+    const uint32_t first = blockIdx.x * NC, stride = gridDim.x * NC;
+    const uint32_t nit = ntiles > first ? (ntiles - first - 1) / stride + 1 : 0;  // rounds of compute wave 0 (the most)
+    auto tile_of = [&](uint32_t c, uint32_t i) { return first + c + i * stride; };
+    auto slot_of = [&](uint32_t c, uint32_t i, uint32_t st) { return tiles + (size_t)c * 4 * kTile + (size_t)((i * NS + st) & 1u) * 2 * kTile; };
 
     if (role == 0) {
         // =============================================================== compute wave
         for (uint32_t i = 0; i < nit; i++) {
-            const uint32_t tile = tile_of(i);
+            const uint32_t tile = tile_of(pair, i);
             const bool live = tile < ntiles;
             const size_t row = (size_t)(live ? tile : 0) * 32 + n;
             half8 xf[4];
@@ -1485,7 +1501,7 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
                 }
                 DUO_STAMP();  // 2: forward re-computed
                 // stage 0: tiles of the last layer, then through it
-                _Float16* T = slot_of(i, 0);
+                _Float16* T = slot_of(pair, i, 0);
                 const half8 gtmp[1] = {gf};
                 transpose_store<1>(T, gtmp, 1, n, h);
                 transpose_store<(int)KS>(T + kTile, a[NH], KS, n, h);
@@ -1493,7 +1509,7 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
                 for (uint32_t m = 0; m < MB; m++) acc[m] = mfma(fbl[m * 64 + lane], gf, zero16());
             }
             DUO_STAMP();  // 3: stage 0 produced
-            __syncthreads();
+            duo_barrier();
             DUO_STAMP();  // 4: past the barrier
 #pragma unroll
             for (int k = NH; k >= 0; k--) {
@@ -1518,7 +1534,7 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
                                 }
                             }
                         }
-                    _Float16* T = slot_of(i, st);
+                    _Float16* T = slot_of(pair, i, st);
                     transpose_store<(int)KS>(T, G, KS, n, h);
                     if (k > 0) {
                         transpose_store<(int)KS>(T + kTile, a[k - 1], KS, n, h);
@@ -1552,11 +1568,11 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
                     }
                 }
                 DUO_STAMP();  // 5 + 2j: stage produced
-                __syncthreads();
+                duo_barrier();
                 DUO_STAMP();  // 6 + 2j: past the barrier
             }
         }
-        if (nit) __syncthreads();  // the partner's draining stage
+        if (nit) duo_barrier();  // the partner's draining stage
     } else {
         // =============================================================== weight-gradient wave
         float16v dw0[MB][IMB], dwh[NH > 0 ? NH : 1][MB][MB], dwl[MB];
@@ -1573,8 +1589,11 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
         // stage st of round i is consumed while the partner produces the next one: one barrier behind
         auto consume = [&](uint32_t i, auto stc) {
             constexpr uint32_t st = decltype(stc)::value;
-            if (tile_of(i) >= ntiles) return;
-            const _Float16* T = slot_of(i, st);
+#pragma unroll 1
+            for (uint32_t j = 0; j < NR; j++) {
+            const uint32_t cw = pair + j * (uint32_t)NG;  // (fixed order over the served compute waves: deterministic sums)
+            if (tile_of(cw, i) >= ntiles) continue;
+            const _Float16* T = slot_of(cw, i, st);
             const _Float16* TXs = T + kTile;
             if constexpr (st == 0) {
 #pragma unroll
@@ -1611,39 +1630,40 @@ __global__ void __launch_bounds__(NP * 128) k_ffmlp_backward_duo(const _Float16*
                     }
                 }
             }
+            }
         };
         for (uint32_t i = 0; i < nit; i++) {
             DUO_STAMP();
             if (i > 0) consume(i - 1, std::integral_constant<uint32_t, NS - 1>{});
             DUO_STAMP();
-            __syncthreads();
+            duo_barrier();
             static_for<NS - 1>([&](auto stc) {
                 DUO_STAMP();
                 consume(i, stc);
                 DUO_STAMP();
-                __syncthreads();
+                duo_barrier();
             });
         }
         if (nit) {
             consume(nit - 1, std::integral_constant<uint32_t, NS - 1>{});
-            __syncthreads();
+            duo_barrier();
         }
         // ---- sum the four weight-gradient waves in a fixed order through LDS (all 512 threads add), one partial per matrix
         float* red = reinterpret_cast<float*>(smem_raw);
-        flush_matrix<MB, IMB, NP * 128, NP>(red, partial, 0, pair, n, h, [&](auto mo, auto ni) { return dw0[mo][ni]; });
+        flush_matrix<MB, IMB, (NC + NG) * 64, NG>(red, partial, 0, pair, n, h, [&](auto mo, auto ni) { return dw0[mo][ni]; });
 #pragma unroll
         for (uint32_t k = 0; k < (uint32_t)NH; k++)
-            flush_matrix<MB, MB, NP * 128, NP>(red, partial, 1 + k, pair, n, h, [&](auto mo, auto ni) { return dwh[k][mo][ni]; });
-        flush_matrix<1, MB, NP * 128, NP>(red, partial, NH + 1, pair, n, h, [&](auto mo, auto ni) { (void)mo; return dwl[ni]; });
+            flush_matrix<MB, MB, (NC + NG) * 64, NG>(red, partial, 1 + k, pair, n, h, [&](auto mo, auto ni) { return dwh[k][mo][ni]; });
+        flush_matrix<1, MB, (NC + NG) * 64, NG>(red, partial, NH + 1, pair, n, h, [&](auto mo, auto ni) { (void)mo; return dwl[ni]; });
         return;
     }
     // compute waves: the same barriers as the flushes above, and their share of the sums
     float* red = reinterpret_cast<float*>(smem_raw);
     const float16v none = zero16();
-    flush_matrix<MB, IMB, NP * 128, NP>(red, partial, 0, NP + pair, n, h, [&](auto, auto) { return none; });
+    flush_matrix<MB, IMB, (NC + NG) * 64, NG>(red, partial, 0, NG + pair, n, h, [&](auto, auto) { return none; });
 #pragma unroll
-    for (uint32_t k = 0; k < (uint32_t)NH; k++) flush_matrix<MB, MB, NP * 128, NP>(red, partial, 1 + k, NP + pair, n, h, [&](auto, auto) { return none; });
-    flush_matrix<1, MB, NP * 128, NP>(red, partial, NH + 1, NP + pair, n, h, [&](auto, auto) { return none; });
+    for (uint32_t k = 0; k < (uint32_t)NH; k++) flush_matrix<MB, MB, (NC + NG) * 64, NG>(red, partial, 1 + k, NG + pair, n, h, [&](auto, auto) { return none; });
+    flush_matrix<1, MB, (NC + NG) * 64, NG>(red, partial, NH + 1, NG + pair, n, h, [&](auto, auto) { return none; });
 }
 
 constexpr uint32_t kWgradBlocks = 256;
@@ -1774,37 +1794,65 @@ int launch_backward_fused_k(const _Float16* grad, const _Float16* X, const _Floa
                             uint32_t out_dim, uint32_t act, _Float16* grad_inputs, _Float16* grad_weights, float* partial,
                             uint32_t in_layout, uint32_t accumulate, hipStream_t st) {
     constexpr uint32_t MB = W / 32, KS = W / 16;
-#ifndef S3D_DUO_PAIRS_LIGHT
-#define S3D_DUO_PAIRS_LIGHT 6
-#endif
-    // (the density network of the BASELINE configs — 32 -> 64 -> 64 -> 16, ReLU — needs 150 registers: six pairs = three waves per SIMD)
-    constexpr uint32_t NP = (W == 64 && NH == 1 && IMB == 1 && KS0T == 2 && ACT == ACT_RELU) ? S3D_DUO_PAIRS_LIGHT : 4;
+    // Wave mix of the two-role kernel, (compute waves, weight-gradient waves) per workgroup.  The compute wave of a 32-row tile
+    // is 3.5x the work of its weight-gradient partner (profiles/r10_mlp_backward.md: 8.2 k against 2.3 k ticks per round), so one
+    // weight-gradient wave serves THREE compute waves: 6 + 2 waves of <= 256 registers, two per SIMD, six tile streams per CU
+    // behind the same weights in LDS (18 KiB of tile slots per stream).  Measured at 269,824 rows (profiles/r11_mlp_backward.md):
+    // colour network 48.0 -> 45.5 us, density network 37.5 - 38.8 (six pairs) -> 36.9 us; 6 + 3 and 6 + 6 within noise of 6 + 2,
+    // seven pairs 57 us (three waves per SIMD no longer fit the registers).  S3D_DUO_MIX / S3D_DUO_MIX_LIGHT = 4x4: round 5's pairs.
+    constexpr bool light = W == 64 && NH == 1 && IMB == 1 && KS0T == 2 && ACT == ACT_RELU;
     const uint32_t nfrag = MB * (in_dim / 16) + NH * MB * KS + MB + NH * MB * KS + (grad_inputs ? IMB * KS : 0);
     static const bool duo = [] { const char* e = getenv("S3D_FFMLP_DUO"); return !(e && e[0] == '0'); }();  // A/B switch
-    const uint32_t np = duo ? NP : 4u;  // tile owners per workgroup
-    size_t smem = (size_t)nfrag * 64 * sizeof(half8) + (size_t)np * 2 * kTRows * kTRow * sizeof(_Float16);
-    if (duo) smem += (size_t)np * 2 * kTRows * kTRow * sizeof(_Float16);  // second tile slot per pair
-    if (smem < np * kWgradPad * kWgradPad * sizeof(float)) smem = np * kWgradPad * kWgradPad * sizeof(float);  // epilogue planes
-    static std::atomic<uint64_t> attr_devs{0};
-    int dev;
-    if (device_needs_setup(attr_devs, &dev)) {
-        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_backward_fused<W, NH, IMB, ACT, KS0T>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_backward_duo<W, NH, IMB, ACT, KS0T, NP>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        device_setup_done(attr_devs, dev);
-    }
+    static const int mix = [] {
+        const char* e = getenv(light ? "S3D_DUO_MIX_LIGHT" : "S3D_DUO_MIX");
+        unsigned c = 0, g = 0;
+        if (e && sscanf(e, "%ux%u", &c, &g) == 2) return (int)(c * 16 + g);
+        return 6 * 16 + 2;
+    }();
     const uint32_t ntiles = B / 32;
     // (four tile owners per workgroup decide the partial count whatever the kernel: s3d_ffmlp_wgrad_reduce_pair derives the
-    //  layout of a deferred reduce from B alone; a six-pair workgroup of a small batch simply has idle pairs)
+    //  layout of a deferred reduce from B alone; a workgroup of a small batch simply has idle streams)
     uint32_t nblk = div_up<uint32_t>(ntiles, 4);
     if (nblk > kWgradBlocks) nblk = kWgradBlocks;
-    if (duo)
-        hipLaunchKernelGGL((k_ffmlp_backward_duo<W, NH, IMB, ACT, KS0T, NP>), dim3(nblk), dim3(NP * 128), smem, st, grad, X, Wt, B, in_dim,
+    auto smem_for = [&](uint32_t owners, uint32_t slots, uint32_t planes) {
+        size_t v = (size_t)nfrag * 64 * sizeof(half8) + (size_t)owners * slots * 2 * kTRows * kTRow * sizeof(_Float16);
+        if (v < planes * kWgradPad * kWgradPad * sizeof(float)) v = planes * kWgradPad * kWgradPad * sizeof(float);  // epilogue planes
+        return v;
+    };
+    auto run_duo = [&](auto ncc, auto ngc) -> int {
+        constexpr int NCv = decltype(ncc)::value, NGv = decltype(ngc)::value;
+        const size_t smem = smem_for(NCv, 2, NGv);
+        S3D_REQUIRE(smem <= 160 * 1024, "ffmlp_backward: wave mix %dx%d needs %zu bytes of LDS", NCv, NGv, smem);
+        static std::atomic<uint64_t> attr_devs{0};
+        int dev;
+        if (device_needs_setup(attr_devs, &dev)) {
+            S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_backward_duo<W, NH, IMB, ACT, KS0T, NCv, NGv>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            device_setup_done(attr_devs, dev);
+        }
+        hipLaunchKernelGGL((k_ffmlp_backward_duo<W, NH, IMB, ACT, KS0T, NCv, NGv>), dim3(nblk), dim3((NCv + NGv) * 64), smem, st, grad, X, Wt,
+                           B, in_dim, out_dim, act, grad_inputs, partial, in_layout, t_n_valid, t_d_rgb, t_rgb_in, t_mid_bwd);
+        return S3D_OK;
+    };
+    using std::integral_constant;
+    if (duo) {
+        int rc;
+        switch (mix) {
+            case 4 * 16 + 4: rc = run_duo(integral_constant<int, 4>{}, integral_constant<int, 4>{}); break;  // (round 5's pairs: A/B)
+            default: rc = run_duo(integral_constant<int, 6>{}, integral_constant<int, 2>{}); break;
+        }
+        if (rc) return rc;
+    } else {
+        static std::atomic<uint64_t> attr_devs{0};
+        int dev;
+        if (device_needs_setup(attr_devs, &dev)) {
+            S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ffmlp_backward_fused<W, NH, IMB, ACT, KS0T>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            device_setup_done(attr_devs, dev);
+        }
+        hipLaunchKernelGGL((k_ffmlp_backward_fused<W, NH, IMB, ACT, KS0T>), dim3(nblk), dim3(256), smem_for(4, 1, 4), st, grad, X, Wt, B, in_dim,
                            out_dim, act, grad_inputs, partial, in_layout, t_n_valid, t_d_rgb, t_rgb_in, t_mid_bwd);
-    else
-        hipLaunchKernelGGL((k_ffmlp_backward_fused<W, NH, IMB, ACT, KS0T>), dim3(nblk), dim3(256), smem, st, grad, X, Wt, B, in_dim,
-                           out_dim, act, grad_inputs, partial, in_layout, t_n_valid, t_d_rgb, t_rgb_in, t_mid_bwd);
+    }
     WgradPlan plan;
     memset(&plan, 0, sizeof(plan));
     plan.n = NH + 2;

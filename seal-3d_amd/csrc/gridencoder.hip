@@ -18,6 +18,7 @@
 //  * Backward: direct atomics for small batches; for training-size batches the contributions are partitioned by
 //    table slice and summed in LDS as 64-bit fixed point (see "binned backward" below): deterministic, no global atomics.
 #include "s3d_common.hpp"
+#include "s3d_adam.hpp"
 #include <math.h>
 #include <type_traits>
 #include <algorithm>
@@ -1532,7 +1533,26 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
 // The kernel also leaves the control block the way it found it (all zero): every item clears its cursors and its spill
 // count after reading them, and the last workgroup to finish (ticket) clears the levels' header words — the caller's next
 // call needs no clearing launch.
-template <typename T, uint32_t D, uint32_t C, bool FIXED24, uint32_t P>
+// ADAM (build extension, s3d_grid_encode_backward_adam): the table's parameter update applied where the row sums are —
+// the write-out walks EVERY row of the item's slice (rows without records take g = 0: Adam moves them on their moments, as
+// torch.optim.Adam on a dense gradient does) and runs the optimizer's own update arithmetic (s3d_adam.hpp) on the fp32 master
+// row, its two moments and the fp16 copy the next forward reads.  The gradient table is neither read nor written.  The row's
+// gradient is the exact sum rounded to binary16 — the value the unfused path stores and the optimizer reads back, so both routes
+// give the same bits — except where that rounding would overflow: then the fp32 sum is used (the unfused path raises
+// GradScaler's flag there; this kernel cannot, rows of other items have been written by then).  The skip decision of the step
+// is taken BEFORE the first row is touched: the flag other producers of the step raised (MLP reduce, ...) and the poison words
+// of every level of this call (a non-finite dL/dy seen by the scatter).
+struct GridAdam {
+    float* p;      // fp32 master table [rows, C]
+    float* m;      // exp_avg
+    float* v;      // exp_avg_sq
+    __half* ph;    // fp16 copy of p (or nullptr)
+    float lr, beta1, beta2, eps;
+    const float* step;        // device: step count before this update
+    const float* grad_scale;  // device: loss scale (or nullptr)
+    const float* lr_scale;    // device: schedule factor (or nullptr)
+};
+template <typename T, uint32_t D, uint32_t C, bool FIXED24, uint32_t P, bool ADAM = false>
 __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate6(const uint16_t* __restrict__ gkeys, const uint32_t* __restrict__ gvals,
                                                                    const uint16_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
                                                                    const int32_t* __restrict__ offsets, T* __restrict__ grad_grid,
@@ -1540,8 +1560,9 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate6(const uint16
                                                                    uint32_t* __restrict__ done, uint32_t* __restrict__ cursor,
                                                                    uint32_t* __restrict__ ovn, const uint2* __restrict__ ovl,
                                                                    uint32_t smax, uint32_t nchunks, uint32_t cap,
-                                                                   float* __restrict__ found_inf) {
+                                                                   float* __restrict__ found_inf, const GridAdam ad) {
     using V = typename FeatVec<T, C>::type;
+    static_assert(!ADAM || (FIXED24 && sizeof(T) == 2 && C == 2), "the fused update is built for the fp16 C = 2 tables of the -O configs");
     static_assert(sizeof(V) == 4, "records carry one 32-bit value word");
     constexpr uint32_t K = 1u << D;
     constexpr uint32_t NS = kBin3Sub;
@@ -1557,6 +1578,16 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate6(const uint16
     bool overflow = false;  // a finite sum that leaves the range of T (fp16: |v| > 65504) — what GradScaler looks for
     bool dirty = true;      // accumulators not known to be zero (first item)
     uint32_t it_no = 0;
+    bool ad_skip = false;
+    AdamCoef ac{};
+    if constexpr (ADAM) {
+        ad_skip = found_inf && *found_inf != 0.0f;
+        bool pois = false;
+        for (uint32_t l = 0; l < nl; l++) pois |= hdr[level0 + l] >= 0x7f800000u;  // (uniform: scalar loads)
+        if (pois && found_inf && threadIdx.x == 0) *found_inf = 1.0f;              // (benign race: everyone writes 1)
+        ad_skip |= pois;
+        ac = adam_coef(ad.lr, ad.beta1, ad.beta2, ad.eps, 0.0f, ad.step, ad.grad_scale, ad.lr_scale);
+    }
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x, it_no++) {
         const uint32_t lip = item / smax, slice = item - lip * smax;  // level inside the pass
         const uint32_t level = level0 + lip;
@@ -1588,6 +1619,109 @@ __global__ void __launch_bounds__(kBinAccThreads) k_bin_accumulate6(const uint16
             __syncthreads();
             if (threadIdx.x < NS) cur_w[threadIdx.x * kCurStride] = 0u;
             if (threadIdx.x == NS) ovn[level * smax + slice] = 0u;
+        }
+        if constexpr (ADAM) {
+            if (ad_skip) continue;  // skipped step: nothing is updated (the control words above are clean again)
+            const bool stream_it = touched;
+            const uint32_t cj_a = cj < cap ? cj : cap;
+            const uint32_t nquads_a = (cj_a + 3) / 4;
+            const size_t base_a = (((size_t)lip * smax + slice) * NS + sj) * cap;
+            auto add_a = [&](auto small_c, uint32_t key, uint32_t bits) {
+                T pr[C];
+                __builtin_memcpy(pr, &bits, 4);
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) {
+                    const float vv = Acc<T>::to_f(pr[c]);
+                    long long q;
+                    if constexpr (decltype(small_c)::value) q = (long long)(int)(vv * 16777216.0f);
+                    else q = fixed24_exact(vv);
+                    atomicAdd(&acc[c * local_rows + key], (unsigned long long)q);
+                }
+            };
+            // the optimizer state of EVERY row of the slice (8 rows per lane: 48 registers) is requested before the records are
+            // streamed: the LDS-bound streaming phase hides the 24 B per parameter of reads, the write-out is arithmetic + stores
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            float* Pm = ad.p + (size_t)off * C;
+            float* Mm = ad.m + (size_t)off * C;
+            float* Vm = ad.v + (size_t)off * C;
+            __half* Hm = ad.ph ? ad.ph + (size_t)off * C : nullptr;
+            constexpr uint32_t WA = kBinAccBytes / (8 * C) / kBinAccThreads;  // rows per lane: the whole slice in one round
+            static_assert(WA * kBinAccThreads * 8 * C == kBinAccBytes && WA <= 8, "a slice is WA rows per lane");
+            f2v pv[WA], mv[WA], vv[WA];
+            uint32_t rowi[WA];
+#pragma unroll
+            for (uint32_t w = 0; w < WA; w++) {
+                const uint32_t rr = threadIdx.x + w * kBinAccThreads;
+                const uint32_t row = rr < local_rows ? row_of_local(rr) : 0xffffffffu;
+                rowi[w] = row < rows ? row : 0xffffffffu;
+            }
+            auto request_state = [&](uint32_t w) {  // (w is a compile-time index at every call site: the arrays stay in registers)
+                if (rowi[w] != 0xffffffffu) {
+                    pv[w] = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(Pm + (size_t)rowi[w] * C));
+                    mv[w] = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(Mm + (size_t)rowi[w] * C));
+                    vv[w] = __builtin_nontemporal_load(reinterpret_cast<const f2v*>(Vm + (size_t)rowi[w] * C));
+                }
+            };
+            // the optimizer state of EVERY row of the slice (8 rows per lane: 48 registers) is requested before the records are
+            // streamed.  [Measured, profiles/r11_grid_backward.md: requests riding behind each trip's records instead (vector
+            // loads return in order, so state in front of the records holds the first trip back) need the trips unrolled and
+            // spill ~50 registers at 1,024 threads: 148 - 152 us against 117 - 121 us for this arrangement at 1.1e5 points.]
+#pragma unroll
+            for (uint32_t w = 0; w < WA; w++) request_state(w);
+            if (stream_it) {
+                if (dirty) {
+                    for (uint32_t i = threadIdx.x; i < kBinAccBytes / 8; i += kBinAccThreads) acc[i] = 0ull;
+                    dirty = false;
+                }
+                lds_barrier();  // accumulators clear (this item's fill, or the previous item's write-out); the state loads stay in flight
+                auto stream_a = [&](auto small_c) {
+                    const uint32_t q0a = (wave / NS) * 64 + (threadIdx.x & 63u);
+                    for (uint32_t qi = q0a; qi < nquads_a; qi += STEP) {
+                        const uint2 k = *reinterpret_cast<const uint2*>(gkeys + base_a + 4 * (size_t)qi);
+                        const uint4 vq = *reinterpret_cast<const uint4*>(gvals + base_a + 4 * (size_t)qi);
+                        const uint32_t nq = cj_a - 4 * qi < 4u ? cj_a - 4 * qi : 4u;
+                        add_a(small_c, k.x & 0xffffu, vq.x);
+                        if (nq > 1) add_a(small_c, k.x >> 16, vq.y);
+                        if (nq > 2) add_a(small_c, k.y & 0xffffu, vq.z);
+                        if (nq > 3) add_a(small_c, k.y >> 16, vq.w);
+                    }
+                };
+                if (small) stream_a(std::true_type{});
+                else stream_a(std::false_type{});
+                for (uint32_t k = threadIdx.x >> 6; k < nspill; k += kBinAccThreads / 64) {
+                    const uint2 d = ovl[((size_t)level * smax + slice) * nchunks + k];
+                    const size_t run = ((size_t)lip * nchunks + (d.x >> 16)) * (P * K) + (d.x & 0xffffu);
+                    for (uint32_t j = threadIdx.x & 63u; j < d.y; j += 64) add_a(std::false_type{}, skeys[run + j], svals[run + j]);
+                }
+                lds_barrier();
+            }
+#pragma unroll
+            for (uint32_t w = 0; w < WA; w++) {
+                if (rowi[w] == 0xffffffffu) continue;
+                const uint32_t rr = threadIdx.x + w * kBinAccThreads;
+                float g[C];
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) {
+                    g[c] = 0.0f;
+                    if (stream_it) {
+                        const long long q = (long long)acc[c * local_rows + rr];
+                        if (q != 0) {
+                            acc[c * local_rows + rr] = 0ull;  // cleared behind the read: the next item finds zeros
+                            const float sum = fixed_to_float(q, (int)kFixedExp);
+                            const float h = Acc<T>::to_f(Acc<T>::from_f(sum));  // the value the gradient table would hold
+                            g[c] = fabsf(h) <= 65504.0f ? h : sum;
+                        }
+                    }
+                }
+                float pp[C] = {pv[w].x, pv[w].y}, mm[C] = {mv[w].x, mv[w].y}, vq[C] = {vv[w].x, vv[w].y};
+#pragma unroll
+                for (uint32_t c = 0; c < C; c++) adam_update(ac, g[c], mm[c], vq[c], pp[c]);
+                __builtin_nontemporal_store(f2v{mm[0], mm[1]}, reinterpret_cast<f2v*>(Mm + (size_t)rowi[w] * C));
+                __builtin_nontemporal_store(f2v{vq[0], vq[1]}, reinterpret_cast<f2v*>(Vm + (size_t)rowi[w] * C));
+                __builtin_nontemporal_store(f2v{pp[0], pp[1]}, reinterpret_cast<f2v*>(Pm + (size_t)rowi[w] * C));
+                if (Hm) *reinterpret_cast<__half2*>(Hm + (size_t)rowi[w] * C) = __floats2half2_rn(pp[0], pp[1]);
+            }
+            continue;
         }
         if (poisoned) {
             for (uint32_t i = threadIdx.x; i < local_rows * C; i += kBinAccThreads) {
@@ -1789,6 +1923,8 @@ __global__ void __launch_bounds__(256) k_table_nonfinite(const T* __restrict__ t
 // found_inf of the entry point being served on this thread, and whether the path taken has reported into it
 static thread_local float* t_found_inf = nullptr;
 static thread_local bool t_reported = false;
+static thread_local const struct GridAdam* t_adam = nullptr;  // s3d_grid_encode_backward_adam: the update to apply in the accumulate
+static thread_local bool t_adam_applied = false;
 
 // gridencoder.cu:340-366
 template <typename T, uint32_t D, uint32_t C>
@@ -2137,9 +2273,28 @@ int launch_binned3(const T* grad, const float* inputs, const int32_t* offsets, T
         hipLaunchKernelGGL((k_bin_scatter6<T, D, C, FIXED24, P>), dim3(lay.chunks, nl), dim3(P), stage, st, grad, inputs, offsets, B, l0,
                            sc, hdr, cursor, ovn, ovl, lay.smax, lay.chunks, lay.cap, keys, vals, skeys, svals, gridtype, ac, interp);
         const uint32_t items = lay.smax * nl;
+        bool fused = false;
+        if constexpr (FIXED24 && sizeof(T) == 2 && C == 2) {
+            if (t_adam && nl == L) {  // (one pass covers every level: the skip decision needs all poison words up front)
+                static std::atomic<uint64_t> attr_adam{0};
+                int dev2;
+                if (device_needs_setup(attr_adam, &dev2)) {
+                    S3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bin_accumulate6<T, D, C, FIXED24, P, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBinAccBytes));
+                    device_setup_done(attr_adam, dev2);
+                }
+                hipLaunchKernelGGL((k_bin_accumulate6<T, D, C, FIXED24, P, true>), dim3(std::min(items, cus * kBinAccPerCu)), dim3(kBinAccThreads),
+                                   kBinAccBytes, st, (const uint16_t*)keys, (const uint32_t*)vals, (const uint16_t*)skeys, (const uint32_t*)svals,
+                                   offsets, grad_emb, B, l0, nl, hdr, done, cursor, ovn, (const uint2*)ovl, lay.smax, lay.chunks, lay.cap,
+                                   t_found_inf, *t_adam);
+                fused = true;
+                t_adam_applied = true;
+            }
+        }
+        if (!fused)
         hipLaunchKernelGGL((k_bin_accumulate6<T, D, C, FIXED24, P>), dim3(std::min(items, cus * kBinAccPerCu)), dim3(kBinAccThreads), kBinAccBytes, st,
                            (const uint16_t*)keys, (const uint32_t*)vals, (const uint16_t*)skeys, (const uint32_t*)svals, offsets,
-                           grad_emb, B, l0, nl, hdr, done, cursor, ovn, (const uint2*)ovl, lay.smax, lay.chunks, lay.cap, t_found_inf);
+                           grad_emb, B, l0, nl, hdr, done, cursor, ovn, (const uint2*)ovl, lay.smax, lay.chunks, lay.cap, t_found_inf, GridAdam{});
     }
     t_reported = true;
     return check_launch("grid_encode_backward");
@@ -2441,6 +2596,30 @@ S3D_EXPORT int s3d_grid_encode_backward(const void* grad, const float* inputs, c
     else
         hipLaunchKernelGGL(k_table_nonfinite<__half>, dim3(kMaxStreamBlocks), dim3(256), 0, st, (const __half*)grad_embeddings, offsets, L, C, found_inf);
     return check_launch("grid_encode_backward (gradient check)");
+}
+
+S3D_EXPORT int s3d_grid_encode_backward_adam(const void* grad, const float* inputs, const void* embeddings, const int32_t* offsets,
+                                             void* grad_embeddings, uint32_t max_level_rows, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                             float S, uint32_t H, uint32_t gridtype, int align_corners, uint32_t interp, int dtype,
+                                             void* workspace, size_t workspace_bytes, float bound, const int32_t* n_valid, float* found_inf,
+                                             void* control, size_t control_bytes, const s3d_grid_adam* adam, int* applied,
+                                             s3d_stream_t stream) {
+    S3D_REQUIRE(adam && applied, "grid_encode_backward_adam: null pointer");
+    S3D_REQUIRE(adam->param && adam->exp_avg && adam->exp_avg_sq && adam->step, "grid_encode_backward_adam: null optimizer state");
+    *applied = 0;
+    GridAdam ga;
+    ga.p = adam->param; ga.m = adam->exp_avg; ga.v = adam->exp_avg_sq; ga.ph = reinterpret_cast<__half*>(adam->param_half);
+    ga.lr = adam->lr; ga.beta1 = adam->beta1; ga.beta2 = adam->beta2; ga.eps = adam->eps;
+    ga.step = adam->step; ga.grad_scale = adam->grad_scale; ga.lr_scale = adam->lr_scale;
+    t_adam = &ga;
+    t_adam_applied = false;
+    const int rc = s3d_grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, max_level_rows, B, D, C, L, S, H, nullptr,
+                                            nullptr, gridtype, align_corners, interp, dtype, workspace, workspace_bytes, bound, n_valid, 0,
+                                            found_inf, control, control_bytes, stream);
+    t_adam = nullptr;
+    *applied = t_adam_applied ? 1 : 0;
+    t_adam_applied = false;
+    return rc;
 }
 
 S3D_EXPORT int s3d_grad_total_variation(const float* inputs, const float* embeddings, float* grad,

@@ -12,6 +12,7 @@
 //   m += (1-b1)(g - m);  v = b2 v + (1-b2) g^2;  p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // with the step count t kept on the device (graph-capturable) and advanced only by steps that are not skipped.
 #include "s3d_common.hpp"
+#include "s3d_adam.hpp"
 
 namespace s3d {
 namespace {
@@ -28,19 +29,6 @@ __global__ void __launch_bounds__(256) k_grads_nonfinite(const G* __restrict__ g
         bad |= !(fabsf(v) <= 3.402823466e38f);  // inf or NaN
     }
     if (__ballot(bad) != 0 && (threadIdx.x & 63) == 0) *found_inf = 1.0f;  // benign race: everyone writes 1
-}
-
-struct AdamCoef {
-    float beta1, beta2, eps, inv_scale, step_size, bc2_sqrt;
-    float l1;  // gradient of an L1 penalty l1 * sum|p| formed here (s3d_adam_tensor.l1): + l1 * sign(p), sign(0) = 0 like torch.sign
-};
-__device__ __forceinline__ void adam_update(const AdamCoef& c, float g, float& m, float& v, float& p) {
-    float gi = g * c.inv_scale;
-    if (c.l1 != 0.0f) gi = gi + (p > 0.0f ? c.l1 : (p < 0.0f ? -c.l1 : 0.0f));
-    m = m + (1.0f - c.beta1) * (gi - m);
-    v = c.beta2 * v + (1.0f - c.beta2) * gi * gi;
-    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
-    p = p - c.step_size * (m / denom);
 }
 
 template <typename G> struct GradVec4;
@@ -141,13 +129,7 @@ __global__ void __launch_bounds__(256) k_adam_step(float* __restrict__ p, const 
                                                    const float* __restrict__ grad_scale, const float* __restrict__ found_inf,
                                                    const float* __restrict__ lr_scale, uint32_t vec) {
     if (found_inf && *found_inf != 0.0f) return;  // the whole step is skipped (GradScaler.step)
-    const float t = *step + 1.0f;                 // this update's step number; k_adam_advance stores it afterwards
-    AdamCoef c;
-    c.beta1 = beta1; c.beta2 = beta2; c.eps = eps; c.l1 = 0.0f;
-    c.inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
-    const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
-    c.step_size = (lr_scale ? lr * *lr_scale : lr) / bc1;  // (lr_scale: the schedule's factor, read at run time by a replayed graph)
-    c.bc2_sqrt = sqrtf(bc2);
+    const AdamCoef c = adam_coef(lr, beta1, beta2, eps, 0.0f, step, grad_scale, lr_scale);
     adam_range<G>(c, p, const_cast<G*>(g), m, v, p_half, n, vec != 0, (size_t)blockIdx.x * 256 + threadIdx.x,
                   (size_t)gridDim.x * 256, false);
 }
@@ -190,13 +172,7 @@ __global__ void __launch_bounds__(256) k_adam_step_multi(AdamBatch b, const floa
         }
         return;
     }
-    const float t = *step + 1.0f;
-    AdamCoef c;
-    c.beta1 = b.beta1[i]; c.beta2 = b.beta2[i]; c.eps = b.eps[i]; c.l1 = b.l1[i];
-    c.inv_scale = grad_scale ? 1.0f / *grad_scale : 1.0f;
-    const float bc1 = 1.0f - powf(c.beta1, t), bc2 = 1.0f - powf(c.beta2, t);
-    c.step_size = (lr_scale ? b.lr[i] * *lr_scale : b.lr[i]) / bc1;
-    c.bc2_sqrt = sqrtf(bc2);
+    const AdamCoef c = adam_coef(b.lr[i], b.beta1[i], b.beta2[i], b.eps[i], b.l1[i], step, grad_scale, lr_scale);
     if (b.stride[i]) {
         if (b.half_grad[i])
             adam_range_packed<__half>(c, b.p[i], (__half*)b.g[i], b.m[i], b.v[i], b.h[i], b.n[i], b.cols[i], b.stride[i], tid, nthreads, b.consume[i] != 0);

@@ -123,6 +123,7 @@ class _GridEncode(Function):
         stash = getattr(ctx.param, "_s3d_grad", None)
         if stash is not None and stash.dtype == embeddings.dtype and stash.shape == embeddings.shape:
             grad_embeddings = stash
+            was_touched = getattr(ctx.param, "_s3d_grad_touched", False)
             ctx.param._s3d_grad_touched = True
             found_inf = getattr(ctx.param, "_s3d_found_inf", None)  # GradScaler's check made by the writing kernel
         else:
@@ -132,6 +133,15 @@ class _GridEncode(Function):
         extra = ctx.extra
         if stash is not None and found_inf is not None:
             extra = dict(extra, found_inf=found_inf)
+        # the optimizer armed this table for THIS backward pass (nerf/optim.py: NativeAdam.arm_fused_tables): the accumulate
+        # kernel applies the update itself and no gradient is written
+        armed = ctx.param.__dict__.pop("_s3d_fused_arm", None) if stash is not None else None
+        if armed is not None and dy_dx is None and hasattr(_backend, "grid_encode_backward_adam"):
+            if _backend.grid_encode_backward_adam(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, gridtype,
+                                                  align_corners, interpolation, armed, **extra):
+                ctx.param._s3d_grad_touched = was_touched  # (nothing was written into the hand-over buffer)
+                ctx.param._s3d_fused_done = True
+            return None, None, None, None, None, None, None, None, None, None, None, None, None, None
         _backend.grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, dy_dx,
                                       grad_inputs, gridtype, align_corners, interpolation, **extra)
         if grad_inputs is not None:
@@ -205,6 +215,7 @@ class _GridEncodePair(Function):
             extra = ctx.extra
             if stash is not None and stash.dtype == table.dtype and stash.shape == table.shape:
                 grad_embeddings = stash
+                param._s3d_fused_prev_touched = getattr(param, "_s3d_grad_touched", False)
                 param._s3d_grad_touched = True
                 found_inf = getattr(param, "_s3d_found_inf", None)
                 if found_inf is not None:
@@ -212,6 +223,18 @@ class _GridEncodePair(Function):
             else:
                 stash = None
                 grad_embeddings = torch.zeros_like(table)
+            # in-backward update (nerf/optim.py: arm_fused_tables) for the LAST table of the pair only: its kernel takes the step's
+            # skip decision when every poison word of the pair is known — the first table's scatter has run by then, but not
+            # vice versa — so the first table keeps the separate update
+            armed = param.__dict__.pop("_s3d_fused_arm", None) if stash is not None else None
+            if armed is not None and k == 1 and hasattr(_backend, "grid_encode_backward_adam"):
+                was = getattr(param, "_s3d_fused_prev_touched", False)
+                if _backend.grid_encode_backward_adam(grad, inputs, table, offsets, grad_embeddings, B, D, C, L, S, H, gridtype,
+                                                      align_corners, interpolation, armed, **extra):
+                    param._s3d_grad_touched = was
+                    param._s3d_fused_done = True
+                outs.append(None)
+                continue
             _backend.grid_encode_backward(grad, inputs, table, offsets, grad_embeddings, B, D, C, L, S, H, None, None, gridtype,
                                           align_corners, interpolation, **extra)
             outs.append(None if stash is not None else grad_embeddings)

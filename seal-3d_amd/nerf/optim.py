@@ -83,10 +83,46 @@ class NativeAdam(torch.optim.Optimizer):
                 off += n
         self.packs = packs
 
+    fuse_table_updates = True  # single replica: a hash table's update rides in its backward's accumulate kernel (arm_fused_tables)
+
+    def arm_fused_tables(self, grad_scale=None):
+        """Called by a trainer right before the ONE backward pass of a step it will follow with `step()` (single replica, every
+        other gradient of the step checked where it is produced): each adopted fp16 C = 2 table is armed — its backward
+        (gridencoder/grid.py) hands this state to s3d_grid_encode_backward_adam, the accumulate kernel applies the update where
+        the row sums are, and `step()` leaves the table alone.  A table whose backward does not run, or falls back to the plain
+        kernels, is updated by `step()` as always.  Returns the number of tables armed."""
+        n = 0
+        if not self.fuse_table_updates or self.flat_half is None:
+            return 0
+        lr_of = {}
+        if self._lr_captured is not None:
+            lr_of = {id(g): lr for g, lr in zip(self.param_groups, self._lr_captured)}
+        for group in self.param_groups:
+            for p in group["params"]:
+                half = getattr(p, "_s3d_half", None)
+                if (getattr(p, "_s3d_grad", None) is None or getattr(p, "_s3d_pack_spec", None) is not None or not p.requires_grad
+                        or p.dim() != 2 or p.shape[1] != 2 or half is None or p._s3d_half_version != p._version
+                        or getattr(p, "_s3d_found_inf", None) is None or float(p.__dict__.get("_s3d_l1", 0.0)) != 0.0):
+                    continue
+                st = self.state[p]
+                b1, b2 = group["betas"]
+                p._s3d_fused_arm = dict(param=p.data, exp_avg=st["exp_avg"], exp_avg_sq=st["exp_avg_sq"], param_half=half,
+                                        lr=lr_of.get(id(group), group["lr"]), betas=(b1, b2), eps=group["eps"], step=self.step_count,
+                                        grad_scale=grad_scale, lr_scale=self.lr_scale)
+                n += 1
+        return n
+
+    def disarm_fused_tables(self):
+        for group in self.param_groups:
+            for p in group["params"]:
+                p.__dict__.pop("_s3d_fused_arm", None)
+
     def grads(self):
         """(param, gradient tensor) for every parameter that has one: the fp16 hand-over buffer or `.grad`"""
         for group in self.param_groups:
             for p in group["params"]:
+                if getattr(p, "_s3d_fused_done", False):
+                    continue  # (updated inside its backward's accumulate kernel this step)
                 g = getattr(p, "_s3d_grad", None)
                 if g is None or not getattr(p, "_s3d_grad_touched", False):
                     g = p.grad  # (a table no backward pass touched this step has no gradient, like `.grad is None`)
@@ -258,6 +294,10 @@ class NativeAdam(torch.optim.Optimizer):
             p._s3d_half_version = p._version
         if advance:
             _backend.adam_advance(self.step_count, found_inf)
+        for group in self.param_groups:  # (the marks of this step's in-backward updates; an arm nobody consumed goes with them)
+            for p in group["params"]:
+                p.__dict__.pop("_s3d_fused_done", None)
+                p.__dict__.pop("_s3d_fused_arm", None)
 
 
 class NativeGradScaler:

@@ -205,7 +205,26 @@ class Trainer:
         sc = self.scaler
         return sc._scale.reshape(()) if (hasattr(sc, "backward") and getattr(sc, "enabled", False)) else None
 
+    # the hash tables' Adam inside their backward's accumulate kernel (nerf/optim.py: arm_fused_tables); S3D_FUSE_TABLE_ADAM=0: A/B
+    fuse_table_updates = __import__("os").environ.get("S3D_FUSE_TABLE_ADAM", "1") != "0"
+
+    def _arm_fused_tables(self):
+        """single replica, native optimizer + scaler, every gradient of the step a hand-over buffer whose producer raises the
+        scaler's flag itself: the step's skip decision is complete when the tables' backward — the last node of the graph —
+        starts, so their update can be applied there.  (Seal's nn.Linear `.grad`s without a pack, TensoRF's factors, data
+        parallelism: the separate update as before.)"""
+        opt, sc = self.optimizer, self.scaler
+        if not (self.fuse_table_updates and self.native_optim and self.dist is None and hasattr(opt, "arm_fused_tables")
+                and hasattr(sc, "_checked_at_source")):
+            return 0
+        params = [p for g in opt.param_groups for p in g["params"]]
+        if not all(getattr(p, "_s3d_grad", None) is not None for p in params) or not sc._checked_at_source(opt):
+            return 0
+        return opt.arm_fused_tables(grad_scale=sc._scale if sc.enabled else None)
+
     def _backward(self, loss):
+        """the step's ONE backward pass (every caller follows it with `_reduce_and_step`)"""
+        self._arm_fused_tables()
         if hasattr(self.scaler, "backward"):  # NativeGradScaler: the scale is passed as the root gradient
             self.scaler.backward(loss)
         else:

@@ -42,7 +42,7 @@ EXPORTS = [
     "s3d_grads_nonfinite", "s3d_adam_step", "s3d_adam_step_multi", "s3d_adam_advance", "s3d_scaler_update", "s3d_step_ring_push", "s3d_step_epilogue",
     "s3d_ngp_mid_forward", "s3d_ngp_mid_backward", "s3d_ngp_mid2_forward", "s3d_ngp_mid2_backward", "s3d_ngp_rgb_forward", "s3d_ngp_rgb_backward",
     "s3d_bg_mse_forward", "s3d_bg_mse_backward", "s3d_bg_targets", "s3d_l1_pair_workspace_size", "s3d_l1_pair_loss",
-    "s3d_seal_bbox_map", "s3d_seal_map_color", "s3d_vm_features_forward",
+    "s3d_seal_bbox_map", "s3d_seal_map_color", "s3d_grid_encode_backward_adam", "s3d_vm_features_forward",
     "s3d_aabb_normalize", "s3d_weighted_abs_sum_workspace_size", "s3d_weighted_abs_sum", "s3d_pack_linear_chain", "s3d_unpack_linear_chain",
     "s3d_vm_backward_max_bins", "s3d_vm_backward_keys", "s3d_vm_backward_bins_workspace_size", "s3d_vm_backward_bins",
     "s3d_vm_features_backward", "s3d_vm_color_forward", "s3d_vm_color_backward",
@@ -526,6 +526,46 @@ class GridBackend:
                                               C.c_int(GridBackend._backward_path), _p(found_inf), _p(ctl),
                                               C.c_size_t(ctl.numel() if ctl is not None else 0), _stream()),
                "grid_encode_backward")
+
+    class _GridAdam(C.Structure):
+        _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("param_half", C.c_void_p),
+                    ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                    ("step", C.c_void_p), ("grad_scale", C.c_void_p), ("lr_scale", C.c_void_p)]
+
+    @staticmethod
+    def grid_encode_backward_adam(grad, inputs, embeddings, offsets, grad_embeddings, B, D, Cc, L, S, H, gridtype, align_corners,
+                                  interp, adam, bound=0.0, n_valid=None, found_inf=None):
+        """backward of a table with its Adam update inside the accumulate kernel (include/seal3d_hip.h:
+        s3d_grid_encode_backward_adam).  `adam`: dict(param, exp_avg, exp_avg_sq, param_half, lr, betas, eps, step, grad_scale,
+        lr_scale).  Returns True when the update was applied there, False when the plain backward ran (the gradient is in
+        `grad_embeddings`)."""
+        _need(inputs, torch.float32, "inputs")
+        if found_inf is not None:
+            _need(found_inf, torch.float32, "found_inf")
+        if grad_embeddings.dtype != grad.dtype:
+            raise RuntimeError("grad_embeddings must have the dtype of grad")
+        for k in ("param", "exp_avg", "exp_avg_sq"):
+            _need(adam[k], torch.float32, k)
+            if adam[k].shape != embeddings.shape or not adam[k].is_contiguous():
+                raise RuntimeError(f"adam[{k!r}] must be a contiguous fp32 tensor of the table's shape")
+        mlr = _max_level_rows(offsets)
+        ws = _ws.get(lib().s3d_grid_encode_backward_workspace_size(_u(B), _u(D), _u(Cc), _u(L), _u(mlr), C.c_int(_dt(grad))), grad.device)
+        ctl = _ctl.get(lib().s3d_grid_encode_backward_control_size(_u(D), _u(Cc), _u(L), _u(mlr), C.c_int(_dt(grad))),
+                       grad.device) if B >= 8192 else None
+        ga = GridBackend._GridAdam()
+        ga.param, ga.exp_avg, ga.exp_avg_sq = adam["param"].data_ptr(), adam["exp_avg"].data_ptr(), adam["exp_avg_sq"].data_ptr()
+        ga.param_half = adam["param_half"].data_ptr() if adam.get("param_half") is not None else None
+        ga.lr, (ga.beta1, ga.beta2), ga.eps = float(adam["lr"]), adam["betas"], float(adam["eps"])
+        ga.step = adam["step"].data_ptr()
+        ga.grad_scale = adam["grad_scale"].data_ptr() if adam.get("grad_scale") is not None else None
+        ga.lr_scale = adam["lr_scale"].data_ptr() if adam.get("lr_scale") is not None else None
+        applied = C.c_int(0)
+        _check(lib().s3d_grid_encode_backward_adam(_p(grad), _p(inputs), _p(embeddings), _p(offsets), _p(grad_embeddings), _u(mlr), _u(B),
+                                                   _u(D), _u(Cc), _u(L), _f(S), _u(H), _u(gridtype), C.c_int(int(align_corners)), _u(interp),
+                                                   C.c_int(_dt(grad)), _p(ws), C.c_size_t(ws.numel()), _f(bound), _nv(n_valid),
+                                                   _p(found_inf), _p(ctl), C.c_size_t(ctl.numel() if ctl is not None else 0),
+                                                   C.byref(ga), C.byref(applied), _stream()), "grid_encode_backward_adam")
+        return bool(applied.value)
 
     _backward_path = 0  # `path` argument of s3d_grid_encode_backward (binding-side state for tests / experiments)
 

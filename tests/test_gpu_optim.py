@@ -318,3 +318,65 @@ def test_native_adam_forms_an_announced_l1_gradient_inside_the_update(hip):
     for a, b in zip(pa, pb):
         torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-6, atol=2e-7)
     assert torch.equal(pa[1].detach()[::11][:1] == 0, pb[1].detach()[::11][:1] == 0)
+
+
+def test_grid_backward_with_adam_inside_matches_backward_then_adam(hip):
+    """s3d_grid_encode_backward_adam vs s3d_grid_encode_backward + s3d_adam_step_multi on the same inputs, two consecutive
+    steps (non-zero moments on the second), loss scale 1024: master table, moments and fp16 copy bit for bit; rows no point
+    touches move on their moments alone; a raised flag or a non-finite dL/dy leaves everything as it was (and raises the flag)."""
+    import numpy as np
+    import s3d_hip
+    from gridencoder import GridEncoder
+    G, O = s3d_hip.GridBackend, s3d_hip.OptimBackend
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=19, desired_resolution=2048)
+    offs = enc.offsets.cuda()
+    rows = int(offs[-1])
+    L, S = 16, float(np.log2(enc.per_level_scale))
+    B = 1 << 16
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(B, 3, generator=gen).cuda()
+    x[: B // 2] = x[: B // 2] * 0.25 + 0.3  # half of the points in a corner of the volume: most fine-level rows stay untouched
+    scale = torch.full((1,), 1024.0, device="cuda")
+    step = torch.zeros(1, device="cuda")
+
+    def state(seed):
+        g = torch.Generator().manual_seed(seed)
+        p = (torch.rand(rows, 2, generator=g) * 2e-4 - 1e-4).cuda()
+        return [p, torch.zeros_like(p), torch.zeros_like(p), p.half()]
+    a, b = state(1), state(1)
+    table = a[3].clone()
+    for it in range(2):
+        grad = (torch.randn(L, B, 2, generator=gen) * 3.0).half().cuda()
+        flag = torch.zeros(1, device="cuda")
+        ge = torch.zeros(rows, 2, dtype=torch.half, device="cuda")
+        G.grid_encode_backward(grad, x, table, offs, ge, B, 3, 2, L, S, 16, None, None, 0, False, 0, found_inf=flag)
+        assert float(flag) == 0.0
+        O.adam_step_multi([(a[0], ge, a[1], a[2], a[3], 1e-2, 0.9, 0.99, 1e-15)], step, scale, flag)
+        ge2 = torch.zeros(rows, 2, dtype=torch.half, device="cuda")
+        adam = dict(param=b[0], exp_avg=b[1], exp_avg_sq=b[2], param_half=b[3], lr=1e-2, betas=(0.9, 0.99), eps=1e-15, step=step,
+                    grad_scale=scale, lr_scale=None)
+        assert G.grid_encode_backward_adam(grad, x, table, offs, ge2, B, 3, 2, L, S, 16, 0, False, 0, adam, found_inf=flag)
+        assert float(ge2.abs().max()) == 0.0 and float(flag) == 0.0
+        for k in range(4):
+            assert torch.equal(a[k], b[k]), (it, k, float((a[k].float() - b[k].float()).abs().max()))
+        if it == 1:
+            untouched = (ge == 0).all(1)
+            assert 0.2 < float(untouched.float().mean()) < 0.99
+        step += 1
+    before = [t.clone() for t in b]
+    flag = torch.ones(1, device="cuda")  # another producer of the step already raised the flag: skipped as a whole
+    assert G.grid_encode_backward_adam(grad, x, table, offs, ge2, B, 3, 2, L, S, 16, 0, False, 0, adam, found_inf=flag)
+    assert all(torch.equal(u, w) for u, w in zip(before, b))
+    flag = torch.zeros(1, device="cuda")
+    bad = grad.clone()
+    bad[7, 12345, 1] = float("inf")
+    assert G.grid_encode_backward_adam(bad, x, table, offs, ge2, B, 3, 2, L, S, 16, 0, False, 0, adam, found_inf=flag)
+    assert float(flag) == 1.0 and all(torch.equal(u, w) for u, w in zip(before, b))
+    # the next clean call finds clean control words
+    flag = torch.zeros(1, device="cuda")
+    assert G.grid_encode_backward_adam(grad, x, table, offs, ge2, B, 3, 2, L, S, 16, 0, False, 0, adam, found_inf=flag)
+    assert float(flag) == 0.0 and not torch.equal(before[0], b[0])
+    # small batches take the direct-atomics kernels: not applied, the gradient is in the table
+    small = G.grid_encode_backward_adam(grad[:, :4096].contiguous(), x[:4096].contiguous(), table, offs, ge2, 4096, 3, 2, L, S, 16, 0, False,
+                                        0, adam, found_inf=flag)
+    assert small is False and float(ge2.abs().max()) > 0

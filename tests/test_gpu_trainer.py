@@ -50,7 +50,7 @@ def test_training_variants_converge_alike(hip, variant):
     if variant == "graph-native":
         assert tr.n_captures >= 1 and tr.graph is not None
         emb = model.encoder.embeddings
-        assert emb.grad is None and emb._s3d_grad_touched          # fp16 hand-over active inside the captured step
+        assert emb.grad is None and (emb._s3d_grad_touched or tr.fuse_table_updates)  # fp16 hand-over / in-backward update active inside the captured step
         assert torch.equal(emb._s3d_half, emb.detach().half())      # the fp16 copy tracks the master weights
     if variant == "eager-torch":
         assert model.encoder.embeddings.grad is not None and not hasattr(model.encoder.embeddings, "_s3d_grad")
@@ -452,3 +452,36 @@ def test_step_with_the_one_launch_criterion_equals_the_three_launch_step_bit_for
     assert torch.equal(res[True][0], res[False][0])
     for a, b in zip(res[True][1], res[False][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_table_update_inside_the_backward_equals_the_separate_update_bit_for_bit(hip, graphed):
+    """The hash table's Adam applied in the grid backward's accumulate kernel (s3d_grid_encode_backward_adam; single replica)
+    against the separate update (gradient table written, s3d_adam_step_multi): same batches, same initial weights -> the same
+    master table, moments, fp16 copy and MLP weights after 40 steps, bit for bit (the in-backward update uses the binary16
+    value the gradient table would hold), and the same losses."""
+    from nerf.trainer import GraphedTrainer, Trainer
+    res = {}
+    for fuse in (True, False):
+        model, batches = _setup()
+        tr = GraphedTrainer(model, 2048, lr=1e-2, fp16=True) if graphed else Trainer(model, lr=1e-2, fp16=True)
+        tr.fuse_table_updates = fuse
+        if graphed:
+            tr.noise_key = 1234
+        torch.manual_seed(7)
+        losses = _run(tr, batches, 40)
+        emb = model.encoder.embeddings
+        st = tr.optimizer.state[emb]
+        res[fuse] = (losses, emb.detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), emb._s3d_half.clone(),
+                     [p.detach().clone() for p in model.parameters()], float(tr.optimizer.step_count))
+        if fuse:
+            assert not emb._s3d_grad_touched and float(emb._s3d_grad.abs().max()) == 0.0, "the gradient table must stay untouched"
+        else:
+            assert emb._s3d_grad_touched
+    a, b = res[True], res[False]
+    assert a[6] == b[6] == 40.0
+    assert torch.equal(a[0], b[0]), (a[0] - b[0]).abs().max()
+    for k in (1, 2, 3, 4):
+        assert torch.equal(a[k], b[k]), k
+    assert all(torch.equal(x, y) for x, y in zip(a[5], b[5]))
+    assert torch.equal(a[4], a[1].half())
