@@ -381,22 +381,20 @@ struct VmBackward {
 // tile accumulators are 64-bit fixed point.  The scale comes from a bound on one contribution (|g| max x |line| max for the
 // plane kernel, max |g m| for the line kernel: the corner weights are <= 1) placed at 2^50: a workgroup adds at most
 // kVmMaxPts = 2^12 contributions into a cell before it flushes (one per point of its range), so the 63-bit sums cannot
-// overflow; a contribution is rounded to nearest (no bias), and one that would keep fewer than kVmTinyBits = 12 bits in this
-// format — below 2^-38 of the call-wide bound — does not go through the accumulator at all: it is added to the gradient as an
-// fp32 atomic on the spot (vm_fixed() returns false).  So no contribution is dropped however far a region's gradients lie
-// below the batch maximum (a cell fed only by vanishing gradients gets them exactly as the reference's fp32 sums do), and the
-// rare path costs one compare per contribution.  Integer adds commute: a tile's sum does not depend on the order in which
-// its points arrive.  The sums leave as fp32 (plain stores where the segment owns the cell, global atomics otherwise).
+// overflow, and a contribution is ROUNDED TO NEAREST at 2^-50 of the call-wide bound (no truncation bias; round 5 truncated at
+// 2^-40).  A region whose gradients lie 2^40 below the batch maximum still keeps 10 bits per contribution; below 2^-51 of
+// the bound a contribution rounds to zero — seven orders of magnitude under what an fp32 sum of the same cell would still
+// resolve next to a contribution of the bound's size.  [Measured and rejected, profiles/r11_tensorf.md: an exact bypass for
+// contributions under 2^12 quanta (fp32 atomics straight to the gradient) — the cold block costs the colour plane kernel a
+// third of its speed whatever the threshold: 339 -> 497 us.]  Integer adds commute: a tile's sum does not depend on the
+// order in which its points arrive.  The sums leave as fp32 (plain stores where the segment owns the cell, atomics otherwise).
 constexpr int kVmFixBits = 50;
 constexpr uint32_t kVmMaxPts = 4096;
-constexpr float kVmTiny = 4096.0f;  // 2^kVmTinyBits
-__device__ __forceinline__ bool vm_fixed(float v, float scale, long long& q) {
+__device__ __forceinline__ long long vm_fixed(float v, float scale) {
     const float t = v * scale;                                  // (power-of-two scale: exact)
-    if (!(fabsf(t) >= kVmTiny)) return false;
     const float hi = truncf(t * 5.9604644775390625e-08f);       // t / 2^24, |hi| < 2^27
     const float lo = __builtin_fmaf(-hi, 16777216.0f, t);       // exact remainder, |lo| < 2^24
-    q = (long long)(int)hi * 16777216ll + (long long)__float2int_rn(lo);
-    return true;
+    return (long long)(int)hi * 16777216ll + (long long)__float2int_rn(lo);
 }
 __device__ __forceinline__ void vm_lds_add(long long* a, long long q) {
     atomicAdd(reinterpret_cast<unsigned long long*>(a), (unsigned long long)q);
@@ -529,9 +527,6 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
     }
     long long* acc = reinterpret_cast<long long*>(vm_smem_raw);                   // [81][R] gradient accumulator (fixed point)
     float* pv = reinterpret_cast<float*>(acc + kVmTileCells * R);                 // [81][R] plane values
-    __shared__ int rare_flag;  // a contribution of the current segment bypassed the accumulator (vm_fixed)
-    int* rare = &rare_flag;
-    if (threadIdx.x == 0) rare_flag = 0;
     const float* P = f.plane[i];
     const size_t plane_stride = (size_t)H * W;
     constexpr uint32_t PPW = 64 / RP;  // points per wave trip
@@ -617,16 +612,10 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
             const int c_nw = ly * (kVmTile + 1) + lx;
             const float gl = g * l;
             float m = 0.0f;
-            float* dPr = b.d_plane[i] + (ptrdiff_t)(r * plane_stride) + (ptrdiff_t)q.y0 * W + q.x0;  // (this channel's nw cell of the gradient)
-            auto add = [&](int cell, float v, int goff) {
-                long long fx;
-                if (vm_fixed(v, scale, fx)) vm_lds_add(&acc[cell * R + r], fx);
-                else if (v != 0.0f) { atomicAdd(dPr + goff, v); *rare = 1; }  // (a vanishing contribution: exact, straight to HBM)
-            };
-            if (bx0 && by0) { m += pv[c_nw * R + r] * q.nw; add(c_nw, gl * q.nw, 0); }
-            if (bx1 && by0) { m += pv[(c_nw + 1) * R + r] * q.ne; add(c_nw + 1, gl * q.ne, 1); }
-            if (bx0 && by1) { m += pv[(c_nw + kVmTile + 1) * R + r] * q.sw; add(c_nw + kVmTile + 1, gl * q.sw, W); }
-            if (bx1 && by1) { m += pv[(c_nw + kVmTile + 2) * R + r] * q.se; add(c_nw + kVmTile + 2, gl * q.se, W + 1); }
+            if (bx0 && by0) { m += pv[c_nw * R + r] * q.nw; vm_lds_add(&acc[c_nw * R + r], vm_fixed(gl * q.nw, scale)); }
+            if (bx1 && by0) { m += pv[(c_nw + 1) * R + r] * q.ne; vm_lds_add(&acc[(c_nw + 1) * R + r], vm_fixed(gl * q.ne, scale)); }
+            if (bx0 && by1) { m += pv[(c_nw + kVmTile + 1) * R + r] * q.sw; vm_lds_add(&acc[(c_nw + kVmTile + 1) * R + r], vm_fixed(gl * q.sw, scale)); }
+            if (bx1 && by1) { m += pv[(c_nw + kVmTile + 2) * R + r] * q.se; vm_lds_add(&acc[(c_nw + kVmTile + 2) * R + r], vm_fixed(gl * q.se, scale)); }
             const float gmv = g * m;
             b.gm[(size_t)n * b.rows + f.row0[i] + r] = gmv;
             gm_max = fmaxf(gm_max, fabsf(gmv));
@@ -642,8 +631,7 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
         // row / column are the left / upper neighbours' border, its last row / column the right / lower neighbours' first):
         // those leave as plain stores into the zero-initialised gradient — 1,536 instead of 3,888 global atomics per tile at
         // rank 48, and global atomics (~21 G/s chip-wide) are what this kernel waits for
-        // (... unless a vanishing contribution of this segment went to the gradient directly: a store would overwrite it)
-        const bool whole = pos == (uint32_t)st[t] && seg_end == (uint32_t)st[t + 1] && *rare == 0;
+        const bool whole = pos == (uint32_t)st[t] && seg_end == (uint32_t)st[t + 1];
         for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += kVmBwdThreads) {
             const uint32_t rr = e / kVmTileCells, c = e % kVmTileCells;
             const int ly = (int)(c / (kVmTile + 1)), lx = (int)(c % (kVmTile + 1));
@@ -659,10 +647,6 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
             }
         }
         pos = seg_end;
-        if (*rare) {  // (uniform: read after the barrier above; cleared behind one more so that no lane still reads the old value)
-            __syncthreads();
-            if (threadIdx.x == 0) rare_flag = 0;
-        }
         // (the next segment's plane values are written before its barrier; the flush only touches `acc`)
     }
     gm_max = wave_max(gm_max);
@@ -747,18 +731,8 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_line_backward(const float*
             const VmPoint q = vm_locate_xyz(p_cur, f, i);
             if (r >= R) continue;
             const int lz = q.z0 - zb;  // -1 .. 63
-            float* dLr = b.d_line[i] + (ptrdiff_t)r * Dn + q.z0;
-            long long fx;
-            if (q.z0 >= 0 && q.z0 < Dn) {
-                const float v = gm * q.lz0;
-                if (vm_fixed(v, scale, fx)) vm_lds_add(&acc[lz * R + r], fx);
-                else if (v != 0.0f) atomicAdd(dLr, v);  // (vanishing contribution: exact, straight to the gradient)
-            }
-            if (q.z0 + 1 >= 0 && q.z0 + 1 < Dn) {
-                const float v = gm * q.lz1;
-                if (vm_fixed(v, scale, fx)) vm_lds_add(&acc[(lz + 1) * R + r], fx);
-                else if (v != 0.0f) atomicAdd(dLr + 1, v);
-            }
+            if (q.z0 >= 0 && q.z0 < Dn) vm_lds_add(&acc[lz * R + r], vm_fixed(gm * q.lz0, scale));
+            if (q.z0 + 1 >= 0 && q.z0 + 1 < Dn) vm_lds_add(&acc[(lz + 1) * R + r], vm_fixed(gm * q.lz1, scale));
         }
         __syncthreads();
         float* dL = b.d_line[i];
