@@ -2105,8 +2105,13 @@ int launch_forward(const float* inputs, const T* emb, const int32_t* offsets, T*
     // (chunk slots of the lane-pair kernel: the inference loop's launches — `live` rows, all of them filled — keep one
     //  workgroup per chunk; everything else walks its chunks from 2,048 slots per XCD, i.e. unchanged up to 2^19 rows)
     const uint32_t chunks = div_up<uint32_t>(B, kFwdBlock);
-    const bool strided = !sc.live && sc.n_valid && chunks > kFwdMaxChunks;  // (a device-side row count: the extent may be mostly padding)
-    const dim3 grid_pair(kXcds * (strided ? kFwdMaxChunks : chunks), emb_b ? 2u : 1u);
+    // S3D_FWD_SLOTS=<n> (experiments, profiles/r11_grid_isolated.md): a persistent queue of n chunk slots per XCD for EVERY launch
+    // — n = 32 CUs x resident workgroups is "sized to residency" — instead of one workgroup per chunk
+    static const uint32_t forced_slots = [] { const char* e = getenv("S3D_FWD_SLOTS"); return e ? (uint32_t)atoi(e) : 0u; }();
+    const uint32_t slots = forced_slots ? (forced_slots + kFwdResidues - 1) / kFwdResidues * kFwdResidues : kFwdMaxChunks;
+    const bool strided = forced_slots ? chunks > slots
+                                      : (!sc.live && sc.n_valid && chunks > kFwdMaxChunks);  // (a device-side row count: the extent may be mostly padding)
+    const dim3 grid_pair(kXcds * (strided ? slots : chunks), emb_b ? 2u : 1u);
     const dim3 grid(xcd_grid(B), emb_b ? 2u : 1u), block(kFwdBlock);
     if (emb_b && (dy_dx || (sizeof(T) * C) % 4 != 0 || (sizeof(T) == 4 && C != 1 && C != 2 && C != 4 && C != 8) ||
                   (sizeof(T) == 2 && C != 2 && C != 4 && C != 8))) {
