@@ -180,7 +180,8 @@ def profile_traffic(op):
     import glob
     import re
     here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_timed_region.md")))
+    files = sorted(f for f in glob.glob(os.path.join(here, "profiles", "r*_timed_region.md"))
+                   if re.match(r"r\d+_timed_region\.md$", os.path.basename(f)))  # (rNNplain_*: the A/B run with the update separate)
     if not files:
         return None, None
     text = open(files[-1]).read()
