@@ -1669,13 +1669,15 @@ __global__ void __launch_bounds__((NC + NG) * 64) k_ffmlp_backward_duo(const _Fl
 constexpr uint32_t kWgradBlocks = 256;
 inline uint32_t wgrad_blocks(uint32_t W) { return W > 64 ? 128u : kWgradBlocks; }  // (W = 128: 64 KiB partial planes)
 }  // namespace
-// csrc/ffmlp_generic.hip: the shapes the register-resident kernels do not cover (hidden 16 / 128 / 256, input_dim > 64)
+// csrc/ffmlp_generic.hip: the shapes the register-resident kernels do not cover (hidden 16 / 256, input_dim > 64 at widths 32 / 64,
+// hidden 128 beyond its LDS budget) run layer by layer on hand-written MFMA kernels
 bool ffmlp_native_shape(uint32_t in_dim, uint32_t W, uint32_t n_layers = 2);
+size_t ffmlp_generic_min_workspace(uint32_t in_dim, uint32_t W, uint32_t n_layers);
 int ffmlp_generic_forward(const _Float16* X, const _Float16* Wt, uint32_t B, uint32_t in_dim, uint32_t W, uint32_t n_layers, uint32_t act,
                           uint32_t out_act, _Float16* acts, bool training, _Float16* out, hipStream_t st);
 int ffmlp_generic_backward(const _Float16* grad, const _Float16* X, const _Float16* Wt, const _Float16* fwd, uint32_t B, uint32_t in_dim,
                            uint32_t W, uint32_t n_layers, uint32_t act, _Float16* bwd, _Float16* grad_inputs, _Float16* grad_weights,
-                           bool accumulate, float* found_inf, hipStream_t st);
+                           bool accumulate, float* found_inf, float* workspace, size_t workspace_bytes, hipStream_t st);
 namespace {
 
 // `n_valid` of the entry point being served on this thread (see valid_rows()); the launch helpers below pass it on
@@ -2051,7 +2053,10 @@ S3D_EXPORT size_t s3d_ffmlp_backward_workspace_size(uint32_t input_dim, uint32_t
                                                     uint32_t num_layers) {
     (void)output_dim;
     const size_t planes = (size_t)num_layers + 1 + (input_dim > hidden_dim && hidden_dim == 128 ? 1 : 0);  // (launch_backward: two column blocks)
-    return planes * wgrad_blocks(hidden_dim) * wgrad_pad(hidden_dim) * wgrad_pad(hidden_dim) * sizeof(float);
+    const size_t native = planes * wgrad_blocks(hidden_dim) * wgrad_pad(hidden_dim) * wgrad_pad(hidden_dim) * sizeof(float);
+    if (ffmlp_native_shape(input_dim, hidden_dim, num_layers)) return native;
+    // layer-by-layer path: up to 16 batch segments' worth of fp32 partial planes of every weight matrix
+    return std::max(native, 16 * ffmlp_generic_min_workspace(input_dim, hidden_dim, num_layers));
 }
 
 S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, const uint16_t* weights,
@@ -2098,7 +2103,7 @@ S3D_EXPORT int s3d_ffmlp_backward(const uint16_t* grad, const uint16_t* inputs, 
                     "[n, B, W], row-major inputs, no heads, no n_valid", hidden_dim, input_dim);
         return ffmlp_generic_backward((const _Float16*)grad, (const _Float16*)inputs, (const _Float16*)weights, (const _Float16*)forward_buffer,
                                       B, input_dim, hidden_dim, num_layers, activation, (_Float16*)backward_buffer, gi,
-                                      (_Float16*)grad_weights, accumulate != 0, found_inf, as_stream(stream));
+                                      (_Float16*)grad_weights, accumulate != 0, found_inf, (float*)workspace, workspace_bytes, as_stream(stream));
     }
     if (!forward_buffer) {
         S3D_REQUIRE(fused_backward_supported(input_dim, 16, hidden_dim, num_layers, activation),

@@ -16,7 +16,7 @@ wait
 OTHERS=$(ls build/*.o | grep -v "build/$SRC.o")
 for v in "$@"; do
   tag=${v%%:*}
-  hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/lib_$tag.so $OTHERS build/variants/${SRC}_$tag.o -L/opt/rocm/lib -lrocblas
+  hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/lib_$tag.so $OTHERS build/variants/${SRC}_$tag.o
   rm -f build/variants/${SRC}_$tag.o
 done
 ls -la build/variants/*.so
