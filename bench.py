@@ -61,9 +61,10 @@ def parse():
     ap.add_argument("--no_cpu_render", action="store_true", help="skip the 64x64 CPU renders (cuda_ray on and off) of BASELINE.md §3 (i)")
     ap.add_argument("--no_seal", action="store_true", help="skip the configs[2] (Seal bbox distillation) section")
     ap.add_argument("--no_tensorf", action="store_true", help="skip the configs[4] (TensoRF VM-48 training step) section")
-    ap.add_argument("--no_long_run", action="store_true", help="skip the 2 x 3,000-step convergence comparison (psnr.long_run)")
-    ap.add_argument("--long_run_steps", type=int, default=3000)
+    ap.add_argument("--no_long_run", action="store_true", help="skip the 2 x 6,000-step convergence comparison (psnr.long_run)")
+    ap.add_argument("--long_run_steps", type=int, default=6000)
     ap.add_argument("--long_run_seeds", type=int, default=8)
+    ap.add_argument("--long_run_views", type=int, default=16, help="held-out views of the long-run PSNR (400x400 each)")
     ap.add_argument("--seal_teacher_steps", type=int, default=256)
     ap.add_argument("--seal_point_step", type=float, default=0.005, help="pretraining_local_point_step (readme.md:109)")
     ap.add_argument("--seal_surrounding_step", type=float, default=0.01, help="pretraining_surrounding_point_step (main_SealNeRF.py:98; <= 0: off)")
@@ -685,7 +686,7 @@ def seal_tensorf_section(args, dev, batches, note=lambda m: None, res=300):
 
 
 # ----------------------------------------------------------------------------- quality over a long run
-def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m: None, seeds=3):
+def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m: None, seeds=3, n_views=4, hw=200):
     """Does the native fp16 path (fp16 table gradients, exact fixed-point sums, native Adam + loss scaling, HIP-graph replay)
     CONVERGE like the reference arrangement (torch.optim.Adam on fp32 `.grad`s + torch GradScaler, eager)?  Both train
     configs[1]'s network from the same initial weights on the same batches for `steps` steps (lr 1e-2 decayed to 0.1x as
@@ -698,8 +699,8 @@ def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m:
     from nerf.trainer import GraphedTrainer, Trainer, psnr
     kw = dict(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10)
     pool, _ = make_batches(768, args.num_rays, 4242, dev, R, scene_bits, boxes)  # 3.1 M distinct rays of the 100 training cameras
-    views = syn.orbit_poses(4, seed=977)  # not among the 100 training cameras (seed 0)
-    rays = [syn.get_rays(views[i:i + 1].to(dev), syn.lego_intrinsics(200, 200), 200, 200) for i in range(4)]
+    views = syn.orbit_poses(n_views, seed=977)  # not among the 100 training cameras (seed 0)
+    rays = [syn.get_rays(views[i:i + 1].to(dev), syn.lego_intrinsics(hw, hw), hw, hw) for i in range(n_views)]
     gts = [analytic_targets(r["rays_o"][0].contiguous(), r["rays_d"][0].contiguous(), scene_bits, boxes, R) for r in rays]
     tags = (("native_fp16_graph", True), ("torch_adam_fp32_eager", False))
     runs = {t: [] for t, _ in tags}
@@ -736,8 +737,9 @@ def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m:
     out["delta_db_per_seed"] = [round(x, 3) for x in d]
     out["delta_db"] = float(np.mean(d))
     out["delta_db_std"] = float(np.std(d, ddof=1)) if len(d) > 1 else 0.0
-    # the paired difference's standard error and 95 % interval (Student t): per-seed differences scatter with sigma ~0.5 dB
-    # (profiles/r10_psnr_seeds*.json: 16 / 64 seeds), so ONE mean of few seeds cannot resolve 0.1 dB
+    # the paired difference's standard error and 95 % interval (Student t): per-seed differences scatter with sigma ~0.25 dB at
+    # 6,000 steps / 16 views of 400x400 (profiles/r11_psnr_seeds96.json; ~0.5 dB at 3,000 steps / 4 views of 200x200,
+    # profiles/r10_psnr_seeds*.json), so a mean of few seeds cannot resolve 0.1 dB: the 96-seed study settles it
     sem = out["delta_db_std"] / math.sqrt(len(d)) if len(d) > 1 else float("nan")
     t975 = {2: 12.706, 3: 4.303, 4: 3.182, 5: 2.776, 6: 2.571, 7: 2.447, 8: 2.365, 12: 2.201, 16: 2.131, 32: 2.040, 64: 1.998}
     tq = t975[max(k for k in t975 if k <= max(len(d), 2))]
@@ -745,7 +747,7 @@ def long_run_quality(args, dev, R, scene_bits, boxes, steps=3000, note=lambda m:
     out["delta_db_ci95"] = [out["delta_db"] - tq * sem, out["delta_db"] + tq * sem]
     out["within_0p1_db"] = bool(abs(out["delta_db"]) <= 0.1)
     out["ci95_overlaps_0p1_db"] = bool(out["delta_db_ci95"][0] <= 0.1 and out["delta_db_ci95"][1] >= -0.1)
-    out["views"] = "4 held-out 200x200 orbit cameras (seed 977), analytic box scene"
+    out["views"] = f"{n_views} held-out {hw}x{hw} orbit cameras (seed 977), analytic box scene"
     return out
 
 
@@ -1061,15 +1063,18 @@ def main():
         extra["psnr"] = psnr_vs_oracle(model, lambda: Net(bound=1, cuda_ray=True, density_scale=1, min_near=0.2, density_thresh=10),
                                        poses, scene_bits, boxes, dev, R)
     if world == 1 and not args.no_long_run and args.net == "ff":
-        lr_ = long_run_quality(args, dev, R, scene_bits, boxes, steps=args.long_run_steps, note=note, seeds=args.long_run_seeds)
+        lr_ = long_run_quality(args, dev, R, scene_bits, boxes, steps=args.long_run_steps, note=note, seeds=args.long_run_seeds,
+                               n_views=args.long_run_views, hw=400)
         # the committed many-seed study of the same comparison (tools/psnr_seeds.py): what settles "within 0.1 dB"
-        study = os.path.join(REPO, "profiles", "r10_psnr_seeds64.json")
+        study = os.path.join(REPO, "profiles", "r11_psnr_seeds96.json")
         if os.path.exists(study):
             try:
                 st = json.load(open(study))
-                lr_["many_seed_study"] = {"file": "profiles/r10_psnr_seeds64.json", "seeds": st["seeds"], "steps": st["steps"],
-                                          "delta_db": st["delta_db"], "delta_db_sem": st["delta_db_sem"],
-                                          "delta_db_ci95": st["delta_db_ci95"], "within_0p1_db": st["within_0p1_db"]}
+                ci = st["delta_db_ci95"]
+                lr_["many_seed_study"] = {"file": "profiles/r11_psnr_seeds96.json", "seeds": st["seeds"], "steps": st["steps"], "views": st.get("views"),
+                                          "delta_db": st["delta_db"], "delta_db_sem": st["delta_db_sem"], "delta_db_std": st["delta_db_std"],
+                                          "delta_db_ci95": ci, "ci95_half_width_db": (ci[1] - ci[0]) / 2,
+                                          "within_0p1_db": st["within_0p1_db"], "ci95_inside_0p1_db": bool(ci[0] >= -0.1 and ci[1] <= 0.1)}
             except (OSError, ValueError, KeyError):
                 pass
         extra.setdefault("psnr", {})["long_run"] = lr_

@@ -32,6 +32,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=16)
     ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--hw", type=int, default=200)
     ap.add_argument("--tag", default="default")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
@@ -46,7 +48,7 @@ def main():
     _, bits = syn.lego_like_density_grid(seed=0)
     scene_bits = torch.from_numpy(bits).to(dev)
     boxes = syn.lego_like_boxes(0)
-    out = bench.long_run_quality(args, dev, R, scene_bits, boxes, steps=a.steps, seeds=a.seeds,
+    out = bench.long_run_quality(args, dev, R, scene_bits, boxes, steps=a.steps, seeds=a.seeds, n_views=a.views, hw=a.hw,
                                  note=lambda m: print("[psnr_seeds]", m, file=sys.stderr, flush=True))
     n = a.seeds
     for tag in ("native_fp16_graph", "torch_adam_fp32_eager"):
