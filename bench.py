@@ -22,6 +22,7 @@ import argparse
 import json
 import math
 import os
+import re
 import sys
 import time
 
@@ -1000,8 +1001,11 @@ def main():
                                 "frac_of_bound": ach / bound, "frac_of_mfma_peak": ach / mfma_peak, "avg_us": k["avg_us"],
                                 "samples_per_launch": k["units"], "flop_per_sample": flops, "algorithmic_bytes_per_sample": byts}
     if roofline_ffmlp:
-        roofline_ffmlp["counters"] = ("profiles/r09_timed_region.md (SQ_INSTS_MFMA, SQ_VALU_MFMA_BUSY_CYCLES per kernel): issued MFMA work = "
-                                      "1.14x / 1.09x the algorithmic work of the density / colour net (16-row output layer on a 32-row tile)")
+        import glob as _glob
+        _tr = sorted(f for f in _glob.glob(os.path.join(REPO, "profiles", "r*_timed_region.md")) if re.match(r"r\d+_timed_region\.md$", os.path.basename(f)))
+        roofline_ffmlp["counters"] = ((f"profiles/{os.path.basename(_tr[-1])}" if _tr else "no committed profile") +
+                                      ", section 'Matrix cores' (SQ_INSTS_VALU_MFMA_MOPS_F16, SQ_VALU_MFMA_BUSY_CYCLES per kernel); issued MFMA "
+                                      "work = 1.14x / 1.09x the algorithmic work of the density / colour net (16-row output layer on a 32-row tile)")
 
     extra = {"roofline_ffmlp": roofline_ffmlp, "samples_per_s_64steps": long_run}
     collectives_in_graph = bool(getattr(trainer, "collectives_in_graph", False))  # (the Seal section below drops `trainer`)

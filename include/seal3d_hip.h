@@ -306,8 +306,8 @@ int s3d_freq_encode_pack_backward(const uint16_t* grad, const uint16_t* a, uint3
  * forward_buffer / backward_buffer: [n, B, W] post-activation / pre-activation-gradient scratch.
  * B must be a multiple of 128 (ffmlp.py:156-159 pads); in % 16 == 0; out == 16; W in {16,32,64,128,256} (ffmlp.cu:40-44).
  * W in {32,64} with in <= 64 (every network of the BASELINE configs) run on the register-resident MFMA kernels and have all
- * the extensions below; the other shapes take a layer-by-layer path (one rocBLAS GEMM per matrix, fp16 storage / fp32
- * accumulation, csrc/ffmlp_generic.hip) that implements the reference's interface only: forward_buffer / backward_buffer
+ * the extensions below; the other shapes take a layer-by-layer path (hand-written MFMA kernels k_layer / k_wgrad_tile / k_wgrad_finish, fp16
+ * storage / fp32 accumulation, csrc/ffmlp_generic.hip; the library links no BLAS) that implements the reference's interface only: forward_buffer / backward_buffer
  * are then REQUIRED for training (plain row-major [n, B, W]) and inference_buffer must hold [2, B, W].
  * input_layout: 0 = inputs [B,in] row-major (the reference); 1 = level-major [in/2][B][2], i.e. the grid
  * encoder's own output layout read in place (and grad_inputs written in it) — no permute copies in between.

@@ -397,7 +397,18 @@ __device__ __forceinline__ long long vm_fixed(float v, float scale) {
     return (long long)(int)hi * 16777216ll + (long long)__float2int_rn(lo);
 }
 __device__ __forceinline__ void vm_lds_add(long long* a, long long q) {
+#ifdef S3D_VM_EXP_NOLDSADD  // timing experiment only (wrong sums): what the LDS atomics cost
+    if (q == 0x7fffffffffffffffll) *a = q;
+#else
     atomicAdd(reinterpret_cast<unsigned long long*>(a), (unsigned long long)q);
+#endif
+}
+__device__ __forceinline__ void vm_flush_add(float* dst, float v) {
+#ifdef S3D_VM_EXP_PLAINFLUSH  // timing experiment only (wrong sums where segments share cells): what the global atomics cost
+    *dst = v;
+#else
+    atomicAdd(dst, v);
+#endif
 }
 // scale for a bound given as two (three) factors' bit patterns; returns false when there is nothing to add (a zero factor)
 // and sets `poison` when a factor is not finite (the gradient is then non-finite as the float sums would be)
@@ -642,7 +653,7 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
                 if (cx < W && cy < H) {
                     float* dst = &dP[rr * plane_stride + (size_t)cy * W + cx];
                     if (whole && lx >= 1 && lx < kVmTile && ly >= 1 && ly < kVmTile) *dst = (float)qv * inv;
-                    else atomicAdd(dst, (float)qv * inv);
+                    else vm_flush_add(dst, (float)qv * inv);
                 }
             }
         }
@@ -669,6 +680,297 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
                 for (uint32_t w = 0; w < NWV; w++) sum += red[(w * HC + e / 64) * 64 + rr];
                 if (rr < R && c < b.Cb && sum != 0.0f) atomicAdd(&b.d_basis[(size_t)c * b.rows + f.row0[i] + rr], sum);
             }
+        }
+    }
+}
+
+// ---- plane backward, ranks a multiple of 16: 32 points per wave trip, matrix cores for basis_mat ----
+// The kernel above gives a wave ONE point (lanes = rank channels): at rank 48 a quarter of the lanes idle and, behind basis_mat,
+// every lane walks two 32-term dot products per point on the VALU (277 vector instructions per point and wave,
+// profiles/r10_tensorf.md; with every atomic switched off the kernel still takes 265 of its 331 us, profiles/r11_tensorf_vm.md).
+// Here a wave takes 32 sorted points of the segment per trip.  Lane (a = lane & 15, q4 = lane >> 4):
+//   1. lanes 0..31 locate one point each and leave a 48-byte record (id, corner flags, window cell, line cell, six weights) in
+//      the wave's LDS scratch; the ids / coordinates of the NEXT trip are requested before this trip's arithmetic.
+//   2. basis_mat (MODE 2): G[p][r] = sum_c g_out[p][c] W[c][r] on v_mfma_f32_16x16x32_f16 — A = the points' g_out rows (one
+//      16-byte load per lane, channels 8 q4 ..; row a of block pb is the trip's point 8 (a >> 2) + 4 pb + (a & 3)), B = W^T block
+//      rb (registers, loaded once), K = 32 = padded Cb.  The result arrives as D[row 4 q4 + e][col = rank a]: lane (a, q4) owns
+//      rank channel 16 rb + a of the points 8 q4 + 4 pb + e — EIGHT CONSECUTIVE sorted positions — so in everything that follows
+//      the sixteen lanes of a group work on ONE point and sixteen ADJACENT rank channels: line values, plane values, the
+//      fixed-point LDS adds and the g m stores are 64 contiguous bytes (128 for the 64-bit accumulators) per group, four points
+//      (eight positions apart) per instruction.  [The first 32-point arrangement had points along the lanes and four rank
+//      channels per lane: sixteen different window cells per LDS instruction at a cell stride of 96 words put 64 lanes on 16
+//      banks — 422 us, 220 of them in the LDS adds, against 331 us for the kernel above; profiles/r11_tensorf_vm.md.]
+//   3. dW[c][r] += sum_p g_out[p][c] prod[p][r]: K = the trip's 32 points in their sorted order, k = 8 q4 + j <-> the lane's own
+//      eight points, which makes the B operand exactly the eight fp16 products the lane has just computed; only g_out^T crosses
+//      the wave's LDS scratch.  fp32 accumulators stay in registers until the end of the kernel.
+// A workgroup's range of the sorted order is moved to tile boundaries: a tile of at most 2 x `pts_plane` points (every tile of
+// the Lego batches: ~450 occupied tiles per plane, 240 points on average, the largest ~900) is processed whole by the workgroup
+// its first position falls to, so its inner 7 x 7 cells leave as plain stores (2,352 of the 3,888 global atomics of a tile flush
+// at rank 48 go away; larger tiles are split at the nominal boundaries as before).
+// Same fixed-point accumulation, flush and bound words as the kernel above; MODE 0 / 1 (no basis_mat; g [N] / [N, rows]).
+typedef _Float16 vm_half8 __attribute__((ext_vector_type(8)));
+typedef float vm_float4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kVmMmThreads = 512, kVmMmWaves = kVmMmThreads / 64;
+constexpr uint32_t kVmMmRec = 12;      // words per point record (three 16-byte reads)
+constexpr uint32_t kVmMmStride = 40;   // halves per row of the g_out^T scratch (32 points + pad: rows start 16-byte aligned)
+constexpr uint32_t kVmFlagX0 = 1, kVmFlagX1 = 2, kVmFlagY0 = 4, kVmFlagY1 = 8, kVmFlagZ0 = 16, kVmFlagZ1 = 32, kVmFlagLive = 64;
+__host__ __device__ constexpr size_t vm_mm_smem(uint32_t RB, bool basis) {
+    const size_t R = 16 * RB;
+    const size_t s = (size_t)kVmTileCells * R * 12 + (size_t)kVmMmWaves * (32 * kVmMmRec * 4 + (basis ? 32 * kVmMmStride * 2 : 0));
+    const size_t red = basis ? (size_t)kVmMmWaves * 2 * RB * 256 * 4 : 0;  // the end-of-kernel sum of basis_mat's gradient
+    return s > red ? s : red;
+}
+__device__ __forceinline__ void vm_wave_lds_fence() {  // this wave's LDS writes before its later LDS reads (in order in hardware; this pins the compiler)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// the range [begin, end) of workgroup `blk` moved to the boundaries of small tiles / chunks (see above); t = the unit of `begin`
+__device__ __forceinline__ bool vm_aligned_range(const int32_t* __restrict__ st, int nunits, uint32_t blk, uint32_t pts, uint32_t whole_max,
+                                                 uint32_t valid_end, uint32_t& begin, uint32_t& end, int& t) {
+    begin = blk * pts;
+    if (begin >= valid_end) return false;
+    end = begin + pts < valid_end ? begin + pts : valid_end;
+    auto unit_of = [&](uint32_t pos) {  // the last u with st[u] <= pos (empty units repeat their neighbour's start)
+        int lo = 0, hi = nunits;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((uint32_t)st[mid] <= pos) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    t = unit_of(begin);
+    if ((uint32_t)st[t] < begin && (uint32_t)st[t + 1] - (uint32_t)st[t] <= whole_max) begin = (uint32_t)st[t + 1];  // an earlier workgroup's
+    if (end < valid_end) {
+        const int te = unit_of(end);
+        if ((uint32_t)st[te] < end && (uint32_t)st[te + 1] - (uint32_t)st[te] <= whole_max) end = (uint32_t)st[te + 1];  // whole, and mine (or nobody's: begin == end)
+    }
+    return begin < end;
+}
+template <int RB, int MODE>
+__global__ void __launch_bounds__(kVmMmThreads, 4) k_vm_plane_backward_mm(const float* __restrict__ x, uint32_t N, VmFactors f, VmBackward b) {
+    constexpr bool BASIS = MODE == 2;
+    constexpr uint32_t R = 16 * RB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem_raw[];
+    const uint32_t i = blockIdx.y;
+    const int W = (int)f.W[i], H = (int)f.H[i], Dn = (int)f.Dn[i];
+    const int tiles_x = (W + kVmTile - 1) / kVmTile, tiles_y = (H + kVmTile - 1) / kVmTile;
+    const int ntiles = tiles_x * tiles_y;
+    const int32_t* __restrict__ st = b.start + (size_t)i * b.n_bounds;
+    const uint32_t valid_end = (uint32_t)st[ntiles];
+    float scale = 1.0f, inv = 1.0f;
+    bool poison;
+    float bound = __uint_as_float(b.bound[0]) * __uint_as_float(b.bound[1]);
+    if constexpr (BASIS) bound *= __uint_as_float(b.bound[3]);
+    if (!vm_scale(bound, scale, inv, poison)) {
+        if (poison && blockIdx.x == 0 && threadIdx.x == 0) {
+            b.d_plane[i][0] = NAN;
+            if (b.found_inf) *b.found_inf = 1.0f;
+        }
+        return;
+    }
+    uint32_t begin, end;
+    int t;
+    if (!vm_aligned_range(st, ntiles, blockIdx.x, b.pts_plane, 2 * b.pts_plane < kVmMaxPts ? 2 * b.pts_plane : kVmMaxPts, valid_end, begin, end, t)) return;
+    long long* acc = reinterpret_cast<long long*>(vm_smem_raw);                  // [81][R]
+    float* pv = reinterpret_cast<float*>(acc + kVmTileCells * R);                // [81][R]
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t a = lane & 15, q4 = lane >> 4, pl = lane & 31;
+    uint32_t* rec = reinterpret_cast<uint32_t*>(pv + kVmTileCells * R) + (size_t)wave * 32 * kVmMmRec;  // [32][kVmMmRec]
+    _Float16* sc = reinterpret_cast<_Float16*>(reinterpret_cast<uint32_t*>(pv + kVmTileCells * R) + (size_t)kVmMmWaves * 32 * kVmMmRec) +
+                   (size_t)wave * 32 * kVmMmStride;                                                     // [32 channels][kVmMmStride]
+    const float* __restrict__ P = f.plane[i];
+    const size_t plane_stride = (size_t)H * W;
+    const int32_t* __restrict__ perm = b.perm + (size_t)i * N;
+    const float* __restrict__ Lt = b.line_t + b.line_t_off[i];  // [Dn][R]
+    float* __restrict__ gm = b.gm;
+    const uint32_t row0 = f.row0[i];
+    vm_half8 wb[BASIS ? RB : 1];                      // B operand of G: k = c = 8 q4 + j, col = rank 16 rb + a
+    vm_float4 dwacc[BASIS ? 2 : 1][BASIS ? RB : 1];   // dW[c = 16 cb + 4 q4 + e][r = 16 rb + a]
+    if constexpr (BASIS) {
+#pragma unroll
+        for (uint32_t rb = 0; rb < (uint32_t)RB; rb++) {
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const uint32_t c = 8 * q4 + j;
+                wb[rb][j] = c < b.Cb ? b.basis[(size_t)c * b.rows + row0 + 16 * rb + a] : (_Float16)0.0f;
+            }
+#pragma unroll
+            for (uint32_t cb = 0; cb < 2; cb++) dwacc[cb][rb] = vm_float4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
+    for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += kVmMmThreads) acc[e] = 0ll;
+    float gm_max = 0.0f;
+    uint32_t pos = begin;
+    while (pos < end) {
+        while ((uint32_t)st[t + 1] <= pos) t++;
+        const uint32_t seg_end = (uint32_t)st[t + 1] < end ? (uint32_t)st[t + 1] : end;
+        const int cx0 = (t % tiles_x) * kVmTile, cy0 = (t / tiles_x) * kVmTile;
+        // the first trip's ids and coordinates are requested before the tile's plane values
+        constexpr uint32_t STEP = kVmMmWaves * 32;
+        const uint32_t kf = pos + wave * 32 + pl;
+        uint32_t n_nx = kf < seg_end ? (uint32_t)perm[kf] : 0u;
+        uint32_t n_nx2 = kf + STEP < seg_end ? (uint32_t)perm[kf + STEP] : 0u;
+        VmXyz p_nx = kf < seg_end ? vm_load_xyz(x, n_nx, f, i) : VmXyz{0.0f, 0.0f, 0.0f};
+        for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += kVmMmThreads) {
+            const uint32_t rr = e / kVmTileCells, c = e % kVmTileCells;
+            const int cy = cy0 + (int)(c / (kVmTile + 1)), cx = cx0 + (int)(c % (kVmTile + 1));
+            pv[c * R + rr] = (cx < W && cy < H) ? P[rr * plane_stride + (size_t)cy * W + cx] : 0.0f;
+        }
+        __syncthreads();  // plane values in place; accumulator clear (start of the kernel / previous flush)
+        for (uint32_t k0 = pos + wave * 32; k0 < seg_end; k0 += STEP) {
+            // ---- 1. one point per lane (lanes 32..63 mirror 0..31): record
+            const uint32_t k = k0 + pl;
+            const bool okp = k < seg_end;
+            const uint32_t n = n_nx;
+            const VmXyz p_cur = p_nx;
+            n_nx = n_nx2;
+            if (k + STEP < seg_end) p_nx = vm_load_xyz(x, n_nx, f, i);
+            if (k + 2 * STEP < seg_end) n_nx2 = (uint32_t)perm[k + 2 * STEP];
+            {
+                const VmPoint q = vm_locate_xyz(p_cur, f, i);
+                uint32_t fl = kVmFlagLive;
+                if (q.x0 >= 0 && q.x0 < W) fl |= kVmFlagX0;
+                if (q.x0 + 1 >= 0 && q.x0 + 1 < W) fl |= kVmFlagX1;
+                if (q.y0 >= 0 && q.y0 < H) fl |= kVmFlagY0;
+                if (q.y0 + 1 >= 0 && q.y0 + 1 < H) fl |= kVmFlagY1;
+                if (q.z0 >= 0 && q.z0 < Dn) fl |= kVmFlagZ0;
+                if (q.z0 + 1 >= 0 && q.z0 + 1 < Dn) fl |= kVmFlagZ1;
+                const int c_nw = (q.y0 - cy0) * (kVmTile + 1) + (q.x0 - cx0);  // nw corner inside the tile's 9x9 window: -1 .. 7 per axis
+                if (lane < 32) {
+                    uint4* r4 = reinterpret_cast<uint4*>(rec + pl * kVmMmRec);
+                    r4[0] = make_uint4(okp ? n : 0u, okp ? fl : 0u, (uint32_t)c_nw, (uint32_t)q.z0);  // (absent rows: no flag set, id 0)
+                    r4[1] = make_uint4(__float_as_uint(q.nw), __float_as_uint(q.ne), __float_as_uint(q.sw), __float_as_uint(q.se));
+                    r4[2] = make_uint4(__float_as_uint(q.lz0), __float_as_uint(q.lz1), 0u, 0u);
+                }
+            }
+            // ---- 2. basis_mat: the points' output gradients, G = g_out W on the matrix cores, g_out^T for the dW product
+            vm_float4 G[2][BASIS ? RB : 1];
+            if constexpr (BASIS) {
+#pragma unroll
+                for (uint32_t pb = 0; pb < 2; pb++) {
+                    // row a of block pb <-> the trip's point kk = 8 (a >> 2) + 4 pb + (a & 3): the result rows 4 q4 + e of block pb are
+                    // then the points 8 q4 + 4 pb + e — a lane walks EIGHT CONSECUTIVE sorted positions (neighbouring samples of a ray:
+                    // every second one in the cell of its predecessor), and the four groups of an instruction are eight positions apart
+                    const uint32_t kk = 8 * (a >> 2) + 4 * pb + (a & 3);  // = its column in the K order of the dW product
+                    const uint32_t n_p = (uint32_t)__shfl((int)n, (int)kk, 64);
+                    const bool ok_p = k0 + kk < seg_end;
+                    vm_half8 gA;
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) gA[j] = (_Float16)0.0f;
+                    if (ok_p) gA = *reinterpret_cast<const vm_half8*>(b.g_out + (size_t)n_p * kVmBasisPad + 8 * q4);
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; j++) sc[(8 * q4 + j) * kVmMmStride + kk] = gA[j];
+#pragma unroll
+                    for (uint32_t rb = 0; rb < (uint32_t)RB; rb++)
+                        G[pb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gA, wb[rb], vm_float4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+                }
+            }
+            vm_wave_lds_fence();  // records (and g_out^T) written
+            // ---- 3. per point: sixteen lanes = sixteen adjacent rank channels.  [Measured and dropped, profiles/r11_tensorf_vm.md: adding
+            // the fixed-point contributions of consecutive points in the SAME cell (about half of them) in registers before one LDS add
+            // per run — the run logic's branches serialise the points' loads (342 us), with the loads hoisted in front it spills at 128
+            // registers (500 us), and the rank-16 kernel, which does neither, gains nothing (142 vs 143 us).]
+            vm_half8 prod[BASIS ? RB : 1];  // [rb][4 pb + e]: the B operand of the dW product
+#pragma unroll
+            for (uint32_t pb = 0; pb < 2; pb++) {
+#pragma unroll
+                for (uint32_t e = 0; e < 4; e++) {
+                    const uint32_t pt = 8 * q4 + 4 * pb + e;
+                    const uint4* r4 = reinterpret_cast<const uint4*>(rec + pt * kVmMmRec);
+                    const uint4 ra = r4[0], rw = r4[1];
+                    const uint2 rl = *reinterpret_cast<const uint2*>(r4 + 2);
+                    const uint32_t n_p = ra.x, fl = ra.y;
+                    const int c_nw = (int)ra.z, z0 = (int)ra.w;
+                    if constexpr (BASIS) {
+#pragma unroll
+                        for (uint32_t rb = 0; rb < (uint32_t)RB; rb++) prod[rb][4 * pb + e] = (_Float16)0.0f;
+                    }
+                    if (!(fl & kVmFlagLive)) continue;
+                    const float nw = __uint_as_float(rw.x), ne = __uint_as_float(rw.y), sw = __uint_as_float(rw.z), se = __uint_as_float(rw.w);
+                    const float lz0 = __uint_as_float(rl.x), lz1 = __uint_as_float(rl.y);
+                    const bool c00 = (fl & kVmFlagX0) && (fl & kVmFlagY0), c10 = (fl & kVmFlagX1) && (fl & kVmFlagY0);
+                    const bool c01 = (fl & kVmFlagX0) && (fl & kVmFlagY1), c11 = (fl & kVmFlagX1) && (fl & kVmFlagY1);
+                    float l0v[RB], l1v[RB], gv[RB];
+#pragma unroll
+                    for (uint32_t rb = 0; rb < (uint32_t)RB; rb++) {
+                        const uint32_t r = 16 * rb + a;
+                        l0v[rb] = (fl & kVmFlagZ0) ? Lt[(size_t)z0 * R + r] : 0.0f;
+                        l1v[rb] = (fl & kVmFlagZ1) ? Lt[(size_t)(z0 + 1) * R + r] : 0.0f;
+                        if constexpr (BASIS) gv[rb] = G[pb][rb][e];
+                        else if constexpr (MODE == 1) gv[rb] = b.g[(size_t)n_p * b.rows + row0 + r];
+                        else gv[rb] = b.g[n_p];
+                    }
+#pragma unroll
+                    for (uint32_t rb = 0; rb < (uint32_t)RB; rb++) {
+                        const uint32_t r = 16 * rb + a;
+                        float l = 0.0f;
+                        if (fl & kVmFlagZ0) l += l0v[rb] * lz0;
+                        if (fl & kVmFlagZ1) l += l1v[rb] * lz1;
+                        const float g = gv[rb], gl = g * l;
+                        float m = 0.0f;
+                        if (c00) { m += pv[c_nw * (int)R + (int)r] * nw; vm_lds_add(&acc[c_nw * (int)R + (int)r], vm_fixed(gl * nw, scale)); }
+                        if (c10) { m += pv[(c_nw + 1) * (int)R + (int)r] * ne; vm_lds_add(&acc[(c_nw + 1) * (int)R + (int)r], vm_fixed(gl * ne, scale)); }
+                        if (c01) { m += pv[(c_nw + kVmTile + 1) * (int)R + (int)r] * sw; vm_lds_add(&acc[(c_nw + kVmTile + 1) * (int)R + (int)r], vm_fixed(gl * sw, scale)); }
+                        if (c11) { m += pv[(c_nw + kVmTile + 2) * (int)R + (int)r] * se; vm_lds_add(&acc[(c_nw + kVmTile + 2) * (int)R + (int)r], vm_fixed(gl * se, scale)); }
+                        const float gmv = g * m;
+                        gm[(size_t)n_p * b.rows + row0 + r] = gmv;
+                        gm_max = fmaxf(gm_max, fabsf(gmv));
+                        if constexpr (BASIS) prod[rb][4 * pb + e] = (_Float16)(m * l);  // (the Linear's fp16 input, as in the forward)
+                    }
+                }
+            }
+            // ---- 4. basis_mat's gradient on the matrix cores
+            if constexpr (BASIS) {
+#pragma unroll
+                for (uint32_t cb = 0; cb < 2; cb++) {
+                    const vm_half8 gT = *reinterpret_cast<const vm_half8*>(sc + (16 * cb + a) * kVmMmStride + 8 * q4);
+#pragma unroll
+                    for (uint32_t rb = 0; rb < (uint32_t)RB; rb++)
+                        dwacc[cb][rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(gT, prod[rb], dwacc[cb][rb], 0, 0, 0);
+                }
+            }
+            vm_wave_lds_fence();  // scratch read before the next trip overwrites it
+        }
+        __syncthreads();
+        float* dP = b.d_plane[i];
+        const bool whole = pos == (uint32_t)st[t] && seg_end == (uint32_t)st[t + 1];
+        for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += kVmMmThreads) {
+            const uint32_t rr = e / kVmTileCells, c = e % kVmTileCells;
+            const int ly = (int)(c / (kVmTile + 1)), lx = (int)(c % (kVmTile + 1));
+            const int cy = cy0 + ly, cx = cx0 + lx;
+            const long long qv = acc[c * R + rr];
+            if (qv != 0ll) {
+                acc[c * R + rr] = 0ll;
+                if (cx < W && cy < H) {
+                    float* dst = &dP[rr * plane_stride + (size_t)cy * W + cx];
+                    if (whole && lx >= 1 && lx < kVmTile && ly >= 1 && ly < kVmTile) *dst = (float)qv * inv;
+                    else vm_flush_add(dst, (float)qv * inv);
+                }
+            }
+        }
+        pos = seg_end;
+    }
+    gm_max = wave_max(gm_max);
+    if (lane == 0 && gm_max > 0.0f) atomicMax(b.bound + 2, __float_as_uint(gm_max));
+    if constexpr (BASIS) {
+        // basis_mat's gradient: the waves' register tiles are added in LDS (fixed order), one global atomic per (c, r) and workgroup
+        float* red = reinterpret_cast<float*>(vm_smem_raw);  // [waves][2 RB tiles][64 lanes][4]
+        __syncthreads();
+#pragma unroll
+        for (uint32_t cb = 0; cb < 2; cb++)
+#pragma unroll
+            for (uint32_t rb = 0; rb < (uint32_t)RB; rb++)
+                *reinterpret_cast<vm_float4*>(red + ((size_t)(wave * 2 * RB + cb * RB + rb) * 64 + lane) * 4) = dwacc[cb][rb];
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < 2 * RB * 256; e += kVmMmThreads) {
+            const uint32_t blk = e / 256, ln = (e % 256) / 4, ee = e % 4;
+            const uint32_t cb = blk / RB, rb = blk % RB;
+            float sum = 0.0f;
+#pragma unroll
+            for (uint32_t w = 0; w < kVmMmWaves; w++) sum += red[((size_t)(w * 2 * RB + blk) * 64 + ln) * 4 + ee];
+            const uint32_t c = 16 * cb + 4 * (ln >> 4) + ee, rr = 16 * rb + (ln & 15);
+            if (c < b.Cb && sum != 0.0f) atomicAdd(&b.d_basis[(size_t)c * b.rows + row0 + rr], sum);
         }
     }
 }
@@ -741,7 +1043,97 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_line_backward(const float*
             const long long qv = acc[e];
             if (qv != 0ll) {
                 acc[e] = 0ll;
-                if (zb + (int)z < Dn) atomicAdd(&dL[(size_t)rr * Dn + zb + z], (float)qv * inv);
+                if (zb + (int)z < Dn) vm_flush_add(&dL[(size_t)rr * Dn + zb + z], (float)qv * inv);
+            }
+        }
+        pos = seg_end;
+    }
+}
+
+// line backward, ranks a multiple of 16: the lane assignment of k_vm_plane_backward_mm (32 points per wave trip; the sixteen
+// lanes of a group = sixteen adjacent rank channels of one point, four points per instruction): lanes 0..31 leave (id, cell in
+// the chunk, the two weights) in the wave's scratch, g m arrives as 64 contiguous bytes per group.  Ranges moved to the
+// boundaries of small chunks like the plane pass (a chunk is usually larger than a range: then nothing changes).
+template <int RB>
+__global__ void __launch_bounds__(kVmMmThreads) k_vm_line_backward_mm(const float* __restrict__ x, uint32_t N, VmFactors f, VmBackward b) {
+    constexpr uint32_t R = 16 * RB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char vm_smem_raw[];
+    const uint32_t i = blockIdx.y;
+    const int Dn = (int)f.Dn[i];
+    const int nchunks = (Dn + kVmZChunk - 1) / kVmZChunk;
+    const int32_t* __restrict__ st = b.start + (size_t)(3 + i) * b.n_bounds;
+    const uint32_t valid_end = (uint32_t)st[nchunks];
+    float scale = 1.0f, inv = 1.0f;
+    bool poison;
+    if (!vm_scale(__uint_as_float(b.bound[2]), scale, inv, poison)) {
+        if (poison && b.found_inf && blockIdx.x == 0 && threadIdx.x == 0) *b.found_inf = 1.0f;
+        return;
+    }
+    uint32_t begin, end;
+    int t;
+    if (!vm_aligned_range(st, nchunks, blockIdx.x, b.pts_line, b.pts_line, valid_end, begin, end, t)) return;
+    long long* acc = reinterpret_cast<long long*>(vm_smem_raw);                     // [65][R]
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t a = lane & 15, q4 = lane >> 4, pl = lane & 31;
+    uint4* rec = reinterpret_cast<uint4*>(acc + (kVmZChunk + 1) * R) + (size_t)wave * 32;  // [32] {id, cell, lz0, lz1 (0 where out of range)}
+    for (uint32_t e = threadIdx.x; e < (kVmZChunk + 1) * R; e += kVmMmThreads) acc[e] = 0ll;
+    const int32_t* __restrict__ perm = b.perm + (size_t)(3 + i) * N;
+    const float* __restrict__ gm = b.gm;
+    const uint32_t row0 = f.row0[i], cw = f.cw[i];
+    uint32_t pos = begin;
+    while (pos < end) {
+        while ((uint32_t)st[t + 1] <= pos) t++;
+        const uint32_t seg_end = (uint32_t)st[t + 1] < end ? (uint32_t)st[t + 1] : end;
+        const int zb = t * kVmZChunk;
+        constexpr uint32_t STEP = kVmMmWaves * 32;
+        const uint32_t kf = pos + wave * 32 + pl;
+        uint32_t n_nx = kf < seg_end ? (uint32_t)perm[kf] : 0u;
+        uint32_t n_nx2 = kf + STEP < seg_end ? (uint32_t)perm[kf + STEP] : 0u;
+        float w_nx = kf < seg_end ? x[(size_t)n_nx * 3 + cw] : 0.0f;
+        __syncthreads();  // accumulator clear (start of the kernel / previous flush)
+        for (uint32_t k0 = pos + wave * 32; k0 < seg_end; k0 += STEP) {
+            const uint32_t k = k0 + pl;
+            const uint32_t n = n_nx;
+            const float wc = w_nx;
+            n_nx = n_nx2;
+            if (k + STEP < seg_end) w_nx = x[(size_t)n_nx * 3 + cw];
+            if (k + 2 * STEP < seg_end) n_nx2 = (uint32_t)perm[k + 2 * STEP];
+            {
+                const float iz = unnormalize(wc, f.Dn[i]);
+                const float fz = floorf(iz);
+                const int z0 = (int)fz;  // (a sorted position below valid_end: finite, at least one end of the segment in range)
+                const bool bz0 = z0 >= 0 && z0 < Dn, bz1 = z0 + 1 >= 0 && z0 + 1 < Dn;
+                const float lz1 = bz1 ? iz - fz : 0.0f, lz0 = bz0 ? (fz + 1.0f) - iz : 0.0f;
+                const uint32_t fl = (k < seg_end ? 4u : 0u) | (bz0 ? 1u : 0u) | (bz1 ? 2u : 0u);
+                if (lane < 32) rec[pl] = make_uint4(k < seg_end ? n : 0u, ((uint32_t)(z0 - zb + 1) << 3) | fl, __float_as_uint(lz0), __float_as_uint(lz1));
+            }
+            vm_wave_lds_fence();
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++) {
+                const uint4 rc = rec[8 * q4 + j];
+                if (!(rc.y & 4u)) continue;
+                const int lz = (int)(rc.y >> 3) - 1;  // cell of z0 inside the chunk's 65-cell window: -1 .. 63
+                const float lz0 = __uint_as_float(rc.z), lz1 = __uint_as_float(rc.w);
+                float gv[RB];
+#pragma unroll
+                for (uint32_t rb = 0; rb < (uint32_t)RB; rb++) gv[rb] = gm[(size_t)rc.x * b.rows + row0 + 16 * rb + a];
+#pragma unroll
+                for (uint32_t rb = 0; rb < (uint32_t)RB; rb++) {
+                    const int r = (int)(16 * rb + a);
+                    if (rc.y & 1u) vm_lds_add(&acc[lz * (int)R + r], vm_fixed(gv[rb] * lz0, scale));
+                    if (rc.y & 2u) vm_lds_add(&acc[(lz + 1) * (int)R + r], vm_fixed(gv[rb] * lz1, scale));
+                }
+            }
+            vm_wave_lds_fence();
+        }
+        __syncthreads();
+        float* dL = b.d_line[i];
+        for (uint32_t e = threadIdx.x; e < (kVmZChunk + 1) * R; e += kVmMmThreads) {
+            const uint32_t z = e / R, rr = e % R;
+            const long long qv = acc[e];
+            if (qv != 0ll) {
+                acc[e] = 0ll;
+                if (zb + (int)z < Dn) vm_flush_add(&dL[(size_t)rr * Dn + zb + z], (float)qv * inv);
             }
         }
         pos = seg_end;
@@ -936,6 +1328,64 @@ static void vm_backward_geometry(VmBackward& b, uint32_t N, uint32_t max_rank, b
     smem_l = (size_t)(kVmZChunk + 1) * max_rank * sizeof(long long);
 }
 
+// the 32-points-per-trip passes (k_vm_plane_backward_mm / k_vm_line_backward_mm) serve calls whose three components share one
+// rank of 32, 48 or 64 (VM-48's colour factors); anything else — rank 16 included: 127 / 30 us on the lane-per-rank kernels
+// against 139 / 34 us here, profiles/r11_tensorf_vm.md — takes the lane-per-rank kernels.  S3D_VM_MM=0 switches them off (A/B),
+// S3D_VM_MM_PTS=plane,-,line,- sets the nominal sorted positions per workgroup (<= kVmMaxPts).
+static uint32_t vm_mm_pts(uint32_t which) {
+    static const std::array<uint32_t, 4> pts = [] {
+        std::array<uint32_t, 4> v = {512u, 512u, 2048u, 1024u};
+        if (const char* e = getenv("S3D_VM_MM_PTS")) {
+            unsigned a, b2, c, d;
+            if (sscanf(e, "%u,%u,%u,%u", &a, &b2, &c, &d) == 4 && a >= 32 && b2 >= 32 && c >= 32 && d >= 32)
+                v = {std::min(a, kVmMaxPts), std::min(b2, kVmMaxPts), std::min(c, kVmMaxPts), std::min(d, kVmMaxPts)};
+        }
+        return v;
+    }();
+    return pts[which];
+}
+template <int RB, int MODE>
+static void launch_plane_mm_t(const float* x, uint32_t N, const VmFactors& f, VmBackward& b, hipStream_t st) {
+    constexpr size_t smem = vm_mm_smem(RB, MODE == 2);
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vm_plane_backward_mm<RB, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        return true;
+    }();
+    (void)attr;
+    b.pts_plane = vm_mm_pts(0);
+    hipLaunchKernelGGL((k_vm_plane_backward_mm<RB, MODE>), dim3(div_up<uint32_t>(N, b.pts_plane), 3), dim3(kVmMmThreads), smem, st, x, N, f, b);
+}
+template <int RB>
+static void launch_line_mm_t(const float* x, uint32_t N, const VmFactors& f, VmBackward& b, hipStream_t st) {
+    b.pts_line = vm_mm_pts(2);
+    const size_t smem = (size_t)(kVmZChunk + 1) * 16 * RB * sizeof(long long) + (size_t)kVmMmWaves * 32 * sizeof(uint4);
+    hipLaunchKernelGGL((k_vm_line_backward_mm<RB>), dim3(div_up<uint32_t>(N, b.pts_line), 3), dim3(kVmMmThreads), smem, st, x, N, f, b);
+}
+static bool launch_line_mm(const float* x, uint32_t N, const VmFactors& f, VmBackward& b, hipStream_t st) {
+    static const bool on = [] { const char* e = getenv("S3D_VM_MM"); return !(e && e[0] == '0'); }();
+    if (!on || f.rank[0] != f.rank[1] || f.rank[0] != f.rank[2] || f.rank[0] % 16 != 0 || f.rank[0] < 32 || f.rank[0] > 64) return false;
+    if (reinterpret_cast<uintptr_t>(b.gm) & 15u) return false;
+    switch (f.rank[0] / 16) {
+        case 2: launch_line_mm_t<2>(x, N, f, b, st); break;
+        case 3: launch_line_mm_t<3>(x, N, f, b, st); break;
+        default: launch_line_mm_t<4>(x, N, f, b, st); break;
+    }
+    return true;
+}
+template <int MODE>
+static bool launch_plane_mm(const float* x, uint32_t N, const VmFactors& f, VmBackward& b, hipStream_t st) {
+    static const bool on = [] { const char* e = getenv("S3D_VM_MM"); return !(e && e[0] == '0'); }();
+    if (!on || f.rank[0] != f.rank[1] || f.rank[0] != f.rank[2] || f.rank[0] % 16 != 0 || f.rank[0] < 32 || f.rank[0] > 64) return false;
+    if ((reinterpret_cast<uintptr_t>(b.gm) | reinterpret_cast<uintptr_t>(b.line_t) | (MODE == 1 ? reinterpret_cast<uintptr_t>(b.g) : 0) |
+         (MODE == 2 ? reinterpret_cast<uintptr_t>(b.g_out) : 0)) & 15u) return false;
+    switch (f.rank[0] / 16) {
+        case 2: launch_plane_mm_t<2, MODE>(x, N, f, b, st); break;
+        case 3: launch_plane_mm_t<3, MODE>(x, N, f, b, st); break;
+        default: launch_plane_mm_t<4, MODE>(x, N, f, b, st); break;
+    }
+    return true;
+}
+
 S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                                         const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
                                         const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
@@ -978,14 +1428,17 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
     const size_t n_g = reduce ? (size_t)N : (size_t)N * b.rows;
     hipLaunchKernelGGL(k_vm_bound, dim3(std::min<uint32_t>(stream_grid(n_g / 4 + 1, 256), 512u)), dim3(256), 0, st, grad, n_g, (const _Float16*)nullptr, (size_t)0, f,
                        (const _Float16*)nullptr, 0u, b.rows, bound_words, line_scratch);
+    const bool mm = reduce ? launch_plane_mm<0>(x, N, f, b, st) : launch_plane_mm<1>(x, N, f, b, st);
     if (max_rank <= 16) {
-        if (reduce) hipLaunchKernelGGL((k_vm_plane_backward<16, true>), gp, block, smem_p, st, x, N, f, b);
+        if (mm) {}
+        else if (reduce) hipLaunchKernelGGL((k_vm_plane_backward<16, true>), gp, block, smem_p, st, x, N, f, b);
         else hipLaunchKernelGGL((k_vm_plane_backward<16, false>), gp, block, smem_p, st, x, N, f, b);
-        hipLaunchKernelGGL((k_vm_line_backward<16>), gl, block, smem_l, st, x, N, f, b);
+        if (!launch_line_mm(x, N, f, b, st)) hipLaunchKernelGGL((k_vm_line_backward<16>), gl, block, smem_l, st, x, N, f, b);
     } else {
-        if (reduce) hipLaunchKernelGGL((k_vm_plane_backward<64, true>), gp, block, smem_p, st, x, N, f, b);
+        if (mm) {}
+        else if (reduce) hipLaunchKernelGGL((k_vm_plane_backward<64, true>), gp, block, smem_p, st, x, N, f, b);
         else hipLaunchKernelGGL((k_vm_plane_backward<64, false>), gp, block, smem_p, st, x, N, f, b);
-        hipLaunchKernelGGL((k_vm_line_backward<64>), gl, block, smem_l, st, x, N, f, b);
+        if (!launch_line_mm(x, N, f, b, st)) hipLaunchKernelGGL((k_vm_line_backward<64>), gl, block, smem_l, st, x, N, f, b);
     }
     return check_launch("vm_features_backward");
 }
@@ -1053,8 +1506,8 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
     const size_t n_g16 = (size_t)N * kVmBasisPad;
     hipLaunchKernelGGL(k_vm_bound, dim3(std::min<uint32_t>(stream_grid(n_g16 / 8 + 1, 256), 512u)), dim3(256), 0, st, (const float*)nullptr, (size_t)0,
                        (const _Float16*)grad_out, n_g16, f, (const _Float16*)basis, basis_rows, b.rows, bound_words, line_scratch);
-    hipLaunchKernelGGL((k_vm_plane_backward<64, false, true>), gp, block, smem_p, st, x, N, f, b);
-    hipLaunchKernelGGL((k_vm_line_backward<64>), gl, block, smem_l, st, x, N, f, b);
+    if (!launch_plane_mm<2>(x, N, f, b, st)) hipLaunchKernelGGL((k_vm_plane_backward<64, false, true>), gp, block, smem_p, st, x, N, f, b);
+    if (!launch_line_mm(x, N, f, b, st)) hipLaunchKernelGGL((k_vm_line_backward<64>), gl, block, smem_l, st, x, N, f, b);
     return check_launch("vm_color_backward");
 }
 

@@ -103,7 +103,7 @@ class NeRFNetwork(NeRFRenderer):
                 and getattr(self.encoder_dir, "degree", None) == 4 and self.geo_feat_dim == 15
                 and self.sigma_net.padded_output_dim == 16 and self.color_net.input_dim == 32
                 and self.color_net.padded_output_dim == 16
-                # widths the fused MFMA kernels do not cover (hidden 16 / 128 / 256: rocBLAS layer path) take the reference's
+                # widths the fused MFMA kernels do not cover (hidden 16 / 256, wide inputs: the layer-by-layer MFMA kernels of csrc/ffmlp_generic.hip) take the reference's
                 # op sequence: the level-major / n_valid / head routes exist in the fused kernels only
                 and self._fused_mlps())
 

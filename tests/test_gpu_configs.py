@@ -767,6 +767,38 @@ def test_vm48_resolution300_backward_vs_grid_sample_autograd(hip, case):
         assert bool(((a != 0) == (b != 0)).all() or (err[(a != 0) != (b != 0)] <= tol[(a != 0) != (b != 0)]).all()), name
 
 
+@pytest.mark.parametrize("sigma_rank,color_rank,res,fused_basis", [(32, 64, 96, True), (48, 32, 72, False), (64, 48, 72, True)])
+def test_vm_matrix_core_backward_other_ranks_vs_grid_sample_autograd(hip, sigma_rank, color_rank, res, fused_basis):
+    """The 32-points-per-trip factor backward (k_vm_plane_backward_mm / k_vm_line_backward_mm: ranks 32 / 48 / 64) on the rank
+    blocks VM-48 does not use and in its three modes: density features summed over the ranks (MODE 0, sigma rank >= 32), colour
+    products handed back un-reduced (MODE 1: fused_basis off), colour behind basis_mat on the matrix cores (MODE 2) — against
+    F.grid_sample's autograd on ray-ordered marched samples, tolerance as in the VM-48 test above."""
+    from tensoRF import network as trf
+    torch.manual_seed(11)
+    net = trf.NeRFNetwork(resolution=[res] * 3, sigma_rank=[sigma_rank] * 3, color_rank=[color_rank] * 3, bound=1, cuda_ray=True).cuda()
+    x, m = _vm48_marched_samples(n_rays=2048)
+    g = torch.Generator().manual_seed(13)
+    gs = torch.randn(m, generator=g).cuda()
+    gc = (torch.randn(m, 27, generator=g) * 0.1).cuda()
+    res_ = {}
+    for fused in (True, False):
+        net.fused_vm = fused
+        net.fused_basis = fused and fused_basis
+        net.zero_grad(set_to_none=True)
+        (net.get_sigma_feat(x) * gs).sum().backward()
+        (net.get_color_feat(x).float() * gc).sum().backward()
+        res_[fused] = _factor_grads(net)
+    net.fused_vm = net.fused_basis = True
+    bound = _abs_sum_bound(net, x, gs.abs(), gc.abs())
+    for k, (a, b, bd) in enumerate(zip(res_[True], res_[False], bound)):
+        assert float(b.abs().max()) > 0, k
+        err = (a - b).abs()
+        tol = 2e-6 * bd + 1e-6 * float(b.abs().max())
+        if k == 12 and not fused_basis:
+            tol = tol + 2e-3 * float(b.abs().max())  # (basis_mat through the fp16 nn.Linear's own autograd on both sides)
+        assert bool((err <= tol).all()), (k, float((err / tol).max()), float(err.max()), float(b.abs().max()))
+
+
 def test_vm_backward_keeps_gradients_far_below_the_batch_maximum(hip):
     """the fixed-point accumulators are scaled by ONE bound per call (placed at 2^50, contributions rounded to
     nearest).  A region whose gradients lie 2^36 below the batch maximum — and, with the bound's slack (max |g| x max |line|),
