@@ -406,7 +406,12 @@ int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* plan
  * line_scratch: sum_i rank_i * resolution[vec_ids[i]] floats, no initialisation: the bound pass leaves the line factors there
  * transposed ([Dn][rank]) for the plane pass, whose lanes are rank channels.
  * found_inf (optional device float): set to 1 when a bound is not finite — the condition under which these kernels write a
- * non-finite gradient — so a GradScaler need not read the 69 MB of factor gradients again to find out. */
+ * non-finite gradient — so a GradScaler need not read the 69 MB of factor gradients again to find out.
+ * stage / stage_bytes (optional, round 6): s3d_vm_backward_stage_bytes(N, rank, resolution) bytes of 16-byte aligned device
+ * scratch, no initialisation.  With it the cells several workgroups add to (the border of a whole tile's 9x9 window, a line
+ * chunk's 65 cells) leave as plain stores into per-tile / per-workgroup rows and one extra launch adds the rows in a FIXED
+ * order; NULL (or too small): those cells take global atomics, as before.  Same sums within fp32 summation order. */
+size_t s3d_vm_backward_stage_bytes(uint32_t N, const uint32_t* rank, const uint32_t* resolution);
 uint32_t s3d_vm_backward_max_bins(const uint32_t* resolution);
 int s3d_vm_backward_keys(const float* x, uint32_t N, const uint32_t* rank, const uint32_t* resolution, int32_t* keys,
                          s3d_stream_t stream);
@@ -420,7 +425,7 @@ int s3d_vm_features_backward(const float* x, uint32_t N, const float* const* pla
                              const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
                              const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
                              float* const* grad_planes, float* const* grad_lines, uint32_t* bound_words, float* line_scratch,
-                             float* found_inf, s3d_stream_t stream);
+                             void* stage, size_t stage_bytes, float* found_inf, s3d_stream_t stream);
 
 /* The colour features with basis_mat applied inside the kernel (tensoRF/network.py:149-153: `basis_mat((mat * vec).T)`, an
  * nn.Linear(sum rank, basis_rows, bias=False) that runs under fp16 autocast): out [N, basis_rows] fp16 =
@@ -437,7 +442,8 @@ int s3d_vm_color_backward(const float* x, uint32_t N, const float* const* planes
                           const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
                           const uint16_t* grad_out, const int32_t* perm, const int32_t* start, uint32_t n_bounds,
                           float* gm, float* const* grad_planes, float* const* grad_lines, float* grad_basis,
-                          uint32_t* bound_words, float* line_scratch, float* found_inf, s3d_stream_t stream);
+                          uint32_t* bound_words, float* line_scratch, void* stage, size_t stage_bytes, float* found_inf,
+                          s3d_stream_t stream);
 
 /* Build extensions for the TensoRF step (chains of tiny launches otherwise):
  * s3d_aabb_normalize: out[n][a] = 2 (x[n][a] - aabb[a]) / (aabb[3 + a] - aabb[a]) - 1 (tensoRF/network.py:155-157, the reference's

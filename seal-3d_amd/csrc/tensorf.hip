@@ -375,7 +375,25 @@ struct VmBackward {
     uint32_t line_t_off[3];
     uint32_t pts_plane, pts_line;  // sorted points per workgroup
     float* found_inf;              // optional: raised when a bound is not finite (GradScaler's check made where the gradient is written)
+    // staged flushes (optional, s3d_vm_backward_stage_bytes): the cells several workgroups add to — the border of a whole tile's
+    // 9 x 9 window, a line chunk's 65 cells — leave as plain stores into per-tile / per-workgroup rows, and k_vm_flush_reduce adds
+    // the rows in a fixed order.  Global atomics on these few, heavily shared addresses were 60 - 70 us of the colour plane pass
+    // and of the colour line pass (profiles/r11_tensorf_vm.md).  nullptr: atomics as before.
+    float* stage_plane;            // [3][stage_tiles][32 border cells][stage_R]
+    float* stage_line;             // [3][stage_lslots][65][stage_R]
+    uint32_t* plane_flag;          // [3][stage_tiles]: 1 = the tile's border rows are staged (cleared by k_vm_bound)
+    uint32_t* line_flag;           // [3][stage_lslots]: chunk + 1 of the staged row block, 0 = unused
+    uint32_t stage_tiles, stage_lslots, stage_R;
 };
+// 9 x 9 window cell -> its place among the window's 32 border cells (row 0: 0..8, row 8: 9..17, column 0 rows 1..7: 18..24,
+// column 8 rows 1..7: 25..31), -1 for an inner cell
+__device__ __forceinline__ int vm_border_index(int lx, int ly) {
+    if (ly == 0) return lx;
+    if (ly == kVmTile) return kVmTile + 1 + lx;
+    if (lx == 0) return 2 * kVmTile + 1 + ly;
+    if (lx == kVmTile) return 3 * kVmTile + ly;
+    return -1;
+}
 
 // LDS float atomics retire at ~0.2 T/s on MI355X, LDS integer atomics at ~2.3 T/s (tools/ubench, csrc/gridencoder.hip): the
 // tile accumulators are 64-bit fixed point.  The scale comes from a bound on one contribution (|g| max x |line| max for the
@@ -433,8 +451,10 @@ __device__ __forceinline__ uint32_t nan_aware_bits(float m, bool bad) { return b
 // three line factors, [3] over the columns of basis_mat
 __global__ void __launch_bounds__(256) k_vm_bound(const float* __restrict__ g, size_t n_g, const _Float16* __restrict__ g16, size_t n_g16,
                                                    VmFactors f, const _Float16* __restrict__ basis, uint32_t Cb, uint32_t rows,
-                                                   uint32_t* __restrict__ bound, float* __restrict__ line_t) {
+                                                   uint32_t* __restrict__ bound, float* __restrict__ line_t,
+                                                   uint32_t* __restrict__ stage_flags, uint32_t n_stage_flags) {
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
+    for (size_t k = tid; k < n_stage_flags; k += nt) stage_flags[k] = 0u;  // (staged flushes: nothing staged yet)
     float m = 0.0f;
     bool bad = false;
     if (g) {
@@ -500,6 +520,28 @@ __global__ void __launch_bounds__(256) k_vm_bound(const float* __restrict__ g, s
     }
 }
 
+// the range [begin, end) of workgroup `blk` moved to the boundaries of small tiles / chunks (k_vm_plane_backward_mm below: a unit of at most `whole_max` points is processed whole by the workgroup its first position falls to); t = the unit of `begin`
+__device__ __forceinline__ bool vm_aligned_range(const int32_t* __restrict__ st, int nunits, uint32_t blk, uint32_t pts, uint32_t whole_max,
+                                                 uint32_t valid_end, uint32_t& begin, uint32_t& end, int& t) {
+    begin = blk * pts;
+    if (begin >= valid_end) return false;
+    end = begin + pts < valid_end ? begin + pts : valid_end;
+    auto unit_of = [&](uint32_t pos) {  // the last u with st[u] <= pos (empty units repeat their neighbour's start)
+        int lo = 0, hi = nunits;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if ((uint32_t)st[mid] <= pos) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    t = unit_of(begin);
+    if ((uint32_t)st[t] < begin && (uint32_t)st[t + 1] - (uint32_t)st[t] <= whole_max) begin = (uint32_t)st[t + 1];  // an earlier workgroup's
+    if (end < valid_end) {
+        const int te = unit_of(end);
+        if ((uint32_t)st[te] < end && (uint32_t)st[te + 1] - (uint32_t)st[te] <= whole_max) end = (uint32_t)st[te + 1];  // whole, and mine (or nobody's: begin == end)
+    }
+    return begin < end;
+}
 // One workgroup = `pts_plane` consecutive positions of plane i's sorted point order (a hot tile is shared by as many
 // workgroups as its points fill, a stretch of sparse tiles is walked by one): per tile segment the 9x9 cells' plane values
 // and a cleared accumulator live in LDS, lanes = rank channels, eight waves = eight points (RP = 64) in flight.
@@ -521,9 +563,6 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
     const int ntiles = tiles_x * tiles_y;
     const int32_t* st = b.start + (size_t)i * b.n_bounds;
     const uint32_t valid_end = (uint32_t)st[ntiles];  // (points without a contribution sort behind every tile)
-    const uint32_t begin = blockIdx.x * b.pts_plane;
-    if (begin >= valid_end) return;
-    const uint32_t end = begin + b.pts_plane < valid_end ? begin + b.pts_plane : valid_end;
     float scale = 1.0f, inv = 1.0f;
     bool poison;
     float bound = __uint_as_float(b.bound[0]) * __uint_as_float(b.bound[1]);
@@ -536,6 +575,10 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
         }
         return;
     }
+    // (ranges moved to tile boundaries, as in k_vm_plane_backward_mm: tiles of up to 2 x pts_plane points are whole)
+    uint32_t begin, end;
+    int t;
+    if (!vm_aligned_range(st, ntiles, blockIdx.x, b.pts_plane, 2 * b.pts_plane < kVmMaxPts ? 2 * b.pts_plane : kVmMaxPts, valid_end, begin, end, t)) return;
     long long* acc = reinterpret_cast<long long*>(vm_smem_raw);                   // [81][R] gradient accumulator (fixed point)
     float* pv = reinterpret_cast<float*>(acc + kVmTileCells * R);                 // [81][R] plane values
     const float* P = f.plane[i];
@@ -555,16 +598,6 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
         }
     }
     for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += kVmBwdThreads) acc[e] = 0ll;
-    // tile of the first position: the last t with st[t] <= begin (empty tiles repeat their neighbour's start)
-    int t = 0;
-    {
-        int lo = 0, hi = ntiles;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if ((uint32_t)st[mid] <= begin) lo = mid; else hi = mid;
-        }
-        t = lo;
-    }
     float gm_max = 0.0f;
     uint32_t pos = begin;
     while (pos < end) {
@@ -643,20 +676,29 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
         // those leave as plain stores into the zero-initialised gradient — 1,536 instead of 3,888 global atomics per tile at
         // rank 48, and global atomics (~21 G/s chip-wide) are what this kernel waits for
         const bool whole = pos == (uint32_t)st[t] && seg_end == (uint32_t)st[t + 1];
+        const bool staged = whole && b.stage_plane != nullptr;  // border cells of a whole tile: plain stores into the tile's staging rows
+        float* stg = staged ? b.stage_plane + ((size_t)i * b.stage_tiles + (size_t)t) * 32 * b.stage_R : nullptr;
         for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += kVmBwdThreads) {
             const uint32_t rr = e / kVmTileCells, c = e % kVmTileCells;
             const int ly = (int)(c / (kVmTile + 1)), lx = (int)(c % (kVmTile + 1));
             const int cy = cy0 + ly, cx = cx0 + lx;
             const long long qv = acc[c * R + rr];
+            const int bi = vm_border_index(lx, ly);
+            if (staged && bi >= 0) {  // (every border cell is written, zeros included: the rows are not initialised)
+                if (qv != 0ll) acc[c * R + rr] = 0ll;
+                stg[(size_t)bi * b.stage_R + rr] = (float)qv * inv;
+                continue;
+            }
             if (qv != 0ll) {
                 acc[c * R + rr] = 0ll;  // cleared behind the read: the next segment starts from zeros
                 if (cx < W && cy < H) {
                     float* dst = &dP[rr * plane_stride + (size_t)cy * W + cx];
-                    if (whole && lx >= 1 && lx < kVmTile && ly >= 1 && ly < kVmTile) *dst = (float)qv * inv;
+                    if (whole && bi < 0) *dst = (float)qv * inv;
                     else vm_flush_add(dst, (float)qv * inv);
                 }
             }
         }
+        if (staged && threadIdx.x == 0) b.plane_flag[(size_t)i * b.stage_tiles + (size_t)t] = 1u;
         pos = seg_end;
         // (the next segment's plane values are written before its barrier; the flush only touches `acc`)
     }
@@ -724,28 +766,6 @@ __device__ __forceinline__ void vm_wave_lds_fence() {  // this wave's LDS writes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-// the range [begin, end) of workgroup `blk` moved to the boundaries of small tiles / chunks (see above); t = the unit of `begin`
-__device__ __forceinline__ bool vm_aligned_range(const int32_t* __restrict__ st, int nunits, uint32_t blk, uint32_t pts, uint32_t whole_max,
-                                                 uint32_t valid_end, uint32_t& begin, uint32_t& end, int& t) {
-    begin = blk * pts;
-    if (begin >= valid_end) return false;
-    end = begin + pts < valid_end ? begin + pts : valid_end;
-    auto unit_of = [&](uint32_t pos) {  // the last u with st[u] <= pos (empty units repeat their neighbour's start)
-        int lo = 0, hi = nunits;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if ((uint32_t)st[mid] <= pos) lo = mid; else hi = mid;
-        }
-        return lo;
-    };
-    t = unit_of(begin);
-    if ((uint32_t)st[t] < begin && (uint32_t)st[t + 1] - (uint32_t)st[t] <= whole_max) begin = (uint32_t)st[t + 1];  // an earlier workgroup's
-    if (end < valid_end) {
-        const int te = unit_of(end);
-        if ((uint32_t)st[te] < end && (uint32_t)st[te + 1] - (uint32_t)st[te] <= whole_max) end = (uint32_t)st[te + 1];  // whole, and mine (or nobody's: begin == end)
-    }
-    return begin < end;
 }
 template <int RB, int MODE>
 __global__ void __launch_bounds__(kVmMmThreads, 4) k_vm_plane_backward_mm(const float* __restrict__ x, uint32_t N, VmFactors f, VmBackward b) {
@@ -935,20 +955,29 @@ __global__ void __launch_bounds__(kVmMmThreads, 4) k_vm_plane_backward_mm(const 
         __syncthreads();
         float* dP = b.d_plane[i];
         const bool whole = pos == (uint32_t)st[t] && seg_end == (uint32_t)st[t + 1];
+        const bool staged = whole && b.stage_plane != nullptr;  // border cells of a whole tile: plain stores into the tile's staging rows
+        float* stg = staged ? b.stage_plane + ((size_t)i * b.stage_tiles + (size_t)t) * 32 * b.stage_R : nullptr;
         for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += kVmMmThreads) {
             const uint32_t rr = e / kVmTileCells, c = e % kVmTileCells;
             const int ly = (int)(c / (kVmTile + 1)), lx = (int)(c % (kVmTile + 1));
             const int cy = cy0 + ly, cx = cx0 + lx;
             const long long qv = acc[c * R + rr];
+            const int bi = vm_border_index(lx, ly);
+            if (staged && bi >= 0) {  // (every border cell is written, zeros included: the rows are not initialised)
+                if (qv != 0ll) acc[c * R + rr] = 0ll;
+                stg[(size_t)bi * b.stage_R + rr] = (float)qv * inv;
+                continue;
+            }
             if (qv != 0ll) {
                 acc[c * R + rr] = 0ll;
                 if (cx < W && cy < H) {
                     float* dst = &dP[rr * plane_stride + (size_t)cy * W + cx];
-                    if (whole && lx >= 1 && lx < kVmTile && ly >= 1 && ly < kVmTile) *dst = (float)qv * inv;
+                    if (whole && bi < 0) *dst = (float)qv * inv;
                     else vm_flush_add(dst, (float)qv * inv);
                 }
             }
         }
+        if (staged && threadIdx.x == 0) b.plane_flag[(size_t)i * b.stage_tiles + (size_t)t] = 1u;
         pos = seg_end;
     }
     gm_max = wave_max(gm_max);
@@ -1010,6 +1039,7 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_line_backward(const float*
         t = lo;
     }
     uint32_t pos = begin;
+    uint32_t nseg = 0;  // segments flushed so far (the first two may be staged)
     while (pos < end) {
         while ((uint32_t)st[t + 1] <= pos) t++;
         const uint32_t seg_end = (uint32_t)st[t + 1] < end ? (uint32_t)st[t + 1] : end;
@@ -1038,14 +1068,20 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_line_backward(const float*
         }
         __syncthreads();
         float* dL = b.d_line[i];
+        // the first two segments of a workgroup leave as plain stores into its staging rows (k_vm_flush_reduce adds them per chunk)
+        const bool staged = b.stage_line != nullptr && nseg < 2;
+        float* stg = staged ? b.stage_line + ((size_t)i * b.stage_lslots + 2 * blockIdx.x + nseg) * (kVmZChunk + 1) * b.stage_R : nullptr;
         for (uint32_t e = threadIdx.x; e < (kVmZChunk + 1) * R; e += kVmBwdThreads) {
             const uint32_t z = e / R, rr = e % R;
             const long long qv = acc[e];
+            if (staged) stg[(size_t)z * b.stage_R + rr] = (float)qv * inv;
             if (qv != 0ll) {
                 acc[e] = 0ll;
-                if (zb + (int)z < Dn) vm_flush_add(&dL[(size_t)rr * Dn + zb + z], (float)qv * inv);
+                if (!staged && zb + (int)z < Dn) vm_flush_add(&dL[(size_t)rr * Dn + zb + z], (float)qv * inv);
             }
         }
+        if (staged && threadIdx.x == 0) b.line_flag[(size_t)i * b.stage_lslots + 2 * blockIdx.x + nseg] = (uint32_t)t + 1u;
+        nseg++;
         pos = seg_end;
     }
 }
@@ -1081,6 +1117,7 @@ __global__ void __launch_bounds__(kVmMmThreads) k_vm_line_backward_mm(const floa
     const float* __restrict__ gm = b.gm;
     const uint32_t row0 = f.row0[i], cw = f.cw[i];
     uint32_t pos = begin;
+    uint32_t nseg = 0;  // segments flushed so far (the first two may be staged)
     while (pos < end) {
         while ((uint32_t)st[t + 1] <= pos) t++;
         const uint32_t seg_end = (uint32_t)st[t + 1] < end ? (uint32_t)st[t + 1] : end;
@@ -1128,15 +1165,140 @@ __global__ void __launch_bounds__(kVmMmThreads) k_vm_line_backward_mm(const floa
         }
         __syncthreads();
         float* dL = b.d_line[i];
+        // the first two segments of a workgroup leave as plain stores into its staging rows (k_vm_flush_reduce adds them per chunk)
+        const bool staged = b.stage_line != nullptr && nseg < 2;
+        float* stg = staged ? b.stage_line + ((size_t)i * b.stage_lslots + 2 * blockIdx.x + nseg) * (kVmZChunk + 1) * b.stage_R : nullptr;
         for (uint32_t e = threadIdx.x; e < (kVmZChunk + 1) * R; e += kVmMmThreads) {
             const uint32_t z = e / R, rr = e % R;
             const long long qv = acc[e];
+            if (staged) stg[(size_t)z * b.stage_R + rr] = (float)qv * inv;
             if (qv != 0ll) {
                 acc[e] = 0ll;
-                if (zb + (int)z < Dn) vm_flush_add(&dL[(size_t)rr * Dn + zb + z], (float)qv * inv);
+                if (!staged && zb + (int)z < Dn) vm_flush_add(&dL[(size_t)rr * Dn + zb + z], (float)qv * inv);
             }
         }
+        if (staged && threadIdx.x == 0) b.line_flag[(size_t)i * b.stage_lslots + 2 * blockIdx.x + nseg] = (uint32_t)t + 1u;
+        nseg++;
         pos = seg_end;
+    }
+}
+
+// Adds the staged rows (VmBackward::stage_*) into the gradients, in a fixed order.  blockIdx.y = component; the first jobs walk the
+// tiles: a tile's own row 0 / column 0 cells (15) take its staged border, its left neighbour's column 8, its upper
+// neighbour's row 8 and the upper-left neighbour's corner — every plane cell on a tile boundary belongs to exactly one such
+// job; behind them kVmLineParts jobs per line chunk: cells 0..63 of the chunk from every staged block of the chunk, plus cell 64
+// of the previous chunk's blocks into cell 0.  Atomics of split tiles / third segments are complete by now (kernel boundary): plain `+=`.
+constexpr uint32_t kVmLineParts = 16;  // line jobs per chunk
+constexpr uint32_t kVmReduceTiles = 16;  // tiles per plane job
+constexpr uint32_t kVmStageMaxSlots = 1024;  // staged line blocks per component a call may have (more: the flushes keep their atomics)
+__global__ void __launch_bounds__(256) k_vm_flush_reduce(VmFactors f, VmBackward b) {
+    const uint32_t i = blockIdx.y;
+    const int W = (int)f.W[i], H = (int)f.H[i], Dn = (int)f.Dn[i];
+    const uint32_t R = f.rank[i], SR = b.stage_R;
+    const uint32_t plane_jobs = (b.stage_tiles + kVmReduceTiles - 1) / kVmReduceTiles;
+    if (blockIdx.x < plane_jobs) {
+        // plane job = kVmReduceTiles consecutive tiles, one wave per tile at a time (most tiles of a plane are empty: one workgroup
+        // per tile spent 15 us of this launch on 4,332 workgroups reading four flags each)
+        const int tiles_x = (W + kVmTile - 1) / kVmTile, tiles_y = (H + kVmTile - 1) / kVmTile;
+        const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const uint32_t* fl = b.plane_flag + (size_t)i * b.stage_tiles;
+        const float* S = b.stage_plane + (size_t)i * b.stage_tiles * 32 * SR;
+        float* dP = b.d_plane[i];
+        const size_t plane_stride = (size_t)H * W;
+        for (uint32_t k = wave; k < kVmReduceTiles; k += 4) {
+            const int t = (int)(blockIdx.x * kVmReduceTiles + k);
+            if (t >= tiles_x * tiles_y) break;
+            const int tx = t % tiles_x, ty = t / tiles_x;
+            const bool f_own = fl[t] != 0u, f_left = tx > 0 && fl[t - 1] != 0u, f_up = ty > 0 && fl[t - tiles_x] != 0u;
+            const bool f_ul = tx > 0 && ty > 0 && fl[t - tiles_x - 1] != 0u;
+            if (!(f_own || f_left || f_up || f_ul)) continue;  // (wave-uniform)
+            // every load of a lane's cells is issued before the first one is used: unconditional, from valid addresses (a
+            // neighbour that does not exist reads tile 0's rows; its value is not added)
+            const size_t t_l = t > 0 ? (size_t)t - 1 : 0, t_u = t >= tiles_x ? (size_t)(t - tiles_x) : 0, t_ul = t > tiles_x ? (size_t)(t - tiles_x - 1) : 0;
+            constexpr uint32_t kB = 4;  // cells of a lane in flight
+            for (uint32_t e0 = lane; e0 < (2 * kVmTile - 1) * R; e0 += 64 * kB) {
+                float v0[kB], v1[kB], v2[kB], v3[kB], old[kB];
+                size_t dst[kB];
+                bool ok[kB];
+                int lxs[kB], lys[kB];
+#pragma unroll
+                for (uint32_t u = 0; u < kB; u++) {
+                    const uint32_t e = e0 + 64 * u;
+                    const bool in = e < (2 * kVmTile - 1) * R;
+                    const uint32_t c15 = in ? e / R : 0u, rr = in ? e % R : 0u;
+                    const int lx = c15 < (uint32_t)kVmTile ? (int)c15 : 0, ly = c15 < (uint32_t)kVmTile ? 0 : (int)c15 - (kVmTile - 1);
+                    const int cx = tx * kVmTile + lx, cy = ty * kVmTile + ly;
+                    ok[u] = in && cx < W && cy < H;
+                    lxs[u] = lx; lys[u] = ly;
+                    v0[u] = S[((size_t)t * 32 + (size_t)vm_border_index(lx, ly)) * SR + rr];
+                    v1[u] = S[(t_l * 32 + (size_t)vm_border_index(kVmTile, ly)) * SR + rr];
+                    v2[u] = S[(t_u * 32 + (size_t)vm_border_index(lx, kVmTile)) * SR + rr];
+                    v3[u] = S[(t_ul * 32 + (size_t)vm_border_index(kVmTile, kVmTile)) * SR + rr];
+                    dst[u] = ok[u] ? rr * plane_stride + (size_t)cy * W + cx : 0;
+                    old[u] = dP[dst[u]];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kB; u++) {
+                    float sum = 0.0f;
+                    if (f_own) sum += v0[u];
+                    if (lxs[u] == 0 && f_left) sum += v1[u];
+                    if (lys[u] == 0 && f_up) sum += v2[u];
+                    if (lxs[u] == 0 && lys[u] == 0 && f_ul) sum += v3[u];
+                    if (ok[u] && sum != 0.0f) dP[dst[u]] = old[u] + sum;
+                }
+            }
+        }
+    } else {
+        // line job = (chunk, four of its 64 cells).  The staged blocks of the chunk (and of the one before it, for cell 0) are found
+        // once per workgroup — a bit per slot, then the ascending list of the set bits: a fixed summation order — and read eight at
+        // a time (independent loads; one load per pass of a scan over the flags was 30 - 45 us for this launch)
+        constexpr uint32_t kMaxWords = kVmStageMaxSlots / 32;  // (static LDS of EVERY workgroup of this launch: kept small)
+        const uint32_t job = blockIdx.x - plane_jobs;
+        const int tc = (int)(job / kVmLineParts);
+        const uint32_t part = job % kVmLineParts;
+        if (tc >= (Dn + kVmZChunk - 1) / kVmZChunk || !b.stage_line) return;
+        __shared__ uint32_t bits[2][kMaxWords];
+        __shared__ uint16_t list[2][kMaxWords * 32];
+        __shared__ uint32_t count[2];
+        const uint32_t nwords = (b.stage_lslots + 31) / 32;
+        for (uint32_t w = threadIdx.x; w < nwords; w += 256) bits[0][w] = bits[1][w] = 0u;
+        __syncthreads();
+        const uint32_t* fl = b.line_flag + (size_t)i * b.stage_lslots;
+        for (uint32_t slot = threadIdx.x; slot < b.stage_lslots; slot += 256) {
+            const uint32_t v = fl[slot];
+            if (v == (uint32_t)tc + 1u) atomicOr(&bits[0][slot >> 5], 1u << (slot & 31));
+            else if (tc > 0 && part == 0 && v == (uint32_t)tc) atomicOr(&bits[1][slot >> 5], 1u << (slot & 31));
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) {  // (two lanes walk the two bitmaps: a few hundred bits)
+            uint32_t n = 0;
+            for (uint32_t w = 0; w < nwords; w++)
+                for (uint32_t m = bits[threadIdx.x][w]; m; m &= m - 1u) list[threadIdx.x][n++] = (uint16_t)(32 * w + (uint32_t)__builtin_ctz(m));
+            count[threadIdx.x] = n;
+        }
+        __syncthreads();
+        const float* S = b.stage_line + (size_t)i * b.stage_lslots * (kVmZChunk + 1) * SR;
+        float* dL = b.d_line[i];
+        constexpr uint32_t ZP = kVmZChunk / kVmLineParts;
+        for (uint32_t e = threadIdx.x; e < ZP * R; e += 256) {
+            const uint32_t z = part * ZP + e / R, rr = e % R;
+            if (tc * kVmZChunk + (int)z >= Dn) continue;
+            float sum = 0.0f;
+            auto add_list = [&](uint32_t which, uint32_t zz) {
+                const uint32_t n = count[which];
+                for (uint32_t k0 = 0; k0 < n; k0 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; u++)
+                        v[u] = k0 + u < n ? S[((size_t)list[which][k0 + u] * (kVmZChunk + 1) + zz) * SR + rr] : 0.0f;
+#pragma unroll
+                    for (uint32_t u = 0; u < 8; u++) sum += v[u];
+                }
+            };
+            add_list(0, z);
+            if (z == 0) add_list(1, kVmZChunk);
+            if (sum != 0.0f) dL[(size_t)rr * Dn + tc * kVmZChunk + z] += sum;
+        }
     }
 }
 
@@ -1302,14 +1464,7 @@ S3D_EXPORT int s3d_vm_backward_bins(const float* x, uint32_t N, const uint32_t* 
     return check_launch("vm_backward_bins");
 }
 
-// launch geometry shared by the two backward entry points: points per workgroup so that the sorted order fills the chip a
-// few times over (eight waves x 64 / RP points in flight per workgroup), LDS = fixed-point accumulator + plane values
-static void vm_backward_geometry(VmBackward& b, uint32_t N, uint32_t max_rank, bool basis, dim3& gp, dim3& gl, size_t& smem_p,
-                                 size_t& smem_l) {
-    const uint32_t rp = max_rank <= 16 ? 16u : 64u;
-    // Every (range, tile) segment ends with one global atomic per cell of the 9 x 9 window and rank channel (3,888 at rank 48)
-    // and global atomics retire at ~21 G/s chip-wide: segments = ranges + occupied tiles, so the ranges are as long as the
-    // workgroup count allows (tools/bench_tensorf_step.py with S3D_VM_PTS=plane64,plane16,line64,line16 sweeps them)
+static const std::array<uint32_t, 4>& vm_lane_pts() {
     static const std::array<uint32_t, 4> pts = [] {
         std::array<uint32_t, 4> v = {256u, 512u, 1024u, 1024u};  // (same-box sweep, tools/vm_pts_sweep.sh)
         if (const char* e = getenv("S3D_VM_PTS")) {
@@ -1318,6 +1473,62 @@ static void vm_backward_geometry(VmBackward& b, uint32_t N, uint32_t max_rank, b
         }
         return v;
     }();
+    return pts;
+}
+static uint32_t vm_mm_pts(uint32_t which);
+// staging rows of the flushes (VmBackward::stage_*): flags | plane rows | line rows
+struct VmStage { uint32_t tiles, lslots, R; size_t flag_words, plane_floats, line_floats, bytes; };
+static VmStage vm_stage_layout(uint32_t N, const uint32_t* rank, const uint32_t* resolution) {
+    VmStage v{};
+    for (uint32_t i = 0; i < 3; i++) {
+        v.R = rank[i] > v.R ? rank[i] : v.R;
+        for (uint32_t j = i + 1; j < 3; j++) {
+            const uint32_t t = div_up<uint32_t>(resolution[i], kVmTile) * div_up<uint32_t>(resolution[j], kVmTile);
+            v.tiles = t > v.tiles ? t : v.tiles;
+        }
+    }
+    const std::array<uint32_t, 4>& lp = vm_lane_pts();
+    const uint32_t min_line = std::min(std::min(std::min(lp[2], lp[3]), kVmMaxPts), vm_mm_pts(2));  // whichever line kernel runs
+    v.lslots = 2 * div_up<uint32_t>(N, min_line);
+    v.flag_words = ((size_t)3 * v.tiles + (size_t)3 * v.lslots + 63) & ~(size_t)63;
+    v.plane_floats = (size_t)3 * v.tiles * 32 * v.R;
+    v.line_floats = (size_t)3 * v.lslots * (kVmZChunk + 1) * v.R;
+    v.bytes = (v.flag_words + v.plane_floats + v.line_floats) * 4;
+    return v;
+}
+// arms the staged flushes when the caller's buffer holds them; returns the flag words for k_vm_bound to clear
+static uint32_t vm_stage_arm(VmBackward& b, uint32_t N, const uint32_t* rank, const uint32_t* resolution, void* stage, size_t stage_bytes,
+                             uint32_t*& flags) {
+    b.stage_plane = b.stage_line = nullptr; b.plane_flag = b.line_flag = nullptr;
+    b.stage_tiles = b.stage_lslots = b.stage_R = 0;
+    flags = nullptr;
+    static const int mode = [] { const char* e = getenv("S3D_VM_STAGE"); return e ? atoi(e) : 1; }();  // (A/B: 0 off, 1 planes + lines, 2 lines only)
+    const bool on = mode != 0;
+    const VmStage v = vm_stage_layout(N, rank, resolution);
+    if (!on || !stage || stage_bytes < v.bytes || (reinterpret_cast<uintptr_t>(stage) & 15u) || v.lslots > kVmStageMaxSlots) return 0;
+    flags = reinterpret_cast<uint32_t*>(stage);
+    b.plane_flag = flags;
+    b.line_flag = flags + (size_t)3 * v.tiles;
+    b.stage_plane = reinterpret_cast<float*>(flags + v.flag_words);
+    b.stage_line = b.stage_plane + v.plane_floats;
+    b.stage_tiles = v.tiles; b.stage_lslots = v.lslots; b.stage_R = v.R;
+    if (mode == 2) { b.stage_plane = nullptr; b.stage_tiles = 0; }
+    return (uint32_t)v.flag_words;
+}
+S3D_EXPORT size_t s3d_vm_backward_stage_bytes(uint32_t N, const uint32_t* rank, const uint32_t* resolution) {
+    if (!rank || !resolution || !N) return 0;
+    return vm_stage_layout(N, rank, resolution).bytes;
+}
+
+// launch geometry shared by the two backward entry points: points per workgroup so that the sorted order fills the chip a
+// few times over (eight waves x 64 / RP points in flight per workgroup), LDS = fixed-point accumulator + plane values
+static void vm_backward_geometry(VmBackward& b, uint32_t N, uint32_t max_rank, bool basis, dim3& gp, dim3& gl, size_t& smem_p,
+                                 size_t& smem_l) {
+    const uint32_t rp = max_rank <= 16 ? 16u : 64u;
+    // Every (range, tile) segment ends with one global atomic per cell of the 9 x 9 window and rank channel (3,888 at rank 48)
+    // and global atomics retire at ~21 G/s chip-wide: segments = ranges + occupied tiles, so the ranges are as long as the
+    // workgroup count allows (tools/bench_tensorf_step.py with S3D_VM_PTS=plane64,plane16,line64,line16 sweeps them)
+    const std::array<uint32_t, 4>& pts = vm_lane_pts();
     b.pts_plane = std::min(rp == 16 ? pts[1] : pts[0], kVmMaxPts);  // (the accumulators' headroom: kVmMaxPts contributions per cell)
     b.pts_line = std::min(rp == 16 ? pts[3] : pts[2], kVmMaxPts);
     gp = dim3(div_up<uint32_t>(N, b.pts_plane), 3);
@@ -1334,7 +1545,7 @@ static void vm_backward_geometry(VmBackward& b, uint32_t N, uint32_t max_rank, b
 // S3D_VM_MM_PTS=plane,-,line,- sets the nominal sorted positions per workgroup (<= kVmMaxPts).
 static uint32_t vm_mm_pts(uint32_t which) {
     static const std::array<uint32_t, 4> pts = [] {
-        std::array<uint32_t, 4> v = {512u, 512u, 2048u, 1024u};
+        std::array<uint32_t, 4> v = {512u, 512u, 1024u, 1024u};  // (line: 2,048 without the staged flush, 1,024 with it)
         if (const char* e = getenv("S3D_VM_MM_PTS")) {
             unsigned a, b2, c, d;
             if (sscanf(e, "%u,%u,%u,%u", &a, &b2, &c, &d) == 4 && a >= 32 && b2 >= 32 && c >= 32 && d >= 32)
@@ -1390,7 +1601,7 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
                                         const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
                                         const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
                                         float* const* grad_planes, float* const* grad_lines, uint32_t* bound_words,
-                                        float* line_scratch, float* found_inf, s3d_stream_t stream) {
+                                        float* line_scratch, void* stage, size_t stage_bytes, float* found_inf, s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && planes && lines && rank && resolution && grad && perm && start && gm && grad_planes && grad_lines && bound_words &&
                 line_scratch, "vm_features_backward: null pointer");
@@ -1426,8 +1637,10 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
     vm_backward_geometry(b, N, max_rank, false, gp, gl, smem_p, smem_l);
     const dim3 block(kVmBwdThreads);
     const size_t n_g = reduce ? (size_t)N : (size_t)N * b.rows;
+    uint32_t* stage_flags;
+    const uint32_t n_stage_flags = vm_stage_arm(b, N, rank, resolution, stage, stage_bytes, stage_flags);
     hipLaunchKernelGGL(k_vm_bound, dim3(std::min<uint32_t>(stream_grid(n_g / 4 + 1, 256), 512u)), dim3(256), 0, st, grad, n_g, (const _Float16*)nullptr, (size_t)0, f,
-                       (const _Float16*)nullptr, 0u, b.rows, bound_words, line_scratch);
+                       (const _Float16*)nullptr, 0u, b.rows, bound_words, line_scratch, stage_flags, n_stage_flags);
     const bool mm = reduce ? launch_plane_mm<0>(x, N, f, b, st) : launch_plane_mm<1>(x, N, f, b, st);
     if (max_rank <= 16) {
         if (mm) {}
@@ -1440,6 +1653,7 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
         else hipLaunchKernelGGL((k_vm_plane_backward<64, false>), gp, block, smem_p, st, x, N, f, b);
         if (!launch_line_mm(x, N, f, b, st)) hipLaunchKernelGGL((k_vm_line_backward<64>), gl, block, smem_l, st, x, N, f, b);
     }
+    if (b.stage_line) hipLaunchKernelGGL(k_vm_flush_reduce, dim3(div_up<uint32_t>(b.stage_tiles, kVmReduceTiles) + kVmLineParts * max_chunks, 3), dim3(256), 0, st, f, b);
     return check_launch("vm_features_backward");
 }
 
@@ -1463,7 +1677,8 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
                                      const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
                                      const uint16_t* grad_out, const int32_t* perm, const int32_t* start, uint32_t n_bounds,
                                      float* gm, float* const* grad_planes, float* const* grad_lines, float* grad_basis,
-                                     uint32_t* bound_words, float* line_scratch, float* found_inf, s3d_stream_t stream) {
+                                     uint32_t* bound_words, float* line_scratch, void* stage, size_t stage_bytes, float* found_inf,
+                                     s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && planes && lines && rank && resolution && basis && grad_out && perm && start && gm && grad_planes && grad_lines &&
                 grad_basis && bound_words && line_scratch, "vm_color_backward: null pointer");
@@ -1504,10 +1719,13 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
     vm_backward_geometry(b, N, 64, true, gp, gl, smem_p, smem_l);  // (the BASIS kernel: 64 lanes per point whatever the rank)
     const dim3 block(kVmBwdThreads);
     const size_t n_g16 = (size_t)N * kVmBasisPad;
+    uint32_t* stage_flags;
+    const uint32_t n_stage_flags = vm_stage_arm(b, N, rank, resolution, stage, stage_bytes, stage_flags);
     hipLaunchKernelGGL(k_vm_bound, dim3(std::min<uint32_t>(stream_grid(n_g16 / 8 + 1, 256), 512u)), dim3(256), 0, st, (const float*)nullptr, (size_t)0,
-                       (const _Float16*)grad_out, n_g16, f, (const _Float16*)basis, basis_rows, b.rows, bound_words, line_scratch);
+                       (const _Float16*)grad_out, n_g16, f, (const _Float16*)basis, basis_rows, b.rows, bound_words, line_scratch, stage_flags, n_stage_flags);
     if (!launch_plane_mm<2>(x, N, f, b, st)) hipLaunchKernelGGL((k_vm_plane_backward<64, false, true>), gp, block, smem_p, st, x, N, f, b);
     if (!launch_line_mm(x, N, f, b, st)) hipLaunchKernelGGL((k_vm_line_backward<64>), gl, block, smem_l, st, x, N, f, b);
+    if (b.stage_line) hipLaunchKernelGGL(k_vm_flush_reduce, dim3(div_up<uint32_t>(b.stage_tiles, kVmReduceTiles) + kVmLineParts * max_chunks, 3), dim3(256), 0, st, f, b);
     return check_launch("vm_color_backward");
 }
 

@@ -45,6 +45,7 @@ EXPORTS = [
     "s3d_seal_bbox_map", "s3d_seal_map_color", "s3d_grid_encode_backward_adam", "s3d_vm_features_forward",
     "s3d_aabb_normalize", "s3d_weighted_abs_sum_workspace_size", "s3d_weighted_abs_sum", "s3d_pack_linear_chain", "s3d_unpack_linear_chain",
     "s3d_vm_backward_max_bins", "s3d_vm_backward_keys", "s3d_vm_backward_bins_workspace_size", "s3d_vm_backward_bins",
+    "s3d_vm_backward_stage_bytes",
     "s3d_vm_features_backward", "s3d_vm_color_forward", "s3d_vm_color_backward",
 ]
 
@@ -74,7 +75,7 @@ def lib():
         for name in ("s3d_march_rays_train_workspace_size", "s3d_compact_alive_workspace_size",
                      "s3d_ffmlp_backward_workspace_size", "s3d_grid_encode_backward_workspace_size",
                      "s3d_grid_encode_backward_control_size", "s3d_l1_pair_workspace_size",
-                     "s3d_sweep_update_workspace_size", "s3d_vm_backward_bins_workspace_size",
+                     "s3d_sweep_update_workspace_size", "s3d_vm_backward_bins_workspace_size", "s3d_vm_backward_stage_bytes",
                      "s3d_weighted_abs_sum_workspace_size"):
             getattr(l, name).restype = C.c_size_t
         l.s3d_vm_backward_max_bins.restype = C.c_uint32
@@ -1153,6 +1154,11 @@ class VmBackend:
         return perm, start, n_bounds
 
     @staticmethod
+    def _stage(N, rank, res, dev):
+        """staging rows of the factor backward's flushes (s3d_vm_backward_stage_bytes; uint8, no initialisation)"""
+        return torch.empty(int(lib().s3d_vm_backward_stage_bytes(_u(N), rank, res)), dtype=torch.uint8, device=dev)
+
+    @staticmethod
     def features_backward(x, planes, lines, resolution, reduce, grad, bins=None, found_inf=None):
         """gradients of features_forward w.r.t. planes / lines (lists shaped like the factors).  grad: [N] (reduce) or
         [N, sum R_i] point-major.  `bins`: a backward_bins() result for the same x / resolution."""
@@ -1170,11 +1176,13 @@ class VmBackend:
         gs, bound_words = _zeros_like_many(list(planes) + list(lines), 4)
         g_planes, g_lines = gs[:3], gs[3:]
         line_scratch = torch.empty(sum(t.numel() for t in lines), dtype=torch.float32, device=dev)
+        stage = VmBackend._stage(N, rank, res, dev)
         _check(lib().s3d_vm_features_backward(_p(x), _u(N), ptr3(*[t.data_ptr() for t in planes]),
                                               ptr3(*[t.data_ptr() for t in lines]), rank, res, C.c_int(int(bool(reduce))),
                                               _p(grad), _p(perm), _p(start), _u(n_bounds), _p(gm),
                                               ptr3(*[t.data_ptr() for t in g_planes]), ptr3(*[t.data_ptr() for t in g_lines]),
-                                              _p(bound_words), _p(line_scratch), _p(found_inf), _stream()), "vm_features_backward")
+                                              _p(bound_words), _p(line_scratch), _p(stage), C.c_size_t(stage.numel()), _p(found_inf),
+                                              _stream()), "vm_features_backward")
         return g_planes, g_lines
 
     @staticmethod
@@ -1218,10 +1226,12 @@ class VmBackend:
         gs, bound_words = _zeros_like_many(list(planes) + list(lines) + [basis], 4)
         g_planes, g_lines, g_basis = gs[:3], gs[3:6], gs[6]
         line_scratch = torch.empty(sum(t.numel() for t in lines), dtype=torch.float32, device=dev)
+        rank, res = u3(*[int(t.shape[1]) for t in planes]), u3(*[int(r) for r in resolution])
+        stage = VmBackend._stage(N, rank, res, dev)
         _check(lib().s3d_vm_color_backward(_p(x), _u(N), ptr3(*[t.data_ptr() for t in planes]),
-                                           ptr3(*[t.data_ptr() for t in lines]), u3(*[int(t.shape[1]) for t in planes]),
-                                           u3(*[int(r) for r in resolution]), _p(basis), _u(basis.shape[0]), _p(grad_out),
+                                           ptr3(*[t.data_ptr() for t in lines]), rank, res, _p(basis), _u(basis.shape[0]), _p(grad_out),
                                            _p(perm), _p(start), _u(n_bounds), _p(gm), ptr3(*[t.data_ptr() for t in g_planes]),
                                            ptr3(*[t.data_ptr() for t in g_lines]), _p(g_basis),
-                                           _p(bound_words), _p(line_scratch), _p(found_inf), _stream()), "vm_color_backward")
+                                           _p(bound_words), _p(line_scratch), _p(stage), C.c_size_t(stage.numel()), _p(found_inf),
+                                           _stream()), "vm_color_backward")
         return g_planes, g_lines, g_basis
