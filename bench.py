@@ -603,6 +603,20 @@ def tensorf_section(args, dev, batches, note=lambda m: None, res=300, steps=24):
         out["roofline"] = {"kernel": "s3d_vm_color_backward (bound + plane + line kernels, with the call's zero fills)", "bound": "hbm",
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "algorithmic_bytes_per_sample": bytes_per, "avg_us": cb["avg_us"], "rows": cb["units"], "traffic": None}
+        # counter traffic of the same call (FETCH_SIZE x 2 + WRITE_SIZE of its kernels, tools/pmc_tensorf_traffic.sh), quoted only while
+        # tensorf.hip still has the digest the passes ran on
+        import glob as _glob
+        pm = sorted(_glob.glob(os.path.join(REPO, "profiles", "r*_tensorf_pmc.json")))
+        if pm:
+            try:
+                rec = json.load(open(pm[-1]))
+                if rec.get("tensorf_hip_sha256_16") == source_digest(os.path.join("seal-3d_amd", "csrc", "tensorf.hip")):
+                    out["roofline"]["traffic"] = rec["color_backward_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = "profiles/" + os.path.basename(pm[-1])
+                else:
+                    out["roofline"]["traffic_source"] = f"profiles/{os.path.basename(pm[-1])} is stale (measured on another tensorf.hip)"
+            except (OSError, ValueError, KeyError):
+                pass
     fb = op.get("features_backward")
     if fb:
         out["density_factor_backward_us"] = fb["avg_us"]
