@@ -1190,7 +1190,7 @@ __global__ void __launch_bounds__(kVmMmThreads) k_vm_line_backward_mm(const floa
 // of the previous chunk's blocks into cell 0.  Atomics of split tiles / third segments are complete by now (kernel boundary): plain `+=`.
 constexpr uint32_t kVmLineParts = 16;  // line jobs per chunk
 constexpr uint32_t kVmReduceTiles = 16;  // tiles per plane job
-constexpr uint32_t kVmStageMaxSlots = 1024;  // staged line blocks per component a call may have (more: the flushes keep their atomics)
+constexpr uint32_t kVmStageMaxSlots = 4096;  // staged line blocks per component a call may have (more: the flushes keep their atomics)
 __global__ void __launch_bounds__(256) k_vm_flush_reduce(VmFactors f, VmBackward b) {
     const uint32_t i = blockIdx.y;
     const int W = (int)f.W[i], H = (int)f.H[i], Dn = (int)f.Dn[i];
