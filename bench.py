@@ -62,9 +62,9 @@ def parse():
     ap.add_argument("--no_cpu_render", action="store_true", help="skip the 64x64 CPU renders (cuda_ray on and off) of BASELINE.md §3 (i)")
     ap.add_argument("--no_seal", action="store_true", help="skip the configs[2] (Seal bbox distillation) section")
     ap.add_argument("--no_tensorf", action="store_true", help="skip the configs[4] (TensoRF VM-48 training step) section")
-    ap.add_argument("--no_long_run", action="store_true", help="skip the 2 x 6,000-step convergence comparison (psnr.long_run)")
+    ap.add_argument("--no_long_run", action="store_true", help="skip the 16 x 2 x 6,000-step convergence comparison (psnr.long_run)")
     ap.add_argument("--long_run_steps", type=int, default=6000)
-    ap.add_argument("--long_run_seeds", type=int, default=8)
+    ap.add_argument("--long_run_seeds", type=int, default=16, help="initialisations of the long-run comparison (per-seed sigma of the paired difference 0.25 dB: 16 seeds = +-0.13 dB at 95 %%)")
     ap.add_argument("--long_run_views", type=int, default=16, help="held-out views of the long-run PSNR (400x400 each)")
     ap.add_argument("--seal_teacher_steps", type=int, default=256)
     ap.add_argument("--seal_point_step", type=float, default=0.005, help="pretraining_local_point_step (readme.md:109)")
@@ -135,7 +135,7 @@ class KernelTimers:
             def wrapped(*a, __f=f, __n=n, **kw):
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 if queue_ahead:
-                    torch.cuda._sleep(150000)
+                    torch.cuda._sleep(150000 if queue_ahead is True else int(queue_ahead))
                 s.record()
                 r = __f(*a, **kw)
                 e.record()
@@ -560,7 +560,9 @@ def tensorf_section(args, dev, batches, note=lambda m: None, res=300, steps=24):
     for k in range(4):
         tr.train_step(*batches[k % len(batches)])
     timers = KernelTimers(s3d_hip.VmBackend, ["color_backward", "features_backward"])
-    timers.install(lambda name, a: a[0].shape[0])
+    # (a ~0.25 ms GPU spin in front of each bracket: the call is three zero fills, two allocations and seven launches — without the
+    #  head start the bracket counts the host's launch latency between them, 426 us against ~340 us of kernels in the trace)
+    timers.install(lambda name, a: a[0].shape[0], queue_ahead=600000)
     for k in range(4):
         tr.train_step(*batches[k % len(batches)])
     torch.cuda.synchronize()
@@ -600,7 +602,7 @@ def tensorf_section(args, dev, batches, note=lambda m: None, res=300, steps=24):
     if cb:
         bytes_per = 3 * (2 * 4 * 48 * 4 + 2 * 48 * 4 + 2 * 48 * 4 + 2 * 48 * 4) + 12 + 64
         ach = bytes_per * cb["units"] / (cb["avg_us"] * 1e-6) / 1e9
-        out["roofline"] = {"kernel": "s3d_vm_color_backward (bound + plane + line kernels, with the call's zero fills)", "bound": "hbm",
+        out["roofline"] = {"kernel": "s3d_vm_color_backward (bound + plane + line + flush-reduce kernels, with the call's zero fills)", "bound": "hbm",
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "algorithmic_bytes_per_sample": bytes_per, "avg_us": cb["avg_us"], "rows": cb["units"], "traffic": None}
         # counter traffic of the same call (FETCH_SIZE x 2 + WRITE_SIZE of its kernels, tools/pmc_tensorf_traffic.sh), quoted only while
