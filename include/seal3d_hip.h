@@ -296,9 +296,9 @@ int s3d_freq_encode_backward(const float* grad, const float* outputs, uint32_t B
  * row's fp16 gradient (s3d_freq_encode_backward's expression, sin / cos re-computed), fp16 [B, ldg] with the columns behind D1
  * zero (ldg = 32: the row layout s3d_vm_color_backward reads); d takes no gradient (view directions). */
 int s3d_freq_encode_pack_forward(const uint16_t* a, const float* d, uint32_t B, uint32_t D1, uint32_t deg1, uint32_t D2,
-                                 uint32_t deg2, uint32_t ld, uint16_t* out, s3d_stream_t stream);
+                                 uint32_t deg2, uint32_t ld, uint16_t* out, const int32_t* n_valid, s3d_stream_t stream);
 int s3d_freq_encode_pack_backward(const uint16_t* grad, const uint16_t* a, uint32_t B, uint32_t D1, uint32_t deg1, uint32_t ld,
-                                  uint32_t ldg, uint16_t* grad_a, s3d_stream_t stream);
+                                  uint32_t ldg, uint16_t* grad_a, const int32_t* n_valid, s3d_stream_t stream);
 
 /* ------------------------------------------------------------------ ffmlp
  * ffmlp/src/ffmlp.h:8-14.  All tensors fp16 (uint16_t bit patterns).
@@ -392,7 +392,7 @@ int s3d_ffmlp_free_splitk(void);
  * (the tensor the reference transposes into basis_mat, network.py:147). */
 int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                             const uint32_t* rank, const uint32_t* resolution, int reduce, float* out,
-                            s3d_stream_t stream);
+                            const int32_t* n_valid, s3d_stream_t stream);
 /* Parameter gradients of the same op (what autograd derives from the grid_sample calls: F.grid_sample's backward
  * scatter-adds every corner with a global atomic).  Binned instead: s3d_vm_backward_keys writes keys [6,N] i32 (rows 0-2
  * the 8x8-cell plane tile of component i, rows 3-5 its 64-row line chunk; 0x7fffffff = contributes nothing); the caller
@@ -407,6 +407,9 @@ int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* plan
  * transposed ([Dn][rank]) for the plane pass, whose lanes are rank channels.
  * found_inf (optional device float): set to 1 when a bound is not finite — the condition under which these kernels write a
  * non-finite gradient — so a GradScaler need not read the 69 MB of factor gradients again to find out.
+ * n_valid (optional, round 6; every s3d_vm_* entry point that walks the points, and s3d_freq_encode_pack_*): the device-side
+ * sample count of a padded batch — rows [round_up(*n_valid, 128), N) are absent: the forwards do not write them, the binning
+ * sorts them behind every bin (the backward passes then never see them) and the bound pass does not look at their gradients.
  * stage / stage_bytes (optional, round 6): s3d_vm_backward_stage_bytes(N, rank, resolution) bytes of 16-byte aligned device
  * scratch, no initialisation.  With it the cells several workgroups add to (the border of a whole tile's 9x9 window, a line
  * chunk's 65 cells) leave as plain stores into per-tile / per-workgroup rows and one extra launch adds the rows in a FIXED
@@ -420,12 +423,13 @@ int s3d_vm_backward_keys(const float* x, uint32_t N, const uint32_t* rank, const
  * backward kernels sum a bin exactly, in fixed point).  workspace: s3d_vm_backward_bins_workspace_size(N, n_bounds) bytes. */
 size_t s3d_vm_backward_bins_workspace_size(uint32_t N, uint32_t n_bounds);
 int s3d_vm_backward_bins(const float* x, uint32_t N, const uint32_t* rank, const uint32_t* resolution, int32_t* perm,
-                         int32_t* start, uint32_t n_bounds, void* workspace, size_t workspace_bytes, s3d_stream_t stream);
+                         int32_t* start, uint32_t n_bounds, void* workspace, size_t workspace_bytes, const int32_t* n_valid,
+                         s3d_stream_t stream);
 int s3d_vm_features_backward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                              const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
                              const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
                              float* const* grad_planes, float* const* grad_lines, uint32_t* bound_words, float* line_scratch,
-                             void* stage, size_t stage_bytes, float* found_inf, s3d_stream_t stream);
+                             void* stage, size_t stage_bytes, float* found_inf, const int32_t* n_valid, s3d_stream_t stream);
 
 /* The colour features with basis_mat applied inside the kernel (tensoRF/network.py:149-153: `basis_mat((mat * vec).T)`, an
  * nn.Linear(sum rank, basis_rows, bias=False) that runs under fp16 autocast): out [N, basis_rows] fp16 =
@@ -437,13 +441,13 @@ int s3d_vm_features_backward(const float* x, uint32_t N, const float* const* pla
  * [basis_rows, sum rank] (zero-initialised; accumulated with atomics). */
 int s3d_vm_color_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                          const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
-                         uint16_t* out, s3d_stream_t stream);
+                         uint16_t* out, const int32_t* n_valid, s3d_stream_t stream);
 int s3d_vm_color_backward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                           const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
                           const uint16_t* grad_out, const int32_t* perm, const int32_t* start, uint32_t n_bounds,
                           float* gm, float* const* grad_planes, float* const* grad_lines, float* grad_basis,
                           uint32_t* bound_words, float* line_scratch, void* stage, size_t stage_bytes, float* found_inf,
-                          s3d_stream_t stream);
+                          const int32_t* n_valid, s3d_stream_t stream);
 
 /* Build extensions for the TensoRF step (chains of tiny launches otherwise):
  * s3d_aabb_normalize: out[n][a] = 2 (x[n][a] - aabb[a]) / (aabb[3 + a] - aabb[a]) - 1 (tensoRF/network.py:155-157, the reference's

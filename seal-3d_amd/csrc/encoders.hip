@@ -90,11 +90,12 @@ __global__ void k_freq_backward(const float* __restrict__ grad, const float* __r
 // branches per value around the same sinf — took 61 us for 1.05e5 rows; the sines themselves are ~35 us of vector issue.]
 __global__ void __launch_bounds__(256) k_freq_pack_forward(const _Float16* __restrict__ a, const float* __restrict__ d, uint32_t B,
                                                             uint32_t D1, uint32_t deg1, uint32_t D2, uint32_t deg2, uint32_t ld,
-                                                            uint32_t lanes_per_row, _Float16* __restrict__ out) {
+                                                            uint32_t lanes_per_row, _Float16* __restrict__ out,
+                                                            const int32_t* __restrict__ n_valid) {
     const float half_pi = 3.141592653589793f / 2;
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     const uint32_t b = t / lanes_per_row, e = t - b * lanes_per_row;
-    if (b >= B) return;
+    if (b >= valid_rows(B, n_valid)) return;
     const uint32_t C1 = D1 + 2 * D1 * deg1, C2 = D2 + 2 * D2 * deg2;
     _Float16* row = out + (size_t)b * ld;
     if (e < D1 + D2) {
@@ -118,10 +119,10 @@ __global__ void __launch_bounds__(256) k_freq_pack_forward(const _Float16* __res
 // the columns behind D1 zero (the layout s3d_vm_color_backward reads: four 16-byte words per point)
 __global__ void __launch_bounds__(256) k_freq_pack_backward(const _Float16* __restrict__ grad, const _Float16* __restrict__ a, uint32_t B,
                                                              uint32_t D1, uint32_t deg1, uint32_t ld, uint32_t ldg,
-                                                             _Float16* __restrict__ grad_a) {
+                                                             _Float16* __restrict__ grad_a, const int32_t* __restrict__ n_valid) {
     const float half_pi = 3.141592653589793f / 2;
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= B * ldg) return;
+    if (t >= valid_rows(B, n_valid) * ldg) return;
     const uint32_t b = t / ldg, dd = t - b * ldg;
     float result = 0.0f;
     if (dd < D1) {
@@ -204,7 +205,7 @@ S3D_EXPORT int s3d_freq_encode_backward(const float* grad, const float* outputs,
 }
 
 S3D_EXPORT int s3d_freq_encode_pack_forward(const uint16_t* a, const float* d, uint32_t B, uint32_t D1, uint32_t deg1, uint32_t D2,
-                                            uint32_t deg2, uint32_t ld, uint16_t* out, s3d_stream_t stream) {
+                                            uint32_t deg2, uint32_t ld, uint16_t* out, const int32_t* n_valid, s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(a && d && out, "freq_encode_pack_forward: null pointer");
     const uint32_t C1 = D1 + 2 * D1 * deg1, C2 = D2 + 2 * D2 * deg2;
@@ -213,16 +214,16 @@ S3D_EXPORT int s3d_freq_encode_pack_forward(const uint16_t* a, const float* d, u
     while (lanes < D1 + D2 + 1) lanes <<= 1;  // (a power of two >= D1 + D2 + 1: at least one spare lane per row for the padding)
     S3D_REQUIRE((uint64_t)B * lanes < (1ull << 32), "freq_encode_pack_forward: too many rows");
     hipLaunchKernelGGL(k_freq_pack_forward, dim3(div_up<uint32_t>(B * lanes, 256)), dim3(256), 0, as_stream(stream),
-                       (const _Float16*)a, d, B, D1, deg1, D2, deg2, ld, lanes, (_Float16*)out);
+                       (const _Float16*)a, d, B, D1, deg1, D2, deg2, ld, lanes, (_Float16*)out, n_valid);
     return check_launch("freq_encode_pack_forward");
 }
 
 S3D_EXPORT int s3d_freq_encode_pack_backward(const uint16_t* grad, const uint16_t* a, uint32_t B, uint32_t D1, uint32_t deg1,
-                                             uint32_t ld, uint32_t ldg, uint16_t* grad_a, s3d_stream_t stream) {
+                                             uint32_t ld, uint32_t ldg, uint16_t* grad_a, const int32_t* n_valid, s3d_stream_t stream) {
     if (B == 0) return S3D_OK;
     S3D_REQUIRE(grad && a && grad_a, "freq_encode_pack_backward: null pointer");
     S3D_REQUIRE(D1 >= 1 && ld >= D1 + 2 * D1 * deg1 && ldg >= D1 && (uint64_t)B * ldg < (1ull << 32), "freq_encode_pack_backward: bad shape");
     hipLaunchKernelGGL(k_freq_pack_backward, dim3(div_up<uint32_t>(B * ldg, 256)), dim3(256), 0, as_stream(stream),
-                       (const _Float16*)grad, (const _Float16*)a, B, D1, deg1, ld, ldg, (_Float16*)grad_a);
+                       (const _Float16*)grad, (const _Float16*)a, B, D1, deg1, ld, ldg, (_Float16*)grad_a, n_valid);
     return check_launch("freq_encode_pack_backward");
 }

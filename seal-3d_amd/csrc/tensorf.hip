@@ -28,9 +28,10 @@ struct VmFactors {
 __device__ __forceinline__ float unnormalize(float c, uint32_t size) { return ((c + 1.0f) / 2.0f) * (float)(size - 1); }
 
 template <bool REDUCE>
-__global__ void __launch_bounds__(256) k_vm_features(const float* __restrict__ x, uint32_t N, VmFactors f, float* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_vm_features(const float* __restrict__ x, uint32_t N, VmFactors f, float* __restrict__ out,
+                                                     const int32_t* __restrict__ n_valid) {
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    if (n >= valid_rows(N, n_valid)) return;  // (a padded sample batch: rows behind the device-side count are absent)
     const float p[3] = {x[(size_t)n * 3], x[(size_t)n * 3 + 1], x[(size_t)n * 3 + 2]};
     float total = 0.0f;
 #pragma unroll
@@ -86,15 +87,16 @@ constexpr uint32_t kVmBasisPad = 32;  // output channels held per lane (basis_ma
 
 __global__ void __launch_bounds__(256) k_vm_color_basis(const float* __restrict__ x, uint32_t N, VmFactors f,
                                                         const _Float16* __restrict__ basis, uint32_t Cb, uint32_t rows,
-                                                        _Float16* __restrict__ out) {
+                                                        _Float16* __restrict__ out, const int32_t* __restrict__ n_valid) {
     extern __shared__ float vm_smem[];  // [rows][kVmBasisPad]
+    if (blockIdx.x * 256 >= valid_rows(N, n_valid)) return;
     for (uint32_t e = threadIdx.x; e < rows * kVmBasisPad; e += 256) {
         const uint32_t row = e / kVmBasisPad, c = e % kVmBasisPad;
         vm_smem[e] = c < Cb ? (float)basis[(size_t)c * rows + row] : 0.0f;
     }
     __syncthreads();
     const uint32_t n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    if (n >= valid_rows(N, n_valid)) return;
     const float p[3] = {x[(size_t)n * 3], x[(size_t)n * 3 + 1], x[(size_t)n * 3 + 2]};
     float acc[kVmBasisPad];
 #pragma unroll
@@ -239,12 +241,14 @@ __global__ void __launch_bounds__(256) k_vm_zero_words(uint32_t* __restrict__ p,
     if (i < n) p[i] = 0u;
 }
 __global__ void __launch_bounds__(kVmBinThreads) k_vm_bin_count(const float* __restrict__ x, uint32_t N, VmFactors f, uint32_t n_bounds,
-                                                                uint32_t nlb, uint32_t* __restrict__ keys, uint32_t* __restrict__ counts) {
+                                                                uint32_t nlb, uint32_t* __restrict__ keys, uint32_t* __restrict__ counts,
+                                                                const int32_t* __restrict__ n_valid) {
     __shared__ uint32_t lc[3][kVmLineSlots];
     if (threadIdx.x < 3 * kVmLineSlots) (&lc[0][0])[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t n = blockIdx.x * kVmBinThreads + threadIdx.x;
     const bool live = n < N;
+    const bool absent = n >= valid_rows(N, n_valid);  // rows behind the device-side count sort behind every bin, like points without a contribution
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
     for (uint32_t i = 0; i < 3; i++) {
@@ -252,14 +256,15 @@ __global__ void __launch_bounds__(kVmBinThreads) k_vm_bin_count(const float* __r
         const int tiles_x = ((int)f.W[i] + kVmTile - 1) / kVmTile;
         const uint32_t tk = (uint32_t)((clampi(q.y0, 0, (int)f.H[i] - 1) / kVmTile) * tiles_x + clampi(q.x0, 0, (int)f.W[i] - 1) / kVmTile);
         const uint32_t zk = (uint32_t)(clampi(q.z0, 0, (int)f.Dn[i] - 1) / kVmZChunk);
-        const uint32_t kp = q.valid ? tk : n_bounds - 1u, kl = q.valid ? zk : n_bounds - 1u;
+        const bool contributes = q.valid && !absent;
+        const uint32_t kp = contributes ? tk : n_bounds - 1u, kl = contributes ? zk : n_bounds - 1u;
         if (live) {
             keys[(size_t)i * N + n] = kp;
             keys[(size_t)(3 + i) * N + n] = kl;
         }
         const BinGroup gp = wave_bin_group(kp, lane, live);
         if (live && lane == gp.leader) atomicAdd(&counts[i * n_bounds + kp], gp.size);  // (no value returned: nothing waits for it)
-        const uint32_t slot = q.valid ? zk : nlb;
+        const uint32_t slot = contributes ? zk : nlb;
         const BinGroup gl = wave_bin_group(slot, lane, live);
         if (live && lane == gl.leader) atomicAdd(&lc[i][slot], gl.size);
     }
@@ -452,8 +457,14 @@ __device__ __forceinline__ uint32_t nan_aware_bits(float m, bool bad) { return b
 __global__ void __launch_bounds__(256) k_vm_bound(const float* __restrict__ g, size_t n_g, const _Float16* __restrict__ g16, size_t n_g16,
                                                    VmFactors f, const _Float16* __restrict__ basis, uint32_t Cb, uint32_t rows,
                                                    uint32_t* __restrict__ bound, float* __restrict__ line_t,
-                                                   uint32_t* __restrict__ stage_flags, uint32_t n_stage_flags) {
+                                                   uint32_t* __restrict__ stage_flags, uint32_t n_stage_flags,
+                                                   uint32_t N, const int32_t* __restrict__ n_valid) {
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
+    if (n_valid) {  // (padded sample batch: the gradient rows behind the count are not looked at — they may hold anything)
+        const size_t nv = valid_rows(N, n_valid);
+        n_g = n_g / N * nv;
+        n_g16 = n_g16 / N * nv;
+    }
     for (size_t k = tid; k < n_stage_flags; k += nt) stage_flags[k] = 0u;  // (staged flushes: nothing staged yet)
     float m = 0.0f;
     bool bad = false;
@@ -1437,7 +1448,7 @@ S3D_EXPORT size_t s3d_vm_backward_bins_workspace_size(uint32_t N, uint32_t n_bou
 // keys + counts, scan, scatter: four launches (with the clearing of the counters) instead of torch.sort's ~20 merge passes over
 // 6N words and a dozen small tensor ops around it
 S3D_EXPORT int s3d_vm_backward_bins(const float* x, uint32_t N, const uint32_t* rank, const uint32_t* resolution, int32_t* perm,
-                                    int32_t* start, uint32_t n_bounds, void* workspace, size_t workspace_bytes, s3d_stream_t stream) {
+                                    int32_t* start, uint32_t n_bounds, void* workspace, size_t workspace_bytes, const int32_t* n_valid, s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && rank && resolution && perm && start && workspace, "vm_backward_bins: null pointer");
     S3D_REQUIRE(n_bounds >= s3d_vm_backward_max_bins(resolution) + 2, "vm_backward_bins: n_bounds must exceed max_bins + 1");
@@ -1457,7 +1468,7 @@ S3D_EXPORT int s3d_vm_backward_bins(const float* x, uint32_t N, const uint32_t* 
     uint32_t nlb = 0;  // line chunks of the longest axis
     for (uint32_t i = 0; i < 3; i++) nlb = std::max(nlb, div_up<uint32_t>(resolution[i], (uint32_t)kVmZChunk));
     S3D_REQUIRE(nlb < kVmLineSlots, "vm_backward_bins: resolution %u has more than %u line chunks", nlb * kVmZChunk, kVmLineSlots - 1);
-    hipLaunchKernelGGL(k_vm_bin_count, dim3(div_up<uint32_t>(N, kVmBinThreads)), dim3(kVmBinThreads), 0, st, x, N, f, n_bounds, nlb, keys, counts);
+    hipLaunchKernelGGL(k_vm_bin_count, dim3(div_up<uint32_t>(N, kVmBinThreads)), dim3(kVmBinThreads), 0, st, x, N, f, n_bounds, nlb, keys, counts, n_valid);
     hipLaunchKernelGGL(k_vm_bin_scan, dim3(1), dim3(384), 0, st, (const uint32_t*)counts, n_bounds, start);
     hipLaunchKernelGGL(k_vm_bin_scatter, dim3(div_up<uint32_t>(N, kVmBinThreads)), dim3(kVmBinThreads), 0, st, (const uint32_t*)keys, N,
                        n_bounds, nlb, (const int32_t*)start, cursors, perm);
@@ -1601,7 +1612,8 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
                                         const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
                                         const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
                                         float* const* grad_planes, float* const* grad_lines, uint32_t* bound_words,
-                                        float* line_scratch, void* stage, size_t stage_bytes, float* found_inf, s3d_stream_t stream) {
+                                        float* line_scratch, void* stage, size_t stage_bytes, float* found_inf, const int32_t* n_valid,
+                                        s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && planes && lines && rank && resolution && grad && perm && start && gm && grad_planes && grad_lines && bound_words &&
                 line_scratch, "vm_features_backward: null pointer");
@@ -1640,7 +1652,7 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
     uint32_t* stage_flags;
     const uint32_t n_stage_flags = vm_stage_arm(b, N, rank, resolution, stage, stage_bytes, stage_flags);
     hipLaunchKernelGGL(k_vm_bound, dim3(std::min<uint32_t>(stream_grid(n_g / 4 + 1, 256), 512u)), dim3(256), 0, st, grad, n_g, (const _Float16*)nullptr, (size_t)0, f,
-                       (const _Float16*)nullptr, 0u, b.rows, bound_words, line_scratch, stage_flags, n_stage_flags);
+                       (const _Float16*)nullptr, 0u, b.rows, bound_words, line_scratch, stage_flags, n_stage_flags, N, n_valid);
     const bool mm = reduce ? launch_plane_mm<0>(x, N, f, b, st) : launch_plane_mm<1>(x, N, f, b, st);
     if (max_rank <= 16) {
         if (mm) {}
@@ -1659,7 +1671,7 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
 
 S3D_EXPORT int s3d_vm_color_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                                     const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
-                                    uint16_t* out, s3d_stream_t stream) {
+                                    uint16_t* out, const int32_t* n_valid, s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && planes && lines && rank && resolution && basis && out, "vm_color_forward: null pointer");
     VmFactors f;
@@ -1669,7 +1681,7 @@ S3D_EXPORT int s3d_vm_color_forward(const float* x, uint32_t N, const float* con
                 basis_rows, kVmBasisPad);
     S3D_REQUIRE(rows * kVmBasisPad * sizeof(float) <= 64 * 1024, "vm_color_forward: %u product rows do not fit the LDS table", rows);
     hipLaunchKernelGGL(k_vm_color_basis, dim3(div_up<uint32_t>(N, 256)), dim3(256), rows * kVmBasisPad * sizeof(float), as_stream(stream),
-                       x, N, f, (const _Float16*)basis, basis_rows, rows, (_Float16*)out);
+                       x, N, f, (const _Float16*)basis, basis_rows, rows, (_Float16*)out, n_valid);
     return check_launch("vm_color_forward");
 }
 
@@ -1678,7 +1690,7 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
                                      const uint16_t* grad_out, const int32_t* perm, const int32_t* start, uint32_t n_bounds,
                                      float* gm, float* const* grad_planes, float* const* grad_lines, float* grad_basis,
                                      uint32_t* bound_words, float* line_scratch, void* stage, size_t stage_bytes, float* found_inf,
-                                     s3d_stream_t stream) {
+                                     const int32_t* n_valid, s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && planes && lines && rank && resolution && basis && grad_out && perm && start && gm && grad_planes && grad_lines &&
                 grad_basis && bound_words && line_scratch, "vm_color_backward: null pointer");
@@ -1722,7 +1734,7 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
     uint32_t* stage_flags;
     const uint32_t n_stage_flags = vm_stage_arm(b, N, rank, resolution, stage, stage_bytes, stage_flags);
     hipLaunchKernelGGL(k_vm_bound, dim3(std::min<uint32_t>(stream_grid(n_g16 / 8 + 1, 256), 512u)), dim3(256), 0, st, (const float*)nullptr, (size_t)0,
-                       (const _Float16*)grad_out, n_g16, f, (const _Float16*)basis, basis_rows, b.rows, bound_words, line_scratch, stage_flags, n_stage_flags);
+                       (const _Float16*)grad_out, n_g16, f, (const _Float16*)basis, basis_rows, b.rows, bound_words, line_scratch, stage_flags, n_stage_flags, N, n_valid);
     if (!launch_plane_mm<2>(x, N, f, b, st)) hipLaunchKernelGGL((k_vm_plane_backward<64, false, true>), gp, block, smem_p, st, x, N, f, b);
     if (!launch_line_mm(x, N, f, b, st)) hipLaunchKernelGGL((k_vm_line_backward<64>), gl, block, smem_l, st, x, N, f, b);
     if (b.stage_line) hipLaunchKernelGGL(k_vm_flush_reduce, dim3(div_up<uint32_t>(b.stage_tiles, kVmReduceTiles) + kVmLineParts * max_chunks, 3), dim3(256), 0, st, f, b);
@@ -1731,15 +1743,15 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
 
 S3D_EXPORT int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                                        const uint32_t* rank, const uint32_t* resolution, int reduce, float* out,
-                                       s3d_stream_t stream) {
+                                       const int32_t* n_valid, s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && planes && lines && rank && resolution && out, "vm_features_forward: null pointer");
     VmFactors f;
     uint32_t row;
     if (int rc = fill_factors(f, planes, lines, rank, resolution, row)) return rc;
     const dim3 grid(div_up<uint32_t>(N, 256)), block(256);
-    if (reduce) hipLaunchKernelGGL((k_vm_features<true>), grid, block, 0, as_stream(stream), x, N, f, out);
-    else hipLaunchKernelGGL((k_vm_features<false>), grid, block, 0, as_stream(stream), x, N, f, out);
+    if (reduce) hipLaunchKernelGGL((k_vm_features<true>), grid, block, 0, as_stream(stream), x, N, f, out, n_valid);
+    else hipLaunchKernelGGL((k_vm_features<false>), grid, block, 0, as_stream(stream), x, N, f, out, n_valid);
     return check_launch("vm_features_forward");
 }
 

@@ -610,24 +610,24 @@ class FreqBackend:
                "freq_encode_forward")
 
     @staticmethod
-    def freq_encode_pack_forward(a, d, deg1, deg2, out):
+    def freq_encode_pack_forward(a, d, deg1, deg2, out, n_valid=None):
         """out fp16 [B, ld] = [freq(a) | freq(d) | 0]: a fp16 [B, D1], d fp32 [B, D2] (seal3d_hip.h)"""
         _need(a, torch.float16, "a"); _need(d, torch.float32, "d"); _need(out, torch.float16, "out")
         B = a.shape[0]
         if not (a.is_contiguous() and d.is_contiguous() and out.is_contiguous()) or d.shape[0] != B or out.shape[0] != B:
             raise RuntimeError("freq_encode_pack_forward: contiguous a [B, D1], d [B, D2], out [B, ld]")
         _check(lib().s3d_freq_encode_pack_forward(_p(a), _p(d), _u(B), _u(a.shape[1]), _u(deg1), _u(d.shape[1]), _u(deg2), _u(out.shape[1]),
-                                                  _p(out), _stream()), "freq_encode_pack_forward")
+                                                  _p(out), _nv(n_valid), _stream()), "freq_encode_pack_forward")
 
     @staticmethod
-    def freq_encode_pack_backward(grad, a, deg1, grad_a):
+    def freq_encode_pack_backward(grad, a, deg1, grad_a, n_valid=None):
         """grad_a fp16 [B, ldg] (columns behind D1 zero) from the packed row's gradient fp16 [B, ld]"""
         _need(grad, torch.float16, "grad"); _need(a, torch.float16, "a"); _need(grad_a, torch.float16, "grad_a")
         B = a.shape[0]
         if not (grad.is_contiguous() and a.is_contiguous() and grad_a.is_contiguous()) or grad.shape[0] != B or grad_a.shape[0] != B:
             raise RuntimeError("freq_encode_pack_backward: contiguous grad [B, ld], a [B, D1], grad_a [B, ldg]")
         _check(lib().s3d_freq_encode_pack_backward(_p(grad), _p(a), _u(B), _u(a.shape[1]), _u(deg1), _u(grad.shape[1]), _u(grad_a.shape[1]),
-                                                   _p(grad_a), _stream()), "freq_encode_pack_backward")
+                                                   _p(grad_a), _nv(n_valid), _stream()), "freq_encode_pack_backward")
 
     @staticmethod
     def freq_encode_backward(grad, outputs, B, D, deg, Cc, grad_inputs):
@@ -1049,7 +1049,7 @@ class VmBackend:
     """csrc/tensorf.hip — TensoRF vector-matrix features (tensoRF/network.py:112-153 of the reference)"""
 
     @staticmethod
-    def features_forward(x, planes, lines, resolution, reduce, out):
+    def features_forward(x, planes, lines, resolution, reduce, out, n_valid=None):
         """x [N,3] fp32; planes[i] [1,R_i,H,W] / lines[i] [1,R_i,D,1] fp32 (the reference's parameter shapes);
         out [N] (reduce) or [sum R_i, N]"""
         _need(x, torch.float32, "x"); _need(out, torch.float32, "out")
@@ -1066,7 +1066,7 @@ class VmBackend:
         rank = u3(*[int(t.shape[1]) for t in planes])
         res = u3(*[int(r) for r in resolution])
         _check(lib().s3d_vm_features_forward(_p(x), _u(x.shape[0]), pl, ln, rank, res, C.c_int(int(bool(reduce))), _p(out),
-                                             _stream()), "vm_features_forward")
+                                             _nv(n_valid), _stream()), "vm_features_forward")
 
     @staticmethod
     def aabb_normalize(x, aabb, out):
@@ -1124,7 +1124,7 @@ class VmBackend:
     native_bins = os.environ.get("S3D_VM_BINS", "native") != "torch"
 
     @staticmethod
-    def backward_bins(x, planes, resolution):
+    def backward_bins(x, planes, resolution, n_valid=None):
         """(perm [6,N] i32, start [6,n_bounds] i32, n_bounds): the points sorted by plane tile / line chunk, as the backward
         kernels want them.  Depends on x and the resolution only — the density and the colour factors of one network share it."""
         N, dev = x.shape[0], x.device
@@ -1138,8 +1138,10 @@ class VmBackend:
             nbytes = int(lib().s3d_vm_backward_bins_workspace_size(_u(N), _u(n_bounds)))
             work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             _check(lib().s3d_vm_backward_bins(_p(x), _u(N), rank, res, _p(perm), _p(start), _u(n_bounds), _p(work), C.c_size_t(nbytes),
-                                              _stream()), "vm_backward_bins")
+                                              _nv(n_valid), _stream()), "vm_backward_bins")
             return perm, start, n_bounds
+        if n_valid is not None:
+            raise RuntimeError("vm backward bins: the torch.sort twin (A/B) has no padded-batch form")
         keys = torch.empty(6, N, dtype=torch.int32, device=dev)
         _check(lib().s3d_vm_backward_keys(_p(x), _u(N), rank, res, _p(keys), _stream()), "vm_backward_keys")
         # (A/B path: the same list through torch.sort — one sort over all six rows, row number above the key bits)
@@ -1159,7 +1161,7 @@ class VmBackend:
         return torch.empty(int(lib().s3d_vm_backward_stage_bytes(_u(N), rank, res)), dtype=torch.uint8, device=dev)
 
     @staticmethod
-    def features_backward(x, planes, lines, resolution, reduce, grad, bins=None, found_inf=None):
+    def features_backward(x, planes, lines, resolution, reduce, grad, bins=None, found_inf=None, n_valid=None):
         """gradients of features_forward w.r.t. planes / lines (lists shaped like the factors).  grad: [N] (reduce) or
         [N, sum R_i] point-major.  `bins`: a backward_bins() result for the same x / resolution."""
         _need(x, torch.float32, "x"); _need(grad, torch.float32, "grad")
@@ -1170,7 +1172,7 @@ class VmBackend:
         rows = sum(int(t.shape[1]) for t in planes)
         if not grad.is_contiguous() or grad.numel() != (N if reduce else N * rows):
             raise RuntimeError("vm features backward: grad must be contiguous [N] / [N, sum rank]")
-        perm, start, n_bounds = bins if bins is not None else VmBackend.backward_bins(x, planes, resolution)
+        perm, start, n_bounds = bins if bins is not None else VmBackend.backward_bins(x, planes, resolution, n_valid)
         gm = torch.empty(N, rows, dtype=torch.float32, device=dev)  # (written by the plane pass for every point the line pass reads)
         # (named locals: temporaries created inside the argument list would be freed one by one and handed the SAME block)
         gs, bound_words = _zeros_like_many(list(planes) + list(lines), 4)
@@ -1182,11 +1184,11 @@ class VmBackend:
                                               _p(grad), _p(perm), _p(start), _u(n_bounds), _p(gm),
                                               ptr3(*[t.data_ptr() for t in g_planes]), ptr3(*[t.data_ptr() for t in g_lines]),
                                               _p(bound_words), _p(line_scratch), _p(stage), C.c_size_t(stage.numel()), _p(found_inf),
-                                              _stream()), "vm_features_backward")
+                                              _nv(n_valid), _stream()), "vm_features_backward")
         return g_planes, g_lines
 
     @staticmethod
-    def color_forward(x, planes, lines, resolution, basis, out):
+    def color_forward(x, planes, lines, resolution, basis, out, n_valid=None):
         """colour products with basis_mat applied in the kernel: basis fp16 [Cb, sum R_i] (the Linear's weight), out fp16 [N, Cb]"""
         _need(x, torch.float32, "x"); _need(basis, torch.float16, "basis"); _need(out, torch.float16, "out")
         for t in list(planes) + list(lines):
@@ -1201,11 +1203,11 @@ class VmBackend:
         ptr3, u3 = C.c_void_p * 3, C.c_uint32 * 3
         _check(lib().s3d_vm_color_forward(_p(x), _u(x.shape[0]), ptr3(*[t.data_ptr() for t in planes]),
                                           ptr3(*[t.data_ptr() for t in lines]), u3(*[int(t.shape[1]) for t in planes]),
-                                          u3(*[int(r) for r in resolution]), _p(basis), _u(basis.shape[0]), _p(out), _stream()),
-               "vm_color_forward")
+                                          u3(*[int(r) for r in resolution]), _p(basis), _u(basis.shape[0]), _p(out), _nv(n_valid),
+                                          _stream()), "vm_color_forward")
 
     @staticmethod
-    def color_backward(x, planes, lines, resolution, basis, grad_out, bins=None, found_inf=None):
+    def color_backward(x, planes, lines, resolution, basis, grad_out, bins=None, found_inf=None, n_valid=None):
         """gradients of color_forward w.r.t. planes / lines / basis from grad_out fp16 [N, Cb]: (g_planes, g_lines, g_basis fp32)"""
         _need(x, torch.float32, "x"); _need(basis, torch.float16, "basis"); _need(grad_out, torch.float16, "grad_out")
         N, dev = x.shape[0], x.device
@@ -1221,7 +1223,7 @@ class VmBackend:
             grad_out = base
         else:
             grad_out = torch.nn.functional.pad(grad_out, (0, 32 - basis.shape[0])).contiguous()
-        perm, start, n_bounds = bins if bins is not None else VmBackend.backward_bins(x, planes, resolution)
+        perm, start, n_bounds = bins if bins is not None else VmBackend.backward_bins(x, planes, resolution, n_valid)
         gm = torch.empty(N, rows, dtype=torch.float32, device=dev)  # (written by the plane pass for every point the line pass reads)
         gs, bound_words = _zeros_like_many(list(planes) + list(lines) + [basis], 4)
         g_planes, g_lines, g_basis = gs[:3], gs[3:6], gs[6]
@@ -1233,5 +1235,5 @@ class VmBackend:
                                            _p(perm), _p(start), _u(n_bounds), _p(gm), ptr3(*[t.data_ptr() for t in g_planes]),
                                            ptr3(*[t.data_ptr() for t in g_lines]), _p(g_basis),
                                            _p(bound_words), _p(line_scratch), _p(stage), C.c_size_t(stage.numel()), _p(found_inf),
-                                           _stream()), "vm_color_backward")
+                                           _nv(n_valid), _stream()), "vm_color_backward")
         return g_planes, g_lines, g_basis

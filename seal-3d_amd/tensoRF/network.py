@@ -49,10 +49,13 @@ class _VmFeatures(torch.autograd.Function):
         mats, vecs = factors[:3], factors[3:]
         N = x.shape[0]
         out = torch.empty((N,) if reduce else (sum(m.shape[1] for m in mats), N), dtype=torch.float32, device=x.device)
+        # (a padded sample batch announced by the renderer, s3d_hip.row_limit: rows behind the device-side count are absent —
+        #  not written here, sorted behind every bin in the backward, nerf/renderer.py never reads them)
+        nv = s3d_hip.active_row_limit(N)
         s3d_hip.VmBackend.features_forward(x, [m.contiguous() for m in mats], [v.contiguous() for v in vecs], net.resolution,
-                                           reduce, out)
+                                           reduce, out, n_valid=nv)
         ctx.save_for_backward(x, *factors)
-        ctx.net, ctx.reduce = net, reduce
+        ctx.net, ctx.reduce, ctx.nv = net, reduce, nv
         return out
 
     @staticmethod
@@ -63,9 +66,12 @@ class _VmFeatures(torch.autograd.Function):
             g = g if ctx.reduce else g.t()  # [rows, N] gradient of the `.T` consumer: point-major underneath
             gp, gl = s3d_hip.VmBackend.features_backward(x, [f.contiguous() for f in factors[:3]],
                                                          [f.contiguous() for f in factors[3:]], ctx.net.resolution, ctx.reduce,
-                                                         g.float().contiguous(), _bins(ctx.net, x, factors[:3]),
-                                                         _source_check(ctx.net, factors))
+                                                         g.float().contiguous(), _bins(ctx.net, x, factors[:3], ctx.nv),
+                                                         _source_check(ctx.net, factors), n_valid=ctx.nv)
             return (None, None, None) + tuple(gp) + tuple(gl)
+        if ctx.nv is not None:  # (the torch route sums over every row: the absent ones hold anything)
+            live = torch.arange(x.shape[0], device=x.device) < (ctx.nv.reshape(-1)[:1] + 127) // 128 * 128
+            g = torch.where(live if ctx.reduce else live.unsqueeze(0), g, torch.zeros((), dtype=g.dtype, device=g.device))
         with torch.enable_grad():
             leaves = [f.detach().requires_grad_(True) for f in factors]
             xin = x.detach().requires_grad_(ctx.needs_input_grad[0])
@@ -77,18 +83,18 @@ class _VmFeatures(torch.autograd.Function):
         return (gx, None, None) + tuple(grads[1:] if ctx.needs_input_grad[0] else grads)
 
 
-def _bins(net, x, mats):
+def _bins(net, x, mats, n_valid=None):
     """the points of x sorted by plane tile / line chunk (VmBackend.backward_bins): x and the resolution decide it, so the
     density and the colour features of one forward share the sort.  Kept on the network, keyed by the storage of x (alive
     until both backward nodes have run), dropped at the next forward."""
     cache = net.__dict__.setdefault("_vm_bins", {})
-    key = (x.data_ptr(), x._version, x.shape[0], tuple(net.resolution))
+    key = (x.data_ptr(), x._version, x.shape[0], tuple(net.resolution), None if n_valid is None else n_valid.data_ptr())
     if key not in cache:
         if len(cache) >= 4:
             cache.clear()
         # (the entry keeps x itself: while it is cached no other tensor can live at its address; two consumers — the density
         #  and the colour features' backward — then the points and their six sorted index rows are let go)
-        cache[key] = [x, s3d_hip.VmBackend.backward_bins(x, [m.contiguous() for m in mats], net.resolution), 2]
+        cache[key] = [x, s3d_hip.VmBackend.backward_bins(x, [m.contiguous() for m in mats], net.resolution, n_valid), 2]
     ent = cache[key]
     ent[2] -= 1
     if ent[2] <= 0:
@@ -108,9 +114,10 @@ class _VmColorBasis(torch.autograd.Function):
         mats, vecs = [f.float().contiguous() for f in factors[:3]], [f.float().contiguous() for f in factors[3:]]
         w16 = weight.detach().to(torch.float16).contiguous()
         out = torch.empty(x.shape[0], w16.shape[0], dtype=torch.float16, device=x.device)
-        s3d_hip.VmBackend.color_forward(x, mats, vecs, net.resolution, w16, out)
+        nv = s3d_hip.active_row_limit(x.shape[0])
+        s3d_hip.VmBackend.color_forward(x, mats, vecs, net.resolution, w16, out, n_valid=nv)
         ctx.save_for_backward(x, w16, *factors)
-        ctx.net = net
+        ctx.net, ctx.nv = net, nv
         return out
 
     @staticmethod
@@ -119,7 +126,8 @@ class _VmColorBasis(torch.autograd.Function):
         mats, vecs = [f.float().contiguous() for f in factors[:3]], [f.float().contiguous() for f in factors[3:]]
         # (g as it arrives: a [:, :27] view of _MlpInput's zero-padded [N, 32] gradient is used in place, anything else is padded)
         gp, gl, gw = s3d_hip.VmBackend.color_backward(x, mats, vecs, ctx.net.resolution, w16, g.to(torch.float16),
-                                                      _bins(ctx.net, x, mats), _source_check(ctx.net, factors, ctx.net.basis_mat.weight))
+                                                      _bins(ctx.net, x, mats, ctx.nv), _source_check(ctx.net, factors, ctx.net.basis_mat.weight),
+                                                      n_valid=ctx.nv)
         return (None, None, gw) + tuple(gp) + tuple(gl)
 
 
@@ -134,16 +142,17 @@ class _MlpInput(torch.autograd.Function):
         feat = feat.to(torch.float16).contiguous()
         dirs = dirs.float().contiguous()
         out = torch.empty(feat.shape[0], ld, dtype=torch.float16, device=feat.device)
-        s3d_hip.FreqBackend.freq_encode_pack_forward(feat, dirs, deg1, deg2, out)
+        nv = s3d_hip.active_row_limit(feat.shape[0])
+        s3d_hip.FreqBackend.freq_encode_pack_forward(feat, dirs, deg1, deg2, out, n_valid=nv)
         ctx.save_for_backward(feat)
-        ctx.deg1 = deg1
+        ctx.deg1, ctx.nv = deg1, nv
         return out
 
     @staticmethod
     def backward(ctx, g):
         feat, = ctx.saved_tensors
         ga = torch.empty(feat.shape[0], max(32, feat.shape[1]), dtype=torch.float16, device=feat.device)
-        s3d_hip.FreqBackend.freq_encode_pack_backward(g.to(torch.float16).contiguous(), feat, ctx.deg1, ga)
+        s3d_hip.FreqBackend.freq_encode_pack_backward(g.to(torch.float16).contiguous(), feat, ctx.deg1, ga, n_valid=ctx.nv)
         ga._s3d_zero_padded = True  # (VmBackend.color_backward takes the buffer behind the view)
         return ga[:, :feat.shape[1]], None, None, None, None
 
@@ -361,12 +370,14 @@ class NeRFNetwork(NeRFRenderer):
         flat = _PackChain.apply(in_pad, *[l.weight for l in net])
         # (the kernels write the output padded to 16 columns, ffmlp.py:117-118, 162-163)
         # (no graph being recorded — rendering: the inference entry point, no activation buffers)
-        out16 = _FFMLPForward.apply(h, flat, in_pad, 16, self.hidden_dim, len(net) - 1, 0, 6, not torch.is_grad_enabled(), True)
+        nv = s3d_hip.active_row_limit(cf.shape[0])  # (padded sample batch: the MLP kernels skip the absent rows too)
+        out16 = _FFMLPForward.apply(h, flat, in_pad, 16, self.hidden_dim, len(net) - 1, 0, 6, not torch.is_grad_enabled(), True,
+                                    None, None, 0, nv)
         if out == 3:
             # sigmoid of the three real columns as fp32 with torch.sigmoid's fp16 rounding, one launch per direction
             # (nerf/network_ff.py: _NgpRgb — instead of slice, sigmoid, cast and their four backward launches)
             from nerf.network_ff import _NgpRgb
-            return _NgpRgb.apply(out16)
+            return _NgpRgb.apply(out16, nv)
         return torch.sigmoid(out16[:, :out])
 
     def density(self, x):

@@ -83,10 +83,10 @@ class GraphedTrainer(TensoRFSteps, _GraphedTrainer):
 
     def __init__(self, model, num_rays, lr0=2e-2, lr1=1e-3, l1_reg_weight=1e-4, upsample_model_steps=(), upsample_resolutions=(), **kw):
         self._init_tensorf(lr0, lr1, l1_reg_weight, upsample_model_steps, upsample_resolutions)
-        # the static sample budget: this backbone's kernels take no device-side row count, so every row of the budget is
-        # processed — 10 % of headroom over the running mean instead of the NGP trainer's 30 % (the reference's own budget is the
-        # running mean itself, nerf/renderer.py:352-356; rays that do not fit are dropped the same way, raymarching.cu:416)
-        kw.setdefault("budget_factor", 1.1)
+        # the static sample budget: since round 6 every kernel of this backbone's sample path takes the device-side row count
+        # (s3d_hip.row_limit -> n_valid), so the padding costs nothing and the budget keeps the NGP trainer's 30 % of headroom over
+        # the running mean (the reference's own budget is the running mean itself, nerf/renderer.py:352-356; rays that do not
+        # fit are dropped the same way, raymarching.cu:416)
         _GraphedTrainer.__init__(self, model, num_rays, lr=lr0, **kw)
         self._attach_source_checks()
 

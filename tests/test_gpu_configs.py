@@ -799,6 +799,44 @@ def test_vm_matrix_core_backward_other_ranks_vs_grid_sample_autograd(hip, sigma_
         assert bool((err <= tol).all()), (k, float((err / tol).max()), float(err.max()), float(b.abs().max()))
 
 
+def test_tensorf_padded_sample_batch_follows_the_device_side_count(hip):
+    """s3d_hip.row_limit -> n_valid on the TensoRF sample path (VM feature kernels, binning, factor backward, frequency packing,
+    W = 128 MLP, rgb head): a batch padded to a static extent with NaN positions behind the announced count gives the outputs of
+    the live rows bit for bit and the same parameter gradients as the unpadded call (factor gradients: exact fixed-point sums,
+    fp32 flush order; MLP weights: the partial-sum split follows the batch extent, 2e-3)."""
+    import s3d_hip
+    net = _vm48(res=96)
+    x, m = _vm48_marched_samples(n_rays=1024)
+    n0 = (m // 128) * 128 - 300 - 37            # the count the marcher would leave on the device
+    live = (n0 + 127) // 128 * 128              # rows the kernels work on
+    M = live + 2048                             # the static extent of the padded buffers
+    g = torch.Generator().manual_seed(3)
+    d = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=-1).cuda()
+    ws, wr = torch.randn(live, generator=g).cuda(), torch.randn(live, 3, generator=g).cuda()
+    xp = torch.full((M, 3), float("nan"), device="cuda")
+    xp[:live] = x[:live]
+    counter = torch.tensor([n0, 0], dtype=torch.int32, device="cuda")
+    res = {}
+    for tag in ("plain", "padded"):
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            if tag == "plain":
+                sigma, rgb = net(x[:live].contiguous(), d[:live].contiguous())
+            else:
+                with s3d_hip.row_limit(counter, M):
+                    sigma, rgb = net(xp, d)
+        ((sigma[:live].float() * ws).sum() + (rgb[:live].float() * wr).sum()).backward()
+        res[tag] = (sigma[:live].detach().float().clone(), rgb[:live].detach().float().clone(),
+                    {n: p.grad.float().clone() for n, p in net.named_parameters() if p.grad is not None})
+    assert torch.equal(res["plain"][0], res["padded"][0]) and torch.equal(res["plain"][1], res["padded"][1])
+    assert set(res["plain"][2]) == set(res["padded"][2]) and len(res["plain"][2]) >= 13
+    for n, a in res["plain"][2].items():
+        b = res["padded"][2][n]
+        assert bool(torch.isfinite(b).all()), n
+        tol = (2e-3 if n.startswith("color_net") else 1e-5) * float(a.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= tol, (n, float((a - b).abs().max()), float(a.abs().max()))
+
+
 def test_vm_backward_keeps_gradients_far_below_the_batch_maximum(hip):
     """the fixed-point accumulators are scaled by ONE bound per call (placed at 2^50, contributions rounded to
     nearest).  A region whose gradients lie 2^36 below the batch maximum — and, with the bound's slack (max |g| x max |line|),
