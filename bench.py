@@ -908,8 +908,12 @@ def main():
                         scaler=trainer.scaler)
         eager.global_step = 1
         install_timers(queue_ahead=True)
-        timer_steps = 8
-        for i in range(timer_steps):
+        timer_steps = 32
+        for i in range(-2, timer_steps):
+            if i == 0:  # (the first step of either kind pays first-use allocations: not kept)
+                torch.cuda.synchronize()
+                for t in (timers, rt, ft):
+                    t.reset()
             ro, rd, gt = batches[i % n_pool]
             # (half of the pass with the table's update as its own launch: the plain scatter + accumulate pair stays measured,
             #  `roofline_grid_backward_plain`, next to the product's in-backward update)
@@ -981,7 +985,7 @@ def main():
                 "kernels_ms_per_step": {k: v["total_ms"] / timer_steps for k, v in ksum.items()},
                 "kernel_calls_in_timing_pass": {k: v["calls"] for k, v in ksum.items()},
                 "timing": "HIP events around each native call on the launch stream; " +
-                          ("eager pass of 8 identical steps right after the graph-replayed timed region, each call queued behind "
+                          ("eager pass of 32 identical steps (2 more discarded) right after the graph-replayed timed region, each call queued behind "
                            "a short GPU spin so that its kernels run back to back as in the graph" if graphed
                            else "inside the timed region")}
 
