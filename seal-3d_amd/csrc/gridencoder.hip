@@ -629,7 +629,7 @@ __device__ __forceinline__ long long to_fixed64(float v, int k) {
 // [An earlier version skipped the partition: every (level, slice) workgroup scanned ALL points and kept the hits.
 //  That is ~55x redundant index arithmetic; the partitioned form measured 2.3-3.5x faster at every size.]
 //
-// Slices are INTERLEAVED in groups of kBinGroup rows (slice = (row / 32) % S): a dense level's rows follow the
+// Slices are INTERLEAVED in groups of kBinGroup rows (slice = (row / kBinGroup) % S): a dense level's rows follow the
 // scene's geometry, and contiguous slices would leave the slabs that cover the object with most of the records.
 #ifndef S3D_BIN_CHUNK  // points per k_bin_scatter workgroup: every workgroup ends with one returning atomic per slice on the
 #define S3D_BIN_CHUNK 1024  // same cursor words (measured: 1024 beats 2048 and 4096 — the reservations are not what bounds the kernel)
@@ -643,7 +643,15 @@ __device__ __forceinline__ long long to_fixed64(float v, int k) {
 #ifndef S3D_BIN_ACC_UNROLL
 #define S3D_BIN_ACC_UNROLL 4
 #endif
-constexpr uint32_t kBinGroup = 32;
+// log2 of the rows per interleave group.  Round 6: 5 -> 8.  With the table's Adam inside the accumulate a slice's optimizer state is
+// read and written in pieces of (group rows x 8 B): 256-byte pieces at 32 rows, 2 KiB at 256 — scatter + accumulate-with-Adam
+// 151 - 158 -> 144 - 145 us at 2.8e5 points (64 rows: 148, 128: 148, 512: 148 - 153 with the plain pair at 108, 1,024: 187;
+// profiles/r11_grid_backward.md).  The plain pair does not care (97 - 98 us at 32 .. 256).
+#ifndef S3D_BIN_GROUP_LOG
+#define S3D_BIN_GROUP_LOG 8
+#endif
+constexpr uint32_t kBinGroupLog = S3D_BIN_GROUP_LOG;
+constexpr uint32_t kBinGroup = 1u << kBinGroupLog;
 #ifndef S3D_BIN_ACC_PER_CU  // persistent accumulate workgroups per CU (2 needs S3D_BIN_ACC_KB <= 64)
 #define S3D_BIN_ACC_PER_CU 1
 #endif
@@ -1140,7 +1148,7 @@ __device__ unsigned long long s3d_prof_buf[2][16384][8];
 #else
 #define S3D_STAMP(kern, wg, k) do { } while (0)
 #endif
-static_assert(kBinGroup == 32, "the scatter's key arithmetic shifts by 5");
+static_assert(kBinGroup == (1u << kBinGroupLog) && kBinGroupLog >= 5 && kBinGroupLog <= 12, "the scatter's key arithmetic shifts by kBinGroupLog");
 constexpr uint32_t kBin3Sub = S3D_BIN3_NSUB;
 static_assert(kBin3Sub == 1 || kBin3Sub == 2 || kBin3Sub == 4 || kBin3Sub == 8, "sub-buckets follow the XCD id");
 
@@ -1391,11 +1399,11 @@ __global__ void __launch_bounds__(P) k_bin_scatter6(const T* __restrict__ grad, 
 #pragma unroll
             for (uint32_t idx = 0; idx < K; idx++) row[idx] = li.row(lo_, idx);
         }
-        const uint32_t hshift = sshift + 5;  // (kBinGroup == 32)
+        const uint32_t hshift = sshift + kBinGroupLog;
 #pragma unroll
         for (uint32_t idx = 0; idx < K; idx++) {
-            const uint32_t slice = (row[idx] >> 5) & (S - 1);
-            key[idx] = (slice << 16) | ((row[idx] >> hshift) << 5) | (row[idx] & 31u);
+            const uint32_t slice = (row[idx] >> kBinGroupLog) & (S - 1);
+            key[idx] = (slice << 16) | ((row[idx] >> hshift) << kBinGroupLog) | (row[idx] & (kBinGroup - 1u));
             rank[idx] = atomicAdd(&cnt[slice], 1u);
             val[idx] = pack_record<T, C>(&v[idx * C]);
         }

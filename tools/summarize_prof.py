@@ -31,9 +31,9 @@ with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
 trace = glob.glob(f"{src}/trace/*/*kernel_trace.csv")[0]
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(trace)))
 march = [i for i, k in enumerate(ks) if "k_march_count" in k[2]]
-# graph mode: bench.py runs 8 extra eager steps after the timed region for its per-kernel timers; skip them
+# graph mode: bench.py runs 34 extra eager steps (2 discarded + 32) after the timed region for its per-kernel timers; skip them
 log = open(f"{src}/trace.log").read()
-tail = 8 if '"launch": "hip-graph replay' in log else 0
+tail = 34 if '"launch": "hip-graph replay' in log else 0
 sel = ks[march[-32 - tail]:(march[-tail] if tail else len(ks))]
 agg, cnt = collections.Counter(), collections.Counter()
 for s, e, n in sel:
