@@ -1528,7 +1528,8 @@ static uint32_t vm_stage_arm(VmBackward& b, uint32_t N, const uint32_t* rank, co
 }
 S3D_EXPORT size_t s3d_vm_backward_stage_bytes(uint32_t N, const uint32_t* rank, const uint32_t* resolution) {
     if (!rank || !resolution || !N) return 0;
-    return vm_stage_layout(N, rank, resolution).bytes;
+    const VmStage v = vm_stage_layout(N, rank, resolution);
+    return v.lslots > kVmStageMaxSlots ? 0 : v.bytes;  // (batches too long for the staged flush keep their atomics: nothing to allocate)
 }
 
 // launch geometry shared by the two backward entry points: points per workgroup so that the sorted order fills the chip a
