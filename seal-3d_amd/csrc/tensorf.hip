@@ -414,10 +414,19 @@ __device__ __forceinline__ int vm_border_index(int lx, int ly) {
 constexpr int kVmFixBits = 50;
 constexpr uint32_t kVmMaxPts = 4096;
 __device__ __forceinline__ long long vm_fixed(float v, float scale) {
+#ifdef S3D_VM_FIXED_TWO_LIMB  // rounds 5 / 6a: hi = trunc(t / 2^24), lo = t - hi 2^24 (exact), q = hi 2^24 + rn(lo) — the same integer, ~12 vector instructions
     const float t = v * scale;                                  // (power-of-two scale: exact)
     const float hi = truncf(t * 5.9604644775390625e-08f);       // t / 2^24, |hi| < 2^27
     const float lo = __builtin_fmaf(-hi, 16777216.0f, t);       // exact remainder, |lo| < 2^24
     return (long long)(int)hi * 16777216ll + (long long)__float2int_rn(lo);
+#else
+    // rn(t) for |t| < 2^51 as the low mantissa bits of t + 1.5 x 2^52 (the sum has an ulp of 1: the double add IS the rounding to
+    // nearest even): one conversion, one double add, one 64-bit subtract — the same integer as the two-limb form.  Colour plane
+    // pass 252 -> 234 us, colour line 38.7 -> 33.9 us (profiles/r11_tensorf_vm.md; an eighth of the LDS adds changes nothing there:
+    // the conversions, not the LDS atomics, are what the fixed-point sums cost).
+    const double d = (double)(v * scale) + 6755399441055744.0;  // (power-of-two scale: exact; |v * scale| <= 2^50 by the bound)
+    return __double_as_longlong(d) - 0x4338000000000000ll;
+#endif
 }
 __device__ __forceinline__ void vm_lds_add(long long* a, long long q) {
 #ifdef S3D_VM_EXP_NOLDSADD  // timing experiment only (wrong sums): what the LDS atomics cost
@@ -537,11 +546,19 @@ __device__ __forceinline__ bool vm_aligned_range(const int32_t* __restrict__ st,
     begin = blk * pts;
     if (begin >= valid_end) return false;
     end = begin + pts < valid_end ? begin + pts : valid_end;
-    auto unit_of = [&](uint32_t pos) {  // the last u with st[u] <= pos (empty units repeat their neighbour's start)
-        int lo = 0, hi = nunits;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if ((uint32_t)st[mid] <= pos) lo = mid; else hi = mid;
+    // the last u with st[u] <= pos (empty units repeat their neighbour's start; st[0] = 0).  A 64-ary search, the lanes of the wave
+    // testing 64 positions at once: two rounds of loads for up to 4,096 units instead of a dozen dependent ones (the two searches
+    // and the walk over empty tiles were ~20 us of latency per workgroup: profiles/r11_tensorf_vm.md, "skeleton")
+    auto unit_of = [&](uint32_t pos) {
+        const int lane = (int)(threadIdx.x & 63u);
+        int lo = 0, n = nunits;  // the answer lies in [lo, lo + n)
+        while (n > 1) {
+            const int step = (n + 63) / 64;
+            const int u = lo + lane * step;
+            const bool le = lane * step < n && (uint32_t)st[u] <= pos;
+            const int k = __popcll(__ballot(le));  // st is non-decreasing: the lanes that pass form a prefix (k >= 1: st[lo] <= pos)
+            lo += (k - 1) * step;
+            n = n - (k - 1) * step < step ? n - (k - 1) * step : step;
         }
         return lo;
     };
@@ -615,10 +632,22 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
         while ((uint32_t)st[t + 1] <= pos) t++;
         const uint32_t seg_end = (uint32_t)st[t + 1] < end ? (uint32_t)st[t + 1] : end;
         const int cx0 = (t % tiles_x) * kVmTile, cy0 = (t / tiles_x) * kVmTile;
-        for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += kVmBwdThreads) {
-            const uint32_t rr = e / kVmTileCells, c = e % kVmTileCells;  // cell fastest: 9-float row segments of one channel
-            const int cy = cy0 + (int)(c / (kVmTile + 1)), cx = cx0 + (int)(c % (kVmTile + 1));
-            pv[c * R + rr] = (cx < W && cy < H) ? P[rr * plane_stride + (size_t)cy * W + cx] : 0.0f;
+        // (cell fastest: 9-float row segments of one channel.  Four values per lane are requested before the first one is parked:
+        //  one element per loop pass waited for its own load each time — 56 of the colour plane pass's 234 us)
+        for (uint32_t e0 = threadIdx.x; e0 < kVmTileCells * R; e0 += 4 * kVmBwdThreads) {
+            float v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t e = e0 + u * kVmBwdThreads;
+                const uint32_t rr = e / kVmTileCells, c = e % kVmTileCells;
+                const int cy = cy0 + (int)(c / (kVmTile + 1)), cx = cx0 + (int)(c % (kVmTile + 1));
+                v[u] = (e < kVmTileCells * R && cx < W && cy < H) ? P[rr * plane_stride + (size_t)cy * W + cx] : 0.0f;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t e = e0 + u * kVmBwdThreads;
+                if (e < kVmTileCells * R) pv[(e % kVmTileCells) * R + e / kVmTileCells] = v[u];
+            }
         }
         __syncthreads();  // plane values in place; accumulator clear (start of the kernel / previous flush)
         // A trip is a chain of dependent loads (sorted position -> point id -> coordinates -> line values / gradients): the id
@@ -843,10 +872,22 @@ __global__ void __launch_bounds__(kVmMmThreads, 4) k_vm_plane_backward_mm(const 
         uint32_t n_nx = kf < seg_end ? (uint32_t)perm[kf] : 0u;
         uint32_t n_nx2 = kf + STEP < seg_end ? (uint32_t)perm[kf + STEP] : 0u;
         VmXyz p_nx = kf < seg_end ? vm_load_xyz(x, n_nx, f, i) : VmXyz{0.0f, 0.0f, 0.0f};
-        for (uint32_t e = threadIdx.x; e < kVmTileCells * R; e += kVmMmThreads) {
-            const uint32_t rr = e / kVmTileCells, c = e % kVmTileCells;
-            const int cy = cy0 + (int)(c / (kVmTile + 1)), cx = cx0 + (int)(c % (kVmTile + 1));
-            pv[c * R + rr] = (cx < W && cy < H) ? P[rr * plane_stride + (size_t)cy * W + cx] : 0.0f;
+        // (cell fastest: 9-float row segments of one channel.  Four values per lane are requested before the first one is parked:
+        //  one element per loop pass waited for its own load each time — 56 of the colour plane pass's 234 us)
+        for (uint32_t e0 = threadIdx.x; e0 < kVmTileCells * R; e0 += 4 * kVmMmThreads) {
+            float v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t e = e0 + u * kVmMmThreads;
+                const uint32_t rr = e / kVmTileCells, c = e % kVmTileCells;
+                const int cy = cy0 + (int)(c / (kVmTile + 1)), cx = cx0 + (int)(c % (kVmTile + 1));
+                v[u] = (e < kVmTileCells * R && cx < W && cy < H) ? P[rr * plane_stride + (size_t)cy * W + cx] : 0.0f;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t e = e0 + u * kVmMmThreads;
+                if (e < kVmTileCells * R) pv[(e % kVmTileCells) * R + e / kVmTileCells] = v[u];
+            }
         }
         __syncthreads();  // plane values in place; accumulator clear (start of the kernel / previous flush)
         for (uint32_t k0 = pos + wave * 32; k0 < seg_end; k0 += STEP) {
