@@ -392,7 +392,8 @@ int s3d_ffmlp_free_splitk(void);
  * (the tensor the reference transposes into basis_mat, network.py:147). */
 int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                             const uint32_t* rank, const uint32_t* resolution, int reduce, float* out,
-                            const int32_t* n_valid, s3d_stream_t stream);
+                            const float* const* planes_t, const float* const* lines_t, const int32_t* n_valid,
+                            s3d_stream_t stream);
 /* Parameter gradients of the same op (what autograd derives from the grid_sample calls: F.grid_sample's backward
  * scatter-adds every corner with a global atomic).  Binned instead: s3d_vm_backward_keys writes keys [6,N] i32 (rows 0-2
  * the 8x8-cell plane tile of component i, rows 3-5 its 64-row line chunk; 0x7fffffff = contributes nothing); the caller
@@ -407,6 +408,11 @@ int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* plan
  * transposed ([Dn][rank]) for the plane pass, whose lanes are rank channels.
  * found_inf (optional device float): set to 1 when a bound is not finite — the condition under which these kernels write a
  * non-finite gradient — so a GradScaler need not read the 69 MB of factor gradients again to find out.
+ * planes_t / lines_t (optional, round 6): rank-fastest shadows of the factors — planes_t[i] [H][W][rank_i], lines_t[i] [Dn][rank_i],
+ * 16-byte aligned, written by s3d_vm_transpose_factors from the current parameters (the caller refreshes them when the parameters
+ * change).  With them a corner's rank channels are one contiguous run instead of rank_i words H * W * 4 bytes apart: the forwards
+ * (ranks that are multiples of four) read four ranks per 16-byte load, the plane passes of the backward load a tile's window as 81
+ * runs.  Same values, same arithmetic, same results bit for bit; NULL: the parameters' own layout.
  * n_valid (optional, round 6; every s3d_vm_* entry point that walks the points, and s3d_freq_encode_pack_*): the device-side
  * sample count of a padded batch — rows [round_up(*n_valid, 128), N) are absent: the forwards do not write them, the binning
  * sorts them behind every bin (the backward passes then never see them) and the bound pass does not look at their gradients.
@@ -415,6 +421,8 @@ int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* plan
  * chunk's 65 cells) leave as plain stores into per-tile / per-workgroup rows and one extra launch adds the rows in a FIXED
  * order; NULL (or too small): those cells take global atomics, as before.  Same sums within fp32 summation order. */
 size_t s3d_vm_backward_stage_bytes(uint32_t N, const uint32_t* rank, const uint32_t* resolution);
+int s3d_vm_transpose_factors(const float* const* planes, const float* const* lines, const uint32_t* rank, const uint32_t* resolution,
+                             float* const* planes_t, float* const* lines_t, s3d_stream_t stream);
 uint32_t s3d_vm_backward_max_bins(const uint32_t* resolution);
 int s3d_vm_backward_keys(const float* x, uint32_t N, const uint32_t* rank, const uint32_t* resolution, int32_t* keys,
                          s3d_stream_t stream);
@@ -429,7 +437,8 @@ int s3d_vm_features_backward(const float* x, uint32_t N, const float* const* pla
                              const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
                              const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
                              float* const* grad_planes, float* const* grad_lines, uint32_t* bound_words, float* line_scratch,
-                             void* stage, size_t stage_bytes, float* found_inf, const int32_t* n_valid, s3d_stream_t stream);
+                             void* stage, size_t stage_bytes, float* found_inf, const float* const* planes_t, const int32_t* n_valid,
+                             s3d_stream_t stream);
 
 /* The colour features with basis_mat applied inside the kernel (tensoRF/network.py:149-153: `basis_mat((mat * vec).T)`, an
  * nn.Linear(sum rank, basis_rows, bias=False) that runs under fp16 autocast): out [N, basis_rows] fp16 =
@@ -441,13 +450,14 @@ int s3d_vm_features_backward(const float* x, uint32_t N, const float* const* pla
  * [basis_rows, sum rank] (zero-initialised; accumulated with atomics). */
 int s3d_vm_color_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                          const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
-                         uint16_t* out, const int32_t* n_valid, s3d_stream_t stream);
+                         uint16_t* out, const float* const* planes_t, const float* const* lines_t, const int32_t* n_valid,
+                         s3d_stream_t stream);
 int s3d_vm_color_backward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                           const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
                           const uint16_t* grad_out, const int32_t* perm, const int32_t* start, uint32_t n_bounds,
                           float* gm, float* const* grad_planes, float* const* grad_lines, float* grad_basis,
                           uint32_t* bound_words, float* line_scratch, void* stage, size_t stage_bytes, float* found_inf,
-                          const int32_t* n_valid, s3d_stream_t stream);
+                          const float* const* planes_t, const int32_t* n_valid, s3d_stream_t stream);
 
 /* Build extensions for the TensoRF step (chains of tiny launches otherwise):
  * s3d_aabb_normalize: out[n][a] = 2 (x[n][a] - aabb[a]) / (aabb[3 + a] - aabb[a]) - 1 (tensoRF/network.py:155-157, the reference's

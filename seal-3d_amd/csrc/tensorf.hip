@@ -23,7 +23,17 @@ struct VmFactors {
     uint32_t W[3], H[3], Dn[3];   // plane i is [rank, H, W] (W <-> coordinate mat_ids[i][0], H <-> mat_ids[i][1]); line i [rank, Dn]
     uint32_t cu[3], cv[3], cw[3]; // coordinate index of u (-> W), v (-> H), w (-> line)
     uint32_t row0[3];             // first output row of component i (reduce = 0)
+    // optional rank-fastest shadows (s3d_vm_transpose_factors): plane_t[i] [H][W][rank], line_t[i] [Dn][rank].  A corner's rank
+    // channels are then ONE contiguous run (192 bytes at rank 48) instead of `rank` four-byte words H * W * 4 bytes apart: the
+    // colour feature kernel spent 77 of its 117 us in those gathers (timing-only build, profiles/r11_tensorf_vm.md)
+    const float* plane_t[3];
+    const float* line_t[3];
 };
+
+// the four ranks r .. r + 3 of a cell of a rank-fastest shadow (16-byte aligned: rank % 4 == 0), or zeros
+__device__ __forceinline__ float4 vm_load4(const float* __restrict__ base, bool ok, size_t cell, uint32_t R, uint32_t r) {
+    return ok ? *reinterpret_cast<const float4*>(base + cell * R + r) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
 
 __device__ __forceinline__ float unnormalize(float c, uint32_t size) { return ((c + 1.0f) / 2.0f) * (float)(size - 1); }
 
@@ -54,6 +64,35 @@ __global__ void __launch_bounds__(256) k_vm_features(const float* __restrict__ x
         const size_t plane_stride = (size_t)H * W;
         const int o_nw = y0 * W + x0;
         float comp = 0.0f;
+        if (f.plane_t[i]) {  // rank-fastest shadows: four ranks per 16-byte load, the same arithmetic per rank in the same order
+            const float* Pt = f.plane_t[i];
+            const float* Ltq = f.line_t[i];
+            const uint32_t R = f.rank[i];
+            for (uint32_t r0 = 0; r0 < R; r0 += 4) {
+                const float4 a_nw = vm_load4(Pt, bx0 && by0, (size_t)o_nw, R, r0), a_ne = vm_load4(Pt, bx1 && by0, (size_t)(o_nw + 1), R, r0);
+                const float4 a_sw = vm_load4(Pt, bx0 && by1, (size_t)(o_nw + W), R, r0), a_se = vm_load4(Pt, bx1 && by1, (size_t)(o_nw + W + 1), R, r0);
+                const float4 a_l0 = vm_load4(Ltq, bz0, (size_t)z0, R, r0), a_l1 = vm_load4(Ltq, bz1, (size_t)(z0 + 1), R, r0);
+                const float vnw[4] = {a_nw.x, a_nw.y, a_nw.z, a_nw.w}, vne[4] = {a_ne.x, a_ne.y, a_ne.z, a_ne.w};
+                const float vsw[4] = {a_sw.x, a_sw.y, a_sw.z, a_sw.w}, vse[4] = {a_se.x, a_se.y, a_se.z, a_se.w};
+                const float vl0[4] = {a_l0.x, a_l0.y, a_l0.z, a_l0.w}, vl1[4] = {a_l1.x, a_l1.y, a_l1.z, a_l1.w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    float m = 0.0f;
+                    if (bx0 && by0) m += vnw[k] * nw;
+                    if (bx1 && by0) m += vne[k] * ne;
+                    if (bx0 && by1) m += vsw[k] * sw;
+                    if (bx1 && by1) m += vse[k] * se;
+                    float l = 0.0f;
+                    if (bz0) l += vl0[k] * lz0;
+                    if (bz1) l += vl1[k] * lz1;
+                    const float prod = m * l;
+                    if (REDUCE) comp += prod;
+                    else out[(size_t)(f.row0[i] + r0 + k) * N + n] = prod;
+                }
+            }
+            total += comp;
+            continue;
+        }
         for (uint32_t r = 0; r < f.rank[i]; r++) {
             const float* pr = P + r * plane_stride;
             const float* lr = Lq + (size_t)r * Dn;
@@ -118,6 +157,43 @@ __global__ void __launch_bounds__(256) k_vm_color_basis(const float* __restrict_
         const float* Lq = f.line[i];
         const size_t plane_stride = (size_t)H * W;
         const int o_nw = y0 * W + x0;
+        auto to_basis = [&](float prod, uint32_t r) {
+            const float4* wrow = reinterpret_cast<const float4*>(vm_smem + (size_t)(f.row0[i] + r) * kVmBasisPad);
+#pragma unroll
+            for (uint32_t q = 0; q < kVmBasisPad / 4; q++) {
+                const float4 w = wrow[q];
+                acc[4 * q] = __builtin_fmaf(prod, w.x, acc[4 * q]);
+                acc[4 * q + 1] = __builtin_fmaf(prod, w.y, acc[4 * q + 1]);
+                acc[4 * q + 2] = __builtin_fmaf(prod, w.z, acc[4 * q + 2]);
+                acc[4 * q + 3] = __builtin_fmaf(prod, w.w, acc[4 * q + 3]);
+            }
+        };
+        if (f.plane_t[i]) {  // rank-fastest shadows (see VmFactors)
+            const float* Pt = f.plane_t[i];
+            const float* Ltq = f.line_t[i];
+            const uint32_t R = f.rank[i];
+            for (uint32_t r0 = 0; r0 < R; r0 += 4) {
+                const float4 a_nw = vm_load4(Pt, bx0 && by0, (size_t)o_nw, R, r0), a_ne = vm_load4(Pt, bx1 && by0, (size_t)(o_nw + 1), R, r0);
+                const float4 a_sw = vm_load4(Pt, bx0 && by1, (size_t)(o_nw + W), R, r0), a_se = vm_load4(Pt, bx1 && by1, (size_t)(o_nw + W + 1), R, r0);
+                const float4 a_l0 = vm_load4(Ltq, bz0, (size_t)z0, R, r0), a_l1 = vm_load4(Ltq, bz1, (size_t)(z0 + 1), R, r0);
+                const float vnw[4] = {a_nw.x, a_nw.y, a_nw.z, a_nw.w}, vne[4] = {a_ne.x, a_ne.y, a_ne.z, a_ne.w};
+                const float vsw[4] = {a_sw.x, a_sw.y, a_sw.z, a_sw.w}, vse[4] = {a_se.x, a_se.y, a_se.z, a_se.w};
+                const float vl0[4] = {a_l0.x, a_l0.y, a_l0.z, a_l0.w}, vl1[4] = {a_l1.x, a_l1.y, a_l1.z, a_l1.w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    float m = 0.0f;
+                    if (bx0 && by0) m += vnw[k] * nw;
+                    if (bx1 && by0) m += vne[k] * ne;
+                    if (bx0 && by1) m += vsw[k] * sw;
+                    if (bx1 && by1) m += vse[k] * se;
+                    float l = 0.0f;
+                    if (bz0) l += vl0[k] * lz0;
+                    if (bz1) l += vl1[k] * lz1;
+                    to_basis((float)(_Float16)(m * l), r0 + k);
+                }
+            }
+            continue;
+        }
         for (uint32_t r = 0; r < f.rank[i]; r++) {
             const float* pr = P + r * plane_stride;
             const float* lr = Lq + (size_t)r * Dn;
@@ -132,16 +208,7 @@ __global__ void __launch_bounds__(256) k_vm_color_basis(const float* __restrict_
             float l = 0.0f;
             if (bz0) l += l0 * lz0;
             if (bz1) l += l1 * lz1;
-            const float prod = (float)(_Float16)(m * l);  // (the autocast Linear's fp16 input)
-            const float4* wrow = reinterpret_cast<const float4*>(vm_smem + (size_t)(f.row0[i] + r) * kVmBasisPad);
-#pragma unroll
-            for (uint32_t q = 0; q < kVmBasisPad / 4; q++) {
-                const float4 w = wrow[q];
-                acc[4 * q] = __builtin_fmaf(prod, w.x, acc[4 * q]);
-                acc[4 * q + 1] = __builtin_fmaf(prod, w.y, acc[4 * q + 1]);
-                acc[4 * q + 2] = __builtin_fmaf(prod, w.z, acc[4 * q + 2]);
-                acc[4 * q + 3] = __builtin_fmaf(prod, w.w, acc[4 * q + 3]);
-            }
+            to_basis((float)(_Float16)(m * l), r);  // (the autocast Linear's fp16 input)
         }
     }
     _Float16* o = out + (size_t)n * Cb;
@@ -634,6 +701,25 @@ __global__ void __launch_bounds__(kVmBwdThreads) k_vm_plane_backward(const float
         const int cx0 = (t % tiles_x) * kVmTile, cy0 = (t / tiles_x) * kVmTile;
         // (cell fastest: 9-float row segments of one channel.  Four values per lane are requested before the first one is parked:
         //  one element per loop pass waited for its own load each time — 56 of the colour plane pass's 234 us)
+        if (const float* Pt = f.plane_t[i]) {
+            // rank-fastest shadow: a cell's R values are one contiguous run, and so is the cell's row of `pv` (element e of the
+            // window IS pv[e]) — 81 runs of R x 4 bytes instead of 81 x R four-byte words from R planes H * W * 4 bytes apart
+            for (uint32_t e0 = threadIdx.x; e0 < kVmTileCells * R; e0 += 4 * kVmBwdThreads) {
+                float v[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    const uint32_t e = e0 + u * kVmBwdThreads;
+                    const uint32_t c = e / R, rr = e % R;
+                    const int cy = cy0 + (int)(c / (kVmTile + 1)), cx = cx0 + (int)(c % (kVmTile + 1));
+                    v[u] = (e < kVmTileCells * R && cx < W && cy < H) ? Pt[((size_t)cy * W + cx) * R + rr] : 0.0f;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    const uint32_t e = e0 + u * kVmBwdThreads;
+                    if (e < kVmTileCells * R) pv[e] = v[u];
+                }
+            }
+        } else
         for (uint32_t e0 = threadIdx.x; e0 < kVmTileCells * R; e0 += 4 * kVmBwdThreads) {
             float v[4];
 #pragma unroll
@@ -874,6 +960,25 @@ __global__ void __launch_bounds__(kVmMmThreads, 4) k_vm_plane_backward_mm(const 
         VmXyz p_nx = kf < seg_end ? vm_load_xyz(x, n_nx, f, i) : VmXyz{0.0f, 0.0f, 0.0f};
         // (cell fastest: 9-float row segments of one channel.  Four values per lane are requested before the first one is parked:
         //  one element per loop pass waited for its own load each time — 56 of the colour plane pass's 234 us)
+        if (const float* Pt = f.plane_t[i]) {
+            // rank-fastest shadow: a cell's R values are one contiguous run, and so is the cell's row of `pv` (element e of the
+            // window IS pv[e]) — 81 runs of R x 4 bytes instead of 81 x R four-byte words from R planes H * W * 4 bytes apart
+            for (uint32_t e0 = threadIdx.x; e0 < kVmTileCells * R; e0 += 4 * kVmMmThreads) {
+                float v[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    const uint32_t e = e0 + u * kVmMmThreads;
+                    const uint32_t c = e / R, rr = e % R;
+                    const int cy = cy0 + (int)(c / (kVmTile + 1)), cx = cx0 + (int)(c % (kVmTile + 1));
+                    v[u] = (e < kVmTileCells * R && cx < W && cy < H) ? Pt[((size_t)cy * W + cx) * R + rr] : 0.0f;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    const uint32_t e = e0 + u * kVmMmThreads;
+                    if (e < kVmTileCells * R) pv[e] = v[u];
+                }
+            }
+        } else
         for (uint32_t e0 = threadIdx.x; e0 < kVmTileCells * R; e0 += 4 * kVmMmThreads) {
             float v[4];
 #pragma unroll
@@ -1363,6 +1468,8 @@ int fill_factors(VmFactors& f, const float* const* planes, const float* const* l
         S3D_REQUIRE(planes[i] && lines[i] && rank[i] > 0 && resolution[i] > 0, "vm features: empty factor %u", i);
         f.plane[i] = planes[i];
         f.line[i] = lines[i];
+        f.plane_t[i] = nullptr;
+        f.line_t[i] = nullptr;
         f.rank[i] = rank[i];
         f.cu[i] = mat_ids[i][0];
         f.cv[i] = mat_ids[i][1];
@@ -1374,6 +1481,50 @@ int fill_factors(VmFactors& f, const float* const* planes, const float* const* l
         rows += rank[i];
     }
     return S3D_OK;
+}
+
+// the optional rank-fastest shadows of a call (s3d_vm_transpose_factors): taken when every rank is a multiple of four (16-byte loads)
+static void vm_set_shadows(VmFactors& f, const float* const* planes_t, const float* const* lines_t) {
+    if (!planes_t || !lines_t) return;
+    for (uint32_t i = 0; i < 3; i++)
+        if (!planes_t[i] || !lines_t[i] || f.rank[i] % 4 != 0 || (reinterpret_cast<uintptr_t>(planes_t[i]) | reinterpret_cast<uintptr_t>(lines_t[i])) & 15u) return;
+    for (uint32_t i = 0; i < 3; i++) { f.plane_t[i] = planes_t[i]; f.line_t[i] = lines_t[i]; }
+}
+// [rank][cells] -> [cells][rank] for the three planes (cells = H * W) and the three lines (cells = Dn) of a factor set: a
+// workgroup moves 64 cells x all ranks through LDS (reads: 256-byte runs per rank, writes: 64 runs of rank x 4 bytes, contiguous)
+__global__ void __launch_bounds__(256) k_vm_transpose_factors(VmFactors f, float* const p0, float* const p1, float* const p2,
+                                                              float* const l0, float* const l1, float* const l2, uint32_t plane_blocks) {
+    __shared__ float tile[64 * 65];
+    const bool is_line = blockIdx.x >= plane_blocks;
+    const uint32_t i = blockIdx.y, blk = is_line ? blockIdx.x - plane_blocks : blockIdx.x;
+    const uint32_t cells = is_line ? f.Dn[i] : f.W[i] * f.H[i], R = f.rank[i];
+    const uint32_t c0 = blk * 64;
+    if (c0 >= cells) return;
+    const float* src = is_line ? f.line[i] : f.plane[i];
+    float* dst = is_line ? (i == 0 ? l0 : i == 1 ? l1 : l2) : (i == 0 ? p0 : i == 1 ? p1 : p2);
+    for (uint32_t r0 = 0; r0 < R; r0 += 64) {
+        const uint32_t nr = R - r0 < 64 ? R - r0 : 64;
+        // (four loads in flight per lane before the first is parked: one element per pass waits for its own load each time)
+        for (uint32_t e0 = threadIdx.x; e0 < nr * 64; e0 += 4 * 256) {
+            float v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t e = e0 + u * 256, r = e / 64, c = e % 64;
+                v[u] = (e < nr * 64 && c0 + c < cells) ? src[(size_t)(r0 + r) * cells + c0 + c] : 0.0f;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t e = e0 + u * 256;
+                if (e < nr * 64) tile[(e / 64) * 65 + e % 64] = v[u];
+            }
+        }
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < nr * 64; e += 256) {
+            const uint32_t c = e / nr, r = e % nr;
+            if (c0 + c < cells) dst[(size_t)(c0 + c) * R + r0 + r] = tile[r * 65 + c];
+        }
+        __syncthreads();
+    }
 }
 
 // ---- the weights of a bias-free Linear chain in the ffmlp package's flat fp16 layout (and the flat fp16 gradient back into
@@ -1654,14 +1805,17 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
                                         const uint32_t* rank, const uint32_t* resolution, int reduce, const float* grad,
                                         const int32_t* perm, const int32_t* start, uint32_t n_bounds, float* gm,
                                         float* const* grad_planes, float* const* grad_lines, uint32_t* bound_words,
-                                        float* line_scratch, void* stage, size_t stage_bytes, float* found_inf, const int32_t* n_valid,
-                                        s3d_stream_t stream) {
+                                        float* line_scratch, void* stage, size_t stage_bytes, float* found_inf, const float* const* planes_t,
+                                        const int32_t* n_valid, s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && planes && lines && rank && resolution && grad && perm && start && gm && grad_planes && grad_lines && bound_words &&
                 line_scratch, "vm_features_backward: null pointer");
     VmFactors f;
     VmBackward b;
     if (int rc = fill_factors(f, planes, lines, rank, resolution, b.rows)) return rc;
+    if (planes_t && planes_t[0] && planes_t[1] && planes_t[2] &&
+        !((reinterpret_cast<uintptr_t>(planes_t[0]) | reinterpret_cast<uintptr_t>(planes_t[1]) | reinterpret_cast<uintptr_t>(planes_t[2])) & 15u))
+        for (uint32_t i = 0; i < 3; i++) f.plane_t[i] = planes_t[i];  // (the tile loads of the plane passes; any rank)
     uint32_t max_rank = 0, max_tiles = 0, max_chunks = 0;
     for (uint32_t i = 0; i < 3; i++) {
         S3D_REQUIRE(grad_planes[i] && grad_lines[i], "vm_features_backward: null gradient buffer %u", i);
@@ -1713,7 +1867,8 @@ S3D_EXPORT int s3d_vm_features_backward(const float* x, uint32_t N, const float*
 
 S3D_EXPORT int s3d_vm_color_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                                     const uint32_t* rank, const uint32_t* resolution, const uint16_t* basis, uint32_t basis_rows,
-                                    uint16_t* out, const int32_t* n_valid, s3d_stream_t stream) {
+                                    uint16_t* out, const float* const* planes_t, const float* const* lines_t, const int32_t* n_valid,
+                                    s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && planes && lines && rank && resolution && basis && out, "vm_color_forward: null pointer");
     VmFactors f;
@@ -1722,6 +1877,7 @@ S3D_EXPORT int s3d_vm_color_forward(const float* x, uint32_t N, const float* con
     S3D_REQUIRE(basis_rows >= 1 && basis_rows <= kVmBasisPad, "vm_color_forward: basis_mat with %u outputs (1 .. %u supported)",
                 basis_rows, kVmBasisPad);
     S3D_REQUIRE(rows * kVmBasisPad * sizeof(float) <= 64 * 1024, "vm_color_forward: %u product rows do not fit the LDS table", rows);
+    vm_set_shadows(f, planes_t, lines_t);
     hipLaunchKernelGGL(k_vm_color_basis, dim3(div_up<uint32_t>(N, 256)), dim3(256), rows * kVmBasisPad * sizeof(float), as_stream(stream),
                        x, N, f, (const _Float16*)basis, basis_rows, rows, (_Float16*)out, n_valid);
     return check_launch("vm_color_forward");
@@ -1732,7 +1888,7 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
                                      const uint16_t* grad_out, const int32_t* perm, const int32_t* start, uint32_t n_bounds,
                                      float* gm, float* const* grad_planes, float* const* grad_lines, float* grad_basis,
                                      uint32_t* bound_words, float* line_scratch, void* stage, size_t stage_bytes, float* found_inf,
-                                     const int32_t* n_valid, s3d_stream_t stream) {
+                                     const float* const* planes_t, const int32_t* n_valid, s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && planes && lines && rank && resolution && basis && grad_out && perm && start && gm && grad_planes && grad_lines &&
                 grad_basis && bound_words && line_scratch, "vm_color_backward: null pointer");
@@ -1741,6 +1897,9 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
     if (int rc = fill_factors(f, planes, lines, rank, resolution, b.rows)) return rc;
     S3D_REQUIRE(basis_rows >= 1 && basis_rows <= kVmBasisPad, "vm_color_backward: basis_mat with %u outputs (1 .. %u supported)",
                 basis_rows, kVmBasisPad);
+    if (planes_t && planes_t[0] && planes_t[1] && planes_t[2] &&
+        !((reinterpret_cast<uintptr_t>(planes_t[0]) | reinterpret_cast<uintptr_t>(planes_t[1]) | reinterpret_cast<uintptr_t>(planes_t[2])) & 15u))
+        for (uint32_t i = 0; i < 3; i++) f.plane_t[i] = planes_t[i];  // (the tile loads of the plane passes; any rank)
     uint32_t max_rank = 0, max_tiles = 0, max_chunks = 0;
     for (uint32_t i = 0; i < 3; i++) {
         S3D_REQUIRE(grad_planes[i] && grad_lines[i], "vm_color_backward: null gradient buffer %u", i);
@@ -1783,14 +1942,33 @@ S3D_EXPORT int s3d_vm_color_backward(const float* x, uint32_t N, const float* co
     return check_launch("vm_color_backward");
 }
 
+S3D_EXPORT int s3d_vm_transpose_factors(const float* const* planes, const float* const* lines, const uint32_t* rank,
+                                        const uint32_t* resolution, float* const* planes_t, float* const* lines_t, s3d_stream_t stream) {
+    S3D_REQUIRE(planes && lines && rank && resolution && planes_t && lines_t, "vm_transpose_factors: null pointer");
+    VmFactors f;
+    uint32_t rows;
+    if (int rc = fill_factors(f, planes, lines, rank, resolution, rows)) return rc;
+    uint32_t pb = 0, lb = 0;
+    for (uint32_t i = 0; i < 3; i++) {
+        S3D_REQUIRE(planes_t[i] && lines_t[i], "vm_transpose_factors: null output %u", i);
+        pb = std::max(pb, div_up<uint32_t>(f.W[i] * f.H[i], 64));
+        lb = std::max(lb, div_up<uint32_t>(f.Dn[i], 64));
+    }
+    hipLaunchKernelGGL(k_vm_transpose_factors, dim3(pb + lb, 3), dim3(256), 0, as_stream(stream), f, planes_t[0], planes_t[1], planes_t[2],
+                       lines_t[0], lines_t[1], lines_t[2], pb);
+    return check_launch("vm_transpose_factors");
+}
+
 S3D_EXPORT int s3d_vm_features_forward(const float* x, uint32_t N, const float* const* planes, const float* const* lines,
                                        const uint32_t* rank, const uint32_t* resolution, int reduce, float* out,
-                                       const int32_t* n_valid, s3d_stream_t stream) {
+                                       const float* const* planes_t, const float* const* lines_t, const int32_t* n_valid,
+                                       s3d_stream_t stream) {
     if (N == 0) return S3D_OK;
     S3D_REQUIRE(x && planes && lines && rank && resolution && out, "vm_features_forward: null pointer");
     VmFactors f;
     uint32_t row;
     if (int rc = fill_factors(f, planes, lines, rank, resolution, row)) return rc;
+    vm_set_shadows(f, planes_t, lines_t);
     const dim3 grid(div_up<uint32_t>(N, 256)), block(256);
     if (reduce) hipLaunchKernelGGL((k_vm_features<true>), grid, block, 0, as_stream(stream), x, N, f, out, n_valid);
     else hipLaunchKernelGGL((k_vm_features<false>), grid, block, 0, as_stream(stream), x, N, f, out, n_valid);

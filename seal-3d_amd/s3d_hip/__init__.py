@@ -45,7 +45,7 @@ EXPORTS = [
     "s3d_seal_bbox_map", "s3d_seal_map_color", "s3d_grid_encode_backward_adam", "s3d_vm_features_forward",
     "s3d_aabb_normalize", "s3d_weighted_abs_sum_workspace_size", "s3d_weighted_abs_sum", "s3d_pack_linear_chain", "s3d_unpack_linear_chain",
     "s3d_vm_backward_max_bins", "s3d_vm_backward_keys", "s3d_vm_backward_bins_workspace_size", "s3d_vm_backward_bins",
-    "s3d_vm_backward_stage_bytes",
+    "s3d_vm_backward_stage_bytes", "s3d_vm_transpose_factors",
     "s3d_vm_features_backward", "s3d_vm_color_forward", "s3d_vm_color_backward",
 ]
 
@@ -178,6 +178,19 @@ def active_row_limit(B):
     if _ROW_LIMIT is not None and _ROW_LIMIT[1] == int(B):
         return _ROW_LIMIT[0]
     return None
+
+
+def _shadow2(shadows):
+    """(planes_t, lines_t) pointer arrays of VmBackend.transpose_factors()' result, or two NULLs"""
+    if shadows is None:
+        return None, None
+    ptr3 = C.c_void_p * 3
+    return ptr3(*[t.data_ptr() for t in shadows[0]]), ptr3(*[t.data_ptr() for t in shadows[1]])
+
+
+def _shadow1(shadows):
+    """planes_t pointer array of VmBackend.transpose_factors()' result, or NULL"""
+    return (_shadow2(shadows)[0],)
 
 
 def _f(x):
@@ -1049,7 +1062,7 @@ class VmBackend:
     """csrc/tensorf.hip — TensoRF vector-matrix features (tensoRF/network.py:112-153 of the reference)"""
 
     @staticmethod
-    def features_forward(x, planes, lines, resolution, reduce, out, n_valid=None):
+    def features_forward(x, planes, lines, resolution, reduce, out, n_valid=None, shadows=None):
         """x [N,3] fp32; planes[i] [1,R_i,H,W] / lines[i] [1,R_i,D,1] fp32 (the reference's parameter shapes);
         out [N] (reduce) or [sum R_i, N]"""
         _need(x, torch.float32, "x"); _need(out, torch.float32, "out")
@@ -1066,7 +1079,7 @@ class VmBackend:
         rank = u3(*[int(t.shape[1]) for t in planes])
         res = u3(*[int(r) for r in resolution])
         _check(lib().s3d_vm_features_forward(_p(x), _u(x.shape[0]), pl, ln, rank, res, C.c_int(int(bool(reduce))), _p(out),
-                                             _nv(n_valid), _stream()), "vm_features_forward")
+                                             *_shadow2(shadows), _nv(n_valid), _stream()), "vm_features_forward")
 
     @staticmethod
     def aabb_normalize(x, aabb, out):
@@ -1156,12 +1169,29 @@ class VmBackend:
         return perm, start, n_bounds
 
     @staticmethod
+    def transpose_factors(planes, lines, resolution):
+        """rank-fastest shadows of a factor set (s3d_vm_transpose_factors): ([H, W, R_i] x 3, [Dn, R_i] x 3) fp32, from the CURRENT
+        values of the parameters — the caller takes them afresh whenever the parameters may have changed"""
+        for t in list(planes) + list(lines):
+            _need(t, torch.float32, "factor")
+            if not t.is_cuda or not t.is_contiguous():
+                raise RuntimeError("vm transpose: factors must be contiguous GPU tensors")
+        ptr3, u3 = C.c_void_p * 3, C.c_uint32 * 3
+        pt = [torch.empty(t.shape[2], t.shape[3], t.shape[1], dtype=torch.float32, device=t.device) for t in planes]
+        lt = [torch.empty(t.shape[2], t.shape[1], dtype=torch.float32, device=t.device) for t in lines]
+        _check(lib().s3d_vm_transpose_factors(ptr3(*[t.data_ptr() for t in planes]), ptr3(*[t.data_ptr() for t in lines]),
+                                              u3(*[int(t.shape[1]) for t in planes]), u3(*[int(r) for r in resolution]),
+                                              ptr3(*[t.data_ptr() for t in pt]), ptr3(*[t.data_ptr() for t in lt]), _stream()),
+               "vm_transpose_factors")
+        return pt, lt
+
+    @staticmethod
     def _stage(N, rank, res, dev):
         """staging rows of the factor backward's flushes (s3d_vm_backward_stage_bytes; uint8, no initialisation)"""
         return torch.empty(int(lib().s3d_vm_backward_stage_bytes(_u(N), rank, res)), dtype=torch.uint8, device=dev)
 
     @staticmethod
-    def features_backward(x, planes, lines, resolution, reduce, grad, bins=None, found_inf=None, n_valid=None):
+    def features_backward(x, planes, lines, resolution, reduce, grad, bins=None, found_inf=None, n_valid=None, shadows=None):
         """gradients of features_forward w.r.t. planes / lines (lists shaped like the factors).  grad: [N] (reduce) or
         [N, sum R_i] point-major.  `bins`: a backward_bins() result for the same x / resolution."""
         _need(x, torch.float32, "x"); _need(grad, torch.float32, "grad")
@@ -1184,11 +1214,11 @@ class VmBackend:
                                               _p(grad), _p(perm), _p(start), _u(n_bounds), _p(gm),
                                               ptr3(*[t.data_ptr() for t in g_planes]), ptr3(*[t.data_ptr() for t in g_lines]),
                                               _p(bound_words), _p(line_scratch), _p(stage), C.c_size_t(stage.numel()), _p(found_inf),
-                                              _nv(n_valid), _stream()), "vm_features_backward")
+                                              *_shadow1(shadows), _nv(n_valid), _stream()), "vm_features_backward")
         return g_planes, g_lines
 
     @staticmethod
-    def color_forward(x, planes, lines, resolution, basis, out, n_valid=None):
+    def color_forward(x, planes, lines, resolution, basis, out, n_valid=None, shadows=None):
         """colour products with basis_mat applied in the kernel: basis fp16 [Cb, sum R_i] (the Linear's weight), out fp16 [N, Cb]"""
         _need(x, torch.float32, "x"); _need(basis, torch.float16, "basis"); _need(out, torch.float16, "out")
         for t in list(planes) + list(lines):
@@ -1203,11 +1233,11 @@ class VmBackend:
         ptr3, u3 = C.c_void_p * 3, C.c_uint32 * 3
         _check(lib().s3d_vm_color_forward(_p(x), _u(x.shape[0]), ptr3(*[t.data_ptr() for t in planes]),
                                           ptr3(*[t.data_ptr() for t in lines]), u3(*[int(t.shape[1]) for t in planes]),
-                                          u3(*[int(r) for r in resolution]), _p(basis), _u(basis.shape[0]), _p(out), _nv(n_valid),
-                                          _stream()), "vm_color_forward")
+                                          u3(*[int(r) for r in resolution]), _p(basis), _u(basis.shape[0]), _p(out),
+                                          *_shadow2(shadows), _nv(n_valid), _stream()), "vm_color_forward")
 
     @staticmethod
-    def color_backward(x, planes, lines, resolution, basis, grad_out, bins=None, found_inf=None, n_valid=None):
+    def color_backward(x, planes, lines, resolution, basis, grad_out, bins=None, found_inf=None, n_valid=None, shadows=None):
         """gradients of color_forward w.r.t. planes / lines / basis from grad_out fp16 [N, Cb]: (g_planes, g_lines, g_basis fp32)"""
         _need(x, torch.float32, "x"); _need(basis, torch.float16, "basis"); _need(grad_out, torch.float16, "grad_out")
         N, dev = x.shape[0], x.device
@@ -1235,5 +1265,5 @@ class VmBackend:
                                            _p(perm), _p(start), _u(n_bounds), _p(gm), ptr3(*[t.data_ptr() for t in g_planes]),
                                            ptr3(*[t.data_ptr() for t in g_lines]), _p(g_basis),
                                            _p(bound_words), _p(line_scratch), _p(stage), C.c_size_t(stage.numel()), _p(found_inf),
-                                           _nv(n_valid), _stream()), "vm_color_backward")
+                                           *_shadow1(shadows), _nv(n_valid), _stream()), "vm_color_backward")
         return g_planes, g_lines, g_basis

@@ -52,10 +52,11 @@ class _VmFeatures(torch.autograd.Function):
         # (a padded sample batch announced by the renderer, s3d_hip.row_limit: rows behind the device-side count are absent —
         #  not written here, sorted behind every bin in the backward, nerf/renderer.py never reads them)
         nv = s3d_hip.active_row_limit(N)
-        s3d_hip.VmBackend.features_forward(x, [m.contiguous() for m in mats], [v.contiguous() for v in vecs], net.resolution,
-                                           reduce, out, n_valid=nv)
+        mats, vecs = [m.contiguous() for m in mats], [v.contiguous() for v in vecs]
+        sh = _shadows(net, mats, vecs, net.resolution)
+        s3d_hip.VmBackend.features_forward(x, mats, vecs, net.resolution, reduce, out, n_valid=nv, shadows=sh)
         ctx.save_for_backward(x, *factors)
-        ctx.net, ctx.reduce, ctx.nv = net, reduce, nv
+        ctx.net, ctx.reduce, ctx.nv, ctx.sh = net, reduce, nv, sh
         return out
 
     @staticmethod
@@ -67,7 +68,7 @@ class _VmFeatures(torch.autograd.Function):
             gp, gl = s3d_hip.VmBackend.features_backward(x, [f.contiguous() for f in factors[:3]],
                                                          [f.contiguous() for f in factors[3:]], ctx.net.resolution, ctx.reduce,
                                                          g.float().contiguous(), _bins(ctx.net, x, factors[:3], ctx.nv),
-                                                         _source_check(ctx.net, factors), n_valid=ctx.nv)
+                                                         _source_check(ctx.net, factors), n_valid=ctx.nv, shadows=ctx.sh)
             return (None, None, None) + tuple(gp) + tuple(gl)
         if ctx.nv is not None:  # (the torch route sums over every row: the absent ones hold anything)
             live = torch.arange(x.shape[0], device=x.device) < (ctx.nv.reshape(-1)[:1] + 127) // 128 * 128
@@ -81,6 +82,16 @@ class _VmFeatures(torch.autograd.Function):
             grads = torch.autograd.grad(out, wanted, g.contiguous())
         gx = grads[0] if ctx.needs_input_grad[0] else None
         return (gx, None, None) + tuple(grads[1:] if ctx.needs_input_grad[0] else grads)
+
+
+def _shadows(net, mats, vecs, resolution):
+    """rank-fastest shadows of a factor set (VmBackend.transpose_factors), taken afresh at EVERY forward: the native optimizer
+    rewrites the parameters without touching `_version`, so nothing cheaper than the ~10 us launch says whether they are stale;
+    the forward and the backward of one step share them (the parameters do not change in between).  None: shapes the
+    16-byte loads do not cover (a rank that is not a multiple of four) or the switch `fused_shadows` off."""
+    if not getattr(net, "fused_shadows", True) or any(m.shape[1] % 4 for m in mats) or not all(t.is_cuda for t in mats):
+        return None
+    return s3d_hip.VmBackend.transpose_factors([m.detach() for m in mats], [v.detach() for v in vecs], resolution)
 
 
 def _bins(net, x, mats, n_valid=None):
@@ -115,9 +126,10 @@ class _VmColorBasis(torch.autograd.Function):
         w16 = weight.detach().to(torch.float16).contiguous()
         out = torch.empty(x.shape[0], w16.shape[0], dtype=torch.float16, device=x.device)
         nv = s3d_hip.active_row_limit(x.shape[0])
-        s3d_hip.VmBackend.color_forward(x, mats, vecs, net.resolution, w16, out, n_valid=nv)
+        sh = _shadows(net, mats, vecs, net.resolution)
+        s3d_hip.VmBackend.color_forward(x, mats, vecs, net.resolution, w16, out, n_valid=nv, shadows=sh)
         ctx.save_for_backward(x, w16, *factors)
-        ctx.net, ctx.nv = net, nv
+        ctx.net, ctx.nv, ctx.sh = net, nv, sh
         return out
 
     @staticmethod
@@ -127,7 +139,7 @@ class _VmColorBasis(torch.autograd.Function):
         # (g as it arrives: a [:, :27] view of _MlpInput's zero-padded [N, 32] gradient is used in place, anything else is padded)
         gp, gl, gw = s3d_hip.VmBackend.color_backward(x, mats, vecs, ctx.net.resolution, w16, g.to(torch.float16),
                                                       _bins(ctx.net, x, mats, ctx.nv), _source_check(ctx.net, factors, ctx.net.basis_mat.weight),
-                                                      n_valid=ctx.nv)
+                                                      n_valid=ctx.nv, shadows=ctx.sh)
         return (None, None, gw) + tuple(gp) + tuple(gl)
 
 

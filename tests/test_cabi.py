@@ -66,7 +66,7 @@ def test_ctypes_call_sites_pass_as_many_arguments_as_the_header_declares():
         args = m.group(2).strip()
         declared[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
     src = open(os.path.join(REPO, "seal-3d_amd", "s3d_hip", "__init__.py")).read()
-    starred_width = {"_live": 2, "_mid_fwd_args": 4, "_mid_bwd_args": 3}  # helpers that expand to several C arguments
+    starred_width = {"_live": 2, "_mid_fwd_args": 4, "_mid_bwd_args": 3, "_shadow2": 2, "_shadow1": 1}  # helpers that expand to several C arguments
     seen = set()
     for node in ast.walk(ast.parse(src)):
         if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr.startswith("s3d_") \

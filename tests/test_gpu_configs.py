@@ -837,6 +837,39 @@ def test_tensorf_padded_sample_batch_follows_the_device_side_count(hip):
         assert float((a - b).abs().max()) <= tol, (n, float((a - b).abs().max()), float(a.abs().max()))
 
 
+def test_tensorf_rank_fastest_shadows_give_the_same_bits(hip):
+    """s3d_vm_transpose_factors + planes_t / lines_t: the feature kernels read a corner's rank channels as one contiguous run
+    ([H][W][R] / [Dn][R] shadows taken from the parameters at every forward) — the same values through the same arithmetic, so
+    density features and colour features equal the run on the parameters' own [R][H][W] layout bit for bit, the factor gradients
+    within the fp32 order of their few atomics."""
+    import s3d_hip
+    net = _vm48(res=96)
+    x, m = _vm48_marched_samples(n_rays=768)
+    mats, vecs = [p.detach().contiguous() for p in net.color_mat], [p.detach().contiguous() for p in net.color_vec]
+    pt, lt = s3d_hip.VmBackend.transpose_factors(mats, vecs, net.resolution)
+    for a, t in zip(mats, pt):
+        assert torch.equal(t, a[0].permute(1, 2, 0).contiguous())
+    for a, t in zip(vecs, lt):
+        assert torch.equal(t, a[0, :, :, 0].t().contiguous())
+    g = torch.Generator().manual_seed(21)
+    gs, gc = torch.randn(m, generator=g).cuda(), (torch.randn(m, 27, generator=g) * 0.1).cuda()
+    res = {}
+    for on in (True, False):
+        net.fused_shadows = on
+        net.zero_grad(set_to_none=True)
+        s = net.get_sigma_feat(x)
+        (s * gs).sum().backward()
+        c = net.get_color_feat(x)
+        (c.float() * gc).sum().backward()
+        res[on] = (s.detach().clone(), c.detach().clone(), _factor_grads(net))
+    net.fused_shadows = True
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    # (the gradients: the same exact tile sums, but tiles split over workgroups and basis_mat's gradient leave through fp32 atomics,
+    #  whose order differs from run to run)
+    for a, b in zip(res[True][2], res[False][2]):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-12
+
+
 def test_vm_backward_keeps_gradients_far_below_the_batch_maximum(hip):
     """the fixed-point accumulators are scaled by ONE bound per call (placed at 2^50, contributions rounded to
     nearest).  A region whose gradients lie 2^36 below the batch maximum — and, with the bound's slack (max |g| x max |line|),
