@@ -1102,6 +1102,11 @@ def main():
             except (OSError, ValueError, KeyError):
                 pass
         extra.setdefault("psnr", {})["long_run"] = lr_
+        ms = lr_.get("many_seed_study")
+        if ms:  # north_star "PSNR within 0.1 dB of the reference path": settled by the committed study, the run above is a 16-seed sample of it
+            extra["psnr"]["vs_reference_path"] = {"delta_db": ms["delta_db"], "ci95": ms["delta_db_ci95"], "seeds": ms["seeds"],
+                                                  "within_0p1_db_with_95pct_confidence": ms["ci95_inside_0p1_db"], "source": ms["file"],
+                                                  "this_run": {"seeds": lr_["seeds"], "delta_db": lr_["delta_db"], "ci95": lr_["delta_db_ci95"]}}
     if not args.no_seal and args.net == "ff":
         # configs[2] on one GPU; under `--gpus N` (or --force_dp) configs[3]: the same section data-parallel over the ranks
         note("seal section")
